@@ -1,0 +1,31 @@
+"""CPU oracle for the echopype hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+This package is a NumPy fp64 restatement of the reference algorithm
+(OSOceanAcoustics/echopype @ 2026-05-01, /root/reference) for the path
+
+    calibrate.compute_Sv / compute_TS  (EK60 CW, EK80 CW power/complex, EK80 BB, AZFP)
+    -> clean.estimate_background_noise / remove_background_noise
+    -> commongrid.compute_MVBS / compute_MVBS_index_binning
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it.  Nothing under ``echopype_amd/`` imports it, and the product
+path fails loudly when the HIP library is missing (see echopype_amd/_lib.py).
+
+Pinning status (see DESIGN.md "Oracle"):
+  * leaf functions (uwa formulas, transmit replica, filter/decimate, tau_effective,
+    norm factor, matched-filter convolution) are pinned against outputs of the
+    reference's OWN code executed in the authoring container through a stub-module
+    loader (oracle/gen_goldens.py -> tests/golden/ref_leaf_goldens.npz);
+  * the array-level chains (Sv/TS, noise, MVBS) cannot be executed from the
+    reference here (xarray/flox/dask absent, Python 3.10 < 3.11), so they are pinned
+    against the reference's synthetic known-answer tests restated in
+    tests/test_oracle_kat.py (noise seed-1 => 6 NaNs, pulse-length lookup tables,
+    MVBS brute-force values/NaN masks, index-binning coarsen formula, ...).
+
+Every function cites the reference file:line it follows.  The pass structure of the
+reference (whole-array temporaries, np.log10 / 10**x, scipy.signal.convolve per
+(ping, beam) slab, group-by with bincount) is kept on purpose so that timing this
+code is a fair stand-in for the reference CPU path (bench.py cpu_baseline, kind="port").
+"""
+
+from . import uwa, ek80, calibrate, clean, commongrid  # noqa: F401
