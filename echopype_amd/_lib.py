@@ -1,0 +1,107 @@
+"""ctypes binding of libechopype_amd.so (the C ABI declared in include/echopype_amd.h).
+
+The HIP library is the product: if it is missing, or fails to load, importing this module
+raises -- there is NO CPU fallback anywhere in echopype_amd.
+
+torch is imported first on purpose: PyTorch-ROCm bundles its own libamdhip64.so.7; loading it
+before our library makes the dynamic linker resolve our DT_NEEDED libamdhip64.so.7 to the copy
+already in the process, so torch tensors (device memory, streams, RCCL) and our kernels share one
+HIP runtime.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libechopype_amd.so")
+
+EPA_OK, EPA_EINVAL, EPA_EHIP, EPA_ENOMEM, EPA_EUNSUPPORTED = range(5)
+F32, F64 = 0, 1
+CAL_SV, CAL_TS = 0, 1
+SONAR_EK60, SONAR_EK80 = 0, 1
+PM_SCALAR, PM_CHANNEL, PM_CHANNEL_PING, PM_PULSE_TABLE = range(4)
+NCOEF = 8
+CF_RA, CF_RB, CF_R0, CF_SHIFT, CF_ALPHA2, CF_A0, CF_G, CF_D = range(8)
+NCCOEF = 8
+CC_K, CC_SHIFT, CC_ALPHA2, CC_A, CC_PSCALE = range(5)
+FLAG_GUARD_POS, FLAG_MASK_RANGE = 1, 2
+BIN_SKIPNA, BIN_CLOSED_RIGHT = 1, 2
+
+
+class EpaError(RuntimeError):
+    """A C-ABI call returned a non-zero status."""
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m echopype_amd.build` "
+            "(hipcc --offload-arch=gfx950).  echopype_amd has no CPU fallback."
+        )
+    return ctypes.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_vp, _i, _u, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_double, ctypes.c_size_t
+_i64 = ctypes.c_int64
+
+# name -> argtypes; every function returns int status except epa_version / epa_last_error
+SIGNATURES = {
+    "epa_version": [],
+    "epa_last_error": [],
+    "epa_device_count": [ctypes.POINTER(_i)],
+    "epa_set_device": [_i],
+    "epa_device_name": [_i, ctypes.c_char_p, _sz],
+    "epa_malloc": [ctypes.POINTER(_vp), _sz],
+    "epa_free": [_vp],
+    "epa_memset": [_vp, _i, _sz, _vp],
+    "epa_memcpy_h2d": [_vp, _vp, _sz, _vp],
+    "epa_memcpy_d2h": [_vp, _vp, _sz, _vp],
+    "epa_stream_synchronize": [_vp],
+    "epa_timer_create": [ctypes.POINTER(_vp)],
+    "epa_timer_destroy": [_vp],
+    "epa_timer_start": [_vp, _vp],
+    "epa_timer_stop": [_vp, _vp],
+    "epa_timer_elapsed_ms": [_vp, ctypes.POINTER(ctypes.c_float)],
+    "epa_power_coef_ek": [_i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp,
+                          _vp, _vp, _i, _i, _vp, _vp],
+    "epa_sv_power": [_vp, _vp, _i, _i, _i, _i, _u, _vp, _vp, _i, _vp],
+    "epa_time_bin_offsets": [_vp, _i, _i64, _i64, _i, _u, _vp, _vp],
+    "epa_sv_mvbs_fused": [_vp, _vp, _i, _i, _i, _i, _u, _vp, _vp, _i, _d, _i, _u, _d, _vp, _vp, _vp,
+                          _vp, _vp, _i, _vp],
+    "epa_mvbs": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _d, _i, _u, _d, _vp, _vp, _vp, _i, _vp],
+    "epa_selftest_lin_from_db": [_vp, _vp, _sz, _vp],
+    "epa_mvbs_finalize": [_vp, _vp, _sz, _d, _vp, _i, _vp],
+    "epa_mvbs_index": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "epa_noise_estimate": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _i, _vp],
+    "epa_noise_apply": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _vp, _vp, _i, _vp],
+    "epa_sv_complex": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
+}
+
+for _name, _args in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the .so does not export a declared symbol
+    _fn.argtypes = _args
+    _fn.restype = ctypes.c_char_p if _name == "epa_last_error" else _i
+
+
+def last_error() -> str:
+    msg = lib.epa_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(status: int, what: str = "") -> None:
+    """Map a non-zero C status to a Python exception (SURVEY 8b error conventions)."""
+    if status == EPA_OK:
+        return
+    msg = f"{what}: {last_error()}" if what else last_error()
+    if status == EPA_EINVAL:
+        raise ValueError(msg)
+    if status == EPA_ENOMEM:
+        raise MemoryError(msg)
+    raise EpaError(f"[status {status}] {msg}")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(lib, name)(*args), name)

@@ -1,0 +1,649 @@
+// K5 / K6 (and the fused K1+K5): linear-domain (ping-bin x range-bin) block reductions.
+//
+// One workgroup owns one (channel, ping-bin) pair -- 20 pings x S samples at the BASELINE
+// configs -- walks its pings with every lane on a fixed 4-sample column (16-B coalesced loads),
+// keeps a private (bin, sum, count) accumulator per column across the pings of the bin, flushes
+// to per-range-bin partial sums in LDS (ds_add_f64 / ds_add_u32) only when the range bin under
+// the column changes, and finishes the bin itself: mean -> 10*log10 -> MVBS row (or, for the
+// noise estimate, min over range blocks).  Nothing is re-read from HBM; with the fused source the
+// raw power is read once (4 B/sample) and Sv written once (8 B/sample in f64).
+//
+// Reference arithmetic replaced (paths under /root/reference/echopype):
+//   commongrid/utils.py:592,614-627 + :92   flox group-by nanmean/mean in the linear domain
+//   commongrid/api.py:108-128               range / ping bin edges (uniform, left or right closed)
+//   commongrid/api.py:217-238               index binning (coarsen ... "pad" mean, echo_range min)
+//   clean/api.py:397-422                    noise estimate (block mean of calibrated power, min)
+//   calibrate_ek.py / range.py              (fused source) as in sv_power.hip
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include <cstdlib>
+
+#include "sample_math.h"
+
+namespace {
+
+enum { SRC_RAW = 0, SRC_SV = 1 };
+enum { OP_MVBS = 0, OP_NOISE = 1 };
+enum { BIN_PHYS = 0, BIN_INDEX = 1 };
+
+struct ReduceArgs {
+  const float* raw;
+  const void* sv;
+  const void* range;
+  const epa::CoefRow* coef;
+  const double* alpha2;
+  int C, P, S;
+  double nspread;
+  unsigned cal_flags;
+  const int32_t* bin_start;
+  const int32_t* ping_perm;
+  int n_tbins, ping_num, nparts;
+  int bin_mode;
+  double range_bin, inv_range_bin;
+  int n_rbins, range_sample_num;
+  unsigned bin_flags;
+  double fill_value, noise_max;
+  void* sv_out;
+  void* range_out;
+  void* out;
+  void* sum_out;
+  uint32_t* cnt_out;
+  int use_lds;
+  unsigned cnt_off;  // byte offset of the count array in dynamic LDS
+};
+
+template <typename T>
+__device__ __forceinline__ void atomic_add(T* p, T v) {
+  unsafeAtomicAdd(p, v);
+}
+
+// NaN-skipping min over the workgroup; returns NaN when no lane contributed.
+template <typename T>
+__device__ T block_nanmin(T v, bool valid, T* scratch /* >= 8 elements of LDS */) {
+  const T inf = (T)__builtin_inf();
+  T m = valid ? v : inf;
+  int any = valid ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    m = fmin(m, __shfl_down(m, o, 64));
+    any |= __shfl_down(any, o, 64);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) {
+    scratch[wave] = m;
+    scratch[4 + wave] = (T)any;
+  }
+  __syncthreads();
+  T r = inf;
+  int a = 0;
+  for (int w = 0; w < epa::kBlock / 64; ++w) {
+    r = fmin(r, scratch[w]);
+    a |= (scratch[4 + w] != (T)0);
+  }
+  return a ? r : epa::M<T>::nan();
+}
+
+template <typename T, int SRC, int OP, int VEC>
+__global__ __launch_bounds__(epa::kBlock) void block_reduce_kernel(ReduceArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int kChunk = epa::kBlock * VEC;
+  T* lsum = reinterpret_cast<T*>(smem);
+  uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + a.cnt_off);
+
+  const int c = blockIdx.y;
+  const int tb = blockIdx.x / a.nparts;
+  const int part = blockIdx.x - tb * a.nparts;
+  int pb, pe;
+  if (a.bin_start) {
+    pb = a.bin_start[tb];
+    pe = a.bin_start[tb + 1];
+  } else {
+    pb = tb * a.ping_num;
+    pe = min(a.P, pb + a.ping_num);
+  }
+  if (a.nparts > 1) {
+    const int per = (pe - pb + a.nparts - 1) / a.nparts;
+    const int b2 = pb + part * per;
+    pe = min(pe, b2 + per);
+    pb = b2;
+  }
+  const int S = a.S, n_rbins = a.n_rbins;
+  const bool use_lds = a.use_lds != 0;
+  const size_t cell0 = ((size_t)c * a.n_tbins + tb) * n_rbins;
+  T* gsum = a.sum_out ? reinterpret_cast<T*>(a.sum_out) + cell0 : nullptr;
+  uint32_t* gcnt = a.cnt_out ? a.cnt_out + cell0 : nullptr;
+
+  if (use_lds) {
+    for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
+      lsum[i] = (T)0;
+      lcnt[i] = 0u;
+    }
+    __syncthreads();
+  }
+  T* asum = use_lds ? lsum : gsum;
+  uint32_t* acnt = use_lds ? lcnt : gcnt;
+
+  const bool skipna = a.bin_flags & EPA_BIN_SKIPNA;
+  const bool closed_right = a.bin_flags & EPA_BIN_CLOSED_RIGHT;
+  const bool guard = a.cal_flags & EPA_FLAG_GUARD_POS;
+  const bool mask_range = a.cal_flags & EPA_FLAG_MASK_RANGE;
+  const bool phys = a.bin_mode == BIN_PHYS;
+  const T nspread = (T)a.nspread;
+  const T* svp = reinterpret_cast<const T*>(a.sv);
+  const T* rgp = reinterpret_cast<const T*>(a.range);
+  T* sv_out = reinterpret_cast<T*>(a.sv_out);
+  T* range_out = reinterpret_cast<T*>(a.range_out);
+
+  for (int chunk0 = 0; chunk0 < S; chunk0 += kChunk) {
+    const int s0 = chunk0 + threadIdx.x * VEC;
+    if (s0 < S) {
+      // per-column state kept across the pings of the bin
+      int acc_rb[VEC];
+      T acc_sum[VEC];
+      uint32_t acc_cnt[VEC];
+      double blo[VEC], bhi[VEC];  // edges of the range bin the column currently sits in
+      epa::ColumnLog<T, VEC> col;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        acc_rb[j] = phys ? -1 : (s0 + j) / a.range_sample_num;
+        acc_sum[j] = (T)0;
+        acc_cnt[j] = 0u;
+        blo[j] = 1.0;
+        bhi[j] = 0.0;  // empty interval: first sample always takes the slow path
+      }
+      for (int pi = pb; pi < pe; ++pi) {
+        // wave-uniform by construction; readfirstlane lets the compiler keep the row index in an
+        // SGPR and fetch the 64-B coefficient row with scalar loads
+        const int p = __builtin_amdgcn_readfirstlane(a.ping_perm ? a.ping_perm[pi] : pi);
+        const size_t row = (size_t)c * a.P + p;
+        const size_t off = row * S + s0;
+        T sv[VEC];
+        double x[VEC];
+        bool xok[VEC];
+        if (SRC == SRC_RAW) {
+          epa::RawVec<VEC> in;
+          in.load(a.raw + off);
+          const epa::RowK<T> rk(a.coef[row]);
+          col.update(rk.d, s0, nspread);
+          T rg[VEC];
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            x[j] = rk.range(s0 + j);
+            sv[j] = epa::cal_power_sample<T>(in.v[j], s0 + j, rk, nspread, col.nL[j], guard, x[j]);
+            xok[j] = !(mask_range && !(in.v[j] == in.v[j]));
+            rg[j] = xok[j] ? (T)x[j] : epa::M<T>::nan();
+          }
+          if (sv_out) epa::store_vec<T, VEC>(sv_out + off, sv);
+          if (range_out) epa::store_vec<T, VEC>(range_out + off, rg);
+        } else {
+          epa::load_vec<T, VEC>(svp + off, sv);
+          if (rgp) {
+            T rg[VEC];
+            epa::load_vec<T, VEC>(rgp + off, rg);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              x[j] = (double)rg[j];
+              xok[j] = true;  // NaN coordinates drop out in the bin search
+            }
+          } else if (a.coef) {
+            const epa::CoefRow cr = a.coef[row];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              x[j] = epa::row_range(cr, s0 + j);
+              xok[j] = true;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              x[j] = 0.0;
+              xok[j] = true;
+            }
+          }
+        }
+        T a2 = (T)0;
+        if (OP == OP_NOISE) a2 = (T)a.alpha2[row];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          T v;
+          if (OP == OP_MVBS) {
+            v = epa::M<T>::exp10(sv[j] * (T)0.1);  // _log2lin, compute.py:14-27
+          } else {
+            // clean/api.py:397-401: where(R >= 1, R, 1) also maps NaN ranges to 1
+            const T xr = (T)x[j];
+            const T tl = (T)20 * epa::M<T>::log10(xr >= (T)1 ? xr : (T)1) + a2 * xr;
+            v = epa::M<T>::exp10((sv[j] - tl) * (T)0.1);
+          }
+          if (phys) {
+            // fast path: the column is still inside the bin it was in for the previous ping
+            const bool same = xok[j] && (closed_right ? (x[j] > blo[j] && x[j] <= bhi[j])
+                                                      : (x[j] >= blo[j] && x[j] < bhi[j]));
+            if (!same) {
+              const int rb = xok[j] ? epa::range_bin_index(x[j], a.range_bin, a.inv_range_bin,
+                                                            n_rbins, closed_right)
+                                    : -1;
+              if (rb != acc_rb[j]) {
+                if (acc_rb[j] >= 0 && acc_cnt[j] > 0u) {
+                  atomic_add(asum + acc_rb[j], acc_sum[j]);
+                  atomicAdd(acnt + acc_rb[j], acc_cnt[j]);
+                }
+                acc_rb[j] = rb;
+                acc_sum[j] = (T)0;
+                acc_cnt[j] = 0u;
+              }
+              if (rb >= 0) {
+                blo[j] = (double)rb * a.range_bin;
+                bhi[j] = (double)(rb + 1) * a.range_bin;
+              } else {
+                blo[j] = 1.0;
+                bhi[j] = 0.0;
+              }
+            }
+          }
+          if (acc_rb[j] >= 0 && (!skipna || v == v)) {
+            acc_sum[j] += v;
+            acc_cnt[j] += 1u;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (acc_rb[j] >= 0 && acc_cnt[j] > 0u) {
+          atomic_add(asum + acc_rb[j], acc_sum[j]);
+          atomicAdd(acnt + acc_rb[j], acc_cnt[j]);
+        }
+      }
+    }
+  }
+
+  if (!use_lds) return;  // accumulated straight into global partials; a finalize kernel follows
+  __syncthreads();
+  if (a.nparts > 1) {
+    for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
+      const uint32_t n = lcnt[i];
+      if (n > 0u) {
+        atomic_add(gsum + i, lsum[i]);
+        atomicAdd(gcnt + i, n);
+      }
+    }
+    return;
+  }
+  if (OP == OP_MVBS) {
+    T* out = reinterpret_cast<T*>(a.out) + cell0;
+    for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
+      const uint32_t n = lcnt[i];
+      const T s = lsum[i];
+      out[i] = n > 0u ? (T)10 * epa::M<T>::log10(s / (T)n) : (T)a.fill_value;  // _lin2log
+      if (gsum) gsum[i] = s;
+      if (gcnt) gcnt[i] = n;
+    }
+  } else {
+    T best = (T)__builtin_inf();
+    bool any = false;
+    for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
+      const uint32_t n = lcnt[i];
+      if (n > 0u) {
+        const T db = (T)10 * epa::M<T>::log10(lsum[i] / (T)n);
+        if (db == db) {
+          best = fmin(best, db);
+          any = true;
+        }
+      }
+    }
+    __syncthreads();  // all reads of lsum done before it is reused as scratch
+    T m = block_nanmin<T>(best, any, lsum);
+    if (threadIdx.x == 0) {
+      double r = (double)m;
+      if (a.noise_max == a.noise_max) r = (r < a.noise_max) ? r : a.noise_max;  // api.py:418-422
+      reinterpret_cast<double*>(a.out)[(size_t)c * a.n_tbins + tb] = r;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(epa::kBlock) void mvbs_finalize_kernel(const T* __restrict__ sum,
+                                                                    const uint32_t* __restrict__ cnt,
+                                                                    size_t n, T fill,
+                                                                    T* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t k = cnt[i];
+    out[i] = k > 0u ? (T)10 * epa::M<T>::log10(sum[i] / (T)k) : fill;
+  }
+}
+
+// noise, multi-part path: one workgroup per (channel, ping block) row of merged partials
+template <typename T>
+__global__ __launch_bounds__(epa::kBlock) void noise_rowmin_kernel(const T* __restrict__ sum,
+                                                                   const uint32_t* __restrict__ cnt,
+                                                                   int n_rbins, double noise_max,
+                                                                   double* __restrict__ out) {
+  __shared__ T scratch[8];
+  const size_t base = (size_t)blockIdx.x * n_rbins;
+  T best = (T)__builtin_inf();
+  bool any = false;
+  for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
+    const uint32_t n = cnt[base + i];
+    if (n > 0u) {
+      const T db = (T)10 * epa::M<T>::log10(sum[base + i] / (T)n);
+      if (db == db) {
+        best = fmin(best, db);
+        any = true;
+      }
+    }
+  }
+  T m = block_nanmin<T>(best, any, scratch);
+  if (threadIdx.x == 0) {
+    double r = (double)m;
+    if (noise_max == noise_max) r = (r < noise_max) ? r : noise_max;
+    out[blockIdx.x] = r;
+  }
+}
+
+// echo_range block min for compute_MVBS_index_binning (api.py:232-238): one wave per output cell
+template <typename T>
+__global__ __launch_bounds__(epa::kBlock) void block_nanmin_kernel(const T* __restrict__ x, int C,
+                                                                   int P, int S, int ping_num,
+                                                                   int rsn, int Pb, int Sb,
+                                                                   T* __restrict__ out) {
+  const long long cells = (long long)C * Pb * Sb;
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long cell = wave0; cell < cells; cell += nwaves) {
+    const int sb = (int)(cell % Sb);
+    const int pbk = (int)((cell / Sb) % Pb);
+    const int c = (int)(cell / ((long long)Sb * Pb));
+    const int p0 = pbk * ping_num, p1 = min(P, p0 + ping_num);
+    const int s0 = sb * rsn, s1 = min(S, s0 + rsn);
+    const int w = s1 - s0;
+    const int n = (p1 - p0) * w;
+    T m = (T)__builtin_inf();
+    int any = 0;
+    for (int e = lane; e < n; e += 64) {
+      const int p = p0 + e / w, s = s0 + e % w;
+      const T v = x[((size_t)c * P + p) * S + s];
+      if (v == v) {
+        m = fmin(m, v);
+        any = 1;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      m = fmin(m, __shfl_down(m, o, 64));
+      any |= __shfl_down(any, o, 64);
+    }
+    if (lane == 0) out[cell] = any ? m : epa::M<T>::nan();
+  }
+}
+
+}  // namespace
+
+// fused_sv_mvbs.hip
+int epa_fused_fast_path(const float* raw, const double* coef, int C, int P, int S, double nspread,
+                        unsigned cal_flags, const int32_t* bin_start, int n_tbins, double range_bin,
+                        int n_rbins, unsigned bin_flags, double fill_value, void* sv_out,
+                        void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
+                        size_t lds_bytes, unsigned cnt_off, hipStream_t st);
+
+namespace {
+
+struct Plan {
+  int nparts, use_lds, vec;
+  size_t lds_bytes;
+  unsigned cnt_off;
+};
+
+template <typename T>
+Plan make_plan(int C, int P, int S, int n_tbins, int n_rbins, bool aligned16) {
+  Plan pl;
+  pl.vec = (S % 4 == 0 && aligned16) ? 4 : 1;
+  if (const char* e = getenv("EPA_REDUCE_VEC")) {  // tuning aid
+    const int v = atoi(e);
+    if ((v == 1) || (v == 2 && S % 2 == 0 && aligned16) || (v == 4 && S % 4 == 0 && aligned16)) pl.vec = v;
+  }
+  const size_t sum_bytes = ((size_t)n_rbins * sizeof(T) + 15) & ~(size_t)15;
+  const size_t need = sum_bytes + (size_t)n_rbins * sizeof(uint32_t);
+  pl.use_lds = need <= 128 * 1024;
+  pl.lds_bytes = pl.use_lds ? (need < 64 ? 64 : need) : 64;
+  pl.cnt_off = (unsigned)sum_bytes;
+  const long long groups = (long long)C * n_tbins;
+  pl.nparts = 1;
+  if (groups < 1024) {
+    const long long avg = n_tbins > 0 ? (P + n_tbins - 1) / n_tbins : P;
+    long long want = (2048 + groups - 1) / groups;
+    long long maxp = (avg + 7) / 8;
+    if (maxp < 1) maxp = 1;
+    pl.nparts = (int)(want < maxp ? want : maxp);
+    if (pl.nparts < 1) pl.nparts = 1;
+  }
+  return pl;
+}
+
+template <typename T, int SRC, int OP>
+int launch_reduce(ReduceArgs& a, const Plan& pl, hipStream_t st) {
+  const dim3 grid((unsigned)((long long)a.n_tbins * a.nparts), (unsigned)a.C);
+  const dim3 block(epa::kBlock);
+  a.use_lds = pl.use_lds;
+  a.cnt_off = pl.cnt_off;
+#define EPA_RL(V)                                                                                 \
+  do {                                                                                            \
+    auto kern = block_reduce_kernel<T, SRC, OP, V>;                                               \
+    if (pl.lds_bytes > 64 * 1024) {                                                               \
+      EPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                      \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,               \
+                                        (int)pl.lds_bytes));                                      \
+    }                                                                                             \
+    hipLaunchKernelGGL(kern, grid, block, pl.lds_bytes, st, a);                                   \
+  } while (0)
+  if (pl.vec == 4) EPA_RL(4); else if (pl.vec == 2) EPA_RL(2); else EPA_RL(1);
+#undef EPA_RL
+  return epa::check_launch("block_reduce_kernel");
+}
+
+inline bool al16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename T>
+int zero_partials(void* sum_out, uint32_t* cnt_out, size_t cells, hipStream_t st) {
+  EPA_CHECK_HIP(hipMemsetAsync(sum_out, 0, cells * sizeof(T), st));
+  EPA_CHECK_HIP(hipMemsetAsync(cnt_out, 0, cells * sizeof(uint32_t), st));
+  return EPA_OK;
+}
+
+template <typename T, int SRC>
+int run_mvbs(ReduceArgs& a, hipStream_t st) {
+  const Plan pl = make_plan<T>(a.C, a.P, a.S, a.n_tbins, a.n_rbins,
+                               al16(a.raw) && al16(a.sv) && al16(a.range) && al16(a.sv_out) &&
+                                   al16(a.range_out));
+  a.nparts = pl.nparts;
+  const size_t cells = (size_t)a.C * a.n_tbins * a.n_rbins;
+  const bool two_stage = pl.nparts > 1 || !pl.use_lds;
+  if (SRC == SRC_RAW && !two_stage && pl.vec == 4 && !a.ping_perm && !a.range_out &&
+      !getenv("EPA_NO_FAST_PATH"))
+    return epa_fused_fast_path(a.raw, reinterpret_cast<const double*>(a.coef), a.C, a.P, a.S,
+                               a.nspread, a.cal_flags, a.bin_start, a.n_tbins, a.range_bin,
+                               a.n_rbins, a.bin_flags, a.fill_value, a.sv_out, a.out, a.sum_out,
+                               a.cnt_out, sizeof(T) == 8 ? EPA_F64 : EPA_F32, pl.lds_bytes,
+                               pl.cnt_off, st);
+  if (two_stage) {
+    EPA_CHECK_ARG(a.sum_out && a.cnt_out,
+                  "binned reduction: this shape (C*n_tbins=%lld, n_rbins=%d) needs the sum_out/"
+                  "cnt_out workspaces", (long long)a.C * a.n_tbins, a.n_rbins);
+    int rc = zero_partials<T>(a.sum_out, a.cnt_out, cells, st);
+    if (rc) return rc;
+  }
+  int rc = launch_reduce<T, SRC, OP_MVBS>(a, pl, st);
+  if (rc) return rc;
+  if (two_stage) {
+    const int grid = (int)((cells + epa::kBlock - 1) / epa::kBlock < 4096
+                               ? (cells + epa::kBlock - 1) / epa::kBlock : 4096);
+    hipLaunchKernelGGL(mvbs_finalize_kernel<T>, dim3(grid), dim3(epa::kBlock), 0, st,
+                       (const T*)a.sum_out, (const uint32_t*)a.cnt_out, cells, (T)a.fill_value,
+                       (T*)a.out);
+    return epa::check_launch("mvbs_finalize_kernel");
+  }
+  return EPA_OK;
+}
+
+int check_bins(const char* fn, const int32_t* bin_start, int n_tbins, double range_bin, int n_rbins) {
+  EPA_CHECK_ARG(bin_start != nullptr, "%s: bin_start is NULL", fn);
+  EPA_CHECK_ARG(n_tbins > 0 && n_rbins > 0, "%s: n_tbins=%d n_rbins=%d must be positive", fn,
+                n_tbins, n_rbins);
+  EPA_CHECK_ARG(range_bin > 0, "%s: range_bin must be positive", fn);
+  return EPA_OK;
+}
+
+}  // namespace
+
+extern "C" int epa_sv_mvbs_fused(const float* raw, const double* coef, int C, int P, int S,
+                                 int cal_type, unsigned cal_flags, const int32_t* bin_start,
+                                 const int32_t* ping_perm, int n_tbins, double range_bin,
+                                 int n_rbins, unsigned bin_flags, double fill_value, void* sv_out,
+                                 void* range_out, void* mvbs_out, void* sum_out, uint32_t* cnt_out,
+                                 int dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(raw && coef && mvbs_out, "epa_sv_mvbs_fused: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_sv_mvbs_fused: C=%d P=%d S=%d", C, P, S);
+  EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_sv_mvbs_fused: bad cal_type");
+  if (int rc = check_bins("epa_sv_mvbs_fused", bin_start, n_tbins, range_bin, n_rbins)) return rc;
+  ReduceArgs a{};
+  a.raw = raw; a.coef = reinterpret_cast<const epa::CoefRow*>(coef);
+  a.C = C; a.P = P; a.S = S;
+  a.nspread = cal_type == EPA_CAL_SV ? 20.0 : 40.0;
+  a.cal_flags = cal_flags;
+  a.bin_start = bin_start; a.ping_perm = ping_perm; a.n_tbins = n_tbins; a.ping_num = 0;
+  a.bin_mode = BIN_PHYS; a.range_bin = range_bin; a.inv_range_bin = 1.0 / range_bin;
+  a.n_rbins = n_rbins; a.range_sample_num = 1; a.bin_flags = bin_flags;
+  a.fill_value = fill_value; a.noise_max = __builtin_nan("");
+  a.sv_out = sv_out; a.range_out = range_out; a.out = mvbs_out; a.sum_out = sum_out; a.cnt_out = cnt_out;
+  if (dtype == EPA_F64) return run_mvbs<double, SRC_RAW>(a, (hipStream_t)stream);
+  if (dtype == EPA_F32) return run_mvbs<float, SRC_RAW>(a, (hipStream_t)stream);
+  epa::set_error("epa_sv_mvbs_fused: bad dtype %d", dtype);
+  return EPA_EINVAL;
+}
+
+extern "C" int epa_mvbs(const void* sv, const void* range, const double* coef, int C, int P, int S,
+                        const int32_t* bin_start, const int32_t* ping_perm, int n_tbins,
+                        double range_bin, int n_rbins, unsigned bin_flags, double fill_value,
+                        void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
+                        epa_stream_t stream) {
+  EPA_CHECK_ARG(sv && mvbs_out, "epa_mvbs: NULL array argument");
+  EPA_CHECK_ARG(range || coef, "epa_mvbs: either range or coef must be given");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_mvbs: C=%d P=%d S=%d", C, P, S);
+  if (int rc = check_bins("epa_mvbs", bin_start, n_tbins, range_bin, n_rbins)) return rc;
+  ReduceArgs a{};
+  a.sv = sv; a.range = range; a.coef = reinterpret_cast<const epa::CoefRow*>(coef);
+  a.C = C; a.P = P; a.S = S;
+  a.bin_start = bin_start; a.ping_perm = ping_perm; a.n_tbins = n_tbins;
+  a.bin_mode = BIN_PHYS; a.range_bin = range_bin; a.inv_range_bin = 1.0 / range_bin;
+  a.n_rbins = n_rbins; a.range_sample_num = 1; a.bin_flags = bin_flags;
+  a.fill_value = fill_value; a.noise_max = __builtin_nan("");
+  a.out = mvbs_out; a.sum_out = sum_out; a.cnt_out = cnt_out;
+  if (dtype == EPA_F64) return run_mvbs<double, SRC_SV>(a, (hipStream_t)stream);
+  if (dtype == EPA_F32) return run_mvbs<float, SRC_SV>(a, (hipStream_t)stream);
+  epa::set_error("epa_mvbs: bad dtype %d", dtype);
+  return EPA_EINVAL;
+}
+
+extern "C" int epa_mvbs_finalize(const void* sum, const uint32_t* cnt, size_t n, double fill_value,
+                                 void* out, int dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(sum && cnt && out, "epa_mvbs_finalize: NULL array argument");
+  if (n == 0) return EPA_OK;
+  const size_t blocks = (n + epa::kBlock - 1) / epa::kBlock;
+  const int grid = (int)(blocks < 4096 ? blocks : 4096);
+  if (dtype == EPA_F64)
+    hipLaunchKernelGGL(mvbs_finalize_kernel<double>, dim3(grid), dim3(epa::kBlock), 0,
+                       (hipStream_t)stream, (const double*)sum, cnt, n, fill_value, (double*)out);
+  else if (dtype == EPA_F32)
+    hipLaunchKernelGGL(mvbs_finalize_kernel<float>, dim3(grid), dim3(epa::kBlock), 0,
+                       (hipStream_t)stream, (const float*)sum, cnt, n, (float)fill_value, (float*)out);
+  else {
+    epa::set_error("epa_mvbs_finalize: bad dtype %d", dtype);
+    return EPA_EINVAL;
+  }
+  return epa::check_launch("mvbs_finalize_kernel");
+}
+
+namespace {
+template <typename T>
+int run_index(const void* sv, const void* range, int C, int P, int S, int ping_num, int rsn,
+              void* mvbs_out, void* range_min_out, hipStream_t st) {
+  const int Pb = (P + ping_num - 1) / ping_num, Sb = (S + rsn - 1) / rsn;
+  ReduceArgs a{};
+  a.sv = sv; a.C = C; a.P = P; a.S = S;
+  a.bin_start = nullptr; a.n_tbins = Pb; a.ping_num = ping_num;
+  a.bin_mode = BIN_INDEX; a.range_bin = 1.0; a.inv_range_bin = 1.0; a.n_rbins = Sb;
+  a.range_sample_num = rsn; a.bin_flags = EPA_BIN_SKIPNA;
+  a.fill_value = __builtin_nan(""); a.noise_max = __builtin_nan("");
+  a.out = mvbs_out;
+  Plan pl = make_plan<T>(C, P, S, Pb, Sb, al16(sv));
+  pl.nparts = 1;  // a ping block is at most ping_num pings; keep the single-stage path
+  a.nparts = 1;
+  EPA_CHECK_ARG(pl.use_lds, "epa_mvbs_index: %d range blocks exceed the LDS budget", Sb);
+  int rc = launch_reduce<T, SRC_SV, OP_MVBS>(a, pl, st);
+  if (rc) return rc;
+  if (range && range_min_out) {
+    const long long cells = (long long)C * Pb * Sb;
+    const long long blocks = (cells + 3) / 4;
+    const int grid = (int)(blocks < 8192 ? blocks : 8192);
+    hipLaunchKernelGGL(block_nanmin_kernel<T>, dim3(grid), dim3(epa::kBlock), 0, st,
+                       (const T*)range, C, P, S, ping_num, rsn, Pb, Sb, (T*)range_min_out);
+    return epa::check_launch("block_nanmin_kernel");
+  }
+  return EPA_OK;
+}
+
+template <typename T>
+int run_noise(const void* sv, const void* range, const double* coef, const double* alpha2, int C,
+              int P, int S, int ping_num, int rsn, double noise_max, double* noise_out,
+              hipStream_t st) {
+  const int Pb = (P + ping_num - 1) / ping_num, Sb = (S + rsn - 1) / rsn;
+  ReduceArgs a{};
+  a.sv = sv; a.range = range; a.coef = reinterpret_cast<const epa::CoefRow*>(coef);
+  a.alpha2 = alpha2;
+  a.C = C; a.P = P; a.S = S;
+  a.bin_start = nullptr; a.n_tbins = Pb; a.ping_num = ping_num;
+  a.bin_mode = BIN_INDEX; a.range_bin = 1.0; a.inv_range_bin = 1.0; a.n_rbins = Sb;
+  a.range_sample_num = rsn; a.bin_flags = EPA_BIN_SKIPNA;
+  a.fill_value = __builtin_nan(""); a.noise_max = noise_max;
+  a.out = noise_out;
+  Plan pl = make_plan<T>(C, P, S, Pb, Sb, al16(sv) && al16(range));
+  pl.nparts = 1;
+  a.nparts = 1;
+  EPA_CHECK_ARG(pl.use_lds, "epa_noise_estimate: %d range blocks exceed the LDS budget", Sb);
+  return launch_reduce<T, SRC_SV, OP_NOISE>(a, pl, st);
+}
+}  // namespace
+
+extern "C" int epa_mvbs_index(const void* sv, const void* range, int C, int P, int S, int ping_num,
+                              int range_sample_num, void* mvbs_out, void* range_min_out, int dtype,
+                              epa_stream_t stream) {
+  EPA_CHECK_ARG(sv && mvbs_out, "epa_mvbs_index: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && ping_num > 0 && range_sample_num > 0,
+                "epa_mvbs_index: sizes must be positive");
+  if (dtype == EPA_F64)
+    return run_index<double>(sv, range, C, P, S, ping_num, range_sample_num, mvbs_out, range_min_out,
+                             (hipStream_t)stream);
+  if (dtype == EPA_F32)
+    return run_index<float>(sv, range, C, P, S, ping_num, range_sample_num, mvbs_out, range_min_out,
+                            (hipStream_t)stream);
+  epa::set_error("epa_mvbs_index: bad dtype %d", dtype);
+  return EPA_EINVAL;
+}
+
+extern "C" int epa_noise_estimate(const void* sv, const void* range, const double* coef,
+                                  const double* alpha2, int C, int P, int S, int ping_num,
+                                  int range_sample_num, double noise_max, double* noise_out,
+                                  int dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(sv && alpha2 && noise_out, "epa_noise_estimate: NULL array argument");
+  EPA_CHECK_ARG(range || coef, "epa_noise_estimate: either range or coef must be given");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && ping_num > 0 && range_sample_num > 0,
+                "epa_noise_estimate: sizes must be positive");
+  if (dtype == EPA_F64)
+    return run_noise<double>(sv, range, coef, alpha2, C, P, S, ping_num, range_sample_num,
+                             noise_max, noise_out, (hipStream_t)stream);
+  if (dtype == EPA_F32)
+    return run_noise<float>(sv, range, coef, alpha2, C, P, S, ping_num, range_sample_num, noise_max,
+                            noise_out, (hipStream_t)stream);
+  epa::set_error("epa_noise_estimate: bad dtype %d", dtype);
+  return EPA_EINVAL;
+}

@@ -1,0 +1,292 @@
+// K3+K4: EK80 complex samples -- matched-filter pulse compression (BB) fused with the
+// sector mean -> received power -> Sv/TS chain.  CW complex data take the same kernel with no
+// replica (taps = 0).
+//
+// Reference arithmetic replaced (paths under /root/reference/echopype/calibrate):
+//   ek80_complex.py:285-369  compress_pulse: NaN -> 0, per (ping, sector) convolution with
+//                            flipud(conj(tx)) cropped at m-1  ==  y[k] = sum_j x[k+j] * conj(tx[j]),
+//                            NaN restored at input-NaN positions
+//   ek80_complex.py:372-391  norm factor ||tx||^2 (here: wavefront __shfl reduction in-kernel)
+//   calibrate_ek.py:483-490  prx = B*|mean_sector(y/||tx||^2)|^2 / 8 * (|z_er+z_et|/z_er)^2 / z_et
+//   calibrate_ek.py:571-638  prx<=0 -> NaN; Sv/TS chain;  range.py:138-148,180-199 ranges
+//
+// Design.  One workgroup (256 lanes) produces a tile of 2048 consecutive range samples of one
+// (channel, ping).  The matched filter is linear and the reference averages the sectors right
+// after it, so the tile is staged ONCE as the sector SUM (NaN zero-filled) plus a per-sample
+// validity bitmask: B x fewer MACs.  That is exact when all sectors share the NaN pattern at a
+// sample (end-of-ping padding, multiplexed pings); a tile that contains a sample with a MIXED
+// pattern falls back to one convolution per sector (block-uniform branch).  The replica (conj
+// applied) sits in LDS; each lane owns 8 consecutive outputs and slides a 16-element register
+// window over the staged tile (LDS rows padded 9/8 -> conflict-free ds_read_b64 / b128).
+// Not a GEMM, no MFMA (BASELINE north_star); vector-FP32/FP64 FMA bound (8*m flops / sample).
+#include "epa_internal.h"
+
+namespace {
+
+constexpr int kR = 8;                      // outputs per lane
+constexpr int kTile = epa::kBlock * kR;    // 2048 outputs per workgroup
+constexpr int kMaxBeams = 8;
+
+template <typename A>
+struct Cx {
+  A re, im;
+};
+
+__device__ __forceinline__ int pad_idx(int a) { return a + (a >> 3); }
+
+struct CxArgs {
+  const void* re;
+  const void* im;
+  const float* replica;        // interleaved (re, im) f32
+  const int32_t* replica_off;  // [C+1] in complex elements, or NULL (CW)
+  const double* ccoef;
+  int C, P, S, B;
+  int tiles;
+  double nspread;
+  void* out;
+  void* range_out;
+  void* prx_out;
+  unsigned rep_lds_off, mask_lds_off;  // byte offsets in dynamic LDS
+  int stage_len;                       // kTile + max_taps - 1 (>= kTile)
+};
+
+// stage samples [k_begin, k_begin + len) of one ping: sector sum (or one sector when `only` >= 0)
+template <typename InT, typename A>
+__device__ __forceinline__ unsigned stage_tile(const InT* __restrict__ re, const InT* __restrict__ im,
+                                               size_t ping_base, int S, int B, int k_begin, int len,
+                                               int only, Cx<A>* xs, uint8_t* vmask) {
+  unsigned mixed = 0;
+  const unsigned full = (1u << B) - 1u;
+  for (int t = threadIdx.x; t < len; t += epa::kBlock) {
+    const int s = k_begin + t;
+    A sr = (A)0, si = (A)0;
+    unsigned m = 0;
+    if (s < S) {
+      const InT* pr = re + ping_base + (size_t)s * B;
+      const InT* pi = im + ping_base + (size_t)s * B;
+      for (int b = 0; b < B; ++b) {
+        const InT vr = pr[b], vi = pi[b];
+        const bool ok = (vr == vr) && (vi == vi);
+        if (ok) {
+          m |= 1u << b;
+          if (only < 0 || only == b) {
+            sr += (A)vr;
+            si += (A)vi;
+          }
+        }
+      }
+      // second mask byte, bit 0: beam-0 real part valid (echo_range mask, range.py:143-146)
+      if (pr[0] == pr[0]) m |= 0x100u;
+    }
+    xs[pad_idx(t)] = Cx<A>{sr, si};
+    if (only < 0) {
+      vmask[2 * t] = (uint8_t)(m & 0xffu);
+      vmask[2 * t + 1] = (uint8_t)(m >> 8);
+      if ((m & full) != 0u && (m & full) != full) mixed = 1u;
+    }
+  }
+  return mixed;
+}
+
+// y[i] = sum_j x[k0+i+j] * conj(rep[j]), i = 0..7, for this lane's 8 outputs
+template <typename A>
+__device__ __forceinline__ void conv8(const Cx<A>* __restrict__ xs, const Cx<A>* __restrict__ rep,
+                                      int taps, int k0, Cx<A> (&acc)[kR]) {
+  Cx<A> w[2 * kR];
+#pragma unroll
+  for (int e = 0; e < kR; ++e) w[e] = xs[pad_idx(k0 + e)];
+  for (int q = 0; q < taps; q += kR) {
+#pragma unroll
+    for (int e = 0; e < kR; ++e) w[kR + e] = xs[pad_idx(k0 + q + kR + e)];
+#pragma unroll
+    for (int jj = 0; jj < kR; ++jj) {
+      // rep is zero-padded to a multiple of 8 taps in LDS
+      const Cx<A> t = rep[q + jj];
+#pragma unroll
+      for (int i = 0; i < kR; ++i) {
+        const Cx<A> x = w[i + jj];
+        acc[i].re = fma(x.re, t.re, acc[i].re);
+        acc[i].re = fma(x.im, t.im, acc[i].re);
+        acc[i].im = fma(x.im, t.re, acc[i].im);
+        acc[i].im = fma(-x.re, t.im, acc[i].im);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < kR; ++e) w[e] = w[kR + e];
+  }
+}
+
+template <typename InT, typename T, typename A>
+__global__ __launch_bounds__(epa::kBlock) void sv_complex_kernel(CxArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Cx<A>* xs = reinterpret_cast<Cx<A>*>(smem);
+  Cx<A>* rep = reinterpret_cast<Cx<A>*>(smem + a.rep_lds_off);
+  uint8_t* vmask = smem + a.mask_lds_off;
+  __shared__ A red[8];
+
+  const int c = blockIdx.y;
+  const int p = blockIdx.x / a.tiles;
+  const int tile = blockIdx.x - p * a.tiles;
+  const int S = a.S, B = a.B;
+  const int k_begin = tile * kTile;
+  const InT* re = reinterpret_cast<const InT*>(a.re);
+  const InT* im = reinterpret_cast<const InT*>(a.im);
+  const size_t ping_base = ((size_t)c * a.P + p) * (size_t)S * B;
+
+  // ---- replica -> LDS (conj is applied in the MAC), zero-padded to a multiple of 8 taps;
+  //      ||tx||^2 by wavefront shuffle reduction
+  int taps = 0;
+  A norm2 = (A)1;
+  if (a.replica) {
+    const int r0 = a.replica_off[c], r1 = a.replica_off[c + 1];
+    taps = r1 - r0;
+    const int taps8 = (taps + kR - 1) / kR * kR;
+    A part = (A)0;
+    for (int j = threadIdx.x; j < taps8; j += epa::kBlock) {
+      Cx<A> t{(A)0, (A)0};
+      if (j < taps) {
+        t.re = (A)a.replica[2 * (size_t)(r0 + j)];
+        t.im = (A)a.replica[2 * (size_t)(r0 + j) + 1];
+      }
+      rep[j] = t;
+      part += t.re * t.re + t.im * t.im;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    norm2 = red[0] + red[1] + red[2] + red[3];
+  }
+  const int taps8 = (taps + kR - 1) / kR * kR;
+  // staged span: outputs [k_begin, k_begin+kTile) need inputs up to k_begin + kTile + taps8 - 1 (+8 lookahead)
+  const int len = kTile + (taps8 > 0 ? taps8 + kR : 0);
+
+  const unsigned mixed_l = stage_tile<InT, A>(re, im, ping_base, S, B, k_begin, len, -1, xs, vmask);
+  const int mixed = __syncthreads_or((int)mixed_l);
+
+  const int k0 = threadIdx.x * kR;  // tile-local first output of this lane
+  Cx<A> y[kR];
+  unsigned nvalid[kR];
+  const unsigned full = (1u << B) - 1u;
+#pragma unroll
+  for (int i = 0; i < kR; ++i) {
+    y[i] = Cx<A>{(A)0, (A)0};
+    nvalid[i] = __popc(vmask[2 * (k0 + i)] & full);
+  }
+  if (!mixed) {
+    if (taps == 0) {
+#pragma unroll
+      for (int i = 0; i < kR; ++i) y[i] = xs[pad_idx(k0 + i)];
+    } else {
+      conv8<A>(xs, rep, taps8, k0, y);
+    }
+  } else {
+    // per-sector convolutions; a sector contributes to output k only where it is valid at k
+    for (int b = 0; b < B; ++b) {
+      __syncthreads();
+      stage_tile<InT, A>(re, im, ping_base, S, B, k_begin, len, b, xs, vmask);
+      __syncthreads();
+      Cx<A> yb[kR];
+#pragma unroll
+      for (int i = 0; i < kR; ++i) yb[i] = Cx<A>{(A)0, (A)0};
+      if (taps == 0) {
+#pragma unroll
+        for (int i = 0; i < kR; ++i) yb[i] = xs[pad_idx(k0 + i)];
+      } else {
+        conv8<A>(xs, rep, taps8, k0, yb);
+      }
+#pragma unroll
+      for (int i = 0; i < kR; ++i) {
+        if (vmask[2 * (k0 + i)] & (1u << b)) {
+          y[i].re += yb[i].re;
+          y[i].im += yb[i].im;
+        }
+      }
+    }
+  }
+
+  // ---- sector mean -> prx -> Sv/TS (calibrate_ek.py:483-490, 571-638)
+  const size_t row = (size_t)c * a.P + p;
+  const double* cc = a.ccoef + row * EPA_NCCOEF;
+  const double kk = cc[EPA_CC_K];
+  const T shift = (T)cc[EPA_CC_SHIFT], alpha2 = (T)cc[EPA_CC_ALPHA2], Aadd = (T)cc[EPA_CC_A];
+  const T pscale = (T)(cc[EPA_CC_PSCALE]);
+  const T nspread = (T)a.nspread;
+  const T inv_norm = (T)1 / (T)norm2;
+  T* out = reinterpret_cast<T*>(a.out);
+  T* range_out = reinterpret_cast<T*>(a.range_out);
+  T* prx_out = reinterpret_cast<T*>(a.prx_out);
+#pragma unroll
+  for (int i = 0; i < kR; ++i) {
+    const int s = k_begin + k0 + i;
+    if (s >= S) break;
+    T mr, mi;
+    if (nvalid[i] == 0u) {
+      mr = mi = epa::M<T>::nan();
+    } else {
+      const T invn = inv_norm / (T)nvalid[i];
+      mr = (T)y[i].re * invn;
+      mi = (T)y[i].im * invn;
+    }
+    T prx = pscale * (mr * mr + mi * mi);
+    if (!(prx > (T)0)) prx = epa::M<T>::nan();
+    const double R = (double)s * kk;
+    T rt = (T)R - shift;
+    if (!(rt > (T)0)) rt = epa::M<T>::nan();
+    const T val = (T)10 * epa::M<T>::log10(prx) + nspread * epa::M<T>::log10(rt) + alpha2 * rt + Aadd;
+    const size_t o = row * S + s;
+    out[o] = val;
+    if (range_out) range_out[o] = (vmask[2 * (k0 + i) + 1] & 1u) ? (T)R : epa::M<T>::nan();
+    if (prx_out) prx_out[o] = prx;
+  }
+}
+
+template <typename InT, typename T, typename A>
+int launch(CxArgs& a, int max_taps, hipStream_t st) {
+  const int taps8 = (max_taps + kR - 1) / kR * kR;
+  const int len = kTile + (taps8 > 0 ? taps8 + kR : 0);
+  const size_t xs_bytes = ((size_t)(len + (len >> 3) + 1) * sizeof(Cx<A>) + 15) & ~(size_t)15;
+  const size_t rep_bytes = ((size_t)(taps8 > 0 ? taps8 : kR) * sizeof(Cx<A>) + 15) & ~(size_t)15;
+  const size_t mask_bytes = (size_t)2 * len;
+  a.rep_lds_off = (unsigned)xs_bytes;
+  a.mask_lds_off = (unsigned)(xs_bytes + rep_bytes);
+  const size_t lds = xs_bytes + rep_bytes + mask_bytes;
+  EPA_CHECK_ARG(lds <= 150 * 1024, "epa_sv_complex: replica of %d taps does not fit the LDS tile",
+                max_taps);
+  a.tiles = (a.S + kTile - 1) / kTile;
+  auto kern = sv_complex_kernel<InT, T, A>;
+  if (lds > 64 * 1024)
+    EPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const dim3 grid((unsigned)((long long)a.P * a.tiles), (unsigned)a.C);
+  hipLaunchKernelGGL(kern, grid, dim3(epa::kBlock), lds, st, a);
+  return epa::check_launch("sv_complex_kernel");
+}
+
+}  // namespace
+
+extern "C" int epa_sv_complex(const void* re, const void* im, int in_dtype, const float* replica,
+                              const int32_t* replica_off, int max_taps, const double* ccoef, int C,
+                              int P, int S, int B, int cal_type, void* out, void* range_out,
+                              void* prx_out, int out_dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(re && im && ccoef && out, "epa_sv_complex: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && B > 0, "epa_sv_complex: C=%d P=%d S=%d B=%d", C, P, S, B);
+  EPA_CHECK_ARG(B <= kMaxBeams, "epa_sv_complex: at most %d sectors supported (got %d)", kMaxBeams, B);
+  EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_sv_complex: bad cal_type");
+  EPA_CHECK_ARG((replica == nullptr) == (replica_off == nullptr),
+                "epa_sv_complex: replica and replica_off must both be given (BB) or both NULL (CW)");
+  EPA_CHECK_ARG(!replica || max_taps > 0, "epa_sv_complex: max_taps must be positive for BB");
+  CxArgs a{};
+  a.re = re; a.im = im; a.replica = replica; a.replica_off = replica_off; a.ccoef = ccoef;
+  a.C = C; a.P = P; a.S = S; a.B = B;
+  a.nspread = cal_type == EPA_CAL_SV ? 20.0 : 40.0;
+  a.out = out; a.range_out = range_out; a.prx_out = prx_out;
+  const int taps = replica ? max_taps : 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (in_dtype == EPA_F64 && out_dtype == EPA_F64) return launch<double, double, double>(a, taps, st);
+  if (in_dtype == EPA_F64 && out_dtype == EPA_F32) return launch<double, float, float>(a, taps, st);
+  if (in_dtype == EPA_F32 && out_dtype == EPA_F64) return launch<float, double, double>(a, taps, st);
+  if (in_dtype == EPA_F32 && out_dtype == EPA_F32) return launch<float, float, float>(a, taps, st);
+  epa::set_error("epa_sv_complex: bad dtype in=%d out=%d", in_dtype, out_dtype);
+  return EPA_EINVAL;
+}

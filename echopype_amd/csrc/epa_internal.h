@@ -1,0 +1,97 @@
+// Internal helpers shared by the HIP translation units of libechopype_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "echopype_amd.h"
+
+namespace epa {
+
+void set_error(const char* fmt, ...);
+
+#define EPA_CHECK_ARG(cond, ...)       \
+  do {                                 \
+    if (!(cond)) {                     \
+      ::epa::set_error(__VA_ARGS__);   \
+      return EPA_EINVAL;               \
+    }                                  \
+  } while (0)
+
+#define EPA_CHECK_HIP(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      ::epa::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                       __LINE__);                                                        \
+      return EPA_EHIP;                                                                   \
+    }                                                                                    \
+  } while (0)
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+    return EPA_EHIP;
+  }
+  return EPA_OK;
+}
+
+constexpr int kBlock = 256;  // 4 wavefronts of 64
+
+// ---- device math, templated on the compute type ------------------------------------------------
+template <typename T>
+struct M;
+template <>
+struct M<double> {
+  static __device__ __forceinline__ double log10(double x) { return ::log10(x); }
+  static __device__ __forceinline__ double exp10(double x) { return ::exp10(x); }
+  static __device__ __forceinline__ double nan() { return __builtin_nan(""); }
+};
+template <>
+struct M<float> {
+  static __device__ __forceinline__ float log10(float x) { return ::log10f(x); }
+  static __device__ __forceinline__ float exp10(float x) { return ::exp10f(x); }
+  static __device__ __forceinline__ float nan() { return __builtin_nanf(""); }
+};
+
+// Per-(channel, ping) coefficient row (EPA_NCOEF doubles, 64 B): two 32-B halves so that a
+// wave-uniform row read is two scalar s_load_dwordx8.
+struct CoefRow {
+  double ra, rb, r0, shift, alpha2, A0, g, d;
+};
+static_assert(sizeof(CoefRow) == EPA_NCOEF * sizeof(double), "coef row layout");
+
+// Uniform-edge bin index: edges e_i = i*bin (np.arange(0, stop, bin) evaluates 0 + i*bin in
+// double), membership decided against those exact edge values (SURVEY A.6 caveat (i)).
+// Returns -1 for NaN, out of range.
+__device__ __forceinline__ int range_bin_index(double x, double bin, double inv_bin, int nbins,
+                                               bool closed_right) {
+  if (!(x == x)) return -1;
+  double t = x * inv_bin;
+  // clamp before the int conversion (inf / huge values)
+  if (!(t > -2.0)) return -1;
+  if (t > (double)nbins + 2.0) return -1;
+  int i;
+  if (!closed_right) {
+    i = (int)floor(t);
+    // fix-up against the true edges
+    if (x < (double)i * bin) --i;
+    else if (x >= (double)(i + 1) * bin) ++i;
+  } else {
+    i = (int)ceil(t) - 1;
+    if (x <= (double)i * bin) --i;
+    else if (x > (double)(i + 1) * bin) ++i;
+  }
+  return (i >= 0 && i < nbins) ? i : -1;
+}
+
+// echo_range of sample s in the reference's operation order (range.py:138: (s*si)*c/2)
+__device__ __forceinline__ double row_range(const CoefRow& r, int s) {
+  return ((double)s * r.ra) * r.rb + r.r0;
+}
+
+}  // namespace epa

@@ -1,0 +1,98 @@
+// K7: background-noise removal, one elementwise pass.
+//
+// Replaces /root/reference/echopype/clean/api.py:425-430 (forward-fill of the per-ping-block noise
+// to every ping + transmission loss) and :485-487 (linear subtraction, SNR threshold):
+//   TL        = 20*log10(R if R >= 1 else 1 [NaN -> 1]) + 2*alpha*R
+//   Sv_noise  = noise[c, p // ping_num] + TL
+//   L         = 10^(Sv/10) - 10^(Sv_noise/10);  Sv_corr = 10*log10(L) if L > 0 else NaN
+//   Sv_corr   = NaN unless Sv_corr - Sv_noise > SNR_threshold
+// HBM-bound: reads Sv (+ echo_range unless affine), writes Sv_noise and Sv_corrected.
+#include "sample_math.h"
+
+namespace {
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(epa::kBlock) void noise_apply_kernel(
+    const T* __restrict__ sv, const T* __restrict__ range, const epa::CoefRow* __restrict__ coef,
+    const double* __restrict__ alpha2, const double* __restrict__ noise, int P, int S,
+    long long rows, int chunks_per_row, int ping_num, int n_pblocks, T snr,
+    T* __restrict__ sv_noise, T* __restrict__ sv_corr) {
+  constexpr int kChunk = epa::kBlock * VEC;
+  const long long items = rows * chunks_per_row;
+  for (long long item = blockIdx.x; item < items; item += gridDim.x) {
+    const long long row = item / chunks_per_row;
+    const int chunk = (int)(item - row * chunks_per_row);
+    const int s0 = chunk * kChunk + threadIdx.x * VEC;
+    if (s0 >= S) continue;
+    const int c = (int)(row / P), p = (int)(row - (long long)c * P);
+    const T nb = (T)noise[(size_t)c * n_pblocks + p / ping_num];
+    const T a2 = (T)alpha2[row];
+    const size_t off = (size_t)row * S + s0;
+    T v[VEC], x[VEC], on[VEC], oc[VEC];
+    epa::load_vec<T, VEC>(sv + off, v);
+    if (range) {
+      epa::load_vec<T, VEC>(range + off, x);
+    } else {
+      const epa::CoefRow cr = coef[row];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) x[j] = (T)epa::row_range(cr, s0 + j);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const T tl = (T)20 * epa::M<T>::log10(x[j] >= (T)1 ? x[j] : (T)1) + a2 * x[j];
+      const T sn = nb + tl;
+      const T lin = epa::M<T>::exp10(v[j] * (T)0.1) - epa::M<T>::exp10(sn * (T)0.1);
+      T corr = lin > (T)0 ? (T)10 * epa::M<T>::log10(lin) : epa::M<T>::nan();
+      if (!(corr - sn > snr)) corr = epa::M<T>::nan();
+      on[j] = sn;
+      oc[j] = corr;
+    }
+    if (sv_noise) epa::store_vec<T, VEC>(sv_noise + off, on);
+    if (sv_corr) epa::store_vec<T, VEC>(sv_corr + off, oc);
+  }
+}
+
+inline bool al16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename T>
+int launch(const void* sv, const void* range, const double* coef, const double* alpha2,
+           const double* noise, int C, int P, int S, int ping_num, double snr, void* sv_noise,
+           void* sv_corr, hipStream_t st) {
+  const long long rows = (long long)C * P;
+  const int vec = (S % 4 == 0 && al16(sv) && al16(range) && al16(sv_noise) && al16(sv_corr)) ? 4 : 1;
+  const int chunk = epa::kBlock * vec;
+  const int chunks_per_row = (S + chunk - 1) / chunk;
+  const long long items = rows * chunks_per_row;
+  const int grid = (int)(items < 8192 ? items : 8192);
+  const int n_pblocks = (P + ping_num - 1) / ping_num;
+  const epa::CoefRow* cf = reinterpret_cast<const epa::CoefRow*>(coef);
+  if (vec == 4)
+    hipLaunchKernelGGL((noise_apply_kernel<T, 4>), dim3(grid), dim3(epa::kBlock), 0, st,
+                       (const T*)sv, (const T*)range, cf, alpha2, noise, P, S, rows, chunks_per_row,
+                       ping_num, n_pblocks, (T)snr, (T*)sv_noise, (T*)sv_corr);
+  else
+    hipLaunchKernelGGL((noise_apply_kernel<T, 1>), dim3(grid), dim3(epa::kBlock), 0, st,
+                       (const T*)sv, (const T*)range, cf, alpha2, noise, P, S, rows, chunks_per_row,
+                       ping_num, n_pblocks, (T)snr, (T*)sv_noise, (T*)sv_corr);
+  return epa::check_launch("noise_apply_kernel");
+}
+
+}  // namespace
+
+extern "C" int epa_noise_apply(const void* sv, const void* range, const double* coef,
+                               const double* alpha2, const double* noise, int C, int P, int S,
+                               int ping_num, double snr_threshold, void* sv_noise_out,
+                               void* sv_corrected_out, int dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(sv && alpha2 && noise, "epa_noise_apply: NULL array argument");
+  EPA_CHECK_ARG(range || coef, "epa_noise_apply: either range or coef must be given");
+  EPA_CHECK_ARG(sv_noise_out || sv_corrected_out, "epa_noise_apply: no output requested");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && ping_num > 0, "epa_noise_apply: sizes must be positive");
+  if (dtype == EPA_F64)
+    return launch<double>(sv, range, coef, alpha2, noise, C, P, S, ping_num, snr_threshold,
+                          sv_noise_out, sv_corrected_out, (hipStream_t)stream);
+  if (dtype == EPA_F32)
+    return launch<float>(sv, range, coef, alpha2, noise, C, P, S, ping_num, snr_threshold,
+                         sv_noise_out, sv_corrected_out, (hipStream_t)stream);
+  epa::set_error("epa_noise_apply: bad dtype %d", dtype);
+  return EPA_EINVAL;
+}

@@ -1,0 +1,153 @@
+// K0: per-(channel, ping) coefficient rows for the power-sample calibration, and the time-bin
+// CSR used by the binned reductions.  O(C*P) work -- a few microseconds next to the sample
+// passes, but kept on the device so that a "step" of the pipeline never leaves HBM.
+//
+// Reference arithmetic replaced (paths under /root/reference/echopype):
+//   calibrate/range.py:138            k = sample_interval * sound_speed / 2
+//   calibrate/range.py:174-199        TVG range shift (Ex60: 2 samples; Ex80: c*tau/4; GPT: both)
+//   calibrate/cal_params.py:261-324   pulse-length table lookup of gain / sa_correction
+//   calibrate/calibrate_ek.py:98,154-162 (CSv), :176-181 (CSp)
+//   commongrid/api.py:118-128         pandas-resample bin assignment (left/right closed)
+#include "epa_internal.h"
+
+namespace {
+
+struct CoefArgs {
+  int C, P, K;
+  const double *si, *tau, *pt;
+  const double *ss, *ab, *gain, *sa, *pl;
+  int ss_mode, ab_mode, gain_mode, sa_mode;
+  const double *psi, *fnom, *taueff;
+  const uint8_t* gpt;
+  int sonar, cal_type;
+  double* coef;
+};
+
+__device__ __forceinline__ double fetch(const double* p, int mode, int c, int idx) {
+  return mode == EPA_PM_SCALAR ? p[0] : (mode == EPA_PM_CHANNEL ? p[c] : p[idx]);
+}
+
+// argmin_k |tau - pulse_length[c,k]|, first minimum, NaN table entries skipped, NaN tau -> NaN
+__device__ __forceinline__ double table_lookup(double tau, const double* pl, const double* tab,
+                                               int K) {
+  if (!(tau == tau)) return __builtin_nan("");
+  int best = 0;
+  double bestd = __builtin_inf();
+  for (int k = 0; k < K; ++k) {
+    double d = fabs(tau - pl[k]);
+    if (d < bestd) {
+      bestd = d;
+      best = k;
+    }
+  }
+  return tab[best];
+}
+
+__global__ __launch_bounds__(epa::kBlock) void power_coef_ek_kernel(CoefArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.C * a.P) return;
+  const int c = idx / a.P;
+  const double si = a.si[idx], tau = a.tau[idx], pt = a.pt[idx];
+  const double cw = fetch(a.ss, a.ss_mode, c, idx);
+  const double alpha = fetch(a.ab, a.ab_mode, c, idx);
+  const double G = a.gain_mode == EPA_PM_PULSE_TABLE
+                       ? table_lookup(tau, a.pl + (size_t)c * a.K, a.gain + (size_t)c * a.K, a.K)
+                       : fetch(a.gain, a.gain_mode, c, idx);
+  const double sa = a.sa_mode == EPA_PM_PULSE_TABLE
+                        ? table_lookup(tau, a.pl + (size_t)c * a.K, a.sa + (size_t)c * a.K, a.K)
+                        : fetch(a.sa, a.sa_mode, c, idx);
+  const double k = si * cw / 2;
+  const double ex60 = 2 * si * cw / 2;
+  // d = shift / k written without the sound speed (it cancels): identical for every ping of a
+  // file with constant tau / sample_interval, which is what lets the kernels hoist log10(s - d)
+  double shift, d;
+  if (a.sonar == EPA_SONAR_EK60) {
+    shift = ex60;
+    d = 2.0;
+  } else {
+    shift = cw * tau / 4;
+    d = tau / (2 * si);
+    if (a.gpt && a.gpt[c]) {
+      shift += ex60;
+      d += 2.0;
+    }
+  }
+  const double lambda = cw / a.fnom[c];
+  const double pi = 3.141592653589793;
+  double A;
+  if (a.cal_type == EPA_CAL_SV) {
+    const double CSv = 10 * log10(pt) + 2 * G + a.psi[c] +
+                       10 * log10(lambda * lambda * a.taueff[c] * cw / (32 * pi * pi));
+    A = -CSv - 2 * sa;
+  } else {
+    const double CSp = 10 * log10(pt) + 2 * G + 10 * log10(lambda * lambda / (16 * pi * pi));
+    A = -CSp;
+  }
+  const double nspread = a.cal_type == EPA_CAL_SV ? 20.0 : 40.0;
+  epa::CoefRow r{si, cw / 2, 0.0, shift, 2 * alpha, A + nspread * log10(k), 1.0, d};
+  reinterpret_cast<epa::CoefRow*>(a.coef)[idx] = r;
+}
+
+__global__ __launch_bounds__(epa::kBlock) void time_bin_offsets_kernel(const int64_t* t, int P,
+                                                                       int64_t t0, int64_t dt,
+                                                                       int n_bins,
+                                                                       bool closed_right,
+                                                                       int32_t* bin_start) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > n_bins) return;
+  const int64_t edge = t0 + (int64_t)b * dt;
+  int lo = 0, hi = P;  // first index with t >= edge (left closed) or t > edge (right closed)
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const int64_t v = t[mid];
+    const bool before = closed_right ? (v <= edge) : (v < edge);
+    if (before) lo = mid + 1;
+    else hi = mid;
+  }
+  bin_start[b] = lo;
+}
+
+}  // namespace
+
+extern "C" int epa_power_coef_ek(int C, int P, const double* sample_interval,
+                                 const double* tau_nominal, const double* transmit_power,
+                                 const double* sound_speed, int ss_mode, const double* absorption,
+                                 int abs_mode, const double* gain, int gain_mode,
+                                 const double* sa_correction, int sa_mode,
+                                 const double* pulse_length, int K, const double* psi,
+                                 const double* f_nominal, const double* tau_eff, const uint8_t* gpt,
+                                 int sonar, int cal_type, double* coef, epa_stream_t stream) {
+  EPA_CHECK_ARG(C > 0 && P > 0, "epa_power_coef_ek: C=%d P=%d must be positive", C, P);
+  EPA_CHECK_ARG(sample_interval && tau_nominal && transmit_power && sound_speed && absorption &&
+                    gain && sa_correction && psi && f_nominal && tau_eff && coef,
+                "epa_power_coef_ek: NULL array argument");
+  EPA_CHECK_ARG(ss_mode >= 0 && ss_mode <= 2 && abs_mode >= 0 && abs_mode <= 2,
+                "epa_power_coef_ek: bad sound_speed/absorption mode");
+  EPA_CHECK_ARG(gain_mode >= 0 && gain_mode <= 3 && sa_mode >= 0 && sa_mode <= 3,
+                "epa_power_coef_ek: bad gain/sa mode");
+  if (gain_mode == EPA_PM_PULSE_TABLE || sa_mode == EPA_PM_PULSE_TABLE)
+    EPA_CHECK_ARG(pulse_length != nullptr && K > 0,
+                  "epa_power_coef_ek: pulse-table mode needs pulse_length and K > 0");
+  EPA_CHECK_ARG(sonar == EPA_SONAR_EK60 || sonar == EPA_SONAR_EK80, "epa_power_coef_ek: bad sonar");
+  EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_power_coef_ek: bad cal_type");
+  CoefArgs a{C, P, K, sample_interval, tau_nominal, transmit_power, sound_speed, absorption, gain,
+             sa_correction, pulse_length, ss_mode, abs_mode, gain_mode, sa_mode, psi, f_nominal,
+             tau_eff, gpt, sonar, cal_type, coef};
+  const long long n = (long long)C * P;
+  const int grid = (int)((n + epa::kBlock - 1) / epa::kBlock);
+  hipLaunchKernelGGL(power_coef_ek_kernel, dim3(grid), dim3(epa::kBlock), 0, (hipStream_t)stream, a);
+  return epa::check_launch("power_coef_ek_kernel");
+}
+
+extern "C" int epa_time_bin_offsets(const int64_t* ping_time, int P, int64_t t0, int64_t dt,
+                                    int n_bins, unsigned flags, int32_t* bin_start,
+                                    epa_stream_t stream) {
+  EPA_CHECK_ARG(ping_time && bin_start, "epa_time_bin_offsets: NULL array argument");
+  EPA_CHECK_ARG(P >= 0 && n_bins > 0 && dt > 0, "epa_time_bin_offsets: P=%d n_bins=%d dt=%lld", P,
+                n_bins, (long long)dt);
+  const int grid = (n_bins + 1 + epa::kBlock - 1) / epa::kBlock;
+  hipLaunchKernelGGL(time_bin_offsets_kernel, dim3(grid), dim3(epa::kBlock), 0,
+                     (hipStream_t)stream, ping_time, P, t0, dt, n_bins,
+                     (flags & EPA_BIN_CLOSED_RIGHT) != 0, bin_start);
+  return epa::check_launch("time_bin_offsets_kernel");
+}

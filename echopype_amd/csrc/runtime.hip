@@ -1,0 +1,110 @@
+// Runtime plumbing of the C ABI: error reporting, device memory helpers, HIP-event timers.
+#include "epa_internal.h"
+
+#include <cstring>
+
+namespace epa {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace epa
+
+struct EpaTimer {
+  hipEvent_t start, stop;
+};
+
+extern "C" {
+
+int epa_version(void) { return EPA_VERSION; }
+const char* epa_last_error(void) { return epa::g_err; }
+
+int epa_device_count(int* n) {
+  EPA_CHECK_ARG(n != nullptr, "epa_device_count: n is NULL");
+  EPA_CHECK_HIP(hipGetDeviceCount(n));
+  return EPA_OK;
+}
+int epa_set_device(int dev) {
+  EPA_CHECK_HIP(hipSetDevice(dev));
+  return EPA_OK;
+}
+int epa_device_name(int dev, char* buf, size_t len) {
+  EPA_CHECK_ARG(buf != nullptr && len > 0, "epa_device_name: empty buffer");
+  hipDeviceProp_t prop;
+  EPA_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+  snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return EPA_OK;
+}
+int epa_malloc(void** ptr, size_t bytes) {
+  EPA_CHECK_ARG(ptr != nullptr, "epa_malloc: ptr is NULL");
+  hipError_t e = hipMalloc(ptr, bytes);
+  if (e == hipErrorOutOfMemory) {
+    epa::set_error("epa_malloc: out of device memory (%zu bytes)", bytes);
+    return EPA_ENOMEM;
+  }
+  EPA_CHECK_HIP(e);
+  return EPA_OK;
+}
+int epa_free(void* ptr) {
+  EPA_CHECK_HIP(hipFree(ptr));
+  return EPA_OK;
+}
+int epa_memset(void* ptr, int value, size_t bytes, epa_stream_t stream) {
+  EPA_CHECK_HIP(hipMemsetAsync(ptr, value, bytes, (hipStream_t)stream));
+  return EPA_OK;
+}
+int epa_memcpy_h2d(void* dst, const void* src_host, size_t bytes, epa_stream_t stream) {
+  EPA_CHECK_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return EPA_OK;
+}
+int epa_memcpy_d2h(void* dst_host, const void* src, size_t bytes, epa_stream_t stream) {
+  EPA_CHECK_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return EPA_OK;
+}
+int epa_stream_synchronize(epa_stream_t stream) {
+  EPA_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return EPA_OK;
+}
+
+int epa_timer_create(void** timer) {
+  EPA_CHECK_ARG(timer != nullptr, "epa_timer_create: timer is NULL");
+  EpaTimer* t = new EpaTimer;
+  hipError_t e = hipEventCreate(&t->start);
+  if (e == hipSuccess) e = hipEventCreate(&t->stop);
+  if (e != hipSuccess) {
+    delete t;
+    EPA_CHECK_HIP(e);
+  }
+  *timer = t;
+  return EPA_OK;
+}
+int epa_timer_destroy(void* timer) {
+  if (!timer) return EPA_OK;
+  EpaTimer* t = (EpaTimer*)timer;
+  hipEventDestroy(t->start);
+  hipEventDestroy(t->stop);
+  delete t;
+  return EPA_OK;
+}
+int epa_timer_start(void* timer, epa_stream_t stream) {
+  EPA_CHECK_ARG(timer != nullptr, "epa_timer_start: timer is NULL");
+  EPA_CHECK_HIP(hipEventRecord(((EpaTimer*)timer)->start, (hipStream_t)stream));
+  return EPA_OK;
+}
+int epa_timer_stop(void* timer, epa_stream_t stream) {
+  EPA_CHECK_ARG(timer != nullptr, "epa_timer_stop: timer is NULL");
+  EPA_CHECK_HIP(hipEventRecord(((EpaTimer*)timer)->stop, (hipStream_t)stream));
+  return EPA_OK;
+}
+int epa_timer_elapsed_ms(void* timer, float* ms) {
+  EPA_CHECK_ARG(timer != nullptr && ms != nullptr, "epa_timer_elapsed_ms: NULL argument");
+  EpaTimer* t = (EpaTimer*)timer;
+  EPA_CHECK_HIP(hipEventSynchronize(t->stop));
+  EPA_CHECK_HIP(hipEventElapsedTime(ms, t->start, t->stop));
+  return EPA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// K1: fused power-sample calibration -- one HBM-coalesced pass replaces the ~15 whole-array
+// xarray temporaries of
+//   /root/reference/echopype/calibrate/range.py:98-201
+//   /root/reference/echopype/calibrate/calibrate_ek.py:104-110,154-184      (EK60 / EK80 power)
+//   /root/reference/echopype/calibrate/range.py:69-95 + calibrate_azfp.py:64-97  (AZFP)
+//
+// Layout: raw f32 (C,P,S) row-major; one coefficient row (64 B) per (c,p).  A workgroup of 256
+// threads owns one 1024-sample chunk of one row per iteration (each lane: one 16-B load of 4
+// samples, 32 B (f64) or 16 B (f32) of stores), grid-strides over (row, chunk).  The row constants
+// are wave-uniform -> scalar loads.  HBM-bound: 4 B in + 8 B (f64) out per sample (+8 B with
+// echo_range); MFMA is irrelevant here (no contraction).
+#include "sample_math.h"
+
+namespace {
+
+template <typename T, int VEC, bool RANGE>
+__global__ __launch_bounds__(epa::kBlock) void sv_power_kernel(const float* __restrict__ raw,
+                                                               const epa::CoefRow* __restrict__ coef,
+                                                               long long rows, int S, T nspread,
+                                                               unsigned flags, T* __restrict__ out,
+                                                               T* __restrict__ range_out) {
+  // blockIdx.y = range chunk (fixed for the life of the block, so that the lane's range column
+  // and its cached log10(s - d) never change); blockIdx.x strides over the (channel, ping) rows.
+  constexpr int kChunk = epa::kBlock * VEC;
+  const bool guard = flags & EPA_FLAG_GUARD_POS;
+  const bool mask_range = flags & EPA_FLAG_MASK_RANGE;
+  const int s0 = blockIdx.y * kChunk + threadIdx.x * VEC;
+  if (s0 >= S) return;
+  epa::ColumnLog<T, VEC> col;
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const epa::RowK<T> rk(coef[row]);
+    col.update(rk.d, s0, nspread);
+    const size_t off = (size_t)row * S + s0;
+    epa::RawVec<VEC> in;
+    in.load(raw + off);
+    T o[VEC], rg[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const double r = rk.range(s0 + j);
+      o[j] = epa::cal_power_sample<T>(in.v[j], s0 + j, rk, nspread, col.nL[j], guard, r);
+      if (RANGE) rg[j] = (mask_range && !(in.v[j] == in.v[j])) ? epa::M<T>::nan() : (T)r;
+    }
+    epa::store_vec<T, VEC>(out + off, o);
+    if (RANGE) epa::store_vec<T, VEC>(range_out + off, rg);
+  }
+}
+
+template <typename T>
+int launch(const float* raw, const double* coef, int C, int P, int S, int cal_type, unsigned flags,
+           void* out, void* range_out, hipStream_t st) {
+  const long long rows = (long long)C * P;
+  const T nspread = cal_type == EPA_CAL_SV ? (T)20 : (T)40;
+  auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+  const int vec = (S % 4 == 0 && al16(raw) && al16(out) && al16(range_out)) ? 4 : 1;
+  const int chunk = epa::kBlock * vec;
+  const int chunks_per_row = (S + chunk - 1) / chunk;
+  long long gx = 8192 / chunks_per_row;
+  if (gx < 1) gx = 1;
+  if (gx > rows) gx = rows;
+  const dim3 grid((unsigned)gx, (unsigned)chunks_per_row);
+  const epa::CoefRow* cf = reinterpret_cast<const epa::CoefRow*>(coef);
+#define EPA_LAUNCH(V, R)                                                                          \
+  hipLaunchKernelGGL((sv_power_kernel<T, V, R>), grid, dim3(epa::kBlock), 0, st, raw, cf, rows,   \
+                     S, nspread, flags, (T*)out, (T*)range_out)
+  if (vec == 4) {
+    if (range_out) EPA_LAUNCH(4, true); else EPA_LAUNCH(4, false);
+  } else {
+    if (range_out) EPA_LAUNCH(1, true); else EPA_LAUNCH(1, false);
+  }
+#undef EPA_LAUNCH
+  return epa::check_launch("sv_power_kernel");
+}
+
+}  // namespace
+
+extern "C" int epa_sv_power(const float* raw, const double* coef, int C, int P, int S, int cal_type,
+                            unsigned flags, void* out, void* range_out, int out_dtype,
+                            epa_stream_t stream) {
+  EPA_CHECK_ARG(raw && coef && out, "epa_sv_power: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_sv_power: C=%d P=%d S=%d must be positive", C, P, S);
+  EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_sv_power: bad cal_type %d",
+                cal_type);
+  if (out_dtype == EPA_F64)
+    return launch<double>(raw, coef, C, P, S, cal_type, flags, out, range_out, (hipStream_t)stream);
+  if (out_dtype == EPA_F32)
+    return launch<float>(raw, coef, C, P, S, cal_type, flags, out, range_out, (hipStream_t)stream);
+  epa::set_error("epa_sv_power: bad out_dtype %d", out_dtype);
+  return EPA_EINVAL;
+}

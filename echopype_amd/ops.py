@@ -1,0 +1,256 @@
+"""Tensor-level wrappers of the C ABI: device buffers are torch CUDA tensors (plumbing only --
+allocation, streams, RCCL), every computation is a call into libechopype_amd.so.
+
+All functions run on the tensors' device and torch's current stream and return torch tensors.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call
+
+_DT = {torch.float32: _lib.F32, torch.float64: _lib.F64}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError("echopype_amd kernels need device (HBM) buffers; got a CPU tensor")
+    if not t.is_contiguous():
+        raise ValueError("echopype_amd kernels need C-contiguous buffers")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def torch_dtype(dtype):
+    if isinstance(dtype, torch.dtype):
+        td = dtype
+    else:
+        td = {"float32": torch.float32, "float64": torch.float64}.get(np.dtype(dtype).name)
+    if td not in _DT:
+        raise ValueError(f"dtype must be float32 or float64, got {dtype!r}")
+    return td
+
+
+def to_device(a, dtype=None, device=None):
+    """numpy / torch -> contiguous CUDA tensor (PCIe copy if it lives on the host)."""
+    if isinstance(a, torch.Tensor):
+        t = a
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if not t.is_cuda:
+        t = t.to(dev, non_blocking=False)
+    return t.contiguous()
+
+
+def _mode_of(t, C, P):
+    n = t.numel()
+    if n == 1:
+        return _lib.PM_SCALAR
+    if n == C and t.dim() <= 1:
+        return _lib.PM_CHANNEL
+    if n == C * P:
+        return _lib.PM_CHANNEL_PING
+    raise ValueError(f"parameter of shape {tuple(t.shape)} is not scalar, (C,) or (C,P) with C={C}, P={P}")
+
+
+def power_coef_ek(sample_interval, tau_nominal, transmit_power, sound_speed, absorption, gain, sa,
+                  psi, f_nominal, tau_eff, *, sonar="EK60", cal_type="Sv", pulse_length=None,
+                  gain_is_table=False, sa_is_table=False, gpt=None):
+    """K0 -> coef (C, P, NCOEF) f64.  All inputs f64 CUDA tensors."""
+    C, P = sample_interval.shape
+    coef = torch.empty((C, P, _lib.NCOEF), dtype=torch.float64, device=sample_interval.device)
+    K = 0 if pulse_length is None else pulse_length.shape[1]
+    gmode = _lib.PM_PULSE_TABLE if gain_is_table else _mode_of(gain, C, P)
+    smode = _lib.PM_PULSE_TABLE if sa_is_table else _mode_of(sa, C, P)
+    call("epa_power_coef_ek", C, P, _p(sample_interval), _p(tau_nominal), _p(transmit_power),
+         _p(sound_speed), _mode_of(sound_speed, C, P), _p(absorption), _mode_of(absorption, C, P),
+         _p(gain), gmode, _p(sa), smode, _p(pulse_length), K, _p(psi), _p(f_nominal), _p(tau_eff),
+         _p(gpt), _lib.SONAR_EK60 if sonar in ("EK60", "ES70") else _lib.SONAR_EK80,
+         _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, _p(coef), _stream())
+    return coef
+
+
+def sv_power(raw, coef, *, cal_type="Sv", flags=_lib.FLAG_GUARD_POS | _lib.FLAG_MASK_RANGE,
+             dtype=torch.float64, want_range=True, out=None, range_out=None):
+    """K1 -> (Sv|TS, echo_range|None), both (C,P,S) of dtype."""
+    C, P, S = raw.shape
+    if raw.dtype != torch.float32:
+        raise ValueError("raw power samples must be float32 (convert/parse_base.py:302)")
+    if out is None:
+        out = torch.empty((C, P, S), dtype=dtype, device=raw.device)
+    if want_range and range_out is None:
+        range_out = torch.empty((C, P, S), dtype=dtype, device=raw.device)
+    call("epa_sv_power", _p(raw), _p(coef), C, P, S, _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS,
+         flags, _p(out), _p(range_out) if want_range else None, _DT[out.dtype], _stream())
+    return out, (range_out if want_range else None)
+
+
+def time_bin_offsets(ping_time_ns, t0, dt, n_bins, closed="left"):
+    """CSR offsets (n_bins+1,) int32 of sorted int64-ns ping times against uniform edges."""
+    P = ping_time_ns.numel()
+    out = torch.empty(n_bins + 1, dtype=torch.int32, device=ping_time_ns.device)
+    call("epa_time_bin_offsets", _p(ping_time_ns), P, int(t0), int(dt), int(n_bins),
+         _lib.BIN_CLOSED_RIGHT if closed == "right" else 0, _p(out), _stream())
+    return out
+
+
+def _bin_flags(skipna, closed):
+    return (_lib.BIN_SKIPNA if skipna else 0) | (_lib.BIN_CLOSED_RIGHT if closed == "right" else 0)
+
+
+def reduce_needs_workspace(C, n_tbins, n_rbins, dtype):
+    """Mirror of block_reduce.hip::make_plan: the two-stage path (few ping bins, or a range grid
+    too large for LDS) needs caller-provided sum/count workspaces."""
+    esz = 8 if dtype == torch.float64 else 4
+    lds = ((n_rbins * esz + 15) & ~15) + 4 * n_rbins
+    return C * n_tbins < 1024 or lds > 128 * 1024
+
+
+def sv_mvbs_fused(raw, coef, bin_start, n_tbins, range_bin, n_rbins, *, cal_type="Sv",
+                  cal_flags=_lib.FLAG_GUARD_POS | _lib.FLAG_MASK_RANGE, skipna=True, closed="left",
+                  fill_value=float("nan"), dtype=torch.float64, want_sv=True, want_range=False,
+                  want_partials=False, ping_perm=None, sv_out=None, range_out=None, mvbs_out=None):
+    """K1+K5 -> dict(Sv, echo_range, MVBS, sum, cnt)."""
+    C, P, S = raw.shape
+    dev = raw.device
+    if want_sv and sv_out is None:
+        sv_out = torch.empty((C, P, S), dtype=dtype, device=dev)
+    if want_range and range_out is None:
+        range_out = torch.empty((C, P, S), dtype=dtype, device=dev)
+    if mvbs_out is None:
+        mvbs_out = torch.empty((C, n_tbins, n_rbins), dtype=dtype, device=dev)
+    ssum = cnt = None
+    if want_partials or reduce_needs_workspace(C, n_tbins, n_rbins, dtype):
+        ssum = torch.empty((C, n_tbins, n_rbins), dtype=dtype, device=dev)
+        cnt = torch.empty((C, n_tbins, n_rbins), dtype=torch.int32, device=dev)
+    call("epa_sv_mvbs_fused", _p(raw), _p(coef), C, P, S,
+         _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, cal_flags, _p(bin_start), _p(ping_perm),
+         int(n_tbins), float(range_bin), int(n_rbins), _bin_flags(skipna, closed), float(fill_value),
+         _p(sv_out) if want_sv else None, _p(range_out) if want_range else None, _p(mvbs_out),
+         _p(ssum), _p(cnt), _DT[dtype], _stream())
+    return dict(Sv=sv_out if want_sv else None, echo_range=range_out if want_range else None,
+                MVBS=mvbs_out, sum=ssum, cnt=cnt)
+
+
+def mvbs(sv, bin_start, n_tbins, range_bin, n_rbins, *, range=None, coef=None, skipna=True,
+         closed="left", fill_value=float("nan"), want_partials=False, ping_perm=None):
+    """K5 on an existing Sv -> dict(MVBS, sum, cnt)."""
+    C, P, S = sv.shape
+    dev, dtype = sv.device, sv.dtype
+    if range is not None and range.dtype != dtype:
+        range = range.to(dtype)
+    out = torch.empty((C, n_tbins, n_rbins), dtype=dtype, device=dev)
+    ssum = cnt = None
+    if want_partials or reduce_needs_workspace(C, n_tbins, n_rbins, dtype):
+        ssum = torch.empty((C, n_tbins, n_rbins), dtype=dtype, device=dev)
+        cnt = torch.empty((C, n_tbins, n_rbins), dtype=torch.int32, device=dev)
+    call("epa_mvbs", _p(sv), _p(range), _p(coef), C, P, S, _p(bin_start), _p(ping_perm), int(n_tbins),
+         float(range_bin), int(n_rbins), _bin_flags(skipna, closed), float(fill_value), _p(out),
+         _p(ssum), _p(cnt), _DT[dtype], _stream())
+    return dict(MVBS=out, sum=ssum, cnt=cnt)
+
+
+def selftest_lin_from_db(u):
+    """10^(u/10) through the fused kernel's table-driven f64 routine (accuracy self-test)."""
+    out = torch.empty_like(u)
+    call("epa_selftest_lin_from_db", _p(u), _p(out), u.numel(), _stream())
+    return out
+
+
+def mvbs_finalize(ssum, cnt, fill_value=float("nan")):
+    out = torch.empty_like(ssum)
+    call("epa_mvbs_finalize", _p(ssum), _p(cnt), ssum.numel(), float(fill_value), _p(out),
+         _DT[ssum.dtype], _stream())
+    return out
+
+
+def mvbs_index(sv, ping_num, range_sample_num, range=None):
+    """K5' -> (MVBS (C,Pb,Sb), echo_range block-min or None)."""
+    C, P, S = sv.shape
+    Pb, Sb = -(-P // ping_num), -(-S // range_sample_num)
+    out = torch.empty((C, Pb, Sb), dtype=sv.dtype, device=sv.device)
+    rmin = None
+    if range is not None:
+        if range.dtype != sv.dtype:
+            range = range.to(sv.dtype)
+        rmin = torch.empty((C, Pb, Sb), dtype=sv.dtype, device=sv.device)
+    call("epa_mvbs_index", _p(sv), _p(range), C, P, S, int(ping_num), int(range_sample_num), _p(out),
+         _p(rmin), _DT[sv.dtype], _stream())
+    return out, rmin
+
+
+def noise_estimate(sv, alpha2, ping_num, range_sample_num, *, range=None, coef=None,
+                   noise_max=float("nan")):
+    """K6 -> noise (C, ceil(P/ping_num)) f64."""
+    C, P, S = sv.shape
+    if range is not None and range.dtype != sv.dtype:
+        range = range.to(sv.dtype)
+    out = torch.empty((C, -(-P // ping_num)), dtype=torch.float64, device=sv.device)
+    call("epa_noise_estimate", _p(sv), _p(range), _p(coef), _p(alpha2), C, P, S, int(ping_num),
+         int(range_sample_num), float(noise_max), _p(out), _DT[sv.dtype], _stream())
+    return out
+
+
+def noise_apply(sv, alpha2, noise, ping_num, snr_threshold, *, range=None, coef=None,
+                want_noise=True, want_corrected=True):
+    """K7 -> (Sv_noise, Sv_corrected)."""
+    C, P, S = sv.shape
+    if range is not None and range.dtype != sv.dtype:
+        range = range.to(sv.dtype)
+    sn = torch.empty_like(sv) if want_noise else None
+    sc = torch.empty_like(sv) if want_corrected else None
+    call("epa_noise_apply", _p(sv), _p(range), _p(coef), _p(alpha2), _p(noise), C, P, S, int(ping_num),
+         float(snr_threshold), _p(sn), _p(sc), _DT[sv.dtype], _stream())
+    return sn, sc
+
+
+def sv_complex(re, im, ccoef, *, replica=None, replica_off=None, max_taps=0, cal_type="Sv",
+               dtype=torch.float64, want_range=True, want_prx=False):
+    """K3+K4 -> dict(out, echo_range, prx)."""
+    C, P, S, B = re.shape
+    if re.dtype != im.dtype or re.dtype not in _DT:
+        raise ValueError("backscatter_r / backscatter_i must both be float32 or float64")
+    dev = re.device
+    out = torch.empty((C, P, S), dtype=dtype, device=dev)
+    rng = torch.empty((C, P, S), dtype=dtype, device=dev) if want_range else None
+    prx = torch.empty((C, P, S), dtype=dtype, device=dev) if want_prx else None
+    call("epa_sv_complex", _p(re), _p(im), _DT[re.dtype], _p(replica), _p(replica_off), int(max_taps),
+         _p(ccoef), C, P, S, B, _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, _p(out), _p(rng),
+         _p(prx), _DT[dtype], _stream())
+    return dict(out=out, echo_range=rng, prx=prx)
+
+
+class Timer:
+    """HIP-event timer on torch's current stream (epa_timer_*)."""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib.epa_timer_create(ctypes.byref(h)), "epa_timer_create")
+        self._h = h
+
+    def start(self):
+        call("epa_timer_start", self._h, _stream())
+
+    def stop(self):
+        call("epa_timer_stop", self._h, _stream())
+
+    def elapsed_ms(self):
+        ms = ctypes.c_float()
+        _lib.check(_lib.lib.epa_timer_elapsed_ms(self._h, ctypes.byref(ms)), "epa_timer_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            _lib.lib.epa_timer_destroy(self._h)
+        except Exception:
+            pass

@@ -1,0 +1,213 @@
+/* echopype_amd -- C ABI of the MI355X (gfx950) hot path of echopype
+ *
+ *   calibrate.compute_Sv / compute_TS  ->  clean.remove_background_noise  ->  commongrid.compute_MVBS
+ *
+ * The reference (OSOceanAcoustics/echopype, pure Python) has no FFI for this path; its boundary is
+ * a set of Python functions on xarray Datasets.  This header is the C-ABI those
+ * functions bind to in the drop-in (echopype_amd/, ctypes; see INTEGRATION.md for the stub a
+ * reference maintainer would add).  Each entry point cites the reference code it replaces
+ * (paths relative to /root/reference/echopype).
+ *
+ * Conventions
+ *   - every function returns an int status (EPA_OK = 0); epa_last_error() gives the message of the
+ *     last failure on the calling thread.  Nothing throws, nothing aborts.
+ *   - all array pointers are DEVICE pointers (HBM) unless the name ends in _host.  Arrays are
+ *     C-contiguous with the reference's dimension order (channel, ping_time, range_sample[, beam]).
+ *   - the library never allocates or frees result memory; the caller owns every buffer.  The only
+ *     allocations are the explicit epa_malloc/epa_free helpers offered to callers without a device
+ *     allocator of their own.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls are asynchronous
+ *     with respect to the host; they are re-entrant and keep no global mutable state.
+ *   - NaN in -> NaN out; numerical edge cases never raise (SURVEY.md 8b "Error conventions").
+ */
+#ifndef ECHOPYPE_AMD_H
+#define ECHOPYPE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EPA_VERSION 100 /* 0.1.0 */
+
+typedef void* epa_stream_t;
+
+enum epa_status { EPA_OK = 0, EPA_EINVAL = 1, EPA_EHIP = 2, EPA_ENOMEM = 3, EPA_EUNSUPPORTED = 4 };
+enum epa_dtype { EPA_F32 = 0, EPA_F64 = 1 };
+enum epa_cal_type { EPA_CAL_SV = 0, EPA_CAL_TS = 1 };
+enum epa_sonar { EPA_SONAR_EK60 = 0, EPA_SONAR_EK80 = 1 };
+/* how a per-ping parameter is laid out: one value, one per channel, one per (channel, ping),
+ * or (gain / sa_correction only) a per-channel pulse-length table to be looked up per ping */
+enum epa_param_mode { EPA_PM_SCALAR = 0, EPA_PM_CHANNEL = 1, EPA_PM_CHANNEL_PING = 2, EPA_PM_PULSE_TABLE = 3 };
+
+/* ---- per-(channel, ping) coefficient row consumed by the power-sample kernels ------------------
+ *   echo_range R(s) = fl(fl(s * ra) * rb) + r0     EK: ra = sample_interval, rb = sound_speed/2, r0 = 0
+ *                                                  -- the reference's own operation order
+ *                                                  (range.py:138), so echo_range is bit-identical and
+ *                                                  bin membership can never differ by a rounding;
+ *                                                  AZFP: ra = 1, rb = c/4*2N/f, r0 per range.py:81-89
+ *   R'(s)          = R(s) - shift                  TVG range shift (range.py:176-199)
+ *   out(s)         = g * raw(s) + n * log10(R') + alpha2 * R' + A           n = 20 (Sv) | 40 (TS)
+ * with the spreading term evaluated in its separable form: R' = k * (s - d), k = ra * rb,
+ * d = (shift - r0) / k, so n*log10(R') = n*log10(k) + n*log10(s - d).  d is (nearly always) the
+ * same for every ping of a file -- exactly 2 for EK60, tau/(2*sample_interval) for EK80, -r0/k for
+ * AZFP -- which lets the kernels evaluate log10(s - d) once per range column instead of once per
+ * sample.  Slot A0 = A + n * log10(k) (so a row is specific to Sv or TS).
+ */
+#define EPA_NCOEF 8
+enum epa_coef_slot { EPA_CF_RA = 0, EPA_CF_RB = 1, EPA_CF_R0 = 2, EPA_CF_SHIFT = 3, EPA_CF_ALPHA2 = 4,
+                     EPA_CF_A0 = 5, EPA_CF_G = 6, EPA_CF_D = 7 };
+
+/* flags of epa_sv_power / epa_sv_mvbs_fused */
+#define EPA_FLAG_GUARD_POS 1u  /* R' <= 0 -> NaN (calibrate_ek.py:107); AZFP has no such guard  */
+#define EPA_FLAG_MASK_RANGE 2u /* echo_range is NaN where the raw sample is NaN (range.py:143-148) */
+
+/* flags of the binned reductions */
+#define EPA_BIN_SKIPNA 1u       /* nanmean (skip NaN values) vs mean (NaN poisons the bin)            */
+#define EPA_BIN_CLOSED_RIGHT 2u /* intervals (a, b] instead of [a, b)  (commongrid/utils.py:283-302) */
+
+/* ---- runtime ------------------------------------------------------------------------------------ */
+int epa_version(void);
+const char* epa_last_error(void);
+int epa_device_count(int* n);
+int epa_set_device(int dev);
+int epa_device_name(int dev, char* buf, size_t len);
+int epa_malloc(void** ptr, size_t bytes);
+int epa_free(void* ptr);
+int epa_memset(void* ptr, int value, size_t bytes, epa_stream_t stream);
+int epa_memcpy_h2d(void* dst, const void* src_host, size_t bytes, epa_stream_t stream);
+int epa_memcpy_d2h(void* dst_host, const void* src, size_t bytes, epa_stream_t stream);
+int epa_stream_synchronize(epa_stream_t stream);
+/* HIP-event timing on `stream` (used by bench.py for the roofline figure): record start/stop
+ * around a region, then read the elapsed milliseconds.  Handles are opaque. */
+int epa_timer_create(void** timer);
+int epa_timer_destroy(void* timer);
+int epa_timer_start(void* timer, epa_stream_t stream);
+int epa_timer_stop(void* timer, epa_stream_t stream);
+int epa_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the stop event */
+
+/* ---- K0: coefficient table for EK60 / EK80 power samples ------------------------------------------
+ * Replaces the per-(channel, ping) arithmetic of
+ *   calibrate/range.py:138 (k = sample_interval*sound_speed/2), :176-199 (TVG shift),
+ *   calibrate/cal_params.py:261-324 (pulse-length table lookup of gain / sa_correction),
+ *   calibrate/calibrate_ek.py:98,154-162 (CSv) and :176-181 (CSp).
+ * sample_interval, tau_nominal, transmit_power: [C*P].  sound_speed / absorption / gain / sa:
+ * pointer + epa_param_mode.  With EPA_PM_PULSE_TABLE, `gain`/`sa` are [C*K] tables matched against
+ * pulse_length [C*K] by argmin_k |tau_nominal - pulse_length| (first minimum; NaN tau -> NaN).
+ * psi, f_nominal, tau_eff: [C].  gpt: [C] bytes or NULL (EK80: channels with GPT transceivers).
+ * coef out: [C*P*EPA_NCOEF].
+ */
+int epa_power_coef_ek(int C, int P, const double* sample_interval, const double* tau_nominal,
+                      const double* transmit_power, const double* sound_speed, int ss_mode,
+                      const double* absorption, int abs_mode, const double* gain, int gain_mode,
+                      const double* sa_correction, int sa_mode, const double* pulse_length, int K,
+                      const double* psi, const double* f_nominal, const double* tau_eff,
+                      const uint8_t* gpt, int sonar, int cal_type, double* coef, epa_stream_t stream);
+
+/* ---- K1: fused power-sample calibration (EK60, EK80 CW power, AZFP) ---------------------------------
+ * Replaces calibrate/range.py:98-201 + calibrate/calibrate_ek.py:104-110,154-184 (EK) and
+ * calibrate/range.py:69-95 + calibrate/calibrate_azfp.py:64-97 (AZFP): ~15 whole-array passes
+ * become one.  raw: f32 [C*P*S] (backscatter_r).  out: Sv or TS, [C*P*S] of out_dtype.
+ * range_out: echo_range [C*P*S] of out_dtype; may be NULL.
+ */
+int epa_sv_power(const float* raw, const double* coef, int C, int P, int S, int cal_type,
+                 unsigned flags, void* out, void* range_out, int out_dtype, epa_stream_t stream);
+
+/* ---- time-bin CSR for the binned reductions ----------------------------------------------------------
+ * Replaces the pandas-resample bin assignment of commongrid/api.py:118-128.  ping_time: int64 ns,
+ * sorted ascending, [P].  Bin b covers [t0 + b*dt, t0 + (b+1)*dt) (or (..] when closed right).
+ * bin_start out: int32 [n_bins + 1]; pings bin_start[b] .. bin_start[b+1]-1 belong to bin b.
+ */
+int epa_time_bin_offsets(const int64_t* ping_time, int P, int64_t t0, int64_t dt, int n_bins,
+                         unsigned flags, int32_t* bin_start, epa_stream_t stream);
+
+/* ---- K1+K5: fused compute_Sv -> compute_MVBS -----------------------------------------------------------
+ * One pass over the raw power: writes Sv (optional) and the MVBS grid.  Replaces K1's references
+ * plus commongrid/utils.py:592,614-627 (flox group-by nanmean in the linear domain) and :92.
+ *   bin_start  : int32 [n_tbins+1] (epa_time_bin_offsets);  ping_perm: int32 [.] or NULL (identity)
+ *   range bins : edges e_i = i * range_bin, i = 0..n_rbins (np.arange(0, max+bin, bin), api.py:115)
+ *   sv_out     : [C*P*S] of dtype or NULL;  range_out as in epa_sv_power or NULL
+ *   mvbs_out   : f64/f32 [C*n_tbins*n_rbins] in dB (fill_value where a bin is empty)
+ *   sum_out/cnt_out : optional raw linear sums (dtype) / counts (u32) per bin, same shape, for
+ *                 cross-shard merges; may be NULL
+ */
+int epa_sv_mvbs_fused(const float* raw, const double* coef, int C, int P, int S, int cal_type,
+                      unsigned cal_flags, const int32_t* bin_start, const int32_t* ping_perm,
+                      int n_tbins, double range_bin, int n_rbins, unsigned bin_flags,
+                      double fill_value, void* sv_out, void* range_out, void* mvbs_out,
+                      void* sum_out, uint32_t* cnt_out, int dtype, epa_stream_t stream);
+
+/* ---- K5: compute_MVBS on an existing Sv dataset -----------------------------------------------------------
+ * Replaces commongrid/utils.py:504-628 (+ :92).  sv: [C*P*S] of dtype.  Range coordinate either
+ * as a full array `range` ([C*P*S], f64 when dtype F64 else f32; echo_range or depth) or, when
+ * `range` is NULL, as the affine form of `coef` (R = r0 + s*k, valid everywhere).
+ */
+int epa_mvbs(const void* sv, const void* range, const double* coef, int C, int P, int S,
+             const int32_t* bin_start, const int32_t* ping_perm, int n_tbins, double range_bin,
+             int n_rbins, unsigned bin_flags, double fill_value, void* mvbs_out, void* sum_out,
+             uint32_t* cnt_out, int dtype, epa_stream_t stream);
+
+/* Self-test hook: out[i] = 10^(u[i]/10) evaluated with the table-driven f64 routine the fused kernel
+ * uses for the linear-domain average (_log2lin, utils/compute.py:14-27); u, out f64 [n]. */
+int epa_selftest_lin_from_db(const double* u, double* out, size_t n, epa_stream_t stream);
+
+/* Finalise merged partial sums: out = 10*log10(sum/cnt), fill_value where cnt == 0. */
+int epa_mvbs_finalize(const void* sum, const uint32_t* cnt, size_t n, double fill_value, void* out,
+                      int dtype, epa_stream_t stream);
+
+/* ---- K5': compute_MVBS_index_binning ------------------------------------------------------------------------
+ * Replaces commongrid/api.py:217-222 (coarsen(ping_num, range_sample_num, "pad").mean(skipna) in the
+ * linear domain) and :232-238 (echo_range block min).  Outputs [C * ceil(P/ping_num) *
+ * ceil(S/range_sample_num)].  range / range_min_out may be NULL.
+ */
+int epa_mvbs_index(const void* sv, const void* range, int C, int P, int S, int ping_num,
+                   int range_sample_num, void* mvbs_out, void* range_min_out, int dtype,
+                   epa_stream_t stream);
+
+/* ---- K6: background-noise estimate (De Robertis & Higginbottom 2007) -------------------------------------------
+ * Replaces clean/api.py:397-422: TL = 20log10(max(R,1) [NaN->1]) + 2*alpha*R; block mean of
+ * 10^((Sv-TL)/10) over ping_num x range_sample_num (NaN-padded, NaN-skipping) -> dB -> min over
+ * range blocks -> optional clamp to noise_max (NaN when noise_max is NaN = not given).
+ * alpha2: 2*alpha per (c,p) [C*P] f64.  noise_out: f64 [C * ceil(P/ping_num)].
+ */
+int epa_noise_estimate(const void* sv, const void* range, const double* coef, const double* alpha2,
+                       int C, int P, int S, int ping_num, int range_sample_num, double noise_max,
+                       double* noise_out, int dtype, epa_stream_t stream);
+
+/* ---- K7: noise removal -------------------------------------------------------------------------------------------
+ * Replaces clean/api.py:425-430 (ffill upsample + TL) and :485-487.  Writes Sv_noise and
+ * Sv_corrected ([C*P*S] of dtype; either may be NULL).  snr_threshold in dB.
+ */
+int epa_noise_apply(const void* sv, const void* range, const double* coef, const double* alpha2,
+                    const double* noise, int C, int P, int S, int ping_num, double snr_threshold,
+                    void* sv_noise_out, void* sv_corrected_out, int dtype, epa_stream_t stream);
+
+/* ---- K3+K4: EK80 complex samples (CW complex and BB pulse compression) ---------------------------------------------
+ * Replaces calibrate/ek80_complex.py:285-369 (compress_pulse: matched filter with the transmit
+ * replica per ping and sector), :372-391 (norm factor), calibrate_ek.py:483-490 (received power
+ * from the sector mean) and :571-638 (Sv / TS chain).
+ *   re, im   : backscatter_r / backscatter_i as stored by echopype: f64 (in_dtype F64) or f32,
+ *              [C*P*S*B], beam innermost, NaN-padded
+ *   replica  : float2-interleaved complex f32 [sum(taps)], conj NOT applied, per channel at
+ *              replica_off[c] .. replica_off[c+1] (int32 [C+1], device); both NULL for CW (no
+ *              pulse compression).  max_taps = longest replica (sizes the LDS tile).
+ *   ccoef    : per-(c,p) rows of EPA_NCCOEF doubles, see enum below.  PSCALE excludes the
+ *              1/||tx||^4 of the pulse-compression normalisation: the kernel computes ||tx||^2
+ *              itself (wavefront shuffle reduction over the LDS-resident replica)
+ *   out      : Sv/TS [C*P*S] of out_dtype; range_out, prx_out (same dtype) optional.
+ *              F64 output accumulates the matched filter in f64, F32 in f32
+ */
+#define EPA_NCCOEF 8
+enum epa_ccoef_slot { EPA_CC_K = 0, EPA_CC_SHIFT = 1, EPA_CC_ALPHA2 = 2, EPA_CC_A = 3, EPA_CC_PSCALE = 4,
+                      EPA_CC_RSV0 = 5, EPA_CC_RSV1 = 6, EPA_CC_RSV2 = 7 };
+int epa_sv_complex(const void* re, const void* im, int in_dtype, const float* replica,
+                   const int32_t* replica_off, int max_taps, const double* ccoef, int C, int P,
+                   int S, int B, int cal_type, void* out, void* range_out, void* prx_out,
+                   int out_dtype, epa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECHOPYPE_AMD_H */
