@@ -1,0 +1,17 @@
+"""echopype_amd -- MI355X (gfx950) native implementation of echopype's array-compute hot path
+
+    calibrate.compute_Sv / compute_TS -> clean.remove_background_noise -> commongrid.compute_MVBS
+
+behind echopype's own function signatures.  Host code is Python; the (channel, ping_time,
+range_sample) arrays go through a C ABI (include/echopype_amd.h, loaded with ctypes) to hand-written
+HIP kernels.  There is no CPU fallback: importing the package loads libechopype_amd.so and fails
+loudly if it has not been built (``python -m echopype_amd.build``).
+"""
+from . import _lib  # noqa: F401  (loads the HIP library; raises if missing)
+from . import calibrate, clean, commongrid, ops, synth, utils  # noqa: F401
+from .echodata import EchoData  # noqa: F401
+from .xr_lite import DataArray, Dataset, DeviceArray  # noqa: F401
+
+__version__ = "0.1.0"
+__all__ = ["calibrate", "clean", "commongrid", "utils", "ops", "synth", "EchoData", "Dataset", "DataArray",
+           "DeviceArray"]

@@ -24,7 +24,7 @@ PM_SCALAR, PM_CHANNEL, PM_CHANNEL_PING, PM_PULSE_TABLE = range(4)
 NCOEF = 8
 CF_RA, CF_RB, CF_R0, CF_SHIFT, CF_ALPHA2, CF_A0, CF_G, CF_D = range(8)
 NCCOEF = 8
-CC_K, CC_SHIFT, CC_ALPHA2, CC_A, CC_PSCALE = range(5)
+CC_RA, CC_RB, CC_SHIFT, CC_ALPHA2, CC_A, CC_PSCALE = range(6)
 FLAG_GUARD_POS, FLAG_MASK_RANGE = 1, 2
 BIN_SKIPNA, BIN_CLOSED_RIGHT = 1, 2
 
@@ -74,6 +74,7 @@ SIGNATURES = {
     "epa_mvbs": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _d, _i, _u, _d, _vp, _vp, _vp, _i, _vp],
     "epa_selftest_lin_from_db": [_vp, _vp, _sz, _vp],
     "epa_mvbs_finalize": [_vp, _vp, _sz, _d, _vp, _i, _vp],
+    "epa_nanminmax": [_vp, _sz, _i, _vp, _vp, _vp],
     "epa_mvbs_index": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "epa_noise_estimate": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _i, _vp],
     "epa_noise_apply": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _vp, _vp, _i, _vp],

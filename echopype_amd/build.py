@@ -18,7 +18,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libechopype_amd.so")
 OBJDIR = os.path.join(HERE, "csrc", "_obj")
 
-SOURCES = ["runtime.hip", "power_coef.hip", "sv_power.hip", "block_reduce.hip", "fused_sv_mvbs.hip", "noise_apply.hip",
+SOURCES = ["runtime.hip", "power_coef.hip", "sv_power.hip", "block_reduce.hip", "fused_sv_mvbs.hip", "noise_apply.hip", "reduce_util.hip",
            "ek80_complex.hip"]
 HEADERS = ["epa_internal.h", "sample_math.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",

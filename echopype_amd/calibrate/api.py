@@ -1,0 +1,102 @@
+"""Public calibration entry points with the reference's signatures
+(/root/reference/echopype/calibrate/api.py: CALIBRATOR :11-18, _compute_cal :23-246, compute_Sv
+:249-345, compute_TS :348-449).  Two extra keyword-only arguments: ``dtype`` ("float64" |
+"float32", the arithmetic and output type) and ``device`` (torch device; default current GPU).
+Outputs stay resident in HBM (``DeviceArray``) until ``.values`` is read.
+"""
+import logging
+
+import numpy as np
+
+from ..utils.prov import echopype_prov_attrs
+from .calibrate_azfp import CalibrateAZFP
+from .calibrate_ek import CalibrateEK60, CalibrateEK80
+
+logger = logging.getLogger("echopype_amd.calibrate")
+
+CALIBRATOR = {"EK60": CalibrateEK60, "EK80": CalibrateEK80, "AZFP": CalibrateAZFP, "ES70": CalibrateEK60,
+              "ES80": CalibrateEK80, "EA640": CalibrateEK80}
+
+
+def check_input_args_combination(waveform_mode, encode_mode, pulse_compression=None):
+    """echodata/simrad.py:12-51."""
+    if waveform_mode not in ["CW", "BB"]:
+        raise ValueError("The input waveform_mode must be either 'CW' or 'BB'!")
+    if encode_mode not in ["complex", "power"]:
+        raise ValueError("The input encode_mode must be either 'complex' or 'power'!")
+    if waveform_mode == "BB" and encode_mode == "power":
+        raise ValueError("Data from broadband ('BB') transmission must be recorded as complex samples")
+    if pulse_compression is not None:
+        if pulse_compression and (waveform_mode != "BB" or encode_mode != "complex"):
+            raise RuntimeError("Pulse compression can only be used with "
+                               "waveform_mode='BB' and encode_mode='complex'")
+
+
+def _compute_cal(cal_type, echodata, env_params=None, cal_params=None, ecs_file=None, waveform_mode=None,
+                 encode_mode=None, assume_single_filter_time=None, drop_last_hanning_zero=False,
+                 dtype="float64", device=None):
+    waveform_mode = "BB" if waveform_mode == "FM" else waveform_mode
+    if echodata.sonar_model == "EK80":
+        if waveform_mode is None or encode_mode is None:
+            raise ValueError("waveform_mode and encode_mode must be specified for EK80 calibration")
+        check_input_args_combination(waveform_mode=waveform_mode, encode_mode=encode_mode)
+    elif echodata.sonar_model in ("EK60", "AZFP"):
+        if waveform_mode is not None and waveform_mode != "CW":
+            logger.warning("This sonar model transmits only narrowband signals (waveform_mode='CW'). "
+                           "Calibration will be in CW mode")
+        if encode_mode is not None and encode_mode != "power":
+            logger.warning("This sonar model only record data as power or power/angle samples "
+                           "(encode_mode='power'). Calibration will be done on the power samples.")
+    if (echodata.sonar_model != "EK80" or encode_mode != "complex") and assume_single_filter_time is not None:
+        raise ValueError("assume_single_filter_time can only be used on complex EK80 data.")
+    if echodata.sonar_model not in CALIBRATOR:
+        raise ValueError(f"unsupported sonar_model {echodata.sonar_model!r}")
+
+    slice_dict = {}
+    if assume_single_filter_time:
+        slice_dict["first_valid_filter_time_per_channel"] = True
+    cal_obj = CALIBRATOR[echodata.sonar_model](
+        echodata, env_params=env_params, cal_params=cal_params, ecs_file=ecs_file,
+        waveform_mode=waveform_mode, encode_mode=encode_mode, slice_dict=slice_dict,
+        drop_last_hanning_zero=drop_last_hanning_zero, dtype=dtype, device=device)
+    cal_obj._check_echodata_backscatter_size()
+    cal_ds = cal_obj.compute_Sv() if cal_type == "Sv" else cal_obj.compute_TS()
+
+    # attributes (api.py:199-219)
+    cal_ds.coords["range_sample"].attrs = {"long_name": "Along-range sample number, base 0"}
+    cal_ds.data_vars["echo_range"].attrs = {"long_name": "Range distance", "units": "m"}
+    cal_ds.data_vars[cal_type].attrs = {
+        "long_name": {"Sv": "Volume backscattering strength (Sv re 1 m-1)",
+                      "TS": "Target strength (TS re 1 m^2)"}[cal_type],
+        "units": "dB",
+    }
+    if echodata.sonar_model == "EK80":
+        cal_ds.data_vars[cal_type].attrs.update({"waveform_mode": waveform_mode, "encode_mode": encode_mode})
+    # provenance (api.py:221-240)
+    if echodata.source_file is not None:
+        source_file = echodata.source_file
+    elif echodata.converted_raw_path is not None:
+        source_file = echodata.converted_raw_path
+    else:
+        source_file = "SOURCE FILE NOT IDENTIFIED"
+    prov = echopype_prov_attrs(process_type="processing")
+    prov["processing_function"] = f"calibrate.compute_{cal_type}"
+    files = [source_file] if isinstance(source_file, str) else list(source_file)
+    cal_ds["source_filenames"] = (("filenames",), np.asarray([str(f) for f in files]),
+                                  {"long_name": "Source filenames"})
+    cal_ds = cal_ds.assign_attrs(prov)
+    if "water_level" in echodata["Platform"].data_vars:
+        cal_ds["water_level"] = echodata["Platform"]["water_level"]
+    return cal_ds
+
+
+def compute_Sv(echodata, **kwargs):
+    """Volume backscattering strength Sv.  Same arguments as the reference (api.py:249-345):
+    env_params, cal_params, ecs_file, waveform_mode, encode_mode, assume_single_filter_time,
+    drop_last_hanning_zero (+ dtype, device)."""
+    return _compute_cal(cal_type="Sv", echodata=echodata, **kwargs)
+
+
+def compute_TS(echodata, **kwargs):
+    """Target strength TS (api.py:348-449)."""
+    return _compute_cal(cal_type="TS", echodata=echodata, **kwargs)

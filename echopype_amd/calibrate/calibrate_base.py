@@ -1,0 +1,122 @@
+"""Shared plumbing of the calibrators (mirrors calibrate/calibrate_base.py:10-128)."""
+import abc
+import logging
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..xr_lite import DataArray, DeviceArray
+
+logger = logging.getLogger("echopype_amd.calibrate")
+
+ECHO_DIMS = ("channel", "ping_time", "range_sample")
+
+
+def cp_array(v, C, P, name="parameter"):
+    """scalar / (C,) / (P,) / (C,P) [DataArray or array-like] -> contiguous float64 (C, P)."""
+    dims = v.dims if isinstance(v, DataArray) else None
+    a = np.asarray(getattr(v, "values", v), dtype=np.float64)
+    if a.ndim == 0:
+        return np.full((C, P), float(a))
+    if a.ndim == 1:
+        if dims == ("ping_time",) or (dims is None and a.shape[0] == P and P != C):
+            return np.ascontiguousarray(np.broadcast_to(a[None, :], (C, P)))
+        if a.shape[0] == C:
+            return np.ascontiguousarray(np.broadcast_to(a[:, None], (C, P)))
+    if a.ndim == 2:
+        if dims == ("ping_time", "channel"):
+            a = a.T
+        if a.shape == (C, P):
+            return np.ascontiguousarray(a)
+        if a.shape == (C, 1):
+            return np.ascontiguousarray(np.broadcast_to(a, (C, P)))
+    raise ValueError(f"{name} of shape {a.shape} cannot be broadcast to (channel={C}, ping_time={P})")
+
+
+class CalibrateBase(abc.ABC):
+    """Common constructor semantics: an ECS file overrides the user dictionaries
+    (calibrate_base.py:20-47); ECS parsing itself is out of scope."""
+
+    def __init__(self, echodata, env_params=None, cal_params=None, ecs_file=None, **kwargs):
+        self.echodata = echodata
+        self.sonar_type = None
+        self.ecs_file = ecs_file
+        self.ecs_dict = {}
+        if self.ecs_file is not None:
+            raise NotImplementedError(
+                "ecs_file: Echoview .ecs parsing (calibrate/ecs.py) is outside the accelerated hot "
+                "path; pass the parameters through env_params / cal_params instead.")
+        self.env_params = {} if env_params is None else env_params
+        self.cal_params = {} if cal_params is None else cal_params
+        self.range_meter = None
+        self.dtype = ops.torch_dtype(kwargs.get("dtype", "float64"))
+        self.device = kwargs.get("device")
+
+    @abc.abstractmethod
+    def compute_echo_range(self, **kwargs):
+        pass
+
+    @abc.abstractmethod
+    def _cal_power_samples(self, cal_type, **kwargs):
+        pass
+
+    @abc.abstractmethod
+    def compute_Sv(self, **kwargs):
+        pass
+
+    @abc.abstractmethod
+    def compute_TS(self, **kwargs):
+        pass
+
+    def _add_params_to_output(self, ds_out):
+        """Every env and cal parameter rides along in the output (calibrate_base.py:83-93)."""
+        for group in (self.env_params, self.cal_params):
+            for key, val in group.items():
+                if val is None:
+                    continue
+                if isinstance(val, DataArray):
+                    ds_out[key] = DataArray(val.data, val.dims, attrs=val.attrs, name=key)
+                elif isinstance(val, str):
+                    ds_out[key] = np.asarray(val)
+                else:
+                    a = np.asarray(val)
+                    C = ds_out.sizes.get("channel")
+                    P = ds_out.sizes.get("ping_time")
+                    if a.ndim == 0:
+                        ds_out[key] = a
+                    elif a.ndim == 1 and a.shape[0] == C:
+                        ds_out[key] = (("channel",), a)
+                    elif a.ndim == 1 and a.shape[0] == P:
+                        ds_out[key] = (("ping_time",), a)
+                    elif a.ndim == 2:
+                        ds_out[key] = (("channel", "ping_time"), a)
+        return ds_out
+
+    def _check_echodata_backscatter_size(self):
+        """> 2 GiB warning, text as calibrate_base.py:116-128 (asserted verbatim by the reference's
+        tests/calibrate/test_calibrate.py:432-441)."""
+        beam = self.echodata[getattr(self, "ed_beam_group", None) or "Sonar/Beam_group1"]
+        total = beam["backscatter_r"].nbytes
+        if "backscatter_i" in beam and getattr(self, "encode_mode", "power") == "complex":
+            total += beam["backscatter_i"].nbytes
+        if total / (1024 ** 3) > 2.0:
+            logger.warning(
+                "The Echodata backscatter variables are large and can cause memory issues. "
+                "Consider modifying the workflow that uses compute_Sv as below: "
+                "Prior to `compute_Sv` run `echodata.chunk(CHUNK_DICTIONARY) "
+                "and after `compute_Sv` run `ds_Sv.to_zarr(ZARR_STORE, compute=True)`. "
+                "This will ensure that the computation is lazily evaluated, "
+                "with the results stored directly in a Zarr store on disk, rather then in memory."
+            )
+
+    # ---- device helpers -------------------------------------------------------------------------
+    def _dev(self, a, dtype=None):
+        if isinstance(a, DeviceArray):
+            t = a.tensor
+            return t if dtype is None or t.dtype == dtype else t.to(dtype)
+        return ops.to_device(np.asarray(getattr(a, "values", a)), dtype=dtype, device=self.device)
+
+    @staticmethod
+    def _wrap(t, dims, attrs=None, name=None):
+        return DataArray(DeviceArray(t), dims, attrs=attrs, name=name)

@@ -1,0 +1,281 @@
+"""EK60 / EK80 calibrators: host-side parameter assembly, GPU sample passes.
+
+Mirrors /root/reference/echopype/calibrate/calibrate_ek.py (CalibrateEK :56-206, CalibrateEK60
+:209-265, CalibrateEK80 :268-710).  The constructors do what the reference's do (beam-group
+selection, env then cal params) -- that is O(C*P) host work.  The O(C*P*S) part of
+``_cal_power_samples`` / ``_cal_complex_samples`` is ONE kernel launch through the C ABI:
+epa_power_coef_ek + epa_sv_power, or epa_sv_complex (matched filter + power + Sv/TS).
+"""
+import logging
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from ..echodata import BEAM1
+from ..xr_lite import DataArray, Dataset
+from .cal_params import get_cal_params_EK
+from .calibrate_base import ECHO_DIMS, CalibrateBase, cp_array
+from .ek80_complex import get_filter_coeff, get_tau_effective, get_transmit_signal
+from .env_params import get_env_params_EK
+
+logger = logging.getLogger("echopype_amd.calibrate")
+
+
+def retrieve_correct_beam_group(echodata, waveform_mode, encode_mode):
+    """Beam group for the requested modes, with the reference's checks (echodata/simrad.py:54-179)."""
+    if echodata.sonar_model in ("EK60", "ES70"):
+        if waveform_mode != "CW":
+            raise RuntimeError("Incorrect waveform_mode input provided!")
+        if encode_mode != "power":
+            raise RuntimeError("Incorrect encode_mode input provided!")
+        if "backscatter_i" in echodata[BEAM1].variables:
+            raise RuntimeError("Provided echodata object does not correspond to an EK60-like "
+                               "sensor, but is labeled as data from an EK60-like sensor!")
+        return BEAM1
+    if echodata.sonar_model in ("EK80", "ES80", "EA640"):
+        if "waveform_encode_descr" not in echodata["Sonar"]:
+            raise ValueError("Echodata missing `waveform_encode_descr`. "
+                             "Reconvert using the latest Echopype version.")
+        descr = np.asarray(echodata["Sonar"]["waveform_encode_descr"].values).astype(str)
+        match = "power" if encode_mode == "power" else ("complex_CW" if waveform_mode == "CW" else "complex_FM")
+        idx = np.flatnonzero(descr == match)
+        if idx.size == 0:
+            raise RuntimeError(f"No beam group with the specified encode_mode {encode_mode} "
+                               f"and waveform_mode {waveform_mode} found in the provided echodata!")
+        return f"Sonar/Beam_group{int(idx[0]) + 1}"
+    raise RuntimeError("EchoData was produced by a non-Simrad or unknown Simrad echo sounder!")
+
+
+class CalibrateEK(CalibrateBase):
+    def __init__(self, echodata, env_params, cal_params, ecs_file, **kwargs):
+        super().__init__(echodata, env_params, cal_params, ecs_file, **kwargs)
+        self.ed_beam_group = None
+        self.slice_dict = {}
+        self.beam = None
+        self.vend = None
+        self._range_dev = None
+
+    # -- shared per-(channel, ping) inputs ---------------------------------------------------------
+    def _shape(self):
+        sz = self.beam["backscatter_r"].shape
+        return sz[0], sz[1], sz[2]
+
+    def _cp(self, v, name):
+        C, P, _ = self._shape()
+        return cp_array(v, C, P, name)
+
+    def _gpt_mask(self):
+        C = self._shape()[0]
+        if self.sonar_type == "EK60":
+            return np.ones(C, dtype=bool)
+        if "transceiver_type" in self.vend:
+            return np.asarray(self.vend["transceiver_type"].values).astype(str) == "GPT"
+        return np.zeros(C, dtype=bool)
+
+    def compute_echo_range(self):
+        """echo_range (range.py:98-157) is produced by the same kernel pass as Sv/TS; it is
+        materialised here only if asked for before calibration."""
+        self.range_meter = None
+
+    def _tau_effective(self, flag_complex):
+        """Effective pulse length per channel (calibrate_ek.py:113-151 / :583-607)."""
+        tau_nom0 = np.asarray(self._cp(self.beam["transmit_duration_nominal"], "transmit_duration_nominal"))[:, 0]
+        try:
+            coeff = get_filter_coeff(self.vend)
+            fs = self.cal_params["receiver_sampling_frequency"]  # KeyError for EK60 -> fallback
+            tx, tx_time = get_transmit_signal(self.beam, coeff, self.waveform_mode, fs,
+                                              getattr(self, "drop_last_hanning_zero", False))
+            te = get_tau_effective(tx, {k: 1 / np.diff(v[:2]) for k, v in tx_time.items()},
+                                   self.waveform_mode, self.beam["channel"]).values.copy()
+        except Exception as e:  # noqa: BLE001 - same catch-all as the reference
+            mode = "complex" if flag_complex else "power"
+            logger.warning("Could not compute tau_effective from transmit signal in %s encoding mode; "
+                           "falling back to transmit_duration_nominal. Error: %s", mode, repr(e))
+            te, tx = tau_nom0.copy(), None
+        gpt = self._gpt_mask()
+        te[gpt] = tau_nom0[gpt]
+        return te, tx
+
+    def _finish(self, cal_type, out_t, range_t, tau_eff):
+        C, P, S = self._shape()
+        ds = Dataset(coords={k: self.beam.coords[k] for k in ECHO_DIMS})
+        ds[cal_type] = self._wrap(out_t, ECHO_DIMS)
+        ds["echo_range"] = self._wrap(range_t, ECHO_DIMS)
+        self.range_meter = ds["echo_range"]
+        if cal_type == "Sv":
+            ds["tau_effective"] = DataArray(tau_eff, ("channel",), attrs=dict(
+                long_name="Effective pulse length", units="s",
+                description="Effective pulse length used for Sv. GPT uses transmit_duration_nominal."))
+        ds["frequency_nominal"] = self.beam["frequency_nominal"]
+        return self._add_params_to_output(ds)
+
+    def _cal_power_samples(self, cal_type):
+        """One fused pass for calibrate_ek.py:79-206."""
+        C, P, S = self._shape()
+        f64 = torch.float64
+        tau_eff, _ = self._tau_effective(False) if cal_type == "Sv" else (np.ones(C), None)
+        gpt = self._gpt_mask()
+        psi = np.asarray(self.cal_params["equivalent_beam_angle"].values, dtype=np.float64)
+        if psi.ndim > 1:
+            psi = psi.reshape(C, -1)[:, 0]
+        coef = ops.power_coef_ek(
+            self._dev(self._cp(self.beam["sample_interval"], "sample_interval"), f64),
+            self._dev(self._cp(self.beam["transmit_duration_nominal"], "transmit_duration_nominal"), f64),
+            self._dev(self._cp(self.beam["transmit_power"], "transmit_power"), f64),
+            self._dev(self._cp(self.env_params["sound_speed"], "sound_speed"), f64),
+            self._dev(self._cp(self.env_params["sound_absorption"], "sound_absorption"), f64),
+            self._dev(self._cp(self.cal_params["gain_correction"], "gain_correction"), f64),
+            self._dev(self._cp(self.cal_params["sa_correction"], "sa_correction"), f64),
+            self._dev(psi, f64), self._dev(np.asarray(self.beam["frequency_nominal"].values, float), f64),
+            self._dev(np.asarray(tau_eff, float), f64),
+            sonar=self.sonar_type, cal_type=cal_type,
+            gpt=self._dev(gpt.astype(np.uint8)) if self.sonar_type == "EK80" else None)
+        raw = self._dev(self.beam["backscatter_r"].data, torch.float32)
+        out_t, range_t = ops.sv_power(raw, coef, cal_type=cal_type, dtype=self.dtype)
+        return self._finish(cal_type, out_t, range_t, tau_eff)
+
+
+class CalibrateEK60(CalibrateEK):
+    def __init__(self, echodata, env_params, cal_params, ecs_file, **kwargs):
+        super().__init__(echodata, env_params, cal_params, ecs_file, **kwargs)
+        self.sonar_type = "EK60"
+        self.waveform_mode = "CW"
+        self.encode_mode = "power"
+        self.ed_beam_group = retrieve_correct_beam_group(self.echodata, self.waveform_mode, self.encode_mode)
+        self.beam = self.echodata[self.ed_beam_group]
+        self.vend = self.echodata["Vendor_specific"]
+        self.env_params = get_env_params_EK("EK60", self.beam, self.echodata["Environment"], self.env_params)
+        self.cal_params = get_cal_params_EK("CW", self.beam["frequency_nominal"], self.beam, self.vend,
+                                            self.cal_params, sonar_type="EK60")
+        self.compute_echo_range()
+
+    def compute_Sv(self, **kwargs):
+        return self._cal_power_samples("Sv")
+
+    def compute_TS(self, **kwargs):
+        return self._cal_power_samples("TS")
+
+
+class CalibrateEK80(CalibrateEK):
+    EK80_params = {"z_et": 75, "z_er": 1000}
+
+    def __init__(self, echodata, env_params, cal_params, waveform_mode, encode_mode, ecs_file=None,
+                 slice_dict=None, drop_last_hanning_zero=False, **kwargs):
+        super().__init__(echodata, env_params, cal_params, ecs_file, **kwargs)
+        self.sonar_type = "EK80"
+        self.waveform_mode = waveform_mode
+        self.encode_mode = encode_mode
+        self.slice_dict = slice_dict or {}
+        self.drop_last_hanning_zero = drop_last_hanning_zero
+        self.ed_beam_group = retrieve_correct_beam_group(self.echodata, waveform_mode, encode_mode)
+        self.beam = self.echodata[self.ed_beam_group]
+        self.vend = self.echodata["Vendor_specific"]
+        if "filter_time" in self.vend.sizes:
+            if self.vend.sizes["filter_time"] > 1 and "first_valid_filter_time_per_channel" not in self.slice_dict:
+                raise NotImplementedError(
+                    "Vendor_specific holds several filter_time entries: pass "
+                    "assume_single_filter_time=True, or calibrate each filter interval separately "
+                    "(the reference's slice-and-merge orchestration, calibrate/api.py:98-197, is host-side "
+                    "glue that is not part of the accelerated path yet).")
+            self.vend = self.vend.isel(filter_time=0)
+        C, P = self.beam["backscatter_r"].shape[:2]
+        if waveform_mode == "BB":
+            f0 = cp_array(self.beam["transmit_frequency_start"], C, P)
+            f1 = cp_array(self.beam["transmit_frequency_stop"], C, P)
+            self.freq_center = DataArray((f0 + f1) / 2, ("channel", "ping_time"))  # :336-340
+        else:
+            self.freq_center = self.beam["frequency_nominal"]
+        self.env_params = get_env_params_EK("EK80", self.beam, self.echodata["Environment"], self.env_params,
+                                            freq=self.freq_center)
+        self.cal_params = get_cal_params_EK(waveform_mode, self.freq_center, self.beam, self.vend,
+                                            self.cal_params, sonar_type="EK80")
+        self.compute_echo_range()
+
+    def _shape(self):
+        sz = self.beam["backscatter_r"].shape
+        return sz[0], sz[1], sz[2]
+
+    def _get_B_theta_phi_m(self):
+        """Transceiver gain compensation for BB mode (calibrate_ek.py:507-530)."""
+        cp = self.cal_params
+        with np.errstate(invalid="ignore", divide="ignore"):
+            fa = (np.abs(-self._cp(cp["angle_offset_alongship"], "angle_offset_alongship"))
+                  / (self._cp(cp["beamwidth_alongship"], "beamwidth_alongship") / 2)) ** 2
+            ft = (np.abs(-self._cp(cp["angle_offset_athwartship"], "angle_offset_athwartship"))
+                  / (self._cp(cp["beamwidth_athwartship"], "beamwidth_athwartship") / 2)) ** 2
+            B = 0.5 * 6.0206 * (fa + ft - 0.18 * fa * ft)
+        return np.where(np.isnan(B), 0.0, B)
+
+    def _cal_complex_samples(self, cal_type):
+        """One fused pass for calibrate_ek.py:532-659 (+ ek80_complex.py:285-391 for BB)."""
+        C, P, S = self._shape()
+        B = self.beam["backscatter_r"].shape[3]
+        bb = self.waveform_mode == "BB"
+        tau_eff, tx = self._tau_effective(True)
+        if tx is None:
+            coeff = get_filter_coeff(self.vend)
+            tx, _ = get_transmit_signal(self.beam, coeff, self.waveform_mode,
+                                        self.cal_params["receiver_sampling_frequency"],
+                                        self.drop_last_hanning_zero)
+        z_er = self._cp(self.cal_params["impedance_transceiver"], "impedance_transceiver")
+        z_et = self._cp(self.cal_params["impedance_transducer"], "impedance_transducer")
+        gain = self._cp(self.cal_params["gain_correction"], "gain_correction")
+        if bb:
+            gain = gain - self._get_B_theta_phi_m()
+        cw = self._cp(self.env_params["sound_speed"], "sound_speed")
+        alpha = self._cp(self.env_params["sound_absorption"], "sound_absorption")
+        si = self._cp(self.beam["sample_interval"], "sample_interval")
+        tau = self._cp(self.beam["transmit_duration_nominal"], "transmit_duration_nominal")
+        pt = self._cp(self.beam["transmit_power"], "transmit_power")
+        fc = self._cp(self.freq_center, "freq_center")
+        psi = self._cp(self.cal_params["equivalent_beam_angle"], "equivalent_beam_angle")
+        sa = self._cp(self.cal_params["sa_correction"], "sa_correction")
+        gpt = self._gpt_mask()
+        wavelength = cw / fc
+        shift = cw * tau / 4
+        shift[gpt] += (2 * si * cw / 2)[gpt]                      # range.py:180-199
+        with np.errstate(invalid="ignore", divide="ignore"):
+            if cal_type == "Sv":
+                A = (-10 * np.log10(wavelength ** 2 * pt * cw / (32 * np.pi ** 2)) - 2 * gain
+                     - 10 * np.log10(tau_eff)[:, None] - psi)
+                if not bb:
+                    A = A - 2 * sa
+            else:
+                A = -10 * np.log10(wavelength ** 2 * pt / (16 * np.pi ** 2)) - 2 * gain
+        # prx = B * |mean|^2 / (2 sqrt 2)^2 * (|z_er + z_et| / z_er)^2 / z_et   (:483-490)
+        pscale = B / (2 * np.sqrt(2)) ** 2 * (np.abs(z_er + z_et) / z_er) ** 2 / z_et
+        cc = np.zeros((C, P, _lib.NCCOEF))
+        cc[..., _lib.CC_RA] = si
+        cc[..., _lib.CC_RB] = cw / 2
+        cc[..., _lib.CC_SHIFT] = shift
+        cc[..., _lib.CC_ALPHA2] = 2 * alpha
+        cc[..., _lib.CC_A] = A
+        cc[..., _lib.CC_PSCALE] = pscale
+        rep = off = None
+        max_taps = 0
+        if bb:
+            chans = list(self.beam["channel"].values)
+            taps = [np.asarray(tx[ch]) for ch in chans]
+            off_h = np.concatenate([[0], np.cumsum([t.size for t in taps])]).astype(np.int32)
+            flat = np.concatenate(taps).astype(np.complex64)
+            rep = self._dev(np.ascontiguousarray(flat.view(np.float32)))
+            off = self._dev(off_h)
+            max_taps = int(max(t.size for t in taps))
+        re = self._dev(self.beam["backscatter_r"].data)
+        im = self._dev(self.beam["backscatter_i"].data)
+        if re.dtype not in (torch.float32, torch.float64):
+            re, im = re.double(), im.double()
+        res = ops.sv_complex(re, im, self._dev(cc, torch.float64), replica=rep, replica_off=off,
+                             max_taps=max_taps, cal_type=cal_type, dtype=self.dtype)
+        return self._finish(cal_type, res["out"], res["echo_range"], tau_eff)
+
+    def _compute_cal(self, cal_type):
+        flag_complex = self.waveform_mode == "BB" or self.encode_mode == "complex"
+        return self._cal_complex_samples(cal_type) if flag_complex else self._cal_power_samples(cal_type)
+
+    def compute_Sv(self):
+        return self._compute_cal("Sv")
+
+    def compute_TS(self):
+        return self._compute_cal("TS")

@@ -1,0 +1,172 @@
+"""compute_MVBS / compute_MVBS_index_binning with the reference's signatures
+(/root/reference/echopype/commongrid/api.py:30-191, :194-266).  Validation, bin edges, coordinates
+and attributes are host Python (O(P)); the (channel, ping_time, range_sample) reduction is one HIP
+kernel launch through the C ABI (epa_mvbs / epa_mvbs_index).  ``method``, ``reindex`` and
+``**flox_kwargs`` are accepted for signature compatibility (flox is not involved).
+"""
+import logging
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..utils.prov import echopype_prov_attrs, insert_processing_level
+from ..xr_lite import DataArray, Dataset, DeviceArray, from_xarray
+from .utils import (_parse_x_bin, _set_MVBS_attrs, _setup_and_validate, ping_time_bin_parsing_and_conversion,
+                    resample_edges)
+
+logger = logging.getLogger("echopype_amd.commongrid")
+
+_AGG_MSG = ("Aggregation may be negatively impacted since Flox will not aggregate any "
+            "```Sv``` values that have corresponding NaN coordinate values. Consider handling "
+            "these values before calling your intended commongrid function.")
+
+
+def _dev(a, dtype=None):
+    data = a.data if isinstance(a, DataArray) else a
+    if isinstance(data, DeviceArray):
+        t = data.tensor
+        return t if dtype is None or t.dtype == dtype else t.to(dtype)
+    return ops.to_device(np.asarray(data), dtype=dtype)
+
+
+def _full(da, ds, order):
+    """Broadcast a variable to the (dim_0, ping_time, range_sample) cube if it is lower-dimensional."""
+    if tuple(da.dims) == tuple(order):
+        return da
+    a = np.asarray(da.values)
+    shape = [ds.sizes[d] for d in order]
+    idx = [slice(None) if d in da.dims else None for d in order]
+    src = np.transpose(a, [da.dims.index(d) for d in order if d in da.dims])
+    return DataArray(np.ascontiguousarray(np.broadcast_to(src[tuple(idx)], shape)), order)
+
+
+def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="20s", method="map-reduce",
+                 reindex=False, skipna=True, fill_value=np.nan, closed="left", range_var_max=None,
+                 **flox_kwargs):
+    """Mean volume backscattering strength on a (ping_time, range) grid in physical units."""
+    if method != "map-reduce" and reindex is not None:
+        raise ValueError(f"Passing in reindex={reindex} is only allowed when method='map_reduce'.")
+    ds_Sv = from_xarray(ds_Sv)
+    ds_Sv, range_bin_m = _setup_and_validate(ds_Sv, range_var, range_bin, closed)
+    if not isinstance(ping_time_bin, str):
+        raise TypeError("ping_time_bin must be a string")
+
+    sv_da = ds_Sv["Sv"]
+    order = tuple(sv_da.dims)
+    dim_0 = order[0]
+    sv_t = _dev(sv_da)
+    if sv_t.dtype not in (torch.float32, torch.float64):
+        sv_t = sv_t.double()
+    rg_t = _dev(_full(ds_Sv[range_var], ds_Sv, order), sv_t.dtype)
+    C, P, S = sv_t.shape
+
+    # range edges: np.arange(0, max + bin, bin)  (api.py:108-115)
+    lo, hi = ops.nanminmax(rg_t)
+    if range_var_max is None:
+        rmax = hi
+    else:
+        rmax = _parse_x_bin(range_var_max) + 1e-8
+    r_edges = np.arange(0, rmax + range_bin_m, range_bin_m)
+    n_r = len(r_edges) - 1
+    if n_r < 1:
+        raise ValueError("range bins are empty: the range variable holds no valid values")
+
+    # NaN coordinates are not aggregated (utils.py:595-608: same warning text)
+    ping_time = np.asarray(ds_Sv["ping_time"].values).astype("datetime64[ns]")
+    if np.isnat(ping_time).any():
+        logging.warning(f"The ```ping_time``` coordinate array contain NaNs. {_AGG_MSG}")
+    if bool(torch.isnan(rg_t).any()):
+        logging.warning(f"The ```{range_var}``` coordinate array contain NaNs. {_AGG_MSG}")
+
+    # ping bins: pandas-resample edges, anchored at midnight (api.py:118-128)
+    e0, dt, n_t = resample_edges(ping_time, ping_time_bin)
+    ns = ping_time.astype(np.int64)
+    perm = None
+    if np.any(np.diff(ns) < 0):  # unsorted pings: sort once on the host, kernels follow the permutation
+        order_idx = np.argsort(ns, kind="stable")
+        perm = ops.to_device(order_idx.astype(np.int32))
+        ns = ns[order_idx]
+    bin_start = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t, closed=closed)
+
+    res = ops.mvbs(sv_t, bin_start, n_t, range_bin_m, n_r, range=rg_t, skipna=skipna, closed=closed,
+                   fill_value=fill_value, ping_perm=perm)
+
+    t_left = (e0 + dt * np.arange(n_t)).astype("datetime64[ns]")
+    ds_MVBS = Dataset(coords={"ping_time": t_left, dim_0: ds_Sv[dim_0].values, range_var: r_edges[:-1]})
+    ds_MVBS["Sv"] = DataArray(DeviceArray(res["MVBS"]), (dim_0, "ping_time", range_var))
+
+    # positions: per-bin nanmean of latitude / longitude (utils.py:453-501); O(P) on the host
+    if "latitude" in ds_Sv and "longitude" in ds_Sv:
+        tb = np.floor_divide(ping_time.astype(np.int64) - e0, dt)
+        if closed == "right":
+            tb = -np.floor_divide(-(ping_time.astype(np.int64) - e0), dt) - 1
+        ok = (tb >= 0) & (tb < n_t) & ~np.isnat(ping_time)
+        for var in ("latitude", "longitude"):
+            v = np.asarray(ds_Sv[var].values, dtype=np.float64)
+            use = ok & ~np.isnan(v)
+            ssum = np.bincount(tb[use], weights=v[use], minlength=n_t)
+            cnt = np.bincount(tb[use], minlength=n_t)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                ds_MVBS[var] = (("ping_time",), np.where(cnt > 0, ssum / cnt, np.nan), dict(ds_Sv[var].attrs))
+    if range_var == "echo_range" and "water_level" in ds_Sv.data_vars:
+        ds_MVBS["water_level"] = ds_Sv["water_level"]
+
+    _set_MVBS_attrs(ds_MVBS)
+    ds_MVBS.coords[range_var].attrs = {"long_name": "Range distance", "units": "m"}
+    val, unit = ping_time_bin_parsing_and_conversion(ping_time_bin)
+    ds_MVBS.data_vars["Sv"].attrs.update({
+        "cell_methods": (f"ping_time: mean (interval: {val} {unit} "
+                         "comment: ping_time is the interval start) "
+                         f"{range_var}: mean (interval: {range_bin_m} meter "
+                         f"comment: {range_var} is the interval start)"),
+        "binning_mode": "physical units",
+        "range_meter_interval": str(range_bin_m) + "m",
+        "ping_time_interval": ping_time_bin,
+    })
+    prov = echopype_prov_attrs(process_type="processing")
+    prov["processing_function"] = "commongrid.compute_MVBS"
+    ds_MVBS = ds_MVBS.assign_attrs(prov)
+    if "frequency_nominal" in ds_Sv:
+        ds_MVBS["frequency_nominal"] = ds_Sv["frequency_nominal"]
+    if "channel" in ds_Sv and dim_0 != "channel":
+        ds_MVBS["channel"] = ds_Sv["channel"]
+    return insert_processing_level(ds_MVBS, "L3*", input_ds=ds_Sv)
+
+
+def compute_MVBS_index_binning(ds_Sv, range_sample_num=100, ping_num=100):
+    """MVBS over blocks of ``ping_num`` pings x ``range_sample_num`` samples (api.py:194-266)."""
+    ds_Sv = from_xarray(ds_Sv)
+    sv_da = ds_Sv["Sv"]
+    order = tuple(sv_da.dims)
+    sv_t = _dev(sv_da)
+    if sv_t.dtype not in (torch.float32, torch.float64):
+        sv_t = sv_t.double()
+    rg_t = _dev(_full(ds_Sv["echo_range"], ds_Sv, order), sv_t.dtype)
+    mv, rmin = ops.mvbs_index(sv_t, ping_num, range_sample_num, range=rg_t)
+    C, Pb, Sb = mv.shape
+    ping_time = np.asarray(ds_Sv["ping_time"].values)
+    ds_MVBS = Dataset(coords={order[0]: ds_Sv[order[0]].values, "ping_time": ping_time[::ping_num][:Pb],
+                              "range_sample": np.arange(Sb)})
+    ds_MVBS.coords["range_sample"].attrs = {"long_name": "Along-range sample number, base 0"}
+    ds_MVBS["Sv"] = DataArray(DeviceArray(mv), (order[0], "ping_time", "range_sample"))
+    ds_MVBS["echo_range"] = DataArray(DeviceArray(rmin), (order[0], "ping_time", "range_sample"))
+    _set_MVBS_attrs(ds_MVBS)
+    lo, hi = ops.nanminmax(mv)
+    ds_MVBS.data_vars["Sv"].attrs.update({
+        "cell_methods": (f"ping_time: mean (interval: {ping_num} pings "
+                         "comment: ping_time is the interval start) "
+                         f"range_sample: mean (interval: {range_sample_num} samples along range "
+                         "comment: range_sample is the interval start)"),
+        "comment": "MVBS binned on the basis of range_sample and ping number specified as index numbers",
+        "binning_mode": "sample number",
+        "range_sample_interval": f"{range_sample_num} samples along range",
+        "ping_interval": f"{ping_num} pings",
+        "actual_range": [round(float(lo), 2), round(float(hi), 2)],
+    })
+    prov = echopype_prov_attrs(process_type="processing")
+    prov["processing_function"] = "commongrid.compute_MVBS_index_binning"
+    ds_MVBS = ds_MVBS.assign_attrs(prov)
+    if "frequency_nominal" in ds_Sv:
+        ds_MVBS["frequency_nominal"] = ds_Sv["frequency_nominal"]
+    return insert_processing_level(ds_MVBS, "L3*", input_ds=ds_Sv)

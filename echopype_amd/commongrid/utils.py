@@ -1,0 +1,93 @@
+"""Host helpers of compute_MVBS (mirrors /root/reference/echopype/commongrid/utils.py:283-450,
+654-698 and the bin construction of commongrid/api.py:108-128).  O(P) work only."""
+import re
+
+import numpy as np
+
+_UNIT_NS = {"ns": 1, "n": 1, "us": 10**3, "u": 10**3, "ms": 10**6, "l": 10**6, "s": 10**9, "sec": 10**9,
+            "second": 10**9, "seconds": 10**9, "min": 60 * 10**9, "t": 60 * 10**9, "m": 60 * 10**9,
+            "minute": 60 * 10**9, "minutes": 60 * 10**9, "h": 3600 * 10**9, "hr": 3600 * 10**9,
+            "hour": 3600 * 10**9, "hours": 3600 * 10**9, "d": 86400 * 10**9, "day": 86400 * 10**9,
+            "days": 86400 * 10**9}
+_LABEL = {1: ("n", "nanosecond"), 10**3: ("us", "microsecond"), 10**6: ("ms", "millisecond"),
+          10**9: ("s", "second"), 60 * 10**9: ("min", "minute"), 3600 * 10**9: ("h", "hour"),
+          86400 * 10**9: ("d", "day")}
+
+
+def _parse_x_bin(x_bin, x_label="range_bin"):
+    """'10m' -> 10.0 (utils.py:305-377; same error types and messages)."""
+    info = {"range_bin": ("Range bin", "m", "10m", "meters", r"([\d+]*[.,]{0,1}[\d+]*)(\s+)?(m)"),
+            "dist_bin": ("Distance bin", "nmi", "0.5nmi", "nautical miles", r"([\d+]*[.,]{0,1}[\d+]*)(\s+)?(nmi)")}
+    if x_label not in info:
+        raise KeyError(f"x_label must be one of {list(info)}")
+    name, _, ex, unit_label, pattern = info[x_label]
+    if not isinstance(x_bin, str):
+        raise TypeError("'x_bin' must be a string")
+    m = re.match(pattern, x_bin.strip().lower())
+    if m is None:
+        raise ValueError(f"{name} must be in {unit_label} (e.g., '{ex}').")
+    return float(m.group(1))
+
+
+def timedelta_ns(ping_time_bin):
+    """'20s' / '1min' / '0.5h' -> integer nanoseconds (what pd.Timedelta(str).value returns)."""
+    m = re.fullmatch(r"\s*([0-9]*\.?[0-9]+)\s*([A-Za-z]+)\s*", ping_time_bin)
+    if m is None or m.group(2).lower() not in _UNIT_NS and m.group(2) not in ("T", "L", "U", "N", "D", "H", "S"):
+        raise ValueError(f"invalid ping_time_bin {ping_time_bin!r}")
+    unit = m.group(2) if m.group(2).lower() in _UNIT_NS else m.group(2).lower()
+    ns = float(m.group(1)) * _UNIT_NS[unit.lower()]
+    if ns <= 0 or ns != int(ns):
+        raise ValueError(f"invalid ping_time_bin {ping_time_bin!r}")
+    return int(ns)
+
+
+def ping_time_bin_parsing_and_conversion(ping_time_bin):
+    """(value, unit label) of the most granular unit, e.g. '20s' -> (20, 'second') (utils.py:654-698)."""
+    ns = timedelta_ns(ping_time_bin)
+    for unit_ns in sorted(_LABEL, reverse=True):
+        if ns % unit_ns == 0:
+            return ns // unit_ns, _LABEL[unit_ns][1]
+    return ns, "nanosecond"
+
+
+def resample_edges(ping_time, ping_time_bin):
+    """Bin edges of ``ping_time.resample(ping_time=bin)`` plus one trailing edge (api.py:118-124).
+
+    pandas anchors fixed-frequency bins at midnight of the first timestamp's day
+    (origin='start_day'), left-closed and left-labelled; bins run contiguously to the one holding
+    the last timestamp.  Returned as int64 ns: (first_edge, step, n_bins).
+    """
+    t = np.asarray(ping_time).astype("datetime64[ns]").astype(np.int64)
+    t = t[t != np.iinfo(np.int64).min]  # NaT
+    if t.size == 0:
+        raise ValueError("ping_time holds no valid timestamps")
+    dt = timedelta_ns(ping_time_bin)
+    first, last = int(t.min()), int(t.max())
+    day = 86400 * 10**9
+    origin = (first // day) * day
+    e0 = origin + ((first - origin) // dt) * dt
+    n = (last - e0) // dt + 1
+    return e0, dt, int(n)
+
+
+def _setup_and_validate(ds_Sv, range_var="echo_range", range_bin=None, closed="left", required_data_vars=None):
+    """Argument checks of compute_MVBS (utils.py:380-450)."""
+    if range_var not in ["echo_range", "depth"]:
+        raise ValueError("range_var must be one of 'echo_range' or 'depth'.")
+    required = set((required_data_vars or []) + [range_var])
+    if not all(v in ds_Sv.variables for v in required):
+        raise ValueError(f"Input Sv dataset must contain all of the following variables: {required}")
+    if not isinstance(range_bin, str):
+        raise TypeError("range_bin must be a string")
+    range_bin = _parse_x_bin(range_bin, "range_bin")
+    if closed not in ["right", "left"]:
+        raise ValueError(f"{closed} is not a valid option. Options are 'left' or 'right'.")
+    return ds_Sv, range_bin
+
+
+def _set_MVBS_attrs(ds):
+    """utils.py:234-262."""
+    ds.coords["ping_time"].attrs = {"long_name": "Ping time", "standard_name": "time", "axis": "T"}
+    ds.data_vars["Sv"].attrs = {"long_name": "Mean volume backscattering strength (MVBS, mean Sv re 1 m-1)",
+                                "units": "dB", "actual_range": None}
+    ds.data_vars["Sv"].attrs.pop("actual_range")

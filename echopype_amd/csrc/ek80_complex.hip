@@ -208,7 +208,7 @@ __global__ __launch_bounds__(epa::kBlock) void sv_complex_kernel(CxArgs a) {
   // ---- sector mean -> prx -> Sv/TS (calibrate_ek.py:483-490, 571-638)
   const size_t row = (size_t)c * a.P + p;
   const double* cc = a.ccoef + row * EPA_NCCOEF;
-  const double kk = cc[EPA_CC_K];
+  const double ra = cc[EPA_CC_RA], rb = cc[EPA_CC_RB];
   const T shift = (T)cc[EPA_CC_SHIFT], alpha2 = (T)cc[EPA_CC_ALPHA2], Aadd = (T)cc[EPA_CC_A];
   const T pscale = (T)(cc[EPA_CC_PSCALE]);
   const T nspread = (T)a.nspread;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(epa::kBlock) void sv_complex_kernel(CxArgs a) {
     }
     T prx = pscale * (mr * mr + mi * mi);
     if (!(prx > (T)0)) prx = epa::M<T>::nan();
-    const double R = (double)s * kk;
+    const double R = ((double)s * ra) * rb;  // range.py:138 operation order
     T rt = (T)R - shift;
     if (!(rt > (T)0)) rt = epa::M<T>::nan();
     const T val = (T)10 * epa::M<T>::log10(prx) + nspread * epa::M<T>::log10(rt) + alpha2 * rt + Aadd;

@@ -174,6 +174,15 @@ def mvbs_finalize(ssum, cnt, fill_value=float("nan")):
     return out
 
 
+def nanminmax(x):
+    """(nanmin, nanmax) of a device tensor as Python floats (one 16-byte D2H copy)."""
+    ws = torch.empty(2048, dtype=torch.float64, device=x.device)
+    out = torch.empty(2, dtype=torch.float64, device=x.device)
+    call("epa_nanminmax", _p(x), x.numel(), _DT[x.dtype], _p(ws), _p(out), _stream())
+    lo, hi = out.cpu().tolist()
+    return lo, hi
+
+
 def mvbs_index(sv, ping_num, range_sample_num, range=None):
     """K5' -> (MVBS (C,Pb,Sb), echo_range block-min or None)."""
     C, P, S = sv.shape

@@ -1,0 +1,319 @@
+"""Minimal labelled-array containers standing in for ``xarray.Dataset`` / ``DataArray``.
+
+xarray is not installed in this image (SURVEY.md probe table), so the drop-in functions accept and
+return these light containers; when real xarray IS importable they also accept ``xarray`` objects
+(converted with :func:`from_xarray`) and can hand results back with :meth:`Dataset.to_xarray`.
+
+Only what the hot path needs is implemented: named dimensions, coordinates, attributes, variable
+access by name.  Array payloads may live on the host (numpy) or in HBM (:class:`DeviceArray`,
+a lazily-copied torch CUDA tensor -- the analogue of the reference's dask-backed laziness:
+``compute_Sv`` output stays on the device and feeds ``remove_background_noise`` /
+``compute_MVBS`` without a PCIe round trip; ``.values`` materialises it on the host).
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+try:  # pragma: no cover - not installed in the build image
+    import xarray as _xr
+except Exception:  # noqa: BLE001
+    _xr = None
+
+__all__ = ["DeviceArray", "DataArray", "Dataset", "from_xarray", "is_device"]
+
+
+class DeviceArray:
+    """A C-contiguous array resident in GPU memory (wraps a torch CUDA tensor)."""
+
+    __slots__ = ("tensor",)
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+    @property
+    def shape(self):
+        return tuple(self.tensor.shape)
+
+    @property
+    def ndim(self):
+        return self.tensor.dim()
+
+    @property
+    def dtype(self):
+        return np.dtype(str(self.tensor.dtype).replace("torch.", ""))
+
+    @property
+    def nbytes(self):
+        return self.tensor.numel() * self.tensor.element_size()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.tensor.detach().cpu().numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+    def __repr__(self):
+        return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, device={self.tensor.device})"
+
+
+def is_device(a):
+    return isinstance(a, DeviceArray)
+
+
+class DataArray:
+    def __init__(self, data, dims=None, coords=None, attrs=None, name=None):
+        if isinstance(data, DataArray):
+            dims = dims if dims is not None else data.dims
+            coords = coords if coords is not None else data.coords
+            attrs = attrs if attrs is not None else data.attrs
+            name = name if name is not None else data.name
+            data = data.data
+        if not isinstance(data, DeviceArray):
+            data = np.asarray(data)
+        self.data = data
+        if dims is None:
+            dims = () if data.ndim == 0 else tuple(f"dim_{i}" for i in range(data.ndim))
+        if isinstance(dims, str):
+            dims = (dims,)
+        self.dims = tuple(dims)
+        if len(self.dims) != data.ndim:
+            raise ValueError(f"dims {self.dims} do not match data of shape {data.shape}")
+        self.coords = OrderedDict()
+        for k, v in (coords or {}).items():
+            self.coords[k] = v if isinstance(v, np.ndarray) else np.asarray(getattr(v, "values", v))
+        self.attrs = dict(attrs or {})
+        self.name = name
+
+    # -- array protocol ---------------------------------------------------------------------
+    @property
+    def values(self):
+        return np.asarray(self.data)
+
+    @property
+    def shape(self):
+        return tuple(self.data.shape)
+
+    @property
+    def ndim(self):
+        return self.data.ndim
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape)) if self.shape else 1
+
+    @property
+    def sizes(self):
+        return OrderedDict(zip(self.dims, self.shape))
+
+    @property
+    def nbytes(self):
+        return self.data.nbytes
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.values
+        return a.astype(dtype) if dtype is not None else a
+
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            return DataArray(self.coords[key], dims=(key,) if self.coords[key].ndim == 1 else None)
+        return self.values[key]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def copy(self):
+        d = self.data if isinstance(self.data, DeviceArray) else self.data.copy()
+        return DataArray(d, self.dims, dict(self.coords), dict(self.attrs), self.name)
+
+    def assign_attrs(self, attrs=None, **kw):
+        out = DataArray(self.data, self.dims, dict(self.coords), dict(self.attrs), self.name)
+        out.attrs.update(attrs or {})
+        out.attrs.update(kw)
+        return out
+
+    def isel(self, **indexers):
+        a = self.values
+        dims = list(self.dims)
+        coords = dict(self.coords)
+        for d, idx in indexers.items():
+            ax = dims.index(d)
+            a = np.take(a, idx, axis=ax) if not isinstance(idx, slice) else a[(slice(None),) * ax + (idx,)]
+            if d in coords:
+                coords[d] = coords[d][idx]
+            if np.isscalar(idx) or isinstance(idx, (int, np.integer)):
+                dims.pop(ax)
+        coords = {k: v for k, v in coords.items() if k in dims}
+        return DataArray(a, dims, coords, dict(self.attrs), self.name)
+
+    def isnull(self):
+        return DataArray(np.isnan(self.values), self.dims, dict(self.coords))
+
+    def min(self):
+        return np.nanmin(self.values)
+
+    def max(self):
+        return np.nanmax(self.values)
+
+    def __repr__(self):
+        return f"<DataArray {self.name!r} {dict(self.sizes)} {self.dtype} on {'device' if is_device(self.data) else 'host'}>"
+
+
+class Dataset:
+    def __init__(self, data_vars=None, coords=None, attrs=None):
+        self.coords = OrderedDict()
+        self.data_vars = OrderedDict()
+        self.attrs = dict(attrs or {})
+        for k, v in (coords or {}).items():
+            self._set_coord(k, v)
+        for k, v in (data_vars or {}).items():
+            self[k] = v
+
+    def _set_coord(self, name, v):
+        if isinstance(v, DataArray):
+            arr, attrs = v.values, v.attrs
+        elif isinstance(v, tuple):
+            arr, attrs = np.asarray(v[1]), (v[2] if len(v) > 2 else {})
+        else:
+            arr, attrs = np.asarray(getattr(v, "values", v)), {}
+        self.coords[name] = DataArray(arr, (name,) if arr.ndim == 1 else None, attrs=attrs, name=name)
+
+    # -- mapping protocol -------------------------------------------------------------------
+    def __setitem__(self, name, v):
+        if isinstance(v, tuple):
+            dims, data = v[0], v[1]
+            attrs = v[2] if len(v) > 2 else {}
+            da = DataArray(data, dims, attrs=attrs, name=name)
+        elif isinstance(v, DataArray):
+            da = DataArray(v.data, v.dims, v.coords, v.attrs, name)
+        else:
+            arr = np.asarray(v)
+            da = DataArray(arr, () if arr.ndim == 0 else None, name=name)
+        for d, n in zip(da.dims, da.shape):
+            if d in self.coords and self.coords[d].shape[0] != n:
+                raise ValueError(f"variable {name!r}: dimension {d!r} has length {n}, dataset has "
+                                 f"{self.coords[d].shape[0]}")
+        for k, c in da.coords.items():
+            if k not in self.coords and np.ndim(c) == 1:
+                self._set_coord(k, c)
+        if name in self.coords and da.dims == (name,):
+            self._set_coord(name, da)
+            return
+        self.data_vars[name] = da
+
+    def __getitem__(self, name):
+        if name in self.data_vars:
+            da = self.data_vars[name]
+            cs = {d: self.coords[d].values for d in da.dims if d in self.coords}
+            return DataArray(da.data, da.dims, cs, da.attrs, name)
+        if name in self.coords:
+            return self.coords[name]
+        raise KeyError(name)
+
+    def __contains__(self, name):
+        return name in self.data_vars or name in self.coords
+
+    def __iter__(self):
+        return iter(self.data_vars)
+
+    def get(self, name, default=None):
+        return self[name] if name in self else default
+
+    @property
+    def variables(self):
+        out = OrderedDict(self.coords)
+        out.update(self.data_vars)
+        return out
+
+    @property
+    def sizes(self):
+        out = OrderedDict()
+        for da in self.data_vars.values():
+            for d, n in zip(da.dims, da.shape):
+                out.setdefault(d, n)
+        for k, c in self.coords.items():
+            if c.ndim == 1:
+                out.setdefault(k, c.shape[0])
+        return out
+
+    dims = sizes
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
+
+    def copy(self):
+        out = Dataset(attrs=dict(self.attrs))
+        for k, c in self.coords.items():
+            out.coords[k] = c
+        for k, v in self.data_vars.items():
+            out.data_vars[k] = v
+        return out
+
+    def assign_attrs(self, attrs=None, **kw):
+        out = self.copy()
+        out.attrs.update(attrs or {})
+        out.attrs.update(kw)
+        return out
+
+    def drop_vars(self, names):
+        names = [names] if isinstance(names, str) else list(names)
+        out = self.copy()
+        for n in names:
+            out.data_vars.pop(n, None)
+            out.coords.pop(n, None)
+        return out
+
+    def isel(self, **indexers):
+        out = Dataset(attrs=dict(self.attrs))
+        for k, c in self.coords.items():
+            out.coords[k] = c.isel(**{d: i for d, i in indexers.items() if d in c.dims}) if any(
+                d in c.dims for d in indexers) else c
+        for k, v in self.data_vars.items():
+            sel = {d: i for d, i in indexers.items() if d in v.dims}
+            out.data_vars[k] = v.isel(**sel) if sel else v
+        return out
+
+    def to_host(self):
+        """Materialise every device-resident variable on the host (PCIe copies)."""
+        out = self.copy()
+        for k, v in list(out.data_vars.items()):
+            if is_device(v.data):
+                out.data_vars[k] = DataArray(v.values, v.dims, v.coords, v.attrs, k)
+        return out
+
+    def to_xarray(self):
+        if _xr is None:
+            raise ImportError("xarray is not installed")
+        return _xr.Dataset(
+            {k: (v.dims, v.values, v.attrs) for k, v in self.data_vars.items()},
+            coords={k: (c.dims, c.values, c.attrs) for k, c in self.coords.items()}, attrs=self.attrs)
+
+    def __repr__(self):
+        lines = [f"<Dataset {dict(self.sizes)}>"]
+        lines += [f"  coord {k}: {c.shape} {c.dtype}" for k, c in self.coords.items()]
+        lines += [f"  {v!r}" for v in self.data_vars.values()]
+        return "\n".join(lines)
+
+
+def from_xarray(obj):
+    """xarray.Dataset / DataArray -> lite container (no-op for lite containers)."""
+    if isinstance(obj, (Dataset, DataArray)) or _xr is None:
+        return obj
+    if isinstance(obj, _xr.DataArray):
+        return DataArray(obj.values, obj.dims, {k: v.values for k, v in obj.coords.items() if v.ndim == 1},
+                         dict(obj.attrs), obj.name)
+    if isinstance(obj, _xr.Dataset):
+        ds = Dataset(attrs=dict(obj.attrs))
+        for k, c in obj.coords.items():
+            if c.ndim == 1 and c.dims == (k,):
+                ds._set_coord(k, (c.dims, c.values, dict(c.attrs)))
+        for k, v in obj.data_vars.items():
+            ds[k] = (v.dims, v.values, dict(v.attrs))
+        return ds
+    return obj

@@ -157,6 +157,15 @@ int epa_selftest_lin_from_db(const double* u, double* out, size_t n, epa_stream_
 int epa_mvbs_finalize(const void* sum, const uint32_t* cnt, size_t n, double fill_value, void* out,
                       int dtype, epa_stream_t stream);
 
+/* ---- NaN-skipping min/max of a device array ---------------------------------------------------------------
+ * Replaces the reductions the reference forces with ds_Sv[range_var].max(skipna=True)
+ * (commongrid/api.py:108-110) and the actual_range attributes (clean/utils.py:392-395,
+ * commongrid/api.py:252-255).  x: [n] of dtype; workspace: f64 [2048]; out: f64 [2] = {min, max}
+ * (NaN, NaN when no element is non-NaN).
+ */
+int epa_nanminmax(const void* x, size_t n, int dtype, double* workspace, double* out,
+                  epa_stream_t stream);
+
 /* ---- K5': compute_MVBS_index_binning ------------------------------------------------------------------------
  * Replaces commongrid/api.py:217-222 (coarsen(ping_num, range_sample_num, "pad").mean(skipna) in the
  * linear domain) and :232-238 (echo_range block min).  Outputs [C * ceil(P/ping_num) *
@@ -200,8 +209,11 @@ int epa_noise_apply(const void* sv, const void* range, const double* coef, const
  *              F64 output accumulates the matched filter in f64, F32 in f32
  */
 #define EPA_NCCOEF 8
-enum epa_ccoef_slot { EPA_CC_K = 0, EPA_CC_SHIFT = 1, EPA_CC_ALPHA2 = 2, EPA_CC_A = 3, EPA_CC_PSCALE = 4,
-                      EPA_CC_RSV0 = 5, EPA_CC_RSV1 = 6, EPA_CC_RSV2 = 7 };
+/* echo_range R = fl(fl(s*RA)*RB) (RA = sample_interval, RB = sound_speed/2: range.py:138 order);
+ * R' = R - SHIFT (<= 0 -> NaN); out = 10log10(prx) + n*log10(R') + ALPHA2*R' + A;
+ * prx = PSCALE * |sector mean of the (pulse-compressed, normalised) samples|^2  (<= 0 -> NaN) */
+enum epa_ccoef_slot { EPA_CC_RA = 0, EPA_CC_RB = 1, EPA_CC_SHIFT = 2, EPA_CC_ALPHA2 = 3, EPA_CC_A = 4,
+                      EPA_CC_PSCALE = 5, EPA_CC_RSV0 = 6, EPA_CC_RSV1 = 7 };
 int epa_sv_complex(const void* re, const void* im, int in_dtype, const float* replica,
                    const int32_t* replica_off, int max_taps, const double* ccoef, int C, int P,
                    int S, int B, int cal_type, void* out, void* range_out, void* prx_out,

@@ -1,0 +1,303 @@
+"""Drop-in API parity on a real MI355X: echopype_amd.{calibrate,clean,commongrid} called exactly
+like the reference's functions (Dataset / EchoData in, Dataset out), compared with the CPU oracle.
+
+These read like the reference's own tests (tests/calibrate/test_calibrate.py, tests/commongrid/
+test_commongrid_api.py, tests/clean/test_noise.py) with the downloaded instrument files replaced
+by the seeded synthetic generators of echopype_amd.synth.
+"""
+import logging
+
+import numpy as np
+import pytest
+
+import kat_fixtures as kf
+import oracle_chain as oc
+from oracle import clean as oclean
+from oracle import commongrid as ogrid
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ep():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need a GPU")
+    import echopype_amd
+
+    return echopype_amd
+
+
+def close(got, exp, rtol, what=""):
+    got, exp = np.asarray(got, dtype=np.float64), np.asarray(exp, dtype=np.float64)
+    assert got.shape == exp.shape, (what, got.shape, exp.shape)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp), err_msg=f"{what}: NaN pattern")
+    fin = np.isfinite(exp)
+    err = np.abs(got[fin] - exp[fin]) / np.maximum(np.abs(exp[fin]), 1.0)
+    assert err.size == 0 or err.max() <= rtol, f"{what}: max rel err {err.max():.3e} > {rtol}"
+
+
+def sv_dataset(ep, d, extra=None):
+    """An Sv dataset as a user would hold it (host arrays)."""
+    C, P, S = d["Sv"].shape
+    ds = ep.Dataset(coords={"channel": [f"ch_{i}" for i in range(C)], "ping_time": d["ping_time"],
+                            "range_sample": np.arange(S)})
+    dims = ("channel", "ping_time", "range_sample")
+    ds["Sv"] = (dims, d["Sv"])
+    ds["echo_range"] = (dims, d["echo_range"])
+    if "depth" in d:
+        ds["depth"] = (dims, d["depth"])
+    ds["frequency_nominal"] = (("channel",), np.arange(C, dtype=float))
+    for k, v in (extra or {}).items():
+        ds[k] = v
+    return ds
+
+
+# ------------------------------------------------------------------------------------ calibrate
+@pytest.mark.parametrize("dtype,rtol", [("float64", 1e-9), ("float32", 1e-3)])
+@pytest.mark.parametrize("cal", ["Sv", "TS"])
+def test_compute_Sv_TS_ek60(ep, dtype, rtol, cal):
+    d = ep.synth.ek60_numpy(2, 120, 1000, vary_tau=True)
+    ed = ep.echodata.from_ek60_arrays(d)
+    fn = ep.calibrate.compute_Sv if cal == "Sv" else ep.calibrate.compute_TS
+    ds = fn(ed, dtype=dtype)
+    exp, exp_r = oc.ek60(d, cal)
+    close(ds[cal].values, exp, rtol, cal)
+    if dtype == "float64":
+        np.testing.assert_array_equal(ds["echo_range"].values, exp_r)
+        assert ds[cal].dtype == np.float64
+    assert ds[cal].dims == ("channel", "ping_time", "range_sample")
+    assert ds[cal].attrs["units"] == "dB"
+    assert ds.attrs["processing_function"] == f"calibrate.compute_{cal}"
+    for k in ("sound_speed", "sound_absorption", "gain_correction", "sa_correction", "equivalent_beam_angle",
+              "frequency_nominal"):
+        assert k in ds, k
+    if cal == "Sv":  # EK60: tau_effective == transmit_duration_nominal of ping 0 (calibrate_ek.py:134-151)
+        np.testing.assert_array_equal(ds["tau_effective"].values, d["transmit_duration_nominal"][:, 0])
+
+
+def test_compute_Sv_ek60_user_env_and_cal_params(ep):
+    d = ep.synth.ek60_numpy(2, 40, 512)
+    ed = ep.echodata.from_ek60_arrays(d)
+    env = {"temperature": 8.0, "salinity": 34.0, "pressure": 50.0, "pH": 8.05}
+    gain = [25.1, 26.3]
+    ds = ep.calibrate.compute_Sv(ed, env_params=env, cal_params={"gain_correction": gain})
+    exp, _ = oc.ek60(d, "Sv", env=env, gain=np.tile(np.array(gain)[:, None], (1, 40)))
+    close(ds["Sv"].values, exp, 1e-9, "user params")
+    assert str(ds["formula_absorption"].values) == "FG"
+
+
+def test_compute_Sv_argument_errors(ep):
+    d = ep.synth.ek60_numpy(1, 4, 64)
+    ed = ep.echodata.from_ek60_arrays(d)
+    with pytest.raises(ValueError, match="assume_single_filter_time can only be used on complex EK80 data."):
+        ep.calibrate.compute_Sv(ed, assume_single_filter_time=True)
+    ed80 = ep.echodata.from_ek80_arrays(ep.synth.ek80_numpy(1, 2, 64), ep.synth.ek80_filters())
+    with pytest.raises(ValueError, match="waveform_mode and encode_mode must be specified for EK80 calibration"):
+        ep.calibrate.compute_Sv(ed80)
+    with pytest.raises(ValueError, match="must be recorded as complex samples"):
+        ep.calibrate.compute_Sv(ed80, waveform_mode="BB", encode_mode="power")
+    with pytest.raises(RuntimeError, match="No beam group with the specified encode_mode"):
+        ep.calibrate.compute_Sv(ed80, waveform_mode="CW", encode_mode="power")
+    ed80["Sonar"] = ep.Dataset()
+    with pytest.raises(ValueError, match="Echodata missing `waveform_encode_descr`"):
+        ep.calibrate.compute_Sv(ed80, waveform_mode="BB", encode_mode="complex")
+    with pytest.raises(ValueError, match="sound_absorption"):
+        ep.calibrate.compute_Sv(ed, env_params={"sound_absorption": 0.01})
+
+
+@pytest.mark.parametrize("cal", ["Sv", "TS"])
+def test_compute_Sv_TS_azfp(ep, cal):
+    d = ep.synth.azfp_numpy(4, 30, 500)
+    ed = ep.echodata.from_azfp_arrays(d)
+    fn = ep.calibrate.compute_Sv if cal == "Sv" else ep.calibrate.compute_TS
+    ds = fn(ed, env_params={"salinity": d["salinity"], "pressure": d["pressure"]})
+    exp, exp_r = oc.azfp(d, cal)
+    close(ds[cal].values, exp, 1e-9, f"AZFP {cal}")
+    close(ds["echo_range"].values, exp_r, 1e-12, "AZFP range")
+    with pytest.raises(ReferenceError, match="Please supply both salinity and pressure"):
+        fn(ed)
+
+
+def _ek80(ep, waveform, **kw):
+    filt = ep.synth.ek80_filters()
+    wf = "BB" if waveform == "BB" else "CW"
+    d0 = dict(ep.synth.EK80_BB)
+    from oracle_chain import ek80_replicas
+    probe = {**{k: v[:2] for k, v in d0.items()}, "fs": np.full(2, 1.5e6), "slope": np.full(2, 0.05)}
+    reps, _ = ek80_replicas(probe, filt, wf)
+    d = ep.synth.ek80_numpy(waveform=wf, replicas=reps if wf == "BB" else None, **kw)
+    return d, filt
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("mixed", [False, True])
+def test_compute_Sv_ek80_bb(ep, dtype, mixed):
+    """BB pulse compression + Sv.  The reference's own output is complex64-rounded
+    (ek80_complex.py:304), so parity is judged like the reference's tests do: in dB with an
+    absolute tolerance (test_calibrate_ek80_CW.py uses 2e-3...5.5e-3 dB), here 2e-4 dB for the f64
+    path and 2e-3 dB for f32, plus identical NaN patterns."""
+    d, filt = _ek80(ep, "BB", C=2, P=12, S=1200, mixed_nan=mixed)
+    ed = ep.echodata.from_ek80_arrays(d, filt)
+    ds = ep.calibrate.compute_Sv(ed, waveform_mode="BB", encode_mode="complex", dtype=dtype)
+    (exp, exp_r, prx), teff = oc.ek80_complex(d, filt, "Sv")
+    got = ds["Sv"].values.astype(np.float64)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+    fin = np.isfinite(exp)
+    # samples more than 60 dB below the ping's peak sit at the reference's own float32 noise floor
+    peak = np.nanmax(np.where(fin, exp, -np.inf), axis=2, keepdims=True)
+    strong = fin & (exp > peak - 60)
+    atol = 2e-4 if dtype == "float64" else 2e-3
+    assert np.abs(got[strong] - exp[strong]).max() < atol
+    assert np.abs(got[fin] - exp[fin]).max() < 0.5
+    np.testing.assert_allclose(ds["tau_effective"].values, teff, rtol=1e-12)
+    if dtype == "float64":
+        np.testing.assert_array_equal(ds["echo_range"].values, exp_r)
+    assert ds["Sv"].attrs["waveform_mode"] == "BB"
+
+
+@pytest.mark.parametrize("cal", ["Sv", "TS"])
+def test_compute_Sv_TS_ek80_cw_complex(ep, cal):
+    d, filt = _ek80(ep, "CW", C=2, P=10, S=700, mixed_nan=True)
+    ed = ep.echodata.from_ek80_arrays(d, filt)
+    fn = ep.calibrate.compute_Sv if cal == "Sv" else ep.calibrate.compute_TS
+    ds = fn(ed, waveform_mode="CW", encode_mode="complex")
+    (exp, exp_r, _), _ = oc.ek80_complex(d, filt, cal)
+    close(ds[cal].values, exp, 1e-9, f"EK80 CW complex {cal}")
+
+
+# ------------------------------------------------------------------------------------ the chain
+@pytest.mark.parametrize("dtype,rtol", [("float64", 1e-9), ("float32", 1e-3)])
+def test_chain_sv_noise_mvbs(ep, dtype, rtol):
+    """compute_Sv -> remove_background_noise -> compute_MVBS, device-resident between the calls."""
+    d = ep.synth.ek60_numpy(2, 205, 1000)
+    ds = ep.calibrate.compute_Sv(ep.echodata.from_ek60_arrays(d), dtype=dtype)
+    assert ep.xr_lite.is_device(ds["Sv"].data)
+    out = ep.clean.remove_background_noise(ds, ping_num=20, range_sample_num=50, SNR_threshold="3.0dB")
+    assert out is ds and "Sv_noise" in ds and "Sv_corrected" in ds  # in-place (clean/api.py:490-502)
+    mv = ep.commongrid.compute_MVBS(ds, range_bin="1m", ping_time_bin="20s")
+    sv, er = oc.ek60(d, "Sv")
+    exp_n, exp_c = oclean.remove_background_noise(sv, er, d["absorption_indicative"], 20, 50)
+    # float32 mode stores echo_range in float32 and compute_MVBS bins the STORED coordinate (as the
+    # reference would for a float32 echo_range): feed the oracle the same rounded coordinate, else
+    # samples within 1e-7 of a bin edge land in the neighbouring bin -- a discrete effect of the
+    # storage precision, not of the arithmetic.
+    er_binned = er if dtype == "float64" else er.astype(np.float32).astype(np.float64)
+    exp_mv, t_left, r_left = ogrid.compute_MVBS(sv, er_binned, d["ping_time"], "1m", "20s")
+    close(ds["Sv_noise"].values, exp_n, rtol, "Sv_noise")
+    if dtype == "float64":
+        close(ds["Sv_corrected"].values, exp_c, 1e-7, "Sv_corrected")
+        assert ds["Sv_corrected"].attrs["actual_range"] == [round(float(np.nanmin(exp_c)), 2),
+                                                            round(float(np.nanmax(exp_c)), 2)]
+    close(mv["Sv"].values, exp_mv, rtol, "MVBS")
+    np.testing.assert_array_equal(mv["ping_time"].values, t_left)
+    np.testing.assert_array_equal(mv["echo_range"].values, r_left)
+    assert mv["Sv"].attrs["binning_mode"] == "physical units"
+    assert mv.attrs["processing_function"] == "commongrid.compute_MVBS"
+
+
+# ------------------------------------------------------------------------------------ commongrid
+@pytest.mark.parametrize("kind", ["regular", "irregular"])
+def test_compute_MVBS_reference_values(ep, kind, caplog):
+    d = kf.mock_small(kind)
+    with caplog.at_level(logging.WARNING):
+        ds = ep.commongrid.compute_MVBS(sv_dataset(ep, d), range_bin="2m", ping_time_bin="1s")
+    exp = kf.brute_force_mvbs(d, "1s", 2)
+    assert ds["Sv"].shape == exp.shape
+    np.testing.assert_allclose(ds["Sv"].values, exp, atol=1e-10, rtol=1e-10, equal_nan=True)
+    if kind == "irregular":  # test_commongrid_api.py:511-519
+        assert any("The ```echo_range``` coordinate array contain NaNs." in r.message for r in caplog.records)
+
+
+def test_compute_MVBS_shapes_edges_positions(ep):
+    d = kf.sv_regular()
+    P = d["Sv"].shape[1]
+    lat = np.linspace(42.48916859, 42.49071833, P)
+    lon = np.linspace(-124.88296688, -124.81919229, P)
+    ds_in = sv_dataset(ep, d, {"latitude": (("ping_time",), lat), "longitude": (("ping_time",), lon)})
+    ds_in.attrs["processing_level"] = "Level 2A"
+    ds = ep.commongrid.compute_MVBS(ds_in, range_bin="5m", ping_time_bin="10s")
+    dt = (d["ping_time"][-1] - d["ping_time"][0]).astype(np.int64)
+    assert ds["Sv"].shape == (2, int(np.ceil(dt / 1e9 / 10)), int(np.ceil(d["echo_range"].max() / 5)))
+    exp_mv, t_left, _ = ogrid.compute_MVBS(d["Sv"], d["echo_range"], d["ping_time"], "5m", "10s")
+    np.testing.assert_array_equal(ds["ping_time"].values, t_left)
+    it = ogrid.bin_index(d["ping_time"], ogrid.ping_edges(d["ping_time"], "10s"))
+    np.testing.assert_allclose(ds["latitude"].values, [lat[it == i].mean() for i in range(len(t_left))], rtol=1e-14)
+    assert ds.attrs["processing_level"] == "Level 3A"
+    mx = ep.commongrid.compute_MVBS(sv_dataset(ep, kf.mock_small("regular")), range_bin="1m", range_var_max="8m")
+    assert mx["echo_range"].values.max() == 8  # test_commongrid_api.py:580-592
+
+
+@pytest.mark.parametrize("skipna,range_var", [(True, "depth"), (False, "depth"), (True, "echo_range"), (False, "echo_range")])
+def test_compute_MVBS_skipna_masks(ep, skipna, range_var):
+    d = kf.mock_small("irregular")
+    sub = {k: (v[:, :2].copy() if v.ndim == 3 else v[:2]) for k, v in d.items()}
+    da = ep.commongrid.compute_MVBS(sv_dataset(ep, sub), range_var=range_var, range_bin="2m", skipna=skipna)["Sv"]
+    mask = np.isnan(da.values)
+    if range_var == "echo_range":
+        exp = [[[False] * 5], [[False] * 5]]
+    elif skipna:
+        exp = [[[True, False, False, False, False, False]]] * 2
+    else:
+        exp = [[[True, True, True, False, False, True]], [[True, False, False, True, True, True]]]
+    np.testing.assert_array_equal(mask, np.array(exp))
+
+
+def test_compute_MVBS_unsorted_pings_and_closed_right(ep):
+    d = kf.sv_regular(2, 60, 0.5, 90, "0.7s")
+    perm = np.random.default_rng(1).permutation(90)
+    shuf = dict(Sv=d["Sv"][:, perm], echo_range=d["echo_range"][:, perm], ping_time=d["ping_time"][perm])
+    for closed in ("left", "right"):
+        exp, _, _ = ogrid.compute_MVBS(d["Sv"], d["echo_range"], d["ping_time"], "3m", "5s", closed=closed)
+        got = ep.commongrid.compute_MVBS(sv_dataset(ep, shuf), range_bin="3m", ping_time_bin="5s", closed=closed)
+        close(got["Sv"].values, exp, 1e-10, f"unsorted closed={closed}")
+
+
+def test_compute_MVBS_argument_errors(ep):
+    ds = sv_dataset(ep, kf.mock_small("regular"))
+    with pytest.raises(TypeError, match="range_bin must be a string"):
+        ep.commongrid.compute_MVBS(ds, range_bin=10)
+    with pytest.raises(ValueError, match="Range bin must be in meters"):
+        ep.commongrid.compute_MVBS(ds, range_bin="10km")
+    with pytest.raises(TypeError, match="ping_time_bin must be a string"):
+        ep.commongrid.compute_MVBS(ds, ping_time_bin=20)
+    with pytest.raises(ValueError, match="range_var must be one of 'echo_range' or 'depth'."):
+        ep.commongrid.compute_MVBS(ds, range_var="range")
+    with pytest.raises(ValueError, match="is not a valid option. Options are 'left' or 'right'."):
+        ep.commongrid.compute_MVBS(ds, closed="both")
+    for method in ("blockwise", "cohorts"):
+        for reindex in (True, False):
+            with pytest.raises(ValueError, match=f"Passing in reindex={reindex} is only allowed when method='map_reduce'."):
+                ep.commongrid.compute_MVBS(ds, method=method, reindex=reindex)
+
+
+def test_compute_MVBS_index_binning(ep):
+    d = kf.sv_regular(4, 4000, 0.5, 100)
+    ds = ep.commongrid.compute_MVBS_index_binning(sv_dataset(ep, d), range_sample_num=7, ping_num=3)
+    exp, exp_r = ogrid.compute_MVBS_index_binning(d["Sv"], d["echo_range"], 7, 3)
+    assert ds["Sv"].shape == tuple(np.ceil((4, 100 / 3, 4000 / 7)).astype(int))
+    close(ds["Sv"].values, exp, 1e-12, "index binning")
+    np.testing.assert_array_equal(ds["echo_range"].values, exp_r)
+    assert ds["Sv"].attrs["actual_range"] == [round(float(np.nanmin(exp)), 2), round(float(np.nanmax(exp)), 2)]
+    np.testing.assert_array_equal(ds["range_sample"].values, np.arange(exp.shape[2]))
+
+
+# ------------------------------------------------------------------------------------ clean
+def test_remove_background_noise_reference_kat(ep):
+    for make, n_nan in ((kf.noise_toy, None), (kf.noise_seed1, 6)):
+        Sv, er, a = make()
+        ds = sv_dataset(ep, dict(Sv=Sv, echo_range=er, ping_time=kf.gen_ping_time(10, "1.6s")),
+                        {"sound_absorption": np.asarray(a)})
+        out = ep.clean.remove_noise(ds, ping_num=2, range_sample_num=5, SNR_threshold="0dB")  # legacy alias
+        c = out["Sv_corrected"].values
+        if n_nan is None:
+            assert np.isnan(c[0, 0, 30]) and np.isnan(c[0, 0, 60])
+        else:
+            assert np.count_nonzero(np.isnan(c[0, :, :50])) == n_nan
+        est = ep.clean.estimate_background_noise(ds, 2, 5)
+        np.testing.assert_array_equal(est.values, out["Sv_noise"].values)
+    with pytest.raises(TypeError):
+        ep.clean.remove_background_noise(ds, 2, 5, SNR_threshold=3.0)
+    with pytest.raises(ValueError):
+        ep.clean.remove_background_noise(ds, 2, 5, background_noise_max="-125")
