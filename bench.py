@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- range-samples/s through compute_Sv -> compute_MVBS on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json): synthetic EK60 CW, 4 channels x 500 000 pings x 2000 range samples PER
+GPU (configs[1]'s volume, 4.0 G samples, through the metric's path compute_Sv -> compute_MVBS with
+20-s x 1-m bins, fp64), generated in HBM; pings shard across ranks (weak scaling: the 8-GPU run is
+the 2 M-ping job of configs[4] at the range depth of configs[1]).
+One STEP = the whole hot path over the resident volume:
+    epa_power_coef_ek (K0)  ->  epa_time_bin_offsets  ->  epa_sv_mvbs_fused (K1+K5: writes Sv f64 and
+    the MVBS grid)  [-> straddling-bin all-reduce when a time bin crosses a shard edge; not the case
+    for this layout, so the data path has no collective].
+value = samples processed by all ranks / max-over-ranks wall time of the K timed steps.
+roofline: HIP-event time of the dominant kernel (epa_sv_mvbs_fused) on torch's stream, algorithmic
+bytes = 12 B/sample (4 B f32 raw in + 8 B f64 Sv out; SURVEY 8d line C) vs 8 TB/s HBM peak.
+cpu_baseline: the NumPy oracle (reference pass structure) on a bounded slice, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (C, pings per GPU, S)
+    "cfg2": (4, 500_000, 2000),
+    "cfg5shard": (4, 250_000, 4096),
+    "small": (4, 20_000, 2000),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+BYTES_PER_SAMPLE = {"float64": 12, "float32": 8}  # SURVEY 8d line C (raw f32 in + Sv out)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="float64", choices=["float64", "float32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(dtype):
+    """Oracle chain (reference pass structure, NumPy fp64, one core) on a 4 x 2500 x 2000 slice of
+    the same synthetic recipe: compute_Sv then compute_MVBS."""
+    from oracle import calibrate as ocal
+    from oracle import commongrid as ogrid
+    from echopype_amd import synth
+
+    C, P, S = 4, 2500, 2000
+    d = synth.ek60_numpy(C, P, S)
+
+    def run():
+        gain = ocal.vend_cal_params_power(d["transmit_duration_nominal"], d["pulse_length"], d["gain_correction"])
+        sa = ocal.vend_cal_params_power(d["transmit_duration_nominal"], d["pulse_length"], d["sa_correction"])
+        sv, er = ocal.cal_power_ek(
+            d["backscatter_r"], sonar="EK60", cal_type="Sv", sample_interval=d["sample_interval"],
+            sound_speed=d["sound_speed_indicative"], absorption=d["absorption_indicative"],
+            transmit_power=d["transmit_power"], tau_nominal=d["transmit_duration_nominal"], gain=gain,
+            sa_correction=sa, psi=d["equivalent_beam_angle"], f_nominal=d["frequency_nominal"],
+            tau_eff=d["transmit_duration_nominal"][:, 0])
+        return ogrid.compute_MVBS(sv, er, d["ping_time"], "1m", "20s")
+
+    run()
+    ts = []
+    t_end = time.perf_counter() + 20.0
+    while len(ts) < 5 and (not ts or time.perf_counter() < t_end):
+        t0 = time.perf_counter()
+        run()
+        ts.append(time.perf_counter() - t0)
+    n = C * P * S
+    return {"value": n / float(np.median(ts)), "unit": "range-samples/s", "cores": 1, "kind": "port",
+            "sample": f"EK60 {C}ch x {P} pings x {S} range, compute_Sv + compute_MVBS(20s x 1m), NumPy fp64 "
+                      f"oracle (reference pass structure), median of {len(ts)} runs, host has {os.cpu_count()} cores"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with "
+                     f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from echopype_amd import ops, sharding, synth
+
+    C, P, S = WORKLOADS[args.workload]
+    dt = torch.float64 if args.dtype == "float64" else torch.float32
+    d = synth.ek60_device(C, P, S, seed=20260501 + rank)
+    # ping times of this shard: global ping index offset by rank (1 ping / s)
+    ns_local = d["ping_time_ns"] + rank * P * 1_000_000_000
+    bin_ns = 20_000_000_000
+    e0, n_t_global = sharding.global_time_grid(ns_local.cpu().numpy(), bin_ns)
+    first_bin, last_bin = sharding.local_bin_span(ns_local.cpu().numpy(), e0, bin_ns)
+    n_t = last_bin - first_bin + 1
+    e0_local = e0 + first_bin * bin_ns
+    # range grid: np.arange(0, max(echo_range) + 1, 1); echo_range max is analytic for this recipe
+    r_max = sharding.global_max(float((S - 1) * 2.56e-4 * float(d["sound_speed_indicative"].max()) / 2))
+    n_r = len(np.arange(0, r_max + 1.0, 1.0)) - 1
+    straddle = (P % 20) != 0  # shard edges cut a 20-ping bin?
+
+    sv = torch.empty((C, P, S), dtype=dt, device="cuda")
+    mvbs = torch.empty((C, n_t, n_r), dtype=dt, device="cuda")
+    tau0 = d["transmit_duration_nominal"][:, 0].contiguous()  # EK60 tau_eff = ping 0 (per shard = global here)
+    timers = [ops.Timer() for _ in range(args.steps)]
+
+    def step(timer=None):
+        coef = ops.power_coef_ek(
+            d["sample_interval"], d["transmit_duration_nominal"], d["transmit_power"],
+            d["sound_speed_indicative"], d["absorption_indicative"], d["gain_correction"], d["sa_correction"],
+            d["equivalent_beam_angle"], d["frequency_nominal"], tau0, pulse_length=d["pulse_length"],
+            gain_is_table=True, sa_is_table=True)
+        bs = ops.time_bin_offsets(ns_local, e0_local, bin_ns, n_t)
+        if timer is not None:
+            timer.start()
+        res = ops.sv_mvbs_fused(d["backscatter_r"], coef, bs, n_t, 1.0, n_r, dtype=dt, sv_out=sv,
+                                mvbs_out=mvbs, want_partials=straddle)
+        if timer is not None:
+            timer.stop()
+        if straddle and world > 1:
+            keep = sharding.merge_straddling_bins(res["sum"], res["cnt"], first_bin, last_bin)
+            mvbs.copy_(ops.mvbs_finalize(res["sum"], res["cnt"]))
+            del keep
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(timers[i])  # HIP events around the dominant kernel, recorded asynchronously
+    sync()
+    elapsed = time.perf_counter() - t0
+    # average launch duration of the dominant kernel over the timed region (events read after it)
+    kernel_ms = float(np.mean([tm.elapsed_ms() for tm in timers]))
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    samples_total = C * P * S * world
+    value = samples_total * args.steps / elapsed
+
+    if rank == 0:
+        bps = BYTES_PER_SAMPLE[args.dtype]
+        achieved = C * P * S * bps / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = f"{args.workload}:{args.dtype}"
+                if key in tj:
+                    traffic = tj[key]["bytes_per_launch"]
+            except Exception:  # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": "range-samples/sec through compute_Sv->compute_MVBS",
+            "value": value, "unit": "range-samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.dtype == "float64" else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"EK60 CW {C}ch x {P} pings x {S} range per GPU ({args.workload}), "
+                                   "fused compute_Sv -> compute_MVBS (20 s x 1 m), Sv + MVBS written",
+                       "pings_total": P * world, "sharding": f"ping_time x{world}",
+                       "collective": "none (shard edges on bin edges)" if not straddle else "edge-bin all-reduce"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "epa_fused::fused_sv_mvbs_kernel", "kernel_ms": kernel_ms,
+                         "bytes_per_sample": bps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.dtype)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
