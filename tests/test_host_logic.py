@@ -1,0 +1,208 @@
+"""Host-side logic of the drop-in (parameter assembly, bin edges, containers) -- CPU only.
+Checked against goldens from the reference's leaf functions, the oracle, pandas, and the
+reference's synthetic unit tests (restated)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import kat_fixtures as kf
+from oracle import calibrate as ocal
+
+from echopype_amd import echodata as ed_mod
+from echopype_amd import synth
+from echopype_amd.calibrate import cal_params, env_params
+from echopype_amd.calibrate import ek80_complex as ek
+from echopype_amd.calibrate.calibrate_azfp import CalibrateAZFP
+from echopype_amd.clean.utils import extract_dB
+from echopype_amd.commongrid import utils as gu
+from echopype_amd.utils import uwa
+from echopype_amd.xr_lite import DataArray, Dataset
+
+
+def test_uwa_matches_reference_goldens(leaf_goldens):
+    g = leaf_goldens
+    for src in ("AM", "FG", "AZFP"):
+        got = [uwa.calc_absorption(f, T, S, P, pH, formula_source=src) for f, T, S, P, pH in g["uwa_pts"]]
+        np.testing.assert_allclose(got, g[f"uwa_abs_{src}"], rtol=1e-14)
+    for src in ("Mackenzie", "AZFP"):
+        got = [uwa.calc_sound_speed(T, S, P, formula_source=src) for T, S, P in g["uwa_ss_pts"]]
+        np.testing.assert_allclose(got, g[f"uwa_ss_{src}"], rtol=1e-15)
+    np.testing.assert_allclose(uwa.calc_absorption(g["uwa_fvec"], 10, 35, 10, 8, formula_source="FG"),
+                               g["uwa_abs_FG_vec"], rtol=1e-14)
+    with pytest.raises(ValueError):
+        uwa.calc_absorption(38e3, formula_source="XX")
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_transmit_replica_matches_reference_goldens(leaf_goldens, i):
+    g = leaf_goldens
+    fs, tau, slope, f0, f1 = g["chan_params"][i]
+    for drop in (False, True):
+        y, _ = ek.tapered_chirp(fs, tau, slope, f0, f1, drop_last_hanning_zero=drop)
+        np.testing.assert_allclose(y, g[f"chirp{i}_drop{int(drop)}"], rtol=1e-13, atol=1e-15)
+    y, _ = ek.tapered_chirp(fs, tau, slope, f0, f1)
+    ytx, t = ek.filter_decimate_chirp(dict(wbt_fil=g["wbt_fil"], wbt_decifac=6, pc_fil=g["pc_fil"], pc_decifac=2), y, fs)
+    np.testing.assert_allclose(ytx, g[f"replica{i}"], rtol=1e-12, atol=1e-15)
+    mode = "CW" if f0 == f1 else "BB"
+    te = ek.get_tau_effective({"c": ytx}, {"c": 1 / np.diff(t[:2])}, mode)
+    np.testing.assert_allclose(te.values, g[f"tau_eff{i}"], rtol=1e-12)
+    np.testing.assert_allclose(ek.get_norm_fac({"c": ytx}).values, g[f"norm_fac{i}"], rtol=1e-13)
+
+
+def test_filter_coeff_extraction_drops_nan_padding():
+    # tests/calibrate/test_ek80_complex.py:15-75 restated: NaN-padded coefficient arrays
+    d = synth.ek80_numpy(2, 2, 32)
+    filt = synth.ek80_filters()
+    e = ed_mod.from_ek80_arrays(d, filt)
+    coeff = ek.get_filter_coeff(e["Vendor_specific"])
+    for ch in e["Vendor_specific"]["channel"].values:
+        np.testing.assert_array_equal(coeff[ch]["wbt_fil"], filt["wbt_fil"].astype(np.complex128))
+        np.testing.assert_array_equal(coeff[ch]["pc_fil"], filt["pc_fil"].astype(np.complex128))
+        assert coeff[ch]["wbt_decifac"] == 6 and coeff[ch]["pc_decifac"] == 2
+    assert ek.get_vend_filter_EK80(Dataset(coords={"channel": ["a"]}), "a", "WBT", "coeff") is None
+
+
+@pytest.mark.parametrize("tau,expected", kf.PULSE_CASES)
+@pytest.mark.parametrize("swap", [False, True])
+def test_get_vend_cal_params_power(tau, expected, swap):
+    # tests/calibrate/test_cal_params.py:751-868 (incl. the channel-order-differs cases)
+    vend = Dataset(coords={"channel": ["chA", "chB"], "pulse_length_bin": np.arange(4)})
+    vend["pulse_length"] = (("channel", "pulse_length_bin"), kf.PULSE_TABLE["pulse_length"])
+    vend["sa_correction"] = (("channel", "pulse_length_bin"), kf.PULSE_TABLE["table"])
+    order = [1, 0] if swap else [0, 1]
+    beam = Dataset(coords={"channel": [["chA", "chB"][i] for i in order], "ping_time": np.arange(4)})
+    beam["transmit_duration_nominal"] = (("channel", "ping_time"), tau[order])
+    got = cal_params.get_vend_cal_params_power(beam, vend, "sa_correction")
+    np.testing.assert_array_equal(got.values, expected[order])
+    with pytest.raises(ValueError, match="Unknown parameter"):
+        cal_params.get_vend_cal_params_power(beam, vend, "gain")
+    with pytest.raises(ValueError, match="does not exist in the Vendor_specific group"):
+        cal_params.get_vend_cal_params_power(beam, vend, "gain_correction")
+
+
+def test_harmonize_env_param_time():
+    # tests/calibrate/test_env_params.py:33-126
+    t1 = np.array(["2017-06-20T01:00:00", "2017-06-20T01:00:30", "2017-06-20T01:01:00"], "datetime64[ns]")
+    p = DataArray(np.array([0.0, 1, 2]), ("time1",), {"time1": t1}, name="p")
+    assert env_params.harmonize_env_param_time(5.0) == 5.0
+    with pytest.raises(ValueError):
+        env_params.harmonize_env_param_time(p, ping_time=None)
+    same = env_params.harmonize_env_param_time(p, ping_time=t1)
+    np.testing.assert_array_equal(same.values, p.values)
+    q = np.array(["2017-06-20T01:00:15"], "datetime64[ns]")
+    assert env_params.harmonize_env_param_time(p, ping_time=q).values[0] == 0.5
+    t_long = np.arange("2017-06-20T01:00:00", "2017-06-22T01:00:31", np.timedelta64(30, "s"), dtype="datetime64[ns]")
+    p2 = DataArray(np.arange(len(t_long), dtype=float), ("time1",), {"time1": t_long})
+    q2 = np.array(["2017-06-20T01:00:15", "2017-06-21T01:00:15"], "datetime64[ns]")
+    np.testing.assert_array_equal(env_params.harmonize_env_param_time(p2, ping_time=q2).values, [0.5, 2880.5])
+    one = DataArray(np.array([[7.0], [8.0]]), ("channel", "time1"), {"time1": t1[:1]})
+    assert env_params.harmonize_env_param_time(one, q).shape == (2,)
+
+
+def test_env_params_ek_precedence_and_errors():
+    d = synth.ek60_numpy(2, 6, 16)
+    e = ed_mod.from_ek60_arrays(d)
+    beam, env = e["Sonar/Beam_group1"], e["Environment"]
+    out = env_params.get_env_params_EK("EK60", beam, env, {})
+    np.testing.assert_array_equal(out["sound_speed"].values, d["sound_speed_indicative"])
+    assert "temperature" not in out and "formula_absorption" not in out
+    user = {"temperature": 8.0, "salinity": 34.0, "pressure": 50.0, "pH": 8.05}
+    out = env_params.get_env_params_EK("EK60", beam, env, user)
+    assert out["formula_sound_speed"] == "Mackenzie" and out["formula_absorption"] == "FG"
+    assert out["sound_speed"] == pytest.approx(uwa.calc_sound_speed(8.0, 34.0, 50.0))
+    out = env_params.get_env_params_EK("EK60", beam, env, {"sound_absorption": [0.01, 0.04]})
+    np.testing.assert_array_equal(out["sound_absorption"].values, [0.01, 0.04])
+    with pytest.raises(ValueError, match="sound_absorption"):
+        env_params.get_env_params_EK("EK60", beam, env, {"sound_absorption": 0.01})
+    with pytest.raises(ValueError, match="formula_absorption"):
+        env_params.get_env_params_EK("EK60", beam, env, {"formula_absorption": "AZFP"})
+    with pytest.raises(ValueError, match="'freq' is required"):
+        env_params.get_env_params_EK("EK80", beam, env, {})
+    with pytest.raises(ValueError, match="lengths of param value and channel do not match"):
+        env_params.get_env_params_EK("EK60", beam, env, {"sound_absorption": [0.01]})
+
+
+def test_cal_params_ek80_bb_scaling():
+    d = synth.ek80_numpy(2, 3, 32)
+    e = ed_mod.from_ek80_arrays(d, synth.ek80_filters())
+    beam, vend = e["Sonar/Beam_group1"], e["Vendor_specific"]
+    fc = DataArray(np.tile(((d["f_start"] + d["f_stop"]) / 2)[:, None], (1, 3)), ("channel", "ping_time"))
+    out = cal_params.get_cal_params_EK("BB", fc, beam, vend, {}, sonar_type="EK80")
+    fn = d["frequency_nominal"][:, None]
+    np.testing.assert_allclose(out["equivalent_beam_angle"].values, d["psi"][:, None] + 20 * np.log10(fn / fc.values))
+    np.testing.assert_allclose(out["beamwidth_alongship"].values, d["beamwidth_alongship"][:, None] * fn / fc.values)
+    np.testing.assert_allclose(out["angle_offset_alongship"].values, np.tile(d["angle_offset_alongship"][:, None], (1, 3)))
+    np.testing.assert_array_equal(out["impedance_transducer"].values, np.full((2, 3), 75.0))
+    np.testing.assert_array_equal(np.asarray(out["impedance_transceiver"].values), d["z_er"])
+    np.testing.assert_array_equal(out["receiver_sampling_frequency"].values, d["fs"])
+    # frequency-dependent gain table from the user: interpolated at the centre frequency
+    gtab = DataArray(np.array([[25.0, 27.0, 29.0]]), ("cal_channel_id", "cal_frequency"),
+                     {"cal_channel_id": np.array([beam["channel"].values[0]]), "cal_frequency": np.array([45e3, 67.5e3, 90e3])})
+    out = cal_params.get_cal_params_EK("BB", fc, beam, vend, {"gain_correction": gtab}, sonar_type="EK80")
+    assert out["gain_correction"].values[0, 0] == pytest.approx(27.0)
+    assert np.isnan(out["gain_correction"].values[1]).all()  # channel without a table, alternative = NaN
+    with pytest.raises(ValueError, match="waveform_mode must be 'CW' or 'BB'"):
+        cal_params.get_cal_params_EK("FM", fc, beam, vend, {})
+    with pytest.raises(TypeError):
+        cal_params.get_cal_params_EK(1, fc, beam, vend, {})
+
+
+def test_azfp_rows_reproduce_oracle_range():
+    d = synth.azfp_numpy(3, 5, 40)
+    e = ed_mod.from_azfp_arrays(d)
+    cal = CalibrateAZFP(e, {"salinity": d["salinity"], "pressure": d["pressure"]}, None)
+    for ct in ("Sv", "TS"):
+        rows = cal._rows(ct)
+        s = np.arange(40)[None, None, :]
+        R = (s * rows[..., 0:1]) * rows[..., 1:2] + rows[..., 2:3]
+        ss = uwa.calc_sound_speed(d["temperature"], d["salinity"], d["pressure"], "AZFP")
+        exp = ocal.range_azfp(40, cal_type=ct, sound_speed=np.tile(ss, (3, 1)), tau=d["transmit_duration_nominal"],
+                              n_avg=d["number_of_samples_per_average_bin"], dig_rate=d["digitization_rate"],
+                              lockout=d["lock_out_index"], C=3, P=5)
+        np.testing.assert_allclose(R, exp, rtol=1e-13)
+        np.testing.assert_allclose(rows[..., 7], -rows[..., 2] / rows[..., 1])
+
+
+@pytest.mark.parametrize("bin_str", ["20s", "7s", "1min", "0.5h", "250ms", "2D", "90s", "1h"])
+@pytest.mark.parametrize("start", ["2018-07-01T13:47:07.300000000", "2026-05-01T00:00:00", "2020-02-29T23:59:58.5"])
+def test_resample_edges_match_pandas(bin_str, start):
+    t0 = np.datetime64(start, "ns")
+    pt = t0 + (np.arange(300) * 0.7e9).astype("timedelta64[ns]")
+    e0, dt, n = gu.resample_edges(pt, bin_str)
+    idx = pd.Series(0, index=pd.DatetimeIndex(pt)).resample(bin_str).first().index
+    assert idx[0].value == e0 and len(idx) == n and pd.Timedelta(bin_str).value == dt
+
+
+def test_bin_string_parsing_and_errors():
+    assert gu._parse_x_bin("10m") == 10.0 and gu._parse_x_bin(" 0.5 M ") == 0.5
+    with pytest.raises(TypeError, match="'x_bin' must be a string"):
+        gu._parse_x_bin(10)
+    with pytest.raises(ValueError, match="Range bin must be in meters"):
+        gu._parse_x_bin("10km")
+    with pytest.raises(KeyError):
+        gu._parse_x_bin("10m", "foo")
+    assert gu.ping_time_bin_parsing_and_conversion("20s") == (20, "second")
+    assert gu.ping_time_bin_parsing_and_conversion("2min") == (2, "minute")
+    assert extract_dB("3.0dB") == 3.0 and extract_dB("-120db") == -120.0
+    with pytest.raises(TypeError):
+        extract_dB(3.0)
+    with pytest.raises(ValueError):
+        extract_dB("3 dB")
+
+
+def test_lite_containers():
+    ds = Dataset(coords={"channel": ["a", "b"], "ping_time": np.arange(3)})
+    ds["x"] = (("channel", "ping_time"), np.arange(6.0).reshape(2, 3), {"units": "m"})
+    assert ds["x"].dims == ("channel", "ping_time") and ds["x"].attrs["units"] == "m"
+    assert dict(ds.sizes) == {"channel": 2, "ping_time": 3} and "x" in ds and "ping_time" in ds
+    np.testing.assert_array_equal(ds.isel(ping_time=slice(0, 2))["x"].values, [[0, 1], [3, 4]])
+    with pytest.raises(ValueError, match="dimension"):
+        ds["bad"] = (("channel",), np.arange(3.0))
+    with pytest.raises(KeyError):
+        ds["nope"]
+    ds2 = ds.assign_attrs(a=1)
+    assert ds2.attrs == {"a": 1} and ds.attrs == {}
+    e = ed_mod.EchoData("EK60", {"Sonar/Beam_group1": ds})
+    assert e["Sonar/Beam_group1"] is ds and "Platform" in e
+    with pytest.raises(KeyError, match="no group"):
+        e["Vendor_specific"]
