@@ -5,7 +5,7 @@
 behind echopype's own function signatures.  Host code is Python; the (channel, ping_time,
 range_sample) arrays go through a C ABI (include/echopype_amd.h, loaded with ctypes) to hand-written
 HIP kernels.  There is no CPU fallback: importing the package loads libechopype_amd.so and fails
-loudly if it has not been built (``python -m echopype_amd.build``).
+loudly if it has not been built (``python echopype_amd/build.py``).
 """
 from . import _lib  # noqa: F401  (loads the HIP library; raises if missing)
 from . import calibrate, clean, commongrid, ops, synth, utils  # noqa: F401

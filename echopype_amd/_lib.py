@@ -36,7 +36,7 @@ class EpaError(RuntimeError):
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
-            f"{LIB_PATH} not found: build it with `python -m echopype_amd.build` "
+            f"{LIB_PATH} not found: build it with `python echopype_amd/build.py` "
             "(hipcc --offload-arch=gfx950).  echopype_amd has no CPU fallback."
         )
     return ctypes.CDLL(LIB_PATH)
@@ -73,6 +73,7 @@ SIGNATURES = {
                           _vp, _vp, _i, _vp],
     "epa_mvbs": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _d, _i, _u, _d, _vp, _vp, _vp, _i, _vp],
     "epa_selftest_lin_from_db": [_vp, _vp, _sz, _vp],
+    "epa_selftest_log10": [_vp, _vp, _sz, _vp],
     "epa_mvbs_finalize": [_vp, _vp, _sz, _d, _vp, _i, _vp],
     "epa_nanminmax": [_vp, _sz, _i, _vp, _vp, _vp],
     "epa_mvbs_index": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],

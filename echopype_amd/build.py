@@ -1,6 +1,7 @@
 """Build libechopype_amd.so (HIP, gfx950 only) in-tree with hipcc.
 
-    python -m echopype_amd.build [--force]
+    python echopype_amd/build.py [--force]      (run as a script: importing the package needs the
+                                                 library this script produces)
 
 The shared library is the product: there is no CPU fallback.  hipcc cross-compiles for gfx950
 without a GPU, so this runs in the authoring container and the built .so travels with the tree.
@@ -20,8 +21,9 @@ OBJDIR = os.path.join(HERE, "csrc", "_obj")
 
 SOURCES = ["runtime.hip", "power_coef.hip", "sv_power.hip", "block_reduce.hip", "fused_sv_mvbs.hip", "noise_apply.hip", "reduce_util.hip",
            "ek80_complex.hip"]
-HEADERS = ["epa_internal.h", "sample_math.h"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))
+EXTRA = os.environ.get("EPA_EXTRA_FLAGS", "").split()
+FLAGS = [*EXTRA, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 

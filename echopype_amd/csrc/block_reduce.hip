@@ -18,6 +18,7 @@
 
 #include <cstdlib>
 
+#include "fast_math.h"
 #include "sample_math.h"
 
 namespace {
@@ -50,6 +51,7 @@ struct ReduceArgs {
   uint32_t* cnt_out;
   int use_lds;
   unsigned cnt_off;  // byte offset of the count array in dynamic LDS
+  unsigned tab_off;  // byte offset of the exp/log tables (fast_math.h) in dynamic LDS
 };
 
 template <typename T>
@@ -114,13 +116,14 @@ __global__ __launch_bounds__(epa::kBlock) void block_reduce_kernel(ReduceArgs a)
   T* gsum = a.sum_out ? reinterpret_cast<T*>(a.sum_out) + cell0 : nullptr;
   uint32_t* gcnt = a.cnt_out ? a.cnt_out + cell0 : nullptr;
 
+  const epa::MathTabs mt = epa::build_math_tabs(smem + a.tab_off);
   if (use_lds) {
     for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
       lsum[i] = (T)0;
       lcnt[i] = 0u;
     }
-    __syncthreads();
   }
+  __syncthreads();
   T* asum = use_lds ? lsum : gsum;
   uint32_t* acnt = use_lds ? lcnt : gcnt;
 
@@ -207,12 +210,12 @@ __global__ __launch_bounds__(epa::kBlock) void block_reduce_kernel(ReduceArgs a)
         for (int j = 0; j < VEC; ++j) {
           T v;
           if (OP == OP_MVBS) {
-            v = epa::M<T>::exp10(sv[j] * (T)0.1);  // _log2lin, compute.py:14-27
+            v = epa::lin_from_db(sv[j], mt.exp2_tab);  // _log2lin, compute.py:14-27
           } else {
             // clean/api.py:397-401: where(R >= 1, R, 1) also maps NaN ranges to 1
             const T xr = (T)x[j];
-            const T tl = (T)20 * epa::M<T>::log10(xr >= (T)1 ? xr : (T)1) + a2 * xr;
-            v = epa::M<T>::exp10((sv[j] - tl) * (T)0.1);
+            const T tl = (T)20 * epa::fast_log10(xr >= (T)1 ? xr : (T)1, mt.log_tab) + a2 * xr;
+            v = epa::lin_from_db(sv[j] - tl, mt.exp2_tab);
           }
           if (phys) {
             // fast path: the column is still inside the bin it was in for the previous ping
@@ -391,7 +394,7 @@ namespace {
 struct Plan {
   int nparts, use_lds, vec;
   size_t lds_bytes;
-  unsigned cnt_off;
+  unsigned cnt_off, tab_off;
 };
 
 template <typename T>
@@ -405,8 +408,10 @@ Plan make_plan(int C, int P, int S, int n_tbins, int n_rbins, bool aligned16) {
   const size_t sum_bytes = ((size_t)n_rbins * sizeof(T) + 15) & ~(size_t)15;
   const size_t need = sum_bytes + (size_t)n_rbins * sizeof(uint32_t);
   pl.use_lds = need <= 128 * 1024;
-  pl.lds_bytes = pl.use_lds ? (need < 64 ? 64 : need) : 64;
+  const size_t acc_bytes = pl.use_lds ? (need < 64 ? 64 : need) : 64;
   pl.cnt_off = (unsigned)sum_bytes;
+  pl.tab_off = (unsigned)((acc_bytes + 15) & ~(size_t)15);
+  pl.lds_bytes = pl.tab_off + epa::kMathTabBytes;
   const long long groups = (long long)C * n_tbins;
   pl.nparts = 1;
   if (groups < 1024) {
@@ -426,6 +431,7 @@ int launch_reduce(ReduceArgs& a, const Plan& pl, hipStream_t st) {
   const dim3 block(epa::kBlock);
   a.use_lds = pl.use_lds;
   a.cnt_off = pl.cnt_off;
+  a.tab_off = pl.tab_off;
 #define EPA_RL(V)                                                                                 \
   do {                                                                                            \
     auto kern = block_reduce_kernel<T, SRC, OP, V>;                                               \
@@ -459,11 +465,12 @@ int run_mvbs(ReduceArgs& a, hipStream_t st) {
   const size_t cells = (size_t)a.C * a.n_tbins * a.n_rbins;
   const bool two_stage = pl.nparts > 1 || !pl.use_lds;
   if (SRC == SRC_RAW && !two_stage && pl.vec == 4 && !a.ping_perm && !a.range_out &&
+      a.cal_flags == (EPA_FLAG_GUARD_POS | EPA_FLAG_MASK_RANGE) && a.bin_flags == EPA_BIN_SKIPNA &&
       !getenv("EPA_NO_FAST_PATH"))
     return epa_fused_fast_path(a.raw, reinterpret_cast<const double*>(a.coef), a.C, a.P, a.S,
                                a.nspread, a.cal_flags, a.bin_start, a.n_tbins, a.range_bin,
                                a.n_rbins, a.bin_flags, a.fill_value, a.sv_out, a.out, a.sum_out,
-                               a.cnt_out, sizeof(T) == 8 ? EPA_F64 : EPA_F32, pl.lds_bytes,
+                               a.cnt_out, sizeof(T) == 8 ? EPA_F64 : EPA_F32, pl.tab_off,
                                pl.cnt_off, st);
   if (two_stage) {
     EPA_CHECK_ARG(a.sum_out && a.cnt_out,

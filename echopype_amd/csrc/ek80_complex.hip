@@ -19,7 +19,7 @@
 // applied) sits in LDS; each lane owns 8 consecutive outputs and slides a 16-element register
 // window over the staged tile (LDS rows padded 9/8 -> conflict-free ds_read_b64 / b128).
 // Not a GEMM, no MFMA (BASELINE north_star); vector-FP32/FP64 FMA bound (8*m flops / sample).
-#include "epa_internal.h"
+#include "fast_math.h"
 
 namespace {
 
@@ -46,7 +46,7 @@ struct CxArgs {
   void* out;
   void* range_out;
   void* prx_out;
-  unsigned rep_lds_off, mask_lds_off;  // byte offsets in dynamic LDS
+  unsigned rep_lds_off, mask_lds_off, tab_lds_off;  // byte offsets in dynamic LDS
   int stage_len;                       // kTile + max_taps - 1 (>= kTile)
 };
 
@@ -122,6 +122,7 @@ __global__ __launch_bounds__(epa::kBlock) void sv_complex_kernel(CxArgs a) {
   Cx<A>* xs = reinterpret_cast<Cx<A>*>(smem);
   Cx<A>* rep = reinterpret_cast<Cx<A>*>(smem + a.rep_lds_off);
   uint8_t* vmask = smem + a.mask_lds_off;
+  const epa::MathTabs mt = epa::build_math_tabs(smem + a.tab_lds_off);  // synchronised before use below
   __shared__ A red[8];
 
   const int c = blockIdx.y;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(epa::kBlock) void sv_complex_kernel(CxArgs a) {
     const double R = ((double)s * ra) * rb;  // range.py:138 operation order
     T rt = (T)R - shift;
     if (!(rt > (T)0)) rt = epa::M<T>::nan();
-    const T val = (T)10 * epa::M<T>::log10(prx) + nspread * epa::M<T>::log10(rt) + alpha2 * rt + Aadd;
+    const T val = (T)10 * epa::fast_log10(prx, mt.log_tab) + nspread * epa::fast_log10(rt, mt.log_tab) + alpha2 * rt + Aadd;
     const size_t o = row * S + s;
     out[o] = val;
     if (range_out) range_out[o] = (vmask[2 * (k0 + i) + 1] & 1u) ? (T)R : epa::M<T>::nan();
@@ -250,7 +251,8 @@ int launch(CxArgs& a, int max_taps, hipStream_t st) {
   const size_t mask_bytes = (size_t)2 * len;
   a.rep_lds_off = (unsigned)xs_bytes;
   a.mask_lds_off = (unsigned)(xs_bytes + rep_bytes);
-  const size_t lds = xs_bytes + rep_bytes + mask_bytes;
+  a.tab_lds_off = (unsigned)((xs_bytes + rep_bytes + mask_bytes + 15) & ~(size_t)15);
+  const size_t lds = a.tab_lds_off + epa::kMathTabBytes;
   EPA_CHECK_ARG(lds <= 150 * 1024, "epa_sv_complex: replica of %d taps does not fit the LDS tile",
                 max_taps);
   a.tiles = (a.S + kTile - 1) / kTile;

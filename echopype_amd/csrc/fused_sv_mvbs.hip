@@ -11,6 +11,7 @@
 // Reference lines replaced: see sv_power.hip and block_reduce.hip.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#include "fast_math.h"
 #include "sample_math.h"
 
 namespace epa_fused {
@@ -26,37 +27,6 @@ struct Args {
   unsigned cnt_off, tab_off;
 };
 
-// ---- 10^(u/10) for the linear-domain average -----------------------------------------------------
-// f64: 2^(u*K), K = log2(10)/10, argument reduced to m/256 + r/256 (|r| <= 1/2): 2^(m>>8) from the
-// exponent, 2^((m&255)/256) from a 256-entry LDS table (built per workgroup with the full-precision
-// exp2), 2^(r/256) from a degree-5 Taylor polynomial (|z| <= 1.4e-3 -> truncation < 1e-18 relative).
-// ~16 fp64 instructions instead of ~35 for ocml exp10, same 1-ulp class accuracy (checked by
-// epa_selftest_exp10 in the GPU tests).
-__device__ __forceinline__ double lin_from_db(double u, const double* __restrict__ tab) {
-  constexpr double K256_HI = 85.04135922911648;       // 256*log2(10)/10, rounded to double
-  constexpr double K256_LO = -4.272771985668806e-15;  // 256*log2(10)/10 - K256_HI
-  constexpr double Z = 0.0027076061740622863;         // ln(2)/256
-  const double t = u * K256_HI;
-  const double m = __builtin_rint(t);
-  double r = fma(u, K256_HI, -m);
-  r = fma(u, K256_LO, r);
-  const double z = r * Z;
-  double p = fma(z, 1.0 / 120.0, 1.0 / 24.0);
-  p = fma(p, z, 1.0 / 6.0);
-  p = fma(p, z, 0.5);
-  p = fma(p, z, 1.0);
-  p = fma(p, z, 1.0);
-  // |u| beyond ~ +-3000 dB saturates like exp10 (inf / 0); NaN propagates through t
-  const double mc = fmin(fmax(m, -300000.0), 300000.0);
-  const int mi = (int)mc;
-  const double v = ldexp(p * tab[mi & 255], mi >> 8);
-  // non-finite arguments: NaN -> NaN, +inf -> +inf, -inf -> 0 (as exp10)
-  return (fabs(t) < __builtin_inf()) ? v : (t < 0.0 ? 0.0 : t);
-}
-__device__ __forceinline__ float lin_from_db(float u, const double*) {
-  return epa::M<float>::exp10(u * 0.1f);
-}
-
 template <typename T>
 __device__ __noinline__ T log10_slow(T x) {
   return epa::M<T>::log10(x);
@@ -67,6 +37,69 @@ __device__ __forceinline__ void lds_add(T* p, T v) {
   unsafeAtomicAdd(p, v);
 }
 
+// Lane-private state of one range column (kept across the pings of a time bin).
+template <typename T>
+struct Column {
+  double sra;       // fl(s * ra): first factor of the range product (range.py:138 order)
+  double blo, bhi;  // edges of the range bin the column currently sits in (empty: blo > bhi)
+  T nL;             // n * log10(s - d)
+  T acc_sum;
+  int acc_rb;
+  uint32_t acc_cnt;
+  __device__ __forceinline__ void init() {
+    sra = 0.0; blo = 1.0; bhi = 0.0; nL = epa::M<T>::nan(); acc_sum = (T)0; acc_rb = -1; acc_cnt = 0u;
+  }
+  __device__ __forceinline__ void flush(T* lsum, uint32_t* lcnt) {
+    if (acc_rb >= 0 && acc_cnt > 0u) {
+      lds_add(lsum + acc_rb, acc_sum);
+      atomicAdd(lcnt + acc_rb, acc_cnt);
+    }
+  }
+};
+
+// One sample: echo_range, R', Sv, linear value, bin membership, private accumulation.
+// Compile-time flags of the hot instantiation = the EK default (R' <= 0 guard, range masked by NaN
+// input, skipna, left-closed bins); any other combination runs the generic kernel (block_reduce.hip).
+template <typename T>
+__device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::CoefRow& r, T g, T a2,
+                                            T A0, T nspread, double bin, double inv_bin, int n_rbins,
+                                            const double* tab, T* lsum, uint32_t* lcnt) {
+  const T NaN = epa::M<T>::nan();
+  const double x = c.sra * r.rb + r.r0;  // echo_range = (s*ra)*rb [+0]
+  const double rtd = x - r.shift;
+  const T rt = (T)rtd;
+  const bool pos = rtd > 0.0;
+  T spread = c.nL;
+  if (pos & !(spread > -(T)__builtin_inf()))  // rounding residue of R - shift (rare)
+    spread = nspread * (log10_slow<T>(rt) - log10_slow<T>((T)(r.ra * r.rb)));
+  spread = pos ? spread : NaN;
+  const T sv = fma(g, (T)raw, spread) + fma(a2, rt, A0);
+  const T v = epa::lin_from_db(sv, tab);
+  // still inside the bin of the previous ping?  NaN raw -> NaN echo_range: never inside
+  const bool xok = raw == raw;
+  const bool same = xok & (x >= c.blo) & (x < c.bhi);
+  if (!same) {
+    const int rb = xok ? epa::range_bin_index(x, bin, inv_bin, n_rbins, false) : -1;
+    if (rb != c.acc_rb) {
+      c.flush(lsum, lcnt);
+      c.acc_rb = rb;
+      c.acc_sum = (T)0;
+      c.acc_cnt = 0u;
+    }
+    c.blo = rb >= 0 ? (double)rb * bin : 1.0;
+    c.bhi = rb >= 0 ? (double)(rb + 1) * bin : 0.0;
+  }
+  const bool take = (c.acc_rb >= 0) & (v == v);
+  c.acc_sum += take ? v : (T)0;
+  c.acc_cnt += take ? 1u : 0u;
+  return sv;
+}
+
+// Lane -> sample mapping inside a 1024-sample chunk (4 waves x 256 samples): lane l of wave w owns
+// the two PAIRS {base + 2l, +1} and {base + 128 + 2l, +1}, base = chunk0 + 256 w.  Every load
+// (8 B/lane) and every store (16 B/lane f64) of a wave is then one contiguous 512 B / 1 KiB
+// segment -- the 4-consecutive-samples-per-lane layout makes each f64 store instruction touch
+// only half of every 128-B line.
 template <typename T, bool WRITE_SV>
 __global__ __launch_bounds__(epa::kBlock) void fused_sv_mvbs_kernel(
     const float* __restrict__ raw, const epa::CoefRow* __restrict__ coef,
@@ -75,8 +108,8 @@ __global__ __launch_bounds__(epa::kBlock) void fused_sv_mvbs_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* lsum = reinterpret_cast<T*>(smem);
   uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + a.cnt_off);
-  double* tab = reinterpret_cast<double*>(smem + a.tab_off);
-  if (sizeof(T) == 8) tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 256.0));  // kBlock == 256
+  const epa::MathTabs mt = epa::build_math_tabs(smem + a.tab_off);  // synchronised below
+  const double* tab = mt.exp2_tab;
 
   const int c = blockIdx.y, tb = blockIdx.x;
   const int S = a.S, n_rbins = a.n_rbins;
@@ -88,87 +121,62 @@ __global__ __launch_bounds__(epa::kBlock) void fused_sv_mvbs_kernel(
   __syncthreads();
 
   const T nspread = (T)a.nspread;
-  const bool guard = a.guard, mask_range = a.mask_range, skipna = a.skipna, cr = a.closed_right;
   const double bin = a.range_bin, inv_bin = a.inv_range_bin;
-  const T NaN = epa::M<T>::nan();
   const epa::CoefRow* __restrict__ rowp0 = coef + (size_t)c * a.P;
   const float* __restrict__ raw_c = raw + (size_t)c * a.P * S;
   T* __restrict__ sv_c = WRITE_SV ? sv_out + (size_t)c * a.P * S : nullptr;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
   for (int chunk0 = 0; chunk0 < S; chunk0 += kChunk) {
-    const int s0 = chunk0 + threadIdx.x * VEC;
-    if (s0 >= S) continue;
-    double sdbl[VEC], blo[VEC], bhi[VEC];
-    T nL[VEC], acc_sum[VEC];
-    int acc_rb[VEC];
-    uint32_t acc_cnt[VEC];
-    double dcur = __builtin_nan("");
+    const int sA = chunk0 + wave * 256 + 2 * lane;  // first sample of pair A
+    const int sB = sA + 128;                        // first sample of pair B
+    if (sA >= S) continue;
+    const bool hasB = sB < S;
+    Column<T> col[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      sdbl[j] = (double)(s0 + j);
-      blo[j] = 1.0;
-      bhi[j] = 0.0;
-      nL[j] = NaN;
-      acc_sum[j] = (T)0;
-      acc_rb[j] = -1;
-      acc_cnt[j] = 0u;
-    }
+    for (int j = 0; j < VEC; ++j) col[j].init();
+    double dcur = __builtin_nan(""), racur = __builtin_nan("");
     for (int p = pb; p < pe; ++p) {
       const epa::CoefRow r = rowp0[p];  // wave-uniform address -> scalar loads
-      const size_t off = (size_t)p * S + s0;
-      const float4 in4 = *reinterpret_cast<const float4*>(raw_c + off);
-      const float in[VEC] = {in4.x, in4.y, in4.z, in4.w};
-      if (!(r.d == dcur)) {  // uniform; once per column for a file with constant tau / interval
-        dcur = r.d;
-        for (int j = 0; j < VEC; ++j) nL[j] = nspread * log10_slow<T>((T)(sdbl[j] - r.d));
+      const size_t row_off = (size_t)p * S;
+      const float2 inA = *reinterpret_cast<const float2*>(raw_c + row_off + sA);
+      float2 inB = make_float2(0.f, 0.f);
+      if (hasB) inB = *reinterpret_cast<const float2*>(raw_c + row_off + sB);
+      if (!((r.d == dcur) & (r.ra == racur))) {  // uniform; once per column for a file with
+        dcur = r.d;                               // constant tau / sample_interval
+        racur = r.ra;
+        for (int j = 0; j < VEC; ++j) {
+          const double sj = (double)((j < 2 ? sA : sB) + (j & 1));
+          col[j].nL = nspread * log10_slow<T>((T)(sj - r.d));
+          col[j].sra = sj * r.ra;
+        }
       }
       const T g = (T)r.g, a2 = (T)r.alpha2, A0 = (T)r.A0;
-      T sv[VEC];
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        const double x = (sdbl[j] * r.ra) * r.rb + r.r0;  // echo_range, range.py:138 order
-        const double rtd = x - r.shift;
-        const T rt = (T)rtd;
-        T spread = nL[j];
-        if (guard) {
-          const bool pos = rtd > 0.0;
-          if (pos && !(spread > -(T)__builtin_inf()))  // rounding residue of R - shift (rare)
-            spread = nspread * (log10_slow<T>(rt) - log10_slow<T>((T)(r.ra * r.rb)));
-          spread = pos ? spread : NaN;
-        }
-        sv[j] = fma(g, (T)in[j], spread) + fma(a2, rt, A0);
-        const T v = lin_from_db(sv[j], tab);
-        // range-bin membership: still inside the bin of the previous ping?  (NaN raw -> NaN range
-        // when masked: never inside)
-        const bool xok = !mask_range || (in[j] == in[j]);
-        const bool same = xok && (cr ? (x > blo[j] && x <= bhi[j]) : (x >= blo[j] && x < bhi[j]));
-        if (!same) {
-          const int rb = xok ? epa::range_bin_index(x, bin, inv_bin, n_rbins, cr) : -1;
-          if (rb != acc_rb[j]) {
-            if (acc_rb[j] >= 0 && acc_cnt[j] > 0u) {
-              lds_add(lsum + acc_rb[j], acc_sum[j]);
-              atomicAdd(lcnt + acc_rb[j], acc_cnt[j]);
-            }
-            acc_rb[j] = rb;
-            acc_sum[j] = (T)0;
-            acc_cnt[j] = 0u;
-          }
-          blo[j] = rb >= 0 ? (double)rb * bin : 1.0;
-          bhi[j] = rb >= 0 ? (double)(rb + 1) * bin : 0.0;
-        }
-        const bool take = (acc_rb[j] >= 0) && (!skipna || v == v);
-        acc_sum[j] += take ? v : (T)0;
-        acc_cnt[j] += take ? 1u : 0u;
+      const T sv0 = process_sample<T>(col[0], inA.x, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt);
+      const T sv1 = process_sample<T>(col[1], inA.y, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt);
+      if (WRITE_SV) {
+#ifndef EPA_PLAIN_STORES  // streaming (nt) stores: +2 % at 4 G samples, Sv is never re-read here
+        epa::store_nt2(sv_c + row_off + sA, sv0, sv1);
+#else
+        const T o[2] = {sv0, sv1};
+        epa::store_vec<T, 2>(sv_c + row_off + sA, o);
+#endif
       }
-      if (WRITE_SV) epa::store_vec<T, VEC>(sv_c + off, sv);
-    }
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      if (acc_rb[j] >= 0 && acc_cnt[j] > 0u) {
-        lds_add(lsum + acc_rb[j], acc_sum[j]);
-        atomicAdd(lcnt + acc_rb[j], acc_cnt[j]);
+      if (hasB) {
+        const T sv2 = process_sample<T>(col[2], inB.x, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt);
+        const T sv3 = process_sample<T>(col[3], inB.y, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt);
+        if (WRITE_SV) {
+#ifndef EPA_PLAIN_STORES  // streaming (nt) stores: +2 % at 4 G samples, Sv is never re-read here
+          epa::store_nt2(sv_c + row_off + sB, sv2, sv3);
+#else
+          const T o[2] = {sv2, sv3};
+          epa::store_vec<T, 2>(sv_c + row_off + sB, o);
+#endif
+        }
       }
     }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) col[j].flush(lsum, lcnt);
   }
   __syncthreads();
   const size_t cell0 = ((size_t)c * a.n_tbins + tb) * n_rbins;
@@ -189,7 +197,7 @@ int launch(Args& a, const float* raw, const double* coef, const int32_t* bin_sta
            void* mvbs_out, void* sum_out, uint32_t* cnt_out, int C, size_t lds_bytes, hipStream_t st) {
   const dim3 grid((unsigned)a.n_tbins, (unsigned)C);
   a.tab_off = (unsigned)((lds_bytes + 15) & ~(size_t)15);
-  lds_bytes = a.tab_off + 256 * sizeof(double);
+  lds_bytes = a.tab_off + epa::kMathTabBytes;
 #define EPA_FL(W)                                                                              \
   do {                                                                                         \
     auto kern = fused_sv_mvbs_kernel<T, W>;                                                    \
@@ -209,12 +217,23 @@ int launch(Args& a, const float* raw, const double* coef, const int32_t* bin_sta
 __global__ __launch_bounds__(epa::kBlock) void selftest_lin_kernel(const double* __restrict__ u,
                                                                    double* __restrict__ out,
                                                                    size_t n) {
-  __shared__ double tab[256];
-  tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 256.0));
+  __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
+  const epa::MathTabs mt = epa::build_math_tabs(tabs);
   __syncthreads();
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x)
-    out[i] = lin_from_db(u[i], tab);
+    out[i] = epa::lin_from_db(u[i], mt.exp2_tab);
+}
+
+__global__ __launch_bounds__(epa::kBlock) void selftest_log_kernel(const double* __restrict__ x,
+                                                                   double* __restrict__ out,
+                                                                   size_t n) {
+  __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
+  const epa::MathTabs mt = epa::build_math_tabs(tabs);
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    out[i] = epa::fast_log10(x[i], mt.log_tab);
 }
 
 }  // namespace epa_fused
@@ -226,6 +245,15 @@ extern "C" int epa_selftest_lin_from_db(const double* u, double* out, size_t n, 
   hipLaunchKernelGGL(epa_fused::selftest_lin_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)),
                      dim3(epa::kBlock), 0, (hipStream_t)stream, u, out, n);
   return epa::check_launch("selftest_lin_kernel");
+}
+
+extern "C" int epa_selftest_log10(const double* x, double* out, size_t n, epa_stream_t stream) {
+  EPA_CHECK_ARG(x && out, "epa_selftest_log10: NULL array argument");
+  if (n == 0) return EPA_OK;
+  const size_t blocks = (n + epa::kBlock - 1) / epa::kBlock;
+  hipLaunchKernelGGL(epa_fused::selftest_log_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)),
+                     dim3(epa::kBlock), 0, (hipStream_t)stream, x, out, n);
+  return epa::check_launch("selftest_log_kernel");
 }
 
 // Called by epa_sv_mvbs_fused (block_reduce.hip) when the fast path applies.

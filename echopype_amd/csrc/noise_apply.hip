@@ -7,6 +7,7 @@
 //   L         = 10^(Sv/10) - 10^(Sv_noise/10);  Sv_corr = 10*log10(L) if L > 0 else NaN
 //   Sv_corr   = NaN unless Sv_corr - Sv_noise > SNR_threshold
 // HBM-bound: reads Sv (+ echo_range unless affine), writes Sv_noise and Sv_corrected.
+#include "fast_math.h"
 #include "sample_math.h"
 
 namespace {
@@ -18,6 +19,9 @@ __global__ __launch_bounds__(epa::kBlock) void noise_apply_kernel(
     long long rows, int chunks_per_row, int ping_num, int n_pblocks, T snr,
     T* __restrict__ sv_noise, T* __restrict__ sv_corr) {
   constexpr int kChunk = epa::kBlock * VEC;
+  __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
+  const epa::MathTabs mt = epa::build_math_tabs(tabs);
+  __syncthreads();
   const long long items = rows * chunks_per_row;
   for (long long item = blockIdx.x; item < items; item += gridDim.x) {
     const long long row = item / chunks_per_row;
@@ -39,10 +43,10 @@ __global__ __launch_bounds__(epa::kBlock) void noise_apply_kernel(
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      const T tl = (T)20 * epa::M<T>::log10(x[j] >= (T)1 ? x[j] : (T)1) + a2 * x[j];
+      const T tl = (T)20 * epa::fast_log10(x[j] >= (T)1 ? x[j] : (T)1, mt.log_tab) + a2 * x[j];
       const T sn = nb + tl;
-      const T lin = epa::M<T>::exp10(v[j] * (T)0.1) - epa::M<T>::exp10(sn * (T)0.1);
-      T corr = lin > (T)0 ? (T)10 * epa::M<T>::log10(lin) : epa::M<T>::nan();
+      const T lin = epa::lin_from_db(v[j], mt.exp2_tab) - epa::lin_from_db(sn, mt.exp2_tab);
+      T corr = lin > (T)0 ? (T)10 * epa::fast_log10(lin, mt.log_tab) : epa::M<T>::nan();
       if (!(corr - sn > snr)) corr = epa::M<T>::nan();
       on[j] = sn;
       oc[j] = corr;

@@ -96,6 +96,19 @@ struct RawVec<1> {
   __device__ __forceinline__ void load(const float* p) { v[0] = *p; }
 };
 
+// Streaming (non-temporal) stores for outputs that are written once and not re-read by the kernel.
+typedef double epa_d2 __attribute__((ext_vector_type(2)));
+typedef float epa_f2 __attribute__((ext_vector_type(2)));
+typedef float epa_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_nt2(double* p, double a, double b) {
+  epa_d2 v = {a, b};
+  __builtin_nontemporal_store(v, reinterpret_cast<epa_d2*>(p));
+}
+__device__ __forceinline__ void store_nt2(float* p, float a, float b) {
+  epa_f2 v = {a, b};
+  __builtin_nontemporal_store(v, reinterpret_cast<epa_f2*>(p));
+}
+
 template <typename T, int VEC>
 __device__ __forceinline__ void store_vec(T* p, const T (&v)[VEC]);
 template <>

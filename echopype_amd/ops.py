@@ -167,6 +167,12 @@ def selftest_lin_from_db(u):
     return out
 
 
+def selftest_log10(x):
+    out = torch.empty_like(x)
+    call("epa_selftest_log10", _p(x), _p(out), x.numel(), _stream())
+    return out
+
+
 def mvbs_finalize(ssum, cnt, fill_value=float("nan")):
     out = torch.empty_like(ssum)
     call("epa_mvbs_finalize", _p(ssum), _p(cnt), ssum.numel(), float(fill_value), _p(out),

@@ -264,6 +264,25 @@ def test_fast_exp10_accuracy(env):
     assert got[u == 3100.0][0] == np.inf and got[u == -3300.0][0] == 0.0
 
 
+def test_fast_log10_accuracy(env):
+    """Table-driven f64 log10 vs an extended-precision reference: absolute error <= 2e-16 * max(1, |log10 x|)."""
+    torch, ops, _ = env
+    rng = np.random.default_rng(4)
+    x = np.concatenate([10 ** rng.uniform(-30, 30, 200000), rng.uniform(0.5, 2.0, 100000),
+                        1 + rng.uniform(-1e-6, 1e-6, 1000), 2.0 ** np.arange(-1000, 1000, 37.0),
+                        np.array([1.0, 2.0, 0.5, np.sqrt(2), 10.0, 5e-324, 1e-310, 0.0, -1.0, np.inf, np.nan])])
+    got = ops.selftest_log10(_dev(torch, x)).cpu().numpy()
+    with np.errstate(all="ignore"):
+        exp = np.log10(np.longdouble(x)).astype(np.longdouble)
+    fin = np.isfinite(x) & (x > 0)
+    err = np.abs(np.longdouble(got[fin]) - exp[fin]).astype(np.float64)
+    bound = 2.3e-16 * np.maximum(1.0, np.abs(exp[fin].astype(np.float64)))
+    assert (err <= bound).all(), float((err / bound).max())
+    assert got[x == 1.0][0] == 0.0 and abs(got[x == 10.0][0] - 1.0) < 3e-16
+    assert got[x == 0.0][0] == -np.inf and np.isnan(got[x == -1.0][0]) and got[x == np.inf][0] == np.inf
+    assert np.isnan(got[np.isnan(x)]).all()
+
+
 def test_argument_errors_from_c_abi(env):
     torch, ops, synth = env
     d = synth.ek60_numpy(1, 4, 64)
