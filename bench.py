@@ -32,6 +32,7 @@ WORKLOADS = {
     "cfg2": (4, 500_000, 2000),
     "cfg5shard": (4, 250_000, 4096),
     "small": (4, 20_000, 2000),
+    "straddle": (4, 20_010, 2000),  # shard edges cut a time bin: exercises the edge-bin all-reduce
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_SAMPLE = {"float64": 12, "float32": 8}  # SURVEY 8d line C (raw f32 in + Sv out)
@@ -45,6 +46,10 @@ def parse():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="float64", choices=["float64", "float32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend (nccl = RCCL; gloo only for dry runs of the N>1 logic)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="dry run: every rank uses cuda:0 (with --backend gloo)")
     return ap.parse_args()
 
 
@@ -94,10 +99,15 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with "
                      f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from echopype_amd import ops, sharding, synth
 
@@ -156,8 +166,9 @@ def main():
     # average launch duration of the dominant kernel over the timed region (events read after it)
     kernel_ms = float(np.mean([tm.elapsed_ms() for tm in timers]))
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64)
     if world > 1:
+        t = t.to(sharding._comm_device())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     samples_total = C * P * S * world

@@ -89,24 +89,26 @@ def merge_straddling_bins(ssum, cnt, first_bin, last_bin, group=None):
     if world == 1 or n_local == 0 and world == 1:
         return keep
     dev = ssum.device
+    # collectives run on the backend's device (GPU for RCCL, host for gloo); partials may live elsewhere
+    cdev = _comm_device() if dist.get_backend(group) != "nccl" or not ssum.is_cuda else dev
     C, _, R = ssum.shape
     # 1. everyone learns every rank's (first, last) global bin ids
-    ids = torch.full((world, 2), -1, dtype=torch.int64, device=dev)
+    ids = torch.full((world, 2), -1, dtype=torch.int64, device=cdev)
     if n_local > 0:
         ids[rank, 0], ids[rank, 1] = first_bin, last_bin
-    span = torch.zeros((world, 2), dtype=torch.int64, device=dev)
+    span = torch.zeros((world, 2), dtype=torch.int64, device=cdev)
     span[rank] = ids[rank] + 1  # +1 so that "no bins" (-1) sums as 0
     dist.all_reduce(span, op=dist.ReduceOp.SUM, group=group)
     span = (span - 1).cpu().numpy()
     # 2. one all-reduce over the edge-bin partials (slot 2r = first bin of rank r, 2r+1 = last)
-    buf_s = torch.zeros((2 * world, C, R), dtype=ssum.dtype, device=dev)
-    buf_c = torch.zeros((2 * world, C, R), dtype=torch.int64, device=dev)
+    buf_s = torch.zeros((2 * world, C, R), dtype=ssum.dtype, device=cdev)
+    buf_c = torch.zeros((2 * world, C, R), dtype=torch.int64, device=cdev)
     if n_local > 0:
-        buf_s[2 * rank] = ssum[:, 0]
-        buf_c[2 * rank] = cnt[:, 0].to(torch.int64)
+        buf_s[2 * rank] = ssum[:, 0].to(cdev)
+        buf_c[2 * rank] = cnt[:, 0].to(cdev, torch.int64)
         if n_local > 1:  # a single local bin is contributed once
-            buf_s[2 * rank + 1] = ssum[:, -1]
-            buf_c[2 * rank + 1] = cnt[:, -1].to(torch.int64)
+            buf_s[2 * rank + 1] = ssum[:, -1].to(cdev)
+            buf_c[2 * rank + 1] = cnt[:, -1].to(cdev, torch.int64)
     dist.all_reduce(buf_s, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(buf_c, op=dist.ReduceOp.SUM, group=group)
     if n_local == 0:
@@ -124,9 +126,9 @@ def merge_straddling_bins(ssum, cnt, first_bin, last_bin, group=None):
         owners = sorted({int(s) // 2 for s in slots})
         if len(owners) <= 1:
             continue
-        idx = torch.as_tensor(slots, device=dev)
-        ssum[:, j] = buf_s.index_select(0, idx).sum(dim=0)
-        cnt[:, j] = buf_c.index_select(0, idx).sum(dim=0).to(cnt.dtype)
+        idx = torch.as_tensor(slots, device=cdev)
+        ssum[:, j] = buf_s.index_select(0, idx).sum(dim=0).to(dev)
+        cnt[:, j] = buf_c.index_select(0, idx).sum(dim=0).to(dev, cnt.dtype)
         if owners[0] != rank:
             keep[j] = False
         if n_local == 1:

@@ -195,6 +195,42 @@ def test_mvbs_few_bins_two_stage_path(env):
     _assert_close(res["MVBS"].cpu().numpy(), exp, 1e-10, "two-stage")
 
 
+def test_mvbs_range_grid_larger_than_lds(env):
+    """20 000 range bins do not fit the LDS budget: accumulation falls back to global atomics."""
+    torch, ops, _ = env
+    d = kf.sv_regular(2, 2000, 0.5, 120, "1s")
+    d["Sv"][0, 7, 100:300] = np.nan
+    exp, _, r_left = ogrid.compute_MVBS(d["Sv"], d["echo_range"], d["ping_time"], "0.05m", "30s")
+    assert len(r_left) > 16000
+    bs, n_t = _time_bins(torch, ops, d["ping_time"], "30s")
+    res = ops.mvbs(_dev(torch, d["Sv"]), bs, n_t, 0.05, len(r_left), range=_dev(torch, d["echo_range"]))
+    _assert_close(res["MVBS"].cpu().numpy(), exp, 1e-10, "global-atomics path")
+    # the fused entry point takes the same fallback (generic kernel) for such a grid
+    d2 = env[2].ek60_numpy(1, 40, 2000)
+    sv, er = _oracle_ek60(d2, "Sv")
+    exp2, _, r_left2 = ogrid.compute_MVBS(sv, er, d2["ping_time"], "0.01m", "20s")
+    bs2, n_t2 = _time_bins(torch, ops, d2["ping_time"], "20s")
+    res2 = ops.sv_mvbs_fused(_dev(torch, d2["backscatter_r"]), _coef_ek60(torch, ops, d2, "Sv"), bs2, n_t2, 0.01,
+                             len(r_left2))
+    _assert_close(res2["MVBS"].cpu().numpy(), exp2, 1e-10, "fused, global-atomics path")
+    _assert_close(res2["Sv"].cpu().numpy(), sv, 1e-9, "fused Sv")
+
+
+def test_fused_flag_combinations_take_generic_kernel(env):
+    """closed='right' / skipna=False / TS are served by the generic kernel: same answers."""
+    torch, ops, synth = env
+    d = synth.ek60_numpy(2, 90, 512)
+    coef = _coef_ek60(torch, ops, d, "Sv")
+    sv, er = _oracle_ek60(d, "Sv")
+    for closed, skipna in (("right", True), ("left", False), ("right", False)):
+        exp, _, r_left = ogrid.compute_MVBS(sv, er, d["ping_time"], "1m", "20s", closed=closed, skipna=skipna)
+        bs, n_t = _time_bins(torch, ops, d["ping_time"], "20s", closed)
+        res = ops.sv_mvbs_fused(_dev(torch, d["backscatter_r"]), coef, bs, n_t, 1.0, len(r_left), closed=closed,
+                                skipna=skipna)
+        _assert_close(res["MVBS"].cpu().numpy(), exp, 1e-9, f"closed={closed} skipna={skipna}")
+        _assert_close(res["Sv"].cpu().numpy(), sv, 1e-9, "Sv")
+
+
 def test_mvbs_index_binning_kat(env):
     # test_commongrid_api.py:171-202 shape (4,100,4000) with ping_num=3, range_sample_num=7
     torch, ops, _ = env
