@@ -96,20 +96,10 @@ __global__ __launch_bounds__(epa::kBlock) void block_reduce_kernel(ReduceArgs a)
   const int c = blockIdx.y;
   const int tb = blockIdx.x / a.nparts;
   const int part = blockIdx.x - tb * a.nparts;
-  int pb, pe;
-  if (a.bin_start) {
-    pb = a.bin_start[tb];
-    pe = a.bin_start[tb + 1];
-  } else {
-    pb = tb * a.ping_num;
-    pe = min(a.P, pb + a.ping_num);
-  }
-  if (a.nparts > 1) {
-    const int per = (pe - pb + a.nparts - 1) / a.nparts;
-    const int b2 = pb + part * per;
-    pe = min(pe, b2 + per);
-    pb = b2;
-  }
+  // tb == n_tbins (fused source only): pings that belong to no time bin still get their Sv/echo_range
+  const bool extra = tb == a.n_tbins;
+  if (extra && (part != 0 || !(a.sv_out || a.range_out))) return;
+  const int nseg = extra ? 2 : 1;
   const int S = a.S, n_rbins = a.n_rbins;
   const bool use_lds = a.use_lds != 0;
   const size_t cell0 = ((size_t)c * a.n_tbins + tb) * n_rbins;
@@ -138,6 +128,24 @@ __global__ __launch_bounds__(epa::kBlock) void block_reduce_kernel(ReduceArgs a)
   T* sv_out = reinterpret_cast<T*>(a.sv_out);
   T* range_out = reinterpret_cast<T*>(a.range_out);
 
+  for (int seg = 0; seg < nseg; ++seg) {
+  int pb, pe;
+  if (extra) {
+    pb = seg == 0 ? 0 : a.bin_start[a.n_tbins];
+    pe = seg == 0 ? a.bin_start[0] : a.P;
+  } else if (a.bin_start) {
+    pb = a.bin_start[tb];
+    pe = a.bin_start[tb + 1];
+  } else {
+    pb = tb * a.ping_num;
+    pe = min(a.P, pb + a.ping_num);
+  }
+  if (a.nparts > 1 && !extra) {
+    const int per = (pe - pb + a.nparts - 1) / a.nparts;
+    const int b2 = pb + part * per;
+    pe = min(pe, b2 + per);
+    pb = b2;
+  }
   for (int chunk0 = 0; chunk0 < S; chunk0 += kChunk) {
     const int s0 = chunk0 + threadIdx.x * VEC;
     if (s0 < S) {
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(epa::kBlock) void block_reduce_kernel(ReduceArgs a)
                                                             n_rbins, closed_right)
                                     : -1;
               if (rb != acc_rb[j]) {
-                if (acc_rb[j] >= 0 && acc_cnt[j] > 0u) {
+                if (acc_rb[j] >= 0 && acc_cnt[j] > 0u && !extra) {
                   atomic_add(asum + acc_rb[j], acc_sum[j]);
                   atomicAdd(acnt + acc_rb[j], acc_cnt[j]);
                 }
@@ -249,15 +257,19 @@ __global__ __launch_bounds__(epa::kBlock) void block_reduce_kernel(ReduceArgs a)
           }
         }
       }
+      if (!extra) {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        if (acc_rb[j] >= 0 && acc_cnt[j] > 0u) {
-          atomic_add(asum + acc_rb[j], acc_sum[j]);
-          atomicAdd(acnt + acc_rb[j], acc_cnt[j]);
+        for (int j = 0; j < VEC; ++j) {
+          if (acc_rb[j] >= 0 && acc_cnt[j] > 0u) {
+            atomic_add(asum + acc_rb[j], acc_sum[j]);
+            atomicAdd(acnt + acc_rb[j], acc_cnt[j]);
+          }
         }
       }
     }
   }
+  }
+  if (extra) return;
 
   if (!use_lds) return;  // accumulated straight into global partials; a finalize kernel follows
   __syncthreads();
@@ -427,7 +439,9 @@ Plan make_plan(int C, int P, int S, int n_tbins, int n_rbins, bool aligned16) {
 
 template <typename T, int SRC, int OP>
 int launch_reduce(ReduceArgs& a, const Plan& pl, hipStream_t st) {
-  const dim3 grid((unsigned)((long long)a.n_tbins * a.nparts), (unsigned)a.C);
+  // fused source: one extra ping-bin slot for the pings that fall in no time bin (Sv only)
+  const long long tslots = (long long)a.n_tbins + ((SRC == SRC_RAW && a.bin_start) ? 1 : 0);
+  const dim3 grid((unsigned)(tslots * a.nparts), (unsigned)a.C);
   const dim3 block(epa::kBlock);
   a.use_lds = pl.use_lds;
   a.cnt_off = pl.cnt_off;

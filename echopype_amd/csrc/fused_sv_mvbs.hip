@@ -113,7 +113,11 @@ __global__ __launch_bounds__(epa::kBlock) void fused_sv_mvbs_kernel(
 
   const int c = blockIdx.y, tb = blockIdx.x;
   const int S = a.S, n_rbins = a.n_rbins;
-  const int pb = bin_start[tb], pe = bin_start[tb + 1];
+  // blockIdx.x == n_tbins: the pings that belong to NO time bin (NaT, or on the first edge of
+  // right-closed bins) still get their Sv; two segments, nothing is accumulated.
+  const bool extra = tb == a.n_tbins;
+  if (extra && !WRITE_SV) return;
+  const int nseg = extra ? 2 : 1;
   for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
     lsum[i] = (T)0;
     lcnt[i] = 0u;
@@ -127,6 +131,9 @@ __global__ __launch_bounds__(epa::kBlock) void fused_sv_mvbs_kernel(
   T* __restrict__ sv_c = WRITE_SV ? sv_out + (size_t)c * a.P * S : nullptr;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
+  for (int seg = 0; seg < nseg; ++seg) {
+  const int pb = extra ? (seg == 0 ? 0 : bin_start[a.n_tbins]) : bin_start[tb];
+  const int pe = extra ? (seg == 0 ? bin_start[0] : a.P) : bin_start[tb + 1];
   for (int chunk0 = 0; chunk0 < S; chunk0 += kChunk) {
     const int sA = chunk0 + wave * 256 + 2 * lane;  // first sample of pair A
     const int sB = sA + 128;                        // first sample of pair B
@@ -178,6 +185,8 @@ __global__ __launch_bounds__(epa::kBlock) void fused_sv_mvbs_kernel(
 #pragma unroll
     for (int j = 0; j < VEC; ++j) col[j].flush(lsum, lcnt);
   }
+  }
+  if (extra) return;
   __syncthreads();
   const size_t cell0 = ((size_t)c * a.n_tbins + tb) * n_rbins;
   T* out = mvbs_out + cell0;
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(epa::kBlock) void fused_sv_mvbs_kernel(
 template <typename T>
 int launch(Args& a, const float* raw, const double* coef, const int32_t* bin_start, void* sv_out,
            void* mvbs_out, void* sum_out, uint32_t* cnt_out, int C, size_t lds_bytes, hipStream_t st) {
-  const dim3 grid((unsigned)a.n_tbins, (unsigned)C);
+  const dim3 grid((unsigned)a.n_tbins + 1u, (unsigned)C);  // +1: pings outside every time bin
   a.tab_off = (unsigned)((lds_bytes + 15) & ~(size_t)15);
   lds_bytes = a.tab_off + epa::kMathTabBytes;
 #define EPA_FL(W)                                                                              \

@@ -231,6 +231,26 @@ def test_fused_flag_combinations_take_generic_kernel(env):
         _assert_close(res["Sv"].cpu().numpy(), sv, 1e-9, "Sv")
 
 
+def test_fused_writes_sv_for_pings_outside_every_bin(env):
+    """Pings that no time bin covers (grid that starts late / ends early) must still be calibrated."""
+    torch, ops, synth = env
+    d = synth.ek60_numpy(2, 100, 512)
+    coef = _coef_ek60(torch, ops, d, "Sv")
+    sv, er = _oracle_ek60(d, "Sv")
+    ns = d["ping_time"].astype("datetime64[ns]").astype(np.int64)
+    # bins cover only pings 30..69
+    bs = ops.time_bin_offsets(_dev(torch, ns), int(ns[30]), 20 * 10**9, 2)
+    assert bs.cpu().tolist() == [30, 50, 70]
+    for kw in (dict(), dict(closed="right")):  # fast kernel / generic kernel
+        if kw:
+            bs = ops.time_bin_offsets(_dev(torch, ns), int(ns[30]) - 1, 20 * 10**9, 2, closed="right")
+        res = ops.sv_mvbs_fused(_dev(torch, d["backscatter_r"]), coef, bs, 2, 1.0, 64, want_range=bool(kw), **kw)
+        _assert_close(res["Sv"].cpu().numpy(), sv, 1e-9, f"Sv outside bins {kw}")
+        exp = ogrid.groupby_mean(sv[:, 30:70], er[:, 30:70], d["ping_time"][30:70],
+                                 d["ping_time"][30:71:20].astype("datetime64[ns]"), np.arange(0, 65.0, 1.0))
+        _assert_close(res["MVBS"].cpu().numpy(), exp, 1e-9, "MVBS of the covered pings")
+
+
 def test_mvbs_index_binning_kat(env):
     # test_commongrid_api.py:171-202 shape (4,100,4000) with ping_num=3, range_sample_num=7
     torch, ops, _ = env
