@@ -47,6 +47,49 @@ def retrieve_correct_beam_group(echodata, waveform_mode, encode_mode):
     raise RuntimeError("EchoData was produced by a non-Simrad or unknown Simrad echo sounder!")
 
 
+def _index_of(ds, dim, label):
+    vals = np.asarray(ds[dim].values)
+    hit = np.flatnonzero(vals == (np.asarray(label).astype(vals.dtype) if vals.dtype.kind == "M" else label))
+    if hit.size == 0:
+        raise KeyError(f"{label!r} not found along {dim!r}")
+    return int(hit[0])
+
+
+def _slice_beam_vend(beam, vend, slice_dict):
+    """One channel, one filter interval (calibrate_ek.py:25-35): pings in [start, end] inclusive."""
+    ci = _index_of(beam, "channel", slice_dict["channel"])
+    pt = np.asarray(beam["ping_time"].values).astype("datetime64[ns]")
+    start, end = slice_dict["beam_group_start_time"], slice_dict["beam_group_end_time"]
+    keep = pt >= np.datetime64(start, "ns")
+    if end is not None and not (isinstance(end, np.datetime64) and np.isnat(end)):
+        keep &= pt <= np.datetime64(end, "ns")
+    idx = np.flatnonzero(keep)
+    beam = beam.isel(channel=[ci], ping_time=idx)
+    vend = vend.isel(filter_time=_index_of(vend, "filter_time", slice_dict["filter_time"]))
+    return beam, vend
+
+
+def _collapse_vend(vend, slice_dict):
+    """assume_single_filter_time: per channel keep the filter set valid at its first valid ping
+    (calibrate_ek.py:38-53): the filter_time dimension collapses."""
+    from ..xr_lite import Dataset as _DS
+
+    chans = list(vend["channel"].values)
+    picks = [_index_of(vend, "filter_time", slice_dict["first_valid_filter_time_per_channel"][ch]) for ch in chans]
+    out = _DS(coords={k: c for k, c in vend.coords.items() if k != "filter_time"})
+    for name, da in vend.data_vars.items():
+        if "filter_time" not in da.dims:
+            out.data_vars[name] = da
+            continue
+        a = np.asarray(da.values)
+        cax, fax = da.dims.index("channel"), da.dims.index("filter_time")
+        a = np.moveaxis(a, (cax, fax), (0, 1))
+        sel = np.stack([a[i, picks[i]] for i in range(len(chans))], axis=0)
+        dims = ("channel",) + tuple(d for d in da.dims if d not in ("channel", "filter_time"))
+        out[name] = (dims, sel, dict(da.attrs))
+    return out
+
+
 class CalibrateEK(CalibrateBase):
     def __init__(self, echodata, env_params, cal_params, ecs_file, **kwargs):
         super().__init__(echodata, env_params, cal_params, ecs_file, **kwargs)
@@ -171,14 +214,18 @@ class CalibrateEK80(CalibrateEK):
         self.ed_beam_group = retrieve_correct_beam_group(self.echodata, waveform_mode, encode_mode)
         self.beam = self.echodata[self.ed_beam_group]
         self.vend = self.echodata["Vendor_specific"]
-        if "filter_time" in self.vend.sizes:
-            if self.vend.sizes["filter_time"] > 1 and "first_valid_filter_time_per_channel" not in self.slice_dict:
-                raise NotImplementedError(
-                    "Vendor_specific holds several filter_time entries: pass "
-                    "assume_single_filter_time=True, or calibrate each filter interval separately "
-                    "(the reference's slice-and-merge orchestration, calibrate/api.py:98-197, is host-side "
-                    "glue that is not part of the accelerated path yet).")
+        # multi-filter_time files (calibrate_ek.py:323-333): one (channel, filter interval) slice,
+        # or the filter set of each channel's first valid ping when a single set is assumed
+        if "channel" in self.slice_dict:
+            self.beam, self.vend = _slice_beam_vend(self.beam, self.vend, self.slice_dict)
+        if "first_valid_filter_time_per_channel" in self.slice_dict:
+            self.vend = _collapse_vend(self.vend, self.slice_dict)
+        elif "filter_time" in self.vend.sizes:
             self.vend = self.vend.isel(filter_time=0)
+        bch = list(map(str, self.beam["channel"].values))
+        vch = list(map(str, self.vend["channel"].values))
+        if bch != vch:  # vend.sel(channel=beam.channel) (:333)
+            self.vend = self.vend.isel(channel=[vch.index(c) for c in bch])
         C, P = self.beam["backscatter_r"].shape[:2]
         if waveform_mode == "BB":
             f0 = cp_array(self.beam["transmit_frequency_start"], C, P)

@@ -10,7 +10,7 @@ can be passed to the calibrators unchanged because they only use this read API.
 """
 import numpy as np
 
-from .xr_lite import Dataset, from_xarray
+from .xr_lite import DataArray, Dataset, from_xarray
 
 BEAM1 = "Sonar/Beam_group1"
 BEAM2 = "Sonar/Beam_group2"
@@ -72,7 +72,7 @@ def from_ek60_arrays(d, source_file="synthetic_ek60.raw"):
                     source_file=source_file)
 
 
-def from_ek80_arrays(d, filters, encode="complex", source_file="synthetic_ek80.raw"):
+def from_ek80_arrays(d, filters, encode="complex", source_file="synthetic_ek80.raw", filter_time_idx=None):
     """EK80 EchoData (complex samples in Beam_group1; convert/set_groups_ek80.py:796-840,967-1068,
     1234-1518).  ``filters`` = dict(wbt_fil, wbt_decifac, pc_fil, pc_decifac) applied to every channel."""
     ch = list(d["channel"])
@@ -106,6 +106,9 @@ def from_ek80_arrays(d, filters, encode="complex", source_file="synthetic_ek80.r
     vend = Dataset(coords={"channel": ch, "pulse_length_bin": np.arange(5), "WBT_filter_n": np.arange(nw + 3),
                            "PC_filter_n": np.arange(npc + 2)})
 
+    vend_dim = {"WBT_coeffs_real": "WBT_filter_n", "WBT_coeffs_imag": "WBT_filter_n",
+                "PC_coeffs_real": "PC_filter_n", "PC_coeffs_imag": "PC_filter_n"}
+
     def _pad(c, n):  # NaN padded like the converter (set_groups_ek80.py:1411-1518)
         out = np.full((C, n), np.nan)
         out[:, : c.size] = c
@@ -117,6 +120,19 @@ def from_ek80_arrays(d, filters, encode="complex", source_file="synthetic_ek80.r
     vend["PC_coeffs_imag"] = (("channel", "PC_filter_n"), _pad(filters["pc_fil"].imag, npc + 2))
     vend["WBT_deci_fac"] = (("channel",), np.full(C, filters["wbt_decifac"]))
     vend["PC_deci_fac"] = (("channel",), np.full(C, filters["pc_decifac"]))
+    if filter_time_idx is not None:
+        # the same filter set recorded at several filter_time stamps (a file whose filter datagrams
+        # were re-sent): (channel, filter_time, n) as in set_groups_ek80.py:1411-1518
+        ft = pt[np.asarray(filter_time_idx)]
+        vend.coords["filter_time"] = DataArray(ft, ("filter_time",), name="filter_time")
+        for k in ("WBT_coeffs_real", "WBT_coeffs_imag", "PC_coeffs_real", "PC_coeffs_imag"):
+            a = vend.data_vars[k].values
+            vend.data_vars.pop(k)
+            vend[k] = (("channel", "filter_time", vend_dim[k]), np.repeat(a[:, None, :], len(ft), axis=1))
+        for k in ("WBT_deci_fac", "PC_deci_fac"):
+            a = vend.data_vars[k].values
+            vend.data_vars.pop(k)
+            vend[k] = (("channel", "filter_time"), np.repeat(a[:, None], len(ft), axis=1))
     vend["transceiver_type"] = (("channel",), np.array(d.get("transceiver_type", ["WBT"] * C)))
     vend["impedance_transceiver"] = (("channel",), np.asarray(d["z_er"], float))
     vend["receiver_sampling_frequency"] = (("channel",), np.asarray(d["fs"], float))

@@ -157,6 +157,24 @@ def test_compute_Sv_ek80_bb(ep, dtype, mixed):
     assert ds["Sv"].attrs["waveform_mode"] == "BB"
 
 
+def test_compute_Sv_ek80_multi_filter_time_equals_single(ep):
+    """tests/calibrate/test_calibrate_ek80.py:610-666: a file with several filter_time entries gives
+    the same Sv whether each (channel, filter interval) is calibrated separately and merged, or a
+    single filter set is assumed, or the file holds one filter_time."""
+    d, filt = _ek80(ep, "BB", C=2, P=12, S=600)
+    single = ep.calibrate.compute_Sv(ep.echodata.from_ek80_arrays(d, filt), waveform_mode="BB", encode_mode="complex")
+    ed_multi = ep.echodata.from_ek80_arrays(d, filt, filter_time_idx=[0, 5, 9])
+    assert ed_multi["Vendor_specific"].sizes["filter_time"] == 3
+    merged = ep.calibrate.compute_Sv(ed_multi, waveform_mode="BB", encode_mode="complex")
+    assumed = ep.calibrate.compute_Sv(ed_multi, waveform_mode="BB", encode_mode="complex",
+                                      assume_single_filter_time=True)
+    for other in (merged, assumed):
+        np.testing.assert_array_equal(other["Sv"].values, single["Sv"].values)
+        np.testing.assert_array_equal(other["echo_range"].values, single["echo_range"].values)
+    assert merged["Sv"].dims == ("channel", "ping_time", "range_sample")
+    np.testing.assert_allclose(merged["sound_absorption"].values, single["sound_absorption"].values)
+
+
 @pytest.mark.parametrize("cal", ["Sv", "TS"])
 def test_compute_Sv_TS_ek80_cw_complex(ep, cal):
     d, filt = _ek80(ep, "CW", C=2, P=10, S=700, mixed_nan=True)
