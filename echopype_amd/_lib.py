@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libechopype_amd.so")
+# ECHOPYPE_AMD_LIB: alternative build of the same library (A/B tuning of kernel variants)
+LIB_PATH = os.environ.get("ECHOPYPE_AMD_LIB") or os.path.join(_HERE, "lib", "libechopype_amd.so")
 
 EPA_OK, EPA_EINVAL, EPA_EHIP, EPA_ENOMEM, EPA_EUNSUPPORTED = range(5)
 F32, F64 = 0, 1

@@ -16,8 +16,9 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIBDIR = os.path.join(HERE, "lib")
-LIBPATH = os.path.join(LIBDIR, "libechopype_amd.so")
-OBJDIR = os.path.join(HERE, "csrc", "_obj")
+VARIANT = os.environ.get("EPA_VARIANT", "")  # tuning aid: separate objects + library per variant
+LIBPATH = os.path.join(LIBDIR, f"libechopype_amd{('_' + VARIANT) if VARIANT else ''}.so")
+OBJDIR = os.path.join(HERE, "csrc", "_obj" + (("_" + VARIANT) if VARIANT else ""))
 
 SOURCES = ["runtime.hip", "power_coef.hip", "sv_power.hip", "block_reduce.hip", "fused_sv_mvbs.hip", "noise_apply.hip", "reduce_util.hip",
            "ek80_complex.hip"]

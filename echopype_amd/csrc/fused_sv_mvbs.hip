@@ -100,8 +100,11 @@ __device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::
 // (8 B/lane) and every store (16 B/lane f64) of a wave is then one contiguous 512 B / 1 KiB
 // segment -- the 4-consecutive-samples-per-lane layout makes each f64 store instruction touch
 // only half of every 128-B line.
+#ifndef EPA_FUSED_MIN_WAVES
+#define EPA_FUSED_MIN_WAVES 1
+#endif
 template <typename T, bool WRITE_SV>
-__global__ __launch_bounds__(epa::kBlock) void fused_sv_mvbs_kernel(
+__global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvbs_kernel(
     const float* __restrict__ raw, const epa::CoefRow* __restrict__ coef,
     const int32_t* __restrict__ bin_start, T* __restrict__ sv_out, T* __restrict__ mvbs_out,
     T* __restrict__ sum_out, uint32_t* __restrict__ cnt_out, Args a) {
@@ -143,12 +146,40 @@ __global__ __launch_bounds__(epa::kBlock) void fused_sv_mvbs_kernel(
 #pragma unroll
     for (int j = 0; j < VEC; ++j) col[j].init();
     double dcur = __builtin_nan(""), racur = __builtin_nan("");
+    // software prefetch: the raw samples and the coefficient row of ping p+1 are requested before
+    // ping p is processed, so their latency hides behind ~150 instructions of arithmetic
+    float2 nxtA = make_float2(0.f, 0.f), nxtB = make_float2(0.f, 0.f);
+    epa::CoefRow nxtR = rowp0[pb < pe ? pb : 0];
+    if (pb < pe) {
+      nxtA = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sA);
+      if (hasB) nxtB = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sB);
+    }
     for (int p = pb; p < pe; ++p) {
-      const epa::CoefRow r = rowp0[p];  // wave-uniform address -> scalar loads
+#ifndef EPA_NO_PREFETCH
+#ifdef EPA_NO_ROW_PREFETCH
+      const epa::CoefRow r = rowp0[p];
+#else
+      const epa::CoefRow r = nxtR;
+#endif
+      const float2 inA = nxtA, inB = nxtB;
       const size_t row_off = (size_t)p * S;
+#else
+      const size_t row_off = (size_t)p * S;
+      const epa::CoefRow r = rowp0[p];
       const float2 inA = *reinterpret_cast<const float2*>(raw_c + row_off + sA);
-      float2 inB = make_float2(0.f, 0.f);
-      if (hasB) inB = *reinterpret_cast<const float2*>(raw_c + row_off + sB);
+      const float2 inB = hasB ? *reinterpret_cast<const float2*>(raw_c + row_off + sB) : make_float2(0.f, 0.f);
+#endif
+#ifndef EPA_NO_PREFETCH
+      if (p + 1 < pe) {
+#else
+      if (false) {
+#endif
+#ifndef EPA_NO_ROW_PREFETCH
+        nxtR = rowp0[p + 1];
+#endif
+        nxtA = *reinterpret_cast<const float2*>(raw_c + row_off + S + sA);
+        if (hasB) nxtB = *reinterpret_cast<const float2*>(raw_c + row_off + S + sB);
+      }
       if (!((r.d == dcur) & (r.ra == racur))) {  // uniform; once per column for a file with
         dcur = r.d;                               // constant tau / sample_interval
         racur = r.ra;

@@ -12,47 +12,54 @@
 
 namespace {
 
-template <typename T, int VEC>
+// SEGLEN samples per 16-B access: f64 -> LaneMap<double> pairs; f32 -> 4 consecutive.  VEC == false:
+// scalar fallback for odd sizes / unaligned buffers.
+template <typename T, bool VEC>
 __global__ __launch_bounds__(epa::kBlock) void noise_apply_kernel(
     const T* __restrict__ sv, const T* __restrict__ range, const epa::CoefRow* __restrict__ coef,
     const double* __restrict__ alpha2, const double* __restrict__ noise, int P, int S,
-    long long rows, int chunks_per_row, int ping_num, int n_pblocks, T snr,
-    T* __restrict__ sv_noise, T* __restrict__ sv_corr) {
-  constexpr int kChunk = epa::kBlock * VEC;
+    long long rows, int ping_num, int n_pblocks, T snr, T* __restrict__ sv_noise,
+    T* __restrict__ sv_corr) {
+  using LM = epa::LaneMap<T>;
+  constexpr int NSEG = VEC ? LM::NSEG : 1, LEN = VEC ? LM::LEN : 1;
   __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
   const epa::MathTabs mt = epa::build_math_tabs(tabs);
   __syncthreads();
-  const long long items = rows * chunks_per_row;
-  for (long long item = blockIdx.x; item < items; item += gridDim.x) {
-    const long long row = item / chunks_per_row;
-    const int chunk = (int)(item - row * chunks_per_row);
-    const int s0 = chunk * kChunk + threadIdx.x * VEC;
-    if (s0 >= S) continue;
+  int s0[NSEG];
+#pragma unroll
+  for (int g = 0; g < NSEG; ++g)
+    s0[g] = VEC ? LM::first(blockIdx.y * 1024, g) : (int)(blockIdx.y * epa::kBlock + threadIdx.x);
+  if (s0[0] >= S) return;
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
     const int c = (int)(row / P), p = (int)(row - (long long)c * P);
     const T nb = (T)noise[(size_t)c * n_pblocks + p / ping_num];
     const T a2 = (T)alpha2[row];
-    const size_t off = (size_t)row * S + s0;
-    T v[VEC], x[VEC], on[VEC], oc[VEC];
-    epa::load_vec<T, VEC>(sv + off, v);
-    if (range) {
-      epa::load_vec<T, VEC>(range + off, x);
-    } else {
-      const epa::CoefRow cr = coef[row];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) x[j] = (T)epa::row_range(cr, s0 + j);
-    }
+    for (int g = 0; g < NSEG; ++g) {
+      if (s0[g] >= S) continue;
+      const size_t off = (size_t)row * S + s0[g];
+      T v[LEN], x[LEN], on[LEN], oc[LEN];
+      epa::load_vec<T, LEN>(sv + off, v);
+      if (range) {
+        epa::load_vec<T, LEN>(range + off, x);
+      } else {
+        const epa::CoefRow cr = coef[row];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      const T tl = (T)20 * epa::fast_log10(x[j] >= (T)1 ? x[j] : (T)1, mt.log_tab) + a2 * x[j];
-      const T sn = nb + tl;
-      const T lin = epa::lin_from_db(v[j], mt.exp2_tab) - epa::lin_from_db(sn, mt.exp2_tab);
-      T corr = lin > (T)0 ? (T)10 * epa::fast_log10(lin, mt.log_tab) : epa::M<T>::nan();
-      if (!(corr - sn > snr)) corr = epa::M<T>::nan();
-      on[j] = sn;
-      oc[j] = corr;
+        for (int j = 0; j < LEN; ++j) x[j] = (T)epa::row_range(cr, s0[g] + j);
+      }
+#pragma unroll
+      for (int j = 0; j < LEN; ++j) {
+        const T tl = (T)20 * epa::fast_log10(x[j] >= (T)1 ? x[j] : (T)1, mt.log_tab) + a2 * x[j];
+        const T sn = nb + tl;
+        const T lin = epa::lin_from_db(v[j], mt.exp2_tab) - epa::lin_from_db(sn, mt.exp2_tab);
+        T corr = lin > (T)0 ? (T)10 * epa::fast_log10(lin, mt.log_tab) : epa::M<T>::nan();
+        if (!(corr - sn > snr)) corr = epa::M<T>::nan();
+        on[j] = sn;
+        oc[j] = corr;
+      }
+      if (sv_noise) epa::store_vec<T, LEN>(sv_noise + off, on);
+      if (sv_corr) epa::store_vec<T, LEN>(sv_corr + off, oc);
     }
-    if (sv_noise) epa::store_vec<T, VEC>(sv_noise + off, on);
-    if (sv_corr) epa::store_vec<T, VEC>(sv_corr + off, oc);
   }
 }
 
@@ -63,21 +70,24 @@ int launch(const void* sv, const void* range, const double* coef, const double* 
            const double* noise, int C, int P, int S, int ping_num, double snr, void* sv_noise,
            void* sv_corr, hipStream_t st) {
   const long long rows = (long long)C * P;
-  const int vec = (S % 4 == 0 && al16(sv) && al16(range) && al16(sv_noise) && al16(sv_corr)) ? 4 : 1;
-  const int chunk = epa::kBlock * vec;
+  const int need = sizeof(T) == 8 ? 2 : 4;
+  const bool vec = S % need == 0 && al16(sv) && al16(range) && al16(sv_noise) && al16(sv_corr);
+  const int chunk = vec ? 1024 : epa::kBlock;
   const int chunks_per_row = (S + chunk - 1) / chunk;
-  const long long items = rows * chunks_per_row;
-  const int grid = (int)(items < 8192 ? items : 8192);
+  long long gx = 8192 / chunks_per_row;
+  if (gx < 1) gx = 1;
+  if (gx > rows) gx = rows;
+  const dim3 grid((unsigned)gx, (unsigned)chunks_per_row);
   const int n_pblocks = (P + ping_num - 1) / ping_num;
   const epa::CoefRow* cf = reinterpret_cast<const epa::CoefRow*>(coef);
-  if (vec == 4)
-    hipLaunchKernelGGL((noise_apply_kernel<T, 4>), dim3(grid), dim3(epa::kBlock), 0, st,
-                       (const T*)sv, (const T*)range, cf, alpha2, noise, P, S, rows, chunks_per_row,
-                       ping_num, n_pblocks, (T)snr, (T*)sv_noise, (T*)sv_corr);
+  if (vec)
+    hipLaunchKernelGGL((noise_apply_kernel<T, true>), grid, dim3(epa::kBlock), 0, st, (const T*)sv,
+                       (const T*)range, cf, alpha2, noise, P, S, rows, ping_num, n_pblocks, (T)snr,
+                       (T*)sv_noise, (T*)sv_corr);
   else
-    hipLaunchKernelGGL((noise_apply_kernel<T, 1>), dim3(grid), dim3(epa::kBlock), 0, st,
-                       (const T*)sv, (const T*)range, cf, alpha2, noise, P, S, rows, chunks_per_row,
-                       ping_num, n_pblocks, (T)snr, (T*)sv_noise, (T*)sv_corr);
+    hipLaunchKernelGGL((noise_apply_kernel<T, false>), grid, dim3(epa::kBlock), 0, st, (const T*)sv,
+                       (const T*)range, cf, alpha2, noise, P, S, rows, ping_num, n_pblocks, (T)snr,
+                       (T*)sv_noise, (T*)sv_corr);
   return epa::check_launch("noise_apply_kernel");
 }
 

@@ -111,27 +111,51 @@ __device__ __forceinline__ void store_nt2(float* p, float a, float b) {
 
 template <typename T, int VEC>
 __device__ __forceinline__ void store_vec(T* p, const T (&v)[VEC]);
+// all bulk outputs of the path are written once and never re-read by the writing kernel: streaming
+// (non-temporal) stores, measured +2...6 % on the write-heavy kernels
 template <>
 __device__ __forceinline__ void store_vec<double, 4>(double* p, const double (&v)[4]) {
+  // two 16-B halves at a 32-B lane stride: plain stores (nt on half lines measured slower)
   reinterpret_cast<double2*>(p)[0] = make_double2(v[0], v[1]);
   reinterpret_cast<double2*>(p)[1] = make_double2(v[2], v[3]);
 }
 template <>
 __device__ __forceinline__ void store_vec<float, 4>(float* p, const float (&v)[4]) {
-  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  epa_f4 t = {v[0], v[1], v[2], v[3]};
+  __builtin_nontemporal_store(t, reinterpret_cast<epa_f4*>(p));
 }
 template <>
 __device__ __forceinline__ void store_vec<double, 2>(double* p, const double (&v)[2]) {
-  *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]);
+  store_nt2(p, v[0], v[1]);
 }
 template <>
 __device__ __forceinline__ void store_vec<float, 2>(float* p, const float (&v)[2]) {
-  *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+  store_nt2(p, v[0], v[1]);
 }
 template <>
 __device__ __forceinline__ void store_vec<double, 1>(double* p, const double (&v)[1]) { p[0] = v[0]; }
 template <>
 __device__ __forceinline__ void store_vec<float, 1>(float* p, const float (&v)[1]) { p[0] = v[0]; }
+
+// Lane -> sample mapping of the streaming kernels inside a 1024-sample chunk (256 lanes x 4
+// samples), chosen so that EVERY access of a wavefront is one contiguous run of 16 B per lane:
+//   f32 outputs: 4 consecutive samples per lane (16-B load, 16-B store)            NSEG=1, LEN=4
+//   f64 outputs: two pairs per lane, {2l, 2l+1} and {128+2l, 128+2l+1} within the wave's 256
+//                samples (8-B loads of the f32 input, 16-B stores / loads of f64)    NSEG=2, LEN=2
+template <typename T>
+struct LaneMap;
+template <>
+struct LaneMap<float> {
+  static constexpr int NSEG = 1, LEN = 4;
+  static __device__ __forceinline__ int first(int chunk0, int) { return chunk0 + (int)threadIdx.x * 4; }
+};
+template <>
+struct LaneMap<double> {
+  static constexpr int NSEG = 2, LEN = 2;
+  static __device__ __forceinline__ int first(int chunk0, int seg) {
+    return chunk0 + ((int)threadIdx.x >> 6) * 256 + seg * 128 + 2 * ((int)threadIdx.x & 63);
+  }
+};
 
 template <typename T, int VEC>
 __device__ __forceinline__ void load_vec(const T* p, T (&v)[VEC]);

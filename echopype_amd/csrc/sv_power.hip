@@ -5,43 +5,76 @@
 //   /root/reference/echopype/calibrate/range.py:69-95 + calibrate_azfp.py:64-97  (AZFP)
 //
 // Layout: raw f32 (C,P,S) row-major; one coefficient row (64 B) per (c,p).  A workgroup of 256
-// threads owns one 1024-sample chunk of one row per iteration (each lane: one 16-B load of 4
-// samples, 32 B (f64) or 16 B (f32) of stores), grid-strides over (row, chunk).  The row constants
-// are wave-uniform -> scalar loads.  HBM-bound: 4 B in + 8 B (f64) out per sample (+8 B with
+// threads owns one 1024-sample range chunk (blockIdx.y) and strides over the rows; lanes map to
+// samples so that every wavefront access is a contiguous run of 16 B per lane (LaneMap in
+// sample_math.h).  The row constants are wave-uniform -> scalar loads.  HBM-bound: 4 B in + 8 B (f64) out per sample (+8 B with
 // echo_range); MFMA is irrelevant here (no contraction).
 #include "sample_math.h"
 
 namespace {
 
-template <typename T, int VEC, bool RANGE>
+// Vector path: S even (f64) / S % 4 == 0 (f32) and 16-byte aligned buffers.
+template <typename T, bool RANGE>
 __global__ __launch_bounds__(epa::kBlock) void sv_power_kernel(const float* __restrict__ raw,
                                                                const epa::CoefRow* __restrict__ coef,
                                                                long long rows, int S, T nspread,
                                                                unsigned flags, T* __restrict__ out,
                                                                T* __restrict__ range_out) {
-  // blockIdx.y = range chunk (fixed for the life of the block, so that the lane's range column
-  // and its cached log10(s - d) never change); blockIdx.x strides over the (channel, ping) rows.
-  constexpr int kChunk = epa::kBlock * VEC;
+  // blockIdx.y = range chunk (fixed for the life of the block, so that the lane's range columns
+  // and their cached log10(s - d) never change); blockIdx.x strides over the (channel, ping) rows.
+  using LM = epa::LaneMap<T>;
+  constexpr int NSEG = LM::NSEG, LEN = LM::LEN;
   const bool guard = flags & EPA_FLAG_GUARD_POS;
   const bool mask_range = flags & EPA_FLAG_MASK_RANGE;
-  const int s0 = blockIdx.y * kChunk + threadIdx.x * VEC;
-  if (s0 >= S) return;
-  epa::ColumnLog<T, VEC> col;
+  int s0[NSEG];
+  bool act[NSEG];
+#pragma unroll
+  for (int g = 0; g < NSEG; ++g) {
+    s0[g] = LM::first(blockIdx.y * 1024, g);
+    act[g] = s0[g] < S;
+  }
+  if (!act[0]) return;
+  epa::ColumnLog<T, LEN> col[NSEG];
   for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
     const epa::RowK<T> rk(coef[row]);
-    col.update(rk.d, s0, nspread);
-    const size_t off = (size_t)row * S + s0;
-    epa::RawVec<VEC> in;
-    in.load(raw + off);
-    T o[VEC], rg[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      const double r = rk.range(s0 + j);
-      o[j] = epa::cal_power_sample<T>(in.v[j], s0 + j, rk, nspread, col.nL[j], guard, r);
-      if (RANGE) rg[j] = (mask_range && !(in.v[j] == in.v[j])) ? epa::M<T>::nan() : (T)r;
+    for (int g = 0; g < NSEG; ++g) {
+      if (!act[g]) continue;
+      col[g].update(rk.d, s0[g], nspread);
+      const size_t off = (size_t)row * S + s0[g];
+      epa::RawVec<LEN> in;
+      in.load(raw + off);
+      T o[LEN], rg[LEN];
+#pragma unroll
+      for (int j = 0; j < LEN; ++j) {
+        const double r = rk.range(s0[g] + j);
+        o[j] = epa::cal_power_sample<T>(in.v[j], s0[g] + j, rk, nspread, col[g].nL[j], guard, r);
+        if (RANGE) rg[j] = (mask_range && !(in.v[j] == in.v[j])) ? epa::M<T>::nan() : (T)r;
+      }
+      epa::store_vec<T, LEN>(out + off, o);
+      if (RANGE) epa::store_vec<T, LEN>(range_out + off, rg);
     }
-    epa::store_vec<T, VEC>(out + off, o);
-    if (RANGE) epa::store_vec<T, VEC>(range_out + off, rg);
+  }
+}
+
+// Scalar path for odd sizes / unaligned buffers: one sample per lane.
+template <typename T, bool RANGE>
+__global__ __launch_bounds__(epa::kBlock) void sv_power_scalar_kernel(
+    const float* __restrict__ raw, const epa::CoefRow* __restrict__ coef, long long rows, int S,
+    T nspread, unsigned flags, T* __restrict__ out, T* __restrict__ range_out) {
+  const bool guard = flags & EPA_FLAG_GUARD_POS;
+  const bool mask_range = flags & EPA_FLAG_MASK_RANGE;
+  const int s = blockIdx.y * epa::kBlock + threadIdx.x;
+  if (s >= S) return;
+  epa::ColumnLog<T, 1> col;
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const epa::RowK<T> rk(coef[row]);
+    col.update(rk.d, s, nspread);
+    const size_t off = (size_t)row * S + s;
+    const float v = raw[off];
+    const double r = rk.range(s);
+    out[off] = epa::cal_power_sample<T>(v, s, rk, nspread, col.nL[0], guard, r);
+    if (RANGE) range_out[off] = (mask_range && !(v == v)) ? epa::M<T>::nan() : (T)r;
   }
 }
 
@@ -51,21 +84,22 @@ int launch(const float* raw, const double* coef, int C, int P, int S, int cal_ty
   const long long rows = (long long)C * P;
   const T nspread = cal_type == EPA_CAL_SV ? (T)20 : (T)40;
   auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-  const int vec = (S % 4 == 0 && al16(raw) && al16(out) && al16(range_out)) ? 4 : 1;
-  const int chunk = epa::kBlock * vec;
+  const int need = sizeof(T) == 8 ? 2 : 4;  // samples per 16-B output access
+  const bool vec = (S % need == 0) && al16(raw) && al16(out) && al16(range_out);
+  const int chunk = vec ? 1024 : epa::kBlock;
   const int chunks_per_row = (S + chunk - 1) / chunk;
   long long gx = 8192 / chunks_per_row;
   if (gx < 1) gx = 1;
   if (gx > rows) gx = rows;
   const dim3 grid((unsigned)gx, (unsigned)chunks_per_row);
   const epa::CoefRow* cf = reinterpret_cast<const epa::CoefRow*>(coef);
-#define EPA_LAUNCH(V, R)                                                                          \
-  hipLaunchKernelGGL((sv_power_kernel<T, V, R>), grid, dim3(epa::kBlock), 0, st, raw, cf, rows,   \
-                     S, nspread, flags, (T*)out, (T*)range_out)
-  if (vec == 4) {
-    if (range_out) EPA_LAUNCH(4, true); else EPA_LAUNCH(4, false);
+#define EPA_LAUNCH(K, R)                                                                        \
+  hipLaunchKernelGGL((K<T, R>), grid, dim3(epa::kBlock), 0, st, raw, cf, rows, S, nspread, flags, \
+                     (T*)out, (T*)range_out)
+  if (vec) {
+    if (range_out) EPA_LAUNCH(sv_power_kernel, true); else EPA_LAUNCH(sv_power_kernel, false);
   } else {
-    if (range_out) EPA_LAUNCH(1, true); else EPA_LAUNCH(1, false);
+    if (range_out) EPA_LAUNCH(sv_power_scalar_kernel, true); else EPA_LAUNCH(sv_power_scalar_kernel, false);
   }
 #undef EPA_LAUNCH
   return epa::check_launch("sv_power_kernel");
