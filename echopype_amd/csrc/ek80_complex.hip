@@ -51,11 +51,26 @@ struct CxArgs {
 };
 
 // stage samples [k_begin, k_begin + len) of one ping: sector sum (or one sector when `only` >= 0)
-template <typename InT, typename A>
+// 16-byte vector loads of the NB sector values of one sample (NB * sizeof(InT) must be a multiple of
+// 16 and the base 16-byte aligned: the launcher checks)
+template <typename InT, int NB>
+__device__ __forceinline__ void load_sectors(const InT* __restrict__ p, InT (&v)[NB]) {
+  constexpr int kPer = 16 / sizeof(InT);
+  typedef InT vec_t __attribute__((ext_vector_type(kPer)));
+#pragma unroll
+  for (int q = 0; q < NB / kPer; ++q) {
+    const vec_t t = reinterpret_cast<const vec_t*>(p)[q];
+#pragma unroll
+    for (int e = 0; e < kPer; ++e) v[q * kPer + e] = t[e];
+  }
+}
+
+template <typename InT, typename A, int NB>
 __device__ __forceinline__ unsigned stage_tile(const InT* __restrict__ re, const InT* __restrict__ im,
-                                               size_t ping_base, int S, int B, int k_begin, int len,
+                                               size_t ping_base, int S, int Brt, int k_begin, int len,
                                                int only, Cx<A>* xs, uint8_t* vmask) {
   unsigned mixed = 0;
+  const int B = NB > 0 ? NB : Brt;
   const unsigned full = (1u << B) - 1u;
   for (int t = threadIdx.x; t < len; t += epa::kBlock) {
     const int s = k_begin + t;
@@ -64,8 +79,14 @@ __device__ __forceinline__ unsigned stage_tile(const InT* __restrict__ re, const
     if (s < S) {
       const InT* pr = re + ping_base + (size_t)s * B;
       const InT* pi = im + ping_base + (size_t)s * B;
+      InT vrs[NB > 0 ? NB : 1], vis[NB > 0 ? NB : 1];
+      if (NB > 0) {
+        load_sectors<InT, (NB > 0 ? NB : 4)>(pr, reinterpret_cast<InT(&)[NB > 0 ? NB : 4]>(vrs));
+        load_sectors<InT, (NB > 0 ? NB : 4)>(pi, reinterpret_cast<InT(&)[NB > 0 ? NB : 4]>(vis));
+      }
+#pragma unroll
       for (int b = 0; b < B; ++b) {
-        const InT vr = pr[b], vi = pi[b];
+        const InT vr = NB > 0 ? vrs[NB > 0 ? b : 0] : pr[b], vi = NB > 0 ? vis[NB > 0 ? b : 0] : pi[b];
         const bool ok = (vr == vr) && (vi == vi);
         if (ok) {
           m |= 1u << b;
@@ -76,7 +97,8 @@ __device__ __forceinline__ unsigned stage_tile(const InT* __restrict__ re, const
         }
       }
       // second mask byte, bit 0: beam-0 real part valid (echo_range mask, range.py:143-146)
-      if (pr[0] == pr[0]) m |= 0x100u;
+      const InT r0v = NB > 0 ? vrs[0] : pr[0];
+      if (r0v == r0v) m |= 0x100u;
     }
     xs[pad_idx(t)] = Cx<A>{sr, si};
     if (only < 0) {
@@ -116,7 +138,7 @@ __device__ __forceinline__ void conv8(const Cx<A>* __restrict__ xs, const Cx<A>*
   }
 }
 
-template <typename InT, typename T, typename A>
+template <typename InT, typename T, typename A, int NB>
 __global__ __launch_bounds__(epa::kBlock) void sv_complex_kernel(CxArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Cx<A>* xs = reinterpret_cast<Cx<A>*>(smem);
@@ -162,7 +184,7 @@ __global__ __launch_bounds__(epa::kBlock) void sv_complex_kernel(CxArgs a) {
   // staged span: outputs [k_begin, k_begin+kTile) need inputs up to k_begin + kTile + taps8 - 1 (+8 lookahead)
   const int len = kTile + (taps8 > 0 ? taps8 + kR : 0);
 
-  const unsigned mixed_l = stage_tile<InT, A>(re, im, ping_base, S, B, k_begin, len, -1, xs, vmask);
+  const unsigned mixed_l = stage_tile<InT, A, NB>(re, im, ping_base, S, B, k_begin, len, -1, xs, vmask);
   const int mixed = __syncthreads_or((int)mixed_l);
 
   const int k0 = threadIdx.x * kR;  // tile-local first output of this lane
@@ -185,7 +207,7 @@ __global__ __launch_bounds__(epa::kBlock) void sv_complex_kernel(CxArgs a) {
     // per-sector convolutions; a sector contributes to output k only where it is valid at k
     for (int b = 0; b < B; ++b) {
       __syncthreads();
-      stage_tile<InT, A>(re, im, ping_base, S, B, k_begin, len, b, xs, vmask);
+      stage_tile<InT, A, NB>(re, im, ping_base, S, B, k_begin, len, b, xs, vmask);
       __syncthreads();
       Cx<A> yb[kR];
 #pragma unroll
@@ -256,12 +278,20 @@ int launch(CxArgs& a, int max_taps, hipStream_t st) {
   EPA_CHECK_ARG(lds <= 150 * 1024, "epa_sv_complex: replica of %d taps does not fit the LDS tile",
                 max_taps);
   a.tiles = (a.S + kTile - 1) / kTile;
-  auto kern = sv_complex_kernel<InT, T, A>;
-  if (lds > 64 * 1024)
-    EPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const dim3 grid((unsigned)((long long)a.P * a.tiles), (unsigned)a.C);
-  hipLaunchKernelGGL(kern, grid, dim3(epa::kBlock), lds, st, a);
+  // four sectors (the usual split-beam transducer) with 16-byte aligned planes: vector loads
+  const bool b4 = a.B == 4 && (reinterpret_cast<uintptr_t>(a.re) & 15u) == 0 &&
+                  (reinterpret_cast<uintptr_t>(a.im) & 15u) == 0;
+#define EPA_CX(NBV)                                                                              \
+  do {                                                                                           \
+    auto kern = sv_complex_kernel<InT, T, A, NBV>;                                               \
+    if (lds > 64 * 1024)                                                                         \
+      EPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                     \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+    hipLaunchKernelGGL(kern, grid, dim3(epa::kBlock), lds, st, a);                               \
+  } while (0)
+  if (b4) EPA_CX(4); else EPA_CX(0);
+#undef EPA_CX
   return epa::check_launch("sv_complex_kernel");
 }
 
