@@ -65,7 +65,42 @@ __global__ __launch_bounds__(epa::kBlock) void minmax_final_kernel(const double*
   }
 }
 
+// depth = offset[c,p] + scale[c,p] * echo_range   (consolidate/api.py:226, add_depth)
+template <typename T>
+__global__ __launch_bounds__(epa::kBlock) void affine_rows_kernel(const T* __restrict__ x,
+                                                                  const double* __restrict__ scale,
+                                                                  const double* __restrict__ offset,
+                                                                  long long rows, int S,
+                                                                  T* __restrict__ out) {
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const T a = (T)scale[row], b = (T)offset[row];
+    const T* xr = x + (size_t)row * S;
+    T* orow = out + (size_t)row * S;
+    for (int s = threadIdx.x; s < S; s += blockDim.x) orow[s] = b + a * xr[s];
+  }
+}
+
 }  // namespace
+
+extern "C" int epa_affine_rows(const void* x, const double* scale, const double* offset, int C, int P,
+                               int S, void* out, int dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(x && scale && offset && out, "epa_affine_rows: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_affine_rows: sizes must be positive");
+  const long long rows = (long long)C * P;
+  const int grid = (int)(rows < 16384 ? rows : 16384);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EPA_F64)
+    hipLaunchKernelGGL(affine_rows_kernel<double>, dim3(grid), dim3(epa::kBlock), 0, st,
+                       (const double*)x, scale, offset, rows, S, (double*)out);
+  else if (dtype == EPA_F32)
+    hipLaunchKernelGGL(affine_rows_kernel<float>, dim3(grid), dim3(epa::kBlock), 0, st,
+                       (const float*)x, scale, offset, rows, S, (float*)out);
+  else {
+    epa::set_error("epa_affine_rows: bad dtype %d", dtype);
+    return EPA_EINVAL;
+  }
+  return epa::check_launch("affine_rows_kernel");
+}
 
 extern "C" int epa_nanminmax(const void* x, size_t n, int dtype, double* workspace, double* out,
                              epa_stream_t stream) {

@@ -180,6 +180,14 @@ def mvbs_finalize(ssum, cnt, fill_value=float("nan")):
     return out
 
 
+def affine_rows(x, scale, offset):
+    """out[c,p,:] = offset[c,p] + scale[c,p] * x[c,p,:]  (add_depth)."""
+    C, P, S = x.shape
+    out = torch.empty_like(x)
+    call("epa_affine_rows", _p(x), _p(scale), _p(offset), C, P, S, _p(out), _DT[x.dtype], _stream())
+    return out
+
+
 def nanminmax(x):
     """(nanmin, nanmax) of a device tensor as Python floats (one 16-byte D2H copy)."""
     ws = torch.empty(2048, dtype=torch.float64, device=x.device)

@@ -159,6 +159,14 @@ int epa_selftest_log10(const double* x, double* out, size_t n, epa_stream_t stre
 int epa_mvbs_finalize(const void* sum, const uint32_t* cnt, size_t n, double fill_value, void* out,
                       int dtype, epa_stream_t stream);
 
+/* ---- depth = offset[c,p] + scale[c,p] * echo_range -----------------------------------------------------------
+ * The array pass of consolidate.add_depth (consolidate/api.py:226: transducer_depth +
+ * orientation * echo_range * cos(tilt)); SURVEY 8f "next" row 1.  x, out: [C*P*S] of dtype;
+ * scale, offset: f64 [C*P].
+ */
+int epa_affine_rows(const void* x, const double* scale, const double* offset, int C, int P, int S,
+                    void* out, int dtype, epa_stream_t stream);
+
 /* ---- NaN-skipping min/max of a device array ---------------------------------------------------------------
  * Replaces the reductions the reference forces with ds_Sv[range_var].max(skipna=True)
  * (commongrid/api.py:108-110) and the actual_range attributes (clean/utils.py:392-395,

@@ -301,6 +301,30 @@ def test_compute_MVBS_index_binning(ep):
     np.testing.assert_array_equal(ds["range_sample"].values, np.arange(exp.shape[2]))
 
 
+def test_add_depth_then_MVBS_on_depth(ep):
+    """compute_Sv -> add_depth(depth_offset, tilt) -> compute_MVBS(range_var="depth") (the reference's
+    MVBS value fixtures are built through add_depth, tests/commongrid/conftest.py:101-118)."""
+    d = ep.synth.ek60_numpy(2, 61, 600)
+    ds = ep.calibrate.compute_Sv(ep.echodata.from_ek60_arrays(d))
+    out = ep.consolidate.add_depth(ds, depth_offset=2.5, tilt=15.0)
+    assert out is ds
+    sv, er = oc.ek60(d, "Sv")
+    exp_depth = 2.5 + er * np.cos(np.deg2rad(15.0))
+    close(ds["depth"].values, exp_depth, 1e-14, "depth")
+    mv = ep.commongrid.compute_MVBS(ds, range_var="depth", range_bin="2m", ping_time_bin="20s")
+    exp, t_left, r_left = ogrid.compute_MVBS(sv, exp_depth, d["ping_time"], "2m", "20s")
+    close(mv["Sv"].values, exp, 1e-9, "MVBS on depth")
+    np.testing.assert_array_equal(mv["depth"].values, r_left)
+    # upward-looking, per-ping offsets given on their own time axis (nearest alignment)
+    t_off = d["ping_time"][::10]
+    off = ep.DataArray(np.linspace(100, 94, len(t_off)), ("time3",), {"time3": t_off})
+    ep.consolidate.add_depth(ds, depth_offset=off, downward=False)
+    idx = np.abs(d["ping_time"][:, None] - t_off[None, :]).argmin(axis=1)
+    close(ds["depth"].values, off.values[idx][None, :, None] - er, 1e-14, "upward depth")
+    with pytest.raises(ValueError, match="then `echodata` cannot be `None`"):
+        ep.consolidate.add_depth(ds, use_platform_angles=True)
+
+
 # ------------------------------------------------------------------------------------ clean
 def test_remove_background_noise_reference_kat(ep):
     for make, n_nan in ((kf.noise_toy, None), (kf.noise_seed1, 6)):
