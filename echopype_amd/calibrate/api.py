@@ -78,6 +78,11 @@ def _compute_cal(cal_type, echodata, env_params=None, cal_params=None, ecs_file=
         else:
             cal_ds = _calibrate_filter_intervals(_compute_cal_ds, cal_type, beam, vend, tau, pt, chans)
 
+    return _finalize_cal_ds(cal_ds, cal_type, echodata, waveform_mode, encode_mode)
+
+
+def _finalize_cal_ds(cal_ds, cal_type, echodata, waveform_mode, encode_mode):
+    """Attributes, provenance and water_level of a calibrated dataset (api.py:199-244)."""
     # attributes (api.py:199-219)
     cal_ds.coords["range_sample"].attrs = {"long_name": "Along-range sample number, base 0"}
     cal_ds.data_vars["echo_range"].attrs = {"long_name": "Range distance", "units": "m"}

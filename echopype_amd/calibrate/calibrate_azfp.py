@@ -70,19 +70,26 @@ class CalibrateAZFP(CalibrateBase):
             rows[..., _lib.CF_D] = -r0 / k
         return rows
 
-    def _cal_power_samples(self, cal_type, **kwargs):
+    def _power_inputs(self, cal_type):
         if cal_type not in ("Sv", "TS"):
             raise ValueError("cal_type not recognized!")
         self.compute_echo_range(cal_type=cal_type)
         coef = self._dev(self._rows(cal_type), torch.float64)
         raw = self._dev(self.beam["backscatter_r"].data, torch.float32)
-        out_t, range_t = ops.sv_power(raw, coef, cal_type=cal_type, flags=0, dtype=self.dtype)
+        return raw, coef, 0, None  # no R' <= 0 guard, echo_range not masked (calibrate_azfp.py)
+
+    def _finish(self, cal_type, out_t, range_t, tau_eff=None):
         ds = Dataset(coords={k: self.beam.coords[k] for k in ECHO_DIMS})
         ds[cal_type] = self._wrap(out_t, ECHO_DIMS)
         ds["echo_range"] = self._wrap(range_t, ECHO_DIMS)
         self.range_meter = ds["echo_range"]
         ds["frequency_nominal"] = self.beam["frequency_nominal"]
         return self._add_params_to_output(ds)
+
+    def _cal_power_samples(self, cal_type, **kwargs):
+        raw, coef, flags, _ = self._power_inputs(cal_type)
+        out_t, range_t = ops.sv_power(raw, coef, cal_type=cal_type, flags=flags, dtype=self.dtype)
+        return self._finish(cal_type, out_t, range_t)
 
     def compute_Sv(self, **kwargs):
         return self._cal_power_samples("Sv")

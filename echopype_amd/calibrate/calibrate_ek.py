@@ -153,8 +153,9 @@ class CalibrateEK(CalibrateBase):
         ds["frequency_nominal"] = self.beam["frequency_nominal"]
         return self._add_params_to_output(ds)
 
-    def _cal_power_samples(self, cal_type):
-        """One fused pass for calibrate_ek.py:79-206."""
+    def _power_inputs(self, cal_type):
+        """(raw f32 tensor, coefficient rows, kernel flags, tau_eff): everything the power-sample
+        kernels need; shared by compute_Sv/TS and the fused Sv->MVBS entry point."""
         C, P, S = self._shape()
         f64 = torch.float64
         tau_eff, _ = self._tau_effective(False) if cal_type == "Sv" else (np.ones(C), None)
@@ -175,7 +176,12 @@ class CalibrateEK(CalibrateBase):
             sonar=self.sonar_type, cal_type=cal_type,
             gpt=self._dev(gpt.astype(np.uint8)) if self.sonar_type == "EK80" else None)
         raw = self._dev(self.beam["backscatter_r"].data, torch.float32)
-        out_t, range_t = ops.sv_power(raw, coef, cal_type=cal_type, dtype=self.dtype)
+        return raw, coef, _lib.FLAG_GUARD_POS | _lib.FLAG_MASK_RANGE, tau_eff
+
+    def _cal_power_samples(self, cal_type):
+        """One fused pass for calibrate_ek.py:79-206."""
+        raw, coef, flags, tau_eff = self._power_inputs(cal_type)
+        out_t, range_t = ops.sv_power(raw, coef, cal_type=cal_type, flags=flags, dtype=self.dtype)
         return self._finish(cal_type, out_t, range_t, tau_eff)
 
 

@@ -92,9 +92,17 @@ def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="
     res = ops.mvbs(sv_t, bin_start, n_t, range_bin_m, n_r, range=rg_t, skipna=skipna, closed=closed,
                    fill_value=fill_value, ping_perm=perm)
 
+    return _assemble_mvbs(ds_Sv, res["MVBS"], dim_0, ping_time, e0, dt, n_t, r_edges, range_var, range_bin_m,
+                          ping_time_bin, closed)
+
+
+def _assemble_mvbs(ds_Sv, mvbs_t, dim_0, ping_time, e0, dt, n_t, r_edges, range_var, range_bin_m,
+                   ping_time_bin, closed):
+    """Coordinates (left bin edges), positions, attributes and provenance of the MVBS dataset
+    (commongrid/api.py:146-189)."""
     t_left = (e0 + dt * np.arange(n_t)).astype("datetime64[ns]")
     ds_MVBS = Dataset(coords={"ping_time": t_left, dim_0: ds_Sv[dim_0].values, range_var: r_edges[:-1]})
-    ds_MVBS["Sv"] = DataArray(DeviceArray(res["MVBS"]), (dim_0, "ping_time", range_var))
+    ds_MVBS["Sv"] = DataArray(DeviceArray(mvbs_t), (dim_0, "ping_time", range_var))
 
     # positions: per-bin nanmean of latitude / longitude (utils.py:453-501); O(P) on the host
     if "latitude" in ds_Sv and "longitude" in ds_Sv:

@@ -28,6 +28,7 @@ enum { OP_MVBS = 0, OP_NOISE = 1 };
 enum { BIN_PHYS = 0, BIN_INDEX = 1 };
 
 struct ReduceArgs {
+  double* range_max_out;  // fused fast path only
   const float* raw;
   const void* sv;
   const void* range;
@@ -399,7 +400,8 @@ int epa_fused_fast_path(const float* raw, const double* coef, int C, int P, int 
                         unsigned cal_flags, const int32_t* bin_start, int n_tbins, double range_bin,
                         int n_rbins, unsigned bin_flags, double fill_value, void* sv_out,
                         void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
-                        size_t lds_bytes, unsigned cnt_off, hipStream_t st);
+                        size_t lds_bytes, unsigned cnt_off, unsigned long long* rmax_key,
+                        hipStream_t st);
 
 namespace {
 
@@ -472,9 +474,10 @@ int zero_partials(void* sum_out, uint32_t* cnt_out, size_t cells, hipStream_t st
 
 template <typename T, int SRC>
 int run_mvbs(ReduceArgs& a, hipStream_t st) {
-  const Plan pl = make_plan<T>(a.C, a.P, a.S, a.n_tbins, a.n_rbins,
+  Plan pl = make_plan<T>(a.C, a.P, a.S, a.n_tbins, a.n_rbins,
                                al16(a.raw) && al16(a.sv) && al16(a.range) && al16(a.sv_out) &&
                                    al16(a.range_out));
+  if (SRC == SRC_RAW && a.range_max_out) pl.nparts = 1;  // by-product only exists on the single-stage kernel
   a.nparts = pl.nparts;
   const size_t cells = (size_t)a.C * a.n_tbins * a.n_rbins;
   const bool two_stage = pl.nparts > 1 || !pl.use_lds;
@@ -485,7 +488,12 @@ int run_mvbs(ReduceArgs& a, hipStream_t st) {
                                a.nspread, a.cal_flags, a.bin_start, a.n_tbins, a.range_bin,
                                a.n_rbins, a.bin_flags, a.fill_value, a.sv_out, a.out, a.sum_out,
                                a.cnt_out, sizeof(T) == 8 ? EPA_F64 : EPA_F32, pl.tab_off,
-                               pl.cnt_off, st);
+                               pl.cnt_off, reinterpret_cast<unsigned long long*>(a.range_max_out), st);
+  if (a.range_max_out) {
+    epa::set_error("epa_sv_mvbs_fused: range_max_out is only produced by the default configuration "
+                   "(guard + masked range, skipna, left-closed bins, sorted pings, no echo_range output)");
+    return EPA_EUNSUPPORTED;
+  }
   if (two_stage) {
     EPA_CHECK_ARG(a.sum_out && a.cnt_out,
                   "binned reduction: this shape (C*n_tbins=%lld, n_rbins=%d) needs the sum_out/"
@@ -516,12 +524,21 @@ int check_bins(const char* fn, const int32_t* bin_start, int n_tbins, double ran
 
 }  // namespace
 
+namespace {
+__global__ void decode_range_max_kernel(double* p) {
+  const unsigned long long k = *reinterpret_cast<unsigned long long*>(p);
+  // inverse of the order-preserving key; key 0 = nothing seen -> NaN
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  *p = k == 0ull ? __builtin_nan("") : __longlong_as_double(b);
+}
+}  // namespace
+
 extern "C" int epa_sv_mvbs_fused(const float* raw, const double* coef, int C, int P, int S,
                                  int cal_type, unsigned cal_flags, const int32_t* bin_start,
                                  const int32_t* ping_perm, int n_tbins, double range_bin,
                                  int n_rbins, unsigned bin_flags, double fill_value, void* sv_out,
                                  void* range_out, void* mvbs_out, void* sum_out, uint32_t* cnt_out,
-                                 int dtype, epa_stream_t stream) {
+                                 double* range_max_out, int dtype, epa_stream_t stream) {
   EPA_CHECK_ARG(raw && coef && mvbs_out, "epa_sv_mvbs_fused: NULL array argument");
   EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_sv_mvbs_fused: C=%d P=%d S=%d", C, P, S);
   EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_sv_mvbs_fused: bad cal_type");
@@ -536,10 +553,16 @@ extern "C" int epa_sv_mvbs_fused(const float* raw, const double* coef, int C, in
   a.n_rbins = n_rbins; a.range_sample_num = 1; a.bin_flags = bin_flags;
   a.fill_value = fill_value; a.noise_max = __builtin_nan("");
   a.sv_out = sv_out; a.range_out = range_out; a.out = mvbs_out; a.sum_out = sum_out; a.cnt_out = cnt_out;
-  if (dtype == EPA_F64) return run_mvbs<double, SRC_RAW>(a, (hipStream_t)stream);
-  if (dtype == EPA_F32) return run_mvbs<float, SRC_RAW>(a, (hipStream_t)stream);
-  epa::set_error("epa_sv_mvbs_fused: bad dtype %d", dtype);
-  return EPA_EINVAL;
+  a.range_max_out = range_max_out;
+  EPA_CHECK_ARG(dtype == EPA_F64 || dtype == EPA_F32, "epa_sv_mvbs_fused: bad dtype %d", dtype);
+  if (range_max_out) EPA_CHECK_HIP(hipMemsetAsync(range_max_out, 0, sizeof(double), (hipStream_t)stream));
+  const int rc = dtype == EPA_F64 ? run_mvbs<double, SRC_RAW>(a, (hipStream_t)stream)
+                                  : run_mvbs<float, SRC_RAW>(a, (hipStream_t)stream);
+  if (rc == EPA_OK && range_max_out) {
+    hipLaunchKernelGGL(decode_range_max_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, range_max_out);
+    return epa::check_launch("decode_range_max_kernel");
+  }
+  return rc;
 }
 
 extern "C" int epa_mvbs(const void* sv, const void* range, const double* coef, int C, int P, int S,

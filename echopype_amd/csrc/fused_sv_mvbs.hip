@@ -25,7 +25,14 @@ struct Args {
   double nspread, fill_value;
   unsigned guard, mask_range, skipna, closed_right;
   unsigned cnt_off, tab_off;
+  unsigned long long* rmax_key;  // optional: max valid echo_range as an order-preserving u64 key
 };
+
+// order-preserving map double -> u64 (so that atomicMax on the key is a max on the double)
+__device__ __forceinline__ unsigned long long ordered_key(double v) {
+  const unsigned long long b = __double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
 
 template <typename T>
 __device__ __noinline__ T log10_slow(T x) {
@@ -63,7 +70,7 @@ struct Column {
 template <typename T>
 __device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::CoefRow& r, T g, T a2,
                                             T A0, T nspread, double bin, double inv_bin, int n_rbins,
-                                            const double* tab, T* lsum, uint32_t* lcnt) {
+                                            const double* tab, T* lsum, uint32_t* lcnt, double& xmax) {
   const T NaN = epa::M<T>::nan();
   const double x = c.sra * r.rb + r.r0;  // echo_range = (s*ra)*rb [+0]
   const double rtd = x - r.shift;
@@ -77,6 +84,7 @@ __device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::
   const T v = epa::lin_from_db(sv, tab);
   // still inside the bin of the previous ping?  NaN raw -> NaN echo_range: never inside
   const bool xok = raw == raw;
+  xmax = fmax(xmax, xok ? x : xmax);  // dead code (removed) unless the caller reads xmax
   const bool same = xok & (x >= c.blo) & (x < c.bhi);
   if (!same) {
     const int rb = xok ? epa::range_bin_index(x, bin, inv_bin, n_rbins, false) : -1;
@@ -103,7 +111,7 @@ __device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::
 #ifndef EPA_FUSED_MIN_WAVES
 #define EPA_FUSED_MIN_WAVES 1
 #endif
-template <typename T, bool WRITE_SV>
+template <typename T, bool WRITE_SV, bool RMAX>
 __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvbs_kernel(
     const float* __restrict__ raw, const epa::CoefRow* __restrict__ coef,
     const int32_t* __restrict__ bin_start, T* __restrict__ sv_out, T* __restrict__ mvbs_out,
@@ -133,6 +141,7 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
   const float* __restrict__ raw_c = raw + (size_t)c * a.P * S;
   T* __restrict__ sv_c = WRITE_SV ? sv_out + (size_t)c * a.P * S : nullptr;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double xmax = -__builtin_inf();
 
   for (int seg = 0; seg < nseg; ++seg) {
   const int pb = extra ? (seg == 0 ? 0 : bin_start[a.n_tbins]) : bin_start[tb];
@@ -190,8 +199,8 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
         }
       }
       const T g = (T)r.g, a2 = (T)r.alpha2, A0 = (T)r.A0;
-      const T sv0 = process_sample<T>(col[0], inA.x, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt);
-      const T sv1 = process_sample<T>(col[1], inA.y, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt);
+      const T sv0 = process_sample<T>(col[0], inA.x, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax);
+      const T sv1 = process_sample<T>(col[1], inA.y, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax);
       if (WRITE_SV) {
 #ifndef EPA_PLAIN_STORES  // streaming (nt) stores: +2 % at 4 G samples, Sv is never re-read here
         epa::store_nt2(sv_c + row_off + sA, sv0, sv1);
@@ -201,8 +210,8 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
 #endif
       }
       if (hasB) {
-        const T sv2 = process_sample<T>(col[2], inB.x, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt);
-        const T sv3 = process_sample<T>(col[3], inB.y, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt);
+        const T sv2 = process_sample<T>(col[2], inB.x, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax);
+        const T sv3 = process_sample<T>(col[3], inB.y, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax);
         if (WRITE_SV) {
 #ifndef EPA_PLAIN_STORES  // streaming (nt) stores: +2 % at 4 G samples, Sv is never re-read here
           epa::store_nt2(sv_c + row_off + sB, sv2, sv3);
@@ -216,6 +225,11 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
 #pragma unroll
     for (int j = 0; j < VEC; ++j) col[j].flush(lsum, lcnt);
   }
+  }
+  if (RMAX) {  // max valid echo_range seen by this workgroup -> one atomic per wave
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) xmax = fmax(xmax, __shfl_down(xmax, o, 64));
+    if (lane == 0 && xmax > -__builtin_inf()) atomicMax(a.rmax_key, ordered_key(xmax));
   }
   if (extra) return;
   __syncthreads();
@@ -238,9 +252,9 @@ int launch(Args& a, const float* raw, const double* coef, const int32_t* bin_sta
   const dim3 grid((unsigned)a.n_tbins + 1u, (unsigned)C);  // +1: pings outside every time bin
   a.tab_off = (unsigned)((lds_bytes + 15) & ~(size_t)15);
   lds_bytes = a.tab_off + epa::kMathTabBytes;
-#define EPA_FL(W)                                                                              \
+#define EPA_FL(W, R)                                                                           \
   do {                                                                                         \
-    auto kern = fused_sv_mvbs_kernel<T, W>;                                                    \
+    auto kern = fused_sv_mvbs_kernel<T, W, R>;                                                 \
     if (lds_bytes > 64 * 1024)                                                                 \
       EPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
                                         hipFuncAttributeMaxDynamicSharedMemorySize,            \
@@ -249,7 +263,11 @@ int launch(Args& a, const float* raw, const double* coef, const int32_t* bin_sta
                        reinterpret_cast<const epa::CoefRow*>(coef), bin_start, (T*)sv_out,     \
                        (T*)mvbs_out, (T*)sum_out, cnt_out, a);                                 \
   } while (0)
-  if (sv_out) EPA_FL(true); else EPA_FL(false);
+  if (a.rmax_key) {
+    if (sv_out) EPA_FL(true, true); else EPA_FL(false, true);
+  } else {
+    if (sv_out) EPA_FL(true, false); else EPA_FL(false, false);
+  }
 #undef EPA_FL
   return epa::check_launch("fused_sv_mvbs_kernel");
 }
@@ -301,8 +319,10 @@ int epa_fused_fast_path(const float* raw, const double* coef, int C, int P, int 
                         unsigned cal_flags, const int32_t* bin_start, int n_tbins, double range_bin,
                         int n_rbins, unsigned bin_flags, double fill_value, void* sv_out,
                         void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
-                        size_t lds_bytes, unsigned cnt_off, hipStream_t st) {
+                        size_t lds_bytes, unsigned cnt_off, unsigned long long* rmax_key,
+                        hipStream_t st) {
   epa_fused::Args a{};
+  a.rmax_key = rmax_key;
   a.P = P; a.S = S; a.n_tbins = n_tbins; a.n_rbins = n_rbins;
   a.range_bin = range_bin; a.inv_range_bin = 1.0 / range_bin;
   a.nspread = nspread; a.fill_value = fill_value;

@@ -132,12 +132,16 @@ int epa_time_bin_offsets(const int64_t* ping_time, int P, int64_t t0, int64_t dt
  *   mvbs_out   : f64/f32 [C*n_tbins*n_rbins] in dB (fill_value where a bin is empty)
  *   sum_out/cnt_out : optional raw linear sums (dtype) / counts (u32) per bin, same shape, for
  *                 cross-shard merges; may be NULL
+ *   range_max_out : optional f64 [1]: nanmax(echo_range) as a by-product (what api.py:108-110 needs
+ *                 to size the range grid: call with a conservative n_rbins, then trim); NULL if not
+ *                 wanted.  Only the default configuration produces it (else EPA_EUNSUPPORTED).
  */
 int epa_sv_mvbs_fused(const float* raw, const double* coef, int C, int P, int S, int cal_type,
                       unsigned cal_flags, const int32_t* bin_start, const int32_t* ping_perm,
                       int n_tbins, double range_bin, int n_rbins, unsigned bin_flags,
                       double fill_value, void* sv_out, void* range_out, void* mvbs_out,
-                      void* sum_out, uint32_t* cnt_out, int dtype, epa_stream_t stream);
+                      void* sum_out, uint32_t* cnt_out, double* range_max_out, int dtype,
+                      epa_stream_t stream);
 
 /* ---- K5: compute_MVBS on an existing Sv dataset -----------------------------------------------------------
  * Replaces commongrid/utils.py:504-628 (+ :92).  sv: [C*P*S] of dtype.  Range coordinate either

@@ -215,6 +215,36 @@ def test_chain_sv_noise_mvbs(ep, dtype, rtol):
     assert mv.attrs["processing_function"] == "commongrid.compute_MVBS"
 
 
+@pytest.mark.parametrize("edge_case", [False, True])
+def test_fused_compute_Sv_MVBS_equals_two_calls(ep, edge_case):
+    """The one-pass entry point == compute_Sv followed by compute_MVBS: same Sv, same grid, same
+    MVBS; the range grid comes from the kernel's nanmax(echo_range) by-product -- including the
+    case where that maximum sits exactly on a bin edge (np.arange drops the last sample)."""
+    d = ep.synth.ek60_numpy(2, 130, 800)
+    if edge_case:
+        d["backscatter_r"] = np.where(np.isnan(d["backscatter_r"]), np.float32(-60), d["backscatter_r"])
+        d["sample_interval"][:] = 1.0 / 3000.0            # k = 0.25 m with c = 1500 exactly
+        d["sound_speed_indicative"][:] = 1500.0
+        rb = "0.25m"
+    else:
+        rb = "1m"
+    ed = ep.echodata.from_ek60_arrays(d)
+    ds1 = ep.calibrate.compute_Sv(ed)
+    mv1 = ep.commongrid.compute_MVBS(ds1, range_bin=rb, ping_time_bin="20s")
+    ds2, mv2 = ep.compute_Sv_MVBS(ed, range_bin=rb, ping_time_bin="20s")
+    np.testing.assert_array_equal(ds2["Sv"].values, ds1["Sv"].values)
+    assert mv2["Sv"].shape == mv1["Sv"].shape
+    np.testing.assert_array_equal(mv2["echo_range"].values, mv1["echo_range"].values)
+    np.testing.assert_array_equal(mv2["ping_time"].values, mv1["ping_time"].values)
+    close(mv2["Sv"].values, mv1["Sv"].values, 1e-11, "fused vs two calls")
+    assert mv2["Sv"].attrs == mv1["Sv"].attrs and "echo_range" not in ds2
+    # flag combinations the fused kernel does not serve take the two-call route: same answer
+    ds3, mv3 = ep.compute_Sv_MVBS(ed, range_bin=rb, ping_time_bin="20s", closed="right")
+    mv4 = ep.commongrid.compute_MVBS(ds1, range_bin=rb, ping_time_bin="20s", closed="right")
+    close(mv3["Sv"].values, mv4["Sv"].values, 1e-11, "closed=right")
+    assert "echo_range" in ds3
+
+
 # ------------------------------------------------------------------------------------ commongrid
 @pytest.mark.parametrize("kind", ["regular", "irregular"])
 def test_compute_MVBS_reference_values(ep, kind, caplog):
