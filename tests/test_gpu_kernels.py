@@ -251,6 +251,52 @@ def test_fused_writes_sv_for_pings_outside_every_bin(env):
         _assert_close(res["MVBS"].cpu().numpy(), exp, 1e-9, "MVBS of the covered pings")
 
 
+@pytest.mark.parametrize("S", [333, 1001, 2, 7, 1026])
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_fused_and_unfused_odd_range_lengths(env, S, dtype):
+    """Ragged sizes: S not a multiple of the vector widths (scalar lanes), S smaller than a wavefront,
+    S just past one 1024-sample chunk."""
+    torch, ops, synth = env
+    d = synth.ek60_numpy(2, 47, S)
+    sv, er = _oracle_ek60(d, "Sv")
+    coef = _coef_ek60(torch, ops, d, "Sv")
+    td = getattr(torch, dtype)
+    out, rng = ops.sv_power(_dev(torch, d["backscatter_r"]), coef, dtype=td)
+    _assert_close(out.cpu().numpy(), sv, RTOL[dtype], f"K1 S={S}")
+    if np.isfinite(er).any() and np.nanmax(er) > 0:
+        exp_mv, _, r_left = ogrid.compute_MVBS(sv, er, d["ping_time"], "0.5m", "20s")
+        bs, n_t = _time_bins(torch, ops, d["ping_time"], "20s")
+        res = ops.sv_mvbs_fused(_dev(torch, d["backscatter_r"]), coef, bs, n_t, 0.5, len(r_left), dtype=td)
+        _assert_close(res["Sv"].cpu().numpy(), sv, RTOL[dtype], f"fused Sv S={S}")
+        _assert_close(res["MVBS"].cpu().numpy(), exp_mv, RTOL[dtype], f"fused MVBS S={S}")
+
+
+def test_empty_and_degenerate_inputs(env):
+    """All-NaN pings, a dataset whose every sample is NaN, a single ping / single sample."""
+    torch, ops, synth = env
+    d = synth.ek60_numpy(1, 40, 64)
+    d["backscatter_r"][:, 10:20, :] = np.nan
+    sv, er = _oracle_ek60(d, "Sv")
+    coef = _coef_ek60(torch, ops, d, "Sv")
+    exp_mv, _, r_left = ogrid.compute_MVBS(sv, er, d["ping_time"], "1m", "10s")
+    bs, n_t = _time_bins(torch, ops, d["ping_time"], "10s")
+    res = ops.sv_mvbs_fused(_dev(torch, d["backscatter_r"]), coef, bs, n_t, 1.0, len(r_left))
+    _assert_close(res["MVBS"].cpu().numpy(), exp_mv, 1e-9, "all-NaN time bin")
+    assert np.isnan(res["MVBS"].cpu().numpy()[0, 1]).all()  # pings 10..19 = one empty bin -> fill_value
+    res = ops.sv_mvbs_fused(_dev(torch, d["backscatter_r"]), coef, bs, n_t, 1.0, len(r_left), fill_value=-999.0)
+    assert (res["MVBS"].cpu().numpy()[0, 1] == -999.0).all()
+    allnan = np.full((1, 5, 8), np.nan, dtype=np.float32)
+    d1 = synth.ek60_numpy(1, 5, 8)
+    out, rng = ops.sv_power(_dev(torch, allnan), _coef_ek60(torch, ops, d1, "Sv"))
+    assert np.isnan(out.cpu().numpy()).all() and np.isnan(rng.cpu().numpy()).all()
+    lo, hi = ops.nanminmax(rng)
+    assert np.isnan(lo) and np.isnan(hi)
+    d2 = synth.ek60_numpy(1, 1, 4)
+    sv2, _ = _oracle_ek60(d2, "Sv")
+    out2, _ = ops.sv_power(_dev(torch, d2["backscatter_r"]), _coef_ek60(torch, ops, d2, "Sv"))
+    _assert_close(out2.cpu().numpy(), sv2, 1e-9, "1 ping x 4 samples")
+
+
 def test_mvbs_index_binning_kat(env):
     # test_commongrid_api.py:171-202 shape (4,100,4000) with ping_num=3, range_sample_num=7
     torch, ops, _ = env
