@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="float64", choices=["float64", "float32"])
+    ap.add_argument("--input", default="float32", choices=["float32", "int16"],
+                    help="float32: backscatter_r as echopype's converter stores it (the drop-in boundary); "
+                         "int16: the instrument's own samples + ping lengths (SURVEY 8f row 4, 2 B/sample in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend (nccl = RCCL; gloo only for dry runs of the N>1 logic)")
@@ -228,7 +231,8 @@ def main():
     dt = torch.float64 if args.dtype == "float64" else torch.float32
     if args.workload == "cfg5":
         return run_tiled(args, torch, dist, ops, sharding, synth, world, rank, C, P, S, dt, cpu)
-    d = synth.ek60_device(C, P, S, seed=20260501 + rank)
+    i16 = args.input == "int16"
+    d = (synth.ek60_device_i16 if i16 else synth.ek60_device)(C, P, S, seed=20260501 + rank)
     # ping times of this shard: global ping index offset by rank (1 ping / s)
     ns_local = d["ping_time_ns"] + rank * P * 1_000_000_000
     bin_ns = 20_000_000_000
@@ -255,8 +259,12 @@ def main():
         bs = ops.time_bin_offsets(ns_local, e0_local, bin_ns, n_t)
         if timer is not None:
             timer.start()
-        res = ops.sv_mvbs_fused(d["backscatter_r"], coef, bs, n_t, 1.0, n_r, dtype=dt, sv_out=sv,
-                                mvbs_out=mvbs, want_partials=straddle)
+        if i16:
+            res = ops.sv_mvbs_fused_i16(d["raw_i16"], d["n_valid"], coef, bs, n_t, 1.0, n_r, dtype=dt, sv_out=sv,
+                                        mvbs_out=mvbs, want_partials=straddle)
+        else:
+            res = ops.sv_mvbs_fused(d["backscatter_r"], coef, bs, n_t, 1.0, n_r, dtype=dt, sv_out=sv,
+                                    mvbs_out=mvbs, want_partials=straddle)
         if timer is not None:
             timer.stop()
         if straddle and world > 1:
@@ -290,14 +298,14 @@ def main():
     value = samples_total * args.steps / elapsed
 
     if rank == 0:
-        bps = BYTES_PER_SAMPLE[args.dtype]
+        bps = BYTES_PER_SAMPLE[args.dtype] - (2 if i16 else 0)
         achieved = C * P * S * bps / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = f"{args.workload}:{args.dtype}"
+                key = f"{args.workload}:{args.dtype}" + (":int16" if i16 else "")
                 if key in tj:
                     traffic = tj[key]["bytes_per_launch"]
             except Exception:  # noqa: BLE001
@@ -309,7 +317,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.dtype == "float64" else "f32",
             "data": "synthetic",
             "config": {"workload": f"EK60 CW {C}ch x {P} pings x {S} range per GPU ({args.workload}), "
-                                   "fused compute_Sv -> compute_MVBS (20 s x 1 m), Sv + MVBS written",
+                                   "fused compute_Sv -> compute_MVBS (20 s x 1 m), Sv + MVBS written"
+                                   + (", int16 instrument samples in" if i16 else ""),
                        "pings_total": P * world, "sharding": f"ping_time x{world}",
                        "collective": "none (shard edges on bin edges)" if not straddle else "edge-bin all-reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -28,7 +28,9 @@ enum { OP_MVBS = 0, OP_NOISE = 1 };
 enum { BIN_PHYS = 0, BIN_INDEX = 1 };
 
 struct ReduceArgs {
-  double* range_max_out;  // fused fast path only
+  double* range_max_out;      // fused fast path only
+  const int16_t* raw_i16;     // fused fast path only: instrument int16 power samples ...
+  const int32_t* n_valid;     // ... with the recorded length of every ping
   const float* raw;
   const void* sv;
   const void* range;
@@ -396,7 +398,8 @@ __global__ __launch_bounds__(epa::kBlock) void block_nanmin_kernel(const T* __re
 }  // namespace
 
 // fused_sv_mvbs.hip
-int epa_fused_fast_path(const float* raw, const double* coef, int C, int P, int S, double nspread,
+int epa_fused_fast_path(const void* raw, int raw_is_i16, const int32_t* n_valid, const double* coef,
+                        int C, int P, int S, double nspread,
                         unsigned cal_flags, const int32_t* bin_start, int n_tbins, double range_bin,
                         int n_rbins, unsigned bin_flags, double fill_value, void* sv_out,
                         void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
@@ -477,18 +480,25 @@ int run_mvbs(ReduceArgs& a, hipStream_t st) {
   Plan pl = make_plan<T>(a.C, a.P, a.S, a.n_tbins, a.n_rbins,
                                al16(a.raw) && al16(a.sv) && al16(a.range) && al16(a.sv_out) &&
                                    al16(a.range_out));
-  if (SRC == SRC_RAW && a.range_max_out) pl.nparts = 1;  // by-product only exists on the single-stage kernel
+  if (SRC == SRC_RAW && (a.range_max_out || a.raw_i16)) pl.nparts = 1;  // single-stage kernel only
   a.nparts = pl.nparts;
   const size_t cells = (size_t)a.C * a.n_tbins * a.n_rbins;
   const bool two_stage = pl.nparts > 1 || !pl.use_lds;
   if (SRC == SRC_RAW && !two_stage && pl.vec == 4 && !a.ping_perm && !a.range_out &&
       a.cal_flags == (EPA_FLAG_GUARD_POS | EPA_FLAG_MASK_RANGE) && a.bin_flags == EPA_BIN_SKIPNA &&
-      !getenv("EPA_NO_FAST_PATH"))
-    return epa_fused_fast_path(a.raw, reinterpret_cast<const double*>(a.coef), a.C, a.P, a.S,
+      (a.raw_i16 || !getenv("EPA_NO_FAST_PATH")))
+    return epa_fused_fast_path(a.raw_i16 ? (const void*)a.raw_i16 : (const void*)a.raw, a.raw_i16 != nullptr,
+                               a.n_valid, reinterpret_cast<const double*>(a.coef), a.C, a.P, a.S,
                                a.nspread, a.cal_flags, a.bin_start, a.n_tbins, a.range_bin,
                                a.n_rbins, a.bin_flags, a.fill_value, a.sv_out, a.out, a.sum_out,
                                a.cnt_out, sizeof(T) == 8 ? EPA_F64 : EPA_F32, pl.tab_off,
                                pl.cnt_off, reinterpret_cast<unsigned long long*>(a.range_max_out), st);
+  if (a.raw_i16) {
+    epa::set_error("epa_sv_mvbs_fused_i16: int16 ingest is served by the default configuration only "
+                   "(guard + masked range, skipna, left-closed bins, sorted pings, S %% 4 == 0, no "
+                   "echo_range output, range grid within LDS)");
+    return EPA_EUNSUPPORTED;
+  }
   if (a.range_max_out) {
     epa::set_error("epa_sv_mvbs_fused: range_max_out is only produced by the default configuration "
                    "(guard + masked range, skipna, left-closed bins, sorted pings, no echo_range output)");
@@ -533,18 +543,50 @@ __global__ void decode_range_max_kernel(double* p) {
 }
 }  // namespace
 
+static int fused_entry(const float* raw, const int16_t* raw_i16, const int32_t* n_valid,
+                       const double* coef, int C, int P, int S, int cal_type, unsigned cal_flags,
+                       const int32_t* bin_start, const int32_t* ping_perm, int n_tbins,
+                       double range_bin, int n_rbins, unsigned bin_flags, double fill_value,
+                       void* sv_out, void* range_out, void* mvbs_out, void* sum_out,
+                       uint32_t* cnt_out, double* range_max_out, int dtype, epa_stream_t stream);
+
 extern "C" int epa_sv_mvbs_fused(const float* raw, const double* coef, int C, int P, int S,
                                  int cal_type, unsigned cal_flags, const int32_t* bin_start,
                                  const int32_t* ping_perm, int n_tbins, double range_bin,
                                  int n_rbins, unsigned bin_flags, double fill_value, void* sv_out,
                                  void* range_out, void* mvbs_out, void* sum_out, uint32_t* cnt_out,
                                  double* range_max_out, int dtype, epa_stream_t stream) {
-  EPA_CHECK_ARG(raw && coef && mvbs_out, "epa_sv_mvbs_fused: NULL array argument");
+  EPA_CHECK_ARG(raw != nullptr, "epa_sv_mvbs_fused: NULL array argument");
+  return fused_entry(raw, nullptr, nullptr, coef, C, P, S, cal_type, cal_flags, bin_start, ping_perm,
+                     n_tbins, range_bin, n_rbins, bin_flags, fill_value, sv_out, range_out, mvbs_out,
+                     sum_out, cnt_out, range_max_out, dtype, stream);
+}
+
+extern "C" int epa_sv_mvbs_fused_i16(const int16_t* raw, const int32_t* n_valid, const double* coef,
+                                     int C, int P, int S, int cal_type, const int32_t* bin_start,
+                                     int n_tbins, double range_bin, int n_rbins, double fill_value,
+                                     void* sv_out, void* mvbs_out, void* sum_out, uint32_t* cnt_out,
+                                     double* range_max_out, int dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(raw && n_valid, "epa_sv_mvbs_fused_i16: NULL array argument");
+  return fused_entry(nullptr, raw, n_valid, coef, C, P, S, cal_type,
+                     EPA_FLAG_GUARD_POS | EPA_FLAG_MASK_RANGE, bin_start, nullptr, n_tbins, range_bin,
+                     n_rbins, EPA_BIN_SKIPNA, fill_value, sv_out, nullptr, mvbs_out, sum_out, cnt_out,
+                     range_max_out, dtype, stream);
+}
+
+static int fused_entry(const float* raw, const int16_t* raw_i16, const int32_t* n_valid,
+                       const double* coef, int C, int P, int S, int cal_type, unsigned cal_flags,
+                       const int32_t* bin_start, const int32_t* ping_perm, int n_tbins,
+                       double range_bin, int n_rbins, unsigned bin_flags, double fill_value,
+                       void* sv_out, void* range_out, void* mvbs_out, void* sum_out,
+                       uint32_t* cnt_out, double* range_max_out, int dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(coef && mvbs_out, "epa_sv_mvbs_fused: NULL array argument");
   EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_sv_mvbs_fused: C=%d P=%d S=%d", C, P, S);
   EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_sv_mvbs_fused: bad cal_type");
   if (int rc = check_bins("epa_sv_mvbs_fused", bin_start, n_tbins, range_bin, n_rbins)) return rc;
   ReduceArgs a{};
-  a.raw = raw; a.coef = reinterpret_cast<const epa::CoefRow*>(coef);
+  a.raw = raw; a.raw_i16 = raw_i16; a.n_valid = n_valid;
+  a.coef = reinterpret_cast<const epa::CoefRow*>(coef);
   a.C = C; a.P = P; a.S = S;
   a.nspread = cal_type == EPA_CAL_SV ? 20.0 : 40.0;
   a.cal_flags = cal_flags;

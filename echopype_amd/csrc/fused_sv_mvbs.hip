@@ -103,6 +103,53 @@ __device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::
   return sv;
 }
 
+// Raw-sample sources.  float: backscatter_r as the converter stores it (f32, NaN-padded,
+// convert/parse_base.py:302).  int16_t: the instrument's own power samples:
+// value = float32(int16) * float32(10*log10(2)/256) exactly as parse_base.py:24,302 computes it, and
+// samples at or beyond the ping's recorded length n_valid[c,p] are the NaN padding
+// (parse_base.py pad_shorter_ping) -- 2 B/sample of input traffic instead of 4.
+template <typename RawT>
+struct PingLoad;
+template <>
+struct PingLoad<float> {
+  float2 a, b;
+  __device__ __forceinline__ PingLoad() : a(make_float2(0.f, 0.f)), b(make_float2(0.f, 0.f)) {}
+  __device__ __forceinline__ void issue(const float* __restrict__ row, int sA, int sB, bool hasB, int, int) {
+    a = *reinterpret_cast<const float2*>(row + sA);
+    if (hasB) b = *reinterpret_cast<const float2*>(row + sB);
+  }
+  __device__ __forceinline__ void resolve(float2& A, float2& B, int, int, int, int) const {
+    A = a;
+    B = b;
+  }
+};
+template <>
+struct PingLoad<int16_t> {
+  // One 8-byte load per lane covers the wave's 256-sample tile (lane l holds samples 4l..4l+3 as two
+  // packed 32-bit words, word j = samples {2j, 2j+1} sits in lane j/2 slot j&1); two ds_bpermute
+  // per pair then hand lane l its words l and 64+l, i.e. the same {2l, 2l+1}, {128+2l, 128+2l+1}
+  // ownership as the float path.  (4-byte loads per lane measured 25 % SLOWER than the f32 input
+  // despite half the bytes.)
+  uint2 q;
+  __device__ __forceinline__ PingLoad() : q(make_uint2(0u, 0u)) {}
+  __device__ __forceinline__ void issue(const int16_t* __restrict__ row, int, int, bool, int s4, int S) {
+    if (s4 < S) q = *reinterpret_cast<const uint2*>(row + s4);
+  }
+  static __device__ __forceinline__ float2 unpack(unsigned w, int s, int n_valid) {
+    constexpr float kIndex2Power = 0.011758984205624266f;  // float32(10*log10(2)/256)
+    const float nanv = __builtin_nanf("");
+    const float x = (float)(short)(w & 0xffffu), y = (float)(short)(w >> 16);
+    return make_float2(s < n_valid ? x * kIndex2Power : nanv, s + 1 < n_valid ? y * kIndex2Power : nanv);
+  }
+  __device__ __forceinline__ void resolve(float2& A, float2& B, int sA, int sB, int nv, int lane) const {
+    const int src = lane >> 1;
+    const unsigned a0 = __shfl(q.x, src, 64), a1 = __shfl(q.y, src, 64);
+    const unsigned b0 = __shfl(q.x, 32 + src, 64), b1 = __shfl(q.y, 32 + src, 64);
+    A = unpack((lane & 1) ? a1 : a0, sA, nv);
+    B = unpack((lane & 1) ? b1 : b0, sB, nv);
+  }
+};
+
 // Lane -> sample mapping inside a 1024-sample chunk (4 waves x 256 samples): lane l of wave w owns
 // the two PAIRS {base + 2l, +1} and {base + 128 + 2l, +1}, base = chunk0 + 256 w.  Every load
 // (8 B/lane) and every store (16 B/lane f64) of a wave is then one contiguous 512 B / 1 KiB
@@ -111,9 +158,10 @@ __device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::
 #ifndef EPA_FUSED_MIN_WAVES
 #define EPA_FUSED_MIN_WAVES 1
 #endif
-template <typename T, bool WRITE_SV, bool RMAX>
+template <typename T, typename RawT, bool WRITE_SV, bool RMAX>
 __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvbs_kernel(
-    const float* __restrict__ raw, const epa::CoefRow* __restrict__ coef,
+    const RawT* __restrict__ raw, const int32_t* __restrict__ n_valid,
+    const epa::CoefRow* __restrict__ coef,
     const int32_t* __restrict__ bin_start, T* __restrict__ sv_out, T* __restrict__ mvbs_out,
     T* __restrict__ sum_out, uint32_t* __restrict__ cnt_out, Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -138,7 +186,8 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
   const T nspread = (T)a.nspread;
   const double bin = a.range_bin, inv_bin = a.inv_range_bin;
   const epa::CoefRow* __restrict__ rowp0 = coef + (size_t)c * a.P;
-  const float* __restrict__ raw_c = raw + (size_t)c * a.P * S;
+  const RawT* __restrict__ raw_c = raw + (size_t)c * a.P * S;
+  const int32_t* __restrict__ nv_c = n_valid ? n_valid + (size_t)c * a.P : nullptr;
   T* __restrict__ sv_c = WRITE_SV ? sv_out + (size_t)c * a.P * S : nullptr;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double xmax = -__builtin_inf();
@@ -156,38 +205,20 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
     for (int j = 0; j < VEC; ++j) col[j].init();
     double dcur = __builtin_nan(""), racur = __builtin_nan("");
     // software prefetch: the raw samples and the coefficient row of ping p+1 are requested before
-    // ping p is processed, so their latency hides behind ~150 instructions of arithmetic
-    float2 nxtA = make_float2(0.f, 0.f), nxtB = make_float2(0.f, 0.f);
+    // ping p is processed, so their latency hides behind ~150 instructions of arithmetic (+8 %)
+    const int s4 = chunk0 + wave * 256 + 4 * lane;  // int16 source: this lane's 8-byte quad
+    PingLoad<RawT> nxt;
     epa::CoefRow nxtR = rowp0[pb < pe ? pb : 0];
-    if (pb < pe) {
-      nxtA = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sA);
-      if (hasB) nxtB = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sB);
-    }
+    if (pb < pe) nxt.issue(raw_c + (size_t)pb * S, sA, sB, hasB, s4, S);
     for (int p = pb; p < pe; ++p) {
-#ifndef EPA_NO_PREFETCH
-#ifdef EPA_NO_ROW_PREFETCH
-      const epa::CoefRow r = rowp0[p];
-#else
       const epa::CoefRow r = nxtR;
-#endif
-      const float2 inA = nxtA, inB = nxtB;
       const size_t row_off = (size_t)p * S;
-#else
-      const size_t row_off = (size_t)p * S;
-      const epa::CoefRow r = rowp0[p];
-      const float2 inA = *reinterpret_cast<const float2*>(raw_c + row_off + sA);
-      const float2 inB = hasB ? *reinterpret_cast<const float2*>(raw_c + row_off + sB) : make_float2(0.f, 0.f);
-#endif
-#ifndef EPA_NO_PREFETCH
+      const int nv = nv_c ? nv_c[p] : S;
+      float2 inA, inB;
+      nxt.resolve(inA, inB, sA, sB, nv, lane);
       if (p + 1 < pe) {
-#else
-      if (false) {
-#endif
-#ifndef EPA_NO_ROW_PREFETCH
         nxtR = rowp0[p + 1];
-#endif
-        nxtA = *reinterpret_cast<const float2*>(raw_c + row_off + S + sA);
-        if (hasB) nxtB = *reinterpret_cast<const float2*>(raw_c + row_off + S + sB);
+        nxt.issue(raw_c + row_off + S, sA, sB, hasB, s4, S);
       }
       if (!((r.d == dcur) & (r.ra == racur))) {  // uniform; once per column for a file with
         dcur = r.d;                               // constant tau / sample_interval
@@ -246,20 +277,21 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
   }
 }
 
-template <typename T>
-int launch(Args& a, const float* raw, const double* coef, const int32_t* bin_start, void* sv_out,
-           void* mvbs_out, void* sum_out, uint32_t* cnt_out, int C, size_t lds_bytes, hipStream_t st) {
+template <typename T, typename RawT>
+int launch(Args& a, const RawT* raw, const int32_t* n_valid, const double* coef, const int32_t* bin_start,
+           void* sv_out, void* mvbs_out, void* sum_out, uint32_t* cnt_out, int C, size_t lds_bytes,
+           hipStream_t st) {
   const dim3 grid((unsigned)a.n_tbins + 1u, (unsigned)C);  // +1: pings outside every time bin
   a.tab_off = (unsigned)((lds_bytes + 15) & ~(size_t)15);
   lds_bytes = a.tab_off + epa::kMathTabBytes;
 #define EPA_FL(W, R)                                                                           \
   do {                                                                                         \
-    auto kern = fused_sv_mvbs_kernel<T, W, R>;                                                 \
+    auto kern = fused_sv_mvbs_kernel<T, RawT, W, R>;                                           \
     if (lds_bytes > 64 * 1024)                                                                 \
       EPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
                                         hipFuncAttributeMaxDynamicSharedMemorySize,            \
                                         (int)lds_bytes));                                      \
-    hipLaunchKernelGGL(kern, grid, dim3(epa::kBlock), lds_bytes, st, raw,                      \
+    hipLaunchKernelGGL(kern, grid, dim3(epa::kBlock), lds_bytes, st, raw, n_valid,             \
                        reinterpret_cast<const epa::CoefRow*>(coef), bin_start, (T*)sv_out,     \
                        (T*)mvbs_out, (T*)sum_out, cnt_out, a);                                 \
   } while (0)
@@ -315,7 +347,8 @@ extern "C" int epa_selftest_log10(const double* x, double* out, size_t n, epa_st
 }
 
 // Called by epa_sv_mvbs_fused (block_reduce.hip) when the fast path applies.
-int epa_fused_fast_path(const float* raw, const double* coef, int C, int P, int S, double nspread,
+int epa_fused_fast_path(const void* raw, int raw_is_i16, const int32_t* n_valid, const double* coef,
+                        int C, int P, int S, double nspread,
                         unsigned cal_flags, const int32_t* bin_start, int n_tbins, double range_bin,
                         int n_rbins, unsigned bin_flags, double fill_value, void* sv_out,
                         void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
@@ -331,9 +364,14 @@ int epa_fused_fast_path(const float* raw, const double* coef, int C, int P, int 
   a.skipna = (bin_flags & EPA_BIN_SKIPNA) != 0;
   a.closed_right = (bin_flags & EPA_BIN_CLOSED_RIGHT) != 0;
   a.cnt_off = cnt_off;
-  if (dtype == EPA_F64)
-    return epa_fused::launch<double>(a, raw, coef, bin_start, sv_out, mvbs_out, sum_out, cnt_out, C,
-                                     lds_bytes, st);
-  return epa_fused::launch<float>(a, raw, coef, bin_start, sv_out, mvbs_out, sum_out, cnt_out, C,
-                                  lds_bytes, st);
+#define EPA_GO(T, RawT)                                                                           \
+  return epa_fused::launch<T, RawT>(a, reinterpret_cast<const RawT*>(raw), n_valid, coef, bin_start, \
+                                    sv_out, mvbs_out, sum_out, cnt_out, C, lds_bytes, st)
+  if (raw_is_i16) {
+    if (dtype == EPA_F64) EPA_GO(double, int16_t);
+    EPA_GO(float, int16_t);
+  }
+  if (dtype == EPA_F64) EPA_GO(double, float);
+  EPA_GO(float, float);
+#undef EPA_GO
 }

@@ -144,6 +144,30 @@ def sv_mvbs_fused(raw, coef, bin_start, n_tbins, range_bin, n_rbins, *, cal_type
                 MVBS=mvbs_out, sum=ssum, cnt=cnt, range_max=rmax)
 
 
+def sv_mvbs_fused_i16(raw_i16, n_valid, coef, bin_start, n_tbins, range_bin, n_rbins, *, cal_type="Sv",
+                      fill_value=float("nan"), dtype=torch.float64, want_sv=True, want_partials=False,
+                      sv_out=None, mvbs_out=None, want_range_max=False):
+    """K1+K5 fed with int16 instrument samples + per-ping recorded lengths."""
+    C, P, S = raw_i16.shape
+    if raw_i16.dtype != torch.int16 or n_valid.dtype != torch.int32:
+        raise ValueError("raw_i16 must be int16 and n_valid int32")
+    dev = raw_i16.device
+    if want_sv and sv_out is None:
+        sv_out = torch.empty((C, P, S), dtype=dtype, device=dev)
+    if mvbs_out is None:
+        mvbs_out = torch.empty((C, n_tbins, n_rbins), dtype=dtype, device=dev)
+    ssum = cnt = None
+    if want_partials:
+        ssum = torch.empty((C, n_tbins, n_rbins), dtype=dtype, device=dev)
+        cnt = torch.empty((C, n_tbins, n_rbins), dtype=torch.int32, device=dev)
+    rmax = torch.empty(1, dtype=torch.float64, device=dev) if want_range_max else None
+    call("epa_sv_mvbs_fused_i16", _p(raw_i16), _p(n_valid), _p(coef), C, P, S,
+         _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, _p(bin_start), int(n_tbins), float(range_bin),
+         int(n_rbins), float(fill_value), _p(sv_out) if want_sv else None, _p(mvbs_out), _p(ssum), _p(cnt),
+         _p(rmax), _DT[dtype], _stream())
+    return dict(Sv=sv_out if want_sv else None, MVBS=mvbs_out, sum=ssum, cnt=cnt, range_max=rmax)
+
+
 def mvbs(sv, bin_start, n_tbins, range_bin, n_rbins, *, range=None, coef=None, skipna=True,
          closed="left", fill_value=float("nan"), want_partials=False, ping_perm=None):
     """K5 on an existing Sv -> dict(MVBS, sum, cnt)."""

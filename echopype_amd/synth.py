@@ -106,6 +106,33 @@ def ek60_device(C, P, S, seed=20260501, device=None, chunk_pings=20000):
     return out
 
 
+def ek60_device_i16(C, P, S, seed=20260501, device=None, chunk_pings=20000):
+    """The same recipe as :func:`ek60_device` before the converter's float conversion: int16 power
+    samples (C,P,S) + the recorded length of every ping (C,P) int32."""
+    import torch
+
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    raw = torch.empty((C, P, S), dtype=torch.int16, device=dev)
+    for c in range(C):
+        for p0 in range(0, P, chunk_pings):
+            p1 = min(P, p0 + chunk_pings)
+            raw[c, p0:p1] = torch.randint(-12000, -2000, (p1 - p0, S), generator=g, device=dev, dtype=torch.int16)
+    short = torch.rand(P, generator=g, device=dev) < 0.10
+    n_valid = torch.full((C, P), S, dtype=torch.int32, device=dev)
+    n_valid[:, short] = S - max(1, int(round(0.05 * S)))
+    h = ek60_params(C, P)
+    out = {"raw_i16": raw, "n_valid": n_valid}
+    for k in ("sample_interval", "transmit_duration_nominal", "transmit_power", "sound_speed_indicative",
+              "absorption_indicative", "equivalent_beam_angle", "frequency_nominal", "pulse_length",
+              "gain_correction", "sa_correction"):
+        out[k] = torch.from_numpy(np.ascontiguousarray(h[k], dtype=np.float64)).to(dev)
+    out["ping_time_ns"] = torch.from_numpy(h["ping_time"].astype(np.int64)).to(dev)
+    out["ping_time"] = h["ping_time"]
+    return out
+
+
 # ---------------------------------------------------------------------------------------- EK80
 def ek80_filters(seed=20260501):
     """Deterministic stand-ins for the Vendor_specific WBT/PC filter coefficients (complex64)."""

@@ -143,6 +143,18 @@ int epa_sv_mvbs_fused(const float* raw, const double* coef, int C, int P, int S,
                       void* sum_out, uint32_t* cnt_out, double* range_max_out, int dtype,
                       epa_stream_t stream);
 
+/* Same pass fed with the instrument's own int16 power samples (SURVEY 8f "next" row 4; replaces the
+ * ingest arithmetic of convert/parse_base.py:24,302 -- float32(int16) * float32(10*log10(2)/256) --
+ * and the NaN padding of short pings, pad_shorter_ping): raw int16 [C*P*S], n_valid int32 [C*P] =
+ * recorded length of each ping (samples at or beyond it are padding = NaN).  2 B/sample of input
+ * instead of 4.  Default configuration only (R' <= 0 guard, echo_range masked by padding, skipna,
+ * left-closed bins, sorted pings, S % 4 == 0); other arguments as epa_sv_mvbs_fused.
+ */
+int epa_sv_mvbs_fused_i16(const int16_t* raw, const int32_t* n_valid, const double* coef, int C, int P,
+                          int S, int cal_type, const int32_t* bin_start, int n_tbins, double range_bin,
+                          int n_rbins, double fill_value, void* sv_out, void* mvbs_out, void* sum_out,
+                          uint32_t* cnt_out, double* range_max_out, int dtype, epa_stream_t stream);
+
 /* ---- K5: compute_MVBS on an existing Sv dataset -----------------------------------------------------------
  * Replaces commongrid/utils.py:504-628 (+ :92).  sv: [C*P*S] of dtype.  Range coordinate either
  * as a full array `range` ([C*P*S], f64 when dtype F64 else f32; echo_range or depth) or, when

@@ -297,6 +297,36 @@ def test_empty_and_degenerate_inputs(env):
     _assert_close(out2.cpu().numpy(), sv2, 1e-9, "1 ping x 4 samples")
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_fused_int16_ingest_is_bit_identical_to_the_f32_path(env, dtype):
+    """feeding the instrument's int16 samples + recorded ping lengths gives exactly
+    what the converter's float32 NaN-padded array gives (parse_base.py:24,302 arithmetic in-kernel)."""
+    torch, ops, synth = env
+    rng = np.random.default_rng(9)
+    C, P, S = 2, 260, 1024
+    d = synth.ek60_numpy(C, P, S)
+    i16 = rng.integers(-12000, -2000, size=(C, P, S), dtype=np.int16)
+    n_valid = np.full((C, P), S, dtype=np.int32)
+    n_valid[:, rng.random(P) < 0.2] = 970
+    n_valid[1, 7] = 0          # an empty ping
+    n_valid[0, 9] = 333        # odd length: the boundary falls inside a sample pair
+    f32 = i16.astype("float32") * synth.INDEX2POWER      # the converter's arithmetic
+    f32[np.arange(S)[None, None, :] >= n_valid[:, :, None]] = np.nan
+    d["backscatter_r"] = f32
+    coef = _coef_ek60(torch, ops, d, "Sv")
+    bs, n_t = _time_bins(torch, ops, d["ping_time"], "20s")
+    td = getattr(torch, dtype)
+    a = ops.sv_mvbs_fused(_dev(torch, f32), coef, bs, n_t, 1.0, 200, dtype=td, want_partials=True)
+    b = ops.sv_mvbs_fused_i16(_dev(torch, i16), _dev(torch, n_valid), coef, bs, n_t, 1.0, 200, dtype=td,
+                              want_partials=True, want_range_max=True)
+    np.testing.assert_array_equal(b["Sv"].cpu().numpy(), a["Sv"].cpu().numpy())
+    np.testing.assert_array_equal(b["cnt"].cpu().numpy(), a["cnt"].cpu().numpy())
+    _assert_close(b["MVBS"].cpu().numpy(), a["MVBS"].cpu().numpy(), 1e-12 if dtype == "float64" else 1e-5, "MVBS")
+    sv, er = _oracle_ek60(d, "Sv")
+    _assert_close(b["Sv"].cpu().numpy(), sv, RTOL[dtype], "int16 ingest vs oracle")
+    assert float(b["range_max"].item()) == np.nanmax(er)
+
+
 def test_mvbs_index_binning_kat(env):
     # test_commongrid_api.py:171-202 shape (4,100,4000) with ping_num=3, range_sample_num=7
     torch, ops, _ = env
