@@ -23,7 +23,14 @@
 
 namespace {
 
-constexpr int kR = 8;                      // outputs per lane
+#ifndef EPA_EK80_R
+#define EPA_EK80_R 8
+#endif
+#ifndef EPA_EK80_MIN_WAVES
+#define EPA_EK80_MIN_WAVES 1
+#endif
+constexpr int kR = EPA_EK80_R;             // outputs per lane (8 or 4)
+constexpr int kRShift = kR == 8 ? 3 : 2;
 constexpr int kTile = epa::kBlock * kR;    // 2048 outputs per workgroup
 constexpr int kMaxBeams = 8;
 
@@ -32,7 +39,7 @@ struct Cx {
   A re, im;
 };
 
-__device__ __forceinline__ int pad_idx(int a) { return a + (a >> 3); }
+__device__ __forceinline__ int pad_idx(int a) { return a + (a >> kRShift); }  // one pad element per kR
 
 struct CxArgs {
   const void* re;
@@ -139,7 +146,7 @@ __device__ __forceinline__ void conv8(const Cx<A>* __restrict__ xs, const Cx<A>*
 }
 
 template <typename InT, typename T, typename A, int NB>
-__global__ __launch_bounds__(epa::kBlock) void sv_complex_kernel(CxArgs a) {
+__global__ __launch_bounds__(epa::kBlock, EPA_EK80_MIN_WAVES) void sv_complex_kernel(CxArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Cx<A>* xs = reinterpret_cast<Cx<A>*>(smem);
   Cx<A>* rep = reinterpret_cast<Cx<A>*>(smem + a.rep_lds_off);
@@ -268,7 +275,7 @@ template <typename InT, typename T, typename A>
 int launch(CxArgs& a, int max_taps, hipStream_t st) {
   const int taps8 = (max_taps + kR - 1) / kR * kR;
   const int len = kTile + (taps8 > 0 ? taps8 + kR : 0);
-  const size_t xs_bytes = ((size_t)(len + (len >> 3) + 1) * sizeof(Cx<A>) + 15) & ~(size_t)15;
+  const size_t xs_bytes = ((size_t)(len + (len >> kRShift) + 1) * sizeof(Cx<A>) + 15) & ~(size_t)15;
   const size_t rep_bytes = ((size_t)(taps8 > 0 ? taps8 : kR) * sizeof(Cx<A>) + 15) & ~(size_t)15;
   const size_t mask_bytes = (size_t)2 * len;
   a.rep_lds_off = (unsigned)xs_bytes;
