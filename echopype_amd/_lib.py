@@ -28,6 +28,7 @@ NCCOEF = 8
 CC_RA, CC_RB, CC_SHIFT, CC_ALPHA2, CC_A, CC_PSCALE = range(6)
 FLAG_GUARD_POS, FLAG_MASK_RANGE = 1, 2
 BIN_SKIPNA, BIN_CLOSED_RIGHT = 1, 2
+POOL_NANMEAN, POOL_NANMEDIAN = 0, 1
 
 
 class EpaError(RuntimeError):
@@ -83,6 +84,16 @@ SIGNATURES = {
     "epa_noise_estimate": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _i, _vp],
     "epa_noise_apply": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _vp, _vp, _i, _vp],
     "epa_sv_complex": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "epa_range_bin_smooth": [_vp, _vp, _i, _i, _i, _i, _d, _d, _i, _vp, _i, _vp],
+    "epa_impulse_mask": [_vp, _i, _i, _i, _i, _d, _vp, _i, _vp],
+    "epa_pool_sv": [_vp, _i, _i, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _i, _vp],
+    "epa_attenuated_mask": [_vp, _vp, _i, _i, _i, _d, _d, _i, _d, _vp, _i, _vp],
+    "epa_apply_mask": [_vp, _vp, _sz, _sz, _d, _vp, _sz, _vp, _i, _vp],
+    "epa_mask_and": [_vp, _vp, _sz, _sz, _vp, _vp],
+    "epa_range_step_mean": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "epa_first_not_le": [_vp, _sz, _d, _i, _vp, _vp],
+    "epa_range_rows_check": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "epa_pool_sv_value": [_vp, _vp, _vp, _i, _i, _i, _d, _i, _d, _d, _d, _i, _d, _vp, _vp, _i, _vp],
 }
 
 for _name, _args in SIGNATURES.items():

@@ -3,12 +3,18 @@
 The per-sample work is two HIP kernel launches (epa_noise_estimate, epa_noise_apply).
 ``remove_background_noise`` adds ``Sv_noise`` and ``Sv_corrected`` to the CALLER's dataset, as the
 reference does (api.py:490-502).
+
+Also the Ryan et al. (2015) noise masks (api.py:30-359: mask_transient_noise, mask_impulse_noise,
+mask_attenuated_signal), each a handful of launches from csrc/noise_masks.hip.
 """
+import logging
+
 import numpy as np
 import torch
 
 from .. import ops
 from ..commongrid.api import _dev, _full
+from ..commongrid.utils import _parse_x_bin
 from ..utils.prov import echopype_prov_attrs, insert_processing_level
 from ..xr_lite import DataArray, DeviceArray, from_xarray
 from .utils import add_remove_background_noise_attrs, extract_dB
@@ -67,6 +73,132 @@ def remove_background_noise(ds_Sv, ping_num, range_sample_num, background_noise_
     prov["processing_function"] = "clean.remove_background_noise"
     ds_Sv.attrs.update(prov)
     return insert_processing_level(ds_Sv, "L*B", input_ds=ds_Sv)
+
+
+# ---- Ryan et al. (2015) noise masks ------------------------------------------------------------------
+
+logger = logging.getLogger("echopype_amd.clean")
+_CPS = ("channel", "ping_time", "range_sample")
+
+
+def _cube(da, ds, dtype=None):
+    """Device tensor of a variable in (channel, ping_time, range_sample) order (the reference
+    transposes to it, clean/utils.py:125-127), broadcast if lower-dimensional."""
+    if set(da.dims) != set(_CPS):
+        da = _full(da, ds, _CPS)
+    t = _dev(da, dtype)
+    if tuple(da.dims) != _CPS:
+        t = t.permute([da.dims.index(d) for d in _CPS])
+    return t.contiguous()
+
+
+def _mask_inputs(ds_Sv, range_var, need_range):
+    sv_t = _cube(ds_Sv["Sv"], ds_Sv)
+    if sv_t.dtype not in (torch.float32, torch.float64):
+        sv_t = sv_t.double()
+    rg_t = _cube(ds_Sv[range_var], ds_Sv, sv_t.dtype) if need_range else None
+    return sv_t, rg_t
+
+
+def _mask_da(ds_Sv, mask_t, dims=_CPS):
+    return DataArray(DeviceArray(mask_t.to(torch.bool)), dims,
+                     {d: ds_Sv[d].values for d in dims if d in ds_Sv.coords})
+
+
+def _samples_per_bin(rg_t, depth_bin):
+    """ceil(depth_bin / nanmean(diff(range))) per channel (clean/utils.py:131-133, :256-260)."""
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.ceil(depth_bin / ops.range_step_mean(rg_t)).astype(int)
+
+
+def _check_range_var(ds_Sv, range_var, what, allow_missing):
+    if range_var not in ["echo_range", "depth"]:
+        raise ValueError("`range_var` must be either `echo_range` or `depth`.")
+    if range_var not in ds_Sv.data_vars and not allow_missing:
+        raise ValueError(f"Masking {what} requires `{range_var}` data variable in `ds_Sv`.")
+
+
+def mask_transient_noise(ds_Sv, func="nanmean", depth_bin="10m", num_side_pings=25, exclude_above="250.0m",
+                         transient_noise_threshold="12.0dB", range_var="depth", use_index_binning=False,
+                         chunk_dict={}):
+    """Boolean (channel, ping_time, range_sample) mask: Sv - pooled Sv > threshold (api.py:30-168).
+    ``chunk_dict`` is accepted for signature compatibility (no dask here)."""
+    ds_Sv = from_xarray(ds_Sv)
+    _check_range_var(ds_Sv, range_var, "transient noise", use_index_binning)
+    if func != "nanmean" and func != "nanmedian":
+        raise ValueError(f"Input `func` is `{func}`. `func` must be `nanmean` or `nanmedian`.")
+    if func == "nanmedian":
+        logger.warning(
+            "`func=nanmedian` is an incredibly slow operation due to the overhead sorting. "
+            "We plan to add the Fielding Transient Noise Filter in the future"
+            "described here: https://github.com/OSOceanAcoustics/echopype/issues/1352")
+    thr = extract_dB(transient_noise_threshold)
+    depth_bin = _parse_x_bin(depth_bin, "range_bin")
+    exclude_above = _parse_x_bin(exclude_above, "range_bin")
+    sv_t, rg_t = _mask_inputs(ds_Sv, range_var, True)
+    C, P, S = sv_t.shape
+    mask = torch.empty((C, P, S), dtype=torch.uint8, device=sv_t.device)
+    if not use_index_binning:
+        nvalid, bad = ops.range_rows_check(rg_t)
+        if bad:
+            raise ValueError(f"`{range_var}` must be non-decreasing along `range_sample` with NaN only as "
+                             f"trailing padding ({bad} pings are not).")
+        lo, hi = ops.nanminmax(rg_t)
+        _, mask = ops.pool_sv_value(sv_t, rg_t, nvalid, depth_bin, num_side_pings, exclude_above, lo, hi,
+                                    func=func, threshold=thr, want_pooled=False)
+    else:
+        n_c = _samples_per_bin(rg_t, depth_bin)
+        s0 = ops.first_not_le(rg_t, exclude_above)  # np.argmin(range <= exclude_above), utils.py:143
+        if s0 == rg_t.numel():
+            s0 = 0
+        for c in range(C):
+            _, m = ops.pool_sv(sv_t[c:c + 1], s0, num_side_pings, int(n_c[c]), func=func, threshold=thr,
+                               want_pooled=False)
+            mask[c] = m[0]
+    return _mask_da(ds_Sv, mask)
+
+
+def mask_impulse_noise(ds_Sv, depth_bin="5m", num_side_pings=2, impulse_noise_threshold="10.0dB",
+                       range_var="depth", use_index_binning=False):
+    """Boolean impulse-noise mask (api.py:171-266); dims (channel, range_sample, ping_time), the
+    order the reference's apply_ufunc leaves them in."""
+    ds_Sv = from_xarray(ds_Sv)
+    _check_range_var(ds_Sv, range_var, "impulse noise", use_index_binning)
+    thr = extract_dB(impulse_noise_threshold)
+    depth_bin = _parse_x_bin(depth_bin, "range_bin")
+    sv_t, rg_t = _mask_inputs(ds_Sv, range_var, True)
+    C, P, S = sv_t.shape
+    if not use_index_binning:
+        lo, hi = ops.nanminmax(rg_t)
+        nb = len(np.arange(lo, hi + depth_bin, depth_bin)) - 1
+        up = ops.range_bin_smooth(sv_t, range=rg_t, r0=lo, bin=depth_bin, nbins=nb)
+    else:
+        n_c = _samples_per_bin(rg_t, depth_bin)
+        up = torch.empty_like(sv_t)
+        for c in range(C):
+            up[c] = ops.range_bin_smooth(sv_t[c:c + 1], nper=int(n_c[c]))[0]
+    mask = ops.impulse_mask(up, num_side_pings, thr)
+    dims = ("channel", "range_sample", "ping_time")
+    return _mask_da(ds_Sv, mask.permute(0, 2, 1).contiguous(), dims)
+
+
+def mask_attenuated_signal(ds_Sv, upper_limit_sl="400.0m", lower_limit_sl="500.0m", num_side_pings=15,
+                           attenuation_signal_threshold="8.0dB", range_var="depth"):
+    """Boolean (channel, ping_time, range_sample) attenuated-signal mask (api.py:269-359)."""
+    ds_Sv = from_xarray(ds_Sv)
+    _check_range_var(ds_Sv, range_var, "attenuated signal", False)
+    if upper_limit_sl > lower_limit_sl:  # compared as given (strings), api.py:308
+        raise ValueError("Minimum range has to be shorter than maximum range")
+    thr = extract_dB(attenuation_signal_threshold)
+    lower = _parse_x_bin(lower_limit_sl, "range_bin")
+    upper = _parse_x_bin(upper_limit_sl, "range_bin")
+    sv_t, rg_t = _mask_inputs(ds_Sv, range_var, True)
+    lo, hi = ops.nanminmax(rg_t)
+    if upper > hi or lower < lo:  # searching range outside the echosounder range, api.py:322-324
+        mask = torch.zeros(sv_t.shape, dtype=torch.uint8, device=sv_t.device)
+    else:
+        mask = ops.attenuated_mask(sv_t, rg_t, upper, lower, num_side_pings, thr)
+    return _mask_da(ds_Sv, mask)
 
 
 # names used by older echopype releases (docs/source/whats-new.md:366)

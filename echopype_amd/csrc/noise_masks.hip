@@ -1,0 +1,877 @@
+// Ryan et al. (2015) noise masks and apply_mask (SURVEY 8f "next" row 2).
+//
+// Replaces, in /root/reference/echopype:
+//   clean/utils.py:173-304  depth-bin down-sampling (linear nanmean) + forward-fill up-sampling
+//   clean/utils.py:307-323  two-sided ping comparison of the impulse-noise mask
+//   clean/utils.py:109-170  (2n+1) x (2m+1) pooled Sv (dask_image generic_filter, reflect boundary)
+//   clean/utils.py:326-372  ping-median vs block-median attenuated-signal mask
+//   clean/api.py:166        Sv - pooled > threshold
+//   mask/api.py:402-432     logical AND of masks, where(mask, Sv, fill_value)
+// Masks are uint8 [C*P*S] (1 = True) in the (channel, ping_time, range_sample) layout of Sv.
+//
+// Linear-domain sums are accumulated in double whatever the storage type; comparisons against the
+// thresholds are done in the storage type, as numpy does for the reference's arrays.
+#include "fast_math.h"
+
+namespace {
+
+using epa::kBlock;
+
+// scipy.ndimage / dask_image mode="reflect":  d c b a | a b c d | d c b a   (period 2n)
+__device__ __forceinline__ int reflect_index(int i, int n) {
+  const int period = 2 * n;
+  i %= period;
+  if (i < 0) i += period;
+  return i < n ? i : period - 1 - i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workgroup reductions (256 threads = 4 wavefronts); every thread gets the result
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned block_sum(unsigned v, unsigned* sh4) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh4[0] + sh4[1] + sh4[2] + sh4[3];
+}
+
+__device__ __forceinline__ unsigned long long block_min(unsigned long long v, unsigned long long* sh4) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long w = __shfl_down(v, o, 64);
+    v = w < v ? w : v;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned long long r = sh4[0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i) r = sh4[i] < r ? sh4[i] : r;
+  return r;
+}
+
+// lexicographic (value, index) minimum -- np.argmin's "first occurrence of the minimum"
+__device__ __forceinline__ int block_argmin(double v, int idx, double* shv, int* shi) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double w = __shfl_down(v, o, 64);
+    const int j = __shfl_down(idx, o, 64);
+    if (w < v || (w == v && j < idx)) { v = w; idx = j; }
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { shv[threadIdx.x >> 6] = v; shi[threadIdx.x >> 6] = idx; }
+  __syncthreads();
+  double bv = shv[0];
+  int bi = shi[0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (shv[i] < bv || (shv[i] == bv && shi[i] < bi)) { bv = shv[i]; bi = shi[i]; }
+  return bi;
+}
+
+// ------------------------------------------------------------------------------------------------
+// depth-bin smoothing: up[c,p,s] = 10 log10( nanmean_{s' in bin(s)} 10^(Sv[c,p,s']/10) )
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double bin_edge(double r0, double delta, int j) {
+  return __dadd_rn(r0, __dmul_rn((double)j, delta));  // np.arange: start + j*delta, two roundings
+}
+
+// FILL == false: flox membership in [e_j, e_j+1), -1 outside or NaN.
+// FILL == true : np.digitize(d, left edges) - 1 clipped to [0, nb-1] (NaN sorts last -> nb-1).
+template <bool FILL>
+__device__ __forceinline__ int value_bin(double d, double r0, double delta, double inv, int nb) {
+  if (!(d == d)) return FILL ? nb - 1 : -1;
+  const double t = (d - r0) * inv;
+  if (!(t > -2.0)) return FILL ? 0 : -1;
+  if (t > (double)nb + 2.0) return FILL ? nb - 1 : -1;
+  int j = (int)floor(t);
+  if (d < bin_edge(r0, delta, j)) --j;
+  else if (d >= bin_edge(r0, delta, j + 1)) ++j;
+  if (FILL) return j < 0 ? 0 : (j >= nb ? nb - 1 : j);
+  return (j >= 0 && j < nb) ? j : -1;
+}
+
+template <typename T, bool BY_VALUE>
+__global__ __launch_bounds__(kBlock) void range_bin_smooth_kernel(
+    const T* __restrict__ sv, const T* __restrict__ range, long long rows, int S, int nper, double r0,
+    double delta, int nbins, T* __restrict__ up) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const epa::MathTabs mt = epa::build_math_tabs(smem);
+  double* ssum = reinterpret_cast<double*>(smem + epa::kMathTabBytes);
+  unsigned* scnt = reinterpret_cast<unsigned*>(ssum + nbins);
+  const double inv = 1.0 / delta;
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += kBlock) {
+      ssum[b] = 0.0;
+      scnt[b] = 0u;
+    }
+    __syncthreads();
+    const T* svr = sv + (size_t)row * S;
+    const T* rr = BY_VALUE ? range + (size_t)row * S : nullptr;
+    // 4 consecutive samples per lane; a run of equal bins is merged before it touches LDS
+    for (int base = 4 * threadIdx.x; base < S; base += 4 * kBlock) {
+      int rb = -1;
+      double rs = 0.0;
+      unsigned rn = 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int s = base + j;
+        if (s >= S) break;
+        const T v = svr[s];
+        const int b = BY_VALUE ? value_bin<false>((double)rr[s], r0, delta, inv, nbins) : s / nper;
+        if (!(v == v) || b < 0) continue;
+        if (b != rb) {
+          if (rn) {
+            unsafeAtomicAdd(&ssum[rb], rs);
+            atomicAdd(&scnt[rb], rn);
+          }
+          rb = b;
+          rs = 0.0;
+          rn = 0u;
+        }
+        rs += (double)epa::lin_from_db(v, mt.exp2_tab);
+        ++rn;
+      }
+      if (rn) {
+        unsafeAtomicAdd(&ssum[rb], rs);
+        atomicAdd(&scnt[rb], rn);
+      }
+    }
+    __syncthreads();
+    T* ur = up + (size_t)row * S;
+    for (int s = threadIdx.x; s < S; s += kBlock) {
+      const int b = BY_VALUE ? value_bin<true>((double)rr[s], r0, delta, inv, nbins) : s / nper;
+      const unsigned n = scnt[b];
+      ur[s] = n ? (T)(10.0 * epa::fast_log10(ssum[b] / (double)n, mt.log_tab)) : epa::M<T>::nan();
+    }
+  }
+}
+
+// mask = (up[p] - up[p+n] > thr) & (up[p] - up[p-n] > thr), NaN differences (and the missing side at
+// the first / last n pings) count as +inf.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void impulse_compare_kernel(const T* __restrict__ up, int P, int S,
+                                                                 long long rows, int n, T thr,
+                                                                 uint8_t* __restrict__ mask) {
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int p = (int)(row % P);
+    const T* a = up + (size_t)row * S;
+    const T* f = (long long)p + n < P ? a + (size_t)n * S : nullptr;
+    const T* b = p - n >= 0 ? a - (size_t)n * S : nullptr;
+    uint8_t* m = mask + (size_t)row * S;
+    for (int s = threadIdx.x; s < S; s += kBlock) {
+      const T x = a[s];
+      T df = f ? x - f[s] : epa::M<T>::nan();
+      T db = b ? x - b[s] : epa::M<T>::nan();
+      if (!(df == df)) df = (T)__builtin_inf();
+      if (!(db == db)) db = (T)__builtin_inf();
+      m[s] = (df > thr && db > thr) ? 1 : 0;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pooled Sv, nanmean: separable box sums with reflect boundaries
+//   pass 1 (range):  vsum/vcnt[c,p,s] = sum / count of the non-NaN linear Sv over s-m..s+m
+//   pass 2 (ping) :  pooled = 10 log10( sum_{p-n..p+n} vsum / sum vcnt ),  mask = Sv - pooled > thr
+// ------------------------------------------------------------------------------------------------
+constexpr int kRangeTile = 2048;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void box_range_kernel(const T* __restrict__ sv, long long rows,
+                                                           int S, int s0, int m,
+                                                           double* __restrict__ vsum,
+                                                           int* __restrict__ vcnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const epa::MathTabs mt = epa::build_math_tabs(smem);
+  double* lin = reinterpret_cast<double*>(smem + epa::kMathTabBytes);
+  const int L = S - s0;
+  const int t0 = blockIdx.y * kRangeTile;  // relative to s0
+  const int nout = min(kRangeTile, L - t0);
+  const int nin = nout + 2 * m;
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    __syncthreads();
+    const T* svr = sv + (size_t)row * S + s0;
+    for (int i = threadIdx.x; i < nin; i += kBlock) {
+      const T v = svr[reflect_index(t0 - m + i, L)];
+      lin[i] = (v == v) ? (double)epa::lin_from_db(v, mt.exp2_tab) : __builtin_nan("");
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < nout; o += kBlock) {
+      double sum = 0.0;
+      int cnt = 0;
+      for (int k = 0; k <= 2 * m; ++k) {
+        const double x = lin[o + k];
+        if (x == x) {
+          sum += x;
+          ++cnt;
+        }
+      }
+      const size_t at = (size_t)row * S + s0 + t0 + o;
+      vsum[at] = sum;
+      vcnt[at] = cnt;
+    }
+  }
+}
+
+constexpr int kPingTile = 64, kColTile = 32;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void box_ping_kernel(const T* __restrict__ sv,
+                                                          const double* __restrict__ vsum,
+                                                          const int* __restrict__ vcnt, int P, int S,
+                                                          int s0, int n, T thr, T* __restrict__ pooled,
+                                                          uint8_t* __restrict__ mask) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const epa::MathTabs mt = epa::build_math_tabs(smem);
+  const int nrow = kPingTile + 2 * n;
+  double* ssum = reinterpret_cast<double*>(smem + epa::kMathTabBytes);
+  int* scnt = reinterpret_cast<int*>(ssum + (size_t)nrow * kColTile);
+  const int c = blockIdx.z, p0 = blockIdx.y * kPingTile, col0 = blockIdx.x * kColTile;
+  const size_t cbase = (size_t)c * P * S;
+  for (int i = threadIdx.x; i < nrow * kColTile; i += kBlock) {
+    const int r = i / kColTile, col = i % kColTile;
+    const int s = col0 + col;
+    double a = 0.0;
+    int k = 0;
+    if (s >= s0 && s < S) {
+      const size_t at = cbase + (size_t)reflect_index(p0 - n + r, P) * S + s;
+      a = vsum[at];
+      k = vcnt[at];
+    }
+    ssum[i] = a;
+    scnt[i] = k;
+  }
+  __syncthreads();
+  const int col = threadIdx.x % kColTile, s = col0 + col;
+  if (s >= S) return;
+  for (int k = threadIdx.x / kColTile; k < kPingTile; k += kBlock / kColTile) {
+    const int p = p0 + k;
+    if (p >= P) break;
+    T out = epa::M<T>::nan();
+    if (s >= s0) {
+      double sum = 0.0;
+      long long cnt = 0;
+      for (int j = 0; j <= 2 * n; ++j) {
+        sum += ssum[(k + j) * kColTile + col];
+        cnt += scnt[(k + j) * kColTile + col];
+      }
+      if (cnt > 0) out = (T)(10.0 * epa::fast_log10(sum / (double)cnt, mt.log_tab));
+    }
+    const size_t at = cbase + (size_t)p * S + s;
+    if (pooled) pooled[at] = out;
+    if (mask) mask[at] = (sv[at] - out > thr) ? 1 : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NaN-skipping median of the LINEAR values of a window, by radix selection on the dB values
+// (10^(x/10) is monotone, so the order statistics are those of x; an even count averages the two
+// middle values in the linear domain, as np.nanmedian(_log2lin(.)) does).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long sort_key(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_value(unsigned long long k) {
+  return __longlong_as_double((long long)((k >> 63) ? (k ^ 0x8000000000000000ull) : ~k));
+}
+
+template <typename T>
+struct Window {
+  const T* base;  // channel base pointer
+  int S;          // row stride
+  int p_lo, np;   // pings p_lo .. p_lo+np-1
+  int s_lo, ns;   // samples s_lo .. s_lo+ns-1
+  int P, s0;      // reflect domain: pings [0,P), samples [s0,S)
+  bool reflect;
+  // calls f(value) for every element this thread owns
+  template <typename F>
+  __device__ __forceinline__ void for_each(F f) const {
+    const int ne = np * ns;
+    for (int i = threadIdx.x; i < ne; i += kBlock) {
+      const int ip = i / ns, is = i - ip * ns;
+      int p = p_lo + ip, s = s_lo + is;
+      if (reflect) {
+        p = reflect_index(p, P);
+        s = s0 + reflect_index(s - s0, S - s0);
+      }
+      f((double)base[(size_t)p * S + s]);
+    }
+  }
+};
+
+// Window by VALUE of the range variable (pool_Sv, clean/utils.py:86-92): in ping q_lo + j the
+// samples lo[j] .. hi[j]-1 (contiguous because the range variable increases along range_sample).
+template <typename T>
+struct RaggedWindow {
+  const T* base;
+  int S, q_lo, nq;
+  const int* lo;  // LDS
+  const int* hi;
+  template <typename F>
+  __device__ __forceinline__ void for_each(F f) const {
+    for (int j = 0; j < nq; ++j) {
+      const T* row = base + (size_t)(q_lo + j) * S;
+      for (int s = lo[j] + (int)threadIdx.x; s < hi[j]; s += kBlock) f((double)row[s]);
+    }
+  }
+};
+
+struct SelectScratch {
+  unsigned hist[256];
+  unsigned u4[4];
+  unsigned long long q4[4];
+  unsigned digit, krem;
+};
+
+// Returns the median of 10^(x/10) over the non-NaN x of the window; n_valid = their count (the
+// result is NaN when it is 0).  Must be called by all threads of the workgroup.
+template <typename W>
+__device__ double window_median_lin(const W& w, SelectScratch* sc, const double* exp2_tab,
+                                    unsigned& n_valid) {
+  unsigned c = 0;
+  w.for_each([&](double v) { c += (v == v) ? 1u : 0u; });
+  const unsigned N = block_sum(c, sc->u4);
+  n_valid = N;
+  if (N == 0) return __builtin_nan("");
+  const unsigned k_lo = (N - 1) / 2;
+  unsigned k = k_lo;
+  unsigned long long prefix = 0ull;
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    __syncthreads();
+    sc->hist[threadIdx.x] = 0u;  // kBlock == 256
+    __syncthreads();
+    const unsigned long long hi_mask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+    unsigned* hist = sc->hist;
+    w.for_each([&](double v) {
+      if (v == v) {
+        const unsigned long long key = sort_key(v);
+        if ((key & hi_mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+      }
+    });
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const unsigned l = threadIdx.x;
+      const unsigned h0 = sc->hist[4 * l], h1 = sc->hist[4 * l + 1], h2 = sc->hist[4 * l + 2],
+                     h3 = sc->hist[4 * l + 3];
+      const unsigned tot = h0 + h1 + h2 + h3;
+      unsigned incl = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o, 64);
+        if ((int)l >= o) incl += t;
+      }
+      const unsigned excl = incl - tot;
+      if (excl <= k && k < incl) {
+        unsigned r = k - excl, d;
+        if (r < h0) d = 0;
+        else if ((r -= h0) < h1) d = 1;
+        else if ((r -= h1) < h2) d = 2;
+        else { r -= h2; d = 3; }
+        sc->digit = 4 * l + d;
+        sc->krem = r;
+      }
+    }
+    __syncthreads();
+    prefix |= (unsigned long long)sc->digit << shift;
+    k = sc->krem;
+  }
+  const double v1 = key_value(prefix);
+  double med = epa::lin_from_db(v1, exp2_tab);
+  if ((N & 1u) == 0u) {  // second middle value: next order statistic
+    unsigned le = 0;
+    unsigned long long gt = ~0ull;
+    w.for_each([&](double v) {
+      if (v == v) {
+        const unsigned long long key = sort_key(v);
+        if (key <= prefix) ++le;
+        else gt = key < gt ? key : gt;
+      }
+    });
+    const unsigned n_le = block_sum(le, sc->u4);
+    const unsigned long long min_gt = block_min(gt, sc->q4);
+    const double v2 = (n_le >= k_lo + 2) ? v1 : key_value(min_gt);
+    med = (med + epa::lin_from_db(v2, exp2_tab)) * 0.5;
+  }
+  return med;
+}
+
+// pooled Sv with func = nanmedian: one workgroup per output sample (the reference warns that this
+// variant is "incredibly slow"; here it is exact and usable on subsets, O(window) per sample).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pool_median_kernel(const T* __restrict__ sv, int P, int S,
+                                                             long long jobs, int s0, int n, int m,
+                                                             T thr, T* __restrict__ pooled,
+                                                             uint8_t* __restrict__ mask) {
+  __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
+  __shared__ SelectScratch sc;
+  const epa::MathTabs mt = epa::build_math_tabs(tabs);
+  __syncthreads();
+  for (long long job = blockIdx.x; job < jobs; job += gridDim.x) {
+    const int s = (int)(job % S);
+    const long long row = job / S;
+    const int p = (int)(row % P);
+    const long long c = row / P;
+    T out = epa::M<T>::nan();
+    if (s >= s0) {
+      Window<T> w{sv + (size_t)c * P * S, S, p - n, 2 * n + 1, s - m, 2 * m + 1, P, s0, true};
+      unsigned nv;
+      const double med = window_median_lin(w, &sc, mt.exp2_tab, nv);
+      if (nv) out = (T)(10.0 * epa::fast_log10(med, mt.log_tab));
+    }
+    if (threadIdx.x == 0) {
+      if (pooled) pooled[job] = out;
+      if (mask) mask[job] = (sv[job] - out > thr) ? 1 : 0;
+    }
+  }
+}
+
+// One workgroup per (channel, ping): layer limits from THIS ping's range row (np.argmin: first
+// NaN, else first minimum), median of the ping's layer vs median of the 2n-ping block [p-n, p+n).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void attenuated_mask_kernel(
+    const T* __restrict__ sv, const T* __restrict__ range, int P, int S, long long rows, T upper,
+    T lower, int n, T thr, uint8_t* __restrict__ mask) {
+  __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
+  __shared__ SelectScratch sc;
+  __shared__ double shv[4];
+  __shared__ int shi[4];
+  const epa::MathTabs mt = epa::build_math_tabs(tabs);
+  __syncthreads();
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int p = (int)(row % P);
+    const long long c = row / P;
+    const T* rr = range + (size_t)row * S;
+    double bu = __builtin_inf(), bl = __builtin_inf();
+    int iu = 0x7fffffff, il = 0x7fffffff;
+    for (int s = threadIdx.x; s < S; s += kBlock) {
+      const T r = rr[s];
+      T du = fabs(r - upper), dl = fabs(r - lower);
+      const double vu = (du == du) ? (double)du : -1.0;  // NaN beats every |.| >= 0
+      const double vl = (dl == dl) ? (double)dl : -1.0;
+      if (vu < bu) { bu = vu; iu = s; }
+      if (vl < bl) { bl = vl; il = s; }
+    }
+    const int up = block_argmin(bu, iu, shv, shi);
+    const int lw = block_argmin(bl, il, shv, shi);
+    bool flag = false;
+    if (p - n >= 0 && (long long)p + n <= (long long)P - 1 && lw > up) {
+      const T* cb = sv + (size_t)c * P * S;
+      unsigned nv;
+      Window<T> w1{cb, S, p, 1, up, lw - up, P, 0, false};
+      const double m1 = window_median_lin(w1, &sc, mt.exp2_tab, nv);
+      if (nv) {
+        Window<T> w2{cb, S, p - n, 2 * n, up, lw - up, P, 0, false};
+        unsigned nv2;
+        const double m2 = window_median_lin(w2, &sc, mt.exp2_tab, nv2);
+        const T ping_db = (T)(10.0 * epa::fast_log10(m1, mt.log_tab));
+        const T block_db = nv2 ? (T)(10.0 * epa::fast_log10(m2, mt.log_tab)) : epa::M<T>::nan();
+        flag = (ping_db - block_db) < thr;
+      }
+    }
+    uint8_t* m = mask + (size_t)row * S;
+    const uint8_t f = flag ? 1 : 0;
+    for (int s = threadIdx.x; s < S; s += kBlock) m[s] = f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pooled Sv by VALUE windows (pool_Sv, clean/utils.py:29-106): for every sample at depth d in ping p
+// the aggregate of the linear Sv over pings p-n..p+n and depths [d - bin, d + bin], where feasible.
+// The range variable must be non-decreasing along range_sample with NaN only as a tail
+// (rows_check_kernel verifies this and yields the valid length of every row).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void rows_check_kernel(const T* __restrict__ x, long long rows, int S,
+                                                            int* __restrict__ nvalid,
+                                                            int* __restrict__ violations) {
+  __shared__ int sfirst;
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const T* xr = x + (size_t)row * S;
+    __syncthreads();
+    if (threadIdx.x == 0) sfirst = S;
+    __syncthreads();
+    int bad = 0;
+    for (int s = threadIdx.x; s < S; s += kBlock) {
+      const T v = xr[s];
+      if (!(v == v)) atomicMin(&sfirst, s);
+      else if (s + 1 < S && xr[s + 1] < v) bad = 1;
+    }
+    __syncthreads();
+    const int first = sfirst;
+    for (int s = first + threadIdx.x; s < S; s += kBlock)
+      if (xr[s] == xr[s]) bad = 1;  // a number after the first NaN
+    if (bad) atomicAdd(violations, 1);
+    if (threadIdx.x == 0) nvalid[row] = first;
+  }
+}
+
+// first index in [0, n) with row[idx] >= v (STRICT == false) or row[idx] > v (STRICT == true)
+template <typename T, bool STRICT>
+__device__ __forceinline__ int bound(const T* __restrict__ row, int n, T v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const T x = row[mid];
+    if (STRICT ? (x > v) : (x >= v)) hi = mid;
+    else lo = mid + 1;
+  }
+  return lo;
+}
+
+template <typename T>
+struct PoolValueArgs {
+  const T* sv;
+  const T* range;
+  const int* nvalid;
+  int P, S, n;
+  T bin, exclude_above, rmin, rmax, thr;
+  T* pooled;
+  uint8_t* mask;
+};
+
+template <typename T>
+__device__ __forceinline__ bool pool_feasible(const PoolValueArgs<T>& a, T d, int p) {
+  // clean/utils.py:77-83 (ping_time_index_max = len(ping_time): p + n == P is accepted)
+  return (d - a.bin >= a.rmin) && (d + a.bin <= a.rmax) && (d - a.bin >= a.exclude_above) &&
+         (p - a.n >= 0) && ((long long)p + a.n <= (long long)a.P);
+}
+
+// nanmean: one thread per output sample
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pool_value_mean_kernel(PoolValueArgs<T> a, long long rows) {
+  __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
+  const epa::MathTabs mt = epa::build_math_tabs(tabs);
+  __syncthreads();
+  const int s = blockIdx.y * kBlock + threadIdx.x;
+  if (s >= a.S) return;
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int p = (int)(row % a.P);
+    const long long c = row / a.P;
+    const size_t at = (size_t)row * a.S + s;
+    const T d = a.range[at];
+    T out = epa::M<T>::nan();
+    if (pool_feasible(a, d, p)) {
+      const T lo_v = d - a.bin, hi_v = d + a.bin;
+      double sum = 0.0;
+      long long cnt = 0;
+      const int q1 = min(p + a.n, a.P - 1);
+      for (int q = p - a.n; q <= q1; ++q) {
+        const size_t qrow = (size_t)(c * a.P + q);
+        const T* rr = a.range + qrow * a.S;
+        const T* vr = a.sv + qrow * a.S;
+        const int nv = a.nvalid[qrow];
+        const int lo = bound<T, false>(rr, nv, lo_v), hi = bound<T, true>(rr, nv, hi_v);
+        for (int k = lo; k < hi; ++k) {
+          const T v = vr[k];
+          if (v == v) {
+            sum += (double)epa::lin_from_db(v, mt.exp2_tab);
+            ++cnt;
+          }
+        }
+      }
+      if (cnt > 0) out = (T)(10.0 * epa::fast_log10(sum / (double)cnt, mt.log_tab));
+    }
+    if (a.pooled) a.pooled[at] = out;
+    if (a.mask) a.mask[at] = (a.sv[at] - out > a.thr) ? 1 : 0;
+  }
+}
+
+// nanmedian: one workgroup per output sample
+constexpr int kMaxSidePings = 512;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pool_value_median_kernel(PoolValueArgs<T> a, long long jobs) {
+  __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
+  __shared__ SelectScratch sc;
+  __shared__ int wlo[2 * kMaxSidePings + 1], whi[2 * kMaxSidePings + 1];
+  const epa::MathTabs mt = epa::build_math_tabs(tabs);
+  __syncthreads();
+  for (long long job = blockIdx.x; job < jobs; job += gridDim.x) {
+    const int s = (int)(job % a.S);
+    const long long row = job / a.S;
+    const int p = (int)(row % a.P);
+    const long long c = row / a.P;
+    const T d = a.range[job];
+    T out = epa::M<T>::nan();
+    if (pool_feasible(a, d, p)) {
+      const T lo_v = d - a.bin, hi_v = d + a.bin;
+      const int q0 = p - a.n, nq = min(p + a.n, a.P - 1) - q0 + 1;
+      __syncthreads();
+      for (int j = threadIdx.x; j < nq; j += kBlock) {
+        const size_t qrow = (size_t)(c * a.P + q0 + j);
+        const T* rr = a.range + qrow * a.S;
+        const int nv = a.nvalid[qrow];
+        wlo[j] = bound<T, false>(rr, nv, lo_v);
+        whi[j] = bound<T, true>(rr, nv, hi_v);
+      }
+      __syncthreads();
+      RaggedWindow<T> w{a.sv + (size_t)c * a.P * a.S, a.S, q0, nq, wlo, whi};
+      unsigned nv;
+      const double med = window_median_lin(w, &sc, mt.exp2_tab, nv);
+      if (nv) out = (T)(10.0 * epa::fast_log10(med, mt.log_tab));
+    }
+    if (threadIdx.x == 0) {
+      if (a.pooled) a.pooled[job] = out;
+      if (a.mask) a.mask[job] = (a.sv[job] - out > a.thr) ? 1 : 0;
+    }
+  }
+}
+
+// out = mask ? src : fill   (fill: scalar, or an array like src when fill_arr != NULL)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void apply_mask_kernel(const T* __restrict__ src,
+                                                            const uint8_t* __restrict__ mask,
+                                                            size_t n, size_t mask_period, T fill,
+                                                            const T* __restrict__ fill_arr,
+                                                            size_t fill_period, T* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+    out[i] = mask[i % mask_period] ? src[i] : (fill_arr ? fill_arr[i % fill_period] : fill);
+}
+
+__global__ __launch_bounds__(kBlock) void mask_and_kernel(const uint8_t* __restrict__ a,
+                                                          const uint8_t* __restrict__ b, size_t n,
+                                                          size_t b_period, uint8_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+    out[i] = (a[i] && b[i % b_period]) ? 1 : 0;
+}
+
+inline int row_grid(long long rows) { return (int)(rows < 65536 ? (rows > 0 ? rows : 1) : 65536); }
+
+template <typename K>
+int set_lds(K kern, size_t lds) {
+  if (lds > 64 * 1024)
+    EPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return EPA_OK;
+}
+
+constexpr size_t kMaxLds = 156 * 1024;
+
+}  // namespace
+
+extern "C" int epa_range_bin_smooth(const void* sv, const void* range, int C, int P, int S, int nper,
+                                    double r0, double bin, int nbins, void* up_out, int dtype,
+                                    epa_stream_t stream) {
+  EPA_CHECK_ARG(sv && up_out, "epa_range_bin_smooth: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_range_bin_smooth: sizes must be positive");
+  EPA_CHECK_ARG(dtype == EPA_F32 || dtype == EPA_F64, "epa_range_bin_smooth: bad dtype %d", dtype);
+  double delta = 1.0;
+  if (range) {
+    EPA_CHECK_ARG(bin > 0 && nbins > 0 && r0 == r0, "epa_range_bin_smooth: bad bin grid");
+    delta = (r0 + bin) - r0;  // np.arange's step
+  } else {
+    EPA_CHECK_ARG(nper > 0, "epa_range_bin_smooth: samples per bin must be positive");
+    nbins = (S + nper - 1) / nper;
+  }
+  const size_t lds = epa::kMathTabBytes + (size_t)nbins * 12 + 8;
+  if (lds > kMaxLds) {
+    epa::set_error("epa_range_bin_smooth: %d bins per ping exceed the LDS budget", nbins);
+    return EPA_EUNSUPPORTED;
+  }
+  const long long rows = (long long)C * P;
+  hipStream_t st = (hipStream_t)stream;
+#define EPA_RBS(T, BV)                                                                            \
+  do {                                                                                            \
+    auto kern = range_bin_smooth_kernel<T, BV>;                                                   \
+    if (int rc = set_lds(kern, lds)) return rc;                                                   \
+    hipLaunchKernelGGL(kern, dim3(row_grid(rows)), dim3(kBlock), lds, st, (const T*)sv,           \
+                       (const T*)range, rows, S, nper, r0, delta, nbins, (T*)up_out);             \
+  } while (0)
+  if (dtype == EPA_F64) { if (range) EPA_RBS(double, true); else EPA_RBS(double, false); }
+  else { if (range) EPA_RBS(float, true); else EPA_RBS(float, false); }
+#undef EPA_RBS
+  return epa::check_launch("range_bin_smooth_kernel");
+}
+
+extern "C" int epa_impulse_mask(const void* up, int C, int P, int S, int num_side_pings,
+                                double threshold, uint8_t* mask_out, int dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(up && mask_out, "epa_impulse_mask: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_impulse_mask: sizes must be positive");
+  EPA_CHECK_ARG(num_side_pings >= 1, "epa_impulse_mask: num_side_pings must be >= 1");
+  EPA_CHECK_ARG(dtype == EPA_F32 || dtype == EPA_F64, "epa_impulse_mask: bad dtype %d", dtype);
+  const long long rows = (long long)C * P;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EPA_F64)
+    hipLaunchKernelGGL(impulse_compare_kernel<double>, dim3(row_grid(rows)), dim3(kBlock), 0, st,
+                       (const double*)up, P, S, rows, num_side_pings, threshold, mask_out);
+  else
+    hipLaunchKernelGGL(impulse_compare_kernel<float>, dim3(row_grid(rows)), dim3(kBlock), 0, st,
+                       (const float*)up, P, S, rows, num_side_pings, (float)threshold, mask_out);
+  return epa::check_launch("impulse_compare_kernel");
+}
+
+extern "C" int epa_pool_sv(const void* sv, int C, int P, int S, int first_sample, int num_side_pings,
+                           int num_side_samples, int func, double threshold, void* pooled_out,
+                           uint8_t* mask_out, double* ws_sum, int32_t* ws_cnt, int dtype,
+                           epa_stream_t stream) {
+  EPA_CHECK_ARG(sv && (pooled_out || mask_out), "epa_pool_sv: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_pool_sv: sizes must be positive");
+  EPA_CHECK_ARG(first_sample >= 0 && num_side_pings >= 0 && num_side_samples >= 0,
+                "epa_pool_sv: negative window argument");
+  EPA_CHECK_ARG(func == EPA_POOL_NANMEAN || func == EPA_POOL_NANMEDIAN, "epa_pool_sv: bad func %d", func);
+  EPA_CHECK_ARG(dtype == EPA_F32 || dtype == EPA_F64, "epa_pool_sv: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  const int s0 = first_sample < S ? first_sample : S;
+  const int n = num_side_pings, m = num_side_samples;
+  if (func == EPA_POOL_NANMEDIAN) {
+    const long long jobs = (long long)C * P * S;
+    const int grid = (int)(jobs < (1 << 20) ? jobs : (1 << 20));
+    if (dtype == EPA_F64)
+      hipLaunchKernelGGL(pool_median_kernel<double>, dim3(grid), dim3(kBlock), 0, st, (const double*)sv,
+                         P, S, jobs, s0, n, m, threshold, (double*)pooled_out, mask_out);
+    else
+      hipLaunchKernelGGL(pool_median_kernel<float>, dim3(grid), dim3(kBlock), 0, st, (const float*)sv,
+                         P, S, jobs, s0, n, m, (float)threshold, (float*)pooled_out, mask_out);
+    return epa::check_launch("pool_median_kernel");
+  }
+  EPA_CHECK_ARG(ws_sum && ws_cnt, "epa_pool_sv: nanmean needs the f64 / int32 [C*P*S] workspaces");
+  const size_t lds1 = epa::kMathTabBytes + (size_t)(kRangeTile + 2 * m) * 8;
+  const size_t lds2 = epa::kMathTabBytes + (size_t)(kPingTile + 2 * n) * kColTile * 12;
+  if (lds1 > kMaxLds || lds2 > kMaxLds) {
+    epa::set_error("epa_pool_sv: window %d x %d exceeds the LDS budget", 2 * n + 1, 2 * m + 1);
+    return EPA_EUNSUPPORTED;
+  }
+  const long long rows = (long long)C * P;
+  if (s0 < S) {
+    const dim3 g1(row_grid(rows) < 16384 ? row_grid(rows) : 16384, (S - s0 + kRangeTile - 1) / kRangeTile);
+#define EPA_BR(T)                                                                                   \
+  do {                                                                                              \
+    auto kern = box_range_kernel<T>;                                                                \
+    if (int rc = set_lds(kern, lds1)) return rc;                                                    \
+    hipLaunchKernelGGL(kern, g1, dim3(kBlock), lds1, st, (const T*)sv, rows, S, s0, m, ws_sum, ws_cnt); \
+  } while (0)
+    if (dtype == EPA_F64) EPA_BR(double); else EPA_BR(float);
+#undef EPA_BR
+    if (int rc = epa::check_launch("box_range_kernel")) return rc;
+  }
+  EPA_CHECK_ARG(C <= 65535 && (P + kPingTile - 1) / kPingTile <= 65535, "epa_pool_sv: grid too large");
+  const dim3 g2((S + kColTile - 1) / kColTile, (P + kPingTile - 1) / kPingTile, C);
+#define EPA_BP(T)                                                                                   \
+  do {                                                                                              \
+    auto kern = box_ping_kernel<T>;                                                                 \
+    if (int rc = set_lds(kern, lds2)) return rc;                                                    \
+    hipLaunchKernelGGL(kern, g2, dim3(kBlock), lds2, st, (const T*)sv, ws_sum, ws_cnt, P, S, s0, n, \
+                       (T)threshold, (T*)pooled_out, mask_out);                                     \
+  } while (0)
+  if (dtype == EPA_F64) EPA_BP(double); else EPA_BP(float);
+#undef EPA_BP
+  return epa::check_launch("box_ping_kernel");
+}
+
+extern "C" int epa_range_rows_check(const void* range, int C, int P, int S, int dtype, int32_t* nvalid_out,
+                                    int32_t* violations_out, epa_stream_t stream) {
+  EPA_CHECK_ARG(range && nvalid_out && violations_out, "epa_range_rows_check: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_range_rows_check: sizes must be positive");
+  EPA_CHECK_ARG(dtype == EPA_F32 || dtype == EPA_F64, "epa_range_rows_check: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  EPA_CHECK_HIP(hipMemsetAsync(violations_out, 0, sizeof(int32_t), st));
+  const long long rows = (long long)C * P;
+  if (dtype == EPA_F64)
+    hipLaunchKernelGGL(rows_check_kernel<double>, dim3(row_grid(rows)), dim3(kBlock), 0, st,
+                       (const double*)range, rows, S, nvalid_out, violations_out);
+  else
+    hipLaunchKernelGGL(rows_check_kernel<float>, dim3(row_grid(rows)), dim3(kBlock), 0, st,
+                       (const float*)range, rows, S, nvalid_out, violations_out);
+  return epa::check_launch("rows_check_kernel");
+}
+
+namespace {
+template <typename T>
+int launch_pool_value(const void* sv, const void* range, const int32_t* nvalid, int C, int P, int S,
+                      double bin, int n, double exclude_above, double rmin, double rmax, int func,
+                      double thr, void* pooled, uint8_t* mask, hipStream_t st) {
+  PoolValueArgs<T> a{(const T*)sv, (const T*)range, nvalid, P, S, n, (T)bin, (T)exclude_above,
+                     (T)rmin, (T)rmax, (T)thr, (T*)pooled, mask};
+  if (func == EPA_POOL_NANMEAN) {
+    const long long rows = (long long)C * P;
+    const dim3 grid(row_grid(rows) < 32768 ? row_grid(rows) : 32768, (S + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(pool_value_mean_kernel<T>, grid, dim3(kBlock), 0, st, a, rows);
+    return epa::check_launch("pool_value_mean_kernel");
+  }
+  const long long jobs = (long long)C * P * S;
+  const int grid = (int)(jobs < (1 << 20) ? jobs : (1 << 20));
+  hipLaunchKernelGGL(pool_value_median_kernel<T>, dim3(grid), dim3(kBlock), 0, st, a, jobs);
+  return epa::check_launch("pool_value_median_kernel");
+}
+}  // namespace
+
+extern "C" int epa_pool_sv_value(const void* sv, const void* range, const int32_t* nvalid, int C, int P,
+                                 int S, double depth_bin, int num_side_pings, double exclude_above,
+                                 double range_min, double range_max, int func, double threshold,
+                                 void* pooled_out, uint8_t* mask_out, int dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(sv && range && nvalid && (pooled_out || mask_out), "epa_pool_sv_value: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_pool_sv_value: sizes must be positive");
+  EPA_CHECK_ARG(num_side_pings >= 0, "epa_pool_sv_value: num_side_pings must be >= 0");
+  EPA_CHECK_ARG(func == EPA_POOL_NANMEAN || func == EPA_POOL_NANMEDIAN, "epa_pool_sv_value: bad func %d", func);
+  EPA_CHECK_ARG(dtype == EPA_F32 || dtype == EPA_F64, "epa_pool_sv_value: bad dtype %d", dtype);
+  if (func == EPA_POOL_NANMEDIAN && num_side_pings > kMaxSidePings) {
+    epa::set_error("epa_pool_sv_value: nanmedian supports at most %d side pings", kMaxSidePings);
+    return EPA_EUNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EPA_F64)
+    return launch_pool_value<double>(sv, range, nvalid, C, P, S, depth_bin, num_side_pings, exclude_above,
+                                     range_min, range_max, func, threshold, pooled_out, mask_out, st);
+  return launch_pool_value<float>(sv, range, nvalid, C, P, S, depth_bin, num_side_pings, exclude_above,
+                                  range_min, range_max, func, threshold, pooled_out, mask_out, st);
+}
+
+extern "C" int epa_attenuated_mask(const void* sv, const void* range, int C, int P, int S,
+                                   double upper_limit, double lower_limit, int num_side_pings,
+                                   double threshold, uint8_t* mask_out, int dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(sv && range && mask_out, "epa_attenuated_mask: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_attenuated_mask: sizes must be positive");
+  EPA_CHECK_ARG(num_side_pings >= 0, "epa_attenuated_mask: num_side_pings must be >= 0");
+  EPA_CHECK_ARG(dtype == EPA_F32 || dtype == EPA_F64, "epa_attenuated_mask: bad dtype %d", dtype);
+  const long long rows = (long long)C * P;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EPA_F64)
+    hipLaunchKernelGGL(attenuated_mask_kernel<double>, dim3(row_grid(rows)), dim3(kBlock), 0, st,
+                       (const double*)sv, (const double*)range, P, S, rows, upper_limit, lower_limit,
+                       num_side_pings, threshold, mask_out);
+  else
+    hipLaunchKernelGGL(attenuated_mask_kernel<float>, dim3(row_grid(rows)), dim3(kBlock), 0, st,
+                       (const float*)sv, (const float*)range, P, S, rows, (float)upper_limit,
+                       (float)lower_limit, num_side_pings, (float)threshold, mask_out);
+  return epa::check_launch("attenuated_mask_kernel");
+}
+
+extern "C" int epa_apply_mask(const void* src, const uint8_t* mask, size_t n, size_t mask_period,
+                              double fill_value, const void* fill_array, size_t fill_period, void* out,
+                              int dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(src && mask && out, "epa_apply_mask: NULL array argument");
+  EPA_CHECK_ARG(mask_period > 0 && n % mask_period == 0, "epa_apply_mask: mask does not tile the source");
+  EPA_CHECK_ARG(!fill_array || (fill_period > 0 && n % fill_period == 0),
+                "epa_apply_mask: fill array does not tile the source");
+  EPA_CHECK_ARG(dtype == EPA_F32 || dtype == EPA_F64, "epa_apply_mask: bad dtype %d", dtype);
+  if (n == 0) return EPA_OK;
+  const size_t blocks = (n + kBlock - 1) / kBlock;
+  const int grid = (int)(blocks < 65536 ? blocks : 65536);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EPA_F64)
+    hipLaunchKernelGGL(apply_mask_kernel<double>, dim3(grid), dim3(kBlock), 0, st, (const double*)src,
+                       mask, n, mask_period, fill_value, (const double*)fill_array,
+                       fill_array ? fill_period : 1, (double*)out);
+  else
+    hipLaunchKernelGGL(apply_mask_kernel<float>, dim3(grid), dim3(kBlock), 0, st, (const float*)src, mask,
+                       n, mask_period, (float)fill_value, (const float*)fill_array,
+                       fill_array ? fill_period : 1, (float*)out);
+  return epa::check_launch("apply_mask_kernel");
+}
+
+extern "C" int epa_mask_and(const uint8_t* a, const uint8_t* b, size_t n, size_t b_period, uint8_t* out,
+                            epa_stream_t stream) {
+  EPA_CHECK_ARG(a && b && out, "epa_mask_and: NULL array argument");
+  EPA_CHECK_ARG(b_period > 0 && n % b_period == 0, "epa_mask_and: second mask does not tile the first");
+  if (n == 0) return EPA_OK;
+  const size_t blocks = (n + kBlock - 1) / kBlock;
+  const int grid = (int)(blocks < 65536 ? blocks : 65536);
+  hipLaunchKernelGGL(mask_and_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, b, n,
+                     b_period, out);
+  return epa::check_launch("mask_and_kernel");
+}

@@ -80,6 +80,85 @@ __global__ __launch_bounds__(epa::kBlock) void affine_rows_kernel(const T* __res
   }
 }
 
+
+// mean range step per channel: np.nanmean(np.diff(range, axis=2), axis=(1, 2))  (clean/utils.py:131).
+// Deterministic two-stage sum: one (sum, count) per (c, p) row, then one workgroup per channel.
+template <typename T>
+__global__ __launch_bounds__(epa::kBlock) void step_rows_kernel(const T* __restrict__ x, long long rows,
+                                                                int S, double* __restrict__ part) {
+  __shared__ double ssum[4], scnt[4];
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const T* xr = x + (size_t)row * S;
+    double sum = 0.0, cnt = 0.0;
+    for (int s = threadIdx.x; s + 1 < S; s += blockDim.x) {
+      const T d = xr[s + 1] - xr[s];  // in the storage type, as np.diff
+      if (d == d) {
+        sum += (double)d;
+        cnt += 1.0;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      sum += __shfl_down(sum, o, 64);
+      cnt += __shfl_down(cnt, o, 64);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+      ssum[threadIdx.x >> 6] = sum;
+      scnt[threadIdx.x >> 6] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      part[2 * row] = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+      part[2 * row + 1] = (scnt[0] + scnt[1]) + (scnt[2] + scnt[3]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(epa::kBlock) void step_final_kernel(const double* __restrict__ part, int P,
+                                                                 double* __restrict__ out) {
+  __shared__ double ssum[4], scnt[4];
+  const double* pc = part + (size_t)blockIdx.x * P * 2;
+  double sum = 0.0, cnt = 0.0;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    sum += pc[2 * p];
+    cnt += pc[2 * p + 1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sum += __shfl_down(sum, o, 64);
+    cnt += __shfl_down(cnt, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    ssum[threadIdx.x >> 6] = sum;
+    scnt[threadIdx.x >> 6] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double s = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+    const double n = (scnt[0] + scnt[1]) + (scnt[2] + scnt[3]);
+    out[blockIdx.x] = n > 0.0 ? s / n : __builtin_nan("");
+  }
+}
+
+// flat index of the first element that is NOT <= limit (NaN counts), n if there is none:
+// np.argmin(x <= limit) over the flattened array (clean/utils.py:143), except that an array with no
+// such element reports n where np.argmin reports 0.
+template <typename T>
+__global__ __launch_bounds__(epa::kBlock) void first_not_le_kernel(const T* __restrict__ x, size_t n,
+                                                                   T limit,
+                                                                   unsigned long long* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    if (i >= *reinterpret_cast<volatile unsigned long long*>(out)) return;  // already beaten
+    if (!(x[i] <= limit)) {
+      atomicMin(out, (unsigned long long)i);
+      return;
+    }
+  }
+}
+
+__global__ void set_u64_kernel(unsigned long long* p, unsigned long long v) { *p = v; }
 }  // namespace
 
 extern "C" int epa_affine_rows(const void* x, const double* scale, const double* offset, int C, int P,
@@ -118,4 +197,42 @@ extern "C" int epa_nanminmax(const void* x, size_t n, int dtype, double* workspa
   if (int rc = epa::check_launch("minmax_partial_kernel")) return rc;
   hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(epa::kBlock), 0, st, workspace, grid, out);
   return epa::check_launch("minmax_final_kernel");
+}
+
+extern "C" int epa_range_step_mean(const void* range, int C, int P, int S, int dtype, double* workspace,
+                                   double* out, epa_stream_t stream) {
+  EPA_CHECK_ARG(range && workspace && out, "epa_range_step_mean: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_range_step_mean: sizes must be positive");
+  EPA_CHECK_ARG(dtype == EPA_F32 || dtype == EPA_F64, "epa_range_step_mean: bad dtype %d", dtype);
+  const long long rows = (long long)C * P;
+  const int grid = (int)(rows < 16384 ? rows : 16384);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EPA_F64)
+    hipLaunchKernelGGL(step_rows_kernel<double>, dim3(grid), dim3(epa::kBlock), 0, st,
+                       (const double*)range, rows, S, workspace);
+  else
+    hipLaunchKernelGGL(step_rows_kernel<float>, dim3(grid), dim3(epa::kBlock), 0, st, (const float*)range,
+                       rows, S, workspace);
+  if (int rc = epa::check_launch("step_rows_kernel")) return rc;
+  hipLaunchKernelGGL(step_final_kernel, dim3(C), dim3(epa::kBlock), 0, st, workspace, P, out);
+  return epa::check_launch("step_final_kernel");
+}
+
+extern "C" int epa_first_not_le(const void* x, size_t n, double limit, int dtype, uint64_t* out,
+                                epa_stream_t stream) {
+  EPA_CHECK_ARG(x && out, "epa_first_not_le: NULL array argument");
+  EPA_CHECK_ARG(dtype == EPA_F32 || dtype == EPA_F64, "epa_first_not_le: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(1), 0, st, (unsigned long long*)out,
+                     (unsigned long long)n);
+  if (n == 0) return epa::check_launch("set_u64_kernel");
+  const size_t blocks = (n + epa::kBlock - 1) / epa::kBlock;
+  const int grid = (int)(blocks < 4096 ? blocks : 4096);
+  if (dtype == EPA_F64)
+    hipLaunchKernelGGL(first_not_le_kernel<double>, dim3(grid), dim3(epa::kBlock), 0, st, (const double*)x,
+                       n, limit, (unsigned long long*)out);
+  else
+    hipLaunchKernelGGL(first_not_le_kernel<float>, dim3(grid), dim3(epa::kBlock), 0, st, (const float*)x, n,
+                       (float)limit, (unsigned long long*)out);
+  return epa::check_launch("first_not_le_kernel");
 }

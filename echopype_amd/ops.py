@@ -303,3 +303,112 @@ class Timer:
             _lib.lib.epa_timer_destroy(self._h)
         except Exception:
             pass
+
+
+# ---- noise masks ------------------------------------------------------------------
+
+def range_bin_smooth(sv, *, nper=None, range=None, r0=0.0, bin=0.0, nbins=0):
+    """Depth-bin smoothing of mask_impulse_noise -> up-sampled Sv like ``sv``.
+    Index mode: ``nper`` samples per bin (one value for all channels of ``sv``).
+    Value mode: ``range`` array + bins np.arange(r0, max + bin, bin) (``nbins`` = len(edges) - 1)."""
+    C, P, S = sv.shape
+    if range is not None and range.dtype != sv.dtype:
+        range = range.to(sv.dtype)
+    out = torch.empty_like(sv)
+    call("epa_range_bin_smooth", _p(sv), _p(range), C, P, S, int(nper or 0), float(r0), float(bin),
+         int(nbins), _p(out), _DT[sv.dtype], _stream())
+    return out
+
+
+def impulse_mask(up, num_side_pings, threshold):
+    """Two-sided ping comparison -> uint8 (C,P,S)."""
+    C, P, S = up.shape
+    out = torch.empty((C, P, S), dtype=torch.uint8, device=up.device)
+    call("epa_impulse_mask", _p(up), C, P, S, int(num_side_pings), float(threshold), _p(out),
+         _DT[up.dtype], _stream())
+    return out
+
+
+def pool_sv(sv, first_sample, num_side_pings, num_side_samples, func="nanmean", threshold=0.0,
+            want_pooled=True, want_mask=True):
+    """Index-binning pooled Sv (reflect window) and/or the mask Sv - pooled > threshold."""
+    C, P, S = sv.shape
+    f = {"nanmean": _lib.POOL_NANMEAN, "nanmedian": _lib.POOL_NANMEDIAN}[func]
+    pooled = torch.empty_like(sv) if want_pooled else None
+    mask = torch.empty((C, P, S), dtype=torch.uint8, device=sv.device) if want_mask else None
+    ws = wc = None
+    if f == _lib.POOL_NANMEAN:
+        ws = torch.empty((C, P, S), dtype=torch.float64, device=sv.device)
+        wc = torch.empty((C, P, S), dtype=torch.int32, device=sv.device)
+    call("epa_pool_sv", _p(sv), C, P, S, int(first_sample), int(num_side_pings), int(num_side_samples),
+         f, float(threshold), _p(pooled), _p(mask), _p(ws), _p(wc), _DT[sv.dtype], _stream())
+    return pooled, mask
+
+
+def attenuated_mask(sv, range, upper_limit, lower_limit, num_side_pings, threshold):
+    C, P, S = sv.shape
+    if range.dtype != sv.dtype:
+        range = range.to(sv.dtype)
+    out = torch.empty((C, P, S), dtype=torch.uint8, device=sv.device)
+    call("epa_attenuated_mask", _p(sv), _p(range), C, P, S, float(upper_limit), float(lower_limit),
+         int(num_side_pings), float(threshold), _p(out), _DT[sv.dtype], _stream())
+    return out
+
+
+def apply_mask(src, mask, fill_value=float("nan"), fill_array=None):
+    """where(mask, src, fill); ``mask`` uint8 with src.numel() % mask.numel() == 0 (trailing-dims
+    broadcast), ``fill_array`` likewise."""
+    out = torch.empty_like(src)
+    if fill_array is not None and fill_array.dtype != src.dtype:
+        fill_array = fill_array.to(src.dtype)
+    call("epa_apply_mask", _p(src), _p(mask), src.numel(), mask.numel(), float(fill_value),
+         _p(fill_array), fill_array.numel() if fill_array is not None else 1, _p(out), _DT[src.dtype],
+         _stream())
+    return out
+
+
+def mask_and(a, b):
+    """a & b, ``b`` broadcast over the leading dims of ``a``."""
+    out = torch.empty_like(a)
+    call("epa_mask_and", _p(a), _p(b), a.numel(), b.numel(), _p(out), _stream())
+    return out
+
+
+def range_step_mean(range):
+    """Per-channel nanmean of the sample-to-sample range step -> numpy f64 [C]."""
+    C, P, S = range.shape
+    ws = torch.empty(2 * C * P, dtype=torch.float64, device=range.device)
+    out = torch.empty(C, dtype=torch.float64, device=range.device)
+    call("epa_range_step_mean", _p(range), C, P, S, _DT[range.dtype], _p(ws), _p(out), _stream())
+    return out.cpu().numpy()
+
+
+def first_not_le(x, limit):
+    """Flat index of the first element not <= limit (NaN counts); x.numel() if none."""
+    out = torch.empty(1, dtype=torch.int64, device=x.device)
+    call("epa_first_not_le", _p(x), x.numel(), float(limit), _DT[x.dtype], _p(out), _stream())
+    return int(out.item())
+
+
+def range_rows_check(range):
+    """-> (nvalid int32 (C,P) device tensor, number of rows violating monotonicity / NaN-tail)."""
+    C, P, S = range.shape
+    nvalid = torch.empty((C, P), dtype=torch.int32, device=range.device)
+    bad = torch.empty(1, dtype=torch.int32, device=range.device)
+    call("epa_range_rows_check", _p(range), C, P, S, _DT[range.dtype], _p(nvalid), _p(bad), _stream())
+    return nvalid, int(bad.item())
+
+
+def pool_sv_value(sv, range, nvalid, depth_bin, num_side_pings, exclude_above, range_min, range_max,
+                  func="nanmean", threshold=0.0, want_pooled=True, want_mask=True):
+    """Value-window pooled Sv (pool_Sv) and/or the mask Sv - pooled > threshold."""
+    C, P, S = sv.shape
+    if range.dtype != sv.dtype:
+        range = range.to(sv.dtype)
+    f = {"nanmean": _lib.POOL_NANMEAN, "nanmedian": _lib.POOL_NANMEDIAN}[func]
+    pooled = torch.empty_like(sv) if want_pooled else None
+    mask = torch.empty((C, P, S), dtype=torch.uint8, device=sv.device) if want_mask else None
+    call("epa_pool_sv_value", _p(sv), _p(range), _p(nvalid), C, P, S, float(depth_bin), int(num_side_pings),
+         float(exclude_above), float(range_min), float(range_max), f, float(threshold), _p(pooled),
+         _p(mask), _DT[sv.dtype], _stream())
+    return pooled, mask

@@ -245,6 +245,81 @@ int epa_sv_complex(const void* re, const void* im, int in_dtype, const float* re
                    int S, int B, int cal_type, void* out, void* range_out, void* prx_out,
                    int out_dtype, epa_stream_t stream);
 
+/* ==== SURVEY 8f "next" row 2: Ryan et al. (2015) noise masks + apply_mask ==============================
+ * Masks are uint8 [C*P*S] (1 = True) in the (channel, ping_time, range_sample) layout of Sv.        */
+
+/* Depth-bin smoothing used by mask_impulse_noise: every sample takes 10*log10 of the NaN-skipping
+ * linear mean of its depth bin within its own ping.  Replaces clean/utils.py:244-304
+ * (index_binning_downsample_upsample_along_depth: coarsen(range_sample=nper, "pad").mean + ffill;
+ * range == NULL, bin b = s / nper -- call per channel, nper is channel specific) and :173-241
+ * (downsample_upsample_along_depth: flox nanmean over bins np.arange(r0, max + bin, bin) closed on
+ * the left, np.digitize up-sampling; range != NULL, nbins = len(edges) - 1).
+ * sv, range, up_out: [C*P*S] of dtype. */
+int epa_range_bin_smooth(const void* sv, const void* range, int C, int P, int S, int nper, double r0,
+                         double bin, int nbins, void* up_out, int dtype, epa_stream_t stream);
+
+/* Two-sided ping comparison (clean/utils.py:307-323 echopy_impulse_noise_mask):
+ * mask = (up[p] - up[p+n] > thr) & (up[p] - up[p-n] > thr), NaN differences count as +inf. */
+int epa_impulse_mask(const void* up, int C, int P, int S, int num_side_pings, double threshold,
+                     uint8_t* mask_out, int dtype, epa_stream_t stream);
+
+/* Pooled Sv of mask_transient_noise, index-binning variant (clean/utils.py:109-170: dask_image
+ * generic_filter over a (2*num_side_pings+1) x (2*num_side_samples+1) window of the linear Sv,
+ * mode="reflect", restricted to range_sample >= first_sample; NaN above) and the mask
+ * Sv - pooled > threshold (clean/api.py:166).  func: EPA_POOL_NANMEAN (separable box sums; needs
+ * ws_sum f64 [C*P*S] and ws_cnt int32 [C*P*S]) or EPA_POOL_NANMEDIAN (radix selection per output
+ * sample, O(window) each -- meant for subsets, as in the reference; workspaces unused).
+ * pooled_out ([C*P*S] of dtype) and mask_out may each be NULL. */
+enum epa_pool_func { EPA_POOL_NANMEAN = 0, EPA_POOL_NANMEDIAN = 1 };
+int epa_pool_sv(const void* sv, int C, int P, int S, int first_sample, int num_side_pings,
+                int num_side_samples, int func, double threshold, void* pooled_out, uint8_t* mask_out,
+                double* ws_sum, int32_t* ws_cnt, int dtype, epa_stream_t stream);
+
+/* Attenuated-signal mask (clean/utils.py:326-372 echopy_attenuated_signal_mask, per channel):
+ * per ping, up / lw = argmin |range - limit| of that ping (first NaN if any, as np.argmin); when
+ * p-n >= 0, p+n <= P-1 and Sv[p, up:lw] is not all NaN, the whole ping is masked if
+ * 10log10(nanmedian lin Sv[p, up:lw]) - 10log10(nanmedian lin Sv[p-n:p+n, up:lw]) < threshold. */
+int epa_attenuated_mask(const void* sv, const void* range, int C, int P, int S, double upper_limit,
+                        double lower_limit, int num_side_pings, double threshold, uint8_t* mask_out,
+                        int dtype, epa_stream_t stream);
+
+/* out[i] = mask[i % mask_period] ? src[i] : fill  (mask/api.py:428-432 xr.where(final_mask, Sv,
+ * fill_value)); fill = fill_array[i % fill_period] when fill_array != NULL, else fill_value.
+ * mask_period = P*S broadcasts a channel-less mask over the channels. */
+int epa_apply_mask(const void* src, const uint8_t* mask, size_t n, size_t mask_period,
+                   double fill_value, const void* fill_array, size_t fill_period, void* out,
+                   int dtype, epa_stream_t stream);
+
+/* out = a & b[i % b_period]  (mask/api.py:405-408, np.logical_and.reduce over broadcast masks). */
+int epa_mask_and(const uint8_t* a, const uint8_t* b, size_t n, size_t b_period, uint8_t* out,
+                 epa_stream_t stream);
+
+/* Mean range step per channel, np.nanmean(np.diff(range, axis=2), axis=(1, 2)) (clean/utils.py:131,
+ * :258: sizes the per-channel index bins).  workspace: f64 [2*C*P]; out: f64 [C] (NaN: no finite step). */
+int epa_range_step_mean(const void* range, int C, int P, int S, int dtype, double* workspace,
+                        double* out, epa_stream_t stream);
+
+/* Flat index of the first element that is not <= limit (NaN counts); n when there is none.
+ * np.argmin(range <= exclude_above) of clean/utils.py:143.  x: [n] of dtype; out: uint64 [1]. */
+int epa_first_not_le(const void* x, size_t n, double limit, int dtype, uint64_t* out,
+                     epa_stream_t stream);
+
+/* Row check of a range variable for the value-window pooling below: nvalid_out int32 [C*P] = index of
+ * the first NaN of each (c,p) row (S if none); violations_out int32 [1] = number of rows that are not
+ * non-decreasing over their valid prefix or hold a number after their first NaN. */
+int epa_range_rows_check(const void* range, int C, int P, int S, int dtype, int32_t* nvalid_out,
+                         int32_t* violations_out, epa_stream_t stream);
+
+/* Pooled Sv of mask_transient_noise, value-window variant (clean/utils.py:29-106 pool_Sv, a triple
+ * Python loop in the reference): for the sample at depth d of ping p, func over the linear Sv of pings
+ * p-n..p+n (clipped to the data) with range in [d - depth_bin, d + depth_bin]; NaN where
+ * d - bin < range_min, d + bin > range_max, d - bin < exclude_above, p - n < 0 or p + n > P.
+ * range rows must pass epa_range_rows_check (nvalid from it).  func / threshold / outputs as epa_pool_sv. */
+int epa_pool_sv_value(const void* sv, const void* range, const int32_t* nvalid, int C, int P, int S,
+                      double depth_bin, int num_side_pings, double exclude_above, double range_min,
+                      double range_max, int func, double threshold, void* pooled_out, uint8_t* mask_out,
+                      int dtype, epa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

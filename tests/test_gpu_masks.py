@@ -1,0 +1,225 @@
+"""Kernel-level parity of the noise-mask kernels through the C ABI vs the oracle
+and vs the outputs of the reference's own leaf functions (tests/golden/ref_mask_goldens.npz).
+
+Masks are boolean: they must be IDENTICAL wherever the oracle's decision margin
+|difference - threshold| exceeds the floating-point noise of the compared quantity (1e-9 dB in
+fp64, 1e-3 dB in fp32); the pooled / smoothed Sv they derive from are held to the usual tolerances.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import masks as omask
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_mask_goldens.npz")
+RTOL = {"float64": 1e-9, "float32": 1e-3}
+MARGIN = {"float64": 1e-9, "float32": 2e-3}
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need a GPU (run with -m 'not gpu' on CPU boxes)")
+    from echopype_amd import ops
+
+    return torch, ops
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLDEN)
+
+
+def _dev(torch, a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def _close(got, exp, rtol, what=""):
+    got, exp = np.asarray(got, dtype=np.float64), np.asarray(exp, dtype=np.float64)
+    assert got.shape == exp.shape
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp), err_msg=f"{what}: NaN pattern")
+    fin = np.isfinite(exp)
+    np.testing.assert_array_equal(got[~fin & ~np.isnan(exp)], exp[~fin & ~np.isnan(exp)])
+    err = np.abs(got[fin] - exp[fin]) / np.maximum(np.abs(exp[fin]), 1.0)
+    assert err.size == 0 or err.max() <= rtol, f"{what}: max rel err {err.max():.3e} > {rtol}"
+
+
+def _scene(C, P, S, seed, step=0.19, nan_frac=0.03, spikes=True, ragged=False):
+    """Sv (dB) with a gradient, impulses, transient blobs, attenuated pings, NaNs; depth per channel."""
+    rng = np.random.default_rng(seed)
+    sv = -70 + 4 * rng.standard_normal((C, P, S)) - 10 * np.linspace(0, 1, S)[None, None, :]
+    if spikes:
+        sv[rng.random((C, P, S)) < 0.02] += 30
+        for _ in range(3):
+            c, p, s = rng.integers(C), rng.integers(P), rng.integers(S)
+            sv[c, max(p - 1, 0):p + 2, max(s - 8, 0):s + 8] += 25
+        sv[:, rng.random(P) < 0.1, :] -= 15
+    sv[rng.random((C, P, S)) < nan_frac] = np.nan
+    steps = step * (1 + 0.37 * np.arange(C))
+    depth = 1.5 + np.arange(S)[None, None, :] * steps[:, None, None] + 0.3 * rng.random((C, P, 1))
+    if ragged:
+        sv[-1, :, S - S // 5:] = np.nan
+        depth[-1, :, S - S // 5:] = np.nan
+    return sv, depth
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_range_bin_smooth_index_mode(env, dtype):
+    torch, ops = env
+    sv, depth = _scene(3, 17, 203, 1, ragged=True)
+    sv, depth = sv.astype(dtype), depth.astype(dtype)
+    exp = omask.index_binning_downsample_upsample(sv.astype(np.float64), depth.astype(np.float64), 2.0)
+    n = omask.nsamples_per_bin(depth.astype(np.float64), 2.0)
+    assert len(set(n.tolist())) == 3  # channel-specific block lengths
+    svt = _dev(torch, sv)
+    for c in range(3):
+        got = ops.range_bin_smooth(svt[c:c + 1].contiguous(), nper=int(n[c])).cpu().numpy()
+        _close(got[0], exp[c], RTOL[dtype], f"channel {c}")
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_range_bin_smooth_value_mode(env, dtype):
+    torch, ops = env
+    sv, depth = _scene(2, 13, 150, 2)
+    sv[0, 3, :] = np.nan  # an all-NaN ping -> every bin NaN
+    sv, depth = sv.astype(dtype), depth.astype(dtype)
+    d64 = depth.astype(np.float64)
+    down, exp = omask.downsample_upsample(sv.astype(np.float64), d64, 5.0)
+    r0 = float(np.nanmin(d64))
+    nb = len(np.arange(r0, np.nanmax(d64) + 5.0, 5.0)) - 1
+    assert down.shape[-1] == nb
+    got = ops.range_bin_smooth(_dev(torch, sv), range=_dev(torch, depth), r0=r0, bin=5.0, nbins=nb)
+    _close(got.cpu().numpy(), exp, RTOL[dtype])
+
+
+def test_range_bin_smooth_value_mode_edges_and_nan_depth(env):
+    """Samples exactly on bin edges go to the bin they open ([e_j, e_j+1)); the global maximum falls
+    outside the last left-closed interval when it is an exact multiple; NaN depth -> last bin."""
+    torch, ops = env
+    S = 41
+    depth = np.tile(10.0 + 0.5 * np.arange(S), (1, 2, 1))  # edges 10, 12.5, 15 ... hit exactly
+    depth[0, 1, -6:] = np.nan
+    rng = np.random.default_rng(0)
+    sv = -60 + 5 * rng.standard_normal((1, 2, S))
+    down, exp = omask.downsample_upsample(sv, depth, 2.5)
+    r0, nb = 10.0, len(np.arange(10.0, np.nanmax(depth) + 2.5, 2.5)) - 1
+    got = ops.range_bin_smooth(_dev(torch, sv), range=_dev(torch, depth), r0=r0, bin=2.5, nbins=nb)
+    _close(got.cpu().numpy(), exp, 1e-9)
+
+
+def test_impulse_mask_reference_goldens(env, gold):
+    torch, ops = env
+    for i in range(4):
+        sv = gold[f"imp{i}_sv"]  # (range_sample, ping_time)
+        n, thr = gold[f"imp{i}_args"]
+        up = _dev(torch, sv.T[None])  # (1, P, S)
+        got = ops.impulse_mask(up, int(n), float(thr)).cpu().numpy()[0].T.astype(bool)
+        np.testing.assert_array_equal(got, gold[f"imp{i}_mask"], err_msg=f"case {i}")
+
+
+def test_impulse_mask_more_side_pings_than_pings(env):
+    torch, ops = env
+    up = _dev(torch, np.zeros((1, 3, 5)))
+    assert ops.impulse_mask(up, 7, 10.0).cpu().numpy().all()  # both sides missing -> inf > thr
+
+
+def test_attenuated_mask_reference_goldens(env, gold):
+    torch, ops = env
+    for i in range(4):
+        sv, rg = gold[f"att{i}_sv"], gold[f"att{i}_range"]
+        up, lw, n, thr = gold[f"att{i}_args"]
+        got = ops.attenuated_mask(_dev(torch, sv[None]), _dev(torch, rg[None]), up, lw, int(n), thr)
+        np.testing.assert_array_equal(got.cpu().numpy()[0].astype(bool), gold[f"att{i}_mask"],
+                                      err_msg=f"case {i}")
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_attenuated_mask_vs_oracle(env, dtype):
+    torch, ops = env
+    sv, depth = _scene(3, 80, 300, 5, step=0.5, ragged=True)
+    sv[1, 40:44, :] = np.nan
+    sv[0, 10, 20:60] = -np.inf
+    sv, depth = sv.astype(dtype), depth.astype(dtype)
+    got = ops.attenuated_mask(_dev(torch, sv), _dev(torch, depth), 30.0, 90.0, 6, -5.0).cpu().numpy()
+    exp = np.stack([omask.echopy_attenuated_signal_mask(sv[c].astype(np.float64), depth[c],
+                                                        np.dtype(dtype).type(30.0), np.dtype(dtype).type(90.0),
+                                                        6, -5.0) for c in range(3)])
+    diff = got.astype(bool) != exp
+    if dtype == "float64":
+        assert not diff.any()
+    else:  # a ping whose median difference sits within fp32 noise of the threshold may flip
+        assert diff.any(axis=2).sum() <= 1
+    assert exp.any() and not exp.all()
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("func", ["nanmean", "nanmedian"])
+def test_pool_sv_vs_generic_filter(env, dtype, func):
+    """The reference's own structural test (tests/clean/test_noise.py:342-441) with
+    scipy.ndimage.generic_filter(mode="reflect") as the engine."""
+    torch, ops = env
+    C, P, S = 2, 23, 70
+    sv, depth = _scene(C, P, S, 7, step=0.4)
+    sv[0, 5:9, 30:50] = np.nan  # a window with no valid sample at all
+    sv, depth = sv.astype(dtype), depth.astype(dtype)
+    f = np.nanmean if func == "nanmean" else np.nanmedian
+    d64 = depth.astype(np.float64)
+    m = omask.nsamples_per_bin(d64, 2.0)
+    exclude_above = 6.0
+    s0 = int(np.argmin(d64 <= exclude_above))
+    assert 0 < s0 < S
+    exp = omask.index_binning_pool_Sv(sv.astype(np.float64), d64, f, 2.0, 3, exclude_above)
+    thr = 8.0
+    svt = _dev(torch, sv)
+    for c in range(C):
+        pooled, mask = ops.pool_sv(svt[c:c + 1].contiguous(), s0, 3, int(m[c]), func=func, threshold=thr)
+        _close(pooled.cpu().numpy()[0], exp[c], RTOL[dtype], f"{func} channel {c}")
+        with np.errstate(invalid="ignore"):
+            margin = sv[c].astype(np.float64) - exp[c] - thr
+        sure = ~(np.abs(margin) < MARGIN[dtype])
+        np.testing.assert_array_equal(mask.cpu().numpy()[0].astype(bool)[sure], (margin > 0)[sure])
+        assert (margin > 0).any()
+
+
+def test_pool_sv_window_larger_than_array(env):
+    """reflect is periodic with period 2N: windows wider than the data wrap several times."""
+    torch, ops = env
+    sv, _ = _scene(1, 5, 9, 11, spikes=False, nan_frac=0.1)
+    import scipy.ndimage
+
+    for func, f in (("nanmean", np.nanmean), ("nanmedian", np.nanmedian)):
+        exp = 10 * np.log10(scipy.ndimage.generic_filter(10 ** (sv[0] / 10), f, size=[2 * 7 + 1, 2 * 11 + 1],
+                                                         mode="reflect"))
+        pooled, _ = ops.pool_sv(_dev(torch, sv), 0, 7, 11, func=func)
+        _close(pooled.cpu().numpy()[0], exp, 1e-9, func)
+
+
+def test_pool_sv_everything_above_exclusion(env):
+    torch, ops = env
+    sv, _ = _scene(1, 6, 10, 3)
+    pooled, mask = ops.pool_sv(_dev(torch, sv), 10, 2, 2)
+    assert np.isnan(pooled.cpu().numpy()).all() and not mask.cpu().numpy().any()
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_apply_mask_and_mask_and(env, dtype):
+    torch, ops = env
+    rng = np.random.default_rng(4)
+    src = rng.standard_normal((3, 7, 11)).astype(dtype)
+    m1 = rng.random((3, 7, 11)) < 0.6
+    m2 = rng.random((7, 11)) < 0.7  # channel-less mask, broadcast
+    both = ops.mask_and(_dev(torch, m1.astype(np.uint8)), _dev(torch, m2.astype(np.uint8)))
+    np.testing.assert_array_equal(both.cpu().numpy().astype(bool), m1 & m2[None])
+    got = ops.apply_mask(_dev(torch, src), both).cpu().numpy()
+    np.testing.assert_array_equal(got, omask.apply_mask(src, [m1, m2]).astype(dtype))
+    got = ops.apply_mask(_dev(torch, src), _dev(torch, m2.astype(np.uint8)), fill_value=-999.0).cpu().numpy()
+    np.testing.assert_array_equal(got, omask.apply_mask(src, m2, -999.0).astype(dtype))
+    fill = rng.standard_normal((7, 11)).astype(dtype)
+    got = ops.apply_mask(_dev(torch, src), _dev(torch, m1.astype(np.uint8)), fill_array=_dev(torch, fill))
+    np.testing.assert_array_equal(got.cpu().numpy(), np.where(m1, src, fill[None]))

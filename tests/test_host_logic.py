@@ -206,3 +206,71 @@ def test_lite_containers():
     assert e["Sonar/Beam_group1"] is ds and "Platform" in e
     with pytest.raises(KeyError, match="no group"):
         e["Vendor_specific"]
+
+
+# ---- noise masks / apply_mask: argument validation happens before any device work ----------------
+def _mask_ds():
+    ds = Dataset(coords={"channel": ["a", "b"], "ping_time": np.arange(4).astype("datetime64[s]"),
+                         "range_sample": np.arange(5)})
+    dims = ("channel", "ping_time", "range_sample")
+    ds["Sv"] = (dims, np.zeros((2, 4, 5)))
+    ds["echo_range"] = (dims, np.tile(np.arange(5.0), (2, 4, 1)))
+    return ds
+
+
+def test_mask_functions_validate_before_touching_the_gpu():
+    from echopype_amd import clean
+
+    ds = _mask_ds()
+    for fn in (clean.mask_transient_noise, clean.mask_impulse_noise, clean.mask_attenuated_signal):
+        with pytest.raises(ValueError, match="`range_var` must be either `echo_range` or `depth`."):
+            fn(ds, range_var="range")
+        with pytest.raises(ValueError, match="requires `depth` data variable in `ds_Sv`"):
+            fn(ds)  # default range_var="depth" is absent
+    with pytest.raises(ValueError, match="Input `func` is `nanmode`"):
+        clean.mask_transient_noise(ds, func="nanmode", range_var="echo_range")
+    with pytest.raises(TypeError, match="Decibal input must be a string"):
+        clean.mask_impulse_noise(ds, impulse_noise_threshold=10.0, range_var="echo_range")
+    with pytest.raises(ValueError, match="Range bin must be in meters"):
+        clean.mask_impulse_noise(ds, depth_bin="5", range_var="echo_range")
+    with pytest.raises(ValueError, match="Minimum range has to be shorter than maximum range"):
+        clean.mask_attenuated_signal(ds, upper_limit_sl="180.0m", lower_limit_sl="170.0m", range_var="echo_range")
+
+
+def test_apply_mask_validation_helpers():
+    """mask/api.py:39-247 helpers, same error types and messages (tests/mask/test_mask.py)."""
+    from echopype_amd.mask import api as mapi
+
+    ds = _mask_ds()
+    ok = DataArray(np.ones((4, 5), bool), ("ping_time", "range_sample"))
+    assert mapi._validate_and_collect_mask_input(ok, {}) is ok
+    assert len(mapi._validate_and_collect_mask_input([ok, ok], {})) == 2
+    with pytest.raises(ValueError, match="single dict because mask is a single value"):
+        mapi._validate_and_collect_mask_input(ok, [{}])
+    with pytest.raises(TypeError, match="must be a list of dict or a dict"):
+        mapi._validate_and_collect_mask_input([ok], 3)
+    with pytest.raises(TypeError, match="must be a list of dict or a dict"):
+        mapi._validate_and_collect_mask_input([ok], [{}, 3])
+    with pytest.raises(ValueError, match="Masks must have one of the following dimensions"):
+        mapi._validate_and_collect_mask_input(DataArray(np.ones((4, 5), bool), ("ping_time", "beam")), {})
+    with pytest.raises(TypeError, match="Mask cannot contain NaN"):
+        mapi._validate_and_collect_mask_input(DataArray(np.full((4, 5), np.nan), ok.dims), {})
+    with pytest.raises(TypeError, match="Mask must be boolean"):
+        mapi._validate_and_collect_mask_input(DataArray(np.full((4, 5), 3), ok.dims), {})
+    with pytest.raises(NotImplementedError):
+        mapi._validate_and_collect_mask_input("mask.zarr", {})
+    with pytest.raises(ValueError, match="'channel' is a dimension in mask but not a dimension in source"):
+        flat = Dataset(coords={"ping_time": ds["ping_time"].values, "range_sample": np.arange(5)})
+        flat["Sv"] = (("ping_time", "range_sample"), np.zeros((4, 5)))
+        mapi._check_mask_dim_alignment(flat, DataArray(np.ones((2, 4, 5), bool), ds["Sv"].dims), "Sv")
+    with pytest.raises(ValueError, match="do not match the dimensions of source"):
+        mapi._check_mask_dim_alignment(ds, DataArray(np.ones((4, 5), bool), ("ping_time", "depth")), "Sv")
+    with pytest.raises(TypeError, match="var_name must be a string"):
+        mapi._check_var_name_fill_value(ds, 1, np.nan)
+    with pytest.raises(ValueError, match="does not contain the variable var_name"):
+        mapi._check_var_name_fill_value(ds, "TS", np.nan)
+    with pytest.raises(TypeError, match="fill_value must be of type int, float, or xr.DataArray"):
+        mapi._check_var_name_fill_value(ds, "Sv", "x")
+    with pytest.raises(ValueError, match="If fill_value is an array it must be of the same shape as Sv"):
+        mapi._check_var_name_fill_value(ds, "Sv", DataArray(np.zeros((4, 4)), ok.dims))
+    assert mapi._check_var_name_fill_value(ds, "Sv", 3) == 3
