@@ -179,6 +179,7 @@ __global__ __launch_bounds__(kBlock) void impulse_compare_kernel(const T* __rest
 //   pass 2 (ping) :  pooled = 10 log10( sum_{p-n..p+n} vsum / sum vcnt ),  mask = Sv - pooled > thr
 // ------------------------------------------------------------------------------------------------
 constexpr int kRangeTile = 2048;
+constexpr int kGroup = 8;  // window sums = two ragged edges + whole groups of 8 (no subtraction anywhere)
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void box_range_kernel(const T* __restrict__ sv, long long rows,
@@ -187,11 +188,14 @@ __global__ __launch_bounds__(kBlock) void box_range_kernel(const T* __restrict__
                                                            int* __restrict__ vcnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const epa::MathTabs mt = epa::build_math_tabs(smem);
-  double* lin = reinterpret_cast<double*>(smem + epa::kMathTabBytes);
   const int L = S - s0;
   const int t0 = blockIdx.y * kRangeTile;  // relative to s0
   const int nout = min(kRangeTile, L - t0);
   const int nin = nout + 2 * m;
+  const int ngrp = nin / kGroup;
+  double* lin = reinterpret_cast<double*>(smem + epa::kMathTabBytes);  // [nin], NaN kept
+  double* gsum = lin + ((nin + 1) & ~1);                                 // [ngrp]
+  int* gcnt = reinterpret_cast<int*>(gsum + ngrp);                       // [ngrp]
   for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
     __syncthreads();
     const T* svr = sv + (size_t)row * S + s0;
@@ -200,11 +204,40 @@ __global__ __launch_bounds__(kBlock) void box_range_kernel(const T* __restrict__
       lin[i] = (v == v) ? (double)epa::lin_from_db(v, mt.exp2_tab) : __builtin_nan("");
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < nout; o += kBlock) {
+    for (int g = threadIdx.x; g < ngrp; g += kBlock) {
       double sum = 0.0;
       int cnt = 0;
-      for (int k = 0; k <= 2 * m; ++k) {
-        const double x = lin[o + k];
+#pragma unroll
+      for (int k = 0; k < kGroup; ++k) {
+        const double x = lin[g * kGroup + k];
+        if (x == x) {
+          sum += x;
+          ++cnt;
+        }
+      }
+      gsum[g] = sum;
+      gcnt[g] = cnt;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < nout; o += kBlock) {
+      const int a = o, b = o + 2 * m + 1;  // window [a, b)
+      int a8 = (a + kGroup - 1) & ~(kGroup - 1), b8 = b & ~(kGroup - 1);
+      if (a8 >= b8) a8 = b8 = b;  // no whole group inside: one plain run
+      double sum = 0.0;
+      int cnt = 0;
+      for (int k = a; k < a8; ++k) {
+        const double x = lin[k];
+        if (x == x) {
+          sum += x;
+          ++cnt;
+        }
+      }
+      for (int g = a8 / kGroup; g < b8 / kGroup; ++g) {
+        sum += gsum[g];
+        cnt += gcnt[g];
+      }
+      for (int k = b8; k < b; ++k) {
+        const double x = lin[k];
         if (x == x) {
           sum += x;
           ++cnt;
@@ -217,53 +250,94 @@ __global__ __launch_bounds__(kBlock) void box_range_kernel(const T* __restrict__
   }
 }
 
-constexpr int kPingTile = 64, kColTile = 32;
+#ifndef EPA_BOX_PT
+#define EPA_BOX_PT 64
+#endif
+#ifndef EPA_BOX_CT
+#define EPA_BOX_CT 16
+#endif
+constexpr int kPingTile = EPA_BOX_PT, kColTile = EPA_BOX_CT;
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void box_ping_kernel(const T* __restrict__ sv,
                                                           const double* __restrict__ vsum,
                                                           const int* __restrict__ vcnt, int P, int S,
-                                                          int s0, int n, T thr, T* __restrict__ pooled,
+                                                          int s0, int n, long long ntiles, T thr,
+                                                          T* __restrict__ pooled,
                                                           uint8_t* __restrict__ mask) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const epa::MathTabs mt = epa::build_math_tabs(smem);
   const int nrow = kPingTile + 2 * n;
-  double* ssum = reinterpret_cast<double*>(smem + epa::kMathTabBytes);
-  int* scnt = reinterpret_cast<int*>(ssum + (size_t)nrow * kColTile);
-  const int c = blockIdx.z, p0 = blockIdx.y * kPingTile, col0 = blockIdx.x * kColTile;
-  const size_t cbase = (size_t)c * P * S;
-  for (int i = threadIdx.x; i < nrow * kColTile; i += kBlock) {
-    const int r = i / kColTile, col = i % kColTile;
-    const int s = col0 + col;
-    double a = 0.0;
-    int k = 0;
-    if (s >= s0 && s < S) {
-      const size_t at = cbase + (size_t)reflect_index(p0 - n + r, P) * S + s;
-      a = vsum[at];
-      k = vcnt[at];
-    }
-    ssum[i] = a;
-    scnt[i] = k;
-  }
-  __syncthreads();
-  const int col = threadIdx.x % kColTile, s = col0 + col;
-  if (s >= S) return;
-  for (int k = threadIdx.x / kColTile; k < kPingTile; k += kBlock / kColTile) {
-    const int p = p0 + k;
-    if (p >= P) break;
-    T out = epa::M<T>::nan();
-    if (s >= s0) {
-      double sum = 0.0;
-      long long cnt = 0;
-      for (int j = 0; j <= 2 * n; ++j) {
-        sum += ssum[(k + j) * kColTile + col];
-        cnt += scnt[(k + j) * kColTile + col];
+  const int ngrp = nrow / kGroup;
+  double* ssum = reinterpret_cast<double*>(smem + epa::kMathTabBytes);  // [nrow][kColTile]
+  double* gsum = ssum + (size_t)nrow * kColTile;                        // [ngrp][kColTile]
+  int* scnt = reinterpret_cast<int*>(gsum + (size_t)ngrp * kColTile);   // [nrow][kColTile]
+  int* gcnt = scnt + (size_t)nrow * kColTile;                           // [ngrp][kColTile]
+  // persistent workgroups: the tables are built once, tiles are taken column-tile fastest
+  const int ncol = (S + kColTile - 1) / kColTile, nping = (P + kPingTile - 1) / kPingTile;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int c = (int)(tile / ((long long)ncol * nping));
+    const int rem = (int)(tile - (long long)c * ncol * nping);
+    const int p0 = (rem / ncol) * kPingTile, col0 = (rem % ncol) * kColTile;
+    const size_t cbase = (size_t)c * P * S;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nrow * kColTile; i += kBlock) {
+      const int r = i / kColTile, col = i % kColTile;
+      const int s = col0 + col;
+      double a = 0.0;
+      int k = 0;
+      if (s >= s0 && s < S) {
+        const size_t at = cbase + (size_t)reflect_index(p0 - n + r, P) * S + s;
+        a = vsum[at];
+        k = vcnt[at];
       }
-      if (cnt > 0) out = (T)(10.0 * epa::fast_log10(sum / (double)cnt, mt.log_tab));
+      ssum[i] = a;
+      scnt[i] = k;
     }
-    const size_t at = cbase + (size_t)p * S + s;
-    if (pooled) pooled[at] = out;
-    if (mask) mask[at] = (sv[at] - out > thr) ? 1 : 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < ngrp * kColTile; i += kBlock) {
+      const int g = i / kColTile, col = i % kColTile;
+      double a = 0.0;
+      int k = 0;
+#pragma unroll
+      for (int j = 0; j < kGroup; ++j) {
+        a += ssum[(g * kGroup + j) * kColTile + col];
+        k += scnt[(g * kGroup + j) * kColTile + col];
+      }
+      gsum[i] = a;
+      gcnt[i] = k;
+    }
+    __syncthreads();
+    const int col = threadIdx.x % kColTile, s = col0 + col;
+    if (s >= S) continue;
+    for (int k = threadIdx.x / kColTile; k < kPingTile; k += kBlock / kColTile) {
+      const int p = p0 + k;
+      if (p >= P) break;
+      T out = epa::M<T>::nan();
+      if (s >= s0) {
+        const int a = k, b = k + 2 * n + 1;  // rows [a, b)
+        int a8 = (a + kGroup - 1) & ~(kGroup - 1), b8 = b & ~(kGroup - 1);
+        if (a8 >= b8) a8 = b8 = b;
+        double sum = 0.0;
+        long long cnt = 0;
+        for (int j = a; j < a8; ++j) {
+          sum += ssum[j * kColTile + col];
+          cnt += scnt[j * kColTile + col];
+        }
+        for (int g = a8 / kGroup; g < b8 / kGroup; ++g) {
+          sum += gsum[g * kColTile + col];
+          cnt += gcnt[g * kColTile + col];
+        }
+        for (int j = b8; j < b; ++j) {
+          sum += ssum[j * kColTile + col];
+          cnt += scnt[j * kColTile + col];
+        }
+        if (cnt > 0) out = (T)(10.0 * epa::fast_log10(sum / (double)cnt, mt.log_tab));
+      }
+      const size_t at = cbase + (size_t)p * S + s;
+      if (pooled) pooled[at] = out;
+      if (mask) mask[at] = (sv[at] - out > thr) ? 1 : 0;
+    }
   }
 }
 
@@ -730,8 +804,9 @@ extern "C" int epa_pool_sv(const void* sv, int C, int P, int S, int first_sample
     return epa::check_launch("pool_median_kernel");
   }
   EPA_CHECK_ARG(ws_sum && ws_cnt, "epa_pool_sv: nanmean needs the f64 / int32 [C*P*S] workspaces");
-  const size_t lds1 = epa::kMathTabBytes + (size_t)(kRangeTile + 2 * m) * 8;
-  const size_t lds2 = epa::kMathTabBytes + (size_t)(kPingTile + 2 * n) * kColTile * 12;
+  const size_t nin = (size_t)kRangeTile + 2 * m, nrow = (size_t)kPingTile + 2 * n;
+  const size_t lds1 = epa::kMathTabBytes + (nin + 2) * 8 + (nin / kGroup + 1) * 12;
+  const size_t lds2 = epa::kMathTabBytes + (nrow + nrow / kGroup + 1) * kColTile * 12;
   if (lds1 > kMaxLds || lds2 > kMaxLds) {
     epa::set_error("epa_pool_sv: window %d x %d exceeds the LDS budget", 2 * n + 1, 2 * m + 1);
     return EPA_EUNSUPPORTED;
@@ -749,14 +824,14 @@ extern "C" int epa_pool_sv(const void* sv, int C, int P, int S, int first_sample
 #undef EPA_BR
     if (int rc = epa::check_launch("box_range_kernel")) return rc;
   }
-  EPA_CHECK_ARG(C <= 65535 && (P + kPingTile - 1) / kPingTile <= 65535, "epa_pool_sv: grid too large");
-  const dim3 g2((S + kColTile - 1) / kColTile, (P + kPingTile - 1) / kPingTile, C);
+  const long long ntiles = (long long)C * ((P + kPingTile - 1) / kPingTile) * ((S + kColTile - 1) / kColTile);
+  const int g2 = (int)(ntiles < 256 * 24 ? ntiles : 256 * 24);
 #define EPA_BP(T)                                                                                   \
   do {                                                                                              \
     auto kern = box_ping_kernel<T>;                                                                 \
     if (int rc = set_lds(kern, lds2)) return rc;                                                    \
-    hipLaunchKernelGGL(kern, g2, dim3(kBlock), lds2, st, (const T*)sv, ws_sum, ws_cnt, P, S, s0, n, \
-                       (T)threshold, (T*)pooled_out, mask_out);                                     \
+    hipLaunchKernelGGL(kern, dim3(g2), dim3(kBlock), lds2, st, (const T*)sv, ws_sum, ws_cnt, P, S,  \
+                       s0, n, ntiles, (T)threshold, (T*)pooled_out, mask_out);                      \
   } while (0)
   if (dtype == EPA_F64) EPA_BP(double); else EPA_BP(float);
 #undef EPA_BP
