@@ -12,8 +12,8 @@ import torch
 from .. import ops
 from ..utils.prov import echopype_prov_attrs, insert_processing_level
 from ..xr_lite import DataArray, Dataset, DeviceArray, from_xarray
-from .utils import (_parse_x_bin, _set_MVBS_attrs, _setup_and_validate, ping_time_bin_parsing_and_conversion,
-                    resample_edges)
+from .utils import (_parse_x_bin, _set_MVBS_attrs, _setup_and_validate, get_distance_from_latlon,
+                    ping_time_bin_parsing_and_conversion, resample_edges)
 
 logger = logging.getLogger("echopype_amd.commongrid")
 
@@ -178,3 +178,86 @@ def compute_MVBS_index_binning(ds_Sv, range_sample_num=100, ping_num=100):
     if "frequency_nominal" in ds_Sv:
         ds_MVBS["frequency_nominal"] = ds_Sv["frequency_nominal"]
     return insert_processing_level(ds_MVBS, "L3*", input_ds=ds_Sv)
+
+
+POSITION_VARIABLES = ["latitude", "longitude"]
+
+
+def compute_NASC(ds_Sv, range_bin="10m", dist_bin="0.5nmi", method="map-reduce", skipna=True, closed="left",
+                 **flox_kwargs):
+    """Nautical Areal Scattering Coefficient on a (distance, depth) grid (api.py:269-416).
+    ``ds_Sv`` must hold ``Sv``, ``depth``, ``latitude`` and ``longitude``; it may be an Sv dataset
+    (dims channel, ping_time, range_sample) or an MVBS dataset gridded on depth."""
+    ds_Sv = from_xarray(ds_Sv)
+    range_var = "depth"
+    ds_Sv, range_bin_m = _setup_and_validate(ds_Sv, range_var, range_bin, closed,
+                                             required_data_vars=POSITION_VARIABLES)
+    if not isinstance(dist_bin, str):
+        raise TypeError("dist_bin must be a string")
+    dist_bin_nmi = _parse_x_bin(dist_bin, "dist_bin")
+
+    dist_nmi = get_distance_from_latlon(ds_Sv)  # O(P) on the host
+    sv_da = ds_Sv["Sv"]
+    order = tuple(sv_da.dims)
+    dim_0 = order[0]
+    sv_t = _dev(sv_da)
+    if sv_t.dtype not in (torch.float32, torch.float64):
+        sv_t = sv_t.double()
+    dp_t = _dev(_full(ds_Sv[range_var], ds_Sv, order), sv_t.dtype)
+    C, P, S = sv_t.shape
+
+    lo, hi = ops.nanminmax(dp_t)
+    r_edges = np.arange(0, hi + range_bin_m, range_bin_m)
+    d_edges = np.arange(0, np.nanmax(dist_nmi) + dist_bin_nmi, dist_bin_nmi)
+    n_r, n_d = len(r_edges) - 1, len(d_edges) - 1
+    if n_r < 1 or n_d < 1:
+        raise ValueError("NASC bins are empty: depth / distance hold no valid values")
+    # cumulative distance is non-decreasing: the pings of a distance bin are contiguous
+    side = "left" if closed == "left" else "right"
+    starts = np.searchsorted(dist_nmi, d_edges, side=side).astype(np.int32)
+    bin_start = ops.to_device(starts)
+
+    nasc_t = ops.nasc(sv_t, dp_t, bin_start, n_d, range_bin_m, n_r, skipna=skipna, closed=closed)
+
+    ds_NASC = Dataset(coords={"distance": d_edges[:-1], dim_0: ds_Sv[dim_0].values, range_var: r_edges[:-1]})
+    ds_NASC["NASC"] = DataArray(DeviceArray(nasc_t), (dim_0, "distance", range_var))
+    # per distance bin: mean position and mean ping_time (utils.py:453-501, :162-171)
+    idx = np.searchsorted(d_edges, dist_nmi, side="right" if closed == "left" else "left") - 1
+    inb = (idx >= 0) & (idx < n_d)
+    for var in POSITION_VARIABLES:
+        v = np.asarray(ds_Sv[var].values, dtype=np.float64)
+        use = inb & ~np.isnan(v)
+        ssum = np.bincount(idx[use], weights=v[use], minlength=n_d)
+        cnt = np.bincount(idx[use], minlength=n_d)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ds_NASC[var] = (("distance",), np.where(cnt > 0, ssum / cnt, np.nan), dict(ds_Sv[var].attrs))
+    ping_time = np.asarray(ds_Sv["ping_time"].values).astype("datetime64[ns]")
+    ns = ping_time.astype(np.int64)
+    valid_t = inb & ~np.isnat(ping_time)
+    n_t = np.bincount(idx[valid_t], minlength=n_d)
+    t0 = ns[valid_t].min() if valid_t.any() else 0
+    tsum = np.bincount(idx[valid_t], weights=(ns[valid_t] - t0).astype(np.float64), minlength=n_d)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        tmean = np.where(n_t > 0, t0 + np.round(tsum / np.maximum(n_t, 1)), np.iinfo(np.int64).min)
+    ds_NASC["ping_time"] = (("distance",), tmean.astype(np.int64).astype("datetime64[ns]"),
+                            dict(ds_Sv["ping_time"].attrs))
+    if "frequency_nominal" in ds_Sv:
+        ds_NASC["frequency_nominal"] = ds_Sv["frequency_nominal"]
+
+    ds_NASC.data_vars["NASC"].attrs = {"long_name": "Nautical Areal Scattering Coefficient (NASC, m2 nmi-2)",
+                                       "units": "m2 nmi-2"}
+    ds_NASC.coords["distance"].attrs = {"long_name": "Cumulative distance", "units": "nmi"}
+    ds_NASC.coords["depth"].attrs = {"long_name": "Cell depth", "units": "m", "standard_name": "depth"}
+    tv = ping_time[~np.isnat(ping_time)]
+    lat = np.asarray(ds_Sv["latitude"].values, dtype=np.float64)
+    lon = np.asarray(ds_Sv["longitude"].values, dtype=np.float64)
+    ds_NASC.attrs.update({
+        "Conventions": "CF-1.7,ACDD-1.3",
+        "time_coverage_start": np.datetime_as_string(tv.min(), timezone="UTC"),
+        "time_coverage_end": np.datetime_as_string(tv.max(), timezone="UTC"),
+        "geospatial_lat_min": round(float(np.nanmin(lat)), 5),
+        "geospatial_lat_max": round(float(np.nanmax(lat)), 5),
+        "geospatial_lon_min": round(float(np.nanmin(lon)), 5),
+        "geospatial_lon_max": round(float(np.nanmax(lon)), 5),
+    })
+    return insert_processing_level(ds_NASC, "L4", input_ds=ds_Sv)

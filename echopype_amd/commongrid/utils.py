@@ -91,3 +91,65 @@ def _set_MVBS_attrs(ds):
     ds.data_vars["Sv"].attrs = {"long_name": "Mean volume backscattering strength (MVBS, mean Sv re 1 m-1)",
                                 "units": "dB", "actual_range": None}
     ds.data_vars["Sv"].attrs.pop("actual_range")
+
+
+# ---- compute_NASC host helpers (utils.py:208-231) ------------------------------------
+_WGS84_A = 6378137.0
+_WGS84_F = 1 / 298.257223563
+
+
+def geodesic_distance_m(lat1, lon1, lat2, lon2):
+    """Geodesic length in metres on WGS-84 between arrays of points (degrees), the quantity the
+    reference takes from ``geopy.distance.distance`` (utils.py:219-225).  Vincenty's inverse
+    iteration, vectorised; coincident points give 0."""
+    a, f = _WGS84_A, _WGS84_F
+    b = (1 - f) * a
+    lat1, lon1, lat2, lon2 = (np.asarray(v, dtype=np.float64) for v in (lat1, lon1, lat2, lon2))
+    U1 = np.arctan((1 - f) * np.tan(np.radians(lat1)))
+    U2 = np.arctan((1 - f) * np.tan(np.radians(lat2)))
+    L = np.radians(lon2 - lon1)
+    sU1, cU1, sU2, cU2 = np.sin(U1), np.cos(U1), np.sin(U2), np.cos(U2)
+    lam = L.copy()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for _ in range(200):
+            sl, cl = np.sin(lam), np.cos(lam)
+            sin_sig = np.hypot(cU2 * sl, cU1 * sU2 - sU1 * cU2 * cl)
+            cos_sig = sU1 * sU2 + cU1 * cU2 * cl
+            sig = np.arctan2(sin_sig, cos_sig)
+            sin_al = np.where(sin_sig == 0, 0.0, cU1 * cU2 * sl / sin_sig)
+            cos2_al = 1 - sin_al**2
+            cos_2sm = np.where(cos2_al == 0, 0.0, cos_sig - 2 * sU1 * sU2 / cos2_al)
+            C = f / 16 * cos2_al * (4 + f * (4 - 3 * cos2_al))
+            lam_new = L + (1 - C) * f * sin_al * (sig + C * sin_sig * (cos_2sm + C * cos_sig * (-1 + 2 * cos_2sm**2)))
+            done = np.all(np.abs(lam_new - lam) < 1e-14)
+            lam = lam_new
+            if done:
+                break
+        u2 = cos2_al * (a * a - b * b) / (b * b)
+        A = 1 + u2 / 16384 * (4096 + u2 * (-768 + u2 * (320 - 175 * u2)))
+        B = u2 / 1024 * (256 + u2 * (-128 + u2 * (74 - 47 * u2)))
+        dsig = B * sin_sig * (cos_2sm + B / 4 * (cos_sig * (-1 + 2 * cos_2sm**2)
+                                                 - B / 6 * cos_2sm * (-3 + 4 * sin_sig**2) * (-3 + 4 * cos_2sm**2)))
+        s = b * A * (sig - dsig)
+    return np.where(sin_sig == 0, 0.0, s)
+
+
+def get_distance_from_latlon(ds_Sv):
+    """Cumulative along-track distance of every ping in nautical miles (utils.py:208-231): distance to
+    the NEXT ping, pairs with a NaN position dropped, cumulative sum, forward then backward fill."""
+    lat = np.asarray(ds_Sv["latitude"].values, dtype=np.float64)
+    lon = np.asarray(ds_Sv["longitude"].values, dtype=np.float64)
+    P = lat.shape[0]
+    lat2, lon2 = np.r_[lat[1:], np.nan], np.r_[lon[1:], np.nan]
+    ok = ~(np.isnan(lat) | np.isnan(lon) | np.isnan(lat2) | np.isnan(lon2))
+    if not ok.any():
+        raise ValueError("All lat/lon entries are NaN!")
+    step = np.zeros(P)
+    step[ok] = geodesic_distance_m(lat[ok], lon[ok], lat2[ok], lon2[ok]) / 1852.0
+    dist = np.where(ok, np.cumsum(step), np.nan)  # pandas cumsum skips NaN rows but keeps them NaN
+    idx = np.where(ok, np.arange(P), -1)
+    last = np.maximum.accumulate(idx)  # forward fill
+    dist = np.where(last >= 0, dist[np.maximum(last, 0)], np.nan)
+    first = np.flatnonzero(ok)[0]
+    dist[:first] = dist[first]  # backward fill of the leading gap
+    return dist

@@ -412,3 +412,19 @@ def pool_sv_value(sv, range, nvalid, depth_bin, num_side_pings, exclude_above, r
          float(exclude_above), float(range_min), float(range_max), f, float(threshold), _p(pooled),
          _p(mask), _DT[sv.dtype], _stream())
     return pooled, mask
+
+
+# ---- NASC ---------------------------------------------------------------------------
+
+def nasc(sv, depth, bin_start, n_dbins, range_bin, n_rbins, skipna=True, closed="left", want_parts=False):
+    """compute_raw_NASC -> NASC (C, n_dbins, n_rbins) [, sv_mean, h_mean]."""
+    C, P, S = sv.shape
+    if depth.dtype != sv.dtype:
+        depth = depth.to(sv.dtype)
+    ws = torch.empty(C * n_dbins * n_rbins * 3, dtype=torch.float64, device=sv.device)  # 24 B / cell
+    out = torch.empty((C, n_dbins, n_rbins), dtype=sv.dtype, device=sv.device)
+    svm = torch.empty_like(out) if want_parts else None
+    hm = torch.empty_like(out) if want_parts else None
+    call("epa_nasc", _p(sv), _p(depth), C, P, S, _p(bin_start), int(n_dbins), float(range_bin), int(n_rbins),
+         _bin_flags(skipna, closed), _p(ws), _p(out), _p(svm), _p(hm), _DT[sv.dtype], _stream())
+    return (out, svm, hm) if want_parts else out

@@ -320,6 +320,20 @@ int epa_pool_sv_value(const void* sv, const void* range, const int32_t* nvalid, 
                       double range_max, int func, double threshold, void* pooled_out, uint8_t* mask_out,
                       int dtype, epa_stream_t stream);
 
+/* ==== SURVEY 8f "next" row 3: compute_NASC ==============================================================
+ * Array pass of commongrid/utils.py:97-205 (compute_raw_NASC): NASC = sv_mean * h_mean * 4*pi*1852^2 with
+ * sv_mean the (nan)mean of the linear Sv per (channel, distance bin, depth bin) and h_mean the nansum of
+ * diff(depth) (labelled by its lower sample) per cell divided by the pings of the distance bin.
+ *   sv, depth : [C*P*S] of dtype, pings ordered by cumulative distance
+ *   bin_start : int32 [n_dbins+1], pings bin_start[d] .. bin_start[d+1]-1 belong to distance bin d
+ *   depth bins: edges i*range_bin, i = 0..n_rbins (np.arange(0, max + bin, bin), api.py:351)
+ *   bin_flags : EPA_BIN_SKIPNA, EPA_BIN_CLOSED_RIGHT (depth bins; the distance side is in bin_start)
+ *   workspace : 24 * C*n_dbins*n_rbins bytes (zeroed by the call)
+ *   nasc_out  : [C*n_dbins*n_rbins] of dtype; sv_mean_out / h_mean_out likewise, optional */
+int epa_nasc(const void* sv, const void* depth, int C, int P, int S, const int32_t* bin_start, int n_dbins,
+             double range_bin, int n_rbins, unsigned bin_flags, void* workspace, void* nasc_out,
+             void* sv_mean_out, void* h_mean_out, int dtype, epa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -274,3 +274,25 @@ def test_apply_mask_validation_helpers():
     with pytest.raises(ValueError, match="If fill_value is an array it must be of the same shape as Sv"):
         mapi._check_var_name_fill_value(ds, "Sv", DataArray(np.zeros((4, 4)), ok.dims))
     assert mapi._check_var_name_fill_value(ds, "Sv", 3) == 3
+
+
+def test_geodesic_and_cumulative_distance_match_oracle():
+    from oracle import nasc as onasc
+
+    rng = np.random.default_rng(0)
+    lat1, lat2 = rng.uniform(-80, 80, 50), rng.uniform(-80, 80, 50)
+    lon1, lon2 = rng.uniform(-180, 180, 50), rng.uniform(-180, 180, 50)
+    lat2[:25], lon2[:25] = lat1[:25] + rng.normal(0, 1e-3, 25), lon1[:25] + rng.normal(0, 1e-3, 25)  # ping spacing
+    lat2[0], lon2[0] = lat1[0], lon1[0]
+    got = gu.geodesic_distance_m(lat1, lon1, lat2, lon2)
+    exp = np.array([onasc.geodesic_m(*p) for p in zip(lat1, lon1, lat2, lon2)])
+    np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-6)
+    assert got[0] == 0.0
+    lat = np.array([np.nan, 10.0, 10.001, np.nan, 10.003, 10.004, 10.004])
+    lon = np.full(7, 20.0)
+    ds = Dataset(coords={"ping_time": np.arange(7).astype("datetime64[s]")})
+    ds["latitude"], ds["longitude"] = (("ping_time",), lat), (("ping_time",), lon)
+    np.testing.assert_allclose(gu.get_distance_from_latlon(ds), onasc.distance_from_latlon(lat, lon), rtol=1e-12)
+    ds["latitude"] = (("ping_time",), np.full(7, np.nan))
+    with pytest.raises(ValueError, match="All lat/lon entries are NaN!"):
+        gu.get_distance_from_latlon(ds)
