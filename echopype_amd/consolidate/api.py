@@ -1,41 +1,47 @@
 """consolidate.add_depth -- the step between compute_Sv and compute_MVBS(range_var="depth")
 (SURVEY 8f "next" row 1; reference: /root/reference/echopype/consolidate/api.py:68-243).
 
-depth = transducer_depth + orientation * echo_range * cos(tilt); the (channel, ping_time,
-range_sample) pass is one kernel launch (epa_affine_rows).  Supported here: numeric or
-single-dimension DataArray ``depth_offset`` / ``tilt`` (aligned to ping_time as the reference does,
-utils/align.py).  The EchoData-driven options (platform vertical offsets, platform / beam angles,
-consolidate/ek_depth_utils.py) are per-ping geometry joins outside this round's scope.
+depth = transducer_depth + orientation * echo_range * echo_range_scaling; the (channel, ping_time,
+range_sample) pass is one kernel launch (epa_affine_rows), everything else is per-ping / per-channel
+host work: numeric or single-dimension DataArray ``depth_offset`` / ``tilt`` (aligned to ping_time as
+the reference does, utils/align.py) and the EchoData-driven options for EK60 / EK80 (platform
+vertical offsets, platform angles, beam angles; consolidate/ek_depth_utils.py).
 """
 import datetime
+import logging
 from numbers import Number
 
 import numpy as np
 import torch
 
 from .. import ops
-from ..calibrate.env_params import _interp_time
 from ..commongrid.api import _dev, _full
 from ..xr_lite import DataArray, DeviceArray, from_xarray
+from .ek_depth_utils import (align_to_ping_time, ek_use_beam_angles, ek_use_platform_angles,
+                             ek_use_platform_vertical_offsets)
+
+logger = logging.getLogger("echopype_amd.consolidate")
 
 
 def _align_to_ping_time(da, ping_time):
-    """utils/align.py:5-61 (method='nearest' in add_depth): identical axis -> as is; one value ->
-    broadcast; none -> NaN; otherwise nearest-neighbour interpolation with extrapolation."""
-    vals = np.asarray(da.values, dtype=np.float64)
-    tname = da.dims[0]
-    t = np.asarray(da.coords[tname]).astype("datetime64[ns]")
-    pt = np.asarray(ping_time).astype("datetime64[ns]")
-    if t.shape == pt.shape and np.array_equal(t, pt):
-        return vals
-    if vals.size == 1:
-        return np.full(pt.shape, vals.reshape(-1)[0])
-    if vals.size == 0:
-        return np.full(pt.shape, np.nan)
-    ti, pi = t.astype(np.int64), pt.astype(np.int64)
-    idx = np.clip(np.searchsorted(ti, pi), 1, ti.size - 1)
-    left_closer = (pi - ti[idx - 1]) <= (ti[idx] - pi)
-    return vals[np.where(left_closer, idx - 1, idx)]
+    return align_to_ping_time(da.values, da.coords[da.dims[0]], ping_time)
+
+
+def _per_channel_ping(values, dims, C, P, what):
+    """Broadcast a scalar / (ping_time,) / (channel,) / (channel, ping_time) quantity to (C, P)."""
+    a = np.asarray(values, dtype=np.float64)
+    if a.ndim == 0:
+        return np.full((C, P), float(a))
+    dims = tuple(dims)
+    if dims == ("ping_time",):
+        return np.broadcast_to(a[None, :], (C, P))
+    if dims == ("channel",):
+        return np.broadcast_to(a[:, None], (C, P))
+    if dims == ("channel", "ping_time"):
+        return a
+    if dims == ("ping_time", "channel"):
+        return a.T
+    raise ValueError(f"{what} has unsupported dimensions {dims}")
 
 
 def add_depth(ds, echodata=None, depth_offset=None, tilt=None, downward=True,
@@ -47,39 +53,74 @@ def add_depth(ds, echodata=None, depth_offset=None, tilt=None, downward=True,
                          "or `use_beam_angles` is `True`, then `echodata` cannot be `None`.")
     if use_platform_angles and use_beam_angles:
         raise NotImplementedError("Computing depth with both platform and beam angles is not implemented yet.")
-    if use_platform_vertical_offsets or use_platform_angles or use_beam_angles:
-        raise NotImplementedError("EchoData-driven depth offsets / angles (consolidate/ek_depth_utils.py) are "
-                                  "not part of the accelerated path yet; pass depth_offset / tilt explicitly.")
+    if depth_offset is not None and use_platform_vertical_offsets:
+        logger.warning("When `depth_offset` is specified, platform vertical offset "
+                       "variables will not be used.")
+    if tilt is not None and (use_beam_angles or use_platform_angles):
+        logger.warning("When `tilt` is specified, beam/platform angle variables will not be used.")
+    sonar_model = None
+    if echodata:
+        sonar_model = echodata["Sonar"].attrs.get("sonar_model", getattr(echodata, "sonar_model", None))
+        if sonar_model not in ["EK60", "EK80"] and (
+                use_platform_vertical_offsets or use_platform_angles or use_beam_angles):
+            raise NotImplementedError(f"`use_platform/beam_...` not implemented yet for `{sonar_model}`.")
+    depth_offset, tilt = from_xarray(depth_offset), from_xarray(tilt)
+
     ping_time = ds["ping_time"].values
     P = len(ping_time)
-    transducer_depth = np.zeros(P)
-    if isinstance(depth_offset, Number):
-        transducer_depth = np.full(P, float(depth_offset))
-    elif isinstance(depth_offset, DataArray):
-        if len(depth_offset.dims) != 1:
-            raise ValueError("If depth_offset is passed in as an xr.DataArray, it must contain a single dimension.")
-        transducer_depth = _align_to_ping_time(depth_offset, ping_time)
-    scaling = np.ones(P)
-    if isinstance(tilt, Number):
-        scaling = np.full(P, np.cos(np.deg2rad(tilt)))
-    elif isinstance(tilt, DataArray):
-        if len(tilt.dims) != 1:
-            raise ValueError("If tilt is passed in as an xr.DataArray, it must contain a single dimension.")
-        scaling = np.cos(np.deg2rad(_align_to_ping_time(tilt, ping_time)))
-    mult = 1.0 if downward else -1.0
     er = ds["echo_range"]
     order = tuple(ds["Sv"].dims) if "Sv" in ds else tuple(er.dims)
     er_t = _dev(_full(er, ds, order))
     if er_t.dtype not in (torch.float32, torch.float64):
         er_t = er_t.double()
     C = er_t.shape[0]
-    scale = ops.to_device(np.ascontiguousarray(np.broadcast_to(mult * scaling, (C, P)), dtype=np.float64))
-    offset = ops.to_device(np.ascontiguousarray(np.broadcast_to(transducer_depth, (C, P)), dtype=np.float64))
+
+    transducer_depth, td_dims = 0.0, ()
+    if isinstance(depth_offset, Number):
+        transducer_depth = float(depth_offset)
+    if isinstance(depth_offset, DataArray):
+        if len(depth_offset.dims) != 1:
+            raise ValueError("If depth_offset is passed in as an xr.DataArray, it must contain a single dimension.")
+        transducer_depth, td_dims = _align_to_ping_time(depth_offset, ping_time), ("ping_time",)
+    elif echodata and sonar_model in ["EK60", "EK80"] and use_platform_vertical_offsets and depth_offset is None:
+        transducer_depth, td_dims = ek_use_platform_vertical_offsets(echodata["Platform"], ping_time)
+
+    scaling, sc_dims = 1.0, ()
+    beam_group_name = None
+    if isinstance(tilt, Number):
+        scaling = float(np.cos(np.deg2rad(tilt)))
+    if isinstance(tilt, DataArray):
+        if len(tilt.dims) != 1:
+            raise ValueError("If tilt is passed in as an xr.DataArray, it must contain a single dimension.")
+        scaling, sc_dims = np.cos(np.deg2rad(_align_to_ping_time(tilt, ping_time))), ("ping_time",)
+    elif echodata and sonar_model in ["EK60", "EK80"] and tilt is None:
+        if use_platform_angles:
+            scaling, sc_dims = ek_use_platform_angles(echodata["Platform"], ping_time)
+        elif use_beam_angles:
+            b1 = echodata["Sonar/Beam_group1"]
+            same = np.array_equal(np.asarray(b1["channel"].values), np.asarray(ds["channel"].values))
+            beam_group_name = "Beam_group1" if same else "Beam_group2"
+            scaling, sc_dims = ek_use_beam_angles(echodata[f"Sonar/{beam_group_name}"])
+
+    mult = 1.0 if downward else -1.0
+    scale = ops.to_device(np.ascontiguousarray(mult * _per_channel_ping(scaling, sc_dims, C, P, "echo range scaling")))
+    offset = ops.to_device(np.ascontiguousarray(_per_channel_ping(transducer_depth, td_dims, C, P, "transducer depth")))
     depth = ops.affine_rows(er_t, scale, offset)
+
+    used_offsets = use_platform_vertical_offsets and not _truthy(depth_offset)
+    used_platform_angles = use_platform_angles and not _truthy(tilt)
+    used_beam_angles = use_beam_angles and not _truthy(tilt)
     now = datetime.datetime.now(datetime.timezone.utc)
     ds["depth"] = DataArray(DeviceArray(depth), order, attrs={
         "long_name": "Depth", "standard_name": "depth", "units": "m",
         "history": f"{now}. `depth` calculated using: Sv `echo_range`"
-                   + (", user-provided `depth_offset`" if depth_offset is not None else "")
-                   + (", user-provided `tilt`" if tilt is not None else "") + "."})
+                   + (", Echodata `Platform` Vertical Offsets" if used_offsets else "")
+                   + (", Echodata `Platform` Angles" if used_platform_angles else "")
+                   + (f", Echodata `{beam_group_name}` Angles" if used_beam_angles and beam_group_name else "")
+                   + "."})
     return ds
+
+
+def _truthy(v):
+    """``not depth_offset`` of the reference (api.py:231-233) without the array-truthiness error."""
+    return v is not None and not (isinstance(v, Number) and v == 0)

@@ -355,6 +355,61 @@ def test_add_depth_then_MVBS_on_depth(ep):
         ep.consolidate.add_depth(ds, use_platform_angles=True)
 
 
+def test_add_depth_with_echodata_platform_and_beam_groups(ep, caplog):
+    """tests/consolidate/test_add_depth.py:398-604: depth from the Platform vertical offsets, the
+    Platform angles and the Beam-group direction vectors of an EK60 / EK80 EchoData."""
+    d = ep.synth.ek60_numpy(2, 40, 300)
+    ed = ep.echodata.from_ek60_arrays(d)
+    ds = ep.calibrate.compute_Sv(ed)
+    _, er = oc.ek60(d, "Sv")
+    t2 = d["ping_time"][::4] + np.timedelta64(300, "ms")
+    rng = np.random.default_rng(0)
+    plat = ep.Dataset(coords={"time2": t2, "channel": ds["channel"].values})
+    plat["water_level"] = (("time2",), rng.uniform(0, 1, t2.size))
+    plat["vertical_offset"] = (("time2",), rng.uniform(-0.5, 0.5, t2.size))
+    plat["transducer_offset_z"] = (("channel",), np.array([4.0, 6.5]))
+    plat["pitch"] = (("time2",), rng.uniform(-10, 10, t2.size))
+    plat["roll"] = (("time2",), rng.uniform(-10, 10, t2.size))
+    ed["Platform"] = plat
+    ed["Sonar"].attrs["sonar_model"] = "EK60"
+    idx = np.abs(d["ping_time"][:, None] - t2[None, :]).argmin(axis=1)  # nearest time2 of every ping
+
+    ep.consolidate.add_depth(ds, ed, use_platform_vertical_offsets=True)
+    td = plat["transducer_offset_z"].values[:, None] - (plat["water_level"].values + plat["vertical_offset"].values)[None, idx]
+    close(ds["depth"].values, td[:, :, None] + er, 1e-14, "platform vertical offsets")
+    assert "Echodata `Platform` Vertical Offsets" in ds["depth"].attrs["history"]
+
+    ep.consolidate.add_depth(ds, ed, use_platform_angles=True)
+    sc = (np.cos(np.deg2rad(plat["pitch"].values)) * np.cos(np.deg2rad(plat["roll"].values)))[idx]
+    close(ds["depth"].values, er * sc[None, :, None], 1e-14, "platform angles")
+    assert "Echodata `Platform` Angles" in ds["depth"].attrs["history"]
+
+    beam = ed["Sonar/Beam_group1"]
+    beam["beam_direction_x"] = (("channel",), np.array([0.0, 0.6]))
+    beam["beam_direction_y"] = (("channel",), np.array([0.0, 0.0]))
+    beam["beam_direction_z"] = (("channel",), np.array([1.0, 0.8]))
+    ep.consolidate.add_depth(ds, ed, use_beam_angles=True, use_platform_vertical_offsets=True, downward=False)
+    close(ds["depth"].values, td[:, :, None] - er * np.array([1.0, 0.8])[:, None, None], 1e-14, "beam angles")
+    assert "Echodata `Beam_group1` Angles" in ds["depth"].attrs["history"]
+
+    # user-given values win over the group variables, with the reference's warnings (:117-126)
+    import logging
+
+    with caplog.at_level(logging.WARNING):
+        ep.consolidate.add_depth(ds, ed, depth_offset=9.0, tilt=0.0, use_platform_vertical_offsets=True,
+                                 use_platform_angles=True)
+    assert "platform vertical offset variables will not be used" in caplog.text
+    assert "beam/platform angle variables will not be used" in caplog.text
+    close(ds["depth"].values, 9.0 + er, 1e-14, "explicit arguments win")
+    with pytest.raises(NotImplementedError, match="both platform and beam angles"):
+        ep.consolidate.add_depth(ds, ed, use_platform_angles=True, use_beam_angles=True)
+    ed["Sonar"].attrs["sonar_model"] = "AZFP"
+    with pytest.raises(NotImplementedError, match="not implemented yet for `AZFP`"):
+        ep.consolidate.add_depth(ds, ed, use_beam_angles=True)
+    with pytest.raises(ValueError, match="must contain a single dimension"):
+        ep.consolidate.add_depth(ds, tilt=ep.DataArray(np.zeros((2, 2)), ("a", "b")))
+
+
 # ------------------------------------------------------------------------------------ clean
 def test_remove_background_noise_reference_kat(ep):
     for make, n_nan in ((kf.noise_toy, None), (kf.noise_seed1, 6)):

@@ -296,3 +296,78 @@ def test_geodesic_and_cumulative_distance_match_oracle():
     ds["latitude"] = (("ping_time",), np.full(7, np.nan))
     with pytest.raises(ValueError, match="All lat/lon entries are NaN!"):
         gu.get_distance_from_latlon(ds)
+
+
+# ---- add_depth EchoData-driven inputs: the reference's unit tests restated
+#      (tests/consolidate/test_add_depth.py:51-187) --------------------------------------------------
+def _hours(n, step):
+    return np.datetime64("2024-07-04", "ns") + np.arange(n) * np.timedelta64(step, "h")
+
+
+def test_ek_use_platform_vertical_offsets_output():
+    from echopype_amd.consolidate import ek_depth_utils as eku
+
+    plat = Dataset(coords={"time2": _hours(4, 5)})
+    plat["water_level"] = (("time2",), np.array([1.5, 0.5, 0.0, 1.0]))
+    plat["vertical_offset"] = (("time2",), np.array([1.0, 0.0, 0.0, 1.0]))
+    plat["transducer_offset_z"] = (("time2",), np.array([3.0, 1.5, 0.0, 11.15]))
+    depth, dims = eku.ek_use_platform_vertical_offsets(plat, _hours(5, 4))
+    assert dims == ("ping_time",)
+    np.testing.assert_allclose(depth, [0.5, 1.0, 0.0, 0.0, 9.15])
+    # per-channel transducer offsets, scalar-in-time water level (EK80 layout)
+    plat = Dataset(coords={"time2": _hours(4, 5), "channel": ["a", "b"]})
+    plat["water_level"] = (("time2",), np.array([1.5, 0.5, 0.0, 1.0]))
+    plat["vertical_offset"] = (("time2",), np.zeros(4))
+    plat["transducer_offset_z"] = (("channel",), np.array([3.0, 5.0]))
+    depth, dims = eku.ek_use_platform_vertical_offsets(plat, _hours(5, 4))
+    assert dims == ("channel", "ping_time")
+    np.testing.assert_allclose(depth, [[1.5, 2.5, 3.0, 3.0, 2.0], [3.5, 4.5, 5.0, 5.0, 4.0]])
+
+
+def test_ek_use_platform_angles_output():
+    from echopype_amd.consolidate import ek_depth_utils as eku
+
+    plat = Dataset(coords={"time2": _hours(4, 5)})
+    plat["pitch"] = (("time2",), np.array([-90, 0, 0, -45]))
+    plat["roll"] = (("time2",), np.array([0, 90, 0, 0]))
+    scaling, dims = eku.ek_use_platform_angles(plat, _hours(5, 4))
+    assert dims == ("ping_time",)
+    np.testing.assert_allclose(scaling, [0.0, 0.0, 1.0, 1.0, 1 / np.sqrt(2)], atol=1e-15)
+    from scipy.spatial.transform import Rotation as R  # what the reference evaluates (ek_depth_utils.py:68-72)
+
+    rng = np.random.default_rng(0)
+    p, r = rng.uniform(-60, 60, 20), rng.uniform(-60, 60, 20)
+    plat = Dataset(coords={"time2": _hours(20, 1)})
+    plat["pitch"], plat["roll"] = (("time2",), p), (("time2",), r)
+    scaling, _ = eku.ek_use_platform_angles(plat, _hours(20, 1))
+    exp = R.from_euler("ZYX", np.column_stack([np.zeros(20), p, r]), degrees=True).as_matrix()[:, -1, -1]
+    np.testing.assert_allclose(scaling, exp, rtol=1e-13)
+
+
+def test_ek_use_beam_angles_output_and_warnings(caplog):
+    import logging
+
+    from echopype_amd.consolidate import ek_depth_utils as eku
+
+    beam = Dataset(coords={"channel": ["chan1", "chan2", "chan3", "chan4"]})
+    beam["beam_direction_x"] = (("channel",), np.array([1, 0, 0, 1]))
+    beam["beam_direction_y"] = (("channel",), np.array([0, 1, 0, 0]))
+    beam["beam_direction_z"] = (("channel",), np.array([0, 0, 1, np.sqrt(3) / 2]))
+    with caplog.at_level(logging.WARNING):
+        scaling, dims = eku.ek_use_beam_angles(beam)
+    assert "Beam direction vector was not normalized" in caplog.text and dims == ("channel",)
+    np.testing.assert_allclose(scaling, [0.0, 0.0, 1.0, (np.sqrt(3) / 2) / np.sqrt((np.sqrt(3) / 2) ** 2 + 1)])
+    caplog.clear()
+    beam = Dataset(coords={"channel": ["a", "b"]})
+    beam["beam_direction_x"] = (("channel",), np.array([0, 0]))
+    beam["beam_direction_y"] = (("channel",), np.array([0, 1]))
+    beam["beam_direction_z"] = (("channel",), np.array([0, 0]))
+    with caplog.at_level(logging.WARNING):
+        scaling, _ = eku.ek_use_beam_angles(beam)
+    assert "Some beam direction vectors are zero" in caplog.text
+    assert np.isnan(scaling[0]) and scaling[1] == 0.0
+    caplog.clear()
+    beam["beam_direction_z"] = (("channel",), np.array([np.nan, 1.0]))
+    with caplog.at_level(logging.WARNING):
+        eku.ek_use_beam_angles(beam)
+    assert "`beam_direction_z` variable array contains NaNs" in caplog.text
