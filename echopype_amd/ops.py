@@ -264,18 +264,29 @@ def noise_apply(sv, alpha2, noise, ping_num, snr_threshold, *, range=None, coef=
 
 
 def sv_complex(re, im, ccoef, *, replica=None, replica_off=None, max_taps=0, cal_type="Sv",
-               dtype=torch.float64, want_range=True, want_prx=False):
-    """K3+K4 -> dict(out, echo_range, prx)."""
+               dtype=torch.float64, want_range=True, want_prx=False, method="auto"):
+    """K3+K4 -> dict(out, echo_range, prx).  ``method``: "direct" (sliding register window),
+    "fft" (LDS-resident 2048-point FFT per tile, fp64 inside) or "auto" (fft for replicas of
+    16 .. 1024 taps, where it is faster; direct otherwise and for CW)."""
     C, P, S, B = re.shape
     if re.dtype != im.dtype or re.dtype not in _DT:
         raise ValueError("backscatter_r / backscatter_i must both be float32 or float64")
+    if method not in ("auto", "direct", "fft"):
+        raise ValueError("method must be 'auto', 'direct' or 'fft'")
     dev = re.device
     out = torch.empty((C, P, S), dtype=dtype, device=dev)
     rng = torch.empty((C, P, S), dtype=dtype, device=dev) if want_range else None
     prx = torch.empty((C, P, S), dtype=dtype, device=dev) if want_prx else None
-    call("epa_sv_complex", _p(re), _p(im), _DT[re.dtype], _p(replica), _p(replica_off), int(max_taps),
-         _p(ccoef), C, P, S, B, _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, _p(out), _p(rng),
-         _p(prx), _DT[dtype], _stream())
+    cal = _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS
+    use_fft = replica is not None and (method == "fft" or (method == "auto" and 16 <= max_taps <= _lib.EK80_NFFT // 2))
+    if use_fft:
+        n_ws = 2 * (_lib.EK80_NFFT // 8) + 4 * C + 2 * C * _lib.EK80_NFFT  # EPA_EK80_FFT_WS_DOUBLES(C)
+        ws = torch.empty(n_ws, dtype=torch.float64, device=dev)
+        call("epa_sv_complex_fft", _p(re), _p(im), _DT[re.dtype], _p(replica), _p(replica_off), int(max_taps),
+             _p(ccoef), C, P, S, B, cal, _p(out), _p(rng), _p(prx), _DT[dtype], _p(ws), _stream())
+    else:
+        call("epa_sv_complex", _p(re), _p(im), _DT[re.dtype], _p(replica), _p(replica_off), int(max_taps),
+             _p(ccoef), C, P, S, B, cal, _p(out), _p(rng), _p(prx), _DT[dtype], _stream())
     return dict(out=out, echo_range=rng, prx=prx)
 
 

@@ -245,6 +245,19 @@ int epa_sv_complex(const void* re, const void* im, int in_dtype, const float* re
                    int S, int B, int cal_type, void* out, void* range_out, void* prx_out,
                    int out_dtype, epa_stream_t stream);
 
+/* Same result for long replicas through an LDS-resident 2048-point FFT per tile (the matched filter
+ * as a circular correlation; scipy.signal.convolve's method="auto" makes the same switch in the
+ * reference, ek80_complex.py:334): ~11x fewer flops than the direct form at 177 taps, the kernel
+ * becomes HBM-bound like CW.  Always fp64 inside.  Replicas of 1 .. EPA_EK80_NFFT/2 taps
+ * (EPA_EUNSUPPORTED beyond: use epa_sv_complex).  workspace: f64 [EPA_EK80_FFT_WS_DOUBLES(C)]
+ * (twiddles; ||tx||^2, span of the non-zero taps and conj(FFT(tx))/N per channel; rebuilt by every call). */
+#define EPA_EK80_NFFT 2048
+#define EPA_EK80_FFT_WS_DOUBLES(C) (2 * (EPA_EK80_NFFT / 8) + 4 * (size_t)(C) + 2 * (size_t)(C) * EPA_EK80_NFFT)
+int epa_sv_complex_fft(const void* re, const void* im, int in_dtype, const float* replica,
+                       const int32_t* replica_off, int max_taps, const double* ccoef, int C, int P,
+                       int S, int B, int cal_type, void* out, void* range_out, void* prx_out,
+                       int out_dtype, double* workspace, epa_stream_t stream);
+
 /* ==== SURVEY 8f "next" row 2: Ryan et al. (2015) noise masks + apply_mask ==============================
  * Masks are uint8 [C*P*S] (1 = True) in the (channel, ping_time, range_sample) layout of Sv.        */
 

@@ -19,14 +19,15 @@ for in_dt in (torch.float64, torch.float32):
     im = (torch.randn((C, P, S, B), generator=g, device="cuda", dtype=torch.float32) * 1e-3).to(in_dt)
     esz = 8 if in_dt == torch.float64 else 4
     for out_dt in (torch.float64, torch.float32):
-        for name, kw in (("BB", dict(replica=rep, replica_off=off, max_taps=taps)), ("CW", dict())):
+        for name, kw in (("BB-fft", dict(replica=rep, replica_off=off, max_taps=taps, method="fft")),
+                         ("BB-direct", dict(replica=rep, replica_off=off, max_taps=taps, method="direct")), ("CW", dict())):
             fn = lambda: ops.sv_complex(re, im, ccd, dtype=out_dt, want_range=False, **kw)
             fn(); torch.cuda.synchronize(); ms = []
             for _ in range(5):
                 t.start(); fn(); t.stop(); ms.append(t.elapsed_ms())
             m = float(np.median(ms))
             osz = 8 if out_dt == torch.float64 else 4
-            flops = 8.0 * taps * n if name == "BB" else 0
-            print(f"{name} in={str(in_dt)[6:]:8s} out/acc={str(out_dt)[6:]:8s} {m:8.3f} ms {n/m/1e6:7.1f} Gsamp/s "
+            flops = 8.0 * taps * n if name.startswith("BB") else 0
+            print(f"{name:9s} in={str(in_dt)[6:]:8s} out/acc={str(out_dt)[6:]:8s} {m:8.3f} ms {n/m/1e6:7.1f} Gsamp/s "
                   f"{n*(2*B*esz+osz)/m/1e9:5.2f} TB/s {flops/m/1e9:6.1f} TFLOP/s", flush=True)
     del re, im

@@ -142,7 +142,8 @@ def test_fullsize_fp32_vs_fp64_tolerance(vol):
     del res
 
 
-def test_fullrange_matched_filter_impulse_response():
+@pytest.mark.parametrize("method", ["direct", "fft"])
+def test_fullrange_matched_filter_impulse_response(method):
     """EK80 BB at the full range depth of configs[3] (S = 8192): a ping that contains only the
     replica at sample k0 compresses to a unit peak at k0 (|y| / ||tx||^2 == 1), i.e.
     prx(k0) = PSCALE; and the kernel is linear: the sector-sum path equals the per-sector path."""
@@ -169,7 +170,7 @@ def test_fullrange_matched_filter_impulse_response():
     repf = dev(np.ascontiguousarray(rep.astype(np.complex64).view(np.float32)))
     off = dev(np.array([0, rep.size], dtype=np.int32))
     res = ops.sv_complex(dev(re), dev(im), dev(cc), replica=repf, replica_off=off, max_taps=rep.size,
-                         want_prx=True)
+                         want_prx=True, method=method)
     prx = res["prx"].cpu().numpy()[0]
     peak = prx[np.arange(Pp), k0s]
     np.testing.assert_allclose(peak, 1.0, rtol=1e-6)           # replica stored as complex64
@@ -179,6 +180,11 @@ def test_fullrange_matched_filter_impulse_response():
     re2 = re.copy()
     re2[0, :, 8000, 2] = np.nan
     res2 = ops.sv_complex(dev(re2), dev(im), dev(cc), replica=repf, replica_off=off, max_taps=rep.size,
-                          want_prx=True)
+                          want_prx=True, method=method)
     prx2 = res2["prx"].cpu().numpy()[0]
     np.testing.assert_allclose(prx2[np.arange(Pp), k0s], peak, rtol=1e-12)
+    # outside the replica's footprint the correlation is exactly 0 -> prx NaN (calibrate_ek.py:571-575);
+    # the FFT form must restore those exact zeros instead of leaving rounding noise of the peak
+    k = np.arange(Ss)[None, :]
+    outside = (k >= k0s[:, None] + rep.size) | (k + rep.size <= k0s[:, None])
+    assert np.isnan(prx[outside]).all() and np.isfinite(prx[~outside]).sum() > Pp * rep.size

@@ -4,6 +4,8 @@ same seeded inputs.  Needs a real MI355X: `pytest -m gpu`.
 Tolerances (BASELINE.json north_star): fp64 1e-5 relative, fp32 1e-3 relative.  The fp64 kernels
 are in fact held to 1e-9 here (observed ~1e-13): a looser pass would hide a formula slip.
 """
+import warnings
+
 import numpy as np
 import pytest
 
@@ -426,3 +428,52 @@ def test_argument_errors_from_c_abi(env):
     from echopype_amd import _lib
     with pytest.raises(ValueError, match="NULL"):
         _lib.call("epa_sv_power", None, None, 1, 1, 1, 0, 0, None, None, 1, None)
+
+
+# ---- EK80 BB: FFT path == direct path ---------------------------------------------------------------
+@pytest.mark.parametrize("in_dtype,out_dtype", [("float64", "float64"), ("float32", "float64"), ("float32", "float32")])
+@pytest.mark.parametrize("taps,S,mixed", [(177, 5000, False), (64, 2048, True), (16, 1873, False), (1024, 3000, True),
+                                          (333, 8192, False)])
+def test_sv_complex_fft_path_matches_direct(env, in_dtype, out_dtype, taps, S, mixed):
+    """The LDS-FFT circular correlation (epa_sv_complex_fft) against the sliding-window direct form
+    (epa_sv_complex) on echoes spanning 140 dB: several tiles, ragged last tile, per-sector fallback
+    for mixed NaN patterns, NaN tails, two channels with different replica lengths."""
+    torch, ops, synth = env
+    rng = np.random.default_rng(taps + S)
+    C, P, B = 2, 3, 4
+    amp = 10.0 ** rng.uniform(-7, 0, (C, P, S, 1))
+    re = (amp * rng.standard_normal((C, P, S, B))).astype(in_dtype)
+    im = (amp * rng.standard_normal((C, P, S, B))).astype(in_dtype)
+    re[:, :, S - 37:], im[:, :, S - 37:] = np.nan, np.nan  # end-of-ping padding
+    re[1, 1], im[1, 1] = np.nan, np.nan                    # a whole missing ping
+    if mixed:
+        re[0, 0, 100:130, 2] = np.nan                      # one sector missing -> per-sector fallback
+        im[0, 2, S // 2, 0] = np.nan
+    lens = [taps, max(taps // 2, 1)]
+    rep = np.concatenate([(rng.standard_normal(n) + 1j * rng.standard_normal(n)) * np.hanning(n + 2)[1:-1]
+                          for n in lens]).astype(np.complex64)
+    repf = _dev(torch, np.stack([rep.real, rep.imag], axis=1).astype(np.float32).reshape(-1))
+    off = _dev(torch, np.array([0, lens[0], lens[0] + lens[1]], dtype=np.int32))
+    cc = np.zeros((C, P, 8))
+    cc[..., 0], cc[..., 1], cc[..., 2], cc[..., 3], cc[..., 4], cc[..., 5] = 2.6e-5, 750.0, 0.2, 0.02, -30.0, 1e3
+    kw = dict(replica=repf, replica_off=off, max_taps=taps, dtype=getattr(torch, out_dtype), want_prx=True)
+    args = (_dev(torch, re), _dev(torch, im), _dev(torch, cc))
+    d = ops.sv_complex(*args, method="direct", **kw)
+    f = ops.sv_complex(*args, method="fft", **kw)
+    pd, pf = d["prx"].cpu().numpy().astype(np.float64), f["prx"].cpu().numpy().astype(np.float64)
+    np.testing.assert_array_equal(np.isnan(pf), np.isnan(pd))
+    np.testing.assert_array_equal(f["echo_range"].cpu().numpy(), d["echo_range"].cpu().numpy())
+    with np.errstate(invalid="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        peak = np.nanmax(pd, axis=2, keepdims=True)
+    # the direct path accumulates in the output precision, the FFT path always in fp64
+    eps = 1e-12 if out_dtype == "float64" else 3e-6
+    with np.errstate(invalid="ignore"):
+        bound = eps * (np.sqrt(pd * peak) + pd) + 1e-300
+        assert np.nanmax(np.abs(pf - pd) / bound) < 1.0
+    sd, sf = d["out"].cpu().numpy().astype(np.float64), f["out"].cpu().numpy().astype(np.float64)
+    np.testing.assert_array_equal(np.isnan(sf), np.isnan(sd))
+    with np.errstate(invalid="ignore"):
+        strong = pd > peak * 1e-10
+    tol = 1e-6 if out_dtype == "float64" else 2e-3
+    assert np.nanmax(np.abs(sf[strong] - sd[strong])) < tol  # NaN where R' <= 0 (both paths alike)
