@@ -20,6 +20,10 @@ def vol():
 
     if not torch.cuda.is_available():
         pytest.fail("needs a GPU")
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
     if free < 150 * 2**30:
         pytest.skip("needs ~150 GB of free HBM")

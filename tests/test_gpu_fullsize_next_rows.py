@@ -17,6 +17,10 @@ def env():
 
     if not torch.cuda.is_available():
         pytest.fail("needs a GPU")
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()  # blocks cached by earlier full-size modules
     free, _ = torch.cuda.mem_get_info()
     if free < 200 * 2**30:
         pytest.skip("needs ~200 GB of free HBM")
