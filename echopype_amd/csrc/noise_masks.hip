@@ -395,83 +395,165 @@ struct RaggedWindow {
   }
 };
 
+constexpr int kCandCap = 2048;  // candidates kept in LDS once the selected radix bucket is this small
+
 struct SelectScratch {
   unsigned hist[256];
   unsigned u4[4];
   unsigned long long q4[4];
-  unsigned digit, krem;
+  unsigned digit, krem, bucket, ncand;
+  unsigned long long cand[kCandCap];
 };
+
+// One 8-bit radix step of the selection: histogram of digit (key >> shift) & 255 over the keys that
+// `each` enumerates and that match `prefix` on the bits above the digit; picks the bucket holding
+// rank k.  Returns the total number of keys counted; updates prefix / k; *bucket = size of the bucket.
+template <typename Each>
+__device__ __forceinline__ unsigned radix_step(Each each, SelectScratch* sc, int shift,
+                                               unsigned long long& prefix, unsigned& k, unsigned& bucket,
+                                               bool k_known, unsigned* total_out) {
+  __syncthreads();
+  sc->hist[threadIdx.x] = 0u;  // kBlock == 256
+  __syncthreads();
+  const unsigned long long hi_mask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+  unsigned* hist = sc->hist;
+  const unsigned long long pre = prefix;
+  each([&](unsigned long long key) {
+    if ((key & hi_mask) == pre) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+  });
+  __syncthreads();
+  if (!k_known) {  // first step: the histogram total is the number of valid values; k = lower median rank
+    const unsigned total = block_sum(sc->hist[threadIdx.x], sc->u4);
+    *total_out = total;
+    if (total == 0u) return 0u;
+    k = (total - 1u) / 2u;
+  }
+  if (threadIdx.x < 64) {
+    const unsigned l = threadIdx.x;
+    const unsigned h0 = sc->hist[4 * l], h1 = sc->hist[4 * l + 1], h2 = sc->hist[4 * l + 2],
+                   h3 = sc->hist[4 * l + 3];
+    const unsigned tot = h0 + h1 + h2 + h3;
+    unsigned incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t = __shfl_up(incl, o, 64);
+      if ((int)l >= o) incl += t;
+    }
+    const unsigned excl = incl - tot;
+    if (excl <= k && k < incl) {
+      unsigned r = k - excl, d;
+      if (r < h0) d = 0;
+      else if ((r -= h0) < h1) d = 1;
+      else if ((r -= h1) < h2) d = 2;
+      else { r -= h2; d = 3; }
+      sc->digit = 4 * l + d;
+      sc->krem = r;
+      sc->bucket = d == 0 ? h0 : (d == 1 ? h1 : (d == 2 ? h2 : h3));
+    }
+  }
+  __syncthreads();
+  prefix |= (unsigned long long)sc->digit << shift;
+  k = sc->krem;
+  bucket = sc->bucket;
+  return 1u;
+}
 
 // Returns the median of 10^(x/10) over the non-NaN x of the window; n_valid = their count (the
 // result is NaN when it is 0).  Must be called by all threads of the workgroup.
+// The window is swept from memory only until the bucket that holds the median has at most kCandCap
+// members (typically 2 sweeps for a 16 k-element block of dB values, 0 for a small window); those
+// candidates are then gathered into LDS in one more sweep and the remaining digits are resolved there.
 template <typename W>
 __device__ double window_median_lin(const W& w, SelectScratch* sc, const double* exp2_tab,
-                                    unsigned& n_valid) {
-  unsigned c = 0;
-  w.for_each([&](double v) { c += (v == v) ? 1u : 0u; });
-  const unsigned N = block_sum(c, sc->u4);
-  n_valid = N;
-  if (N == 0) return __builtin_nan("");
-  const unsigned k_lo = (N - 1) / 2;
-  unsigned k = k_lo;
-  unsigned long long prefix = 0ull;
-  for (int shift = 56; shift >= 0; shift -= 8) {
-    __syncthreads();
-    sc->hist[threadIdx.x] = 0u;  // kBlock == 256
-    __syncthreads();
-    const unsigned long long hi_mask = shift == 56 ? 0ull : (~0ull << (shift + 8));
-    unsigned* hist = sc->hist;
+                                    unsigned& n_valid, int size_hint = 0x7fffffff) {
+  auto each_global = [&](auto f) {
     w.for_each([&](double v) {
-      if (v == v) {
-        const unsigned long long key = sort_key(v);
-        if ((key & hi_mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
-      }
+      if (v == v) f(sort_key(v));
     });
-    __syncthreads();
-    if (threadIdx.x < 64) {
-      const unsigned l = threadIdx.x;
-      const unsigned h0 = sc->hist[4 * l], h1 = sc->hist[4 * l + 1], h2 = sc->hist[4 * l + 2],
-                     h3 = sc->hist[4 * l + 3];
-      const unsigned tot = h0 + h1 + h2 + h3;
-      unsigned incl = tot;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const unsigned t = __shfl_up(incl, o, 64);
-        if ((int)l >= o) incl += t;
+  };
+  unsigned long long prefix = 0ull;
+  unsigned k = 0u, bucket = 0xffffffffu, N = 0u;
+  bool k_known = false;
+  int shift = 64;  // bits [shift, 64) of the median's key are decided
+  if (size_hint > kCandCap) {
+    while (shift > 0 && bucket > (unsigned)kCandCap) {
+      shift -= 8;
+      if (!radix_step(each_global, sc, shift, prefix, k, bucket, k_known, &N)) {
+        n_valid = 0u;
+        return __builtin_nan("");
       }
-      const unsigned excl = incl - tot;
-      if (excl <= k && k < incl) {
-        unsigned r = k - excl, d;
-        if (r < h0) d = 0;
-        else if ((r -= h0) < h1) d = 1;
-        else if ((r -= h1) < h2) d = 2;
-        else { r -= h2; d = 3; }
-        sc->digit = 4 * l + d;
-        sc->krem = r;
-      }
+      k_known = true;
     }
-    __syncthreads();
-    prefix |= (unsigned long long)sc->digit << shift;
-    k = sc->krem;
   }
-  const double v1 = key_value(prefix);
-  double med = epa::lin_from_db(v1, exp2_tab);
-  if ((N & 1u) == 0u) {  // second middle value: next order statistic
-    unsigned le = 0;
-    unsigned long long gt = ~0ull;
-    w.for_each([&](double v) {
-      if (v == v) {
-        const unsigned long long key = sort_key(v);
+  unsigned long long key1, key2;
+  if (shift == 0) {
+    // resolved entirely from memory (a bucket of > kCandCap equal values): one more sweep for the even case
+    key1 = key2 = prefix;
+    if ((N & 1u) == 0u) {
+      unsigned le = 0;
+      unsigned long long gt = ~0ull;
+      each_global([&](unsigned long long key) {
         if (key <= prefix) ++le;
         else gt = key < gt ? key : gt;
+      });
+      const unsigned n_le = block_sum(le, sc->u4);
+      const unsigned long long min_gt = block_min(gt, sc->q4);
+      if (n_le < (N - 1u) / 2u + 2u) key2 = min_gt;
+    }
+  } else {
+    // gather the candidates (keys matching the decided bits) into LDS; remember the smallest key above them
+    const unsigned long long dmask = shift == 64 ? 0ull : (~0ull << shift);
+    __syncthreads();
+    if (threadIdx.x == 0) sc->ncand = 0u;
+    __syncthreads();
+    unsigned long long above = ~0ull;
+    unsigned* ncand = &sc->ncand;
+    unsigned long long* cand = sc->cand;
+    const unsigned long long pre = prefix;
+    each_global([&](unsigned long long key) {
+      const unsigned long long hi = key & dmask;
+      if (hi == pre) {
+        const unsigned at = atomicAdd(ncand, 1u);
+        if (at < (unsigned)kCandCap) cand[at] = key;
+      } else if (hi > pre) {
+        above = key < above ? key : above;
       }
     });
-    const unsigned n_le = block_sum(le, sc->u4);
-    const unsigned long long min_gt = block_min(gt, sc->q4);
-    const double v2 = (n_le >= k_lo + 2) ? v1 : key_value(min_gt);
-    med = (med + epa::lin_from_db(v2, exp2_tab)) * 0.5;
+    const unsigned long long min_above = block_min(above, sc->q4);  // (barriers inside publish cand / ncand)
+    const unsigned M = sc->ncand;
+    if (!k_known) {  // small window gathered whole: M is the number of valid values
+      N = M;
+      if (N == 0u) {
+        n_valid = 0u;
+        return __builtin_nan("");
+      }
+      k = (N - 1u) / 2u;
+    }
+    const unsigned r0 = k;  // rank of the median inside the candidate set
+    auto each_cand = [&](auto f) {
+      for (unsigned i = threadIdx.x; i < M; i += kBlock) f(cand[i]);
+    };
+    unsigned dummy;
+    while (shift > 0) {
+      shift -= 8;
+      radix_step(each_cand, sc, shift, prefix, k, bucket, true, &dummy);
+    }
+    key1 = key2 = prefix;
+    if ((N & 1u) == 0u) {
+      unsigned le = 0;
+      unsigned long long gt = ~0ull;
+      each_cand([&](unsigned long long key) {
+        if (key <= prefix) ++le;
+        else gt = key < gt ? key : gt;
+      });
+      const unsigned n_le = block_sum(le, sc->u4);
+      const unsigned long long min_gt = block_min(gt, sc->q4);
+      if (n_le < r0 + 2u) key2 = (min_gt != ~0ull) ? min_gt : min_above;
+    }
   }
-  return med;
+  n_valid = N;
+  const double a = epa::lin_from_db(key_value(key1), exp2_tab);
+  return key1 == key2 ? a : (a + epa::lin_from_db(key_value(key2), exp2_tab)) * 0.5;
 }
 
 // pooled Sv with func = nanmedian: one workgroup per output sample (the reference warns that this
@@ -494,7 +576,7 @@ __global__ __launch_bounds__(kBlock) void pool_median_kernel(const T* __restrict
     if (s >= s0) {
       Window<T> w{sv + (size_t)c * P * S, S, p - n, 2 * n + 1, s - m, 2 * m + 1, P, s0, true};
       unsigned nv;
-      const double med = window_median_lin(w, &sc, mt.exp2_tab, nv);
+      const double med = window_median_lin(w, &sc, mt.exp2_tab, nv, (2 * n + 1) * (2 * m + 1));
       if (nv) out = (T)(10.0 * epa::fast_log10(med, mt.log_tab));
     }
     if (threadIdx.x == 0) {
@@ -537,11 +619,11 @@ __global__ __launch_bounds__(kBlock) void attenuated_mask_kernel(
       const T* cb = sv + (size_t)c * P * S;
       unsigned nv;
       Window<T> w1{cb, S, p, 1, up, lw - up, P, 0, false};
-      const double m1 = window_median_lin(w1, &sc, mt.exp2_tab, nv);
+      const double m1 = window_median_lin(w1, &sc, mt.exp2_tab, nv, lw - up);
       if (nv) {
         Window<T> w2{cb, S, p - n, 2 * n, up, lw - up, P, 0, false};
         unsigned nv2;
-        const double m2 = window_median_lin(w2, &sc, mt.exp2_tab, nv2);
+        const double m2 = window_median_lin(w2, &sc, mt.exp2_tab, nv2, 2 * n * (lw - up));
         const T ping_db = (T)(10.0 * epa::fast_log10(m1, mt.log_tab));
         const T block_db = nv2 ? (T)(10.0 * epa::fast_log10(m2, mt.log_tab)) : epa::M<T>::nan();
         flag = (ping_db - block_db) < thr;
