@@ -84,8 +84,8 @@ int epa_timer_create(void** timer) {
 int epa_timer_destroy(void* timer) {
   if (!timer) return EPA_OK;
   EpaTimer* t = (EpaTimer*)timer;
-  hipEventDestroy(t->start);
-  hipEventDestroy(t->stop);
+  (void)hipEventDestroy(t->start);
+  (void)hipEventDestroy(t->stop);
   delete t;
   return EPA_OK;
 }

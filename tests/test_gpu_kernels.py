@@ -432,22 +432,23 @@ def test_argument_errors_from_c_abi(env):
 
 # ---- EK80 BB: FFT path == direct path ---------------------------------------------------------------
 @pytest.mark.parametrize("in_dtype,out_dtype", [("float64", "float64"), ("float32", "float64"), ("float32", "float32")])
-@pytest.mark.parametrize("taps,S,mixed", [(177, 5000, False), (64, 2048, True), (16, 1873, False), (1024, 3000, True),
-                                          (333, 8192, False)])
-def test_sv_complex_fft_path_matches_direct(env, in_dtype, out_dtype, taps, S, mixed):
+@pytest.mark.parametrize("taps,S,mixed,B", [(177, 5000, False, 4), (64, 2048, True, 4), (16, 1873, False, 4),
+                                            (1024, 3000, True, 4), (333, 8192, False, 4), (90, 2500, True, 3),
+                                            (40, 1000, False, 1)])
+def test_sv_complex_fft_path_matches_direct(env, in_dtype, out_dtype, taps, S, mixed, B):
     """The LDS-FFT circular correlation (epa_sv_complex_fft) against the sliding-window direct form
     (epa_sv_complex) on echoes spanning 140 dB: several tiles, ragged last tile, per-sector fallback
     for mixed NaN patterns, NaN tails, two channels with different replica lengths."""
     torch, ops, synth = env
     rng = np.random.default_rng(taps + S)
-    C, P, B = 2, 3, 4
+    C, P = 2, 3
     amp = 10.0 ** rng.uniform(-7, 0, (C, P, S, 1))
     re = (amp * rng.standard_normal((C, P, S, B))).astype(in_dtype)
     im = (amp * rng.standard_normal((C, P, S, B))).astype(in_dtype)
     re[:, :, S - 37:], im[:, :, S - 37:] = np.nan, np.nan  # end-of-ping padding
     re[1, 1], im[1, 1] = np.nan, np.nan                    # a whole missing ping
     if mixed:
-        re[0, 0, 100:130, 2] = np.nan                      # one sector missing -> per-sector fallback
+        re[0, 0, 100:130, B - 1] = np.nan                  # one sector missing -> per-sector fallback
         im[0, 2, S // 2, 0] = np.nan
     lens = [taps, max(taps // 2, 1)]
     rep = np.concatenate([(rng.standard_normal(n) + 1j * rng.standard_normal(n)) * np.hanning(n + 2)[1:-1]
