@@ -23,7 +23,7 @@
 
 namespace {
 
-enum { SRC_RAW = 0, SRC_SV = 1 };
+enum { SRC_RAW = 0, SRC_SV = 1, SRC_SV_DENOISE = 2, SRC_RAW_DENOISE = 3 };
 enum { OP_MVBS = 0, OP_NOISE = 1 };
 enum { BIN_PHYS = 0, BIN_INDEX = 1 };
 
@@ -52,6 +52,11 @@ struct ReduceArgs {
   void* out;
   void* sum_out;
   uint32_t* cnt_out;
+  // SRC_SV_DENOISE: background-noise removal applied on the fly (K7 fused into the reduction)
+  const double* noise;   // [C * n_pblocks] per ping-block noise (epa_noise_estimate layout)
+  int noise_ping_num, n_pblocks;
+  double snr;
+  void* sv_noise_out;    // optional Sv_noise output (Sv_corrected goes to sv_out)
   int use_lds;
   unsigned cnt_off;  // byte offset of the count array in dynamic LDS
   unsigned tab_off;  // byte offset of the exp/log tables (fast_math.h) in dynamic LDS
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(epa::kBlock) void block_reduce_kernel(ReduceArgs a)
   const int part = blockIdx.x - tb * a.nparts;
   // tb == n_tbins (fused source only): pings that belong to no time bin still get their Sv/echo_range
   const bool extra = tb == a.n_tbins;
-  if (extra && (part != 0 || !(a.sv_out || a.range_out))) return;
+  if (extra && (part != 0 || !(a.sv_out || a.range_out || a.sv_noise_out))) return;
   const int nseg = extra ? 2 : 1;
   const int S = a.S, n_rbins = a.n_rbins;
   const bool use_lds = a.use_lds != 0;
@@ -130,7 +135,9 @@ __global__ __launch_bounds__(epa::kBlock) void block_reduce_kernel(ReduceArgs a)
   const T* rgp = reinterpret_cast<const T*>(a.range);
   T* sv_out = reinterpret_cast<T*>(a.sv_out);
   T* range_out = reinterpret_cast<T*>(a.range_out);
+  T* sv_noise_out = reinterpret_cast<T*>(a.sv_noise_out);
 
+  double xmax = -__builtin_inf();  // max valid echo_range seen by this lane (raw sources, optional)
   for (int seg = 0; seg < nseg; ++seg) {
   int pb, pe;
   if (extra) {
@@ -158,6 +165,9 @@ __global__ __launch_bounds__(epa::kBlock) void block_reduce_kernel(ReduceArgs a)
       uint32_t acc_cnt[VEC];
       double blo[VEC], bhi[VEC];  // edges of the range bin the column currently sits in
       epa::ColumnLog<T, VEC> col;
+      // transmission-loss log of the UNSHIFTED range, separable like the spreading term:
+      // log10(R) = log10(k) + log10(s - d_tl), d_tl = -r0/k (0 for EK); cached per column
+      epa::ColumnLog<T, VEC> col_tl;
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         acc_rb[j] = phys ? -1 : (s0 + j) / a.range_sample_num;
@@ -173,13 +183,24 @@ __global__ __launch_bounds__(epa::kBlock) void block_reduce_kernel(ReduceArgs a)
         const size_t row = (size_t)c * a.P + p;
         const size_t off = row * S + s0;
         T sv[VEC];
+        T vlin[VEC];  // SRC_SV_DENOISE: linear value of the corrected Sv (NaN where removed)
+        T logR[VEC];  // raw sources: log10(echo_range) from the cached column logs
         double x[VEC];
         bool xok[VEC];
-        if (SRC == SRC_RAW) {
+        constexpr bool kFromRaw = SRC == SRC_RAW || SRC == SRC_RAW_DENOISE;
+        constexpr bool kDenoise = SRC == SRC_SV_DENOISE || SRC == SRC_RAW_DENOISE;
+        if (kFromRaw) {
           epa::RawVec<VEC> in;
           in.load(a.raw + off);
           const epa::RowK<T> rk(a.coef[row]);
           col.update(rk.d, s0, nspread);
+          if (OP == OP_NOISE || kDenoise) {
+            const double k = rk.ra * rk.rb;
+            col_tl.update(-rk.r0 / k, s0, (T)1);
+            const T log10k = epa::fast_log10((T)k, mt.log_tab);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) logR[j] = col_tl.nL[j] + log10k;
+          }
           T rg[VEC];
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {
@@ -187,8 +208,9 @@ __global__ __launch_bounds__(epa::kBlock) void block_reduce_kernel(ReduceArgs a)
             sv[j] = epa::cal_power_sample<T>(in.v[j], s0 + j, rk, nspread, col.nL[j], guard, x[j]);
             xok[j] = !(mask_range && !(in.v[j] == in.v[j]));
             rg[j] = xok[j] ? (T)x[j] : epa::M<T>::nan();
+            if (a.range_max_out && xok[j]) xmax = fmax(xmax, (double)rg[j]);  // as stored (T)
           }
-          if (sv_out) epa::store_vec<T, VEC>(sv_out + off, sv);
+          if (sv_out && !kDenoise) epa::store_vec<T, VEC>(sv_out + off, sv);
           if (range_out) epa::store_vec<T, VEC>(range_out + off, rg);
         } else {
           epa::load_vec<T, VEC>(svp + off, sv);
@@ -215,17 +237,42 @@ __global__ __launch_bounds__(epa::kBlock) void block_reduce_kernel(ReduceArgs a)
             }
           }
         }
+        if (kDenoise) {
+          {
+            // clean/api.py:425-430 (noise of the ping block + transmission loss) and :485-487
+            const T nb = (T)a.noise[(size_t)c * a.n_pblocks + p / a.noise_ping_num];
+            const T na2 = (T)a.alpha2[row];
+            const T snr = (T)a.snr;
+            T sn[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              const T xr = xok[j] ? (T)x[j] : epa::M<T>::nan();  // echo_range is NaN where masked
+              const T lg = kFromRaw ? logR[j] : epa::fast_log10(xr >= (T)1 ? xr : (T)1, mt.log_tab);
+              const T tl = (T)20 * (xr >= (T)1 ? lg : (T)0) + na2 * xr;
+              sn[j] = nb + tl;
+              const T lin = epa::lin_from_db(sv[j], mt.exp2_tab) - epa::lin_from_db(sn[j], mt.exp2_tab);
+              T corr = lin > (T)0 ? (T)10 * epa::fast_log10(lin, mt.log_tab) : epa::M<T>::nan();
+              const bool keep = corr - sn[j] > snr;
+              sv[j] = keep ? corr : epa::M<T>::nan();
+              vlin[j] = keep ? lin : epa::M<T>::nan();
+            }
+            if (sv_noise_out) epa::store_vec<T, VEC>(sv_noise_out + off, sn);
+            if (sv_out) epa::store_vec<T, VEC>(sv_out + off, sv);
+          }
+        }
         T a2 = (T)0;
         if (OP == OP_NOISE) a2 = (T)a.alpha2[row];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           T v;
           if (OP == OP_MVBS) {
-            v = epa::lin_from_db(sv[j], mt.exp2_tab);  // _log2lin, compute.py:14-27
+            // _log2lin, compute.py:14-27 (the denoised source already holds the linear value)
+            v = kDenoise ? vlin[j] : epa::lin_from_db(sv[j], mt.exp2_tab);
           } else {
             // clean/api.py:397-401: where(R >= 1, R, 1) also maps NaN ranges to 1
             const T xr = (T)x[j];
-            const T tl = (T)20 * epa::fast_log10(xr >= (T)1 ? xr : (T)1, mt.log_tab) + a2 * xr;
+            const T lg = kFromRaw ? logR[j] : epa::fast_log10(xr >= (T)1 ? xr : (T)1, mt.log_tab);
+            const T tl = (T)20 * (xr >= (T)1 ? lg : (T)0) + a2 * xr;
             v = epa::lin_from_db(sv[j] - tl, mt.exp2_tab);
           }
           if (phys) {
@@ -271,6 +318,15 @@ __global__ __launch_bounds__(epa::kBlock) void block_reduce_kernel(ReduceArgs a)
       }
     }
   }
+  }
+  if (a.range_max_out) {  // nanmax(echo_range) by-product: order-preserving u64 key, decoded by the launcher
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) xmax = fmax(xmax, __shfl_down(xmax, o, 64));
+    if ((threadIdx.x & 63) == 0 && xmax > -__builtin_inf()) {
+      const unsigned long long b = (unsigned long long)__double_as_longlong(xmax);
+      atomicMax(reinterpret_cast<unsigned long long*>(a.range_max_out),
+                (b >> 63) ? ~b : (b | 0x8000000000000000ull));
+    }
   }
   if (extra) return;
 
@@ -445,7 +501,7 @@ Plan make_plan(int C, int P, int S, int n_tbins, int n_rbins, bool aligned16) {
 template <typename T, int SRC, int OP>
 int launch_reduce(ReduceArgs& a, const Plan& pl, hipStream_t st) {
   // fused source: one extra ping-bin slot for the pings that fall in no time bin (Sv only)
-  const long long tslots = (long long)a.n_tbins + ((SRC == SRC_RAW && a.bin_start) ? 1 : 0);
+  const long long tslots = (long long)a.n_tbins + ((SRC != SRC_SV && a.bin_start) ? 1 : 0);
   const dim3 grid((unsigned)(tslots * a.nparts), (unsigned)a.C);
   const dim3 block(epa::kBlock);
   a.use_lds = pl.use_lds;
@@ -497,11 +553,6 @@ int run_mvbs(ReduceArgs& a, hipStream_t st) {
     epa::set_error("epa_sv_mvbs_fused_i16: int16 ingest is served by the default configuration only "
                    "(guard + masked range, skipna, left-closed bins, sorted pings, S %% 4 == 0, no "
                    "echo_range output, range grid within LDS)");
-    return EPA_EUNSUPPORTED;
-  }
-  if (a.range_max_out) {
-    epa::set_error("epa_sv_mvbs_fused: range_max_out is only produced by the default configuration "
-                   "(guard + masked range, skipna, left-closed bins, sorted pings, no echo_range output)");
     return EPA_EUNSUPPORTED;
   }
   if (two_stage) {
@@ -731,5 +782,110 @@ extern "C" int epa_noise_estimate(const void* sv, const void* range, const doubl
     return run_noise<float>(sv, range, coef, alpha2, C, P, S, ping_num, range_sample_num, noise_max,
                             noise_out, (hipStream_t)stream);
   epa::set_error("epa_noise_estimate: bad dtype %d", dtype);
+  return EPA_EINVAL;
+}
+
+// ---- fused chain: compute_Sv + estimate_background_noise, then remove_background_noise + compute_MVBS ----
+namespace {
+template <typename T>
+int run_sv_noise(const float* raw, const double* coef, const double* alpha2, int C, int P, int S,
+                 double nspread, unsigned cal_flags, int ping_num, int rsn, double noise_max, void* sv_out,
+                 void* range_out, double* noise_out, double* range_max_out, hipStream_t st) {
+  const int Pb = (P + ping_num - 1) / ping_num, Sb = (S + rsn - 1) / rsn;
+  ReduceArgs a{};
+  a.raw = raw; a.coef = reinterpret_cast<const epa::CoefRow*>(coef); a.alpha2 = alpha2;
+  a.C = C; a.P = P; a.S = S; a.nspread = nspread; a.cal_flags = cal_flags;
+  a.bin_start = nullptr; a.n_tbins = Pb; a.ping_num = ping_num;
+  a.bin_mode = BIN_INDEX; a.range_bin = 1.0; a.inv_range_bin = 1.0; a.n_rbins = Sb;
+  a.range_sample_num = rsn; a.bin_flags = EPA_BIN_SKIPNA;
+  a.fill_value = __builtin_nan(""); a.noise_max = noise_max;
+  a.sv_out = sv_out; a.range_out = range_out; a.out = noise_out; a.range_max_out = range_max_out;
+  Plan pl = make_plan<T>(C, P, S, Pb, Sb, al16(raw) && al16(sv_out) && al16(range_out));
+  pl.nparts = 1;
+  a.nparts = 1;
+  EPA_CHECK_ARG(pl.use_lds, "epa_sv_noise_fused: %d range blocks exceed the LDS budget", Sb);
+  return launch_reduce<T, SRC_RAW, OP_NOISE>(a, pl, st);
+}
+}  // namespace
+
+extern "C" int epa_sv_noise_fused(const float* raw, const double* coef, const double* alpha2, int C, int P,
+                                  int S, int cal_type, unsigned cal_flags, int ping_num,
+                                  int range_sample_num, double noise_max, void* sv_out, void* range_out,
+                                  double* noise_out, double* range_max_out, int dtype,
+                                  epa_stream_t stream) {
+  EPA_CHECK_ARG(raw && coef && alpha2 && noise_out, "epa_sv_noise_fused: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && ping_num > 0 && range_sample_num > 0,
+                "epa_sv_noise_fused: sizes must be positive");
+  EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_sv_noise_fused: bad cal_type");
+  const double nspread = cal_type == EPA_CAL_SV ? 20.0 : 40.0;
+  EPA_CHECK_ARG(dtype == EPA_F64 || dtype == EPA_F32, "epa_sv_noise_fused: bad dtype %d", dtype);
+  if (range_max_out) EPA_CHECK_HIP(hipMemsetAsync(range_max_out, 0, sizeof(double), (hipStream_t)stream));
+  const int rc = dtype == EPA_F64
+      ? run_sv_noise<double>(raw, coef, alpha2, C, P, S, nspread, cal_flags, ping_num, range_sample_num,
+                             noise_max, sv_out, range_out, noise_out, range_max_out, (hipStream_t)stream)
+      : run_sv_noise<float>(raw, coef, alpha2, C, P, S, nspread, cal_flags, ping_num, range_sample_num,
+                            noise_max, sv_out, range_out, noise_out, range_max_out, (hipStream_t)stream);
+  if (rc == EPA_OK && range_max_out) {
+    hipLaunchKernelGGL(decode_range_max_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, range_max_out);
+    return epa::check_launch("decode_range_max_kernel");
+  }
+  return rc;
+}
+
+extern "C" int epa_denoise_mvbs(const void* sv, const void* range, const double* coef, const double* alpha2,
+                                const double* noise, int C, int P, int S, int ping_num,
+                                double snr_threshold, const int32_t* bin_start, const int32_t* ping_perm,
+                                int n_tbins, double range_bin, int n_rbins, unsigned bin_flags,
+                                double fill_value, void* sv_noise_out, void* sv_corrected_out,
+                                void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
+                                epa_stream_t stream) {
+  EPA_CHECK_ARG(sv && alpha2 && noise && mvbs_out, "epa_denoise_mvbs: NULL array argument");
+  EPA_CHECK_ARG(range || coef, "epa_denoise_mvbs: either range or coef must be given");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && ping_num > 0, "epa_denoise_mvbs: sizes must be positive");
+  if (int rc = check_bins("epa_denoise_mvbs", bin_start, n_tbins, range_bin, n_rbins)) return rc;
+  ReduceArgs a{};
+  a.sv = sv; a.range = range; a.coef = reinterpret_cast<const epa::CoefRow*>(coef);
+  a.alpha2 = alpha2; a.noise = noise; a.noise_ping_num = ping_num; a.n_pblocks = (P + ping_num - 1) / ping_num;
+  a.snr = snr_threshold;
+  a.C = C; a.P = P; a.S = S;
+  a.bin_start = bin_start; a.ping_perm = ping_perm; a.n_tbins = n_tbins;
+  a.bin_mode = BIN_PHYS; a.range_bin = range_bin; a.inv_range_bin = 1.0 / range_bin;
+  a.n_rbins = n_rbins; a.range_sample_num = 1; a.bin_flags = bin_flags;
+  a.fill_value = fill_value; a.noise_max = __builtin_nan("");
+  a.sv_out = sv_corrected_out; a.sv_noise_out = sv_noise_out;
+  a.out = mvbs_out; a.sum_out = sum_out; a.cnt_out = cnt_out;
+  if (dtype == EPA_F64) return run_mvbs<double, SRC_SV_DENOISE>(a, (hipStream_t)stream);
+  if (dtype == EPA_F32) return run_mvbs<float, SRC_SV_DENOISE>(a, (hipStream_t)stream);
+  epa::set_error("epa_denoise_mvbs: bad dtype %d", dtype);
+  return EPA_EINVAL;
+}
+
+extern "C" int epa_sv_denoise_mvbs(const float* raw, const double* coef, const double* alpha2,
+                                   const double* noise, int C, int P, int S, int cal_type, unsigned cal_flags,
+                                   int ping_num, double snr_threshold, const int32_t* bin_start,
+                                   const int32_t* ping_perm, int n_tbins, double range_bin, int n_rbins,
+                                   unsigned bin_flags, double fill_value, void* sv_noise_out,
+                                   void* sv_corrected_out, void* range_out, void* mvbs_out, void* sum_out,
+                                   uint32_t* cnt_out, int dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(raw && coef && alpha2 && noise && mvbs_out, "epa_sv_denoise_mvbs: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && ping_num > 0, "epa_sv_denoise_mvbs: sizes must be positive");
+  EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_sv_denoise_mvbs: bad cal_type");
+  if (int rc = check_bins("epa_sv_denoise_mvbs", bin_start, n_tbins, range_bin, n_rbins)) return rc;
+  ReduceArgs a{};
+  a.raw = raw; a.coef = reinterpret_cast<const epa::CoefRow*>(coef);
+  a.alpha2 = alpha2; a.noise = noise; a.noise_ping_num = ping_num; a.n_pblocks = (P + ping_num - 1) / ping_num;
+  a.snr = snr_threshold;
+  a.C = C; a.P = P; a.S = S;
+  a.nspread = cal_type == EPA_CAL_SV ? 20.0 : 40.0;
+  a.cal_flags = cal_flags;
+  a.bin_start = bin_start; a.ping_perm = ping_perm; a.n_tbins = n_tbins;
+  a.bin_mode = BIN_PHYS; a.range_bin = range_bin; a.inv_range_bin = 1.0 / range_bin;
+  a.n_rbins = n_rbins; a.range_sample_num = 1; a.bin_flags = bin_flags;
+  a.fill_value = fill_value; a.noise_max = __builtin_nan("");
+  a.sv_out = sv_corrected_out; a.sv_noise_out = sv_noise_out; a.range_out = range_out;
+  a.out = mvbs_out; a.sum_out = sum_out; a.cnt_out = cnt_out;
+  if (dtype == EPA_F64) return run_mvbs<double, SRC_RAW_DENOISE>(a, (hipStream_t)stream);
+  if (dtype == EPA_F32) return run_mvbs<float, SRC_RAW_DENOISE>(a, (hipStream_t)stream);
+  epa::set_error("epa_sv_denoise_mvbs: bad dtype %d", dtype);
   return EPA_EINVAL;
 }

@@ -439,3 +439,66 @@ def nasc(sv, depth, bin_start, n_dbins, range_bin, n_rbins, skipna=True, closed=
     call("epa_nasc", _p(sv), _p(depth), C, P, S, _p(bin_start), int(n_dbins), float(range_bin), int(n_rbins),
          _bin_flags(skipna, closed), _p(ws), _p(out), _p(svm), _p(hm), _DT[sv.dtype], _stream())
     return (out, svm, hm) if want_parts else out
+
+
+# ---- the whole chain in two passes ---------------------------------------------------------------------
+
+def sv_noise_fused(raw, coef, alpha2, ping_num, range_sample_num, *, cal_type="Sv",
+                   flags=_lib.FLAG_GUARD_POS | _lib.FLAG_MASK_RANGE, dtype=torch.float64,
+                   noise_max=float("nan"), want_sv=True, want_range=False, want_range_max=False):
+    """K1+K6 -> (Sv|None, echo_range|None, noise (C, ceil(P/ping_num)) f64[, nanmax(echo_range)])."""
+    C, P, S = raw.shape
+    if raw.dtype != torch.float32:
+        raise ValueError("raw power samples must be float32 (convert/parse_base.py:302)")
+    dev = raw.device
+    sv = torch.empty((C, P, S), dtype=dtype, device=dev) if want_sv else None
+    rng = torch.empty((C, P, S), dtype=dtype, device=dev) if want_range else None
+    noise = torch.empty((C, -(-P // ping_num)), dtype=torch.float64, device=dev)
+    rmax = torch.empty(1, dtype=torch.float64, device=dev) if want_range_max else None
+    call("epa_sv_noise_fused", _p(raw), _p(coef), _p(alpha2), C, P, S,
+         _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, flags, int(ping_num), int(range_sample_num),
+         float(noise_max), _p(sv), _p(rng), _p(noise), _p(rmax), _DT[dtype], _stream())
+    return (sv, rng, noise, float(rmax.item())) if want_range_max else (sv, rng, noise)
+
+
+def denoise_mvbs(sv, alpha2, noise, ping_num, snr_threshold, bin_start, n_tbins, range_bin, n_rbins, *,
+                 range=None, coef=None, skipna=True, closed="left", fill_value=float("nan"),
+                 ping_perm=None, want_noise=False, want_corrected=True, want_partials=False):
+    """K7+K5 -> dict(MVBS of the corrected Sv, Sv_noise, Sv_corrected, sum, cnt)."""
+    C, P, S = sv.shape
+    dev, dtype = sv.device, sv.dtype
+    if range is not None and range.dtype != dtype:
+        range = range.to(dtype)
+    sn = torch.empty_like(sv) if want_noise else None
+    sc = torch.empty_like(sv) if want_corrected else None
+    out = torch.empty((C, n_tbins, n_rbins), dtype=dtype, device=dev)
+    ssum = cnt = None
+    if want_partials or reduce_needs_workspace(C, n_tbins, n_rbins, dtype):
+        ssum = torch.empty((C, n_tbins, n_rbins), dtype=dtype, device=dev)
+        cnt = torch.empty((C, n_tbins, n_rbins), dtype=torch.int32, device=dev)
+    call("epa_denoise_mvbs", _p(sv), _p(range), _p(coef), _p(alpha2), _p(noise), C, P, S, int(ping_num),
+         float(snr_threshold), _p(bin_start), _p(ping_perm), int(n_tbins), float(range_bin), int(n_rbins),
+         _bin_flags(skipna, closed), float(fill_value), _p(sn), _p(sc), _p(out), _p(ssum), _p(cnt),
+         _DT[dtype], _stream())
+    return dict(MVBS=out, Sv_noise=sn, Sv_corrected=sc, sum=ssum, cnt=cnt)
+
+
+def sv_denoise_mvbs(raw, coef, alpha2, noise, ping_num, snr_threshold, bin_start, n_tbins, range_bin, n_rbins,
+                    *, cal_type="Sv", flags=_lib.FLAG_GUARD_POS | _lib.FLAG_MASK_RANGE, dtype=torch.float64,
+                    skipna=True, closed="left", fill_value=float("nan"), ping_perm=None, want_noise=False,
+                    want_corrected=True, want_range=False, want_partials=False):
+    """K1+K7+K5 from the raw power -> dict(MVBS of the corrected Sv, Sv_noise, Sv_corrected, echo_range, sum, cnt)."""
+    C, P, S = raw.shape
+    dev = raw.device
+    mk = lambda want: torch.empty((C, P, S), dtype=dtype, device=dev) if want else None  # noqa: E731
+    sn, sc, rng = mk(want_noise), mk(want_corrected), mk(want_range)
+    out = torch.empty((C, n_tbins, n_rbins), dtype=dtype, device=dev)
+    ssum = cnt = None
+    if want_partials or reduce_needs_workspace(C, n_tbins, n_rbins, dtype):
+        ssum = torch.empty((C, n_tbins, n_rbins), dtype=dtype, device=dev)
+        cnt = torch.empty((C, n_tbins, n_rbins), dtype=torch.int32, device=dev)
+    call("epa_sv_denoise_mvbs", _p(raw), _p(coef), _p(alpha2), _p(noise), C, P, S,
+         _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, flags, int(ping_num), float(snr_threshold),
+         _p(bin_start), _p(ping_perm), int(n_tbins), float(range_bin), int(n_rbins), _bin_flags(skipna, closed),
+         float(fill_value), _p(sn), _p(sc), _p(rng), _p(out), _p(ssum), _p(cnt), _DT[dtype], _stream())
+    return dict(MVBS=out, Sv_noise=sn, Sv_corrected=sc, echo_range=rng, sum=ssum, cnt=cnt)

@@ -134,7 +134,7 @@ int epa_time_bin_offsets(const int64_t* ping_time, int P, int64_t t0, int64_t dt
  *                 cross-shard merges; may be NULL
  *   range_max_out : optional f64 [1]: nanmax(echo_range) as a by-product (what api.py:108-110 needs
  *                 to size the range grid: call with a conservative n_rbins, then trim); NULL if not
- *                 wanted.  Only the default configuration produces it (else EPA_EUNSUPPORTED).
+ *                 wanted.
  */
 int epa_sv_mvbs_fused(const float* raw, const double* coef, int C, int P, int S, int cal_type,
                       unsigned cal_flags, const int32_t* bin_start, const int32_t* ping_perm,
@@ -346,6 +346,43 @@ int epa_pool_sv_value(const void* sv, const void* range, const int32_t* nvalid, 
 int epa_nasc(const void* sv, const void* depth, int C, int P, int S, const int32_t* bin_start, int n_dbins,
              double range_bin, int n_rbins, unsigned bin_flags, void* workspace, void* nasc_out,
              void* sv_mean_out, void* h_mean_out, int dtype, epa_stream_t stream);
+
+/* ==== the whole north-star chain in two passes ==========================================================
+ * compute_Sv -> remove_background_noise -> compute_MVBS as four separate calls moves 84 B/sample in
+ * fp64 (K1 20, K6 16, K7 32, K5 16); these two entry points do the same arithmetic in 12 + 16..24.
+ *
+ * Pass 1 = K1 + K6: Sv (and optionally echo_range) written once, the noise estimate of
+ * clean/api.py:397-422 accumulated from the Sv values still in registers (transmission loss from the
+ * coefficient rows).  Arguments as epa_sv_power and epa_noise_estimate.  sv_out may be NULL;
+ * range_max_out (f64 [1], optional) = nanmax(echo_range), which sizes the range grid of pass 2. */
+int epa_sv_noise_fused(const float* raw, const double* coef, const double* alpha2, int C, int P, int S,
+                       int cal_type, unsigned cal_flags, int ping_num, int range_sample_num,
+                       double noise_max, void* sv_out, void* range_out, double* noise_out,
+                       double* range_max_out, int dtype, epa_stream_t stream);
+
+/* Pass 2 = K7 + K5: reads Sv once, applies clean/api.py:425-430,485-487 with the per-ping-block noise
+ * of pass 1 and bins the CORRECTED Sv (commongrid/utils.py:592-627) in the same sweep.  Arguments as
+ * epa_noise_apply (sv, range | coef, alpha2, noise, ping_num, snr_threshold) and epa_mvbs (bins,
+ * outputs); sv_noise_out / sv_corrected_out ([C*P*S] of dtype) may each be NULL. */
+/* (With `coef` instead of `range`, Sv_noise is finite at NaN-padded samples, where the reference's
+ * echo_range -- and therefore its Sv_noise -- is NaN; Sv_corrected and the MVBS are unaffected.) */
+int epa_denoise_mvbs(const void* sv, const void* range, const double* coef, const double* alpha2,
+                     const double* noise, int C, int P, int S, int ping_num, double snr_threshold,
+                     const int32_t* bin_start, const int32_t* ping_perm, int n_tbins, double range_bin,
+                     int n_rbins, unsigned bin_flags, double fill_value, void* sv_noise_out,
+                     void* sv_corrected_out, void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
+                     epa_stream_t stream);
+
+/* Pass 2 fed with the RAW power again instead of Sv (4 B/sample read instead of 8, and the NaN padding
+ * that masks echo_range is seen directly): Sv is recomputed in registers as in epa_sv_power, then as
+ * epa_denoise_mvbs.  With pass 1 the chain costs 4 + 8 (Sv) and 4 + 8 (Sv_corrected) [+ 8 Sv_noise]
+ * = 24..32 B/sample.  range_out optional as in epa_sv_power. */
+int epa_sv_denoise_mvbs(const float* raw, const double* coef, const double* alpha2, const double* noise,
+                        int C, int P, int S, int cal_type, unsigned cal_flags, int ping_num,
+                        double snr_threshold, const int32_t* bin_start, const int32_t* ping_perm,
+                        int n_tbins, double range_bin, int n_rbins, unsigned bin_flags, double fill_value,
+                        void* sv_noise_out, void* sv_corrected_out, void* range_out, void* mvbs_out,
+                        void* sum_out, uint32_t* cnt_out, int dtype, epa_stream_t stream);
 
 #ifdef __cplusplus
 }

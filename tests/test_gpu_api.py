@@ -245,6 +245,62 @@ def test_fused_compute_Sv_MVBS_equals_two_calls(ep, edge_case):
     assert "echo_range" in ds3
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("closed", ["left", "right"])
+def test_two_pass_chain_equals_three_calls(ep, dtype, closed):
+    """compute_Sv_clean_MVBS (two sweeps of the raw power) == compute_Sv -> remove_background_noise ->
+    compute_MVBS of Sv_corrected (four array sweeps), and both == the oracle chain."""
+    d = ep.synth.ek60_numpy(2, 205, 1000)
+    ed = ep.echodata.from_ek60_arrays(d)
+    kw = dict(background_noise_max="-125.0dB", SNR_threshold="3.0dB")
+    ds1 = ep.calibrate.compute_Sv(ed, dtype=dtype)
+    ep.clean.remove_background_noise(ds1, 20, 50, **kw)
+    corr = ds1.copy()
+    corr["Sv"] = ds1["Sv_corrected"]
+    mv1 = ep.commongrid.compute_MVBS(corr, range_bin="1m", ping_time_bin="20s", closed=closed)
+    ds2, mv2 = ep.compute_Sv_clean_MVBS(ed, 20, 50, range_bin="1m", ping_time_bin="20s", closed=closed, dtype=dtype,
+                                        materialize_echo_range=True, **kw)
+    np.testing.assert_array_equal(ds2["Sv"].values, ds1["Sv"].values)
+    np.testing.assert_array_equal(ds2["echo_range"].values, ds1["echo_range"].values)
+    rtol = 1e-9 if dtype == "float64" else 1e-3
+    close(ds2["Sv_noise"].values, ds1["Sv_noise"].values, 1e-11 if dtype == "float64" else 2e-4, "Sv_noise")
+    close(ds2["Sv_corrected"].values, ds1["Sv_corrected"].values, rtol, "Sv_corrected")
+    np.testing.assert_array_equal(mv2["echo_range"].values, mv1["echo_range"].values)
+    np.testing.assert_array_equal(mv2["ping_time"].values, mv1["ping_time"].values)
+    if dtype == "float64":  # (fp32: the three calls bin the float32-stored echo_range, see test_chain_sv_noise_mvbs)
+        close(mv2["Sv"].values, mv1["Sv"].values, 1e-9, "MVBS of Sv_corrected")
+        for k in ("noise_ping_num", "noise_range_sample_num", "SNR_threshold", "noise_max", "units"):
+            assert ds2["Sv_corrected"].attrs[k] == ds1["Sv_corrected"].attrs[k]
+        assert ds2["Sv_corrected"].attrs["actual_range"] == ds1["Sv_corrected"].attrs["actual_range"]
+        assert mv2["Sv"].attrs["cell_methods"] == mv1["Sv"].attrs["cell_methods"]
+        if closed == "left":
+            sv, er = oc.ek60(d, "Sv")
+            exp_n, exp_c = oclean.remove_background_noise(sv, er, d["absorption_indicative"], 20, 50, "-125.0dB")
+            exp_mv, _, _ = ogrid.compute_MVBS(exp_c, er, d["ping_time"], "1m", "20s")
+            close(ds2["Sv_noise"].values, exp_n, 1e-9, "oracle Sv_noise")
+            close(ds2["Sv_corrected"].values, exp_c, 1e-7, "oracle Sv_corrected")
+            close(mv2["Sv"].values, exp_mv, 1e-9, "oracle MVBS")
+    # without the materialised echo_range / Sv_noise: same numbers, fewer bytes
+    ds3, mv3 = ep.compute_Sv_clean_MVBS(ed, 20, 50, range_bin="1m", ping_time_bin="20s", closed=closed, dtype=dtype,
+                                        keep_Sv_noise=False, **kw)
+    assert "echo_range" not in ds3 and "Sv_noise" not in ds3
+    np.testing.assert_array_equal(ds3["Sv_corrected"].values, ds2["Sv_corrected"].values)
+    close(mv3["Sv"].values, mv2["Sv"].values, 1e-12 if dtype == "float64" else 1e-5, "rerun")  # LDS atomics order
+    with pytest.raises(TypeError, match="Decibal input must be a string"):
+        ep.compute_Sv_clean_MVBS(ed, 20, 50, SNR_threshold=3.0)
+
+
+def test_two_pass_chain_other_sonars_take_the_separate_calls(ep):
+    d = ep.synth.azfp_numpy(2, 60, 400)
+    ed = ep.echodata.from_azfp_arrays(d)
+    env = {"temperature": 8.0, "salinity": 30.0, "pressure": 60.0}
+    ds, mv = ep.compute_Sv_clean_MVBS(ed, 10, 40, range_bin="2m", ping_time_bin="10s", env_params=env)
+    ref = ep.calibrate.compute_Sv(ed, env_params=env)
+    ep.clean.remove_background_noise(ref, 10, 40)
+    np.testing.assert_array_equal(ds["Sv_corrected"].values, ref["Sv_corrected"].values)
+    assert mv["Sv"].dims == ("channel", "ping_time", "echo_range")
+
+
 # ------------------------------------------------------------------------------------ commongrid
 @pytest.mark.parametrize("kind", ["regular", "irregular"])
 def test_compute_MVBS_reference_values(ep, kind, caplog):
