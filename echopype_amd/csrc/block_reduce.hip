@@ -462,6 +462,16 @@ int epa_fused_fast_path(const void* raw, int raw_is_i16, const int32_t* n_valid,
                         size_t lds_bytes, unsigned cnt_off, unsigned long long* rmax_key,
                         hipStream_t st);
 
+// chain_fast.hip
+int epa_chain_fast_pass1(const float* raw, const double* coef, const double* alpha2, int C, int P, int S,
+                         double nspread, int ping_num, int rsn, double noise_max, void* sv_out,
+                         double* noise_out, unsigned long long* rmax_key, int dtype, hipStream_t st);
+int epa_chain_fast_pass2(const float* raw, const double* coef, const double* alpha2, const double* noise, int C,
+                         int P, int S, double nspread, int ping_num, double snr, const int32_t* bin_start,
+                         int n_tbins, double range_bin, int n_rbins, double fill_value, void* noise_out,
+                         void* corr_out, void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
+                         size_t lds_acc_bytes, unsigned cnt_off, hipStream_t st);
+
 namespace {
 
 struct Plan {
@@ -549,6 +559,13 @@ int run_mvbs(ReduceArgs& a, hipStream_t st) {
                                a.n_rbins, a.bin_flags, a.fill_value, a.sv_out, a.out, a.sum_out,
                                a.cnt_out, sizeof(T) == 8 ? EPA_F64 : EPA_F32, pl.tab_off,
                                pl.cnt_off, reinterpret_cast<unsigned long long*>(a.range_max_out), st);
+  if (SRC == SRC_RAW_DENOISE && !two_stage && pl.vec == 4 && !a.ping_perm && !a.range_out &&
+      a.cal_flags == (EPA_FLAG_GUARD_POS | EPA_FLAG_MASK_RANGE) && a.bin_flags == EPA_BIN_SKIPNA &&
+      !getenv("EPA_NO_FAST_PATH"))
+    return epa_chain_fast_pass2(a.raw, reinterpret_cast<const double*>(a.coef), a.alpha2, a.noise, a.C, a.P, a.S,
+                                a.nspread, a.noise_ping_num, a.snr, a.bin_start, a.n_tbins, a.range_bin,
+                                a.n_rbins, a.fill_value, a.sv_noise_out, a.sv_out, a.out, a.sum_out, a.cnt_out,
+                                sizeof(T) == 8 ? EPA_F64 : EPA_F32, pl.tab_off, pl.cnt_off, st);
   if (a.raw_i16) {
     epa::set_error("epa_sv_mvbs_fused_i16: int16 ingest is served by the default configuration only "
                    "(guard + masked range, skipna, left-closed bins, sorted pings, S %% 4 == 0, no "
@@ -804,6 +821,11 @@ int run_sv_noise(const float* raw, const double* coef, const double* alpha2, int
   pl.nparts = 1;
   a.nparts = 1;
   EPA_CHECK_ARG(pl.use_lds, "epa_sv_noise_fused: %d range blocks exceed the LDS budget", Sb);
+  if (pl.vec == 4 && !range_out && cal_flags == (EPA_FLAG_GUARD_POS | EPA_FLAG_MASK_RANGE) &&
+      !getenv("EPA_NO_FAST_PATH"))
+    return epa_chain_fast_pass1(raw, coef, alpha2, C, P, S, nspread, ping_num, rsn, noise_max, sv_out, noise_out,
+                                reinterpret_cast<unsigned long long*>(range_max_out),
+                                sizeof(T) == 8 ? EPA_F64 : EPA_F32, st);
   return launch_reduce<T, SRC_RAW, OP_NOISE>(a, pl, st);
 }
 }  // namespace

@@ -1,0 +1,474 @@
+// Fast paths of the two-pass chain compute_Sv -> remove_background_noise -> compute_MVBS(Sv_corrected)
+// for the hot configuration (EK power samples, R' <= 0 guard + masked range, sorted pings, skipna,
+// left-closed bins, range grid in LDS): the structure of the headline kernel (fused_sv_mvbs.hip) --
+// one workgroup per (channel, ping group), every lane on two sample PAIRS so that each load / store of a
+// wavefront is one contiguous run, coefficient rows by scalar loads, logs cached per range column --
+// applied to the two sources that the generic kernel of block_reduce.hip otherwise serves:
+//
+//   pass 1  sv_noise_fast_kernel      raw -> Sv (written once) + the noise estimate of
+//                                     clean/api.py:397-422 per (channel, ping block)
+//   pass 2  sv_denoise_mvbs_fast_kernel  raw -> Sv_noise / Sv_corrected (clean/api.py:425-430,485-487)
+//                                     + MVBS of Sv_corrected (commongrid/utils.py:592-627) in the same sweep
+//
+// Per sample, fp64: pass 1 one exp10; pass 2 two exp10 + one log10 (table-driven, fast_math.h).  The
+// transmission loss 20 log10(R) is separable like the spreading term: log10(R) = log10(k) + log10(s - d),
+// d = -r0/k, cached per column.  Same arithmetic as the generic kernel (tests hold the two to <= 1e-9).
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "fast_math.h"
+#include "sample_math.h"
+
+namespace epa_chain {
+
+constexpr int VEC = 4;
+constexpr int kChunk = epa::kBlock * VEC;
+
+struct Args {
+  int P, S;
+  double nspread;
+  // pass 1
+  int ping_num, rsn, n_pblocks, n_rblocks;
+  double noise_max;
+  // pass 2
+  int n_tbins, n_rbins, noise_ping_num;
+  double range_bin, inv_range_bin, fill_value, snr;
+  unsigned cnt_off, tab_off;
+  unsigned long long* rmax_key;
+};
+
+__device__ __forceinline__ unsigned long long ordered_key(double v) {
+  const unsigned long long b = __double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+template <typename T>
+__device__ __noinline__ T log10_slow(T x) {
+  return epa::M<T>::log10(x);
+}
+
+template <typename T>
+__device__ __forceinline__ void lds_add(T* p, T v) {
+  unsafeAtomicAdd(p, v);
+}
+
+// what both passes keep per range column across the pings of a group
+template <typename T>
+struct ColBase {
+  double sra;  // fl(s * ra)
+  T nL;        // n * log10(s - d)        spreading (TVG-shifted range)
+  T lgs;       // log10(s - d_tl)         transmission loss (unshifted range)
+};
+
+// echo_range, R', Sv of one sample -- as process_sample of fused_sv_mvbs.hip
+template <typename T>
+__device__ __forceinline__ T calibrate(const ColBase<T>& c, float raw, const epa::CoefRow& r, T g, T a2, T A0,
+                                       T nspread, double& x) {
+  const T NaN = epa::M<T>::nan();
+  x = c.sra * r.rb + r.r0;
+  const double rtd = x - r.shift;
+  const T rt = (T)rtd;
+  const bool pos = rtd > 0.0;
+  T spread = c.nL;
+  if (pos & !(spread > -(T)__builtin_inf()))  // rounding residue of R - shift (rare)
+    spread = nspread * (log10_slow<T>(rt) - log10_slow<T>((T)(r.ra * r.rb)));
+  spread = pos ? spread : NaN;
+  return fma(g, (T)raw, spread) + fma(a2, rt, A0);
+}
+
+// clean/api.py:397-398: 20 log10(R if R >= 1 else 1) + 2 alpha R, R = echo_range (NaN where masked)
+template <typename T>
+__device__ __forceinline__ T transmission_loss(const ColBase<T>& c, T xr, T log10k, T na2) {
+  return (T)20 * (xr >= (T)1 ? c.lgs + log10k : (T)0) + na2 * xr;
+}
+
+// refresh of the cached column logs when the row constants they depend on change (uniform branch; once
+// per column for a file with constant pulse length / sample interval / sound speed)
+template <typename T>
+struct RowCache {
+  double d, ra, rb, dtl;
+  T log10k;
+  __device__ __forceinline__ RowCache() : d(__builtin_nan("")), ra(d), rb(d), dtl(d), log10k((T)0) {}
+  template <typename C>
+  __device__ __forceinline__ void update(const epa::CoefRow& r, C (&col)[VEC], int sA, int sB, T nspread,
+                                         const double2* log_tab) {
+    if (!((r.d == d) & (r.ra == ra))) {
+      d = r.d;
+      for (int j = 0; j < VEC; ++j) {
+        const double sj = (double)((j < 2 ? sA : sB) + (j & 1));
+        col[j].nL = nspread * log10_slow<T>((T)(sj - r.d));
+        col[j].sra = sj * r.ra;
+      }
+    }
+    const double k = r.ra * r.rb;
+    if (!((r.ra == ra) & (r.rb == rb))) {  // sound speed may drift from ping to ping: table-driven log
+      log10k = epa::fast_log10((T)k, log_tab);
+      rb = r.rb;
+    }
+    ra = r.ra;
+    const double dnew = r.r0 == 0.0 ? 0.0 : -r.r0 / k;  // EK rows: echo_range starts at 0
+    if (!(dnew == dtl)) {
+      dtl = dnew;
+      for (int j = 0; j < VEC; ++j) {
+        const double sj = (double)((j < 2 ? sA : sB) + (j & 1));
+        col[j].lgs = log10_slow<T>((T)(sj - dnew));
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// pass 1
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct NoiseCol : ColBase<T> {
+  T acc_sum;
+  uint32_t acc_cnt;
+};
+
+template <typename T, bool WRITE_SV, bool RMAX>
+__global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
+    const float* __restrict__ raw, const epa::CoefRow* __restrict__ coef,
+    const double* __restrict__ alpha2, T* __restrict__ sv_out, double* __restrict__ noise_out, Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* lsum = reinterpret_cast<T*>(smem);
+  uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + a.cnt_off);
+  const epa::MathTabs mt = epa::build_math_tabs(smem + a.tab_off);
+  __shared__ T red[8];
+
+  const int c = blockIdx.y, pbk = blockIdx.x;
+  const int S = a.S, Sb = a.n_rblocks;
+  for (int i = threadIdx.x; i < Sb; i += epa::kBlock) {
+    lsum[i] = (T)0;
+    lcnt[i] = 0u;
+  }
+  __syncthreads();
+  const T nspread = (T)a.nspread;
+  const epa::CoefRow* __restrict__ rowp0 = coef + (size_t)c * a.P;
+  const double* __restrict__ a2p = alpha2 + (size_t)c * a.P;
+  const float* __restrict__ raw_c = raw + (size_t)c * a.P * S;
+  T* __restrict__ sv_c = WRITE_SV ? sv_out + (size_t)c * a.P * S : nullptr;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int pb = pbk * a.ping_num, pe = min(a.P, pb + a.ping_num);
+  double xmax = -__builtin_inf();
+
+  for (int chunk0 = 0; chunk0 < S; chunk0 += kChunk) {
+    const int sA = chunk0 + wave * 256 + 2 * lane, sB = sA + 128;
+    if (sA >= S) continue;
+    const bool hasB = sB < S;
+    NoiseCol<T> col[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      col[j].sra = 0.0; col[j].nL = epa::M<T>::nan(); col[j].lgs = (T)0;
+      col[j].acc_sum = (T)0; col[j].acc_cnt = 0u;
+    }
+    RowCache<T> rc;
+    float2 nA = make_float2(0.f, 0.f), nB = nA;
+    epa::CoefRow nxtR = rowp0[pb];
+    nA = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sA);
+    if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sB);
+    for (int p = pb; p < pe; ++p) {
+      const epa::CoefRow r = nxtR;
+      const size_t row_off = (size_t)p * S;
+      const float2 inA = nA, inB = nB;
+      if (p + 1 < pe) {  // software prefetch of the next ping
+        nxtR = rowp0[p + 1];
+        nA = *reinterpret_cast<const float2*>(raw_c + row_off + S + sA);
+        if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + row_off + S + sB);
+      }
+      rc.update(r, col, sA, sB, nspread, mt.log_tab);
+      const T g = (T)r.g, a2 = (T)r.alpha2, A0 = (T)r.A0, na2 = (T)a2p[p];
+      const float in[VEC] = {inA.x, inA.y, inB.x, inB.y};
+      T sv[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (j >= 2 && !hasB) break;
+        double x;
+        sv[j] = calibrate<T>(col[j], in[j], r, g, a2, A0, nspread, x);
+        const bool xok = in[j] == in[j];
+        if (RMAX) xmax = fmax(xmax, xok ? (double)(T)x : xmax);
+        // the block mean uses the UNMASKED range (the generic kernel does too: a masked sample has a NaN Sv)
+        const T xr = (T)x;
+        const T v = epa::lin_from_db(sv[j] - transmission_loss<T>(col[j], xr, rc.log10k, na2), mt.exp2_tab);
+        const bool take = v == v;
+        col[j].acc_sum += take ? v : (T)0;
+        col[j].acc_cnt += take ? 1u : 0u;
+      }
+      if (WRITE_SV) {
+        epa::store_nt2(sv_c + row_off + sA, sv[0], sv[1]);
+        if (hasB) epa::store_nt2(sv_c + row_off + sB, sv[2], sv[3]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      if (col[j].acc_cnt > 0u) {
+        const int rbk = ((j < 2 ? sA : sB) + (j & 1)) / a.rsn;
+        lds_add(lsum + rbk, col[j].acc_sum);
+        atomicAdd(lcnt + rbk, col[j].acc_cnt);
+      }
+    }
+  }
+  if (RMAX) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) xmax = fmax(xmax, __shfl_down(xmax, o, 64));
+    if (lane == 0 && xmax > -__builtin_inf()) atomicMax(a.rmax_key, ordered_key(xmax));
+  }
+  __syncthreads();
+  // min over the range blocks of 10 log10(block mean) (clean/api.py:402-411), optional clamp (:418-422)
+  T best = (T)__builtin_inf();
+  int any = 0;
+  for (int i = threadIdx.x; i < Sb; i += epa::kBlock) {
+    const uint32_t n = lcnt[i];
+    if (n > 0u) {
+      const T db = (T)10 * epa::M<T>::log10(lsum[i] / (T)n);
+      if (db == db) {
+        best = fmin(best, db);
+        any = 1;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    best = fmin(best, __shfl_down(best, o, 64));
+    any |= __shfl_down(any, o, 64);
+  }
+  if (lane == 0) {
+    red[wave] = best;
+    red[4 + wave] = (T)any;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    T m = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+    const bool some = (red[4] != (T)0) | (red[5] != (T)0) | (red[6] != (T)0) | (red[7] != (T)0);
+    double rr = some ? (double)m : __builtin_nan("");
+    if (a.noise_max == a.noise_max) rr = (rr < a.noise_max) ? rr : a.noise_max;
+    noise_out[(size_t)c * a.n_pblocks + pbk] = rr;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 2
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct BinCol : ColBase<T> {
+  double blo, bhi;  // edges of the range bin the column currently sits in (empty: blo > bhi)
+  T acc_sum;
+  int acc_rb;
+  uint32_t acc_cnt;
+  __device__ __forceinline__ void flush(T* lsum, uint32_t* lcnt) {
+    if (acc_rb >= 0 && acc_cnt > 0u) {
+      lds_add(lsum + acc_rb, acc_sum);
+      atomicAdd(lcnt + acc_rb, acc_cnt);
+    }
+  }
+};
+
+template <typename T, bool WRITE_NOISE, bool WRITE_CORR>
+__global__ __launch_bounds__(epa::kBlock) void sv_denoise_mvbs_fast_kernel(
+    const float* __restrict__ raw, const epa::CoefRow* __restrict__ coef,
+    const double* __restrict__ alpha2, const double* __restrict__ noise,
+    const int32_t* __restrict__ bin_start, T* __restrict__ noise_out, T* __restrict__ corr_out,
+    T* __restrict__ mvbs_out, T* __restrict__ sum_out, uint32_t* __restrict__ cnt_out, Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* lsum = reinterpret_cast<T*>(smem);
+  uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + a.cnt_off);
+  const epa::MathTabs mt = epa::build_math_tabs(smem + a.tab_off);
+
+  const int c = blockIdx.y, tb = blockIdx.x;
+  const int S = a.S, n_rbins = a.n_rbins;
+  // blockIdx.x == n_tbins: pings that belong to no time bin still get their Sv_noise / Sv_corrected
+  const bool extra = tb == a.n_tbins;
+  if (extra && !(WRITE_NOISE || WRITE_CORR)) return;
+  const int nseg = extra ? 2 : 1;
+  for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
+    lsum[i] = (T)0;
+    lcnt[i] = 0u;
+  }
+  __syncthreads();
+
+  const T nspread = (T)a.nspread, snr = (T)a.snr;
+  const double bin = a.range_bin, inv_bin = a.inv_range_bin;
+  const epa::CoefRow* __restrict__ rowp0 = coef + (size_t)c * a.P;
+  const double* __restrict__ a2p = alpha2 + (size_t)c * a.P;
+  const double* __restrict__ nzp = noise + (size_t)c * a.n_pblocks;
+  const float* __restrict__ raw_c = raw + (size_t)c * a.P * S;
+  T* __restrict__ sn_c = WRITE_NOISE ? noise_out + (size_t)c * a.P * S : nullptr;
+  T* __restrict__ sc_c = WRITE_CORR ? corr_out + (size_t)c * a.P * S : nullptr;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+  for (int seg = 0; seg < nseg; ++seg) {
+  const int pb = extra ? (seg == 0 ? 0 : bin_start[a.n_tbins]) : bin_start[tb];
+  const int pe = extra ? (seg == 0 ? bin_start[0] : a.P) : bin_start[tb + 1];
+  for (int chunk0 = 0; chunk0 < S; chunk0 += kChunk) {
+    const int sA = chunk0 + wave * 256 + 2 * lane, sB = sA + 128;
+    if (sA >= S) continue;
+    const bool hasB = sB < S;
+    BinCol<T> col[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      col[j].sra = 0.0; col[j].nL = epa::M<T>::nan(); col[j].lgs = (T)0;
+      col[j].blo = 1.0; col[j].bhi = 0.0; col[j].acc_sum = (T)0; col[j].acc_rb = -1; col[j].acc_cnt = 0u;
+    }
+    RowCache<T> rc;
+    float2 nA = make_float2(0.f, 0.f), nB = nA;
+    epa::CoefRow nxtR = rowp0[pb < pe ? pb : 0];
+    if (pb < pe) {
+      nA = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sA);
+      if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sB);
+    }
+    for (int p = pb; p < pe; ++p) {
+      const epa::CoefRow r = nxtR;
+      const size_t row_off = (size_t)p * S;
+      const float2 inA = nA, inB = nB;
+      if (p + 1 < pe) {
+        nxtR = rowp0[p + 1];
+        nA = *reinterpret_cast<const float2*>(raw_c + row_off + S + sA);
+        if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + row_off + S + sB);
+      }
+      rc.update(r, col, sA, sB, nspread, mt.log_tab);
+      const T g = (T)r.g, a2 = (T)r.alpha2, A0 = (T)r.A0, na2 = (T)a2p[p];
+      const T nb = (T)nzp[p / a.noise_ping_num];
+      const float in[VEC] = {inA.x, inA.y, inB.x, inB.y};
+      T sn[VEC], sc[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (j >= 2 && !hasB) break;
+        BinCol<T>& cj = col[j];
+        double x;
+        const T sv = calibrate<T>(cj, in[j], r, g, a2, A0, nspread, x);
+        const bool xok = in[j] == in[j];
+        const T xr = xok ? (T)x : epa::M<T>::nan();  // echo_range is NaN where the input is
+        sn[j] = nb + transmission_loss<T>(cj, xr, rc.log10k, na2);
+        const T lin = epa::lin_from_db(sv, mt.exp2_tab) - epa::lin_from_db(sn[j], mt.exp2_tab);
+        const T corr = lin > (T)0 ? (T)10 * epa::fast_log10(lin, mt.log_tab) : epa::M<T>::nan();
+        const bool keep = corr - sn[j] > snr;
+        sc[j] = keep ? corr : epa::M<T>::nan();
+        const T v = keep ? lin : epa::M<T>::nan();
+        // range bin of the column (left-closed), as in the headline kernel
+        const bool same = xok & (x >= cj.blo) & (x < cj.bhi);
+        if (!same) {
+          const int rb = xok ? epa::range_bin_index(x, bin, inv_bin, n_rbins, false) : -1;
+          if (rb != cj.acc_rb) {
+            if (!extra) cj.flush(lsum, lcnt);
+            cj.acc_rb = rb;
+            cj.acc_sum = (T)0;
+            cj.acc_cnt = 0u;
+          }
+          cj.blo = rb >= 0 ? (double)rb * bin : 1.0;
+          cj.bhi = rb >= 0 ? (double)(rb + 1) * bin : 0.0;
+        }
+        const bool take = (cj.acc_rb >= 0) & (v == v);
+        cj.acc_sum += take ? v : (T)0;
+        cj.acc_cnt += take ? 1u : 0u;
+      }
+      if (WRITE_NOISE) {
+        epa::store_nt2(sn_c + row_off + sA, sn[0], sn[1]);
+        if (hasB) epa::store_nt2(sn_c + row_off + sB, sn[2], sn[3]);
+      }
+      if (WRITE_CORR) {
+        epa::store_nt2(sc_c + row_off + sA, sc[0], sc[1]);
+        if (hasB) epa::store_nt2(sc_c + row_off + sB, sc[2], sc[3]);
+      }
+    }
+    if (!extra) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) col[j].flush(lsum, lcnt);
+    }
+  }
+  }
+  if (extra) return;
+  __syncthreads();
+  const size_t cell0 = ((size_t)c * a.n_tbins + tb) * n_rbins;
+  T* out = mvbs_out + cell0;
+  T* gsum = sum_out ? sum_out + cell0 : nullptr;
+  uint32_t* gcnt = cnt_out ? cnt_out + cell0 : nullptr;
+  for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
+    const uint32_t n = lcnt[i];
+    const T s = lsum[i];
+    out[i] = n > 0u ? (T)10 * epa::M<T>::log10(s / (T)n) : (T)a.fill_value;
+    if (gsum) gsum[i] = s;
+    if (gcnt) gcnt[i] = n;
+  }
+}
+
+template <typename K>
+int set_lds(K kern, size_t lds) {
+  if (lds > 64 * 1024)
+    EPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return EPA_OK;
+}
+
+template <typename T>
+int launch_pass1(Args& a, const float* raw, const double* coef, const double* alpha2, void* sv_out,
+                 double* noise_out, int C, hipStream_t st) {
+  const size_t sum_bytes = ((size_t)a.n_rblocks * sizeof(T) + 15) & ~(size_t)15;
+  a.cnt_off = (unsigned)sum_bytes;
+  a.tab_off = (unsigned)((sum_bytes + (size_t)a.n_rblocks * 4 + 15) & ~(size_t)15);
+  const size_t lds = a.tab_off + epa::kMathTabBytes;
+  const dim3 grid((unsigned)a.n_pblocks, (unsigned)C);
+#define EPA_P1(W, R)                                                                                    \
+  do {                                                                                                  \
+    auto kern = sv_noise_fast_kernel<T, W, R>;                                                          \
+    if (int rc = set_lds(kern, lds)) return rc;                                                         \
+    hipLaunchKernelGGL(kern, grid, dim3(epa::kBlock), lds, st, raw,                                     \
+                       reinterpret_cast<const epa::CoefRow*>(coef), alpha2, (T*)sv_out, noise_out, a);  \
+  } while (0)
+  if (a.rmax_key) { if (sv_out) EPA_P1(true, true); else EPA_P1(false, true); }
+  else { if (sv_out) EPA_P1(true, false); else EPA_P1(false, false); }
+#undef EPA_P1
+  return epa::check_launch("sv_noise_fast_kernel");
+}
+
+template <typename T>
+int launch_pass2(Args& a, const float* raw, const double* coef, const double* alpha2, const double* noise,
+                 const int32_t* bin_start, void* noise_out, void* corr_out, void* mvbs_out, void* sum_out,
+                 uint32_t* cnt_out, int C, size_t lds_acc_bytes, hipStream_t st) {
+  a.tab_off = (unsigned)((lds_acc_bytes + 15) & ~(size_t)15);
+  const size_t lds = a.tab_off + epa::kMathTabBytes;
+  const dim3 grid((unsigned)a.n_tbins + 1u, (unsigned)C);
+#define EPA_P2(N, K)                                                                                     \
+  do {                                                                                                   \
+    auto kern = sv_denoise_mvbs_fast_kernel<T, N, K>;                                                    \
+    if (int rc = set_lds(kern, lds)) return rc;                                                          \
+    hipLaunchKernelGGL(kern, grid, dim3(epa::kBlock), lds, st, raw,                                      \
+                       reinterpret_cast<const epa::CoefRow*>(coef), alpha2, noise, bin_start,            \
+                       (T*)noise_out, (T*)corr_out, (T*)mvbs_out, (T*)sum_out, cnt_out, a);              \
+  } while (0)
+  if (noise_out) { if (corr_out) EPA_P2(true, true); else EPA_P2(true, false); }
+  else { if (corr_out) EPA_P2(false, true); else EPA_P2(false, false); }
+#undef EPA_P2
+  return epa::check_launch("sv_denoise_mvbs_fast_kernel");
+}
+
+}  // namespace epa_chain
+
+// Called by epa_sv_noise_fused (block_reduce.hip) when the fast path applies.
+int epa_chain_fast_pass1(const float* raw, const double* coef, const double* alpha2, int C, int P, int S,
+                         double nspread, int ping_num, int rsn, double noise_max, void* sv_out,
+                         double* noise_out, unsigned long long* rmax_key, int dtype, hipStream_t st) {
+  epa_chain::Args a{};
+  a.P = P; a.S = S; a.nspread = nspread;
+  a.ping_num = ping_num; a.rsn = rsn;
+  a.n_pblocks = (P + ping_num - 1) / ping_num; a.n_rblocks = (S + rsn - 1) / rsn;
+  a.noise_max = noise_max; a.rmax_key = rmax_key;
+  if (dtype == EPA_F64) return epa_chain::launch_pass1<double>(a, raw, coef, alpha2, sv_out, noise_out, C, st);
+  return epa_chain::launch_pass1<float>(a, raw, coef, alpha2, sv_out, noise_out, C, st);
+}
+
+// Called by epa_sv_denoise_mvbs (block_reduce.hip) when the fast path applies.
+int epa_chain_fast_pass2(const float* raw, const double* coef, const double* alpha2, const double* noise, int C,
+                         int P, int S, double nspread, int ping_num, double snr, const int32_t* bin_start,
+                         int n_tbins, double range_bin, int n_rbins, double fill_value, void* noise_out,
+                         void* corr_out, void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
+                         size_t lds_acc_bytes, unsigned cnt_off, hipStream_t st) {
+  epa_chain::Args a{};
+  a.P = P; a.S = S; a.nspread = nspread;
+  a.noise_ping_num = ping_num; a.n_pblocks = (P + ping_num - 1) / ping_num; a.snr = snr;
+  a.n_tbins = n_tbins; a.n_rbins = n_rbins; a.range_bin = range_bin; a.inv_range_bin = 1.0 / range_bin;
+  a.fill_value = fill_value; a.cnt_off = cnt_off;
+  if (dtype == EPA_F64)
+    return epa_chain::launch_pass2<double>(a, raw, coef, alpha2, noise, bin_start, noise_out, corr_out, mvbs_out,
+                                           sum_out, cnt_out, C, lds_acc_bytes, st);
+  return epa_chain::launch_pass2<float>(a, raw, coef, alpha2, noise, bin_start, noise_out, corr_out, mvbs_out,
+                                        sum_out, cnt_out, C, lds_acc_bytes, st);
+}
