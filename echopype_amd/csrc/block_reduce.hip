@@ -57,6 +57,7 @@ struct ReduceArgs {
   int noise_ping_num, n_pblocks;
   double snr;
   void* sv_noise_out;    // optional Sv_noise output (Sv_corrected goes to sv_out)
+  unsigned long long* mm_keys;  // optional [4]: ordered keys of min/max(Sv_noise), min/max(Sv_corrected)
   int use_lds;
   unsigned cnt_off;  // byte offset of the count array in dynamic LDS
   unsigned tab_off;  // byte offset of the exp/log tables (fast_math.h) in dynamic LDS
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(epa::kBlock) void block_reduce_kernel(ReduceArgs a)
   T* sv_noise_out = reinterpret_cast<T*>(a.sv_noise_out);
 
   double xmax = -__builtin_inf();  // max valid echo_range seen by this lane (raw sources, optional)
+  double mm[4] = {__builtin_inf(), -__builtin_inf(), __builtin_inf(), -__builtin_inf()};  // denoise by-product
   for (int seg = 0; seg < nseg; ++seg) {
   int pb, pe;
   if (extra) {
@@ -255,6 +257,12 @@ __global__ __launch_bounds__(epa::kBlock) void block_reduce_kernel(ReduceArgs a)
               const bool keep = corr - sn[j] > snr;
               sv[j] = keep ? corr : epa::M<T>::nan();
               vlin[j] = keep ? lin : epa::M<T>::nan();
+              if (a.mm_keys) {  // fmin / fmax ignore NaN operands
+                mm[0] = fmin(mm[0], (double)sn[j]);
+                mm[1] = fmax(mm[1], (double)sn[j]);
+                mm[2] = fmin(mm[2], (double)sv[j]);
+                mm[3] = fmax(mm[3], (double)sv[j]);
+              }
             }
             if (sv_noise_out) epa::store_vec<T, VEC>(sv_noise_out + off, sn);
             if (sv_out) epa::store_vec<T, VEC>(sv_out + off, sv);
@@ -326,6 +334,29 @@ __global__ __launch_bounds__(epa::kBlock) void block_reduce_kernel(ReduceArgs a)
       const unsigned long long b = (unsigned long long)__double_as_longlong(xmax);
       atomicMax(reinterpret_cast<unsigned long long*>(a.range_max_out),
                 (b >> 63) ? ~b : (b | 0x8000000000000000ull));
+    }
+  }
+  if (a.mm_keys) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mm[0] = fmin(mm[0], __shfl_down(mm[0], o, 64));
+      mm[1] = fmax(mm[1], __shfl_down(mm[1], o, 64));
+      mm[2] = fmin(mm[2], __shfl_down(mm[2], o, 64));
+      mm[3] = fmax(mm[3], __shfl_down(mm[3], o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      auto key = [](double v) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+      };
+      if (mm[0] <= mm[1]) {
+        atomicMin(a.mm_keys + 0, key(mm[0]));
+        atomicMax(a.mm_keys + 1, key(mm[1]));
+      }
+      if (mm[2] <= mm[3]) {
+        atomicMin(a.mm_keys + 2, key(mm[2]));
+        atomicMax(a.mm_keys + 3, key(mm[3]));
+      }
     }
   }
   if (extra) return;
@@ -470,7 +501,7 @@ int epa_chain_fast_pass2(const float* raw, const double* coef, const double* alp
                          int P, int S, double nspread, int ping_num, double snr, const int32_t* bin_start,
                          int n_tbins, double range_bin, int n_rbins, double fill_value, void* noise_out,
                          void* corr_out, void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
-                         size_t lds_acc_bytes, unsigned cnt_off, hipStream_t st);
+                         size_t lds_acc_bytes, unsigned cnt_off, unsigned long long* mm_keys, hipStream_t st);
 
 namespace {
 
@@ -565,7 +596,7 @@ int run_mvbs(ReduceArgs& a, hipStream_t st) {
     return epa_chain_fast_pass2(a.raw, reinterpret_cast<const double*>(a.coef), a.alpha2, a.noise, a.C, a.P, a.S,
                                 a.nspread, a.noise_ping_num, a.snr, a.bin_start, a.n_tbins, a.range_bin,
                                 a.n_rbins, a.fill_value, a.sv_noise_out, a.sv_out, a.out, a.sum_out, a.cnt_out,
-                                sizeof(T) == 8 ? EPA_F64 : EPA_F32, pl.tab_off, pl.cnt_off, st);
+                                sizeof(T) == 8 ? EPA_F64 : EPA_F32, pl.tab_off, pl.cnt_off, a.mm_keys, st);
   if (a.raw_i16) {
     epa::set_error("epa_sv_mvbs_fused_i16: int16 ingest is served by the default configuration only "
                    "(guard + masked range, skipna, left-closed bins, sorted pings, S %% 4 == 0, no "
@@ -603,6 +634,16 @@ int check_bins(const char* fn, const int32_t* bin_start, int n_tbins, double ran
 }  // namespace
 
 namespace {
+// keys [min, max, min, max] -> doubles; untouched slots (min key ~0, max key 0) -> NaN
+__global__ void decode_minmax_kernel(double* p) {
+  const int i = threadIdx.x;
+  const unsigned long long k = reinterpret_cast<unsigned long long*>(p)[i];
+  const bool none = (i & 1) ? k == 0ull : k == ~0ull;
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  p[i] = none ? __builtin_nan("") : __longlong_as_double(b);
+}
+__global__ void init_minmax_kernel(unsigned long long* p) { p[threadIdx.x] = (threadIdx.x & 1) ? 0ull : ~0ull; }
+
 __global__ void decode_range_max_kernel(double* p) {
   const unsigned long long k = *reinterpret_cast<unsigned long long*>(p);
   // inverse of the order-preserving key; key 0 = nothing seen -> NaN
@@ -888,7 +929,7 @@ extern "C" int epa_sv_denoise_mvbs(const float* raw, const double* coef, const d
                                    const int32_t* ping_perm, int n_tbins, double range_bin, int n_rbins,
                                    unsigned bin_flags, double fill_value, void* sv_noise_out,
                                    void* sv_corrected_out, void* range_out, void* mvbs_out, void* sum_out,
-                                   uint32_t* cnt_out, int dtype, epa_stream_t stream) {
+                                   uint32_t* cnt_out, double* minmax_out, int dtype, epa_stream_t stream) {
   EPA_CHECK_ARG(raw && coef && alpha2 && noise && mvbs_out, "epa_sv_denoise_mvbs: NULL array argument");
   EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && ping_num > 0, "epa_sv_denoise_mvbs: sizes must be positive");
   EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_sv_denoise_mvbs: bad cal_type");
@@ -906,8 +947,17 @@ extern "C" int epa_sv_denoise_mvbs(const float* raw, const double* coef, const d
   a.fill_value = fill_value; a.noise_max = __builtin_nan("");
   a.sv_out = sv_corrected_out; a.sv_noise_out = sv_noise_out; a.range_out = range_out;
   a.out = mvbs_out; a.sum_out = sum_out; a.cnt_out = cnt_out;
-  if (dtype == EPA_F64) return run_mvbs<double, SRC_RAW_DENOISE>(a, (hipStream_t)stream);
-  if (dtype == EPA_F32) return run_mvbs<float, SRC_RAW_DENOISE>(a, (hipStream_t)stream);
-  epa::set_error("epa_sv_denoise_mvbs: bad dtype %d", dtype);
-  return EPA_EINVAL;
+  a.mm_keys = reinterpret_cast<unsigned long long*>(minmax_out);
+  EPA_CHECK_ARG(dtype == EPA_F64 || dtype == EPA_F32, "epa_sv_denoise_mvbs: bad dtype %d", dtype);
+  if (minmax_out) {
+    hipLaunchKernelGGL(init_minmax_kernel, dim3(1), dim3(4), 0, (hipStream_t)stream, a.mm_keys);
+    if (int rc = epa::check_launch("init_minmax_kernel")) return rc;
+  }
+  const int rc = dtype == EPA_F64 ? run_mvbs<double, SRC_RAW_DENOISE>(a, (hipStream_t)stream)
+                                  : run_mvbs<float, SRC_RAW_DENOISE>(a, (hipStream_t)stream);
+  if (rc == EPA_OK && minmax_out) {
+    hipLaunchKernelGGL(decode_minmax_kernel, dim3(1), dim3(4), 0, (hipStream_t)stream, minmax_out);
+    return epa::check_launch("decode_minmax_kernel");
+  }
+  return rc;
 }

@@ -34,6 +34,7 @@ struct Args {
   double range_bin, inv_range_bin, fill_value, snr;
   unsigned cnt_off, tab_off;
   unsigned long long* rmax_key;
+  unsigned long long* mm_keys;  // pass 2, optional [4]: min/max of Sv_noise, min/max of Sv_corrected
 };
 
 __device__ __forceinline__ unsigned long long ordered_key(double v) {
@@ -262,7 +263,7 @@ struct BinCol : ColBase<T> {
   }
 };
 
-template <typename T, bool WRITE_NOISE, bool WRITE_CORR>
+template <typename T, bool WRITE_NOISE, bool WRITE_CORR, bool MINMAX>
 __global__ __launch_bounds__(epa::kBlock) void sv_denoise_mvbs_fast_kernel(
     const float* __restrict__ raw, const epa::CoefRow* __restrict__ coef,
     const double* __restrict__ alpha2, const double* __restrict__ noise,
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(epa::kBlock) void sv_denoise_mvbs_fast_kernel(
   T* __restrict__ sn_c = WRITE_NOISE ? noise_out + (size_t)c * a.P * S : nullptr;
   T* __restrict__ sc_c = WRITE_CORR ? corr_out + (size_t)c * a.P * S : nullptr;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double mm[4] = {__builtin_inf(), -__builtin_inf(), __builtin_inf(), -__builtin_inf()};
 
   for (int seg = 0; seg < nseg; ++seg) {
   const int pb = extra ? (seg == 0 ? 0 : bin_start[a.n_tbins]) : bin_start[tb];
@@ -343,6 +345,12 @@ __global__ __launch_bounds__(epa::kBlock) void sv_denoise_mvbs_fast_kernel(
         const bool keep = corr - sn[j] > snr;
         sc[j] = keep ? corr : epa::M<T>::nan();
         const T v = keep ? lin : epa::M<T>::nan();
+        if (MINMAX) {  // fmin / fmax ignore NaN operands
+          mm[0] = fmin(mm[0], (double)sn[j]);
+          mm[1] = fmax(mm[1], (double)sn[j]);
+          mm[2] = fmin(mm[2], (double)sc[j]);
+          mm[3] = fmax(mm[3], (double)sc[j]);
+        }
         // range bin of the column (left-closed), as in the headline kernel
         const bool same = xok & (x >= cj.blo) & (x < cj.bhi);
         if (!same) {
@@ -374,6 +382,25 @@ __global__ __launch_bounds__(epa::kBlock) void sv_denoise_mvbs_fast_kernel(
       for (int j = 0; j < VEC; ++j) col[j].flush(lsum, lcnt);
     }
   }
+  }
+  if (MINMAX) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mm[0] = fmin(mm[0], __shfl_down(mm[0], o, 64));
+      mm[1] = fmax(mm[1], __shfl_down(mm[1], o, 64));
+      mm[2] = fmin(mm[2], __shfl_down(mm[2], o, 64));
+      mm[3] = fmax(mm[3], __shfl_down(mm[3], o, 64));
+    }
+    if (lane == 0) {
+      if (mm[0] <= mm[1]) {
+        atomicMin(a.mm_keys + 0, ordered_key(mm[0]));
+        atomicMax(a.mm_keys + 1, ordered_key(mm[1]));
+      }
+      if (mm[2] <= mm[3]) {
+        atomicMin(a.mm_keys + 2, ordered_key(mm[2]));
+        atomicMax(a.mm_keys + 3, ordered_key(mm[3]));
+      }
+    }
   }
   if (extra) return;
   __syncthreads();
@@ -428,7 +455,11 @@ int launch_pass2(Args& a, const float* raw, const double* coef, const double* al
   const dim3 grid((unsigned)a.n_tbins + 1u, (unsigned)C);
 #define EPA_P2(N, K)                                                                                     \
   do {                                                                                                   \
-    auto kern = sv_denoise_mvbs_fast_kernel<T, N, K>;                                                    \
+    if (a.mm_keys) EPA_P2M(N, K, true); else EPA_P2M(N, K, false);                                       \
+  } while (0)
+#define EPA_P2M(N, K, M)                                                                                 \
+  do {                                                                                                   \
+    auto kern = sv_denoise_mvbs_fast_kernel<T, N, K, M>;                                                 \
     if (int rc = set_lds(kern, lds)) return rc;                                                          \
     hipLaunchKernelGGL(kern, grid, dim3(epa::kBlock), lds, st, raw,                                      \
                        reinterpret_cast<const epa::CoefRow*>(coef), alpha2, noise, bin_start,            \
@@ -437,6 +468,7 @@ int launch_pass2(Args& a, const float* raw, const double* coef, const double* al
   if (noise_out) { if (corr_out) EPA_P2(true, true); else EPA_P2(true, false); }
   else { if (corr_out) EPA_P2(false, true); else EPA_P2(false, false); }
 #undef EPA_P2
+#undef EPA_P2M
   return epa::check_launch("sv_denoise_mvbs_fast_kernel");
 }
 
@@ -460,12 +492,12 @@ int epa_chain_fast_pass2(const float* raw, const double* coef, const double* alp
                          int P, int S, double nspread, int ping_num, double snr, const int32_t* bin_start,
                          int n_tbins, double range_bin, int n_rbins, double fill_value, void* noise_out,
                          void* corr_out, void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
-                         size_t lds_acc_bytes, unsigned cnt_off, hipStream_t st) {
+                         size_t lds_acc_bytes, unsigned cnt_off, unsigned long long* mm_keys, hipStream_t st) {
   epa_chain::Args a{};
   a.P = P; a.S = S; a.nspread = nspread;
   a.noise_ping_num = ping_num; a.n_pblocks = (P + ping_num - 1) / ping_num; a.snr = snr;
   a.n_tbins = n_tbins; a.n_rbins = n_rbins; a.range_bin = range_bin; a.inv_range_bin = 1.0 / range_bin;
-  a.fill_value = fill_value; a.cnt_off = cnt_off;
+  a.fill_value = fill_value; a.cnt_off = cnt_off; a.mm_keys = mm_keys;
   if (dtype == EPA_F64)
     return epa_chain::launch_pass2<double>(a, raw, coef, alpha2, noise, bin_start, noise_out, corr_out, mvbs_out,
                                            sum_out, cnt_out, C, lds_acc_bytes, st);

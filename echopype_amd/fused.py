@@ -169,7 +169,7 @@ def compute_Sv_clean_MVBS(echodata, ping_num, range_sample_num, *, background_no
         res = ops.sv_denoise_mvbs(raw, coef, alpha2, noise, ping_num, float(snr), bin_start, n_t, range_bin_m,
                                   n_r, flags=flags, dtype=cal.dtype, skipna=skipna, closed=closed,
                                   fill_value=fill_value, want_noise=keep_Sv_noise,
-                                  want_range=materialize_echo_range)
+                                  want_range=materialize_echo_range, want_minmax=True)
     except _lib.EpaError:  # e.g. a range grid too fine for the LDS accumulators
         return separate_calls()
 
@@ -190,12 +190,13 @@ def compute_Sv_clean_MVBS(echodata, ping_num, range_sample_num, *, background_no
     ds_Sv = _finalize_cal_ds(ds_Sv, "Sv", echodata, waveform_mode, encode_mode)
     if not have_range:
         ds_Sv.data_vars.pop("echo_range")
-    outs = [("Sv_corrected", res["Sv_corrected"], "corrected")]
+    mm = res["minmax"]  # actual_range of both outputs comes out of the kernel: no extra sweep
+    outs = [("Sv_corrected", res["Sv_corrected"], "corrected", mm[2:4])]
     if keep_Sv_noise:
-        outs.insert(0, ("Sv_noise", res["Sv_noise"], "noise"))
-    for name, t, kind in outs:  # clean/api.py:490-502
+        outs.insert(0, ("Sv_noise", res["Sv_noise"], "noise", mm[0:2]))
+    for name, t, kind, rng_mm in outs:  # clean/api.py:490-502
         ds_Sv[name] = add_remove_background_noise_attrs(DataArray(DeviceArray(t), dims), kind, ping_num,
-                                                        range_sample_num, snr, nmax, ops.nanminmax(t))
+                                                        range_sample_num, snr, nmax, rng_mm)
     prov = echopype_prov_attrs(process_type="processing")
     prov["processing_function"] = "clean.remove_background_noise"
     ds_Sv.attrs.update(prov)

@@ -486,8 +486,9 @@ def denoise_mvbs(sv, alpha2, noise, ping_num, snr_threshold, bin_start, n_tbins,
 def sv_denoise_mvbs(raw, coef, alpha2, noise, ping_num, snr_threshold, bin_start, n_tbins, range_bin, n_rbins,
                     *, cal_type="Sv", flags=_lib.FLAG_GUARD_POS | _lib.FLAG_MASK_RANGE, dtype=torch.float64,
                     skipna=True, closed="left", fill_value=float("nan"), ping_perm=None, want_noise=False,
-                    want_corrected=True, want_range=False, want_partials=False):
-    """K1+K7+K5 from the raw power -> dict(MVBS of the corrected Sv, Sv_noise, Sv_corrected, echo_range, sum, cnt)."""
+                    want_corrected=True, want_range=False, want_partials=False, want_minmax=False):
+    """K1+K7+K5 from the raw power -> dict(MVBS of the corrected Sv, Sv_noise, Sv_corrected, echo_range, sum,
+    cnt, minmax = [min, max of Sv_noise, min, max of Sv_corrected] (host floats) if asked)."""
     C, P, S = raw.shape
     dev = raw.device
     mk = lambda want: torch.empty((C, P, S), dtype=dtype, device=dev) if want else None  # noqa: E731
@@ -497,8 +498,10 @@ def sv_denoise_mvbs(raw, coef, alpha2, noise, ping_num, snr_threshold, bin_start
     if want_partials or reduce_needs_workspace(C, n_tbins, n_rbins, dtype):
         ssum = torch.empty((C, n_tbins, n_rbins), dtype=dtype, device=dev)
         cnt = torch.empty((C, n_tbins, n_rbins), dtype=torch.int32, device=dev)
+    mm = torch.empty(4, dtype=torch.float64, device=dev) if want_minmax else None
     call("epa_sv_denoise_mvbs", _p(raw), _p(coef), _p(alpha2), _p(noise), C, P, S,
          _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, flags, int(ping_num), float(snr_threshold),
          _p(bin_start), _p(ping_perm), int(n_tbins), float(range_bin), int(n_rbins), _bin_flags(skipna, closed),
-         float(fill_value), _p(sn), _p(sc), _p(rng), _p(out), _p(ssum), _p(cnt), _DT[dtype], _stream())
-    return dict(MVBS=out, Sv_noise=sn, Sv_corrected=sc, echo_range=rng, sum=ssum, cnt=cnt)
+         float(fill_value), _p(sn), _p(sc), _p(rng), _p(out), _p(ssum), _p(cnt), _p(mm), _DT[dtype], _stream())
+    return dict(MVBS=out, Sv_noise=sn, Sv_corrected=sc, echo_range=rng, sum=ssum, cnt=cnt,
+                minmax=mm.cpu().tolist() if want_minmax else None)

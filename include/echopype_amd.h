@@ -376,13 +376,15 @@ int epa_denoise_mvbs(const void* sv, const void* range, const double* coef, cons
 /* Pass 2 fed with the RAW power again instead of Sv (4 B/sample read instead of 8, and the NaN padding
  * that masks echo_range is seen directly): Sv is recomputed in registers as in epa_sv_power, then as
  * epa_denoise_mvbs.  With pass 1 the chain costs 4 + 8 (Sv) and 4 + 8 (Sv_corrected) [+ 8 Sv_noise]
- * = 24..32 B/sample.  range_out optional as in epa_sv_power. */
+ * = 24..32 B/sample.  range_out optional as in epa_sv_power.  minmax_out (f64 [4], optional): NaN-skipping
+ * {min, max} of Sv_noise and {min, max} of Sv_corrected as a by-product (the actual_range attributes of
+ * clean/utils.py:392-395, otherwise one more sweep of each array). */
 int epa_sv_denoise_mvbs(const float* raw, const double* coef, const double* alpha2, const double* noise,
                         int C, int P, int S, int cal_type, unsigned cal_flags, int ping_num,
                         double snr_threshold, const int32_t* bin_start, const int32_t* ping_perm,
                         int n_tbins, double range_bin, int n_rbins, unsigned bin_flags, double fill_value,
                         void* sv_noise_out, void* sv_corrected_out, void* range_out, void* mvbs_out,
-                        void* sum_out, uint32_t* cnt_out, int dtype, epa_stream_t stream);
+                        void* sum_out, uint32_t* cnt_out, double* minmax_out, int dtype, epa_stream_t stream);
 
 #ifdef __cplusplus
 }
