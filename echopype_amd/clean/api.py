@@ -64,11 +64,12 @@ def remove_background_noise(ds_Sv, ping_num, range_sample_num, background_noise_
     if SNR_threshold is not None:
         SNR_threshold = extract_dB(SNR_threshold)
     order, sv_t, rg_t, a2, noise, nmax = _estimate(ds_Sv, ping_num, range_sample_num, background_noise_max)
-    sn, sc = ops.noise_apply(sv_t, a2, noise, ping_num, float(SNR_threshold), range=rg_t)
-    for name, t, kind in (("Sv_noise", sn, "noise"), ("Sv_corrected", sc, "corrected")):
+    # actual_range of both outputs is a by-product of the kernel (no extra sweeps)
+    sn, sc, mm = ops.noise_apply(sv_t, a2, noise, ping_num, float(SNR_threshold), range=rg_t, want_minmax=True)
+    for name, t, kind, rng_mm in (("Sv_noise", sn, "noise", mm[0:2]), ("Sv_corrected", sc, "corrected", mm[2:4])):
         da = DataArray(DeviceArray(t), order)
         ds_Sv[name] = add_remove_background_noise_attrs(da, kind, ping_num, range_sample_num, SNR_threshold,
-                                                        nmax, ops.nanminmax(t))
+                                                        nmax, rng_mm)
     prov = echopype_prov_attrs(process_type="processing")
     prov["processing_function"] = "clean.remove_background_noise"
     ds_Sv.attrs.update(prov)

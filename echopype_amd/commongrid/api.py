@@ -62,7 +62,7 @@ def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="
     C, P, S = sv_t.shape
 
     # range edges: np.arange(0, max + bin, bin)  (api.py:108-115)
-    lo, hi = ops.nanminmax(rg_t)
+    lo, hi, n_nan_range = ops.nanminmax(rg_t, with_nan_count=True)
     if range_var_max is None:
         rmax = hi
     else:
@@ -76,7 +76,7 @@ def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="
     ping_time = np.asarray(ds_Sv["ping_time"].values).astype("datetime64[ns]")
     if np.isnat(ping_time).any():
         logging.warning(f"The ```ping_time``` coordinate array contain NaNs. {_AGG_MSG}")
-    if bool(torch.isnan(rg_t).any()):
+    if n_nan_range > 0:
         logging.warning(f"The ```{range_var}``` coordinate array contain NaNs. {_AGG_MSG}")
 
     # ping bins: pandas-resample edges, anchored at midnight (api.py:118-128)

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(epa::kBlock) void noise_apply_kernel(
     const T* __restrict__ sv, const T* __restrict__ range, const epa::CoefRow* __restrict__ coef,
     const double* __restrict__ alpha2, const double* __restrict__ noise, int P, int S,
     long long rows, int ping_num, int n_pblocks, T snr, T* __restrict__ sv_noise,
-    T* __restrict__ sv_corr) {
+    T* __restrict__ sv_corr, unsigned long long* __restrict__ mm_keys) {
   using LM = epa::LaneMap<T>;
   constexpr int NSEG = VEC ? LM::NSEG : 1, LEN = VEC ? LM::LEN : 1;
   __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
@@ -30,6 +30,8 @@ __global__ __launch_bounds__(epa::kBlock) void noise_apply_kernel(
   for (int g = 0; g < NSEG; ++g)
     s0[g] = VEC ? LM::first(blockIdx.y * 1024, g) : (int)(blockIdx.y * epa::kBlock + threadIdx.x);
   if (s0[0] >= S) return;
+  // optional by-product: NaN-skipping min / max of both outputs (actual_range, clean/utils.py:392-395)
+  double mm[4] = {__builtin_inf(), -__builtin_inf(), __builtin_inf(), -__builtin_inf()};
   for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
     const int c = (int)(row / P), p = (int)(row - (long long)c * P);
     const T nb = (T)noise[(size_t)c * n_pblocks + p / ping_num];
@@ -56,11 +58,49 @@ __global__ __launch_bounds__(epa::kBlock) void noise_apply_kernel(
         if (!(corr - sn > snr)) corr = epa::M<T>::nan();
         on[j] = sn;
         oc[j] = corr;
+        if (mm_keys) {  // fmin / fmax ignore NaN operands
+          mm[0] = fmin(mm[0], (double)sn);
+          mm[1] = fmax(mm[1], (double)sn);
+          mm[2] = fmin(mm[2], (double)corr);
+          mm[3] = fmax(mm[3], (double)corr);
+        }
       }
       if (sv_noise) epa::store_vec<T, LEN>(sv_noise + off, on);
       if (sv_corr) epa::store_vec<T, LEN>(sv_corr + off, oc);
     }
   }
+  if (mm_keys) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mm[0] = fmin(mm[0], __shfl_down(mm[0], o, 64));
+      mm[1] = fmax(mm[1], __shfl_down(mm[1], o, 64));
+      mm[2] = fmin(mm[2], __shfl_down(mm[2], o, 64));
+      mm[3] = fmax(mm[3], __shfl_down(mm[3], o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      auto key = [](double v) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+      };
+      if (mm[0] <= mm[1]) {
+        atomicMin(mm_keys + 0, key(mm[0]));
+        atomicMax(mm_keys + 1, key(mm[1]));
+      }
+      if (mm[2] <= mm[3]) {
+        atomicMin(mm_keys + 2, key(mm[2]));
+        atomicMax(mm_keys + 3, key(mm[3]));
+      }
+    }
+  }
+}
+
+__global__ void init_minmax_kernel(unsigned long long* p) { p[threadIdx.x] = (threadIdx.x & 1) ? 0ull : ~0ull; }
+__global__ void decode_minmax_kernel(double* p) {
+  const int i = threadIdx.x;
+  const unsigned long long k = reinterpret_cast<unsigned long long*>(p)[i];
+  const bool none = (i & 1) ? k == 0ull : k == ~0ull;
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  p[i] = none ? __builtin_nan("") : __longlong_as_double(b);
 }
 
 inline bool al16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -68,7 +108,7 @@ inline bool al16(const void* p) { return p == nullptr || (reinterpret_cast<uintp
 template <typename T>
 int launch(const void* sv, const void* range, const double* coef, const double* alpha2,
            const double* noise, int C, int P, int S, int ping_num, double snr, void* sv_noise,
-           void* sv_corr, hipStream_t st) {
+           void* sv_corr, double* minmax_out, hipStream_t st) {
   const long long rows = (long long)C * P;
   const int need = sizeof(T) == 8 ? 2 : 4;
   const bool vec = S % need == 0 && al16(sv) && al16(range) && al16(sv_noise) && al16(sv_corr);
@@ -80,15 +120,22 @@ int launch(const void* sv, const void* range, const double* coef, const double* 
   const dim3 grid((unsigned)gx, (unsigned)chunks_per_row);
   const int n_pblocks = (P + ping_num - 1) / ping_num;
   const epa::CoefRow* cf = reinterpret_cast<const epa::CoefRow*>(coef);
+  unsigned long long* mm = reinterpret_cast<unsigned long long*>(minmax_out);
+  if (mm) hipLaunchKernelGGL(init_minmax_kernel, dim3(1), dim3(4), 0, st, mm);
   if (vec)
     hipLaunchKernelGGL((noise_apply_kernel<T, true>), grid, dim3(epa::kBlock), 0, st, (const T*)sv,
                        (const T*)range, cf, alpha2, noise, P, S, rows, ping_num, n_pblocks, (T)snr,
-                       (T*)sv_noise, (T*)sv_corr);
+                       (T*)sv_noise, (T*)sv_corr, mm);
   else
     hipLaunchKernelGGL((noise_apply_kernel<T, false>), grid, dim3(epa::kBlock), 0, st, (const T*)sv,
                        (const T*)range, cf, alpha2, noise, P, S, rows, ping_num, n_pblocks, (T)snr,
-                       (T*)sv_noise, (T*)sv_corr);
-  return epa::check_launch("noise_apply_kernel");
+                       (T*)sv_noise, (T*)sv_corr, mm);
+  if (int rc = epa::check_launch("noise_apply_kernel")) return rc;
+  if (mm) {
+    hipLaunchKernelGGL(decode_minmax_kernel, dim3(1), dim3(4), 0, st, minmax_out);
+    return epa::check_launch("decode_minmax_kernel");
+  }
+  return EPA_OK;
 }
 
 }  // namespace
@@ -96,17 +143,17 @@ int launch(const void* sv, const void* range, const double* coef, const double* 
 extern "C" int epa_noise_apply(const void* sv, const void* range, const double* coef,
                                const double* alpha2, const double* noise, int C, int P, int S,
                                int ping_num, double snr_threshold, void* sv_noise_out,
-                               void* sv_corrected_out, int dtype, epa_stream_t stream) {
+                               void* sv_corrected_out, double* minmax_out, int dtype, epa_stream_t stream) {
   EPA_CHECK_ARG(sv && alpha2 && noise, "epa_noise_apply: NULL array argument");
   EPA_CHECK_ARG(range || coef, "epa_noise_apply: either range or coef must be given");
   EPA_CHECK_ARG(sv_noise_out || sv_corrected_out, "epa_noise_apply: no output requested");
   EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && ping_num > 0, "epa_noise_apply: sizes must be positive");
   if (dtype == EPA_F64)
     return launch<double>(sv, range, coef, alpha2, noise, C, P, S, ping_num, snr_threshold,
-                          sv_noise_out, sv_corrected_out, (hipStream_t)stream);
+                          sv_noise_out, sv_corrected_out, minmax_out, (hipStream_t)stream);
   if (dtype == EPA_F32)
     return launch<float>(sv, range, coef, alpha2, noise, C, P, S, ping_num, snr_threshold,
-                         sv_noise_out, sv_corrected_out, (hipStream_t)stream);
+                         sv_noise_out, sv_corrected_out, minmax_out, (hipStream_t)stream);
   epa::set_error("epa_noise_apply: bad dtype %d", dtype);
   return EPA_EINVAL;
 }

@@ -18,41 +18,51 @@ __device__ __forceinline__ void wave_minmax(double& lo, double& hi) {
 template <typename T>
 __global__ __launch_bounds__(epa::kBlock) void minmax_partial_kernel(const T* __restrict__ x, size_t n,
                                                                      double* __restrict__ part) {
-  __shared__ double slo[4], shi[4];
-  double lo = __builtin_inf(), hi = -__builtin_inf();
+  __shared__ double slo[4], shi[4], snan[4];
+  double lo = __builtin_inf(), hi = -__builtin_inf(), nn = 0.0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x) {
     const double v = (double)x[i];
     if (v == v) {
       lo = fmin(lo, v);
       hi = fmax(hi, v);
+    } else {
+      nn += 1.0;
     }
   }
   wave_minmax<T>(lo, hi);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nn += __shfl_down(nn, o, 64);
   if ((threadIdx.x & 63) == 0) {
     slo[threadIdx.x >> 6] = lo;
     shi[threadIdx.x >> 6] = hi;
+    snan[threadIdx.x >> 6] = nn;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    part[2 * blockIdx.x] = fmin(fmin(slo[0], slo[1]), fmin(slo[2], slo[3]));
-    part[2 * blockIdx.x + 1] = fmax(fmax(shi[0], shi[1]), fmax(shi[2], shi[3]));
+    part[3 * blockIdx.x] = fmin(fmin(slo[0], slo[1]), fmin(slo[2], slo[3]));
+    part[3 * blockIdx.x + 1] = fmax(fmax(shi[0], shi[1]), fmax(shi[2], shi[3]));
+    part[3 * blockIdx.x + 2] = (snan[0] + snan[1]) + (snan[2] + snan[3]);
   }
 }
 
 __global__ __launch_bounds__(epa::kBlock) void minmax_final_kernel(const double* __restrict__ part,
                                                                    int nparts,
                                                                    double* __restrict__ out) {
-  __shared__ double slo[4], shi[4];
-  double lo = __builtin_inf(), hi = -__builtin_inf();
+  __shared__ double slo[4], shi[4], snan[4];
+  double lo = __builtin_inf(), hi = -__builtin_inf(), nn = 0.0;
   for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
-    lo = fmin(lo, part[2 * i]);
-    hi = fmax(hi, part[2 * i + 1]);
+    lo = fmin(lo, part[3 * i]);
+    hi = fmax(hi, part[3 * i + 1]);
+    nn += part[3 * i + 2];
   }
   wave_minmax<double>(lo, hi);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nn += __shfl_down(nn, o, 64);
   if ((threadIdx.x & 63) == 0) {
     slo[threadIdx.x >> 6] = lo;
     shi[threadIdx.x >> 6] = hi;
+    snan[threadIdx.x >> 6] = nn;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -62,6 +72,7 @@ __global__ __launch_bounds__(epa::kBlock) void minmax_final_kernel(const double*
     const bool none = lo > hi;
     out[0] = none ? __builtin_nan("") : lo;
     out[1] = none ? __builtin_nan("") : hi;
+    out[2] = (snan[0] + snan[1]) + (snan[2] + snan[3]);  // number of NaN elements
   }
 }
 

@@ -214,13 +214,13 @@ def affine_rows(x, scale, offset):
     return out
 
 
-def nanminmax(x):
-    """(nanmin, nanmax) of a device tensor as Python floats (one 16-byte D2H copy)."""
-    ws = torch.empty(2048, dtype=torch.float64, device=x.device)
-    out = torch.empty(2, dtype=torch.float64, device=x.device)
+def nanminmax(x, with_nan_count=False):
+    """(nanmin, nanmax[, number of NaNs]) of a device tensor as Python floats (one 24-byte D2H copy)."""
+    ws = torch.empty(3072, dtype=torch.float64, device=x.device)
+    out = torch.empty(3, dtype=torch.float64, device=x.device)
     call("epa_nanminmax", _p(x), x.numel(), _DT[x.dtype], _p(ws), _p(out), _stream())
-    lo, hi = out.cpu().tolist()
-    return lo, hi
+    lo, hi, nn = out.cpu().tolist()
+    return (lo, hi, int(nn)) if with_nan_count else (lo, hi)
 
 
 def mvbs_index(sv, ping_num, range_sample_num, range=None):
@@ -251,16 +251,17 @@ def noise_estimate(sv, alpha2, ping_num, range_sample_num, *, range=None, coef=N
 
 
 def noise_apply(sv, alpha2, noise, ping_num, snr_threshold, *, range=None, coef=None,
-                want_noise=True, want_corrected=True):
-    """K7 -> (Sv_noise, Sv_corrected)."""
+                want_noise=True, want_corrected=True, want_minmax=False):
+    """K7 -> (Sv_noise, Sv_corrected[, [min, max of Sv_noise, min, max of Sv_corrected]])."""
     C, P, S = sv.shape
     if range is not None and range.dtype != sv.dtype:
         range = range.to(sv.dtype)
     sn = torch.empty_like(sv) if want_noise else None
     sc = torch.empty_like(sv) if want_corrected else None
+    mm = torch.empty(4, dtype=torch.float64, device=sv.device) if want_minmax else None
     call("epa_noise_apply", _p(sv), _p(range), _p(coef), _p(alpha2), _p(noise), C, P, S, int(ping_num),
-         float(snr_threshold), _p(sn), _p(sc), _DT[sv.dtype], _stream())
-    return sn, sc
+         float(snr_threshold), _p(sn), _p(sc), _p(mm), _DT[sv.dtype], _stream())
+    return (sn, sc, mm.cpu().tolist()) if want_minmax else (sn, sc)
 
 
 def sv_complex(re, im, ccoef, *, replica=None, replica_off=None, max_taps=0, cal_type="Sv",

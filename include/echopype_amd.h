@@ -186,8 +186,9 @@ int epa_affine_rows(const void* x, const double* scale, const double* offset, in
 /* ---- NaN-skipping min/max of a device array ---------------------------------------------------------------
  * Replaces the reductions the reference forces with ds_Sv[range_var].max(skipna=True)
  * (commongrid/api.py:108-110) and the actual_range attributes (clean/utils.py:392-395,
- * commongrid/api.py:252-255).  x: [n] of dtype; workspace: f64 [2048]; out: f64 [2] = {min, max}
- * (NaN, NaN when no element is non-NaN).
+ * commongrid/api.py:252-255).  x: [n] of dtype; workspace: f64 [3072]; out: f64 [3] = {min, max,
+ * number of NaN elements} (min = max = NaN when no element is non-NaN).  The NaN count serves the
+ * "coordinate array contain NaNs" warning of commongrid/utils.py:595-608 without another sweep.
  */
 int epa_nanminmax(const void* x, size_t n, int dtype, double* workspace, double* out,
                   epa_stream_t stream);
@@ -213,11 +214,14 @@ int epa_noise_estimate(const void* sv, const void* range, const double* coef, co
 
 /* ---- K7: noise removal -------------------------------------------------------------------------------------------
  * Replaces clean/api.py:425-430 (ffill upsample + TL) and :485-487.  Writes Sv_noise and
- * Sv_corrected ([C*P*S] of dtype; either may be NULL).  snr_threshold in dB.
+ * Sv_corrected ([C*P*S] of dtype; either may be NULL).  snr_threshold in dB.  minmax_out (f64 [4],
+ * optional): NaN-skipping {min, max} of Sv_noise and of Sv_corrected as a by-product (the actual_range
+ * attributes of clean/utils.py:392-395 without two more sweeps).
  */
 int epa_noise_apply(const void* sv, const void* range, const double* coef, const double* alpha2,
                     const double* noise, int C, int P, int S, int ping_num, double snr_threshold,
-                    void* sv_noise_out, void* sv_corrected_out, int dtype, epa_stream_t stream);
+                    void* sv_noise_out, void* sv_corrected_out, double* minmax_out, int dtype,
+                    epa_stream_t stream);
 
 /* ---- K3+K4: EK80 complex samples (CW complex and BB pulse compression) ---------------------------------------------
  * Replaces calibrate/ek80_complex.py:285-369 (compress_pulse: matched filter with the transmit
