@@ -41,6 +41,19 @@ struct Cx {
 
 __device__ __forceinline__ int pad_idx(int a) { return a + (a >> kRShift); }  // one pad element per kR
 
+// R' = R - shift decides the R' <= 0 guard: when the two are equal (tau = 2^k sample intervals) the
+// difference must be the rounded difference of the rounded range, not the fused residue of its product
+// (HIP compiles with -ffp-contract=fast: the backend fuses across statements, so the rounded range is
+// pinned in a register with an empty asm before the subtraction)
+__device__ __forceinline__ double sub_rn(double a, double b) {
+  asm volatile("" : "+v"(a));
+  return a - b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+  asm volatile("" : "+v"(a));
+  return a - b;
+}
+
 struct CxArgs {
   const void* re;
   const void* im;
@@ -261,7 +274,7 @@ __global__ __launch_bounds__(epa::kBlock, EPA_EK80_MIN_WAVES) void sv_complex_ke
     T prx = pscale * (mr * mr + mi * mi);
     if (!(prx > (T)0)) prx = epa::M<T>::nan();
     const double R = ((double)s * ra) * rb;  // range.py:138 operation order
-    T rt = (T)R - shift;
+    T rt = sub_rn((T)R, shift);  // never contracted with the range product into an fma
     if (!(rt > (T)0)) rt = epa::M<T>::nan();
     const T val = (T)10 * epa::fast_log10(prx, mt.log_tab) + nspread * epa::fast_log10(rt, mt.log_tab) + alpha2 * rt + Aadd;
     const size_t o = row * S + s;
@@ -561,7 +574,7 @@ __global__ __launch_bounds__(epa::kBlock) void sv_complex_fft_kernel(CxArgs a, c
     T prx = pscale * (mr * mr + mi * mi);
     if (!(prx > (T)0)) prx = epa::M<T>::nan();
     const double R = ((double)s * ra) * rb;
-    T rt = (T)R - shift;
+    T rt = sub_rn((T)R, shift);  // never contracted with the range product into an fma
     if (!(rt > (T)0)) rt = epa::M<T>::nan();
     const T val = (T)10 * epa::fast_log10(prx, mt.log_tab) + nspread * epa::fast_log10(rt, mt.log_tab) + alpha2 * rt + Aadd;
     const size_t o = row * S + s;

@@ -16,11 +16,16 @@ Pinning status (see DESIGN.md "Oracle"):
     norm factor, matched-filter convolution) are pinned against outputs of the
     reference's OWN code executed in the authoring container through a stub-module
     loader (oracle/gen_goldens.py -> tests/golden/ref_leaf_goldens.npz);
-  * the array-level chains (Sv/TS, noise, MVBS) cannot be executed from the
-    reference here (xarray/flox/dask absent, Python 3.10 < 3.11), so they are pinned
-    against the reference's synthetic known-answer tests restated in
-    tests/test_oracle_kat.py (noise seed-1 => 6 NaNs, pulse-length lookup tables,
-    MVBS brute-force values/NaN masks, index-binning coarsen formula, ...).
+  * the Sv/TS chains (EK60, EK80 power incl. GPT, AZFP, EK80 complex CW / BB) are pinned
+    against outputs of the reference's OWN calibrator methods, executed over a strict
+    named-dimension array shim (oracle/xr_shim.py, oracle/gen_chain_goldens.py ->
+    tests/golden/ref_chain_goldens.npz); the noise-mask leaf functions likewise
+    (oracle/gen_mask_goldens.py -> tests/golden/ref_mask_goldens.npz);
+  * noise removal and MVBS / NASC (xarray coarsen, flox group-bys) cannot be executed from
+    the reference here, so they are pinned against the reference's synthetic
+    known-answer tests restated in tests/test_oracle_kat.py, test_oracle_masks.py,
+    test_oracle_nasc.py (noise seed-1 => 6 NaNs, pulse-length lookup tables, MVBS
+    brute-force values/NaN masks, index-binning coarsen formula, Echoview NASC value, ...).
 
 Every function cites the reference file:line it follows.  The pass structure of the
 reference (whole-array temporaries, np.log10 / 10**x, scipy.signal.convolve per
@@ -28,4 +33,4 @@ reference (whole-array temporaries, np.log10 / 10**x, scipy.signal.convolve per
 code is a fair stand-in for the reference CPU path (bench.py cpu_baseline, kind="port").
 """
 
-from . import uwa, ek80, calibrate, clean, commongrid  # noqa: F401
+from . import uwa, ek80, calibrate, clean, commongrid, masks, nasc  # noqa: F401

@@ -1,0 +1,389 @@
+"""A minimal named-dimension array (the subset of xarray semantics the reference's calibrator methods
+use) -- TEST INFRASTRUCTURE for oracle/gen_chain_goldens.py, authoring container only.
+
+xarray is not installable here, so the reference's array-level methods (calibrate/range.py,
+CalibrateEK._cal_power_samples, CalibrateAZFP._cal_power_samples) cannot run as they are.  Their
+bodies are plain arithmetic on labelled arrays; this shim gives them exactly that: arrays that
+broadcast BY DIMENSION NAME (result dims = dims of the left operand, then the new ones of the right,
+as xarray orders them), NumPy ufuncs applied element-wise, ``where`` / ``isnull`` / ``isel`` /
+``transpose`` / boolean selection along one dimension.  Label alignment is emulated only where the
+reference relies on it (inner join of a channel subset, range.py:199); otherwise operands that share
+a dimension must share its length (asserted).
+It is deliberately small and strict: anything the reference calls that is not implemented raises
+AttributeError, so a silent semantic difference cannot slip in.
+"""
+import numpy as np
+
+__all__ = ["DataArray", "Dataset", "where", "merge", "apply_ufunc"]
+
+
+def _as_da(x):
+    return x if isinstance(x, DataArray) else None
+
+
+class _Coords(dict):
+    pass
+
+
+class DataArray:
+    __array_priority__ = 1000
+
+    def __init__(self, data=None, coords=None, dims=None, name=None, attrs=None):
+        if isinstance(data, DataArray):
+            dims = data.dims if dims is None else dims
+            coords = data.coords if coords is None else coords
+            name = data.name if name is None else name
+            attrs = data.attrs if attrs is None else attrs
+            data = data.data
+        self.data = np.asarray(data)
+        if dims is None:
+            if isinstance(coords, (list, tuple)) and coords and isinstance(coords[0], tuple):
+                dims = [c[0] for c in coords]
+            elif isinstance(coords, dict) and self.data.ndim == len(coords):
+                dims = list(coords)
+            else:
+                dims = [f"dim_{i}" for i in range(self.data.ndim)]
+        if isinstance(dims, str):
+            dims = [dims]
+        self.dims = tuple(dims)
+        assert len(self.dims) == self.data.ndim, (self.dims, self.data.shape)
+        self.coords = _Coords()
+        if isinstance(coords, dict):
+            for k, v in coords.items():
+                v = v.data if isinstance(v, DataArray) else (v[1] if isinstance(v, tuple) else v)
+                self.coords[k] = np.asarray(v)
+        self.name = name
+        self.attrs = dict(attrs or {})
+
+    # ---- basic protocol
+    @property
+    def values(self):
+        return self.data
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    @property
+    def ndim(self):
+        return self.data.ndim
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def sizes(self):
+        return dict(zip(self.dims, self.data.shape))
+
+    def __len__(self):
+        return self.data.shape[0]
+
+    def __array__(self, dtype=None, copy=None):
+        return self.data.astype(dtype) if dtype is not None else self.data
+
+    def __repr__(self):
+        return f"<shim.DataArray {self.name!r} {self.sizes}>"
+
+    def compute(self):
+        return self
+
+    def copy(self):
+        return DataArray(self.data.copy(), dict(self.coords), self.dims, self.name, dict(self.attrs))
+
+    def astype(self, dt):
+        return self._like(self.data.astype(dt))
+
+    def _like(self, data, dims=None):
+        dims = self.dims if dims is None else tuple(dims)
+        return DataArray(data, {k: v for k, v in self.coords.items() if k in dims and np.ndim(v) == 1}, dims, self.name,
+                         self.attrs)
+
+    # ---- broadcasting by dimension name
+    def _expand(self, dims_out):
+        perm = [self.dims.index(d) for d in dims_out if d in self.dims]
+        a = np.transpose(self.data, perm)
+        idx = tuple(slice(None) if d in self.dims else None for d in dims_out)
+        return a[idx]
+
+    @staticmethod
+    def _union(a, b):
+        dims = list(a.dims) + [d for d in b.dims if d not in a.dims]
+        sa, sb = a.sizes, b.sizes
+        for d in dims:
+            if d in sa and d in sb:
+                assert sa[d] == sb[d], f"dimension {d!r}: {sa[d]} vs {sb[d]} (no label alignment in the shim)"
+        return dims
+
+    @staticmethod
+    def _align(a, b):
+        """xarray's default inner join, only for a shared dimension whose lengths differ and whose
+        labels both operands carry (range.py:199: all channels vs the GPT channels)."""
+        for d in a.dims:
+            if d in b.dims and a.sizes[d] != b.sizes[d]:
+                la, lb = list(a.coords[d]), list(b.coords[d])
+                common = [x for x in la if x in lb]
+                a = a.isel(**{d: np.array([la.index(x) for x in common])})
+                b = b.isel(**{d: np.array([lb.index(x) for x in common])})
+        return a, b
+
+    def _binary(self, other, f, reflexive=False):
+        o = _as_da(other)
+        if o is None:
+            if isinstance(other, np.ndarray) and other.ndim > 0:
+                raise TypeError("unlabelled ndarray operand")
+            r = f(other, self.data) if reflexive else f(self.data, other)
+            return self._like(r)
+        self, o = DataArray._align(self, o)
+        dims = self._union(self, o) if not reflexive else self._union(o, self)
+        x, y = self._expand(dims), o._expand(dims)
+        r = f(y, x) if reflexive else f(x, y)
+        coords = {**{k: v for k, v in o.coords.items() if np.ndim(v) == 1},
+                  **{k: v for k, v in self.coords.items() if np.ndim(v) == 1}}
+        return DataArray(r, {k: v for k, v in coords.items() if k in dims}, dims)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kw):
+        if method != "__call__" or kw.get("out") is not None:
+            return NotImplemented
+        if len(inputs) == 1:
+            return self._like(ufunc(self.data, **kw))
+        if len(inputs) == 2:
+            a, b = inputs
+            if a is self:
+                return self._binary(b, lambda x, y: ufunc(x, y, **kw))
+            return self._binary(a, lambda x, y: ufunc(x, y, **kw), reflexive=True)
+        return NotImplemented
+
+
+def _op(name, f):
+    def fwd(self, other):
+        return self._binary(other, f)
+
+    def rev(self, other):
+        return self._binary(other, f, reflexive=True)
+
+    setattr(DataArray, f"__{name}__", fwd)
+    setattr(DataArray, f"__r{name}__", rev)
+
+
+for _n, _f in (("add", np.add), ("sub", np.subtract), ("mul", np.multiply), ("truediv", np.true_divide),
+               ("pow", np.power)):
+    _op(_n, _f)
+for _n, _f in (("gt", np.greater), ("lt", np.less), ("ge", np.greater_equal), ("le", np.less_equal),
+               ("eq", np.equal), ("ne", np.not_equal), ("and", np.logical_and), ("or", np.logical_or)):
+    setattr(DataArray, f"__{_n}__", (lambda f: lambda self, other: self._binary(other, f))(_f))
+DataArray.__hash__ = None
+DataArray.__neg__ = lambda self: self._like(-self.data)
+DataArray.__invert__ = lambda self: self._like(~self.data)
+DataArray.__contains__ = lambda self, v: bool(np.any(self.data == v))
+
+
+def _methods():
+    def isnull(self):
+        return self._like(np.isnan(self.data))
+
+    def where(self, cond, other=np.nan):
+        c = cond if isinstance(cond, DataArray) else DataArray(cond, dims=self.dims)
+        dims = DataArray._union(self, c)
+        r = np.where(c._expand(dims), self._expand(dims), other)
+        return self._like(r, dims)
+
+    def transpose(self, *dims):
+        dims = [d for d in dims if d in self.dims] + [d for d in self.dims if d not in dims]
+        return self._like(np.transpose(self.data, [self.dims.index(d) for d in dims]), dims)
+
+    def isel(self, **ix):
+        a, dims = self.data, list(self.dims)
+        coords = {k: v for k, v in self.coords.items() if np.ndim(v) == 1}
+        for d, i in ix.items():
+            ax = dims.index(d)
+            a = a[(slice(None),) * ax + (i,)]
+            if d in coords:
+                coords[d] = coords[d][i]
+            if not isinstance(i, slice) and np.ndim(i) == 0:  # integer index drops the dimension
+                dims.pop(ax)
+                coords.pop(d, None)
+        return DataArray(a, coords, dims, self.name, self.attrs)
+
+    def drop_vars(self, names, errors="raise"):
+        names = [names] if isinstance(names, str) else names
+        out = self.copy()
+        for n in names:
+            out.coords.pop(n, None)
+        return out
+
+    def squeeze(self):
+        keep = [d for d, n in self.sizes.items() if n != 1]
+        return self._like(self.data.reshape([self.sizes[d] for d in keep]), keep)
+
+    def to_dataset(self):
+        ds = Dataset()
+        ds[self.name] = self
+        return ds
+
+    def getitem(self, key):
+        if isinstance(key, str):
+            return DataArray(self.coords[key], dims=[key], name=key)
+        k = _as_da(key)
+        if k is not None and k.data.dtype == bool and k.ndim == 1:  # boolean selection along its dimension
+            ax = self.dims.index(k.dims[0])
+            out = np.compress(k.data, self.data, axis=ax)
+            coords = {c: (v[k.data] if c == k.dims[0] else v) for c, v in self.coords.items() if np.ndim(v) == 1}
+            return DataArray(out, coords, self.dims, self.name, self.attrs)
+        raise NotImplementedError(f"DataArray[{key!r}]")
+
+    def setitem(self, key, value):
+        k = _as_da(key)
+        if k is not None and k.data.dtype == bool and k.ndim == 1:
+            ax = self.dims.index(k.dims[0])
+            v = value.data if isinstance(value, DataArray) else np.asarray(value)
+            idx = (slice(None),) * ax + (k.data,)
+            self.data = self.data.copy()
+            self.data[idx] = v
+            return
+        raise NotImplementedError(f"DataArray[{key!r}] = ...")
+
+    def sel(self, **ix):
+        out = self
+        for d, k in ix.items():
+            k = _as_da(k)
+            if k is None or k.data.dtype != bool:
+                raise NotImplementedError("sel: boolean DataArray indexers only")
+            out = out.isel(**{d: np.flatnonzero(k.data)})
+        return out
+
+    class _Loc:
+        def __init__(self, da):
+            self.da = da
+
+        def __setitem__(self, key, value):
+            (d, k), = key.items()
+            idx = np.flatnonzero(_as_da(k).data)
+            v = value.transpose(*self.da.dims).data if isinstance(value, DataArray) else value
+            ax = self.da.dims.index(d)
+            self.da.data = self.da.data.copy()
+            self.da.data[(slice(None),) * ax + (idx,)] = v
+
+    def mean(self, dim=None):
+        ax = self.dims.index(dim)
+        return self._like(self.data.mean(axis=ax), [d for d in self.dims if d != dim])
+
+    def fillna(self, v):
+        return self._like(np.where(np.isnan(self.data), v, self.data))
+
+    def iterate(self):
+        assert self.ndim == 1
+        for i in range(self.data.shape[0]):
+            yield DataArray(self.data[i], dims=[], name=self.name)
+
+    for f in (isnull, where, transpose, isel, drop_vars, squeeze, to_dataset, sel, mean, fillna):
+        setattr(DataArray, f.__name__, f)
+    DataArray.__iter__ = iterate
+    DataArray.size = property(lambda self: int(self.data.size))
+    DataArray.chunks = None
+    DataArray.loc = property(lambda self: _Loc(self))
+    DataArray.__getitem__ = getitem
+    DataArray.__setitem__ = setitem
+
+
+_methods()
+
+
+class Dataset:
+    def __init__(self, data_vars=None, coords=None, attrs=None):
+        self._vars = {}
+        self.coords = {}
+        self.attrs = dict(attrs or {})
+        for k, v in (coords or {}).items():
+            self.coords[k] = np.asarray(v.data if isinstance(v, DataArray) else v)
+        for k, v in (data_vars or {}).items():
+            self[k] = v
+
+    def __setitem__(self, name, v):
+        if isinstance(v, tuple):
+            v = DataArray(v[1], dims=v[0])
+        if not isinstance(v, DataArray):
+            v = DataArray(v, dims=[] if np.ndim(v) == 0 else None)
+        v = DataArray(v, name=name)
+        for d, n in v.sizes.items():
+            if d in self.coords:
+                assert len(self.coords[d]) == n, (name, d)
+            elif d in v.coords:
+                self.coords[d] = v.coords[d]
+        self._vars[name] = v
+
+    def __getitem__(self, name):
+        if name in self._vars:
+            v = self._vars[name]
+            return DataArray(v.data, {d: self.coords[d] for d in v.dims if d in self.coords}, v.dims, name, v.attrs)
+        if name in self.coords:
+            return DataArray(self.coords[name], {name: self.coords[name]}, [name], name)
+        raise KeyError(name)
+
+    def __contains__(self, name):
+        return name in self._vars or name in self.coords
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
+
+    @property
+    def sizes(self):
+        out = {k: len(v) for k, v in self.coords.items()}
+        for v in self._vars.values():
+            out.update(v.sizes)
+        return out
+
+    @property
+    def data_vars(self):
+        return self._vars
+
+    def merge(self, other):
+        out = Dataset(coords=self.coords, attrs=self.attrs)
+        for k, v in self._vars.items():
+            out[k] = v
+        others = other.data_vars.items() if isinstance(other, Dataset) else [(other.name, other)]
+        for k, v in others:
+            out[k] = v
+        return out
+
+
+def where(cond, x, y):
+    """xr.where for operands with the same SET of dims as the condition (or scalars)."""
+    c = cond if isinstance(cond, DataArray) else DataArray(cond)
+
+    def conform(o):
+        if not isinstance(o, DataArray):
+            return o
+        assert set(o.dims) == set(c.dims), (o.dims, c.dims)
+        return o.transpose(*c.dims).data
+
+    xd, yd = conform(x), conform(y)
+    return c._like(np.where(c.data, xd, yd))
+
+
+def apply_ufunc(func, da, input_core_dims=None, output_core_dims=None, vectorize=False, **kw):
+    """xr.apply_ufunc(vectorize=True) for ONE input: core dims moved last, ``func`` called on every
+    core-dim slab, output dims = loop dims + output core dims (ek80_complex.py:356-364)."""
+    core = list(input_core_dims[0])
+    assert vectorize and list(output_core_dims[0]) == core
+    loop = [d for d in da.dims if d not in core]
+    a = da.transpose(*(loop + core)).data
+    out = None
+    for idx in np.ndindex(*a.shape[:len(loop)]):
+        r = np.asarray(func(a[idx]))
+        if out is None:
+            out = np.empty(a.shape, dtype=r.dtype)
+        out[idx] = r
+    return da._like(out, loop + core)
+
+
+def merge(objs, **kw):
+    out = Dataset()
+    for o in objs:
+        out = out.merge(o)
+    return out

@@ -484,3 +484,47 @@ def test_remove_background_noise_reference_kat(ep):
         ep.clean.remove_background_noise(ds, 2, 5, SNR_threshold=3.0)
     with pytest.raises(ValueError):
         ep.clean.remove_background_noise(ds, 2, 5, background_noise_max="-125")
+
+
+# ------------------------------------------------------------ goldens from the reference's own methods
+def test_power_chains_match_reference_method_goldens(ep):
+    """The HIP path against tests/golden/ref_chain_goldens.npz: Sv / TS / echo_range produced by the
+    reference's own compute_range_EK / range_mod_TVG_EK / compute_range_AZFP / _cal_power_samples
+    (executed over a named-dimension shim by oracle/gen_chain_goldens.py) -- EK60, EK80 power with a GPT
+    channel, AZFP."""
+    import os
+
+    import torch
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_chain_goldens.npz"))
+    ops = ep.ops
+    dev = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).cuda().to(dt)  # noqa: E731
+    for tag, sonar in (("ek60", "EK60"), ("ek80p", "EK80")):
+        gpt = dev(g[f"{tag}_is_gpt"].astype(np.uint8), torch.uint8) if sonar == "EK80" else None
+        for cal in ("Sv", "TS"):
+            coef = ops.power_coef_ek(
+                dev(g[f"{tag}_sample_interval"]), dev(g[f"{tag}_tau"]), dev(g[f"{tag}_transmit_power"]),
+                dev(g[f"{tag}_sound_speed"]), dev(g[f"{tag}_absorption"]), dev(g[f"{tag}_gain"]), dev(g[f"{tag}_sa"]),
+                dev(g[f"{tag}_psi"]), dev(g[f"{tag}_frequency"]), dev(g[f"{tag}_tau_effective"]), sonar=sonar,
+                cal_type=cal, gpt=gpt)
+            out, rng = ops.sv_power(dev(g[f"{tag}_raw"], torch.float32), coef, cal_type=cal)
+            close(out.cpu().numpy(), g[f"{tag}_{cal}"], 1e-9, f"{tag} {cal}")
+            np.testing.assert_array_equal(rng.cpu().numpy(), g[f"{tag}_echo_range"])
+    # AZFP through the Dataset API with the golden's parameters as user env / cal params
+    C, P, S = g["azfp_counts"].shape
+    t = np.datetime64("2026-05-01T00:00:00", "ns") + np.arange(P) * np.timedelta64(2, "s")
+    d = dict(backscatter_r=g["azfp_counts"].astype(np.float32), frequency_nominal=np.array([38e3, 125e3, 200e3])[:C],
+             channel=[f"ch{i}" for i in range(C)], transmit_duration_nominal=np.tile(g["azfp_tau"][:, None], (1, P)),
+             number_of_samples_per_average_bin=g["azfp_N"], digitization_rate=g["azfp_f"], lock_out_index=g["azfp_L"],
+             EL=g["azfp_EL"], DS=g["azfp_DS"], TVR=g["azfp_TVR"], VTX0=g["azfp_VTX0"], Sv_offset=g["azfp_Sv_offset"],
+             equivalent_beam_angle=g["azfp_equivalent_beam_angle"], temperature=np.full(P, 8.0), ping_time=t)
+    ed = ep.echodata.from_azfp_arrays(d)
+    env = {"salinity": 30.0, "pressure": 50.0,
+           "sound_speed": ep.DataArray(np.tile(g["azfp_sound_speed"], (C, 1)), ("channel", "ping_time"),
+                                       {"channel": d["channel"], "ping_time": t}),
+           "sound_absorption": ep.DataArray(g["azfp_absorption"], ("channel",), {"channel": d["channel"]})}
+    for cal in ("Sv", "TS"):
+        fn = ep.calibrate.compute_Sv if cal == "Sv" else ep.calibrate.compute_TS
+        ds = fn(ed, env_params=env)
+        close(ds[cal].values, g[f"azfp_{cal}"], 1e-9, f"AZFP {cal}")
+        close(ds["echo_range"].values, g[f"azfp_echo_range_{cal}"], 1e-13, f"AZFP echo_range {cal}")

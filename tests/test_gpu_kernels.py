@@ -541,3 +541,60 @@ def test_fused_chain_equals_the_four_separate_kernels(env, dtype, closed, few_bi
         exp_m, _, _ = ogrid.compute_MVBS(exp_c, er, d["ping_time"], "1m", "20s")
         _assert_close(res["Sv_corrected"].cpu().numpy(), exp_c, 1e-9, "oracle Sv_corrected")
         _assert_close(res["MVBS"].cpu().numpy(), exp_m, 1e-9, "oracle MVBS")
+
+
+# ---- EK80 complex kernels against the reference's own _cal_complex_samples outputs ---------------------
+@pytest.mark.parametrize("tag,wf", [("ek80bb", "BB"), ("ek80cw", "CW")])
+@pytest.mark.parametrize("method", ["direct", "fft"])
+def test_sv_complex_matches_reference_method_goldens(env, tag, wf, method):
+    """epa_sv_complex / epa_sv_complex_fft on the inputs of tests/golden/ref_chain_goldens.npz vs the Sv / TS the
+    reference's CalibrateEK80._cal_complex_samples produced for them (oracle/gen_chain_goldens.py)."""
+    import os
+
+    torch, ops, synth = env
+    from echopype_amd import _lib
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_chain_goldens.npz"))
+    C, P, S, B = g[f"{tag}_re"].shape
+    reps = [g[f"{tag}_replica{i}"] for i in range(C)]
+    cw, si, pt = g[f"{tag}_sound_speed"], g[f"{tag}_sample_interval"], g[f"{tag}_transmit_power"]
+    tau = np.tile(g[f"{tag}_tau"][:, None], (1, P))
+    lam = cw / g[f"{tag}_f_center"][:, None]
+    gain = g[f"{tag}_gain"]
+    if wf == "BB":
+        gain = gain - ocal.b_theta_phi_m(g[f"{tag}_angle_offset_alongship"], g[f"{tag}_angle_offset_athwartship"],
+                                         g[f"{tag}_beamwidth_alongship"], g[f"{tag}_beamwidth_athwartship"])[:, None]
+    z_er, z_et = 5400.0, 75.0
+    for cal in ("Sv", "TS"):
+        cc = np.zeros((C, P, _lib.NCCOEF))
+        cc[..., _lib.CC_RA], cc[..., _lib.CC_RB] = si, cw / 2
+        cc[..., _lib.CC_SHIFT], cc[..., _lib.CC_ALPHA2] = cw * tau / 4, 2 * g[f"{tag}_absorption"]
+        cc[..., _lib.CC_PSCALE] = B / 8.0 * (abs(z_er + z_et) / z_er) ** 2 / z_et
+        if cal == "Sv":
+            A = (-10 * np.log10(lam**2 * pt * cw / (32 * np.pi**2)) - 2 * gain
+                 - 10 * np.log10(g[f"{tag}_tau_effective"])[:, None] - g[f"{tag}_psi"][:, None])
+            if wf == "CW":
+                A = A - 2 * g[f"{tag}_sa"]
+        else:
+            A = -10 * np.log10(lam**2 * pt / (16 * np.pi**2)) - 2 * gain
+        cc[..., _lib.CC_A] = A
+        kw = {}
+        if wf == "BB":
+            rep = np.concatenate(reps).astype(np.complex64)
+            kw = dict(replica=_dev(torch, np.stack([rep.real, rep.imag], axis=1).astype(np.float32).reshape(-1)),
+                      replica_off=_dev(torch, np.cumsum([0] + [r.size for r in reps]).astype(np.int32)),
+                      max_taps=max(r.size for r in reps), method=method)
+        elif method == "fft":
+            continue  # CW has no replica
+        res = ops.sv_complex(_dev(torch, g[f"{tag}_re"]), _dev(torch, g[f"{tag}_im"]), _dev(torch, cc), cal_type=cal, **kw)
+        got, exp = res["out"].cpu().numpy(), g[f"{tag}_{cal}"]
+        np.testing.assert_array_equal(res["echo_range"].cpu().numpy(), g[f"{tag}_echo_range"])
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+        ok = ~np.isnan(exp)
+        if wf == "CW":
+            np.testing.assert_allclose(got[ok], exp[ok], rtol=1e-11, atol=1e-10)
+        else:  # the reference's pulse-compressed samples are complex64 (ek80_complex.py:304)
+            peak = np.nanmax(np.where(ok, exp, -np.inf), axis=2, keepdims=True)
+            strong = ok & (exp > peak - 60)
+            assert np.abs(got[strong] - exp[strong]).max() < 2e-4
+            assert np.abs(got[ok] - exp[ok]).max() < 0.5
