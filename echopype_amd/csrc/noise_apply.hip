@@ -29,10 +29,10 @@ __global__ __launch_bounds__(epa::kBlock) void noise_apply_kernel(
 #pragma unroll
   for (int g = 0; g < NSEG; ++g)
     s0[g] = VEC ? LM::first(blockIdx.y * 1024, g) : (int)(blockIdx.y * epa::kBlock + threadIdx.x);
-  if (s0[0] >= S) return;
   // optional by-product: NaN-skipping min / max of both outputs (actual_range, clean/utils.py:392-395)
   double mm[4] = {__builtin_inf(), -__builtin_inf(), __builtin_inf(), -__builtin_inf()};
-  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+  // lanes beyond the row stay alive for the wavefront reduction below (no early return)
+  for (long long row = blockIdx.x; row < rows && s0[0] < S; row += gridDim.x) {
     const int c = (int)(row / P), p = (int)(row - (long long)c * P);
     const T nb = (T)noise[(size_t)c * n_pblocks + p / ping_num];
     const T a2 = (T)alpha2[row];

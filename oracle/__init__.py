@@ -21,7 +21,9 @@ Pinning status (see DESIGN.md "Oracle"):
     named-dimension array shim (oracle/xr_shim.py, oracle/gen_chain_goldens.py ->
     tests/golden/ref_chain_goldens.npz); the noise-mask leaf functions likewise
     (oracle/gen_mask_goldens.py -> tests/golden/ref_mask_goldens.npz);
-  * noise removal and MVBS / NASC (xarray coarsen, flox group-bys) cannot be executed from
+  * noise removal likewise: the reference's own estimate / remove_background_noise run over
+    the shim (oracle/gen_noise_goldens.py -> tests/golden/ref_noise_goldens.npz);
+  * MVBS / NASC (flox group-bys) cannot be executed from
     the reference here, so they are pinned against the reference's synthetic
     known-answer tests restated in tests/test_oracle_kat.py, test_oracle_masks.py,
     test_oracle_nasc.py (noise seed-1 => 6 NaNs, pulse-length lookup tables, MVBS

@@ -271,13 +271,98 @@ def _methods():
     def fillna(self, v):
         return self._like(np.where(np.isnan(self.data), v, self.data))
 
+    def _reduce(self, f, dim):
+        if dim is None:
+            return DataArray(f(self.data, axis=None), dims=[])
+        ax = self.dims.index(dim)
+        return self._like(f(self.data, axis=ax), [d for d in self.dims if d != dim])
+
+    def amin(self, dim=None, skipna=True):  # xarray skips NaN for float data by default
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            return self._reduce(np.nanmin if skipna else np.min, dim)
+
+    def amax(self, dim=None, skipna=True):
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            return self._reduce(np.nanmax if skipna else np.max, dim)
+
+    def assign_coords(self, **kw):
+        out = self.copy()
+        for k, v in kw.items():
+            out.coords[k] = np.asarray(v.data if isinstance(v, DataArray) else v)
+            assert k not in out.dims or len(out.coords[k]) == out.sizes[k]
+        return out
+
+    def reindex(self, indexers, method=None):
+        """Forward-fill reindex along one sorted integer coordinate (clean/api.py:425-428)."""
+        (dim, target), = indexers.items()
+        assert method == "ffill"
+        src = np.asarray(self.coords[dim])
+        tgt = np.asarray(target.data if isinstance(target, DataArray) else target)
+        pos = np.searchsorted(src, tgt, side="right") - 1
+        ax = self.dims.index(dim)
+        out = np.take(self.data, np.clip(pos, 0, None), axis=ax).astype(float)
+        out[(slice(None),) * ax + (pos < 0,)] = np.nan
+        res = self._like(out)
+        res.coords[dim] = tgt
+        return res
+
+    class _Coarsen:
+        def __init__(self, da, windows, boundary):
+            assert boundary == "pad"
+            self.da, self.windows = da, windows
+
+        def mean(self, skipna=True):
+            """All window axes are reduced TOGETHER (xarray reshapes every coarsened dimension into
+            (blocks, window) and reduces over the window axes at once): a NaN-skipping mean over the 2-D
+            block, not a mean of per-row means."""
+            import warnings
+
+            a, dims = self.da.data.astype(float), self.da.dims
+            shape, red = [], []
+            for ax, d in enumerate(dims):
+                n = self.windows.get(d)
+                if n is None:
+                    shape.append(a.shape[ax])
+                    continue
+                padn = (-a.shape[ax]) % n
+                if padn:  # boundary="pad": NaN padding up to a whole number of windows
+                    pad = [(0, 0)] * a.ndim
+                    pad[ax] = (0, padn)
+                    a = np.pad(a, pad, constant_values=np.nan)
+                shape += [a.shape[ax] // n, n]
+                red.append(len(shape) - 1)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                a = (np.nanmean if skipna else np.mean)(a.reshape(shape), axis=tuple(red))
+            out = DataArray(a, dims=dims)
+            for d in dims:  # labels of a coarsened dimension are replaced by the caller (assign_coords)
+                if d in self.windows:
+                    out.coords[d] = np.arange(a.shape[dims.index(d)])
+                elif d in self.da.coords:
+                    out.coords[d] = self.da.coords[d]
+            return out
+
+    def coarsen(self, boundary="exact", **windows):
+        return _Coarsen(self, windows, boundary)
+
+    def pipe(self, f, *a, **k):
+        return f(self, *a, **k)
+
     def iterate(self):
         assert self.ndim == 1
         for i in range(self.data.shape[0]):
             yield DataArray(self.data[i], dims=[], name=self.name)
 
-    for f in (isnull, where, transpose, isel, drop_vars, squeeze, to_dataset, sel, mean, fillna):
+    for f in (isnull, where, transpose, isel, drop_vars, squeeze, to_dataset, sel, mean, fillna, _reduce, assign_coords,
+              reindex, coarsen, pipe):
         setattr(DataArray, f.__name__, f)
+    DataArray.min, DataArray.max = amin, amax
     DataArray.__iter__ = iterate
     DataArray.size = property(lambda self: int(self.data.size))
     DataArray.chunks = None
@@ -341,6 +426,12 @@ class Dataset:
     @property
     def data_vars(self):
         return self._vars
+
+    def assign_attrs(self, attrs=None, **kw):
+        out = Dataset(coords=self.coords, attrs={**self.attrs, **(attrs or {}), **kw})
+        for k, v in self._vars.items():
+            out[k] = v
+        return out
 
     def merge(self, other):
         out = Dataset(coords=self.coords, attrs=self.attrs)

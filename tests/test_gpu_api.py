@@ -528,3 +528,26 @@ def test_power_chains_match_reference_method_goldens(ep):
         ds = fn(ed, env_params=env)
         close(ds[cal].values, g[f"azfp_{cal}"], 1e-9, f"AZFP {cal}")
         close(ds["echo_range"].values, g[f"azfp_echo_range_{cal}"], 1e-13, f"AZFP echo_range {cal}")
+
+
+@pytest.mark.parametrize("tag", ["n0", "n1", "n2"])
+def test_remove_background_noise_matches_reference_function_goldens(ep, tag):
+    """clean.remove_background_noise against tests/golden/ref_noise_goldens.npz = outputs of the reference's own
+    estimate_background_noise / remove_background_noise (oracle/gen_noise_goldens.py)."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_noise_goldens.npz"))
+    ping_num, rsn, nmax, snr = g[f"{tag}_args"]
+    sv = g[f"{tag}_Sv"]
+    C, P, S = sv.shape
+    t = np.datetime64("2026-05-01T00:00:00", "ns") + np.arange(P) * np.timedelta64(1, "s")
+    ds = sv_dataset(ep, dict(Sv=sv, echo_range=g[f"{tag}_echo_range"], ping_time=t),
+                    {"sound_absorption": (("channel", "ping_time"), g[f"{tag}_absorption"])})
+    kw = dict(background_noise_max=None if np.isnan(nmax) else f"{nmax}dB", SNR_threshold=f"{snr}dB")
+    est = ep.clean.estimate_background_noise(ds, int(ping_num), int(rsn), background_noise_max=kw["background_noise_max"])
+    close(est.values, g[f"{tag}_Sv_noise"], 1e-11, "estimate_background_noise")
+    out = ep.clean.remove_background_noise(ds, int(ping_num), int(rsn), **kw)
+    close(out["Sv_noise"].values, g[f"{tag}_Sv_noise"], 1e-11, "Sv_noise")
+    close(out["Sv_corrected"].values, g[f"{tag}_Sv_corrected"], 1e-9, "Sv_corrected")
+    got_rng = out["Sv_noise"].attrs["actual_range"] + out["Sv_corrected"].attrs["actual_range"]
+    np.testing.assert_allclose(got_rng, g[f"{tag}_noise_attrs_range"], atol=0.011)  # rounded to 2 decimals
