@@ -67,10 +67,10 @@ def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="
         rmax = hi
     else:
         rmax = _parse_x_bin(range_var_max) + 1e-8
-    r_edges = np.arange(0, rmax + range_bin_m, range_bin_m)
-    n_r = len(r_edges) - 1
-    if n_r < 1:
+    if not np.isfinite(rmax):
         raise ValueError("range bins are empty: the range variable holds no valid values")
+    r_edges = np.arange(0, rmax + range_bin_m, range_bin_m)
+    n_r = len(r_edges) - 1  # 0 when the only valid range is 0 (one sample per ping): an empty grid, as in the reference
 
     # NaN coordinates are not aggregated (utils.py:595-608: same warning text)
     ping_time = np.asarray(ds_Sv["ping_time"].values).astype("datetime64[ns]")
@@ -89,10 +89,13 @@ def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="
         ns = ns[order_idx]
     bin_start = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t, closed=closed)
 
-    res = ops.mvbs(sv_t, bin_start, n_t, range_bin_m, n_r, range=rg_t, skipna=skipna, closed=closed,
-                   fill_value=fill_value, ping_perm=perm)
+    if n_r == 0:
+        mvbs_t = torch.empty((C, n_t, 0), dtype=sv_t.dtype, device=sv_t.device)
+    else:
+        mvbs_t = ops.mvbs(sv_t, bin_start, n_t, range_bin_m, n_r, range=rg_t, skipna=skipna, closed=closed,
+                          fill_value=fill_value, ping_perm=perm)["MVBS"]
 
-    return _assemble_mvbs(ds_Sv, res["MVBS"], dim_0, ping_time, e0, dt, n_t, r_edges, range_var, range_bin_m,
+    return _assemble_mvbs(ds_Sv, mvbs_t, dim_0, ping_time, e0, dt, n_t, r_edges, range_var, range_bin_m,
                           ping_time_bin, closed)
 
 

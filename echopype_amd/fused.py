@@ -65,7 +65,10 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
     r_cap = float(np.nanmax((S - 1) * rows[..., 0] * rows[..., 1] + rows[..., 2]))
     if range_var_max is not None:
         r_cap = _parse_x_bin(range_var_max) + 1e-8
-    n_cap = len(np.arange(0, r_cap + range_bin_m, range_bin_m)) - 1
+    n_cap = len(np.arange(0, r_cap + range_bin_m, range_bin_m)) - 1 if np.isfinite(r_cap) else 0
+    if n_cap < 1:  # degenerate grid (one sample per ping, no valid range): the two calls deal with it
+        ds_Sv = _compute_cal("Sv", echodata, **cal_kw)
+        return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)
     try:
         res = ops.sv_mvbs_fused(raw, coef, bin_start, n_t, range_bin_m, n_cap, cal_flags=flags, skipna=True,
                                 closed="left", fill_value=fill_value, dtype=cal.dtype, want_range_max=True)
@@ -73,6 +76,9 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
         ds_Sv = _compute_cal("Sv", echodata, **cal_kw)
         return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)
     rmax = r_cap if range_var_max is not None else float(res["range_max"].item())
+    if not np.isfinite(rmax):  # no valid echo_range at all
+        ds_Sv = _compute_cal("Sv", echodata, **cal_kw)
+        return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)
     r_edges = np.arange(0, rmax + range_bin_m, range_bin_m)
     n_r = len(r_edges) - 1
     mvbs_t = res["MVBS"][..., :n_r].contiguous() if n_r != n_cap else res["MVBS"]
@@ -161,10 +167,12 @@ def compute_Sv_clean_MVBS(echodata, ping_num, range_sample_num, *, background_no
     bin_start = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t, closed=closed)
     if range_var_max is not None:
         rmax = _parse_x_bin(range_var_max) + 1e-8
+    if not np.isfinite(rmax):
+        return separate_calls()
     r_edges = np.arange(0, rmax + range_bin_m, range_bin_m)
     n_r = len(r_edges) - 1
-    if n_r < 1:
-        raise ValueError("range bins are empty: the range variable holds no valid values")
+    if n_r < 1:  # degenerate grid: the separate calls return the empty MVBS the reference would
+        return separate_calls()
     try:
         res = ops.sv_denoise_mvbs(raw, coef, alpha2, noise, ping_num, float(snr), bin_start, n_t, range_bin_m,
                                   n_r, flags=flags, dtype=cal.dtype, skipna=skipna, closed=closed,

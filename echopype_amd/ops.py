@@ -43,7 +43,10 @@ def to_device(a, dtype=None, device=None):
     if isinstance(a, torch.Tensor):
         t = a
     else:
-        t = torch.from_numpy(np.ascontiguousarray(a))
+        a = np.ascontiguousarray(a)
+        if not a.flags.writeable:  # e.g. a contiguous broadcast view: torch wants a writable buffer
+            a = a.copy()
+        t = torch.from_numpy(a)
     if dtype is not None and t.dtype != dtype:
         t = t.to(dtype)
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
