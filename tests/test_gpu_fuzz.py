@@ -70,3 +70,59 @@ def test_random_shapes_and_flags(ep, seed):
     close(ds3["Sv_corrected"].values, exp_c, 1e-7, "two-pass Sv_corrected")
     exp_mvc, _, _ = ogrid.compute_MVBS(exp_c, er, d["ping_time"], rbin, tbin, skipna=skipna, closed=closed)
     close(mv3["Sv"].values, exp_mvc, 1e-7, "two-pass MVBS")
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_masks_and_nasc(ep, seed):
+    """Noise masks, apply_mask and NASC on random small shapes / window sizes (windows larger than the data,
+    a single ping, odd lengths) against the oracle."""
+    from oracle import masks as omask
+    from oracle import nasc as onasc
+    from test_gpu_masks import _scene
+    from test_gpu_masks_api import _ds
+
+    rng = np.random.default_rng(5000 + seed)
+    C, P, S = int(rng.integers(1, 4)), int(rng.choice([1, 2, 5, 13, 32])), int(rng.choice([2, 7, 30, 65, 128]))
+    sv, depth = _scene(C, P, S, seed, step=float(rng.choice([0.2, 0.5, 1.3])), spikes=P > 2 and S > 8)
+    ds = _ds(ep, sv, depth)
+    n = int(rng.choice([1, 2, 6]))
+    dbin = str(rng.choice(["1m", "2.5m", "40m"]))
+    for index in (True, False):
+        m = ep.clean.mask_impulse_noise(ds, depth_bin=dbin, num_side_pings=n, use_index_binning=index).values
+        np.testing.assert_array_equal(m, omask.mask_impulse_noise(sv, depth, dbin, n, "10.0dB", index))
+    excl = f"{float(rng.choice([0.0, 3.0, 1e4]))}m"
+    func = str(rng.choice(["nanmean", "nanmedian"]))
+    m = ep.clean.mask_transient_noise(ds, func=func, depth_bin=dbin, num_side_pings=n, exclude_above=excl,
+                                      transient_noise_threshold="6.0dB", use_index_binning=True).values
+    f = np.nanmean if func == "nanmean" else np.nanmedian
+    m_c = omask.nsamples_per_bin(depth, float(dbin[:-1]))
+    # scipy's generic_filter (the oracle's engine) stops reflecting correctly once the window is several
+    # times the array (checked against np.pad(mode="symmetric"), which the HIP kernel matches); the
+    # reference's dask_image path cannot take such windows either
+    if 2 * m_c.max() + 1 <= 2 * S and 2 * n + 1 <= 2 * P:
+        pooled = omask.index_binning_pool_Sv(sv, depth, f, float(dbin[:-1]), n, float(excl[:-1]))
+        with np.errstate(invalid="ignore"):
+            margin = sv - pooled - 6.0
+        sure = ~(np.abs(margin) < 1e-9)
+        np.testing.assert_array_equal(m[sure], (margin > 0)[sure])
+    up, lw = sorted(rng.uniform(np.nanmin(depth), np.nanmax(depth), 2))
+    att = ep.clean.mask_attenuated_signal(ds, upper_limit_sl=f"{up:09.3f}m", lower_limit_sl=f"{lw:09.3f}m",
+                                          num_side_pings=n, attenuation_signal_threshold="-3.0dB").values
+    exp_att = omask.mask_attenuated_signal(sv, depth, f"{up:09.3f}m", f"{lw:09.3f}m", n, "-3.0dB")
+    np.testing.assert_array_equal(att, exp_att)
+    out = ep.mask.apply_mask(ds, [ep.DataArray(~att, DIMS3), ep.DataArray(~m, DIMS3)], fill_value=-1.0)
+    np.testing.assert_array_equal(out["Sv"].values, omask.apply_mask(sv, [~exp_att, ~m], -1.0))
+    # NASC on the same scene with a random track
+    lat = 40.0 + np.cumsum(rng.uniform(0, 2e-4, P))
+    lon = -125.0 + np.cumsum(rng.uniform(0, 2e-4, P))
+    ds["latitude"], ds["longitude"] = (("ping_time",), lat), (("ping_time",), lon)
+    if P > 1:
+        closed = str(rng.choice(["left", "right"]))
+        got = ep.commongrid.compute_NASC(ds, range_bin=dbin, dist_bin="0.01nmi", closed=closed)
+        exp = onasc.compute_NASC(sv, depth, lat, lon, ds["ping_time"].values, float(dbin[:-1]), 0.01, closed=closed)
+        g, e = got["NASC"].values, exp["NASC"]
+        np.testing.assert_array_equal(np.isnan(g), np.isnan(e))
+        np.testing.assert_allclose(g[~np.isnan(e)], e[~np.isnan(e)], rtol=1e-10)
+
+
+DIMS3 = ("channel", "ping_time", "range_sample")
