@@ -126,3 +126,32 @@ def test_random_masks_and_nasc(ep, seed):
 
 
 DIMS3 = ("channel", "ping_time", "range_sample")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_ek80_complex(ep, seed):
+    """EK80 complex (BB through the LDS-FFT path over one to several tiles, CW) on random shapes, NaN
+    patterns and output types against the oracle, judged like test_compute_Sv_ek80_bb."""
+    from test_gpu_api import _ek80
+
+    rng = np.random.default_rng(9000 + seed)
+    wf = "BB" if seed % 3 else "CW"
+    P, S = int(rng.choice([1, 3, 6])), int(rng.choice([300, 1200, 1872, 1873, 2500, 4100]))
+    dtype = str(rng.choice(["float64", "float32"]))
+    d, filt = _ek80(ep, wf, C=2, P=P, S=S, mixed_nan=bool(rng.integers(0, 2)), seed=seed)
+    cal = str(rng.choice(["Sv", "TS"]))
+    fn = ep.calibrate.compute_Sv if cal == "Sv" else ep.calibrate.compute_TS
+    ds = fn(ep.echodata.from_ek80_arrays(d, filt), waveform_mode=wf, encode_mode="complex", dtype=dtype)
+    (exp, exp_r, _), _ = oc.ek80_complex(d, filt, cal)
+    got = ds[cal].values.astype(np.float64)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+    fin = np.isfinite(exp)
+    if wf == "CW":
+        close(got, exp, 1e-9 if dtype == "float64" else 1e-3, f"CW {cal}")
+    else:
+        peak = np.nanmax(np.where(fin, exp, -np.inf), axis=2, keepdims=True)
+        strong = fin & (exp > peak - 60)
+        assert np.abs(got[strong] - exp[strong]).max() < (2e-4 if dtype == "float64" else 2e-3)
+        assert np.abs(got[fin] - exp[fin]).max() < 0.5
+    if dtype == "float64":
+        np.testing.assert_array_equal(ds["echo_range"].values, exp_r)
