@@ -30,6 +30,9 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (C, pings per GPU, S)
     "cfg2": (4, 500_000, 2000),
+    # BASELINE configs[2]: the same volume through the WHOLE chain compute_Sv -> remove_background_noise ->
+    # compute_MVBS(Sv_corrected) (two sweeps of the raw power, Sv and Sv_corrected written); not the headline
+    "cfg3": (4, 500_000, 2000),
     "cfg5shard": (4, 250_000, 4096),
     # BASELINE configs[4] in full: 4 x 2 M x 4096 (32.8 G samples, 131 GB raw, 262 GB of Sv) split
     # over the ranks (STRONG scaling) and, per rank, into resident 250 k-ping tiles ("files") whose Sv
@@ -245,7 +248,10 @@ def main():
     n_r = len(np.arange(0, r_max + 1.0, 1.0)) - 1
     straddle = (P % 20) != 0  # shard edges cut a 20-ping bin?
 
-    sv = torch.empty((C, P, S), dtype=dt, device="cuda")
+    chain = args.workload == "cfg3"
+    if chain and (i16 or straddle):
+        sys.exit("cfg3 runs the float32 input on bin-aligned shards")
+    sv = torch.empty((C, P, S), dtype=dt, device="cuda") if not chain else None
     mvbs = torch.empty((C, n_t, n_r), dtype=dt, device="cuda")
     tau0 = d["transmit_duration_nominal"][:, 0].contiguous()  # EK60 tau_eff = ping 0 (per shard = global here)
     timers = [ops.Timer() for _ in range(args.steps)]
@@ -259,7 +265,11 @@ def main():
         bs = ops.time_bin_offsets(ns_local, e0_local, bin_ns, n_t)
         if timer is not None:
             timer.start()
-        if i16:
+        if chain:  # noise blocks of 20 pings x 50 samples, SNR 3 dB
+            a2 = coef[..., 4].contiguous()
+            _, _, nz = ops.sv_noise_fused(d["backscatter_r"], coef, a2, 20, 50, dtype=dt)
+            res = ops.sv_denoise_mvbs(d["backscatter_r"], coef, a2, nz, 20, 3.0, bs, n_t, 1.0, n_r, dtype=dt)
+        elif i16:
             res = ops.sv_mvbs_fused_i16(d["raw_i16"], d["n_valid"], coef, bs, n_t, 1.0, n_r, dtype=dt, sv_out=sv,
                                         mvbs_out=mvbs, want_partials=straddle)
         else:
@@ -299,6 +309,8 @@ def main():
 
     if rank == 0:
         bps = BYTES_PER_SAMPLE[args.dtype] - (2 if i16 else 0)
+        if chain:
+            bps = 2 * BYTES_PER_SAMPLE[args.dtype]  # two sweeps: 4 B in + Sv out, 4 B in + Sv_corrected out
         achieved = C * P * S * bps / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -311,19 +323,23 @@ def main():
             except Exception:  # noqa: BLE001
                 traffic = None
         out = {
-            "metric": "range-samples/sec through compute_Sv->compute_MVBS",
+            "metric": "range-samples/sec through compute_Sv->compute_MVBS" + (
+                " with remove_background_noise" if chain else ""),
             "value": value, "unit": "range-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.dtype == "float64" else "f32",
             "data": "synthetic",
             "config": {"workload": f"EK60 CW {C}ch x {P} pings x {S} range per GPU ({args.workload}), "
-                                   "fused compute_Sv -> compute_MVBS (20 s x 1 m), Sv + MVBS written"
+                                   + ("fused compute_Sv -> compute_MVBS (20 s x 1 m), Sv + MVBS written" if not chain else
+                                      "two-pass compute_Sv -> remove_background_noise (20 x 50, 3 dB) -> compute_MVBS of "
+                                      "Sv_corrected (20 s x 1 m), Sv + Sv_corrected + MVBS written")
                                    + (", int16 instrument samples in" if i16 else ""),
                        "pings_total": P * world, "sharding": f"ping_time x{world}",
                        "collective": "none (shard edges on bin edges)" if not straddle else "edge-bin all-reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "epa_fused::fused_sv_mvbs_kernel", "kernel_ms": kernel_ms,
+                         "kernel": ("epa_chain::sv_noise_fast_kernel + sv_denoise_mvbs_fast_kernel" if chain
+                                    else "epa_fused::fused_sv_mvbs_kernel"), "kernel_ms": kernel_ms,
                          "bytes_per_sample": bps},
         }
         if cpu is not None:
