@@ -153,9 +153,8 @@ def mask_transient_noise(ds_Sv, func="nanmean", depth_bin="10m", num_side_pings=
         if s0 == rg_t.numel():
             s0 = 0
         for c in range(C):
-            _, m = ops.pool_sv(sv_t[c:c + 1], s0, num_side_pings, int(n_c[c]), func=func, threshold=thr,
-                               want_pooled=False)
-            mask[c] = m[0]
+            ops.pool_sv(sv_t[c:c + 1], s0, num_side_pings, int(n_c[c]), func=func, threshold=thr,
+                        want_pooled=False, mask_out=mask[c:c + 1])  # written in place, no copy
     return _mask_da(ds_Sv, mask)
 
 
@@ -177,7 +176,7 @@ def mask_impulse_noise(ds_Sv, depth_bin="5m", num_side_pings=2, impulse_noise_th
         n_c = _samples_per_bin(rg_t, depth_bin)
         up = torch.empty_like(sv_t)
         for c in range(C):
-            up[c] = ops.range_bin_smooth(sv_t[c:c + 1], nper=int(n_c[c]))[0]
+            ops.range_bin_smooth(sv_t[c:c + 1], nper=int(n_c[c]), out=up[c:c + 1])  # in place, no copy
     mask = ops.impulse_mask(up, num_side_pings, thr)
     dims = ("channel", "range_sample", "ping_time")
     return _mask_da(ds_Sv, mask.permute(0, 2, 1).contiguous(), dims)

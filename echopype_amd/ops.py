@@ -322,14 +322,15 @@ class Timer:
 
 # ---- noise masks ------------------------------------------------------------------
 
-def range_bin_smooth(sv, *, nper=None, range=None, r0=0.0, bin=0.0, nbins=0):
+def range_bin_smooth(sv, *, nper=None, range=None, r0=0.0, bin=0.0, nbins=0, out=None):
     """Depth-bin smoothing of mask_impulse_noise -> up-sampled Sv like ``sv``.
     Index mode: ``nper`` samples per bin (one value for all channels of ``sv``).
     Value mode: ``range`` array + bins np.arange(r0, max + bin, bin) (``nbins`` = len(edges) - 1)."""
     C, P, S = sv.shape
     if range is not None and range.dtype != sv.dtype:
         range = range.to(sv.dtype)
-    out = torch.empty_like(sv)
+    if out is None:
+        out = torch.empty_like(sv)
     call("epa_range_bin_smooth", _p(sv), _p(range), C, P, S, int(nper or 0), float(r0), float(bin),
          int(nbins), _p(out), _DT[sv.dtype], _stream())
     return out
@@ -345,12 +346,13 @@ def impulse_mask(up, num_side_pings, threshold):
 
 
 def pool_sv(sv, first_sample, num_side_pings, num_side_samples, func="nanmean", threshold=0.0,
-            want_pooled=True, want_mask=True):
+            want_pooled=True, want_mask=True, mask_out=None):
     """Index-binning pooled Sv (reflect window) and/or the mask Sv - pooled > threshold."""
     C, P, S = sv.shape
     f = {"nanmean": _lib.POOL_NANMEAN, "nanmedian": _lib.POOL_NANMEDIAN}[func]
     pooled = torch.empty_like(sv) if want_pooled else None
-    mask = torch.empty((C, P, S), dtype=torch.uint8, device=sv.device) if want_mask else None
+    mask = (mask_out if mask_out is not None else
+            torch.empty((C, P, S), dtype=torch.uint8, device=sv.device)) if want_mask else None
     ws = wc = None
     if f == _lib.POOL_NANMEAN:
         ws = torch.empty((C, P, S), dtype=torch.float64, device=sv.device)
