@@ -748,7 +748,6 @@ __global__ __launch_bounds__(kBlock) void pool_value_median_kernel(PoolValueArgs
   const epa::MathTabs mt = epa::build_math_tabs(tabs);
   __syncthreads();
   for (long long job = blockIdx.x; job < jobs; job += gridDim.x) {
-    const int s = (int)(job % a.S);
     const long long row = job / a.S;
     const int p = (int)(row % a.P);
     const long long c = row / a.P;
