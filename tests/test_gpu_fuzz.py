@@ -155,3 +155,30 @@ def test_random_ek80_complex(ep, seed):
         assert np.abs(got[fin] - exp[fin]).max() < 0.5
     if dtype == "float64":
         np.testing.assert_array_equal(ds["echo_range"].values, exp_r)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_ping_times(ep, seed):
+    """compute_MVBS on irregular ping cadences: random gaps (empty time bins), bins crossing the midnight
+    anchor, duplicate timestamps, unsorted pings and NaT -- the time-bin edges come from pandas' resample in
+    the oracle, from the host arithmetic of commongrid/utils.py here."""
+    rng = np.random.default_rng(7000 + seed)
+    C, P, S = 2, int(rng.choice([5, 40, 160])), int(rng.choice([16, 200]))
+    d = ep.synth.ek60_numpy(C, P, S, seed=seed)
+    start = np.datetime64("2026-05-01T23:58:30", "ns") + np.timedelta64(int(rng.integers(0, 3600)), "s")
+    gaps = rng.choice([0.0, 0.2, 1.0, 3.7, 45.0, 400.0], size=P, p=[0.05, 0.3, 0.4, 0.15, 0.07, 0.03])
+    t = start + (np.cumsum(gaps) * 1e9).astype("timedelta64[ns]")
+    if seed % 3 == 1:
+        t = t[rng.permutation(P)]  # unsorted
+    sv, er = oc.ek60({**d, "ping_time": t}, "Sv")
+    ds = ep.Dataset(coords={"channel": d["channel"], "ping_time": t, "range_sample": np.arange(S)})
+    dims = ("channel", "ping_time", "range_sample")
+    ds["Sv"], ds["echo_range"] = (dims, sv), (dims, er)
+    tbin = str(rng.choice(["2s", "20s", "1min", "10min", "1h"]))
+    closed = str(rng.choice(["left", "right"]))
+    skipna = bool(rng.integers(0, 2))
+    exp, t_left, r_left = ogrid.compute_MVBS(sv, er, t, "5m", tbin, skipna=skipna, closed=closed)
+    mv = ep.commongrid.compute_MVBS(ds, range_bin="5m", ping_time_bin=tbin, skipna=skipna, closed=closed)
+    np.testing.assert_array_equal(mv["ping_time"].values, t_left)
+    np.testing.assert_array_equal(mv["echo_range"].values, r_left)
+    close(mv["Sv"].values, exp, 1e-9, f"{tbin} closed={closed} skipna={skipna}")
