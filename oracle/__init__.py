@@ -20,7 +20,9 @@ Pinning status (see DESIGN.md "Oracle"):
     against outputs of the reference's OWN calibrator methods, executed over a strict
     named-dimension array shim (oracle/xr_shim.py, oracle/gen_chain_goldens.py ->
     tests/golden/ref_chain_goldens.npz); the noise-mask leaf functions likewise
-    (oracle/gen_mask_goldens.py -> tests/golden/ref_mask_goldens.npz);
+    (oracle/gen_mask_goldens.py -> tests/golden/ref_mask_goldens.npz) and the three mask API
+    functions end to end over the shim (oracle/gen_maskapi_goldens.py ->
+    tests/golden/ref_maskapi_goldens.npz);
   * noise removal likewise: the reference's own estimate / remove_background_noise run over
     the shim (oracle/gen_noise_goldens.py -> tests/golden/ref_noise_goldens.npz);
   * MVBS / NASC (flox group-bys) cannot be executed from

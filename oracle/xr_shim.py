@@ -14,7 +14,7 @@ AttributeError, so a silent semantic difference cannot slip in.
 """
 import numpy as np
 
-__all__ = ["DataArray", "Dataset", "where", "merge", "apply_ufunc"]
+__all__ = ["DataArray", "Dataset", "where", "merge", "apply_ufunc", "concat", "full_like", "zeros_like"]
 
 
 def _as_da(x):
@@ -39,6 +39,8 @@ class DataArray:
         if dims is None:
             if isinstance(coords, (list, tuple)) and coords and isinstance(coords[0], tuple):
                 dims = [c[0] for c in coords]
+            elif isinstance(coords, (list, tuple)) and coords and isinstance(coords[0], DataArray):
+                dims = [c.dims[0] for c in coords]
             elif isinstance(coords, dict) and self.data.ndim == len(coords):
                 dims = list(coords)
             else:
@@ -48,6 +50,8 @@ class DataArray:
         self.dims = tuple(dims)
         assert len(self.dims) == self.data.ndim, (self.dims, self.data.shape)
         self.coords = _Coords()
+        if isinstance(coords, (list, tuple)) and coords and isinstance(coords[0], DataArray):
+            coords = {d: c for d, c in zip(dims, coords)}
         if isinstance(coords, dict):
             for k, v in coords.items():
                 v = v.data if isinstance(v, DataArray) else (v[1] if isinstance(v, tuple) else v)
@@ -59,6 +63,19 @@ class DataArray:
     @property
     def values(self):
         return self.data
+
+    @values.setter
+    def values(self, v):  # replaces the variable's data, no write-through to the array it was sliced from
+        v = np.asarray(v)
+        assert v.shape == self.data.shape
+        self.data = v
+
+    def __bool__(self):
+        assert self.data.size == 1
+        return bool(self.data.reshape(()))
+
+    def chunk(self, *a, **k):
+        return self
 
     @property
     def shape(self):
@@ -233,6 +250,10 @@ def _methods():
         raise NotImplementedError(f"DataArray[{key!r}]")
 
     def setitem(self, key, value):
+        if isinstance(key, dict):  # da[dict(dim=int, ...)] = scalar
+            idx = tuple(key.get(d, slice(None)) for d in self.dims)
+            self.data[idx] = value.data if isinstance(value, DataArray) else value
+            return
         k = _as_da(key)
         if k is not None and k.data.dtype == bool and k.ndim == 1:
             ax = self.dims.index(k.dims[0])
@@ -312,6 +333,22 @@ def _methods():
         res.coords[dim] = tgt
         return res
 
+    def reindex_like(self, other):
+        """Conform to ``other``'s labels along every shared dimension; labels this array lacks become NaN."""
+        out = self
+        for d in self.dims:
+            src, tgt = np.asarray(out.coords[d]), np.asarray(other.coords[d])
+            if len(src) == len(tgt) and np.array_equal(src, tgt):
+                continue
+            pos = {v: i for i, v in enumerate(src.tolist())}
+            take = np.array([pos.get(v, -1) for v in tgt.tolist()])
+            ax = out.dims.index(d)
+            a = np.take(out.data, np.clip(take, 0, None), axis=ax).astype(float)
+            a[(slice(None),) * ax + (take < 0,)] = np.nan
+            out = out._like(a)
+            out.coords[d] = tgt
+        return out
+
     class _Coarsen:
         def __init__(self, da, windows, boundary):
             assert boundary == "pad"
@@ -360,7 +397,7 @@ def _methods():
             yield DataArray(self.data[i], dims=[], name=self.name)
 
     for f in (isnull, where, transpose, isel, drop_vars, squeeze, to_dataset, sel, mean, fillna, _reduce, assign_coords,
-              reindex, coarsen, pipe):
+              reindex, reindex_like, coarsen, pipe):
         setattr(DataArray, f.__name__, f)
     DataArray.min, DataArray.max = amin, amax
     DataArray.__iter__ = iterate
@@ -433,6 +470,23 @@ class Dataset:
             out[k] = v
         return out
 
+    def copy(self):
+        return self.assign_attrs()
+
+    def drop_dims(self, names, errors="raise"):
+        names = [names] if isinstance(names, str) else list(names)
+        out = Dataset(coords={k: v for k, v in self.coords.items() if k not in names}, attrs=self.attrs)
+        for k, v in self._vars.items():
+            if not set(v.dims) & set(names):
+                out[k] = v
+        return out
+
+    def transpose(self, *dims):
+        out = Dataset(coords=self.coords, attrs=self.attrs)
+        for k, v in self._vars.items():
+            out[k] = v.transpose(*[d for d in dims if d in v.dims]) if set(v.dims) <= set(dims) else v
+        return out
+
     def merge(self, other):
         out = Dataset(coords=self.coords, attrs=self.attrs)
         for k, v in self._vars.items():
@@ -457,20 +511,42 @@ def where(cond, x, y):
     return c._like(np.where(c.data, xd, yd))
 
 
-def apply_ufunc(func, da, input_core_dims=None, output_core_dims=None, vectorize=False, **kw):
-    """xr.apply_ufunc(vectorize=True) for ONE input: core dims moved last, ``func`` called on every
-    core-dim slab, output dims = loop dims + output core dims (ek80_complex.py:356-364)."""
+def apply_ufunc(func, *das, input_core_dims=None, output_core_dims=None, vectorize=False, **kw):
+    """xr.apply_ufunc(vectorize=True) for inputs with the SAME dims: core dims moved last, ``func`` called
+    on every core-dim slab, output dims = loop dims + output core dims (ek80_complex.py:356-364,
+    clean/api.py:256-264, 348-357)."""
     core = list(input_core_dims[0])
     assert vectorize and list(output_core_dims[0]) == core
+    assert all(list(c) == core for c in input_core_dims) and all(set(d.dims) == set(das[0].dims) for d in das)
+    da = das[0]
     loop = [d for d in da.dims if d not in core]
-    a = da.transpose(*(loop + core)).data
-    out = None
+    arrs = [d.transpose(*(loop + core)).data for d in das]
+    a, out = arrs[0], None
     for idx in np.ndindex(*a.shape[:len(loop)]):
-        r = np.asarray(func(a[idx]))
+        r = np.asarray(func(*[x[idx] for x in arrs]))
         if out is None:
             out = np.empty(a.shape, dtype=r.dtype)
         out[idx] = r
     return da._like(out, loop + core)
+
+
+def concat(objs, dim):
+    """xr.concat of same-shaped arrays along a NEW leading dimension (clean/utils.py:179, 313)."""
+    first = objs[0]
+    assert dim not in first.dims and all(o.dims == first.dims and o.shape == first.shape for o in objs)
+    for o in objs[1:]:
+        for d in first.dims:
+            assert np.array_equal(o.coords[d], first.coords[d]), d
+    return DataArray(np.stack([o.data for o in objs]), {k: v for k, v in first.coords.items() if np.ndim(v) == 1},
+                     (dim,) + first.dims, first.name, first.attrs)
+
+
+def full_like(da, fill, dtype=None):
+    return da._like(np.full(da.shape, fill, dtype=dtype or da.dtype))
+
+
+def zeros_like(da, dtype=None):
+    return da._like(np.zeros(da.shape, dtype=dtype or da.dtype))
 
 
 def merge(objs, **kw):

@@ -286,3 +286,26 @@ def test_calibrate_mask_apply_mvbs_chain(ep):
     assert agree.mean() > 0.9999  # threshold-margin flips only
     mvbs = ep.commongrid.compute_MVBS(clean, range_var="depth", range_bin="5m", ping_time_bin="20s")
     assert np.isfinite(mvbs["Sv"].values).any()
+
+
+# ------------------------------------------------- the reference's own functions, executed end to end
+@pytest.mark.parametrize("tag", ["tri0", "tri1", "tri2", "trv0", "trv1", "imp0", "imp1", "imp2", "att0", "att1", "att2"])
+def test_mask_api_vs_reference_goldens(ep, tag):
+    """tests/golden/ref_maskapi_goldens.npz holds masks produced by the reference's clean/api.py functions
+    themselves (oracle/gen_maskapi_goldens.py); same call, same keyword strings, same dimension order."""
+    import os
+
+    from test_oracle_masks import API_GOLDEN, _kw
+
+    assert os.path.exists(API_GOLDEN)
+    gold = np.load(API_GOLDEN)
+    sv, er, kw = gold[f"{tag}_Sv"], gold[f"{tag}_echo_range"], _kw(gold, tag)
+    ds = _ds(ep, sv, er, range_name="echo_range")
+    if tag.startswith("tr"):
+        m = ep.clean.mask_transient_noise(ds, range_var="echo_range", use_index_binning=tag.startswith("tri"), **kw)
+    elif tag.startswith("imp"):
+        m = ep.clean.mask_impulse_noise(ds, range_var="echo_range", use_index_binning=True, **kw)
+    else:
+        m = ep.clean.mask_attenuated_signal(ds, range_var="echo_range", **kw)
+    assert list(m.dims) == gold[f"{tag}_dims"].tolist()
+    _same_mask(m.values, gold[f"{tag}_mask"])

@@ -112,3 +112,30 @@ def test_mask_wrappers_shapes_errors_and_apply_mask():
         omask.mask_attenuated_signal(sv, depth, "180.0m", "170.0m")
     out = omask.apply_mask(sv, [~tr, np.ones((12, 30))], fill_value=-1.0)
     np.testing.assert_array_equal(out, np.where(~tr, sv, -1.0))
+
+
+API_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_maskapi_goldens.npz")
+
+
+def _kw(gold, tag):
+    import ast
+
+    return {k: ast.literal_eval(v) for k, v in (s.split("=", 1) for s in gold[f"{tag}_kw"].tolist())}
+
+
+@pytest.mark.parametrize("tag", ["tri0", "tri1", "tri2", "trv0", "trv1", "imp0", "imp1", "imp2", "att0", "att1", "att2"])
+def test_mask_api_matches_reference_end_to_end(tag):
+    """The reference's own clean/api.py mask functions, executed end to end (oracle/gen_maskapi_goldens.py):
+    string parsing, samples-per-bin, pooling / up-sampling, start index, early return, dimension order."""
+    gold = np.load(API_GOLDEN)
+    sv, er, kw = gold[f"{tag}_Sv"], gold[f"{tag}_echo_range"], _kw(gold, tag)
+    if tag.startswith("tr"):
+        got = omask.mask_transient_noise(sv, er, use_index_binning=tag.startswith("tri"), **kw)
+        assert gold[f"{tag}_dims"].tolist() == ["channel", "ping_time", "range_sample"]
+    elif tag.startswith("imp"):
+        got = omask.mask_impulse_noise(sv, er, use_index_binning=True, **kw)
+        assert gold[f"{tag}_dims"].tolist() == ["channel", "range_sample", "ping_time"]
+    else:
+        got = omask.mask_attenuated_signal(sv, er, **kw)
+        assert gold[f"{tag}_dims"].tolist() == ["channel", "ping_time", "range_sample"]
+    np.testing.assert_array_equal(got, gold[f"{tag}_mask"])
