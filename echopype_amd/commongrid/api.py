@@ -12,7 +12,7 @@ import torch
 from .. import ops
 from ..utils.prov import echopype_prov_attrs, insert_processing_level
 from ..xr_lite import DataArray, Dataset, DeviceArray, from_xarray
-from .utils import (_parse_x_bin, _set_MVBS_attrs, _setup_and_validate, get_distance_from_latlon,
+from .utils import (_parse_x_bin, _set_MVBS_attrs, _setup_and_validate, coarsen_time_mean, get_distance_from_latlon,
                     ping_time_bin_parsing_and_conversion, resample_edges)
 
 logger = logging.getLogger("echopype_amd.commongrid")
@@ -157,7 +157,7 @@ def compute_MVBS_index_binning(ds_Sv, range_sample_num=100, ping_num=100):
     mv, rmin = ops.mvbs_index(sv_t, ping_num, range_sample_num, range=rg_t)
     C, Pb, Sb = mv.shape
     ping_time = np.asarray(ds_Sv["ping_time"].values)
-    ds_MVBS = Dataset(coords={order[0]: ds_Sv[order[0]].values, "ping_time": ping_time[::ping_num][:Pb],
+    ds_MVBS = Dataset(coords={order[0]: ds_Sv[order[0]].values, "ping_time": coarsen_time_mean(ping_time, ping_num)[:Pb],
                               "range_sample": np.arange(Sb)})
     ds_MVBS.coords["range_sample"].attrs = {"long_name": "Along-range sample number, base 0"}
     ds_MVBS["Sv"] = DataArray(DeviceArray(mv), (order[0], "ping_time", "range_sample"))

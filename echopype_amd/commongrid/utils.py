@@ -70,6 +70,27 @@ def resample_edges(ping_time, ping_time_bin):
     return e0, dt, int(n)
 
 
+def coarsen_time_mean(ping_time, n):
+    """``ping_time`` labels of ``da.coarsen(ping_time=n, boundary="pad")``: xarray reduces the coordinates of a
+    coarsened dimension with its default ``coord_func="mean"`` -- per window the NaT-skipping float mean of the
+    ns offsets from the earliest timestamp, truncated to whole ns (api.py:217-221 keeps these labels).
+    Host O(P)."""
+    t = np.asarray(ping_time).astype("datetime64[ns]")
+    if t.size == 0:
+        return t
+    valid = ~np.isnat(t)
+    if not valid.any():
+        return np.full(-(-t.size // n), np.datetime64("NaT", "ns"))
+    off = t[valid].min()
+    rel = np.where(valid, (t - off).astype(np.int64).astype(np.float64), np.nan)
+    rel = np.pad(rel, (0, (-t.size) % n), constant_values=np.nan).reshape(-1, n)
+    cnt = np.sum(~np.isnan(rel), axis=1)
+    mean = np.divide(np.nansum(rel, axis=1), cnt, out=np.zeros(len(cnt)), where=cnt > 0)
+    out = off + mean.astype(np.int64).astype("timedelta64[ns]")
+    out[cnt == 0] = np.datetime64("NaT", "ns")
+    return out
+
+
 def _setup_and_validate(ds_Sv, range_var="echo_range", range_bin=None, closed="left", required_data_vars=None):
     """Argument checks of compute_MVBS (utils.py:380-450)."""
     if range_var not in ["echo_range", "depth"]:

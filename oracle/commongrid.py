@@ -30,6 +30,7 @@ __all__ = [
     "groupby_mean",
     "compute_MVBS",
     "compute_MVBS_index_binning",
+    "coarsen_label_mean",
 ]
 
 
@@ -123,6 +124,25 @@ def compute_MVBS(Sv, range_var, ping_time, range_bin="20m", ping_time_bin="20s",
     t_edges = ping_edges(ping_time, ping_time_bin)
     mv = groupby_mean(Sv, range_var, ping_time, t_edges, r_edges, skipna, fill_value, closed)
     return mv, t_edges[:-1], r_edges[:-1]
+
+
+def coarsen_label_mean(labels, n):
+    """Labels xarray gives a coarsened dimension (DataArray.coarsen default ``coord_func="mean"``): the NaT /
+    NaN-skipping mean of the labels in each window of ``n`` (last one padded).  datetime64 labels: float mean
+    of the ns offsets from the earliest label, truncated to whole ns, plus that label
+    (xarray duck_array_ops.mean); commongrid/api.py:217-221 keeps these labels for ``ping_time``."""
+    lab = np.asarray(labels)
+    padn = (-len(lab)) % n
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        if lab.dtype.kind == "M":
+            lab = lab.astype("datetime64[ns]")
+            off = np.nanmin(lab)
+            rel = np.where(np.isnat(lab), np.nan, (lab - off).astype("timedelta64[ns]").astype(float))
+            rel = np.pad(rel, (0, padn), constant_values=np.nan).reshape(-1, n)
+            return np.nanmean(rel, axis=1).astype("timedelta64[ns]") + off
+        rel = np.pad(lab.astype(float), (0, padn), constant_values=np.nan).reshape(-1, n)
+        return np.nanmean(rel, axis=1)
 
 
 def compute_MVBS_index_binning(Sv, echo_range, range_sample_num=100, ping_num=100):

@@ -360,6 +360,22 @@ def _methods():
             block, not a mean of per-row means."""
             import warnings
 
+            a, shape, red = self._blocks()  # boundary="pad": NaN padding up to a whole number of windows
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                a = (np.nanmean if skipna else np.mean)(a.reshape(shape), axis=tuple(red))
+            return self._with_coords(a)
+
+        def min(self, skipna=True):
+            import warnings
+
+            a, shape, red = self._blocks()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                a = (np.nanmin if skipna else np.min)(a.reshape(shape), axis=tuple(red))
+            return self._with_coords(a)
+
+        def _blocks(self):
             a, dims = self.da.data.astype(float), self.da.dims
             shape, red = [], []
             for ax, d in enumerate(dims):
@@ -368,21 +384,42 @@ def _methods():
                     shape.append(a.shape[ax])
                     continue
                 padn = (-a.shape[ax]) % n
-                if padn:  # boundary="pad": NaN padding up to a whole number of windows
+                if padn:
                     pad = [(0, 0)] * a.ndim
                     pad[ax] = (0, padn)
                     a = np.pad(a, pad, constant_values=np.nan)
                 shape += [a.shape[ax] // n, n]
                 red.append(len(shape) - 1)
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore", RuntimeWarning)
-                a = (np.nanmean if skipna else np.mean)(a.reshape(shape), axis=tuple(red))
-            out = DataArray(a, dims=dims)
-            for d in dims:  # labels of a coarsened dimension are replaced by the caller (assign_coords)
-                if d in self.windows:
-                    out.coords[d] = np.arange(a.shape[dims.index(d)])
-                elif d in self.da.coords:
-                    out.coords[d] = self.da.coords[d]
+            return a, shape, red
+
+        def _with_coords(self, a):
+            """Coordinates of a coarsened dimension: xarray's default ``coord_func="mean"`` -- the NaN / NaT
+            skipping mean of the labels in each window (datetime64: float mean of the offsets from the
+            earliest label, truncated to whole ns, duck_array_ops.mean)."""
+            import warnings
+
+            dims = self.da.dims
+            out = DataArray(a, dims=dims, name=self.da.name, attrs=self.da.attrs)
+            for d in dims:
+                if d not in self.da.coords:
+                    continue
+                lab = np.asarray(self.da.coords[d])
+                n = self.windows.get(d)
+                if n is None:
+                    out.coords[d] = lab
+                    continue
+                padn = (-len(lab)) % n
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore", RuntimeWarning)
+                    if lab.dtype.kind == "M":
+                        lab = lab.astype("datetime64[ns]")
+                        off = np.nanmin(lab)
+                        rel = np.where(np.isnat(lab), np.nan, (lab - off).astype("timedelta64[ns]").astype(float))
+                        rel = np.pad(rel, (0, padn), constant_values=np.nan).reshape(-1, n)
+                        out.coords[d] = np.nanmean(rel, axis=1).astype("timedelta64[ns]") + off
+                    else:
+                        rel = np.pad(lab.astype(float), (0, padn), constant_values=np.nan).reshape(-1, n)
+                        out.coords[d] = np.nanmean(rel, axis=1)
             return out
 
     def coarsen(self, boundary="exact", **windows):
@@ -391,13 +428,18 @@ def _methods():
     def pipe(self, f, *a, **k):
         return f(self, *a, **k)
 
+    def assign_attrs(self, attrs=None, **kw):
+        out = self.copy()
+        out.attrs.update({**(attrs or {}), **kw})
+        return out
+
     def iterate(self):
         assert self.ndim == 1
         for i in range(self.data.shape[0]):
             yield DataArray(self.data[i], dims=[], name=self.name)
 
     for f in (isnull, where, transpose, isel, drop_vars, squeeze, to_dataset, sel, mean, fillna, _reduce, assign_coords,
-              reindex, reindex_like, coarsen, pipe):
+              reindex, reindex_like, coarsen, pipe, assign_attrs):
         setattr(DataArray, f.__name__, f)
     DataArray.min, DataArray.max = amin, amax
     DataArray.__iter__ = iterate
@@ -411,10 +453,17 @@ def _methods():
 _methods()
 
 
+class _DsCoords(dict):
+    def __setitem__(self, k, v):  # ds.coords[name] = (dim, values, attrs)
+        if isinstance(v, tuple):
+            v = v[1]
+        super().__setitem__(k, np.asarray(v.data if isinstance(v, DataArray) else v))
+
+
 class Dataset:
     def __init__(self, data_vars=None, coords=None, attrs=None):
         self._vars = {}
-        self.coords = {}
+        self.coords = _DsCoords()
         self.attrs = dict(attrs or {})
         for k, v in (coords or {}).items():
             self.coords[k] = np.asarray(v.data if isinstance(v, DataArray) else v)

@@ -387,6 +387,23 @@ def test_compute_MVBS_index_binning(ep):
     np.testing.assert_array_equal(ds["range_sample"].values, np.arange(exp.shape[2]))
 
 
+@pytest.mark.parametrize("tag", ["ix0", "ix1", "ix2", "ix3"])
+def test_compute_MVBS_index_binning_vs_reference_goldens(ep, tag):
+    """Outputs of the reference's own compute_MVBS_index_binning (oracle/gen_mvbs_index_goldens.py):
+    values, block minimum of echo_range, coarsened ping_time labels, range_sample reset."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_mvbs_index_goldens.npz"))
+    rn, pn = (int(v) for v in g[f"{tag}_args"])
+    d = {"Sv": g[f"{tag}_Sv"], "echo_range": g[f"{tag}_echo_range"], "ping_time": g[f"{tag}_ping_time"]}
+    ds = ep.commongrid.compute_MVBS_index_binning(sv_dataset(ep, d), range_sample_num=rn, ping_num=pn)
+    close(ds["Sv"].values, g[f"{tag}_out_Sv"], 1e-12, "index binning vs reference")
+    np.testing.assert_array_equal(np.isnan(ds["Sv"].values), np.isnan(g[f"{tag}_out_Sv"]))
+    np.testing.assert_array_equal(ds["echo_range"].values, g[f"{tag}_out_echo_range"])
+    np.testing.assert_array_equal(ds["ping_time"].values, g[f"{tag}_out_ping_time"])
+    np.testing.assert_array_equal(ds["range_sample"].values, g[f"{tag}_out_range_sample"])
+
+
 def test_add_depth_then_MVBS_on_depth(ep):
     """compute_Sv -> add_depth(depth_offset, tilt) -> compute_MVBS(range_var="depth") (the reference's
     MVBS value fixtures are built through add_depth, tests/commongrid/conftest.py:101-118)."""

@@ -1,6 +1,8 @@
 """Host-side logic of the drop-in (parameter assembly, bin edges, containers) -- CPU only.
 Checked against goldens from the reference's leaf functions, the oracle, pandas, and the
 reference's synthetic unit tests (restated)."""
+import warnings
+
 import numpy as np
 import pandas as pd
 import pytest
@@ -371,3 +373,51 @@ def test_ek_use_beam_angles_output_and_warnings(caplog):
     with caplog.at_level(logging.WARNING):
         eku.ek_use_beam_angles(beam)
     assert "`beam_direction_z` variable array contains NaNs" in caplog.text
+
+
+def test_bin_string_parsers_match_reference_outputs():
+    """_parse_x_bin / ping_time_bin_parsing_and_conversion against the table the reference's own functions
+    produced (oracle/gen_mvbs_index_goldens.py): accepted values, exception types and x-bin messages.
+    Strings pandas turns into a zero-length Timedelta ('20', the integer 20) are rejected here (the reference
+    fails on them one line later, in resample)."""
+    import ast
+    import os
+
+    from echopype_amd.commongrid import utils as u
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_mvbs_index_goldens.npz"))
+    n = 0
+    for label, v, kind, res in g["parse_rows"].tolist():
+        val = ast.literal_eval(v)
+        if label == "ping_time_bin":
+            if kind != "ok" or res.startswith("(0,"):
+                with pytest.raises((ValueError, TypeError)):
+                    u.ping_time_bin_parsing_and_conversion(val)
+            else:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    assert repr(u.ping_time_bin_parsing_and_conversion(val)) == res, v
+        elif kind == "ok":
+            assert repr(float(u._parse_x_bin(val, label))) == res, v
+        else:
+            with pytest.raises({"ValueError": ValueError, "TypeError": TypeError}[kind]) as e:
+                u._parse_x_bin(val, label)
+            assert str(e.value) == res, v
+        n += 1
+    assert n >= 30
+
+
+def test_coarsen_time_mean_matches_reference_labels():
+    import os
+
+    from echopype_amd.commongrid.utils import coarsen_time_mean
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_mvbs_index_goldens.npz"))
+    for tag in ("ix0", "ix1", "ix2", "ix3"):
+        np.testing.assert_array_equal(coarsen_time_mean(g[f"{tag}_ping_time"], int(g[f"{tag}_args"][1])),
+                                      g[f"{tag}_out_ping_time"])
+    t = g["ix0_ping_time"].copy()
+    t[:3] = np.datetime64("NaT")  # an all-NaT window and a partly NaT one
+    t[4] = np.datetime64("NaT")
+    out = coarsen_time_mean(t, 3)
+    assert np.isnat(out[0]) and out[1] == t[3] + (t[5] - t[3]) // 2
