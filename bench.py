@@ -56,6 +56,9 @@ def parse():
                     help="float32: backscatter_r as echopype's converter stores it (the drop-in boundary); "
                          "int16: the instrument's own samples + ping lengths (SURVEY 8f row 4, 2 B/sample in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chain-outputs", default="all", choices=["all", "corrected"],
+                    help="cfg3: full-size arrays written -- all = Sv + Sv_noise + Sv_corrected (what "
+                         "remove_background_noise adds, SURVEY 8d line E: 32 B/sample fp64); corrected = without Sv_noise")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend (nccl = RCCL; gloo only for dry runs of the N>1 logic)")
     ap.add_argument("--single-device", action="store_true",
@@ -268,7 +271,8 @@ def main():
         if chain:  # noise blocks of 20 pings x 50 samples, SNR 3 dB
             a2 = coef[..., 4].contiguous()
             _, _, nz = ops.sv_noise_fused(d["backscatter_r"], coef, a2, 20, 50, dtype=dt)
-            res = ops.sv_denoise_mvbs(d["backscatter_r"], coef, a2, nz, 20, 3.0, bs, n_t, 1.0, n_r, dtype=dt)
+            res = ops.sv_denoise_mvbs(d["backscatter_r"], coef, a2, nz, 20, 3.0, bs, n_t, 1.0, n_r, dtype=dt,
+                                      want_noise=args.chain_outputs == "all")
         elif i16:
             res = ops.sv_mvbs_fused_i16(d["raw_i16"], d["n_valid"], coef, bs, n_t, 1.0, n_r, dtype=dt, sv_out=sv,
                                         mvbs_out=mvbs, want_partials=straddle)
@@ -310,7 +314,8 @@ def main():
     if rank == 0:
         bps = BYTES_PER_SAMPLE[args.dtype] - (2 if i16 else 0)
         if chain:
-            bps = 2 * BYTES_PER_SAMPLE[args.dtype]  # two sweeps: 4 B in + Sv out, 4 B in + Sv_corrected out
+            # two sweeps over the 4-B input + Sv, Sv_corrected (+ Sv_noise) out: SURVEY 8d line E = 32 / 20 B
+            bps = 2 * BYTES_PER_SAMPLE[args.dtype] + ((BYTES_PER_SAMPLE[args.dtype] - 4) if args.chain_outputs == "all" else 0)
         achieved = C * P * S * bps / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -332,7 +337,8 @@ def main():
             "config": {"workload": f"EK60 CW {C}ch x {P} pings x {S} range per GPU ({args.workload}), "
                                    + ("fused compute_Sv -> compute_MVBS (20 s x 1 m), Sv + MVBS written" if not chain else
                                       "two-pass compute_Sv -> remove_background_noise (20 x 50, 3 dB) -> compute_MVBS of "
-                                      "Sv_corrected (20 s x 1 m), Sv + Sv_corrected + MVBS written")
+                                      "Sv_corrected (20 s x 1 m), Sv + "
+                                      + ("Sv_noise + " if args.chain_outputs == "all" else "") + "Sv_corrected + MVBS written")
                                    + (", int16 instrument samples in" if i16 else ""),
                        "pings_total": P * world, "sharding": f"ping_time x{world}",
                        "collective": "none (shard edges on bin edges)" if not straddle else "edge-bin all-reduce"},
