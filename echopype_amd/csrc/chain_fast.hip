@@ -42,8 +42,41 @@ __device__ __forceinline__ unsigned long long ordered_key(double v) {
   return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
+// log10 on the rare paths (column refresh, rounding residue).  Call-free by default: an out-of-line call inside
+// the ping loop makes the compiler spill the ~90 live SGPRs around it (v_readlane / v_writelane per ping).
+#ifdef EPA_CHAIN_CALLS
 template <typename T>
-__device__ __noinline__ T log10_slow(T x) {
+__device__ __noinline__ T log10_slow(T x, const double2*) {
+  return epa::M<T>::log10(x);
+}
+template <typename T>
+__device__ __forceinline__ T log10_pos(T x, const double2* tab) {
+  return epa::fast_log10(x, tab);
+}
+template <typename T>
+__device__ __forceinline__ T log10_lin(T x, const double2* tab) {
+  return epa::fast_log10(x, tab);
+}
+#else
+// fp64: table-driven and branch-free (measured +7 % on pass 2, +4 % on pass 1).  fp32 keeps the call: ocml's
+// log10f inlined at ten rare sites costs more registers than the spills it saves (measured -7 %).
+__device__ __forceinline__ double log10_slow(double x, const double2* tab) {
+  return epa::fast_log10_inl<false>(x, tab);
+}
+__device__ __noinline__ float log10_slow(float x, const double2*) { return ::log10f(x); }
+__device__ __forceinline__ double log10_pos(double x, const double2* tab) {
+  return epa::fast_log10_inl<true>(x, tab);
+}
+// per-sample log of the denoised linear value: no exact-at-1 select (a result of 1e-17 dB instead of 0)
+__device__ __forceinline__ double log10_lin(double x, const double2* tab) {
+  return epa::fast_log10_inl<true, false>(x, tab);
+}
+__device__ __forceinline__ float log10_lin(float x, const double2*) { return ::log10f(x); }
+__device__ __forceinline__ float log10_pos(float x, const double2*) { return ::log10f(x); }
+#endif
+// The spreading log of a column stays ocml's log10 so that Sv is bit-identical to sv_power.hip / fused_sv_mvbs.hip.
+template <typename T>
+__device__ __noinline__ T log10_exact(T x) {
   return epa::M<T>::log10(x);
 }
 
@@ -63,7 +96,7 @@ struct ColBase {
 // echo_range, R', Sv of one sample -- as process_sample of fused_sv_mvbs.hip
 template <typename T>
 __device__ __forceinline__ T calibrate(const ColBase<T>& c, float raw, const epa::CoefRow& r, T g, T a2, T A0,
-                                       T nspread, double& x) {
+                                       T nspread, double& x, const double2* log_tab) {
   const T NaN = epa::M<T>::nan();
   x = c.sra * r.rb + r.r0;
   const double rtd = x - r.shift;
@@ -71,7 +104,7 @@ __device__ __forceinline__ T calibrate(const ColBase<T>& c, float raw, const epa
   const bool pos = rtd > 0.0;
   T spread = c.nL;
   if (pos & !(spread > -(T)__builtin_inf()))  // rounding residue of R - shift (rare)
-    spread = nspread * (log10_slow<T>(rt) - log10_slow<T>((T)(r.ra * r.rb)));
+    spread = nspread * (log10_exact<T>(rt) - log10_exact<T>((T)(r.ra * r.rb)));
   spread = pos ? spread : NaN;
   return fma(g, (T)raw, spread) + fma(a2, rt, A0);
 }
@@ -82,6 +115,16 @@ __device__ __forceinline__ T transmission_loss(const ColBase<T>& c, T xr, T log1
   return (T)20 * (xr >= (T)1 ? c.lgs + log10k : (T)0) + na2 * xr;
 }
 
+// log10(k), k = ra * rb, of the first kPingLogs pings of a workgroup's ping group: every wavefront needs it for
+// every ping of every chunk (a uniform ~35-instruction log); computed once, one ping per lane, kept in LDS.
+constexpr int kPingLogs = 64;
+template <typename T>
+__device__ __forceinline__ void fill_ping_logs(T* plog, const epa::CoefRow* __restrict__ rows, int n,
+                                               const double2* log_tab) {
+  for (int i = threadIdx.x; i < min(n, kPingLogs); i += epa::kBlock)
+    plog[i] = log10_pos((T)(rows[i].ra * rows[i].rb), log_tab);
+}
+
 // refresh of the cached column logs when the row constants they depend on change (uniform branch; once
 // per column for a file with constant pulse length / sample interval / sound speed)
 template <typename T>
@@ -89,29 +132,32 @@ struct RowCache {
   double d, ra, rb, dtl;
   T log10k;
   __device__ __forceinline__ RowCache() : d(__builtin_nan("")), ra(d), rb(d), dtl(d), log10k((T)0) {}
+  // plog / pi: log10(k) of ping pi of the group, computed once per workgroup (fill_ping_logs), pi < kPingLogs
   template <typename C>
   __device__ __forceinline__ void update(const epa::CoefRow& r, C (&col)[VEC], int sA, int sB, T nspread,
-                                         const double2* log_tab) {
+                                         const double2* log_tab, const T* plog, int pi) {
     if (!((r.d == d) & (r.ra == ra))) {
       d = r.d;
       for (int j = 0; j < VEC; ++j) {
         const double sj = (double)((j < 2 ? sA : sB) + (j & 1));
-        col[j].nL = nspread * log10_slow<T>((T)(sj - r.d));
+        col[j].nL = nspread * log10_exact<T>((T)(sj - r.d));
         col[j].sra = sj * r.ra;
       }
     }
     const double k = r.ra * r.rb;
-    if (!((r.ra == ra) & (r.rb == rb))) {  // sound speed may drift from ping to ping: table-driven log
-      log10k = epa::fast_log10((T)k, log_tab);
-      rb = r.rb;
+    if (pi < kPingLogs) {
+      log10k = plog[pi];
+    } else if (!((r.ra == ra) & (r.rb == rb))) {  // sound speed may drift from ping to ping: table-driven log
+      log10k = log10_pos((T)k, log_tab);
     }
+    rb = r.rb;
     ra = r.ra;
     const double dnew = r.r0 == 0.0 ? 0.0 : -r.r0 / k;  // EK rows: echo_range starts at 0
     if (!(dnew == dtl)) {
       dtl = dnew;
       for (int j = 0; j < VEC; ++j) {
         const double sj = (double)((j < 2 ? sA : sB) + (j & 1));
-        col[j].lgs = log10_slow<T>((T)(sj - dnew));
+        col[j].lgs = log10_slow((T)(sj - dnew), log_tab);
       }
     }
   }
@@ -151,6 +197,9 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int pb = pbk * a.ping_num, pe = min(a.P, pb + a.ping_num);
   double xmax = -__builtin_inf();
+  __shared__ T plog[kPingLogs];
+  fill_ping_logs<T>(plog, rowp0 + pb, pe - pb, mt.log_tab);
+  __syncthreads();
 
   for (int chunk0 = 0; chunk0 < S; chunk0 += kChunk) {
     const int sA = chunk0 + wave * 256 + 2 * lane, sB = sA + 128;
@@ -176,7 +225,7 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
         nA = *reinterpret_cast<const float2*>(raw_c + row_off + S + sA);
         if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + row_off + S + sB);
       }
-      rc.update(r, col, sA, sB, nspread, mt.log_tab);
+      rc.update(r, col, sA, sB, nspread, mt.log_tab, plog, p - pb);
       const T g = (T)r.g, a2 = (T)r.alpha2, A0 = (T)r.A0, na2 = (T)a2p[p];
       const float in[VEC] = {inA.x, inA.y, inB.x, inB.y};
       T sv[VEC];
@@ -184,7 +233,7 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
       for (int j = 0; j < VEC; ++j) {
         if (j >= 2 && !hasB) break;
         double x;
-        sv[j] = calibrate<T>(col[j], in[j], r, g, a2, A0, nspread, x);
+        sv[j] = calibrate<T>(col[j], in[j], r, g, a2, A0, nspread, x, mt.log_tab);
         const bool xok = in[j] == in[j];
         if (RMAX) xmax = fmax(xmax, xok ? (double)(T)x : xmax);
         // the block mean uses the UNMASKED range (the generic kernel does too: a masked sample has a NaN Sv)
@@ -296,10 +345,14 @@ __global__ __launch_bounds__(epa::kBlock) void sv_denoise_mvbs_fast_kernel(
   T* __restrict__ sc_c = WRITE_CORR ? corr_out + (size_t)c * a.P * S : nullptr;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double mm[4] = {__builtin_inf(), -__builtin_inf(), __builtin_inf(), -__builtin_inf()};
+  __shared__ T plog[kPingLogs];
 
   for (int seg = 0; seg < nseg; ++seg) {
   const int pb = extra ? (seg == 0 ? 0 : bin_start[a.n_tbins]) : bin_start[tb];
   const int pe = extra ? (seg == 0 ? bin_start[0] : a.P) : bin_start[tb + 1];
+  __syncthreads();  // all wavefronts are done with the previous segment's logs
+  fill_ping_logs<T>(plog, rowp0 + pb, pe - pb, mt.log_tab);
+  __syncthreads();
   for (int chunk0 = 0; chunk0 < S; chunk0 += kChunk) {
     const int sA = chunk0 + wave * 256 + 2 * lane, sB = sA + 128;
     if (sA >= S) continue;
@@ -312,21 +365,23 @@ __global__ __launch_bounds__(epa::kBlock) void sv_denoise_mvbs_fast_kernel(
     }
     RowCache<T> rc;
     float2 nA = make_float2(0.f, 0.f), nB = nA;
+    // fp64 is short of SGPRs (about 90 spilled to VGPR lanes): there the next coefficient row is not prefetched
+    constexpr bool kPrefetchRow = sizeof(T) == 4;
     epa::CoefRow nxtR = rowp0[pb < pe ? pb : 0];
     if (pb < pe) {
       nA = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sA);
       if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sB);
     }
     for (int p = pb; p < pe; ++p) {
-      const epa::CoefRow r = nxtR;
+      const epa::CoefRow r = kPrefetchRow ? nxtR : rowp0[p];
       const size_t row_off = (size_t)p * S;
       const float2 inA = nA, inB = nB;
       if (p + 1 < pe) {
-        nxtR = rowp0[p + 1];
+        if (kPrefetchRow) nxtR = rowp0[p + 1];
         nA = *reinterpret_cast<const float2*>(raw_c + row_off + S + sA);
         if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + row_off + S + sB);
       }
-      rc.update(r, col, sA, sB, nspread, mt.log_tab);
+      rc.update(r, col, sA, sB, nspread, mt.log_tab, plog, p - pb);
       const T g = (T)r.g, a2 = (T)r.alpha2, A0 = (T)r.A0, na2 = (T)a2p[p];
       const T nb = (T)nzp[p / a.noise_ping_num];
       const float in[VEC] = {inA.x, inA.y, inB.x, inB.y};
@@ -336,15 +391,14 @@ __global__ __launch_bounds__(epa::kBlock) void sv_denoise_mvbs_fast_kernel(
         if (j >= 2 && !hasB) break;
         BinCol<T>& cj = col[j];
         double x;
-        const T sv = calibrate<T>(cj, in[j], r, g, a2, A0, nspread, x);
+        const T sv = calibrate<T>(cj, in[j], r, g, a2, A0, nspread, x, mt.log_tab);
         const bool xok = in[j] == in[j];
         const T xr = xok ? (T)x : epa::M<T>::nan();  // echo_range is NaN where the input is
         sn[j] = nb + transmission_loss<T>(cj, xr, rc.log10k, na2);
         const T lin = epa::lin_from_db(sv, mt.exp2_tab) - epa::lin_from_db(sn[j], mt.exp2_tab);
-        const T corr = lin > (T)0 ? (T)10 * epa::fast_log10(lin, mt.log_tab) : epa::M<T>::nan();
+        const T corr = lin > (T)0 ? (T)10 * log10_lin(lin, mt.log_tab) : epa::M<T>::nan();
         const bool keep = corr - sn[j] > snr;
         sc[j] = keep ? corr : epa::M<T>::nan();
-        const T v = keep ? lin : epa::M<T>::nan();
         if (MINMAX) {  // fmin / fmax ignore NaN operands
           mm[0] = fmin(mm[0], (double)sn[j]);
           mm[1] = fmax(mm[1], (double)sn[j]);
@@ -364,8 +418,8 @@ __global__ __launch_bounds__(epa::kBlock) void sv_denoise_mvbs_fast_kernel(
           cj.blo = rb >= 0 ? (double)rb * bin : 1.0;
           cj.bhi = rb >= 0 ? (double)(rb + 1) * bin : 0.0;
         }
-        const bool take = (cj.acc_rb >= 0) & (v == v);
-        cj.acc_sum += take ? v : (T)0;
+        const bool take = (cj.acc_rb >= 0) & keep;  // keep implies a finite positive lin
+        cj.acc_sum += take ? lin : (T)0;
         cj.acc_cnt += take ? 1u : 0u;
       }
       if (WRITE_NOISE) {

@@ -93,4 +93,41 @@ __device__ __forceinline__ double fast_log10(double x, const double2* __restrict
 }
 __device__ __forceinline__ float fast_log10(float x, const double2*) { return ::log10f(x); }
 
+// The same log10 without the out-of-line call: every special case folded into selects, so that a hot loop
+// holding many live SGPRs does not have to spill them around a call it (almost) never makes.
+//   subnormal -> scaled by 2^54 first; +inf / NaN -> x; 0 -> -inf; x < 0 -> NaN.
+// POSITIVE = the caller guarantees x > 0 or NaN (saves the last two selects); EXACT_AT_1 = return exactly 0
+// for x == 1 (otherwise within 1e-17 of it).
+template <bool POSITIVE, bool EXACT_AT_1 = true>
+__device__ __forceinline__ double fast_log10_inl(double x, const double2* __restrict__ tab) {
+  constexpr double LOG10_2 = 0.30102999566398120;
+  constexpr double C1 = 0.43429448190325182765, C2 = -0.21714724095162591383,
+                   C3 = 0.14476482730108394255, C4 = -0.10857362047581295691,
+                   C5 = 0.086858896380650365530, C6 = -0.072382413650541971275;
+  const bool sub = ((unsigned)__double2hiint(x) & 0x7ff00000u) == 0u;  // exponent field 0: subnormal or 0
+  const double xs = sub ? x * 0x1p54 : x;
+  const unsigned long long bits = __double_as_longlong(xs);
+  const unsigned ex = (unsigned)(bits >> 52) & 0x7ffu;
+  const int j = (int)((bits >> 45) & 127ull);
+  const double m = __longlong_as_double((bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+  const double2 t = tab[j];
+  const double r = fma(m, t.x, -1.0);
+  double p = fma(r, C6, C5);
+  p = fma(p, r, C4);
+  p = fma(p, r, C3);
+  p = fma(p, r, C2);
+  p = fma(p, r, C1);
+  const double ef = (double)((int)ex - (sub ? 1023 + 54 : 1023) + (j >= 53 ? 1 : 0));
+  double res = fma(ef, LOG10_2, t.y) + r * p;
+  if (EXACT_AT_1) res = x == 1.0 ? 0.0 : res;
+  res = ex == 0x7ffu ? x : res;
+  if (!POSITIVE) {
+    res = x == 0.0 ? -__builtin_inf() : res;
+    res = x < 0.0 ? __builtin_nan("") : res;
+  }
+  return res;
+}
+template <bool POSITIVE, bool EXACT_AT_1 = true>
+__device__ __forceinline__ float fast_log10_inl(float x, const double2*) { return ::log10f(x); }
+
 }  // namespace epa

@@ -326,6 +326,16 @@ __global__ __launch_bounds__(epa::kBlock) void selftest_log_kernel(const double*
     out[i] = epa::fast_log10(x[i], mt.log_tab);
 }
 
+__global__ __launch_bounds__(epa::kBlock) void selftest_log_inl_kernel(const double* __restrict__ x,
+                                                                       double* __restrict__ out, size_t n) {
+  __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
+  const epa::MathTabs mt = epa::build_math_tabs(tabs);
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    out[i] = epa::fast_log10_inl<false>(x[i], mt.log_tab);
+}
+
 }  // namespace epa_fused
 
 extern "C" int epa_selftest_lin_from_db(const double* u, double* out, size_t n, epa_stream_t stream) {
@@ -344,6 +354,15 @@ extern "C" int epa_selftest_log10(const double* x, double* out, size_t n, epa_st
   hipLaunchKernelGGL(epa_fused::selftest_log_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)),
                      dim3(epa::kBlock), 0, (hipStream_t)stream, x, out, n);
   return epa::check_launch("selftest_log_kernel");
+}
+
+extern "C" int epa_selftest_log10_inline(const double* x, double* out, size_t n, epa_stream_t stream) {
+  EPA_CHECK_ARG(x && out, "epa_selftest_log10_inline: NULL array argument");
+  if (n == 0) return EPA_OK;
+  const size_t blocks = (n + epa::kBlock - 1) / epa::kBlock;
+  hipLaunchKernelGGL(epa_fused::selftest_log_inl_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)),
+                     dim3(epa::kBlock), 0, (hipStream_t)stream, x, out, n);
+  return epa::check_launch("selftest_log_inl_kernel");
 }
 
 // Called by epa_sv_mvbs_fused (block_reduce.hip) when the fast path applies.

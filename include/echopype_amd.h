@@ -170,6 +170,8 @@ int epa_mvbs(const void* sv, const void* range, const double* coef, int C, int P
 int epa_selftest_lin_from_db(const double* u, double* out, size_t n, epa_stream_t stream);
 /* Same for the table-driven f64 log10 used by _lin2log and the transmission-loss terms. */
 int epa_selftest_log10(const double* x, double* out, size_t n, epa_stream_t stream);
+/* The call-free variant of that log10 (every special case folded into selects) the chain kernels use. */
+int epa_selftest_log10_inline(const double* x, double* out, size_t n, epa_stream_t stream);
 
 /* Finalise merged partial sums: out = 10*log10(sum/cnt), fill_value where cnt == 0. */
 int epa_mvbs_finalize(const void* sum, const uint32_t* cnt, size_t n, double fill_value, void* out,
