@@ -484,10 +484,12 @@ def test_sv_complex_fft_path_matches_direct(env, in_dtype, out_dtype, taps, S, m
 
 # ---- the whole chain in two passes ------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
-@pytest.mark.parametrize("closed,few_bins", [("left", False), ("right", False), ("left", True)])
-def test_fused_chain_equals_the_four_separate_kernels(env, dtype, closed, few_bins):
+@pytest.mark.parametrize("closed,few_bins,pn,bin_s", [("left", False, 20, 20), ("right", False, 20, 20),
+                                                       ("left", True, 20, 20), ("left", False, 80, 100)])
+def test_fused_chain_equals_the_four_separate_kernels(env, dtype, closed, few_bins, pn, bin_s):
     """epa_sv_noise_fused == epa_sv_power + epa_noise_estimate and epa_denoise_mvbs == epa_noise_apply +
-    epa_mvbs (same arithmetic, fewer sweeps), and both equal the oracle chain."""
+    epa_mvbs (same arithmetic, fewer sweeps), and both equal the oracle chain.  The (80, 100) case has more
+    pings per noise block / time bin than the 64 per-ping logs a workgroup caches."""
     torch, ops, synth = env
     C, P, S = 2, (45 if few_bins else 203), 1000
     d = synth.ek60_numpy(C, P, S)
@@ -502,10 +504,10 @@ def test_fused_chain_equals_the_four_separate_kernels(env, dtype, closed, few_bi
     a2 = _dev(torch, np.broadcast_to(2 * d["absorption_indicative"], (C, P)).copy(), torch.float64)
     # reference kernels
     sv0, rg0 = ops.sv_power(raw, coef, dtype=dt)
-    n0 = ops.noise_estimate(sv0, a2, 20, 50, range=rg0, noise_max=-120.0)
-    sn0, sc0 = ops.noise_apply(sv0, a2, n0, 20, 3.0, range=rg0)
+    n0 = ops.noise_estimate(sv0, a2, pn, 50, range=rg0, noise_max=-120.0)
+    sn0, sc0 = ops.noise_apply(sv0, a2, n0, pn, 3.0, range=rg0)
     ns = d["ping_time"].astype("datetime64[ns]").astype(np.int64)
-    dt_ns = 20_000_000_000
+    dt_ns = bin_s * 1_000_000_000
     n_t = int((ns[-1] - ns[0]) // dt_ns) + 1
     bs = ops.time_bin_offsets(_dev(torch, ns), int(ns[0]), dt_ns, n_t, closed=closed)
     _, rmax = ops.nanminmax(rg0)
@@ -515,17 +517,21 @@ def test_fused_chain_equals_the_four_separate_kernels(env, dtype, closed, few_bi
     # bin edge may change bins, so the affine / raw variants are held to the affine-binned reference
     m0c = ops.mvbs(sc0, bs, n_t, 1.0, n_r, coef=coef, closed=closed)["MVBS"]
     # fused pair (transmission loss / bins from the coefficient rows: no echo_range array is read)
-    sv1, rg1, n1 = ops.sv_noise_fused(raw, coef, a2, 20, 50, dtype=dt, noise_max=-120.0, want_range=True)
+    sv1, rg1, n1 = ops.sv_noise_fused(raw, coef, a2, pn, 50, dtype=dt, noise_max=-120.0, want_range=True)
     assert torch.equal(torch.nan_to_num(sv1, nan=1.0), torch.nan_to_num(sv0, nan=1.0))
     assert torch.equal(torch.nan_to_num(rg1, nan=-1.0), torch.nan_to_num(rg0, nan=-1.0))
     _assert_close(n1.cpu().numpy(), n0.cpu().numpy(), 1e-12 if dtype == "float64" else 1e-5, "noise estimate")
     tol = 1e-11 if dtype == "float64" else 2e-4
-    variants = [("range", lambda: ops.denoise_mvbs(sv1, a2, n1, 20, 3.0, bs, n_t, 1.0, n_r, closed=closed,
+    variants = [("range", lambda: ops.denoise_mvbs(sv1, a2, n1, pn, 3.0, bs, n_t, 1.0, n_r, closed=closed,
                                                     want_noise=True, range=rg0)),
-                ("coef", lambda: ops.denoise_mvbs(sv1, a2, n1, 20, 3.0, bs, n_t, 1.0, n_r, closed=closed,
+                ("coef", lambda: ops.denoise_mvbs(sv1, a2, n1, pn, 3.0, bs, n_t, 1.0, n_r, closed=closed,
                                                    want_noise=True, coef=coef)),
-                ("raw", lambda: ops.sv_denoise_mvbs(raw, coef, a2, n1, 20, 3.0, bs, n_t, 1.0, n_r, closed=closed,
-                                                    dtype=dt, want_noise=True, want_range=True))]
+                ("raw", lambda: ops.sv_denoise_mvbs(raw, coef, a2, n1, pn, 3.0, bs, n_t, 1.0, n_r, closed=closed,
+                                                    dtype=dt, want_noise=True, want_range=True)),
+                # without echo_range out: the specialised two-pass kernels (csrc/chain_fast.hip) when closed="left"
+                ("raw-fast", lambda: ops.sv_denoise_mvbs(raw, coef, a2, ops.sv_noise_fused(
+                    raw, coef, a2, pn, 50, dtype=dt, noise_max=-120.0)[2], pn, 3.0, bs, n_t, 1.0, n_r, closed=closed,
+                    dtype=dt, want_noise=True))]
     for name, run in variants:
         res = run()
         got_n, exp_n0 = res["Sv_noise"].cpu().numpy(), sn0.cpu().numpy()
@@ -539,8 +545,8 @@ def test_fused_chain_equals_the_four_separate_kernels(env, dtype, closed, few_bi
             assert torch.equal(torch.nan_to_num(res["echo_range"], nan=-1.0), torch.nan_to_num(rg0, nan=-1.0))
     if dtype == "float64" and closed == "left":
         sv, er = _oracle_ek60(d, "Sv")
-        exp_n, exp_c = oclean.remove_background_noise(sv, er, d["absorption_indicative"], 20, 50, "-120.0dB", "3.0dB")
-        exp_m, _, _ = ogrid.compute_MVBS(exp_c, er, d["ping_time"], "1m", "20s")
+        exp_n, exp_c = oclean.remove_background_noise(sv, er, d["absorption_indicative"], pn, 50, "-120.0dB", "3.0dB")
+        exp_m, _, _ = ogrid.compute_MVBS(exp_c, er, d["ping_time"], "1m", f"{bin_s}s")
         _assert_close(res["Sv_corrected"].cpu().numpy(), exp_c, 1e-9, "oracle Sv_corrected")
         _assert_close(res["MVBS"].cpu().numpy(), exp_m, 1e-9, "oracle MVBS")
 
