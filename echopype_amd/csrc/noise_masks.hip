@@ -250,94 +250,236 @@ __global__ __launch_bounds__(kBlock) void box_range_kernel(const T* __restrict__
   }
 }
 
-#ifndef EPA_BOX_PT
-#define EPA_BOX_PT 64
+// The same range pass in O(1) additions per sample (van Herk / Gil-Werman without any subtraction): the tile is
+// cut into blocks of w = 2m+1 samples; with pre[i] / suf[i] = running sums from the start / to the end of i's
+// block, the window [o, o+w) is  suf[o] + pre[o+w-1]  (or pre alone when o starts a block).  The running sums
+// of a block are built by kBlock / nblk lanes: each sums its run, the runs before / after it give its offsets,
+// a second sweep writes pre and suf.  (PMC on the grouped kernel above: ~295 VALU instructions per sample,
+// 97 % VALU-busy; this one is bound by its 20 B/sample of HBM traffic.)
+#ifndef EPA_SCAN_TILE
+#define EPA_SCAN_TILE 1024
 #endif
-#ifndef EPA_BOX_CT
-#define EPA_BOX_CT 16
-#endif
-constexpr int kPingTile = EPA_BOX_PT, kColTile = EPA_BOX_CT;
+constexpr int kScanTile = EPA_SCAN_TILE;
+constexpr int kScanMinW = 8, kScanMaxW = 512;
 
 template <typename T>
-__global__ __launch_bounds__(kBlock) void box_ping_kernel(const T* __restrict__ sv,
-                                                          const double* __restrict__ vsum,
-                                                          const int* __restrict__ vcnt, int P, int S,
-                                                          int s0, int n, long long ntiles, T thr,
-                                                          T* __restrict__ pooled,
-                                                          uint8_t* __restrict__ mask) {
+__global__ __launch_bounds__(kBlock) void box_range_scan_kernel(const T* __restrict__ sv, long long rows,
+                                                                int S, int s0, int m,
+                                                                double* __restrict__ vsum,
+                                                                int* __restrict__ vcnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const epa::MathTabs mt = epa::build_math_tabs(smem);
-  const int nrow = kPingTile + 2 * n;
-  const int ngrp = nrow / kGroup;
-  double* ssum = reinterpret_cast<double*>(smem + epa::kMathTabBytes);  // [nrow][kColTile]
-  double* gsum = ssum + (size_t)nrow * kColTile;                        // [ngrp][kColTile]
-  int* scnt = reinterpret_cast<int*>(gsum + (size_t)ngrp * kColTile);   // [nrow][kColTile]
-  int* gcnt = scnt + (size_t)nrow * kColTile;                           // [ngrp][kColTile]
-  // persistent workgroups: the tables are built once, tiles are taken column-tile fastest
-  const int ncol = (S + kColTile - 1) / kColTile, nping = (P + kPingTile - 1) / kPingTile;
-  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int c = (int)(tile / ((long long)ncol * nping));
-    const int rem = (int)(tile - (long long)c * ncol * nping);
-    const int p0 = (rem / ncol) * kPingTile, col0 = (rem % ncol) * kColTile;
-    const size_t cbase = (size_t)c * P * S;
-    __syncthreads();
-    for (int i = threadIdx.x; i < nrow * kColTile; i += kBlock) {
-      const int r = i / kColTile, col = i % kColTile;
-      const int s = col0 + col;
-      double a = 0.0;
-      int k = 0;
-      if (s >= s0 && s < S) {
-        const size_t at = cbase + (size_t)reflect_index(p0 - n + r, P) * S + s;
-        a = vsum[at];
-        k = vcnt[at];
-      }
-      ssum[i] = a;
-      scnt[i] = k;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < ngrp * kColTile; i += kBlock) {
-      const int g = i / kColTile, col = i % kColTile;
-      double a = 0.0;
-      int k = 0;
+  const int L = S - s0, w = 2 * m + 1;
+  const int t0 = blockIdx.y * kScanTile;  // relative to s0
+  const int nout = min(kScanTile, L - t0);
+  const int nin = nout + 2 * m;
+  const int ninp = (kScanTile + 2 * m + 2) & ~1;  // array pitch, the same for every tile of the launch
+  double* lin = reinterpret_cast<double*>(smem + epa::kMathTabBytes);  // [nin] NaN kept; becomes suf
+  double* pre_s = lin + ninp;
+  double* tot_s = pre_s + ninp;                                    // [nvirt <= 2 * kBlock]
+  unsigned short* pre_c = reinterpret_cast<unsigned short*>(tot_s + 2 * kBlock);
+  unsigned short* suf_c = pre_c + ninp;
+  unsigned short* tot_c = suf_c + ninp;
+  const int nblk = (nin + w - 1) / w;
+  const int tpb = max(1, kBlock / nblk);     // lanes per block
+  const int r = (w + tpb - 1) / tpb;         // samples per lane
+  const int nvirt = nblk * tpb;              // <= 2 * kBlock for w >= kScanMinW
+  // the next row's samples are requested before this row is scanned (the scan phases are latency-bound)
+  constexpr int kPf = (kScanTile + kScanMaxW + kBlock - 1) / kBlock;
+  T pf[kPf];
+  int src[kPf];
 #pragma unroll
-      for (int j = 0; j < kGroup; ++j) {
-        a += ssum[(g * kGroup + j) * kColTile + col];
-        k += scnt[(g * kGroup + j) * kColTile + col];
-      }
-      gsum[i] = a;
-      gcnt[i] = k;
+  for (int j = 0; j < kPf; ++j) {
+    const int i = threadIdx.x + j * kBlock;
+    src[j] = i < nin ? reflect_index(t0 - m + i, L) : -1;
+    pf[j] = (src[j] >= 0 && blockIdx.x < rows) ? sv[(size_t)blockIdx.x * S + s0 + src[j]] : (T)0;
+  }
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPf; ++j) {
+      const int i = threadIdx.x + j * kBlock;
+      const T v = pf[j];
+      if (src[j] >= 0) lin[i] = (v == v) ? (double)epa::lin_from_db(v, mt.exp2_tab) : __builtin_nan("");
+    }
+    const long long nrow = row + gridDim.x;
+    if (nrow < rows) {
+      const T* svn = sv + (size_t)nrow * S + s0;
+#pragma unroll
+      for (int j = 0; j < kPf; ++j)
+        if (src[j] >= 0) pf[j] = svn[src[j]];
     }
     __syncthreads();
-    const int col = threadIdx.x % kColTile, s = col0 + col;
-    if (s >= S) continue;
-    for (int k = threadIdx.x / kColTile; k < kPingTile; k += kBlock / kColTile) {
-      const int p = p0 + k;
-      if (p >= P) break;
-      T out = epa::M<T>::nan();
-      if (s >= s0) {
-        const int a = k, b = k + 2 * n + 1;  // rows [a, b)
-        int a8 = (a + kGroup - 1) & ~(kGroup - 1), b8 = b & ~(kGroup - 1);
-        if (a8 >= b8) a8 = b8 = b;
-        double sum = 0.0;
-        long long cnt = 0;
-        for (int j = a; j < a8; ++j) {
-          sum += ssum[j * kColTile + col];
-          cnt += scnt[j * kColTile + col];
-        }
-        for (int g = a8 / kGroup; g < b8 / kGroup; ++g) {
-          sum += gsum[g * kColTile + col];
-          cnt += gcnt[g * kColTile + col];
-        }
-        for (int j = b8; j < b; ++j) {
-          sum += ssum[j * kColTile + col];
-          cnt += scnt[j * kColTile + col];
-        }
-        if (cnt > 0) out = (T)(10.0 * epa::fast_log10(sum / (double)cnt, mt.log_tab));
+    for (int v = threadIdx.x; v < nvirt; v += kBlock) {  // run totals
+      const int k = v / tpb, t = v - k * tpb;
+      const int lo = k * w + t * r, hi = min(min(lo + r, (k + 1) * w), nin);
+      double sum = 0.0;
+      int cnt = 0;
+      for (int i = lo; i < hi; ++i) {
+        const double x = lin[i];
+        const bool ok = x == x;
+        sum += ok ? x : 0.0;
+        cnt += ok ? 1 : 0;
       }
-      const size_t at = cbase + (size_t)p * S + s;
-      if (pooled) pooled[at] = out;
-      if (mask) mask[at] = (sv[at] - out > thr) ? 1 : 0;
+      tot_s[v] = sum;
+      tot_c[v] = (unsigned short)cnt;
     }
+    __syncthreads();
+    for (int v = threadIdx.x; v < nvirt; v += kBlock) {  // running sums of the block, both directions
+      const int k = v / tpb, t = v - k * tpb;
+      const int lo = k * w + t * r, hi = min(min(lo + r, (k + 1) * w), nin);
+      double fs = 0.0, bs = 0.0;
+      int fc = 0, bc = 0;
+      for (int u = 0; u < t; ++u) {
+        fs += tot_s[k * tpb + u];
+        fc += tot_c[k * tpb + u];
+      }
+      for (int u = tpb - 1; u > t; --u) {
+        bs += tot_s[k * tpb + u];
+        bc += tot_c[k * tpb + u];
+      }
+      for (int i = lo; i < hi; ++i) {
+        const double x = lin[i];
+        const bool ok = x == x;
+        fs += ok ? x : 0.0;
+        fc += ok ? 1 : 0;
+        pre_s[i] = fs;
+        pre_c[i] = (unsigned short)fc;
+      }
+      for (int i = hi - 1; i >= lo; --i) {
+        const double x = lin[i];
+        const bool ok = x == x;
+        bs += ok ? x : 0.0;
+        bc += ok ? 1 : 0;
+        lin[i] = bs;  // suf
+        suf_c[i] = (unsigned short)bc;
+      }
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < nout; o += kBlock) {
+      const int k = o / w, e = o + w - 1;
+      const bool whole = o == k * w;
+      const double sum = whole ? pre_s[e] : lin[o] + pre_s[e];
+      const int cnt = whole ? (int)pre_c[e] : (int)suf_c[o] + (int)pre_c[e];
+      const size_t at = (size_t)row * S + s0 + t0 + o;
+      vsum[at] = sum;
+      vcnt[at] = cnt;
+    }
+  }
+}
+
+// The ping pass as a sliding window: one lane per range column walks a segment of kSlideSeg pings; the window
+// sum is carried from ping to ping -- row p+n enters, row p-n-1 leaves -- in double-double arithmetic (Knuth
+// two-sum, the rounding error of every addition is kept in `lo`), so the subtraction loses nothing: the result
+// is the correctly rounded window sum to ~1e-30 relative, however large the values that have passed through.
+// Every segment starts from a freshly summed window.  Reads 2.2 rows per output (the leaving row is 2n+1
+// pings old: L2), ~60 VALU instructions per sample instead of ~290 (PMC on box_ping_kernel: 97 % VALU-busy,
+// 1.7x the HBM bytes because of its ping halo).  +inf contributions are counted, not added (inf - inf).
+#ifndef EPA_SLIDE_PAD
+#define EPA_SLIDE_PAD 36864  // caps the kernel at 4 workgroups per CU: the rows about to leave the windows stay cached (-5 %)
+#endif
+#ifndef EPA_SLIDE_SEG
+#define EPA_SLIDE_SEG 512
+#endif
+constexpr int kSlideSeg = EPA_SLIDE_SEG, kSlideUnroll = 4, kSlidePad = EPA_SLIDE_PAD;
+
+struct DdSum {
+  double hi = 0.0, lo = 0.0;
+  long long cnt = 0;
+  int ninf = 0;
+  __device__ __forceinline__ void add(double x, int k, double sign) {
+    cnt += sign > 0.0 ? k : -k;
+    if (x == __builtin_inf()) {
+      ninf += sign > 0.0 ? 1 : -1;
+      return;
+    }
+    x *= sign;
+    const double t = hi + x;
+    const double bb = t - hi;
+    lo += (hi - (t - bb)) + (x - bb);
+    hi = t;
+  }
+  __device__ __forceinline__ double value() const { return ninf > 0 ? __builtin_inf() : hi + lo; }
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void box_ping_slide_kernel(const T* __restrict__ sv,
+                                                                const double* __restrict__ vsum,
+                                                                const int* __restrict__ vcnt, int P, int S,
+                                                                int s0, int n, T thr, T* __restrict__ pooled,
+                                                                uint8_t* __restrict__ mask) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const epa::MathTabs mt = epa::build_math_tabs(smem);
+  __syncthreads();
+  const int s = blockIdx.y * kBlock + threadIdx.x;
+  if (s >= S) return;
+  const int p0 = blockIdx.x * kSlideSeg, p1 = min(P, p0 + kSlideSeg);
+  const size_t cbase = (size_t)blockIdx.z * P * S;
+  if (s < s0) {  // above the first pooled sample: NaN, never masked
+    for (int p = p0; p < p1; ++p) {
+      const size_t at = cbase + (size_t)p * S + s;
+      if (pooled) pooled[at] = epa::M<T>::nan();
+      if (mask) mask[at] = 0;
+    }
+    return;
+  }
+  const double* __restrict__ vs = vsum + cbase + s;
+  const int* __restrict__ vc = vcnt + cbase + s;
+  DdSum w;
+  {  // the first window of the segment, summed afresh (independent loads, four rows at a time)
+    int q = p0 - n;
+    for (; q + 3 <= p0 + n; q += 4) {
+      double a[4];
+      int k[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const size_t r = (size_t)reflect_index(q + j, P) * S;
+        a[j] = vs[r];
+        k[j] = vc[r];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w.add(a[j], k[j], 1.0);
+    }
+    for (; q <= p0 + n; ++q) {
+      const size_t r = (size_t)reflect_index(q, P) * S;
+      w.add(vs[r], vc[r], 1.0);
+    }
+  }
+  auto emit = [&](int p, T x) {
+    T out = epa::M<T>::nan();
+    if (w.cnt > 0) out = (T)(10.0 * epa::fast_log10(w.value() / (double)w.cnt, mt.log_tab));
+    const size_t at = cbase + (size_t)p * S + s;
+    if (pooled) pooled[at] = out;
+    if (mask) mask[at] = (x - out > thr) ? 1 : 0;
+  };
+  const T* __restrict__ svc = sv + cbase + s;
+  emit(p0, mask ? svc[(size_t)p0 * S] : (T)0);
+  int p = p0 + 1;
+  for (; p + kSlideUnroll <= p1; p += kSlideUnroll) {
+    double ain[kSlideUnroll], aout[kSlideUnroll];
+    int kin[kSlideUnroll], kout[kSlideUnroll];
+    T x[kSlideUnroll];
+#pragma unroll
+    for (int j = 0; j < kSlideUnroll; ++j) {
+      const size_t ri = (size_t)reflect_index(p + j + n, P) * S, ro = (size_t)reflect_index(p + j - n - 1, P) * S;
+      ain[j] = vs[ri];
+      kin[j] = vc[ri];
+      aout[j] = vs[ro];
+      kout[j] = vc[ro];
+      x[j] = mask ? svc[(size_t)(p + j) * S] : (T)0;
+    }
+#pragma unroll
+    for (int j = 0; j < kSlideUnroll; ++j) {
+      w.add(ain[j], kin[j], 1.0);
+      w.add(aout[j], kout[j], -1.0);
+      emit(p + j, x[j]);
+    }
+  }
+  for (; p < p1; ++p) {
+    const size_t ri = (size_t)reflect_index(p + n, P) * S, ro = (size_t)reflect_index(p - n - 1, P) * S;
+    w.add(vs[ri], vc[ri], 1.0);
+    w.add(vs[ro], vc[ro], -1.0);
+    emit(p, mask ? svc[(size_t)p * S] : (T)0);
   }
 }
 
@@ -737,6 +879,164 @@ __global__ __launch_bounds__(kBlock) void pool_value_mean_kernel(PoolValueArgs<T
   }
 }
 
+// ---- nanmean through per-row running sums ------------------------------------------------------------------
+// The brute-force kernel above visits every value of every window (and converts it to linear each time):
+// (2n+1) x ~2*bin/step values per sample.  With the running sums of the linear Sv along each row,
+//   W[k] = sum_{j<=k} lin(Sv[j]),  N[k] = number of non-NaN values among j<=k,
+// a row contributes W[hi-1] - W[lo-1] for its index interval [lo, hi) -- O(1) per row once lo / hi are known, and
+// they are known from the row above unless the range vectors differ (checked with two loads, re-searched if
+// not).  W is kept in double-double (two-sum), so the difference of two running sums is the window sum to
+// ~1e-30 of the ROW total: nothing is lost to cancellation.  Rows holding a +inf Sv are flagged and summed
+// value by value (inf - inf).  Workspace: 20 B per sample + 1 B per row.
+struct Dd {
+  double hi, lo;
+  __device__ __forceinline__ void add(double x) {  // x finite
+    const double t = hi + x, bb = t - hi;
+    lo += (hi - (t - bb)) + (x - bb);
+    hi = t;
+  }
+  __device__ __forceinline__ void add(const Dd& b, double sign) {
+    const double bh = sign * b.hi, bl = sign * b.lo;
+    const double t = hi + bh, bb = t - hi;
+    const double e = (hi - (t - bb)) + (bh - bb) + lo + bl;
+    hi = t + e;
+    lo = e - (hi - t);
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void row_running_sum_kernel(const T* __restrict__ sv, long long rows, int S,
+                                                                 double* __restrict__ wh, double* __restrict__ wl,
+                                                                 int* __restrict__ wn, uint8_t* __restrict__ dirty) {
+  __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
+  __shared__ double th[kBlock], tl[kBlock], gh[16], gl[16];
+  __shared__ int tc[kBlock], gc[16], any_inf;
+  const epa::MathTabs mt = epa::build_math_tabs(tabs);
+  const int t = threadIdx.x, E = (S + kBlock - 1) / kBlock;
+  const int k0 = min(S, t * E), k1 = min(S, k0 + E);
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    __syncthreads();
+    if (t == 0) any_inf = 0;
+    const T* svr = sv + (size_t)row * S;
+    Dd acc{0.0, 0.0};
+    int cnt = 0;
+    bool inf = false;
+    for (int k = k0; k < k1; ++k) {
+      const T v = svr[k];
+      if (v == v) {
+        const double x = (double)epa::lin_from_db(v, mt.exp2_tab);
+        if (x == __builtin_inf()) inf = true; else acc.add(x);
+        ++cnt;
+      }
+    }
+    th[t] = acc.hi; tl[t] = acc.lo; tc[t] = cnt;
+    __syncthreads();
+    if (inf) any_inf = 1;
+    // exclusive offset of this lane's run: 16 groups of 16 lanes
+    Dd off{0.0, 0.0};
+    int offc = 0;
+    for (int j = t & ~15; j < t; ++j) {
+      off.add(Dd{th[j], tl[j]}, 1.0);
+      offc += tc[j];
+    }
+    if ((t & 15) == 15) {
+      Dd g = off;
+      g.add(acc, 1.0);
+      gh[t >> 4] = g.hi; gl[t >> 4] = g.lo; gc[t >> 4] = offc + cnt;
+    }
+    __syncthreads();
+    for (int h = 0; h < (t >> 4); ++h) {
+      off.add(Dd{gh[h], gl[h]}, 1.0);
+      offc += gc[h];
+    }
+    double* whr = wh + (size_t)row * S;
+    double* wlr = wl + (size_t)row * S;
+    int* wnr = wn + (size_t)row * S;
+    for (int k = k0; k < k1; ++k) {
+      const T v = svr[k];
+      if (v == v) {
+        const double x = (double)epa::lin_from_db(v, mt.exp2_tab);
+        if (x != __builtin_inf()) off.add(x);
+        ++offc;
+      }
+      whr[k] = off.hi; wlr[k] = off.lo; wnr[k] = offc;
+    }
+    if (t == 0) dirty[row] = (uint8_t)any_inf;
+  }
+}
+
+// first index with row[idx] >= v / > v, trying the answer of the previous row first
+template <typename T, bool STRICT>
+__device__ __forceinline__ int bound_hint(const T* __restrict__ row, int n, T v, int hint) {
+  if (hint >= 0 && hint <= n) {
+    const bool below = hint == 0 || !(STRICT ? (row[hint - 1] > v) : (row[hint - 1] >= v));
+    const bool above = hint == n || (STRICT ? (row[hint] > v) : (row[hint] >= v));
+    if (below && above) return hint;
+  }
+  return bound<T, STRICT>(row, n, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pool_value_mean_prefix_kernel(PoolValueArgs<T> a, long long rows,
+                                                                        const double* __restrict__ wh,
+                                                                        const double* __restrict__ wl,
+                                                                        const int* __restrict__ wn,
+                                                                        const uint8_t* __restrict__ dirty) {
+  __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
+  const epa::MathTabs mt = epa::build_math_tabs(tabs);
+  __syncthreads();
+  const int s = blockIdx.y * kBlock + threadIdx.x;
+  if (s >= a.S) return;
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int p = (int)(row % a.P);
+    const long long c = row / a.P;
+    const size_t at = (size_t)row * a.S + s;
+    const T d = a.range[at];
+    T out = epa::M<T>::nan();
+    if (pool_feasible(a, d, p)) {
+      const T lo_v = d - a.bin, hi_v = d + a.bin;
+      Dd sum{0.0, 0.0};
+      long long cnt = 0;
+      bool has_inf = false;
+      int lo = -1, hi = -1;
+      const int q1 = min(p + a.n, a.P - 1);
+      for (int q = p - a.n; q <= q1; ++q) {
+        const size_t qrow = (size_t)(c * a.P + q);
+        const T* rr = a.range + qrow * a.S;
+        const int nv = a.nvalid[qrow];
+        lo = bound_hint<T, false>(rr, nv, lo_v, lo);
+        hi = bound_hint<T, true>(rr, nv, hi_v, hi);
+        if (hi <= lo) continue;
+        const size_t base = qrow * a.S;
+        if (dirty[qrow]) {  // a +inf Sv somewhere in this row: value by value
+          const T* vr = a.sv + base;
+          for (int k = lo; k < hi; ++k) {
+            const T v = vr[k];
+            if (v == v) {
+              const double x = (double)epa::lin_from_db(v, mt.exp2_tab);
+              if (x == __builtin_inf()) has_inf = true; else sum.add(x);
+              ++cnt;
+            }
+          }
+          continue;
+        }
+        sum.add(Dd{wh[base + hi - 1], wl[base + hi - 1]}, 1.0);
+        cnt += wn[base + hi - 1];
+        if (lo > 0) {
+          sum.add(Dd{wh[base + lo - 1], wl[base + lo - 1]}, -1.0);
+          cnt -= wn[base + lo - 1];
+        }
+      }
+      if (cnt > 0) {
+        const double tot = has_inf ? __builtin_inf() : sum.hi + sum.lo;
+        out = (T)(10.0 * epa::fast_log10(tot / (double)cnt, mt.log_tab));
+      }
+    }
+    if (a.pooled) a.pooled[at] = out;
+    if (a.mask) a.mask[at] = (a.sv[at] - out > a.thr) ? 1 : 0;
+  }
+}
+
 // nanmedian: one workgroup per output sample
 constexpr int kMaxSidePings = 512;
 
@@ -885,15 +1185,28 @@ extern "C" int epa_pool_sv(const void* sv, int C, int P, int S, int first_sample
     return epa::check_launch("pool_median_kernel");
   }
   EPA_CHECK_ARG(ws_sum && ws_cnt, "epa_pool_sv: nanmean needs the f64 / int32 [C*P*S] workspaces");
-  const size_t nin = (size_t)kRangeTile + 2 * m, nrow = (size_t)kPingTile + 2 * n;
+  const size_t nin = (size_t)kRangeTile + 2 * m;
   const size_t lds1 = epa::kMathTabBytes + (nin + 2) * 8 + (nin / kGroup + 1) * 12;
-  const size_t lds2 = epa::kMathTabBytes + (nrow + nrow / kGroup + 1) * kColTile * 12;
-  if (lds1 > kMaxLds || lds2 > kMaxLds) {
+  if (lds1 > kMaxLds) {
     epa::set_error("epa_pool_sv: window %d x %d exceeds the LDS budget", 2 * n + 1, 2 * m + 1);
     return EPA_EUNSUPPORTED;
   }
   const long long rows = (long long)C * P;
-  if (s0 < S) {
+  const int w = 2 * m + 1;
+  if (s0 < S && w >= kScanMinW && w <= kScanMaxW) {
+    const size_t ninp = (size_t)((kScanTile + 2 * m + 2) & ~1);
+    const size_t lds = epa::kMathTabBytes + (2 * ninp + 2 * kBlock) * 8 + (2 * ninp + 2 * kBlock) * 2;
+    const dim3 g1(row_grid(rows) < 16384 ? row_grid(rows) : 16384, (S - s0 + kScanTile - 1) / kScanTile);
+#define EPA_BR(T)                                                                                   \
+  do {                                                                                              \
+    auto kern = box_range_scan_kernel<T>;                                                           \
+    if (int rc = set_lds(kern, lds)) return rc;                                                     \
+    hipLaunchKernelGGL(kern, g1, dim3(kBlock), lds, st, (const T*)sv, rows, S, s0, m, ws_sum, ws_cnt); \
+  } while (0)
+    if (dtype == EPA_F64) EPA_BR(double); else EPA_BR(float);
+#undef EPA_BR
+    if (int rc = epa::check_launch("box_range_scan_kernel")) return rc;
+  } else if (s0 < S) {
     const dim3 g1(row_grid(rows) < 16384 ? row_grid(rows) : 16384, (S - s0 + kRangeTile - 1) / kRangeTile);
 #define EPA_BR(T)                                                                                   \
   do {                                                                                              \
@@ -905,18 +1218,17 @@ extern "C" int epa_pool_sv(const void* sv, int C, int P, int S, int first_sample
 #undef EPA_BR
     if (int rc = epa::check_launch("box_range_kernel")) return rc;
   }
-  const long long ntiles = (long long)C * ((P + kPingTile - 1) / kPingTile) * ((S + kColTile - 1) / kColTile);
-  const int g2 = (int)(ntiles < 256 * 24 ? ntiles : 256 * 24);
-#define EPA_BP(T)                                                                                   \
-  do {                                                                                              \
-    auto kern = box_ping_kernel<T>;                                                                 \
-    if (int rc = set_lds(kern, lds2)) return rc;                                                    \
-    hipLaunchKernelGGL(kern, dim3(g2), dim3(kBlock), lds2, st, (const T*)sv, ws_sum, ws_cnt, P, S,  \
-                       s0, n, ntiles, (T)threshold, (T*)pooled_out, mask_out);                      \
-  } while (0)
-  if (dtype == EPA_F64) EPA_BP(double); else EPA_BP(float);
-#undef EPA_BP
-  return epa::check_launch("box_ping_kernel");
+  // ping pass: grid = (ping segments, column stripes, channels)
+  const dim3 g2((P + kSlideSeg - 1) / kSlideSeg, (S + kBlock - 1) / kBlock, C);
+  EPA_CHECK_ARG(g2.y <= 65535u && g2.z <= 65535u, "epa_pool_sv: more than 65535 channels or 16.7 M samples per ping");
+  if (dtype == EPA_F64)
+    hipLaunchKernelGGL(box_ping_slide_kernel<double>, g2, dim3(kBlock), epa::kMathTabBytes + kSlidePad, st,
+                       (const double*)sv, ws_sum, ws_cnt, P, S, s0, n, threshold, (double*)pooled_out, mask_out);
+  else
+    hipLaunchKernelGGL(box_ping_slide_kernel<float>, g2, dim3(kBlock), epa::kMathTabBytes + kSlidePad, st,
+                       (const float*)sv, ws_sum, ws_cnt, P, S, s0, n, (float)threshold, (float*)pooled_out,
+                       mask_out);
+  return epa::check_launch("box_ping_slide_kernel");
 }
 
 extern "C" int epa_range_rows_check(const void* range, int C, int P, int S, int dtype, int32_t* nvalid_out,
@@ -940,12 +1252,24 @@ namespace {
 template <typename T>
 int launch_pool_value(const void* sv, const void* range, const int32_t* nvalid, int C, int P, int S,
                       double bin, int n, double exclude_above, double rmin, double rmax, int func,
-                      double thr, void* pooled, uint8_t* mask, hipStream_t st) {
+                      double thr, void* pooled, uint8_t* mask, void* ws, hipStream_t st) {
   PoolValueArgs<T> a{(const T*)sv, (const T*)range, nvalid, P, S, n, (T)bin, (T)exclude_above,
                      (T)rmin, (T)rmax, (T)thr, (T*)pooled, mask};
   if (func == EPA_POOL_NANMEAN) {
     const long long rows = (long long)C * P;
     const dim3 grid(row_grid(rows) < 32768 ? row_grid(rows) : 32768, (S + kBlock - 1) / kBlock);
+    if (ws) {
+      const size_t N = (size_t)rows * S;
+      double* wh = static_cast<double*>(ws);
+      double* wl = wh + N;
+      int* wn = reinterpret_cast<int*>(wl + N);
+      uint8_t* dirty = reinterpret_cast<uint8_t*>(wn + N);
+      hipLaunchKernelGGL(row_running_sum_kernel<T>, dim3(row_grid(rows) < 16384 ? row_grid(rows) : 16384),
+                         dim3(kBlock), 0, st, (const T*)sv, rows, S, wh, wl, wn, dirty);
+      if (int rc = epa::check_launch("row_running_sum_kernel")) return rc;
+      hipLaunchKernelGGL(pool_value_mean_prefix_kernel<T>, grid, dim3(kBlock), 0, st, a, rows, wh, wl, wn, dirty);
+      return epa::check_launch("pool_value_mean_prefix_kernel");
+    }
     hipLaunchKernelGGL(pool_value_mean_kernel<T>, grid, dim3(kBlock), 0, st, a, rows);
     return epa::check_launch("pool_value_mean_kernel");
   }
@@ -959,7 +1283,7 @@ int launch_pool_value(const void* sv, const void* range, const int32_t* nvalid, 
 extern "C" int epa_pool_sv_value(const void* sv, const void* range, const int32_t* nvalid, int C, int P,
                                  int S, double depth_bin, int num_side_pings, double exclude_above,
                                  double range_min, double range_max, int func, double threshold,
-                                 void* pooled_out, uint8_t* mask_out, int dtype, epa_stream_t stream) {
+                                 void* pooled_out, uint8_t* mask_out, void* ws, int dtype, epa_stream_t stream) {
   EPA_CHECK_ARG(sv && range && nvalid && (pooled_out || mask_out), "epa_pool_sv_value: NULL array argument");
   EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_pool_sv_value: sizes must be positive");
   EPA_CHECK_ARG(num_side_pings >= 0, "epa_pool_sv_value: num_side_pings must be >= 0");
@@ -972,9 +1296,9 @@ extern "C" int epa_pool_sv_value(const void* sv, const void* range, const int32_
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EPA_F64)
     return launch_pool_value<double>(sv, range, nvalid, C, P, S, depth_bin, num_side_pings, exclude_above,
-                                     range_min, range_max, func, threshold, pooled_out, mask_out, st);
+                                     range_min, range_max, func, threshold, pooled_out, mask_out, ws, st);
   return launch_pool_value<float>(sv, range, nvalid, C, P, S, depth_bin, num_side_pings, exclude_above,
-                                  range_min, range_max, func, threshold, pooled_out, mask_out, st);
+                                  range_min, range_max, func, threshold, pooled_out, mask_out, ws, st);
 }
 
 extern "C" int epa_attenuated_mask(const void* sv, const void* range, int C, int P, int S,

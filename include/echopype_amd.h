@@ -334,10 +334,14 @@ int epa_range_rows_check(const void* range, int C, int P, int S, int dtype, int3
  * p-n..p+n (clipped to the data) with range in [d - depth_bin, d + depth_bin]; NaN where
  * d - bin < range_min, d + bin > range_max, d - bin < exclude_above, p - n < 0 or p + n > P.
  * range rows must pass epa_range_rows_check (nvalid from it).  func / threshold / outputs as epa_pool_sv. */
+#define EPA_POOL_VALUE_WS_BYTES(C, P, S) ((size_t)(C) * (P) * (S) * 20 + (size_t)(C) * (P))
+/* ws (optional, nanmean only): EPA_POOL_VALUE_WS_BYTES bytes, 8-byte aligned.  With it the window sums come from
+ * per-row running sums kept in double-double -- O(pings) work per sample instead of O(window); without it every
+ * window is summed value by value.  Same results to rounding. */
 int epa_pool_sv_value(const void* sv, const void* range, const int32_t* nvalid, int C, int P, int S,
                       double depth_bin, int num_side_pings, double exclude_above, double range_min,
                       double range_max, int func, double threshold, void* pooled_out, uint8_t* mask_out,
-                      int dtype, epa_stream_t stream);
+                      void* ws, int dtype, epa_stream_t stream);
 
 /* ==== SURVEY 8f "next" row 3: compute_NASC ==============================================================
  * Array pass of commongrid/utils.py:97-205 (compute_raw_NASC): NASC = sv_mean * h_mean * 4*pi*1852^2 with

@@ -200,6 +200,69 @@ def test_pool_sv_window_larger_than_array(env):
         _close(pooled.cpu().numpy()[0], exp, 1e-9, func)
 
 
+def test_pool_sv_sliding_sum_keeps_small_values_after_a_huge_one(env):
+    """The ping pass carries the window sum from ping to ping (enter / leave); a value 10^14 times larger than its
+    neighbours passing through the window must leave nothing behind (double-double carry), a +inf must not turn
+    the pings after it into NaN, and segment joins (512 pings) must be seamless."""
+    import scipy.ndimage
+
+    torch, ops = env
+    rng = np.random.default_rng(5)
+    P, S, n, m = 1300, 24, 6, 4
+    sv = -120 + 3 * rng.standard_normal((1, P, S))
+    sv[0, 40, 5] = 25.0          # 10^14.5 above the background
+    sv[0, 700:703, 10:14] = 40.0
+    sv[0, 511, 3] = sv[0, 512, 17] = 30.0   # at a segment join
+    sv[0, rng.random((P, S)) < 0.05] = np.nan
+    with np.errstate(invalid="ignore"):
+        exp = 10 * np.log10(scipy.ndimage.generic_filter(10 ** (sv[0] / 10), np.nanmean, size=[2 * n + 1, 2 * m + 1],
+                                                         mode="reflect"))
+    pooled, _ = ops.pool_sv(_dev(torch, sv), 0, n, m)
+    got = pooled.cpu().numpy()[0]
+    _close(got, exp, 1e-9, "sliding window after a spike")
+    assert np.nanmin(exp) < -115 and np.nanmax(exp) > 0  # both regimes present
+    sv[0, 100, 7] = np.inf
+    pooled, _ = ops.pool_sv(_dev(torch, sv), 0, n, m)
+    got2 = pooled.cpu().numpy()[0]
+    hit = np.zeros((P, S), bool)
+    hit[100 - n:100 + n + 1, 7 - m:7 + m + 1] = True
+    assert np.isposinf(got2[hit]).all()
+    np.testing.assert_array_equal(got2[~hit], got[~hit])
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_pool_sv_value_running_sums_equal_window_sums(env, dtype):
+    """Value-window pooling: per-row double-double running sums (default) == summing every window (workspace
+    NULL) == the oracle's triple loop, on rows whose range vectors differ from ping to ping, with a NaN-padded
+    tail, a 140 dB spike and a +inf sample."""
+    torch, ops = env
+    rng = np.random.default_rng(8)
+    C, P, S, n, dbin = 2, 40, 300, 4, 1.5
+    sv, depth = _scene(C, P, S, 12, step=0.3)
+    depth = depth * (1 + 0.01 * rng.random((C, P, 1)))          # a different range vector per ping
+    depth[:, 7, S - 20:] = np.nan
+    sv[:, 7, S - 20:] = np.nan
+    sv[0, 10, 100] = 60.0
+    sv[1, 20, 50] = np.inf
+    sv, depth = sv.astype(dtype), depth.astype(dtype)
+    svt, rgt = _dev(torch, sv), _dev(torch, depth)
+    nvalid, bad = ops.range_rows_check(rgt)
+    assert bad == 0
+    lo, hi = ops.nanminmax(rgt)
+    a, ma = ops.pool_sv_value(svt, rgt, nvalid, dbin, n, 2.0, lo, hi, threshold=6.0, running_sums=True)
+    b, mb = ops.pool_sv_value(svt, rgt, nvalid, dbin, n, 2.0, lo, hi, threshold=6.0, running_sums=False)
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+    _close(a, b, 1e-12 if dtype == "float64" else 1e-5, "running sums vs window sums")
+    assert np.isposinf(a).any() and np.isfinite(a).any()
+    exp = omask.pool_Sv(sv.astype(np.float64), depth.astype(np.float64), np.nanmean, dbin, n, 2.0)
+    _close(a, exp, RTOL[dtype], "vs oracle")
+    agree = ma.cpu().numpy() == mb.cpu().numpy()
+    with np.errstate(invalid="ignore"):
+        sure = ~(np.abs(sv.astype(np.float64) - exp - 6.0) < MARGIN[dtype])
+    assert agree[sure].all()
+
+
 def test_pool_sv_everything_above_exclusion(env):
     torch, ops = env
     sv, _ = _scene(1, 6, 10, 3)
