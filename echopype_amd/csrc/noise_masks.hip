@@ -904,24 +904,32 @@ struct Dd {
   }
 };
 
+// One workgroup per row, one quarter of the row per wavefront, lanes interleaved (coalesced 512-B accesses):
+// sweep 1 sums the quarter (wave totals -> offsets), sweep 2 scans it 64 samples at a time with a shuffle scan
+// in double-double and carries the running value to the next 64.
+__device__ __forceinline__ Dd dd_shfl_up(const Dd& v, int o) {
+  return Dd{__shfl_up(v.hi, o, 64), __shfl_up(v.lo, o, 64)};
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void row_running_sum_kernel(const T* __restrict__ sv, long long rows, int S,
                                                                  double* __restrict__ wh, double* __restrict__ wl,
                                                                  int* __restrict__ wn, uint8_t* __restrict__ dirty) {
   __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
-  __shared__ double th[kBlock], tl[kBlock], gh[16], gl[16];
-  __shared__ int tc[kBlock], gc[16], any_inf;
+  __shared__ double th[4], tl[4];
+  __shared__ int tc[4], any_inf;
   const epa::MathTabs mt = epa::build_math_tabs(tabs);
-  const int t = threadIdx.x, E = (S + kBlock - 1) / kBlock;
-  const int k0 = min(S, t * E), k1 = min(S, k0 + E);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int Q = (((S + 3) / 4) + 63) & ~63;
+  const int k0 = min(S, wave * Q), k1 = min(S, k0 + Q);
   for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
     __syncthreads();
-    if (t == 0) any_inf = 0;
+    if (threadIdx.x == 0) any_inf = 0;
     const T* svr = sv + (size_t)row * S;
     Dd acc{0.0, 0.0};
     int cnt = 0;
     bool inf = false;
-    for (int k = k0; k < k1; ++k) {
+    for (int k = k0 + lane; k < k1; k += 64) {
       const T v = svr[k];
       if (v == v) {
         const double x = (double)epa::lin_from_db(v, mt.exp2_tab);
@@ -929,39 +937,54 @@ __global__ __launch_bounds__(kBlock) void row_running_sum_kernel(const T* __rest
         ++cnt;
       }
     }
-    th[t] = acc.hi; tl[t] = acc.lo; tc[t] = cnt;
-    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      acc.add(Dd{__shfl_down(acc.hi, o, 64), __shfl_down(acc.lo, o, 64)}, 1.0);
+      cnt += __shfl_down(cnt, o, 64);
+    }
+    __syncthreads();  // any_inf reset, previous row's totals consumed
+    if (lane == 0) { th[wave] = acc.hi; tl[wave] = acc.lo; tc[wave] = cnt; }
     if (inf) any_inf = 1;
-    // exclusive offset of this lane's run: 16 groups of 16 lanes
-    Dd off{0.0, 0.0};
-    int offc = 0;
-    for (int j = t & ~15; j < t; ++j) {
-      off.add(Dd{th[j], tl[j]}, 1.0);
-      offc += tc[j];
-    }
-    if ((t & 15) == 15) {
-      Dd g = off;
-      g.add(acc, 1.0);
-      gh[t >> 4] = g.hi; gl[t >> 4] = g.lo; gc[t >> 4] = offc + cnt;
-    }
     __syncthreads();
-    for (int h = 0; h < (t >> 4); ++h) {
-      off.add(Dd{gh[h], gl[h]}, 1.0);
-      offc += gc[h];
+    Dd carry{0.0, 0.0};
+    int carry_n = 0;
+    for (int w = 0; w < wave; ++w) {
+      carry.add(Dd{th[w], tl[w]}, 1.0);
+      carry_n += tc[w];
     }
     double* whr = wh + (size_t)row * S;
     double* wlr = wl + (size_t)row * S;
     int* wnr = wn + (size_t)row * S;
-    for (int k = k0; k < k1; ++k) {
-      const T v = svr[k];
-      if (v == v) {
-        const double x = (double)epa::lin_from_db(v, mt.exp2_tab);
-        if (x != __builtin_inf()) off.add(x);
-        ++offc;
+    for (int kb = k0; kb < k1; kb += 64) {
+      const int k = kb + lane;
+      Dd v{0.0, 0.0};
+      int c = 0;
+      if (k < k1) {
+        const T x = svr[k];
+        if (x == x) {
+          const double y = (double)epa::lin_from_db(x, mt.exp2_tab);
+          if (y != __builtin_inf()) v.hi = y;
+          c = 1;
+        }
       }
-      whr[k] = off.hi; wlr[k] = off.lo; wnr[k] = offc;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {  // inclusive scan across the wavefront
+        const Dd u = dd_shfl_up(v, o);
+        const int uc = __shfl_up(c, o, 64);
+        if (lane >= o) {
+          v.add(u, 1.0);
+          c += uc;
+        }
+      }
+      v.add(carry, 1.0);
+      c += carry_n;
+      if (k < k1) {
+        whr[k] = v.hi; wlr[k] = v.lo; wnr[k] = c;
+      }
+      carry = Dd{__shfl(v.hi, 63, 64), __shfl(v.lo, 63, 64)};
+      carry_n = __shfl(c, 63, 64);
     }
-    if (t == 0) dirty[row] = (uint8_t)any_inf;
+    if (threadIdx.x == 0) dirty[row] = (uint8_t)any_inf;
   }
 }
 
@@ -981,7 +1004,8 @@ __global__ __launch_bounds__(kBlock) void pool_value_mean_prefix_kernel(PoolValu
                                                                         const double* __restrict__ wh,
                                                                         const double* __restrict__ wl,
                                                                         const int* __restrict__ wn,
-                                                                        const uint8_t* __restrict__ dirty) {
+                                                                        const uint8_t* __restrict__ dirty,
+                                                                        const int* __restrict__ differ) {
   __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
   const epa::MathTabs mt = epa::build_math_tabs(tabs);
   __syncthreads();
@@ -990,6 +1014,7 @@ __global__ __launch_bounds__(kBlock) void pool_value_mean_prefix_kernel(PoolValu
   for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
     const int p = (int)(row % a.P);
     const long long c = row / a.P;
+    if (!differ[c]) continue;  // every ping of the channel has the same range vector: value_slide_kernel
     const size_t at = (size_t)row * a.S + s;
     const T d = a.range[at];
     T out = epa::M<T>::nan();
@@ -1034,6 +1059,164 @@ __global__ __launch_bounds__(kBlock) void pool_value_mean_prefix_kernel(PoolValu
     }
     if (a.pooled) a.pooled[at] = out;
     if (a.mask) a.mask[at] = (a.sv[at] - out > a.thr) ? 1 : 0;
+  }
+}
+
+// ---- channels whose pings all share one range vector (the usual echo_range) ---------------------------------
+// Then the index interval [lo, hi) of a depth window depends on the sample only, a neighbour ping contributes
+// R[q][s] = W_q[hi-1] - W_q[lo-1] whatever the ping it is needed for, and the window sum over pings is a sliding
+// sum of R down the column (double-double as in box_ping_slide_kernel): ~140 B of HBM traffic per sample instead
+// of ~500 cached loads.  Rows may be NaN-padded to different lengths (intervals are clipped to each row's length).
+__global__ __launch_bounds__(kBlock) void ref_row_kernel(const int* __restrict__ nvalid, int P,
+                                                         int* __restrict__ ref, int* __restrict__ differ) {
+  __shared__ int best[kBlock], arg[kBlock];
+  const int c = blockIdx.x;
+  int b = -1, a = 0;
+  for (int p = threadIdx.x; p < P; p += kBlock) {
+    const int v = nvalid[(size_t)c * P + p];
+    if (v > b) { b = v; a = p; }
+  }
+  best[threadIdx.x] = b; arg[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const int b2 = best[threadIdx.x + o], a2 = arg[threadIdx.x + o];
+      if (b2 > best[threadIdx.x] || (b2 == best[threadIdx.x] && a2 < arg[threadIdx.x])) {
+        best[threadIdx.x] = b2; arg[threadIdx.x] = a2;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { ref[c] = arg[0]; differ[c] = 0; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void rows_same_kernel(const T* __restrict__ range,
+                                                           const int* __restrict__ nvalid, long long rows, int P,
+                                                           int S, const int* __restrict__ ref,
+                                                           int* __restrict__ differ) {
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const long long c = row / P;
+    const T* xr = range + (size_t)row * S;
+    const T* rr = range + (size_t)(c * P + ref[c]) * S;
+    const int nv = nvalid[row];
+    int bad = 0;
+    for (int k = threadIdx.x; k < nv; k += kBlock) bad |= xr[k] != rr[k];
+    if (bad) atomicOr(&differ[c], 1);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void value_intervals_kernel(PoolValueArgs<T> a, const int* __restrict__ ref,
+                                                                 int* __restrict__ ilo, int* __restrict__ ihi) {
+  const int s = blockIdx.x * kBlock + threadIdx.x, c = blockIdx.y;
+  if (s >= a.S) return;
+  const size_t rrow = (size_t)c * a.P + ref[c];
+  const T* rr = a.range + rrow * a.S;
+  const int nv = a.nvalid[rrow];
+  int lo = -1, hi = -1;
+  if (s < nv) {
+    const T d = rr[s];
+    if ((d - a.bin >= a.rmin) && (d + a.bin <= a.rmax) && (d - a.bin >= a.exclude_above)) {  // pool_feasible
+      lo = bound<T, false>(rr, nv, d - a.bin);
+      hi = bound<T, true>(rr, nv, d + a.bin);
+    }
+  }
+  ilo[(size_t)c * a.S + s] = lo;
+  ihi[(size_t)c * a.S + s] = hi;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void row_interval_sum_kernel(
+    PoolValueArgs<T> a, long long rows, const double* __restrict__ wh, const double* __restrict__ wl,
+    const int* __restrict__ wn, const uint8_t* __restrict__ dirty, const int* __restrict__ differ,
+    const int* __restrict__ ilo, const int* __restrict__ ihi, double* __restrict__ rh, double* __restrict__ rl,
+    int* __restrict__ rn) {
+  __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
+  const epa::MathTabs mt = epa::build_math_tabs(tabs);
+  __syncthreads();
+  const int s = blockIdx.y * kBlock + threadIdx.x;
+  if (s >= a.S) return;
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const long long c = row / a.P;
+    if (differ[c]) continue;
+    const int nv = a.nvalid[row];
+    const int lo = min(ilo[(size_t)c * a.S + s], nv), hi = min(ihi[(size_t)c * a.S + s], nv);
+    const size_t base = (size_t)row * a.S;
+    Dd sum{0.0, 0.0};
+    int cnt = 0;
+    bool has_inf = false;
+    if (lo >= 0 && hi > lo) {
+      if (dirty[row]) {
+        const T* vr = a.sv + base;
+        for (int k = lo; k < hi; ++k) {
+          const T v = vr[k];
+          if (v == v) {
+            const double x = (double)epa::lin_from_db(v, mt.exp2_tab);
+            if (x == __builtin_inf()) has_inf = true; else sum.add(x);
+            ++cnt;
+          }
+        }
+      } else {
+        sum.add(Dd{wh[base + hi - 1], wl[base + hi - 1]}, 1.0);
+        cnt = wn[base + hi - 1];
+        if (lo > 0) {
+          sum.add(Dd{wh[base + lo - 1], wl[base + lo - 1]}, -1.0);
+          cnt -= wn[base + lo - 1];
+        }
+      }
+    }
+    rh[base + s] = has_inf ? __builtin_inf() : sum.hi;
+    rl[base + s] = has_inf ? 0.0 : sum.lo;
+    rn[base + s] = cnt;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void value_slide_kernel(PoolValueArgs<T> a, const int* __restrict__ differ,
+                                                             const int* __restrict__ ilo,
+                                                             const double* __restrict__ rh,
+                                                             const double* __restrict__ rl,
+                                                             const int* __restrict__ rn) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const epa::MathTabs mt = epa::build_math_tabs(smem);
+  __syncthreads();
+  const int s = blockIdx.y * kBlock + threadIdx.x, c = blockIdx.z;
+  if (s >= a.S || differ[c]) return;
+  const int P = a.P, S = a.S, n = a.n;
+  const int p0 = blockIdx.x * kSlideSeg, p1 = min(P, p0 + kSlideSeg);
+  const size_t cbase = (size_t)c * P * S;
+  const bool depth_ok = ilo[(size_t)c * S + s] >= 0;
+  const double* __restrict__ h = rh + cbase + s;
+  const double* __restrict__ l = rl + cbase + s;
+  const int* __restrict__ k = rn + cbase + s;
+  DdSum w;
+  if (depth_ok)
+    for (int q = max(0, p0 - n); q <= min(P - 1, p0 + n); ++q) {
+      const size_t r = (size_t)q * S;
+      w.add(h[r], k[r], 1.0);
+      w.add(l[r], 0, 1.0);
+    }
+  for (int p = p0; p < p1; ++p) {
+    if (depth_ok && p > p0) {
+      const int in = p + n, out = p - n - 1;
+      if (in <= P - 1) {
+        const size_t r = (size_t)in * S;
+        w.add(h[r], k[r], 1.0);
+        w.add(l[r], 0, 1.0);
+      }
+      if (out >= 0) {
+        const size_t r = (size_t)out * S;
+        w.add(h[r], k[r], -1.0);
+        w.add(l[r], 0, -1.0);
+      }
+    }
+    T res = epa::M<T>::nan();
+    const bool ok = depth_ok && (p - n >= 0) && ((long long)p + n <= (long long)P) && s < a.nvalid[(size_t)c * P + p];
+    if (ok && w.cnt > 0) res = (T)(10.0 * epa::fast_log10(w.value() / (double)w.cnt, mt.log_tab));
+    const size_t at = cbase + (size_t)p * S + s;
+    if (a.pooled) a.pooled[at] = res;
+    if (a.mask) a.mask[at] = (a.sv[at] - res > a.thr) ? 1 : 0;
   }
 }
 
@@ -1262,12 +1445,35 @@ int launch_pool_value(const void* sv, const void* range, const int32_t* nvalid, 
       const size_t N = (size_t)rows * S;
       double* wh = static_cast<double*>(ws);
       double* wl = wh + N;
-      int* wn = reinterpret_cast<int*>(wl + N);
-      uint8_t* dirty = reinterpret_cast<uint8_t*>(wn + N);
-      hipLaunchKernelGGL(row_running_sum_kernel<T>, dim3(row_grid(rows) < 16384 ? row_grid(rows) : 16384),
-                         dim3(kBlock), 0, st, (const T*)sv, rows, S, wh, wl, wn, dirty);
+      double* rh = wl + N;
+      double* rl = rh + N;
+      int* wn = reinterpret_cast<int*>(rl + N);
+      int* rn = wn + N;
+      int* ilo = rn + N;
+      int* ihi = ilo + (size_t)C * S;
+      int* ref = ihi + (size_t)C * S;
+      int* differ = ref + C;
+      uint8_t* dirty = reinterpret_cast<uint8_t*>(differ + C);
+      const dim3 rowg(row_grid(rows) < 16384 ? row_grid(rows) : 16384);
+      hipLaunchKernelGGL(row_running_sum_kernel<T>, rowg, dim3(kBlock), 0, st, (const T*)sv, rows, S, wh, wl, wn, dirty);
       if (int rc = epa::check_launch("row_running_sum_kernel")) return rc;
-      hipLaunchKernelGGL(pool_value_mean_prefix_kernel<T>, grid, dim3(kBlock), 0, st, a, rows, wh, wl, wn, dirty);
+      // which channels have one range vector for all their pings?
+      hipLaunchKernelGGL(ref_row_kernel, dim3(C), dim3(kBlock), 0, st, nvalid, P, ref, differ);
+      hipLaunchKernelGGL(rows_same_kernel<T>, rowg, dim3(kBlock), 0, st, (const T*)range, nvalid, rows, P, S, ref, differ);
+      hipLaunchKernelGGL(value_intervals_kernel<T>, dim3((S + kBlock - 1) / kBlock, C), dim3(kBlock), 0, st, a, ref, ilo, ihi);
+      if (int rc = epa::check_launch("rows_same_kernel")) return rc;
+      // those: interval sums per row, then a sliding sum down every column; the others: row by row
+      hipLaunchKernelGGL(row_interval_sum_kernel<T>, grid, dim3(kBlock), 0, st, a, rows, wh, wl, wn, dirty, differ, ilo,
+                         ihi, rh, rl, rn);
+      const dim3 g2((P + kSlideSeg - 1) / kSlideSeg, (S + kBlock - 1) / kBlock, C);
+      if (g2.y > 65535u || g2.z > 65535u) {
+        epa::set_error("epa_pool_sv_value: more than 65535 channels or 16.7 M samples per ping");
+        return EPA_EINVAL;
+      }
+      hipLaunchKernelGGL(value_slide_kernel<T>, g2, dim3(kBlock), epa::kMathTabBytes + kSlidePad, st, a, differ, ilo, rh,
+                         rl, rn);
+      if (int rc = epa::check_launch("value_slide_kernel")) return rc;
+      hipLaunchKernelGGL(pool_value_mean_prefix_kernel<T>, grid, dim3(kBlock), 0, st, a, rows, wh, wl, wn, dirty, differ);
       return epa::check_launch("pool_value_mean_prefix_kernel");
     }
     hipLaunchKernelGGL(pool_value_mean_kernel<T>, grid, dim3(kBlock), 0, st, a, rows);

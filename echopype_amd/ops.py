@@ -428,7 +428,7 @@ def pool_sv_value(sv, range, nvalid, depth_bin, num_side_pings, exclude_above, r
     mask = torch.empty((C, P, S), dtype=torch.uint8, device=sv.device) if want_mask else None
     ws = None
     if running_sums and func == "nanmean":
-        ws = torch.empty((C * P * S * 20 + C * P + 7) // 8, dtype=torch.float64, device=sv.device)
+        ws = torch.empty((C * P * S * 40 + C * S * 8 + C * 8 + C * P + 7) // 8, dtype=torch.float64, device=sv.device)
     call("epa_pool_sv_value", _p(sv), _p(range), _p(nvalid), C, P, S, float(depth_bin), int(num_side_pings),
          float(exclude_above), float(range_min), float(range_max), f, float(threshold), _p(pooled),
          _p(mask), _p(ws), _DT[sv.dtype], _stream())

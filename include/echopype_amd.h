@@ -334,10 +334,12 @@ int epa_range_rows_check(const void* range, int C, int P, int S, int dtype, int3
  * p-n..p+n (clipped to the data) with range in [d - depth_bin, d + depth_bin]; NaN where
  * d - bin < range_min, d + bin > range_max, d - bin < exclude_above, p - n < 0 or p + n > P.
  * range rows must pass epa_range_rows_check (nvalid from it).  func / threshold / outputs as epa_pool_sv. */
-#define EPA_POOL_VALUE_WS_BYTES(C, P, S) ((size_t)(C) * (P) * (S) * 20 + (size_t)(C) * (P))
+#define EPA_POOL_VALUE_WS_BYTES(C, P, S) \
+  ((size_t)(C) * (P) * (S) * 40 + (size_t)(C) * (S) * 8 + (size_t)(C) * 8 + (size_t)(C) * (P))
 /* ws (optional, nanmean only): EPA_POOL_VALUE_WS_BYTES bytes, 8-byte aligned.  With it the window sums come from
- * per-row running sums kept in double-double -- O(pings) work per sample instead of O(window); without it every
- * window is summed value by value.  Same results to rounding. */
+ * per-row running sums kept in double-double: a channel whose pings all share one range vector (checked on the
+ * device) gets per-row interval sums + a sliding sum down every column, O(1) per sample; any other channel
+ * O(pings) per sample.  Without it every window is summed value by value.  Same results to rounding. */
 int epa_pool_sv_value(const void* sv, const void* range, const int32_t* nvalid, int C, int P, int S,
                       double depth_bin, int num_side_pings, double exclude_above, double range_min,
                       double range_max, int func, double threshold, void* pooled_out, uint8_t* mask_out,

@@ -52,6 +52,10 @@ for dt, b in ((torch.float64, 8), (torch.float32, 4)):
     timeit(f"pool_sv_value nanmean, every window summed (1 x {Ps} x {S})", lambda: ops.pool_sv_value(svs, rgs, nvalid, 10.0, 25, 20.0, lo, hi, threshold=12.0, want_pooled=False, running_sums=False), ns, 0)
     nv_all, _ = ops.range_rows_check(rng)
     timeit(f"pool_sv_value nanmean n=25 +-10 m ({C} x {P} x {S})", lambda: ops.pool_sv_value(sv, rng, nv_all, 10.0, 25, 20.0, lo, hi, threshold=12.0, want_pooled=False), n, 2 * b + 1)
+    rng1 = rng[:, :1].expand(C, P, S).contiguous()  # one range vector for all pings of a channel (constant sound speed)
+    nv1, _ = ops.range_rows_check(rng1)
+    timeit(f"pool_sv_value nanmean, one range vector per channel ({C} x {P} x {S})", lambda: ops.pool_sv_value(sv, rng1, nv1, 10.0, 25, 20.0, lo, hi, threshold=12.0, want_pooled=False), n, 2 * b + 1)
+    del rng1
     Pm = min(P, 64)
     svm, rgm = sv[:1, :Pm].contiguous(), rng[:1, :Pm].contiguous()
     nvm, _ = ops.range_rows_check(rgm)

@@ -230,17 +230,24 @@ def test_pool_sv_sliding_sum_keeps_small_values_after_a_huge_one(env):
     np.testing.assert_array_equal(got2[~hit], got[~hit])
 
 
+@pytest.mark.parametrize("same_rows", [False, True, "mixed"])
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
-def test_pool_sv_value_running_sums_equal_window_sums(env, dtype):
+def test_pool_sv_value_running_sums_equal_window_sums(env, dtype, same_rows):
     """Value-window pooling: per-row double-double running sums (default) == summing every window (workspace
-    NULL) == the oracle's triple loop, on rows whose range vectors differ from ping to ping, with a NaN-padded
-    tail, a 140 dB spike and a +inf sample."""
+    NULL) == the oracle's triple loop; range vectors that differ from ping to ping (row-by-row path), that are
+    identical (interval sums + sliding sum down the columns) or both in one call; NaN-padded tails of different
+    lengths, a 140 dB spike and a +inf sample."""
     torch, ops = env
     rng = np.random.default_rng(8)
-    C, P, S, n, dbin = 2, 40, 300, 4, 1.5
+    C, P, S, n, dbin = 2, 40, 300, 4, 1.45  # not a multiple of the 0.3 m step: no window edge on a sample
     sv, depth = _scene(C, P, S, 12, step=0.3)
-    depth = depth * (1 + 0.01 * rng.random((C, P, 1)))          # a different range vector per ping
+    if same_rows is False:
+        depth = depth * (1 + 0.01 * rng.random((C, P, 1)))      # a different range vector per ping
+    elif same_rows == "mixed":
+        depth[1] = depth[1] * (1 + 0.01 * rng.random((P, 1)))   # channel 0: one vector (sliding path), channel 1: not
     depth[:, 7, S - 20:] = np.nan
+    depth[0, 30, S - 55:] = np.nan                               # rows of different valid lengths
+    sv[0, 30, S - 55:] = np.nan
     sv[:, 7, S - 20:] = np.nan
     sv[0, 10, 100] = 60.0
     sv[1, 20, 50] = np.inf
