@@ -141,11 +141,15 @@ __global__ __launch_bounds__(kBlock) void range_bin_smooth_kernel(
       }
     }
     __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += kBlock) {  // the dB value of a bin once, not once per sample
+      const unsigned n = scnt[b];
+      ssum[b] = n ? 10.0 * epa::fast_log10(ssum[b] / (double)n, mt.log_tab) : __builtin_nan("");
+    }
+    __syncthreads();
     T* ur = up + (size_t)row * S;
     for (int s = threadIdx.x; s < S; s += kBlock) {
       const int b = BY_VALUE ? value_bin<true>((double)rr[s], r0, delta, inv, nbins) : s / nper;
-      const unsigned n = scnt[b];
-      ur[s] = n ? (T)(10.0 * epa::fast_log10(ssum[b] / (double)n, mt.log_tab)) : epa::M<T>::nan();
+      ur[s] = (T)ssum[b];
     }
   }
 }
