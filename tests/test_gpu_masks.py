@@ -293,3 +293,57 @@ def test_apply_mask_and_mask_and(env, dtype):
     fill = rng.standard_normal((7, 11)).astype(dtype)
     got = ops.apply_mask(_dev(torch, src), _dev(torch, m1.astype(np.uint8)), fill_array=_dev(torch, fill))
     np.testing.assert_array_equal(got.cpu().numpy(), np.where(m1, src, fill[None]))
+
+
+def _box_mean_db(sv, n, m, s0):
+    """Index-window pooled Sv by separable running sums in extended precision (np.pad 'symmetric' == scipy
+    'reflect', periodic for windows wider than the data)."""
+    lin = (10 ** (np.longdouble(sv[:, s0:]) / 10))
+    ok = ~np.isnan(lin)
+    val = np.where(ok, lin, np.longdouble(0))
+
+    def box(a, k, axis):
+        a = np.moveaxis(a, axis, -1)
+        L = a.shape[-1]
+        idx = np.arange(-k, L + k)
+        per = 2 * L
+        idx = np.mod(idx, per)
+        idx = np.where(idx < L, idx, per - 1 - idx)
+        ext = np.take(a, idx, axis=-1)
+        cs = np.concatenate([np.zeros(a.shape[:-1] + (1,), a.dtype), np.cumsum(ext, axis=-1)], axis=-1)
+        out = cs[..., 2 * k + 1:] - cs[..., :-(2 * k + 1)]
+        return np.moveaxis(out, -1, axis)
+
+    s = box(box(val, m, 1), n, 0)
+    c = box(box(ok.astype(np.int64), m, 1), n, 0)
+    with np.errstate(all="ignore"):
+        out = np.where(c > 0, 10 * np.log10(s / np.maximum(c, 1)), np.nan).astype(np.float64)
+    full = np.full(sv.shape, np.nan)
+    full[:, s0:] = out
+    return full
+
+
+@pytest.mark.parametrize("P,S,n,m,s0", [
+    (700, 1100, 25, 53, 100),    # two ping segments, two range tiles (1024 + ragged), block-scan range pass
+    (513, 2300, 1, 4, 0),        # w = 9: smallest scanned window; three range tiles
+    (40, 1500, 600, 255, 7),     # w = 511: largest scanned window; ping window wraps the data many times
+    (90, 1300, 3, 256, 0),       # w = 513: grouped range kernel
+    (33, 60, 0, 3, 59),          # w = 7: grouped kernel; a single pooled column
+    (1030, 35, 2, 20, 3),        # window wider than the row (reflect wraps), three ping segments
+])
+def test_pool_sv_index_windows_against_running_sums(env, P, S, n, m, s0):
+    torch, ops = env
+    rng = np.random.default_rng(P + S + n + m)
+    sv = -80 + 8 * rng.standard_normal((1, P, S))
+    sv[0, rng.random((P, S)) < 0.03] += 50
+    sv[0, rng.random((P, S)) < 0.05] = np.nan
+    sv[0, P // 2, :] = np.nan
+    exp = _box_mean_db(sv[0], n, m, s0)
+    pooled, mask = ops.pool_sv(_dev(torch, sv), s0, n, m, threshold=9.0)
+    got = pooled.cpu().numpy()[0]
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+    _close(got, exp, 1e-9, f"pooled {P}x{S} window {2*n+1}x{2*m+1}")
+    with np.errstate(invalid="ignore"):
+        margin = sv[0] - exp - 9.0
+    sure = ~(np.abs(margin) < 1e-7)
+    np.testing.assert_array_equal(mask.cpu().numpy()[0].astype(bool)[sure], (margin > 0)[sure])
