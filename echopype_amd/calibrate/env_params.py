@@ -43,7 +43,8 @@ def harmonize_env_param_time(p, ping_time=None):
     if ping_time is None:
         raise ValueError(f"ping_time needs to be provided for comparison or interpolating {p.name}")
     pt = np.asarray(getattr(ping_time, "values", ping_time))
-    vals, t1 = vals[..., finite], t1[finite]
+    if not finite.all():
+        vals, t1 = vals[..., finite], t1[finite]
     if t1.shape == pt.shape and np.array_equal(t1, pt):
         out = vals
     else:

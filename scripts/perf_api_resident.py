@@ -1,0 +1,34 @@
+"""The Dataset API on DEVICE-resident echodata at the headline volume (EK60 4 x 500 000 x 2000): what the host-side
+parameter assembly and Dataset bookkeeping cost on top of the kernels (development aid)."""
+import sys, time, logging
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+import echopype_amd as ep
+C, P, S = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (4, 500000, 2000)))
+dd = ep.synth.ek60_device(C, P, S)
+d = ep.synth.ek60_numpy(C, 4, 8)  # host-side parameter layout; per-ping vectors re-made at full length below
+p = np.arange(P)
+for k, v in list(d.items()):
+    if isinstance(v, np.ndarray) and v.ndim == 2 and v.shape == (C, 4):
+        d[k] = np.repeat(v[:, :1], P, axis=1)
+d["sound_speed_indicative"] = np.tile(1500.0 + 0.5 * np.sin(2 * np.pi * p / 1e5), (C, 1)) if np.ndim(d["sound_speed_indicative"]) == 2 else d["sound_speed_indicative"]
+d["backscatter_r"] = ep.DeviceArray(dd["backscatter_r"])
+d["ping_time"] = np.datetime64("2026-05-01T00:00:00", "ns") + (p * 1_000_000_000).astype("timedelta64[ns]")
+ed = ep.echodata.from_ek60_arrays(d)
+n = C * P * S
+logging.disable(logging.WARNING)
+def t(f):
+    f(); torch.cuda.synchronize(); ts = []
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), r
+a, ds = t(lambda: ep.calibrate.compute_Sv(ed))
+b, mv = t(lambda: ep.commongrid.compute_MVBS(ds, range_bin="1m", ping_time_bin="20s"))
+print(f"compute_Sv   {a*1e3:7.1f} ms = {n/a/1e9:6.1f} Gsamp/s      compute_MVBS {b*1e3:7.1f} ms = {n/b/1e9:6.1f} Gsamp/s     both {n/(a+b)/1e9:6.1f}")
+del ds, mv
+c, r = t(lambda: ep.compute_Sv_MVBS(ed, range_bin="1m", ping_time_bin="20s"))
+print(f"compute_Sv_MVBS (one pass) {c*1e3:7.1f} ms = {n/c/1e9:6.1f} Gsamp/s")
+del r
+e, r = t(lambda: ep.compute_Sv_clean_MVBS(ed, 20, 50, range_bin="1m", ping_time_bin="20s"))
+print(f"compute_Sv_clean_MVBS (two passes) {e*1e3:7.1f} ms = {n/e/1e9:6.1f} Gsamp/s")
