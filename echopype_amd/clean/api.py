@@ -102,7 +102,8 @@ def _mask_inputs(ds_Sv, range_var, need_range):
 
 
 def _mask_da(ds_Sv, mask_t, dims=_CPS):
-    return DataArray(DeviceArray(mask_t.to(torch.bool)), dims,
+    """uint8 0/1 kernel output -> boolean DataArray without a copy (same item size: reinterpreted)."""
+    return DataArray(DeviceArray(mask_t.view(torch.bool)), dims,
                      {d: ds_Sv[d].values for d in dims if d in ds_Sv.coords})
 
 
@@ -178,8 +179,11 @@ def mask_impulse_noise(ds_Sv, depth_bin="5m", num_side_pings=2, impulse_noise_th
         for c in range(C):
             ops.range_bin_smooth(sv_t[c:c + 1], nper=int(n_c[c]), out=up[c:c + 1])  # in place, no copy
     mask = ops.impulse_mask(up, num_side_pings, thr)
+    # the reference's dimension order, as a transposed VIEW of the (channel, ping_time, range_sample) buffer: a
+    # materialised transpose of the mask costs three times the two kernels that made it, and apply_mask permutes
+    # back (to the contiguous layout) anyway
     dims = ("channel", "range_sample", "ping_time")
-    return _mask_da(ds_Sv, mask.permute(0, 2, 1).contiguous(), dims)
+    return _mask_da(ds_Sv, mask.permute(0, 2, 1), dims)
 
 
 def mask_attenuated_signal(ds_Sv, upper_limit_sl="400.0m", lower_limit_sl="500.0m", num_side_pings=15,

@@ -112,6 +112,8 @@ def _mask_tensor(m, order):
     t = _dev(m)
     if list(m.dims) != want:
         t = t.permute([m.dims.index(d) for d in want])
+    if t.dtype == torch.bool:  # the masks of echopype_amd.clean: reinterpreted, not copied
+        return t.contiguous().view(torch.uint8)
     return (t != 0).to(torch.uint8).contiguous()
 
 

@@ -23,7 +23,8 @@ __all__ = ["DeviceArray", "DataArray", "Dataset", "from_xarray", "is_device"]
 
 
 class DeviceArray:
-    """A C-contiguous array resident in GPU memory (wraps a torch CUDA tensor)."""
+    """An array resident in GPU memory (wraps a torch CUDA tensor).  C-contiguous except for lazily transposed
+    views (the impulse-noise mask); whoever hands the buffer to a kernel asks for ``.contiguous()`` first."""
 
     __slots__ = ("tensor",)
 

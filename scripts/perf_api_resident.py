@@ -32,3 +32,28 @@ print(f"compute_Sv_MVBS (one pass) {c*1e3:7.1f} ms = {n/c/1e9:6.1f} Gsamp/s")
 del r
 e, r = t(lambda: ep.compute_Sv_clean_MVBS(ed, 20, 50, range_bin="1m", ping_time_bin="20s"))
 print(f"compute_Sv_clean_MVBS (two passes) {e*1e3:7.1f} ms = {n/e/1e9:6.1f} Gsamp/s")
+# ---- the steps either side, on the Sv dataset of the first 100 000 pings
+del r
+Pm = min(P, 100000)
+d2 = dict(d); d2["backscatter_r"] = ep.DeviceArray(dd["backscatter_r"][:, :Pm].contiguous())
+for k, v in list(d2.items()):
+    if isinstance(v, np.ndarray) and v.ndim == 2 and v.shape == (C, P):
+        d2[k] = v[:, :Pm]
+d2["ping_time"] = d["ping_time"][:Pm]
+ds = ep.calibrate.compute_Sv(ep.echodata.from_ek60_arrays(d2))
+nm = C * Pm * S
+for name, f in (
+    ("remove_background_noise(20, 50)", lambda: ep.clean.remove_background_noise(ds, 20, 50)),
+    ("estimate_background_noise", lambda: ep.clean.estimate_background_noise(ds, 20, 50)),
+    ("mask_impulse_noise (index)", lambda: ep.clean.mask_impulse_noise(ds, range_var="echo_range", use_index_binning=True)),
+    ("mask_transient_noise (index)", lambda: ep.clean.mask_transient_noise(ds, range_var="echo_range", use_index_binning=True, exclude_above="20.0m")),
+    ("mask_transient_noise (value windows, default)", lambda: ep.clean.mask_transient_noise(ds, range_var="echo_range", exclude_above="20.0m")),
+    ("mask_attenuated_signal", lambda: ep.clean.mask_attenuated_signal(ds, range_var="echo_range", upper_limit_sl="150.0m", lower_limit_sl="250.0m")),
+    ("compute_MVBS_index_binning", lambda: ep.commongrid.compute_MVBS_index_binning(ds, 100, 100)),
+    ("add_depth(depth_offset, tilt)", lambda: ep.consolidate.add_depth(ds, depth_offset=5.0, tilt=10.0)),
+):
+    try:
+        tt, _ = t(f)
+        print(f"{name:48s} {tt*1e3:8.1f} ms = {nm/tt/1e9:7.1f} Gsamp/s", flush=True)
+    except Exception as ex:  # noqa: BLE001
+        print(name, "failed:", type(ex).__name__, ex, flush=True)
