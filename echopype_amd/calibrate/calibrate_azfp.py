@@ -78,18 +78,19 @@ class CalibrateAZFP(CalibrateBase):
         raw = self._dev(self.beam["backscatter_r"].data, torch.float32)
         return raw, coef, 0, None  # no R' <= 0 guard, echo_range not masked (calibrate_azfp.py)
 
-    def _finish(self, cal_type, out_t, range_t, tau_eff=None):
+    def _finish(self, cal_type, out_t, range_t, tau_eff=None, range_stats=None):
         ds = Dataset(coords={k: self.beam.coords[k] for k in ECHO_DIMS})
         ds[cal_type] = self._wrap(out_t, ECHO_DIMS)
-        ds["echo_range"] = self._wrap(range_t, ECHO_DIMS)
+        ds["echo_range"] = self._wrap(range_t, ECHO_DIMS, stats=range_stats)
         self.range_meter = ds["echo_range"]
         ds["frequency_nominal"] = self.beam["frequency_nominal"]
         return self._add_params_to_output(ds)
 
     def _cal_power_samples(self, cal_type, **kwargs):
         raw, coef, flags, _ = self._power_inputs(cal_type)
-        out_t, range_t = ops.sv_power(raw, coef, cal_type=cal_type, flags=flags, dtype=self.dtype)
-        return self._finish(cal_type, out_t, range_t)
+        out_t, range_t, stats = ops.sv_power(raw, coef, cal_type=cal_type, flags=flags, dtype=self.dtype,
+                                             want_range_stats=True)
+        return self._finish(cal_type, out_t, range_t, range_stats=stats)
 
     def compute_Sv(self, **kwargs):
         return self._cal_power_samples("Sv")

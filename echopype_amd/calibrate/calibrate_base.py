@@ -118,5 +118,5 @@ class CalibrateBase(abc.ABC):
         return ops.to_device(np.asarray(getattr(a, "values", a)), dtype=dtype, device=self.device)
 
     @staticmethod
-    def _wrap(t, dims, attrs=None, name=None):
-        return DataArray(DeviceArray(t), dims, attrs=attrs, name=name)
+    def _wrap(t, dims, attrs=None, name=None, stats=None):
+        return DataArray(DeviceArray(t, stats=stats), dims, attrs=attrs, name=name)

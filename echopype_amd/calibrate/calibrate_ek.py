@@ -140,11 +140,12 @@ class CalibrateEK(CalibrateBase):
         te[gpt] = tau_nom0[gpt]
         return te, tx
 
-    def _finish(self, cal_type, out_t, range_t, tau_eff):
+    def _finish(self, cal_type, out_t, range_t, tau_eff, range_stats=None):
         C, P, S = self._shape()
         ds = Dataset(coords={k: self.beam.coords[k] for k in ECHO_DIMS})
         ds[cal_type] = self._wrap(out_t, ECHO_DIMS)
-        ds["echo_range"] = self._wrap(range_t, ECHO_DIMS)
+        # nanmin / nanmax / NaN count of echo_range travel with the array (what compute_MVBS asks for next)
+        ds["echo_range"] = self._wrap(range_t, ECHO_DIMS, stats=range_stats)
         self.range_meter = ds["echo_range"]
         if cal_type == "Sv":
             ds["tau_effective"] = DataArray(tau_eff, ("channel",), attrs=dict(
@@ -181,8 +182,9 @@ class CalibrateEK(CalibrateBase):
     def _cal_power_samples(self, cal_type):
         """One fused pass for calibrate_ek.py:79-206."""
         raw, coef, flags, tau_eff = self._power_inputs(cal_type)
-        out_t, range_t = ops.sv_power(raw, coef, cal_type=cal_type, flags=flags, dtype=self.dtype)
-        return self._finish(cal_type, out_t, range_t, tau_eff)
+        out_t, range_t, stats = ops.sv_power(raw, coef, cal_type=cal_type, flags=flags, dtype=self.dtype,
+                                             want_range_stats=True)
+        return self._finish(cal_type, out_t, range_t, tau_eff, range_stats=stats)
 
 
 class CalibrateEK60(CalibrateEK):

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from ..commongrid.api import _dev, _full
+from ..commongrid.api import _dev, _full, _range_stats
 from ..commongrid.utils import _parse_x_bin
 from ..utils.prov import echopype_prov_attrs, insert_processing_level
 from ..xr_lite import DataArray, DeviceArray, from_xarray
@@ -145,7 +145,7 @@ def mask_transient_noise(ds_Sv, func="nanmean", depth_bin="10m", num_side_pings=
         if bad:
             raise ValueError(f"`{range_var}` must be non-decreasing along `range_sample` with NaN only as "
                              f"trailing padding ({bad} pings are not).")
-        lo, hi = ops.nanminmax(rg_t)
+        lo, hi, _ = _range_stats(ds_Sv[range_var], rg_t)
         _, mask = ops.pool_sv_value(sv_t, rg_t, nvalid, depth_bin, num_side_pings, exclude_above, lo, hi,
                                     func=func, threshold=thr, want_pooled=False)
     else:
@@ -170,7 +170,7 @@ def mask_impulse_noise(ds_Sv, depth_bin="5m", num_side_pings=2, impulse_noise_th
     sv_t, rg_t = _mask_inputs(ds_Sv, range_var, True)
     C, P, S = sv_t.shape
     if not use_index_binning:
-        lo, hi = ops.nanminmax(rg_t)
+        lo, hi, _ = _range_stats(ds_Sv[range_var], rg_t)
         nb = len(np.arange(lo, hi + depth_bin, depth_bin)) - 1
         up = ops.range_bin_smooth(sv_t, range=rg_t, r0=lo, bin=depth_bin, nbins=nb)
     else:
@@ -197,7 +197,7 @@ def mask_attenuated_signal(ds_Sv, upper_limit_sl="400.0m", lower_limit_sl="500.0
     lower = _parse_x_bin(lower_limit_sl, "range_bin")
     upper = _parse_x_bin(upper_limit_sl, "range_bin")
     sv_t, rg_t = _mask_inputs(ds_Sv, range_var, True)
-    lo, hi = ops.nanminmax(rg_t)
+    lo, hi, _ = _range_stats(ds_Sv[range_var], rg_t)
     if upper > hi or lower < lo:  # searching range outside the echosounder range, api.py:322-324
         mask = torch.zeros(sv_t.shape, dtype=torch.uint8, device=sv_t.device)
     else:

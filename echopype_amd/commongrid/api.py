@@ -30,6 +30,17 @@ def _dev(a, dtype=None):
     return ops.to_device(np.asarray(data), dtype=dtype)
 
 
+def _range_stats(da, t):
+    """(nanmin, nanmax, NaN count) of a range variable: left with the array by the kernel that wrote it
+    (compute_Sv), or one sweep of the device tensor ``t`` actually handed to the kernels."""
+    d = da.data if isinstance(da, DataArray) else None
+    if isinstance(d, DeviceArray) and d.tensor.dtype == t.dtype and d.tensor.shape == t.shape:
+        st = d.cached_stats()
+        if st is not None:
+            return st
+    return ops.nanminmax(t, with_nan_count=True)
+
+
 def _full(da, ds, order):
     """Broadcast a variable to the (dim_0, ping_time, range_sample) cube if it is lower-dimensional."""
     if tuple(da.dims) == tuple(order):
@@ -62,7 +73,7 @@ def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="
     C, P, S = sv_t.shape
 
     # range edges: np.arange(0, max + bin, bin)  (api.py:108-115)
-    lo, hi, n_nan_range = ops.nanminmax(rg_t, with_nan_count=True)
+    lo, hi, n_nan_range = _range_stats(ds_Sv[range_var], rg_t)
     if range_var_max is None:
         rmax = hi
     else:
@@ -209,7 +220,7 @@ def compute_NASC(ds_Sv, range_bin="10m", dist_bin="0.5nmi", method="map-reduce",
     dp_t = _dev(_full(ds_Sv[range_var], ds_Sv, order), sv_t.dtype)
     C, P, S = sv_t.shape
 
-    lo, hi = ops.nanminmax(dp_t)
+    lo, hi, _ = _range_stats(ds_Sv[range_var], dp_t)
     r_edges = np.arange(0, hi + range_bin_m, range_bin_m)
     d_edges = np.arange(0, np.nanmax(dist_nmi) + dist_bin_nmi, dist_bin_nmi)
     n_r, n_d = len(r_edges) - 1, len(d_edges) - 1

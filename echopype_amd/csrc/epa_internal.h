@@ -95,3 +95,6 @@ __device__ __forceinline__ double row_range(const CoefRow& r, int s) {
 }
 
 }  // namespace epa
+
+// reduce_util.hip: {min, max, NaN count} partials (3 doubles per workgroup) -> out[3]
+int epa_minmax_final(const double* part, int nparts, double* out, hipStream_t st);

@@ -192,6 +192,12 @@ extern "C" int epa_affine_rows(const void* x, const double* scale, const double*
   return epa::check_launch("affine_rows_kernel");
 }
 
+// {min, max, NaN count} partials of another kernel (3 doubles per workgroup) -> out[3]; used by sv_power.hip
+int epa_minmax_final(const double* part, int nparts, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(epa::kBlock), 0, st, part, nparts, out);
+  return epa::check_launch("minmax_final_kernel");
+}
+
 extern "C" int epa_nanminmax(const void* x, size_t n, int dtype, double* workspace, double* out,
                              epa_stream_t stream) {
   EPA_CHECK_ARG(x && workspace && out, "epa_nanminmax: NULL array argument");

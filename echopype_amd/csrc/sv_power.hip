@@ -14,12 +14,13 @@
 namespace {
 
 // Vector path: S even (f64) / S % 4 == 0 (f32) and 16-byte aligned buffers.
-template <typename T, bool RANGE>
+template <typename T, bool RANGE, bool STATS = false>
 __global__ __launch_bounds__(epa::kBlock) void sv_power_kernel(const float* __restrict__ raw,
                                                                const epa::CoefRow* __restrict__ coef,
                                                                long long rows, int S, T nspread,
                                                                unsigned flags, T* __restrict__ out,
-                                                               T* __restrict__ range_out) {
+                                                               T* __restrict__ range_out,
+                                                               double* __restrict__ part) {
   // blockIdx.y = range chunk (fixed for the life of the block, so that the lane's range columns
   // and their cached log10(s - d) never change); blockIdx.x strides over the (channel, ping) rows.
   using LM = epa::LaneMap<T>;
@@ -33,9 +34,12 @@ __global__ __launch_bounds__(epa::kBlock) void sv_power_kernel(const float* __re
     s0[g] = LM::first(blockIdx.y * 1024, g);
     act[g] = s0[g] < S;
   }
-  if (!act[0]) return;
+  if (!STATS && !act[0]) return;
+  // STATS: {min, max, NaN count} of the echo_range written, one partial per workgroup (no lane leaves early:
+  // the wavefront reduction at the end needs them all)
+  double lo = __builtin_inf(), hi = -__builtin_inf(), nn = 0.0;
   epa::ColumnLog<T, LEN> col[NSEG];
-  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+  for (long long row = blockIdx.x; row < rows && act[0]; row += gridDim.x) {
     const epa::RowK<T> rk(coef[row]);
 #pragma unroll
     for (int g = 0; g < NSEG; ++g) {
@@ -50,9 +54,34 @@ __global__ __launch_bounds__(epa::kBlock) void sv_power_kernel(const float* __re
         const double r = rk.range(s0[g] + j);
         o[j] = epa::cal_power_sample<T>(in.v[j], s0[g] + j, rk, nspread, col[g].nL[j], guard, r);
         if (RANGE) rg[j] = (mask_range && !(in.v[j] == in.v[j])) ? epa::M<T>::nan() : (T)r;
+        if (STATS) {
+          const double x = (double)rg[j];
+          lo = fmin(lo, x);  // fmin / fmax ignore a NaN operand
+          hi = fmax(hi, x);
+          nn += x == x ? 0.0 : 1.0;
+        }
       }
       epa::store_vec<T, LEN>(out + off, o);
       if (RANGE) epa::store_vec<T, LEN>(range_out + off, rg);
+    }
+  }
+  if (STATS) {
+    __shared__ double slo[4], shi[4], snn[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo = fmin(lo, __shfl_down(lo, o, 64));
+      hi = fmax(hi, __shfl_down(hi, o, 64));
+      nn += __shfl_down(nn, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; snn[threadIdx.x >> 6] = nn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double* pp = part + 3 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+      pp[0] = fmin(fmin(slo[0], slo[1]), fmin(slo[2], slo[3]));
+      pp[1] = fmax(fmax(shi[0], shi[1]), fmax(shi[2], shi[3]));
+      pp[2] = (snn[0] + snn[1]) + (snn[2] + snn[3]);
     }
   }
 }
@@ -80,7 +109,7 @@ __global__ __launch_bounds__(epa::kBlock) void sv_power_scalar_kernel(
 
 template <typename T>
 int launch(const float* raw, const double* coef, int C, int P, int S, int cal_type, unsigned flags,
-           void* out, void* range_out, hipStream_t st) {
+           void* out, void* range_out, double* part, double* stats_out, hipStream_t st) {
   const long long rows = (long long)C * P;
   const T nspread = cal_type == EPA_CAL_SV ? (T)20 : (T)40;
   auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
@@ -96,13 +125,28 @@ int launch(const float* raw, const double* coef, int C, int P, int S, int cal_ty
 #define EPA_LAUNCH(K, R)                                                                        \
   hipLaunchKernelGGL((K<T, R>), grid, dim3(epa::kBlock), 0, st, raw, cf, rows, S, nspread, flags, \
                      (T*)out, (T*)range_out)
+  if (vec && stats_out) {  // echo_range statistics as a by-product: one partial per workgroup, then one small kernel
+    hipLaunchKernelGGL((sv_power_kernel<T, true, true>), grid, dim3(epa::kBlock), 0, st, raw, cf, rows, S, nspread,
+                       flags, (T*)out, (T*)range_out, part);
+    if (int rc = epa::check_launch("sv_power_kernel")) return rc;
+    return epa_minmax_final(part, (int)(grid.x * grid.y), stats_out, st);
+  }
   if (vec) {
-    if (range_out) EPA_LAUNCH(sv_power_kernel, true); else EPA_LAUNCH(sv_power_kernel, false);
+    if (range_out)
+      hipLaunchKernelGGL((sv_power_kernel<T, true>), grid, dim3(epa::kBlock), 0, st, raw, cf, rows, S, nspread, flags,
+                         (T*)out, (T*)range_out, (double*)nullptr);
+    else
+      hipLaunchKernelGGL((sv_power_kernel<T, false>), grid, dim3(epa::kBlock), 0, st, raw, cf, rows, S, nspread, flags,
+                         (T*)out, (T*)range_out, (double*)nullptr);
   } else {
     if (range_out) EPA_LAUNCH(sv_power_scalar_kernel, true); else EPA_LAUNCH(sv_power_scalar_kernel, false);
   }
 #undef EPA_LAUNCH
-  return epa::check_launch("sv_power_kernel");
+  if (int rc = epa::check_launch("sv_power_kernel")) return rc;
+  if (stats_out)  // odd sizes / unaligned buffers: a separate sweep of the echo_range just written
+    return epa_nanminmax(range_out, (size_t)rows * S, sizeof(T) == 8 ? EPA_F64 : EPA_F32, part, stats_out,
+                         (epa_stream_t)st);
+  return EPA_OK;
 }
 
 }  // namespace
@@ -115,9 +159,26 @@ extern "C" int epa_sv_power(const float* raw, const double* coef, int C, int P, 
   EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_sv_power: bad cal_type %d",
                 cal_type);
   if (out_dtype == EPA_F64)
-    return launch<double>(raw, coef, C, P, S, cal_type, flags, out, range_out, (hipStream_t)stream);
+    return launch<double>(raw, coef, C, P, S, cal_type, flags, out, range_out, nullptr, nullptr, (hipStream_t)stream);
   if (out_dtype == EPA_F32)
-    return launch<float>(raw, coef, C, P, S, cal_type, flags, out, range_out, (hipStream_t)stream);
+    return launch<float>(raw, coef, C, P, S, cal_type, flags, out, range_out, nullptr, nullptr, (hipStream_t)stream);
   epa::set_error("epa_sv_power: bad out_dtype %d", out_dtype);
+  return EPA_EINVAL;
+}
+
+extern "C" int epa_sv_power_stats(const float* raw, const double* coef, int C, int P, int S, int cal_type,
+                                  unsigned flags, void* out, void* range_out, int out_dtype, double* workspace,
+                                  double* range_stats_out, epa_stream_t stream) {
+  EPA_CHECK_ARG(raw && coef && out && range_out && workspace && range_stats_out,
+                "epa_sv_power_stats: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_sv_power_stats: C=%d P=%d S=%d must be positive", C, P, S);
+  EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_sv_power_stats: bad cal_type %d", cal_type);
+  if (out_dtype == EPA_F64)
+    return launch<double>(raw, coef, C, P, S, cal_type, flags, out, range_out, workspace, range_stats_out,
+                          (hipStream_t)stream);
+  if (out_dtype == EPA_F32)
+    return launch<float>(raw, coef, C, P, S, cal_type, flags, out, range_out, workspace, range_stats_out,
+                         (hipStream_t)stream);
+  epa::set_error("epa_sv_power_stats: bad out_dtype %d", out_dtype);
   return EPA_EINVAL;
 }

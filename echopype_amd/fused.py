@@ -9,6 +9,7 @@ it: the function then simply runs the two calls).  The fused kernel serves power
 calls as well -- same results either way.
 """
 import numpy as np
+import torch
 
 from . import _lib, ops
 from .calibrate.api import CALIBRATOR, _compute_cal, _finalize_cal_ds
@@ -61,10 +62,13 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
 
     # range grid np.arange(0, nanmax(echo_range) + bin, bin) (api.py:108-115): run on a conservative
     # grid (largest range any row can reach), get nanmax(echo_range) back as a by-product, trim
-    rows = coef[..., [_lib.CF_RA, _lib.CF_RB, _lib.CF_R0]].cpu().numpy()
-    r_cap = float(np.nanmax((S - 1) * rows[..., 0] * rows[..., 1] + rows[..., 2]))
     if range_var_max is not None:
         r_cap = _parse_x_bin(range_var_max) + 1e-8
+    else:  # reduced on the device: one scalar comes back instead of three columns of the coefficient rows
+        reach = (S - 1) * coef[..., _lib.CF_RA] * coef[..., _lib.CF_RB] + coef[..., _lib.CF_R0]
+        reach = torch.nan_to_num(reach, nan=float("-inf"))
+        r_cap = float(reach.max().item())
+        r_cap = r_cap if r_cap > float("-inf") else float("nan")
     n_cap = len(np.arange(0, r_cap + range_bin_m, range_bin_m)) - 1 if np.isfinite(r_cap) else 0
     if n_cap < 1:  # degenerate grid (one sample per ping, no valid range): the two calls deal with it
         ds_Sv = _compute_cal("Sv", echodata, **cal_kw)

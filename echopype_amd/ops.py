@@ -84,8 +84,9 @@ def power_coef_ek(sample_interval, tau_nominal, transmit_power, sound_speed, abs
 
 
 def sv_power(raw, coef, *, cal_type="Sv", flags=_lib.FLAG_GUARD_POS | _lib.FLAG_MASK_RANGE,
-             dtype=torch.float64, want_range=True, out=None, range_out=None):
-    """K1 -> (Sv|TS, echo_range|None), both (C,P,S) of dtype."""
+             dtype=torch.float64, want_range=True, out=None, range_out=None, want_range_stats=False):
+    """K1 -> (Sv|TS, echo_range|None), both (C,P,S) of dtype [, f64 device tensor {nanmin, nanmax, NaN count} of
+    the echo_range, a by-product of the same pass]."""
     C, P, S = raw.shape
     if raw.dtype != torch.float32:
         raise ValueError("raw power samples must be float32 (convert/parse_base.py:302)")
@@ -93,8 +94,17 @@ def sv_power(raw, coef, *, cal_type="Sv", flags=_lib.FLAG_GUARD_POS | _lib.FLAG_
         out = torch.empty((C, P, S), dtype=dtype, device=raw.device)
     if want_range and range_out is None:
         range_out = torch.empty((C, P, S), dtype=dtype, device=raw.device)
-    call("epa_sv_power", _p(raw), _p(coef), C, P, S, _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS,
-         flags, _p(out), _p(range_out) if want_range else None, _DT[out.dtype], _stream())
+    ct = _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS
+    if want_range_stats:
+        if not want_range:
+            raise ValueError("range statistics come with the echo_range array")
+        ws = torch.empty(3 * (S // 256 + 8192 + 1024), dtype=torch.float64, device=raw.device)
+        stats = torch.empty(3, dtype=torch.float64, device=raw.device)
+        call("epa_sv_power_stats", _p(raw), _p(coef), C, P, S, ct, flags, _p(out), _p(range_out), _DT[out.dtype],
+             _p(ws), _p(stats), _stream())
+        return out, range_out, stats
+    call("epa_sv_power", _p(raw), _p(coef), C, P, S, ct, flags, _p(out), _p(range_out) if want_range else None,
+         _DT[out.dtype], _stream())
     return out, (range_out if want_range else None)
 
 

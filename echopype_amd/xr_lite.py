@@ -26,10 +26,20 @@ class DeviceArray:
     """An array resident in GPU memory (wraps a torch CUDA tensor).  C-contiguous except for lazily transposed
     views (the impulse-noise mask); whoever hands the buffer to a kernel asks for ``.contiguous()`` first."""
 
-    __slots__ = ("tensor",)
+    __slots__ = ("tensor", "_stats")
 
-    def __init__(self, tensor):
+    def __init__(self, tensor, stats=None):
         self.tensor = tensor
+        # optional (f64 device tensor {nanmin, nanmax, NaN count}, tensor._version when they were taken): a
+        # by-product of the kernel that wrote the array; void once the tensor has been modified in place
+        self._stats = (stats, tensor._version) if stats is not None else None
+
+    def cached_stats(self):
+        """(nanmin, nanmax, nan_count) if the kernel that wrote this array left them and nothing touched it since."""
+        if self._stats is None or self._stats[1] != self.tensor._version:
+            return None
+        lo, hi, nn = self._stats[0].cpu().tolist()
+        return lo, hi, int(nn)
 
     @property
     def shape(self):

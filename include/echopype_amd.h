@@ -114,6 +114,13 @@ int epa_power_coef_ek(int C, int P, const double* sample_interval, const double*
  */
 int epa_sv_power(const float* raw, const double* coef, int C, int P, int S, int cal_type,
                  unsigned flags, void* out, void* range_out, int out_dtype, epa_stream_t stream);
+/* The same with {nanmin, nanmax, NaN count} of the echo_range written as a by-product (range_stats_out f64 [3],
+ * as epa_nanminmax would give): what compute_MVBS (api.py:108-110), compute_NASC and the masks ask of the range
+ * variable next, without another sweep of it.  workspace: f64 [EPA_SV_POWER_STATS_WS_DOUBLES(S)]. */
+#define EPA_SV_POWER_STATS_WS_DOUBLES(S) (3 * ((size_t)(S) / 256 + 8192 + 1024))
+int epa_sv_power_stats(const float* raw, const double* coef, int C, int P, int S, int cal_type,
+                       unsigned flags, void* out, void* range_out, int out_dtype, double* workspace,
+                       double* range_stats_out, epa_stream_t stream);
 
 /* ---- time-bin CSR for the binned reductions ----------------------------------------------------------
  * Replaces the pandas-resample bin assignment of commongrid/api.py:118-128.  ping_time: int64 ns,

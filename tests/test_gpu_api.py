@@ -404,6 +404,25 @@ def test_compute_MVBS_index_binning_vs_reference_goldens(ep, tag):
     np.testing.assert_array_equal(ds["range_sample"].values, g[f"{tag}_out_range_sample"])
 
 
+def test_echo_range_statistics_travel_with_the_array_until_it_is_modified(ep):
+    """compute_Sv leaves nanmin / nanmax / NaN count of echo_range with the device array (a by-product of the
+    kernel); compute_MVBS uses them instead of sweeping the array, and stops trusting them once the tensor has
+    been modified in place."""
+    d = ep.synth.ek60_numpy(2, 60, 500)
+    ds = ep.calibrate.compute_Sv(ep.echodata.from_ek60_arrays(d))
+    er = ds["echo_range"].values
+    st = ds["echo_range"].data.cached_stats()
+    assert st == (float(np.nanmin(er)), float(np.nanmax(er)), int(np.isnan(er).sum()))
+    mv = ep.commongrid.compute_MVBS(ds, range_bin="5m", ping_time_bin="20s")
+    assert mv["echo_range"].values[-1] <= np.nanmax(er) < mv["echo_range"].values[-1] + 5
+    ds["echo_range"].data.tensor.mul_(2.0)   # twice the range: the cached maximum is stale now
+    assert ds["echo_range"].data.cached_stats() is None
+    mv2 = ep.commongrid.compute_MVBS(ds, range_bin="5m", ping_time_bin="20s")
+    assert mv2["echo_range"].values[-1] <= 2 * np.nanmax(er) < mv2["echo_range"].values[-1] + 5
+    exp, _, _ = ogrid.compute_MVBS(ds["Sv"].values, 2 * er, d["ping_time"], "5m", "20s")
+    close(mv2["Sv"].values, exp, 1e-9, "MVBS after the range was doubled in place")
+
+
 def test_add_depth_then_MVBS_on_depth(ep):
     """compute_Sv -> add_depth(depth_offset, tilt) -> compute_MVBS(range_var="depth") (the reference's
     MVBS value fixtures are built through add_depth, tests/commongrid/conftest.py:101-118)."""

@@ -398,6 +398,25 @@ def test_fast_exp10_accuracy(env):
     assert got[u == 3100.0][0] == np.inf and got[u == -3300.0][0] == 0.0
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("S", [1000, 1001, 37])
+def test_sv_power_range_stats_by_product(env, dtype, S):
+    """epa_sv_power_stats: {nanmin, nanmax, NaN count} of the echo_range it writes == epa_nanminmax of that array
+    (vector path, and the scalar path of odd sizes); outputs identical to epa_sv_power."""
+    torch, ops, synth = env
+    d = synth.ek60_numpy(2, 33, S, seed=S)
+    coef = _coef_ek60(torch, ops, d, "Sv")
+    raw = _dev(torch, d["backscatter_r"])
+    dt = getattr(torch, dtype)
+    sv0, rg0 = ops.sv_power(raw, coef, dtype=dt)
+    sv1, rg1, st = ops.sv_power(raw, coef, dtype=dt, want_range_stats=True)
+    assert torch.equal(torch.nan_to_num(sv0, nan=1.0), torch.nan_to_num(sv1, nan=1.0))
+    assert torch.equal(torch.nan_to_num(rg0, nan=-1.0), torch.nan_to_num(rg1, nan=-1.0))
+    lo, hi, nn = ops.nanminmax(rg0, with_nan_count=True)
+    assert st.cpu().tolist() == [lo, hi, float(nn)]
+    assert nn > 0 and hi > lo
+
+
 @pytest.mark.parametrize("inline", [False, True])
 def test_fast_log10_accuracy(env, inline):
     """Table-driven f64 log10 (and its call-free variant) vs an extended-precision reference: absolute error
