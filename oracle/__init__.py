@@ -27,6 +27,8 @@ Pinning status (see DESIGN.md "Oracle"):
     the shim (oracle/gen_noise_goldens.py -> tests/golden/ref_noise_goldens.npz);
   * compute_MVBS_index_binning (coarsen) and the bin-string parsers run from the reference too
     (oracle/gen_mvbs_index_goldens.py -> tests/golden/ref_mvbs_index_goldens.npz);
+  * the EchoData-driven inputs of add_depth likewise (oracle/gen_depth_goldens.py ->
+    tests/golden/ref_depth_goldens.npz);
   * MVBS / NASC (flox group-bys) cannot be executed from
     the reference here, so they are pinned against the reference's synthetic
     known-answer tests restated in tests/test_oracle_kat.py, test_oracle_masks.py,

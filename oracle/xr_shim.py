@@ -239,8 +239,8 @@ def _methods():
         return ds
 
     def getitem(self, key):
-        if isinstance(key, str):
-            return DataArray(self.coords[key], dims=[key], name=key)
+        if isinstance(key, str):  # a coordinate comes back as an array labelled by itself, as in xarray
+            return DataArray(self.coords[key], {key: self.coords[key]}, [key], key)
         k = _as_da(key)
         if k is not None and k.data.dtype == bool and k.ndim == 1:  # boolean selection along its dimension
             ax = self.dims.index(k.dims[0])
@@ -428,6 +428,25 @@ def _methods():
     def pipe(self, f, *a, **k):
         return f(self, *a, **k)
 
+    def any_(self):
+        return bool(np.any(self.data))
+
+    def rename(self, mapping):
+        dims = tuple(mapping.get(d, d) for d in self.dims)
+        coords = {mapping.get(k, k): v for k, v in self.coords.items()}
+        return DataArray(self.data, coords, dims, mapping.get(self.name, self.name), self.attrs)
+
+    def equals(self, other):
+        """Same dims, same values (NaN == NaN), same coordinate labels."""
+        if not isinstance(other, DataArray) or self.dims != other.dims or self.shape != other.shape:
+            return False
+        a, b = self.data, other.data
+        same = (a == b) | ((a != a) & (b != b)) if a.dtype.kind == "f" else (a == b)
+        if not bool(np.all(same)):
+            return False
+        return all(k in other.coords and np.array_equal(v, other.coords[k]) for k, v in self.coords.items()
+                   if np.ndim(v) == 1)
+
     def assign_attrs(self, attrs=None, **kw):
         out = self.copy()
         out.attrs.update({**(attrs or {}), **kw})
@@ -439,9 +458,10 @@ def _methods():
             yield DataArray(self.data[i], dims=[], name=self.name)
 
     for f in (isnull, where, transpose, isel, drop_vars, squeeze, to_dataset, sel, mean, fillna, _reduce, assign_coords,
-              reindex, reindex_like, coarsen, pipe, assign_attrs):
+              reindex, reindex_like, coarsen, pipe, assign_attrs, rename, equals):
         setattr(DataArray, f.__name__, f)
     DataArray.min, DataArray.max = amin, amax
+    DataArray.any = any_
     DataArray.__iter__ = iterate
     DataArray.size = property(lambda self: int(self.data.size))
     DataArray.chunks = None

@@ -421,3 +421,36 @@ def test_coarsen_time_mean_matches_reference_labels():
     t[4] = np.datetime64("NaT")
     out = coarsen_time_mean(t, 3)
     assert np.isnat(out[0]) and out[1] == t[3] + (t[5] - t[3]) // 2
+
+
+def test_ek_depth_utils_match_the_reference_functions():
+    """tests/golden/ref_depth_goldens.npz: outputs of the reference's own consolidate/ek_depth_utils.py
+    (oracle/gen_depth_goldens.py) -- vertical offsets and pitch / roll scaling on an identical time axis and on a
+    single time, beam-angle scaling incl. zero / tiny / NaN / unnormalised vectors."""
+    import os
+
+    from echopype_amd.consolidate import ek_depth_utils as eku
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_depth_goldens.npz"))
+    pt = np.datetime64("2026-05-01T00:00:00", "ns") + np.arange(9) * np.timedelta64(3, "s")
+    for tag in ("same", "single"):
+        t2 = g[f"vo_{tag}_time2"]
+        plat = Dataset(coords={"time2": t2})
+        for k in ("water_level", "vertical_offset", "transducer_offset_z"):
+            plat[k] = (("time2",), g[f"vo_{tag}_{k}"])
+        depth, dims = eku.ek_use_platform_vertical_offsets(plat, pt)
+        assert dims == ("ping_time",)
+        np.testing.assert_array_equal(depth, g[f"vo_{tag}_out"])
+        plat = Dataset(coords={"time2": g[f"pa_{tag}_time2"]})
+        plat["pitch"], plat["roll"] = (("time2",), g[f"pa_{tag}_pitch"]), (("time2",), g[f"pa_{tag}_roll"])
+        scaling, dims = eku.ek_use_platform_angles(plat, pt)
+        assert dims == ("ping_time",)
+        np.testing.assert_allclose(scaling, g[f"pa_{tag}_out"], rtol=0, atol=5e-16)  # cos*cos vs a rotation matrix: 2 ulp
+        np.testing.assert_array_equal(np.isnan(scaling), np.isnan(g[f"pa_{tag}_out"]))
+    v = g["ba_vectors"]
+    beam = Dataset(coords={"channel": [f"ch{i}" for i in range(len(v))]})
+    for i, k in enumerate(("beam_direction_x", "beam_direction_y", "beam_direction_z")):
+        beam[k] = (("channel",), v[:, i])
+    scaling, dims = eku.ek_use_beam_angles(beam)
+    assert dims == ("channel",)
+    np.testing.assert_array_equal(scaling, g["ba_out"])
