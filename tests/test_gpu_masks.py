@@ -298,6 +298,9 @@ def test_apply_mask_and_mask_and(env, dtype):
 def _box_mean_db(sv, n, m, s0):
     """Index-window pooled Sv by separable running sums in extended precision (np.pad 'symmetric' == scipy
     'reflect', periodic for windows wider than the data)."""
+    if s0 >= sv.shape[1]:
+        return np.full(sv.shape, np.nan)
+    # (cumulative sums cancel: good to ~1e-9 dB only while the window is not ~1e9 times smaller than the row sum)
     lin = (10 ** (np.longdouble(sv[:, s0:]) / 10))
     ok = ~np.isnan(lin)
     val = np.where(ok, lin, np.longdouble(0))
