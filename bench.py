@@ -322,7 +322,8 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = f"{args.workload}:{args.dtype}" + (":int16" if i16 else "")
+                key = f"{args.workload}:{args.dtype}" + (":int16" if i16 else "") + (
+                    ":corrected" if chain and args.chain_outputs != "all" else "")
                 if key in tj:
                     traffic = tj[key]["bytes_per_launch"]
             except Exception:  # noqa: BLE001
