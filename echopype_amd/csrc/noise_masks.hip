@@ -285,7 +285,11 @@ __global__ __launch_bounds__(kBlock) void box_range_scan_kernel(const T* __restr
   unsigned short* suf_c = pre_c + ninp;
   unsigned short* tot_c = suf_c + ninp;
   const int nblk = (nin + w - 1) / w;
-  const int tpb = max(1, kBlock / nblk);     // lanes per block
+  // at most 12 lanes share a block: more lanes shorten the runs but lengthen the offset sums (measured 12 best)
+#ifndef EPA_SCAN_TPB
+#define EPA_SCAN_TPB 12
+#endif
+  const int tpb = max(1, min(EPA_SCAN_TPB, kBlock / nblk));  // lanes per block
   const int r = (w + tpb - 1) / tpb;         // samples per lane
   const int nvirt = nblk * tpb;              // <= 2 * kBlock for w >= kScanMinW
   // the next row's samples are requested before this row is scanned (the scan phases are latency-bound)
