@@ -38,6 +38,10 @@ WORKLOADS = {
     # over the ranks (STRONG scaling) and, per rank, into resident 250 k-ping tiles ("files") whose Sv
     # goes to one reused 32.8 GB buffer -- the volume does not fit 288 GB otherwise
     "cfg5": (4, 2_000_000, 4096),
+    # BASELINE configs[3]: EK80 broadband, 2 ch x 200 000 pings x 8192 samples x 4 sectors per GPU, complex samples as
+    # float32 planes (105 GB resident): pulse compression + Sv (K3+K4) then MVBS (20 s x 0.1 m); own run function
+    "cfg4": (2, 200_000, 8192),
+    "cfg4small": (2, 20_000, 8192),
     "small": (4, 20_000, 2000),
     "straddle": (4, 20_010, 2000),  # shard edges cut a time bin: exercises the edge-bin all-reduce
 }
@@ -132,6 +136,108 @@ def _cpu_worker(a):
         tau_eff=d["transmit_duration_nominal"][:, 0])
     ogrid.compute_MVBS(sv, er, d["ping_time"], "1m", "20s")
     return 0
+
+
+def run_ek80(args, torch, dist, ops, sharding, synth, world, rank, C, P, S, dt):
+    """cfg4: EK80 BB complex -> pulse compression + Sv (epa_sv_complex_fft) -> MVBS.  The per-(channel, ping)
+    parameter rows and the replicas are assembled once by the drop-in's own calibrator (host, O(C*P)); one step =
+    the two kernels over the resident planes."""
+    import echopype_amd as ep
+    from echopype_amd import _lib
+    from echopype_amd.calibrate.api import CALIBRATOR
+
+    B = 4
+    d = synth.ek80_numpy(C, 4, 64, B)  # parameters only; the sample planes are generated on the device
+    g = torch.Generator(device="cuda")
+    g.manual_seed(20260504 + rank)
+    re = torch.empty((C, P, S, B), dtype=torch.float32, device="cuda")
+    im = torch.empty((C, P, S, B), dtype=torch.float32, device="cuda")
+    slab = max(1, P // 50)
+    for p0 in range(0, P, slab):  # in slabs: no second copy of the planes
+        n = min(slab, P - p0)
+        re[:, p0:p0 + n] = torch.randn((C, n, S, B), generator=g, device="cuda", dtype=torch.float32) * 1e-3
+        im[:, p0:p0 + n] = torch.randn((C, n, S, B), generator=g, device="cuda", dtype=torch.float32) * 1e-3
+    nan_pings = torch.rand(P, generator=g, device="cuda") < 0.10
+    tail = int(round(0.05 * S))
+    re[:, nan_pings, S - tail:] = float("nan")
+    im[:, nan_pings, S - tail:] = float("nan")
+    pidx = np.arange(P) + rank * P
+    ping_time = np.datetime64("2026-05-01T00:00:00", "ns") + (pidx * 1_000_000_000).astype("timedelta64[ns]")
+    d.update(backscatter_r=ep.DeviceArray(re), backscatter_i=ep.DeviceArray(im), sample_interval=np.full((C, P), 8e-6),
+             sound_speed=np.tile(1500.0 + 0.5 * np.sin(2 * np.pi * pidx / 1e5), (C, 1)), ping_time=ping_time)
+    ed = ep.echodata.from_ek80_arrays(d, synth.ek80_filters())
+    cal = CALIBRATOR["EK80"](ed, env_params=None, cal_params=None, ecs_file=None, waveform_mode="BB",
+                             encode_mode="complex", dtype=args.dtype, device=None)
+    k, _ = cal._complex_inputs("Sv")
+    # time bins (20 s) and the range grid of compute_MVBS; echo_range = s * sample_interval * sound_speed / 2
+    ns = torch.from_numpy(ping_time.astype(np.int64)).cuda()
+    bin_ns = 20_000_000_000
+    e0, _ = sharding.global_time_grid(ns.cpu().numpy(), bin_ns)
+    first_bin, last_bin = sharding.local_bin_span(ns.cpu().numpy(), e0, bin_ns)
+    n_t = last_bin - first_bin + 1
+    range_bin = 0.1
+    rmax = sharding.global_max(float((S - 1) * 8e-6 * 1500.5 / 2))
+    n_r = len(np.arange(0, rmax + range_bin, range_bin)) - 1
+    rows = torch.zeros((C, P, _lib.NCOEF), dtype=torch.float64, device="cuda")
+    rows[..., _lib.CF_RA] = k["ccoef"][..., _lib.CC_RA]
+    rows[..., _lib.CF_RB] = k["ccoef"][..., _lib.CC_RB]
+    n_out = C * P * S
+    timers = [ops.Timer() for _ in range(args.steps)]
+
+    def step(timer=None):
+        bs = ops.time_bin_offsets(ns, e0 + first_bin * bin_ns, bin_ns, n_t)
+        if timer is not None:
+            timer.start()
+        res = ops.sv_complex(k["re"], k["im"], k["ccoef"], replica=k["replica"], replica_off=k["replica_off"],
+                             max_taps=k["max_taps"], dtype=dt, want_range=False)
+        if timer is not None:
+            timer.stop()
+        return ops.mvbs(res["out"], bs, n_t, range_bin, n_r, coef=rows)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(timers[i])
+    sync()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([tm.elapsed_ms() for tm in timers]))
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    if world > 1:
+        t = t.to(sharding._comm_device())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        bps = B * 8 + (8 if args.dtype == "float64" else 4)  # SURVEY 8d line F: complex64 sectors in, Sv out
+        achieved = n_out * bps / (kernel_ms * 1e-3) / 1e9
+        taps = int(k["max_taps"])
+        print(json.dumps({
+            "metric": "range-samples/sec through compute_Sv->compute_MVBS", "value": n_out * world * args.steps / elapsed,
+            "unit": "range-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" if args.dtype == "float64" else "f32", "data": "synthetic",
+            "config": {"workload": f"EK80 BB complex {C}ch x {P} pings x {S} samples x {B} sectors per GPU ({args.workload}), "
+                                   f"float32 planes resident, {taps}-tap replica: pulse compression + Sv, then MVBS "
+                                   f"(20 s x {range_bin} m); a sample = one (channel, ping, range_sample) output",
+                       "pings_total": P * world, "sharding": f"ping_time x{world}",
+                       "collective": "none (shard edges on bin edges)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "sv_complex_fft_kernel",
+                         "kernel_ms": kernel_ms, "bytes_per_sample": bps,
+                         "direct_form_tflops": 8.0 * taps * n_out / (kernel_ms * 1e-3) / 1e12,
+                         "note": "with float32 planes this kernel is held by its LDS-resident fp64 FFT (3 workgroups per "
+                                 "CU), not by HBM; fed float64 planes (72 B/sample) it moves 3.9-4.1 TB/s"},
+        }), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def run_tiled(args, torch, dist, ops, sharding, synth, world, rank, C, P_total, S, dt, cpu=None):
@@ -237,6 +343,8 @@ def main():
     dt = torch.float64 if args.dtype == "float64" else torch.float32
     if args.workload == "cfg5":
         return run_tiled(args, torch, dist, ops, sharding, synth, world, rank, C, P, S, dt, cpu)
+    if args.workload.startswith("cfg4"):
+        return run_ek80(args, torch, dist, ops, sharding, synth, world, rank, C, P, S, dt)
     i16 = args.input == "int16"
     d = (synth.ek60_device_i16 if i16 else synth.ek60_device)(C, P, S, seed=20260501 + rank)
     # ping times of this shard: global ping index offset by rank (1 ping / s)

@@ -262,8 +262,9 @@ class CalibrateEK80(CalibrateEK):
             B = 0.5 * 6.0206 * (fa + ft - 0.18 * fa * ft)
         return np.where(np.isnan(B), 0.0, B)
 
-    def _cal_complex_samples(self, cal_type):
-        """One fused pass for calibrate_ek.py:532-659 (+ ek80_complex.py:285-391 for BB)."""
+    def _complex_inputs(self, cal_type):
+        """Everything epa_sv_complex needs, assembled on the host from O(C*P) parameters: the sample planes on the
+        device, the (C, P, 6) coefficient rows, the flattened replicas + offsets (BB), tau_effective."""
         C, P, S = self._shape()
         B = self.beam["backscatter_r"].shape[3]
         bb = self.waveform_mode == "BB"
@@ -321,8 +322,14 @@ class CalibrateEK80(CalibrateEK):
         im = self._dev(self.beam["backscatter_i"].data)
         if re.dtype not in (torch.float32, torch.float64):
             re, im = re.double(), im.double()
-        res = ops.sv_complex(re, im, self._dev(cc, torch.float64), replica=rep, replica_off=off,
-                             max_taps=max_taps, cal_type=cal_type, dtype=self.dtype)
+        return dict(re=re, im=im, ccoef=self._dev(cc, torch.float64), replica=rep, replica_off=off,
+                    max_taps=max_taps), tau_eff
+
+    def _cal_complex_samples(self, cal_type):
+        """One fused pass for calibrate_ek.py:532-659 (+ ek80_complex.py:285-391 for BB)."""
+        k, tau_eff = self._complex_inputs(cal_type)
+        res = ops.sv_complex(k["re"], k["im"], k["ccoef"], replica=k["replica"], replica_off=k["replica_off"],
+                             max_taps=k["max_taps"], cal_type=cal_type, dtype=self.dtype)
         return self._finish(cal_type, res["out"], res["echo_range"], tau_eff)
 
     def _compute_cal(self, cal_type):
