@@ -3,7 +3,6 @@ import abc
 import logging
 
 import numpy as np
-import torch
 
 from .. import ops
 from ..xr_lite import DataArray, DeviceArray
