@@ -96,7 +96,7 @@ __device__ T block_nanmin(T v, bool valid, T* scratch /* >= 8 elements of LDS */
 }
 
 template <typename T, int SRC, int OP, int VEC>
-__global__ __launch_bounds__(epa::kBlock) void block_reduce_kernel(ReduceArgs a) {
+__global__ __launch_bounds__(epa::kBlock, 3) void block_reduce_kernel(ReduceArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int kChunk = epa::kBlock * VEC;
   T* lsum = reinterpret_cast<T*>(smem);

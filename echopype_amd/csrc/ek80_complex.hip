@@ -490,7 +490,7 @@ __device__ __forceinline__ void fft_correlate(Cd* xs, const Cd* tw, const Cd* __
 }
 
 template <typename InT, typename T, int NB>
-__global__ __launch_bounds__(epa::kBlock) void sv_complex_fft_kernel(CxArgs a, const double* __restrict__ ws,
+__global__ __launch_bounds__(epa::kBlock, 3) void sv_complex_fft_kernel(CxArgs a, const double* __restrict__ ws,
                                                                      int out_per_tile) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Cd* xs = reinterpret_cast<Cd*>(smem);
