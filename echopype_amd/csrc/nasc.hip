@@ -56,12 +56,27 @@ __global__ __launch_bounds__(kBlock) void nasc_accumulate_kernel(
       double rs = 0.0, rh = 0.0;
       unsigned rn = 0u, rnan = 0u;
       bool any = false;
-      T dcur = dr[base];
+      // the lane's four samples and the depth after them in 16-byte accesses where the row allows
+      T dv[5], vv[4];
+      if (base + 4 <= S) {
+        typedef T pair_t __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+        const pair_t d01 = *reinterpret_cast<const pair_t*>(dr + base), d23 = *reinterpret_cast<const pair_t*>(dr + base + 2);
+        const pair_t v01 = *reinterpret_cast<const pair_t*>(svr + base), v23 = *reinterpret_cast<const pair_t*>(svr + base + 2);
+        dv[0] = d01.x; dv[1] = d01.y; dv[2] = d23.x; dv[3] = d23.y;
+        vv[0] = v01.x; vv[1] = v01.y; vv[2] = v23.x; vv[3] = v23.y;
+        dv[4] = (base + 4 < S) ? dr[base + 4] : epa::M<T>::nan();
+      } else {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) dv[j] = (base + j < S) ? dr[base + j] : epa::M<T>::nan();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vv[j] = (base + j < S) ? svr[base + j] : epa::M<T>::nan();
+      }
+      T dcur = dv[0];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int s = base + j;
         if (s >= S) break;
-        const T dnext = (s + 1 < S) ? dr[s + 1] : epa::M<T>::nan();
+        const T dnext = dv[j + 1];
         const int b = epa::range_bin_index((double)dcur, range_bin, inv_bin, n_rbins, closed_right != 0);
         if (b >= 0) {
           if (b != rb) {
@@ -72,7 +87,7 @@ __global__ __launch_bounds__(kBlock) void nasc_accumulate_kernel(
             }
             rb = b; rs = 0.0; rh = 0.0; rn = 0u; rnan = 0u; any = true;
           }
-          const T v = svr[s];
+          const T v = vv[j];
           if (v == v) {
             rs += (double)epa::lin_from_db(v, mt.exp2_tab);
             ++rn;
