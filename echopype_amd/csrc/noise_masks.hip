@@ -116,12 +116,29 @@ __global__ __launch_bounds__(kBlock) void range_bin_smooth_kernel(
       int rb = -1;
       double rs = 0.0;
       unsigned rn = 0u;
+      // the lane's four samples in 16-byte accesses where the row allows (one request instead of four)
+      T vv[4], xx[4];
+      if (base + 4 <= S) {
+        typedef T pair_t __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+        const pair_t v01 = *reinterpret_cast<const pair_t*>(svr + base), v23 = *reinterpret_cast<const pair_t*>(svr + base + 2);
+        vv[0] = v01.x; vv[1] = v01.y; vv[2] = v23.x; vv[3] = v23.y;
+        if (BY_VALUE) {
+          const pair_t x01 = *reinterpret_cast<const pair_t*>(rr + base), x23 = *reinterpret_cast<const pair_t*>(rr + base + 2);
+          xx[0] = x01.x; xx[1] = x01.y; xx[2] = x23.x; xx[3] = x23.y;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vv[j] = (base + j < S) ? svr[base + j] : epa::M<T>::nan();
+          if (BY_VALUE) xx[j] = (base + j < S) ? rr[base + j] : epa::M<T>::nan();
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int s = base + j;
         if (s >= S) break;
-        const T v = svr[s];
-        const int b = BY_VALUE ? value_bin<false>((double)rr[s], r0, delta, inv, nbins) : s / nper;
+        const T v = vv[j];
+        const int b = BY_VALUE ? value_bin<false>((double)xx[j], r0, delta, inv, nbins) : s / nper;
         if (!(v == v) || b < 0) continue;
         if (b != rb) {
           if (rn) {
