@@ -956,22 +956,43 @@ __global__ __launch_bounds__(kBlock) void row_running_sum_kernel(const T* __rest
   __shared__ int tc[4], any_inf;
   const epa::MathTabs mt = epa::build_math_tabs(tabs);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int Q = (((S + 3) / 4) + 63) & ~63;
+  const int Q = (((S + 3) / 4) + 127) & ~127;
   const int k0 = min(S, wave * Q), k1 = min(S, k0 + Q);
+  // two consecutive samples per lane: 16-byte loads and stores (half the requests of one sample per lane)
+  typedef T pair_t __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+  typedef double dpair_t __attribute__((ext_vector_type(2), aligned(8)));
+  typedef int ipair_t __attribute__((ext_vector_type(2), aligned(4)));
   for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
     __syncthreads();
     if (threadIdx.x == 0) any_inf = 0;
     const T* svr = sv + (size_t)row * S;
+    auto lin_of = [&](T v, double& x, int& c, bool& inf) {  // linear value (0 for NaN / +inf), count, inf flag
+      x = 0.0;
+      c = 0;
+      if (v == v) {
+        const double y = (double)epa::lin_from_db(v, mt.exp2_tab);
+        if (y == __builtin_inf()) inf = true; else x = y;
+        c = 1;
+      }
+    };
     Dd acc{0.0, 0.0};
     int cnt = 0;
     bool inf = false;
-    for (int k = k0 + lane; k < k1; k += 64) {
-      const T v = svr[k];
-      if (v == v) {
-        const double x = (double)epa::lin_from_db(v, mt.exp2_tab);
-        if (x == __builtin_inf()) inf = true; else acc.add(x);
-        ++cnt;
+    for (int k = k0 + 2 * lane; k < k1; k += 128) {
+      T v0, v1 = epa::M<T>::nan();
+      if (k + 1 < k1) {
+        const pair_t v = *reinterpret_cast<const pair_t*>(svr + k);
+        v0 = v.x; v1 = v.y;
+      } else {
+        v0 = svr[k];
       }
+      double x0, x1;
+      int c0, c1;
+      lin_of(v0, x0, c0, inf);
+      lin_of(v1, x1, c1, inf);
+      acc.add(x0);
+      acc.add(x1);
+      cnt += c0 + c1;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -991,20 +1012,25 @@ __global__ __launch_bounds__(kBlock) void row_running_sum_kernel(const T* __rest
     double* whr = wh + (size_t)row * S;
     double* wlr = wl + (size_t)row * S;
     int* wnr = wn + (size_t)row * S;
-    for (int kb = k0; kb < k1; kb += 64) {
-      const int k = kb + lane;
-      Dd v{0.0, 0.0};
-      int c = 0;
-      if (k < k1) {
-        const T x = svr[k];
-        if (x == x) {
-          const double y = (double)epa::lin_from_db(x, mt.exp2_tab);
-          if (y != __builtin_inf()) v.hi = y;
-          c = 1;
-        }
+    for (int kb = k0; kb < k1; kb += 128) {
+      const int k = kb + 2 * lane;
+      T v0 = epa::M<T>::nan(), v1 = epa::M<T>::nan();
+      if (k + 1 < k1) {
+        const pair_t v = *reinterpret_cast<const pair_t*>(svr + k);
+        v0 = v.x; v1 = v.y;
+      } else if (k < k1) {
+        v0 = svr[k];
       }
+      double x0, x1;
+      int c0, c1;
+      bool dummy = false;
+      lin_of(v0, x0, c0, dummy);
+      lin_of(v1, x1, c1, dummy);
+      Dd v{x0, 0.0};
+      v.add(x1);          // the lane's pair total
+      int c = c0 + c1;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {  // inclusive scan across the wavefront
+      for (int o = 1; o < 64; o <<= 1) {  // inclusive scan of the pair totals across the wavefront
         const Dd u = dd_shfl_up(v, o);
         const int uc = __shfl_up(c, o, 64);
         if (lane >= o) {
@@ -1012,13 +1038,26 @@ __global__ __launch_bounds__(kBlock) void row_running_sum_kernel(const T* __rest
           c += uc;
         }
       }
-      v.add(carry, 1.0);
-      c += carry_n;
-      if (k < k1) {
-        whr[k] = v.hi; wlr[k] = v.lo; wnr[k] = c;
+      // running value before this lane's pair = scan of the lane below (+ what came before this trip)
+      Dd before = dd_shfl_up(v, 1);
+      int before_n = __shfl_up(c, 1, 64);
+      if (lane == 0) { before = Dd{0.0, 0.0}; before_n = 0; }
+      before.add(carry, 1.0);
+      before_n += carry_n;
+      Dd r0 = before;
+      r0.add(x0);
+      Dd r1 = r0;
+      r1.add(x1);
+      if (k + 1 < k1) {
+        *reinterpret_cast<dpair_t*>(whr + k) = dpair_t{r0.hi, r1.hi};
+        *reinterpret_cast<dpair_t*>(wlr + k) = dpair_t{r0.lo, r1.lo};
+        *reinterpret_cast<ipair_t*>(wnr + k) = ipair_t{before_n + c0, before_n + c0 + c1};
+      } else if (k < k1) {
+        whr[k] = r0.hi; wlr[k] = r0.lo; wnr[k] = before_n + c0;
       }
-      carry = Dd{__shfl(v.hi, 63, 64), __shfl(v.lo, 63, 64)};
-      carry_n = __shfl(c, 63, 64);
+      Dd tot{__shfl(v.hi, 63, 64), __shfl(v.lo, 63, 64)};
+      carry.add(tot, 1.0);
+      carry_n += __shfl(c, 63, 64);
     }
     if (threadIdx.x == 0) dirty[row] = (uint8_t)any_inf;
   }
