@@ -1274,26 +1274,43 @@ __global__ __launch_bounds__(kBlock) void value_slide_kernel(PoolValueArgs<T> a,
       w.add(h[r], k[r], 1.0);
       w.add(l[r], 0, 1.0);
     }
-  for (int p = p0; p < p1; ++p) {
-    if (depth_ok && p > p0) {
+  // four pings per trip: the rows entering and leaving at each of them (and the Sv compared with the result)
+  // are requested together, then consumed in order
+  constexpr int U = 4;
+  for (int pb = p0; pb < p1; pb += U) {
+    double hin[U], lin_[U], hout[U], lout[U];
+    int kin[U], kout[U], nvp[U];
+    T x[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int p = min(pb + j, p1 - 1);
       const int in = p + n, out = p - n - 1;
-      if (in <= P - 1) {
-        const size_t r = (size_t)in * S;
-        w.add(h[r], k[r], 1.0);
-        w.add(l[r], 0, 1.0);
-      }
-      if (out >= 0) {
-        const size_t r = (size_t)out * S;
-        w.add(h[r], k[r], -1.0);
-        w.add(l[r], 0, -1.0);
-      }
+      const bool gi = depth_ok && p > p0 && in <= P - 1, go = depth_ok && p > p0 && out >= 0;
+      const size_t ri = (size_t)(gi ? in : 0) * S, ro = (size_t)(go ? out : 0) * S;
+      hin[j] = gi ? h[ri] : 0.0;
+      lin_[j] = gi ? l[ri] : 0.0;
+      kin[j] = gi ? k[ri] : 0;
+      hout[j] = go ? h[ro] : 0.0;
+      lout[j] = go ? l[ro] : 0.0;
+      kout[j] = go ? k[ro] : 0;
+      nvp[j] = a.nvalid[(size_t)c * P + p];
+      x[j] = a.mask ? a.sv[cbase + (size_t)p * S + s] : (T)0;
     }
-    T res = epa::M<T>::nan();
-    const bool ok = depth_ok && (p - n >= 0) && ((long long)p + n <= (long long)P) && s < a.nvalid[(size_t)c * P + p];
-    if (ok && w.cnt > 0) res = (T)(10.0 * epa::fast_log10(w.value() / (double)w.cnt, mt.log_tab));
-    const size_t at = cbase + (size_t)p * S + s;
-    if (a.pooled) a.pooled[at] = res;
-    if (a.mask) a.mask[at] = (a.sv[at] - res > a.thr) ? 1 : 0;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int p = pb + j;
+      if (p >= p1) break;
+      w.add(hin[j], kin[j], 1.0);
+      w.add(lin_[j], 0, 1.0);
+      w.add(hout[j], kout[j], -1.0);
+      w.add(lout[j], 0, -1.0);
+      T res = epa::M<T>::nan();
+      const bool ok = depth_ok && (p - n >= 0) && ((long long)p + n <= (long long)P) && s < nvp[j];
+      if (ok && w.cnt > 0) res = (T)(10.0 * epa::fast_log10(w.value() / (double)w.cnt, mt.log_tab));
+      const size_t at = cbase + (size_t)p * S + s;
+      if (a.pooled) a.pooled[at] = res;
+      if (a.mask) a.mask[at] = (x[j] - res > a.thr) ? 1 : 0;
+    }
   }
 }
 
