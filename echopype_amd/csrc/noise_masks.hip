@@ -947,10 +947,27 @@ __device__ __forceinline__ Dd dd_shfl_up(const Dd& v, int o) {
   return Dd{__shfl_up(v.hi, o, 64), __shfl_up(v.lo, o, 64)};
 }
 
-template <typename T>
+// FUSED: for the channels whose pings share one range vector the running sums of a row never leave LDS -- the row's
+// interval sums R[s] = W[hi(s)-1] - W[lo(s)-1] are formed right there and only they are written (28 instead of
+// 88 B/sample of traffic for the two steps); rows of the other channels are left to the unfused launch, which in
+// turn skips these (skip_same).
+struct FuseArgs {
+  const int* differ;
+  const int* nvalid;
+  const int* ilo;
+  const int* ihi;
+  double* rh;
+  double* rl;
+  int* rn;
+  int P, skip_same;
+};
+
+template <typename T, bool FUSED>
 __global__ __launch_bounds__(kBlock) void row_running_sum_kernel(const T* __restrict__ sv, long long rows, int S,
                                                                  double* __restrict__ wh, double* __restrict__ wl,
-                                                                 int* __restrict__ wn, uint8_t* __restrict__ dirty) {
+                                                                 int* __restrict__ wn, uint8_t* __restrict__ dirty,
+                                                                 FuseArgs fa) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fuse_smem[];  // FUSED: W of one row, 20 B / sample
   __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
   __shared__ double th[4], tl[4];
   __shared__ int tc[4], any_inf;
@@ -963,6 +980,8 @@ __global__ __launch_bounds__(kBlock) void row_running_sum_kernel(const T* __rest
   typedef double dpair_t __attribute__((ext_vector_type(2), aligned(8)));
   typedef int ipair_t __attribute__((ext_vector_type(2), aligned(4)));
   for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const long long chan = row / fa.P;
+    if (FUSED ? fa.differ[chan] != 0 : (fa.skip_same && fa.differ[chan] == 0)) continue;  // uniform per workgroup
     __syncthreads();
     if (threadIdx.x == 0) any_inf = 0;
     const T* svr = sv + (size_t)row * S;
@@ -1009,9 +1028,9 @@ __global__ __launch_bounds__(kBlock) void row_running_sum_kernel(const T* __rest
       carry.add(Dd{th[w], tl[w]}, 1.0);
       carry_n += tc[w];
     }
-    double* whr = wh + (size_t)row * S;
-    double* wlr = wl + (size_t)row * S;
-    int* wnr = wn + (size_t)row * S;
+    double* whr = FUSED ? reinterpret_cast<double*>(fuse_smem) : wh + (size_t)row * S;
+    double* wlr = FUSED ? whr + ((S + 1) & ~1) : wl + (size_t)row * S;
+    int* wnr = FUSED ? reinterpret_cast<int*>(wlr + ((S + 1) & ~1)) : wn + (size_t)row * S;
     for (int kb = k0; kb < k1; kb += 128) {
       const int k = kb + 2 * lane;
       T v0 = epa::M<T>::nan(), v1 = epa::M<T>::nan();
@@ -1060,6 +1079,39 @@ __global__ __launch_bounds__(kBlock) void row_running_sum_kernel(const T* __rest
       carry_n += __shfl(c, 63, 64);
     }
     if (threadIdx.x == 0) dirty[row] = (uint8_t)any_inf;
+    if (FUSED) {  // the row's interval sums, straight from the LDS copy of W (row_interval_sum_kernel otherwise)
+      __syncthreads();
+      const int nv = fa.nvalid[row];
+      const bool row_dirty = any_inf != 0;
+      const size_t base = (size_t)row * S;
+      for (int s = threadIdx.x; s < S; s += kBlock) {
+        const int lo = min(fa.ilo[(size_t)chan * S + s], nv), hi = min(fa.ihi[(size_t)chan * S + s], nv);
+        Dd sum{0.0, 0.0};
+        int cnt = 0;
+        bool has_inf = false;
+        if (lo >= 0 && hi > lo) {
+          if (row_dirty) {
+            for (int k = lo; k < hi; ++k) {
+              double x;
+              int c1;
+              lin_of(svr[k], x, c1, has_inf);
+              sum.add(x);
+              cnt += c1;
+            }
+          } else {
+            sum.add(Dd{whr[hi - 1], wlr[hi - 1]}, 1.0);
+            cnt = wnr[hi - 1];
+            if (lo > 0) {
+              sum.add(Dd{whr[lo - 1], wlr[lo - 1]}, -1.0);
+              cnt -= wnr[lo - 1];
+            }
+          }
+        }
+        fa.rh[base + s] = has_inf ? __builtin_inf() : sum.hi;
+        fa.rl[base + s] = has_inf ? 0.0 : sum.lo;
+        fa.rn[base + s] = cnt;
+      }
+    }
   }
 }
 
@@ -1549,16 +1601,28 @@ int launch_pool_value(const void* sv, const void* range, const int32_t* nvalid, 
       int* differ = ref + C;
       uint8_t* dirty = reinterpret_cast<uint8_t*>(differ + C);
       const dim3 rowg(row_grid(rows) < 16384 ? row_grid(rows) : 16384);
-      hipLaunchKernelGGL(row_running_sum_kernel<T>, rowg, dim3(kBlock), 0, st, (const T*)sv, rows, S, wh, wl, wn, dirty);
-      if (int rc = epa::check_launch("row_running_sum_kernel")) return rc;
       // which channels have one range vector for all their pings?
       hipLaunchKernelGGL(ref_row_kernel, dim3(C), dim3(kBlock), 0, st, nvalid, P, ref, differ);
       hipLaunchKernelGGL(rows_same_kernel<T>, rowg, dim3(kBlock), 0, st, (const T*)range, nvalid, rows, P, S, ref, differ);
       hipLaunchKernelGGL(value_intervals_kernel<T>, dim3((S + kBlock - 1) / kBlock, C), dim3(kBlock), 0, st, a, ref, ilo, ihi);
       if (int rc = epa::check_launch("rows_same_kernel")) return rc;
-      // those: interval sums per row, then a sliding sum down every column; the others: row by row
-      hipLaunchKernelGGL(row_interval_sum_kernel<T>, grid, dim3(kBlock), 0, st, a, rows, wh, wl, wn, dirty, differ, ilo,
-                         ihi, rh, rl, rn);
+      // those channels: running sums in LDS -> interval sums per row (one kernel), then a sliding sum down every
+      // column; the others: running sums to the workspace, then row by row
+      const size_t fuse_lds = (size_t)((S + 1) & ~1) * 16 + (size_t)S * 4;
+      const bool fuse = fuse_lds + epa::kMathTabBytes + 1024 <= kMaxLds;
+      FuseArgs fa{differ, nvalid, ilo, ihi, rh, rl, rn, P, fuse ? 1 : 0};
+      if (fuse) {
+        auto kern = row_running_sum_kernel<T, true>;
+        if (int rc = set_lds(kern, fuse_lds)) return rc;
+        hipLaunchKernelGGL(kern, rowg, dim3(kBlock), fuse_lds, st, (const T*)sv, rows, S, wh, wl, wn, dirty, fa);
+        if (int rc = epa::check_launch("row_running_sum_kernel<fused>")) return rc;
+      }
+      hipLaunchKernelGGL((row_running_sum_kernel<T, false>), rowg, dim3(kBlock), 0, st, (const T*)sv, rows, S, wh, wl, wn,
+                         dirty, fa);
+      if (int rc = epa::check_launch("row_running_sum_kernel")) return rc;
+      if (!fuse)
+        hipLaunchKernelGGL(row_interval_sum_kernel<T>, grid, dim3(kBlock), 0, st, a, rows, wh, wl, wn, dirty, differ, ilo,
+                           ihi, rh, rl, rn);
       const dim3 g2((P + kSlideSeg - 1) / kSlideSeg, (S + kBlock - 1) / kBlock, C);
       if (g2.y > 65535u || g2.z > 65535u) {
         epa::set_error("epa_pool_sv_value: more than 65535 channels or 16.7 M samples per ping");
