@@ -270,6 +270,27 @@ def test_pool_sv_value_running_sums_equal_window_sums(env, dtype, same_rows):
     assert agree[sure].all()
 
 
+def test_pool_sv_value_rows_longer_than_the_lds_copy(env):
+    """8200 samples per ping: the running sums of a row no longer fit the fused kernel's LDS copy, the unfused
+    kernels (running sums and interval sums through the workspace) take over -- same answers."""
+    torch, ops = env
+    rng = np.random.default_rng(17)
+    C, P, S, n, dbin = 1, 14, 8200, 2, 2.2
+    depth = (1.0 + 0.05 * np.arange(S))[None, None, :] + np.zeros((C, P, 1))
+    sv = -75 + 5 * rng.standard_normal((C, P, S))
+    sv[rng.random((C, P, S)) < 0.05] = np.nan
+    svt, rgt = _dev(torch, sv), _dev(torch, depth)
+    nvalid, bad = ops.range_rows_check(rgt)
+    assert bad == 0
+    lo, hi = ops.nanminmax(rgt)
+    a, _ = ops.pool_sv_value(svt, rgt, nvalid, dbin, n, 5.0, lo, hi, running_sums=True)
+    b, _ = ops.pool_sv_value(svt, rgt, nvalid, dbin, n, 5.0, lo, hi, running_sums=False)
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+    _close(a, b, 1e-12, "unfused running sums vs window sums")
+    assert np.isfinite(a).any()
+
+
 def test_pool_sv_everything_above_exclusion(env):
     torch, ops = env
     sv, _ = _scene(1, 6, 10, 3)
