@@ -87,7 +87,7 @@ SIGNATURES = {
     "epa_noise_estimate": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _i, _vp],
     "epa_noise_apply": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp],
     "epa_sv_complex": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
-    "epa_sv_complex_fft": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
+    "epa_sv_complex_fft": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "epa_range_bin_smooth": [_vp, _vp, _i, _i, _i, _i, _d, _d, _i, _vp, _i, _vp],
     "epa_impulse_mask": [_vp, _i, _i, _i, _i, _d, _vp, _i, _vp],
     "epa_pool_sv": [_vp, _i, _i, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _i, _vp],

@@ -1,0 +1,755 @@
+// K3+K4 for long replicas: EK80 broadband pulse compression as a circular correlation of a 2048-sample
+// tile through an LDS-resident FFT, fused with the sector mean -> received power -> Sv/TS chain.
+//
+// Reference arithmetic replaced (paths under /root/reference/echopype/calibrate):
+//   ek80_complex.py:285-369  compress_pulse (scipy.signal.convolve per (ping, sector); its method="auto"
+//                            makes the same direct -> FFT switch for these sizes, :310-313)
+//   ek80_complex.py:372-391  norm factor ||tx||^2
+//   calibrate_ek.py:483-490  prx from the sector mean;  :571-638  Sv / TS chain;  range.py:138-148,180-199
+//
+//   y[k] = sum_j x[k+j] conj(tx[j])  =  IFFT( FFT(x) . conj(FFT(tx)) )[k]      for k <= N - taps
+//
+// Design (one workgroup of 256 lanes = one tile of N = 2048 samples of one (channel, ping)):
+//   * lane j owns the samples j + 256 i (i = 0..7) from the global load to the Sv store: every wavefront
+//     load is 1 KiB contiguous per plane, every store 512 B (f64) contiguous; the sector SUM (the matched
+//     filter is linear and the reference averages the sectors right after it), the per-sample validity
+//     bits and the final outputs never leave the lane's registers.
+//   * forward transform = decimation in frequency, radix 4.8.8.8, IN PLACE: a lane reads and writes the
+//     same LDS elements in a pass, so a pass needs ONE barrier and no second buffer.  Its output is in
+//     digit-reversed order, which a convolution does not care about: the replica spectrum is stored in that
+//     order by replica_prepare, and the inverse transform is the transposed algorithm (decimation in time,
+//     radix 8.8.8.4) which takes digit-reversed input back to natural order.  The last forward pass, the
+//     spectral product and the first inverse pass work on the same eight elements of a lane and are fused
+//     in registers.  Per tile: 6 LDS round trips and 6 barriers (the Stockham form this replaces needed 11
+//     round trips and ~20 barriers), first and last pass entirely in registers.
+//   * LDS elements are 8 bytes (float2; fp64 keeps separate re / im planes), one pad element per 32, and
+//     the lane <-> butterfly maps of the stride-8 and stride-1 passes are chosen so that every ds_read_b64 /
+//     ds_write_b64 of every pass is bank-conflict free (the model is scripts/fft_bank_model.py).
+//   * fft_dtype F32: complex64 butterflies (v_pk_* candidates), 19 KiB LDS per workgroup; F64: 40 KiB
+//     (4 workgroups per CU).  FFT errors scale with the strongest echo of the TILE, not with the sample:
+//     F32 keeps 1e-3 relative on dB values up to ~90 dB of in-tile dynamic range and is the default for
+//     float32 output only.
+//   * the direct form returns an exact 0 where every staged sample under the replica's non-zero taps is 0
+//     (zero-filled NaN padding, blanked samples) and the chain turns prx == 0 into NaN; an FFT leaves
+//     rounding noise there.  To keep the NaN pattern such outputs are set to 0 from a bit mask of the
+//     non-zero staged samples (wave ballots) and its prefix popcounts.
+//   * a tile holding a sample whose sectors are only PARTLY NaN (never seen in files, allowed by the
+//     reference) is redone one sector at a time (block-uniform branch).
+#include "fast_math.h"
+
+namespace {
+
+constexpr int kN = EPA_EK80_NFFT;
+constexpr int kPlane = kN + kN / 32;  // padded element count
+constexpr int kMaxBeams = 8;
+static_assert(kN == 2048 && epa::kBlock == 256, "written for N = 2048, 256 lanes");
+
+template <typename F>
+struct C2 {
+  F re, im;
+};
+
+__device__ __forceinline__ int pad(int a) { return a + (a >> 5); }
+
+// ---- LDS element access: float2 elements / separate double planes (8-byte accesses either way)
+template <typename F>
+struct Xs;
+template <>
+struct Xs<float> {
+  static constexpr size_t kBytes = (size_t)kPlane * 8;
+  static __device__ __forceinline__ C2<float> ld(const unsigned char* xs, int a) {
+    const float2 v = reinterpret_cast<const float2*>(xs)[pad(a)];
+    return C2<float>{v.x, v.y};
+  }
+  static __device__ __forceinline__ void st(unsigned char* xs, int a, C2<float> v) {
+    reinterpret_cast<float2*>(xs)[pad(a)] = make_float2(v.re, v.im);
+  }
+};
+template <>
+struct Xs<double> {
+  static constexpr size_t kBytes = (size_t)kPlane * 16;
+  static __device__ __forceinline__ C2<double> ld(const unsigned char* xs, int a) {
+    const double* p = reinterpret_cast<const double*>(xs);
+    return C2<double>{p[pad(a)], p[kPlane + pad(a)]};
+  }
+  static __device__ __forceinline__ void st(unsigned char* xs, int a, C2<double> v) {
+    double* p = reinterpret_cast<double*>(xs);
+    p[pad(a)] = v.re;
+    p[kPlane + pad(a)] = v.im;
+  }
+};
+
+template <typename F>
+__device__ __forceinline__ C2<F> cmul(C2<F> a, C2<F> b) {
+  return C2<F>{fma(a.re, b.re, -a.im * b.im), fma(a.re, b.im, a.im * b.re)};
+}
+template <typename F>
+__device__ __forceinline__ C2<F> cmulc(C2<F> a, C2<F> b) {  // a * conj(b)
+  return C2<F>{fma(a.re, b.re, a.im * b.im), fma(a.im, b.re, -a.re * b.im)};
+}
+template <typename F>
+__device__ __forceinline__ C2<F> cadd(C2<F> a, C2<F> b) { return C2<F>{a.re + b.re, a.im + b.im}; }
+template <typename F>
+__device__ __forceinline__ C2<F> csub(C2<F> a, C2<F> b) { return C2<F>{a.re - b.re, a.im - b.im}; }
+template <typename F>
+__device__ __forceinline__ C2<F> mul_mi(C2<F> a) { return C2<F>{a.im, -a.re}; }  // * (-i)
+template <typename F>
+__device__ __forceinline__ C2<F> cswap(C2<F> a) { return C2<F>{a.im, a.re}; }
+
+// forward 4-point DFT (e^{-2 pi i rq/4}), in place
+template <typename F>
+__device__ __forceinline__ void dft4(C2<F>& u0, C2<F>& u1, C2<F>& u2, C2<F>& u3) {
+  const C2<F> s02 = cadd(u0, u2), d02 = csub(u0, u2), s13 = cadd(u1, u3), d13 = mul_mi(csub(u1, u3));
+  u0 = cadd(s02, s13);
+  u2 = csub(s02, s13);
+  u1 = cadd(d02, d13);
+  u3 = csub(d02, d13);
+}
+template <typename F>
+__device__ __forceinline__ void dft8(C2<F> (&v)[8]) {
+  const F kH = (F)0.70710678118654752440;
+  C2<F> e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+  dft4(e0, e1, e2, e3);
+  dft4(o0, o1, o2, o3);
+  const C2<F> t1 = C2<F>{(o1.re + o1.im) * kH, (o1.im - o1.re) * kH};   // * e^{-i pi/4}
+  const C2<F> t2 = mul_mi(o2);                                           // * e^{-i pi/2}
+  const C2<F> t3 = C2<F>{(o3.im - o3.re) * kH, -(o3.re + o3.im) * kH};  // * e^{-3i pi/4}
+  v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+  v[1] = cadd(e1, t1); v[5] = csub(e1, t1);
+  v[2] = cadd(e2, t2); v[6] = csub(e2, t2);
+  v[3] = cadd(e3, t3); v[7] = csub(e3, t3);
+}
+// the conjugate transforms through swap(DFT(swap(.))): the swaps are register renames
+template <typename F>
+__device__ __forceinline__ void idft4(C2<F>& u0, C2<F>& u1, C2<F>& u2, C2<F>& u3) {
+  u0 = cswap(u0); u1 = cswap(u1); u2 = cswap(u2); u3 = cswap(u3);
+  dft4(u0, u1, u2, u3);
+  u0 = cswap(u0); u1 = cswap(u1); u2 = cswap(u2); u3 = cswap(u3);
+}
+template <typename F>
+__device__ __forceinline__ void idft8(C2<F> (&v)[8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = cswap(v[r]);
+  dft8(v);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = cswap(v[r]);
+}
+
+// v[q] *= w^q (CONJ: conj(w)^q), q = 1..7, powers by a depth-3 product tree
+template <typename F, bool CONJ>
+__device__ __forceinline__ void twiddle8(C2<F> (&v)[8], C2<F> w1) {
+  if (CONJ) w1.im = -w1.im;
+  const C2<F> w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+  v[1] = cmul(v[1], w1);
+  v[2] = cmul(v[2], w2);
+  v[3] = cmul(v[3], w3);
+  v[4] = cmul(v[4], w4);
+  v[5] = cmul(v[5], cmul(w4, w1));
+  v[6] = cmul(v[6], cmul(w3, w3));
+  v[7] = cmul(v[7], cmul(w4, w3));
+}
+template <typename F, bool CONJ>
+__device__ __forceinline__ void twiddle4(C2<F>& u1, C2<F>& u2, C2<F>& u3, C2<F> w1) {
+  if (CONJ) w1.im = -w1.im;
+  const C2<F> w2 = cmul(w1, w1);
+  u1 = cmul(u1, w1);
+  u2 = cmul(u2, w2);
+  u3 = cmul(u3, cmul(w2, w1));
+}
+
+// lane <-> butterfly maps (element index of r = 0 and the element stride); see the header comment
+struct LaneMap {
+  int a1, a2, a3;  // first element of the lane's butterfly in the stride-64, stride-8 and stride-1 passes
+  int t1, t2;      // twiddle table index (w_2048^t) of those butterflies' offset
+};
+__device__ __forceinline__ LaneMap lane_map() {
+  const int j = threadIdx.x;
+  LaneMap m;
+  m.a1 = 512 * (j >> 6) + (j & 63);
+  m.t1 = 4 * (j & 63);
+  const int g = j >> 5, u = (j >> 3) & 3, b = (g & 3) + 4 * u + 16 * (g >> 2);
+  m.a2 = 64 * b + (j & 7);
+  m.t2 = 32 * (j & 7);
+  const int beta = (j & 1) | (((j >> 4) & 1) << 1) | (((j >> 1) & 7) << 2) | ((j >> 5) << 5);
+  m.a3 = 8 * beta;
+  return m;
+}
+
+// first forward pass (sub-size 2048, radix 4, two butterflies per lane), on the lane's registers:
+// v[i] = sample j + 256 i.  tw = 256-entry table of w_2048^m.
+template <typename F>
+__device__ __forceinline__ void fwd_pass0(C2<F> (&v)[8], const C2<F>* tw) {
+  const C2<F> wa = tw[threadIdx.x];
+  const F kH = (F)0.70710678118654752440;
+  const C2<F> wb = C2<F>{(wa.re + wa.im) * kH, (wa.im - wa.re) * kH};  // w^(j+256) = w^j e^{-i pi/4}
+  dft4(v[0], v[2], v[4], v[6]);
+  twiddle4<F, false>(v[2], v[4], v[6], wa);
+  dft4(v[1], v[3], v[5], v[7]);
+  twiddle4<F, false>(v[3], v[5], v[7], wb);
+}
+template <typename F>
+__device__ __forceinline__ void inv_pass0(C2<F> (&v)[8], const C2<F>* tw) {
+  const C2<F> wa = tw[threadIdx.x];
+  const F kH = (F)0.70710678118654752440;
+  const C2<F> wb = C2<F>{(wa.re + wa.im) * kH, (wa.im - wa.re) * kH};
+  twiddle4<F, true>(v[2], v[4], v[6], wa);
+  idft4(v[0], v[2], v[4], v[6]);
+  twiddle4<F, true>(v[3], v[5], v[7], wb);
+  idft4(v[1], v[3], v[5], v[7]);
+}
+
+template <typename F, int STRIDE>
+__device__ __forceinline__ void ld8(const unsigned char* xs, int a0, C2<F> (&v)[8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = Xs<F>::ld(xs, a0 + STRIDE * r);
+}
+template <typename F, int STRIDE>
+__device__ __forceinline__ void st8(unsigned char* xs, int a0, const C2<F> (&v)[8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) Xs<F>::st(xs, a0 + STRIDE * r, v[r]);
+}
+
+// Circular correlation of the tile held as v[i] = x[j + 256 i] with the channel's replica (spectrum `spec` in
+// the digit-reversed order of the forward transform, conj and 1/N applied).  Result in v, same ownership.
+// Barriers: the caller guarantees nobody still reads xs on entry; on exit xs holds nothing of value.
+template <typename F>
+__device__ __forceinline__ void correlate(C2<F> (&v)[8], unsigned char* xs, const C2<F>* tw,
+                                          const C2<F>* __restrict__ spec, const LaneMap& lm) {
+  const int j = threadIdx.x;
+  fwd_pass0(v, tw);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) Xs<F>::st(xs, j + 256 * i, v[i]);
+  __syncthreads();
+  ld8<F, 64>(xs, lm.a1, v);
+  dft8(v);
+  twiddle8<F, false>(v, tw[lm.t1]);
+  st8<F, 64>(xs, lm.a1, v);
+  __syncthreads();
+  ld8<F, 8>(xs, lm.a2, v);
+  // the replica spectrum of the fused pass: 8 consecutive elements per lane, requested before the barrier
+  C2<F> sp[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) sp[r] = spec[lm.a3 + r];
+  dft8(v);
+  twiddle8<F, false>(v, tw[lm.t2]);
+  st8<F, 8>(xs, lm.a2, v);
+  __syncthreads();
+  ld8<F, 1>(xs, lm.a3, v);
+  dft8(v);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], sp[r]);
+  idft8(v);
+  st8<F, 1>(xs, lm.a3, v);
+  __syncthreads();
+  ld8<F, 8>(xs, lm.a2, v);
+  twiddle8<F, true>(v, tw[lm.t2]);
+  idft8(v);
+  st8<F, 8>(xs, lm.a2, v);
+  __syncthreads();
+  ld8<F, 64>(xs, lm.a1, v);
+  twiddle8<F, true>(v, tw[lm.t1]);
+  idft8(v);
+  st8<F, 64>(xs, lm.a1, v);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = Xs<F>::ld(xs, j + 256 * i);
+  inv_pass0(v, tw);
+}
+
+// ---- workspace layout (doubles):
+//   [0, 512)            256 twiddles w_2048^m as double2
+//   [512, 768)          the same as float2
+//   [768, 768 + 4C)     per channel: ||tx||^2, first non-zero tap, one past the last non-zero tap, 0
+//   then per channel    the replica spectrum conj(FFT(tx))/N in transform order: 2048 double2, then 2048 float2
+__host__ __device__ inline size_t ws_tw64() { return 0; }
+__host__ __device__ inline size_t ws_tw32() { return 512; }
+__host__ __device__ inline size_t ws_chan() { return 768; }
+__host__ __device__ inline size_t ws_spec64(int C, int c) { return 768 + 4 * (size_t)C + (size_t)c * 3 * kN; }
+__host__ __device__ inline size_t ws_spec32(int C, int c) { return ws_spec64(C, c) + 2 * kN; }
+//   then                kStatSlots x {min, max, NaN count} of the echo_range (merged by f64 atomics; optional)
+constexpr int kStatSlots = 1024;
+__host__ __device__ inline size_t ws_stats(int C) { return 768 + 4 * (size_t)C + (size_t)C * 3 * kN; }
+//   then                [1 double] counter of deferred (partly-NaN) tiles, then one bit per tile
+__host__ __device__ inline size_t ws_mixed(int C) { return ws_stats(C) + 3 * kStatSlots; }
+
+__global__ __launch_bounds__(epa::kBlock) void replica_prepare_kernel(const float* __restrict__ replica,
+                                                                      const int32_t* __restrict__ off, int C,
+                                                                      double* __restrict__ ws, int init_stats) {
+  __shared__ __attribute__((aligned(16))) unsigned char xs[Xs<double>::kBytes];
+  __shared__ C2<double> tw[256];
+  __shared__ double red[4];
+  __shared__ int tap_lo, tap_hi;
+  const int c = blockIdx.x, j = threadIdx.x;
+  if (j == 0) {
+    tap_lo = kN;
+    tap_hi = 0;
+  }
+  if (init_stats && c == 0) {
+    double* sp = ws + ws_stats(C);
+    for (int k = j; k < kStatSlots; k += epa::kBlock) {
+      sp[3 * k] = __builtin_inf();
+      sp[3 * k + 1] = -__builtin_inf();
+      sp[3 * k + 2] = 0.0;
+    }
+  }
+  {
+    double sn, cs;
+    sincospi(-2.0 * (double)j / (double)kN, &sn, &cs);
+    tw[j] = C2<double>{cs, sn};
+    if (c == 0) {
+      reinterpret_cast<C2<double>*>(ws + ws_tw64())[j] = tw[j];
+      reinterpret_cast<C2<float>*>(ws + ws_tw32())[j] = C2<float>{(float)cs, (float)sn};
+    }
+  }
+  __syncthreads();
+  const int r0 = off[c], taps = off[c + 1] - r0;
+  double part = 0.0;
+  C2<double> v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int n = j + 256 * i;
+    C2<double> t{0.0, 0.0};
+    if (n < taps) {
+      t.re = (double)replica[2 * (size_t)(r0 + n)];
+      t.im = (double)replica[2 * (size_t)(r0 + n) + 1];
+    }
+    v[i] = t;
+    part += t.re * t.re + t.im * t.im;
+    if (t.re != 0.0 || t.im != 0.0) {  // tapered replicas start (and may end) with exact zeros
+      atomicMin(&tap_lo, n);
+      atomicMax(&tap_hi, n + 1);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);  // ||tx||^2 (ek80_complex.py:372-391)
+  if ((j & 63) == 0) red[j >> 6] = part;
+  const LaneMap lm = lane_map();
+  fwd_pass0(v, tw);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) Xs<double>::st(xs, j + 256 * i, v[i]);
+  __syncthreads();
+  if (j == 0) {
+    double* ch = ws + ws_chan() + 4 * (size_t)c;
+    ch[0] = (red[0] + red[1]) + (red[2] + red[3]);
+    ch[1] = (double)(tap_lo < tap_hi ? tap_lo : 0);
+    ch[2] = (double)tap_hi;
+    ch[3] = 0.0;
+  }
+  ld8<double, 64>(xs, lm.a1, v);
+  dft8(v);
+  twiddle8<double, false>(v, tw[lm.t1]);
+  st8<double, 64>(xs, lm.a1, v);
+  __syncthreads();
+  ld8<double, 8>(xs, lm.a2, v);
+  dft8(v);
+  twiddle8<double, false>(v, tw[lm.t2]);
+  st8<double, 8>(xs, lm.a2, v);
+  __syncthreads();
+  ld8<double, 1>(xs, lm.a3, v);
+  dft8(v);
+  C2<double>* s64 = reinterpret_cast<C2<double>*>(ws + ws_spec64(C, c));
+  C2<float>* s32 = reinterpret_cast<C2<float>*>(ws + ws_spec32(C, c));
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const C2<double> z{v[r].re * (1.0 / kN), -v[r].im * (1.0 / kN)};
+    s64[lm.a3 + r] = z;
+    s32[lm.a3 + r] = C2<float>{(float)z.re, (float)z.im};
+  }
+}
+
+struct FftArgs {
+  const void* re;
+  const void* im;
+  const double* ccoef;
+  const double* ws;
+  int C, P, S, B;
+  int tiles, out_per_tile;
+  double nspread;
+  void* out;
+  void* range_out;
+  void* prx_out;
+  double* stats_part;   // optional [3 * kStatSlots]: {min, max, NaN count} of echo_range, merged by atomics
+  unsigned* mixed_map;  // bit per tile (linear id (c * P + p) * tiles + tile): the tile holds a partly-NaN sample
+  unsigned* mixed_cnt;  // number of bits set
+  int map_words;
+};
+
+// sector sum (or one sector when only >= 0) + validity bits of sample s (bits 0..B-1 sector valid, bit 8: beam-0
+// real part valid = the echo_range mask of range.py:143-146)
+template <typename InT, typename F, int NB>
+__device__ __forceinline__ void load_sample(const InT* __restrict__ re, const InT* __restrict__ im, size_t ping_base,
+                                            int S, int Brt, int s, int only, C2<F>& v, unsigned& m) {
+  const int B = NB > 0 ? NB : Brt;
+  F sr = (F)0, si = (F)0;
+  m = 0;
+  if (s < S) {
+    const InT* pr = re + ping_base + (size_t)s * B;
+    const InT* pi = im + ping_base + (size_t)s * B;
+    if (NB > 0) {
+      constexpr int kPer = 16 / sizeof(InT);
+      typedef InT vec_t __attribute__((ext_vector_type(kPer)));
+      InT vr[NB > 0 ? NB : 1], vi[NB > 0 ? NB : 1];
+#pragma unroll
+      for (int q = 0; q < (NB > 0 ? NB : kPer) / kPer; ++q) {
+        const vec_t tr = reinterpret_cast<const vec_t*>(pr)[q], ti = reinterpret_cast<const vec_t*>(pi)[q];
+#pragma unroll
+        for (int e = 0; e < kPer; ++e) {
+          vr[q * kPer + e] = tr[e];
+          vi[q * kPer + e] = ti[e];
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const bool ok = (vr[b] == vr[b]) && (vi[b] == vi[b]);
+        if (ok) {
+          m |= 1u << b;
+          if (only < 0 || only == b) {
+            sr += (F)vr[b];
+            si += (F)vi[b];
+          }
+        }
+      }
+      if (vr[0] == vr[0]) m |= 0x100u;
+    } else {
+      for (int b = 0; b < B; ++b) {
+        const InT xr = pr[b], xi = pi[b];
+        const bool ok = (xr == xr) && (xi == xi);
+        if (ok) {
+          m |= 1u << b;
+          if (only < 0 || only == b) {
+            sr += (F)xr;
+            si += (F)xi;
+          }
+        }
+      }
+      if (pr[0] == pr[0]) m |= 0x100u;
+    }
+  }
+  v = C2<F>{sr, si};
+}
+
+__device__ __forceinline__ double sub_rn(double a, double b) {
+  asm volatile("" : "+v"(a));
+  return a - b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+  asm volatile("" : "+v"(a));
+  return a - b;
+}
+
+#ifndef EPA_FFT_WAVES_F32
+#define EPA_FFT_WAVES_F32 4
+#endif
+#ifndef EPA_FFT_WAVES_F64
+#define EPA_FFT_WAVES_F64 4
+#endif
+
+template <typename F, typename T>
+struct TileLds {
+  unsigned char* xs;
+  const C2<F>* tw;
+  unsigned long long* nzw;  // [33]
+  unsigned* wp;             // [34]
+  unsigned* wflags;         // [4]
+  const double2* log_tab;
+  double* sred;             // [12]
+};
+
+// One tile.  MIXED = false: the fast form (sector sum; a tile that turns out to hold a partly-NaN sample is
+// recorded in the bitmap and left to the MIXED = true pass, which convolves one sector at a time).
+// Returns false when the tile was deferred.
+template <typename InT, typename T, typename F, int NB, bool MIXED>
+__device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, T>& L, const LaneMap& lm, int c, int p,
+                                             int tile) {
+  const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
+  const int S = a.S, B = NB > 0 ? NB : a.B;
+  const int k_begin = tile * a.out_per_tile;
+  const double* chan = a.ws + ws_chan() + 4 * (size_t)c;
+  const InT* re = reinterpret_cast<const InT*>(a.re);
+  const InT* im = reinterpret_cast<const InT*>(a.im);
+  const size_t ping_base = ((size_t)c * a.P + p) * (size_t)S * B;
+  const C2<F>* spec = reinterpret_cast<const C2<F>*>(a.ws + (sizeof(F) == 4 ? ws_spec32(a.C, c) : ws_spec64(a.C, c)));
+  const unsigned full = (1u << B) - 1u;
+
+  // ---- the lane's eight samples: sector sums + validity bits
+  C2<F> v[8];
+  unsigned m[MIXED ? 8 : 1];
+  unsigned vbits = 0;  // bit i: sample i has valid sectors; bit 8 + i: its beam-0 real part is valid
+  unsigned mixed_l = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    unsigned mi;
+    load_sample<InT, F, NB>(re, im, ping_base, S, B, k_begin + j + 256 * i, -1, v[i], mi);
+    if (MIXED) m[i] = mi;
+    vbits |= ((mi & full) != 0u ? 1u : 0u) << i;
+    vbits |= ((mi >> 8) & 1u) << (8 + i);
+    mixed_l |= ((mi & full) != 0u && (mi & full) != full) ? 1u : 0u;
+  }
+
+  C2<F> y[MIXED ? 8 : 1];
+  for (int only = -1;;) {
+    if (MIXED) {
+      if (++only == B) break;
+      if (only > 0) __syncthreads();  // the previous sector's pass is done with xs / nzw / wflags
+      unsigned dummy;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        load_sample<InT, F, NB>(re, im, ping_base, S, B, k_begin + j + 256 * i, only, v[i], dummy);
+        if (only == 0) y[i] = C2<F>{(F)0, (F)0};
+      }
+    }
+    // bit mask of the non-zero staged samples (word 4 i + wave covers samples 256 i + 64 wave + lane)
+    unsigned zero_l = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool nz = v[i].re != (F)0 || v[i].im != (F)0;
+      const unsigned long long bal = __ballot(nz);
+      if (lane == 0) L.nzw[4 * i + wave] = bal;
+      zero_l |= nz ? 0u : 2u;
+    }
+    {
+      const unsigned any = (__ballot(mixed_l != 0u) != 0ull ? 1u : 0u) | (__ballot(zero_l != 0u) != 0ull ? 2u : 0u);
+      if (lane == 0) L.wflags[wave] = any;
+      if (j == 0) L.nzw[32] = 0ull;
+    }
+    // correlate() publishes nzw / wflags (and, on the first tile, tw / log_tab) with its first barrier
+    correlate<F>(v, L.xs, L.tw, spec, lm);
+    const unsigned flags = L.wflags[0] | L.wflags[1] | L.wflags[2] | L.wflags[3];
+    if (!MIXED && (flags & 1u)) {  // block-uniform: leave the tile to the per-sector pass
+      if (j == 0) {
+        const size_t lin = ((size_t)c * a.P + p) * a.tiles + tile;
+        atomicOr(a.mixed_map + (lin >> 5), 1u << (lin & 31));
+        atomicAdd(a.mixed_cnt, 1u);
+      }
+      return;
+    }
+    if (flags & 2u) {  // some staged sample is 0: restore the exact zeros of the direct form
+      __syncthreads();  // (block-uniform) everyone has read wflags; wp is rebuilt below
+      if (j < 64) {
+        const unsigned cnt = j < 32 ? (unsigned)__popcll(L.nzw[j]) : 0u;
+        unsigned incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned up = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += up;
+        }
+        if (j < 33) L.wp[j] = incl - cnt;  // exclusive prefix; wp[32] = total
+      }
+      __syncthreads();
+      const int lo = (int)chan[1], hi = (int)chan[2];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int t = j + 256 * i;
+        if (t < a.out_per_tile) {
+          const int ta = t + lo, tb = min(t + hi, kN);
+          const unsigned ca = L.wp[ta >> 6] + (unsigned)__popcll(L.nzw[ta >> 6] & ((1ull << (ta & 63)) - 1ull));
+          const unsigned cb = L.wp[tb >> 6] + (unsigned)__popcll(L.nzw[tb >> 6] & ((1ull << (tb & 63)) - 1ull));
+          if (ca == cb) v[i] = C2<F>{(F)0, (F)0};
+        }
+      }
+    }
+    if (!MIXED) break;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (m[MIXED ? i : 0] & (1u << only)) {
+        y[MIXED ? i : 0].re += v[i].re;
+        y[MIXED ? i : 0].im += v[i].im;
+      }
+    }
+  }
+
+  // ---- sector mean -> prx -> Sv/TS (calibrate_ek.py:483-490, 571-638)
+  const size_t row = (size_t)c * a.P + p;
+  const double* cc = a.ccoef + row * EPA_NCCOEF;
+  const double ra = cc[EPA_CC_RA], rb = cc[EPA_CC_RB];
+  const T shift = (T)cc[EPA_CC_SHIFT], alpha2 = (T)cc[EPA_CC_ALPHA2], Aadd = (T)cc[EPA_CC_A];
+  const T pscale = (T)(cc[EPA_CC_PSCALE]);
+  const T nspread = (T)a.nspread;
+  const double inv_norm = 1.0 / chan[0];
+  T* out = reinterpret_cast<T*>(a.out);
+  T* range_out = reinterpret_cast<T*>(a.range_out);
+  T* prx_out = reinterpret_cast<T*>(a.prx_out);
+  double rmin = __builtin_inf(), rmax = -__builtin_inf();
+  unsigned rnan = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int t = j + 256 * i;
+    const int s = k_begin + t;
+    if (t < a.out_per_tile && s < S) {
+      const unsigned nvalid = MIXED ? __popc(m[MIXED ? i : 0] & full) : (((vbits >> i) & 1u) ? (unsigned)B : 0u);
+      const C2<F> yi = MIXED ? y[MIXED ? i : 0] : v[i];
+      T mr, mi;
+      if (nvalid == 0u) {
+        mr = mi = epa::M<T>::nan();
+      } else {
+        const double invn = inv_norm / (double)nvalid;
+        mr = (T)((double)yi.re * invn);
+        mi = (T)((double)yi.im * invn);
+      }
+      T prx = pscale * (mr * mr + mi * mi);
+      if (!(prx > (T)0)) prx = epa::M<T>::nan();
+      const double R = ((double)s * ra) * rb;  // range.py:138 operation order
+      T rt = sub_rn((T)R, shift);              // never contracted with the range product into an fma
+      if (!(rt > (T)0)) rt = epa::M<T>::nan();
+      const T val =
+          (T)10 * epa::fast_log10(prx, L.log_tab) + nspread * epa::fast_log10(rt, L.log_tab) + alpha2 * rt + Aadd;
+      const size_t o = row * S + s;
+      out[o] = val;
+      if (range_out) {
+        const bool ok = ((vbits >> (8 + i)) & 1u) != 0u;
+        range_out[o] = ok ? (T)R : epa::M<T>::nan();
+        if (ok) {
+          const double rr = (double)(T)R;
+          rmin = fmin(rmin, rr);
+          rmax = fmax(rmax, rr);
+        } else {
+          ++rnan;
+        }
+      }
+      if (prx_out) prx_out[o] = prx;
+    }
+  }
+  if (a.stats_part) {  // {nanmin, nanmax, NaN count} of the echo_range written by this workgroup
+    double cnt = (double)rnan;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      rmin = fmin(rmin, __shfl_down(rmin, o, 64));
+      rmax = fmax(rmax, __shfl_down(rmax, o, 64));
+      cnt += __shfl_down(cnt, o, 64);
+    }
+    if (lane == 0) {
+      L.sred[3 * wave] = rmin;
+      L.sred[3 * wave + 1] = rmax;
+      L.sred[3 * wave + 2] = cnt;
+    }
+    __syncthreads();
+    if (j == 0) {
+      const size_t lin = ((size_t)c * a.P + p) * a.tiles + tile;
+      double* dst = a.stats_part + 3 * (lin & (kStatSlots - 1));
+      const double mn = fmin(fmin(L.sred[0], L.sred[3]), fmin(L.sred[6], L.sred[9]));
+      const double mx = fmax(fmax(L.sred[1], L.sred[4]), fmax(L.sred[7], L.sred[10]));
+      const double nn = (L.sred[2] + L.sred[5]) + (L.sred[8] + L.sred[11]);
+      if (mn <= mx) {  // the workgroup wrote at least one number
+        atomicMin(dst, mn);
+        atomicMax(dst + 1, mx);
+      }
+      if (nn > 0.0) atomicAdd(dst + 2, nn);
+    }
+  }
+}
+
+template <typename InT, typename T, typename F, int NB, bool MIXED>
+__global__ __launch_bounds__(epa::kBlock, MIXED ? 1 : (sizeof(F) == 4 ? EPA_FFT_WAVES_F32 : EPA_FFT_WAVES_F64))
+void sv_complex_fft_kernel(FftArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char xs[Xs<F>::kBytes];
+  __shared__ C2<F> tw[256];
+  __shared__ unsigned long long nzw[33];
+  __shared__ unsigned wp[34];
+  __shared__ unsigned wflags[4];
+  __shared__ double2 log_tab[sizeof(T) == 8 ? epa::kLogTabN : 1];
+  __shared__ double sred[12];
+  const int j = threadIdx.x;
+  if (MIXED && *a.mixed_cnt == 0u) return;  // the usual case: no tile was deferred
+
+  tw[j] = reinterpret_cast<const C2<F>*>(a.ws + (sizeof(F) == 4 ? ws_tw32() : ws_tw64()))[j];
+  if (sizeof(T) == 8 && j < epa::kLogTabN) {
+    const double cc = 1.0 + ((double)j + 0.5) * (1.0 / epa::kLogTabN);
+    const double inv = 1.0 / cc;
+    double lg = -::log10(inv);
+    if (cc > 1.4142135623730951) lg -= 0.30102999566398120;
+    log_tab[j] = make_double2(inv, lg);
+  }
+  const LaneMap lm = lane_map();
+  const TileLds<F, T> L{xs, tw, nzw, wp, wflags, log_tab, sred};
+  if (!MIXED) {
+    const int c = blockIdx.y;
+    const int p = blockIdx.x / a.tiles;
+    process_tile<InT, T, F, NB, false>(a, L, lm, c, p, blockIdx.x - p * a.tiles);
+  } else {
+    for (int w = blockIdx.x; w < a.map_words; w += gridDim.x) {
+      unsigned bits = a.mixed_map[w];
+      while (bits) {
+        const int bit = __ffs(bits) - 1;
+        bits &= bits - 1u;
+        const size_t lin = (size_t)w * 32 + bit;
+        const int tile = (int)(lin % a.tiles);
+        const size_t row = lin / a.tiles;
+        __syncthreads();  // the previous tile is done with the LDS arrays
+        process_tile<InT, T, F, NB, true>(a, L, lm, (int)(row / a.P), (int)(row % a.P), tile);
+      }
+    }
+  }
+}
+
+template <typename InT, typename T, typename F>
+int launch_fft(FftArgs& a, hipStream_t st) {
+  const dim3 grid((unsigned)((long long)a.P * a.tiles), (unsigned)a.C);
+  const bool b4 = a.B == 4 && (reinterpret_cast<uintptr_t>(a.re) & 15u) == 0 &&
+                  (reinterpret_cast<uintptr_t>(a.im) & 15u) == 0;
+  const int slow_grid = a.map_words < 2048 ? a.map_words : 2048;
+  if (b4) {
+    hipLaunchKernelGGL((sv_complex_fft_kernel<InT, T, F, 4, false>), grid, dim3(epa::kBlock), 0, st, a);
+    hipLaunchKernelGGL((sv_complex_fft_kernel<InT, T, F, 4, true>), dim3(slow_grid), dim3(epa::kBlock), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((sv_complex_fft_kernel<InT, T, F, 0, false>), grid, dim3(epa::kBlock), 0, st, a);
+    hipLaunchKernelGGL((sv_complex_fft_kernel<InT, T, F, 0, true>), dim3(slow_grid), dim3(epa::kBlock), 0, st, a);
+  }
+  return epa::check_launch("sv_complex_fft_kernel");
+}
+
+}  // namespace
+
+extern "C" int epa_sv_complex_fft(const void* re, const void* im, int in_dtype, const float* replica,
+                                  const int32_t* replica_off, int max_taps, const double* ccoef, int C,
+                                  int P, int S, int B, int cal_type, void* out, void* range_out,
+                                  void* prx_out, int out_dtype, int fft_dtype, double* workspace,
+                                  double* range_stats_out, epa_stream_t stream) {
+  EPA_CHECK_ARG(re && im && ccoef && out && replica && replica_off && workspace,
+                "epa_sv_complex_fft: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && B > 0, "epa_sv_complex_fft: C=%d P=%d S=%d B=%d", C, P, S, B);
+  EPA_CHECK_ARG(B <= kMaxBeams, "epa_sv_complex_fft: at most %d sectors supported (got %d)", kMaxBeams, B);
+  EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_sv_complex_fft: bad cal_type");
+  EPA_CHECK_ARG((in_dtype == EPA_F32 || in_dtype == EPA_F64) && (out_dtype == EPA_F32 || out_dtype == EPA_F64) &&
+                    (fft_dtype == EPA_F32 || fft_dtype == EPA_F64),
+                "epa_sv_complex_fft: bad dtype in=%d out=%d fft=%d", in_dtype, out_dtype, fft_dtype);
+  EPA_CHECK_ARG(!range_stats_out || range_out, "epa_sv_complex_fft: range statistics come with the echo_range array");
+  if (max_taps < 1 || max_taps > kN / 2) {
+    epa::set_error("epa_sv_complex_fft: replicas of 1..%d taps only (got %d); use epa_sv_complex", kN / 2, max_taps);
+    return EPA_EUNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(replica_prepare_kernel, dim3(C), dim3(epa::kBlock), 0, st, replica, replica_off, C, workspace,
+                     range_stats_out ? 1 : 0);
+  if (int rc = epa::check_launch("replica_prepare_kernel")) return rc;
+  FftArgs a{};
+  a.re = re; a.im = im; a.ccoef = ccoef; a.ws = workspace;
+  a.C = C; a.P = P; a.S = S; a.B = B;
+  a.out_per_tile = kN - max_taps + 1;
+  a.tiles = (S + a.out_per_tile - 1) / a.out_per_tile;
+  a.nspread = cal_type == EPA_CAL_SV ? 20.0 : 40.0;
+  a.out = out; a.range_out = range_out; a.prx_out = prx_out;
+  a.stats_part = range_stats_out ? workspace + ws_stats(C) : nullptr;
+  const size_t ntiles = (size_t)C * P * a.tiles;
+  EPA_CHECK_ARG(ntiles < ((size_t)1 << 36), "epa_sv_complex_fft: too many tiles");
+  a.map_words = (int)((ntiles + 31) / 32);
+  a.mixed_cnt = reinterpret_cast<unsigned*>(workspace + ws_mixed(C));
+  a.mixed_map = a.mixed_cnt + 2;
+  EPA_CHECK_HIP(hipMemsetAsync(a.mixed_cnt, 0, 8 + 4 * (size_t)a.map_words, st));
+  int rc;
+#define EPA_FFT_CASE(IN, OUT, FF) rc = launch_fft<IN, OUT, FF>(a, st)
+  const int key = (in_dtype == EPA_F64 ? 4 : 0) | (out_dtype == EPA_F64 ? 2 : 0) | (fft_dtype == EPA_F64 ? 1 : 0);
+  switch (key) {
+    case 0: EPA_FFT_CASE(float, float, float); break;
+    case 1: EPA_FFT_CASE(float, float, double); break;
+    case 2: EPA_FFT_CASE(float, double, float); break;
+    case 3: EPA_FFT_CASE(float, double, double); break;
+    case 4: EPA_FFT_CASE(double, float, float); break;
+    case 5: EPA_FFT_CASE(double, float, double); break;
+    case 6: EPA_FFT_CASE(double, double, float); break;
+    default: EPA_FFT_CASE(double, double, double); break;
+  }
+#undef EPA_FFT_CASE
+  if (rc) return rc;
+  if (range_stats_out) return epa_minmax_final(a.stats_part, kStatSlots, range_stats_out, st);
+  return EPA_OK;
+}

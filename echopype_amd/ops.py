@@ -278,10 +278,14 @@ def noise_apply(sv, alpha2, noise, ping_num, snr_threshold, *, range=None, coef=
 
 
 def sv_complex(re, im, ccoef, *, replica=None, replica_off=None, max_taps=0, cal_type="Sv",
-               dtype=torch.float64, want_range=True, want_prx=False, method="auto"):
-    """K3+K4 -> dict(out, echo_range, prx).  ``method``: "direct" (sliding register window),
-    "fft" (LDS-resident 2048-point FFT per tile, fp64 inside) or "auto" (fft for replicas of
-    16 .. 1024 taps, where it is faster; direct otherwise and for CW)."""
+               dtype=torch.float64, want_range=True, want_prx=False, method="auto", fft_dtype=None,
+               want_range_stats=False):
+    """K3+K4 -> dict(out, echo_range, prx[, range_stats]).  ``method``: "direct" (sliding register window),
+    "fft" (LDS-resident 2048-point FFT per tile) or "auto" (fft for replicas of 16 .. 1024 taps, where it is
+    faster; direct otherwise and for CW).  ``fft_dtype``: arithmetic of the transform, default = ``dtype`` (float32
+    output takes complex64 butterflies, as precise as that output; float64 output a complex128 transform).
+    ``want_range_stats`` (fft form, with ``want_range``): f64 device tensor {nanmin, nanmax, NaN count} of the
+    echo_range as a by-product of the same pass."""
     C, P, S, B = re.shape
     if re.dtype != im.dtype or re.dtype not in _DT:
         raise ValueError("backscatter_r / backscatter_i must both be float32 or float64")
@@ -293,15 +297,21 @@ def sv_complex(re, im, ccoef, *, replica=None, replica_off=None, max_taps=0, cal
     prx = torch.empty((C, P, S), dtype=dtype, device=dev) if want_prx else None
     cal = _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS
     use_fft = replica is not None and (method == "fft" or (method == "auto" and 16 <= max_taps <= _lib.EK80_NFFT // 2))
+    stats = None
     if use_fft:
-        n_ws = 2 * (_lib.EK80_NFFT // 8) + 4 * C + 2 * C * _lib.EK80_NFFT  # EPA_EK80_FFT_WS_DOUBLES(C)
+        n_ws = (768 + 4 * C + 3 * C * _lib.EK80_NFFT + 3 * 1024 + 2
+                + (C * P * (S // (_lib.EK80_NFFT // 2 + 1) + 1) + 63) // 64)  # EPA_EK80_FFT_WS_DOUBLES(C, P, S)
         ws = torch.empty(n_ws, dtype=torch.float64, device=dev)
+        fdt = torch_dtype(fft_dtype) if fft_dtype is not None else dtype
+        if want_range_stats and want_range:
+            stats = torch.empty(3, dtype=torch.float64, device=dev)
         call("epa_sv_complex_fft", _p(re), _p(im), _DT[re.dtype], _p(replica), _p(replica_off), int(max_taps),
-             _p(ccoef), C, P, S, B, cal, _p(out), _p(rng), _p(prx), _DT[dtype], _p(ws), _stream())
+             _p(ccoef), C, P, S, B, cal, _p(out), _p(rng), _p(prx), _DT[dtype], _DT[fdt], _p(ws), _p(stats),
+             _stream())
     else:
         call("epa_sv_complex", _p(re), _p(im), _DT[re.dtype], _p(replica), _p(replica_off), int(max_taps),
              _p(ccoef), C, P, S, B, cal, _p(out), _p(rng), _p(prx), _DT[dtype], _stream())
-    return dict(out=out, echo_range=rng, prx=prx)
+    return dict(out=out, echo_range=rng, prx=prx, range_stats=stats)
 
 
 class Timer:

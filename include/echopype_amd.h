@@ -258,18 +258,27 @@ int epa_sv_complex(const void* re, const void* im, int in_dtype, const float* re
                    int S, int B, int cal_type, void* out, void* range_out, void* prx_out,
                    int out_dtype, epa_stream_t stream);
 
-/* Same result for long replicas through an LDS-resident 2048-point FFT per tile (the matched filter
- * as a circular correlation; scipy.signal.convolve's method="auto" makes the same switch in the
- * reference, ek80_complex.py:334): ~11x fewer flops than the direct form at 177 taps, the kernel
- * becomes HBM-bound like CW.  Always fp64 inside.  Replicas of 1 .. EPA_EK80_NFFT/2 taps
- * (EPA_EUNSUPPORTED beyond: use epa_sv_complex).  workspace: f64 [EPA_EK80_FFT_WS_DOUBLES(C)]
- * (twiddles; ||tx||^2, span of the non-zero taps and conj(FFT(tx))/N per channel; rebuilt by every call). */
+/* Same result for long replicas through an LDS-resident 2048-point FFT per tile (the matched filter as a
+ * circular correlation; scipy.signal.convolve's method="auto" makes the same switch in the reference,
+ * ek80_complex.py:310-313): ~11x fewer flops than the direct form at 177 taps, the kernel becomes HBM-bound
+ * like CW.  Replicas of 1 .. EPA_EK80_NFFT/2 taps (EPA_EUNSUPPORTED beyond: use epa_sv_complex).
+ *   fft_dtype  : arithmetic of the transform.  EPA_F64: errors ~1e-16 of the strongest echo of the 2048-sample
+ *                tile (the reference convolves in complex128 and stores complex64, ek80_complex.py:304-313).
+ *                EPA_F32: complex64 butterflies, errors ~3e-7 of the tile's strongest echo -- for float32 output.
+ *   workspace  : f64 [EPA_EK80_FFT_WS_DOUBLES(C, P, S)] (twiddles; ||tx||^2, span of the non-zero taps and
+ *                conj(FFT(tx))/N per channel; range-statistics slots; one bit per tile marking tiles with a
+ *                partly-NaN sample, which a second launch redoes sector by sector; rebuilt by every call)
+ *   range_stats_out : optional f64 [3] = {nanmin, nanmax, NaN count} of the echo_range written to range_out, a
+ *                by-product of the same pass (what compute_MVBS, commongrid/api.py:108-110, asks next) */
 #define EPA_EK80_NFFT 2048
-#define EPA_EK80_FFT_WS_DOUBLES(C) (2 * (EPA_EK80_NFFT / 8) + 4 * (size_t)(C) + 2 * (size_t)(C) * EPA_EK80_NFFT)
+#define EPA_EK80_FFT_WS_DOUBLES(C, P, S)                                              \
+  (768 + 4 * (size_t)(C) + 3 * (size_t)(C) * EPA_EK80_NFFT + 3 * 1024 + 2 +          \
+   ((size_t)(C) * (size_t)(P) * ((size_t)(S) / (EPA_EK80_NFFT / 2 + 1) + 1) + 63) / 64)
 int epa_sv_complex_fft(const void* re, const void* im, int in_dtype, const float* replica,
                        const int32_t* replica_off, int max_taps, const double* ccoef, int C, int P,
                        int S, int B, int cal_type, void* out, void* range_out, void* prx_out,
-                       int out_dtype, double* workspace, epa_stream_t stream);
+                       int out_dtype, int fft_dtype, double* workspace, double* range_stats_out,
+                       epa_stream_t stream);
 
 /* ==== SURVEY 8f "next" row 2: Ryan et al. (2015) noise masks + apply_mask ==============================
  * Masks are uint8 [C*P*S] (1 = True) in the (channel, ping_time, range_sample) layout of Sv.        */

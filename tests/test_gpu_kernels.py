@@ -452,14 +452,17 @@ def test_argument_errors_from_c_abi(env):
 
 
 # ---- EK80 BB: FFT path == direct path ---------------------------------------------------------------
-@pytest.mark.parametrize("in_dtype,out_dtype", [("float64", "float64"), ("float32", "float64"), ("float32", "float32")])
+@pytest.mark.parametrize("in_dtype,out_dtype,fft_dtype", [("float64", "float64", None), ("float32", "float64", None),
+                                                          ("float32", "float32", None), ("float32", "float32", "float64"),
+                                                          ("float32", "float64", "float32"), ("float64", "float32", None)])
 @pytest.mark.parametrize("taps,S,mixed,B", [(177, 5000, False, 4), (64, 2048, True, 4), (16, 1873, False, 4),
                                             (1024, 3000, True, 4), (333, 8192, False, 4), (90, 2500, True, 3),
                                             (40, 1000, False, 1)])
-def test_sv_complex_fft_path_matches_direct(env, in_dtype, out_dtype, taps, S, mixed, B):
+def test_sv_complex_fft_path_matches_direct(env, in_dtype, out_dtype, fft_dtype, taps, S, mixed, B):
     """The LDS-FFT circular correlation (epa_sv_complex_fft) against the sliding-window direct form
-    (epa_sv_complex) on echoes spanning 140 dB: several tiles, ragged last tile, per-sector fallback
-    for mixed NaN patterns, NaN tails, two channels with different replica lengths."""
+    (epa_sv_complex) on echoes spanning 140 dB: several tiles, ragged last tile, per-sector second pass
+    for mixed NaN patterns, NaN tails, two channels with different replica lengths; complex64 and complex128
+    transforms (default: the output's precision)."""
     torch, ops, synth = env
     rng = np.random.default_rng(taps + S)
     C, P = 2, 3
@@ -481,15 +484,19 @@ def test_sv_complex_fft_path_matches_direct(env, in_dtype, out_dtype, taps, S, m
     kw = dict(replica=repf, replica_off=off, max_taps=taps, dtype=getattr(torch, out_dtype), want_prx=True)
     args = (_dev(torch, re), _dev(torch, im), _dev(torch, cc))
     d = ops.sv_complex(*args, method="direct", **kw)
-    f = ops.sv_complex(*args, method="fft", **kw)
+    f = ops.sv_complex(*args, method="fft", fft_dtype=fft_dtype, want_range_stats=True, **kw)
+    er = f["echo_range"].cpu().numpy().astype(np.float64)
+    st = f["range_stats"].cpu().numpy()
+    assert st[2] == np.isnan(er).sum() and st[0] == np.nanmin(er) and st[1] == np.nanmax(er)
     pd, pf = d["prx"].cpu().numpy().astype(np.float64), f["prx"].cpu().numpy().astype(np.float64)
     np.testing.assert_array_equal(np.isnan(pf), np.isnan(pd))
     np.testing.assert_array_equal(f["echo_range"].cpu().numpy(), d["echo_range"].cpu().numpy())
     with np.errstate(invalid="ignore"), warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)
         peak = np.nanmax(pd, axis=2, keepdims=True)
-    # the direct path accumulates in the output precision, the FFT path always in fp64
-    eps = 1e-12 if out_dtype == "float64" else 3e-6
+    # the direct path accumulates in the output precision; the transform in fft_dtype (default: the same)
+    f32 = out_dtype == "float32" or fft_dtype == "float32"
+    eps = 1e-12 if not f32 else 3e-6
     with np.errstate(invalid="ignore"):
         bound = eps * (np.sqrt(pd * peak) + pd) + 1e-300
         assert np.nanmax(np.abs(pf - pd) / bound) < 1.0
@@ -497,7 +504,7 @@ def test_sv_complex_fft_path_matches_direct(env, in_dtype, out_dtype, taps, S, m
     np.testing.assert_array_equal(np.isnan(sf), np.isnan(sd))
     with np.errstate(invalid="ignore"):
         strong = pd > peak * 1e-10
-    tol = 1e-6 if out_dtype == "float64" else 2e-3
+    tol = 1e-6 if not f32 else 2e-3
     assert np.nanmax(np.abs(sf[strong] - sd[strong])) < tol  # NaN where R' <= 0 (both paths alike)
 
 
