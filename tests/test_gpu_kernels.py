@@ -494,16 +494,22 @@ def test_sv_complex_fft_path_matches_direct(env, in_dtype, out_dtype, fft_dtype,
     with np.errstate(invalid="ignore"), warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)
         peak = np.nanmax(pd, axis=2, keepdims=True)
-    # the direct path accumulates in the output precision; the transform in fft_dtype (default: the same)
+    # the direct path accumulates in the output precision; the transform in fft_dtype (default: the same).
+    # Error model: the amplitude error of a transform is delta = eps_a * (strongest echo of the ping) whatever the
+    # sample, so |d prx| <= delta * (2 sqrt(prx) + delta) (+ the relative rounding of the epilogue)
     f32 = out_dtype == "float32" or fft_dtype == "float32"
-    eps = 1e-12 if not f32 else 3e-6
+    fft32 = (fft_dtype or out_dtype) == "float32"
+    eps_a = 1e-12 if not f32 else 2e-6
     with np.errstate(invalid="ignore"):
-        bound = eps * (np.sqrt(pd * peak) + pd) + 1e-300
+        delta = eps_a * np.sqrt(peak)
+        bound = delta * (2 * np.sqrt(pd) + delta) + eps_a * pd + 1e-300
         assert np.nanmax(np.abs(pf - pd) / bound) < 1.0
     sd, sf = d["out"].cpu().numpy().astype(np.float64), f["out"].cpu().numpy().astype(np.float64)
     np.testing.assert_array_equal(np.isnan(sf), np.isnan(sd))
+    # dB values agree wherever the sample is within 100 dB (complex128 transform) / 40 dB (complex64 transform:
+    # its error is relative to the tile's strongest echo) of the ping's strongest echo
     with np.errstate(invalid="ignore"):
-        strong = pd > peak * 1e-10
+        strong = pd > peak * (1e-4 if fft32 else 1e-10)
     tol = 1e-6 if not f32 else 2e-3
     assert np.nanmax(np.abs(sf[strong] - sd[strong])) < tol  # NaN where R' <= 0 (both paths alike)
 
