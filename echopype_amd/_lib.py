@@ -84,8 +84,9 @@ SIGNATURES = {
     "epa_affine_rows": [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
     "epa_nanminmax": [_vp, _sz, _i, _vp, _vp, _vp],
     "epa_mvbs_index": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
-    "epa_noise_estimate": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _i, _vp],
-    "epa_noise_apply": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp],
+    "epa_noise_estimate": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp],
+    "epa_noise_finalize": [_vp, _vp, _i, _i, _d, _vp, _vp],
+    "epa_noise_apply": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp],
     "epa_sv_complex": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "epa_sv_complex_fft": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "epa_range_bin_smooth": [_vp, _vp, _i, _i, _i, _i, _d, _d, _i, _vp, _i, _vp],

@@ -124,6 +124,8 @@ class CalibrateEK(CalibrateBase):
     def _tau_effective(self, flag_complex):
         """Effective pulse length per channel (calibrate_ek.py:113-151 / :583-607)."""
         tau_nom0 = np.asarray(self._cp(self.beam["transmit_duration_nominal"], "transmit_duration_nominal"))[:, 0]
+        if getattr(self, "tau_nominal_first_ping", None) is not None:  # a ping shard: ping 0 of the WHOLE file
+            tau_nom0 = np.asarray(self.tau_nominal_first_ping, dtype=np.float64).reshape(tau_nom0.shape)
         try:
             coeff = get_filter_coeff(self.vend)
             fs = self.cal_params["receiver_sampling_frequency"]  # KeyError for EK60 -> fallback

@@ -39,12 +39,20 @@ def _inputs(ds_Sv):
     return order, sv_t, rg_t, ops.to_device(np.ascontiguousarray(a2, dtype=np.float64))
 
 
-def _estimate(ds_Sv, ping_num, range_sample_num, background_noise_max):
+def _estimate(ds_Sv, ping_num, range_sample_num, background_noise_max, shard=None):
     if background_noise_max is not None:
         background_noise_max = extract_dB(background_noise_max)
     order, sv_t, rg_t, a2 = _inputs(ds_Sv)
     nmax = float("nan") if background_noise_max is None else float(background_noise_max)
-    noise = ops.noise_estimate(sv_t, a2, ping_num, range_sample_num, range=rg_t, noise_max=nmax)
+    if shard is None:
+        noise = ops.noise_estimate(sv_t, a2, ping_num, range_sample_num, range=rg_t, noise_max=nmax)
+    else:  # one rank's ping shard: blocks count from the dataset's first ping; blocks cut by a shard edge are merged
+        from .. import sharding
+
+        ping_offset, group = shard
+        noise, es, ec = ops.noise_estimate(sv_t, a2, ping_num, range_sample_num, range=rg_t, noise_max=nmax,
+                                           ping_phase=ping_offset % ping_num, want_edges=True)
+        sharding.merge_noise_edges(noise, es, ec, ping_offset, sv_t.shape[1], ping_num, nmax, group)
     return order, sv_t, rg_t, a2, noise, background_noise_max
 
 
@@ -58,14 +66,16 @@ def estimate_background_noise(ds_Sv, ping_num, range_sample_num, background_nois
 
 
 def remove_background_noise(ds_Sv, ping_num, range_sample_num, background_noise_max=None,
-                            SNR_threshold="3.0dB"):
-    """Adds Sv_noise and Sv_corrected to ``ds_Sv`` and returns it (api.py:472-511)."""
+                            SNR_threshold="3.0dB", _shard=None):
+    """Adds Sv_noise and Sv_corrected to ``ds_Sv`` and returns it (api.py:472-511).
+    (``_shard`` = (ping_offset, group): set by echopype_amd.sharding.remove_background_noise.)"""
     ds_Sv = from_xarray(ds_Sv)
     if SNR_threshold is not None:
         SNR_threshold = extract_dB(SNR_threshold)
-    order, sv_t, rg_t, a2, noise, nmax = _estimate(ds_Sv, ping_num, range_sample_num, background_noise_max)
+    order, sv_t, rg_t, a2, noise, nmax = _estimate(ds_Sv, ping_num, range_sample_num, background_noise_max, _shard)
     # actual_range of both outputs is a by-product of the kernel (no extra sweeps)
-    sn, sc, mm = ops.noise_apply(sv_t, a2, noise, ping_num, float(SNR_threshold), range=rg_t, want_minmax=True)
+    sn, sc, mm = ops.noise_apply(sv_t, a2, noise, ping_num, float(SNR_threshold), range=rg_t, want_minmax=True,
+                                 ping_phase=0 if _shard is None else _shard[0] % ping_num)
     for name, t, kind, rng_mm in (("Sv_noise", sn, "noise", mm[0:2]), ("Sv_corrected", sc, "corrected", mm[2:4])):
         da = DataArray(DeviceArray(t), order)
         ds_Sv[name] = add_remove_background_noise_attrs(da, kind, ping_num, range_sample_num, SNR_threshold,

@@ -42,6 +42,7 @@ struct ReduceArgs {
   const int32_t* bin_start;
   const int32_t* ping_perm;
   int n_tbins, ping_num, nparts;
+  int ping_phase;  // index blocks: local ping p belongs to block (p + ping_phase) / ping_num (shards of a longer file)
   int bin_mode;
   double range_bin, inv_range_bin;
   int n_rbins, range_sample_num;
@@ -54,7 +55,11 @@ struct ReduceArgs {
   uint32_t* cnt_out;
   // SRC_SV_DENOISE: background-noise removal applied on the fly (K7 fused into the reduction)
   const double* noise;   // [C * n_pblocks] per ping-block noise (epa_noise_estimate layout)
-  int noise_ping_num, n_pblocks;
+  int noise_ping_num, n_pblocks, noise_phase;
+  // OP_NOISE, optional: raw linear (sum, count) per range block of the FIRST and LAST ping block, [2][C][n_rbins]
+  // (slot 1 is written only when the last block is not the first) -- what a ping-sharded run merges across ranks
+  double* edge_sum_out;
+  uint32_t* edge_cnt_out;
   double snr;
   void* sv_noise_out;    // optional Sv_noise output (Sv_corrected goes to sv_out)
   unsigned long long* mm_keys;  // optional [4]: ordered keys of min/max(Sv_noise), min/max(Sv_corrected)
@@ -149,8 +154,8 @@ __global__ __launch_bounds__(epa::kBlock, 3) void block_reduce_kernel(ReduceArgs
     pb = a.bin_start[tb];
     pe = a.bin_start[tb + 1];
   } else {
-    pb = tb * a.ping_num;
-    pe = min(a.P, pb + a.ping_num);
+    pb = max(0, tb * a.ping_num - a.ping_phase);
+    pe = min(a.P, (tb + 1) * a.ping_num - a.ping_phase);
   }
   if (a.nparts > 1 && !extra) {
     const int per = (pe - pb + a.nparts - 1) / a.nparts;
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(epa::kBlock, 3) void block_reduce_kernel(ReduceArgs
         if (kDenoise) {
           {
             // clean/api.py:425-430 (noise of the ping block + transmission loss) and :485-487
-            const T nb = (T)a.noise[(size_t)c * a.n_pblocks + p / a.noise_ping_num];
+            const T nb = (T)a.noise[(size_t)c * a.n_pblocks + (p + a.noise_phase) / a.noise_ping_num];
             const T na2 = (T)a.alpha2[row];
             const T snr = (T)a.snr;
             T sn[VEC];
@@ -383,6 +388,13 @@ __global__ __launch_bounds__(epa::kBlock, 3) void block_reduce_kernel(ReduceArgs
       if (gcnt) gcnt[i] = n;
     }
   } else {
+    if (a.edge_sum_out && (tb == 0 || tb == a.n_tbins - 1)) {
+      const size_t e0 = ((size_t)(tb == 0 ? 0 : 1) * a.C + c) * n_rbins;
+      for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
+        a.edge_sum_out[e0 + i] = (double)lsum[i];
+        a.edge_cnt_out[e0 + i] = lcnt[i];
+      }
+    }
     T best = (T)__builtin_inf();
     bool any = false;
     for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
@@ -789,18 +801,19 @@ int run_index(const void* sv, const void* range, int C, int P, int S, int ping_n
 
 template <typename T>
 int run_noise(const void* sv, const void* range, const double* coef, const double* alpha2, int C,
-              int P, int S, int ping_num, int rsn, double noise_max, double* noise_out,
-              hipStream_t st) {
-  const int Pb = (P + ping_num - 1) / ping_num, Sb = (S + rsn - 1) / rsn;
+              int P, int S, int ping_num, int rsn, int ping_phase, double noise_max, double* noise_out,
+              double* edge_sum_out, uint32_t* edge_cnt_out, hipStream_t st) {
+  const int Pb = (P + ping_phase + ping_num - 1) / ping_num, Sb = (S + rsn - 1) / rsn;
   ReduceArgs a{};
   a.sv = sv; a.range = range; a.coef = reinterpret_cast<const epa::CoefRow*>(coef);
   a.alpha2 = alpha2;
   a.C = C; a.P = P; a.S = S;
-  a.bin_start = nullptr; a.n_tbins = Pb; a.ping_num = ping_num;
+  a.bin_start = nullptr; a.n_tbins = Pb; a.ping_num = ping_num; a.ping_phase = ping_phase;
   a.bin_mode = BIN_INDEX; a.range_bin = 1.0; a.inv_range_bin = 1.0; a.n_rbins = Sb;
   a.range_sample_num = rsn; a.bin_flags = EPA_BIN_SKIPNA;
   a.fill_value = __builtin_nan(""); a.noise_max = noise_max;
   a.out = noise_out;
+  a.edge_sum_out = edge_sum_out; a.edge_cnt_out = edge_cnt_out;
   Plan pl = make_plan<T>(C, P, S, Pb, Sb, al16(sv) && al16(range));
   pl.nparts = 1;
   a.nparts = 1;
@@ -827,20 +840,63 @@ extern "C" int epa_mvbs_index(const void* sv, const void* range, int C, int P, i
 
 extern "C" int epa_noise_estimate(const void* sv, const void* range, const double* coef,
                                   const double* alpha2, int C, int P, int S, int ping_num,
-                                  int range_sample_num, double noise_max, double* noise_out,
-                                  int dtype, epa_stream_t stream) {
+                                  int range_sample_num, int ping_phase, double noise_max, double* noise_out,
+                                  double* edge_sum_out, uint32_t* edge_cnt_out, int dtype,
+                                  epa_stream_t stream) {
   EPA_CHECK_ARG(sv && alpha2 && noise_out, "epa_noise_estimate: NULL array argument");
   EPA_CHECK_ARG(range || coef, "epa_noise_estimate: either range or coef must be given");
   EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && ping_num > 0 && range_sample_num > 0,
                 "epa_noise_estimate: sizes must be positive");
+  EPA_CHECK_ARG(ping_phase >= 0 && ping_phase < ping_num, "epa_noise_estimate: ping_phase %d not in [0, %d)",
+                ping_phase, ping_num);
+  EPA_CHECK_ARG((edge_sum_out == nullptr) == (edge_cnt_out == nullptr),
+                "epa_noise_estimate: edge_sum_out and edge_cnt_out come together");
   if (dtype == EPA_F64)
-    return run_noise<double>(sv, range, coef, alpha2, C, P, S, ping_num, range_sample_num,
-                             noise_max, noise_out, (hipStream_t)stream);
+    return run_noise<double>(sv, range, coef, alpha2, C, P, S, ping_num, range_sample_num, ping_phase,
+                             noise_max, noise_out, edge_sum_out, edge_cnt_out, (hipStream_t)stream);
   if (dtype == EPA_F32)
-    return run_noise<float>(sv, range, coef, alpha2, C, P, S, ping_num, range_sample_num, noise_max,
-                            noise_out, (hipStream_t)stream);
+    return run_noise<float>(sv, range, coef, alpha2, C, P, S, ping_num, range_sample_num, ping_phase, noise_max,
+                            noise_out, edge_sum_out, edge_cnt_out, (hipStream_t)stream);
   epa::set_error("epa_noise_estimate: bad dtype %d", dtype);
   return EPA_EINVAL;
+}
+
+// merged (sum, count) rows of noise blocks -> noise value per row (clean/api.py:402-422: mean -> dB -> min over
+// the range blocks -> clamp); the counts come as doubles because they travel through an all-reduce with the sums
+namespace {
+__global__ __launch_bounds__(epa::kBlock) void noise_rows_f64_kernel(const double* __restrict__ sum,
+                                                                     const double* __restrict__ cnt, int n_rbins,
+                                                                     double noise_max, double* __restrict__ out) {
+  __shared__ double scratch[8];
+  const size_t base = (size_t)blockIdx.x * n_rbins;
+  double best = __builtin_inf();
+  bool any = false;
+  for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
+    const double n = cnt[base + i];
+    if (n > 0.0) {
+      const double db = 10.0 * ::log10(sum[base + i] / n);
+      if (db == db) {
+        best = fmin(best, db);
+        any = true;
+      }
+    }
+  }
+  const double m = block_nanmin<double>(best, any, scratch);
+  if (threadIdx.x == 0) {
+    double r = m;
+    if (noise_max == noise_max) r = (r < noise_max) ? r : noise_max;
+    out[blockIdx.x] = r;
+  }
+}
+}  // namespace
+
+extern "C" int epa_noise_finalize(const double* sum, const double* cnt, int rows, int n_rblocks, double noise_max,
+                                  double* noise_out, epa_stream_t stream) {
+  EPA_CHECK_ARG(sum && cnt && noise_out, "epa_noise_finalize: NULL array argument");
+  EPA_CHECK_ARG(rows > 0 && n_rblocks > 0, "epa_noise_finalize: sizes must be positive");
+  hipLaunchKernelGGL(noise_rows_f64_kernel, dim3(rows), dim3(epa::kBlock), 0, (hipStream_t)stream, sum, cnt,
+                     n_rblocks, noise_max, noise_out);
+  return epa::check_launch("noise_rows_f64_kernel");
 }
 
 // ---- fused chain: compute_Sv + estimate_background_noise, then remove_background_noise + compute_MVBS ----

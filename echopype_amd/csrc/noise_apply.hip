@@ -3,7 +3,7 @@
 // Replaces /root/reference/echopype/clean/api.py:425-430 (forward-fill of the per-ping-block noise
 // to every ping + transmission loss) and :485-487 (linear subtraction, SNR threshold):
 //   TL        = 20*log10(R if R >= 1 else 1 [NaN -> 1]) + 2*alpha*R
-//   Sv_noise  = noise[c, p // ping_num] + TL
+//   Sv_noise  = noise[c, (p + ping_phase) // ping_num] + TL     (ping_phase: the shard's offset into its first block)
 //   L         = 10^(Sv/10) - 10^(Sv_noise/10);  Sv_corr = 10*log10(L) if L > 0 else NaN
 //   Sv_corr   = NaN unless Sv_corr - Sv_noise > SNR_threshold
 // HBM-bound: reads Sv (+ echo_range unless affine), writes Sv_noise and Sv_corrected.
@@ -18,7 +18,7 @@ template <typename T, bool VEC>
 __global__ __launch_bounds__(epa::kBlock) void noise_apply_kernel(
     const T* __restrict__ sv, const T* __restrict__ range, const epa::CoefRow* __restrict__ coef,
     const double* __restrict__ alpha2, const double* __restrict__ noise, int P, int S,
-    long long rows, int ping_num, int n_pblocks, T snr, T* __restrict__ sv_noise,
+    long long rows, int ping_num, int ping_phase, int n_pblocks, T snr, T* __restrict__ sv_noise,
     T* __restrict__ sv_corr, unsigned long long* __restrict__ mm_keys) {
   using LM = epa::LaneMap<T>;
   constexpr int NSEG = VEC ? LM::NSEG : 1, LEN = VEC ? LM::LEN : 1;
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(epa::kBlock) void noise_apply_kernel(
   // lanes beyond the row stay alive for the wavefront reduction below (no early return)
   for (long long row = blockIdx.x; row < rows && s0[0] < S; row += gridDim.x) {
     const int c = (int)(row / P), p = (int)(row - (long long)c * P);
-    const T nb = (T)noise[(size_t)c * n_pblocks + p / ping_num];
+    const T nb = (T)noise[(size_t)c * n_pblocks + (p + ping_phase) / ping_num];
     const T a2 = (T)alpha2[row];
 #pragma unroll
     for (int g = 0; g < NSEG; ++g) {
@@ -107,7 +107,7 @@ inline bool al16(const void* p) { return p == nullptr || (reinterpret_cast<uintp
 
 template <typename T>
 int launch(const void* sv, const void* range, const double* coef, const double* alpha2,
-           const double* noise, int C, int P, int S, int ping_num, double snr, void* sv_noise,
+           const double* noise, int C, int P, int S, int ping_num, int ping_phase, double snr, void* sv_noise,
            void* sv_corr, double* minmax_out, hipStream_t st) {
   const long long rows = (long long)C * P;
   const int need = sizeof(T) == 8 ? 2 : 4;
@@ -118,17 +118,17 @@ int launch(const void* sv, const void* range, const double* coef, const double* 
   if (gx < 1) gx = 1;
   if (gx > rows) gx = rows;
   const dim3 grid((unsigned)gx, (unsigned)chunks_per_row);
-  const int n_pblocks = (P + ping_num - 1) / ping_num;
+  const int n_pblocks = (P + ping_phase + ping_num - 1) / ping_num;
   const epa::CoefRow* cf = reinterpret_cast<const epa::CoefRow*>(coef);
   unsigned long long* mm = reinterpret_cast<unsigned long long*>(minmax_out);
   if (mm) hipLaunchKernelGGL(init_minmax_kernel, dim3(1), dim3(4), 0, st, mm);
   if (vec)
     hipLaunchKernelGGL((noise_apply_kernel<T, true>), grid, dim3(epa::kBlock), 0, st, (const T*)sv,
-                       (const T*)range, cf, alpha2, noise, P, S, rows, ping_num, n_pblocks, (T)snr,
+                       (const T*)range, cf, alpha2, noise, P, S, rows, ping_num, ping_phase, n_pblocks, (T)snr,
                        (T*)sv_noise, (T*)sv_corr, mm);
   else
     hipLaunchKernelGGL((noise_apply_kernel<T, false>), grid, dim3(epa::kBlock), 0, st, (const T*)sv,
-                       (const T*)range, cf, alpha2, noise, P, S, rows, ping_num, n_pblocks, (T)snr,
+                       (const T*)range, cf, alpha2, noise, P, S, rows, ping_num, ping_phase, n_pblocks, (T)snr,
                        (T*)sv_noise, (T*)sv_corr, mm);
   if (int rc = epa::check_launch("noise_apply_kernel")) return rc;
   if (mm) {
@@ -142,17 +142,19 @@ int launch(const void* sv, const void* range, const double* coef, const double* 
 
 extern "C" int epa_noise_apply(const void* sv, const void* range, const double* coef,
                                const double* alpha2, const double* noise, int C, int P, int S,
-                               int ping_num, double snr_threshold, void* sv_noise_out,
+                               int ping_num, int ping_phase, double snr_threshold, void* sv_noise_out,
                                void* sv_corrected_out, double* minmax_out, int dtype, epa_stream_t stream) {
   EPA_CHECK_ARG(sv && alpha2 && noise, "epa_noise_apply: NULL array argument");
   EPA_CHECK_ARG(range || coef, "epa_noise_apply: either range or coef must be given");
   EPA_CHECK_ARG(sv_noise_out || sv_corrected_out, "epa_noise_apply: no output requested");
   EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && ping_num > 0, "epa_noise_apply: sizes must be positive");
+  EPA_CHECK_ARG(ping_phase >= 0 && ping_phase < ping_num, "epa_noise_apply: ping_phase %d not in [0, %d)", ping_phase,
+                ping_num);
   if (dtype == EPA_F64)
-    return launch<double>(sv, range, coef, alpha2, noise, C, P, S, ping_num, snr_threshold,
+    return launch<double>(sv, range, coef, alpha2, noise, C, P, S, ping_num, ping_phase, snr_threshold,
                           sv_noise_out, sv_corrected_out, minmax_out, (hipStream_t)stream);
   if (dtype == EPA_F32)
-    return launch<float>(sv, range, coef, alpha2, noise, C, P, S, ping_num, snr_threshold,
+    return launch<float>(sv, range, coef, alpha2, noise, C, P, S, ping_num, ping_phase, snr_threshold,
                          sv_noise_out, sv_corrected_out, minmax_out, (hipStream_t)stream);
   epa::set_error("epa_noise_apply: bad dtype %d", dtype);
   return EPA_EINVAL;

@@ -24,15 +24,17 @@ from .xr_lite import DataArray, Dataset, DeviceArray
 def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=True, fill_value=np.nan,
                     closed="left", range_var_max=None, materialize_echo_range=False, env_params=None,
                     cal_params=None, ecs_file=None, waveform_mode=None, encode_mode=None, dtype="float64",
-                    device=None):
+                    device=None, _shard=None, _tau_first=None):
     cal_kw = dict(env_params=env_params, cal_params=cal_params, ecs_file=ecs_file, waveform_mode=waveform_mode,
                   encode_mode=encode_mode, dtype=dtype, device=device)
     mv_kw = dict(range_bin=range_bin, ping_time_bin=ping_time_bin, skipna=skipna, fill_value=fill_value,
-                 closed=closed, range_var_max=range_var_max)
+                 closed=closed, range_var_max=range_var_max, _shard=_shard)
     is_power = echodata.sonar_model in ("EK60", "ES70", "AZFP") or (
         echodata.sonar_model in ("EK80", "ES80", "EA640") and encode_mode == "power")
     fast = is_power and not materialize_echo_range and skipna and closed == "left" and \
         echodata.sonar_model != "AZFP"  # AZFP rows carry no guard/mask flags -> generic kernel, two calls
+    if _tau_first is not None and not fast:
+        raise NotImplementedError("a ping shard with tau_effective_first_ping is served by the fused EK power path only")
     if not fast:
         ds_Sv = _compute_cal("Sv", echodata, **cal_kw)
         return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)
@@ -50,14 +52,21 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
                                            ecs_file=ecs_file, waveform_mode=waveform_mode,
                                            encode_mode=encode_mode, dtype=dtype, device=device)
     cal._check_echodata_backscatter_size()
+    cal.tau_nominal_first_ping = _tau_first
     raw, coef, flags, tau_eff = cal._power_inputs("Sv")
     C, P, S = raw.shape
     ping_time = np.asarray(cal.beam["ping_time"].values).astype("datetime64[ns]")
     ns = ping_time.astype(np.int64)
-    if np.any(np.diff(ns) < 0) or np.isnat(ping_time).any():
+    if np.any(ns[1:] < ns[:-1]) or np.isnat(ping_time).any():
+        if _tau_first is not None:
+            raise NotImplementedError("a ping shard needs sorted, valid ping times")
         ds_Sv = _compute_cal("Sv", echodata, **cal_kw)  # unsorted / NaT pings: generic path
         return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)
     e0, dt, n_t = resample_edges(ping_time, ping_time_bin)
+    first_bin = 0
+    if _shard is not None:  # the time grid of the whole dataset; this shard covers global bins first_bin .. last_bin
+        e0, _, first_bin, last_bin = _shard.time_grid(ns, dt, "left")
+        e0, n_t = e0 + first_bin * dt, last_bin - first_bin + 1
     bin_start = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t)
 
     # range grid np.arange(0, nanmax(echo_range) + bin, bin) (api.py:108-115): run on a conservative
@@ -68,6 +77,8 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
         reach = (S - 1) * coef[..., _lib.CF_RA] * coef[..., _lib.CF_RB] + coef[..., _lib.CF_R0]
         reach = torch.nan_to_num(reach, nan=float("-inf"))
         r_cap = float(reach.max().item())
+        if _shard is not None:
+            r_cap = _shard.range_max(r_cap)
         r_cap = r_cap if r_cap > float("-inf") else float("nan")
     n_cap = len(np.arange(0, r_cap + range_bin_m, range_bin_m)) - 1 if np.isfinite(r_cap) else 0
     if n_cap < 1:  # degenerate grid (one sample per ping, no valid range): the two calls deal with it
@@ -75,11 +86,17 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
         return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)
     try:
         res = ops.sv_mvbs_fused(raw, coef, bin_start, n_t, range_bin_m, n_cap, cal_flags=flags, skipna=True,
-                                closed="left", fill_value=fill_value, dtype=cal.dtype, want_range_max=True)
+                                closed="left", fill_value=fill_value, dtype=cal.dtype, want_range_max=True,
+                                want_partials=_shard is not None)
     except _lib.EpaError:  # e.g. a range grid too fine for the LDS accumulators: two calls instead
         ds_Sv = _compute_cal("Sv", echodata, **cal_kw)
         return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)
     rmax = r_cap if range_var_max is not None else float(res["range_max"].item())
+    if _shard is not None and range_var_max is None:
+        rmax = _shard.range_max(rmax)
+    if _shard is not None:  # bins cut by a shard edge: totals over all ranks, reported by the lowest holder
+        res["MVBS"], lo = _shard.finish(res, first_bin, last_bin, fill_value)
+        e0, n_t = e0 + lo * dt, res["MVBS"].shape[1]
     if not np.isfinite(rmax):  # no valid echo_range at all
         ds_Sv = _compute_cal("Sv", echodata, **cal_kw)
         return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)

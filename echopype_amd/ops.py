@@ -252,19 +252,33 @@ def mvbs_index(sv, ping_num, range_sample_num, range=None):
 
 
 def noise_estimate(sv, alpha2, ping_num, range_sample_num, *, range=None, coef=None,
-                   noise_max=float("nan")):
-    """K6 -> noise (C, ceil(P/ping_num)) f64."""
+                   noise_max=float("nan"), ping_phase=0, want_edges=False):
+    """K6 -> noise (C, ceil((P + ping_phase) / ping_num)) f64 [, edge_sum f64 (2, C, Sb), edge_cnt int32 (2, C, Sb):
+    raw (sum, count) per range block of the first / last ping block, for the cross-shard merge]."""
     C, P, S = sv.shape
     if range is not None and range.dtype != sv.dtype:
         range = range.to(sv.dtype)
-    out = torch.empty((C, -(-P // ping_num)), dtype=torch.float64, device=sv.device)
+    out = torch.empty((C, -(-(P + ping_phase) // ping_num)), dtype=torch.float64, device=sv.device)
+    es = ec = None
+    if want_edges:
+        Sb = -(-S // range_sample_num)
+        es = torch.zeros((2, C, Sb), dtype=torch.float64, device=sv.device)
+        ec = torch.zeros((2, C, Sb), dtype=torch.int32, device=sv.device)
     call("epa_noise_estimate", _p(sv), _p(range), _p(coef), _p(alpha2), C, P, S, int(ping_num),
-         int(range_sample_num), float(noise_max), _p(out), _DT[sv.dtype], _stream())
+         int(range_sample_num), int(ping_phase), float(noise_max), _p(out), _p(es), _p(ec), _DT[sv.dtype], _stream())
+    return (out, es, ec) if want_edges else out
+
+
+def noise_finalize(ssum, cnt, noise_max=float("nan")):
+    """Merged (sum, count) rows (rows, Sb) f64 -> noise per row (clean/api.py:402-422)."""
+    rows, Sb = ssum.shape
+    out = torch.empty(rows, dtype=torch.float64, device=ssum.device)
+    call("epa_noise_finalize", _p(ssum), _p(cnt), rows, Sb, float(noise_max), _p(out), _stream())
     return out
 
 
 def noise_apply(sv, alpha2, noise, ping_num, snr_threshold, *, range=None, coef=None,
-                want_noise=True, want_corrected=True, want_minmax=False):
+                want_noise=True, want_corrected=True, want_minmax=False, ping_phase=0):
     """K7 -> (Sv_noise, Sv_corrected[, [min, max of Sv_noise, min, max of Sv_corrected]])."""
     C, P, S = sv.shape
     if range is not None and range.dtype != sv.dtype:
@@ -273,7 +287,7 @@ def noise_apply(sv, alpha2, noise, ping_num, snr_threshold, *, range=None, coef=
     sc = torch.empty_like(sv) if want_corrected else None
     mm = torch.empty(4, dtype=torch.float64, device=sv.device) if want_minmax else None
     call("epa_noise_apply", _p(sv), _p(range), _p(coef), _p(alpha2), _p(noise), C, P, S, int(ping_num),
-         float(snr_threshold), _p(sn), _p(sc), _p(mm), _DT[sv.dtype], _stream())
+         int(ping_phase), float(snr_threshold), _p(sn), _p(sc), _p(mm), _DT[sv.dtype], _stream())
     return (sn, sc, mm.cpu().tolist()) if want_minmax else (sn, sc)
 
 

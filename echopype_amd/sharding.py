@@ -1,22 +1,44 @@
-"""Ping-sharded multi-GPU execution: one process per GPU, ``torch.distributed`` (backend "nccl" =
-RCCL over xGMI on ROCm; "gloo" for the CPU tests).
+"""Ping-sharded multi-GPU execution: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" for the CPU tests and single-GPU dry runs).
 
-The path shards along ``ping_time``: calibration is independent per ping; the only
-cross-shard quantities are
-  * scalars fixed before sharding -- EK60 tau_effective (ping 0 of the whole file), the day origin
-    of the ping-time bins and the range-bin grid (all-reduce MIN / MAX of one number each);
-  * MVBS time bins that straddle a shard edge: each rank contributes the raw linear (sum, count) of
-    its FIRST and LAST local time bin, one all-reduce(SUM) over a (2 * world, C, n_rbins) buffer
-    (<= a few hundred KB: latency-bound on xGMI, never bandwidth-bound), then the lowest rank that
-    holds a shared bin finalises it (10*log10(sum/count)) and the others drop their copy.
-When every shard holds a whole number of time bins (the bench's weak-scaling layout) the straddle
-exchange is skipped and the data path has no collective at all.
+The path shards along ``ping_time``: calibration is independent per ping; the only cross-shard
+quantities are
+  * scalars fixed before sharding -- EK60 tau_effective (ping 0 of the whole file), the day origin of the
+    ping-time bins and the range-bin grid (all-reduce MIN / MAX of one number each, once per dataset);
+  * MVBS time bins that straddle a shard edge (commongrid/utils.py:614-627 sums a bin over ALL its pings);
+  * background-noise ping blocks that straddle a shard edge: the block mean comes BEFORE the minimum over range
+    blocks (/root/reference/echopype/clean/api.py:402-411), so the raw (sum, count) per range block of the cut
+    block are merged, not the per-shard minima.
+Both exchanges have the same shape and share one mechanism, ``EdgeExchange``: a shard is a list of SEGMENTS
+(resident tiles; one per rank in the simplest case), every segment contributes the raw linear (sum, count) rows
+of its FIRST and LAST bin / block, one all-reduce(SUM) moves a (slots, 2, C, R) fp64 buffer (a few hundred KB:
+latency-bound on xGMI, never bandwidth-bound), and every holder of a shared bin reads the total back.  The slot
+topology is exchanged ONCE (host, at plan time); a step is: pack (device) -> all_reduce -> one small matrix
+product that adds the slots of each shared bin (device) -- no host synchronisation on the data path.
+When no bin is shared (shard edges on bin edges) the exchange is skipped: no collective at all.
 
-This module holds only the bin bookkeeping and the exchange; kernels are called through ops.
+Product entry points (same signatures as the single-process functions plus ``group`` / ``ping_offset``):
+``compute_MVBS``, ``compute_Sv_MVBS``, ``remove_background_noise``.  Kernels are called through ops.
 """
 import numpy as np
 import torch
 import torch.distributed as dist
+
+NO_BIN = -(2**62)  # id of an absent edge (matches nothing)
+
+
+def _world(group=None):
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
+def _rank(group=None):
+    return dist.get_rank(group) if dist.is_initialized() else 0
+
+
+def _comm_device(group=None):
+    if dist.is_initialized() and dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
 
 
 def shard_bounds(P_total, world, rank, align=1):
@@ -36,8 +58,8 @@ def global_time_grid(local_ping_ns, dt_ns, group=None):
     t = t[t != np.iinfo(np.int64).min]
     lo = torch.tensor([t.min() if t.size else np.iinfo(np.int64).max], dtype=torch.int64)
     hi = torch.tensor([t.max() if t.size else np.iinfo(np.int64).min + 1], dtype=torch.int64)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dev = _comm_device()
+    if _world(group) > 1:
+        dev = _comm_device(group)
         lo, hi = lo.to(dev), hi.to(dev)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
@@ -48,15 +70,12 @@ def global_time_grid(local_ping_ns, dt_ns, group=None):
     return e0, int((last - e0) // dt_ns + 1)
 
 
-def _comm_device():
-    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-
-
 def global_max(value, group=None):
-    """all-reduce MAX of one float (e.g. nanmax(echo_range) for the range grid, api.py:110)."""
-    t = torch.tensor([value], dtype=torch.float64)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
-        t = t.to(_comm_device())
+    """all-reduce MAX of one float (e.g. nanmax(echo_range) for the range grid, api.py:110); NaN = nothing here."""
+    v = float(value)
+    t = torch.tensor([v if v == v else -np.inf], dtype=torch.float64)
+    if _world(group) > 1:
+        t = t.to(_comm_device(group))
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
 
@@ -74,63 +93,209 @@ def local_bin_span(local_ping_ns, e0, dt_ns, closed="left"):
     return int(b.min()), int(b.max())
 
 
-def merge_straddling_bins(ssum, cnt, first_bin, last_bin, group=None):
-    """Merge partial sums of time bins shared between ranks.
+class EdgeExchange:
+    """Totals of the bins / blocks shared between segments of a ping-sharded dataset.
 
-    ssum, cnt : (C, n_local_bins, n_rbins) raw linear sums / counts of THIS rank's local bins,
-                local bin j == global bin first_bin + j.  Modified in place: after the call every
-                shared bin holds the global total on its OWNER (lowest rank that has it).
-    Returns ``keep``: boolean mask over local bins, False for shared bins owned by another rank.
+    ``spans``: [(first_id, last_id)] global bin ids of THIS rank's segments, in order ((0, -1) = empty segment).
+    After ``plan = EdgeExchange(spans, C, R, device)``:
+      plan.shared           -- False when no bin is held by two segments anywhere (merge() is then a no-op)
+      plan.edges            -- [(segment, 0 | 1, bin id, owner)] local edges that are shared; ``owner`` is True on
+                               the globally first segment holding the bin (it reports the bin, the others drop it)
+      totals = plan.merge(rows) -- rows[(segment, which)] = (sum (C, R), count (C, R)) raw linear partials of every
+                               local edge listed in plan.edges; returns {(segment, which): (sum, count)} fp64
+                               totals over all segments of all ranks.  ONE all-reduce.
+    A segment with a single bin contributes it once (as its first edge).
     """
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def __init__(self, spans, C, R, device, group=None):
+        self.group, self.C, self.R = group, int(C), int(R)
+        self.device = torch.device(device)
+        world, rank = _world(group), _rank(group)
+        nseg = torch.tensor([len(spans)], dtype=torch.int64)
+        if world > 1:
+            nseg = nseg.to(_comm_device(group))
+            dist.all_reduce(nseg, op=dist.ReduceOp.MAX, group=group)
+        self.max_seg = int(nseg.item())
+        ids = np.full((world, self.max_seg, 2), NO_BIN, dtype=np.int64)
+        for k, (f, l) in enumerate(spans):
+            if l >= f:
+                ids[rank, k, 0] = f
+                if l != f:
+                    ids[rank, k, 1] = l
+        if world > 1:  # every rank fills its own rows, the others are 0 after the shift
+            t = torch.zeros((world, self.max_seg, 2), dtype=torch.int64)
+            t[rank] = torch.from_numpy(ids[rank] - NO_BIN)
+            t = t.to(_comm_device(group))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            ids = t.cpu().numpy() + NO_BIN
+        flat = ids.reshape(-1)  # slot = (rank * max_seg + segment) * 2 + which
+        self.n_slots = flat.size
+        groups = {}
+        for slot, b in enumerate(flat):
+            if b != NO_BIN:
+                groups.setdefault(int(b), []).append(slot)
+        self.edges, rows = [], []
+        base = rank * self.max_seg * 2
+        for k in range(len(spans)):
+            for which in (0, 1):
+                b = int(flat[base + 2 * k + which])
+                if b == NO_BIN or len(groups[b]) < 2:
+                    continue
+                self.edges.append((k, which, b, groups[b][0] == base + 2 * k + which))
+                m = np.zeros(self.n_slots)
+                m[groups[b]] = 1.0
+                rows.append(m)
+        self.shared = any(len(g) > 1 for g in groups.values())
+        self._slot = {(k, w): base + 2 * k + w for k, w, _, _ in self.edges}
+        self._cdev = _comm_device(group) if world > 1 else self.device  # host buffer under gloo
+        self._buf = torch.zeros((self.n_slots, 2, self.C, self.R), dtype=torch.float64, device=self._cdev) \
+            if self.shared else None
+        self._pick = torch.from_numpy(np.stack(rows)).to(self._cdev) if rows else None
+
+    def merge(self, rows):
+        if not self.shared:
+            return {}
+        buf = self._buf
+        buf.zero_()
+        for key, (s, c) in rows.items():
+            slot = self._slot.get(key)
+            if slot is not None:
+                buf[slot, 0].copy_(s)
+                buf[slot, 1].copy_(c)
+        if _world(self.group) > 1:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        if self._pick is None:
+            return {}
+        tot = (self._pick @ buf.view(self.n_slots, -1)).view(len(self.edges), 2, self.C, self.R).to(self.device)
+        return {(k, w): (tot[i, 0], tot[i, 1]) for i, (k, w, _, _) in enumerate(self.edges)}
+
+
+# ---- MVBS time bins ----------------------------------------------------------------------------------------------
+
+def mvbs_edge_rows(ssum, cnt):
+    """The rows EdgeExchange wants from one segment's raw partials (C, n_bins, R)."""
+    out = {0: (ssum[:, 0], cnt[:, 0])}
+    if ssum.shape[1] > 1:
+        out[1] = (ssum[:, -1], cnt[:, -1])
+    return out
+
+
+def merge_straddling_bins(ssum, cnt, first_bin, last_bin, group=None):
+    """One-segment convenience form: merge the partial sums of time bins shared between ranks.
+    ssum, cnt : (C, n_local_bins, R) raw linear sums / counts, local bin j == global bin first_bin + j; modified
+    in place so that every shared bin holds the global total.  Returns ``keep`` (bool per local bin): False for
+    shared bins reported by a lower rank."""
     n_local = ssum.shape[1]
     keep = np.ones(n_local, dtype=bool)
-    if world == 1 or n_local == 0 and world == 1:
-        return keep
-    dev = ssum.device
-    # collectives run on the backend's device (GPU for RCCL, host for gloo); partials may live elsewhere
-    cdev = _comm_device() if dist.get_backend(group) != "nccl" or not ssum.is_cuda else dev
-    C, _, R = ssum.shape
-    # 1. everyone learns every rank's (first, last) global bin ids
-    ids = torch.full((world, 2), -1, dtype=torch.int64, device=cdev)
-    if n_local > 0:
-        ids[rank, 0], ids[rank, 1] = first_bin, last_bin
-    span = torch.zeros((world, 2), dtype=torch.int64, device=cdev)
-    span[rank] = ids[rank] + 1  # +1 so that "no bins" (-1) sums as 0
-    dist.all_reduce(span, op=dist.ReduceOp.SUM, group=group)
-    span = (span - 1).cpu().numpy()
-    # 2. one all-reduce over the edge-bin partials (slot 2r = first bin of rank r, 2r+1 = last)
-    buf_s = torch.zeros((2 * world, C, R), dtype=ssum.dtype, device=cdev)
-    buf_c = torch.zeros((2 * world, C, R), dtype=torch.int64, device=cdev)
-    if n_local > 0:
-        buf_s[2 * rank] = ssum[:, 0].to(cdev)
-        buf_c[2 * rank] = cnt[:, 0].to(cdev, torch.int64)
-        if n_local > 1:  # a single local bin is contributed once
-            buf_s[2 * rank + 1] = ssum[:, -1].to(cdev)
-            buf_c[2 * rank + 1] = cnt[:, -1].to(cdev, torch.int64)
-    dist.all_reduce(buf_s, op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(buf_c, op=dist.ReduceOp.SUM, group=group)
-    if n_local == 0:
-        return keep
-    # 3. totals of my edge bins = sum over every slot carrying the same global bin id
-    slot_bin = np.full(2 * world, -2, dtype=np.int64)
-    for r in range(world):
-        f, l = span[r]
-        if f >= 0:
-            slot_bin[2 * r] = f
-            if l != f:
-                slot_bin[2 * r + 1] = l
-    for j, g in ((0, first_bin), (n_local - 1, last_bin)):
-        slots = np.flatnonzero(slot_bin == g)
-        owners = sorted({int(s) // 2 for s in slots})
-        if len(owners) <= 1:
-            continue
-        idx = torch.as_tensor(slots, device=cdev)
-        ssum[:, j] = buf_s.index_select(0, idx).sum(dim=0).to(dev)
-        cnt[:, j] = buf_c.index_select(0, idx).sum(dim=0).to(dev, cnt.dtype)
-        if owners[0] != rank:
-            keep[j] = False
-        if n_local == 1:
-            break
+    plan = EdgeExchange([(first_bin, last_bin) if n_local else (0, -1)], ssum.shape[0], ssum.shape[2], ssum.device, group)
+    rows = {(0, w): r for w, r in mvbs_edge_rows(ssum, cnt).items()} if n_local else {}
+    for (k, w), (s, c) in plan.merge(rows).items():
+        j = 0 if w == 0 else n_local - 1
+        ssum[:, j] = s.to(ssum.dtype)
+        cnt[:, j] = c.to(cnt.dtype)
+    for k, w, _, owner in plan.edges:
+        if not owner:
+            keep[0 if w == 0 else n_local - 1] = False
     return keep
+
+
+# ---- background-noise ping blocks ---------------------------------------------------------------------------------
+
+def noise_block_span(ping_offset, P, ping_num):
+    """Global ids (first, last) of the ping blocks a shard of P pings starting at global ping ``ping_offset`` touches."""
+    return (ping_offset // ping_num, (ping_offset + P - 1) // ping_num) if P > 0 else (0, -1)
+
+
+def merge_noise_edges(noise, edge_sum, edge_cnt, ping_offset, P, ping_num, noise_max=float("nan"), group=None,
+                      finalize=None):
+    """Replace the noise of the shard's first / last ping block by the value over the WHOLE block when a shard edge
+    cuts it (clean/api.py:402-411: mean over the block, then dB, then min over range blocks).
+    noise (C, n_blocks) f64, edge_sum / edge_cnt (2, C, Sb) from ops.noise_estimate(want_edges=True); in place.
+    ``finalize(sum (rows, Sb), cnt (rows, Sb)) -> (rows,)``: epa_noise_finalize by default."""
+    C, nb = noise.shape
+    plan = EdgeExchange([noise_block_span(ping_offset, P, ping_num)], C, edge_sum.shape[2], noise.device, group)
+    rows = {(0, 0): (edge_sum[0], edge_cnt[0])}
+    if nb > 1:
+        rows[(0, 1)] = (edge_sum[1], edge_cnt[1])
+    tot = plan.merge(rows)
+    if not tot:
+        return noise
+    if finalize is None:
+        from . import ops
+
+        finalize = lambda s, c: ops.noise_finalize(s.contiguous(), c.contiguous(), noise_max)  # noqa: E731
+    for (k, w), (s, c) in tot.items():
+        noise[:, 0 if w == 0 else nb - 1] = finalize(s, c)
+    return noise
+
+
+def remove_background_noise(ds_Sv, ping_num, range_sample_num, background_noise_max=None, SNR_threshold="3.0dB", *,
+                            ping_offset, group=None):
+    """clean.remove_background_noise on THIS rank's ping shard of a longer dataset: ``ping_offset`` = global index
+    of the shard's first ping.  Adds Sv_noise / Sv_corrected to ``ds_Sv`` exactly as the single-process call on
+    the whole dataset would for these pings."""
+    from .clean import api as clean_api
+
+    return clean_api.remove_background_noise(ds_Sv, ping_num, range_sample_num, background_noise_max, SNR_threshold,
+                                             _shard=(int(ping_offset), group))
+
+
+# ---- compute_MVBS / compute_Sv_MVBS on a shard -----------------------------------------------------------------------
+
+class MVBSShard:
+    """Hooks the single-process compute_MVBS calls when it runs on one rank's shard (commongrid/api.py)."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def time_grid(self, ns, dt, closed):
+        e0, n_glob = global_time_grid(ns, dt, self.group)
+        first, last = local_bin_span(ns, e0, dt, closed)
+        return e0, n_glob, first, last
+
+    def range_max(self, hi):
+        return global_max(hi, self.group)
+
+    def finish(self, res, first_bin, last_bin, fill_value):
+        """Merged, finalised MVBS of the bins this rank reports: (tensor (C, n_kept, R), index of the first kept
+        local bin)."""
+        from . import ops
+
+        ssum, cnt, mv = res["sum"], res["cnt"], res["MVBS"]
+        n_local = mv.shape[1]
+        plan = EdgeExchange([(first_bin, last_bin) if n_local else (0, -1)], mv.shape[0], mv.shape[2], mv.device,
+                            self.group)
+        rows = {(0, w): r for w, r in mvbs_edge_rows(ssum, cnt).items()} if n_local else {}
+        tot = plan.merge(rows)
+        lo, hi = 0, n_local
+        for k, w, _, owner in plan.edges:
+            j = 0 if w == 0 else n_local - 1
+            if owner:
+                s, c = tot[(k, w)]
+                mv[:, j] = ops.mvbs_finalize(s.to(mv.dtype).contiguous(), c.to(torch.int32).contiguous(), fill_value)
+            elif w == 0:
+                lo = 1
+            else:
+                hi = n_local - 1
+        return mv[:, lo:max(lo, hi)], lo
+
+
+def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="20s", skipna=True, fill_value=np.nan,
+                 closed="left", range_var_max=None, *, group=None):
+    """commongrid.compute_MVBS on THIS rank's ping shard.  The time grid (day origin) and the range grid are those
+    of the whole dataset; a time bin cut by a shard edge is summed over all its pings (one small all-reduce) and
+    reported by the lowest rank holding it.  Returns the MVBS dataset of the bins this rank reports; concatenating
+    the ranks' results along ``ping_time`` gives the single-process answer."""
+    from .commongrid import api as cg_api
+
+    return cg_api.compute_MVBS(ds_Sv, range_var, range_bin, ping_time_bin, skipna=skipna, fill_value=fill_value,
+                               closed=closed, range_var_max=range_var_max, _shard=MVBSShard(group))
+
+
+def compute_Sv_MVBS(echodata, *, tau_effective_first_ping=None, group=None, **kw):
+    """fused.compute_Sv_MVBS on THIS rank's ping shard (see compute_MVBS above for the grid and the shared bins).
+    EK60: tau_effective is ping 0 of the WHOLE file (calibrate_ek.py:154-162) -- pass the (channel,) values of the
+    global first ping as ``tau_effective_first_ping`` on every rank but the first (None = this shard's own ping 0)."""
+    from . import fused
+
+    return fused.compute_Sv_MVBS(echodata, _shard=MVBSShard(group), _tau_first=tau_effective_first_ping, **kw)

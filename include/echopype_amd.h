@@ -215,20 +215,36 @@ int epa_mvbs_index(const void* sv, const void* range, int C, int P, int S, int p
  * Replaces clean/api.py:397-422: TL = 20log10(max(R,1) [NaN->1]) + 2*alpha*R; block mean of
  * 10^((Sv-TL)/10) over ping_num x range_sample_num (NaN-padded, NaN-skipping) -> dB -> min over
  * range blocks -> optional clamp to noise_max (NaN when noise_max is NaN = not given).
- * alpha2: 2*alpha per (c,p) [C*P] f64.  noise_out: f64 [C * ceil(P/ping_num)].
+ * alpha2: 2*alpha per (c,p) [C*P] f64.
+ * ping_phase (0 .. ping_num-1): the arrays hold a ping shard of a longer dataset whose first ping sits
+ * `ping_phase` pings into a block (global ping index of the shard's first ping modulo ping_num; 0 for a whole
+ * dataset): local ping p belongs to block (p + ping_phase) / ping_num.
+ * noise_out: f64 [C * ceil((P + ping_phase) / ping_num)].
+ * edge_sum_out / edge_cnt_out (optional, both or neither; f64 / u32 [2 * C * ceil(S/range_sample_num)], zeroed by the
+ * caller): the raw linear (sum, count) per range block of the shard's FIRST (slot 0) and LAST (slot 1, written only
+ * when it is another block) ping block -- blocks a shard edge may cut; the owner merges them across shards before the
+ * mean and the min, then epa_noise_finalize.
  */
 int epa_noise_estimate(const void* sv, const void* range, const double* coef, const double* alpha2,
-                       int C, int P, int S, int ping_num, int range_sample_num, double noise_max,
-                       double* noise_out, int dtype, epa_stream_t stream);
+                       int C, int P, int S, int ping_num, int range_sample_num, int ping_phase, double noise_max,
+                       double* noise_out, double* edge_sum_out, uint32_t* edge_cnt_out, int dtype,
+                       epa_stream_t stream);
+
+/* Merged (sum, count) rows of noise blocks -> noise value per row (clean/api.py:402-422: mean -> dB -> min over the
+ * range blocks -> clamp).  sum, cnt: f64 [rows * n_rblocks] (the counts travel through an all-reduce with the sums);
+ * noise_out: f64 [rows]. */
+int epa_noise_finalize(const double* sum, const double* cnt, int rows, int n_rblocks, double noise_max,
+                       double* noise_out, epa_stream_t stream);
 
 /* ---- K7: noise removal -------------------------------------------------------------------------------------------
  * Replaces clean/api.py:425-430 (ffill upsample + TL) and :485-487.  Writes Sv_noise and
- * Sv_corrected ([C*P*S] of dtype; either may be NULL).  snr_threshold in dB.  minmax_out (f64 [4],
+ * Sv_corrected ([C*P*S] of dtype; either may be NULL).  snr_threshold in dB.  ping_phase as in
+ * epa_noise_estimate (noise holds ceil((P + ping_phase) / ping_num) blocks per channel).  minmax_out (f64 [4],
  * optional): NaN-skipping {min, max} of Sv_noise and of Sv_corrected as a by-product (the actual_range
  * attributes of clean/utils.py:392-395 without two more sweeps).
  */
 int epa_noise_apply(const void* sv, const void* range, const double* coef, const double* alpha2,
-                    const double* noise, int C, int P, int S, int ping_num, double snr_threshold,
+                    const double* noise, int C, int P, int S, int ping_num, int ping_phase, double snr_threshold,
                     void* sv_noise_out, void* sv_corrected_out, double* minmax_out, int dtype,
                     epa_stream_t stream);
 

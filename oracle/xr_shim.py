@@ -74,6 +74,12 @@ class DataArray:
         assert self.data.size == 1
         return bool(self.data.reshape(()))
 
+    def __float__(self):  # xarray defines the scalar conversions for one-element arrays
+        return float(self.data.reshape(()))
+
+    def __int__(self):
+        return int(self.data.reshape(()))
+
     def chunk(self, *a, **k):
         return self
 
@@ -147,8 +153,9 @@ class DataArray:
     def _binary(self, other, f, reflexive=False):
         o = _as_da(other)
         if o is None:
-            if isinstance(other, np.ndarray) and other.ndim > 0:
-                raise TypeError("unlabelled ndarray operand")
+            if isinstance(other, np.ndarray) and other.ndim > 0 and other.shape != self.data.shape:
+                # (an ndarray of exactly the array's shape combines positionally, as in xarray)
+                raise TypeError("unlabelled ndarray operand of a different shape")
             r = f(other, self.data) if reflexive else f(self.data, other)
             return self._like(r)
         self, o = DataArray._align(self, o)
@@ -267,11 +274,54 @@ def _methods():
     def sel(self, **ix):
         out = self
         for d, k in ix.items():
+            if isinstance(k, slice):
+                # label slice on a monotonic index: xarray hands it to pandas' Index.slice_indexer (both ends
+                # inclusive); pandas itself is executed here
+                import pandas as pd
+
+                assert k.step is None
+                idx = pd.Index(np.asarray(out.coords[d]))
+                assert idx.is_monotonic_increasing, f"sel(slice) on a non-monotonic {d}"
+                out = out.isel(**{d: idx.slice_indexer(k.start, k.stop)})
+                continue
             k = _as_da(k)
             if k is None or k.data.dtype != bool:
-                raise NotImplementedError("sel: boolean DataArray indexers only")
+                raise NotImplementedError("sel: label slices and boolean DataArray indexers only")
             out = out.isel(**{d: np.flatnonzero(k.data)})
         return out
+
+    class _Resample:
+        """da.resample(time=freq).first().indexes[time]: the bin LABELS only.  xarray groups with a
+        pandas Grouper(freq, closed / label / origin at pandas' defaults), so the labels are those of a pandas
+        resample of the same index -- pandas is executed."""
+
+        def __init__(self, da, dim, freq):
+            import pandas as pd
+
+            t = pd.DatetimeIndex(np.asarray(da.coords[dim]))
+            self.dim = dim
+            self.index = pd.Series(np.arange(len(t)), index=t).resample(freq).first().index
+
+        def first(self):
+            return self
+
+        @property
+        def indexes(self):
+            return {self.dim: self.index}
+
+    def resample(self, skipna=None, **kw):
+        (dim, freq), = kw.items()
+        return _Resample(self, dim, freq)
+
+    def diff(self, dim, n=1, label="upper"):
+        assert n == 1
+        ax = self.dims.index(dim)
+        out = np.diff(self.data, axis=ax)
+        res = self._like(out)
+        if dim in self.coords:
+            c = np.asarray(self.coords[dim])
+            res.coords[dim] = c[:-1] if label == "lower" else c[1:]
+        return res
 
     class _Loc:
         def __init__(self, da):
@@ -458,7 +508,7 @@ def _methods():
             yield DataArray(self.data[i], dims=[], name=self.name)
 
     for f in (isnull, where, transpose, isel, drop_vars, squeeze, to_dataset, sel, mean, fillna, _reduce, assign_coords,
-              reindex, reindex_like, coarsen, pipe, assign_attrs, rename, equals):
+              reindex, reindex_like, coarsen, pipe, assign_attrs, rename, equals, resample, diff):
         setattr(DataArray, f.__name__, f)
     DataArray.min, DataArray.max = amin, amax
     DataArray.any = any_
@@ -541,6 +591,29 @@ class Dataset:
 
     def copy(self):
         return self.assign_attrs()
+
+    def assign_coords(self, coords=None, **kw):
+        out = self.copy()
+        for k, v in {**(coords or {}), **kw}.items():
+            out.coords[k] = v  # (dim, values) tuples keep the values; the dimension is checked by swap_dims
+        return out
+
+    def swap_dims(self, mapping):
+        """The coordinate ``new`` (1-D along ``old``) becomes the index of that dimension; ``old`` stays as a
+        plain variable along the renamed dimension."""
+        out = Dataset(attrs=self.attrs)
+        for k, v in self.coords.items():
+            out.coords[k] = v
+        for old, new in mapping.items():
+            assert len(self.coords[new]) == len(self.coords[old])
+        for k, v in self._vars.items():
+            out._vars[k] = DataArray(v.data, None, [mapping.get(d, d) for d in v.dims], k, v.attrs)
+        for old, new in mapping.items():
+            out._vars[old] = DataArray(out.coords.pop(old), None, [new], old)
+        return out
+
+    def pipe(self, f, *a, **k):
+        return f(self, *a, **k)
 
     def drop_dims(self, names, errors="raise"):
         names = [names] if isinstance(names, str) else list(names)

@@ -1,6 +1,8 @@
-"""N>1 path on CPU: world_size-2 gloo processes exercise the cross-shard bookkeeping of
-echopype_amd.sharding (global time grid, range-grid max, straddling-bin merge) against a
-single-process NumPy evaluation of the same MVBS partial sums."""
+"""N>1 path on CPU: world_size-2 / -3 gloo processes exercise the cross-shard bookkeeping of
+echopype_amd.sharding (global time grid, range-grid max, the EdgeExchange behind the straddling MVBS time bins and
+the straddling background-noise ping blocks, several resident segments per rank) against a single-process NumPy
+evaluation.  The per-sample partial sums come from NumPy here (the HIP kernels need a GPU: tests/test_gpu_sharded.py
+runs the same exchange on their output)."""
 import os
 import socket
 
@@ -105,3 +107,169 @@ def test_shard_bounds_align_to_bins():
     assert all(a % 20 == 0 for a, _ in spans)
     spans = [shard_bounds(1003, 4, r, align=20) for r in range(4)]
     assert spans[-1][1] == 1003 and sum(b - a for a, b in spans) == 1003
+
+
+# ---- several resident segments (tiles) per rank: intra-rank and inter-rank shared bins in ONE exchange ----------
+def _worker_segments(rank, world, port, P_total, cuts, owner_of, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from echopype_amd import sharding
+
+    rng = np.random.default_rng(5)
+    C, S = 2, 40
+    Sv = rng.normal(-70, 6, size=(C, P_total, S))
+    er = np.tile(np.arange(S) * 0.23, (C, P_total, 1))
+    ns = (np.datetime64("2026-05-01T00:00:07", "ns").astype(np.int64) + np.arange(P_total) * 10**9)
+    bounds = [0] + list(cuts) + [P_total]
+    segs = [(bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1) if owner_of[i] == rank]
+    dt = 20 * 10**9
+    mine = np.concatenate([ns[a:b] for a, b in segs]) if segs else ns[:0]
+    e0, _ = sharding.global_time_grid(mine, dt)
+    rmax = sharding.global_max(float(np.nanmax(er)))
+    r_edges = np.arange(0, rmax + 1.0, 1.0)
+    spans, parts = [], []
+    for a, b in segs:
+        first, last = sharding.local_bin_span(ns[a:b], e0, dt)
+        ssum, cnt = _partials(Sv[:, a:b], er[:, a:b], ns[a:b], e0, dt, last - first + 1, first, r_edges)
+        spans.append((first, last))
+        parts.append((torch.from_numpy(ssum), torch.from_numpy(cnt.astype(np.float64))))
+    plan = sharding.EdgeExchange(spans, C, len(r_edges) - 1, "cpu")
+    rows = {}
+    for k, (ssum, cnt) in enumerate(parts):
+        for w, r in sharding.mvbs_edge_rows(ssum, cnt).items():
+            rows[(k, w)] = r
+    tot = plan.merge(rows)
+    out = []
+    for k, (ssum, cnt) in enumerate(parts):
+        keep = np.ones(ssum.shape[1], dtype=bool)
+        for kk, w, _, owner in plan.edges:
+            if kk != k:
+                continue
+            j = 0 if w == 0 else ssum.shape[1] - 1
+            ssum[:, j], cnt[:, j] = tot[(k, w)]
+            keep[j] = owner
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mv = np.where(cnt.numpy() > 0, 10 * np.log10(ssum.numpy() / np.maximum(cnt.numpy(), 1)), np.nan)
+        out.append((spans[k][0], keep, mv[:, keep]))
+    q.put((rank, e0, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("P_total,cuts,owner_of", [
+    (200, (50, 110, 150), (0, 0, 1, 1)),      # two tiles per rank, every cut inside a 20-ping bin
+    (120, (30, 45, 100), (0, 1, 1, 0)),       # rank 0 holds the first and the last tile; a 15-ping tile inside one bin
+    (90, (20, 40, 60), (0, 1, 2, 0)),         # three ranks, cuts on bin edges but the 7-s phase still splits bins
+])
+def test_edge_exchange_with_several_segments_per_rank(P_total, cuts, owner_of):
+    world = max(owner_of) + 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_segments, args=(r, world, port, P_total, cuts, owner_of, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(5)
+    C, S = 2, 40
+    Sv = rng.normal(-70, 6, size=(C, P_total, S))
+    er = np.tile(np.arange(S) * 0.23, (C, P_total, 1))
+    pt = np.datetime64("2026-05-01T00:00:07", "ns") + (np.arange(P_total) * 10**9).astype("timedelta64[ns]")
+    exp, t_left, _ = ogrid.compute_MVBS(Sv, er, pt, "1m", "20s")
+    got = np.full_like(exp, np.nan)
+    seen = np.zeros(len(t_left), dtype=int)
+    for rank, e0, segs in res:
+        assert e0 == t_left[0].astype(np.int64)
+        for first, keep, mv in segs:
+            ids = first + np.flatnonzero(keep)
+            seen[ids] += 1
+            got[:, ids] = mv
+    assert (seen == 1).all(), seen
+    np.testing.assert_allclose(got, exp, rtol=1e-12, equal_nan=True)
+
+
+# ---- background-noise ping blocks cut by a shard edge (clean/api.py:402-411: block mean BEFORE the min) ----------
+def _noise_partials(Sv, er, alpha, ping_num, rsn, phase):
+    """NumPy stand-in of epa_noise_estimate(ping_phase, want_edges): noise per local block + raw (sum, count) per
+    range block of the first / last block."""
+    C, P, S = Sv.shape
+    with np.errstate(invalid="ignore", divide="ignore"):
+        tl = 20 * np.log10(np.where(er >= 1, er, 1)) + 2 * alpha * er
+        lin = 10 ** ((Sv - tl) / 10)
+    blk = (np.arange(P) + phase) // ping_num
+    nb, Sb = blk.max() + 1, -(-S // rsn)
+    rb = np.arange(S) // rsn
+    ssum, cnt = np.zeros((C, nb, Sb)), np.zeros((C, nb, Sb))
+    ok = ~np.isnan(lin)
+    for c in range(C):
+        flat = (blk[:, None] * Sb + rb[None, :])
+        ssum[c] = np.bincount(flat[ok[c]], weights=lin[c][ok[c]], minlength=nb * Sb).reshape(nb, Sb)
+        cnt[c] = np.bincount(flat[ok[c]], minlength=nb * Sb).reshape(nb, Sb)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        noise = np.nanmin(np.where(cnt > 0, 10 * np.log10(ssum / np.maximum(cnt, 1)), np.nan), axis=2)
+    es, ec = np.zeros((2, C, Sb)), np.zeros((2, C, Sb))
+    es[0], ec[0] = ssum[:, 0], cnt[:, 0]
+    if nb > 1:
+        es[1], ec[1] = ssum[:, -1], cnt[:, -1]
+    return noise, es, ec
+
+
+def _worker_noise(rank, world, port, P_total, split, ping_num, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from echopype_amd import sharding
+
+    rng = np.random.default_rng(9)
+    C, S, rsn = 2, 50, 8
+    Sv = rng.normal(-80, 5, size=(C, P_total, S))
+    Sv[rng.random(Sv.shape) < 0.05] = np.nan
+    er = np.tile(np.linspace(0, 40, S), (C, P_total, 1))
+    bounds = [0] + list(split) + [P_total]
+    p0, p1 = bounds[rank], bounds[rank + 1]
+    noise, es, ec = _noise_partials(Sv[:, p0:p1], er[:, p0:p1], 0.01, ping_num, rsn, p0 % ping_num)
+    noise_t = torch.from_numpy(noise.copy())
+
+    def finalize(s, c):  # NumPy stand-in of epa_noise_finalize
+        s, c = s.numpy(), c.numpy()
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return torch.from_numpy(np.nanmin(np.where(c > 0, 10 * np.log10(s / np.maximum(c, 1)), np.nan), axis=1))
+
+    sharding.merge_noise_edges(noise_t, torch.from_numpy(es), torch.from_numpy(ec), p0, p1 - p0, ping_num, finalize=finalize)
+    q.put((rank, p0, p1, noise_t.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("P_total,split,ping_num", [(100, (47,), 10), (100, (50,), 10), (64, (5, 9), 20), (30, (7, 19), 4)])
+def test_noise_blocks_cut_by_shard_edges_equal_single_process(P_total, split, ping_num):
+    from oracle import clean as oclean
+
+    world = len(split) + 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_noise, args=(r, world, port, P_total, split, ping_num, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(9)
+    C, S, rsn = 2, 50, 8
+    Sv = rng.normal(-80, 5, size=(C, P_total, S))
+    Sv[rng.random(Sv.shape) < 0.05] = np.nan
+    er = np.tile(np.linspace(0, 40, S), (C, P_total, 1))
+    # the single-process oracle: Sv_noise - TL is the per-ping noise of the whole dataset
+    sn = oclean.estimate_background_noise(Sv, er, 0.01, ping_num, rsn)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        tl = 20 * np.log10(np.where(er >= 1, er, 1)) + 2 * 0.01 * er
+    per_ping = (sn - tl)[:, :, 3]
+    for rank, p0, p1, noise in res:
+        blk = (np.arange(p1 - p0) + p0 % ping_num) // ping_num
+        np.testing.assert_allclose(noise[:, blk], per_ping[:, p0:p1], rtol=1e-12, atol=1e-10)
