@@ -46,8 +46,18 @@ class CalibrateBase(abc.ABC):
             raise NotImplementedError(
                 "ecs_file: Echoview .ecs parsing (calibrate/ecs.py) is outside the accelerated hot "
                 "path; pass the parameters through env_params / cal_params instead.")
-        self.env_params = {} if env_params is None else env_params
-        self.cal_params = {} if cal_params is None else cal_params
+        if env_params is None:  # calibrate_base.py:35-47
+            self.env_params = {}
+        elif isinstance(env_params, dict):
+            self.env_params = env_params
+        else:
+            raise ValueError("'env_params' has to be None or a dict")
+        if cal_params is None:
+            self.cal_params = {}
+        elif isinstance(cal_params, dict):
+            self.cal_params = cal_params
+        else:
+            raise ValueError("'cal_params' has to be None or a dict")
         self.range_meter = None
         self.dtype = ops.torch_dtype(kwargs.get("dtype", "float64"))
         self.device = kwargs.get("device")

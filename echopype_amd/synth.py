@@ -36,10 +36,12 @@ def _channels(C):
     return np.arange(C) % 4
 
 
-def ek60_params(C, P, vary_tau=False, seed=0):
-    """Per-channel / per-ping parameters of the synthetic EK60 file (host, O(C*P))."""
+def ek60_params(C, P, vary_tau=False, seed=0, ping0=0):
+    """Per-channel / per-ping parameters of the synthetic EK60 file (host, O(C*P)).  ``ping0``: global index of
+    the first ping when the arrays are a ping shard / tile of a longer file (ping times and the sound-speed drift
+    follow the global index)."""
     ch = _channels(C)
-    p = np.arange(P)
+    p = np.arange(P) + ping0
     si = np.full((C, P), 2.56e-4)
     tau = np.full((C, P), 1.024e-3)
     if vary_tau:  # exercise the pulse-length table lookup (+ a NaN ping)
@@ -76,7 +78,7 @@ def ek60_numpy(C=2, P=200, S=1000, seed=20260501, vary_tau=False):
     return d
 
 
-def ek60_device(C, P, S, seed=20260501, device=None, chunk_pings=20000):
+def ek60_device(C, P, S, seed=20260501, device=None, chunk_pings=20000, ping0=0):
     """Same recipe generated in HBM: returns dict of torch CUDA tensors (raw f32 + f64 params)."""
     import torch
 
@@ -94,7 +96,7 @@ def ek60_device(C, P, S, seed=20260501, device=None, chunk_pings=20000):
     nan_pings = torch.rand(P, generator=g, device=dev) < 0.10
     idx = torch.nonzero(nan_pings).flatten()
     raw[:, idx, S - tail:] = float("nan")
-    h = ek60_params(C, P)
+    h = ek60_params(C, P, ping0=ping0)
     out = {"backscatter_r": raw}
     for k in ("sample_interval", "transmit_duration_nominal", "transmit_power", "sound_speed_indicative",
               "absorption_indicative", "equivalent_beam_angle", "frequency_nominal", "pulse_length",

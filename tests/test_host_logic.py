@@ -454,3 +454,49 @@ def test_ek_depth_utils_match_the_reference_functions():
     scaling, dims = eku.ek_use_beam_angles(beam)
     assert dims == ("channel",)
     np.testing.assert_array_equal(scaling, g["ba_out"])
+
+
+# ---- a26: the > 2 GiB backscatter warning and the env_params / cal_params type check ---------------------------
+def test_check_echodata_backscatter_size_warning(caplog):
+    """tests/calibrate/test_calibrate.py:342-441 of the reference: the calibrator warns, with exactly this text, when
+    the backscatter variables exceed 2 GiB (calibrate_base.py:95-128).  The large array is a zero-stride broadcast
+    view: it reports 2.2 GiB without occupying them."""
+    import logging
+
+    import echopype_amd as ep
+    from echopype_amd.calibrate.api import CALIBRATOR
+
+    expected = (
+        "The Echodata backscatter variables are large and can cause memory issues. "
+        "Consider modifying the workflow that uses compute_Sv as below: "
+        "Prior to `compute_Sv` run `echodata.chunk(CHUNK_DICTIONARY) "
+        "and after `compute_Sv` run `ds_Sv.to_zarr(ZARR_STORE, compute=True)`. "
+        "This will ensure that the computation is lazily evaluated, "
+        "with the results stored directly in a Zarr store on disk, rather then in memory.")
+    for P, warns in ((300_000, True), (200, False)):
+        d = ep.synth.ek60_numpy(2, 4, 8)
+        for k, v in list(d.items()):
+            if isinstance(v, np.ndarray) and v.ndim == 2 and v.shape == (2, 4):
+                d[k] = np.repeat(v[:, :1], P, axis=1)
+        d["ping_time"] = ep.synth.T0 + (np.arange(P) * 1_000_000_000).astype("timedelta64[ns]")
+        d["backscatter_r"] = np.broadcast_to(np.float32(-70.0), (2, P, 1000))
+        assert (d["backscatter_r"].nbytes / 1024**3 > 2.0) == warns
+        cal = CALIBRATOR["EK60"](ep.echodata.from_ek60_arrays(d), env_params=None, cal_params=None, ecs_file=None)
+        caplog.clear()
+        with caplog.at_level(logging.WARNING, logger="echopype_amd.calibrate"):
+            cal._check_echodata_backscatter_size()
+        msgs = [r.message for r in caplog.records]
+        assert msgs == ([expected] if warns else [])
+
+
+@pytest.mark.parametrize("bad", ["env_params", "cal_params"])
+def test_env_and_cal_params_must_be_dicts(bad):
+    """calibrate_base.py:35-47: anything but None or a dict is rejected with the reference's message."""
+    import echopype_amd as ep
+    from echopype_amd.calibrate.api import CALIBRATOR
+
+    ed = ep.echodata.from_ek60_arrays(ep.synth.ek60_numpy(2, 5, 16))
+    kw = dict(env_params=None, cal_params=None, ecs_file=None)
+    kw[bad] = [("sound_speed", 1500.0)]
+    with pytest.raises(ValueError, match=f"'{bad}' has to be None or a dict"):
+        CALIBRATOR["EK60"](ed, **kw)
