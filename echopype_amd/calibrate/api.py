@@ -34,7 +34,7 @@ def check_input_args_combination(waveform_mode, encode_mode, pulse_compression=N
 
 def _compute_cal(cal_type, echodata, env_params=None, cal_params=None, ecs_file=None, waveform_mode=None,
                  encode_mode=None, assume_single_filter_time=None, drop_last_hanning_zero=False,
-                 dtype="float64", device=None):
+                 dtype="float64", device=None, fft_dtype=None):
     waveform_mode = "BB" if waveform_mode == "FM" else waveform_mode
     if echodata.sonar_model == "EK80":
         if waveform_mode is None or encode_mode is None:
@@ -56,7 +56,7 @@ def _compute_cal(cal_type, echodata, env_params=None, cal_params=None, ecs_file=
         cal_obj = CALIBRATOR[echodata.sonar_model](
             echodata, env_params=env_params, cal_params=cal_params, ecs_file=ecs_file,
             waveform_mode=waveform_mode, encode_mode=encode_mode, slice_dict=slice_dict,
-            drop_last_hanning_zero=drop_last_hanning_zero, dtype=dtype, device=device)
+            drop_last_hanning_zero=drop_last_hanning_zero, dtype=dtype, device=device, fft_dtype=fft_dtype)
         cal_obj._check_echodata_backscatter_size()
         return cal_obj.compute_Sv() if cal_type == "Sv" else cal_obj.compute_TS()
 
@@ -164,7 +164,10 @@ def _calibrate_filter_intervals(compute, cal_type, beam, vend, tau, pt, chans):
 def compute_Sv(echodata, **kwargs):
     """Volume backscattering strength Sv.  Same arguments as the reference (api.py:249-345):
     env_params, cal_params, ecs_file, waveform_mode, encode_mode, assume_single_filter_time,
-    drop_last_hanning_zero (+ dtype, device)."""
+    drop_last_hanning_zero (+ dtype, device; EK80 broadband: fft_dtype = arithmetic of the pulse-compression
+    transform, "float64" | "float32", default = dtype -- a complex64 transform is as precise as a float32 output,
+    with errors relative to the strongest echo of each 2048-sample tile; a float64 output always gets complex128
+    unless asked otherwise)."""
     return _compute_cal(cal_type="Sv", echodata=echodata, **kwargs)
 
 

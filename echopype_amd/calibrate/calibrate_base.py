@@ -61,6 +61,7 @@ class CalibrateBase(abc.ABC):
         self.range_meter = None
         self.dtype = ops.torch_dtype(kwargs.get("dtype", "float64"))
         self.device = kwargs.get("device")
+        self.fft_dtype = kwargs.get("fft_dtype")  # EK80 BB: arithmetic of the pulse-compression transform (None = dtype)
 
     @abc.abstractmethod
     def compute_echo_range(self, **kwargs):

@@ -331,8 +331,10 @@ class CalibrateEK80(CalibrateEK):
         """One fused pass for calibrate_ek.py:532-659 (+ ek80_complex.py:285-391 for BB)."""
         k, tau_eff = self._complex_inputs(cal_type)
         res = ops.sv_complex(k["re"], k["im"], k["ccoef"], replica=k["replica"], replica_off=k["replica_off"],
-                             max_taps=k["max_taps"], cal_type=cal_type, dtype=self.dtype)
-        return self._finish(cal_type, res["out"], res["echo_range"], tau_eff)
+                             max_taps=k["max_taps"], cal_type=cal_type, dtype=self.dtype, fft_dtype=self.fft_dtype,
+                             want_range_stats=True)
+        # {nanmin, nanmax, NaN count} of echo_range ride along (the FFT form leaves them as a by-product)
+        return self._finish(cal_type, res["out"], res["echo_range"], tau_eff, range_stats=res["range_stats"])
 
     def _compute_cal(self, cal_type):
         flag_complex = self.waveform_mode == "BB" or self.encode_mode == "complex"

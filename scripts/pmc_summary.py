@@ -18,7 +18,7 @@ for f in files:
             k = r["Kernel_Name"]
             if not any(s in k for s in subs) or k.startswith("void at::"):
                 continue
-            k = k.split("(")[0][-110:]
+            k = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-110:]
             acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
             meta[k] = (r["VGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"])
 print("kernel,Counter_Name,mean_value,dispatches,vgpr,lds,scratch")

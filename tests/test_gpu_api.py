@@ -15,6 +15,8 @@ import oracle_chain as oc
 from oracle import clean as oclean
 from oracle import commongrid as ogrid
 
+from bb_tolerance import assert_bb_close  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -136,21 +138,13 @@ def _ek80(ep, waveform, **kw):
 def test_compute_Sv_ek80_bb(ep, dtype, mixed):
     """BB pulse compression + Sv.  The reference's own output is complex64-rounded
     (ek80_complex.py:304), so parity is judged like the reference's tests do: in dB with an
-    absolute tolerance (test_calibrate_ek80_CW.py uses 2e-3...5.5e-3 dB), here 2e-4 dB for the f64
-    path and 2e-3 dB for f32, plus identical NaN patterns."""
+    absolute tolerance (test_calibrate_ek80_CW.py uses 2e-3...5.5e-3 dB), see tests/bb_tolerance.py, plus
+    identical NaN patterns."""
     d, filt = _ek80(ep, "BB", C=2, P=12, S=1200, mixed_nan=mixed)
     ed = ep.echodata.from_ek80_arrays(d, filt)
     ds = ep.calibrate.compute_Sv(ed, waveform_mode="BB", encode_mode="complex", dtype=dtype)
     (exp, exp_r, prx), teff = oc.ek80_complex(d, filt, "Sv")
-    got = ds["Sv"].values.astype(np.float64)
-    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
-    fin = np.isfinite(exp)
-    # samples more than 60 dB below the ping's peak sit at the reference's own float32 noise floor
-    peak = np.nanmax(np.where(fin, exp, -np.inf), axis=2, keepdims=True)
-    strong = fin & (exp > peak - 60)
-    atol = 2e-4 if dtype == "float64" else 2e-3
-    assert np.abs(got[strong] - exp[strong]).max() < atol
-    assert np.abs(got[fin] - exp[fin]).max() < 0.5
+    assert_bb_close(ds["Sv"].values, exp, dtype)
     np.testing.assert_allclose(ds["tau_effective"].values, teff, rtol=1e-12)
     if dtype == "float64":
         np.testing.assert_array_equal(ds["echo_range"].values, exp_r)
