@@ -468,11 +468,11 @@ def run_cfg5(ctx, cpu):
     def layout(offset_ns):
         """Time grid + exchange plan for ping times shifted by ``offset_ns`` against the 20-s grid."""
         info = []
-        for d in tiles:
-            t = d["ping_time_ns"] + offset_ns
-            tn = t.cpu().numpy()
-            e0, _ = sharding.global_time_grid(tn, bin_ns)
-            f, l = sharding.local_bin_span(tn, e0, bin_ns)
+        ts = [d["ping_time_ns"] + offset_ns for d in tiles]
+        ends = np.array([int(x) for t in ts for x in (t[0], t[-1])], dtype=np.int64)
+        e0, _ = sharding.global_time_grid(ends, bin_ns)  # ONE grid for every tile of every rank
+        for t in ts:
+            f, l = sharding.local_bin_span(t[[0, -1]].cpu().numpy(), e0, bin_ns)
             info.append((t, e0 + f * bin_ns, f, l, l - f + 1))
         plan = sharding.EdgeExchange([(f, l) for _, _, f, l, _ in info], C, n_r, "cuda")
         mv = [torch.empty((C, n, n_r), dtype=dt, device="cuda") for *_, n in info]

@@ -2,7 +2,7 @@
 # one GPU call: the whole -m gpu suite, the default bench (all lines), a 2-rank single-GPU dry run of the N>1 path
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/full; mkdir -p $O
-python -m pytest tests -q -m gpu -x 2>&1 | tail -25 > $O/tests.txt; cat $O/tests.txt
+python -m pytest tests -q -m gpu 2>&1 | tail -40 > $O/tests.txt; cat $O/tests.txt
 python bench.py > $O/bench_default.jsonl 2> $O/bench_default.err; tail -c 600 $O/bench_default.err
 python - <<'PY'
 import json

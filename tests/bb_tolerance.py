@@ -6,7 +6,8 @@ absolute tolerances of 2e-3 ... 5.5e-3 dB (test_calibrate_ek80_CW / _BB).  Here:
   float32 output (complex64 transform, whose error is relative to the strongest echo of the 2048-sample tile, not to
       the sample): 2e-3 dB within 40 dB of the ping's peak, and the north-star's fp32 tolerance -- 1e-3 relative on the
       dB value -- within 60 dB;
-  everything finite: 0.5 dB (samples at the reference's own float32 noise floor)."""
+  everything finite (float64) / within 90 dB of the ping's peak (float32: a complex64 transform has a noise floor
+      about 120 dB below the tile's strongest echo): 0.5 dB (samples at the reference's own float32 noise floor)."""
 import numpy as np
 
 
@@ -23,4 +24,4 @@ def assert_bb_close(got, exp, dtype):
         assert err[within(40)].max() < 2e-3
         s = within(60)
         assert (err[s] / np.maximum(np.abs(exp[s]), 1.0)).max() < 1e-3
-    assert err[fin].max() < 0.5
+    assert err[fin if str(dtype) == "float64" else within(90)].max() < 0.5
