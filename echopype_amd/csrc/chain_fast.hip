@@ -91,6 +91,7 @@ struct ColBase {
   double sra;  // fl(s * ra)
   T nL;        // n * log10(s - d)        spreading (TVG-shifted range)
   T lgs;       // log10(s - d_tl)         transmission loss (unshifted range)
+  T c2;        // (s - d)^(n/10)          the spreading term in the linear domain; 0 where s - d <= 0
 };
 
 // echo_range, R', Sv of one sample -- as process_sample of fused_sv_mvbs.hip
@@ -125,6 +126,40 @@ __device__ __forceinline__ void fill_ping_logs(T* plog, const epa::CoefRow* __re
     plog[i] = log10_pos((T)(rows[i].ra * rows[i].rb), log_tab);
 }
 
+// Pass 2 in fp64 forms the LINEAR values as products instead of exponentials of sums (the kernel is bound by VALU
+// issue, two exp10 + one log10 per sample; this leaves one exp10 + one log10):
+//   10^(Sv/10)       = 10^(g raw/10) . (s - d)^(n/10) . 10^((A0 - a2 shift + a2 r0)/10) . E(s)
+//   10^(Sv_noise/10) = 10^((noise + a2 r0)/10) . (R >= 1 ? R^2 : 1) . E(s)
+//   E(s) = 10^(a2 k s / 10),  k = ra rb                      (absorption over the unshifted range k s)
+// E is a geometric progression along the range: the lane evaluates it once per ping at its first column and
+// reaches its other three columns (s + 1, s + 128, s + 129) with the per-ping ratios q1, q128, q129.  The per-ping
+// constants come from LDS, one ping per lane (fill_ping_consts), like the log10(k) table.
+struct PingConst {
+  double a2k;   // a2 * k                       [dB per sample index]; a2 = the noise removal's 2 alpha
+  double da2k;  // (a2 of the calibration - a2) * k: 0 unless the caller passed two different absorptions
+  double q1, q128, q129;
+  double csv;   // 10^((A0 - a2 shift + a2 r0)/10)
+  double cn;    // 10^((noise of the ping's block + a2 r0)/10)
+};
+__device__ __forceinline__ PingConst ping_const(const epa::CoefRow& r, double na2, double nb, const double* exp2_tab) {
+  PingConst c;
+  const double k = r.ra * r.rb;
+  c.a2k = na2 * k;
+  c.da2k = (r.alpha2 - na2) * k;
+  c.q1 = epa::lin_from_db(c.a2k, exp2_tab);
+  c.q128 = epa::lin_from_db(128.0 * c.a2k, exp2_tab);
+  c.q129 = c.q1 * c.q128;
+  c.csv = epa::lin_from_db(r.A0 - r.alpha2 * r.shift + r.alpha2 * r.r0, exp2_tab);
+  c.cn = epa::lin_from_db(nb + na2 * r.r0, exp2_tab);
+  return c;
+}
+__device__ __forceinline__ void fill_ping_consts(PingConst* pc, const epa::CoefRow* __restrict__ rows,
+                                                 const double* __restrict__ a2, const double* __restrict__ noise,
+                                                 int p0, int n, int ping_num, const double* exp2_tab) {
+  for (int i = threadIdx.x; i < min(n, kPingLogs); i += epa::kBlock)
+    pc[i] = ping_const(rows[i], a2[i], noise[(p0 + i) / ping_num], exp2_tab);
+}
+
 // refresh of the cached column logs when the row constants they depend on change (uniform branch; once
 // per column for a file with constant pulse length / sample interval / sound speed)
 template <typename T>
@@ -142,6 +177,8 @@ struct RowCache {
         const double sj = (double)((j < 2 ? sA : sB) + (j & 1));
         col[j].nL = nspread * log10_exact<T>((T)(sj - r.d));
         col[j].sra = sj * r.ra;
+        const T v = (T)(sj - r.d), v2 = v * v;
+        col[j].c2 = v > (T)0 ? (nspread == (T)20 ? v2 : v2 * v2) : (T)0;
       }
     }
     const double k = r.ra * r.rb;
@@ -208,7 +245,7 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
     NoiseCol<T> col[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      col[j].sra = 0.0; col[j].nL = epa::M<T>::nan(); col[j].lgs = (T)0;
+      col[j].sra = 0.0; col[j].nL = epa::M<T>::nan(); col[j].lgs = (T)0; col[j].c2 = (T)0;
       col[j].acc_sum = (T)0; col[j].acc_cnt = 0u;
     }
     RowCache<T> rc;
@@ -348,12 +385,15 @@ __global__ __launch_bounds__(epa::kBlock, 3) void sv_denoise_mvbs_fast_kernel(
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double mm[4] = {__builtin_inf(), -__builtin_inf(), __builtin_inf(), -__builtin_inf()};
   __shared__ T plog[kPingLogs];
+  constexpr bool kProd = sizeof(T) == 8;  // linear values as products (see PingConst); fp32 keeps the exponentials
+  __shared__ PingConst pcs[kProd ? kPingLogs : 1];
 
   for (int seg = 0; seg < nseg; ++seg) {
   const int pb = extra ? (seg == 0 ? 0 : bin_start[a.n_tbins]) : bin_start[tb];
   const int pe = extra ? (seg == 0 ? bin_start[0] : a.P) : bin_start[tb + 1];
   __syncthreads();  // all wavefronts are done with the previous segment's logs
   fill_ping_logs<T>(plog, rowp0 + pb, pe - pb, mt.log_tab);
+  if (kProd) fill_ping_consts(pcs, rowp0 + pb, a2p + pb, nzp, pb, pe - pb, a.noise_ping_num, mt.exp2_tab);
   __syncthreads();
   for (int chunk0 = 0; chunk0 < S; chunk0 += kChunk) {
     const int sA = chunk0 + wave * 256 + 2 * lane, sB = sA + 128;
@@ -362,7 +402,7 @@ __global__ __launch_bounds__(epa::kBlock, 3) void sv_denoise_mvbs_fast_kernel(
     BinCol<T> col[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      col[j].sra = 0.0; col[j].nL = epa::M<T>::nan(); col[j].lgs = (T)0;
+      col[j].sra = 0.0; col[j].nL = epa::M<T>::nan(); col[j].lgs = (T)0; col[j].c2 = (T)0;
       col[j].blo = 1.0; col[j].bhi = 0.0; col[j].acc_sum = (T)0; col[j].acc_rb = -1; col[j].acc_cnt = 0u;
     }
     RowCache<T> rc;
@@ -388,16 +428,43 @@ __global__ __launch_bounds__(epa::kBlock, 3) void sv_denoise_mvbs_fast_kernel(
       const T nb = (T)nzp[p / a.noise_ping_num];
       const float in[VEC] = {inA.x, inA.y, inB.x, inB.y};
       T sn[VEC], sc[VEC];
+      // product form (fp64): per-ping constants, E at the lane's first column, ratios to the other three
+      PingConst pc{};
+      T ecol[VEC] = {};
+      if constexpr (kProd) {
+        pc = (p - pb) < kPingLogs ? pcs[p - pb] : ping_const(r, (double)na2, (double)nb, mt.exp2_tab);
+        const T e0 = (T)epa::lin_from_db(pc.a2k * (double)sA, mt.exp2_tab);
+        ecol[0] = e0; ecol[1] = e0 * (T)pc.q1; ecol[2] = e0 * (T)pc.q128; ecol[3] = e0 * (T)pc.q129;
+      }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         if (j >= 2 && !hasB) break;
         BinCol<T>& cj = col[j];
         double x;
-        const T sv = calibrate<T>(cj, in[j], r, g, a2, A0, nspread, x, mt.log_tab);
         const bool xok = in[j] == in[j];
-        const T xr = xok ? (T)x : epa::M<T>::nan();  // echo_range is NaN where the input is
-        sn[j] = nb + transmission_loss<T>(cj, xr, rc.log10k, na2);
-        const T lin = epa::lin_from_db(sv, mt.exp2_tab) - epa::lin_from_db(sn[j], mt.exp2_tab);
+        T lin;
+        if constexpr (kProd) {
+          x = cj.sra * r.rb + r.r0;
+          const double rtd = x - r.shift;  // R' <= 0 -> NaN (calibrate_ek.py:107)
+          T c2 = cj.c2;
+          if ((rtd > 0.0) & !(c2 > (T)0)) {  // rounding residue of R - shift (rare): the range itself
+            const T v = (T)(rtd / (r.ra * r.rb)), v2 = v * v;
+            c2 = nspread == (T)20 ? v2 : v2 * v2;
+          }
+          c2 = rtd > 0.0 ? c2 : epa::M<T>::nan();
+          const T xr = xok ? (T)x : epa::M<T>::nan();  // echo_range is NaN where the input is
+          sn[j] = nb + transmission_loss<T>(cj, xr, rc.log10k, na2);
+          const T xx = xr >= (T)1 ? xr * xr : (xok ? (T)1 : epa::M<T>::nan());
+          T lsv = epa::lin_from_db(g * (T)in[j], mt.exp2_tab) * (c2 * (T)pc.csv);
+          if (pc.da2k != 0.0)  // (uniform, never through the Dataset API) the calibration used another absorption
+            lsv *= (T)epa::lin_from_db(pc.da2k * (double)((j < 2 ? sA : sB) + (j & 1)), mt.exp2_tab);
+          lin = ecol[j] * (lsv - (T)pc.cn * xx);
+        } else {
+          const T sv = calibrate<T>(cj, in[j], r, g, a2, A0, nspread, x, mt.log_tab);
+          const T xr = xok ? (T)x : epa::M<T>::nan();  // echo_range is NaN where the input is
+          sn[j] = nb + transmission_loss<T>(cj, xr, rc.log10k, na2);
+          lin = epa::lin_from_db(sv, mt.exp2_tab) - epa::lin_from_db(sn[j], mt.exp2_tab);
+        }
         const T corr = lin > (T)0 ? (T)10 * log10_lin(lin, mt.log_tab) : epa::M<T>::nan();
         const bool keep = corr - sn[j] > snr;
         sc[j] = keep ? corr : epa::M<T>::nan();

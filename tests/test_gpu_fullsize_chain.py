@@ -130,9 +130,11 @@ def test_chain_fp32_vs_fp64_on_the_corrected_output(chain):
         diff = ((a[c] - b[c].double()).abs() / a[c].abs().clamp_min(1.0))
         worst = max(worst, float(torch.where(both, diff, torch.zeros_like(diff)).max()))
     assert worst < 1e-3, worst
-    assert flips / total < 1e-5, (flips, total)
+    # a flip needs corr - Sv_noise within float32 rounding (~1e-4 dB) of the 3 dB threshold: a few per million
+    assert flips / total < 1e-4, (flips, total)
     m64, m32 = chain["f64"]["MVBS"], chain["f32"]["MVBS"].double()
-    assert bool((torch.isnan(m64) == torch.isnan(m32)).all())
+    # a cell whose only surviving sample flipped may appear / vanish: a handful among 39 M cells
+    assert int((torch.isnan(m64) != torch.isnan(m32)).sum().item()) < 1e-5 * m64.numel()
     assert float(torch.nan_to_num((m64 - m32).abs() / m64.abs().clamp_min(1.0)).max()) < 1e-3
 
 
@@ -152,15 +154,24 @@ def bb():
         n = min(4000, P - p0)
         for t in (re, im):
             t[:, p0:p0 + n] = torch.randn((C, n, S, B), generator=g, device="cuda", dtype=torch.float32) * 1e-3
-    layer = (torch.arange(P, device="cuda") * 7) % (S - 400) + 100
-    idx = layer[:, None] + torch.arange(40, device="cuda")[None, :]
+    filt, par = synth.ek80_filters(), synth.EK80_BB
+    reps = [oek.transmit_replica(1.5e6, par["tau"][c], 0.05, par["f_start"][c], par["f_stop"][c], filt)[0] for c in range(C)]
+    # a strong replica-shaped echo (a sea-floor return) that wanders with the ping: ~60 dB above the noise after
+    # compression, inside one tile with it
+    layer = (torch.arange(P, device="cuda") * 7) % (S - 600) + 100
+    ar = torch.arange(P, device="cuda")[:, None]
     for c in range(C):
-        re[c, torch.arange(P, device="cuda")[:, None], idx] += 1.0
+        m = reps[c].size
+        idx = layer[:, None] + torch.arange(m, device="cuda")[None, :]
+        rr = torch.from_numpy(np.ascontiguousarray(reps[c].real, dtype=np.float32)).cuda()
+        ri = torch.from_numpy(np.ascontiguousarray(reps[c].imag, dtype=np.float32)).cuda()
+        amp = 1.0 / float(np.linalg.norm(reps[c]))  # compressed peak = amp, noise floor = 1e-3 / ||tx||: 60 dB
+        for b in range(B):
+            re[c, ar, idx, b] += amp * rr[None, :]
+            im[c, ar, idx, b] += amp * ri[None, :]
     nan_pings = torch.rand(P, generator=g, device="cuda") < 0.10
     re[:, nan_pings, S - 410:] = float("nan")
     im[:, nan_pings, S - 410:] = float("nan")
-    filt, par = synth.ek80_filters(), synth.EK80_BB
-    reps = [oek.transmit_replica(1.5e6, par["tau"][c], 0.05, par["f_start"][c], par["f_stop"][c], filt)[0] for c in range(C)]
     rep = np.concatenate(reps).astype(np.complex64)
     repf = torch.from_numpy(np.ascontiguousarray(rep.view(np.float32))).cuda()
     off = torch.from_numpy(np.cumsum([0] + [r.size for r in reps]).astype(np.int32)).cuda()
