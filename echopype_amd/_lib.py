@@ -70,6 +70,7 @@ SIGNATURES = {
     "epa_timer_elapsed_ms": [_vp, ctypes.POINTER(ctypes.c_float)],
     "epa_power_coef_ek": [_i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp,
                           _vp, _vp, _i, _i, _vp, _vp],
+    "epa_pulse_table_lookup": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "epa_sv_power": [_vp, _vp, _i, _i, _i, _i, _u, _vp, _vp, _i, _vp],
     "epa_sv_power_stats": [_vp, _vp, _i, _i, _i, _i, _u, _vp, _vp, _i, _vp, _vp, _vp],
     "epa_time_bin_offsets": [_vp, _i, _i64, _i64, _i, _u, _vp, _vp],

@@ -7,7 +7,7 @@ Mirrors /root/reference/echopype/calibrate/cal_params.py: CAL_PARAMS / EK80_DEFA
 """
 import numpy as np
 
-from ..xr_lite import DataArray
+from ..xr_lite import DataArray, DeviceArray
 
 CAL_PARAMS = {
     "EK60": ("sa_correction", "gain_correction", "equivalent_beam_angle", "angle_offset_alongship",
@@ -39,21 +39,64 @@ _BEAM_NAME = {
 }
 
 
-def get_vend_cal_params_power(beam, vend, param):
-    """argmin_k |transmit_duration_nominal - pulse_length[c,k]| lookup -> (C, P) array."""
-    if param not in ("sa_correction", "gain_correction"):
-        raise ValueError(f"Unknown parameter {param}")
-    if param not in vend:
-        raise ValueError(f"{param} does not exist in the Vendor_specific group!")
-    tau = np.asarray(beam["transmit_duration_nominal"].values, dtype=np.float64)
-    if beam["transmit_duration_nominal"].dims[0] != "channel":
-        tau = tau.T
-    pl = np.asarray(vend["pulse_length"].values, dtype=np.float64)
-    tab = np.asarray(vend[param].values, dtype=np.float64)
-    bch, vch = list(map(str, beam["channel"].values)), list(map(str, vend["channel"].values))
-    if bch != vch:  # channel order differs between Vendor_specific and the beam group (:302-305)
-        order = [vch.index(c) for c in bch]
-        pl, tab = pl[order], tab[order]
+class PulseTableParam(DataArray):
+    """gain_correction / sa_correction as the reference returns them -- a (channel, ping_time) array looked up per ping
+    in the Vendor_specific pulse-length table (cal_params.py:261-324) -- but LAZY: the calibrator hands the (C, K)
+    table itself to the coefficient kernel (epa_power_coef_ek, EPA_PM_PULSE_TABLE), so the (C, P) array only comes
+    into being when somebody reads it (``.values``, or the output dataset: one small kernel when the per-ping
+    parameters live in HBM, the run-length NumPy evaluation otherwise)."""
+
+    def __init__(self, tau_da, pl, tab, name):
+        self._tau, self.pulse_length, self.table = tau_da, pl, tab
+        self._data = None
+        shape = tau_da.shape if tau_da.dims[0] == "channel" else tau_da.shape[::-1]
+        self._shape = tuple(shape)
+        self.dims = ("channel", "ping_time")
+        from collections import OrderedDict
+
+        self.coords = OrderedDict()
+        self.attrs = {}
+        self.name = name
+
+    @property
+    def materialized(self):
+        return self._data is not None
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def ndim(self):
+        return 2
+
+    @property
+    def dtype(self):
+        return np.dtype(np.float64)
+
+    @property
+    def data(self):
+        if self._data is None:
+            tau = self._tau.data
+            if isinstance(tau, DeviceArray) and self._tau.dims[0] == "channel":
+                import torch
+
+                from .. import ops
+
+                t = tau.tensor if tau.tensor.dtype == torch.float64 else tau.tensor.double()
+                dev = lambda a: ops.to_device(np.ascontiguousarray(a, dtype=np.float64), device=t.device)  # noqa: E731
+                self._data = DeviceArray(ops.pulse_table_lookup(t.contiguous(), dev(self.pulse_length), dev(self.table)))
+            else:
+                self._data = _lookup_host(np.asarray(self._tau.values, dtype=np.float64) if self._tau.dims[0] == "channel"
+                                          else np.asarray(self._tau.values, dtype=np.float64).T, self.pulse_length, self.table)
+        return self._data
+
+    @data.setter
+    def data(self, v):
+        self._data = v
+
+
+def _lookup_host(tau, pl, tab):
     # The pulse length is piecewise constant along ping_time (usually constant): the (C, P, K) distance table of the
     # reference is evaluated only where some channel's tau changes, then repeated over the run -- same values,
     # O(C P) instead of O(C P K) temporaries (0.1 s per call at 4 x 500 000 pings otherwise).
@@ -70,9 +113,23 @@ def get_vend_cal_params_power(beam, vend, param):
     diff = np.where(np.isnan(diff), np.inf, diff)
     idx = np.argmin(diff, axis=2)
     out_u = np.where(isnull, np.nan, np.take_along_axis(tab, idx, axis=1))
-    out = np.repeat(out_u, np.diff(np.concatenate([starts, [P]])), axis=1) if starts.size > 1 else \
+    return np.repeat(out_u, np.diff(np.concatenate([starts, [P]])), axis=1) if starts.size > 1 else \
         np.repeat(out_u, P, axis=1)
-    return DataArray(out, ("channel", "ping_time"))
+
+
+def get_vend_cal_params_power(beam, vend, param):
+    """argmin_k |transmit_duration_nominal - pulse_length[c,k]| lookup -> (C, P) array (lazy, see PulseTableParam)."""
+    if param not in ("sa_correction", "gain_correction"):
+        raise ValueError(f"Unknown parameter {param}")
+    if param not in vend:
+        raise ValueError(f"{param} does not exist in the Vendor_specific group!")
+    pl = np.asarray(vend["pulse_length"].values, dtype=np.float64)
+    tab = np.asarray(vend[param].values, dtype=np.float64)
+    bch, vch = list(map(str, beam["channel"].values)), list(map(str, vend["channel"].values))
+    if bch != vch:  # channel order differs between Vendor_specific and the beam group (:302-305)
+        order = [vch.index(c) for c in bch]
+        pl, tab = pl[order], tab[order]
+    return PulseTableParam(beam["transmit_duration_nominal"], pl, tab, param)
 
 
 def sanitize_user_cal_dict(sonar_type, user_dict, channel):

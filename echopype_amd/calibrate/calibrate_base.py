@@ -121,6 +121,15 @@ class CalibrateBase(abc.ABC):
             )
 
     # ---- device helpers -------------------------------------------------------------------------
+    def _cp_dev(self, v, C, P, name, dtype=None):
+        """A per-(channel, ping) parameter as a contiguous (C, P) device tensor: straight from HBM when it already
+        lives there in that shape (EchoData.to_device), through cp_array + one upload otherwise."""
+        d = v.data if isinstance(v, DataArray) else None
+        if isinstance(d, DeviceArray) and tuple(v.dims) == ("channel", "ping_time") and d.shape == (C, P):
+            t = d.tensor
+            return (t if dtype is None or t.dtype == dtype else t.to(dtype)).contiguous()
+        return self._dev(cp_array(v, C, P, name), dtype)
+
     def _dev(self, a, dtype=None):
         if isinstance(a, DeviceArray):
             t = a.tensor

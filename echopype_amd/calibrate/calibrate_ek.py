@@ -13,8 +13,8 @@ import torch
 
 from .. import _lib, ops
 from ..echodata import BEAM1
-from ..xr_lite import DataArray, Dataset
-from .cal_params import get_cal_params_EK
+from ..xr_lite import DataArray, Dataset, DeviceArray
+from .cal_params import PulseTableParam, get_cal_params_EK
 from .calibrate_base import ECHO_DIMS, CalibrateBase, cp_array
 from .ek80_complex import get_filter_coeff, get_tau_effective, get_transmit_signal
 from .env_params import get_env_params_EK
@@ -123,7 +123,11 @@ class CalibrateEK(CalibrateBase):
 
     def _tau_effective(self, flag_complex):
         """Effective pulse length per channel (calibrate_ek.py:113-151 / :583-607)."""
-        tau_nom0 = np.asarray(self._cp(self.beam["transmit_duration_nominal"], "transmit_duration_nominal"))[:, 0]
+        tdn = self.beam["transmit_duration_nominal"]
+        if isinstance(tdn.data, DeviceArray) and tuple(tdn.dims) == ("channel", "ping_time"):
+            tau_nom0 = tdn.data.tensor[:, 0].double().cpu().numpy()  # C values
+        else:
+            tau_nom0 = np.asarray(self._cp(tdn, "transmit_duration_nominal"))[:, 0]
         if getattr(self, "tau_nominal_first_ping", None) is not None:  # a ping shard: ping 0 of the WHOLE file
             tau_nom0 = np.asarray(self.tau_nominal_first_ping, dtype=np.float64).reshape(tau_nom0.shape)
         try:
@@ -165,19 +169,32 @@ class CalibrateEK(CalibrateBase):
         gpt = self._gpt_mask()
         psi = np.asarray(self.cal_params["equivalent_beam_angle"].values, dtype=np.float64)
         if psi.ndim > 1:
-            psi = psi.reshape(C, -1)[:, 0]
+            psi = psi.reshape(C, -1)
+            if not np.all((psi == psi[:, :1]) | np.isnan(psi)):
+                raise NotImplementedError("equivalent_beam_angle varying along ping_time is not supported for power "
+                                          "samples (the coefficient kernel takes one value per channel)")
+            psi = psi[:, 0]
+        cpd = lambda v, name: self._cp_dev(v, C, P, name, f64)  # noqa: E731
+        # gain / sa_correction straight from the Vendor_specific pulse-length tables: looked up per ping by the kernel
+        g, sa = self.cal_params["gain_correction"], self.cal_params["sa_correction"]
+        tables = (isinstance(g, PulseTableParam) and isinstance(sa, PulseTableParam) and not g.materialized
+                  and not sa.materialized and np.array_equal(g.pulse_length, sa.pulse_length, equal_nan=True))
+        if tables:
+            kw = dict(pulse_length=self._dev(g.pulse_length, f64), gain_is_table=True, sa_is_table=True)
+            g_t, sa_t = self._dev(g.table, f64), self._dev(sa.table, f64)
+        else:
+            kw = {}
+            g_t, sa_t = cpd(g, "gain_correction"), cpd(sa, "sa_correction")
         coef = ops.power_coef_ek(
-            self._dev(self._cp(self.beam["sample_interval"], "sample_interval"), f64),
-            self._dev(self._cp(self.beam["transmit_duration_nominal"], "transmit_duration_nominal"), f64),
-            self._dev(self._cp(self.beam["transmit_power"], "transmit_power"), f64),
-            self._dev(self._cp(self.env_params["sound_speed"], "sound_speed"), f64),
-            self._dev(self._cp(self.env_params["sound_absorption"], "sound_absorption"), f64),
-            self._dev(self._cp(self.cal_params["gain_correction"], "gain_correction"), f64),
-            self._dev(self._cp(self.cal_params["sa_correction"], "sa_correction"), f64),
-            self._dev(psi, f64), self._dev(np.asarray(self.beam["frequency_nominal"].values, float), f64),
+            cpd(self.beam["sample_interval"], "sample_interval"),
+            cpd(self.beam["transmit_duration_nominal"], "transmit_duration_nominal"),
+            cpd(self.beam["transmit_power"], "transmit_power"),
+            cpd(self.env_params["sound_speed"], "sound_speed"),
+            cpd(self.env_params["sound_absorption"], "sound_absorption"),
+            g_t, sa_t, self._dev(psi, f64), self._dev(np.asarray(self.beam["frequency_nominal"].values, float), f64),
             self._dev(np.asarray(tau_eff, float), f64),
             sonar=self.sonar_type, cal_type=cal_type,
-            gpt=self._dev(gpt.astype(np.uint8)) if self.sonar_type == "EK80" else None)
+            gpt=self._dev(gpt.astype(np.uint8)) if self.sonar_type == "EK80" else None, **kw)
         raw = self._dev(self.beam["backscatter_r"].data, torch.float32)
         return raw, coef, _lib.FLAG_GUARD_POS | _lib.FLAG_MASK_RANGE, tau_eff
 

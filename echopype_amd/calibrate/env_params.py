@@ -11,7 +11,7 @@ Parameters are plain numpy values of shape (), (C,) or (C, P).
 import numpy as np
 
 from ..utils import uwa
-from ..xr_lite import DataArray
+from ..xr_lite import DataArray, DeviceArray
 
 ENV_PARAMS = ("sound_speed", "sound_absorption", "temperature", "salinity", "pressure", "pH",
               "formula_sound_speed", "formula_absorption")
@@ -31,6 +31,19 @@ def harmonize_env_param_time(p, ping_time=None):
     """Bring a parameter with a ``time1`` dimension onto ``ping_time``; anything else passes through."""
     if not isinstance(p, DataArray) or "time1" not in p.dims:
         return p
+    if isinstance(p.data, DeviceArray):  # per-ping parameters resident in HBM (EchoData.to_device)
+        t1 = np.asarray(p.coords["time1"]) if "time1" in p.coords else None
+        pt = None if ping_time is None else np.asarray(getattr(ping_time, "values", ping_time))
+        dims = tuple("ping_time" if d == "time1" else d for d in p.dims)
+        if p.sizes["time1"] == 1:
+            ax1 = p.dims.index("time1")
+            return DataArray(DeviceArray(p.data.tensor.select(ax1, 0).contiguous()), tuple(d for d in p.dims if d != "time1"),
+                             {d: p.coords[d] for d in p.dims if d != "time1" and d in p.coords})
+        if t1 is not None and pt is not None and t1.shape == pt.shape and np.array_equal(t1, pt):
+            coords = {d: p.coords[d] for d in p.dims if d != "time1" and d in p.coords}
+            coords["ping_time"] = pt
+            return DataArray(p.data, dims, coords)
+        p = DataArray(np.asarray(p.values), p.dims, p.coords, p.attrs, p.name)  # anything else: the host path
     ax = p.dims.index("time1")
     vals = np.moveaxis(np.asarray(p.values, dtype=np.float64), ax, -1)
     dims = tuple(d for d in p.dims if d != "time1")

@@ -433,7 +433,7 @@ __global__ __launch_bounds__(epa::kBlock, 3) void sv_denoise_mvbs_fast_kernel(
       T ecol[VEC] = {};
       if constexpr (kProd) {
         pc = (p - pb) < kPingLogs ? pcs[p - pb] : ping_const(r, (double)na2, (double)nb, mt.exp2_tab);
-        const T e0 = (T)epa::lin_from_db(pc.a2k * (double)sA, mt.exp2_tab);
+        const T e0 = (T)epa::lin_from_db_lean(pc.a2k * (double)sA, mt.exp2_tab);
         ecol[0] = e0; ecol[1] = e0 * (T)pc.q1; ecol[2] = e0 * (T)pc.q128; ecol[3] = e0 * (T)pc.q129;
       }
 #pragma unroll
@@ -454,10 +454,11 @@ __global__ __launch_bounds__(epa::kBlock, 3) void sv_denoise_mvbs_fast_kernel(
           c2 = rtd > 0.0 ? c2 : epa::M<T>::nan();
           const T xr = xok ? (T)x : epa::M<T>::nan();  // echo_range is NaN where the input is
           sn[j] = nb + transmission_loss<T>(cj, xr, rc.log10k, na2);
-          const T xx = xr >= (T)1 ? xr * xr : (xok ? (T)1 : epa::M<T>::nan());
-          T lsv = epa::lin_from_db(g * (T)in[j], mt.exp2_tab) * (c2 * (T)pc.csv);
+          // (R >= 1 ? R^2 : 1); a NaN sample needs no masking here: it makes lsv, hence lin, NaN by itself
+          const T mx = fmax((T)x, (T)1), xx = mx * mx;
+          T lsv = epa::lin_from_db_lean(g * (T)in[j], mt.exp2_tab) * (c2 * (T)pc.csv);
           if (pc.da2k != 0.0)  // (uniform, never through the Dataset API) the calibration used another absorption
-            lsv *= (T)epa::lin_from_db(pc.da2k * (double)((j < 2 ? sA : sB) + (j & 1)), mt.exp2_tab);
+            lsv *= (T)epa::lin_from_db_lean(pc.da2k * (double)((j < 2 ? sA : sB) + (j & 1)), mt.exp2_tab);
           lin = ecol[j] * (lsv - (T)pc.cn * xx);
         } else {
           const T sv = calibrate<T>(cj, in[j], r, g, a2, A0, nspread, x, mt.log_tab);
@@ -465,7 +466,8 @@ __global__ __launch_bounds__(epa::kBlock, 3) void sv_denoise_mvbs_fast_kernel(
           sn[j] = nb + transmission_loss<T>(cj, xr, rc.log10k, na2);
           lin = epa::lin_from_db(sv, mt.exp2_tab) - epa::lin_from_db(sn[j], mt.exp2_tab);
         }
-        const T corr = lin > (T)0 ? (T)10 * log10_lin(lin, mt.log_tab) : epa::M<T>::nan();
+        const T corr = lin > (T)0 ? (T)10 * (kProd ? epa::fast_log10_lean(lin, mt.log_tab) : log10_lin(lin, mt.log_tab))
+                                  : epa::M<T>::nan();
         const bool keep = corr - sn[j] > snr;
         sc[j] = keep ? corr : epa::M<T>::nan();
         if (MINMAX) {  // fmin / fmax ignore NaN operands

@@ -398,16 +398,30 @@ __device__ __forceinline__ void load_sample(const InT* __restrict__ re, const In
           vi[q * kPer + e] = ti[e];
         }
       }
+      // the usual sample holds 2 NB numbers: their sum is then a number too, and no per-sector test is needed
+      F fr = (F)vr[0], fi = (F)vi[0];
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const bool ok = (vr[b] == vr[b]) && (vi[b] == vi[b]);
-        if (ok) {
-          m |= 1u << b;
-          if (only < 0 || only == b) {
-            sr += (F)vr[b];
-            si += (F)vi[b];
+      for (int b = 1; b < NB; ++b) {
+        fr += (F)vr[b];
+        fi += (F)vi[b];
+      }
+      if (__builtin_expect(only < 0 && fr == fr && fi == fi, 1)) {
+        sr = fr;
+        si = fi;
+        m = ((1u << NB) - 1u) | 0x100u;
+      } else {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const bool ok = (vr[b] == vr[b]) && (vi[b] == vi[b]);
+          if (ok) {
+            m |= 1u << b;
+            if (only < 0 || only == b) {
+              sr += (F)vr[b];
+              si += (F)vi[b];
+            }
           }
         }
+        if (vr[0] == vr[0]) m |= 0x100u;
       }
       if (vr[0] == vr[0]) m |= 0x100u;
     } else {
@@ -566,6 +580,7 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
   const T pscale = (T)(cc[EPA_CC_PSCALE]);
   const T nspread = (T)a.nspread;
   const double inv_norm = 1.0 / chan[0];
+  const double inv_norm_b = inv_norm / (double)B;  // every sector valid (the only case of the fast form)
   T* out = reinterpret_cast<T*>(a.out);
   T* range_out = reinterpret_cast<T*>(a.range_out);
   T* prx_out = reinterpret_cast<T*>(a.prx_out);
@@ -582,7 +597,7 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
       if (nvalid == 0u) {
         mr = mi = epa::M<T>::nan();
       } else {
-        const double invn = inv_norm / (double)nvalid;
+        const double invn = MIXED ? inv_norm / (double)nvalid : inv_norm_b;
         mr = (T)((double)yi.re * invn);
         mi = (T)((double)yi.im * invn);
       }
@@ -591,8 +606,9 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
       const double R = ((double)s * ra) * rb;  // range.py:138 operation order
       T rt = sub_rn((T)R, shift);              // never contracted with the range product into an fma
       if (!(rt > (T)0)) rt = epa::M<T>::nan();
-      const T val =
-          (T)10 * epa::fast_log10(prx, L.log_tab) + nspread * epa::fast_log10(rt, L.log_tab) + alpha2 * rt + Aadd;
+      // prx and rt are positive or NaN here: the lean log (zero / subnormal / inf / NaN through a rare branch)
+      const T val = (T)10 * epa::fast_log10_lean(prx, L.log_tab) + nspread * epa::fast_log10_lean(rt, L.log_tab) +
+                    alpha2 * rt + Aadd;
       const size_t o = row * S + s;
       out[o] = val;
       if (range_out) {

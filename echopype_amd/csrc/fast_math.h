@@ -65,6 +65,27 @@ __device__ __forceinline__ double lin_from_db(double u, const double* __restrict
 }
 __device__ __forceinline__ float lin_from_db(float u, const double*) { return ::exp10f(u * 0.1f); }
 
+// The same value with the non-finite cases out of the instruction stream: NaN falls through the arithmetic, +-inf
+// (never a calibrated sample) takes a branch -- six selects / compares fewer per call in VALU-bound loops.
+__device__ __forceinline__ double lin_from_db_lean(double u, const double* __restrict__ tab) {
+  constexpr double K256_HI = 85.04135922911648, K256_LO = -4.272771985668806e-15, Z = 0.0027076061740622863;
+  const double t = u * K256_HI;
+  const double m = __builtin_rint(t);
+  double r = fma(u, K256_HI, -m);
+  r = fma(u, K256_LO, r);
+  const double z = r * Z;
+  double p = fma(z, 1.0 / 120.0, 1.0 / 24.0);
+  p = fma(p, z, 1.0 / 6.0);
+  p = fma(p, z, 0.5);
+  p = fma(p, z, 1.0);
+  p = fma(p, z, 1.0);
+  const int mi = (int)fmin(fmax(m, -300000.0), 300000.0);  // NaN -> -300000; p is NaN then, and so is the result
+  double v = ldexp(p * tab[mi & 255], mi >> 8);
+  if (__builtin_expect(__builtin_isinf(t), 0)) v = t < 0.0 ? 0.0 : t;
+  return v;
+}
+__device__ __forceinline__ float lin_from_db_lean(float u, const double*) { return ::exp10f(u * 0.1f); }
+
 __device__ __noinline__ double log10_special(double x) { return ::log10(x); }
 
 // log10(x), fp64.  x <= 0, subnormal, inf and NaN take the (out-of-line) ocml path.
@@ -129,5 +150,30 @@ __device__ __forceinline__ double fast_log10_inl(double x, const double2* __rest
 }
 template <bool POSITIVE, bool EXACT_AT_1 = true>
 __device__ __forceinline__ float fast_log10_inl(float x, const double2*) { return ::log10f(x); }
+
+// log10 of a positive NORMAL number without any select; zero, subnormals, +inf and NaN take a branch to the general
+// routine (the argument must not be negative: callers select on x > 0 themselves).  Within 1e-17 of 0 at x == 1.
+__device__ __forceinline__ double fast_log10_lean(double x, const double2* __restrict__ tab) {
+  constexpr double LOG10_2 = 0.30102999566398120;
+  constexpr double C1 = 0.43429448190325182765, C2 = -0.21714724095162591383,
+                   C3 = 0.14476482730108394255, C4 = -0.10857362047581295691,
+                   C5 = 0.086858896380650365530, C6 = -0.072382413650541971275;
+  const unsigned long long bits = __double_as_longlong(x);
+  const unsigned ex = (unsigned)(bits >> 52) & 0x7ffu;
+  const int j = (int)((bits >> 45) & 127ull);
+  const double m = __longlong_as_double((bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+  const double2 t = tab[j];
+  const double r = fma(m, t.x, -1.0);
+  double p = fma(r, C6, C5);
+  p = fma(p, r, C4);
+  p = fma(p, r, C3);
+  p = fma(p, r, C2);
+  p = fma(p, r, C1);
+  const double ef = (double)((int)ex - 1023 + (j >= 53 ? 1 : 0));
+  double res = fma(ef, LOG10_2, t.y) + r * p;
+  if (__builtin_expect(ex == 0u || ex == 0x7ffu, 0)) res = fast_log10_inl<true, false>(x, tab);
+  return res;
+}
+__device__ __forceinline__ float fast_log10_lean(float x, const double2*) { return ::log10f(x); }
 
 }  // namespace epa

@@ -88,6 +88,16 @@ __global__ __launch_bounds__(epa::kBlock) void power_coef_ek_kernel(CoefArgs a) 
   reinterpret_cast<epa::CoefRow*>(a.coef)[idx] = r;
 }
 
+__global__ __launch_bounds__(epa::kBlock) void pulse_table_lookup_kernel(const double* __restrict__ tau,
+                                                                         const double* __restrict__ pl,
+                                                                         const double* __restrict__ tab, int C, int P,
+                                                                         int K, double* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= C * P) return;
+  const int c = idx / P;
+  out[idx] = table_lookup(tau[idx], pl + (size_t)c * K, tab + (size_t)c * K, K);
+}
+
 __global__ __launch_bounds__(epa::kBlock) void time_bin_offsets_kernel(const int64_t* t, int P,
                                                                        int64_t t0, int64_t dt,
                                                                        int n_bins,
@@ -137,6 +147,17 @@ extern "C" int epa_power_coef_ek(int C, int P, const double* sample_interval,
   const int grid = (int)((n + epa::kBlock - 1) / epa::kBlock);
   hipLaunchKernelGGL(power_coef_ek_kernel, dim3(grid), dim3(epa::kBlock), 0, (hipStream_t)stream, a);
   return epa::check_launch("power_coef_ek_kernel");
+}
+
+extern "C" int epa_pulse_table_lookup(const double* tau_nominal, const double* pulse_length, const double* table, int C,
+                                      int P, int K, double* out, epa_stream_t stream) {
+  EPA_CHECK_ARG(tau_nominal && pulse_length && table && out, "epa_pulse_table_lookup: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && K > 0, "epa_pulse_table_lookup: C=%d P=%d K=%d must be positive", C, P, K);
+  const long long n = (long long)C * P;
+  const int grid = (int)((n + epa::kBlock - 1) / epa::kBlock);
+  hipLaunchKernelGGL(pulse_table_lookup_kernel, dim3(grid), dim3(epa::kBlock), 0, (hipStream_t)stream, tau_nominal,
+                     pulse_length, table, C, P, K, out);
+  return epa::check_launch("pulse_table_lookup_kernel");
 }
 
 extern "C" int epa_time_bin_offsets(const int64_t* ping_time, int P, int64_t t0, int64_t dt,

@@ -41,6 +41,26 @@ class EchoData:
     def group_paths(self):
         return list(self._groups)
 
+    def to_device(self, device=None, groups=(BEAM1, BEAM2, "Environment")):
+        """Move the floating-point array variables of the beam and Environment groups into HBM (DeviceArray), in place;
+        returns self.  The samples AND the per-(channel, ping) parameters (sample_interval, transmit power / duration,
+        sound speed, absorption ...) then stay resident between calls: compute_Sv / compute_Sv_MVBS read them where
+        they are instead of assembling and uploading (channel, ping_time) arrays on every call (the analogue of keeping
+        the reference's dask arrays persisted).  Coordinates and string / integer variables stay on the host."""
+        from . import ops
+        from .xr_lite import DeviceArray
+
+        for gname in groups:
+            if gname not in self._groups:
+                continue
+            ds = self._groups[gname]
+            for name, da in list(ds.data_vars.items()):
+                if isinstance(da.data, DeviceArray) or da.ndim < 2 or da.dtype.kind != "f":
+                    continue
+                ds.data_vars[name] = DataArray(DeviceArray(ops.to_device(np.asarray(da.data), device=device)), da.dims,
+                                               da.coords, da.attrs, name)
+        return self
+
     def __repr__(self):
         return f"<EchoData sonar_model={self.sonar_model!r} groups={self.group_paths}>"
 

@@ -83,6 +83,15 @@ def power_coef_ek(sample_interval, tau_nominal, transmit_power, sound_speed, abs
     return coef
 
 
+def pulse_table_lookup(tau_nominal, pulse_length, table):
+    """(C, P) f64: table[c, argmin_k |tau[c,p] - pulse_length[c,k]|] (get_vend_cal_params_power on the device)."""
+    C, P = tau_nominal.shape
+    out = torch.empty((C, P), dtype=torch.float64, device=tau_nominal.device)
+    call("epa_pulse_table_lookup", _p(tau_nominal), _p(pulse_length), _p(table), C, P, pulse_length.shape[1], _p(out),
+         _stream())
+    return out
+
+
 def sv_power(raw, coef, *, cal_type="Sv", flags=_lib.FLAG_GUARD_POS | _lib.FLAG_MASK_RANGE,
              dtype=torch.float64, want_range=True, out=None, range_out=None, want_range_stats=False):
     """K1 -> (Sv|TS, echo_range|None), both (C,P,S) of dtype [, f64 device tensor {nanmin, nanmax, NaN count} of

@@ -106,6 +106,13 @@ int epa_power_coef_ek(int C, int P, const double* sample_interval, const double*
                       const double* psi, const double* f_nominal, const double* tau_eff,
                       const uint8_t* gpt, int sonar, int cal_type, double* coef, epa_stream_t stream);
 
+/* The pulse-length table lookup on its own (calibrate/cal_params.py:261-324 get_vend_cal_params_power): out[c,p] =
+ * table[c, argmin_k |tau_nominal[c,p] - pulse_length[c,k]|] (first minimum; NaN tau -> NaN).  What compute_Sv attaches to
+ * its output as gain_correction / sa_correction (channel, ping_time) when the per-ping parameters live in HBM.
+ * tau_nominal, out: f64 [C*P]; pulse_length, table: f64 [C*K]. */
+int epa_pulse_table_lookup(const double* tau_nominal, const double* pulse_length, const double* table, int C, int P,
+                           int K, double* out, epa_stream_t stream);
+
 /* ---- K1: fused power-sample calibration (EK60, EK80 CW power, AZFP) ---------------------------------
  * Replaces calibrate/range.py:98-201 + calibrate/calibrate_ek.py:104-110,154-184 (EK) and
  * calibrate/range.py:69-95 + calibrate/calibrate_azfp.py:64-97 (AZFP): ~15 whole-array passes

@@ -1,0 +1,20 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/pmc_hot; rm -rf $O; mkdir -p $O
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+  n=$(echo $grp | tr ' ' '_' | cut -c1-30)
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace -d $O/$n -o p --output-format csv -- python scripts/pmc_hot.py ${1:-all} > $O/$n.log 2>&1
+done
+python scripts/pmc_summary.py $O fast_kernel fused_sv_mvbs_kernel sv_complex_fft > $O/summary.csv
+python - <<'PY'
+import csv, collections
+rows = collections.defaultdict(dict)
+for r in csv.DictReader(open("gpurun_out/pmc_hot/summary.csv")):
+    rows[r["kernel"]][r["Counter_Name"]] = float(r["mean_value"]); rows[r["kernel"]]["vgpr"] = r["vgpr"]
+for k, v in rows.items():
+    if "true>" in k and "fft" in k: continue
+    n = 800e6 if "fft" not in k else 81.92e6
+    print("%-70s VALU/sample %.1f SALU/sample %.1f LDS/sample %.2f  valu_busy %.2f  vgpr %s" % (
+        k[-70:], v.get("SQ_INSTS_VALU", 0) * 64 / n, v.get("SQ_INSTS_SALU", 0) * 64 / n, v.get("SQ_INSTS_LDS", 0) * 64 / n,
+        v.get("SQ_ACTIVE_INST_VALU", 0) / max(v.get("SQ_WAVE_CYCLES", 1), 1), v["vgpr"]))
+PY
