@@ -285,7 +285,7 @@ def api_ms(ctx, C, P, S, raw):
     d["sound_speed_indicative"] = np.tile(1500.0 + 0.5 * np.sin(2 * np.pi * p / 1e5), (C, 1))
     d["backscatter_r"] = ep.DeviceArray(raw)
     d["ping_time"] = ctx.synth.T0 + (p * 1_000_000_000).astype("timedelta64[ns]")
-    ed = ep.echodata.from_ek60_arrays(d)
+    ed = ep.echodata.from_ek60_arrays(d).to_device()  # samples AND per-ping parameters resident in HBM
     logging.disable(logging.WARNING)
     try:
         dtype = ctx.args.dtype
@@ -351,8 +351,9 @@ def run_ek60(ctx, name, cpu):
         del sv, mvbs
         ctx.free()
         cfg["api_ms_per_step"] = api_ms(ctx, C, P, S, d["backscatter_r"])
-        cfg["api_note"] = ("echopype_amd.compute_Sv_MVBS(echodata) on the same resident samples through the Dataset API "
-                           "(host parameter selection + kernels + Dataset assembly), median of 5 calls")
+        cfg["api_note"] = ("echopype_amd.compute_Sv_MVBS(echodata) through the Dataset API on the same volume, echodata "
+                           "resident in HBM (EchoData.to_device: samples and per-ping parameters): parameter selection + "
+                           "kernels + Dataset assembly, median of 5 calls")
     what = ("fused compute_Sv -> compute_MVBS (20 s x 1 m), Sv + MVBS written" if not chain else
             "two-pass compute_Sv -> remove_background_noise (20 x 50, 3 dB) -> compute_MVBS of Sv_corrected (20 s x 1 m), "
             "Sv + " + ("Sv_noise + " if args.chain_outputs == "all" else "") + "Sv_corrected + MVBS written")

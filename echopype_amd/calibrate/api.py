@@ -12,6 +12,8 @@ from ..utils.prov import echopype_prov_attrs
 from .calibrate_azfp import CalibrateAZFP
 from .calibrate_ek import CalibrateEK60, CalibrateEK80
 
+from ..xr_lite import xarray_io  # noqa: E402
+
 logger = logging.getLogger("echopype_amd.calibrate")
 
 CALIBRATOR = {"EK60": CalibrateEK60, "EK80": CalibrateEK80, "AZFP": CalibrateAZFP, "ES70": CalibrateEK60,
@@ -161,6 +163,7 @@ def _calibrate_filter_intervals(compute, cal_type, beam, vend, tau, pt, chans):
     return out
 
 
+@xarray_io()
 def compute_Sv(echodata, **kwargs):
     """Volume backscattering strength Sv.  Same arguments as the reference (api.py:249-345):
     env_params, cal_params, ecs_file, waveform_mode, encode_mode, assume_single_filter_time,
@@ -171,6 +174,7 @@ def compute_Sv(echodata, **kwargs):
     return _compute_cal(cal_type="Sv", echodata=echodata, **kwargs)
 
 
+@xarray_io()
 def compute_TS(echodata, **kwargs):
     """Target strength TS (api.py:348-449)."""
     return _compute_cal(cal_type="TS", echodata=echodata, **kwargs)

@@ -27,6 +27,12 @@ def _interp_time(values, t_src, t_dst):
     return slope * (xq - x[lo]) + values[..., lo]
 
 
+def _same_buffer(a, b):
+    """The two time axes are one and the same array (the usual EK60 file: Environment.time1 is ping_time)."""
+    return a is b or (a.shape == b.shape and a.dtype == b.dtype and a.__array_interface__["data"][0] ==
+                      b.__array_interface__["data"][0] and a.strides == b.strides)
+
+
 def harmonize_env_param_time(p, ping_time=None):
     """Bring a parameter with a ``time1`` dimension onto ``ping_time``; anything else passes through."""
     if not isinstance(p, DataArray) or "time1" not in p.dims:
@@ -39,7 +45,7 @@ def harmonize_env_param_time(p, ping_time=None):
             ax1 = p.dims.index("time1")
             return DataArray(DeviceArray(p.data.tensor.select(ax1, 0).contiguous()), tuple(d for d in p.dims if d != "time1"),
                              {d: p.coords[d] for d in p.dims if d != "time1" and d in p.coords})
-        if t1 is not None and pt is not None and t1.shape == pt.shape and np.array_equal(t1, pt):
+        if t1 is not None and pt is not None and t1.shape == pt.shape and (_same_buffer(t1, pt) or np.array_equal(t1, pt)):
             coords = {d: p.coords[d] for d in p.dims if d != "time1" and d in p.coords}
             coords["ping_time"] = pt
             return DataArray(p.data, dims, coords)
@@ -58,7 +64,7 @@ def harmonize_env_param_time(p, ping_time=None):
     pt = np.asarray(getattr(ping_time, "values", ping_time))
     if not finite.all():
         vals, t1 = vals[..., finite], t1[finite]
-    if t1.shape == pt.shape and np.array_equal(t1, pt):
+    if t1.shape == pt.shape and (_same_buffer(t1, pt) or np.array_equal(t1, pt)):
         out = vals
     else:
         out = _interp_time(vals, t1, pt)

@@ -16,7 +16,7 @@ from .. import ops
 from ..commongrid.api import _dev, _full, _range_stats
 from ..commongrid.utils import _parse_x_bin
 from ..utils.prov import echopype_prov_attrs, insert_processing_level
-from ..xr_lite import DataArray, DeviceArray, from_xarray
+from ..xr_lite import DataArray, DeviceArray, from_xarray, xarray_io
 from .utils import add_remove_background_noise_attrs, extract_dB
 
 
@@ -56,6 +56,7 @@ def _estimate(ds_Sv, ping_num, range_sample_num, background_noise_max, shard=Non
     return order, sv_t, rg_t, a2, noise, background_noise_max
 
 
+@xarray_io()
 def estimate_background_noise(ds_Sv, ping_num, range_sample_num, background_noise_max=None):
     """Sv_noise (same shape as Sv): block-minimum noise + transmission loss (api.py:392-431)."""
     ds_Sv = from_xarray(ds_Sv)
@@ -65,6 +66,7 @@ def estimate_background_noise(ds_Sv, ping_num, range_sample_num, background_nois
                      name="Sv_noise")
 
 
+@xarray_io(in_place=("Sv_noise", "Sv_corrected"))
 def remove_background_noise(ds_Sv, ping_num, range_sample_num, background_noise_max=None,
                             SNR_threshold="3.0dB", _shard=None):
     """Adds Sv_noise and Sv_corrected to ``ds_Sv`` and returns it (api.py:472-511).
@@ -130,6 +132,7 @@ def _check_range_var(ds_Sv, range_var, what, allow_missing):
         raise ValueError(f"Masking {what} requires `{range_var}` data variable in `ds_Sv`.")
 
 
+@xarray_io()
 def mask_transient_noise(ds_Sv, func="nanmean", depth_bin="10m", num_side_pings=25, exclude_above="250.0m",
                          transient_noise_threshold="12.0dB", range_var="depth", use_index_binning=False,
                          chunk_dict={}):
@@ -169,6 +172,7 @@ def mask_transient_noise(ds_Sv, func="nanmean", depth_bin="10m", num_side_pings=
     return _mask_da(ds_Sv, mask)
 
 
+@xarray_io()
 def mask_impulse_noise(ds_Sv, depth_bin="5m", num_side_pings=2, impulse_noise_threshold="10.0dB",
                        range_var="depth", use_index_binning=False):
     """Boolean impulse-noise mask (api.py:171-266); dims (channel, range_sample, ping_time), the
@@ -196,6 +200,7 @@ def mask_impulse_noise(ds_Sv, depth_bin="5m", num_side_pings=2, impulse_noise_th
     return _mask_da(ds_Sv, mask.permute(0, 2, 1), dims)
 
 
+@xarray_io()
 def mask_attenuated_signal(ds_Sv, upper_limit_sl="400.0m", lower_limit_sl="500.0m", num_side_pings=15,
                            attenuation_signal_threshold="8.0dB", range_var="depth"):
     """Boolean (channel, ping_time, range_sample) attenuated-signal mask (api.py:269-359)."""

@@ -11,7 +11,7 @@ import torch
 
 from .. import ops
 from ..utils.prov import echopype_prov_attrs, insert_processing_level
-from ..xr_lite import DataArray, Dataset, DeviceArray, from_xarray
+from ..xr_lite import DataArray, Dataset, DeviceArray, from_xarray, xarray_io
 from .utils import (_parse_x_bin, _set_MVBS_attrs, _setup_and_validate, coarsen_time_mean, get_distance_from_latlon,
                     ping_time_bin_parsing_and_conversion, resample_edges)
 
@@ -52,6 +52,7 @@ def _full(da, ds, order):
     return DataArray(np.ascontiguousarray(np.broadcast_to(src[tuple(idx)], shape)), order)
 
 
+@xarray_io()
 def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="20s", method="map-reduce",
                  reindex=False, skipna=True, fill_value=np.nan, closed="left", range_var_max=None, _shard=None,
                  **flox_kwargs):
@@ -168,6 +169,7 @@ def _assemble_mvbs(ds_Sv, mvbs_t, dim_0, ping_time, e0, dt, n_t, r_edges, range_
     return insert_processing_level(ds_MVBS, "L3*", input_ds=ds_Sv)
 
 
+@xarray_io()
 def compute_MVBS_index_binning(ds_Sv, range_sample_num=100, ping_num=100):
     """MVBS over blocks of ``ping_num`` pings x ``range_sample_num`` samples (api.py:194-266)."""
     ds_Sv = from_xarray(ds_Sv)
@@ -209,6 +211,7 @@ def compute_MVBS_index_binning(ds_Sv, range_sample_num=100, ping_num=100):
 POSITION_VARIABLES = ["latitude", "longitude"]
 
 
+@xarray_io()
 def compute_NASC(ds_Sv, range_bin="10m", dist_bin="0.5nmi", method="map-reduce", skipna=True, closed="left",
                  **flox_kwargs):
     """Nautical Areal Scattering Coefficient on a (distance, depth) grid (api.py:269-416).

@@ -57,12 +57,15 @@ def resample_edges(ping_time, ping_time_bin):
     (origin='start_day'), left-closed and left-labelled; bins run contiguously to the one holding
     the last timestamp.  Returned as int64 ns: (first_edge, step, n_bins).
     """
-    t = np.asarray(ping_time).astype("datetime64[ns]").astype(np.int64)
-    t = t[t != np.iinfo(np.int64).min]  # NaT
-    if t.size == 0:
-        raise ValueError("ping_time holds no valid timestamps")
+    t = np.asarray(ping_time).astype("datetime64[ns]", copy=False).view(np.int64)
     dt = timedelta_ns(ping_time_bin)
-    first, last = int(t.min()), int(t.max())
+    first = int(t.min()) if t.size else 0
+    if t.size == 0 or first == np.iinfo(np.int64).min:  # NaT present (INT64_MIN): drop them
+        t = t[t != np.iinfo(np.int64).min]
+        if t.size == 0:
+            raise ValueError("ping_time holds no valid timestamps")
+        first = int(t.min())
+    last = int(t.max())
     day = 86400 * 10**9
     origin = (first // day) * day
     e0 = origin + ((first - origin) // dt) * dt

@@ -16,7 +16,7 @@ import torch
 
 from .. import ops
 from ..commongrid.api import _dev, _full
-from ..xr_lite import DataArray, DeviceArray, from_xarray
+from ..xr_lite import DataArray, DeviceArray, from_xarray, xarray_io
 from .ek_depth_utils import (align_to_ping_time, ek_use_beam_angles, ek_use_platform_angles,
                              ek_use_platform_vertical_offsets)
 
@@ -44,6 +44,7 @@ def _per_channel_ping(values, dims, C, P, what):
     raise ValueError(f"{what} has unsupported dimensions {dims}")
 
 
+@xarray_io()
 def add_depth(ds, echodata=None, depth_offset=None, tilt=None, downward=True,
               use_platform_vertical_offsets=False, use_platform_angles=False, use_beam_angles=False):
     """Add a ``depth`` variable to an Sv dataset (in place, like the reference) and return it."""

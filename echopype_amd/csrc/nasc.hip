@@ -24,7 +24,9 @@ struct Cell {  // workspace layout per (c, d, r)
 };
 static_assert(sizeof(Cell) == 24, "workspace cell");
 
-template <typename T>
+// USE_LDS = false: a depth grid too fine for the LDS accumulators -- the lane's runs go straight to the global
+// workspace cells with atomics (same sums, more atomic traffic), as epa_mvbs does for its large grids.
+template <typename T, bool USE_LDS>
 __global__ __launch_bounds__(kBlock) void nasc_accumulate_kernel(
     const T* __restrict__ sv, const T* __restrict__ depth, int P, int S,
     const int32_t* __restrict__ bin_start, int n_dbins, int nparts, double range_bin, double inv_bin,
@@ -39,14 +41,28 @@ __global__ __launch_bounds__(kBlock) void nasc_accumulate_kernel(
   const int b0 = bin_start[d], b1 = bin_start[d + 1];
   const int per = (b1 - b0 + nparts - 1) / nparts;
   const int p0 = b0 + part * per, p1 = min(b1, p0 + per);
+  Cell* cell = ws + ((size_t)c * n_dbins + d) * n_rbins;
+  auto flush = [&](int rb, double rs, unsigned rn, unsigned rnan, double rh) {
+    if (USE_LDS) {
+      if (rn) { unsafeAtomicAdd(&lss[rb], rs); atomicAdd(&lcn[rb], rn); }
+      if (rnan) atomicAdd(&lnn[rb], rnan);
+      if (rh != 0.0) unsafeAtomicAdd(&lhs[rb], rh);
+    } else {
+      if (rn) { unsafeAtomicAdd(&cell[rb].ssum, rs); atomicAdd(&cell[rb].cnt, rn); }
+      if (rnan) atomicAdd(&cell[rb].nnan, rnan);
+      if (rh != 0.0) unsafeAtomicAdd(&cell[rb].hsum, rh);
+    }
+  };
   if (p0 >= p1) return;
-  for (int i = threadIdx.x; i < n_rbins; i += kBlock) {
-    lss[i] = 0.0;
-    lhs[i] = 0.0;
-    lcn[i] = 0u;
-    lnn[i] = 0u;
+  if (USE_LDS) {
+    for (int i = threadIdx.x; i < n_rbins; i += kBlock) {
+      lss[i] = 0.0;
+      lhs[i] = 0.0;
+      lcn[i] = 0u;
+      lnn[i] = 0u;
+    }
   }
-  __syncthreads();
+  __syncthreads();  // (also publishes the exp table)
   for (int p = p0; p < p1; ++p) {
     const size_t row = ((size_t)c * P + p) * S;
     const T* svr = sv + row;
@@ -80,11 +96,7 @@ __global__ __launch_bounds__(kBlock) void nasc_accumulate_kernel(
         const int b = epa::range_bin_index((double)dcur, range_bin, inv_bin, n_rbins, closed_right != 0);
         if (b >= 0) {
           if (b != rb) {
-            if (any) {
-              if (rn) { unsafeAtomicAdd(&lss[rb], rs); atomicAdd(&lcn[rb], rn); }
-              if (rnan) atomicAdd(&lnn[rb], rnan);
-              if (rh != 0.0) unsafeAtomicAdd(&lhs[rb], rh);
-            }
+            if (any) flush(rb, rs, rn, rnan, rh);
             rb = b; rs = 0.0; rh = 0.0; rn = 0u; rnan = 0u; any = true;
           }
           const T v = vv[j];
@@ -99,15 +111,11 @@ __global__ __launch_bounds__(kBlock) void nasc_accumulate_kernel(
         }
         dcur = dnext;
       }
-      if (any) {
-        if (rn) { unsafeAtomicAdd(&lss[rb], rs); atomicAdd(&lcn[rb], rn); }
-        if (rnan) atomicAdd(&lnn[rb], rnan);
-        if (rh != 0.0) unsafeAtomicAdd(&lhs[rb], rh);
-      }
+      if (any) flush(rb, rs, rn, rnan, rh);
     }
   }
+  if (!USE_LDS) return;
   __syncthreads();
-  Cell* cell = ws + ((size_t)c * n_dbins + d) * n_rbins;
   for (int i = threadIdx.x; i < n_rbins; i += kBlock) {
     if (lcn[i]) {
       unsafeAtomicAdd(&cell[i].ssum, lss[i]);
@@ -149,11 +157,8 @@ extern "C" int epa_nasc(const void* sv, const void* depth, int C, int P, int S, 
   EPA_CHECK_ARG(range_bin > 0, "epa_nasc: range_bin must be positive");
   EPA_CHECK_ARG(dtype == EPA_F32 || dtype == EPA_F64, "epa_nasc: bad dtype %d", dtype);
   EPA_CHECK_ARG(C <= 65535 && n_dbins <= 65535, "epa_nasc: more than 65535 channels / distance bins");
-  const size_t lds = epa::kMathTabBytes + (size_t)n_rbins * 24;
-  if (lds > 156 * 1024) {
-    epa::set_error("epa_nasc: %d range bins exceed the LDS budget", n_rbins);
-    return EPA_EUNSUPPORTED;
-  }
+  const bool use_lds = epa::kMathTabBytes + (size_t)n_rbins * 24 <= 156 * 1024;
+  const size_t lds = epa::kMathTabBytes + (use_lds ? (size_t)n_rbins * 24 : 0);
   hipStream_t st = (hipStream_t)stream;
   const size_t n = (size_t)C * n_dbins * n_rbins;
   EPA_CHECK_HIP(hipMemsetAsync(workspace, 0, n * sizeof(Cell), st));
@@ -167,7 +172,7 @@ extern "C" int epa_nasc(const void* sv, const void* depth, int C, int P, int S, 
   const int cr = (bin_flags & EPA_BIN_CLOSED_RIGHT) ? 1 : 0, skipna = (bin_flags & EPA_BIN_SKIPNA) ? 1 : 0;
 #define EPA_NASC(T)                                                                                   \
   do {                                                                                                \
-    auto kern = nasc_accumulate_kernel<T>;                                                            \
+    auto kern = use_lds ? nasc_accumulate_kernel<T, true> : nasc_accumulate_kernel<T, false>;         \
     if (lds > 64 * 1024)                                                                              \
       EPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                          \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \

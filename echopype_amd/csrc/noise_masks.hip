@@ -96,21 +96,25 @@ __device__ __forceinline__ int value_bin(double d, double r0, double delta, doub
 template <typename T, bool BY_VALUE>
 __global__ __launch_bounds__(kBlock) void range_bin_smooth_kernel(
     const T* __restrict__ sv, const T* __restrict__ range, long long rows, int S, int nper, double r0,
-    double delta, int nbins, T* __restrict__ up) {
+    double delta, int nbins, int seg_bins, T* __restrict__ up) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const epa::MathTabs mt = epa::build_math_tabs(smem);
   double* ssum = reinterpret_cast<double*>(smem + epa::kMathTabBytes);
-  unsigned* scnt = reinterpret_cast<unsigned*>(ssum + nbins);
+  unsigned* scnt = reinterpret_cast<unsigned*>(ssum + seg_bins);
   const double inv = 1.0 / delta;
   for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const T* svr = sv + (size_t)row * S;
+    const T* rr = BY_VALUE ? range + (size_t)row * S : nullptr;
+    // seg_bins == nbins unless the ping has more bins than the LDS accumulators hold: then the bins are taken
+    // seg_bins at a time, the ping (a few KB, in L2) swept once per segment
+    for (int b0 = 0; b0 < nbins; b0 += seg_bins) {
+    const int nseg = min(seg_bins, nbins - b0);
     __syncthreads();
-    for (int b = threadIdx.x; b < nbins; b += kBlock) {
+    for (int b = threadIdx.x; b < nseg; b += kBlock) {
       ssum[b] = 0.0;
       scnt[b] = 0u;
     }
     __syncthreads();
-    const T* svr = sv + (size_t)row * S;
-    const T* rr = BY_VALUE ? range + (size_t)row * S : nullptr;
     // 4 consecutive samples per lane; a run of equal bins is merged before it touches LDS
     for (int base = 4 * threadIdx.x; base < S; base += 4 * kBlock) {
       int rb = -1;
@@ -138,8 +142,8 @@ __global__ __launch_bounds__(kBlock) void range_bin_smooth_kernel(
         const int s = base + j;
         if (s >= S) break;
         const T v = vv[j];
-        const int b = BY_VALUE ? value_bin<false>((double)xx[j], r0, delta, inv, nbins) : s / nper;
-        if (!(v == v) || b < 0) continue;
+        const int b = (BY_VALUE ? value_bin<false>((double)xx[j], r0, delta, inv, nbins) : s / nper) - b0;
+        if (!(v == v) || b < 0 || b >= nseg) continue;
         if (b != rb) {
           if (rn) {
             unsafeAtomicAdd(&ssum[rb], rs);
@@ -158,15 +162,16 @@ __global__ __launch_bounds__(kBlock) void range_bin_smooth_kernel(
       }
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < nbins; b += kBlock) {  // the dB value of a bin once, not once per sample
+    for (int b = threadIdx.x; b < nseg; b += kBlock) {  // the dB value of a bin once, not once per sample
       const unsigned n = scnt[b];
       ssum[b] = n ? 10.0 * epa::fast_log10(ssum[b] / (double)n, mt.log_tab) : __builtin_nan("");
     }
     __syncthreads();
     T* ur = up + (size_t)row * S;
     for (int s = threadIdx.x; s < S; s += kBlock) {
-      const int b = BY_VALUE ? value_bin<true>((double)rr[s], r0, delta, inv, nbins) : s / nper;
-      ur[s] = (T)ssum[b];
+      const int b = (BY_VALUE ? value_bin<true>((double)rr[s], r0, delta, inv, nbins) : s / nper) - b0;
+      if (b >= 0 && b < nseg) ur[s] = (T)ssum[b];
+    }
     }
   }
 }
@@ -1452,11 +1457,10 @@ extern "C" int epa_range_bin_smooth(const void* sv, const void* range, int C, in
     EPA_CHECK_ARG(nper > 0, "epa_range_bin_smooth: samples per bin must be positive");
     nbins = (S + nper - 1) / nper;
   }
-  const size_t lds = epa::kMathTabBytes + (size_t)nbins * 12 + 8;
-  if (lds > kMaxLds) {
-    epa::set_error("epa_range_bin_smooth: %d bins per ping exceed the LDS budget", nbins);
-    return EPA_EUNSUPPORTED;
-  }
+  // bins of a ping held in LDS at once; a finer grid is taken in segments (the ping is re-swept per segment)
+  const int seg_cap = (int)((kMaxLds - epa::kMathTabBytes - 8) / 12) & ~1;
+  const int seg_bins = nbins < seg_cap ? ((nbins + 1) & ~1) : seg_cap;
+  const size_t lds = epa::kMathTabBytes + (size_t)seg_bins * 12 + 8;
   const long long rows = (long long)C * P;
   hipStream_t st = (hipStream_t)stream;
 #define EPA_RBS(T, BV)                                                                            \
@@ -1464,7 +1468,7 @@ extern "C" int epa_range_bin_smooth(const void* sv, const void* range, int C, in
     auto kern = range_bin_smooth_kernel<T, BV>;                                                   \
     if (int rc = set_lds(kern, lds)) return rc;                                                   \
     hipLaunchKernelGGL(kern, dim3(row_grid(rows)), dim3(kBlock), lds, st, (const T*)sv,           \
-                       (const T*)range, rows, S, nper, r0, delta, nbins, (T*)up_out);             \
+                       (const T*)range, rows, S, nper, r0, delta, nbins, seg_bins, (T*)up_out);   \
   } while (0)
   if (dtype == EPA_F64) { if (range) EPA_RBS(double, true); else EPA_RBS(double, false); }
   else { if (range) EPA_RBS(float, true); else EPA_RBS(float, false); }

@@ -65,6 +65,27 @@ class EchoData:
         return f"<EchoData sonar_model={self.sonar_model!r} groups={self.group_paths}>"
 
 
+KNOWN_GROUPS = ("Top-level", "Environment", "Platform", "Platform/NMEA", "Provenance", "Sonar", BEAM1, BEAM2,
+                "Vendor_specific")
+
+
+def as_lite_echodata(ed):
+    """echopype's own EchoData (an xr.DataTree wrapper: groups are xarray Datasets) -> this module's EchoData over
+    lite Datasets; the calibrators only use the read API both share."""
+    if isinstance(ed, EchoData):
+        return ed
+    groups = {}
+    for g in getattr(ed, "group_paths", KNOWN_GROUPS):
+        try:
+            ds = ed[g]
+        except Exception:  # noqa: BLE001 - a group this file does not have
+            continue
+        if ds is not None:
+            groups[g] = from_xarray(ds)
+    return EchoData(ed.sonar_model, groups, source_file=getattr(ed, "source_file", None),
+                    converted_raw_path=getattr(ed, "converted_raw_path", None))
+
+
 def _time1(ping_time):
     return np.asarray(ping_time, dtype="datetime64[ns]")
 

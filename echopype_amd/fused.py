@@ -18,9 +18,10 @@ from .clean.utils import add_remove_background_noise_attrs, extract_dB
 from .commongrid.api import _assemble_mvbs, compute_MVBS
 from .commongrid.utils import _parse_x_bin, resample_edges
 from .utils.prov import echopype_prov_attrs, insert_processing_level
-from .xr_lite import DataArray, Dataset, DeviceArray
+from .xr_lite import DataArray, Dataset, DeviceArray, xarray_io
 
 
+@xarray_io()
 def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=True, fill_value=np.nan,
                     closed="left", range_var_max=None, materialize_echo_range=False, env_params=None,
                     cal_params=None, ecs_file=None, waveform_mode=None, encode_mode=None, dtype="float64",
@@ -55,9 +56,9 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
     cal.tau_nominal_first_ping = _tau_first
     raw, coef, flags, tau_eff = cal._power_inputs("Sv")
     C, P, S = raw.shape
-    ping_time = np.asarray(cal.beam["ping_time"].values).astype("datetime64[ns]")
-    ns = ping_time.astype(np.int64)
-    if np.any(ns[1:] < ns[:-1]) or np.isnat(ping_time).any():
+    ping_time = np.asarray(cal.beam["ping_time"].values).astype("datetime64[ns]", copy=False)
+    ns = ping_time.view(np.int64)
+    if np.any(ns[1:] < ns[:-1]) or (ns.size and ns.min() == np.iinfo(np.int64).min):  # unsorted, or NaT (INT64_MIN)
         if _tau_first is not None:
             raise NotImplementedError("a ping shard needs sorted, valid ping times")
         ds_Sv = _compute_cal("Sv", echodata, **cal_kw)  # unsorted / NaT pings: generic path
@@ -123,6 +124,7 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
     return ds_Sv, ds_MVBS
 
 
+@xarray_io()
 def compute_Sv_clean_MVBS(echodata, ping_num, range_sample_num, *, background_noise_max=None,
                           SNR_threshold="3.0dB", range_bin="20m", ping_time_bin="20s", skipna=True,
                           fill_value=np.nan, closed="left", range_var_max=None, keep_Sv_noise=True,

@@ -13,7 +13,7 @@ import torch
 from .. import ops
 from ..commongrid.api import _dev
 from ..utils.prov import echopype_prov_attrs, insert_processing_level
-from ..xr_lite import DataArray, DeviceArray, from_xarray, is_device
+from ..xr_lite import DataArray, DeviceArray, from_xarray, is_device, xarray_io
 
 _ALLOWED_DIMS = [
     {"ping_time", "range_sample"}, {"ping_time", "depth"}, {"ping_time", "echo_range"},
@@ -117,6 +117,7 @@ def _mask_tensor(m, order):
     return (t != 0).to(torch.uint8).contiguous()
 
 
+@xarray_io()
 def apply_mask(source_ds, mask, var_name="Sv", fill_value=np.nan, storage_options_ds={},
                storage_options_mask={}):
     """Dataset like ``source_ds`` with ``var_name`` replaced by where(AND of masks, var, fill_value)."""

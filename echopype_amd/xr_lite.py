@@ -19,7 +19,7 @@ try:  # pragma: no cover - not installed in the build image
 except Exception:  # noqa: BLE001
     _xr = None
 
-__all__ = ["DeviceArray", "DataArray", "Dataset", "from_xarray", "is_device"]
+__all__ = ["DeviceArray", "DataArray", "Dataset", "from_xarray", "is_device", "is_xarray", "to_xarray", "xarray_io"]
 
 
 class DeviceArray:
@@ -328,3 +328,56 @@ def from_xarray(obj):
             ds[k] = (v.dims, v.values, dict(v.attrs))
         return ds
     return obj
+
+
+# ---- the xarray boundary: xarray in -> xarray out ------------------------------------------------------------------
+def is_xarray(obj):
+    return _xr is not None and isinstance(obj, (_xr.Dataset, _xr.DataArray))
+
+
+def to_xarray(obj):
+    """lite Dataset / DataArray (or a tuple / list of them) -> xarray objects; anything else passes through."""
+    if isinstance(obj, Dataset):
+        return obj.to_xarray()
+    if isinstance(obj, DataArray):
+        if _xr is None:
+            raise ImportError("xarray is not installed")
+        return _xr.DataArray(obj.values, dims=obj.dims, coords={k: v for k, v in obj.coords.items() if np.ndim(v) == 1},
+                             attrs=dict(obj.attrs), name=obj.name)
+    if isinstance(obj, (tuple, list)):
+        return type(obj)(to_xarray(o) for o in obj)
+    return obj
+
+
+def xarray_io(in_place=()):
+    """Decorator of the drop-in API functions (first argument = the dataset / EchoData the reference takes).
+
+    Lite containers in -> lite containers out (results stay in HBM).  A real ``xarray`` Dataset / DataArray in, or an
+    EchoData whose groups are xarray Datasets (echopype's own): the function runs on the converted copy and its
+    results are handed back as ``xarray`` objects (``.values`` of device arrays are copied to the host once).
+    ``in_place``: names of variables the reference ADDS TO THE CALLER'S dataset (clean/api.py:490-502 assigns
+    ``ds_Sv["Sv_noise"]`` / ``ds_Sv["Sv_corrected"]`` before it returns): they are written into the caller's xarray
+    dataset too, and that dataset (with the updated attributes) is returned."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapper(first, *args, **kwargs):
+            from .echodata import EchoData, as_lite_echodata
+
+            foreign_ed = not isinstance(first, EchoData) and hasattr(first, "sonar_model")
+            if not (is_xarray(first) or foreign_ed):
+                return fn(first, *args, **kwargs)
+            lite = as_lite_echodata(first) if foreign_ed else from_xarray(first)
+            out = fn(lite, *args, **kwargs)
+            if in_place and isinstance(out, Dataset) and is_xarray(first):
+                for name in in_place:
+                    if name in out.data_vars:
+                        v = out.data_vars[name]
+                        first[name] = (v.dims, v.values, dict(v.attrs))
+                return first.assign_attrs(dict(out.attrs))
+            return to_xarray(out)
+
+        return wrapper
+
+    return deco

@@ -312,7 +312,8 @@ int epa_sv_complex_fft(const void* re, const void* im, int in_dtype, const float
  * range == NULL, bin b = s / nper -- call per channel, nper is channel specific) and :173-241
  * (downsample_upsample_along_depth: flox nanmean over bins np.arange(r0, max + bin, bin) closed on
  * the left, np.digitize up-sampling; range != NULL, nbins = len(edges) - 1).
- * sv, range, up_out: [C*P*S] of dtype. */
+ * sv, range, up_out: [C*P*S] of dtype.  (A ping with more bins than the LDS accumulators hold, ~13 000, is processed
+ * in segments of bins.) */
 int epa_range_bin_smooth(const void* sv, const void* range, int C, int P, int S, int nper, double r0,
                          double bin, int nbins, void* up_out, int dtype, epa_stream_t stream);
 
@@ -392,7 +393,8 @@ int epa_pool_sv_value(const void* sv, const void* range, const int32_t* nvalid, 
  *   bin_start : int32 [n_dbins+1], pings bin_start[d] .. bin_start[d+1]-1 belong to distance bin d
  *   depth bins: edges i*range_bin, i = 0..n_rbins (np.arange(0, max + bin, bin), api.py:351)
  *   bin_flags : EPA_BIN_SKIPNA, EPA_BIN_CLOSED_RIGHT (depth bins; the distance side is in bin_start)
- *   workspace : 24 * C*n_dbins*n_rbins bytes (zeroed by the call)
+ *   workspace : 24 * C*n_dbins*n_rbins bytes (zeroed by the call); a depth grid too fine for the LDS accumulators
+ *               (> ~6500 bins) is accumulated straight into it with atomics
  *   nasc_out  : [C*n_dbins*n_rbins] of dtype; sv_mean_out / h_mean_out likewise, optional */
 int epa_nasc(const void* sv, const void* depth, int C, int P, int S, const int32_t* bin_start, int n_dbins,
              double range_bin, int n_rbins, unsigned bin_flags, void* workspace, void* nasc_out,

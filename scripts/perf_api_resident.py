@@ -15,7 +15,7 @@ for k, v in list(d.items()):
 d["sound_speed_indicative"] = np.tile(1500.0 + 0.5 * np.sin(2 * np.pi * p / 1e5), (C, 1)) if np.ndim(d["sound_speed_indicative"]) == 2 else d["sound_speed_indicative"]
 d["backscatter_r"] = ep.DeviceArray(dd["backscatter_r"])
 d["ping_time"] = np.datetime64("2026-05-01T00:00:00", "ns") + (p * 1_000_000_000).astype("timedelta64[ns]")
-ed = ep.echodata.from_ek60_arrays(d)
+ed = ep.echodata.from_ek60_arrays(d).to_device()
 n = C * P * S
 logging.disable(logging.WARNING)
 def t(f):

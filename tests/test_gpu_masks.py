@@ -113,6 +113,31 @@ def test_range_bin_smooth_value_mode_edges_and_nan_depth(env):
     _close(got.cpu().numpy(), exp, 1e-9)
 
 
+@pytest.mark.parametrize("mode", ["value", "index"])
+def test_range_bin_smooth_more_bins_than_the_lds_holds(env, mode):
+    """A ping with ~14 000+ bins (bins finer than the samples): the kernel takes the bins in segments -- same result
+    as the oracle (every bin holds one sample or none: smoothing is the identity where defined)."""
+    torch, ops = env
+    rng = np.random.default_rng(3)
+    if mode == "value":
+        S = 3000
+        depth = np.tile(5.0 + 0.05 * np.arange(S), (1, 3, 1))
+        sv = -60 + 5 * rng.standard_normal((1, 3, S))
+        sv[0, 1, 100:140] = np.nan
+        down, exp = omask.downsample_upsample(sv, depth, 0.01)
+        r0, nb = 5.0, len(np.arange(5.0, np.nanmax(depth) + 0.01, 0.01)) - 1
+        assert nb > 13500
+        got = ops.range_bin_smooth(_dev(torch, sv), range=_dev(torch, depth), r0=r0, bin=0.01, nbins=nb)
+    else:
+        S = 30_001
+        sv = -60 + 5 * rng.standard_normal((1, 2, S))
+        sv[0, 0, 7::11] = np.nan
+        depth = np.tile(np.arange(S) * 1.0, (1, 2, 1))
+        exp = omask.index_binning_downsample_upsample(sv, depth, 2.0)  # 2 samples per bin -> 15 001 bins
+        got = ops.range_bin_smooth(_dev(torch, sv), nper=2)
+    _close(got.cpu().numpy(), exp, 1e-9)
+
+
 def test_impulse_mask_reference_goldens(env, gold):
     torch, ops = env
     for i in range(4):

@@ -124,3 +124,25 @@ def test_compute_NASC_from_MVBS_dataset_and_errors(ep):
     bad["latitude"] = (("ping_time",), np.full(P, np.nan))
     with pytest.raises(ValueError, match="All lat/lon entries are NaN!"):
         ep.commongrid.compute_NASC(bad)
+
+
+def test_nasc_depth_grid_beyond_the_lds_accumulators(ep):
+    """7 000+ depth bins (0.1 m over 700 m) do not fit the per-workgroup LDS cells: the kernel accumulates straight
+    into the global workspace with atomics -- same answer."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    C, P, S = 2, 40, 3000
+    depth = np.tile(np.arange(S) * 0.2347 + 0.1, (C, P, 1))
+    Sv = 10 * np.log10(rng.random((C, P, S)) * 1e-6 + 1e-8)
+    Sv[rng.random((C, P, S)) < 0.05] = np.nan
+    dist = np.sort(rng.random(P) * 2.0)
+    t = np.datetime64("2020-01-01T00:00:00", "ns") + np.arange(P) * np.timedelta64(1, "s")
+    r_edges = np.arange(0, depth.max() + 0.1, 0.1)
+    d_edges = np.arange(0, dist.max() + 0.5, 0.5)
+    assert len(r_edges) - 1 > 6500
+    exp, _ = onasc.compute_raw_NASC(Sv, depth, dist, t, r_edges, d_edges)
+    starts = np.searchsorted(dist, d_edges, side="left").astype(np.int32)
+    got = ep.ops.nasc(torch.from_numpy(Sv).cuda(), torch.from_numpy(depth).cuda(), torch.from_numpy(starts).cuda(),
+                      len(d_edges) - 1, 0.1, len(r_edges) - 1)
+    _close(got.cpu().numpy(), exp, 1e-10)

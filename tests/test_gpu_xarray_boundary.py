@@ -1,0 +1,78 @@
+"""xarray in -> xarray out (the drop-in keeps the reference's Dataset-in / Dataset-out signatures).  xarray
+cannot be installed here, so the boundary is exercised with tests/fake_xarray.py, a duck-typed stand-in for the public
+API subset it touches, patched in as ``echopype_amd.xr_lite._xr``: an "xarray" EchoData / Dataset goes in, "xarray"
+Datasets come out, and remove_background_noise writes Sv_noise / Sv_corrected into the CALLER's dataset as the reference
+does (/root/reference/echopype/clean/api.py:490-502)."""
+import numpy as np
+import pytest
+
+import fake_xarray as fx
+
+pytestmark = pytest.mark.gpu
+DIMS = ("channel", "ping_time", "range_sample")
+
+
+@pytest.fixture()
+def ep(monkeypatch):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need a GPU")
+    import echopype_amd
+    from echopype_amd import xr_lite
+
+    monkeypatch.setattr(xr_lite, "_xr", fx)
+    return echopype_amd
+
+
+def _as_fake(ds):
+    """lite Dataset -> the stand-in (what a user holding real xarray objects would pass)."""
+    return fx.Dataset({k: (v.dims, np.asarray(v.values), dict(v.attrs)) for k, v in ds.data_vars.items()},
+                      coords={k: (c.dims, np.asarray(c.values), dict(c.attrs)) for k, c in ds.coords.items()},
+                      attrs=dict(ds.attrs))
+
+
+class ForeignEchoData:
+    """Looks like echopype's EchoData: sonar_model + group access returning "xarray" Datasets."""
+
+    def __init__(self, lite_ed):
+        self.sonar_model, self.source_file, self.converted_raw_path = lite_ed.sonar_model, lite_ed.source_file, None
+        self._g = {g: _as_fake(lite_ed[g]) for g in lite_ed.group_paths}
+        self.group_paths = list(self._g)
+
+    def __getitem__(self, g):
+        return self._g[g]
+
+
+def test_xarray_in_xarray_out_through_the_chain(ep):
+    d = ep.synth.ek60_numpy(2, 60, 300)
+    lite_ed = ep.echodata.from_ek60_arrays(d)
+    ref_sv = ep.calibrate.compute_Sv(lite_ed)                      # lite in -> lite out, device resident
+    assert isinstance(ref_sv, ep.Dataset) and ep.xr_lite.is_device(ref_sv["Sv"].data)
+    ds = ep.calibrate.compute_Sv(ForeignEchoData(lite_ed))         # "xarray" EchoData in -> "xarray" Dataset out
+    assert isinstance(ds, fx.Dataset) and isinstance(ds["Sv"].values, np.ndarray)
+    np.testing.assert_array_equal(ds["Sv"].values, ref_sv["Sv"].values)
+    np.testing.assert_array_equal(ds["echo_range"].values, ref_sv["echo_range"].values)
+    assert ds["Sv"].dims == DIMS and set(ds.coords) >= set(DIMS)
+    # remove_background_noise: adds to the caller's dataset and returns it with the provenance attributes
+    before = set(ds.data_vars)
+    out = ep.clean.remove_background_noise(ds, 20, 50)
+    assert {"Sv_noise", "Sv_corrected"} <= set(ds.data_vars) - before          # the CALLER's object was extended
+    assert isinstance(out, fx.Dataset) and out.attrs["processing_function"] == "clean.remove_background_noise"
+    ref = ep.clean.remove_background_noise(ref_sv, 20, 50)
+    np.testing.assert_array_equal(ds["Sv_corrected"].values, ref["Sv_corrected"].values)
+    assert ds["Sv_noise"].attrs == ref["Sv_noise"].attrs
+    # compute_MVBS / estimate_background_noise / masks / apply_mask: "xarray" in -> "xarray" out
+    mv = ep.commongrid.compute_MVBS(ds, range_bin="2m", ping_time_bin="20s")
+    assert isinstance(mv, fx.Dataset)
+    np.testing.assert_array_equal(mv["Sv"].values, ep.commongrid.compute_MVBS(ref_sv, range_bin="2m", ping_time_bin="20s")["Sv"].values)
+    sn = ep.clean.estimate_background_noise(ds, 20, 50)
+    assert isinstance(sn, fx.DataArray) and sn.dims == DIMS
+    m = ep.clean.mask_impulse_noise(ds, range_var="echo_range", use_index_binning=True)
+    assert isinstance(m, fx.DataArray) and m.values.dtype == bool
+    masked = ep.mask.apply_mask(ds, m)
+    assert isinstance(masked, fx.Dataset)
+    # the fused entry point returns a pair
+    a, b = ep.compute_Sv_MVBS(ForeignEchoData(lite_ed), range_bin="2m", ping_time_bin="20s")
+    assert isinstance(a, fx.Dataset) and isinstance(b, fx.Dataset)
+    np.testing.assert_allclose(b["Sv"].values, mv["Sv"].values, rtol=1e-12, equal_nan=True)
