@@ -275,7 +275,11 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
         if (RMAX) xmax = fmax(xmax, xok ? (double)(T)x : xmax);
         // the block mean uses the UNMASKED range (the generic kernel does too: a masked sample has a NaN Sv)
         const T xr = (T)x;
+#ifdef EPA_LEAN_EXP
+        const T v = epa::lin_from_db_lean(sv[j] - transmission_loss<T>(col[j], xr, rc.log10k, na2), mt.exp2_tab);
+#else
         const T v = epa::lin_from_db(sv[j] - transmission_loss<T>(col[j], xr, rc.log10k, na2), mt.exp2_tab);
+#endif
         const bool take = v == v;
         col[j].acc_sum += take ? v : (T)0;
         col[j].acc_cnt += take ? 1u : 0u;

@@ -81,7 +81,11 @@ __device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::
     spread = nspread * (log10_slow<T>(rt) - log10_slow<T>((T)(r.ra * r.rb)));
   spread = pos ? spread : NaN;
   const T sv = fma(g, (T)raw, spread) + fma(a2, rt, A0);
+#ifdef EPA_LEAN_EXP
+  const T v = epa::lin_from_db_lean(sv, tab);  // +-inf through a rare branch instead of two selects per sample
+#else
   const T v = epa::lin_from_db(sv, tab);
+#endif
   // still inside the bin of the previous ping?  NaN raw -> NaN echo_range: never inside
   const bool xok = raw == raw;
   xmax = fmax(xmax, xok ? x : xmax);  // dead code (removed) unless the caller reads xmax

@@ -1,0 +1,58 @@
+"""PMC FETCH_SIZE / WRITE_SIZE passes of bench.py -> profiles/hbm_traffic.json (bytes per launch of the dominant
+kernel of each workload, with the hash of the kernel sources they were measured on; bench.py reads it back into
+roofline.traffic and drops it when the sources changed).
+    python scripts/make_traffic_json.py <dir holding fetch_<wl>/ and write_<wl>/ rocprofv3 outputs>
+Counters are in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE x 2 for wide coalesced reads;
+WRITE_SIZE x 1.  Calibration on epa_power_coef_ek's known traffic is recorded next to the numbers."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import csrc_hash  # noqa: E402
+
+src = sys.argv[1]
+KERNELS = {
+    "cfg2": (["fused_sv_mvbs_kernel"], 4 * 500_000 * 2000 * 12),
+    "cfg3": (["sv_noise_fast_kernel", "sv_denoise_mvbs_fast_kernel"], 4 * 500_000 * 2000 * 32),
+    "cfg4": (["sv_complex_fft_kernel"], 2 * 200_000 * 8192 * 40),
+}
+
+
+def mean_per_kernel(d, counter):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f, newline="")):
+            if r["Counter_Name"] == counter:
+                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+out = {}
+for wl, (names, algo) in KERNELS.items():
+    fd, wd = os.path.join(src, f"fetch_{wl}"), os.path.join(src, f"write_{wl}")
+    if not (os.path.isdir(fd) and os.path.isdir(wd)):
+        continue
+    fe, wr = mean_per_kernel(fd, "FETCH_SIZE"), mean_per_kernel(wd, "WRITE_SIZE")
+    fkb = sum(v for k, v in fe.items() if any(n in k for n in names) and "true>" not in k.split("fft_kernel")[-1][:40])
+    wkb = sum(v for k, v in wr.items() if any(n in k for n in names) and "true>" not in k.split("fft_kernel")[-1][:40])
+    e = {"bytes_per_launch": 2 * fkb * 1024 + wkb * 1024, "fetch_size_kb_raw": fkb, "write_size_kb_raw": wkb,
+         "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE x1"
+                       + ("; the two kernels of a step summed" if len(names) > 1 else ""),
+         "algorithmic_bytes": algo, "csrc_sha16": csrc_hash(),
+         "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of bench.py --workload {wl} (profiles/r02_pmc_traffic.csv)"}
+    k0f = [v for k, v in fe.items() if "power_coef_ek_kernel" in k]
+    k0w = [v for k, v in wr.items() if "power_coef_ek_kernel" in k]
+    if wl in ("cfg2", "cfg3") and k0f and k0w:  # K0 reads 5 x (C, P) f64 + small tables, writes 64 B per (c, p)
+        cp = 4 * 500_000
+        e["calibration"] = {"kernel": "power_coef_ek_kernel (known 80 MB read, 128 MB write)",
+                            "FETCH_SIZE_ratio_raw": k0f[0] * 1024 / (cp * 40.0), "WRITE_SIZE_ratio_raw": k0w[0] * 1024 / (cp * 64.0)}
+    out[f"{wl}:float64"] = e
+    print(wl, "traffic / algorithmic = %.4f" % (e["bytes_per_launch"] / algo), e.get("calibration"))
+path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+json.dump(out, open(path, "w"), indent=1)
+print("wrote", path)
