@@ -29,6 +29,9 @@ CC_RA, CC_RB, CC_SHIFT, CC_ALPHA2, CC_A, CC_PSCALE = range(6)
 FLAG_GUARD_POS, FLAG_MASK_RANGE = 1, 2
 BIN_SKIPNA, BIN_CLOSED_RIGHT = 1, 2
 POOL_NANMEAN, POOL_NANMEDIAN = 0, 1
+CCP = ("sample_interval", "tau_nominal", "transmit_power", "sound_speed", "absorption", "gain", "freq_center", "psi",
+       "sa_correction", "z_er", "z_et", "angle_offset_alongship", "angle_offset_athwartship", "beamwidth_alongship",
+       "beamwidth_athwartship")  # enum epa_ccoef_param
 EK80_NFFT = 2048
 
 
@@ -88,6 +91,7 @@ SIGNATURES = {
     "epa_noise_estimate": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp],
     "epa_noise_finalize": [_vp, _vp, _i, _i, _d, _vp, _vp],
     "epa_noise_apply": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp],
+    "epa_complex_coef_ek80": [_i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "epa_sv_complex": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "epa_sv_complex_fft": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "epa_range_bin_smooth": [_vp, _vp, _i, _i, _i, _i, _d, _d, _i, _vp, _i, _vp],

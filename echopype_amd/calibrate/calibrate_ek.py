@@ -254,10 +254,23 @@ class CalibrateEK80(CalibrateEK):
         if bch != vch:  # vend.sel(channel=beam.channel) (:333)
             self.vend = self.vend.isel(channel=[vch.index(c) for c in bch])
         C, P = self.beam["backscatter_r"].shape[:2]
+        self._fc_collapsed = False
         if waveform_mode == "BB":
             f0 = cp_array(self.beam["transmit_frequency_start"], C, P)
             f1 = cp_array(self.beam["transmit_frequency_stop"], C, P)
-            self.freq_center = DataArray((f0 + f1) / 2, ("channel", "ping_time"))  # :336-340
+            tdn = self.beam["transmit_duration_nominal"]
+            tdn_host = not isinstance(tdn.data, DeviceArray)
+            tau = cp_array(tdn, C, P) if tdn_host else None
+            const = lambda a: a is not None and bool(np.all((a == a[:, :1]) | np.isnan(a)))  # noqa: E731
+            # The usual file sweeps the same band with the same pulse on every ping: the (channel, ping_time) centre
+            # frequency of calibrate_ek.py:336-340 is then one number per channel, and everything derived from it
+            # (absorption formula, calibration tables interpolated at it) is evaluated per channel -- same values,
+            # broadcast back to (channel, ping_time) where the output dataset carries them (_add_params_to_output).
+            if P > 1 and const(f0) and const(f1) and const(tau):
+                self.freq_center = DataArray(((f0 + f1) / 2)[:, 0].copy(), ("channel",))
+                self._fc_collapsed = True
+            else:
+                self.freq_center = DataArray((f0 + f1) / 2, ("channel", "ping_time"))  # :336-340
         else:
             self.freq_center = self.beam["frequency_nominal"]
         self.env_params = get_env_params_EK("EK80", self.beam, self.echodata["Environment"], self.env_params,
@@ -269,6 +282,30 @@ class CalibrateEK80(CalibrateEK):
     def _shape(self):
         sz = self.beam["backscatter_r"].shape
         return sz[0], sz[1], sz[2]
+
+    _FC_KEYS = ("sound_absorption", "gain_correction", "equivalent_beam_angle", "impedance_transducer",
+                "angle_offset_alongship", "angle_offset_athwartship", "angle_sensitivity_alongship",
+                "angle_sensitivity_athwartship", "beamwidth_alongship", "beamwidth_athwartship")
+
+    def _add_params_to_output(self, ds_out):
+        """Parameters evaluated per channel because the centre frequency does not change along ping_time go out with
+        the (channel, ping_time) dimensions the reference gives them (zero-copy broadcast views)."""
+        if not self._fc_collapsed:
+            return super()._add_params_to_output(ds_out)
+        C, P, _ = self._shape()
+        saved = {}
+        for group in (self.env_params, self.cal_params):
+            for key in self._FC_KEYS:
+                v = group.get(key)
+                if isinstance(v, DataArray) and tuple(v.dims) == ("channel",) and not isinstance(v.data, DeviceArray):
+                    saved[(id(group), key)] = (group, v)
+                    group[key] = DataArray(np.broadcast_to(np.asarray(v.values)[:, None], (C, P)), ("channel", "ping_time"),
+                                           attrs=v.attrs)
+        try:
+            return super()._add_params_to_output(ds_out)
+        finally:
+            for (_, key), (group, v) in saved.items():
+                group[key] = v
 
     def _get_B_theta_phi_m(self):
         """Transceiver gain compensation for BB mode (calibrate_ek.py:507-530)."""
@@ -293,40 +330,33 @@ class CalibrateEK80(CalibrateEK):
             tx, _ = get_transmit_signal(self.beam, coeff, self.waveform_mode,
                                         self.cal_params["receiver_sampling_frequency"],
                                         self.drop_last_hanning_zero)
-        z_er = self._cp(self.cal_params["impedance_transceiver"], "impedance_transceiver")
-        z_et = self._cp(self.cal_params["impedance_transducer"], "impedance_transducer")
-        gain = self._cp(self.cal_params["gain_correction"], "gain_correction")
+        # the (C, P, 8) coefficient rows are built on the device (epa_complex_coef_ek80): parameters go up in the shape
+        # they have -- scalar, (C,), or (C, P) (straight from HBM when the echodata is resident) -- no (C, P) NumPy math
+        def dv(v, name):
+            d = v.data if isinstance(v, DataArray) else None
+            if isinstance(d, DeviceArray) and tuple(v.dims) == ("channel", "ping_time") and d.shape == (C, P):
+                return d.tensor
+            a = np.asarray(getattr(v, "values", v), dtype=np.float64)
+            dims = tuple(v.dims) if isinstance(v, DataArray) else None
+            if a.ndim == 0 or (a.ndim == 1 and a.shape[0] == C and dims != ("ping_time",) and not (P == C and dims is None)):
+                return self._dev(np.ascontiguousarray(a), torch.float64)
+            return self._dev(cp_array(v, C, P, name), torch.float64)
+
+        cpar, env = self.cal_params, self.env_params
+        params = dict(sample_interval=dv(self.beam["sample_interval"], "sample_interval"),
+                      tau_nominal=dv(self.beam["transmit_duration_nominal"], "transmit_duration_nominal"),
+                      transmit_power=dv(self.beam["transmit_power"], "transmit_power"),
+                      sound_speed=dv(env["sound_speed"], "sound_speed"), absorption=dv(env["sound_absorption"], "sound_absorption"),
+                      gain=dv(cpar["gain_correction"], "gain_correction"), freq_center=dv(self.freq_center, "freq_center"),
+                      psi=dv(cpar["equivalent_beam_angle"], "equivalent_beam_angle"),
+                      sa_correction=None if bb else dv(cpar["sa_correction"], "sa_correction"),
+                      z_er=dv(cpar["impedance_transceiver"], "impedance_transceiver"),
+                      z_et=dv(cpar["impedance_transducer"], "impedance_transducer"))
         if bb:
-            gain = gain - self._get_B_theta_phi_m()
-        cw = self._cp(self.env_params["sound_speed"], "sound_speed")
-        alpha = self._cp(self.env_params["sound_absorption"], "sound_absorption")
-        si = self._cp(self.beam["sample_interval"], "sample_interval")
-        tau = self._cp(self.beam["transmit_duration_nominal"], "transmit_duration_nominal")
-        pt = self._cp(self.beam["transmit_power"], "transmit_power")
-        fc = self._cp(self.freq_center, "freq_center")
-        psi = self._cp(self.cal_params["equivalent_beam_angle"], "equivalent_beam_angle")
-        sa = self._cp(self.cal_params["sa_correction"], "sa_correction")
-        gpt = self._gpt_mask()
-        wavelength = cw / fc
-        shift = cw * tau / 4
-        shift[gpt] += (2 * si * cw / 2)[gpt]                      # range.py:180-199
-        with np.errstate(invalid="ignore", divide="ignore"):
-            if cal_type == "Sv":
-                A = (-10 * np.log10(wavelength ** 2 * pt * cw / (32 * np.pi ** 2)) - 2 * gain
-                     - 10 * np.log10(tau_eff)[:, None] - psi)
-                if not bb:
-                    A = A - 2 * sa
-            else:
-                A = -10 * np.log10(wavelength ** 2 * pt / (16 * np.pi ** 2)) - 2 * gain
-        # prx = B * |mean|^2 / (2 sqrt 2)^2 * (|z_er + z_et| / z_er)^2 / z_et   (:483-490)
-        pscale = B / (2 * np.sqrt(2)) ** 2 * (np.abs(z_er + z_et) / z_er) ** 2 / z_et
-        cc = np.zeros((C, P, _lib.NCCOEF))
-        cc[..., _lib.CC_RA] = si
-        cc[..., _lib.CC_RB] = cw / 2
-        cc[..., _lib.CC_SHIFT] = shift
-        cc[..., _lib.CC_ALPHA2] = 2 * alpha
-        cc[..., _lib.CC_A] = A
-        cc[..., _lib.CC_PSCALE] = pscale
+            for k in ("angle_offset_alongship", "angle_offset_athwartship", "beamwidth_alongship", "beamwidth_athwartship"):
+                params[k] = dv(cpar[k], k)
+        cc_t = ops.complex_coef_ek80(params, self._dev(np.asarray(tau_eff, dtype=np.float64), torch.float64), C, P, B=B, bb=bb,
+                                     cal_type=cal_type, gpt=self._dev(self._gpt_mask().astype(np.uint8)))
         rep = off = None
         max_taps = 0
         if bb:
@@ -341,8 +371,7 @@ class CalibrateEK80(CalibrateEK):
         im = self._dev(self.beam["backscatter_i"].data)
         if re.dtype not in (torch.float32, torch.float64):
             re, im = re.double(), im.double()
-        return dict(re=re, im=im, ccoef=self._dev(cc, torch.float64), replica=rep, replica_off=off,
-                    max_taps=max_taps), tau_eff
+        return dict(re=re, im=im, ccoef=cc_t, replica=rep, replica_off=off, max_taps=max_taps), tau_eff
 
     def _cal_complex_samples(self, cal_type):
         """One fused pass for calibrate_ek.py:532-659 (+ ek80_complex.py:285-391 for BB)."""

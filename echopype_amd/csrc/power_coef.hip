@@ -88,6 +88,56 @@ __global__ __launch_bounds__(epa::kBlock) void power_coef_ek_kernel(CoefArgs a) 
   reinterpret_cast<epa::CoefRow*>(a.coef)[idx] = r;
 }
 
+// ---- EK80 complex samples: the per-(channel, ping) rows consumed by epa_sv_complex / epa_sv_complex_fft
+struct CCoefArgs {
+  int C, P, B, bb, cal_type;
+  const double* p[EPA_CCP_COUNT];
+  int mode[EPA_CCP_COUNT];
+  const double* taueff;
+  const uint8_t* gpt;
+  double* ccoef;
+};
+
+__global__ __launch_bounds__(epa::kBlock) void complex_coef_ek80_kernel(CCoefArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.C * a.P) return;
+  const int c = idx / a.P;
+  auto get = [&](int k) { return fetch(a.p[k], a.mode[k], c, idx); };
+  const double si = get(EPA_CCP_SAMPLE_INTERVAL), tau = get(EPA_CCP_TAU_NOMINAL), pt = get(EPA_CCP_TRANSMIT_POWER);
+  const double cw = get(EPA_CCP_SOUND_SPEED), alpha = get(EPA_CCP_ABSORPTION), fc = get(EPA_CCP_FREQ_CENTER);
+  const double z_er = get(EPA_CCP_Z_ER), z_et = get(EPA_CCP_Z_ET);
+  double gain = get(EPA_CCP_GAIN);
+  if (a.bb) {  // transceiver gain compensation of the broadband mode (calibrate_ek.py:507-530)
+    const double fa0 = fabs(-get(EPA_CCP_ANGLE_OFFSET_ALONGSHIP)) / (get(EPA_CCP_BEAMWIDTH_ALONGSHIP) / 2);
+    const double ft0 = fabs(-get(EPA_CCP_ANGLE_OFFSET_ATHWARTSHIP)) / (get(EPA_CCP_BEAMWIDTH_ATHWARTSHIP) / 2);
+    const double fa = fa0 * fa0, ft = ft0 * ft0;
+    const double Bt = 0.5 * 6.0206 * (fa + ft - 0.18 * fa * ft);
+    gain -= (Bt == Bt) ? Bt : 0.0;  // NaN (missing angles) -> no compensation, as the reference's fillna(0)
+  }
+  const double lambda = cw / fc;
+  double shift = cw * tau / 4;                       // range.py:180-199
+  if (a.gpt && a.gpt[c]) shift += 2 * si * cw / 2;
+  const double pi = 3.141592653589793;
+  double A;
+  if (a.cal_type == EPA_CAL_SV) {                    // calibrate_ek.py:610-638
+    A = -10 * log10(lambda * lambda * pt * cw / (32 * pi * pi)) - 2 * gain - 10 * log10(a.taueff[c]) - get(EPA_CCP_PSI);
+    if (!a.bb) A -= 2 * get(EPA_CCP_SA_CORRECTION);
+  } else {
+    A = -10 * log10(lambda * lambda * pt / (16 * pi * pi)) - 2 * gain;
+  }
+  // prx = B |mean|^2 / (2 sqrt 2)^2 (|z_er + z_et| / z_er)^2 / z_et   (calibrate_ek.py:483-490)
+  const double zr = fabs(z_er + z_et) / z_er;
+  double* row = a.ccoef + (size_t)idx * EPA_NCCOEF;
+  row[EPA_CC_RA] = si;
+  row[EPA_CC_RB] = cw / 2;
+  row[EPA_CC_SHIFT] = shift;
+  row[EPA_CC_ALPHA2] = 2 * alpha;
+  row[EPA_CC_A] = A;
+  row[EPA_CC_PSCALE] = (double)a.B / 8.0 * (zr * zr) / z_et;
+  row[EPA_CC_RSV0] = 0.0;
+  row[EPA_CC_RSV1] = 0.0;
+}
+
 __global__ __launch_bounds__(epa::kBlock) void pulse_table_lookup_kernel(const double* __restrict__ tau,
                                                                          const double* __restrict__ pl,
                                                                          const double* __restrict__ tab, int C, int P,
@@ -147,6 +197,29 @@ extern "C" int epa_power_coef_ek(int C, int P, const double* sample_interval,
   const int grid = (int)((n + epa::kBlock - 1) / epa::kBlock);
   hipLaunchKernelGGL(power_coef_ek_kernel, dim3(grid), dim3(epa::kBlock), 0, (hipStream_t)stream, a);
   return epa::check_launch("power_coef_ek_kernel");
+}
+
+extern "C" int epa_complex_coef_ek80(int C, int P, const double* const* params, const int* modes,
+                                     const double* tau_eff, const uint8_t* gpt, int B, int bb, int cal_type,
+                                     double* ccoef, epa_stream_t stream) {
+  EPA_CHECK_ARG(C > 0 && P > 0 && B > 0, "epa_complex_coef_ek80: C=%d P=%d B=%d must be positive", C, P, B);
+  EPA_CHECK_ARG(params && modes && tau_eff && ccoef, "epa_complex_coef_ek80: NULL array argument");
+  EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_complex_coef_ek80: bad cal_type");
+  CCoefArgs a{};
+  a.C = C; a.P = P; a.B = B; a.bb = bb ? 1 : 0; a.cal_type = cal_type;
+  for (int k = 0; k < EPA_CCP_COUNT; ++k) {
+    const bool needed = !(k >= EPA_CCP_ANGLE_OFFSET_ALONGSHIP && !bb) && !(k == EPA_CCP_SA_CORRECTION && (bb || cal_type != EPA_CAL_SV)) &&
+                        !(k == EPA_CCP_PSI && cal_type != EPA_CAL_SV);
+    EPA_CHECK_ARG(!needed || params[k] != nullptr, "epa_complex_coef_ek80: parameter %d is NULL", k);
+    EPA_CHECK_ARG(modes[k] >= EPA_PM_SCALAR && modes[k] <= EPA_PM_CHANNEL_PING, "epa_complex_coef_ek80: bad mode of parameter %d", k);
+    a.p[k] = params[k];
+    a.mode[k] = modes[k];
+  }
+  a.taueff = tau_eff; a.gpt = gpt; a.ccoef = ccoef;
+  const long long n = (long long)C * P;
+  hipLaunchKernelGGL(complex_coef_ek80_kernel, dim3((unsigned)((n + epa::kBlock - 1) / epa::kBlock)), dim3(epa::kBlock), 0,
+                     (hipStream_t)stream, a);
+  return epa::check_launch("complex_coef_ek80_kernel");
 }
 
 extern "C" int epa_pulse_table_lookup(const double* tau_nominal, const double* pulse_length, const double* table, int C,

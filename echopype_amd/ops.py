@@ -300,6 +300,27 @@ def noise_apply(sv, alpha2, noise, ping_num, snr_threshold, *, range=None, coef=
     return (sn, sc, mm.cpu().tolist()) if want_minmax else (sn, sc)
 
 
+def complex_coef_ek80(params, tau_eff, C, P, *, B, bb, cal_type="Sv", gpt=None):
+    """EK80 complex-sample coefficient rows (C, P, NCCOEF) f64 on the device.  ``params``: name -> f64 device tensor of
+    shape (), (C,) or (C, P) for the names of _lib.CCP (missing / None = unused by this mode)."""
+    dev = tau_eff.device
+    ptrs = (ctypes.c_void_p * len(_lib.CCP))()
+    modes = (ctypes.c_int * len(_lib.CCP))()
+    keep = []
+    for k, name in enumerate(_lib.CCP):
+        t = params.get(name)
+        if t is None:
+            ptrs[k], modes[k] = None, _lib.PM_SCALAR
+            continue
+        t = t.to(torch.float64).contiguous()
+        keep.append(t)
+        ptrs[k], modes[k] = t.data_ptr(), _mode_of(t, C, P)
+    out = torch.empty((C, P, _lib.NCCOEF), dtype=torch.float64, device=dev)
+    call("epa_complex_coef_ek80", C, P, ptrs, modes, _p(tau_eff), _p(gpt), int(B), 1 if bb else 0,
+         _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, _p(out), _stream())
+    return out
+
+
 def sv_complex(re, im, ccoef, *, replica=None, replica_off=None, max_taps=0, cal_type="Sv",
                dtype=torch.float64, want_range=True, want_prx=False, method="auto", fft_dtype=None,
                want_range_stats=False):

@@ -276,6 +276,19 @@ int epa_noise_apply(const void* sv, const void* range, const double* coef, const
  * prx = PSCALE * |sector mean of the (pulse-compressed, normalised) samples|^2  (<= 0 -> NaN) */
 enum epa_ccoef_slot { EPA_CC_RA = 0, EPA_CC_RB = 1, EPA_CC_SHIFT = 2, EPA_CC_ALPHA2 = 3, EPA_CC_A = 4,
                       EPA_CC_PSCALE = 5, EPA_CC_RSV0 = 6, EPA_CC_RSV1 = 7 };
+/* The rows above built on the device from the per-(channel, ping) parameters (the EK80 counterpart of
+ * epa_power_coef_ek; replaces the (channel, ping_time) arithmetic of calibrate_ek.py:483-490, 507-530, 583-638 and
+ * range.py:180-199).  params / modes: HOST arrays of EPA_CCP_COUNT DEVICE pointers (f64) and their epa_param_mode
+ * (SCALAR, CHANNEL [C] or CHANNEL_PING [C*P]), indexed by epa_ccoef_param; entries a mode does not use may be NULL
+ * (the angle offsets / beamwidths without bb; sa_correction with bb or TS; psi with TS).  tau_eff: f64 [C] (device);
+ * gpt: u8 [C] or NULL.  bb != 0: broadband (gain is compensated by B(theta, phi), no sa_correction). */
+enum epa_ccoef_param { EPA_CCP_SAMPLE_INTERVAL = 0, EPA_CCP_TAU_NOMINAL, EPA_CCP_TRANSMIT_POWER, EPA_CCP_SOUND_SPEED,
+                       EPA_CCP_ABSORPTION, EPA_CCP_GAIN, EPA_CCP_FREQ_CENTER, EPA_CCP_PSI, EPA_CCP_SA_CORRECTION,
+                       EPA_CCP_Z_ER, EPA_CCP_Z_ET, EPA_CCP_ANGLE_OFFSET_ALONGSHIP, EPA_CCP_ANGLE_OFFSET_ATHWARTSHIP,
+                       EPA_CCP_BEAMWIDTH_ALONGSHIP, EPA_CCP_BEAMWIDTH_ATHWARTSHIP, EPA_CCP_COUNT };
+int epa_complex_coef_ek80(int C, int P, const double* const* params, const int* modes, const double* tau_eff,
+                          const uint8_t* gpt, int B, int bb, int cal_type, double* ccoef, epa_stream_t stream);
+
 int epa_sv_complex(const void* re, const void* im, int in_dtype, const float* replica,
                    const int32_t* replica_off, int max_taps, const double* ccoef, int C, int P,
                    int S, int B, int cal_type, void* out, void* range_out, void* prx_out,
