@@ -581,6 +581,7 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
   const T nspread = (T)a.nspread;
   const double inv_norm = 1.0 / chan[0];
   const double inv_norm_b = inv_norm / (double)B;  // every sector valid (the only case of the fast form)
+  const epa::LogCoef lk = epa::make_log_coef();
   T* out = reinterpret_cast<T*>(a.out);
   T* range_out = reinterpret_cast<T*>(a.range_out);
   T* prx_out = reinterpret_cast<T*>(a.prx_out);
@@ -607,7 +608,7 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
       T rt = sub_rn((T)R, shift);              // never contracted with the range product into an fma
       if (!(rt > (T)0)) rt = epa::M<T>::nan();
       // prx and rt are positive or NaN here: the lean log (zero / subnormal / inf / NaN through a rare branch)
-      const T val = (T)10 * epa::fast_log10_lean(prx, L.log_tab) + nspread * epa::fast_log10_lean(rt, L.log_tab) +
+      const T val = (T)10 * epa::fast_log10_lean(prx, L.log_tab, lk) + nspread * epa::fast_log10_lean(rt, L.log_tab, lk) +
                     alpha2 * rt + Aadd;
       const size_t o = row * S + s;
       out[o] = val;

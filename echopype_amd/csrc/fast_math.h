@@ -176,4 +176,40 @@ __device__ __forceinline__ double fast_log10_lean(double x, const double2* __res
 }
 __device__ __forceinline__ float fast_log10_lean(float x, const double2*) { return ::log10f(x); }
 
+// The polynomial coefficients of fast_log10_lean held in SGPR pairs.  In straight-line code (no loop to hoist them
+// out of) the compiler otherwise re-creates each 64-bit literal with two v_mov_b32 at every use -- ten VALU moves per
+// log; an opaque scalar copy made once per kernel turns every Horner step into one v_fma_f64 with an SGPR operand.
+struct LogCoef {
+  double c1, c2, c3, c4, c5, c6, log10_2;
+};
+__device__ __forceinline__ double opaque_scalar(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ LogCoef make_log_coef() {
+  return LogCoef{opaque_scalar(0.43429448190325182765),  opaque_scalar(-0.21714724095162591383),
+                 opaque_scalar(0.14476482730108394255),  opaque_scalar(-0.10857362047581295691),
+                 opaque_scalar(0.086858896380650365530), opaque_scalar(-0.072382413650541971275),
+                 opaque_scalar(0.30102999566398120)};
+}
+__device__ __forceinline__ double fast_log10_lean(double x, const double2* __restrict__ tab, const LogCoef& K) {
+  const unsigned long long bits = __double_as_longlong(x);
+  const unsigned ex = (unsigned)(bits >> 52) & 0x7ffu;
+  const int j = (int)((bits >> 45) & 127ull);
+  const double m = __longlong_as_double((bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+  const double2 t = tab[j];
+  const double r = fma(m, t.x, -1.0);
+  double p = fma(r, K.c6, K.c5);
+  p = fma(p, r, K.c4);
+  p = fma(p, r, K.c3);
+  p = fma(p, r, K.c2);
+  p = fma(p, r, K.c1);
+  const double ef = (double)((int)ex - 1023 + (j >= 53 ? 1 : 0));
+  double res = fma(ef, K.log10_2, t.y) + r * p;
+  if (__builtin_expect(ex == 0u || ex == 0x7ffu, 0)) res = fast_log10_inl<true, false>(x, tab);
+  return res;
+}
+__device__ __forceinline__ float fast_log10_lean(float x, const double2*, const LogCoef&) { return ::log10f(x); }
+
 }  // namespace epa
