@@ -819,6 +819,390 @@ __global__ __launch_bounds__(kBlock) void attenuated_mask_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same mask with the block median carried from ping to ping (round 2).  attenuated_mask_kernel sweeps the
+// 2n-ping x layer block of every ping three times (radix selection from memory): ~48 000 element visits per ping at
+// n = 15, a 520-sample layer.  Consecutive pings share all but one ping of their blocks, so a workgroup that walks a
+// CHUNK of consecutive pings keeps
+//   * a 4096-bin histogram of the block's values (dB quantised linearly over [-200, 50) dB: ~0.06 dB per bin -- any
+//     monotone map would do, the ends are clamped) in LDS, updated with the ping that enters and the ping that leaves;
+//   * the 12-bit codes of the 2n pings of the block in an LDS ring (2 bytes per value).
+// The bin holding the median rank comes from a prefix scan of the histogram; the few dozen values of that bin are
+// found by comparing the ring's codes, re-read from memory (L2) by position, and ranked exactly among themselves.
+// The ping's own median uses its ring slot the same way with a 256-bin histogram.  Exact medians, ~1 500 element
+// visits per ping.  The layer limits come from every ping's own range row as before; whenever they differ from the
+// previous ping's (or the block exceeds the ring) the block is rebuilt / the ping takes the sweeping path.
+// ------------------------------------------------------------------------------------------------
+constexpr int kAttBins = 4096;  // bins of the block's running histogram: the top 12 bits of a value's 16-bit code
+constexpr int kAttCand = 512;
+constexpr int kAttChunkMax = 256;  // pings per workgroup (+ 2n of warm-up): chosen by the launcher, at most this
+constexpr int kAttPre = 4;      // values of the entering ping a lane prefetches (layers up to 1024 samples)
+
+struct AttScratch {
+  unsigned hist[kAttBins];
+  unsigned small[256];    // the ping's own layer by the top 8 bits
+  unsigned sub_own[512];  // low 8 bits inside the one or two selected top-8 bins
+  unsigned sub_blk[256];  // low 4 bits inside the one or two selected 12-bit bins (32 used)
+  unsigned wsum[2][4];
+  unsigned ncand, overflow;
+  int bin[8];  // of two order statistics each: [0..1] own top-8, [2..3] block 12-bit, [4..5] own low bits, [6..7] block's
+  unsigned rank[8];
+  unsigned long long key[4];
+  unsigned long long cand[kAttCand];
+  unsigned ctag[kAttCand];  // bit 16: of the ping's own layer; low 16 bits: the code
+};
+
+__device__ __forceinline__ unsigned att_code(double v) {
+  // monotone 16-bit code of a dB value over [-200, 50] (clamped), NaN excluded by the caller; 0xffff is kept for NaN
+  const double t = (v + 200.0) * (65535.0 / 250.0);
+  const int c = (int)fmin(fmax(t, 0.0), 65534.0);
+  return (unsigned)c;
+}
+
+template <int PER>
+struct AttScan {
+  unsigned h[PER], tot, incl;
+  __device__ __forceinline__ void load(const unsigned* hist) {  // this lane's PER consecutive bins + the wave's prefix
+    const int t = threadIdx.x;
+    tot = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      h[i] = hist[t * PER + i];
+      tot += h[i];
+    }
+    incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned u = __shfl_up(incl, o, 64);
+      if ((t & 63) >= o) incl += u;
+    }
+  }
+  // the lane whose bins hold rank k records the bin and the rank inside it
+  __device__ __forceinline__ void pick(unsigned base, unsigned k, int* bin, unsigned* rank) const {
+    const unsigned excl = base + incl - tot;
+    if (excl <= k && k < excl + tot) {
+      unsigned r = k - excl;
+      int b = 0;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {  // (static indices: h stays in registers)
+        const bool here = b == i && r >= h[i];
+        r -= here ? h[i] : 0u;
+        b += here ? 1 : 0;
+      }
+      *bin = threadIdx.x * PER + b;
+      *rank = r;
+    }
+  }
+};
+
+// Two order statistics in each of two histograms (256 * PA and 256 * PB bins) behind ONE barrier -> sc->bin / rank
+// [ea..ea+1], [eb..eb+1].  MEDIAN: the two middle ones, else the given ranks.  na / nb = the counted values.  All threads
+// call it after a barrier that completed the histograms; the caller's next barrier publishes bin / rank.
+template <int PA, int PB, bool MEDIAN>
+__device__ __forceinline__ void att_locate2(const unsigned* ha, const unsigned* hb, AttScratch* sc, int ea, int eb,
+                                            unsigned& na, unsigned& nb, unsigned ka0 = 0, unsigned ka1 = 0,
+                                            unsigned kb0 = 0, unsigned kb1 = 0) {
+  const int t = threadIdx.x;
+  AttScan<PA> a;
+  AttScan<PB> b;
+  a.load(ha);
+  b.load(hb);
+  if ((t & 63) == 63) {
+    sc->wsum[0][t >> 6] = a.incl;
+    sc->wsum[1][t >> 6] = b.incl;
+  }
+  __syncthreads();
+  unsigned base_a = 0, base_b = 0;
+  na = nb = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const unsigned wa = sc->wsum[0][w], wb = sc->wsum[1][w];
+    base_a += w < (t >> 6) ? wa : 0u;
+    base_b += w < (t >> 6) ? wb : 0u;
+    na += wa;
+    nb += wb;
+  }
+  if (na) {
+    a.pick(base_a, MEDIAN ? (na - 1u) / 2u : ka0, &sc->bin[ea], &sc->rank[ea]);
+    a.pick(base_a, MEDIAN ? na / 2u : ka1, &sc->bin[ea + 1], &sc->rank[ea + 1]);
+  }
+  if (nb) {
+    b.pick(base_b, MEDIAN ? (nb - 1u) / 2u : kb0, &sc->bin[eb], &sc->rank[eb]);
+    b.pick(base_b, MEDIAN ? nb / 2u : kb1, &sc->bin[eb + 1], &sc->rank[eb + 1]);
+  }
+}
+
+// exact order statistics crank[e] among the candidates tagged tag[e] -> sc->key[e]
+__device__ __forceinline__ void att_rank(AttScratch* sc, const unsigned (&tag)[4], const unsigned (&crank)[4]) {
+  const unsigned M = min(sc->ncand, (unsigned)kAttCand);
+  for (unsigned i = threadIdx.x; i < M; i += kBlock) {
+    const unsigned long long ki = sc->cand[i];
+    const unsigned ti = sc->ctag[i];
+    unsigned less = 0;
+    for (unsigned j = 0; j < M; ++j) {
+      const unsigned long long kj = sc->cand[j];
+      less += (sc->ctag[j] == ti && (kj < ki || (kj == ki && j < i))) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (ti == tag[e] && less == crank[e]) sc->key[e] = ki;
+  }
+  __syncthreads();
+}
+
+// layer limits of every ping from its own range row (np.argmin: first NaN, else first minimum), stashed in the first
+// eight bytes of the ping's row of the (not yet written) mask: one fully parallel sweep of the range array instead of a
+// dependent load + reduction in front of every step of the sequential walk below
+template <typename T>
+__global__ __launch_bounds__(kBlock) void attenuated_limits_kernel(const T* __restrict__ range, int S, long long rows,
+                                                                   T upper, T lower, uint8_t* __restrict__ mask) {
+  __shared__ double shv[4];
+  __shared__ int shi[4];
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const T* rr = range + (size_t)row * S;
+    double bu = __builtin_inf(), bl = __builtin_inf();
+    int iu = 0x7fffffff, il = 0x7fffffff;
+    for (int s = threadIdx.x; s < S; s += kBlock) {
+      const T r = rr[s];
+      T du = fabs(r - upper), dl = fabs(r - lower);
+      const double vu = (du == du) ? (double)du : -1.0;  // NaN beats every |.| >= 0
+      const double vl = (dl == dl) ? (double)dl : -1.0;
+      if (vu < bu) { bu = vu; iu = s; }
+      if (vl < bl) { bl = vl; il = s; }
+    }
+    const int up = block_argmin(bu, iu, shv, shi);
+    const int lw = block_argmin(bl, il, shv, shi);
+    if (threadIdx.x == 0) {
+      int* dst = reinterpret_cast<int*>(mask + (size_t)row * S);  // rows are S >= 8 bytes apart, S % 4 == 0 checked
+      dst[0] = up;
+      dst[1] = lw;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock, 2) void attenuated_slide_kernel(
+    const T* __restrict__ sv, int P, int S, int nchunks, int chunk_len, int n, T thr, int ring_cap,
+    uint8_t* __restrict__ mask) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const epa::MathTabs mt = epa::build_math_tabs(smem);
+  unsigned short* ring = reinterpret_cast<unsigned short*>(smem + epa::kMathTabBytes);
+  // the sweeping path (blocks beyond the ring, many equal values) borrows the ring's memory: the ring is rebuilt after it
+  SelectScratch* sel = reinterpret_cast<SelectScratch*>(smem + epa::kMathTabBytes);
+  __shared__ AttScratch sc;
+  __shared__ int lim[kAttChunkMax][2];
+  const int c = blockIdx.x / nchunks, chunk = blockIdx.x - c * nchunks;
+  const int p0 = chunk * chunk_len, p1 = min(P, p0 + chunk_len);
+  const T* cb = sv + (size_t)c * P * S;
+  uint8_t* mb = mask + (size_t)c * P * S;
+  const int W = 2 * n;  // pings of a block: [p - n, p + n)
+  int w_up = -1, w_lw = -1, w_lo = 0;  // window state: layer limits and first ping of the block held in LDS
+  bool valid = false;
+  // the chunk's layer limits, read before any of its mask rows is overwritten
+  for (int i = threadIdx.x; i < p1 - p0; i += kBlock) {
+    const int* src = reinterpret_cast<const int*>(mb + (size_t)(p0 + i) * S);
+    lim[i][0] = src[0];
+    lim[i][1] = src[1];
+  }
+  __syncthreads();
+
+  auto enter = [&](int q, int L, const T (&pre)[kAttPre]) {  // values of ping q (already in registers) enter
+    unsigned short* slot = ring + (size_t)(q % W) * L;
+#pragma unroll
+    for (int k = 0; k < kAttPre; ++k) {
+      const int i = threadIdx.x + k * kBlock;
+      if (i < L) {
+        const double v = (double)pre[k];
+        const unsigned code = (v == v) ? att_code(v) : 0xffffu;
+        slot[i] = (unsigned short)code;
+        if (code != 0xffffu) atomicAdd(&sc.hist[code >> 4], 1u);
+      }
+    }
+  };
+  auto fetch = [&](int q, int up, int L, T (&pre)[kAttPre]) {
+    const T* row = cb + (size_t)q * S + up;
+#pragma unroll
+    for (int k = 0; k < kAttPre; ++k) {
+      const int i = threadIdx.x + k * kBlock;
+      pre[k] = (q < P && i < L) ? row[i] : (T)0;
+    }
+  };
+  auto leave = [&](int q, int L) {
+    const unsigned short* slot = ring + (size_t)(q % W) * L;
+    for (int i = threadIdx.x; i < L; i += kBlock) {
+      const unsigned code = slot[i];
+      if (code != 0xffffu) atomicSub(&sc.hist[code >> 4], 1u);
+    }
+  };
+  auto median_lin = [&](int e) {  // from sc.key[e], sc.key[e + 1]
+    const double a = epa::lin_from_db(key_value(sc.key[e]), mt.exp2_tab);
+    return sc.key[e] == sc.key[e + 1] ? a : (a + epa::lin_from_db(key_value(sc.key[e + 1]), mt.exp2_tab)) * 0.5;
+  };
+  auto sweep = [&](int p, int up, int L, bool& flag) {  // both medians from memory (window_median_lin)
+    unsigned nv;
+    Window<T> w1{cb, S, p, 1, up, L, P, 0, false};
+    const double m1 = window_median_lin(w1, sel, mt.exp2_tab, nv, L);
+    if (nv) {
+      Window<T> w2{cb, S, p - n, W, up, L, P, 0, false};
+      unsigned nv2;
+      const double m2 = window_median_lin(w2, sel, mt.exp2_tab, nv2, W * L);
+      const T ping_db = (T)(10.0 * epa::fast_log10(m1, mt.log_tab));
+      const T block_db = nv2 ? (T)(10.0 * epa::fast_log10(m2, mt.log_tab)) : epa::M<T>::nan();
+      flag = (ping_db - block_db) < thr;
+    }
+  };
+
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  T pre[kAttPre];
+  int pre_q = -1, pre_up = -1, pre_L = -1;  // what `pre` holds: ping, layer
+  for (int p = p0; p < p1; ++p) {
+    const int up = lim[p - p0][0], lw = lim[p - p0][1];
+    bool flag = false;
+    if (p - n >= 0 && (long long)p + n <= (long long)P - 1 && lw > up) {
+      const int L = lw - up;
+      if ((long long)W * L > ring_cap || L > kAttPre * kBlock) {  // block beyond the ring
+        __syncthreads();
+        valid = false;
+        sweep(p, up, L, flag);
+      } else {
+        const unsigned short* slot = ring + (size_t)(p % W) * L;  // the ping's own codes
+        auto count_own = [&]() {
+          for (int i = threadIdx.x; i < L; i += kBlock) {
+            const unsigned code = slot[i];
+            if (code != 0xffffu) atomicAdd(&sc.small[code >> 8], 1u);
+          }
+        };
+        sc.small[threadIdx.x] = 0u;  // (the step before ended on a barrier behind its last reads of these)
+        sc.sub_own[threadIdx.x] = 0u;
+        sc.sub_own[threadIdx.x + 256] = 0u;
+        sc.sub_blk[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) {
+          sc.ncand = 0u;
+          sc.overflow = 0u;
+        }
+        if (valid && up == w_up && lw == w_lw && w_lo == p - n - 1) {  // slide by one ping
+          if (!(pre_q == p + n - 1 && pre_up == up && pre_L == L)) fetch(p + n - 1, up, L, pre);
+          leave(p - n - 1, L);
+          __syncthreads();  // the leaving ping's slot is the entering ping's
+          enter(p + n - 1, L, pre);
+          if (n == 1) __syncthreads();  // (the entering ping is ping p itself)
+          count_own();
+        } else {  // (re)build the block
+          __syncthreads();
+          for (int i = threadIdx.x; i < kAttBins; i += kBlock) sc.hist[i] = 0u;
+          __syncthreads();
+          for (int q = p - n; q < p + n; ++q) {
+            fetch(q, up, L, pre);
+            enter(q, L, pre);
+          }
+          __syncthreads();
+          count_own();
+        }
+        valid = true;
+        w_up = up; w_lw = lw; w_lo = p - n;
+        // the ping that enters at the next step, requested now (its latency hides behind the medians of this step)
+        pre_q = p + n; pre_up = up; pre_L = L;
+        fetch(pre_q, up, L, pre);
+        __syncthreads();
+        // ---- first level: the ping's own layer by the top 8 bits of its codes, the block by its running 12-bit histogram
+        unsigned nv, nv2;
+        att_locate2<1, kAttBins / 256, true>(sc.small, sc.hist, &sc, 0, 2, nv, nv2);
+        __syncthreads();
+        if (nv && nv2) {
+          const int o0 = sc.bin[0], o1 = sc.bin[1], b0 = sc.bin[2], b1 = sc.bin[3];
+          // ---- second level: the remaining low bits inside the selected bins.  The ring is swept eight codes per
+          // 128-bit LDS read with packed 16-bit tests (no code lies strictly between two adjacent order statistics, so
+          // one range test per code is exact); a position is decoded only for the few codes that match
+          auto sweep_ring = [&](unsigned lo, unsigned hi, auto hit) {
+            const int total = W * L, first = (p - n) % W;
+            const unsigned short l16 = (unsigned short)lo, span1 = (unsigned short)(hi - lo + 1u);
+            const us2 lo2 = {l16, l16}, sp2 = {span1, span1};
+            const uint4* r4 = reinterpret_cast<const uint4*>(ring);
+            for (int i8 = threadIdx.x; i8 * 8 < total; i8 += kBlock) {
+              const uint4 v = r4[i8];
+              const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const us2 d = __builtin_bit_cast(us2, w[k]) - lo2;
+                const us2 m = __builtin_elementwise_min(d, sp2);
+                if (__builtin_bit_cast(unsigned, m) != __builtin_bit_cast(unsigned, sp2)) {
+#pragma unroll
+                  for (int hbit = 0; hbit < 2; ++hbit) {
+                    const unsigned code = hbit ? (w[k] >> 16) : (w[k] & 0xffffu);
+                    const int i = i8 * 8 + 2 * k + hbit;
+                    if (code - lo <= hi - lo && i < total) {
+                      const int sl = i / L, idx = i - sl * L;
+                      hit(code, p - n + (sl - first + W) % W, idx);
+                    }
+                  }
+                }
+              }
+            }
+          };
+          // (the NaN code 0xffff shares the last 12-bit bin with values at the clamp: the range stops before it)
+          sweep_ring((unsigned)b0 << 4, min(((unsigned)b1 << 4) | 15u, 0xfffeu), [&](unsigned code, int, int) {
+            atomicAdd(&sc.sub_blk[((int)(code >> 4) == b0 ? 0u : 16u) + (code & 15u)], 1u);
+          });
+          for (int i = threadIdx.x; i < L; i += kBlock) {
+            const unsigned code = slot[i];
+            if (code != 0xffffu) {
+              const int ho = (int)(code >> 8);
+              if (ho == o0) atomicAdd(&sc.sub_own[code & 255u], 1u);
+              else if (ho == o1) atomicAdd(&sc.sub_own[256u + (code & 255u)], 1u);
+            }
+          }
+          // (two selected bins: the second one's ranks continue after the first one's members)
+          const unsigned ko0 = sc.rank[0], ko1 = o1 == o0 ? sc.rank[1] : sc.small[o0] + sc.rank[1];
+          const unsigned kb0 = sc.rank[2], kb1 = b1 == b0 ? sc.rank[3] : sc.hist[b0] + sc.rank[3];
+          __syncthreads();
+          unsigned d0, d1;
+          att_locate2<2, 1, false>(sc.sub_own, sc.sub_blk, &sc, 4, 6, d0, d1, ko0, ko1, kb0, kb1);
+          __syncthreads();
+          unsigned tag[4], crank[4];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int io = sc.bin[4 + e], ib = sc.bin[6 + e];
+            tag[e] = 0x10000u | ((unsigned)(io < 256 ? o0 : o1) << 8) | (unsigned)(io & 255);
+            tag[2 + e] = ((unsigned)(ib < 16 ? b0 : b1) << 4) | (unsigned)(ib & 15);
+            crank[e] = sc.rank[4 + e];
+            crank[2 + e] = sc.rank[6 + e];
+          }
+          // ---- the values of exactly those codes, re-read by position; ranks settled among them
+          auto take = [&](unsigned code, int q, int idx, unsigned set) {
+            const unsigned long long key = sort_key((double)cb[(size_t)q * S + up + idx]);
+            const unsigned at = atomicAdd(&sc.ncand, 1u);
+            if (at < (unsigned)kAttCand) { sc.cand[at] = key; sc.ctag[at] = set | code; }
+            else sc.overflow = 1u;
+          };
+          sweep_ring(tag[2], tag[3], [&](unsigned code, int q, int idx) { take(code, q, idx, 0u); });
+          const unsigned oc0 = tag[0] & 0xffffu, oc1 = tag[1] & 0xffffu;
+          for (int i = threadIdx.x; i < L; i += kBlock) {
+            const unsigned code = slot[i];
+            if (code == oc0 || code == oc1) take(code, p, i, 0x10000u);
+          }
+          __syncthreads();
+          if (sc.overflow) {  // hundreds of values within 0.004 dB of the median: the sweeping path settles it
+            valid = false;
+            __syncthreads();
+            sweep(p, up, L, flag);
+            __syncthreads();
+          } else {
+            att_rank(&sc, tag, crank);
+            const T ping_db = (T)(10.0 * epa::fast_log10(median_lin(0), mt.log_tab));
+            const T block_db = (T)(10.0 * epa::fast_log10(median_lin(2), mt.log_tab));
+            flag = (ping_db - block_db) < thr;
+          }
+        }
+      }
+    } else {
+      valid = false;
+    }
+    uint8_t* m = mb + (size_t)p * S;
+    const unsigned f4 = flag ? 0x01010101u : 0u;
+    for (int s = 4 * threadIdx.x; s < S; s += 4 * kBlock) *reinterpret_cast<unsigned*>(m + s) = f4;  // S % 4 == 0
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // pooled Sv by VALUE windows (pool_Sv, clean/utils.py:29-106): for every sample at depth d in ping p
 // the aggregate of the linear Sv over pings p-n..p+n and depths [d - bin, d + bin], where feasible.
 // The range variable must be non-decreasing along range_sample with NaN only as a tail
@@ -1676,8 +2060,45 @@ extern "C" int epa_attenuated_mask(const void* sv, const void* range, int C, int
   EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_attenuated_mask: sizes must be positive");
   EPA_CHECK_ARG(num_side_pings >= 0, "epa_attenuated_mask: num_side_pings must be >= 0");
   EPA_CHECK_ARG(dtype == EPA_F32 || dtype == EPA_F64, "epa_attenuated_mask: bad dtype %d", dtype);
-  const long long rows = (long long)C * P;
   hipStream_t st = (hipStream_t)stream;
+  if (num_side_pings >= 1 && S >= 8 && S % 4 == 0 && (reinterpret_cast<uintptr_t>(mask_out) & 3u) == 0) {
+    // block medians carried from ping to ping: layer limits of every ping first (stashed in the mask rows), then the walk
+    const long long rows = (long long)C * P;
+    // pings per workgroup: every chunk pays 2n pings of warm-up, and the workgroups run in rounds of two per CU -- the
+    // length in [64, kAttChunkMax] with the fewest sequential steps (rounds x (length + 2n)) is taken
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      cus = 256;
+    const long long slots = 2ll * std::max(cus, 1);
+    int chunk_len = std::min(P, kAttChunkMax);
+    long long best = -1;
+    for (int len = std::min(P, kAttChunkMax); len >= std::min(P, 64); --len) {
+      const long long wgs = (long long)C * ((P + len - 1) / len);
+      const long long steps = ((wgs + slots - 1) / slots) * (len + 2ll * num_side_pings);
+      if (best < 0 || steps < best) {
+        best = steps;
+        chunk_len = len;
+      }
+    }
+    const int nchunks = (P + chunk_len - 1) / chunk_len;
+    const int ring_cap = 20480;  // u16 codes: 2 n x layer length up to this, longer blocks take the sweeping path
+    static_assert(sizeof(SelectScratch) <= 20480 * 2, "the sweeping path's scratch borrows the ring");
+    const size_t lds = epa::kMathTabBytes + (size_t)ring_cap * 2;
+    const dim3 grid((unsigned)((long long)C * nchunks));
+    if (dtype == EPA_F64) {
+      hipLaunchKernelGGL(attenuated_limits_kernel<double>, dim3(row_grid(rows)), dim3(kBlock), 0, st, (const double*)range, S,
+                         rows, upper_limit, lower_limit, mask_out);
+      hipLaunchKernelGGL(attenuated_slide_kernel<double>, grid, dim3(kBlock), lds, st, (const double*)sv, P, S, nchunks,
+                         chunk_len, num_side_pings, threshold, ring_cap, mask_out);
+    } else {
+      hipLaunchKernelGGL(attenuated_limits_kernel<float>, dim3(row_grid(rows)), dim3(kBlock), 0, st, (const float*)range, S,
+                         rows, (float)upper_limit, (float)lower_limit, mask_out);
+      hipLaunchKernelGGL(attenuated_slide_kernel<float>, grid, dim3(kBlock), lds, st, (const float*)sv, P, S, nchunks,
+                         chunk_len, num_side_pings, (float)threshold, ring_cap, mask_out);
+    }
+    return epa::check_launch("attenuated_slide_kernel");
+  }
+  const long long rows = (long long)C * P;
   if (dtype == EPA_F64)
     hipLaunchKernelGGL(attenuated_mask_kernel<double>, dim3(row_grid(rows)), dim3(kBlock), 0, st,
                        (const double*)sv, (const double*)range, P, S, rows, upper_limit, lower_limit,

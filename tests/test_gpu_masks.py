@@ -164,6 +164,27 @@ def test_attenuated_mask_reference_goldens(env, gold):
                                       err_msg=f"case {i}")
 
 
+@pytest.mark.parametrize("n", [1, 6, 15])
+def test_attenuated_mask_sliding_blocks_vs_oracle(env, n):
+    """The block median carried from ping to ping (attenuated_slide_kernel): several 128-ping chunks, layer limits
+    that change along the pings (a platform that sinks by one range step every 90 pings), runs of NaN pings, runs of
+    equal values (more candidates in the median's bin than its LDS list holds -> the sweeping path), -inf samples,
+    attenuated pings on both sides of the threshold."""
+    torch, ops = env
+    C, P, S = 2, 420, 260
+    rng = np.random.default_rng(100 + n)
+    sv, depth = _scene(C, P, S, 100 + n, step=0.5, spikes=False)
+    depth = depth[:, :1, :] + 0.5 * (np.arange(P) // 90)[None, :, None]      # identical rows that shift in steps
+    sv[:, rng.random(P) < 0.15, :] -= rng.uniform(2, 9)                      # attenuated pings
+    sv[0, 100:104, :] = np.nan
+    sv[1, 200:260, 40:200] = -63.25                                          # ~10 000 equal values in a block
+    sv[0, 300, 50:90] = -np.inf
+    got = ops.attenuated_mask(_dev(torch, sv), _dev(torch, depth), 30.0, 110.0, n, -4.0).cpu().numpy().astype(bool)
+    exp = np.stack([omask.echopy_attenuated_signal_mask(sv[c], depth[c], 30.0, 110.0, n, -4.0) for c in range(C)])
+    np.testing.assert_array_equal(got, exp)
+    assert exp.any() and not exp.all()
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_attenuated_mask_vs_oracle(env, dtype):
     torch, ops = env
