@@ -568,12 +568,12 @@ def main():
     elif args.workload:
         todo = [args.workload]
     else:
-        todo = (["cfg2"] if args.only_headline else ["cfg3", "cfg4", "cfg5", "cfg2"])
+        todo = (["cfg2"] if args.only_headline else ["cfg3", "cfg4", "cfg4:f32", "cfg5", "cfg2"])
     # CPU baselines first: they fork worker processes, which must happen before HIP is initialised
     cpu = {}
     if world == 1 and not args.no_cpu_baseline:
         for w in todo:
-            kind = {"cfg3": "chain", "cfg4": "bb", "cfg4small": "bb"}.get(w, "ek60")
+            kind = {"cfg3": "chain", "cfg4": "bb", "cfg4small": "bb"}.get(w.partition(":")[0], "ek60")
             if kind not in cpu:
                 cpu[kind] = (cpu_baseline_bb() if kind == "bb" else
                              cpu_baseline_ek60(chain=kind == "chain", multicore=kind == "ek60"))
@@ -589,7 +589,12 @@ def main():
             dist.init_process_group("gloo")
     ctx = Ctx(args, world, rank)
     for w in todo:
+        w, _, other_dtype = w.partition(":")  # "cfg4:f32": the same workload with float32 output (complex64 transform)
         kind = {"cfg3": "chain", "cfg4": "bb", "cfg4small": "bb"}.get(w, "ek60")
+        asked = args.dtype
+        if other_dtype:
+            args.dtype = {"f32": "float32", "f64": "float64"}[other_dtype]
+            ctx.dt = torch.float64 if args.dtype == "float64" else torch.float32
         if w == "cfg5":
             out = run_cfg5(ctx, cpu.get(kind))
         elif w.startswith("cfg4"):
@@ -599,6 +604,8 @@ def main():
         if rank == 0 and out is not None:
             print(json.dumps(out), flush=True)
         ctx.free()
+        args.dtype = asked
+        ctx.dt = torch.float64 if asked == "float64" else torch.float32
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -271,10 +271,18 @@ constexpr int kStatSlots = 1024;
 __host__ __device__ inline size_t ws_stats(int C) { return 768 + 4 * (size_t)C + (size_t)C * 3 * kN; }
 //   then                [1 double] counter of deferred (partly-NaN) tiles, then one bit per tile
 __host__ __device__ inline size_t ws_mixed(int C) { return ws_stats(C) + 3 * kStatSlots; }
+//   then                per channel {ra, rb, shift, 2 alpha of its first ping} + S values of the time-varied gain
+//                       n log10(R') + 2 alpha R' (tvg_table_kernel)
+__host__ __device__ inline size_t ws_tvg(int C, int P, int S) {
+  return ws_mixed(C) + 2 + ((size_t)C * (size_t)P * ((size_t)S / (kN / 2 + 1) + 1) + 63) / 64;
+}
+//   then                the 128 x {1/c, log10 c} table of fast_log10 (fast_math.h), copied to LDS by every workgroup
+__host__ __device__ inline size_t ws_logtab(int C, int P, int S) { return ws_tvg(C, P, S) + (size_t)C * ((size_t)S + 4); }
 
 __global__ __launch_bounds__(epa::kBlock) void replica_prepare_kernel(const float* __restrict__ replica,
                                                                       const int32_t* __restrict__ off, int C,
-                                                                      double* __restrict__ ws, int init_stats) {
+                                                                      double* __restrict__ ws, int init_stats,
+                                                                      double* __restrict__ log_tab_out) {
   __shared__ __attribute__((aligned(16))) unsigned char xs[Xs<double>::kBytes];
   __shared__ C2<double> tw[256];
   __shared__ double red[4];
@@ -283,6 +291,13 @@ __global__ __launch_bounds__(epa::kBlock) void replica_prepare_kernel(const floa
   if (j == 0) {
     tap_lo = kN;
     tap_hi = 0;
+  }
+  if (c == 0 && j < epa::kLogTabN) {  // as build_math_tabs
+    const double cc = 1.0 + ((double)j + 0.5) * (1.0 / epa::kLogTabN);
+    const double inv = 1.0 / cc;
+    double lg = -::log10(inv);
+    if (cc > 1.4142135623730951) lg -= 0.30102999566398120;
+    reinterpret_cast<double2*>(log_tab_out)[j] = make_double2(inv, lg);
   }
   if (init_stats && c == 0) {
     double* sp = ws + ws_stats(C);
@@ -372,6 +387,8 @@ struct FftArgs {
   unsigned* mixed_map;  // bit per tile (linear id (c * P + p) * tiles + tile): the tile holds a partly-NaN sample
   unsigned* mixed_cnt;  // number of bits set
   int map_words;
+  const double* tvg;  // [C][4 + S], see ws_tvg
+  const double* log_tab;  // see ws_logtab
 };
 
 // sector sum (or one sector when only >= 0) + validity bits of sample s (bits 0..B-1 sector valid, bit 8: beam-0
@@ -472,6 +489,31 @@ struct TileLds {
 // One tile.  MIXED = false: the fast form (sector sum; a tile that turns out to hold a partly-NaN sample is
 // recorded in the bitmap and left to the MIXED = true pass, which convolves one sector at a time).
 // Returns false when the tile was deferred.
+// The time-varied gain n log10(R') + 2 alpha R' depends on the sample index and on four per-ping numbers that a file
+// almost never changes from ping to ping (sample interval, sound speed, pulse length, absorption).  Tabulated once per
+// channel for its first ping's numbers (double output only) -- with the roundings of the per-sample form -- it turns
+// one of the two logarithms of a sample into an 8-byte read from L2; a ping with other numbers takes the per-sample form.
+template <typename T>
+__global__ __launch_bounds__(epa::kBlock) void tvg_table_kernel(const double* __restrict__ ccoef, int P, int S,
+                                                                double nspread, double* __restrict__ tvg) {
+  const int c = blockIdx.y, s = blockIdx.x * epa::kBlock + threadIdx.x;
+  const double* cc = ccoef + (size_t)c * P * EPA_NCCOEF;
+  double* tab = tvg + (size_t)c * (S + 4);
+  const double ra = cc[EPA_CC_RA], rb = cc[EPA_CC_RB], shift = cc[EPA_CC_SHIFT], alpha2 = cc[EPA_CC_ALPHA2];
+  if (s == 0) {
+    tab[0] = ra;
+    tab[1] = rb;
+    tab[2] = shift;
+    tab[3] = alpha2;
+  }
+  if (s < S) {
+    const double R = ((double)s * ra) * rb;
+    T rt = sub_rn((T)R, (T)shift);
+    if (!(rt > (T)0)) rt = epa::M<T>::nan();
+    tab[4 + s] = (double)((T)nspread * epa::M<T>::log10(rt) + (T)alpha2 * rt);
+  }
+}
+
 template <typename InT, typename T, typename F, int NB, bool MIXED>
 __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, T>& L, const LaneMap& lm, int c, int p,
                                              int tile) {
@@ -582,6 +624,11 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
   const double inv_norm = 1.0 / chan[0];
   const double inv_norm_b = inv_norm / (double)B;  // every sector valid (the only case of the fast form)
   const epa::LogCoef lk = epa::make_log_coef();
+  const double* tkey = a.tvg + (size_t)c * (S + 4);
+  const double* tvg_tab = tkey + 4;
+  // (float output: the hardware logarithm is cheaper than the read -- measured; the table is not built then)
+  const bool tabulated = sizeof(T) == 8 && ((tkey[0] == ra) & (tkey[1] == rb) & (tkey[2] == cc[EPA_CC_SHIFT]) &
+                                            (tkey[3] == cc[EPA_CC_ALPHA2]));
   T* out = reinterpret_cast<T*>(a.out);
   T* range_out = reinterpret_cast<T*>(a.range_out);
   T* prx_out = reinterpret_cast<T*>(a.prx_out);
@@ -605,11 +652,16 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
       T prx = pscale * (mr * mr + mi * mi);
       if (!(prx > (T)0)) prx = epa::M<T>::nan();
       const double R = ((double)s * ra) * rb;  // range.py:138 operation order
-      T rt = sub_rn((T)R, shift);              // never contracted with the range product into an fma
-      if (!(rt > (T)0)) rt = epa::M<T>::nan();
-      // prx and rt are positive or NaN here: the lean log (zero / subnormal / inf / NaN through a rare branch)
-      const T val = (T)10 * epa::fast_log10_lean(prx, L.log_tab, lk) + nspread * epa::fast_log10_lean(rt, L.log_tab, lk) +
-                    alpha2 * rt + Aadd;
+      T tvg;
+      if (tabulated) {  // (block-uniform)
+        tvg = (T)tvg_tab[s];
+      } else {
+        T rt = sub_rn((T)R, shift);  // never contracted with the range product into an fma
+        if (!(rt > (T)0)) rt = epa::M<T>::nan();
+        tvg = nspread * epa::fast_log10_lean(rt, L.log_tab, lk) + alpha2 * rt;
+      }
+      // prx (and rt) are positive or NaN here: the lean log (zero / subnormal / inf / NaN through a rare branch)
+      const T val = ((T)10 * epa::fast_log10_lean(prx, L.log_tab, lk) + tvg) + Aadd;
       const size_t o = row * S + s;
       out[o] = val;
       if (range_out) {
@@ -669,13 +721,7 @@ void sv_complex_fft_kernel(FftArgs a) {
   if (MIXED && *a.mixed_cnt == 0u) return;  // the usual case: no tile was deferred
 
   tw[j] = reinterpret_cast<const C2<F>*>(a.ws + (sizeof(F) == 4 ? ws_tw32() : ws_tw64()))[j];
-  if (sizeof(T) == 8 && j < epa::kLogTabN) {
-    const double cc = 1.0 + ((double)j + 0.5) * (1.0 / epa::kLogTabN);
-    const double inv = 1.0 / cc;
-    double lg = -::log10(inv);
-    if (cc > 1.4142135623730951) lg -= 0.30102999566398120;
-    log_tab[j] = make_double2(inv, lg);
-  }
+  if (sizeof(T) == 8 && j < epa::kLogTabN) log_tab[j] = reinterpret_cast<const double2*>(a.log_tab)[j];
   const LaneMap lm = lane_map();
   const TileLds<F, T> L{xs, tw, nzw, wp, wflags, log_tab, sred};
   if (!MIXED) {
@@ -736,7 +782,7 @@ extern "C" int epa_sv_complex_fft(const void* re, const void* im, int in_dtype, 
   }
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(replica_prepare_kernel, dim3(C), dim3(epa::kBlock), 0, st, replica, replica_off, C, workspace,
-                     range_stats_out ? 1 : 0);
+                     range_stats_out ? 1 : 0, workspace + ws_logtab(C, P, S));
   if (int rc = epa::check_launch("replica_prepare_kernel")) return rc;
   FftArgs a{};
   a.re = re; a.im = im; a.ccoef = ccoef; a.ws = workspace;
@@ -752,6 +798,16 @@ extern "C" int epa_sv_complex_fft(const void* re, const void* im, int in_dtype, 
   a.mixed_cnt = reinterpret_cast<unsigned*>(workspace + ws_mixed(C));
   a.mixed_map = a.mixed_cnt + 2;
   EPA_CHECK_HIP(hipMemsetAsync(a.mixed_cnt, 0, 8 + 4 * (size_t)a.map_words, st));
+  double* tvg = workspace + ws_tvg(C, P, S);
+  a.tvg = tvg;
+  a.log_tab = workspace + ws_logtab(C, P, S);
+  {
+    const dim3 tg((unsigned)((S + epa::kBlock - 1) / epa::kBlock), (unsigned)C);
+    if (out_dtype == EPA_F64) {
+      hipLaunchKernelGGL(tvg_table_kernel<double>, tg, dim3(epa::kBlock), 0, st, ccoef, P, S, a.nspread, tvg);
+      if (int rc2 = epa::check_launch("tvg_table_kernel")) return rc2;
+    }
+  }
   int rc;
 #define EPA_FFT_CASE(IN, OUT, FF) rc = launch_fft<IN, OUT, FF>(a, st)
   const int key = (in_dtype == EPA_F64 ? 4 : 0) | (out_dtype == EPA_F64 ? 2 : 0) | (fft_dtype == EPA_F64 ? 1 : 0);

@@ -303,13 +303,16 @@ int epa_sv_complex(const void* re, const void* im, int in_dtype, const float* re
  *                EPA_F32: complex64 butterflies, errors ~3e-7 of the tile's strongest echo -- for float32 output.
  *   workspace  : f64 [EPA_EK80_FFT_WS_DOUBLES(C, P, S)] (twiddles; ||tx||^2, span of the non-zero taps and
  *                conj(FFT(tx))/N per channel; range-statistics slots; one bit per tile marking tiles with a
- *                partly-NaN sample, which a second launch redoes sector by sector; rebuilt by every call)
+ *                partly-NaN sample, which a second launch redoes sector by sector; the time-varied gain
+ *                n log10(R') + 2 alpha R' of each channel's first ping by sample index, read instead of computed
+ *                by every ping with the same range numbers; the logarithm's lookup table; rebuilt by every call)
  *   range_stats_out : optional f64 [3] = {nanmin, nanmax, NaN count} of the echo_range written to range_out, a
  *                by-product of the same pass (what compute_MVBS, commongrid/api.py:108-110, asks next) */
 #define EPA_EK80_NFFT 2048
 #define EPA_EK80_FFT_WS_DOUBLES(C, P, S)                                              \
   (768 + 4 * (size_t)(C) + 3 * (size_t)(C) * EPA_EK80_NFFT + 3 * 1024 + 2 +          \
-   ((size_t)(C) * (size_t)(P) * ((size_t)(S) / (EPA_EK80_NFFT / 2 + 1) + 1) + 63) / 64)
+   ((size_t)(C) * (size_t)(P) * ((size_t)(S) / (EPA_EK80_NFFT / 2 + 1) + 1) + 63) / 64 + \
+   (size_t)(C) * ((size_t)(S) + 4) + 256)
 int epa_sv_complex_fft(const void* re, const void* im, int in_dtype, const float* replica,
                        const int32_t* replica_off, int max_taps, const double* ccoef, int C, int P,
                        int S, int B, int cal_type, void* out, void* range_out, void* prx_out,

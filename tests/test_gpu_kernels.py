@@ -481,6 +481,8 @@ def test_sv_complex_fft_path_matches_direct(env, in_dtype, out_dtype, fft_dtype,
     off = _dev(torch, np.array([0, lens[0], lens[0] + lens[1]], dtype=np.int32))
     cc = np.zeros((C, P, 8))
     cc[..., 0], cc[..., 1], cc[..., 2], cc[..., 3], cc[..., 4], cc[..., 5] = 2.6e-5, 750.0, 0.2, 0.02, -30.0, 1e3
+    # the last ping with its own sound speed / absorption: it leaves the per-channel time-varied-gain table
+    cc[0, 2, 1], cc[1, 2, 3] = 751.5, 0.021
     kw = dict(replica=repf, replica_off=off, max_taps=taps, dtype=getattr(torch, out_dtype), want_prx=True)
     args = (_dev(torch, re), _dev(torch, im), _dev(torch, cc))
     d = ops.sv_complex(*args, method="direct", **kw)
