@@ -249,7 +249,10 @@ def line(ctx, *, value, steps, warmup, elapsed, scaling, workload, config, roofl
     out = {"metric": metric, "value": value, "unit": "range-samples/s", "n_gpus": ctx.world, "steps": steps,
            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": scaling,
            "vs_baseline": None, "dtype": "f64" if ctx.args.dtype == "float64" else "f32", "data": "synthetic",
-           "config": {"workload": workload, **config}, "roofline": roofline}
+           "config": {"workload": workload, **config,
+                      "synthetic_data": "10 % of pings short and NaN-padded; the recorded sound speed follows a slow "
+                                        "drift (EK60: a new value every 2000 pings, EK80: every ping)"},
+           "roofline": roofline}
     if cpu is not None:
         out["cpu_baseline"] = cpu
     return out

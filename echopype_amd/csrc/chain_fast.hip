@@ -15,6 +15,8 @@
 // d = -r0/k, cached per column.  Same arithmetic as the generic kernel (tests hold the two to <= 1e-9).
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#include <cstdlib>
+
 #include "fast_math.h"
 #include "sample_math.h"
 
@@ -35,6 +37,7 @@ struct Args {
   unsigned cnt_off, tab_off;
   unsigned long long* rmax_key;
   unsigned long long* mm_keys;  // pass 2, optional [4]: min/max of Sv_noise, min/max of Sv_corrected
+  int flagged_only;  // pass 2, general kernel after the uniform-group kernel: only the groups that one left (kLeftToGeneral)
 };
 
 __device__ __forceinline__ unsigned long long ordered_key(double v) {
@@ -339,6 +342,10 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
 // ------------------------------------------------------------------------------------------------
 // pass 2
 // ------------------------------------------------------------------------------------------------
+// written by the uniform-group kernel into the first MVBS cell of a group it leaves to the general kernel (a NaN
+// payload no computation produces; the general kernel overwrites it)
+constexpr unsigned long long kLeftToGeneral = 0x7ff8dead0c0ffee1ull;
+
 template <typename T>
 struct BinCol : ColBase<T> {
   double blo, bhi;  // edges of the range bin the column currently sits in (empty: blo > bhi)
@@ -371,6 +378,9 @@ __global__ __launch_bounds__(epa::kBlock, 3) void sv_denoise_mvbs_fast_kernel(
   // blockIdx.x == n_tbins: pings that belong to no time bin still get their Sv_noise / Sv_corrected
   const bool extra = tb == a.n_tbins;
   if (extra && !(WRITE_NOISE || WRITE_CORR)) return;
+  if (a.flagged_only && !extra &&
+      reinterpret_cast<const unsigned long long*>(mvbs_out + ((size_t)c * a.n_tbins + tb) * n_rbins)[0] != kLeftToGeneral)
+    return;  // (uniform) the group was done by sv_denoise_mvbs_uniform_kernel
   const int nseg = extra ? 2 : 1;
   for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
     lsum[i] = (T)0;
@@ -546,6 +556,205 @@ __global__ __launch_bounds__(epa::kBlock, 3) void sv_denoise_mvbs_fast_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pass 2, fp64, ping groups whose pings share ONE range vector and ONE absorption (the sample interval, sound speed,
+// pulse length and absorption of a file rarely change from ping to ping).  Then everything that depends on the range is
+// a per-column constant of the group -- the spreading and absorption factors of the linear Sv, the linear noise shape,
+// the transmission loss in dB, the range bin -- and a sample costs one exp10 (of g raw), one log10 and a few multiplies:
+//   lin(Sv)       = 10^(g raw/10) . [ (s - d)^(n/10) E(s) ] . C_sv(ping)          E(s) = 10^(a2 k s / 10)
+//   lin(Sv_noise) = C_n(ping) . [ max(R, 1)^2 E(s) ]
+//   Sv_noise      = noise(ping) + [ 20 log10 max(R, 1) + a2 R ]
+// (brackets: per column; C_sv, C_n as PingConst).  A workgroup that finds its group not uniform (or longer than
+// kUniPings) marks the group's first MVBS cell and leaves it to sv_denoise_mvbs_fast_kernel, launched right after.
+// ------------------------------------------------------------------------------------------------
+constexpr int kUniPings = 256;
+struct PingLin {
+  double g, csv, cn, nb;
+};
+
+__device__ __forceinline__ double vmin_f64(double a, double b) {  // IEEE minNum / maxNum without the canonicalising copy
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmax_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+template <bool WRITE_NOISE, bool WRITE_CORR, bool MINMAX>
+__global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_uniform_kernel(
+    const float* __restrict__ raw, const epa::CoefRow* __restrict__ coef, const double* __restrict__ alpha2,
+    const double* __restrict__ noise, const int32_t* __restrict__ bin_start, double* __restrict__ noise_out,
+    double* __restrict__ corr_out, double* __restrict__ mvbs_out, double* __restrict__ sum_out,
+    uint32_t* __restrict__ cnt_out, Args a) {
+  typedef double T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* lsum = reinterpret_cast<T*>(smem);
+  uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + a.cnt_off);
+  const epa::MathTabs mt = epa::build_math_tabs(smem + a.tab_off);
+  __shared__ PingLin pl[kUniPings];
+  __shared__ int differs;
+
+  const int c = blockIdx.y, tb = blockIdx.x;
+  const int S = a.S, n_rbins = a.n_rbins;
+  const int pb = bin_start[tb], pe = bin_start[tb + 1], np = pe - pb;
+  const size_t cell0 = ((size_t)c * a.n_tbins + tb) * n_rbins;
+  for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
+    lsum[i] = (T)0;
+    lcnt[i] = 0u;
+  }
+  if (threadIdx.x == 0) differs = np > kUniPings ? 1 : 0;
+  __syncthreads();  // (also publishes the math tables)
+  const epa::CoefRow* __restrict__ rowp0 = coef + (size_t)c * a.P;
+  const double* __restrict__ a2p = alpha2 + (size_t)c * a.P;
+  const double* __restrict__ nzp = noise + (size_t)c * a.n_pblocks;
+  const epa::CoefRow r = rowp0[np > 0 ? pb : 0];
+  const double na2 = a2p[np > 0 ? pb : 0];
+  if ((int)threadIdx.x < min(np, kUniPings)) {
+    const int p = pb + threadIdx.x;
+    const epa::CoefRow ri = rowp0[p];
+    const double a2i = a2p[p];
+    const bool same = (ri.ra == r.ra) & (ri.rb == r.rb) & (ri.r0 == r.r0) & (ri.shift == r.shift) & (ri.d == r.d) &
+                      (a2i == na2) & (ri.alpha2 == a2i);
+    if (!same) differs = 1;
+    const double nbi = nzp[p / a.noise_ping_num];
+    pl[threadIdx.x] = PingLin{ri.g, epa::lin_from_db(ri.A0 - ri.alpha2 * ri.shift + ri.alpha2 * ri.r0, mt.exp2_tab),
+                              epa::lin_from_db(nbi + a2i * ri.r0, mt.exp2_tab), nbi};
+  }
+  __syncthreads();
+  if (differs) {
+    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(mvbs_out + cell0)[0] = kLeftToGeneral;
+    return;
+  }
+
+  const T nspread = (T)a.nspread, snr = (T)a.snr;
+  const double k = r.ra * r.rb, a2k = na2 * k;
+  const double dtl = r.r0 == 0.0 ? 0.0 : -r.r0 / k;  // EK rows: echo_range starts at 0
+  const T log10k = log10_pos((T)k, mt.log_tab);
+  const epa::LogCoef lk = epa::make_log_coef();
+  const float* __restrict__ raw_c = raw + (size_t)c * a.P * S;
+  T* __restrict__ sn_c = WRITE_NOISE ? noise_out + (size_t)c * a.P * S : nullptr;
+  T* __restrict__ sc_c = WRITE_CORR ? corr_out + (size_t)c * a.P * S : nullptr;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double mm[4] = {__builtin_inf(), -__builtin_inf(), __builtin_inf(), -__builtin_inf()};
+
+  for (int chunk0 = 0; chunk0 < S; chunk0 += kChunk) {
+    const int sA = chunk0 + wave * 256 + 2 * lane, sB = sA + 128;
+    if (sA >= S) continue;
+    const bool hasB = sB < S;
+    // ---- the group's per-column constants
+    T c2E[VEC], xxE[VEC], sncol[VEC], acc_sum[VEC];
+    int rbin[VEC];
+    uint32_t acc_cnt[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const double sj = (double)((j < 2 ? sA : sB) + (j & 1));
+      const double x = (sj * r.ra) * r.rb + r.r0;  // echo_range (range.py:138 operation order)
+      const double rtd = x - r.shift;              // R' <= 0 -> NaN (calibrate_ek.py:107)
+      const T v = (T)(sj - r.d), v2 = v * v;
+      T c2 = v > (T)0 ? (nspread == (T)20 ? v2 : v2 * v2) : (T)0;
+      if ((rtd > 0.0) & !(c2 > (T)0)) {  // rounding residue of R - shift (rare): the range itself
+        const T w = (T)(rtd / k), w2 = w * w;
+        c2 = nspread == (T)20 ? w2 : w2 * w2;
+      }
+      c2 = rtd > 0.0 ? c2 : epa::M<T>::nan();
+      const T E = epa::lin_from_db_lean(a2k * sj, mt.exp2_tab);
+      const T mx = fmax((T)x, (T)1);
+      c2E[j] = c2 * E;
+      xxE[j] = (mx * mx) * E;
+      const T lgs = log10_slow((T)(sj - dtl), mt.log_tab);
+      sncol[j] = (T)20 * (x >= 1.0 ? lgs + log10k : (T)0) + (T)na2 * (T)x;
+      rbin[j] = epa::range_bin_index(x, a.range_bin, a.inv_range_bin, n_rbins, false);
+      acc_sum[j] = (T)0;
+      acc_cnt[j] = 0u;
+    }
+    float2 nA = make_float2(0.f, 0.f), nB = nA;
+    if (np > 0) {
+      nA = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sA);
+      if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sB);
+    }
+    for (int p = pb; p < pe; ++p) {
+      const size_t row_off = (size_t)p * S;
+      const float2 inA = nA, inB = nB;
+      if (p + 1 < pe) {
+        nA = *reinterpret_cast<const float2*>(raw_c + row_off + S + sA);
+        if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + row_off + S + sB);
+      }
+      const PingLin q = pl[p - pb];
+      const float in[VEC] = {inA.x, inA.y, inB.x, inB.y};
+      T sn[VEC], sc[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (j >= 2 && !hasB) break;
+        const bool xok = in[j] == in[j];
+        // a NaN sample needs no masking: it makes the exponential, hence lin, NaN by itself
+        const T e = epa::lin_from_db_lean(q.g * (T)in[j], mt.exp2_tab);
+        const T lin = fma(-q.cn, xxE[j], e * (c2E[j] * q.csv));
+        const T corr = lin > (T)0 ? (T)10 * epa::fast_log10_lean(lin, mt.log_tab, lk) : epa::M<T>::nan();
+        sn[j] = xok ? q.nb + sncol[j] : epa::M<T>::nan();  // echo_range is NaN where the input is
+        const bool keep = corr - sn[j] > snr;
+        sc[j] = keep ? corr : epa::M<T>::nan();
+        if (MINMAX) {
+          mm[0] = vmin_f64(mm[0], sn[j]);
+          mm[1] = vmax_f64(mm[1], sn[j]);
+          mm[2] = vmin_f64(mm[2], sc[j]);
+          mm[3] = vmax_f64(mm[3], sc[j]);
+        }
+        const bool take = (rbin[j] >= 0) & keep;  // keep implies a finite positive lin (and a valid input)
+        acc_sum[j] += take ? lin : (T)0;
+        acc_cnt[j] += take ? 1u : 0u;
+      }
+      if (WRITE_NOISE) {
+        epa::store_nt2(sn_c + row_off + sA, sn[0], sn[1]);
+        if (hasB) epa::store_nt2(sn_c + row_off + sB, sn[2], sn[3]);
+      }
+      if (WRITE_CORR) {
+        epa::store_nt2(sc_c + row_off + sA, sc[0], sc[1]);
+        if (hasB) epa::store_nt2(sc_c + row_off + sB, sc[2], sc[3]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      if (rbin[j] >= 0 && acc_cnt[j] > 0u) {
+        lds_add(lsum + rbin[j], acc_sum[j]);
+        atomicAdd(lcnt + rbin[j], acc_cnt[j]);
+      }
+    }
+  }
+  if (MINMAX) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mm[0] = fmin(mm[0], __shfl_down(mm[0], o, 64));
+      mm[1] = fmax(mm[1], __shfl_down(mm[1], o, 64));
+      mm[2] = fmin(mm[2], __shfl_down(mm[2], o, 64));
+      mm[3] = fmax(mm[3], __shfl_down(mm[3], o, 64));
+    }
+    if (lane == 0) {
+      if (mm[0] <= mm[1]) {
+        atomicMin(a.mm_keys + 0, ordered_key(mm[0]));
+        atomicMax(a.mm_keys + 1, ordered_key(mm[1]));
+      }
+      if (mm[2] <= mm[3]) {
+        atomicMin(a.mm_keys + 2, ordered_key(mm[2]));
+        atomicMax(a.mm_keys + 3, ordered_key(mm[3]));
+      }
+    }
+  }
+  __syncthreads();
+  T* out = mvbs_out + cell0;
+  T* gsum = sum_out ? sum_out + cell0 : nullptr;
+  uint32_t* gcnt = cnt_out ? cnt_out + cell0 : nullptr;
+  for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
+    const uint32_t n = lcnt[i];
+    const T s = lsum[i];
+    out[i] = n > 0u ? (T)10 * epa::M<T>::log10(s / (T)n) : (T)a.fill_value;
+    if (gsum) gsum[i] = s;
+    if (gcnt) gcnt[i] = n;
+  }
+}
+
 template <typename K>
 int set_lds(K kern, size_t lds) {
   if (lds > 64 * 1024)
@@ -582,6 +791,33 @@ int launch_pass2(Args& a, const float* raw, const double* coef, const double* al
   a.tab_off = (unsigned)((lds_acc_bytes + 15) & ~(size_t)15);
   const size_t lds = a.tab_off + epa::kMathTabBytes;
   const dim3 grid((unsigned)a.n_tbins + 1u, (unsigned)C);
+  a.flagged_only = 0;
+  static const bool uniform_off = [] {  // development knob: EPA_CHAIN_UNIFORM=0 leaves every group to the general kernel
+    const char* e = getenv("EPA_CHAIN_UNIFORM");
+    return e && e[0] == '0';
+  }();
+  if (sizeof(T) == 8 && a.n_tbins > 0 && a.n_rbins > 0 && !uniform_off) {
+    // uniform ping groups first; the general kernel then takes the groups that one left, and the pings outside every bin
+    const dim3 ugrid((unsigned)a.n_tbins, (unsigned)C);
+#define EPA_U2(N, K, M)                                                                                  \
+  do {                                                                                                   \
+    auto kern = sv_denoise_mvbs_uniform_kernel<N, K, M>;                                                 \
+    if (int rc = set_lds(kern, lds)) return rc;                                                          \
+    hipLaunchKernelGGL(kern, ugrid, dim3(epa::kBlock), lds, st, raw,                                     \
+                       reinterpret_cast<const epa::CoefRow*>(coef), alpha2, noise, bin_start,            \
+                       (double*)noise_out, (double*)corr_out, (double*)mvbs_out, (double*)sum_out, cnt_out, a); \
+  } while (0)
+#define EPA_U2M(N, K)                                                                                    \
+  do {                                                                                                   \
+    if (a.mm_keys) EPA_U2(N, K, true); else EPA_U2(N, K, false);                                         \
+  } while (0)
+    if (noise_out) { if (corr_out) EPA_U2M(true, true); else EPA_U2M(true, false); }
+    else { if (corr_out) EPA_U2M(false, true); else EPA_U2M(false, false); }
+#undef EPA_U2M
+#undef EPA_U2
+    if (int rc = epa::check_launch("sv_denoise_mvbs_uniform_kernel")) return rc;
+    a.flagged_only = 1;
+  }
 #define EPA_P2(N, K)                                                                                     \
   do {                                                                                                   \
     if (a.mm_keys) EPA_P2M(N, K, true); else EPA_P2M(N, K, false);                                       \

@@ -36,10 +36,12 @@ def _channels(C):
     return np.arange(C) % 4
 
 
-def ek60_params(C, P, vary_tau=False, seed=0, ping0=0):
+def ek60_params(C, P, vary_tau=False, seed=0, ping0=0, ss_every=1):
     """Per-channel / per-ping parameters of the synthetic EK60 file (host, O(C*P)).  ``ping0``: global index of
     the first ping when the arrays are a ping shard / tile of a longer file (ping times and the sound-speed drift
-    follow the global index)."""
+    follow the global index).  ``ss_every``: the sound speed an EK60 records with every ping is the operator's
+    setting -- it follows the slow drift in steps of this many pings (1: a new value every ping, the hardest case
+    for the kernels that cache per-range-column terms)."""
     ch = _channels(C)
     p = np.arange(P) + ping0
     si = np.full((C, P), 2.56e-4)
@@ -48,7 +50,7 @@ def ek60_params(C, P, vary_tau=False, seed=0, ping0=0):
         rng = np.random.default_rng(seed + 99)
         tau = PULSE_LENGTHS[rng.integers(0, 5, size=(C, P))]
         tau[:, 0] = 1.024e-3
-    ss = np.tile(1500.0 + 0.5 * np.sin(2 * np.pi * p / 1e5), (C, 1))
+    ss = np.tile(1500.0 + 0.5 * np.sin(2 * np.pi * (p // ss_every * ss_every) / 1e5), (C, 1))
     g = EK60_G[ch]
     return dict(
         channel=[f"GPT {int(EK60_FREQ[i] / 1e3)} kHz 00907205{i:04d} 1 ES{int(EK60_FREQ[i] / 1e3)}" for i in ch],
@@ -66,20 +68,21 @@ def ek60_params(C, P, vary_tau=False, seed=0, ping0=0):
     )
 
 
-def ek60_numpy(C=2, P=200, S=1000, seed=20260501, vary_tau=False):
+def ek60_numpy(C=2, P=200, S=1000, seed=20260501, vary_tau=False, ss_every=1):
     """Host arrays: backscatter_r f32 (C,P,S) + params."""
     rng = np.random.default_rng(seed)
     raw = rng.integers(-12000, -2000, size=(C, P, S), dtype=np.int16).astype(np.float32) * INDEX2POWER
     nan_pings = rng.random(P) < 0.10
     tail = max(1, int(round(0.05 * S)))
     raw[:, nan_pings, S - tail:] = np.nan
-    d = ek60_params(C, P, vary_tau=vary_tau, seed=seed)
+    d = ek60_params(C, P, vary_tau=vary_tau, seed=seed, ss_every=ss_every)
     d["backscatter_r"] = raw
     return d
 
 
-def ek60_device(C, P, S, seed=20260501, device=None, chunk_pings=20000, ping0=0):
-    """Same recipe generated in HBM: returns dict of torch CUDA tensors (raw f32 + f64 params)."""
+def ek60_device(C, P, S, seed=20260501, device=None, chunk_pings=20000, ping0=0, ss_every=2000):
+    """Same recipe generated in HBM: returns dict of torch CUDA tensors (raw f32 + f64 params).  The recorded sound
+    speed changes every ``ss_every`` pings (see :func:`ek60_params`)."""
     import torch
 
     dev = device or torch.device("cuda", torch.cuda.current_device())
@@ -96,7 +99,7 @@ def ek60_device(C, P, S, seed=20260501, device=None, chunk_pings=20000, ping0=0)
     nan_pings = torch.rand(P, generator=g, device=dev) < 0.10
     idx = torch.nonzero(nan_pings).flatten()
     raw[:, idx, S - tail:] = float("nan")
-    h = ek60_params(C, P, ping0=ping0)
+    h = ek60_params(C, P, ping0=ping0, ss_every=ss_every)
     out = {"backscatter_r": raw}
     for k in ("sample_interval", "transmit_duration_nominal", "transmit_power", "sound_speed_indicative",
               "absorption_indicative", "equivalent_beam_angle", "frequency_nominal", "pulse_length",
@@ -108,7 +111,7 @@ def ek60_device(C, P, S, seed=20260501, device=None, chunk_pings=20000, ping0=0)
     return out
 
 
-def ek60_device_i16(C, P, S, seed=20260501, device=None, chunk_pings=20000):
+def ek60_device_i16(C, P, S, seed=20260501, device=None, chunk_pings=20000, ss_every=2000):
     """The same recipe as :func:`ek60_device` before the converter's float conversion: int16 power
     samples (C,P,S) + the recorded length of every ping (C,P) int32."""
     import torch
@@ -124,7 +127,7 @@ def ek60_device_i16(C, P, S, seed=20260501, device=None, chunk_pings=20000):
     short = torch.rand(P, generator=g, device=dev) < 0.10
     n_valid = torch.full((C, P), S, dtype=torch.int32, device=dev)
     n_valid[:, short] = S - max(1, int(round(0.05 * S)))
-    h = ek60_params(C, P)
+    h = ek60_params(C, P, ss_every=ss_every)
     out = {"raw_i16": raw, "n_valid": n_valid}
     for k in ("sample_interval", "transmit_duration_nominal", "transmit_power", "sound_speed_indicative",
               "absorption_indicative", "equivalent_beam_angle", "frequency_nominal", "pulse_length",

@@ -520,13 +520,18 @@ def test_sv_complex_fft_path_matches_direct(env, in_dtype, out_dtype, fft_dtype,
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("closed,few_bins,pn,bin_s", [("left", False, 20, 20), ("right", False, 20, 20),
                                                        ("left", True, 20, 20), ("left", False, 80, 100)])
-def test_fused_chain_equals_the_four_separate_kernels(env, dtype, closed, few_bins, pn, bin_s):
+@pytest.mark.parametrize("ss_every", [1, 50])
+def test_fused_chain_equals_the_four_separate_kernels(env, dtype, closed, few_bins, pn, bin_s, ss_every):
     """epa_sv_noise_fused == epa_sv_power + epa_noise_estimate and epa_denoise_mvbs == epa_noise_apply +
     epa_mvbs (same arithmetic, fewer sweeps), and both equal the oracle chain.  The (80, 100) case has more
-    pings per noise block / time bin than the 64 per-ping logs a workgroup caches."""
+    pings per noise block / time bin than the 64 per-ping logs a workgroup caches.  ss_every = 1: a new sound speed
+    with every ping (no two pings share a range vector); 50: most time bins hold pings of one range vector (the
+    fp64 pass 2 takes them with per-column constants, chain_fast.hip: sv_denoise_mvbs_uniform_kernel), the bins that
+    straddle a change go to the general kernel in the same call."""
     torch, ops, synth = env
     C, P, S = 2, (45 if few_bins else 203), 1000
-    d = synth.ek60_numpy(C, P, S)
+    d = synth.ek60_numpy(C, P, S, ss_every=ss_every)
+    d["transmit_power"] = d["transmit_power"] * (1.0 + 0.1 * (np.arange(P) % 7 == 3))  # a per-ping term that may vary
     dt = getattr(torch, dtype)
     g = lambda k: _dev(torch, d[k], torch.float64)  # noqa: E731
     coef = ops.power_coef_ek(g("sample_interval"), g("transmit_duration_nominal"), g("transmit_power"),
