@@ -1,5 +1,6 @@
 // Internal helpers shared by the HIP translation units of libechopype_amd.so (gfx950 only).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -64,6 +65,23 @@ struct CoefRow {
   double ra, rb, r0, shift, alpha2, A0, g, d;
 };
 static_assert(sizeof(CoefRow) == EPA_NCOEF * sizeof(double), "coef row layout");
+
+// Workgroups are dealt to the 8 XCDs round-robin by their linear id.  With this remap of a 1-D work index the
+// workgroups of one XCD walk ONE contiguous eighth of the index range instead of every eighth item: on the streaming
+// probe (scripts/probes/hbm_mix_probe.hip, 4 B read + 8 B written per sample by workgroups that each walk a long run)
+// that is 6.1 instead of 5.5 TB/s.  Items past the last multiple of 8 keep their index.
+__device__ __forceinline__ int xcd_contiguous(int x, int n) {
+  const int per = n >> 3;
+  return x < per * 8 ? (x & 7) * per + (x >> 3) : x;
+}
+// EPA_XCD_MAP=0 turns the remap off (development knob, read once)
+inline bool xcd_map_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("EPA_XCD_MAP");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
 
 // Uniform-edge bin index: edges e_i = i*bin (np.arange(0, stop, bin) evaluates 0 + i*bin in
 // double), membership decided against those exact edge values (SURVEY A.6 caveat (i)).

@@ -26,6 +26,7 @@ struct Args {
   unsigned guard, mask_range, skipna, closed_right;
   unsigned cnt_off, tab_off;
   unsigned long long* rmax_key;  // optional: max valid echo_range as an order-preserving u64 key
+  int xcd_map;  // time bins dealt to the XCDs in contiguous eighths (epa::xcd_contiguous)
 };
 
 // order-preserving map double -> u64 (so that atomicMax on the key is a max on the double)
@@ -174,9 +175,9 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
   const epa::MathTabs mt = epa::build_math_tabs(smem + a.tab_off);  // synchronised below
   const double* tab = mt.exp2_tab;
 
-  const int c = blockIdx.y, tb = blockIdx.x;
+  const int c = blockIdx.y, tb = a.xcd_map ? epa::xcd_contiguous(blockIdx.x, a.n_tbins) : (int)blockIdx.x;
   const int S = a.S, n_rbins = a.n_rbins;
-  // blockIdx.x == n_tbins: the pings that belong to NO time bin (NaT, or on the first edge of
+  // tb == n_tbins: the pings that belong to NO time bin (NaT, or on the first edge of
   // right-closed bins) still get their Sv; two segments, nothing is accumulated.
   const bool extra = tb == a.n_tbins;
   if (extra && !WRITE_SV) return;
@@ -288,6 +289,7 @@ int launch(Args& a, const RawT* raw, const int32_t* n_valid, const double* coef,
   const dim3 grid((unsigned)a.n_tbins + 1u, (unsigned)C);  // +1: pings outside every time bin
   a.tab_off = (unsigned)((lds_bytes + 15) & ~(size_t)15);
   lds_bytes = a.tab_off + epa::kMathTabBytes;
+  a.xcd_map = epa::xcd_map_enabled() ? 1 : 0;
 #define EPA_FL(W, R)                                                                           \
   do {                                                                                         \
     auto kern = fused_sv_mvbs_kernel<T, RawT, W, R>;                                           \

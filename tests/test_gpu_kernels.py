@@ -528,8 +528,20 @@ def test_fused_chain_equals_the_four_separate_kernels(env, dtype, closed, few_bi
     with every ping (no two pings share a range vector); 50: most time bins hold pings of one range vector (the
     fp64 pass 2 takes them with per-column constants, chain_fast.hip: sv_denoise_mvbs_uniform_kernel), the bins that
     straddle a change go to the general kernel in the same call."""
+    _chain_equivalence(env, dtype, closed, 45 if few_bins else 203, pn, bin_s, ss_every)
+
+
+@pytest.mark.parametrize("bin_s", [100, 300])
+def test_fused_chain_long_uniform_groups(env, bin_s):
+    """Time bins of 100 pings (beyond the 64 per-ping logs of the general kernel, inside the 256 per-ping constants of
+    the uniform-group kernel) and of 300 pings (beyond both: the uniform-group kernel hands the bin over) on a file
+    whose pings share one range vector."""
+    _chain_equivalence(env, "float64", "left", 620, 20, bin_s, 100000, S=512)
+
+
+def _chain_equivalence(env, dtype, closed, P, pn, bin_s, ss_every, S=1000):
     torch, ops, synth = env
-    C, P, S = 2, (45 if few_bins else 203), 1000
+    C = 2
     d = synth.ek60_numpy(C, P, S, ss_every=ss_every)
     d["transmit_power"] = d["transmit_power"] * (1.0 + 0.1 * (np.arange(P) % 7 == 3))  # a per-ping term that may vary
     dt = getattr(torch, dtype)
