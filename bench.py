@@ -364,7 +364,7 @@ def run_ek60(ctx, name, cpu):
                 metric=METRIC + (" with remove_background_noise" if chain else ""),
                 workload=f"EK60 CW {C}ch x {P} pings x {S} range ({name}), {what}" + (", int16 instrument samples in" if i16 else ""),
                 config=cfg, cpu=cpu,
-                roofline=roofline("epa_chain::sv_noise_fast_kernel + sv_denoise_mvbs_fast_kernel" if chain
+                roofline=roofline("epa_chain::sv_noise_fast_kernel + sv_denoise_mvbs_uniform_kernel (+ sv_denoise_mvbs_fast_kernel for time bins whose pings differ)" if chain
                                   else "epa_fused::fused_sv_mvbs_kernel", kernel_ms, n * bps, bps, traffic_key=key))
 
 

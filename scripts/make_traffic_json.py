@@ -18,7 +18,7 @@ from bench import csrc_hash  # noqa: E402
 src = sys.argv[1]
 KERNELS = {
     "cfg2": (["fused_sv_mvbs_kernel"], 4 * 500_000 * 2000 * 12),
-    "cfg3": (["sv_noise_fast_kernel", "sv_denoise_mvbs_fast_kernel"], 4 * 500_000 * 2000 * 32),
+    "cfg3": (["sv_noise_fast_kernel", "sv_denoise_mvbs_fast_kernel", "sv_denoise_mvbs_uniform_kernel"], 4 * 500_000 * 2000 * 32),
     "cfg4": (["sv_complex_fft_kernel"], 2 * 200_000 * 8192 * 40),
 }
 
