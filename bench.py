@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--ss-every", type=int, default=2000,
+                    help="EK60 volumes: the sound speed recorded with the pings changes every this many pings "
+                         "(1: at every ping -- no two pings share a range vector)")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="one workload only (default: N=1 -> cfg3, cfg4, cfg5 lines then the cfg2 headline; N>1 -> cfg5)")
     ap.add_argument("--only-headline", action="store_true", help="N=1: skip the cfg3 / cfg4 / cfg5 lines")
@@ -251,7 +254,7 @@ def line(ctx, *, value, steps, warmup, elapsed, scaling, workload, config, roofl
            "vs_baseline": None, "dtype": "f64" if ctx.args.dtype == "float64" else "f32", "data": "synthetic",
            "config": {"workload": workload, **config,
                       "synthetic_data": "10 % of pings short and NaN-padded; the recorded sound speed follows a slow "
-                                        "drift (EK60: a new value every 2000 pings, EK80: every ping)"},
+                                        f"drift (EK60: a new value every {ctx.args.ss_every} pings, EK80: every ping)"},
            "roofline": roofline}
     if cpu is not None:
         out["cpu_baseline"] = cpu
@@ -314,7 +317,7 @@ def run_ek60(ctx, name, cpu):
     chain = name == "cfg3"
     i16 = args.input == "int16" and not chain
     dt = ctx.dt
-    d = (ctx.synth.ek60_device_i16 if i16 else ctx.synth.ek60_device)(C, P, S, seed=20260501)
+    d = (ctx.synth.ek60_device_i16 if i16 else ctx.synth.ek60_device)(C, P, S, seed=20260501, ss_every=args.ss_every)
     ns = d["ping_time_ns"]
     bin_ns = 20_000_000_000
     e0, _ = sharding.global_time_grid(ns.cpu().numpy(), bin_ns)
@@ -455,7 +458,7 @@ def run_cfg5(ctx, cpu):
     spans = [(a, min(p1, a + tile_p)) for a in range(p0, p1, tile_p)]
     tiles = []
     for a, b in spans:
-        d = synth.ek60_device(C, b - a, S, seed=20260505 + a // 20, ping0=a)
+        d = synth.ek60_device(C, b - a, S, seed=20260505 + a // 20, ping0=a, ss_every=args.ss_every)
         d["tau0"] = torch.full((C,), 1.024e-3, dtype=torch.float64, device="cuda")  # ping 0 of the WHOLE file
         tiles.append(d)
     n_r = len(np.arange(0, float((S - 1) * 2.56e-4 * 1500.5 / 2) + 1.0, 1.0)) - 1

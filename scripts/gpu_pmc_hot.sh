@@ -14,7 +14,9 @@ for r in csv.DictReader(open("gpurun_out/pmc_hot/summary.csv")):
 for k, v in rows.items():
     if "true>" in k and "fft" in k: continue
     n = 800e6 if "fft" not in k else 81.92e6
-    print("%-70s VALU/sample %.1f SALU/sample %.1f LDS/sample %.2f  valu_busy %.2f  vgpr %s" % (
+    # VALU-issue floor: wavefront instructions x 4 cycles over 256 CUs x 4 SIMDs at 2.4 GHz (what the kernel would take
+    # if nothing but VALU issue limited it)
+    print("%-70s VALU/sample %.1f SALU/sample %.1f LDS/sample %.2f  VALU-issue floor %.2f ms  arch vgpr %s" % (
         k[-70:], v.get("SQ_INSTS_VALU", 0) * 64 / n, v.get("SQ_INSTS_SALU", 0) * 64 / n, v.get("SQ_INSTS_LDS", 0) * 64 / n,
-        v.get("SQ_ACTIVE_INST_VALU", 0) / max(v.get("SQ_WAVE_CYCLES", 1), 1), v["vgpr"]))
+        v.get("SQ_INSTS_VALU", 0) * 4 / 1024 / 2.4e9 * 1e3, v["vgpr"]))
 PY
