@@ -278,10 +278,14 @@ __global__ __launch_bounds__(epa::kBlock, EPA_EK80_MIN_WAVES) void sv_complex_ke
     const double R = ((double)s * ra) * rb;  // range.py:138 operation order
     T rt = sub_rn((T)R, shift);  // never contracted with the range product into an fma
     if (!(rt > (T)0)) rt = epa::M<T>::nan();
+    // the range the reference calibrates with is the MASKED echo_range (NaN where beam 0 is, range.py:143-148): a
+    // sample whose beam 0 is missing is NaN even when its other sectors are valid (calibrate_ek.py:571-576)
+    const bool range_ok = (vmask[2 * (k0 + i) + 1] & 1u) != 0u;
+    if (!range_ok) rt = epa::M<T>::nan();
     const T val = (T)10 * epa::fast_log10(prx, mt.log_tab) + nspread * epa::fast_log10(rt, mt.log_tab) + alpha2 * rt + Aadd;
     const size_t o = row * S + s;
     out[o] = val;
-    if (range_out) range_out[o] = (vmask[2 * (k0 + i) + 1] & 1u) ? (T)R : epa::M<T>::nan();
+    if (range_out) range_out[o] = range_ok ? (T)R : epa::M<T>::nan();
     if (prx_out) prx_out[o] = prx;
   }
 }

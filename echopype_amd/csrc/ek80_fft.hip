@@ -661,11 +661,14 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
         tvg = nspread * epa::fast_log10_lean(rt, L.log_tab, lk) + alpha2 * rt;
       }
       // prx (and rt) are positive or NaN here: the lean log (zero / subnormal / inf / NaN through a rare branch)
-      const T val = ((T)10 * epa::fast_log10_lean(prx, L.log_tab, lk) + tvg) + Aadd;
+      // the range the reference calibrates with is the MASKED echo_range (NaN where beam 0 is, range.py:143-148): a
+      // sample whose beam 0 is missing is NaN even when its other sectors are valid (calibrate_ek.py:571-576)
+      const bool range_ok = ((vbits >> (8 + i)) & 1u) != 0u;
+      const T val = range_ok ? ((T)10 * epa::fast_log10_lean(prx, L.log_tab, lk) + tvg) + Aadd : epa::M<T>::nan();
       const size_t o = row * S + s;
       out[o] = val;
       if (range_out) {
-        const bool ok = ((vbits >> (8 + i)) & 1u) != 0u;
+        const bool ok = range_ok;
         range_out[o] = ok ? (T)R : epa::M<T>::nan();
         if (ok) {
           const double rr = (double)(T)R;

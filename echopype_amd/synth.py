@@ -195,6 +195,8 @@ def ek80_numpy(C=2, P=16, S=1024, B=4, seed=20260504, waveform="BB", replicas=No
         im[C - 1, P - 1, 10, B - 1] = np.nan   # imag-only NaN (convert sets imag 0 -> NaN)
         re[C - 1, P - 1, 17, :] = np.nan       # whole sample NaN in the middle of a ping
         im[C - 1, P - 1, 17, :] = np.nan
+        # beam 0 missing, the other sectors valid: echo_range is masked there (range.py:143-148), hence Sv NaN
+        re[0, min(1, P - 1), S // 2: S // 2 + 3, 0] = np.nan
     p = np.arange(P)
     d = dict(EK80_BB)
     d = {k: (v[:C].copy() if isinstance(v, np.ndarray) else v) for k, v in d.items()}

@@ -267,7 +267,9 @@ int epa_noise_apply(const void* sv, const void* range, const double* coef, const
  *   ccoef    : per-(c,p) rows of EPA_NCCOEF doubles, see enum below.  PSCALE excludes the
  *              1/||tx||^4 of the pulse-compression normalisation: the kernel computes ||tx||^2
  *              itself (wavefront shuffle reduction over the LDS-resident replica)
- *   out      : Sv/TS [C*P*S] of out_dtype; range_out, prx_out (same dtype) optional.
+ *   out      : Sv/TS [C*P*S] of out_dtype; range_out, prx_out (same dtype) optional.  A sample whose beam-0 real
+ *              part is NaN is NaN in out and range_out whatever its other sectors hold: the reference calibrates
+ *              with the masked echo_range (range.py:143-148, calibrate_ek.py:571-576); prx_out is unaffected.
  *              F64 output accumulates the matched filter in f64, F32 in f32
  */
 #define EPA_NCCOEF 8

@@ -192,6 +192,12 @@ def ek80_complex_case(ek, ekc, rng_mod, g, tag, waveform, C, P, S, B, seed):
             x[c, p, k0:k0 + n, :] += 0.3 * r[:n, None]
     x[:, 1, S - 9:, :] = np.nan
     x[0, 2] = np.nan
+    # partly-NaN samples: some sectors missing (the reference zeroes them for the convolution, restores the NaN and
+    # averages the remaining sectors -- a NaN-skipping complex mean, calibrate_ek.py:483 over xarray's default skipna);
+    # a NaN in beam 0 also masks echo_range (range.py:143-148)
+    x[1, 0, 40:44, B - 1] = np.nan
+    x[0, 3, 100, 0] = np.nan
+    x[1, 3, 7:9, 1:3] = np.nan
     si = np.full((C, P), 1.0 / (fs / 12))
     pt = np.array([750.0, 250.0])[:C, None] * np.ones((1, P))
     c_w = 1490.0 + 2.0 * rng.random((C, P))

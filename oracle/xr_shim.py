@@ -335,9 +335,15 @@ def _methods():
             self.da.data = self.da.data.copy()
             self.da.data[(slice(None),) * ax + (idx,)] = v
 
-    def mean(self, dim=None):
-        ax = self.dims.index(dim)
-        return self._like(self.data.mean(axis=ax), [d for d in self.dims if d != dim])
+    def mean(self, dim=None, skipna=None):
+        """xarray's default: NaN-skipping for float and complex data (duck_array_ops.mean: dtype.kind in "cfO"), plain
+        otherwise; an all-NaN slice gives NaN."""
+        import warnings
+
+        skip = skipna if skipna is not None else self.data.dtype.kind in "fc"
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            return self._reduce(np.nanmean if skip else np.mean, dim)
 
     def fillna(self, v):
         return self._like(np.where(np.isnan(self.data), v, self.data))

@@ -474,6 +474,7 @@ def test_sv_complex_fft_path_matches_direct(env, in_dtype, out_dtype, fft_dtype,
     if mixed:
         re[0, 0, 100:130, B - 1] = np.nan                  # one sector missing -> per-sector fallback
         im[0, 2, S // 2, 0] = np.nan
+        re[1, 0, 200:203, 0] = np.nan                      # beam 0 missing: masked echo_range, Sv NaN (B > 1: others valid)
     lens = [taps, max(taps // 2, 1)]
     rep = np.concatenate([(rng.standard_normal(n) + 1j * rng.standard_normal(n)) * np.hanning(n + 2)[1:-1]
                           for n in lens]).astype(np.complex64)
