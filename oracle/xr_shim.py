@@ -148,6 +148,13 @@ class DataArray:
                 common = [x for x in la if x in lb]
                 a = a.isel(**{d: np.array([la.index(x) for x in common])})
                 b = b.isel(**{d: np.array([lb.index(x) for x in common])})
+            elif d in b.dims and d in a.coords and d in b.coords:
+                # equal lengths: xarray would still join on the LABELS (reordering / dropping); the shim combines by
+                # position, so it insists that the labels agree -- anything else must fail loudly, not silently
+                la, lb = np.asarray(a.coords[d]), np.asarray(b.coords[d])
+                same = la.shape == lb.shape and bool(np.all((la == lb) | ((la != la) & (lb != lb)))) \
+                    if la.dtype.kind not in "OUS" else list(la) == list(lb)
+                assert same, f"operands carry different {d!r} labels: label alignment beyond the shim"
         return a, b
 
     def _binary(self, other, f, reflexive=False):

@@ -160,5 +160,7 @@ def test_scalar_conversions_and_strictness():
     a = _da(np.zeros((2, 3)), channel=np.arange(2), ping_time=np.arange(3))
     with pytest.raises(TypeError):  # an unlabelled ndarray of another shape does not broadcast silently
         a + np.zeros(3)
+    with pytest.raises(AssertionError):  # equal lengths but other / permuted labels: xarray would re-align, the shim refuses
+        _da(np.arange(3.0), channel=np.array(["a", "b", "c"])) + _da(np.arange(3.0), channel=np.array(["b", "a", "c"]))
     with pytest.raises((AssertionError, KeyError)):  # same dimension, different lengths, no labels to join on
         a + xr.DataArray(np.zeros(4), dims=["ping_time"])
