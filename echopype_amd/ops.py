@@ -483,7 +483,9 @@ def range_rows_check(range):
 def pool_sv_value(sv, range, nvalid, depth_bin, num_side_pings, exclude_above, range_min, range_max,
                   func="nanmean", threshold=0.0, want_pooled=True, want_mask=True, running_sums=True):
     """Value-window pooled Sv (pool_Sv) and/or the mask Sv - pooled > threshold.  ``running_sums`` (nanmean):
-    per-row double-double running sums in a 20 B/sample workspace instead of summing every window."""
+    per-row double-double running sums and interval sums in a 40 B/sample workspace instead of summing every window
+    (EPA_POOL_VALUE_WS_BYTES in the header); when that does not fit next to the arrays the workspace-free kernel runs
+    (same results, every window summed value by value)."""
     C, P, S = sv.shape
     if range.dtype != sv.dtype:
         range = range.to(sv.dtype)
@@ -492,7 +494,10 @@ def pool_sv_value(sv, range, nvalid, depth_bin, num_side_pings, exclude_above, r
     mask = torch.empty((C, P, S), dtype=torch.uint8, device=sv.device) if want_mask else None
     ws = None
     if running_sums and func == "nanmean":
-        ws = torch.empty((C * P * S * 40 + C * S * 8 + C * 8 + C * P + 7) // 8, dtype=torch.float64, device=sv.device)
+        try:
+            ws = torch.empty((C * P * S * 40 + C * S * 8 + C * 8 + C * P + 7) // 8, dtype=torch.float64, device=sv.device)
+        except torch.cuda.OutOfMemoryError:
+            ws = None
     call("epa_pool_sv_value", _p(sv), _p(range), _p(nvalid), C, P, S, float(depth_bin), int(num_side_pings),
          float(exclude_above), float(range_min), float(range_max), f, float(threshold), _p(pooled),
          _p(mask), _p(ws), _DT[sv.dtype], _stream())
