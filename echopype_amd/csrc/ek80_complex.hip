@@ -258,6 +258,7 @@ __global__ __launch_bounds__(epa::kBlock, EPA_EK80_MIN_WAVES) void sv_complex_ke
   const T pscale = (T)(cc[EPA_CC_PSCALE]);
   const T nspread = (T)a.nspread;
   const T inv_norm = (T)1 / (T)norm2;
+  const epa::LogCoef lk = epa::make_log_coef();
   T* out = reinterpret_cast<T*>(a.out);
   T* range_out = reinterpret_cast<T*>(a.range_out);
   T* prx_out = reinterpret_cast<T*>(a.prx_out);
@@ -282,7 +283,8 @@ __global__ __launch_bounds__(epa::kBlock, EPA_EK80_MIN_WAVES) void sv_complex_ke
     // sample whose beam 0 is missing is NaN even when its other sectors are valid (calibrate_ek.py:571-576)
     const bool range_ok = (vmask[2 * (k0 + i) + 1] & 1u) != 0u;
     if (!range_ok) rt = epa::M<T>::nan();
-    const T val = (T)10 * epa::fast_log10(prx, mt.log_tab) + nspread * epa::fast_log10(rt, mt.log_tab) + alpha2 * rt + Aadd;
+    // prx and rt are positive or NaN here: the lean log (zero / subnormal / inf / NaN through a rare branch)
+    const T val = (T)10 * epa::fast_log10_lean(prx, mt.log_tab, lk) + nspread * epa::fast_log10_lean(rt, mt.log_tab, lk) + alpha2 * rt + Aadd;
     const size_t o = row * S + s;
     out[o] = val;
     if (range_out) range_out[o] = range_ok ? (T)R : epa::M<T>::nan();
