@@ -292,6 +292,113 @@ __global__ __launch_bounds__(epa::kBlock, EPA_EK80_MIN_WAVES) void sv_complex_ke
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// CW (no replica): nothing is convolved, a sample depends on its own sectors only -- a plain streaming kernel.  Lane j
+// of a workgroup takes the samples j + 256 i of a 2048- (1024-) sample piece of one ping, so that every load of a wavefront is
+// 1 KiB (float32 planes) contiguous per plane and every store 512 B (the tile kernel above gives a lane eight CONSECUTIVE outputs, which
+// its sliding window needs and which makes each of its stores touch 64 separate 64-byte segments).  The NaN-skipping
+// sector mean (calibrate_ek.py:483, xarray's skipna) needs no second pass here.
+// ------------------------------------------------------------------------------------------------
+// samples of a ping per workgroup: eight per lane for float32 planes, four for float64 planes (the lane holds all of
+// its sectors in registers: 64 VGPRs either way)
+template <typename InT>
+constexpr int cw_piece() { return sizeof(InT) == 8 ? 1024 : 2048; }
+
+template <typename InT, typename T, int NB>
+__global__ __launch_bounds__(epa::kBlock) void sv_complex_cw_kernel(CxArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
+  const epa::MathTabs mt = epa::build_math_tabs(tabs);
+  __syncthreads();
+  const int c = blockIdx.y;
+  const int p = blockIdx.x / a.tiles, piece = blockIdx.x - p * a.tiles;
+  const int S = a.S, B = NB > 0 ? NB : a.B;
+  const InT* re = reinterpret_cast<const InT*>(a.re);
+  const InT* im = reinterpret_cast<const InT*>(a.im);
+  const size_t row = (size_t)c * a.P + p;
+  const size_t ping_base = row * (size_t)S * B;
+  const double* cc = a.ccoef + row * EPA_NCCOEF;
+  const double ra = cc[EPA_CC_RA], rb = cc[EPA_CC_RB];
+  const T shift = (T)cc[EPA_CC_SHIFT], alpha2 = (T)cc[EPA_CC_ALPHA2], Aadd = (T)cc[EPA_CC_A];
+  const T pscale = (T)(cc[EPA_CC_PSCALE]);
+  const T nspread = (T)a.nspread;
+  const epa::LogCoef lk = epa::make_log_coef();
+  T* out = reinterpret_cast<T*>(a.out);
+  T* range_out = reinterpret_cast<T*>(a.range_out);
+  T* prx_out = reinterpret_cast<T*>(a.prx_out);
+  constexpr int kCwPiece = cw_piece<InT>();
+  constexpr int kPer = kCwPiece / epa::kBlock;
+  // all loads of the lane first (independent), then the arithmetic
+  InT vr[kPer][NB > 0 ? NB : 1], vi[kPer][NB > 0 ? NB : 1];
+  if (NB > 0) {
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int s = min(piece * kCwPiece + (int)threadIdx.x + epa::kBlock * i, S - 1);  // (clamped: no partial arrays)
+      load_sectors<InT, (NB > 0 ? NB : 4)>(re + ping_base + (size_t)s * B, reinterpret_cast<InT(&)[NB > 0 ? NB : 4]>(vr[i]));
+      load_sectors<InT, (NB > 0 ? NB : 4)>(im + ping_base + (size_t)s * B, reinterpret_cast<InT(&)[NB > 0 ? NB : 4]>(vi[i]));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) {
+    const int s = piece * kCwPiece + (int)threadIdx.x + epa::kBlock * i;
+    if (s >= S) break;
+    T sr = (T)0, si = (T)0;
+    unsigned nvalid = 0;
+    bool range_ok;
+    if (NB > 0) {
+#pragma unroll
+      for (int b = 0; b < (NB > 0 ? NB : 1); ++b) {
+        const InT xr = vr[i][b], xi = vi[i][b];
+        const bool ok = (xr == xr) && (xi == xi);
+        sr += ok ? (T)xr : (T)0;
+        si += ok ? (T)xi : (T)0;
+        nvalid += ok ? 1u : 0u;
+      }
+      range_ok = vr[i][0] == vr[i][0];
+    } else {
+      const InT* pr = re + ping_base + (size_t)s * B;
+      const InT* pi = im + ping_base + (size_t)s * B;
+      for (int b = 0; b < B; ++b) {
+        const InT xr = pr[b], xi = pi[b];
+        const bool ok = (xr == xr) && (xi == xi);
+        sr += ok ? (T)xr : (T)0;
+        si += ok ? (T)xi : (T)0;
+        nvalid += ok ? 1u : 0u;
+      }
+      range_ok = pr[0] == pr[0];
+    }
+    T mr, mi;
+    if (nvalid == 0u) {
+      mr = mi = epa::M<T>::nan();
+    } else {
+      const T invn = (T)1 / (T)nvalid;
+      mr = sr * invn;
+      mi = si * invn;
+    }
+    T prx = pscale * (mr * mr + mi * mi);
+    if (!(prx > (T)0)) prx = epa::M<T>::nan();
+    const double R = ((double)s * ra) * rb;  // range.py:138 operation order
+    T rt = sub_rn((T)R, shift);
+    if (!(rt > (T)0) || !range_ok) rt = epa::M<T>::nan();  // the masked echo_range calibrates (see the tile kernel)
+    const T val = (T)10 * epa::fast_log10_lean(prx, mt.log_tab, lk) + nspread * epa::fast_log10_lean(rt, mt.log_tab, lk) +
+                  alpha2 * rt + Aadd;
+    const size_t o = row * S + s;
+    out[o] = val;
+    if (range_out) range_out[o] = range_ok ? (T)R : epa::M<T>::nan();
+    if (prx_out) prx_out[o] = prx;
+  }
+}
+
+template <typename InT, typename T>
+int launch_cw(CxArgs& a, hipStream_t st) {
+  a.tiles = (a.S + cw_piece<InT>() - 1) / cw_piece<InT>();
+  const dim3 grid((unsigned)((long long)a.P * a.tiles), (unsigned)a.C);
+  const bool b4 = a.B == 4 && (reinterpret_cast<uintptr_t>(a.re) & 15u) == 0 &&
+                  (reinterpret_cast<uintptr_t>(a.im) & 15u) == 0;
+  if (b4) hipLaunchKernelGGL((sv_complex_cw_kernel<InT, T, 4>), grid, dim3(epa::kBlock), 0, st, a);
+  else hipLaunchKernelGGL((sv_complex_cw_kernel<InT, T, 0>), grid, dim3(epa::kBlock), 0, st, a);
+  return epa::check_launch("sv_complex_cw_kernel");
+}
+
 template <typename InT, typename T, typename A>
 int launch(CxArgs& a, int max_taps, hipStream_t st) {
   const int taps8 = (max_taps + kR - 1) / kR * kR;
@@ -343,6 +450,14 @@ extern "C" int epa_sv_complex(const void* re, const void* im, int in_dtype, cons
   a.out = out; a.range_out = range_out; a.prx_out = prx_out;
   const int taps = replica ? max_taps : 0;
   hipStream_t st = (hipStream_t)stream;
+  if (!replica) {  // CW: the streaming kernel
+    if (in_dtype == EPA_F64 && out_dtype == EPA_F64) return launch_cw<double, double>(a, st);
+    if (in_dtype == EPA_F64 && out_dtype == EPA_F32) return launch_cw<double, float>(a, st);
+    if (in_dtype == EPA_F32 && out_dtype == EPA_F64) return launch_cw<float, double>(a, st);
+    if (in_dtype == EPA_F32 && out_dtype == EPA_F32) return launch_cw<float, float>(a, st);
+    epa::set_error("epa_sv_complex: bad dtype in=%d out=%d", in_dtype, out_dtype);
+    return EPA_EINVAL;
+  }
   if (in_dtype == EPA_F64 && out_dtype == EPA_F64) return launch<double, double, double>(a, taps, st);
   if (in_dtype == EPA_F64 && out_dtype == EPA_F32) return launch<double, float, float>(a, taps, st);
   if (in_dtype == EPA_F32 && out_dtype == EPA_F64) return launch<float, double, double>(a, taps, st);
