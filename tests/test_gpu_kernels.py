@@ -540,10 +540,20 @@ def test_fused_chain_long_uniform_groups(env, bin_s):
     _chain_equivalence(env, "float64", "left", 620, 20, bin_s, 100000, S=512)
 
 
-def _chain_equivalence(env, dtype, closed, P, pn, bin_s, ss_every, S=1000):
+def test_fused_chain_with_empty_time_bins(env):
+    """A 130-s hole in the pings: time bins without a single ping between bins of uniform pings (the uniform-group
+    pass 2 writes their fill value) -- and an all-NaN ping block in the noise estimate."""
+    _chain_equivalence(env, "float64", "left", 140, 20, 20, 100000, S=512, gap_after=60)
+
+
+def _chain_equivalence(env, dtype, closed, P, pn, bin_s, ss_every, S=1000, gap_after=None):
     torch, ops, synth = env
     C = 2
     d = synth.ek60_numpy(C, P, S, ss_every=ss_every)
+    if gap_after is not None:
+        d["ping_time"] = d["ping_time"].copy()
+        d["ping_time"][gap_after:] += np.timedelta64(130, "s")
+        d["backscatter_r"][:, 20:40, :] = np.nan
     d["transmit_power"] = d["transmit_power"] * (1.0 + 0.1 * (np.arange(P) % 7 == 3))  # a per-ping term that may vary
     dt = getattr(torch, dtype)
     g = lambda k: _dev(torch, d[k], torch.float64)  # noqa: E731
