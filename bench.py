@@ -238,7 +238,9 @@ class Ctx:
 
     def steps(self, workload):
         a = self.args
-        return (a.steps if a.steps is not None else WORKLOADS[workload][3],
+        # (strong scaling: a rank's step shrinks with the world size; the default keeps the timed region near 2 s)
+        scale = self.world if workload == "cfg5" else 1
+        return (a.steps if a.steps is not None else WORKLOADS[workload][3] * scale,
                 a.warmup if a.warmup is not None else WORKLOADS[workload][4])
 
     def free(self):
