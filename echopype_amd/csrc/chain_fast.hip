@@ -206,6 +206,8 @@ struct RowCache {
 // ------------------------------------------------------------------------------------------------
 // pass 1
 // ------------------------------------------------------------------------------------------------
+constexpr int kP1Blocks = 2;  // ping blocks per workgroup of pass 1
+
 template <typename T>
 struct NoiseCol : ColBase<T> {
   T acc_sum;
@@ -222,9 +224,14 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
   const epa::MathTabs mt = epa::build_math_tabs(smem + a.tab_off);
   __shared__ T red[8];
 
-  const int c = blockIdx.y, pbk = blockIdx.x;
+  // One workgroup takes kP1Blocks consecutive ping blocks: the per-column logs it caches (two ocml-grade logs per
+  // column and chunk) are then paid once per 40 pings instead of once per 20 (interleaved A/B on one box, 2 G samples:
+  // 5.45 -> 5.27 ms with 2 blocks, 5.30 with 4: the larger footprint of a workgroup starts to cost what the fixed work
+  // saves).  lsum / lcnt hold one row of range-block sums per ping block.
+  const int c = blockIdx.y, pbk0 = blockIdx.x * kP1Blocks;
+  const int nb = min(kP1Blocks, a.n_pblocks - pbk0);
   const int S = a.S, Sb = a.n_rblocks;
-  for (int i = threadIdx.x; i < Sb; i += epa::kBlock) {
+  for (int i = threadIdx.x; i < kP1Blocks * Sb; i += epa::kBlock) {
     lsum[i] = (T)0;
     lcnt[i] = 0u;
   }
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
   const float* __restrict__ raw_c = raw + (size_t)c * a.P * S;
   T* __restrict__ sv_c = WRITE_SV ? sv_out + (size_t)c * a.P * S : nullptr;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int pb = pbk * a.ping_num, pe = min(a.P, pb + a.ping_num);
+  const int pb = pbk0 * a.ping_num, pe = min(a.P, pb + nb * a.ping_num);
   double xmax = -__builtin_inf();
   __shared__ T plog[kPingLogs];
   fill_ping_logs<T>(plog, rowp0 + pb, pe - pb, mt.log_tab);
@@ -251,11 +258,26 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
       col[j].sra = 0.0; col[j].nL = epa::M<T>::nan(); col[j].lgs = (T)0; col[j].c2 = (T)0;
       col[j].acc_sum = (T)0; col[j].acc_cnt = 0u;
     }
+    int rbk[VEC];  // range block of each column
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) rbk[j] = ((j < 2 ? sA : sB) + (j & 1)) / a.rsn;
+    auto flush = [&](int g) {  // the columns' sums of ping block g -> its row of range-block sums
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (col[j].acc_cnt > 0u) {
+          lds_add(lsum + g * Sb + rbk[j], col[j].acc_sum);
+          atomicAdd(lcnt + g * Sb + rbk[j], col[j].acc_cnt);
+        }
+        col[j].acc_sum = (T)0;
+        col[j].acc_cnt = 0u;
+      }
+    };
     RowCache<T> rc;
     float2 nA = make_float2(0.f, 0.f), nB = nA;
     epa::CoefRow nxtR = rowp0[pb];
     nA = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sA);
     if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sB);
+    int left = a.ping_num, g = 0;  // pings left in the current ping block
     for (int p = pb; p < pe; ++p) {
       const epa::CoefRow r = nxtR;
       const size_t row_off = (size_t)p * S;
@@ -266,14 +288,14 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
         if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + row_off + S + sB);
       }
       rc.update(r, col, sA, sB, nspread, mt.log_tab, plog, p - pb);
-      const T g = (T)r.g, a2 = (T)r.alpha2, A0 = (T)r.A0, na2 = (T)a2p[p];
+      const T g_ = (T)r.g, a2 = (T)r.alpha2, A0 = (T)r.A0, na2 = (T)a2p[p];
       const float in[VEC] = {inA.x, inA.y, inB.x, inB.y};
       T sv[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         if (j >= 2 && !hasB) break;
         double x;
-        sv[j] = calibrate<T>(col[j], in[j], r, g, a2, A0, nspread, x, mt.log_tab);
+        sv[j] = calibrate<T>(col[j], in[j], r, g_, a2, A0, nspread, x, mt.log_tab);
         const bool xok = in[j] == in[j];
         if (RMAX) xmax = fmax(xmax, xok ? (double)(T)x : xmax);
         // the block mean uses the UNMASKED range (the generic kernel does too: a masked sample has a NaN Sv)
@@ -291,51 +313,51 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
         epa::store_nt2(sv_c + row_off + sA, sv[0], sv[1]);
         if (hasB) epa::store_nt2(sv_c + row_off + sB, sv[2], sv[3]);
       }
-    }
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      if (col[j].acc_cnt > 0u) {
-        const int rbk = ((j < 2 ? sA : sB) + (j & 1)) / a.rsn;
-        lds_add(lsum + rbk, col[j].acc_sum);
-        atomicAdd(lcnt + rbk, col[j].acc_cnt);
+      if (--left == 0) {  // (uniform) the ping block is complete
+        flush(g);
+        ++g;
+        left = a.ping_num;
       }
     }
+    if (left != a.ping_num) flush(g);  // the last, shorter ping block of the array
   }
   if (RMAX) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) xmax = fmax(xmax, __shfl_down(xmax, o, 64));
     if (lane == 0 && xmax > -__builtin_inf()) atomicMax(a.rmax_key, ordered_key(xmax));
   }
-  __syncthreads();
   // min over the range blocks of 10 log10(block mean) (clean/api.py:402-411), optional clamp (:418-422)
-  T best = (T)__builtin_inf();
-  int any = 0;
-  for (int i = threadIdx.x; i < Sb; i += epa::kBlock) {
-    const uint32_t n = lcnt[i];
-    if (n > 0u) {
-      const T db = (T)10 * epa::M<T>::log10(lsum[i] / (T)n);
-      if (db == db) {
-        best = fmin(best, db);
-        any = 1;
+  for (int g = 0; g < nb; ++g) {
+    __syncthreads();  // the sums are complete / the previous block's `red` is consumed
+    T best = (T)__builtin_inf();
+    int any = 0;
+    for (int i = threadIdx.x; i < Sb; i += epa::kBlock) {
+      const uint32_t n = lcnt[g * Sb + i];
+      if (n > 0u) {
+        const T db = (T)10 * epa::M<T>::log10(lsum[g * Sb + i] / (T)n);
+        if (db == db) {
+          best = fmin(best, db);
+          any = 1;
+        }
       }
     }
-  }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    best = fmin(best, __shfl_down(best, o, 64));
-    any |= __shfl_down(any, o, 64);
-  }
-  if (lane == 0) {
-    red[wave] = best;
-    red[4 + wave] = (T)any;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    T m = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
-    const bool some = (red[4] != (T)0) | (red[5] != (T)0) | (red[6] != (T)0) | (red[7] != (T)0);
-    double rr = some ? (double)m : __builtin_nan("");
-    if (a.noise_max == a.noise_max) rr = (rr < a.noise_max) ? rr : a.noise_max;
-    noise_out[(size_t)c * a.n_pblocks + pbk] = rr;
+    for (int o = 32; o > 0; o >>= 1) {
+      best = fmin(best, __shfl_down(best, o, 64));
+      any |= __shfl_down(any, o, 64);
+    }
+    if (lane == 0) {
+      red[wave] = best;
+      red[4 + wave] = (T)any;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      T m = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+      const bool some = (red[4] != (T)0) | (red[5] != (T)0) | (red[6] != (T)0) | (red[7] != (T)0);
+      double rr = some ? (double)m : __builtin_nan("");
+      if (a.noise_max == a.noise_max) rr = (rr < a.noise_max) ? rr : a.noise_max;
+      noise_out[(size_t)c * a.n_pblocks + pbk0 + g] = rr;
+    }
   }
 }
 
@@ -766,11 +788,11 @@ int set_lds(K kern, size_t lds) {
 template <typename T>
 int launch_pass1(Args& a, const float* raw, const double* coef, const double* alpha2, void* sv_out,
                  double* noise_out, int C, hipStream_t st) {
-  const size_t sum_bytes = ((size_t)a.n_rblocks * sizeof(T) + 15) & ~(size_t)15;
+  const size_t sum_bytes = ((size_t)kP1Blocks * a.n_rblocks * sizeof(T) + 15) & ~(size_t)15;
   a.cnt_off = (unsigned)sum_bytes;
-  a.tab_off = (unsigned)((sum_bytes + (size_t)a.n_rblocks * 4 + 15) & ~(size_t)15);
+  a.tab_off = (unsigned)((sum_bytes + (size_t)kP1Blocks * a.n_rblocks * 4 + 15) & ~(size_t)15);
   const size_t lds = a.tab_off + epa::kMathTabBytes;
-  const dim3 grid((unsigned)a.n_pblocks, (unsigned)C);
+  const dim3 grid((unsigned)((a.n_pblocks + kP1Blocks - 1) / kP1Blocks), (unsigned)C);
 #define EPA_P1(W, R)                                                                                    \
   do {                                                                                                  \
     auto kern = sv_noise_fast_kernel<T, W, R>;                                                          \
