@@ -38,6 +38,7 @@ struct Args {
   unsigned long long* rmax_key;
   unsigned long long* mm_keys;  // pass 2, optional [4]: min/max of Sv_noise, min/max of Sv_corrected
   int flagged_only;  // pass 2, general kernel after the uniform-group kernel: only the groups that one left (kLeftToGeneral)
+  int uni_bins;      // pass 2, uniform-group kernel: time bins per workgroup
 };
 
 __device__ __forceinline__ unsigned long long ordered_key(double v) {
@@ -619,11 +620,14 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_uniform_kernel
   __shared__ PingLin pl[kUniPings];
   __shared__ int differs;
 
-  const int c = blockIdx.y, tb = blockIdx.x;
+  // a workgroup takes a.uni_bins consecutive time bins (their pings are one run): the per-column constants are paid
+  // once for all of them; lsum / lcnt hold one row of range bins per time bin
+  const int c = blockIdx.y, tb0 = blockIdx.x * a.uni_bins;
+  const int nbn = min(a.uni_bins, a.n_tbins - tb0);
   const int S = a.S, n_rbins = a.n_rbins;
-  const int pb = bin_start[tb], pe = bin_start[tb + 1], np = pe - pb;
-  const size_t cell0 = ((size_t)c * a.n_tbins + tb) * n_rbins;
-  for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
+  const int pb = bin_start[tb0], pe = bin_start[tb0 + nbn], np = pe - pb;
+  const size_t cell0 = ((size_t)c * a.n_tbins + tb0) * n_rbins;
+  for (int i = threadIdx.x; i < nbn * n_rbins; i += epa::kBlock) {
     lsum[i] = (T)0;
     lcnt[i] = 0u;
   }
@@ -647,7 +651,8 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_uniform_kernel
   }
   __syncthreads();
   if (differs) {
-    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(mvbs_out + cell0)[0] = kLeftToGeneral;
+    if ((int)threadIdx.x < nbn)
+      reinterpret_cast<unsigned long long*>(mvbs_out + cell0 + (size_t)threadIdx.x * n_rbins)[0] = kLeftToGeneral;
     return;
   }
 
@@ -692,12 +697,29 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_uniform_kernel
       acc_sum[j] = (T)0;
       acc_cnt[j] = 0u;
     }
+    auto flush = [&](int g) {  // the columns' sums of time bin g -> its row of range bins
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (rbin[j] >= 0 && acc_cnt[j] > 0u) {
+          lds_add(lsum + g * n_rbins + rbin[j], acc_sum[j]);
+          atomicAdd(lcnt + g * n_rbins + rbin[j], acc_cnt[j]);
+        }
+        acc_sum[j] = (T)0;
+        acc_cnt[j] = 0u;
+      }
+    };
     float2 nA = make_float2(0.f, 0.f), nB = nA;
     if (np > 0) {
       nA = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sA);
       if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sB);
     }
+    int g = 0, edge = bin_start[tb0 + 1];  // first ping of the next time bin
     for (int p = pb; p < pe; ++p) {
+      while (p >= edge) {  // (uniform) ping p opens a later time bin; empty bins are stepped over
+        flush(g);
+        ++g;
+        edge = bin_start[tb0 + g + 1];
+      }
       const size_t row_off = (size_t)p * S;
       const float2 inA = nA, inB = nB;
       if (p + 1 < pe) {
@@ -737,13 +759,7 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_uniform_kernel
         if (hasB) epa::store_nt2(sc_c + row_off + sB, sc[2], sc[3]);
       }
     }
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      if (rbin[j] >= 0 && acc_cnt[j] > 0u) {
-        lds_add(lsum + rbin[j], acc_sum[j]);
-        atomicAdd(lcnt + rbin[j], acc_cnt[j]);
-      }
-    }
+    flush(g);
   }
   if (MINMAX) {
 #pragma unroll
@@ -768,7 +784,7 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_uniform_kernel
   T* out = mvbs_out + cell0;
   T* gsum = sum_out ? sum_out + cell0 : nullptr;
   uint32_t* gcnt = cnt_out ? cnt_out + cell0 : nullptr;
-  for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
+  for (int i = threadIdx.x; i < nbn * n_rbins; i += epa::kBlock) {
     const uint32_t n = lcnt[i];
     const T s = lsum[i];
     out[i] = n > 0u ? (T)10 * epa::M<T>::log10(s / (T)n) : (T)a.fill_value;
@@ -820,14 +836,21 @@ int launch_pass2(Args& a, const float* raw, const double* coef, const double* al
   }();
   if (sizeof(T) == 8 && a.n_tbins > 0 && a.n_rbins > 0 && !uniform_off) {
     // uniform ping groups first; the general kernel then takes the groups that one left, and the pings outside every bin
-    const dim3 ugrid((unsigned)a.n_tbins, (unsigned)C);
+    // two time bins per workgroup (the per-column constants paid once for both) when both rows of accumulators fit
+    Args au = a;
+    au.uni_bins = (size_t)2 * a.n_rbins * 12 + epa::kMathTabBytes <= 48 * 1024 ? 2 : 1;
+    const size_t usum = ((size_t)au.uni_bins * a.n_rbins * sizeof(double) + 15) & ~(size_t)15;
+    au.cnt_off = (unsigned)usum;
+    au.tab_off = (unsigned)((usum + (size_t)au.uni_bins * a.n_rbins * 4 + 15) & ~(size_t)15);
+    const size_t ulds = au.tab_off + epa::kMathTabBytes;
+    const dim3 ugrid((unsigned)((a.n_tbins + au.uni_bins - 1) / au.uni_bins), (unsigned)C);
 #define EPA_U2(N, K, M)                                                                                  \
   do {                                                                                                   \
     auto kern = sv_denoise_mvbs_uniform_kernel<N, K, M>;                                                 \
-    if (int rc = set_lds(kern, lds)) return rc;                                                          \
-    hipLaunchKernelGGL(kern, ugrid, dim3(epa::kBlock), lds, st, raw,                                     \
+    if (int rc = set_lds(kern, ulds)) return rc;                                                         \
+    hipLaunchKernelGGL(kern, ugrid, dim3(epa::kBlock), ulds, st, raw,                                    \
                        reinterpret_cast<const epa::CoefRow*>(coef), alpha2, noise, bin_start,            \
-                       (double*)noise_out, (double*)corr_out, (double*)mvbs_out, (double*)sum_out, cnt_out, a); \
+                       (double*)noise_out, (double*)corr_out, (double*)mvbs_out, (double*)sum_out, cnt_out, au); \
   } while (0)
 #define EPA_U2M(N, K)                                                                                    \
   do {                                                                                                   \
