@@ -517,6 +517,57 @@ def test_sv_complex_fft_path_matches_direct(env, in_dtype, out_dtype, fft_dtype,
     assert np.nanmax(np.abs(sf[strong] - sd[strong])) < tol  # NaN where R' <= 0 (both paths alike)
 
 
+@pytest.mark.parametrize("in_dtype", ["float32", "float64"])
+@pytest.mark.parametrize("out_dtype", ["float64", "float32"])
+@pytest.mark.parametrize("B,S,offset", [(4, 5000, 0), (4, 2049, 1), (3, 700, 0), (1, 300, 0), (6, 1000, 0)])
+def test_sv_complex_cw_streaming_kernel(env, in_dtype, out_dtype, B, S, offset):
+    """epa_sv_complex without a replica (CW: the streaming kernel) against a NumPy statement of calibrate_ek.py:483-490,
+    571-638: NaN-skipping sector mean, prx > 0 else NaN, masked echo_range (beam-0 real part), R' <= 0 -> NaN.  Four
+    sectors on 16-byte aligned planes take vector loads, every other sector count / an unaligned plane the scalar
+    form (offset = 1 element shifts the planes off the 16-byte boundary); ragged last piece, NaN tails, partly-NaN
+    samples, a missing beam 0."""
+    torch, ops, synth = env
+    rng = np.random.default_rng(B * 1000 + S)
+    C, P = 2, 5
+    amp = 10.0 ** rng.uniform(-6, 0, (C, P, S, 1))
+    re = (amp * rng.standard_normal((C, P, S, B))).astype(in_dtype)
+    im = (amp * rng.standard_normal((C, P, S, B))).astype(in_dtype)
+    re[:, 1, S - 40:], im[:, 1, S - 40:] = np.nan, np.nan
+    re[1, 2], im[1, 2] = np.nan, np.nan
+    re[0, 0, 50:60, B - 1] = np.nan       # one sector missing (the only one when B == 1)
+    im[0, 3, 100, 0] = np.nan             # imaginary part of beam 0 only: the range stays valid
+    re[1, 4, 200:203, 0] = np.nan         # beam 0 missing: echo_range and Sv NaN
+    cc = np.zeros((C, P, 8))
+    cc[..., 0], cc[..., 1], cc[..., 2], cc[..., 3], cc[..., 4], cc[..., 5] = 2.6e-5, 750.0, 0.2, 0.02, -30.0, 1e3
+    cc[..., 1] += rng.uniform(-1, 1, (C, P))
+    def dev_plane(a):  # optionally off the 16-byte boundary
+        flat = torch.empty(a.size + offset, dtype=getattr(torch, in_dtype), device="cuda")
+        flat[offset:] = torch.from_numpy(a.reshape(-1)).cuda()
+        return flat[offset:].view(a.shape)
+    res = ops.sv_complex(dev_plane(re), dev_plane(im), _dev(torch, cc), dtype=getattr(torch, out_dtype), want_prx=True)
+    # ---- the reference's arithmetic
+    z = re.astype(np.float64) + 1j * im.astype(np.float64)
+    with np.errstate(invalid="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        mean_b = np.nanmean(np.where(np.isnan(z), np.nan, z), axis=3)
+        prx = cc[..., 5:6] * np.abs(mean_b) ** 2
+        prx = np.where(prx > 0, prx, np.nan)
+        R = (np.arange(S)[None, None, :] * cc[..., 0:1]) * cc[..., 1:2]
+        R = np.where(np.isnan(re[..., 0]), np.nan, R)
+        Rt = R - cc[..., 2:3]
+        Rt = np.where(Rt > 0, Rt, np.nan)
+        exp = 10 * np.log10(prx) + 20 * np.log10(Rt) + cc[..., 3:4] * Rt + cc[..., 4:5]
+    got = res["out"].cpu().numpy().astype(np.float64)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+    ok = ~np.isnan(exp)
+    f32 = "float32" in (in_dtype, out_dtype) and out_dtype == "float32"
+    np.testing.assert_allclose(got[ok], exp[ok], rtol=0, atol=2e-3 if f32 else 1e-9)
+    er = res["echo_range"].cpu().numpy().astype(np.float64)
+    np.testing.assert_array_equal(np.isnan(er), np.isnan(R))
+    np.testing.assert_allclose(er[~np.isnan(R)], R[~np.isnan(R)], rtol=1e-6 if out_dtype == "float32" else 0, atol=0)
+    assert ok.mean() > 0.5
+
+
 # ---- the whole chain in two passes ------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("closed,few_bins,pn,bin_s", [("left", False, 20, 20), ("right", False, 20, 20),

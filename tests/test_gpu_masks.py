@@ -185,6 +185,21 @@ def test_attenuated_mask_sliding_blocks_vs_oracle(env, n):
     assert exp.any() and not exp.all()
 
 
+def test_attenuated_mask_layers_beyond_the_lds_ring(env):
+    """Layers longer than the 1024 samples a lane prefetches, and blocks of more than 20 480 values: the sliding kernel
+    takes the sweeping selection for those pings (same kernel, other branch)."""
+    torch, ops = env
+    C, P, S = 1, 70, 1500
+    sv, depth = _scene(C, P, S, 321, step=0.1, spikes=False)
+    rng = np.random.default_rng(9)
+    sv[:, rng.random(P) < 0.2, :] -= 7.0
+    for n, lo, hi in ((6, 10.0, 130.0), (12, 20.0, 110.0)):   # 1200-sample layer; 24 x 900 = 21 600 values per block
+        got = ops.attenuated_mask(_dev(torch, sv), _dev(torch, depth), lo, hi, n, -4.0).cpu().numpy().astype(bool)
+        exp = np.stack([omask.echopy_attenuated_signal_mask(sv[c], depth[c], lo, hi, n, -4.0) for c in range(C)])
+        np.testing.assert_array_equal(got, exp)
+        assert exp.any() and not exp.all()
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_attenuated_mask_vs_oracle(env, dtype):
     torch, ops = env
