@@ -591,13 +591,19 @@ def test_fused_chain_long_uniform_groups(env, bin_s):
     _chain_equivalence(env, "float64", "left", 620, 20, bin_s, 100000, S=512)
 
 
+def test_fused_chain_with_a_fine_range_grid(env):
+    """0.1-m range bins over 190 m: 1900 bins -- one row of LDS accumulators per workgroup instead of the two the
+    uniform-bin kernel otherwise keeps."""
+    _chain_equivalence(env, "float64", "left", 83, 20, 20, 100000, S=1000, rbin=0.1)
+
+
 def test_fused_chain_with_empty_time_bins(env):
     """A 130-s hole in the pings: time bins without a single ping between bins of uniform pings (the uniform-group
     pass 2 writes their fill value) -- and an all-NaN ping block in the noise estimate."""
     _chain_equivalence(env, "float64", "left", 140, 20, 20, 100000, S=512, gap_after=60)
 
 
-def _chain_equivalence(env, dtype, closed, P, pn, bin_s, ss_every, S=1000, gap_after=None):
+def _chain_equivalence(env, dtype, closed, P, pn, bin_s, ss_every, S=1000, gap_after=None, rbin=1.0):
     torch, ops, synth = env
     C = 2
     d = synth.ek60_numpy(C, P, S, ss_every=ss_every)
@@ -624,26 +630,26 @@ def _chain_equivalence(env, dtype, closed, P, pn, bin_s, ss_every, S=1000, gap_a
     n_t = int((ns[-1] - ns[0]) // dt_ns) + 1
     bs = ops.time_bin_offsets(_dev(torch, ns), int(ns[0]), dt_ns, n_t, closed=closed)
     _, rmax = ops.nanminmax(rg0)
-    n_r = len(np.arange(0, rmax + 1.0, 1.0)) - 1
-    m0 = ops.mvbs(sc0, bs, n_t, 1.0, n_r, range=rg0, closed=closed)["MVBS"]
+    n_r = len(np.arange(0, rmax + rbin, rbin)) - 1
+    m0 = ops.mvbs(sc0, bs, n_t, rbin, n_r, range=rg0, closed=closed)["MVBS"]
     # fp32 stores echo_range rounded to float32, the coefficient rows carry it in double: samples next to a
     # bin edge may change bins, so the affine / raw variants are held to the affine-binned reference
-    m0c = ops.mvbs(sc0, bs, n_t, 1.0, n_r, coef=coef, closed=closed)["MVBS"]
+    m0c = ops.mvbs(sc0, bs, n_t, rbin, n_r, coef=coef, closed=closed)["MVBS"]
     # fused pair (transmission loss / bins from the coefficient rows: no echo_range array is read)
     sv1, rg1, n1 = ops.sv_noise_fused(raw, coef, a2, pn, 50, dtype=dt, noise_max=-120.0, want_range=True)
     assert torch.equal(torch.nan_to_num(sv1, nan=1.0), torch.nan_to_num(sv0, nan=1.0))
     assert torch.equal(torch.nan_to_num(rg1, nan=-1.0), torch.nan_to_num(rg0, nan=-1.0))
     _assert_close(n1.cpu().numpy(), n0.cpu().numpy(), 1e-12 if dtype == "float64" else 1e-5, "noise estimate")
     tol = 1e-11 if dtype == "float64" else 2e-4
-    variants = [("range", lambda: ops.denoise_mvbs(sv1, a2, n1, pn, 3.0, bs, n_t, 1.0, n_r, closed=closed,
+    variants = [("range", lambda: ops.denoise_mvbs(sv1, a2, n1, pn, 3.0, bs, n_t, rbin, n_r, closed=closed,
                                                     want_noise=True, range=rg0)),
-                ("coef", lambda: ops.denoise_mvbs(sv1, a2, n1, pn, 3.0, bs, n_t, 1.0, n_r, closed=closed,
+                ("coef", lambda: ops.denoise_mvbs(sv1, a2, n1, pn, 3.0, bs, n_t, rbin, n_r, closed=closed,
                                                    want_noise=True, coef=coef)),
-                ("raw", lambda: ops.sv_denoise_mvbs(raw, coef, a2, n1, pn, 3.0, bs, n_t, 1.0, n_r, closed=closed,
+                ("raw", lambda: ops.sv_denoise_mvbs(raw, coef, a2, n1, pn, 3.0, bs, n_t, rbin, n_r, closed=closed,
                                                     dtype=dt, want_noise=True, want_range=True)),
                 # without echo_range out: the specialised two-pass kernels (csrc/chain_fast.hip) when closed="left"
                 ("raw-fast", lambda: ops.sv_denoise_mvbs(raw, coef, a2, ops.sv_noise_fused(
-                    raw, coef, a2, pn, 50, dtype=dt, noise_max=-120.0)[2], pn, 3.0, bs, n_t, 1.0, n_r, closed=closed,
+                    raw, coef, a2, pn, 50, dtype=dt, noise_max=-120.0)[2], pn, 3.0, bs, n_t, rbin, n_r, closed=closed,
                     dtype=dt, want_noise=True))]
     for name, run in variants:
         res = run()
@@ -659,7 +665,7 @@ def _chain_equivalence(env, dtype, closed, P, pn, bin_s, ss_every, S=1000, gap_a
     if dtype == "float64" and closed == "left":
         sv, er = _oracle_ek60(d, "Sv")
         exp_n, exp_c = oclean.remove_background_noise(sv, er, d["absorption_indicative"], pn, 50, "-120.0dB", "3.0dB")
-        exp_m, _, _ = ogrid.compute_MVBS(exp_c, er, d["ping_time"], "1m", f"{bin_s}s")
+        exp_m, _, _ = ogrid.compute_MVBS(exp_c, er, d["ping_time"], f"{rbin}m", f"{bin_s}s")
         _assert_close(res["Sv_corrected"].cpu().numpy(), exp_c, 1e-9, "oracle Sv_corrected")
         _assert_close(res["MVBS"].cpu().numpy(), exp_m, 1e-9, "oracle MVBS")
 
