@@ -40,7 +40,7 @@
 namespace {
 
 constexpr int kN = EPA_EK80_NFFT;
-constexpr int kPlane = kN + kN / 32;  // padded element count
+constexpr int kPlane = kN + kN / 8;  // padded element count
 constexpr int kMaxBeams = 8;
 static_assert(kN == 2048 && epa::kBlock == 256, "written for N = 2048, 256 lanes");
 
@@ -49,7 +49,10 @@ struct C2 {
   F re, im;
 };
 
-__device__ __forceinline__ int pad(int a) { return a + (a >> 5); }
+// One pad element per 8: with the lane <-> butterfly maps below the stride-8 and stride-1 passes of a wavefront are
+// free of bank conflicts (slot = element + element / 8 mod 32: 8 g + 9 r + o resp. 9 lane + r over the 32 lanes of a
+// read group), the stride-64 pass and the lane's own samples collide two-fold on 3 of 32 slots.
+__device__ __forceinline__ int pad(int a) { return a + (a >> 3); }
 
 // ---- LDS element access: float2 elements / separate double planes (8-byte accesses either way)
 template <typename F>
@@ -165,21 +168,41 @@ struct LaneMap {
 __device__ __forceinline__ LaneMap lane_map() {
   const int j = threadIdx.x;
   LaneMap m;
-  m.a1 = 512 * (j >> 6) + (j & 63);
-  m.t1 = 4 * (j & 63);
-  const int g = j >> 5, u = (j >> 3) & 3, b = (g & 3) + 4 * u + 16 * (g >> 2);
-  m.a2 = 64 * b + (j & 7);
-  m.t2 = 32 * (j & 7);
-  const int beta = (j & 1) | (((j >> 4) & 1) << 1) | (((j >> 1) & 7) << 2) | ((j >> 5) << 5);
-  m.a3 = 8 * beta;
+  // After the first pass the transform is four independent 512-point transforms, elements [512 w, 512 w + 512): a
+  // wavefront holds exactly one of them (64 lanes x 8 elements), so its three inner passes -- and their inverses --
+  // exchange data among its OWN lanes only: no workgroup barrier between them (LDS serves a wavefront's requests in
+  // order), two barriers per tile instead of seven.
+  const int w = j >> 6, l = j & 63;
+  m.a1 = 512 * w + l;
+  m.t1 = 4 * l;
+  m.a2 = 512 * w + 64 * (l >> 3) + (l & 7);
+  m.t2 = 32 * (l & 7);
+  m.a3 = 512 * w + 8 * l;
   return m;
 }
 
+// The twiddle table w_2048^m, m < 256.  The double-precision tile leaves no room for all 256 entries next to its
+// padded planes (4 workgroups per CU = 40 960 B each): SMALL keeps w^(4k), k < 64, and w^0..w^3 -- every index of
+// the inner passes is a multiple of 4, the first pass pays one complex product.
+template <typename F, bool SMALL>
+__device__ __forceinline__ C2<F> tw_any(const C2<F>* tw, int m) {
+  if (!SMALL) return tw[m];
+  return cmul(tw[m >> 2], tw[64 + (m & 3)]);
+}
+template <typename F, bool SMALL>
+__device__ __forceinline__ C2<F> tw_mul4(const C2<F>* tw, int t) {  // t % 4 == 0
+  return SMALL ? tw[t >> 2] : tw[t];
+}
+template <typename F>
+constexpr bool kSmallTw = sizeof(F) == 8;
+template <typename F>
+constexpr int kTwEntries = kSmallTw<F> ? 68 : 256;
+
 // first forward pass (sub-size 2048, radix 4, two butterflies per lane), on the lane's registers:
 // v[i] = sample j + 256 i.  tw = 256-entry table of w_2048^m.
-template <typename F>
+template <typename F, bool SMALL>
 __device__ __forceinline__ void fwd_pass0(C2<F> (&v)[8], const C2<F>* tw) {
-  const C2<F> wa = tw[threadIdx.x];
+  const C2<F> wa = tw_any<F, SMALL>(tw, threadIdx.x);
   const F kH = (F)0.70710678118654752440;
   const C2<F> wb = C2<F>{(wa.re + wa.im) * kH, (wa.im - wa.re) * kH};  // w^(j+256) = w^j e^{-i pi/4}
   dft4(v[0], v[2], v[4], v[6]);
@@ -187,9 +210,9 @@ __device__ __forceinline__ void fwd_pass0(C2<F> (&v)[8], const C2<F>* tw) {
   dft4(v[1], v[3], v[5], v[7]);
   twiddle4<F, false>(v[3], v[5], v[7], wb);
 }
-template <typename F>
+template <typename F, bool SMALL>
 __device__ __forceinline__ void inv_pass0(C2<F> (&v)[8], const C2<F>* tw) {
-  const C2<F> wa = tw[threadIdx.x];
+  const C2<F> wa = tw_any<F, SMALL>(tw, threadIdx.x);
   const F kH = (F)0.70710678118654752440;
   const C2<F> wb = C2<F>{(wa.re + wa.im) * kH, (wa.im - wa.re) * kH};
   twiddle4<F, true>(v[2], v[4], v[6], wa);
@@ -216,44 +239,45 @@ template <typename F>
 __device__ __forceinline__ void correlate(C2<F> (&v)[8], unsigned char* xs, const C2<F>* tw,
                                           const C2<F>* __restrict__ spec, const LaneMap& lm) {
   const int j = threadIdx.x;
-  fwd_pass0(v, tw);
+  constexpr bool SMALL = kSmallTw<F>;
+  fwd_pass0<F, SMALL>(v, tw);
 #pragma unroll
   for (int i = 0; i < 8; ++i) Xs<F>::st(xs, j + 256 * i, v[i]);
   __syncthreads();
   ld8<F, 64>(xs, lm.a1, v);
   dft8(v);
-  twiddle8<F, false>(v, tw[lm.t1]);
+  twiddle8<F, false>(v, tw_mul4<F, SMALL>(tw, lm.t1));
   st8<F, 64>(xs, lm.a1, v);
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();  // (own wavefront's data: ordering for the compiler only)
   ld8<F, 8>(xs, lm.a2, v);
   // the replica spectrum of the fused pass: 8 consecutive elements per lane, requested before the barrier
   C2<F> sp[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) sp[r] = spec[lm.a3 + r];
   dft8(v);
-  twiddle8<F, false>(v, tw[lm.t2]);
+  twiddle8<F, false>(v, tw_mul4<F, SMALL>(tw, lm.t2));
   st8<F, 8>(xs, lm.a2, v);
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();  // (own wavefront's data: ordering for the compiler only)
   ld8<F, 1>(xs, lm.a3, v);
   dft8(v);
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], sp[r]);
   idft8(v);
   st8<F, 1>(xs, lm.a3, v);
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();  // (own wavefront's data: ordering for the compiler only)
   ld8<F, 8>(xs, lm.a2, v);
-  twiddle8<F, true>(v, tw[lm.t2]);
+  twiddle8<F, true>(v, tw_mul4<F, SMALL>(tw, lm.t2));
   idft8(v);
   st8<F, 8>(xs, lm.a2, v);
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();  // (own wavefront's data: ordering for the compiler only)
   ld8<F, 64>(xs, lm.a1, v);
-  twiddle8<F, true>(v, tw[lm.t1]);
+  twiddle8<F, true>(v, tw_mul4<F, SMALL>(tw, lm.t1));
   idft8(v);
   st8<F, 64>(xs, lm.a1, v);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = Xs<F>::ld(xs, j + 256 * i);
-  inv_pass0(v, tw);
+  inv_pass0<F, SMALL>(v, tw);
 }
 
 // ---- workspace layout (doubles):
@@ -339,7 +363,7 @@ __global__ __launch_bounds__(epa::kBlock) void replica_prepare_kernel(const floa
   for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);  // ||tx||^2 (ek80_complex.py:372-391)
   if ((j & 63) == 0) red[j >> 6] = part;
   const LaneMap lm = lane_map();
-  fwd_pass0(v, tw);
+  fwd_pass0<double, false>(v, tw);
 #pragma unroll
   for (int i = 0; i < 8; ++i) Xs<double>::st(xs, j + 256 * i, v[i]);
   __syncthreads();
@@ -354,12 +378,12 @@ __global__ __launch_bounds__(epa::kBlock) void replica_prepare_kernel(const floa
   dft8(v);
   twiddle8<double, false>(v, tw[lm.t1]);
   st8<double, 64>(xs, lm.a1, v);
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   ld8<double, 8>(xs, lm.a2, v);
   dft8(v);
   twiddle8<double, false>(v, tw[lm.t2]);
   st8<double, 8>(xs, lm.a2, v);
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   ld8<double, 1>(xs, lm.a3, v);
   dft8(v);
   C2<double>* s64 = reinterpret_cast<C2<double>*>(ws + ws_spec64(C, c));
@@ -714,7 +738,7 @@ template <typename InT, typename T, typename F, int NB, bool MIXED>
 __global__ __launch_bounds__(epa::kBlock, MIXED ? 1 : (sizeof(F) == 4 ? EPA_FFT_WAVES_F32 : EPA_FFT_WAVES_F64))
 void sv_complex_fft_kernel(FftArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char xs[Xs<F>::kBytes];
-  __shared__ C2<F> tw[256];
+  __shared__ C2<F> tw[kTwEntries<F>];
   __shared__ unsigned long long nzw[33];
   __shared__ unsigned wp[34];
   __shared__ unsigned wflags[4];
@@ -723,7 +747,11 @@ void sv_complex_fft_kernel(FftArgs a) {
   const int j = threadIdx.x;
   if (MIXED && *a.mixed_cnt == 0u) return;  // the usual case: no tile was deferred
 
-  tw[j] = reinterpret_cast<const C2<F>*>(a.ws + (sizeof(F) == 4 ? ws_tw32() : ws_tw64()))[j];
+  {
+    const C2<F>* wtab = reinterpret_cast<const C2<F>*>(a.ws + (sizeof(F) == 4 ? ws_tw32() : ws_tw64()));
+    if (!kSmallTw<F>) tw[j] = wtab[j];
+    else if (j < 68) tw[j] = j < 64 ? wtab[4 * j] : wtab[j - 64];
+  }
   if (sizeof(T) == 8 && j < epa::kLogTabN) log_tab[j] = reinterpret_cast<const double2*>(a.log_tab)[j];
   const LaneMap lm = lane_map();
   const TileLds<F, T> L{xs, tw, nzw, wp, wflags, log_tab, sred};
