@@ -20,13 +20,18 @@
 //     order by replica_prepare, and the inverse transform is the transposed algorithm (decimation in time,
 //     radix 8.8.8.4) which takes digit-reversed input back to natural order.  The last forward pass, the
 //     spectral product and the first inverse pass work on the same eight elements of a lane and are fused
-//     in registers.  Per tile: 6 LDS round trips and 6 barriers (the Stockham form this replaces needed 11
-//     round trips and ~20 barriers), first and last pass entirely in registers.
-//   * LDS elements are 8 bytes (float2; fp64 keeps separate re / im planes), one pad element per 32, and
-//     the lane <-> butterfly maps of the stride-8 and stride-1 passes are chosen so that every ds_read_b64 /
-//     ds_write_b64 of every pass is bank-conflict free (the model is scripts/fft_bank_model.py).
-//   * fft_dtype F32: complex64 butterflies (v_pk_* candidates), 19 KiB LDS per workgroup; F64: 40 KiB
-//     (4 workgroups per CU).  FFT errors scale with the strongest echo of the TILE, not with the sample:
+//     in registers.  Per tile: 6 LDS round trips (the Stockham form this replaces needed 11 round trips and
+//     ~20 barriers), first and last pass entirely in registers.
+//   * after the first pass the transform is FOUR independent 512-point transforms, and a wavefront holds
+//     exactly one of them (64 lanes x 8 elements): the three inner passes and their inverses exchange data
+//     among the lanes of one wavefront only, which needs no workgroup barrier (LDS serves a wavefront's
+//     requests in order).  Two barriers per tile are left -- after the first pass's stores, before the last
+//     pass's loads.
+//   * LDS elements are 8 bytes (float2; fp64 keeps separate re / im planes), one pad element per 8: the
+//     stride-8 and stride-1 passes of a wavefront are bank-conflict free with the plain lane <-> butterfly
+//     maps, the stride-64 pass and the lane's own samples collide two-fold on 3 of 32 slots.
+//   * fft_dtype F32: complex64 butterflies (v_pk_* candidates), 21 KiB LDS per workgroup; F64: 39.6 KiB
+//     (4 workgroups per CU: to stay under 40 960 B it keeps 68 twiddles instead of 256, see tw_any).
 //     F32 keeps 1e-3 relative on dB values up to ~90 dB of in-tile dynamic range and is the default for
 //     float32 output only.
 //   * the direct form returns an exact 0 where every staged sample under the replica's non-zero taps is 0
