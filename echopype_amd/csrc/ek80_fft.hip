@@ -32,6 +32,7 @@
 //     maps, the stride-64 pass and the lane's own samples collide two-fold on 3 of 32 slots.
 //   * fft_dtype F32: complex64 butterflies (v_pk_* candidates), 21 KiB LDS per workgroup; F64: 39.6 KiB
 //     (4 workgroups per CU: to stay under 40 960 B it keeps 68 twiddles instead of 256, see tw_any).
+//     FFT errors scale with the strongest echo of the TILE, not with the sample:
 //     F32 keeps 1e-3 relative on dB values up to ~90 dB of in-tile dynamic range and is the default for
 //     float32 output only.
 //   * the direct form returns an exact 0 where every staged sample under the replica's non-zero taps is 0
