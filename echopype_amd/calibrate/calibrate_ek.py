@@ -13,7 +13,7 @@ import torch
 
 from .. import _lib, ops
 from ..echodata import BEAM1
-from ..xr_lite import DataArray, Dataset, DeviceArray
+from ..xr_lite import DataArray, Dataset, DeviceArray, host_readable
 from .cal_params import PulseTableParam, get_cal_params_EK
 from .calibrate_base import ECHO_DIMS, CalibrateBase, cp_array
 from .ek80_complex import get_filter_coeff, get_tau_effective, get_transmit_signal
@@ -124,7 +124,7 @@ class CalibrateEK(CalibrateBase):
     def _tau_effective(self, flag_complex):
         """Effective pulse length per channel (calibrate_ek.py:113-151 / :583-607)."""
         tdn = self.beam["transmit_duration_nominal"]
-        if isinstance(tdn.data, DeviceArray) and tuple(tdn.dims) == ("channel", "ping_time"):
+        if isinstance(tdn.data, DeviceArray) and not host_readable(tdn.data) and tuple(tdn.dims) == ("channel", "ping_time"):
             tau_nom0 = tdn.data.tensor[:, 0].double().cpu().numpy()  # C values
         else:
             tau_nom0 = np.asarray(self._cp(tdn, "transmit_duration_nominal"))[:, 0]
@@ -259,7 +259,7 @@ class CalibrateEK80(CalibrateEK):
             f0 = cp_array(self.beam["transmit_frequency_start"], C, P)
             f1 = cp_array(self.beam["transmit_frequency_stop"], C, P)
             tdn = self.beam["transmit_duration_nominal"]
-            tdn_host = not isinstance(tdn.data, DeviceArray)
+            tdn_host = host_readable(tdn.data)
             tau = cp_array(tdn, C, P) if tdn_host else None
             const = lambda a: a is not None and bool(np.all((a == a[:, :1]) | np.isnan(a)))  # noqa: E731
             # The usual file sweeps the same band with the same pulse on every ping: the (channel, ping_time) centre

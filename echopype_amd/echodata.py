@@ -57,7 +57,14 @@ class EchoData:
             for name, da in list(ds.data_vars.items()):
                 if isinstance(da.data, DeviceArray) or da.ndim < 2 or da.dtype.kind != "f":
                     continue
-                ds.data_vars[name] = DataArray(DeviceArray(ops.to_device(np.asarray(da.data), device=device)), da.dims,
+                host = np.asarray(da.data)
+                # per-(channel, ping) parameters keep a read-only view of their host copy: the host logic that only has
+                # to LOOK at them (is the pulse the same on every ping?) then never copies anything back
+                mirror = None
+                if host.nbytes <= 64 * 1024 * 1024:
+                    mirror = host.view()
+                    mirror.flags.writeable = False
+                ds.data_vars[name] = DataArray(DeviceArray(ops.to_device(host, device=device), host=mirror), da.dims,
                                                da.coords, da.attrs, name)
         return self
 

@@ -26,10 +26,13 @@ class DeviceArray:
     """An array resident in GPU memory (wraps a torch CUDA tensor).  C-contiguous except for lazily transposed
     views (the impulse-noise mask); whoever hands the buffer to a kernel asks for ``.contiguous()`` first."""
 
-    __slots__ = ("tensor", "_stats")
+    __slots__ = ("tensor", "_stats", "_host")
 
-    def __init__(self, tensor, stats=None):
+    def __init__(self, tensor, stats=None, host=None):
         self.tensor = tensor
+        # optional host copy the tensor was uploaded from (small parameter arrays, EchoData.to_device): host-side
+        # decisions read it instead of copying the array back; void once the tensor has been modified in place
+        self._host = (host, tensor._version) if host is not None else None
         # optional (f64 device tensor {nanmin, nanmax, NaN count}, tensor._version when they were taken): a
         # by-product of the kernel that wrote the array; void once the tensor has been modified in place
         self._stats = (stats, tensor._version) if stats is not None else None
@@ -58,7 +61,10 @@ class DeviceArray:
         return self.tensor.numel() * self.tensor.element_size()
 
     def __array__(self, dtype=None, copy=None):
-        a = self.tensor.detach().cpu().numpy()
+        if self._host is not None and self._host[1] == self.tensor._version:
+            a = self._host[0]
+        else:
+            a = self.tensor.detach().cpu().numpy()
         return a.astype(dtype) if dtype is not None else a
 
     def __repr__(self):
@@ -67,6 +73,14 @@ class DeviceArray:
 
 def is_device(a):
     return isinstance(a, DeviceArray)
+
+
+def host_readable(a):
+    """True when np.asarray(a) costs no device-to-host copy: a host array, or a DeviceArray that still holds the host
+    copy it was uploaded from."""
+    if not isinstance(a, DeviceArray):
+        return True
+    return a._host is not None and a._host[1] == a.tensor._version
 
 
 class DataArray:

@@ -581,3 +581,26 @@ def test_remove_background_noise_matches_reference_function_goldens(ep, tag):
     close(out["Sv_corrected"].values, g[f"{tag}_Sv_corrected"], 1e-9, "Sv_corrected")
     got_rng = out["Sv_noise"].attrs["actual_range"] + out["Sv_corrected"].attrs["actual_range"]
     np.testing.assert_allclose(got_rng, g[f"{tag}_noise_attrs_range"], atol=0.011)  # rounded to 2 decimals
+
+
+def test_to_device_keeps_a_host_view_of_the_parameters(ep):
+    """EchoData.to_device(): the per-(channel, ping) parameters are readable on the host without a device-to-host
+    copy (the calibrators decide e.g. "is the pulse the same on every ping?" from them), the view is read-only, and it
+    is dropped as soon as the device tensor is modified in place; the sample planes carry no view."""
+    import torch
+
+    from echopype_amd.xr_lite import DeviceArray, host_readable
+
+    d = ep.synth.ek60_numpy(2, 30, 64)
+    ed = ep.echodata.from_ek60_arrays(d).to_device()
+    beam = ed["Sonar/Beam_group1"]
+    ss = beam["transmit_duration_nominal"].data
+    assert isinstance(ss, DeviceArray) and host_readable(ss)
+    a = np.asarray(ss)
+    np.testing.assert_array_equal(a, d["transmit_duration_nominal"])
+    assert not a.flags.writeable
+    ss.tensor.mul_(2.0)  # in place: the host view is stale now
+    assert not host_readable(ss)
+    np.testing.assert_array_equal(np.asarray(ss), 2.0 * d["transmit_duration_nominal"])
+    big = DeviceArray(torch.zeros(4, device="cuda"))
+    assert not host_readable(big)
