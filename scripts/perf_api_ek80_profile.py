@@ -24,4 +24,4 @@ for resident in (False, True):
         del r; torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     print(f"parameters {'in HBM' if resident else 'on the host'}: compute_Sv {np.median(ts)*1e3:7.2f} ms")
     pr = cProfile.Profile(); pr.enable(); r = f(); torch.cuda.synchronize(); pr.disable()
-    pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(30)
