@@ -1515,66 +1515,216 @@ __device__ __forceinline__ int bound_hint(const T* __restrict__ row, int n, T v,
   return bound<T, STRICT>(row, n, v);
 }
 
+// ---- value windows over pings whose range rows differ: running sums W, neighbour rows staged in LDS -----------------
+// One lane per sample with the bounds and W[hi-1], W[lo-1] read from global memory asks the L1 for ~14 scattered loads
+// per (sample, neighbour ping): with 2n + 1 = 51 pings that is ~7 KB of cache traffic per sample, and the kernel ran
+// at the L1's rate (2.4 Gsamp/s).  Here a workgroup takes kStageRows consecutive pings x 256 range columns.  For every neighbour ping q it needs the index span
+// [kmin, kmax) of q's range row that the windows of ALL its samples can reach: the rows are non-decreasing, so two
+// binary searches per neighbour, and the searches of all neighbours run side by side on the workgroup's lanes before
+// the loop.  Per neighbour the span of the range row and of the running sums W is copied into LDS with coalesced loads
+// (fetched into registers while the previous neighbour is being summed), every lane resolves its own window bounds in
+// LDS and reads W[hi-1], W[lo-1] there.  Pings of the group with the same range value at a column -- all of them while
+// the recorded sound speed holds -- share the interval and its sum: resolved once per (neighbour, column), added to
+// each ping that has q inside its ping window.  A span longer than kStageCap, a row holding a +inf Sv (summed value
+// by value), or a ping window of more than kSpanMax neighbours reads global memory directly for that (ping, q) pair.
+// Counters on 4 x 20 000 x 2000 fp64 (scripts/gpu_pmc_value_windows.sh): 1500 VALU + 2000 SALU + 130 LDS instructions
+// per sample, 58 % of the wave cycles waiting (the copies and the two barriers per neighbour), 28 ms = 5.6 Gsamp/s.
+constexpr int kStageRows = 8, kStageLoads = 3, kStageCap = kStageLoads * kBlock - 1, kSpanMax = 512;
+
 template <typename T>
-__global__ __launch_bounds__(kBlock) void pool_value_mean_prefix_kernel(PoolValueArgs<T> a, long long rows,
+__global__ __launch_bounds__(kBlock) void pool_value_mean_staged_kernel(PoolValueArgs<T> a, int C,
                                                                         const double* __restrict__ wh,
                                                                         const double* __restrict__ wl,
                                                                         const int* __restrict__ wn,
                                                                         const uint8_t* __restrict__ dirty,
                                                                         const int* __restrict__ differ) {
   __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
+  __shared__ T seg_r[kStageCap];
+  __shared__ double seg_h[kStageCap + 1], seg_l[kStageCap + 1];
+  __shared__ int seg_n[kStageCap + 1];
+  __shared__ double red_lo[4], red_hi[4];
+  __shared__ int kspan[2 * kSpanMax];
   const epa::MathTabs mt = epa::build_math_tabs(tabs);
   __syncthreads();
   const int s = blockIdx.y * kBlock + threadIdx.x;
-  if (s >= a.S) return;
-  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
-    const int p = (int)(row % a.P);
-    const long long c = row / a.P;
+  const bool in_row = s < a.S;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int groups_per_channel = (a.P + kStageRows - 1) / kStageRows;
+  const long long ngroups = (long long)C * groups_per_channel;
+  for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const long long c = grp / groups_per_channel;
     if (!differ[c]) continue;  // every ping of the channel has the same range vector: value_slide_kernel
-    const size_t at = (size_t)row * a.S + s;
-    const T d = a.range[at];
-    T out = epa::M<T>::nan();
-    if (pool_feasible(a, d, p)) {
-      const T lo_v = d - a.bin, hi_v = d + a.bin;
-      Dd sum{0.0, 0.0};
-      long long cnt = 0;
-      bool has_inf = false;
-      int lo = -1, hi = -1;
-      const int q1 = min(p + a.n, a.P - 1);
-      for (int q = p - a.n; q <= q1; ++q) {
+    const int p0 = (int)(grp - c * groups_per_channel) * kStageRows;
+    const int nrows = min(kStageRows, a.P - p0);
+    // ---- this lane's samples of the group's pings
+    T d[kStageRows];
+    unsigned feas = 0;
+    double vmin = __builtin_inf(), vmax = -__builtin_inf();
+#pragma unroll
+    for (int r = 0; r < kStageRows; ++r) {
+      d[r] = epa::M<T>::nan();
+      if (r < nrows && in_row) {
+        d[r] = a.range[((size_t)(c * a.P + p0 + r)) * a.S + s];
+        if (pool_feasible(a, d[r], p0 + r)) {
+          feas |= 1u << r;
+          vmin = fmin(vmin, (double)(d[r] - a.bin));
+          vmax = fmax(vmax, (double)(d[r] + a.bin));
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      vmin = fmin(vmin, __shfl_down(vmin, o, 64));
+      vmax = fmax(vmax, __shfl_down(vmax, o, 64));
+    }
+    __syncthreads();  // (the previous group is done with red / kspan / the staged span)
+    if (lane == 0) {
+      red_lo[wave] = vmin;
+      red_hi[wave] = vmax;
+    }
+    __syncthreads();
+    const T gmin = (T)fmin(fmin(red_lo[0], red_lo[1]), fmin(red_lo[2], red_lo[3]));
+    const T gmax = (T)fmax(fmax(red_hi[0], red_hi[1]), fmax(red_hi[2], red_hi[3]));
+    Dd sum[kStageRows];
+    int cnt[kStageRows], lo[kStageRows], hi[kStageRows];
+    unsigned has_inf = 0;
+#pragma unroll
+    for (int r = 0; r < kStageRows; ++r) {
+      sum[r] = Dd{0.0, 0.0};
+      cnt[r] = 0;
+      lo[r] = hi[r] = -1;
+    }
+    if (gmin <= gmax) {  // (uniform) some window of the group is feasible
+      const int q_first = max(p0 - a.n, 0), q_last = min(p0 + nrows - 1 + a.n, a.P - 1);
+      const int nq = q_last - q_first + 1;
+      const bool can_stage = nq <= kSpanMax;  // (uniform)
+      if (can_stage) {  // the spans of all neighbours: one binary search per lane, side by side
+        for (int i = threadIdx.x; i < 2 * nq; i += kBlock) {
+          const size_t row = (size_t)(c * a.P + q_first) + (i >> 1);
+          const T* r2 = a.range + row * a.S;
+          kspan[i] = (i & 1) ? bound<T, true>(r2, a.nvalid[row], gmax) : bound<T, false>(r2, a.nvalid[row], gmin);
+        }
+      }
+      __syncthreads();
+      // a neighbour's span travels HBM/L2 -> registers while the previous neighbour is being summed, registers -> LDS after
+      T pre_r[kStageLoads];
+      double pre_h[kStageLoads], pre_l[kStageLoads];
+      int pre_n[kStageLoads];
+      auto staged_at = [&](int qi) {
+        return can_stage && kspan[2 * qi + 1] - kspan[2 * qi] <= kStageCap && dirty[(size_t)(c * a.P + q_first + qi)] == 0;
+      };
+      auto fetch = [&](int qi) {
+        if (!staged_at(qi)) return;
+        const size_t base = (size_t)(c * a.P + q_first + qi) * a.S;
+        const int kmin = kspan[2 * qi], len = kspan[2 * qi + 1] - kmin;
+#pragma unroll
+        for (int u = 0; u < kStageLoads; ++u) {
+          const int i = threadIdx.x + u * kBlock, k = kmin - 1 + i;  // entry i of the sums = W[kmin - 1 + i]
+          pre_r[u] = i < len ? a.range[base + kmin + i] : (T)0;
+          const bool in = i <= len && k >= 0;
+          pre_h[u] = in ? wh[base + k] : 0.0;
+          pre_l[u] = in ? wl[base + k] : 0.0;
+          pre_n[u] = in ? wn[base + k] : 0;
+        }
+      };
+      fetch(0);
+      for (int q = q_first; q <= q_last; ++q) {
+        const int qi = q - q_first;
         const size_t qrow = (size_t)(c * a.P + q);
         const T* rr = a.range + qrow * a.S;
         const int nv = a.nvalid[qrow];
-        lo = bound_hint<T, false>(rr, nv, lo_v, lo);
-        hi = bound_hint<T, true>(rr, nv, hi_v, hi);
-        if (hi <= lo) continue;
         const size_t base = qrow * a.S;
-        if (dirty[qrow]) {  // a +inf Sv somewhere in this row: value by value
-          const T* vr = a.sv + base;
-          for (int k = lo; k < hi; ++k) {
-            const T v = vr[k];
-            if (v == v) {
-              const double x = (double)epa::lin_from_db(v, mt.exp2_tab);
-              if (x == __builtin_inf()) has_inf = true; else sum.add(x);
-              ++cnt;
+        const bool dirty_q = dirty[qrow] != 0;
+        const bool staged = staged_at(qi);  // (uniform)
+        const int kmin = can_stage ? kspan[2 * qi] : 0, len = can_stage ? kspan[2 * qi + 1] - kmin : 0;
+        __syncthreads();  // the previous neighbour's span has been consumed
+        if (staged) {
+#pragma unroll
+          for (int u = 0; u < kStageLoads; ++u) {
+            const int i = threadIdx.x + u * kBlock;
+            if (i < len) seg_r[i] = pre_r[u];
+            if (i <= len) {
+              seg_h[i] = pre_h[u];
+              seg_l[i] = pre_l[u];
+              seg_n[i] = pre_n[u];
             }
           }
-          continue;
         }
-        sum.add(Dd{wh[base + hi - 1], wl[base + hi - 1]}, 1.0);
-        cnt += wn[base + hi - 1];
-        if (lo > 0) {
-          sum.add(Dd{wh[base + lo - 1], wl[base + lo - 1]}, -1.0);
-          cnt -= wn[base + lo - 1];
+        __syncthreads();
+        if (q < q_last) fetch(qi + 1);
+        // the group's pings that have q inside their ping window [p - n, min(p + n, P - 1)]
+        const int r_lo = max(q - a.n - p0, 0), r_hi = min(q + a.n - p0, nrows - 1);
+        // pings of the group that share a range value at this column (all of them, while the sound speed holds) share
+        // the interval in q's row and its sum: resolved once, added to each
+        T same_d = epa::M<T>::nan();
+        int same_l = 0, same_h = 0, same_c = 0;
+        double same_w = 0.0;
+#pragma unroll
+        for (int r = 0; r < kStageRows; ++r) {
+          if (r < r_lo || r > r_hi || !((feas >> r) & 1u)) continue;
+          const T lo_v = d[r] - a.bin, hi_v = d[r] + a.bin;
+          if (staged) {
+            if (d[r] != same_d) {
+              // the bounds inside the span are the bounds in the whole row: everything before kmin is below every
+              // window of the group, everything from kmax on above
+              const int l = bound_hint<T, false>(seg_r, len, lo_v, lo[r] - kmin);
+              const int h = bound_hint<T, true>(seg_r, len, hi_v, hi[r] - kmin);
+              same_d = d[r];
+              same_l = kmin + l;
+              same_h = kmin + h;
+              same_w = 0.0;
+              same_c = 0;
+              if (h > l) {
+                // W[hi-1] - W[lo-1] in double-double (nothing lost to cancellation: the row total may be 1e14 times
+                // the window's), then a plain sum of the -- non-negative -- window sums
+                Dd w{seg_h[h], seg_l[h]};
+                w.add(Dd{seg_h[l], seg_l[l]}, -1.0);
+                same_w = w.hi + w.lo;
+                same_c = seg_n[h] - seg_n[l];
+              }
+            }
+            lo[r] = same_l;
+            hi[r] = same_h;
+            sum[r].hi += same_w;
+            cnt[r] += same_c;
+          } else {
+            lo[r] = bound_hint<T, false>(rr, nv, lo_v, lo[r]);
+            hi[r] = bound_hint<T, true>(rr, nv, hi_v, hi[r]);
+            if (hi[r] <= lo[r]) continue;
+            if (dirty_q) {  // a +inf Sv somewhere in this row: value by value
+              const T* vr = a.sv + base;
+              for (int k = lo[r]; k < hi[r]; ++k) {
+                const T v = vr[k];
+                if (v == v) {
+                  const double x = (double)epa::lin_from_db(v, mt.exp2_tab);
+                  if (x == __builtin_inf()) has_inf |= 1u << r; else sum[r].add(x);
+                  ++cnt[r];
+                }
+              }
+              continue;
+            }
+            sum[r].add(Dd{wh[base + hi[r] - 1], wl[base + hi[r] - 1]}, 1.0);
+            cnt[r] += wn[base + hi[r] - 1];
+            if (lo[r] > 0) {
+              sum[r].add(Dd{wh[base + lo[r] - 1], wl[base + lo[r] - 1]}, -1.0);
+              cnt[r] -= wn[base + lo[r] - 1];
+            }
+          }
         }
-      }
-      if (cnt > 0) {
-        const double tot = has_inf ? __builtin_inf() : sum.hi + sum.lo;
-        out = (T)(10.0 * epa::fast_log10(tot / (double)cnt, mt.log_tab));
       }
     }
-    if (a.pooled) a.pooled[at] = out;
-    if (a.mask) a.mask[at] = (a.sv[at] - out > a.thr) ? 1 : 0;
+#pragma unroll
+    for (int r = 0; r < kStageRows; ++r) {
+      if (r >= nrows || !in_row) continue;
+      T out = epa::M<T>::nan();
+      if (((feas >> r) & 1u) && cnt[r] > 0) {
+        const double tot = ((has_inf >> r) & 1u) ? __builtin_inf() : sum[r].hi + sum[r].lo;
+        out = (T)(10.0 * epa::fast_log10(tot / (double)cnt[r], mt.log_tab));
+      }
+      const size_t at = ((size_t)(c * a.P + p0 + r)) * a.S + s;
+      if (a.pooled) a.pooled[at] = out;
+      if (a.mask) a.mask[at] = (a.sv[at] - out > a.thr) ? 1 : 0;
+    }
   }
 }
 
@@ -2019,8 +2169,12 @@ int launch_pool_value(const void* sv, const void* range, const int32_t* nvalid, 
       hipLaunchKernelGGL(value_slide_kernel<T>, g2, dim3(kBlock), epa::kMathTabBytes + kSlidePad, st, a, differ, ilo, rh,
                          rl, rn);
       if (int rc = epa::check_launch("value_slide_kernel")) return rc;
-      hipLaunchKernelGGL(pool_value_mean_prefix_kernel<T>, grid, dim3(kBlock), 0, st, a, rows, wh, wl, wn, dirty, differ);
-      return epa::check_launch("pool_value_mean_prefix_kernel");
+      {  // channels whose pings differ in their range vectors: neighbour rows staged in LDS
+        const long long ngroups = (long long)C * ((P + kStageRows - 1) / kStageRows);
+        const dim3 sgrid((unsigned)std::min<long long>(ngroups, 65535 * 4), grid.y);
+        hipLaunchKernelGGL(pool_value_mean_staged_kernel<T>, sgrid, dim3(kBlock), 0, st, a, C, wh, wl, wn, dirty, differ);
+      }
+      return epa::check_launch("pool_value_mean_staged_kernel");
     }
     hipLaunchKernelGGL(pool_value_mean_kernel<T>, grid, dim3(kBlock), 0, st, a, rows);
     return epa::check_launch("pool_value_mean_kernel");
