@@ -1504,13 +1504,19 @@ __global__ __launch_bounds__(kBlock) void row_running_sum_kernel(const T* __rest
   }
 }
 
-// first index with row[idx] >= v / > v, trying the answer of the previous row first
+// first index with row[idx] >= v / > v, trying the answer of the previous row first and, when that is off, its
+// neighbours (range rows that differ by a heave offset or a drifting sound speed move the answer by a sample or two)
 template <typename T, bool STRICT>
 __device__ __forceinline__ int bound_hint(const T* __restrict__ row, int n, T v, int hint) {
   if (hint >= 0 && hint <= n) {
-    const bool below = hint == 0 || !(STRICT ? (row[hint - 1] > v) : (row[hint - 1] >= v));
-    const bool above = hint == n || (STRICT ? (row[hint] > v) : (row[hint] >= v));
-    if (below && above) return hint;
+    int h = hint;
+#pragma unroll 1
+    for (int tries = 0; tries < 4; ++tries) {
+      const bool below = h == 0 || !(STRICT ? (row[h - 1] > v) : (row[h - 1] >= v));
+      const bool above = h == n || (STRICT ? (row[h] > v) : (row[h] >= v));
+      if (below && above) return h;
+      h += below ? 1 : -1;  // (below: row[h] is still short of v; otherwise row[h - 1] already reaches it)
+    }
   }
   return bound<T, STRICT>(row, n, v);
 }
@@ -1518,29 +1524,36 @@ __device__ __forceinline__ int bound_hint(const T* __restrict__ row, int n, T v,
 // ---- value windows over pings whose range rows differ: running sums W, neighbour rows staged in LDS -----------------
 // One lane per sample with the bounds and W[hi-1], W[lo-1] read from global memory asks the L1 for ~14 scattered loads
 // per (sample, neighbour ping): with 2n + 1 = 51 pings that is ~7 KB of cache traffic per sample, and the kernel ran
-// at the L1's rate (2.4 Gsamp/s).  Here a workgroup takes kStageRows consecutive pings x 256 range columns.  For every neighbour ping q it needs the index span
-// [kmin, kmax) of q's range row that the windows of ALL its samples can reach: the rows are non-decreasing, so two
-// binary searches per neighbour, and the searches of all neighbours run side by side on the workgroup's lanes before
-// the loop.  Per neighbour the span of the range row and of the running sums W is copied into LDS with coalesced loads
-// (fetched into registers while the previous neighbour is being summed), every lane resolves its own window bounds in
-// LDS and reads W[hi-1], W[lo-1] there.  Pings of the group with the same range value at a column -- all of them while
-// the recorded sound speed holds -- share the interval and its sum: resolved once per (neighbour, column), added to
-// each ping that has q inside its ping window.  A span longer than kStageCap, a row holding a +inf Sv (summed value
-// by value), or a ping window of more than kSpanMax neighbours reads global memory directly for that (ping, q) pair.
-// Counters on 4 x 20 000 x 2000 fp64 (scripts/gpu_pmc_value_windows.sh): 1500 VALU + 2000 SALU + 130 LDS instructions
-// per sample, 58 % of the wave cycles waiting (the copies and the two barriers per neighbour), 28 ms = 5.6 Gsamp/s.
+// at the L1's rate (2.4 Gsamp/s; 1.5 when a heave offset moved the bounds from ping to ping).  Here a workgroup takes
+// kStageRows consecutive pings x 256 range columns.  For every neighbour ping q it needs the index span [kmin, kmax)
+// of q's range row that the windows of ALL its samples can reach: the rows are non-decreasing, so two binary searches
+// per neighbour, and the searches of all neighbours run side by side on the workgroup's lanes before the loop.  Per
+// neighbour the span of the range row and of the running sums W is copied into LDS with coalesced loads (fetched into
+// registers while the previous neighbour is being summed).  A lane's window bounds inside the span: range rows are
+// affine in the sample index (echo_range, depth = echo_range x cos(tilt) + offset), so the position is computed from
+// the span's two ends and confirmed on the four values around it (sentinels at both ends, no bounds checks, no
+// branches) -- a wavefront with a lane that cannot confirm searches the span instead.  The window sum is
+// (Wh[hi-1] - Wh[lo-1]) + (Wl[hi-1] - Wl[lo-1]).  Pings of the group with the same range value at a column -- all of
+// them while the recorded sound speed holds -- share the interval and its sum: resolved once per (neighbour,
+// wavefront), added to each ping that has q inside its ping window.  A span longer than kStageCap, a row holding a
+// +inf Sv (summed value by value), or a ping window of more than kSpanMax neighbours reads global memory directly for
+// that (ping, q) pair.  4 x 20 000 x 2000: 20 ms fp64 / 18 ms fp32 when the range vector changes every 2000 pings,
+// 29 / 25 ms with a heave offset on every ping (57 / 109 ms before); three workgroups per CU (launch bound: 168
+// registers; the fp64 instantiation spills 12 dwords outside the loop over neighbours).
 constexpr int kStageRows = 8, kStageLoads = 3, kStageCap = kStageLoads * kBlock - 1, kSpanMax = 512;
 
 template <typename T>
-__global__ __launch_bounds__(kBlock) void pool_value_mean_staged_kernel(PoolValueArgs<T> a, int C,
+__global__ __launch_bounds__(kBlock, 3) void pool_value_mean_staged_kernel(PoolValueArgs<T> a, int C,
                                                                         const double* __restrict__ wh,
                                                                         const double* __restrict__ wl,
                                                                         const int* __restrict__ wn,
                                                                         const uint8_t* __restrict__ dirty,
                                                                         const int* __restrict__ differ) {
   __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
-  __shared__ T seg_r[kStageCap];
-  __shared__ double seg_h[kStageCap + 1], seg_l[kStageCap + 1];
+  // seg_r[2 + i] = range[kmin + i], two -inf before and two +inf behind: the three candidate positions around a guess
+  // are tested without a bounds check
+  __shared__ T seg_r[kStageCap + 4];
+  __shared__ double seg_h[kStageCap + 1], seg_l[kStageCap + 1];  // entry i = W[kmin - 1 + i] (0 before the row)
   __shared__ int seg_n[kStageCap + 1];
   __shared__ double red_lo[4], red_hi[4];
   __shared__ int kspan[2 * kSpanMax];
@@ -1551,6 +1564,7 @@ __global__ __launch_bounds__(kBlock) void pool_value_mean_staged_kernel(PoolValu
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int groups_per_channel = (a.P + kStageRows - 1) / kStageRows;
   const long long ngroups = (long long)C * groups_per_channel;
+  const T inf = (T)__builtin_inf();
   for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const long long c = grp / groups_per_channel;
     if (!differ[c]) continue;  // every ping of the channel has the same range vector: value_slide_kernel
@@ -1585,14 +1599,13 @@ __global__ __launch_bounds__(kBlock) void pool_value_mean_staged_kernel(PoolValu
     __syncthreads();
     const T gmin = (T)fmin(fmin(red_lo[0], red_lo[1]), fmin(red_lo[2], red_lo[3]));
     const T gmax = (T)fmax(fmax(red_hi[0], red_hi[1]), fmax(red_hi[2], red_hi[3]));
-    Dd sum[kStageRows];
-    int cnt[kStageRows], lo[kStageRows], hi[kStageRows];
+    double sum[kStageRows];
+    int cnt[kStageRows];
     unsigned has_inf = 0;
 #pragma unroll
     for (int r = 0; r < kStageRows; ++r) {
-      sum[r] = Dd{0.0, 0.0};
+      sum[r] = 0.0;
       cnt[r] = 0;
-      lo[r] = hi[r] = -1;
     }
     if (gmin <= gmax) {  // (uniform) some window of the group is feasible
       const int q_first = max(p0 - a.n, 0), q_last = min(p0 + nrows - 1 + a.n, a.P - 1);
@@ -1617,97 +1630,133 @@ __global__ __launch_bounds__(kBlock) void pool_value_mean_staged_kernel(PoolValu
         if (!staged_at(qi)) return;
         const size_t base = (size_t)(c * a.P + q_first + qi) * a.S;
         const int kmin = kspan[2 * qi], len = kspan[2 * qi + 1] - kmin;
+        // (uniform row pointers + a lane offset: one address register per load instead of a 64-bit sum each)
+        const T* rb = a.range + base + kmin;
+        const size_t w0 = base + kmin - (kmin > 0 ? 1 : 0);
+        const double *hb = wh + w0, *lb = wl + w0;
+        const int* nb = wn + w0;
+        const unsigned skip = kmin > 0 ? 0u : 1u;  // entry 0 = W[-1] = 0 when the span starts the row
 #pragma unroll
         for (int u = 0; u < kStageLoads; ++u) {
-          const int i = threadIdx.x + u * kBlock, k = kmin - 1 + i;  // entry i of the sums = W[kmin - 1 + i]
-          pre_r[u] = i < len ? a.range[base + kmin + i] : (T)0;
-          const bool in = i <= len && k >= 0;
-          pre_h[u] = in ? wh[base + k] : 0.0;
-          pre_l[u] = in ? wl[base + k] : 0.0;
-          pre_n[u] = in ? wn[base + k] : 0;
+          const unsigned i = threadIdx.x + u * kBlock;
+          pre_r[u] = i < (unsigned)len ? rb[i] : inf;  // (+inf: the two sentinels behind the span)
+          const bool in = i <= (unsigned)len && i >= skip;
+          pre_h[u] = in ? hb[i - skip] : 0.0;
+          pre_l[u] = in ? lb[i - skip] : 0.0;
+          pre_n[u] = in ? nb[i - skip] : 0;
+        }
+      };
+      auto store = [&](int qi) {
+        if (!staged_at(qi)) return;
+        const int len = kspan[2 * qi + 1] - kspan[2 * qi];
+        if (threadIdx.x < 2) seg_r[threadIdx.x] = -inf;
+#pragma unroll
+        for (int u = 0; u < kStageLoads; ++u) {
+          const int i = threadIdx.x + u * kBlock;
+          if (i < len + 2) seg_r[2 + i] = pre_r[u];
+          if (i <= len) {
+            seg_h[i] = pre_h[u];
+            seg_l[i] = pre_l[u];
+            seg_n[i] = pre_n[u];
+          }
         }
       };
       fetch(0);
+      int hint_l = -1, hint_h = -1;  // (pairs that read global memory: the previous pair's answer first)
       for (int q = q_first; q <= q_last; ++q) {
         const int qi = q - q_first;
         const size_t qrow = (size_t)(c * a.P + q);
-        const T* rr = a.range + qrow * a.S;
-        const int nv = a.nvalid[qrow];
-        const size_t base = qrow * a.S;
-        const bool dirty_q = dirty[qrow] != 0;
         const bool staged = staged_at(qi);  // (uniform)
-        const int kmin = can_stage ? kspan[2 * qi] : 0, len = can_stage ? kspan[2 * qi + 1] - kmin : 0;
+        const int len = can_stage ? kspan[2 * qi + 1] - kspan[2 * qi] : 0;
         __syncthreads();  // the previous neighbour's span has been consumed
-        if (staged) {
-#pragma unroll
-          for (int u = 0; u < kStageLoads; ++u) {
-            const int i = threadIdx.x + u * kBlock;
-            if (i < len) seg_r[i] = pre_r[u];
-            if (i <= len) {
-              seg_h[i] = pre_h[u];
-              seg_l[i] = pre_l[u];
-              seg_n[i] = pre_n[u];
-            }
-          }
-        }
+        store(qi);
         __syncthreads();
-        if (q < q_last) fetch(qi + 1);
+        if (q < q_last) fetch(qi + 1);  // (in flight while this neighbour is summed)
         // the group's pings that have q inside their ping window [p - n, min(p + n, P - 1)]
         const int r_lo = max(q - a.n - p0, 0), r_hi = min(q + a.n - p0, nrows - 1);
-        // pings of the group that share a range value at this column (all of them, while the sound speed holds) share
-        // the interval in q's row and its sum: resolved once, added to each
-        T same_d = epa::M<T>::nan();
-        int same_l = 0, same_h = 0, same_c = 0;
-        double same_w = 0.0;
+        if (staged) {
+          // range rows are (nearly always) affine in the sample index: the position of a value is guessed from the
+          // span's ends and confirmed on the values around the guess; anything else is searched
+          const T first = seg_r[2], last = seg_r[len + 1];
+          const T inv = (len > 1 && last > first) ? (T)(len - 1) / (last - first) : (T)0;
+          const T reach = a.bin * inv;
+          // pings of the group with the same range value at this column (all of them, while the sound speed holds)
+          // share the interval in q's row and its sum: resolved once, added to each
+          T same_d = epa::M<T>::nan();
+          double same_w = 0.0;
+          int same_c = 0;
 #pragma unroll
-        for (int r = 0; r < kStageRows; ++r) {
-          if (r < r_lo || r > r_hi || !((feas >> r) & 1u)) continue;
-          const T lo_v = d[r] - a.bin, hi_v = d[r] + a.bin;
-          if (staged) {
-            if (d[r] != same_d) {
-              // the bounds inside the span are the bounds in the whole row: everything before kmin is below every
-              // window of the group, everything from kmax on above
-              const int l = bound_hint<T, false>(seg_r, len, lo_v, lo[r] - kmin);
-              const int h = bound_hint<T, true>(seg_r, len, hi_v, hi[r] - kmin);
+          for (int r = 0; r < kStageRows; ++r) {
+            if (r < r_lo || r > r_hi) continue;  // (uniform)
+            const bool live = (feas >> r) & 1u;
+            if (!__all(d[r] == same_d || !live)) {  // (uniform)
               same_d = d[r];
-              same_l = kmin + l;
-              same_h = kmin + h;
-              same_w = 0.0;
-              same_c = 0;
-              if (h > l) {
-                // W[hi-1] - W[lo-1] in double-double (nothing lost to cancellation: the row total may be 1e14 times
-                // the window's), then a plain sum of the -- non-negative -- window sums
-                Dd w{seg_h[h], seg_l[h]};
-                w.add(Dd{seg_h[l], seg_l[l]}, -1.0);
-                same_w = w.hi + w.lo;
-                same_c = seg_n[h] - seg_n[l];
+              const T lo_v = d[r] - a.bin, hi_v = d[r] + a.bin;
+              const T x = (d[r] - first) * inv;
+              // first index with range >= lo_v / > hi_v, as positions 0 .. len inside the span
+              int gl = (int)ceil(x - reach), gh = (int)floor(x + reach) + 1;
+              gl = min(max(gl, 0), len);
+              gh = min(max(gh, 0), len);
+              const T a0 = seg_r[gl], a1 = seg_r[gl + 1], a2 = seg_r[gl + 2], a3 = seg_r[gl + 3];
+              const T b0 = seg_r[gh], b1 = seg_r[gh + 1], b2 = seg_r[gh + 2], b3 = seg_r[gh + 3];
+              int l = (a1 < lo_v && lo_v <= a2) ? gl : (a0 < lo_v && lo_v <= a1) ? gl - 1 : (a2 < lo_v && lo_v <= a3) ? gl + 1 : -1;
+              int h = (b1 <= hi_v && hi_v < b2) ? gh : (b0 <= hi_v && hi_v < b1) ? gh - 1 : (b2 <= hi_v && hi_v < b3) ? gh + 1 : -1;
+              if (__any(live && (l < 0 || h < 0))) {  // (uniform, rare) a row that is not affine around here
+                if (live && l < 0) l = bound<T, false>(seg_r + 2, len, lo_v);
+                if (live && h < 0) h = bound<T, true>(seg_r + 2, len, hi_v);
               }
+              l = max(l, 0);
+              h = max(h, 0);
+              // W[hi-1] - W[lo-1]: the high parts subtract exactly when they are close (a window far down a row whose
+              // total is 1e14 times its own), the low parts carry what the running sum had rounded away
+              const double w = (seg_h[h] - seg_h[l]) + (seg_l[h] - seg_l[l]);
+              const int n_in = seg_n[h] - seg_n[l];
+              same_w = h > l ? w : 0.0;
+              same_c = h > l ? n_in : 0;
             }
-            lo[r] = same_l;
-            hi[r] = same_h;
-            sum[r].hi += same_w;
+            sum[r] += same_w;  // (a plain sum of the -- non-negative -- window sums)
             cnt[r] += same_c;
-          } else {
-            lo[r] = bound_hint<T, false>(rr, nv, lo_v, lo[r]);
-            hi[r] = bound_hint<T, true>(rr, nv, hi_v, hi[r]);
-            if (hi[r] <= lo[r]) continue;
-            if (dirty_q) {  // a +inf Sv somewhere in this row: value by value
-              const T* vr = a.sv + base;
-              for (int k = lo[r]; k < hi[r]; ++k) {
-                const T v = vr[k];
-                if (v == v) {
-                  const double x = (double)epa::lin_from_db(v, mt.exp2_tab);
-                  if (x == __builtin_inf()) has_inf |= 1u << r; else sum[r].add(x);
-                  ++cnt[r];
+          }
+        } else {
+          // (rare: a span beyond the LDS copy, a row holding +inf, a very long ping window.  One pass of compact code
+          // per ping, the ping's registers picked by selects, instead of eight unrolled copies)
+          const T* rr = a.range + qrow * a.S;
+          const int nv = a.nvalid[qrow];
+          const size_t base = qrow * a.S;
+          const bool dirty_q = dirty[qrow] != 0;
+#pragma unroll 1
+          for (int r = r_lo; r <= r_hi; ++r) {
+            T dr = d[0];
+#pragma unroll
+            for (int k = 1; k < kStageRows; ++k) dr = r == k ? d[k] : dr;
+            double add_w = 0.0;
+            int add_c = 0;
+            if ((feas >> r) & 1u) {
+              hint_l = bound_hint<T, false>(rr, nv, dr - a.bin, hint_l);
+              hint_h = bound_hint<T, true>(rr, nv, dr + a.bin, hint_h);
+              if (hint_h > hint_l) {
+                if (dirty_q) {  // a +inf Sv somewhere in this row: value by value
+                  const T* vr = a.sv + base;
+                  for (int k = hint_l; k < hint_h; ++k) {
+                    const T v = vr[k];
+                    if (v == v) {
+                      const double x = (double)epa::lin_from_db(v, mt.exp2_tab);
+                      if (x == __builtin_inf()) has_inf |= 1u << r; else add_w += x;
+                      ++add_c;
+                    }
+                  }
+                } else {
+                  const size_t kh = base + hint_h - 1, kl = base + max(hint_l, 1) - 1;
+                  const bool from0 = hint_l == 0;
+                  add_w = (wh[kh] - (from0 ? 0.0 : wh[kl])) + (wl[kh] - (from0 ? 0.0 : wl[kl]));
+                  add_c = wn[kh] - (from0 ? 0 : wn[kl]);
                 }
               }
-              continue;
             }
-            sum[r].add(Dd{wh[base + hi[r] - 1], wl[base + hi[r] - 1]}, 1.0);
-            cnt[r] += wn[base + hi[r] - 1];
-            if (lo[r] > 0) {
-              sum[r].add(Dd{wh[base + lo[r] - 1], wl[base + lo[r] - 1]}, -1.0);
-              cnt[r] -= wn[base + lo[r] - 1];
+#pragma unroll
+            for (int k = 0; k < kStageRows; ++k) {
+              sum[k] += r == k ? add_w : 0.0;
+              cnt[k] += r == k ? add_c : 0;
             }
           }
         }
@@ -1718,12 +1767,13 @@ __global__ __launch_bounds__(kBlock) void pool_value_mean_staged_kernel(PoolValu
       if (r >= nrows || !in_row) continue;
       T out = epa::M<T>::nan();
       if (((feas >> r) & 1u) && cnt[r] > 0) {
-        const double tot = ((has_inf >> r) & 1u) ? __builtin_inf() : sum[r].hi + sum[r].lo;
+        const double tot = ((has_inf >> r) & 1u) ? __builtin_inf() : sum[r];
         out = (T)(10.0 * epa::fast_log10(tot / (double)cnt[r], mt.log_tab));
       }
       const size_t at = ((size_t)(c * a.P + p0 + r)) * a.S + s;
       if (a.pooled) a.pooled[at] = out;
       if (a.mask) a.mask[at] = (a.sv[at] - out > a.thr) ? 1 : 0;
+      __builtin_amdgcn_sched_barrier(0);  // (one row's logarithm at a time: eight side by side cost 40 registers)
     }
   }
 }

@@ -12,6 +12,8 @@ cf = ops.power_coef_ek(d["sample_interval"], d["transmit_duration_nominal"], d["
     d["equivalent_beam_angle"], d["frequency_nominal"], d["transmit_duration_nominal"][:, 0].contiguous(),
     pulse_length=d["pulse_length"], gain_is_table=True, sa_is_table=True)
 sv, rng = ops.sv_power(d["backscatter_r"], cf, dtype=dt)
+if "heave" in sys.argv:  # depth = range + a per-ping offset of a few sample steps (a moving platform)
+    rng = rng + (0.4 * torch.sin(torch.arange(P, device="cuda", dtype=dt) * 0.9))[None, :, None]
 lo, hi = ops.nanminmax(rng)
 nv, _ = ops.range_rows_check(rng)
 t = ops.Timer()

@@ -352,16 +352,19 @@ def test_pool_sv_value_rows_longer_than_the_lds_copy(env):
     assert np.isfinite(a).any()
 
 
-@pytest.mark.parametrize("case", ["blocks_of_pings", "span_beyond_the_lds_copy", "more_neighbours_than_span_slots"])
+@pytest.mark.parametrize("case", ["blocks_of_pings", "span_beyond_the_lds_copy", "more_neighbours_than_span_slots",
+                                  "rows_not_affine"])
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_pool_sv_value_staged_neighbour_rows(env, dtype, case):
     """The LDS-staged value-window kernel (pings whose range rows differ) against summing every window: the range
     vector changing every 5 pings (the 8-ping groups straddle the changes: shared and separate intervals in one group),
-    depth windows whose index span exceeds the LDS copy (direct loads for those pairs), and a ping window of more
-    neighbours than the kernel keeps spans for (direct loads for the whole group); P, S not multiples of 8 / 256."""
+    depth windows whose index span exceeds the LDS copy (direct loads for those pairs), a ping window of more
+    neighbours than the kernel keeps spans for (direct loads for the whole group), and range rows that are monotone
+    but far from affine in the sample index (the position guessed from the span's ends is wrong: searched instead);
+    P, S not multiples of 8 / 256."""
     torch, ops = env
     rng = np.random.default_rng(23)
-    if case == "blocks_of_pings":
+    if case in ("blocks_of_pings", "rows_not_affine"):
         C, P, S, n, dbin, step = 2, 43, 700, 6, 3.1, 0.3
     elif case == "span_beyond_the_lds_copy":
         C, P, S, n, dbin, step = 1, 21, 1500, 3, 85.0, 0.3
@@ -371,6 +374,12 @@ def test_pool_sv_value_staged_neighbour_rows(env, dtype, case):
     block = 5 if case == "blocks_of_pings" else 1
     scale = 1 + 0.01 * rng.random((C, (P + block - 1) // block, 1))
     depth = (1.5 + step * np.arange(S))[None, None, :] * np.repeat(scale, block, axis=1)[:, :P]
+    if case == "rows_not_affine":
+        k = np.arange(S)  # uneven steps (0.06 .. 0.54 m), a 3 m jump, a curvature, a per-ping offset
+        uneven = np.cumsum(step * (0.2 + 1.6 * rng.random(S)))
+        depth = (1.5 + uneven + 2e-4 * k * k + 3.0 * (k > 300))[None, None, :] * np.repeat(scale, block, axis=1)[:, :P] \
+            + 0.7 * rng.random((C, P, 1))
+        assert (np.diff(depth, axis=-1) > 0).all()
     depth[:, 7, S - 20:] = np.nan
     sv[:, 7, S - 20:] = np.nan
     sv[0, 10, 100 % S] = 60.0
@@ -387,7 +396,7 @@ def test_pool_sv_value_staged_neighbour_rows(env, dtype, case):
     np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
     _close(a, b, 1e-12 if dtype == "float64" else 1e-5, "staged running sums vs window sums")
     assert np.isposinf(a).any() and np.isfinite(a).any()
-    if case == "blocks_of_pings" and dtype == "float64":  # (fp32 window edges d -+ bin round differently: a vs b only)
+    if case in ("blocks_of_pings", "rows_not_affine") and dtype == "float64":  # (fp32 window edges d -+ bin round differently: a vs b only)
         exp = omask.pool_Sv(sv.astype(np.float64), depth.astype(np.float64), np.nanmean, dbin, n, 2.0)
         _close(a, exp, RTOL[dtype], "vs oracle")
 
