@@ -27,7 +27,7 @@ CF_RA, CF_RB, CF_R0, CF_SHIFT, CF_ALPHA2, CF_A0, CF_G, CF_D = range(8)
 NCCOEF = 8
 CC_RA, CC_RB, CC_SHIFT, CC_ALPHA2, CC_A, CC_PSCALE = range(6)
 FLAG_GUARD_POS, FLAG_MASK_RANGE = 1, 2
-BIN_SKIPNA, BIN_CLOSED_RIGHT = 1, 2
+BIN_SKIPNA, BIN_CLOSED_RIGHT, BIN_RANGE_AS_STORED = 1, 2, 4
 POOL_NANMEAN, POOL_NANMEDIAN = 0, 1
 CCP = ("sample_interval", "tau_nominal", "transmit_power", "sound_speed", "absorption", "gain", "freq_center", "psi",
        "sa_correction", "z_er", "z_et", "angle_offset_alongship", "angle_offset_athwartship", "beamwidth_alongship",
@@ -76,6 +76,7 @@ SIGNATURES = {
     "epa_pulse_table_lookup": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "epa_sv_power": [_vp, _vp, _i, _i, _i, _i, _u, _vp, _vp, _i, _vp],
     "epa_sv_power_stats": [_vp, _vp, _i, _i, _i, _i, _u, _vp, _vp, _i, _vp, _vp, _vp],
+    "epa_range_power": [_vp, _vp, _i, _i, _i, _u, _vp, _i, _vp],
     "epa_time_bin_offsets": [_vp, _i, _i64, _i64, _i, _u, _vp, _vp],
     "epa_sv_mvbs_fused": [_vp, _vp, _i, _i, _i, _i, _u, _vp, _vp, _i, _d, _i, _u, _d, _vp, _vp, _vp,
                           _vp, _vp, _vp, _i, _vp],

@@ -88,8 +88,7 @@ class CalibrateAZFP(CalibrateBase):
 
     def _cal_power_samples(self, cal_type, **kwargs):
         raw, coef, flags, _ = self._power_inputs(cal_type)
-        out_t, range_t, stats = ops.sv_power(raw, coef, cal_type=cal_type, flags=flags, dtype=self.dtype,
-                                             want_range_stats=True)
+        out_t, range_t, stats = self._sv_power_lazy_range(raw, coef, cal_type, flags)
         return self._finish(cal_type, out_t, range_t, range_stats=stats)
 
     def compute_Sv(self, **kwargs):

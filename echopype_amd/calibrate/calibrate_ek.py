@@ -201,8 +201,7 @@ class CalibrateEK(CalibrateBase):
     def _cal_power_samples(self, cal_type):
         """One fused pass for calibrate_ek.py:79-206."""
         raw, coef, flags, tau_eff = self._power_inputs(cal_type)
-        out_t, range_t, stats = ops.sv_power(raw, coef, cal_type=cal_type, flags=flags, dtype=self.dtype,
-                                             want_range_stats=True)
+        out_t, range_t, stats = self._sv_power_lazy_range(raw, coef, cal_type, flags)
         return self._finish(cal_type, out_t, range_t, tau_eff, range_stats=stats)
 
 

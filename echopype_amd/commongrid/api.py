@@ -11,11 +11,12 @@ import torch
 
 from .. import ops
 from ..utils.prov import echopype_prov_attrs, insert_processing_level
-from ..xr_lite import DataArray, Dataset, DeviceArray, from_xarray, xarray_io
+from ..xr_lite import DataArray, Dataset, DeviceArray, LazyDeviceArray, from_xarray, xarray_io
 from .utils import (_parse_x_bin, _set_MVBS_attrs, _setup_and_validate, coarsen_time_mean, get_distance_from_latlon,
                     ping_time_bin_parsing_and_conversion, resample_edges)
 
 logger = logging.getLogger("echopype_amd.commongrid")
+_TORCH_DT = {"float64": torch.float64, "float32": torch.float32}
 
 _AGG_MSG = ("Aggregation may be negatively impacted since Flox will not aggregate any "
             "```Sv``` values that have corresponding NaN coordinate values. Consider handling "
@@ -32,13 +33,28 @@ def _dev(a, dtype=None):
 
 def _range_stats(da, t):
     """(nanmin, nanmax, NaN count) of a range variable: left with the array by the kernel that wrote it
-    (compute_Sv), or one sweep of the device tensor ``t`` actually handed to the kernels."""
+    (compute_Sv), or one sweep of the device tensor ``t`` actually handed to the kernels (None: a lazy array binned
+    through its coefficient rows; it is written only if it carries no statistics)."""
     d = da.data if isinstance(da, DataArray) else None
-    if isinstance(d, DeviceArray) and d.tensor.dtype == t.dtype and d.tensor.shape == t.shape:
+    if isinstance(d, DeviceArray) and (t is None or (_TORCH_DT.get(d.dtype.name) == t.dtype and d.shape == tuple(t.shape))):
         st = d.cached_stats()
         if st is not None:
             return st
-    return ops.nanminmax(t, with_nan_count=True)
+    return ops.nanminmax(d.tensor if t is None else t, with_nan_count=True)
+
+
+def _coef_rows(da, order, sv_t):
+    """The coefficient rows a lazy echo_range (xr_lite.LazyDeviceArray, left by compute_Sv on power samples) is an
+    affine function of, when the binning kernels can take them in place of the array: same dims, shape and dtype as
+    Sv, array untouched since.  The kernels evaluate ``fl(fl(s * ra) * rb) + r0`` rounded to the array's dtype --
+    what the array holds wherever the raw sample is not NaN; where it is NaN, so is Sv, which a NaN-skipping mean
+    drops like the reference drops the NaN coordinate."""
+    d = da.data if isinstance(da, DataArray) else None
+    if not isinstance(d, LazyDeviceArray) or tuple(da.dims) != tuple(order):
+        return None
+    if d.shape != tuple(sv_t.shape) or _TORCH_DT.get(d.dtype.name) != sv_t.dtype:
+        return None
+    return d.coef_rows()
 
 
 def _full(da, ds, order):
@@ -71,7 +87,9 @@ def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="
     sv_t = _dev(sv_da)
     if sv_t.dtype not in (torch.float32, torch.float64):
         sv_t = sv_t.double()
-    rg_t = _dev(_full(ds_Sv[range_var], ds_Sv, order), sv_t.dtype)
+    # (a lazy echo_range straight from compute_Sv: binned through its coefficient rows, never written)
+    rows = _coef_rows(ds_Sv[range_var], order, sv_t) if skipna else None
+    rg_t = _dev(_full(ds_Sv[range_var], ds_Sv, order), sv_t.dtype) if rows is None else None
     C, P, S = sv_t.shape
 
     # range edges: np.arange(0, max + bin, bin)  (api.py:108-115)
@@ -112,7 +130,7 @@ def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="
     if n_r == 0:
         mvbs_t = torch.empty((C, n_t, 0), dtype=sv_t.dtype, device=sv_t.device)
     else:
-        res = ops.mvbs(sv_t, bin_start, n_t, range_bin_m, n_r, range=rg_t, skipna=skipna, closed=closed,
+        res = ops.mvbs(sv_t, bin_start, n_t, range_bin_m, n_r, range=rg_t, coef=rows, coef_as_stored=True, skipna=skipna, closed=closed,
                        fill_value=fill_value, ping_perm=perm, want_partials=_shard is not None)
         mvbs_t = res["MVBS"]
         if _shard is not None:  # bins cut by a shard edge: totals over all ranks, reported by the lowest holder

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(epa::kBlock, 3) void block_reduce_kernel(ReduceArgs
 
   const bool skipna = a.bin_flags & EPA_BIN_SKIPNA;
   const bool closed_right = a.bin_flags & EPA_BIN_CLOSED_RIGHT;
+  const bool range_as_stored = a.bin_flags & EPA_BIN_RANGE_AS_STORED;
   const bool guard = a.cal_flags & EPA_FLAG_GUARD_POS;
   const bool mask_range = a.cal_flags & EPA_FLAG_MASK_RANGE;
   const bool phys = a.bin_mode == BIN_PHYS;
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(epa::kBlock, 3) void block_reduce_kernel(ReduceArgs
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
               x[j] = epa::row_range(cr, s0 + j);
+              if (range_as_stored) x[j] = (double)(T)x[j];  // what the echo_range array of dtype T would hold
               xok[j] = true;
             }
           } else {

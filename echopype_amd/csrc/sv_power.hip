@@ -35,8 +35,8 @@ __global__ __launch_bounds__(epa::kBlock) void sv_power_kernel(const float* __re
     act[g] = s0[g] < S;
   }
   if (!STATS && !act[0]) return;
-  // STATS: {min, max, NaN count} of the echo_range written, one partial per workgroup (no lane leaves early:
-  // the wavefront reduction at the end needs them all)
+  // STATS: {min, max, NaN count} of the echo_range (written when RANGE, else left to epa_range_power for whoever asks
+  // for the array), one partial per workgroup (no lane leaves early: the wavefront reduction at the end needs them all)
   double lo = __builtin_inf(), hi = -__builtin_inf(), nn = 0.0;
   epa::ColumnLog<T, LEN> col[NSEG];
   for (long long row = blockIdx.x; row < rows && act[0]; row += gridDim.x) {
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(epa::kBlock) void sv_power_kernel(const float* __re
       for (int j = 0; j < LEN; ++j) {
         const double r = rk.range(s0[g] + j);
         o[j] = epa::cal_power_sample<T>(in.v[j], s0[g] + j, rk, nspread, col[g].nL[j], guard, r);
-        if (RANGE) rg[j] = (mask_range && !(in.v[j] == in.v[j])) ? epa::M<T>::nan() : (T)r;
+        if (RANGE || STATS) rg[j] = (mask_range && !(in.v[j] == in.v[j])) ? epa::M<T>::nan() : (T)r;
         if (STATS) {
           const double x = (double)rg[j];
           lo = fmin(lo, x);  // fmin / fmax ignore a NaN operand
@@ -125,9 +125,18 @@ int launch(const float* raw, const double* coef, int C, int P, int S, int cal_ty
 #define EPA_LAUNCH(K, R)                                                                        \
   hipLaunchKernelGGL((K<T, R>), grid, dim3(epa::kBlock), 0, st, raw, cf, rows, S, nspread, flags, \
                      (T*)out, (T*)range_out)
+  if (!vec && stats_out && !range_out) {
+    epa::set_error("epa_sv_power_stats: range statistics without the echo_range array need S %% %d == 0 and 16-byte "
+                   "aligned buffers (S=%d)", need, S);
+    return EPA_EUNSUPPORTED;
+  }
   if (vec && stats_out) {  // echo_range statistics as a by-product: one partial per workgroup, then one small kernel
-    hipLaunchKernelGGL((sv_power_kernel<T, true, true>), grid, dim3(epa::kBlock), 0, st, raw, cf, rows, S, nspread,
-                       flags, (T*)out, (T*)range_out, part);
+    if (range_out)
+      hipLaunchKernelGGL((sv_power_kernel<T, true, true>), grid, dim3(epa::kBlock), 0, st, raw, cf, rows, S, nspread,
+                         flags, (T*)out, (T*)range_out, part);
+    else
+      hipLaunchKernelGGL((sv_power_kernel<T, false, true>), grid, dim3(epa::kBlock), 0, st, raw, cf, rows, S, nspread,
+                         flags, (T*)out, (T*)range_out, part);
     if (int rc = epa::check_launch("sv_power_kernel")) return rc;
     return epa_minmax_final(part, (int)(grid.x * grid.y), stats_out, st);
   }
@@ -149,7 +158,46 @@ int launch(const float* raw, const double* coef, int C, int P, int S, int cal_ty
   return EPA_OK;
 }
 
+// echo_range alone, for a caller that asked epa_sv_power_stats not to write it and needs the array after all
+template <typename T>
+__global__ __launch_bounds__(epa::kBlock) void range_power_kernel(const float* __restrict__ raw,
+                                                                  const epa::CoefRow* __restrict__ coef,
+                                                                  long long rows, int S, unsigned flags,
+                                                                  T* __restrict__ range_out) {
+  const bool mask_range = flags & EPA_FLAG_MASK_RANGE;
+  const int s = blockIdx.y * epa::kBlock + threadIdx.x;
+  if (s >= S) return;
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const epa::CoefRow cr = coef[row];
+    const size_t off = (size_t)row * S + s;
+    const bool nan_in = mask_range && !(raw[off] == raw[off]);
+    range_out[off] = nan_in ? epa::M<T>::nan() : (T)epa::row_range(cr, s);
+  }
+}
+
 }  // namespace
+
+extern "C" int epa_range_power(const float* raw, const double* coef, int C, int P, int S, unsigned flags,
+                               void* range_out, int out_dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(coef && range_out, "epa_range_power: NULL array argument");
+  EPA_CHECK_ARG(raw || !(flags & EPA_FLAG_MASK_RANGE), "epa_range_power: EPA_FLAG_MASK_RANGE needs the raw samples");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_range_power: C=%d P=%d S=%d must be positive", C, P, S);
+  EPA_CHECK_ARG(out_dtype == EPA_F64 || out_dtype == EPA_F32, "epa_range_power: bad out_dtype %d", out_dtype);
+  const long long rows = (long long)C * P;
+  const int chunks = (S + epa::kBlock - 1) / epa::kBlock;
+  long long gx = 16384 / chunks;
+  if (gx < 1) gx = 1;
+  if (gx > rows) gx = rows;
+  const dim3 grid((unsigned)gx, (unsigned)chunks);
+  const epa::CoefRow* cf = reinterpret_cast<const epa::CoefRow*>(coef);
+  if (out_dtype == EPA_F64)
+    hipLaunchKernelGGL(range_power_kernel<double>, grid, dim3(epa::kBlock), 0, (hipStream_t)stream, raw, cf, rows, S,
+                       flags, (double*)range_out);
+  else
+    hipLaunchKernelGGL(range_power_kernel<float>, grid, dim3(epa::kBlock), 0, (hipStream_t)stream, raw, cf, rows, S,
+                       flags, (float*)range_out);
+  return epa::check_launch("range_power_kernel");
+}
 
 extern "C" int epa_sv_power(const float* raw, const double* coef, int C, int P, int S, int cal_type,
                             unsigned flags, void* out, void* range_out, int out_dtype,
@@ -169,8 +217,7 @@ extern "C" int epa_sv_power(const float* raw, const double* coef, int C, int P, 
 extern "C" int epa_sv_power_stats(const float* raw, const double* coef, int C, int P, int S, int cal_type,
                                   unsigned flags, void* out, void* range_out, int out_dtype, double* workspace,
                                   double* range_stats_out, epa_stream_t stream) {
-  EPA_CHECK_ARG(raw && coef && out && range_out && workspace && range_stats_out,
-                "epa_sv_power_stats: NULL array argument");
+  EPA_CHECK_ARG(raw && coef && out && workspace && range_stats_out, "epa_sv_power_stats: NULL array argument");
   EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_sv_power_stats: C=%d P=%d S=%d must be positive", C, P, S);
   EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_sv_power_stats: bad cal_type %d", cal_type);
   if (out_dtype == EPA_F64)

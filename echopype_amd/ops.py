@@ -92,10 +92,16 @@ def pulse_table_lookup(tau_nominal, pulse_length, table):
     return out
 
 
+def sv_power_vectorized(raw, S, dtype):
+    """True when K1 takes its 16-byte path on these buffers (needed for range statistics without the range array)."""
+    return S % (2 if dtype == torch.float64 else 4) == 0 and raw.data_ptr() % 16 == 0
+
+
 def sv_power(raw, coef, *, cal_type="Sv", flags=_lib.FLAG_GUARD_POS | _lib.FLAG_MASK_RANGE,
              dtype=torch.float64, want_range=True, out=None, range_out=None, want_range_stats=False):
     """K1 -> (Sv|TS, echo_range|None), both (C,P,S) of dtype [, f64 device tensor {nanmin, nanmax, NaN count} of
-    the echo_range, a by-product of the same pass]."""
+    the echo_range, a by-product of the same pass].  ``want_range=False`` with ``want_range_stats=True``: the
+    statistics of the echo_range that would be written, without the array (range_power writes it later if needed)."""
     C, P, S = raw.shape
     if raw.dtype != torch.float32:
         raise ValueError("raw power samples must be float32 (convert/parse_base.py:302)")
@@ -105,16 +111,22 @@ def sv_power(raw, coef, *, cal_type="Sv", flags=_lib.FLAG_GUARD_POS | _lib.FLAG_
         range_out = torch.empty((C, P, S), dtype=dtype, device=raw.device)
     ct = _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS
     if want_range_stats:
-        if not want_range:
-            raise ValueError("range statistics come with the echo_range array")
         ws = torch.empty(3 * (S // 256 + 8192 + 1024), dtype=torch.float64, device=raw.device)
         stats = torch.empty(3, dtype=torch.float64, device=raw.device)
-        call("epa_sv_power_stats", _p(raw), _p(coef), C, P, S, ct, flags, _p(out), _p(range_out), _DT[out.dtype],
-             _p(ws), _p(stats), _stream())
-        return out, range_out, stats
+        call("epa_sv_power_stats", _p(raw), _p(coef), C, P, S, ct, flags, _p(out),
+             _p(range_out) if want_range else None, _DT[out.dtype], _p(ws), _p(stats), _stream())
+        return out, (range_out if want_range else None), stats
     call("epa_sv_power", _p(raw), _p(coef), C, P, S, ct, flags, _p(out), _p(range_out) if want_range else None,
          _DT[out.dtype], _stream())
     return out, (range_out if want_range else None)
+
+
+def range_power(raw, coef, *, flags=_lib.FLAG_MASK_RANGE, dtype=torch.float64):
+    """echo_range (C,P,S) of the power-sample coefficient rows alone (what K1 writes as range_out)."""
+    C, P, S = raw.shape
+    out = torch.empty((C, P, S), dtype=dtype, device=raw.device)
+    call("epa_range_power", _p(raw), _p(coef), C, P, S, flags, _p(out), _DT[dtype], _stream())
+    return out
 
 
 def time_bin_offsets(ping_time_ns, t0, dt, n_bins, closed="left"):
@@ -191,8 +203,10 @@ def sv_mvbs_fused_i16(raw_i16, n_valid, coef, bin_start, n_tbins, range_bin, n_r
 
 
 def mvbs(sv, bin_start, n_tbins, range_bin, n_rbins, *, range=None, coef=None, skipna=True,
-         closed="left", fill_value=float("nan"), want_partials=False, ping_perm=None):
-    """K5 on an existing Sv -> dict(MVBS, sum, cnt)."""
+         closed="left", fill_value=float("nan"), want_partials=False, ping_perm=None, coef_as_stored=False):
+    """K5 on an existing Sv -> dict(MVBS, sum, cnt).  ``coef`` (power-sample coefficient rows) in place of ``range``:
+    the range is evaluated in the kernel; ``coef_as_stored`` rounds it to Sv's dtype first, i.e. bins exactly as on
+    the echo_range array K1 would have written."""
     C, P, S = sv.shape
     dev, dtype = sv.device, sv.dtype
     if range is not None and range.dtype != dtype:
@@ -203,8 +217,8 @@ def mvbs(sv, bin_start, n_tbins, range_bin, n_rbins, *, range=None, coef=None, s
         ssum = torch.empty((C, n_tbins, n_rbins), dtype=dtype, device=dev)
         cnt = torch.empty((C, n_tbins, n_rbins), dtype=torch.int32, device=dev)
     call("epa_mvbs", _p(sv), _p(range), _p(coef), C, P, S, _p(bin_start), _p(ping_perm), int(n_tbins),
-         float(range_bin), int(n_rbins), _bin_flags(skipna, closed), float(fill_value), _p(out),
-         _p(ssum), _p(cnt), _DT[dtype], _stream())
+         float(range_bin), int(n_rbins), _bin_flags(skipna, closed) | (_lib.BIN_RANGE_AS_STORED if coef_as_stored else 0),
+         float(fill_value), _p(out), _p(ssum), _p(cnt), _DT[dtype], _stream())
     return dict(MVBS=out, sum=ssum, cnt=cnt)
 
 

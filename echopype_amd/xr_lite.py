@@ -19,7 +19,7 @@ try:  # pragma: no cover - not installed in the build image
 except Exception:  # noqa: BLE001
     _xr = None
 
-__all__ = ["DeviceArray", "DataArray", "Dataset", "from_xarray", "is_device", "is_xarray", "to_xarray", "xarray_io"]
+__all__ = ["DeviceArray", "LazyDeviceArray", "DataArray", "Dataset", "from_xarray", "is_device", "is_xarray", "to_xarray", "xarray_io"]
 
 
 class DeviceArray:
@@ -69,6 +69,69 @@ class DeviceArray:
 
     def __repr__(self):
         return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, device={self.tensor.device})"
+
+
+class LazyDeviceArray(DeviceArray):
+    """A device array that is written on first use (the analogue of a dask-backed variable of the reference):
+    ``compute_Sv`` on power samples leaves ``echo_range`` in this form -- shape, dtype and the {nanmin, nanmax, NaN
+    count} by-product are known, the 8 B/sample array itself is produced by ``make()`` when somebody reads ``.tensor``
+    / ``.values``.  ``rows`` = the per-(channel, ping) coefficient rows the array is an affine function of
+    (``range = fl(fl(s * ra) * rb) + r0``): kernels that accept those rows in place of the array (``compute_MVBS``)
+    never need it."""
+
+    __slots__ = ("_make", "_shape", "_tdtype", "_device", "_tensor", "_rows")
+
+    def __init__(self, shape, dtype, device, make, stats=None, rows=None):
+        self._make, self._shape, self._tdtype, self._device = make, tuple(int(n) for n in shape), dtype, device
+        self._tensor = None
+        self._host = None
+        self._stats = (stats, 0) if stats is not None else None
+        self._rows = rows
+
+    @property
+    def materialized(self):
+        return self._tensor is not None
+
+    @property
+    def tensor(self):
+        if self._tensor is None:
+            self._tensor = self._make()
+            self._make = None
+            if self._stats is not None:
+                self._stats = (self._stats[0], self._tensor._version)
+        return self._tensor
+
+    def coef_rows(self):
+        """The coefficient rows, while the array still is the function of them it was created as."""
+        if self._tensor is not None and self._stats is not None and self._stats[1] != self._tensor._version:
+            return None
+        return self._rows
+
+    def cached_stats(self):
+        if self._stats is None or (self._tensor is not None and self._stats[1] != self._tensor._version):
+            return None
+        lo, hi, nn = self._stats[0].cpu().tolist()
+        return lo, hi, int(nn)
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def ndim(self):
+        return len(self._shape)
+
+    @property
+    def dtype(self):
+        return np.dtype(str(self._tdtype).replace("torch.", ""))
+
+    @property
+    def nbytes(self):
+        return int(np.prod(self._shape)) * self.dtype.itemsize
+
+    def __repr__(self):
+        state = "materialized" if self.materialized else "lazy"
+        return f"LazyDeviceArray(shape={self.shape}, dtype={self.dtype}, device={self._device}, {state})"
 
 
 def is_device(a):

@@ -67,6 +67,9 @@ enum epa_coef_slot { EPA_CF_RA = 0, EPA_CF_RB = 1, EPA_CF_R0 = 2, EPA_CF_SHIFT =
 /* flags of the binned reductions */
 #define EPA_BIN_SKIPNA 1u       /* nanmean (skip NaN values) vs mean (NaN poisons the bin)            */
 #define EPA_BIN_CLOSED_RIGHT 2u /* intervals (a, b] instead of [a, b)  (commongrid/utils.py:283-302) */
+#define EPA_BIN_RANGE_AS_STORED 4u /* epa_mvbs with coefficient rows in place of the range array: round the range to
+                                    * dtype before binning, i.e. bin exactly as on the echo_range array epa_sv_power
+                                    * would have written (a no-op for EPA_F64)                                        */
 
 /* ---- runtime ------------------------------------------------------------------------------------ */
 int epa_version(void);
@@ -128,6 +131,14 @@ int epa_sv_power(const float* raw, const double* coef, int C, int P, int S, int 
 int epa_sv_power_stats(const float* raw, const double* coef, int C, int P, int S, int cal_type,
                        unsigned flags, void* out, void* range_out, int out_dtype, double* workspace,
                        double* range_stats_out, epa_stream_t stream);
+/* range_out may be NULL there (S even for F64 / S % 4 == 0 for F32, 16-byte aligned buffers; EPA_EUNSUPPORTED
+ * otherwise): the statistics are taken of the echo_range that WOULD be written and the array itself -- 8 of the 20
+ * bytes per sample the pass moves -- is left to this entry for whoever asks for it later (the reference's echo_range is
+ * just as lazy when the echodata is dask-backed; range.py:98-157 with the NaN mask of :143-148 under
+ * EPA_FLAG_MASK_RANGE, then raw is read).  epa_mvbs / epa_noise_estimate / epa_noise_apply take the same coefficient
+ * rows in place of the array. */
+int epa_range_power(const float* raw, const double* coef, int C, int P, int S, unsigned flags, void* range_out,
+                    int out_dtype, epa_stream_t stream);
 
 /* ---- time-bin CSR for the binned reductions ----------------------------------------------------------
  * Replaces the pandas-resample bin assignment of commongrid/api.py:118-128.  ping_time: int64 ns,

@@ -604,3 +604,103 @@ def test_to_device_keeps_a_host_view_of_the_parameters(ep):
     np.testing.assert_array_equal(np.asarray(ss), 2.0 * d["transmit_duration_nominal"])
     big = DeviceArray(torch.zeros(4, device="cuda"))
     assert not host_readable(big)
+
+
+# ---- echo_range left lazy by compute_Sv on power samples -------------------------------------------------------------
+def _lazy_case(ep, S=1000, dtype="float64", P=240):
+    d = ep.synth.ek60_numpy(3, P, S, ss_every=7)
+    d["backscatter_r"][1, 5, S - 60:] = np.nan      # a NaN-padded ping: echo_range is NaN there (range.py:143-148)
+    d["backscatter_r"][0, 11, 3] = np.nan
+    return ep.echodata.from_ek60_arrays(d), dtype
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_compute_Sv_leaves_echo_range_lazy_and_identical(dtype):
+    """compute_Sv on power samples does not write echo_range (8 of the pass's 20 B/sample): the Dataset variable is a
+    LazyDeviceArray carrying shape, dtype and the {nanmin, nanmax, NaN count} by-product; reading it produces exactly
+    the array K1 writes (bit-identical, NaN mask of padded samples included), and the statistics are those of that
+    array."""
+    import torch
+    import echopype_amd as ep
+    from echopype_amd import ops
+    from echopype_amd.xr_lite import LazyDeviceArray
+
+    ed, _ = _lazy_case(ep)
+    ds = ep.calibrate.compute_Sv(ed, dtype=dtype)
+    rng = ds["echo_range"].data
+    assert isinstance(rng, LazyDeviceArray) and not rng.materialized
+    assert rng.shape == ds["Sv"].shape and rng.dtype == np.dtype(dtype)
+    lo, hi, nn = rng.cached_stats()
+    assert not rng.materialized
+    # the eager pass, through the C ABI
+    cal = ep.calibrate.api.CALIBRATOR["EK60"](ed, None, None, None, dtype=dtype)
+    raw, coef, flags, _ = cal._power_inputs("Sv")
+    sv_e, rg_e, st_e = ops.sv_power(raw, coef, flags=flags, dtype=getattr(torch, dtype), want_range_stats=True)
+    got = ds["echo_range"].values
+    assert rng.materialized
+    np.testing.assert_array_equal(got, rg_e.cpu().numpy())
+    np.testing.assert_array_equal(ds["Sv"].values, sv_e.cpu().numpy())
+    assert (lo, hi, nn) == tuple(st_e.cpu().tolist()[:2]) + (int(st_e[2]),)
+    raw_nan = np.isnan(ed["Sonar/Beam_group1"]["backscatter_r"].values)
+    assert np.isnan(got[1, 5, -60:]).all() and np.isnan(got[0, 11, 3]) and nn == int(raw_nan.sum())
+    np.testing.assert_array_equal(np.isnan(got), raw_nan)
+    assert rng.cached_stats() == (lo, hi, nn)          # still valid after the array has been written
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("closed", ["left", "right"])
+def test_compute_MVBS_bins_a_lazy_echo_range_through_its_coefficient_rows(dtype, closed):
+    """compute_MVBS on the Dataset straight from compute_Sv never writes echo_range (the binning kernel evaluates the
+    coefficient rows) and gives the MVBS of the same call on the materialised array (1e-13); skipna=False needs the
+    NaN mask of the array and takes it."""
+    import echopype_amd as ep
+
+    ed, _ = _lazy_case(ep)
+    ds = ep.calibrate.compute_Sv(ed, dtype=dtype)
+    lazy = ds["echo_range"].data
+    a = ep.commongrid.compute_MVBS(ds, range_bin="2m", ping_time_bin="10s", closed=closed)
+    assert not lazy.materialized
+    ds2 = ep.calibrate.compute_Sv(ed, dtype=dtype)
+    ds2["echo_range"].values                                   # written: the array path from here on
+    ds2["echo_range"] = ep.xr_lite.DataArray(ep.DeviceArray(ds2["echo_range"].data.tensor), ds2["echo_range"].dims)
+    b = ep.commongrid.compute_MVBS(ds2, range_bin="2m", ping_time_bin="10s", closed=closed)
+    # (same bins, same members; the two kernel instantiations add a bin's members in different orders: last-bit noise)
+    np.testing.assert_array_equal(np.isnan(a["Sv"].values), np.isnan(b["Sv"].values))
+    np.testing.assert_allclose(a["Sv"].values, b["Sv"].values, rtol=1e-13 if dtype == "float64" else 2e-6, atol=0)
+    np.testing.assert_array_equal(a["echo_range"].values, b["echo_range"].values)
+    assert np.isfinite(a["Sv"].values).any()
+    c = ep.commongrid.compute_MVBS(ds, range_bin="2m", ping_time_bin="10s", closed=closed, skipna=False)
+    assert lazy.materialized
+    d = ep.commongrid.compute_MVBS(ds2, range_bin="2m", ping_time_bin="10s", closed=closed, skipna=False)
+    np.testing.assert_allclose(c["Sv"].values, d["Sv"].values, rtol=1e-13 if dtype == "float64" else 2e-6, atol=0)
+
+
+@pytest.mark.gpu
+def test_lazy_echo_range_edge_cases():
+    """An odd number of samples per ping (K1's one-sample-per-lane path) keeps the eager array; backscatter modified
+    in place between compute_Sv and the first read of a lazy echo_range raises instead of returning a wrong mask; the
+    steps after compute_Sv that read the array (remove_background_noise) find the same values as before."""
+    import torch
+    import echopype_amd as ep
+    from echopype_amd.xr_lite import LazyDeviceArray
+
+    ed, _ = _lazy_case(ep, S=999)
+    ds = ep.calibrate.compute_Sv(ed)
+    assert not isinstance(ds["echo_range"].data, LazyDeviceArray)
+    ed, _ = _lazy_case(ep)
+    ed.to_device()
+    ds = ep.calibrate.compute_Sv(ed)
+    assert isinstance(ds["echo_range"].data, LazyDeviceArray)
+    ed["Sonar/Beam_group1"]["backscatter_r"].data.tensor[0, 0, 0] = 1.0
+    with pytest.raises(RuntimeError, match="modified in place"):
+        ds["echo_range"].values
+    ed, _ = _lazy_case(ep)
+    ds = ep.calibrate.compute_Sv(ed)
+    out = ep.clean.remove_background_noise(ds, 20, 50)
+    assert ds["echo_range"].data.materialized
+    ds2 = ep.calibrate.compute_Sv(ed)
+    ds2["echo_range"].values
+    out2 = ep.clean.remove_background_noise(ds2, 20, 50)
+    np.testing.assert_array_equal(out["Sv_corrected"].values, out2["Sv_corrected"].values)
