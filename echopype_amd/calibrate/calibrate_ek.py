@@ -13,7 +13,7 @@ import torch
 
 from .. import _lib, ops
 from ..echodata import BEAM1
-from ..xr_lite import DataArray, Dataset, DeviceArray, host_readable
+from ..xr_lite import DataArray, Dataset, DeviceArray, LazyDeviceArray, host_readable
 from .cal_params import PulseTableParam, get_cal_params_EK
 from .calibrate_base import ECHO_DIMS, CalibrateBase, cp_array
 from .ek80_complex import get_filter_coeff, get_tau_effective, get_transmit_signal
@@ -375,11 +375,25 @@ class CalibrateEK80(CalibrateEK):
     def _cal_complex_samples(self, cal_type):
         """One fused pass for calibrate_ek.py:532-659 (+ ek80_complex.py:285-391 for BB)."""
         k, tau_eff = self._complex_inputs(cal_type)
+        # the LDS-FFT form leaves {nanmin, nanmax, NaN count} of echo_range as a by-product: the array itself can stay
+        # lazy then (written by epa_range_complex if somebody reads it; compute_MVBS bins through the coefficient rows)
+        lazy = ops.sv_complex_uses_fft(k["replica"], k["max_taps"])
         res = ops.sv_complex(k["re"], k["im"], k["ccoef"], replica=k["replica"], replica_off=k["replica_off"],
                              max_taps=k["max_taps"], cal_type=cal_type, dtype=self.dtype, fft_dtype=self.fft_dtype,
-                             want_range_stats=True)
-        # {nanmin, nanmax, NaN count} of echo_range ride along (the FFT form leaves them as a by-product)
-        return self._finish(cal_type, res["out"], res["echo_range"], tau_eff, range_stats=res["range_stats"])
+                             want_range=not lazy, want_range_stats=True)
+        range_t = res["echo_range"]
+        if lazy:
+            re, ccoef, dtype, version = k["re"], k["ccoef"], self.dtype, k["re"]._version
+
+            def make():
+                if re._version != version:
+                    raise RuntimeError("echo_range was left lazy by compute_Sv/compute_TS and backscatter_r has been "
+                                       "modified in place since: its NaN mask can no longer be reproduced")
+                return ops.range_complex(re, ccoef, dtype=dtype)
+
+            range_t = LazyDeviceArray(res["out"].shape, dtype, re.device, make, stats=res["range_stats"],
+                                      rows=ops.power_rows_of_complex(ccoef))
+        return self._finish(cal_type, res["out"], range_t, tau_eff, range_stats=res["range_stats"])
 
     def _compute_cal(self, cal_type):
         flag_complex = self.waveform_mode == "BB" or self.encode_mode == "complex"

@@ -697,9 +697,9 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
       const T val = range_ok ? ((T)10 * epa::fast_log10_lean(prx, L.log_tab, lk) + tvg) + Aadd : epa::M<T>::nan();
       const size_t o = row * S + s;
       out[o] = val;
-      if (range_out) {
+      if (range_out || a.stats_part) {  // (statistics without the array: epa_range_complex writes it when asked for)
         const bool ok = range_ok;
-        range_out[o] = ok ? (T)R : epa::M<T>::nan();
+        if (range_out) range_out[o] = ok ? (T)R : epa::M<T>::nan();
         if (ok) {
           const double rr = (double)(T)R;
           rmin = fmin(rmin, rr);
@@ -797,7 +797,48 @@ int launch_fft(FftArgs& a, hipStream_t st) {
   return epa::check_launch("sv_complex_fft_kernel");
 }
 
+// echo_range of complex samples alone: (s * ra) * rb per (channel, ping) coefficient row, NaN where the real part of
+// sector 0 is (range.py:138-148) -- what the sample kernels write as range_out
+template <typename InT, typename T>
+__global__ __launch_bounds__(epa::kBlock) void range_complex_kernel(const InT* __restrict__ re,
+                                                                    const double* __restrict__ ccoef, long long rows,
+                                                                    int S, int B, T* __restrict__ range_out) {
+  const int s = blockIdx.y * epa::kBlock + threadIdx.x;
+  if (s >= S) return;
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const double* cc = ccoef + (size_t)row * EPA_NCCOEF;
+    const double ra = cc[EPA_CC_RA], rb = cc[EPA_CC_RB];
+    const size_t o = (size_t)row * S + s;
+    const InT v = re[o * B];
+    range_out[o] = (v == v) ? (T)(((double)s * ra) * rb) : epa::M<T>::nan();
+  }
+}
+
 }  // namespace
+
+extern "C" int epa_range_complex(const void* re, int in_dtype, const double* ccoef, int C, int P, int S, int B,
+                                 void* range_out, int out_dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(re && ccoef && range_out, "epa_range_complex: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && B > 0, "epa_range_complex: C=%d P=%d S=%d B=%d", C, P, S, B);
+  EPA_CHECK_ARG((in_dtype == EPA_F32 || in_dtype == EPA_F64) && (out_dtype == EPA_F32 || out_dtype == EPA_F64),
+                "epa_range_complex: bad dtype in=%d out=%d", in_dtype, out_dtype);
+  const long long rows = (long long)C * P;
+  const int chunks = (S + epa::kBlock - 1) / epa::kBlock;
+  long long gx = 16384 / chunks;
+  if (gx < 1) gx = 1;
+  if (gx > rows) gx = rows;
+  const dim3 grid((unsigned)gx, (unsigned)chunks);
+  hipStream_t st = (hipStream_t)stream;
+#define EPA_RC(IN, OUT)                                                                                          \
+  hipLaunchKernelGGL((range_complex_kernel<IN, OUT>), grid, dim3(epa::kBlock), 0, st, (const IN*)re, ccoef, rows, S, B, \
+                     (OUT*)range_out)
+  if (in_dtype == EPA_F32 && out_dtype == EPA_F64) EPA_RC(float, double);
+  else if (in_dtype == EPA_F32) EPA_RC(float, float);
+  else if (out_dtype == EPA_F64) EPA_RC(double, double);
+  else EPA_RC(double, float);
+#undef EPA_RC
+  return epa::check_launch("range_complex_kernel");
+}
 
 extern "C" int epa_sv_complex_fft(const void* re, const void* im, int in_dtype, const float* replica,
                                   const int32_t* replica_off, int max_taps, const double* ccoef, int C,
@@ -812,7 +853,6 @@ extern "C" int epa_sv_complex_fft(const void* re, const void* im, int in_dtype, 
   EPA_CHECK_ARG((in_dtype == EPA_F32 || in_dtype == EPA_F64) && (out_dtype == EPA_F32 || out_dtype == EPA_F64) &&
                     (fft_dtype == EPA_F32 || fft_dtype == EPA_F64),
                 "epa_sv_complex_fft: bad dtype in=%d out=%d fft=%d", in_dtype, out_dtype, fft_dtype);
-  EPA_CHECK_ARG(!range_stats_out || range_out, "epa_sv_complex_fft: range statistics come with the echo_range array");
   if (max_taps < 1 || max_taps > kN / 2) {
     epa::set_error("epa_sv_complex_fft: replicas of 1..%d taps only (got %d); use epa_sv_complex", kN / 2, max_taps);
     return EPA_EUNSUPPORTED;

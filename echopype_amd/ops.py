@@ -335,6 +335,28 @@ def complex_coef_ek80(params, tau_eff, C, P, *, B, bb, cal_type="Sv", gpt=None):
     return out
 
 
+def sv_complex_uses_fft(replica, max_taps, method="auto"):
+    """The form sv_complex picks: LDS-FFT for replicas of 16 .. 1024 taps (or on request), direct otherwise / CW."""
+    return replica is not None and (method == "fft" or (method == "auto" and 16 <= max_taps <= _lib.EK80_NFFT // 2))
+
+
+def range_complex(re, ccoef, *, dtype=torch.float64):
+    """echo_range (C,P,S) of complex samples alone (what the sample kernels write as range_out)."""
+    C, P, S, B = re.shape
+    out = torch.empty((C, P, S), dtype=dtype, device=re.device)
+    call("epa_range_complex", _p(re), _DT[re.dtype], _p(ccoef), C, P, S, B, _p(out), _DT[dtype], _stream())
+    return out
+
+
+def power_rows_of_complex(ccoef):
+    """(C, P, NCOEF) power-sample coefficient rows with the range terms of the complex-sample rows (range =
+    (s * ra) * rb, nothing else set): what epa_mvbs takes in place of an echo_range array."""
+    rows = torch.zeros(tuple(ccoef.shape[:2]) + (_lib.NCOEF,), dtype=torch.float64, device=ccoef.device)
+    rows[..., 0] = ccoef[..., _lib.CC_RA]
+    rows[..., 1] = ccoef[..., _lib.CC_RB]
+    return rows
+
+
 def sv_complex(re, im, ccoef, *, replica=None, replica_off=None, max_taps=0, cal_type="Sv",
                dtype=torch.float64, want_range=True, want_prx=False, method="auto", fft_dtype=None,
                want_range_stats=False):
@@ -342,8 +364,8 @@ def sv_complex(re, im, ccoef, *, replica=None, replica_off=None, max_taps=0, cal
     "fft" (LDS-resident 2048-point FFT per tile) or "auto" (fft for replicas of 16 .. 1024 taps, where it is
     faster; direct otherwise and for CW).  ``fft_dtype``: arithmetic of the transform, default = ``dtype`` (float32
     output takes complex64 butterflies, as precise as that output; float64 output a complex128 transform).
-    ``want_range_stats`` (fft form, with ``want_range``): f64 device tensor {nanmin, nanmax, NaN count} of the
-    echo_range as a by-product of the same pass."""
+    ``want_range_stats`` (fft form): f64 device tensor {nanmin, nanmax, NaN count} of the echo_range as a by-product
+    of the same pass -- with ``want_range=False`` of the array range_complex would write."""
     C, P, S, B = re.shape
     if re.dtype != im.dtype or re.dtype not in _DT:
         raise ValueError("backscatter_r / backscatter_i must both be float32 or float64")
@@ -354,14 +376,14 @@ def sv_complex(re, im, ccoef, *, replica=None, replica_off=None, max_taps=0, cal
     rng = torch.empty((C, P, S), dtype=dtype, device=dev) if want_range else None
     prx = torch.empty((C, P, S), dtype=dtype, device=dev) if want_prx else None
     cal = _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS
-    use_fft = replica is not None and (method == "fft" or (method == "auto" and 16 <= max_taps <= _lib.EK80_NFFT // 2))
+    use_fft = sv_complex_uses_fft(replica, max_taps, method)
     stats = None
     if use_fft:
         n_ws = (768 + 4 * C + 3 * C * _lib.EK80_NFFT + 3 * 1024 + 2
                 + (C * P * (S // (_lib.EK80_NFFT // 2 + 1) + 1) + 63) // 64 + C * (S + 4) + 256)  # EPA_EK80_FFT_WS_DOUBLES
         ws = torch.empty(n_ws, dtype=torch.float64, device=dev)
         fdt = torch_dtype(fft_dtype) if fft_dtype is not None else dtype
-        if want_range_stats and want_range:
+        if want_range_stats:
             stats = torch.empty(3, dtype=torch.float64, device=dev)
         call("epa_sv_complex_fft", _p(re), _p(im), _DT[re.dtype], _p(replica), _p(replica_off), int(max_taps),
              _p(ccoef), C, P, S, B, cal, _p(out), _p(rng), _p(prx), _DT[dtype], _DT[fdt], _p(ws), _p(stats),

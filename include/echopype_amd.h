@@ -319,8 +319,9 @@ int epa_sv_complex(const void* re, const void* im, int in_dtype, const float* re
  *                partly-NaN sample, which a second launch redoes sector by sector; the time-varied gain
  *                n log10(R') + 2 alpha R' of each channel's first ping by sample index, read instead of computed
  *                by every ping with the same range numbers; the logarithm's lookup table; rebuilt by every call)
- *   range_stats_out : optional f64 [3] = {nanmin, nanmax, NaN count} of the echo_range written to range_out, a
- *                by-product of the same pass (what compute_MVBS, commongrid/api.py:108-110, asks next) */
+ *   range_stats_out : optional f64 [3] = {nanmin, nanmax, NaN count} of the echo_range (written to range_out, or --
+ *                range_out NULL -- left to epa_range_complex for whoever reads the array later), a by-product of the
+ *                same pass (what compute_MVBS, commongrid/api.py:108-110, asks next) */
 #define EPA_EK80_NFFT 2048
 #define EPA_EK80_FFT_WS_DOUBLES(C, P, S)                                              \
   (768 + 4 * (size_t)(C) + 3 * (size_t)(C) * EPA_EK80_NFFT + 3 * 1024 + 2 +          \
@@ -331,6 +332,12 @@ int epa_sv_complex_fft(const void* re, const void* im, int in_dtype, const float
                        int S, int B, int cal_type, void* out, void* range_out, void* prx_out,
                        int out_dtype, int fft_dtype, double* workspace, double* range_stats_out,
                        epa_stream_t stream);
+
+/* echo_range of complex samples alone (range.py:98-157: (range_sample * sample_interval) * sound_speed / 2, NaN where
+ * the real part of sector 0 is, :143-148) -- what epa_sv_complex / epa_sv_complex_fft write as range_out, for a caller
+ * that left it out of the sample pass.  re as there ([C*P*S*B], in_dtype), range_out [C*P*S] of out_dtype. */
+int epa_range_complex(const void* re, int in_dtype, const double* ccoef, int C, int P, int S, int B,
+                      void* range_out, int out_dtype, epa_stream_t stream);
 
 /* ==== SURVEY 8f "next" row 2: Ryan et al. (2015) noise masks + apply_mask ==============================
  * Masks are uint8 [C*P*S] (1 = True) in the (channel, ping_time, range_sample) layout of Sv.        */

@@ -9,6 +9,9 @@ grep -E "epa_|sv_complex|block_reduce|power_coef|noise|mvbs" $F/pmc_traffic.csv 
 cp $F/pmc_hot.csv profiles/r02_pmc_hot.csv
 (cat $F/pmc_hot.txt; echo "(pmc_hot.py volumes: chain / fused 4 x 100 000 x 2000 = 0.8 G samples per launch; FFT 2 x 5000 x 8192 = 81.92 M output samples per launch)") > profiles/r02_pmc_hot.txt
 cp $F/tests.txt profiles/r02_tests_gpu.txt
+cp $F/api_resident.txt profiles/r02_api_resident.txt
+cp $F/api_two_calls.txt profiles/r02_api_two_calls.txt
+cp $F/masks_probe.txt profiles/r02_masks_probe.txt
 cp $F/hbm_traffic.json profiles/hbm_traffic.json   # carries the hash of the kernel sources it was measured on
 python - <<'PY'
 import json, sys

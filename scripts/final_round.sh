@@ -1,14 +1,9 @@
 #!/bin/bash
 # Round-end GPU call: whole -m gpu suite, default bench, 2-rank gloo dry run, rocprofv3 kernel stats of the default bench,
-# PMC HBM-traffic passes, PMC instruction counters of the hot kernels.  Results under gpurun_out/final/.
+# PMC HBM-traffic passes, PMC instruction counters of the hot kernels, API and mask probes.  Results under gpurun_out/final/.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/final; rm -rf $O; mkdir -p $O
 python -m pytest tests -q -m gpu 2>&1 | tail -15 > $O/tests.txt; tail -3 $O/tests.txt
-python bench.py > $O/bench_default.jsonl 2> $O/bench_default.err
-python bench.py --gpus 2 --backend gloo --single-device --pings-total 400000 > $O/bench_gloo2.json 2> $O/bench_gloo2.err
-rocprofv3 --kernel-trace --stats -d $O/kt -o k --output-format csv -- python bench.py --no-cpu-baseline > $O/bench_under_rocprof.jsonl 2> $O/bench_under_rocprof.err
-find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
-find $O/kt -name "*kernel_trace.csv" -delete
 for wl in cfg2 cfg3 cfg4; do
   for c in FETCH_SIZE WRITE_SIZE; do
     n=fetch; [ $c = "FETCH_SIZE" ] || n=write
@@ -17,6 +12,15 @@ for wl in cfg2 cfg3 cfg4; do
 done
 python scripts/make_traffic_json.py $O | tee $O/traffic.txt
 cp profiles/hbm_traffic.json $O/hbm_traffic.json
+# (the bench lines come after the traffic measurement: they carry it, stamped with the hash of the sources)
+python bench.py > $O/bench_default.jsonl 2> $O/bench_default.err
+python bench.py --gpus 2 --backend gloo --single-device --pings-total 400000 > $O/bench_gloo2.json 2> $O/bench_gloo2.err
+rocprofv3 --kernel-trace --stats -d $O/kt -o k --output-format csv -- python bench.py --no-cpu-baseline > $O/bench_under_rocprof.jsonl 2> $O/bench_under_rocprof.err
+find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+find $O/kt -name "*kernel_trace.csv" -delete
+python scripts/perf_api_resident.py > $O/api_resident.txt 2>&1
+python scripts/perf_api_two_calls.py 2>&1 | grep -v "^$" | cut -c1-160 > $O/api_two_calls.txt
+python scripts/perf_masks.py > $O/masks_probe.txt 2>&1
 python scripts/pmc_summary.py $O/fetch_cfg2 > $O/pmc_traffic_a.csv 2>/dev/null
 for wl in cfg2 cfg3 cfg4; do for n in fetch write; do python scripts/pmc_summary.py $O/${n}_$wl kernel | grep -v "^kernel," | sed "s/^/$wl,/" ; done; done > $O/pmc_traffic.csv
 find $O -name "*counter_collection.csv" -delete; find $O -name "*kernel_trace.csv" -delete

@@ -668,13 +668,13 @@ def test_compute_MVBS_bins_a_lazy_echo_range_through_its_coefficient_rows(dtype,
     b = ep.commongrid.compute_MVBS(ds2, range_bin="2m", ping_time_bin="10s", closed=closed)
     # (same bins, same members; the two kernel instantiations add a bin's members in different orders: last-bit noise)
     np.testing.assert_array_equal(np.isnan(a["Sv"].values), np.isnan(b["Sv"].values))
-    np.testing.assert_allclose(a["Sv"].values, b["Sv"].values, rtol=1e-13 if dtype == "float64" else 2e-6, atol=0)
+    np.testing.assert_allclose(a["Sv"].values, b["Sv"].values, rtol=1e-13 if dtype == "float64" else 1e-5, atol=0)
     np.testing.assert_array_equal(a["echo_range"].values, b["echo_range"].values)
     assert np.isfinite(a["Sv"].values).any()
     c = ep.commongrid.compute_MVBS(ds, range_bin="2m", ping_time_bin="10s", closed=closed, skipna=False)
     assert lazy.materialized
     d = ep.commongrid.compute_MVBS(ds2, range_bin="2m", ping_time_bin="10s", closed=closed, skipna=False)
-    np.testing.assert_allclose(c["Sv"].values, d["Sv"].values, rtol=1e-13 if dtype == "float64" else 2e-6, atol=0)
+    np.testing.assert_allclose(c["Sv"].values, d["Sv"].values, rtol=1e-13 if dtype == "float64" else 1e-5, atol=0)
 
 
 @pytest.mark.gpu
@@ -704,3 +704,42 @@ def test_lazy_echo_range_edge_cases():
     ds2["echo_range"].values
     out2 = ep.clean.remove_background_noise(ds2, 20, 50)
     np.testing.assert_array_equal(out["Sv_corrected"].values, out2["Sv_corrected"].values)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_ek80_bb_echo_range_lazy_and_mvbs_through_rows(ep, dtype):
+    """EK80 broadband compute_Sv (the LDS-FFT form) leaves echo_range lazy too: statistics from the sample pass,
+    the array from epa_range_complex on first read (bit-identical to the eager range_out, NaN where sector 0 is),
+    compute_MVBS through the coefficient rows == compute_MVBS on the array; CW complex samples (no statistics in that
+    kernel) keep the eager array."""
+    import torch
+    from echopype_amd import ops
+    from echopype_amd.xr_lite import LazyDeviceArray
+
+    d, filt = _ek80(ep, "BB", C=2, P=40, S=1200, mixed_nan=True)
+    ed = ep.echodata.from_ek80_arrays(d, filt)
+    ds = ep.calibrate.compute_Sv(ed, waveform_mode="BB", encode_mode="complex", dtype=dtype)
+    lazy = ds["echo_range"].data
+    assert isinstance(lazy, LazyDeviceArray) and not lazy.materialized
+    a = ep.commongrid.compute_MVBS(ds, range_bin="0.5m", ping_time_bin="5s")
+    assert not lazy.materialized
+    cal = ep.calibrate.api.CALIBRATOR["EK80"](ed, None, None, "BB", "complex", dtype=dtype)
+    k, _ = cal._complex_inputs("Sv")
+    eager = ops.sv_complex(k["re"], k["im"], k["ccoef"], replica=k["replica"], replica_off=k["replica_off"],
+                           max_taps=k["max_taps"], dtype=getattr(torch, dtype), want_range_stats=True)
+    stats = lazy.cached_stats()
+    got = ds["echo_range"].values
+    np.testing.assert_array_equal(got, eager["echo_range"].cpu().numpy())
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(d["backscatter_r"][..., 0]))
+    lo, hi, nn = eager["range_stats"].cpu().tolist()
+    assert stats == (lo, hi, int(nn)) and nn == np.isnan(got).sum() and hi == np.nanmax(got)
+    ds2 = ep.calibrate.compute_Sv(ed, waveform_mode="BB", encode_mode="complex", dtype=dtype)
+    ds2["echo_range"] = ep.xr_lite.DataArray(ep.DeviceArray(ds2["echo_range"].data.tensor), ds2["echo_range"].dims)
+    b = ep.commongrid.compute_MVBS(ds2, range_bin="0.5m", ping_time_bin="5s")
+    np.testing.assert_array_equal(np.isnan(a["Sv"].values), np.isnan(b["Sv"].values))
+    np.testing.assert_allclose(a["Sv"].values, b["Sv"].values, rtol=1e-13 if dtype == "float64" else 1e-5, atol=0)
+    assert np.isfinite(a["Sv"].values).any()
+    dcw, filt = _ek80(ep, "CW", C=2, P=12, S=600)
+    dscw = ep.calibrate.compute_Sv(ep.echodata.from_ek80_arrays(dcw, filt), waveform_mode="CW", encode_mode="complex")
+    assert not isinstance(dscw["echo_range"].data, LazyDeviceArray)
