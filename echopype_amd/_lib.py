@@ -78,6 +78,7 @@ SIGNATURES = {
     "epa_sv_power_stats": [_vp, _vp, _i, _i, _i, _i, _u, _vp, _vp, _i, _vp, _vp, _vp],
     "epa_range_power": [_vp, _vp, _i, _i, _i, _u, _vp, _i, _vp],
     "epa_range_complex": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp],
+    "epa_sv_complex_cw_stats": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "epa_time_bin_offsets": [_vp, _i, _i64, _i64, _i, _u, _vp, _vp],
     "epa_sv_mvbs_fused": [_vp, _vp, _i, _i, _i, _i, _u, _vp, _vp, _i, _d, _i, _u, _d, _vp, _vp, _vp,
                           _vp, _vp, _vp, _i, _vp],

@@ -375,9 +375,9 @@ class CalibrateEK80(CalibrateEK):
     def _cal_complex_samples(self, cal_type):
         """One fused pass for calibrate_ek.py:532-659 (+ ek80_complex.py:285-391 for BB)."""
         k, tau_eff = self._complex_inputs(cal_type)
-        # the LDS-FFT form leaves {nanmin, nanmax, NaN count} of echo_range as a by-product: the array itself can stay
+        # the LDS-FFT form and the CW kernel leave {nanmin, nanmax, NaN count} of echo_range as a by-product: the array can stay
         # lazy then (written by epa_range_complex if somebody reads it; compute_MVBS bins through the coefficient rows)
-        lazy = ops.sv_complex_uses_fft(k["replica"], k["max_taps"])
+        lazy = k["replica"] is None or ops.sv_complex_uses_fft(k["replica"], k["max_taps"])
         res = ops.sv_complex(k["re"], k["im"], k["ccoef"], replica=k["replica"], replica_off=k["replica_off"],
                              max_taps=k["max_taps"], cal_type=cal_type, dtype=self.dtype, fft_dtype=self.fft_dtype,
                              want_range=not lazy, want_range_stats=True)

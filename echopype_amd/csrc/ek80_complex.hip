@@ -70,7 +70,9 @@ struct CxArgs {
   void* prx_out;
   unsigned rep_lds_off, mask_lds_off, tab_lds_off;  // byte offsets in dynamic LDS
   int stage_len;                       // kTile + max_taps - 1 (>= kTile)
+  double* stats_part;                  // optional [3 * kCwStatSlots] {min, max, NaN count} of echo_range (CW kernel)
 };
+constexpr int kCwStatSlots = 1024;
 
 // stage samples [k_begin, k_begin + len) of one ping: sector sum (or one sector when `only` >= 0)
 // 16-byte vector loads of the NB sector values of one sample (NB * sizeof(InT) must be a multiple of
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(epa::kBlock, EPA_EK80_MIN_WAVES) void sv_complex_ke
 template <typename InT>
 constexpr int cw_piece() { return sizeof(InT) == 8 ? 1024 : 2048; }
 
-template <typename InT, typename T, int NB>
+template <typename InT, typename T, int NB, bool STATS>
 __global__ __launch_bounds__(epa::kBlock) void sv_complex_cw_kernel(CxArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
   const epa::MathTabs mt = epa::build_math_tabs(tabs);
@@ -327,6 +329,8 @@ __global__ __launch_bounds__(epa::kBlock) void sv_complex_cw_kernel(CxArgs a) {
   T* prx_out = reinterpret_cast<T*>(a.prx_out);
   constexpr int kCwPiece = cw_piece<InT>();
   constexpr int kPer = kCwPiece / epa::kBlock;
+  double rmin = __builtin_inf(), rmax = -__builtin_inf();  // statistics of the echo_range (written or not)
+  int rnan = 0;
   // all loads of the lane first (independent), then the arithmetic
   InT vr[kPer][NB > 0 ? NB : 1], vi[kPer][NB > 0 ? NB : 1];
   if (NB > 0) {
@@ -385,6 +389,51 @@ __global__ __launch_bounds__(epa::kBlock) void sv_complex_cw_kernel(CxArgs a) {
     out[o] = val;
     if (range_out) range_out[o] = range_ok ? (T)R : epa::M<T>::nan();
     if (prx_out) prx_out[o] = prx;
+    if (STATS) {
+      if (range_ok) {
+        const double rr = (double)(T)R;
+        rmin = fmin(rmin, rr);
+        rmax = fmax(rmax, rr);
+      } else {
+        ++rnan;
+      }
+    }
+  }
+  if (STATS) {  // one merge per workgroup into one of kCwStatSlots slots (f64 atomics)
+    __shared__ double sred[12];
+    double cnt = (double)rnan;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      rmin = fmin(rmin, __shfl_down(rmin, o, 64));
+      rmax = fmax(rmax, __shfl_down(rmax, o, 64));
+      cnt += __shfl_down(cnt, o, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+      sred[3 * wave] = rmin;
+      sred[3 * wave + 1] = rmax;
+      sred[3 * wave + 2] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double* dst = a.stats_part + 3 * ((row * a.tiles + piece) & (size_t)(kCwStatSlots - 1));
+      const double mn = fmin(fmin(sred[0], sred[3]), fmin(sred[6], sred[9]));
+      const double mx = fmax(fmax(sred[1], sred[4]), fmax(sred[7], sred[10]));
+      const double nn = (sred[2] + sred[5]) + (sred[8] + sred[11]);
+      if (mn <= mx) {
+        atomicMin(dst, mn);
+        atomicMax(dst + 1, mx);
+      }
+      if (nn > 0.0) atomicAdd(dst + 2, nn);
+    }
+  }
+}
+
+__global__ __launch_bounds__(epa::kBlock) void cw_stats_init_kernel(double* __restrict__ sp) {
+  for (int k = threadIdx.x; k < kCwStatSlots; k += epa::kBlock) {
+    sp[3 * k] = __builtin_inf();
+    sp[3 * k + 1] = -__builtin_inf();
+    sp[3 * k + 2] = 0.0;
   }
 }
 
@@ -394,8 +443,13 @@ int launch_cw(CxArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)((long long)a.P * a.tiles), (unsigned)a.C);
   const bool b4 = a.B == 4 && (reinterpret_cast<uintptr_t>(a.re) & 15u) == 0 &&
                   (reinterpret_cast<uintptr_t>(a.im) & 15u) == 0;
-  if (b4) hipLaunchKernelGGL((sv_complex_cw_kernel<InT, T, 4>), grid, dim3(epa::kBlock), 0, st, a);
-  else hipLaunchKernelGGL((sv_complex_cw_kernel<InT, T, 0>), grid, dim3(epa::kBlock), 0, st, a);
+  if (a.stats_part) {
+    if (b4) hipLaunchKernelGGL((sv_complex_cw_kernel<InT, T, 4, true>), grid, dim3(epa::kBlock), 0, st, a);
+    else hipLaunchKernelGGL((sv_complex_cw_kernel<InT, T, 0, true>), grid, dim3(epa::kBlock), 0, st, a);
+  } else {
+    if (b4) hipLaunchKernelGGL((sv_complex_cw_kernel<InT, T, 4, false>), grid, dim3(epa::kBlock), 0, st, a);
+    else hipLaunchKernelGGL((sv_complex_cw_kernel<InT, T, 0, false>), grid, dim3(epa::kBlock), 0, st, a);
+  }
   return epa::check_launch("sv_complex_cw_kernel");
 }
 
@@ -432,10 +486,10 @@ int launch(CxArgs& a, int max_taps, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int epa_sv_complex(const void* re, const void* im, int in_dtype, const float* replica,
-                              const int32_t* replica_off, int max_taps, const double* ccoef, int C,
-                              int P, int S, int B, int cal_type, void* out, void* range_out,
-                              void* prx_out, int out_dtype, epa_stream_t stream) {
+static int sv_complex_entry(const void* re, const void* im, int in_dtype, const float* replica,
+                            const int32_t* replica_off, int max_taps, const double* ccoef, int C,
+                            int P, int S, int B, int cal_type, void* out, void* range_out,
+                            void* prx_out, int out_dtype, double* stats_part, epa_stream_t stream) {
   EPA_CHECK_ARG(re && im && ccoef && out, "epa_sv_complex: NULL array argument");
   EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && B > 0, "epa_sv_complex: C=%d P=%d S=%d B=%d", C, P, S, B);
   EPA_CHECK_ARG(B <= kMaxBeams, "epa_sv_complex: at most %d sectors supported (got %d)", kMaxBeams, B);
@@ -448,6 +502,7 @@ extern "C" int epa_sv_complex(const void* re, const void* im, int in_dtype, cons
   a.C = C; a.P = P; a.S = S; a.B = B;
   a.nspread = cal_type == EPA_CAL_SV ? 20.0 : 40.0;
   a.out = out; a.range_out = range_out; a.prx_out = prx_out;
+  a.stats_part = stats_part;
   const int taps = replica ? max_taps : 0;
   hipStream_t st = (hipStream_t)stream;
   if (!replica) {  // CW: the streaming kernel
@@ -464,4 +519,26 @@ extern "C" int epa_sv_complex(const void* re, const void* im, int in_dtype, cons
   if (in_dtype == EPA_F32 && out_dtype == EPA_F32) return launch<float, float, float>(a, taps, st);
   epa::set_error("epa_sv_complex: bad dtype in=%d out=%d", in_dtype, out_dtype);
   return EPA_EINVAL;
+}
+
+extern "C" int epa_sv_complex(const void* re, const void* im, int in_dtype, const float* replica,
+                              const int32_t* replica_off, int max_taps, const double* ccoef, int C,
+                              int P, int S, int B, int cal_type, void* out, void* range_out,
+                              void* prx_out, int out_dtype, epa_stream_t stream) {
+  return sv_complex_entry(re, im, in_dtype, replica, replica_off, max_taps, ccoef, C, P, S, B, cal_type, out, range_out,
+                          prx_out, out_dtype, nullptr, stream);
+}
+
+extern "C" int epa_sv_complex_cw_stats(const void* re, const void* im, int in_dtype, const double* ccoef, int C, int P,
+                                       int S, int B, int cal_type, void* out, void* range_out, void* prx_out,
+                                       int out_dtype, double* workspace, double* range_stats_out,
+                                       epa_stream_t stream) {
+  EPA_CHECK_ARG(workspace && range_stats_out, "epa_sv_complex_cw_stats: NULL workspace / range_stats_out");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(cw_stats_init_kernel, dim3(1), dim3(epa::kBlock), 0, st, workspace);
+  if (int rc = epa::check_launch("cw_stats_init_kernel")) return rc;
+  if (int rc = sv_complex_entry(re, im, in_dtype, nullptr, nullptr, 0, ccoef, C, P, S, B, cal_type, out, range_out,
+                                prx_out, out_dtype, workspace, stream))
+    return rc;
+  return epa_minmax_final(workspace, kCwStatSlots, range_stats_out, st);
 }

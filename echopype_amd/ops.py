@@ -364,7 +364,7 @@ def sv_complex(re, im, ccoef, *, replica=None, replica_off=None, max_taps=0, cal
     "fft" (LDS-resident 2048-point FFT per tile) or "auto" (fft for replicas of 16 .. 1024 taps, where it is
     faster; direct otherwise and for CW).  ``fft_dtype``: arithmetic of the transform, default = ``dtype`` (float32
     output takes complex64 butterflies, as precise as that output; float64 output a complex128 transform).
-    ``want_range_stats`` (fft form): f64 device tensor {nanmin, nanmax, NaN count} of the echo_range as a by-product
+    ``want_range_stats`` (fft form and CW): f64 device tensor {nanmin, nanmax, NaN count} of the echo_range as a by-product
     of the same pass -- with ``want_range=False`` of the array range_complex would write."""
     C, P, S, B = re.shape
     if re.dtype != im.dtype or re.dtype not in _DT:
@@ -388,6 +388,11 @@ def sv_complex(re, im, ccoef, *, replica=None, replica_off=None, max_taps=0, cal
         call("epa_sv_complex_fft", _p(re), _p(im), _DT[re.dtype], _p(replica), _p(replica_off), int(max_taps),
              _p(ccoef), C, P, S, B, cal, _p(out), _p(rng), _p(prx), _DT[dtype], _DT[fdt], _p(ws), _p(stats),
              _stream())
+    elif replica is None and want_range_stats:  # CW: the streaming kernel leaves the statistics as well
+        ws = torch.empty(3072, dtype=torch.float64, device=dev)  # EPA_SV_COMPLEX_CW_STATS_WS_DOUBLES
+        stats = torch.empty(3, dtype=torch.float64, device=dev)
+        call("epa_sv_complex_cw_stats", _p(re), _p(im), _DT[re.dtype], _p(ccoef), C, P, S, B, cal, _p(out), _p(rng),
+             _p(prx), _DT[dtype], _p(ws), _p(stats), _stream())
     else:
         call("epa_sv_complex", _p(re), _p(im), _DT[re.dtype], _p(replica), _p(replica_off), int(max_taps),
              _p(ccoef), C, P, S, B, cal, _p(out), _p(rng), _p(prx), _DT[dtype], _stream())

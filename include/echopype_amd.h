@@ -333,6 +333,15 @@ int epa_sv_complex_fft(const void* re, const void* im, int in_dtype, const float
                        int out_dtype, int fft_dtype, double* workspace, double* range_stats_out,
                        epa_stream_t stream);
 
+/* epa_sv_complex on CW samples (no replica) with {nanmin, nanmax, NaN count} of the echo_range as a by-product
+ * (range_stats_out f64 [3]; merged through 1024 slots of f64 atomics in workspace, f64
+ * [EPA_SV_COMPLEX_CW_STATS_WS_DOUBLES]); range_out may be NULL: the statistics are then those of the array
+ * epa_range_complex would write.  Other arguments as epa_sv_complex. */
+#define EPA_SV_COMPLEX_CW_STATS_WS_DOUBLES 3072
+int epa_sv_complex_cw_stats(const void* re, const void* im, int in_dtype, const double* ccoef, int C, int P, int S,
+                            int B, int cal_type, void* out, void* range_out, void* prx_out, int out_dtype,
+                            double* workspace, double* range_stats_out, epa_stream_t stream);
+
 /* echo_range of complex samples alone (range.py:98-157: (range_sample * sample_interval) * sound_speed / 2, NaN where
  * the real part of sector 0 is, :143-148) -- what epa_sv_complex / epa_sv_complex_fft write as range_out, for a caller
  * that left it out of the sample pass.  re as there ([C*P*S*B], in_dtype), range_out [C*P*S] of out_dtype. */

@@ -16,12 +16,15 @@ for plane in (torch.float32, torch.float64):
     re = (torch.randn((C, P, S, B), generator=g, device="cuda", dtype=torch.float32) * 1e-3).to(plane)
     im = (torch.randn((C, P, S, B), generator=g, device="cuda", dtype=torch.float32) * 1e-3).to(plane)
     for out_dt in (torch.float64, torch.float32):
-        for want_range in (False, True):
-            f = lambda: ops.sv_complex(re, im, ccd, dtype=out_dt, want_range=want_range)
+        for want_range in (False, True, "stats only"):
+            if want_range == "stats only":  # what compute_Sv asks for: echo_range stays lazy, its statistics come along
+                f = lambda: ops.sv_complex(re, im, ccd, dtype=out_dt, want_range=False, want_range_stats=True)
+            else:
+                f = lambda: ops.sv_complex(re, im, ccd, dtype=out_dt, want_range=want_range)
             f(); torch.cuda.synchronize(); ms = []
             for _ in range(3):
                 t.start(); f(); t.stop(); ms.append(t.elapsed_ms())
             m = float(np.median(ms)); n = C * P * S
-            bps = B * 2 * re.element_size() + (2 if want_range else 1) * (8 if out_dt == torch.float64 else 4)
-            print(f"CW planes {str(plane)[6:]} -> {str(out_dt)[6:]}{' + echo_range' if want_range else ''}: {m:7.3f} ms  {n/m/1e6:7.1f} Gsamp/s  {n*bps/m/1e9:5.2f} TB/s", flush=True)
+            bps = B * 2 * re.element_size() + (2 if want_range is True else 1) * (8 if out_dt == torch.float64 else 4)
+            print(f"CW planes {str(plane)[6:]} -> {str(out_dt)[6:]}{' + echo_range' if want_range is True else ' + range statistics' if want_range else ''}: {m:7.3f} ms  {n/m/1e6:7.1f} Gsamp/s  {n*bps/m/1e9:5.2f} TB/s", flush=True)
     del re, im

@@ -711,8 +711,8 @@ def test_lazy_echo_range_edge_cases():
 def test_ek80_bb_echo_range_lazy_and_mvbs_through_rows(ep, dtype):
     """EK80 broadband compute_Sv (the LDS-FFT form) leaves echo_range lazy too: statistics from the sample pass,
     the array from epa_range_complex on first read (bit-identical to the eager range_out, NaN where sector 0 is),
-    compute_MVBS through the coefficient rows == compute_MVBS on the array; CW complex samples (no statistics in that
-    kernel) keep the eager array."""
+    compute_MVBS through the coefficient rows == compute_MVBS on the array; the same for CW complex samples (the
+    streaming kernel's by-product), echo_range bit-identical to the plain epa_sv_complex call."""
     import torch
     from echopype_amd import ops
     from echopype_amd.xr_lite import LazyDeviceArray
@@ -740,6 +740,19 @@ def test_ek80_bb_echo_range_lazy_and_mvbs_through_rows(ep, dtype):
     np.testing.assert_array_equal(np.isnan(a["Sv"].values), np.isnan(b["Sv"].values))
     np.testing.assert_allclose(a["Sv"].values, b["Sv"].values, rtol=1e-13 if dtype == "float64" else 1e-5, atol=0)
     assert np.isfinite(a["Sv"].values).any()
-    dcw, filt = _ek80(ep, "CW", C=2, P=12, S=600)
-    dscw = ep.calibrate.compute_Sv(ep.echodata.from_ek80_arrays(dcw, filt), waveform_mode="CW", encode_mode="complex")
-    assert not isinstance(dscw["echo_range"].data, LazyDeviceArray)
+    # CW complex samples: the streaming kernel leaves the statistics too (epa_sv_complex_cw_stats)
+    dcw, filt = _ek80(ep, "CW", C=2, P=30, S=2100, mixed_nan=True)
+    edcw = ep.echodata.from_ek80_arrays(dcw, filt)
+    dscw = ep.calibrate.compute_Sv(edcw, waveform_mode="CW", encode_mode="complex", dtype=dtype)
+    lz = dscw["echo_range"].data
+    assert isinstance(lz, LazyDeviceArray) and not lz.materialized
+    calcw = ep.calibrate.api.CALIBRATOR["EK80"](edcw, None, None, "CW", "complex", dtype=dtype)
+    kc, _ = calcw._complex_inputs("Sv")
+    eg = ops.sv_complex(kc["re"], kc["im"], kc["ccoef"], dtype=getattr(torch, dtype))
+    st = lz.cached_stats()
+    gr = dscw["echo_range"].values
+    np.testing.assert_array_equal(gr, eg["echo_range"].cpu().numpy())
+    # (two instantiations of the kernel: the compiler contracts the dB sum differently, last-bit differences)
+    np.testing.assert_array_equal(np.isnan(dscw["Sv"].values), np.isnan(eg["out"].cpu().numpy()))
+    np.testing.assert_allclose(dscw["Sv"].values, eg["out"].cpu().numpy(), rtol=1e-14 if dtype == "float64" else 1e-6)
+    assert st == (np.nanmin(gr), np.nanmax(gr), int(np.isnan(gr).sum())) and st[2] > 0
