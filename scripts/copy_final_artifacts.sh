@@ -12,6 +12,7 @@ cp $F/tests.txt profiles/r02_tests_gpu.txt
 cp $F/api_resident.txt profiles/r02_api_resident.txt
 cp $F/api_two_calls.txt profiles/r02_api_two_calls.txt
 cp $F/masks_probe.txt profiles/r02_masks_probe.txt
+cp $F/cw_probe.txt profiles/r02_ek80_cw_probe.txt
 cp $F/hbm_traffic.json profiles/hbm_traffic.json   # carries the hash of the kernel sources it was measured on
 python - <<'PY'
 import json, sys
