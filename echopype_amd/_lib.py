@@ -94,6 +94,7 @@ SIGNATURES = {
     "epa_noise_estimate": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp],
     "epa_noise_finalize": [_vp, _vp, _i, _i, _d, _vp, _vp],
     "epa_noise_apply": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp],
+    "epa_noise_apply_rows": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp],
     "epa_complex_coef_ek80": [_i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "epa_sv_complex": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "epa_sv_complex_fft": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],

@@ -161,4 +161,5 @@ class CalibrateBase(abc.ABC):
                                    "modified in place since: its NaN mask can no longer be reproduced")
             return ops.range_power(raw, coef, flags=mask_flag, dtype=dtype)
 
-        return out_t, LazyDeviceArray((C, P, S), dtype, raw.device, make, stats=stats, rows=coef), stats
+        return out_t, LazyDeviceArray((C, P, S), dtype, raw.device, make, stats=stats, rows=coef,
+                                      nan_where=raw if mask_flag else None), stats

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from ..commongrid.api import _dev, _full, _range_stats
+from ..commongrid.api import _coef_rows, _dev, _full, _range_stats
 from ..commongrid.utils import _parse_x_bin
 from ..utils.prov import echopype_prov_attrs, insert_processing_level
 from ..xr_lite import DataArray, DeviceArray, from_xarray, xarray_io
@@ -26,7 +26,14 @@ def _inputs(ds_Sv):
     sv_t = _dev(sv_da)
     if sv_t.dtype not in (torch.float32, torch.float64):
         sv_t = sv_t.double()
-    rg_t = _dev(_full(ds_Sv["echo_range"], ds_Sv, order), sv_t.dtype)
+    # a lazy echo_range straight from compute_Sv on power samples: the kernels evaluate its coefficient rows and take the
+    # NaN pattern from the raw samples (rg_t = (rows, raw)); the array is never written
+    rows = _coef_rows(ds_Sv["echo_range"], order, sv_t)
+    raw = ds_Sv["echo_range"].data.nan_source() if rows is not None else None
+    if raw is not None and raw.dtype == torch.float32 and tuple(raw.shape) == tuple(sv_t.shape) and raw.is_contiguous():
+        rg_t = (rows, raw)
+    else:
+        rg_t = _dev(_full(ds_Sv["echo_range"], ds_Sv, order), sv_t.dtype)
     C, P, S = sv_t.shape
     a = ds_Sv["sound_absorption"]
     av = np.asarray(a.values, dtype=np.float64)
@@ -39,18 +46,25 @@ def _inputs(ds_Sv):
     return order, sv_t, rg_t, ops.to_device(np.ascontiguousarray(a2, dtype=np.float64))
 
 
+def _rng_kw(rg_t, apply=False):
+    """Keyword arguments of ops.noise_estimate / noise_apply for a range given as an array or as (rows, raw)."""
+    if isinstance(rg_t, tuple):
+        return dict(coef=rg_t[0], mask_raw=rg_t[1]) if apply else dict(coef=rg_t[0])
+    return dict(range=rg_t)
+
+
 def _estimate(ds_Sv, ping_num, range_sample_num, background_noise_max, shard=None):
     if background_noise_max is not None:
         background_noise_max = extract_dB(background_noise_max)
     order, sv_t, rg_t, a2 = _inputs(ds_Sv)
     nmax = float("nan") if background_noise_max is None else float(background_noise_max)
     if shard is None:
-        noise = ops.noise_estimate(sv_t, a2, ping_num, range_sample_num, range=rg_t, noise_max=nmax)
+        noise = ops.noise_estimate(sv_t, a2, ping_num, range_sample_num, noise_max=nmax, **_rng_kw(rg_t))
     else:  # one rank's ping shard: blocks count from the dataset's first ping; blocks cut by a shard edge are merged
         from .. import sharding
 
         ping_offset, group = shard
-        noise, es, ec = ops.noise_estimate(sv_t, a2, ping_num, range_sample_num, range=rg_t, noise_max=nmax,
+        noise, es, ec = ops.noise_estimate(sv_t, a2, ping_num, range_sample_num, noise_max=nmax, **_rng_kw(rg_t),
                                            ping_phase=ping_offset % ping_num, want_edges=True)
         sharding.merge_noise_edges(noise, es, ec, ping_offset, sv_t.shape[1], ping_num, nmax, group)
     return order, sv_t, rg_t, a2, noise, background_noise_max
@@ -61,7 +75,7 @@ def estimate_background_noise(ds_Sv, ping_num, range_sample_num, background_nois
     """Sv_noise (same shape as Sv): block-minimum noise + transmission loss (api.py:392-431)."""
     ds_Sv = from_xarray(ds_Sv)
     order, sv_t, rg_t, a2, noise, _ = _estimate(ds_Sv, ping_num, range_sample_num, background_noise_max)
-    sn, _ = ops.noise_apply(sv_t, a2, noise, ping_num, 0.0, range=rg_t, want_corrected=False)
+    sn, _ = ops.noise_apply(sv_t, a2, noise, ping_num, 0.0, want_corrected=False, **_rng_kw(rg_t, apply=True))
     return DataArray(DeviceArray(sn), order, {d: ds_Sv[d].values for d in order if d in ds_Sv.coords},
                      name="Sv_noise")
 
@@ -76,7 +90,7 @@ def remove_background_noise(ds_Sv, ping_num, range_sample_num, background_noise_
         SNR_threshold = extract_dB(SNR_threshold)
     order, sv_t, rg_t, a2, noise, nmax = _estimate(ds_Sv, ping_num, range_sample_num, background_noise_max, _shard)
     # actual_range of both outputs is a by-product of the kernel (no extra sweeps)
-    sn, sc, mm = ops.noise_apply(sv_t, a2, noise, ping_num, float(SNR_threshold), range=rg_t, want_minmax=True,
+    sn, sc, mm = ops.noise_apply(sv_t, a2, noise, ping_num, float(SNR_threshold), want_minmax=True, **_rng_kw(rg_t, apply=True),
                                  ping_phase=0 if _shard is None else _shard[0] % ping_num)
     for name, t, kind, rng_mm in (("Sv_noise", sn, "noise", mm[0:2]), ("Sv_corrected", sc, "corrected", mm[2:4])):
         da = DataArray(DeviceArray(t), order)

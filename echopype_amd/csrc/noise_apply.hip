@@ -17,7 +17,7 @@ namespace {
 template <typename T, bool VEC>
 __global__ __launch_bounds__(epa::kBlock) void noise_apply_kernel(
     const T* __restrict__ sv, const T* __restrict__ range, const epa::CoefRow* __restrict__ coef,
-    const double* __restrict__ alpha2, const double* __restrict__ noise, int P, int S,
+    const float* __restrict__ mask_raw, const double* __restrict__ alpha2, const double* __restrict__ noise, int P, int S,
     long long rows, int ping_num, int ping_phase, int n_pblocks, T snr, T* __restrict__ sv_noise,
     T* __restrict__ sv_corr, unsigned long long* __restrict__ mm_keys) {
   using LM = epa::LaneMap<T>;
@@ -48,6 +48,13 @@ __global__ __launch_bounds__(epa::kBlock) void noise_apply_kernel(
         const epa::CoefRow cr = coef[row];
 #pragma unroll
         for (int j = 0; j < LEN; ++j) x[j] = (T)epa::row_range(cr, s0[g] + j);
+        if (mask_raw) {  // the echo_range array is NaN where the raw sample is (range.py:143-148): so is Sv_noise
+          epa::RawVec<LEN> in;
+          in.load(mask_raw + off);
+#pragma unroll
+          for (int j = 0; j < LEN; ++j)
+            if (!(in.v[j] == in.v[j])) x[j] = epa::M<T>::nan();
+        }
       }
 #pragma unroll
       for (int j = 0; j < LEN; ++j) {
@@ -106,12 +113,12 @@ __global__ void decode_minmax_kernel(double* p) {
 inline bool al16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <typename T>
-int launch(const void* sv, const void* range, const double* coef, const double* alpha2,
+int launch(const void* sv, const void* range, const double* coef, const float* mask_raw, const double* alpha2,
            const double* noise, int C, int P, int S, int ping_num, int ping_phase, double snr, void* sv_noise,
            void* sv_corr, double* minmax_out, hipStream_t st) {
   const long long rows = (long long)C * P;
   const int need = sizeof(T) == 8 ? 2 : 4;
-  const bool vec = S % need == 0 && al16(sv) && al16(range) && al16(sv_noise) && al16(sv_corr);
+  const bool vec = S % need == 0 && al16(sv) && al16(range) && al16(sv_noise) && al16(sv_corr) && al16(mask_raw);
   const int chunk = vec ? 1024 : epa::kBlock;
   const int chunks_per_row = (S + chunk - 1) / chunk;
   long long gx = 8192 / chunks_per_row;
@@ -124,11 +131,11 @@ int launch(const void* sv, const void* range, const double* coef, const double* 
   if (mm) hipLaunchKernelGGL(init_minmax_kernel, dim3(1), dim3(4), 0, st, mm);
   if (vec)
     hipLaunchKernelGGL((noise_apply_kernel<T, true>), grid, dim3(epa::kBlock), 0, st, (const T*)sv,
-                       (const T*)range, cf, alpha2, noise, P, S, rows, ping_num, ping_phase, n_pblocks, (T)snr,
+                       (const T*)range, cf, mask_raw, alpha2, noise, P, S, rows, ping_num, ping_phase, n_pblocks, (T)snr,
                        (T*)sv_noise, (T*)sv_corr, mm);
   else
     hipLaunchKernelGGL((noise_apply_kernel<T, false>), grid, dim3(epa::kBlock), 0, st, (const T*)sv,
-                       (const T*)range, cf, alpha2, noise, P, S, rows, ping_num, ping_phase, n_pblocks, (T)snr,
+                       (const T*)range, cf, mask_raw, alpha2, noise, P, S, rows, ping_num, ping_phase, n_pblocks, (T)snr,
                        (T*)sv_noise, (T*)sv_corr, mm);
   if (int rc = epa::check_launch("noise_apply_kernel")) return rc;
   if (mm) {
@@ -151,11 +158,30 @@ extern "C" int epa_noise_apply(const void* sv, const void* range, const double* 
   EPA_CHECK_ARG(ping_phase >= 0 && ping_phase < ping_num, "epa_noise_apply: ping_phase %d not in [0, %d)", ping_phase,
                 ping_num);
   if (dtype == EPA_F64)
-    return launch<double>(sv, range, coef, alpha2, noise, C, P, S, ping_num, ping_phase, snr_threshold,
+    return launch<double>(sv, range, coef, nullptr, alpha2, noise, C, P, S, ping_num, ping_phase, snr_threshold,
                           sv_noise_out, sv_corrected_out, minmax_out, (hipStream_t)stream);
   if (dtype == EPA_F32)
-    return launch<float>(sv, range, coef, alpha2, noise, C, P, S, ping_num, ping_phase, snr_threshold,
+    return launch<float>(sv, range, coef, nullptr, alpha2, noise, C, P, S, ping_num, ping_phase, snr_threshold,
                          sv_noise_out, sv_corrected_out, minmax_out, (hipStream_t)stream);
   epa::set_error("epa_noise_apply: bad dtype %d", dtype);
+  return EPA_EINVAL;
+}
+
+extern "C" int epa_noise_apply_rows(const void* sv, const double* coef, const float* mask_raw, const double* alpha2,
+                                    const double* noise, int C, int P, int S, int ping_num, int ping_phase,
+                                    double snr_threshold, void* sv_noise_out, void* sv_corrected_out,
+                                    double* minmax_out, int dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(sv && coef && alpha2 && noise, "epa_noise_apply_rows: NULL array argument");
+  EPA_CHECK_ARG(sv_noise_out || sv_corrected_out, "epa_noise_apply_rows: no output requested");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && ping_num > 0, "epa_noise_apply_rows: sizes must be positive");
+  EPA_CHECK_ARG(ping_phase >= 0 && ping_phase < ping_num, "epa_noise_apply_rows: ping_phase %d not in [0, %d)",
+                ping_phase, ping_num);
+  if (dtype == EPA_F64)
+    return launch<double>(sv, nullptr, coef, mask_raw, alpha2, noise, C, P, S, ping_num, ping_phase, snr_threshold,
+                          sv_noise_out, sv_corrected_out, minmax_out, (hipStream_t)stream);
+  if (dtype == EPA_F32)
+    return launch<float>(sv, nullptr, coef, mask_raw, alpha2, noise, C, P, S, ping_num, ping_phase, snr_threshold,
+                         sv_noise_out, sv_corrected_out, minmax_out, (hipStream_t)stream);
+  epa::set_error("epa_noise_apply_rows: bad dtype %d", dtype);
   return EPA_EINVAL;
 }

@@ -300,17 +300,23 @@ def noise_finalize(ssum, cnt, noise_max=float("nan")):
     return out
 
 
-def noise_apply(sv, alpha2, noise, ping_num, snr_threshold, *, range=None, coef=None,
+def noise_apply(sv, alpha2, noise, ping_num, snr_threshold, *, range=None, coef=None, mask_raw=None,
                 want_noise=True, want_corrected=True, want_minmax=False, ping_phase=0):
-    """K7 -> (Sv_noise, Sv_corrected[, [min, max of Sv_noise, min, max of Sv_corrected]])."""
+    """K7 -> (Sv_noise, Sv_corrected[, [min, max of Sv_noise, min, max of Sv_corrected]]).  ``coef`` + ``mask_raw``
+    (the f32 power samples) in place of ``range``: the echo_range array evaluated in the kernel, NaN where the raw
+    sample is."""
     C, P, S = sv.shape
     if range is not None and range.dtype != sv.dtype:
         range = range.to(sv.dtype)
     sn = torch.empty_like(sv) if want_noise else None
     sc = torch.empty_like(sv) if want_corrected else None
     mm = torch.empty(4, dtype=torch.float64, device=sv.device) if want_minmax else None
-    call("epa_noise_apply", _p(sv), _p(range), _p(coef), _p(alpha2), _p(noise), C, P, S, int(ping_num),
-         int(ping_phase), float(snr_threshold), _p(sn), _p(sc), _p(mm), _DT[sv.dtype], _stream())
+    if range is None and mask_raw is not None:
+        call("epa_noise_apply_rows", _p(sv), _p(coef), _p(mask_raw), _p(alpha2), _p(noise), C, P, S, int(ping_num),
+             int(ping_phase), float(snr_threshold), _p(sn), _p(sc), _p(mm), _DT[sv.dtype], _stream())
+    else:
+        call("epa_noise_apply", _p(sv), _p(range), _p(coef), _p(alpha2), _p(noise), C, P, S, int(ping_num),
+             int(ping_phase), float(snr_threshold), _p(sn), _p(sc), _p(mm), _DT[sv.dtype], _stream())
     return (sn, sc, mm.cpu().tolist()) if want_minmax else (sn, sc)
 
 

@@ -79,14 +79,23 @@ class LazyDeviceArray(DeviceArray):
     (``range = fl(fl(s * ra) * rb) + r0``): kernels that accept those rows in place of the array (``compute_MVBS``)
     never need it."""
 
-    __slots__ = ("_make", "_shape", "_tdtype", "_device", "_tensor", "_rows")
+    __slots__ = ("_make", "_shape", "_tdtype", "_device", "_tensor", "_rows", "_mask")
 
-    def __init__(self, shape, dtype, device, make, stats=None, rows=None):
+    def __init__(self, shape, dtype, device, make, stats=None, rows=None, nan_where=None):
         self._make, self._shape, self._tdtype, self._device = make, tuple(int(n) for n in shape), dtype, device
         self._tensor = None
         self._host = None
         self._stats = (stats, 0) if stats is not None else None
         self._rows = rows
+        # the array is NaN exactly where this device tensor of the same shape is (the raw power samples): kernels that
+        # need the NaN pattern as well as the values read it next to the rows
+        self._mask = (nan_where, nan_where._version) if nan_where is not None else None
+
+    def nan_source(self):
+        """The tensor whose NaNs are the array's NaNs, if there is one and nothing has written to it since."""
+        if self._mask is None or self._mask[0]._version != self._mask[1]:
+            return None
+        return self._mask[0]
 
     @property
     def materialized(self):

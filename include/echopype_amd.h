@@ -265,6 +265,14 @@ int epa_noise_apply(const void* sv, const void* range, const double* coef, const
                     const double* noise, int C, int P, int S, int ping_num, int ping_phase, double snr_threshold,
                     void* sv_noise_out, void* sv_corrected_out, double* minmax_out, int dtype,
                     epa_stream_t stream);
+/* The same on an Sv whose echo_range was left out of the sample pass (epa_sv_power_stats with range_out = NULL): the
+ * range is evaluated from the power-sample coefficient rows and -- mask_raw, float [C*P*S], optional -- set to NaN
+ * where the raw sample is NaN, as the echo_range array would be (range.py:143-148; Sv_noise is NaN there, api.py:425-430).
+ * 4 B/sample of raw instead of 8 (or 4) of echo_range, and the array is never written. */
+int epa_noise_apply_rows(const void* sv, const double* coef, const float* mask_raw, const double* alpha2,
+                         const double* noise, int C, int P, int S, int ping_num, int ping_phase,
+                         double snr_threshold, void* sv_noise_out, void* sv_corrected_out, double* minmax_out,
+                         int dtype, epa_stream_t stream);
 
 /* ---- K3+K4: EK80 complex samples (CW complex and BB pulse compression) ---------------------------------------------
  * Replaces calibrate/ek80_complex.py:285-369 (compress_pulse: matched filter with the transmit

@@ -680,8 +680,8 @@ def test_compute_MVBS_bins_a_lazy_echo_range_through_its_coefficient_rows(dtype,
 @pytest.mark.gpu
 def test_lazy_echo_range_edge_cases():
     """An odd number of samples per ping (K1's one-sample-per-lane path) keeps the eager array; backscatter modified
-    in place between compute_Sv and the first read of a lazy echo_range raises instead of returning a wrong mask; the
-    steps after compute_Sv that read the array (remove_background_noise) find the same values as before."""
+    in place between compute_Sv and the first read of a lazy echo_range raises instead of returning a wrong mask;
+    remove_background_noise on the lazy dataset leaves it lazy and returns what it returns on the array."""
     import torch
     import echopype_amd as ep
     from echopype_amd.xr_lite import LazyDeviceArray
@@ -696,14 +696,24 @@ def test_lazy_echo_range_edge_cases():
     ed["Sonar/Beam_group1"]["backscatter_r"].data.tensor[0, 0, 0] = 1.0
     with pytest.raises(RuntimeError, match="modified in place"):
         ds["echo_range"].values
-    ed, _ = _lazy_case(ep)
-    ds = ep.calibrate.compute_Sv(ed)
-    out = ep.clean.remove_background_noise(ds, 20, 50)
-    assert ds["echo_range"].data.materialized
-    ds2 = ep.calibrate.compute_Sv(ed)
-    ds2["echo_range"].values
-    out2 = ep.clean.remove_background_noise(ds2, 20, 50)
-    np.testing.assert_array_equal(out["Sv_corrected"].values, out2["Sv_corrected"].values)
+    for dtype in ("float64", "float32"):
+        # remove_background_noise / estimate_background_noise on the lazy dataset: coefficient rows + the NaN pattern of
+        # the raw samples instead of the array (never written) == the same calls on the array
+        ed, _ = _lazy_case(ep)
+        ed["Sonar/Beam_group1"]["backscatter_r"].values[2, 17, :] = np.nan       # a dropped ping: NaN from sample 0 on
+        ds = ep.calibrate.compute_Sv(ed, dtype=dtype)
+        est = ep.clean.estimate_background_noise(ds, 20, 50)
+        out = ep.clean.remove_background_noise(ds, 20, 50)
+        assert not ds["echo_range"].data.materialized
+        ds2 = ep.calibrate.compute_Sv(ed, dtype=dtype)
+        ds2["echo_range"] = ep.xr_lite.DataArray(ep.DeviceArray(ds2["echo_range"].data.tensor), ds2["echo_range"].dims)
+        est2 = ep.clean.estimate_background_noise(ds2, 20, 50)
+        out2 = ep.clean.remove_background_noise(ds2, 20, 50)
+        for a, b in ((est, est2), (out["Sv_noise"], out2["Sv_noise"]), (out["Sv_corrected"], out2["Sv_corrected"])):
+            np.testing.assert_array_equal(a.values, b.values)
+        sn = out["Sv_noise"].values
+        assert np.isnan(sn[2, 17]).all() and np.isnan(sn[1, 5, -60:]).all() and np.isfinite(sn[0, 0, :3]).all()
+        assert np.isnan(out["Sv"].values[0, 0, :2]).all()   # (R' <= 0: Sv is NaN there, echo_range and Sv_noise are not)
 
 
 @pytest.mark.gpu
