@@ -152,6 +152,11 @@ class CalibrateBase(abc.ABC):
             return ops.sv_power(raw, coef, cal_type=cal_type, flags=flags, dtype=self.dtype, want_range_stats=True)
         out_t, _, stats = ops.sv_power(raw, coef, cal_type=cal_type, flags=flags, dtype=self.dtype, want_range=False,
                                        want_range_stats=True)
+        return out_t, self._lazy_power_range(raw, coef, flags, stats), stats
+
+    def _lazy_power_range(self, raw, coef, flags, stats=None):
+        """echo_range of power samples as a LazyDeviceArray: coefficient rows + the raw samples' NaN pattern; written by
+        epa_range_power on first read."""
         mask_flag = flags & _lib.FLAG_MASK_RANGE
         version, dtype = raw._version, self.dtype
 
@@ -161,5 +166,5 @@ class CalibrateBase(abc.ABC):
                                    "modified in place since: its NaN mask can no longer be reproduced")
             return ops.range_power(raw, coef, flags=mask_flag, dtype=dtype)
 
-        return out_t, LazyDeviceArray((C, P, S), dtype, raw.device, make, stats=stats, rows=coef,
-                                      nan_where=raw if mask_flag else None), stats
+        return LazyDeviceArray(tuple(raw.shape), dtype, raw.device, make, stats=stats, rows=coef,
+                               nan_where=raw if mask_flag else None)

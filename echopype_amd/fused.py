@@ -2,9 +2,9 @@
 12 + 16 for the two separate calls) -- the path BASELINE.json's metric is quoted on.
 
 ``compute_Sv_MVBS`` takes the union of the two reference signatures (calibrate/api.py:249-345 and
-commongrid/api.py:30-191) and returns ``(ds_Sv, ds_MVBS)`` exactly as the two calls would, except
-that ``ds_Sv`` carries no materialised ``echo_range`` (pass ``materialize_echo_range=True`` to get
-it: the function then simply runs the two calls).  The fused kernel serves power-sample sonars
+commongrid/api.py:30-191) and returns ``(ds_Sv, ds_MVBS)`` exactly as the two calls would;
+``ds_Sv["echo_range"]`` is lazy (an ``xr_lite.LazyDeviceArray``: written by ``epa_range_power`` when somebody
+reads it; ``materialize_echo_range=True`` runs the two calls instead).  The fused kernel serves power-sample sonars
 (EK60, EK80 CW power, AZFP) with the default binning flags; everything else falls back to the two
 calls as well -- same results either way.
 """
@@ -108,17 +108,16 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
     dims = ("channel", "ping_time", "range_sample")
     ds_Sv = Dataset(coords={k: cal.beam.coords[k] for k in dims})
     ds_Sv["Sv"] = DataArray(DeviceArray(res["Sv"]), dims)
-    # echo_range is not materialised; its separable form travels instead
+    # echo_range is not written: the variable is lazy (coefficient rows + the raw samples' NaN pattern; epa_range_power
+    # on first read), as after compute_Sv
     ds_Sv.attrs["echo_range_form"] = "echo_range[c,p,s] = s * sample_interval[c,p] * sound_speed[c,p] / 2 (NaN where Sv input was NaN)"
     ds_Sv["sample_interval"] = cal.beam["sample_interval"]
     if tau_eff is not None:
         ds_Sv["tau_effective"] = DataArray(np.asarray(tau_eff), ("channel",))
     ds_Sv["frequency_nominal"] = cal.beam["frequency_nominal"]
     ds_Sv = cal._add_params_to_output(ds_Sv)
-    # placeholder so that the shared finaliser can set the attrs it owns
-    ds_Sv["echo_range"] = DataArray(np.float64(np.nan), ())
+    ds_Sv["echo_range"] = DataArray(cal._lazy_power_range(raw, coef, flags), dims)
     ds_Sv = _finalize_cal_ds(ds_Sv, "Sv", echodata, waveform_mode, encode_mode)
-    ds_Sv.data_vars.pop("echo_range")
     ds_MVBS = _assemble_mvbs(ds_Sv, mvbs_t, "channel", ping_time, e0, dt, n_t, r_edges, "echo_range", range_bin_m,
                              ping_time_bin, "left")
     return ds_Sv, ds_MVBS
@@ -139,7 +138,7 @@ def compute_Sv_clean_MVBS(echodata, ping_num, range_sample_num, *, background_no
 
     24-40 B/sample in fp64 instead of 84.  Returns ``(ds_Sv, ds_MVBS)``: ``ds_Sv`` as
     ``remove_background_noise(compute_Sv(echodata), ...)`` would leave it (``Sv``, ``Sv_corrected``, ``Sv_noise``
-    unless ``keep_Sv_noise=False``; ``echo_range`` only with ``materialize_echo_range=True``), ``ds_MVBS`` as
+    unless ``keep_Sv_noise=False``; ``echo_range`` lazy unless ``materialize_echo_range=True``), ``ds_MVBS`` as
     ``compute_MVBS`` of that dataset with ``Sv := Sv_corrected``.  Served for power-sample EK data with sorted
     pings; anything else runs the three separate calls -- same results either way."""
     cal_kw = dict(env_params=env_params, cal_params=cal_params, ecs_file=ecs_file, waveform_mode=waveform_mode,
@@ -208,8 +207,8 @@ def compute_Sv_clean_MVBS(echodata, ping_num, range_sample_num, *, background_no
     ds_Sv = Dataset(coords={k: cal.beam.coords[k] for k in dims})
     ds_Sv["Sv"] = DataArray(DeviceArray(sv_t), dims)
     have_range = materialize_echo_range
-    ds_Sv["echo_range"] = DataArray(DeviceArray(res["echo_range"]), dims) if have_range else DataArray(
-        np.float64(np.nan), ())
+    ds_Sv["echo_range"] = DataArray(DeviceArray(res["echo_range"]) if have_range else
+                                    cal._lazy_power_range(raw, coef, flags), dims)
     if not have_range:
         ds_Sv.attrs["echo_range_form"] = ("echo_range[c,p,s] = s * sample_interval[c,p] * sound_speed[c,p] / 2 "
                                           "(NaN where Sv input was NaN)")
@@ -219,8 +218,6 @@ def compute_Sv_clean_MVBS(echodata, ping_num, range_sample_num, *, background_no
     ds_Sv["frequency_nominal"] = cal.beam["frequency_nominal"]
     ds_Sv = cal._add_params_to_output(ds_Sv)
     ds_Sv = _finalize_cal_ds(ds_Sv, "Sv", echodata, waveform_mode, encode_mode)
-    if not have_range:
-        ds_Sv.data_vars.pop("echo_range")
     mm = res["minmax"]  # actual_range of both outputs comes out of the kernel: no extra sweep
     outs = [("Sv_corrected", res["Sv_corrected"], "corrected", mm[2:4])]
     if keep_Sv_noise:
