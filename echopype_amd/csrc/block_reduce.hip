@@ -508,6 +508,10 @@ int epa_fused_fast_path(const void* raw, int raw_is_i16, const int32_t* n_valid,
                         hipStream_t st);
 
 // chain_fast.hip
+int epa_mvbs_rows_fast_path(const void* sv, const double* coef, int C, int P, int S, const int32_t* bin_start,
+                            int n_tbins, double range_bin, int n_rbins, int as_stored, double fill_value,
+                            void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype, size_t lds_bytes,
+                            unsigned cnt_off, hipStream_t st);
 int epa_chain_fast_pass1(const float* raw, const double* coef, const double* alpha2, int C, int P, int S,
                          double nspread, int ping_num, int rsn, double noise_max, void* sv_out,
                          double* noise_out, unsigned long long* rmax_key, int dtype, hipStream_t st);
@@ -611,6 +615,12 @@ int run_mvbs(ReduceArgs& a, hipStream_t st) {
                                 a.nspread, a.noise_ping_num, a.snr, a.bin_start, a.n_tbins, a.range_bin,
                                 a.n_rbins, a.fill_value, a.sv_noise_out, a.sv_out, a.out, a.sum_out, a.cnt_out,
                                 sizeof(T) == 8 ? EPA_F64 : EPA_F32, pl.tab_off, pl.cnt_off, a.mm_keys, st);
+  if (SRC == SRC_SV && !a.range && a.coef && !two_stage && pl.vec == 4 && !a.ping_perm &&
+      (a.bin_flags & ~EPA_BIN_RANGE_AS_STORED) == EPA_BIN_SKIPNA && !getenv("EPA_NO_FAST_PATH"))
+    return epa_mvbs_rows_fast_path(a.sv, reinterpret_cast<const double*>(a.coef), a.C, a.P, a.S, a.bin_start, a.n_tbins,
+                                   a.range_bin, a.n_rbins, (a.bin_flags & EPA_BIN_RANGE_AS_STORED) ? 1 : 0,
+                                   a.fill_value, a.out, a.sum_out, a.cnt_out, sizeof(T) == 8 ? EPA_F64 : EPA_F32,
+                                   pl.tab_off, pl.cnt_off, st);
   if (a.raw_i16) {
     epa::set_error("epa_sv_mvbs_fused_i16: int16 ingest is served by the default configuration only "
                    "(guard + masked range, skipna, left-closed bins, sorted pings, S %% 4 == 0, no "

@@ -342,7 +342,166 @@ __global__ __launch_bounds__(epa::kBlock) void selftest_log_inl_kernel(const dou
     out[i] = epa::fast_log10_inl<false>(x[i], mt.log_tab);
 }
 
+// ---- the same reduction on an EXISTING Sv whose echo_range is given by the coefficient rows ------------------------------
+// compute_MVBS(ds_Sv) after compute_Sv left echo_range lazy (epa_mvbs with coef, no range array): Sv is read (8 or 4
+// B/sample, nothing written but the MVBS), the range of a sample is evaluated as in the fused kernel and -- AS_STORED --
+// rounded to T first, i.e. binned exactly as the echo_range array would be.  Same lane map, same software prefetch, same
+// lane-private accumulation over the pings of a time bin; a NaN Sv is skipped (skipna), a NaN coefficient row bins
+// nothing.
+template <typename T>
+struct SvColumn {
+  double sra, blo, bhi;
+  T acc_sum;
+  int acc_rb;
+  uint32_t acc_cnt;
+  __device__ __forceinline__ void init() { sra = 0.0; blo = 1.0; bhi = 0.0; acc_sum = (T)0; acc_rb = -1; acc_cnt = 0u; }
+  __device__ __forceinline__ void flush(T* lsum, uint32_t* lcnt) {
+    if (acc_rb >= 0 && acc_cnt > 0u) {
+      lds_add(lsum + acc_rb, acc_sum);
+      atomicAdd(lcnt + acc_rb, acc_cnt);
+    }
+  }
+};
+
+template <typename T, bool AS_STORED>
+__device__ __forceinline__ void bin_sv_sample(SvColumn<T>& c, T sv, const epa::CoefRow& r, double bin, double inv_bin,
+                                              int n_rbins, const double* tab, T* lsum, uint32_t* lcnt) {
+  const double x0 = c.sra * r.rb + r.r0;
+  const double x = AS_STORED ? (double)(T)x0 : x0;
+  const T v = epa::lin_from_db(sv, tab);
+  const bool same = (x >= c.blo) & (x < c.bhi);
+  if (!same) {
+    const int rb = (x == x) ? epa::range_bin_index(x, bin, inv_bin, n_rbins, false) : -1;
+    if (rb != c.acc_rb) {
+      c.flush(lsum, lcnt);
+      c.acc_rb = rb;
+      c.acc_sum = (T)0;
+      c.acc_cnt = 0u;
+    }
+    c.blo = rb >= 0 ? (double)rb * bin : 1.0;
+    c.bhi = rb >= 0 ? (double)(rb + 1) * bin : 0.0;
+  }
+  const bool take = (c.acc_rb >= 0) & (v == v);
+  c.acc_sum += take ? v : (T)0;
+  c.acc_cnt += take ? 1u : 0u;
+}
+
+template <typename T, bool AS_STORED>
+__global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void mvbs_of_sv_rows_kernel(
+    const T* __restrict__ sv, const epa::CoefRow* __restrict__ coef, const int32_t* __restrict__ bin_start,
+    T* __restrict__ mvbs_out, T* __restrict__ sum_out, uint32_t* __restrict__ cnt_out, Args a) {
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* lsum = reinterpret_cast<T*>(smem);
+  uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + a.cnt_off);
+  const epa::MathTabs mt = epa::build_math_tabs(smem + a.tab_off);  // synchronised below
+  const double* tab = mt.exp2_tab;
+  const int c = blockIdx.y, tb = a.xcd_map ? epa::xcd_contiguous(blockIdx.x, a.n_tbins) : (int)blockIdx.x;
+  const int S = a.S, n_rbins = a.n_rbins;
+  for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
+    lsum[i] = (T)0;
+    lcnt[i] = 0u;
+  }
+  __syncthreads();
+  const double bin = a.range_bin, inv_bin = a.inv_range_bin;
+  const epa::CoefRow* __restrict__ rowp0 = coef + (size_t)c * a.P;
+  const T* __restrict__ sv_c = sv + (size_t)c * a.P * S;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int pb = bin_start[tb], pe = bin_start[tb + 1];
+  for (int chunk0 = 0; chunk0 < S; chunk0 += kChunk) {
+    const int sA = chunk0 + wave * 256 + 2 * lane;  // first sample of pair A
+    const int sB = sA + 128;                        // first sample of pair B
+    if (sA >= S) continue;
+    const bool hasB = sB < S;
+    SvColumn<T> col[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) col[j].init();
+    double racur = __builtin_nan("");
+    // the samples and the coefficient row of ping p + 1 are requested before ping p is processed
+    T2 nA = {(T)0, (T)0}, nB = {(T)0, (T)0};
+    epa::CoefRow nxtR = rowp0[pb < pe ? pb : 0];
+    if (pb < pe) {
+      nA = *reinterpret_cast<const T2*>(sv_c + (size_t)pb * S + sA);
+      if (hasB) nB = *reinterpret_cast<const T2*>(sv_c + (size_t)pb * S + sB);
+    }
+    for (int p = pb; p < pe; ++p) {
+      const epa::CoefRow r = nxtR;
+      const T2 inA = nA, inB = nB;
+      if (p + 1 < pe) {
+        nxtR = rowp0[p + 1];
+        const T* nx = sv_c + (size_t)(p + 1) * S;
+        nA = *reinterpret_cast<const T2*>(nx + sA);
+        if (hasB) nB = *reinterpret_cast<const T2*>(nx + sB);
+      }
+      if (!(r.ra == racur)) {  // uniform; once per column for a file with a constant sample_interval
+        racur = r.ra;
+        for (int j = 0; j < VEC; ++j) col[j].sra = (double)((j < 2 ? sA : sB) + (j & 1)) * r.ra;
+      }
+      bin_sv_sample<T, AS_STORED>(col[0], inA.x, r, bin, inv_bin, n_rbins, tab, lsum, lcnt);
+      bin_sv_sample<T, AS_STORED>(col[1], inA.y, r, bin, inv_bin, n_rbins, tab, lsum, lcnt);
+      if (hasB) {
+        bin_sv_sample<T, AS_STORED>(col[2], inB.x, r, bin, inv_bin, n_rbins, tab, lsum, lcnt);
+        bin_sv_sample<T, AS_STORED>(col[3], inB.y, r, bin, inv_bin, n_rbins, tab, lsum, lcnt);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) col[j].flush(lsum, lcnt);
+  }
+  __syncthreads();
+  const size_t cell0 = ((size_t)c * a.n_tbins + tb) * n_rbins;
+  T* out = mvbs_out + cell0;
+  T* gsum = sum_out ? sum_out + cell0 : nullptr;
+  uint32_t* gcnt = cnt_out ? cnt_out + cell0 : nullptr;
+  for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
+    const uint32_t n = lcnt[i];
+    const T s = lsum[i];
+    out[i] = n > 0u ? (T)10 * epa::M<T>::log10(s / (T)n) : (T)a.fill_value;
+    if (gsum) gsum[i] = s;
+    if (gcnt) gcnt[i] = n;
+  }
+}
+
+template <typename T>
+int launch_sv_rows(Args& a, const void* sv, const double* coef, const int32_t* bin_start, void* mvbs_out, void* sum_out,
+                   uint32_t* cnt_out, int C, size_t lds_bytes, bool as_stored, hipStream_t st) {
+  const dim3 grid((unsigned)a.n_tbins, (unsigned)C);
+  a.tab_off = (unsigned)((lds_bytes + 15) & ~(size_t)15);
+  lds_bytes = a.tab_off + epa::kMathTabBytes;
+  a.xcd_map = epa::xcd_map_enabled() ? 1 : 0;
+#define EPA_SR(AS)                                                                                       \
+  do {                                                                                                   \
+    auto kern = mvbs_of_sv_rows_kernel<T, AS>;                                                           \
+    if (lds_bytes > 64 * 1024)                                                                           \
+      EPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                             \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));    \
+    hipLaunchKernelGGL(kern, grid, dim3(epa::kBlock), lds_bytes, st, (const T*)sv,                       \
+                       reinterpret_cast<const epa::CoefRow*>(coef), bin_start, (T*)mvbs_out, (T*)sum_out, \
+                       cnt_out, a);                                                                      \
+  } while (0)
+  if (as_stored) EPA_SR(true); else EPA_SR(false);
+#undef EPA_SR
+  return epa::check_launch("mvbs_of_sv_rows_kernel");
+}
+
 }  // namespace epa_fused
+
+// Called by epa_mvbs (block_reduce.hip): Sv in, range from the coefficient rows, default binning flags.
+int epa_mvbs_rows_fast_path(const void* sv, const double* coef, int C, int P, int S, const int32_t* bin_start,
+                            int n_tbins, double range_bin, int n_rbins, int as_stored, double fill_value,
+                            void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype, size_t lds_bytes,
+                            unsigned cnt_off, hipStream_t st) {
+  epa_fused::Args a{};
+  a.P = P; a.S = S; a.n_tbins = n_tbins; a.n_rbins = n_rbins;
+  a.range_bin = range_bin; a.inv_range_bin = 1.0 / range_bin;
+  a.fill_value = fill_value;
+  a.skipna = 1;
+  a.cnt_off = cnt_off;
+  if (dtype == EPA_F64)
+    return epa_fused::launch_sv_rows<double>(a, sv, coef, bin_start, mvbs_out, sum_out, cnt_out, C, lds_bytes,
+                                             as_stored != 0, st);
+  return epa_fused::launch_sv_rows<float>(a, sv, coef, bin_start, mvbs_out, sum_out, cnt_out, C, lds_bytes,
+                                          as_stored != 0, st);
+}
 
 extern "C" int epa_selftest_lin_from_db(const double* u, double* out, size_t n, epa_stream_t stream) {
   EPA_CHECK_ARG(u && out, "epa_selftest_lin_from_db: NULL array argument");

@@ -725,3 +725,40 @@ def test_sv_complex_matches_reference_method_goldens(env, tag, wf, method):
             strong = ok & (exp > peak - 60)
             assert np.abs(got[strong] - exp[strong]).max() < 2e-4
             assert np.abs(got[ok] - exp[ok]).max() < 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("S", [1000, 2052, 260])
+def test_mvbs_of_sv_through_coefficient_rows_fast_kernel(env, dtype, S):
+    """epa_mvbs with coefficient rows in place of the range array (compute_MVBS after a lazy echo_range): the
+    specialised kernel == the generic reduction (EPA_NO_FAST_PATH) == the reduction on the echo_range array K1 writes
+    (EPA_BIN_RANGE_AS_STORED), partial sums and counts included; NaN Sv skipped, pings before the first edge and empty
+    time bins, range bins finer than a sample step."""
+    import os
+    torch, ops, synth = env
+    d = synth.ek60_numpy(3, 157, S, ss_every=5)
+    d["backscatter_r"][1, 40:44] = np.nan
+    cf = _coef_ek60(torch, ops, d, "Sv")
+    dt = getattr(torch, dtype)
+    sv, rng = ops.sv_power(_dev(torch, d["backscatter_r"]), cf, dtype=dt)
+    ns = torch.from_numpy(d["ping_time"].astype("datetime64[ns]").astype(np.int64)).cuda()
+    e0 = int(ns[7])                         # the first 7 pings lie before the first edge
+    n_t = 12
+    dtn = (int(ns[-1]) - e0) // 9 + 1       # the last three time bins are empty
+    bs = ops.time_bin_offsets(ns, e0, dtn, n_t)
+    for rbin in (1.0, 0.07):
+        n_r = int(float(np.nanmax(rng.cpu().numpy())) / rbin) + 1
+        fast = ops.mvbs(sv, bs, n_t, rbin, n_r, coef=cf, coef_as_stored=True, want_partials=True)
+        os.environ["EPA_NO_FAST_PATH"] = "1"
+        try:
+            slow = ops.mvbs(sv, bs, n_t, rbin, n_r, coef=cf, coef_as_stored=True, want_partials=True)
+        finally:
+            del os.environ["EPA_NO_FAST_PATH"]
+        arr = ops.mvbs(sv, bs, n_t, rbin, n_r, range=rng, want_partials=True)
+        for other in (slow, arr):
+            np.testing.assert_array_equal(fast["cnt"].cpu().numpy(), other["cnt"].cpu().numpy())
+            a, b = fast["MVBS"].cpu().numpy(), other["MVBS"].cpu().numpy()
+            np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+            np.testing.assert_allclose(a, b, rtol=1e-12 if dtype == "float64" else 1e-5, atol=1e-12 if dtype == "float64" else 1e-5)
+        assert np.isfinite(fast["MVBS"].cpu().numpy()).any() and (fast["cnt"].cpu().numpy()[:, -3:] == 0).all()
