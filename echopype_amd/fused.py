@@ -1,5 +1,6 @@
 """compute_Sv -> compute_MVBS in ONE pass over the raw power samples (12 B/sample in fp64 instead of
-12 + 16 for the two separate calls) -- the path BASELINE.json's metric is quoted on.
+12 + 8 for the two separate calls with echo_range left lazy, 20 + 16 with the array) -- the path BASELINE.json's
+metric is quoted on.
 
 ``compute_Sv_MVBS`` takes the union of the two reference signatures (calibrate/api.py:249-345 and
 commongrid/api.py:30-191) and returns ``(ds_Sv, ds_MVBS)`` exactly as the two calls would;
