@@ -16,7 +16,7 @@ import torch
 
 from .. import ops
 from ..commongrid.api import _dev, _full
-from ..xr_lite import DataArray, DeviceArray, from_xarray, xarray_io
+from ..xr_lite import DataArray, DeviceArray, LazyDeviceArray, from_xarray, xarray_io
 from .ek_depth_utils import (align_to_ping_time, ek_use_beam_angles, ek_use_platform_angles,
                              ek_use_platform_vertical_offsets)
 
@@ -71,10 +71,19 @@ def add_depth(ds, echodata=None, depth_offset=None, tilt=None, downward=True,
     P = len(ping_time)
     er = ds["echo_range"]
     order = tuple(ds["Sv"].dims) if "Sv" in ds else tuple(er.dims)
-    er_t = _dev(_full(er, ds, order))
-    if er_t.dtype not in (torch.float32, torch.float64):
-        er_t = er_t.double()
-    C = er_t.shape[0]
+    # a lazy echo_range straight from compute_Sv on power samples: its coefficient rows + the raw samples' NaN pattern go
+    # to the kernel, the array is not written for this
+    lazy = er.data if isinstance(er.data, LazyDeviceArray) and tuple(er.dims) == order else None
+    rows = lazy.coef_rows() if lazy is not None else None
+    raw = lazy.nan_source() if rows is not None else None
+    if raw is not None and raw.dtype == torch.float32 and tuple(raw.shape) == lazy.shape and raw.is_contiguous():
+        er_t, C = None, lazy.shape[0]
+    else:
+        rows = raw = None
+        er_t = _dev(_full(er, ds, order))
+        if er_t.dtype not in (torch.float32, torch.float64):
+            er_t = er_t.double()
+        C = er_t.shape[0]
 
     transducer_depth, td_dims = 0.0, ()
     if isinstance(depth_offset, Number):
@@ -106,13 +115,18 @@ def add_depth(ds, echodata=None, depth_offset=None, tilt=None, downward=True,
     mult = 1.0 if downward else -1.0
     scale = ops.to_device(np.ascontiguousarray(mult * _per_channel_ping(scaling, sc_dims, C, P, "echo range scaling")))
     offset = ops.to_device(np.ascontiguousarray(_per_channel_ping(transducer_depth, td_dims, C, P, "transducer depth")))
-    depth = ops.affine_rows(er_t, scale, offset)
+    # {nanmin, nanmax, NaN count} of depth come out of the same pass (what compute_MVBS(range_var="depth") asks next)
+    if er_t is None:
+        depth, stats = ops.depth_rows(scale, offset, coef=rows, mask_raw=raw, shape=lazy.shape,
+                                      dtype=torch.float64 if lazy.dtype == np.dtype("float64") else torch.float32)
+    else:
+        depth, stats = ops.depth_rows(scale, offset, range=er_t)
 
     used_offsets = use_platform_vertical_offsets and not _truthy(depth_offset)
     used_platform_angles = use_platform_angles and not _truthy(tilt)
     used_beam_angles = use_beam_angles and not _truthy(tilt)
     now = datetime.datetime.now(datetime.timezone.utc)
-    ds["depth"] = DataArray(DeviceArray(depth), order, attrs={
+    ds["depth"] = DataArray(DeviceArray(depth, stats=stats), order, attrs={
         "long_name": "Depth", "standard_name": "depth", "units": "m",
         "history": f"{now}. `depth` calculated using: Sv `echo_range`"
                    + (", Echodata `Platform` Vertical Offsets" if used_offsets else "")

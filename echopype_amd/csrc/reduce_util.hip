@@ -182,7 +182,86 @@ __global__ __launch_bounds__(epa::kBlock) void first_not_le_kernel(const T* __re
 }
 
 __global__ void set_u64_kernel(unsigned long long* p, unsigned long long v) { *p = v; }
+
+// depth = offset[c,p] + scale[c,p] * echo_range with echo_range read from the array or -- x == NULL -- evaluated from
+// the power-sample coefficient rows (NaN where the raw sample is, when mask_raw is given), and {min, max, NaN count}
+// of the depth written as a by-product: one partial per workgroup in `part` (deterministic, no atomics)
+template <typename T>
+__global__ __launch_bounds__(epa::kBlock) void depth_rows_kernel(const T* __restrict__ x,
+                                                                 const epa::CoefRow* __restrict__ coef,
+                                                                 const float* __restrict__ mask_raw,
+                                                                 const double* __restrict__ scale,
+                                                                 const double* __restrict__ offset, long long rows,
+                                                                 int S, T* __restrict__ out,
+                                                                 double* __restrict__ part) {
+  __shared__ double slo[4], shi[4], snan[4];
+  double lo = __builtin_inf(), hi = -__builtin_inf(), nn = 0.0;
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const T a = (T)scale[row], b = (T)offset[row];
+    const size_t base = (size_t)row * S;
+    T* orow = out + base;
+    epa::CoefRow cr{};
+    if (!x) cr = coef[row];
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+      T r;
+      if (x) {
+        r = x[base + s];
+      } else {
+        r = (T)epa::row_range(cr, s);
+        if (mask_raw && !(mask_raw[base + s] == mask_raw[base + s])) r = epa::M<T>::nan();
+      }
+      const T d = b + a * r;
+      orow[s] = d;
+      if (part) {
+        const double dd = (double)d;
+        lo = fmin(lo, dd);  // fmin / fmax ignore a NaN operand
+        hi = fmax(hi, dd);
+        nn += dd == dd ? 0.0 : 1.0;
+      }
+    }
+  }
+  if (part) {
+    wave_minmax<double>(lo, hi);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nn += __shfl_down(nn, o, 64);
+    if ((threadIdx.x & 63) == 0) {
+      slo[threadIdx.x >> 6] = lo;
+      shi[threadIdx.x >> 6] = hi;
+      snan[threadIdx.x >> 6] = nn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double* pp = part + 3 * (size_t)blockIdx.x;
+      pp[0] = fmin(fmin(slo[0], slo[1]), fmin(slo[2], slo[3]));
+      pp[1] = fmax(fmax(shi[0], shi[1]), fmax(shi[2], shi[3]));
+      pp[2] = (snan[0] + snan[1]) + (snan[2] + snan[3]);
+    }
+  }
+}
 }  // namespace
+
+extern "C" int epa_depth_rows(const void* range, const double* coef, const float* mask_raw, const double* scale,
+                              const double* offset, int C, int P, int S, void* out, int dtype, double* workspace,
+                              double* stats_out, epa_stream_t stream) {
+  EPA_CHECK_ARG((range || coef) && scale && offset && out, "epa_depth_rows: NULL array argument");
+  EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_depth_rows: sizes must be positive");
+  EPA_CHECK_ARG(!stats_out || workspace, "epa_depth_rows: the statistics need the workspace");
+  EPA_CHECK_ARG(dtype == EPA_F32 || dtype == EPA_F64, "epa_depth_rows: bad dtype %d", dtype);
+  const long long rows = (long long)C * P;
+  const int grid = (int)(rows < 16384 ? rows : 16384);
+  hipStream_t st = (hipStream_t)stream;
+  const epa::CoefRow* cf = reinterpret_cast<const epa::CoefRow*>(coef);
+  double* part = stats_out ? workspace : nullptr;
+  if (dtype == EPA_F64)
+    hipLaunchKernelGGL(depth_rows_kernel<double>, dim3(grid), dim3(epa::kBlock), 0, st, (const double*)range, cf,
+                       mask_raw, scale, offset, rows, S, (double*)out, part);
+  else
+    hipLaunchKernelGGL(depth_rows_kernel<float>, dim3(grid), dim3(epa::kBlock), 0, st, (const float*)range, cf,
+                       mask_raw, scale, offset, rows, S, (float*)out, part);
+  if (int rc = epa::check_launch("depth_rows_kernel")) return rc;
+  if (stats_out) return epa_minmax_final(workspace, grid, stats_out, st);
+  return EPA_OK;
+}
 
 extern "C" int epa_affine_rows(const void* x, const double* scale, const double* offset, int C, int P,
                                int S, void* out, int dtype, epa_stream_t stream) {

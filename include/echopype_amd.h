@@ -209,6 +209,15 @@ int epa_mvbs_finalize(const void* sum, const uint32_t* cnt, size_t n, double fil
  */
 int epa_affine_rows(const void* x, const double* scale, const double* offset, int C, int P, int S,
                     void* out, int dtype, epa_stream_t stream);
+/* The same with (i) echo_range either as the array `range` or -- range NULL -- evaluated from the power-sample
+ * coefficient rows `coef`, NaN where mask_raw (float [C*P*S], optional) is NaN: an echo_range left out of the sample
+ * pass (epa_sv_power_stats with range_out = NULL) never has to be written for add_depth; (ii) {nanmin, nanmax, NaN
+ * count} of the depth as a by-product (stats_out f64 [3], workspace f64 [EPA_DEPTH_ROWS_WS_DOUBLES]; both optional):
+ * what compute_MVBS(range_var="depth") asks of the variable next (commongrid/api.py:108-110). */
+#define EPA_DEPTH_ROWS_WS_DOUBLES (3 * 16384)
+int epa_depth_rows(const void* range, const double* coef, const float* mask_raw, const double* scale,
+                   const double* offset, int C, int P, int S, void* out, int dtype, double* workspace,
+                   double* stats_out, epa_stream_t stream);
 
 /* ---- NaN-skipping min/max of a device array ---------------------------------------------------------------
  * Replaces the reductions the reference forces with ds_Sv[range_var].max(skipna=True)

@@ -772,3 +772,34 @@ def test_ek80_bb_echo_range_lazy_and_mvbs_through_rows(ep, dtype):
     np.testing.assert_array_equal(np.isnan(dscw["Sv"].values), np.isnan(eg["out"].cpu().numpy()))
     np.testing.assert_allclose(dscw["Sv"].values, eg["out"].cpu().numpy(), rtol=1e-14 if dtype == "float64" else 1e-6)
     assert st == (np.nanmin(gr), np.nanmax(gr), int(np.isnan(gr).sum())) and st[2] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_add_depth_from_a_lazy_echo_range_and_its_statistics(dtype):
+    """add_depth on the Dataset straight from compute_Sv evaluates the coefficient rows (echo_range stays unwritten)
+    and gives bit-identical depth to add_depth on the array; the depth variable carries {nanmin, nanmax, NaN count},
+    so compute_MVBS(range_var="depth") does not sweep it again -- same MVBS either way."""
+    import echopype_amd as ep
+
+    ed, _ = _lazy_case(ep)
+    tilt = ep.xr_lite.DataArray(np.linspace(0.0, 20.0, 240), ("ping_time",),
+                                coords={"ping_time": ed["Sonar/Beam_group1"]["ping_time"].values})
+    ds = ep.calibrate.compute_Sv(ed, dtype=dtype)
+    out = ep.consolidate.add_depth(ds, depth_offset=4.5, tilt=tilt)
+    assert not ds["echo_range"].data.materialized
+    ds2 = ep.calibrate.compute_Sv(ed, dtype=dtype)
+    ds2["echo_range"] = ep.xr_lite.DataArray(ep.DeviceArray(ds2["echo_range"].data.tensor), ds2["echo_range"].dims)
+    out2 = ep.consolidate.add_depth(ds2, depth_offset=4.5, tilt=tilt)
+    got = out["depth"].values
+    np.testing.assert_array_equal(got, out2["depth"].values)
+    er = ds2["echo_range"].values
+    exp = 4.5 + np.cos(np.deg2rad(tilt.values))[None, :, None].astype(dtype) * er   # consolidate/api.py:226
+    np.testing.assert_allclose(got, exp, rtol=1e-14 if dtype == "float64" else 1e-6)
+    for o in (out, out2):
+        assert o["depth"].data.cached_stats() == (np.nanmin(got), np.nanmax(got), int(np.isnan(got).sum()))
+    a = ep.commongrid.compute_MVBS(out, range_var="depth", range_bin="2m", ping_time_bin="10s")
+    b = ep.commongrid.compute_MVBS(out2, range_var="depth", range_bin="2m", ping_time_bin="10s")
+    np.testing.assert_array_equal(np.isnan(a["Sv"].values), np.isnan(b["Sv"].values))
+    np.testing.assert_allclose(a["Sv"].values, b["Sv"].values, rtol=1e-12 if dtype == "float64" else 1e-5, atol=1e-12)
+    assert np.isfinite(a["Sv"].values).any()
