@@ -674,13 +674,13 @@ def test_compute_MVBS_bins_a_lazy_echo_range_through_its_coefficient_rows(dtype,
     b = ep.commongrid.compute_MVBS(ds2, range_bin="2m", ping_time_bin="10s", closed=closed)
     # (same bins, same members; the two kernel instantiations add a bin's members in different orders: last-bit noise)
     np.testing.assert_array_equal(np.isnan(a["Sv"].values), np.isnan(b["Sv"].values))
-    np.testing.assert_allclose(a["Sv"].values, b["Sv"].values, rtol=1e-12 if dtype == "float64" else 1e-5, atol=1e-12 if dtype == "float64" else 1e-5)
+    np.testing.assert_allclose(a["Sv"].values, b["Sv"].values, rtol=1e-12 if dtype == "float64" else 1e-5, atol=1e-12 if dtype == "float64" else 1e-4)
     np.testing.assert_array_equal(a["echo_range"].values, b["echo_range"].values)
     assert np.isfinite(a["Sv"].values).any()
     c = ep.commongrid.compute_MVBS(ds, range_bin="2m", ping_time_bin="10s", closed=closed, skipna=False)
     assert lazy.materialized
     d = ep.commongrid.compute_MVBS(ds2, range_bin="2m", ping_time_bin="10s", closed=closed, skipna=False)
-    np.testing.assert_allclose(c["Sv"].values, d["Sv"].values, rtol=1e-12 if dtype == "float64" else 1e-5, atol=1e-12 if dtype == "float64" else 1e-5)
+    np.testing.assert_allclose(c["Sv"].values, d["Sv"].values, rtol=1e-12 if dtype == "float64" else 1e-5, atol=1e-12 if dtype == "float64" else 1e-4)
 
 
 @pytest.mark.gpu
@@ -754,7 +754,7 @@ def test_ek80_bb_echo_range_lazy_and_mvbs_through_rows(ep, dtype):
     ds2["echo_range"] = ep.xr_lite.DataArray(ep.DeviceArray(ds2["echo_range"].data.tensor), ds2["echo_range"].dims)
     b = ep.commongrid.compute_MVBS(ds2, range_bin="0.5m", ping_time_bin="5s")
     np.testing.assert_array_equal(np.isnan(a["Sv"].values), np.isnan(b["Sv"].values))
-    np.testing.assert_allclose(a["Sv"].values, b["Sv"].values, rtol=1e-12 if dtype == "float64" else 1e-5, atol=1e-12 if dtype == "float64" else 1e-5)
+    np.testing.assert_allclose(a["Sv"].values, b["Sv"].values, rtol=1e-12 if dtype == "float64" else 1e-5, atol=1e-12 if dtype == "float64" else 1e-4)
     assert np.isfinite(a["Sv"].values).any()
     # CW complex samples: the streaming kernel leaves the statistics too (epa_sv_complex_cw_stats)
     dcw, filt = _ek80(ep, "CW", C=2, P=30, S=2100, mixed_nan=True)
@@ -801,5 +801,7 @@ def test_add_depth_from_a_lazy_echo_range_and_its_statistics(dtype):
     a = ep.commongrid.compute_MVBS(out, range_var="depth", range_bin="2m", ping_time_bin="10s")
     b = ep.commongrid.compute_MVBS(out2, range_var="depth", range_bin="2m", ping_time_bin="10s")
     np.testing.assert_array_equal(np.isnan(a["Sv"].values), np.isnan(b["Sv"].values))
-    np.testing.assert_allclose(a["Sv"].values, b["Sv"].values, rtol=1e-12 if dtype == "float64" else 1e-5, atol=1e-12)
+    # (the two runs add a bin's members in different orders -- LDS atomics: last-bit noise)
+    np.testing.assert_allclose(a["Sv"].values, b["Sv"].values, rtol=1e-12 if dtype == "float64" else 1e-5,
+                               atol=1e-12 if dtype == "float64" else 1e-4)
     assert np.isfinite(a["Sv"].values).any()

@@ -760,5 +760,5 @@ def test_mvbs_of_sv_through_coefficient_rows_fast_kernel(env, dtype, S):
             np.testing.assert_array_equal(fast["cnt"].cpu().numpy(), other["cnt"].cpu().numpy())
             a, b = fast["MVBS"].cpu().numpy(), other["MVBS"].cpu().numpy()
             np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
-            np.testing.assert_allclose(a, b, rtol=1e-12 if dtype == "float64" else 1e-5, atol=1e-12 if dtype == "float64" else 1e-5)
+            np.testing.assert_allclose(a, b, rtol=1e-12 if dtype == "float64" else 1e-5, atol=1e-12 if dtype == "float64" else 1e-4)
         assert np.isfinite(fast["MVBS"].cpu().numpy()).any() and (fast["cnt"].cpu().numpy()[:, -3:] == 0).all()
