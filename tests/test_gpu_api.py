@@ -715,8 +715,15 @@ def test_lazy_echo_range_edge_cases():
         ds2["echo_range"] = ep.xr_lite.DataArray(ep.DeviceArray(ds2["echo_range"].data.tensor), ds2["echo_range"].dims)
         est2 = ep.clean.estimate_background_noise(ds2, 20, 50)
         out2 = ep.clean.remove_background_noise(ds2, 20, 50)
-        for a, b in ((est, est2), (out["Sv_noise"], out2["Sv_noise"]), (out["Sv_corrected"], out2["Sv_corrected"])):
-            np.testing.assert_array_equal(a.values, b.values)
+        # (equal up to the last-bit noise of the estimate's LDS atomics, which moves whole ping blocks of Sv_noise)
+        ntol = dict(rtol=1e-13, atol=1e-12) if dtype == "float64" else dict(rtol=2e-6, atol=1e-4)
+        for a, b in ((est, est2), (out["Sv_noise"], out2["Sv_noise"])):
+            np.testing.assert_array_equal(np.isnan(a.values), np.isnan(b.values))
+            np.testing.assert_allclose(a.values, b.values, **ntol)
+        ca, cb = out["Sv_corrected"].values, out2["Sv_corrected"].values
+        both = np.isfinite(ca) & np.isfinite(cb)
+        assert (np.isnan(ca) != np.isnan(cb)).mean() < 2e-3
+        np.testing.assert_allclose(ca[both], cb[both], rtol=1e-9 if dtype == "float64" else 1e-3, atol=1e-9 if dtype == "float64" else 1e-4)
         sn = out["Sv_noise"].values
         assert np.isnan(sn[2, 17]).all() and np.isnan(sn[1, 5, -60:]).all() and np.isfinite(sn[0, 0, :3]).all()
         assert np.isnan(out["Sv"].values[0, 0, :2]).all()   # (R' <= 0: Sv is NaN there, echo_range and Sv_noise are not)

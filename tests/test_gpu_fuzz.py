@@ -180,3 +180,60 @@ def test_random_ping_times(ep, seed):
     np.testing.assert_array_equal(mv["ping_time"].values, t_left)
     np.testing.assert_array_equal(mv["echo_range"].values, r_left)
     close(mv["Sv"].values, exp, 1e-9, f"{tbin} closed={closed} skipna={skipna}")
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_lazy_echo_range_paths_against_the_array_paths(ep, seed):
+    """What the steps after compute_Sv make of a LAZY echo_range (coefficient rows, the raw samples' NaN pattern) against
+    the same steps on the written array, over random shapes / dtypes / flags: compute_MVBS (same bins and members: sums
+    agree to rounding), remove_background_noise (to the last-bit noise of the estimate's atomics), add_depth (bit-identical) and the variable itself when read."""
+    rng, C, P, S = _case(100 + seed)
+    S = max(S, 4)
+    dtype = str(rng.choice(["float64", "float32"]))
+    d = ep.synth.ek60_numpy(C, P, S, seed=seed, vary_tau=bool(rng.integers(0, 2)), ss_every=int(rng.choice([1, 3, 1000])))
+    raw = d["backscatter_r"]
+    raw[rng.random(raw.shape) < 0.05] = np.nan
+    if P > 2 and rng.random() < 0.5:
+        raw[:, int(rng.integers(0, P))] = np.nan
+    ed = ep.echodata.from_ek60_arrays(d)
+    closed = str(rng.choice(["left", "right"]))
+    rbin = str(rng.choice(["0.3m", "1m", "7.5m", "500m"]))
+    tbin = str(rng.choice(["1s", "7s", "20s", "3min"]))
+
+    def fresh(written):
+        ds = ep.calibrate.compute_Sv(ed, dtype=dtype)
+        if written:
+            ds["echo_range"] = ep.xr_lite.DataArray(ep.DeviceArray(ds["echo_range"].data.tensor), ds["echo_range"].dims,
+                                                    attrs=ds["echo_range"].attrs)
+        return ds
+
+    lazy, arr = fresh(False), fresh(True)
+    if not np.isfinite(arr["echo_range"].values).any():
+        return
+    tol = dict(rtol=1e-12, atol=1e-12) if dtype == "float64" else dict(rtol=1e-5, atol=1e-4)
+    a = ep.commongrid.compute_MVBS(lazy, range_bin=rbin, ping_time_bin=tbin, closed=closed)
+    b = ep.commongrid.compute_MVBS(arr, range_bin=rbin, ping_time_bin=tbin, closed=closed)
+    np.testing.assert_array_equal(np.isnan(a["Sv"].values), np.isnan(b["Sv"].values))
+    np.testing.assert_allclose(a["Sv"].values, b["Sv"].values, **tol)
+    np.testing.assert_array_equal(a["echo_range"].values, b["echo_range"].values)
+    pn, rsn = int(rng.choice([1, 5, 20, 300])), int(rng.choice([1, 4, 50, 5000]))
+    snr = str(rng.choice(["0.0dB", "3.0dB"]))
+    na = ep.clean.remove_background_noise(lazy, pn, rsn, SNR_threshold=snr)
+    nb = ep.clean.remove_background_noise(arr, pn, rsn, SNR_threshold=snr)
+    assert not getattr(lazy["echo_range"].data, "materialized", False)     # (odd S: K1 wrote the array, nothing is lazy)
+    # (the noise estimate sums through LDS atomics: two runs may differ in the last bit, and with them whole ping blocks
+    # of Sv_noise and the odd sample sitting exactly on the SNR threshold)
+    ntol = dict(rtol=1e-13, atol=1e-12) if dtype == "float64" else dict(rtol=2e-6, atol=1e-4)
+    np.testing.assert_array_equal(np.isnan(na["Sv_noise"].values), np.isnan(nb["Sv_noise"].values))
+    np.testing.assert_allclose(na["Sv_noise"].values, nb["Sv_noise"].values, **ntol)
+    ca, cb = na["Sv_corrected"].values, nb["Sv_corrected"].values
+    both = np.isfinite(ca) & np.isfinite(cb)
+    assert (np.isnan(ca) != np.isnan(cb)).mean() < 2e-3
+    np.testing.assert_allclose(ca[both], cb[both], rtol=1e-9 if dtype == "float64" else 1e-3, atol=1e-9 if dtype == "float64" else 1e-4)
+    off, tilt = float(rng.uniform(0, 9)), float(rng.uniform(0, 30))
+    da = ep.consolidate.add_depth(lazy, depth_offset=off, tilt=tilt)
+    db = ep.consolidate.add_depth(arr, depth_offset=off, tilt=tilt)
+    assert not getattr(lazy["echo_range"].data, "materialized", False)     # (odd S: K1 wrote the array, nothing is lazy)
+    np.testing.assert_array_equal(da["depth"].values, db["depth"].values)
+    assert da["depth"].data.cached_stats() == db["depth"].data.cached_stats()
+    np.testing.assert_array_equal(lazy["echo_range"].values, arr["echo_range"].values)
