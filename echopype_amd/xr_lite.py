@@ -77,7 +77,9 @@ class LazyDeviceArray(DeviceArray):
     count} by-product are known, the 8 B/sample array itself is produced by ``make()`` when somebody reads ``.tensor``
     / ``.values``.  ``rows`` = the per-(channel, ping) coefficient rows the array is an affine function of
     (``range = fl(fl(s * ra) * rb) + r0``): kernels that accept those rows in place of the array (``compute_MVBS``)
-    never need it."""
+    never need it.  The producer, the rows and the NaN source keep the raw samples and the coefficient rows alive for
+    as long as this object lives (the echodata normally does anyway): replace the variable by
+    ``DeviceArray(lazy.tensor)`` to cut that tie."""
 
     __slots__ = ("_make", "_shape", "_tdtype", "_device", "_tensor", "_rows", "_mask")
 
