@@ -118,7 +118,22 @@ def test_fullsize_fused_equals_unfused_and_counts_are_conserved(vol):
     # every sample with a valid Sv and an in-grid range is counted exactly once
     n_valid = sum(int((~torch.isnan(sv1[c]) & (rng1[c] < float(vol["n_r"]))).sum().item()) for c in range(C))
     assert int(vol["res"]["cnt"].to(torch.int64).sum().item()) == n_valid
-    del sv1, rng1, mv2
+    del mv2
+    # the route compute_Sv / compute_MVBS take when echo_range stays lazy, at full size: the statistics K1 leaves
+    # without writing the array, the array epa_range_power writes on demand, the reduction on the coefficient rows
+    cf = vol["coef"]()
+    sv2, none, stats = ops.sv_power(d["backscatter_r"], cf, want_range=False, want_range_stats=True)
+    assert none is None and all(bool(((sv2[c] == sv1[c]) | (torch.isnan(sv2[c]) & torch.isnan(sv1[c]))).all()) for c in range(C))
+    del sv2
+    lo, hi, nn = ops.nanminmax(rng1, with_nan_count=True)
+    assert stats.cpu().tolist() == [lo, hi, float(nn)]
+    rng2 = ops.range_power(d["backscatter_r"], cf)
+    assert all(bool(((rng2[c] == rng1[c]) | (torch.isnan(rng2[c]) & torch.isnan(rng1[c]))).all()) for c in range(C))
+    del rng2
+    mv3 = ops.mvbs(sv1, vol["bs"], vol["n_t"], 1.0, vol["n_r"], coef=cf, coef_as_stored=True, want_partials=True)
+    assert _nan_equal(torch, m1, mv3["MVBS"]) and _max_err(torch, m1, mv3["MVBS"], relative=True) < 1e-11
+    assert bool((vol["res"]["cnt"] == mv3["cnt"]).all())
+    del sv1, rng1, mv3
 
 
 def test_fullsize_gain_offset_is_a_pure_db_shift(vol):
