@@ -71,7 +71,7 @@ SIGNATURES = {
     "epa_timer_start": [_vp, _vp],
     "epa_timer_stop": [_vp, _vp],
     "epa_timer_elapsed_ms": [_vp, ctypes.POINTER(ctypes.c_float)],
-    "epa_power_coef_ek": [_i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp,
+    "epa_power_coef_ek": [_i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp,
                           _vp, _vp, _i, _i, _vp, _vp],
     "epa_pulse_table_lookup": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "epa_sv_power": [_vp, _vp, _i, _i, _i, _i, _u, _vp, _vp, _i, _vp],

@@ -167,14 +167,14 @@ class CalibrateEK(CalibrateBase):
         f64 = torch.float64
         tau_eff, _ = self._tau_effective(False) if cal_type == "Sv" else (np.ones(C), None)
         gpt = self._gpt_mask()
-        psi = np.asarray(self.cal_params["equivalent_beam_angle"].values, dtype=np.float64)
-        if psi.ndim > 1:
-            psi = psi.reshape(C, -1)
-            if not np.all((psi == psi[:, :1]) | np.isnan(psi)):
-                raise NotImplementedError("equivalent_beam_angle varying along ping_time is not supported for power "
-                                          "samples (the coefficient kernel takes one value per channel)")
-            psi = psi[:, 0]
         cpd = lambda v, name: self._cp_dev(v, C, P, name, f64)  # noqa: E731
+        # equivalent_beam_angle: per channel as in the files, or (channel, ping_time) -- the reference broadcasts any
+        # cal parameter of that shape into CSv (calibrate_ek.py:154-162); K0 takes either (EPA_PM_CHANNEL[_PING])
+        psi_da = self.cal_params["equivalent_beam_angle"]
+        if getattr(psi_da, "ndim", 0) > 1:
+            psi_t = cpd(psi_da, "equivalent_beam_angle")
+        else:
+            psi_t = self._dev(np.asarray(psi_da.values, dtype=np.float64).reshape(-1), f64)
         # gain / sa_correction straight from the Vendor_specific pulse-length tables: looked up per ping by the kernel
         g, sa = self.cal_params["gain_correction"], self.cal_params["sa_correction"]
         tables = (isinstance(g, PulseTableParam) and isinstance(sa, PulseTableParam) and not g.materialized
@@ -191,7 +191,7 @@ class CalibrateEK(CalibrateBase):
             cpd(self.beam["transmit_power"], "transmit_power"),
             cpd(self.env_params["sound_speed"], "sound_speed"),
             cpd(self.env_params["sound_absorption"], "sound_absorption"),
-            g_t, sa_t, self._dev(psi, f64), self._dev(np.asarray(self.beam["frequency_nominal"].values, float), f64),
+            g_t, sa_t, psi_t, self._dev(np.asarray(self.beam["frequency_nominal"].values, float), f64),
             self._dev(np.asarray(tau_eff, float), f64),
             sonar=self.sonar_type, cal_type=cal_type,
             gpt=self._dev(gpt.astype(np.uint8)) if self.sonar_type == "EK80" else None, **kw)

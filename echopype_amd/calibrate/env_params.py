@@ -154,6 +154,8 @@ def get_env_params_EK(sonar_type, beam, env, user_dict=None, freq=None):
         t1 = None
         for n in names:
             v = native.get(n)
+            if isinstance(v, DataArray) and "channel" in v.dims:
+                return None  # a per-channel parameter: the harmonised branch broadcasts it (bc) against (C, P)
             if isinstance(v, DataArray) and "time1" in v.dims and v.sizes["time1"] > 1:
                 if v.dims != ("time1",) or np.isnan(np.asarray(v.values, dtype=np.float64)).any():
                     return None
@@ -176,7 +178,7 @@ def get_env_params_EK(sonar_type, beam, env, user_dict=None, freq=None):
         if isinstance(v, DataArray) and v.dims == ("time1",) and v.sizes["time1"] > 1:
             return np.asarray(v.values, dtype=np.float64)[idx]
         h = out[name] if name in out else harmonize_env_param_time(v, beam["ping_time"])
-        return _val(h)
+        return bc(h)
 
     if out["sound_speed"] is None:
         if not tspa:

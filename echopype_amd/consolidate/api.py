@@ -44,7 +44,7 @@ def _per_channel_ping(values, dims, C, P, what):
     raise ValueError(f"{what} has unsupported dimensions {dims}")
 
 
-@xarray_io()
+@xarray_io(in_place=("depth",))  # the reference assigns ds["depth"] on the CALLER's dataset (consolidate/api.py:221-241)
 def add_depth(ds, echodata=None, depth_offset=None, tilt=None, downward=True,
               use_platform_vertical_offsets=False, use_platform_angles=False, use_beam_angles=False):
     """Add a ``depth`` variable to an Sv dataset (in place, like the reference) and return it."""

@@ -16,7 +16,7 @@ struct CoefArgs {
   int C, P, K;
   const double *si, *tau, *pt;
   const double *ss, *ab, *gain, *sa, *pl;
-  int ss_mode, ab_mode, gain_mode, sa_mode;
+  int ss_mode, ab_mode, gain_mode, sa_mode, psi_mode;
   const double *psi, *fnom, *taueff;
   const uint8_t* gpt;
   int sonar, cal_type;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(epa::kBlock) void power_coef_ek_kernel(CoefArgs a) 
   const double pi = 3.141592653589793;
   double A;
   if (a.cal_type == EPA_CAL_SV) {
-    const double CSv = 10 * log10(pt) + 2 * G + a.psi[c] +
+    const double CSv = 10 * log10(pt) + 2 * G + fetch(a.psi, a.psi_mode, c, idx) +
                        10 * log10(lambda * lambda * a.taueff[c] * cw / (32 * pi * pi));
     A = -CSv - 2 * sa;
   } else {
@@ -174,7 +174,7 @@ extern "C" int epa_power_coef_ek(int C, int P, const double* sample_interval,
                                  const double* sound_speed, int ss_mode, const double* absorption,
                                  int abs_mode, const double* gain, int gain_mode,
                                  const double* sa_correction, int sa_mode,
-                                 const double* pulse_length, int K, const double* psi,
+                                 const double* pulse_length, int K, const double* psi, int psi_mode,
                                  const double* f_nominal, const double* tau_eff, const uint8_t* gpt,
                                  int sonar, int cal_type, double* coef, epa_stream_t stream) {
   EPA_CHECK_ARG(C > 0 && P > 0, "epa_power_coef_ek: C=%d P=%d must be positive", C, P);
@@ -185,13 +185,14 @@ extern "C" int epa_power_coef_ek(int C, int P, const double* sample_interval,
                 "epa_power_coef_ek: bad sound_speed/absorption mode");
   EPA_CHECK_ARG(gain_mode >= 0 && gain_mode <= 3 && sa_mode >= 0 && sa_mode <= 3,
                 "epa_power_coef_ek: bad gain/sa mode");
+  EPA_CHECK_ARG(psi_mode >= 0 && psi_mode <= 2, "epa_power_coef_ek: bad equivalent_beam_angle mode");
   if (gain_mode == EPA_PM_PULSE_TABLE || sa_mode == EPA_PM_PULSE_TABLE)
     EPA_CHECK_ARG(pulse_length != nullptr && K > 0,
                   "epa_power_coef_ek: pulse-table mode needs pulse_length and K > 0");
   EPA_CHECK_ARG(sonar == EPA_SONAR_EK60 || sonar == EPA_SONAR_EK80, "epa_power_coef_ek: bad sonar");
   EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_power_coef_ek: bad cal_type");
   CoefArgs a{C, P, K, sample_interval, tau_nominal, transmit_power, sound_speed, absorption, gain,
-             sa_correction, pulse_length, ss_mode, abs_mode, gain_mode, sa_mode, psi, f_nominal,
+             sa_correction, pulse_length, ss_mode, abs_mode, gain_mode, sa_mode, psi_mode, psi, f_nominal,
              tau_eff, gpt, sonar, cal_type, coef};
   const long long n = (long long)C * P;
   const int grid = (int)((n + epa::kBlock - 1) / epa::kBlock);

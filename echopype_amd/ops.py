@@ -69,7 +69,7 @@ def _mode_of(t, C, P):
 def power_coef_ek(sample_interval, tau_nominal, transmit_power, sound_speed, absorption, gain, sa,
                   psi, f_nominal, tau_eff, *, sonar="EK60", cal_type="Sv", pulse_length=None,
                   gain_is_table=False, sa_is_table=False, gpt=None):
-    """K0 -> coef (C, P, NCOEF) f64.  All inputs f64 CUDA tensors."""
+    """K0 -> coef (C, P, NCOEF) f64.  All inputs f64 CUDA tensors; ``psi`` scalar, (C,) or (C, P)."""
     C, P = sample_interval.shape
     coef = torch.empty((C, P, _lib.NCOEF), dtype=torch.float64, device=sample_interval.device)
     K = 0 if pulse_length is None else pulse_length.shape[1]
@@ -77,7 +77,7 @@ def power_coef_ek(sample_interval, tau_nominal, transmit_power, sound_speed, abs
     smode = _lib.PM_PULSE_TABLE if sa_is_table else _mode_of(sa, C, P)
     call("epa_power_coef_ek", C, P, _p(sample_interval), _p(tau_nominal), _p(transmit_power),
          _p(sound_speed), _mode_of(sound_speed, C, P), _p(absorption), _mode_of(absorption, C, P),
-         _p(gain), gmode, _p(sa), smode, _p(pulse_length), K, _p(psi), _p(f_nominal), _p(tau_eff),
+         _p(gain), gmode, _p(sa), smode, _p(pulse_length), K, _p(psi), _mode_of(psi, C, P), _p(f_nominal), _p(tau_eff),
          _p(gpt), _lib.SONAR_EK60 if sonar in ("EK60", "ES70") else _lib.SONAR_EK80,
          _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, _p(coef), _stream())
     return coef

@@ -81,11 +81,12 @@ class LazyDeviceArray(DeviceArray):
     as long as this object lives (the echodata normally does anyway): replace the variable by
     ``DeviceArray(lazy.tensor)`` to cut that tie."""
 
-    __slots__ = ("_make", "_shape", "_tdtype", "_device", "_tensor", "_rows", "_mask")
+    __slots__ = ("_make", "_shape", "_tdtype", "_device", "_tensor", "_rows", "_mask", "_made_version")
 
     def __init__(self, shape, dtype, device, make, stats=None, rows=None, nan_where=None):
         self._make, self._shape, self._tdtype, self._device = make, tuple(int(n) for n in shape), dtype, device
         self._tensor = None
+        self._made_version = None  # tensor._version right after make(): any later in-place write voids rows and stats
         self._host = None
         self._stats = (stats, 0) if stats is not None else None
         self._rows = rows
@@ -108,13 +109,14 @@ class LazyDeviceArray(DeviceArray):
         if self._tensor is None:
             self._tensor = self._make()
             self._make = None
+            self._made_version = self._tensor._version
             if self._stats is not None:
                 self._stats = (self._stats[0], self._tensor._version)
         return self._tensor
 
     def coef_rows(self):
         """The coefficient rows, while the array still is the function of them it was created as."""
-        if self._tensor is not None and self._stats is not None and self._stats[1] != self._tensor._version:
+        if self._tensor is not None and self._made_version != self._tensor._version:
             return None
         return self._rows
 
@@ -447,12 +449,27 @@ def xarray_io(in_place=()):
     ``ds_Sv["Sv_noise"]`` / ``ds_Sv["Sv_corrected"]`` before it returns): they are written into the caller's xarray
     dataset too, and that dataset (with the updated attributes) is returned."""
     import functools
+    import inspect
 
     def deco(fn):
+        params = list(inspect.signature(fn).parameters)
+        first_name = params[0]
+        # other arguments that may be foreign containers too (add_depth(ds, echodata=ed), apply_mask(source_ds, mask))
+        ed_kw = "echodata" if "echodata" in params[1:] else None
+
         @functools.wraps(fn)
-        def wrapper(first, *args, **kwargs):
+        def wrapper(*args, **kwargs):
             from .echodata import EchoData, as_lite_echodata
 
+            if args:
+                first, args = args[0], args[1:]
+            elif first_name in kwargs:  # the reference's functions take their dataset by keyword as well
+                first = kwargs.pop(first_name)
+            else:
+                raise TypeError(f"{fn.__name__}() missing 1 required positional argument: '{first_name}'")
+            if ed_kw and kwargs.get(ed_kw) is not None and not isinstance(kwargs[ed_kw], EchoData) \
+                    and hasattr(kwargs[ed_kw], "sonar_model"):
+                kwargs[ed_kw] = as_lite_echodata(kwargs[ed_kw])
             foreign_ed = not isinstance(first, EchoData) and hasattr(first, "sonar_model")
             if not (is_xarray(first) or foreign_ed):
                 return fn(first, *args, **kwargs)

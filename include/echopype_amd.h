@@ -99,14 +99,15 @@ int epa_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the stop ev
  * sample_interval, tau_nominal, transmit_power: [C*P].  sound_speed / absorption / gain / sa:
  * pointer + epa_param_mode.  With EPA_PM_PULSE_TABLE, `gain`/`sa` are [C*K] tables matched against
  * pulse_length [C*K] by argmin_k |tau_nominal - pulse_length| (first minimum; NaN tau -> NaN).
- * psi, f_nominal, tau_eff: [C].  gpt: [C] bytes or NULL (EK80: channels with GPT transceivers).
+ * psi (equivalent_beam_angle): pointer + epa_param_mode (scalar, [C] or [C*P]: calibrate_ek.py:154-162 broadcasts any
+ * (channel, ping_time) cal parameter into CSv; Sv only).  f_nominal, tau_eff: [C].  gpt: [C] bytes or NULL (EK80: channels with GPT transceivers).
  * coef out: [C*P*EPA_NCOEF].
  */
 int epa_power_coef_ek(int C, int P, const double* sample_interval, const double* tau_nominal,
                       const double* transmit_power, const double* sound_speed, int ss_mode,
                       const double* absorption, int abs_mode, const double* gain, int gain_mode,
                       const double* sa_correction, int sa_mode, const double* pulse_length, int K,
-                      const double* psi, const double* f_nominal, const double* tau_eff,
+                      const double* psi, int psi_mode, const double* f_nominal, const double* tau_eff,
                       const uint8_t* gpt, int sonar, int cal_type, double* coef, epa_stream_t stream);
 
 /* The pulse-length table lookup on its own (calibrate/cal_params.py:261-324 get_vend_cal_params_power): out[c,p] =

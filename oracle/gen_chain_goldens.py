@@ -84,7 +84,7 @@ def _cp(a, chans, pings):
     return DA(a, {"channel": chans, "ping_time": pings}, ["channel", "ping_time"])
 
 
-def ek_case(ek, rng_mod, g, tag, sonar, C, P, S, seed, gpt=None):
+def ek_case(ek, rng_mod, g, tag, sonar, C, P, S, seed, gpt=None, psi_per_ping=False):
     rng = np.random.default_rng(seed)
     chans = np.array([f"ch{i}" for i in range(C)])
     pings = np.datetime64("2026-05-01T00:00:00", "ns") + np.arange(P) * np.timedelta64(1, "s")
@@ -101,6 +101,8 @@ def ek_case(ek, rng_mod, g, tag, sonar, C, P, S, seed, gpt=None):
     gain = np.array([22.9, 26.5, 27.0, 25.3])[:C, None] + 0.2 * rng.random((C, P))
     sa = -0.6 + 0.2 * rng.random((C, P))
     psi = np.array([-17.0, -20.6, -20.4, -20.2])[:C]
+    if psi_per_ping:  # a (channel, ping_time) cal parameter: the reference broadcasts it into CSv (calibrate_ek.py:154-162)
+        psi = psi[:, None] + 0.3 * rng.random((C, P))
     beam = DS(coords={"channel": chans, "ping_time": pings, "range_sample": np.arange(S)})
     beam["backscatter_r"] = DA(raw, dims=["channel", "ping_time", "range_sample"])
     beam["sample_interval"] = _cp(si, chans, pings)
@@ -112,7 +114,7 @@ def ek_case(ek, rng_mod, g, tag, sonar, C, P, S, seed, gpt=None):
         vend["transceiver_type"] = DA(np.array(gpt), {"channel": chans}, ["channel"])
     env = {"sound_speed": _cp(c_w, chans, pings), "sound_absorption": _cp(alpha, chans, pings)}
     cal = {"gain_correction": _cp(gain, chans, pings), "sa_correction": _cp(sa, chans, pings),
-           "equivalent_beam_angle": DA(psi, {"channel": chans}, ["channel"])}
+           "equivalent_beam_angle": _cp(psi, chans, pings) if psi_per_ping else DA(psi, {"channel": chans}, ["channel"])}
     cls = ek.CalibrateEK60 if sonar == "EK60" else ek.CalibrateEK80
     obj = object.__new__(cls)
     obj.echodata = _ED(sonar, {})
@@ -255,6 +257,7 @@ def main():
     g = {}
     ek_case(ek, rng_mod, g, "ek60", "EK60", 3, 6, 40, 1)
     ek_case(ek, rng_mod, g, "ek80p", "EK80", 3, 5, 32, 2, gpt=["WBT", "GPT", "WBT"])
+    ek_case(ek, rng_mod, g, "ek60psi", "EK60", 3, 7, 36, 6, psi_per_ping=True)
     azfp_case(az, g, 3, 4, 24, 3)
     ek80_complex_case(ek, ekc, rng_mod, g, "ek80bb", "BB", 2, 4, 420, 4, 4)
     ek80_complex_case(ek, ekc, rng_mod, g, "ek80cw", "CW", 2, 4, 300, 4, 5)

@@ -535,7 +535,7 @@ def test_power_chains_match_reference_method_goldens(ep):
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_chain_goldens.npz"))
     ops = ep.ops
     dev = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).cuda().to(dt)  # noqa: E731
-    for tag, sonar in (("ek60", "EK60"), ("ek80p", "EK80")):
+    for tag, sonar in (("ek60", "EK60"), ("ek80p", "EK80"), ("ek60psi", "EK60")):  # ek60psi: psi per (channel, ping)
         gpt = dev(g[f"{tag}_is_gpt"].astype(np.uint8), torch.uint8) if sonar == "EK80" else None
         for cal in ("Sv", "TS"):
             coef = ops.power_coef_ek(
@@ -546,6 +546,26 @@ def test_power_chains_match_reference_method_goldens(ep):
             out, rng = ops.sv_power(dev(g[f"{tag}_raw"], torch.float32), coef, cal_type=cal)
             close(out.cpu().numpy(), g[f"{tag}_{cal}"], 1e-9, f"{tag} {cal}")
             np.testing.assert_array_equal(rng.cpu().numpy(), g[f"{tag}_echo_range"])
+    # a (channel, ping_time) equivalent_beam_angle through the Dataset API (calibrate_ek.py:154-162 broadcasts it)
+    tag = "ek60psi"
+    C, P, S = g[f"{tag}_raw"].shape
+    chans = [f"ch{i}" for i in range(C)]
+    t = np.datetime64("2026-05-01T00:00:00", "ns") + np.arange(P) * np.timedelta64(1, "s")
+    d = ep.synth.ek60_numpy(C, P, S)
+    d.update(backscatter_r=g[f"{tag}_raw"], sample_interval=g[f"{tag}_sample_interval"], channel=chans, ping_time=t,
+             transmit_duration_nominal=g[f"{tag}_tau"], transmit_power=g[f"{tag}_transmit_power"],
+             frequency_nominal=g[f"{tag}_frequency"])
+    cp = lambda a: ep.DataArray(a, ("channel", "ping_time"), {"channel": chans, "ping_time": t})  # noqa: E731
+    env = {"sound_speed": cp(g[f"{tag}_sound_speed"]), "sound_absorption": cp(g[f"{tag}_absorption"])}
+    calp = {"gain_correction": cp(g[f"{tag}_gain"]), "sa_correction": cp(g[f"{tag}_sa"]),
+            "equivalent_beam_angle": cp(g[f"{tag}_psi"])}
+    for ed in (ep.echodata.from_ek60_arrays(d), ep.echodata.from_ek60_arrays(d).to_device()):
+        for cal in ("Sv", "TS"):
+            fn = ep.calibrate.compute_Sv if cal == "Sv" else ep.calibrate.compute_TS
+            ds = fn(ed, env_params=env, cal_params=calp)
+            close(ds[cal].values, g[f"{tag}_{cal}"], 1e-9, f"{tag} API {cal}")
+            np.testing.assert_array_equal(ds["echo_range"].values, g[f"{tag}_echo_range"])
+        np.testing.assert_array_equal(ds["equivalent_beam_angle"].values, g[f"{tag}_psi"])
     # AZFP through the Dataset API with the golden's parameters as user env / cal params
     C, P, S = g["azfp_counts"].shape
     t = np.datetime64("2026-05-01T00:00:00", "ns") + np.arange(P) * np.timedelta64(2, "s")

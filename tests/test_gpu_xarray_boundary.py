@@ -78,3 +78,28 @@ def test_xarray_in_xarray_out_through_the_chain(ep):
     a, b = ep.compute_Sv_MVBS(ForeignEchoData(lite_ed), range_bin="2m", ping_time_bin="20s")
     assert isinstance(a, fx.Dataset) and isinstance(b, fx.Dataset)
     np.testing.assert_allclose(b["Sv"].values, mv["Sv"].values, rtol=1e-12, equal_nan=True)
+
+
+def test_first_argument_by_keyword_and_add_depth_in_place(ep):
+    """The reference's functions take their dataset by keyword too (compute_Sv(echodata=ed), compute_MVBS(ds_Sv=ds),
+    apply_mask(source_ds=..., mask=...)); add_depth assigns ds["depth"] on the CALLER's dataset
+    (/root/reference/echopype/consolidate/api.py:221-241) and converts a foreign ``echodata=``."""
+    d = ep.synth.ek60_numpy(2, 40, 200)
+    lite_ed = ep.echodata.from_ek60_arrays(d)
+    fed = ForeignEchoData(lite_ed)
+    ds = ep.calibrate.compute_Sv(echodata=fed)
+    assert isinstance(ds, fx.Dataset)
+    ref = ep.calibrate.compute_Sv(echodata=lite_ed)
+    np.testing.assert_array_equal(ds["Sv"].values, ref["Sv"].values)
+    mv = ep.commongrid.compute_MVBS(ds_Sv=ds, range_bin="2m", ping_time_bin="20s")
+    assert isinstance(mv, fx.Dataset)
+    np.testing.assert_allclose(mv["Sv"].values, ep.commongrid.compute_MVBS(ds_Sv=ref, range_bin="2m", ping_time_bin="20s")["Sv"].values,
+                               rtol=1e-12, equal_nan=True)
+    m = ep.clean.mask_impulse_noise(ds_Sv=ds, range_var="echo_range", use_index_binning=True)
+    assert isinstance(ep.mask.apply_mask(source_ds=ds, mask=m), fx.Dataset)
+    with pytest.raises(TypeError, match="missing 1 required positional argument"):
+        ep.commongrid.compute_MVBS(range_bin="2m")
+    out = ep.consolidate.add_depth(ds=ds, echodata=fed, depth_offset=3.5)
+    assert "depth" in ds.data_vars and isinstance(out, fx.Dataset)           # the caller's dataset carries depth now
+    np.testing.assert_allclose(ds["depth"].values, ds["echo_range"].values + 3.5, rtol=1e-15, equal_nan=True)
+    assert "history" in ds["depth"].attrs

@@ -544,6 +544,41 @@ def test_env_params_ek80_formulas_on_time1_then_onto_ping_time():
     np.testing.assert_allclose(out2["sound_speed"].values, exp_ss, rtol=1e-13)
 
 
+def test_env_params_multi_timestamp_environment_with_a_per_channel_user_parameter():
+    """Several Environment timestamps AND a per-channel user parameter (a pH per channel): the per-channel value
+    cannot ride the time1 path -- the parameters are harmonised onto ping_time and the (channel,) value broadcasts as
+    (C, 1) against the (P,) ones (the advisor's round-2 finding: it came back as (C,) and mis-broadcast)."""
+    d = synth.ek80_numpy(2, 7, 32)
+    e = ed_mod.from_ek80_arrays(d, synth.ek80_filters())
+    beam = e["Sonar/Beam_group1"]
+    t0 = np.asarray(beam["ping_time"].values)[0]
+    time1 = t0 + np.array([-2, 1, 9]) * np.timedelta64(1, "s")
+    T1, S1, D1, pH1, ss1 = (np.array(v, float) for v in ([4.0, 12.0, 18.0], [33.0, 34.5, 35.0], [5.0, 60.0, 200.0],
+                                                          [7.9, 8.0, 8.1], [1470.0, 1495.0, 1510.0]))
+    chans = np.asarray(beam["channel"].values)
+    env = ed_mod.Dataset(coords={"time1": time1, "channel": chans})
+    for k, v in (("temperature", T1), ("salinity", S1), ("depth", D1), ("acidity", pH1), ("sound_speed_indicative", ss1)):
+        env[k] = (("time1",), v)
+    freq = DataArray(d["frequency_nominal"], ("channel",))
+    pH_c = np.array([7.8, 8.2])
+    out = env_params.get_env_params_EK("EK80", beam, env, {"pH": DataArray(pH_c, ("channel",), {"channel": chans})},
+                                       freq=freq)
+    x = time1.astype("datetime64[ns]").astype(np.int64).astype(float)
+    xq = np.asarray(beam["ping_time"].values).astype("datetime64[ns]").astype(np.int64).astype(float)
+
+    def lin(v):  # linear inter- / extrapolation onto ping_time, as harmonize_env_param_time does
+        hi = np.clip(np.searchsorted(x, xq, side="left"), 1, 2)
+        lo = hi - 1
+        return v[lo] + (v[hi] - v[lo]) * (xq - x[lo]) / (x[hi] - x[lo])
+
+    exp = uwa.calc_absorption(frequency=d["frequency_nominal"][:, None], temperature=lin(T1)[None, :],
+                              salinity=lin(S1)[None, :], pressure=lin(D1)[None, :], pH=pH_c[:, None],
+                              sound_speed=lin(ss1)[None, :], formula_source="FG")
+    assert out["sound_absorption"].shape == (2, 7)
+    np.testing.assert_allclose(out["sound_absorption"].values, exp, rtol=1e-12)
+    assert np.abs(exp[0] - exp[1]).max() > 0  # (the channels really differ)
+
+
 def test_lazy_device_array_bookkeeping():
     """xr_lite.LazyDeviceArray (the echo_range compute_Sv leaves behind) on CPU tensors: shape / dtype / size and the
     statistics are known without producing the array; the producer runs once, on first read; the coefficient rows,
@@ -575,6 +610,10 @@ def test_lazy_device_array_bookkeeping():
     assert lz.cached_stats() == (0.0, 1.5, 1) and lz.coef_rows() is rows
     lz.tensor[0, 0, 0] = 7.0                                      # written to: no longer the function of its rows
     assert lz.cached_stats() is None and lz.coef_rows() is None
+    lz3 = LazyDeviceArray((1, 1, 4), torch.float64, raw.device, make, rows=rows, nan_where=raw)  # no statistics (fused path)
+    assert lz3.coef_rows() is rows and lz3.cached_stats() is None
+    lz3.tensor.add_(1.0)
+    assert lz3.coef_rows() is None                                # ... the rows are withdrawn all the same
     lz2 = LazyDeviceArray((1, 1, 4), torch.float64, raw.device, make, stats=stats, rows=rows, nan_where=raw)
     raw[0, 0, 0] = float("nan")                                   # the NaN source was written to
     assert lz2.nan_source() is None and lz2.coef_rows() is rows
