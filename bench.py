@@ -1,27 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- range-samples/s through compute_Sv -> compute_MVBS on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ...]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME[:VARIANT]] ...
 
-N = 1 (default).  The HEADLINE line (printed LAST) is BASELINE configs[1]: synthetic EK60 CW, 4 channels x 500 000
-pings x 2000 range samples (4.0 G samples) through the metric's path compute_Sv -> compute_MVBS (20 s x 1 m bins), fp64,
-generated in HBM.  One STEP = the whole hot path over the resident volume:
-    epa_power_coef_ek (K0) -> epa_time_bin_offsets -> epa_sv_mvbs_fused (K1+K5: writes Sv f64 and the MVBS grid).
-Before it, one JSON line each for the other single-GPU configs (skipped with --only-headline or an explicit
---workload): cfg3 = configs[2] (the same volume through compute_Sv -> remove_background_noise -> compute_MVBS), cfg4 =
-configs[3] (EK80 broadband, 2 x 200 000 x 8192 x 4 sectors: pulse compression + Sv + MVBS), cfg5 = configs[4]'s
-32.8 G-sample volume on one GPU as resident tiles.  Every line carries `roofline` (HIP-event time of the dominant
-kernel on torch's stream vs the algorithmic bytes of SURVEY 8d) and its own `cpu_baseline` (the NumPy / SciPy oracle
-with the reference's pass structure on a bounded slice, host cores, timed before HIP is initialised).
+ONE workload carries the 1 -> 8 GPU curve: BASELINE configs[4], the metric's own volume -- EK60 CW 4 ch x 2 M pings x
+4096 range (32.8 G samples) as eight resident tiles of 250 000 pings, split by ping_time over the N ranks (STRONG
+scaling: N = 1 holds all eight tiles, N = 8 one each).  The ping-time origin sits 10 s off the 20-s bin grid, so every
+tile / shard edge cuts a time bin and the edge-bin exchange (sharding.EdgeExchange: epa_edge_pack -> ONE all-reduce of
+a few hundred KB -> epa_edge_finalize_mvbs) is inside the timed region at every N.  That line is printed LAST at every
+N (the driver parses the last line); the same invocation times the bin-aligned layout too (config.aligned_ms_per_step).
 
-N > 1.  `python bench.py --gpus N` launches its own N ranks (torch.distributed.run, one per GPU, RCCL); under a
-launcher (WORLD_SIZE set) it runs as one rank.  Workload = BASELINE configs[4]: EK60 4 ch x 2 M pings x 4096 range
-(32.8 G samples) split by ping_time over the N ranks -- STRONG scaling -- each rank holding its share as resident
-tiles.  The ping-time origin sits 10 s off the 20-s bin grid, so EVERY tile and shard edge cuts a time bin: the raw
-(sum, count) partials of the cut bins go through the edge-bin all-reduce (sharding.EdgeExchange: one RCCL all-reduce
-of a few hundred KB per step) inside the timed region.  The same invocation also times the bin-aligned layout (no
-collective at all) and reports it as config.aligned_ms_per_step, so the cost of the exchange is on the line.
-value = samples processed by all ranks / max-over-ranks wall time of the K timed steps.
+A STEP is `passes_per_step` back-to-back passes of the hot path over the resident volume (so that the driver's 20 steps
+are a ~2 s region); `value` = samples processed by all ranks in the K timed steps / max-over-ranks wall time.
+
+N = 1 prints, before the headline, one JSON line per single-GPU configuration of BASELINE.json (skipped with
+--only-headline or an explicit --workload): cfg3 = configs[2] (compute_Sv -> remove_background_noise -> compute_MVBS;
+SURVEY 8d recipe: a new sound speed at every ping; then the every-2000-pings variant and fp32), cfg2 = configs[1] (fp64,
+fp32), the reference's own two API calls on the cfg2 volume, cfg4 = configs[3] (EK80 BB pulse compression + Sv, float32
+planes -> fp64 / fp32, and float64 planes as the converter stores them).  Every line carries `roofline` (HIP-event
+time of the dominant kernel on torch's stream vs the algorithmic bytes of SURVEY 8d) and `cpu_baseline` (the NumPy /
+SciPy oracle with the reference's pass structure on a bounded slice, host cores, timed before HIP is initialised).
+The headline line also carries the other lines' key figures as flat `also_*` strings.
 """
 import argparse
 import hashlib
@@ -39,42 +38,44 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_SAMPLE = {"float64": 12, "float32": 8}  # SURVEY 8d line C (raw f32 in + Sv out)
 METRIC = "range-samples/sec through compute_Sv->compute_MVBS"
-# name: (C, pings, S, default timed steps, default warmup) -- steps sized for a timed region of ~2 s
+# name: (C, pings, S, passes per step for f64, for f32)
 WORKLOADS = {
-    "cfg2": (4, 500_000, 2000, 220, 10),
-    "cfg3": (4, 500_000, 2000, 70, 4),
-    "cfg4": (2, 200_000, 8192, 45, 3),
-    "cfg4small": (2, 20_000, 8192, 100, 5),
-    "cfg5": (4, 2_000_000, 4096, 26, 2),
-    "small": (4, 20_000, 2000, 200, 10),
+    "cfg2": (4, 500_000, 2000, 10, 14),
+    "cfg3": (4, 500_000, 2000, 4, 6),
+    "api": (4, 500_000, 2000, 5, 8),
+    "cfg4": (2, 200_000, 8192, 2, 3),
+    "cfg4small": (2, 20_000, 8192, 20, 30),
+    "cfg5": (4, 2_000_000, 4096, 2, 3),
+    "small": (4, 20_000, 2000, 50, 50),
 }
+DEFAULT_LINES = ["cfg3", "cfg3:ss2000", "cfg3:f32", "cfg2", "cfg2:f32", "api", "cfg4", "cfg4:f32", "cfg4:planes64", "cfg5"]
 TILE_PINGS = 250_000
+DT = {"f32": "float32", "f64": "float64"}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--ss-every", type=int, default=2000,
-                    help="EK60 volumes: the sound speed recorded with the pings changes every this many pings "
-                         "(1: at every ping -- no two pings share a range vector)")
-    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help="one workload only (default: N=1 -> cfg3, cfg4, cfg5 lines then the cfg2 headline; N>1 -> cfg5)")
-    ap.add_argument("--only-headline", action="store_true", help="N=1: skip the cfg3 / cfg4 / cfg5 lines")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--passes", type=int, default=None, help="passes over the volume per step (default: per workload)")
+    ap.add_argument("--ss-every", type=int, default=1,
+                    help="EK60 volumes: the recorded sound speed changes every this many pings (1 = SURVEY 8d's recipe: "
+                         "no two pings share a range vector)")
+    ap.add_argument("--workload", default=None,
+                    help="one line only: cfg2 | cfg3 | cfg4 | cfg5 | api | small | cfg4small, optionally with a variant "
+                         "(:f32, :ss2000, :planes64, :int16)")
+    ap.add_argument("--only-headline", action="store_true", help="N=1: skip the other single-GPU lines")
     ap.add_argument("--dtype", default="float64", choices=["float64", "float32"])
-    ap.add_argument("--input", default="float32", choices=["float32", "int16"],
-                    help="cfg2: float32 = backscatter_r as echopype's converter stores it (the drop-in boundary); "
-                         "int16 = the instrument's own samples + ping lengths (SURVEY 8f row 4, 2 B/sample in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chain-outputs", default="all", choices=["all", "corrected"],
-                    help="cfg3: full-size arrays written -- all = Sv + Sv_noise + Sv_corrected (what "
-                         "remove_background_noise adds, SURVEY 8d line E: 32 B/sample fp64); corrected = without Sv_noise")
-    ap.add_argument("--pings-total", type=int, default=None, help="N>1 / cfg5: total pings (default 2 000 000)")
+                    help="cfg3: full-size arrays written -- all = Sv + Sv_noise + Sv_corrected (SURVEY 8d line E: "
+                         "32 B/sample fp64); corrected = without Sv_noise")
+    ap.add_argument("--pings-total", type=int, default=None, help="cfg5: total pings (default 2 000 000)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend (nccl = RCCL; gloo only for dry runs of the N>1 logic)")
-    ap.add_argument("--single-device", action="store_true",
-                    help="dry run: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--single-device", action="store_true", help="dry run: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--out", default=None, help="also append every JSON line to this file")
     return ap.parse_args()
 
 
@@ -97,7 +98,7 @@ def _oracle_ek60(d, chain):
     return ogrid.compute_MVBS(sv, er, d["ping_time"], "1m", "20s")
 
 
-def _time_runs(run, budget_s=20.0, max_runs=5):
+def _time_runs(run, budget_s=12.0, max_runs=5):
     run()
     ts = []
     t_end = time.perf_counter() + budget_s
@@ -125,10 +126,10 @@ def cpu_baseline_ek60(chain=False, multicore=False):
     d = synth.ek60_numpy(C, P, S)
     med, n_runs = _time_runs(lambda: _oracle_ek60(d, chain))
     n = C * P * S
-    what = "compute_Sv + remove_background_noise(20 x 50, 3 dB) + compute_MVBS" if chain else "compute_Sv + compute_MVBS"
+    what = "Sv+denoise(20x50,3dB)+MVBS" if chain else "Sv+MVBS"
     out = {"value": n / med, "unit": "range-samples/s", "cores": 1, "kind": "port",
-           "sample": f"BASELINE configs[0] shape: EK60 {C}ch x {P} pings x {S} range, {what}(20s x 1m), NumPy fp64 "
-                     f"oracle (reference pass structure), median of {n_runs} runs, host has {os.cpu_count()} cores"}
+           "sample": f"configs[0] shape EK60 {C}x{P}x{S}, {what} 20s x 1m, NumPy f64 oracle, median of {n_runs}, "
+                     f"host has {os.cpu_count()} cores"}
     if multicore:  # what dask chunk-parallelism over ping_time could reach at best: the same slice in N processes
         try:
             import multiprocessing as mp
@@ -139,10 +140,9 @@ def cpu_baseline_ek60(chain=False, multicore=False):
                     t0 = time.perf_counter()
                     pool.map(_cpu_worker, [(C, P, S, i) for i in range(ncore)])
                     dtm = time.perf_counter() - t0
-                out["multicore"] = {"value": n * ncore / dtm, "cores": ncore,
-                                    "sample": f"{ncore} processes x the same slice (ping-sharded, no communication)"}
+                out["multicore_value"], out["multicore_cores"] = n * ncore / dtm, ncore
         except Exception as e:  # noqa: BLE001 - the single-core figure stands on its own
-            out["multicore"] = {"error": repr(e)}
+            out["multicore_error"] = repr(e)[:100]
     return out
 
 
@@ -165,11 +165,10 @@ def cpu_baseline_bb():
         with np.errstate(invalid="ignore", divide="ignore"):
             return 10 * np.log10(prx) + 20 * np.log10(r) + 0.02 * r - 30.0
 
-    med, n_runs = _time_runs(run, budget_s=15.0, max_runs=3)
+    med, n_runs = _time_runs(run, budget_s=12.0, max_runs=3)
     return {"value": C * P * S / med, "unit": "range-samples/s", "cores": 1, "kind": "port",
-            "sample": f"EK80 BB {C}ch x {P} pings x {S} samples x {B} sectors, {reps[0].size}-tap replicas: "
-                      f"scipy.signal.convolve per (ping, sector) + sector mean + Sv (oracle/ek80.py), median of "
-                      f"{n_runs} runs, host has {os.cpu_count()} cores"}
+            "sample": f"EK80 BB {C}x{P}x{S}x{B}, {reps[0].size}-tap replicas: scipy.signal.convolve per (ping, sector) + "
+                      f"sector mean + Sv, median of {n_runs}, host has {os.cpu_count()} cores"}
 
 
 # ---------------------------------------------------------------------------------------- helpers
@@ -188,16 +187,14 @@ def measured_traffic(key):
     of this command; dropped when the kernel sources changed since."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
-        tj = json.load(open(path))
-        e = tj.get(key)
+        e = json.load(open(path)).get(key)
         if not e:
-            return None, "no PMC measurement of this workload under profiles/"
+            return None, "no PMC run of this line under profiles/"
         if e.get("csrc_sha16") != csrc_hash():
-            return None, f"stale: PMC measurement in profiles/hbm_traffic.json was taken at csrc {e.get('csrc_sha16')}"
-        return e["bytes_per_launch"], (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 correction), "
-                                       f"{e.get('source', 'profiles/')}, csrc {e['csrc_sha16']}")
+            return None, f"stale: PMC run at csrc {e.get('csrc_sha16')}"
+        return e["bytes_per_launch"], f"PMC FETCH/WRITE_SIZE, {e.get('source', 'profiles/')}, csrc {e['csrc_sha16']}"
     except Exception as ex:  # noqa: BLE001
-        return None, f"unreadable profiles/hbm_traffic.json: {ex!r}"
+        return None, f"unreadable profiles/hbm_traffic.json: {ex!r}"[:100]
 
 
 class Ctx:
@@ -210,7 +207,12 @@ class Ctx:
 
         self.args, self.world, self.rank = args, world, rank
         self.torch, self.dist, self.ops, self.sharding, self.synth = torch, dist, ops, sharding, synth
-        self.dt = torch.float64 if args.dtype == "float64" else torch.float32
+        self.dtype = args.dtype
+        self.cache = {}
+
+    @property
+    def dt(self):
+        return self.torch.float64 if self.dtype == "float64" else self.torch.float32
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -218,15 +220,22 @@ class Ctx:
             self.dist.barrier()
             self.torch.cuda.synchronize()
 
-    def timed(self, step, steps, warmup):
-        """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks.  step(timer | None)."""
-        timers = [self.ops.Timer() for _ in range(steps)]
-        for _ in range(warmup):
-            step(None)
+    def passes(self, workload):
+        if self.args.passes:
+            return self.args.passes
+        return WORKLOADS[workload][3 if self.dtype == "float64" else 4]
+
+    def timed(self, one_pass, passes):
+        """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks.  A step = ``passes``
+        calls of one_pass(timer | None); returns (elapsed s, mean HIP-event ms of the regions the passes timed)."""
+        steps, warmup = self.args.steps, self.args.warmup
+        timers = [self.ops.Timer() for _ in range(steps * passes)]
+        for _ in range(warmup * passes):
+            one_pass(None)
         self.sync()
         t0 = time.perf_counter()
-        for i in range(steps):
-            step(timers[i])
+        for i in range(steps * passes):
+            one_pass(timers[i])
         self.sync()
         elapsed = time.perf_counter() - t0
         kernel_ms = float(np.mean([tm.elapsed_ms() for tm in timers]))
@@ -236,13 +245,6 @@ class Ctx:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item()), kernel_ms
 
-    def steps(self, workload):
-        a = self.args
-        # (strong scaling: a rank's step shrinks with the world size; the default keeps the timed region near 2 s)
-        scale = self.world if workload == "cfg5" else 1
-        return (a.steps if a.steps is not None else WORKLOADS[workload][3] * scale,
-                a.warmup if a.warmup is not None else WORKLOADS[workload][4])
-
     def free(self):
         import gc
 
@@ -250,13 +252,14 @@ class Ctx:
         self.torch.cuda.empty_cache()
 
 
-def line(ctx, *, value, steps, warmup, elapsed, scaling, workload, config, roofline, metric=METRIC, cpu=None):
-    out = {"metric": metric, "value": value, "unit": "range-samples/s", "n_gpus": ctx.world, "steps": steps,
-           "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": scaling,
-           "vs_baseline": None, "dtype": "f64" if ctx.args.dtype == "float64" else "f32", "data": "synthetic",
-           "config": {"workload": workload, **config,
-                      "synthetic_data": "10 % of pings short and NaN-padded; the recorded sound speed follows a slow "
-                                        f"drift (EK60: a new value every {ctx.args.ss_every} pings, EK80: every ping)"},
+def line(ctx, *, samples_per_pass, passes, elapsed, scaling, workload, config, roofline, metric=METRIC, cpu=None):
+    steps = ctx.args.steps
+    out = {"metric": metric, "value": samples_per_pass * passes * steps / elapsed, "unit": "range-samples/s",
+           "n_gpus": ctx.world, "steps": steps, "warmup": ctx.args.warmup, "ms_per_step": elapsed / steps * 1e3,
+           "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+           "dtype": "f64" if ctx.dtype == "float64" else "f32", "data": "synthetic",
+           "config": {"workload": workload, "passes_per_step": passes, "samples_per_step": samples_per_pass * passes,
+                      "ms_per_pass": elapsed / steps / passes * 1e3, **config},
            "roofline": roofline}
     if cpu is not None:
         out["cpu_baseline"] = cpu
@@ -265,13 +268,13 @@ def line(ctx, *, value, steps, warmup, elapsed, scaling, workload, config, roofl
 
 def roofline(kernel, kernel_ms, bytes_per_launch, bps, traffic_key=None, **extra):
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-    traffic, src = measured_traffic(traffic_key) if traffic_key else (None, "not measured for this workload")
+    traffic, src = measured_traffic(traffic_key) if traffic_key else (None, "not measured for this line")
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src, "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_sample": bps,
             **extra}
 
 
-# ---------------------------------------------------------------------------------------- EK60: cfg2 / cfg3
+# ---------------------------------------------------------------------------------------- EK60: cfg2 / cfg3 / api
 def _coef(ctx, d):
     return ctx.ops.power_coef_ek(
         d["sample_interval"], d["transmit_duration_nominal"], d["transmit_power"], d["sound_speed_indicative"],
@@ -279,57 +282,34 @@ def _coef(ctx, d):
         d["frequency_nominal"], d["tau0"], pulse_length=d["pulse_length"], gain_is_table=True, sa_is_table=True)
 
 
-def api_ms(ctx, C, P, S, raw):
-    """The same step through the drop-in Dataset API on the resident samples: (compute_Sv_MVBS(echodata), compute_Sv(echodata),
-    compute_MVBS(ds_Sv)) in ms."""
-    import logging
-
-    import echopype_amd as ep
-
-    d = ctx.synth.ek60_numpy(C, 4, 8)
-    for k, v in list(d.items()):
-        if isinstance(v, np.ndarray) and v.ndim == 2 and v.shape == (C, 4):
-            d[k] = np.repeat(v[:, :1], P, axis=1)
+def ek60_volume(ctx, name, ss_every, i16=False):
+    """The cfg2 / cfg3 volume, generated once per shape and kept between lines; the recorded sound speed (O(C P)) is
+    rewritten for the ``ss_every`` asked (the samples do not depend on it)."""
+    torch = ctx.torch
+    C, P, S = WORKLOADS[name][:3]
+    key = ("ek60", C, P, S, i16)
+    if key not in ctx.cache:
+        for k in [k for k in ctx.cache if k != key]:
+            del ctx.cache[k]
+        ctx.free()
+        d = (ctx.synth.ek60_device_i16 if i16 else ctx.synth.ek60_device)(C, P, S, seed=20260501, ss_every=ss_every)
+        d["tau0"] = d["transmit_duration_nominal"][:, 0].contiguous()  # EK60 tau_eff = ping 0
+        ctx.cache[key] = d
+    d = ctx.cache[key]
     p = np.arange(P)
-    d["sound_speed_indicative"] = np.tile(1500.0 + 0.5 * np.sin(2 * np.pi * p / 1e5), (C, 1))
-    d["backscatter_r"] = ep.DeviceArray(raw)
-    d["ping_time"] = ctx.synth.T0 + (p * 1_000_000_000).astype("timedelta64[ns]")
-    ed = ep.echodata.from_ek60_arrays(d).to_device()  # samples AND per-ping parameters resident in HBM
-    logging.disable(logging.WARNING)
-    dtype = ctx.args.dtype
-
-    def med(f):
-        r = f()
-        ctx.torch.cuda.synchronize()
-        ts = []
-        for _ in range(5):
-            del r
-            ctx.torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            r = f()
-            ctx.torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t0)
-        return float(np.median(ts)) * 1e3, r
-
-    try:
-        one, r = med(lambda: ep.compute_Sv_MVBS(ed, range_bin="1m", ping_time_bin="20s", dtype=dtype))
-        del r
-        # the reference's own two calls
-        sv_ms, ds = med(lambda: ep.calibrate.compute_Sv(ed, dtype=dtype))
-        mv_ms, r = med(lambda: ep.commongrid.compute_MVBS(ds, range_bin="1m", ping_time_bin="20s"))
-        del r, ds
-    finally:
-        logging.disable(logging.NOTSET)
-    return one, sv_ms, mv_ms
+    ss = np.tile(1500.0 + 0.5 * np.sin(2 * np.pi * (p // ss_every * ss_every) / 1e5), (C, 1))
+    d["sound_speed_indicative"] = torch.from_numpy(ss).cuda()
+    return d
 
 
-def run_ek60(ctx, name, cpu):
+def run_ek60(ctx, name, variant, cpu):
     args, torch, ops, sharding = ctx.args, ctx.torch, ctx.ops, ctx.sharding
     C, P, S = WORKLOADS[name][:3]
     chain = name == "cfg3"
-    i16 = args.input == "int16" and not chain
+    i16 = variant == "int16" and not chain
+    ss_every = 2000 if variant == "ss2000" else args.ss_every
     dt = ctx.dt
-    d = (ctx.synth.ek60_device_i16 if i16 else ctx.synth.ek60_device)(C, P, S, seed=20260501, ss_every=args.ss_every)
+    d = ek60_volume(ctx, name, ss_every, i16)
     ns = d["ping_time_ns"]
     bin_ns = 20_000_000_000
     e0, _ = sharding.global_time_grid(ns.cpu().numpy(), bin_ns)
@@ -338,9 +318,8 @@ def run_ek60(ctx, name, cpu):
     n_r = len(np.arange(0, r_max + 1.0, 1.0)) - 1
     sv = torch.empty((C, P, S), dtype=dt, device="cuda") if not chain else None
     mvbs = torch.empty((C, n_t, n_r), dtype=dt, device="cuda")
-    d["tau0"] = d["transmit_duration_nominal"][:, 0].contiguous()  # EK60 tau_eff = ping 0
 
-    def step(timer):
+    def one_pass(timer):
         coef = _coef(ctx, d)
         bs = ops.time_bin_offsets(ns, e0, bin_ns, n_t)
         if timer is not None:
@@ -357,68 +336,130 @@ def run_ek60(ctx, name, cpu):
         if timer is not None:
             timer.stop()
 
-    steps, warmup = ctx.steps(name)
-    elapsed, kernel_ms = ctx.timed(step, steps, warmup)
+    passes = ctx.passes(name)
+    elapsed, kernel_ms = ctx.timed(one_pass, passes)
     n = C * P * S
-    bps = BYTES_PER_SAMPLE[args.dtype] - (2 if i16 else 0)
+    bps = BYTES_PER_SAMPLE[ctx.dtype] - (2 if i16 else 0)
     if chain:  # two sweeps over the 4-B input + Sv, Sv_corrected (+ Sv_noise) out: SURVEY 8d line E = 32 / 20 B
-        bps = 2 * BYTES_PER_SAMPLE[args.dtype] + ((BYTES_PER_SAMPLE[args.dtype] - 4) if args.chain_outputs == "all" else 0)
-    key = f"{name}:{args.dtype}" + (":int16" if i16 else "") + (":corrected" if chain and args.chain_outputs != "all" else "")
-    cfg = {"pings_total": P, "sharding": "one GPU", "collective": "none"}
-    if not chain and not i16:
-        del sv, mvbs
-        ctx.free()
-        cfg["api_ms_per_step"], sv_ms, mv_ms = api_ms(ctx, C, P, S, d["backscatter_r"])
-        cfg["api_two_calls_ms"] = {"compute_Sv": sv_ms, "compute_MVBS": mv_ms}
-        cfg["api_note"] = ("api_ms_per_step: echopype_amd.compute_Sv_MVBS(echodata) through the Dataset API on the same "
-                           "volume, echodata resident in HBM (EchoData.to_device: samples and per-ping parameters): "
-                           "parameter selection + kernels + Dataset assembly, median of 5 calls; api_two_calls_ms: the "
-                           "reference's own sequence calibrate.compute_Sv(echodata) then commongrid.compute_MVBS(ds_Sv) "
-                           "(echo_range stays lazy, binned through its coefficient rows)")
-    what = ("fused compute_Sv -> compute_MVBS (20 s x 1 m), Sv + MVBS written" if not chain else
-            "two-pass compute_Sv -> remove_background_noise (20 x 50, 3 dB) -> compute_MVBS of Sv_corrected (20 s x 1 m), "
-            "Sv + " + ("Sv_noise + " if args.chain_outputs == "all" else "") + "Sv_corrected + MVBS written")
-    return line(ctx, value=n * steps / elapsed, steps=steps, warmup=warmup, elapsed=elapsed, scaling="weak",
+        bps = 2 * BYTES_PER_SAMPLE[ctx.dtype] + ((BYTES_PER_SAMPLE[ctx.dtype] - 4) if args.chain_outputs == "all" else 0)
+    key = f"{name}:{ctx.dtype}" + (":int16" if i16 else "") + (":corrected" if chain and args.chain_outputs != "all" else "") \
+        + (f":ss{ss_every}" if chain and ss_every != 1 else "")
+    what = ("fused compute_Sv->compute_MVBS(20s x 1m), Sv+MVBS out" if not chain else
+            "compute_Sv->remove_background_noise(20x50,3dB)->compute_MVBS(20s x 1m) in two sweeps, Sv+"
+            + ("Sv_noise+" if args.chain_outputs == "all" else "") + "Sv_corrected+MVBS out")
+    return line(ctx, samples_per_pass=n, passes=passes, elapsed=elapsed, scaling="weak",
                 metric=METRIC + (" with remove_background_noise" if chain else ""),
-                workload=f"EK60 CW {C}ch x {P} pings x {S} range ({name}), {what}" + (", int16 instrument samples in" if i16 else ""),
-                config=cfg, cpu=cpu,
-                roofline=roofline("epa_chain::sv_noise_fast_kernel + sv_denoise_mvbs_uniform_kernel (+ sv_denoise_mvbs_fast_kernel for time bins whose pings differ)" if chain
-                                  else "epa_fused::fused_sv_mvbs_kernel", kernel_ms, n * bps, bps, traffic_key=key))
+                workload=f"{name}: EK60 CW {C}x{P}x{S}, {what}" + (", int16 samples in" if i16 else ""),
+                config={"sound_speed_changes_every_n_pings": ss_every, "sharding": "one GPU", "collective": "none"}, cpu=cpu,
+                roofline=roofline("sv_noise_fast_kernel + sv_denoise_mvbs_{uniform,fast}_kernel" if chain
+                                  else "fused_sv_mvbs_kernel", kernel_ms, n * bps, bps, traffic_key=key))
+
+
+def run_api(ctx, cpu):
+    """The reference's own two calls on the cfg2 volume through the drop-in Dataset API, echodata resident in HBM
+    (EchoData.to_device): one pass = calibrate.compute_Sv(echodata) then commongrid.compute_MVBS(ds_Sv, '1m', '20s')
+    (echo_range stays lazy and is binned through its coefficient rows).  Also timed: the one-call compute_Sv_MVBS."""
+    import logging
+
+    import echopype_amd as ep
+
+    C, P, S = WORKLOADS["api"][:3]
+    raw = ek60_volume(ctx, "cfg2", ctx.args.ss_every)["backscatter_r"]
+    d = ctx.synth.ek60_numpy(C, 4, 8)
+    for k, v in list(d.items()):
+        if isinstance(v, np.ndarray) and v.ndim == 2 and v.shape == (C, 4):
+            d[k] = np.repeat(v[:, :1], P, axis=1)
+    p = np.arange(P)
+    d["sound_speed_indicative"] = np.tile(1500.0 + 0.5 * np.sin(2 * np.pi * p / 1e5), (C, 1))
+    d["backscatter_r"] = ep.DeviceArray(raw)
+    d["ping_time"] = ctx.synth.T0 + (p * 1_000_000_000).astype("timedelta64[ns]")
+    ed = ep.echodata.from_ek60_arrays(d).to_device()  # samples AND per-ping parameters resident in HBM
+    dtype = ctx.dtype
+    split = {"sv": [], "mv": []}
+
+    def one_pass(timer):
+        if timer is not None:
+            timer.start()
+        ds = ep.calibrate.compute_Sv(ed, dtype=dtype)
+        mv = ep.commongrid.compute_MVBS(ds, range_bin="1m", ping_time_bin="20s")
+        if timer is not None:
+            timer.stop()
+        del ds, mv
+
+    logging.disable(logging.WARNING)
+    try:
+        passes = ctx.passes("api")
+        elapsed, region_ms = ctx.timed(one_pass, passes)
+
+        def med(f):
+            ts = []
+            for _ in range(4):
+                ctx.torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r = f()
+                ctx.torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+                del r
+            return float(np.median(ts[1:])) * 1e3
+
+        split["sv"] = med(lambda: ep.calibrate.compute_Sv(ed, dtype=dtype))
+        ds = ep.calibrate.compute_Sv(ed, dtype=dtype)
+        split["mv"] = med(lambda: ep.commongrid.compute_MVBS(ds, range_bin="1m", ping_time_bin="20s"))
+        del ds
+        one_call = med(lambda: ep.compute_Sv_MVBS(ed, range_bin="1m", ping_time_bin="20s", dtype=dtype))
+    finally:
+        logging.disable(logging.NOTSET)
+    n = C * P * S
+    bps = BYTES_PER_SAMPLE[dtype] + (8 if dtype == "float64" else 4)  # Sv written, then read again by compute_MVBS
+    return line(ctx, samples_per_pass=n, passes=passes, elapsed=elapsed, scaling="weak", cpu=cpu,
+                workload=f"api: EK60 CW {C}x{P}x{S}, calibrate.compute_Sv(echodata) then commongrid.compute_MVBS(ds_Sv) "
+                         "through the Dataset API, echodata resident in HBM",
+                config={"compute_Sv_ms": split["sv"], "compute_MVBS_ms": split["mv"], "one_call_compute_Sv_MVBS_ms": one_call,
+                        "sharding": "one GPU", "collective": "none"},
+                roofline=roofline("sv_power_kernel + mvbs_of_sv_rows_kernel (+ host parameter selection)", region_ms, n * bps,
+                                  bps, note="region = both API calls incl. host work"))
 
 
 # ---------------------------------------------------------------------------------------- EK80 BB: cfg4
-def run_ek80(ctx, name, cpu):
+def run_ek80(ctx, name, variant, cpu):
     """EK80 BB complex -> pulse compression + Sv (epa_sv_complex_fft) -> MVBS.  The per-(channel, ping) parameter rows
-    and the replicas are assembled once by the drop-in's own calibrator (host, O(C*P)); one step = the two kernels over
-    the resident planes."""
+    and the replicas are assembled once by the drop-in's own calibrator (host, O(C*P)); one pass = the two kernels over
+    the resident planes.  ``planes64``: backscatter_r / _i float64 as the converter stores them (parse_base.py:306-309)."""
     import echopype_amd as ep
     from echopype_amd import _lib
     from echopype_amd.calibrate.api import CALIBRATOR
 
-    args, torch, ops, sharding, synth = ctx.args, ctx.torch, ctx.ops, ctx.sharding, ctx.synth
+    torch, ops, sharding, synth = ctx.torch, ctx.ops, ctx.sharding, ctx.synth
     C, P, S = WORKLOADS[name][:3]
     B = 4
+    pdt = torch.float64 if variant == "planes64" else torch.float32
+    key = ("ek80", C, P, S, pdt)
+    if key not in ctx.cache:
+        ctx.cache.clear()
+        ctx.free()
+        g = torch.Generator(device="cuda")
+        g.manual_seed(20260504)
+        re = torch.empty((C, P, S, B), dtype=pdt, device="cuda")
+        im = torch.empty((C, P, S, B), dtype=pdt, device="cuda")
+        slab = max(1, P // 50)
+        for p0 in range(0, P, slab):  # in slabs: no second copy of the planes
+            n = min(slab, P - p0)
+            re[:, p0:p0 + n] = torch.randn((C, n, S, B), generator=g, device="cuda", dtype=torch.float32) * 1e-3
+            im[:, p0:p0 + n] = torch.randn((C, n, S, B), generator=g, device="cuda", dtype=torch.float32) * 1e-3
+        nan_pings = torch.rand(P, generator=g, device="cuda") < 0.10
+        tail = int(round(0.05 * S))
+        re[:, nan_pings, S - tail:] = float("nan")
+        im[:, nan_pings, S - tail:] = float("nan")
+        ctx.cache[key] = (re, im)
+    re, im = ctx.cache[key]
     d = synth.ek80_numpy(C, 4, 64, B)  # parameters only; the sample planes are generated on the device
-    g = torch.Generator(device="cuda")
-    g.manual_seed(20260504)
-    re = torch.empty((C, P, S, B), dtype=torch.float32, device="cuda")
-    im = torch.empty((C, P, S, B), dtype=torch.float32, device="cuda")
-    slab = max(1, P // 50)
-    for p0 in range(0, P, slab):  # in slabs: no second copy of the planes
-        n = min(slab, P - p0)
-        re[:, p0:p0 + n] = torch.randn((C, n, S, B), generator=g, device="cuda", dtype=torch.float32) * 1e-3
-        im[:, p0:p0 + n] = torch.randn((C, n, S, B), generator=g, device="cuda", dtype=torch.float32) * 1e-3
-    nan_pings = torch.rand(P, generator=g, device="cuda") < 0.10
-    tail = int(round(0.05 * S))
-    re[:, nan_pings, S - tail:] = float("nan")
-    im[:, nan_pings, S - tail:] = float("nan")
     pidx = np.arange(P)
     ping_time = synth.T0 + (pidx * 1_000_000_000).astype("timedelta64[ns]")
     d.update(backscatter_r=ep.DeviceArray(re), backscatter_i=ep.DeviceArray(im), sample_interval=np.full((C, P), 8e-6),
              sound_speed=np.tile(1500.0 + 0.5 * np.sin(2 * np.pi * pidx / 1e5), (C, 1)), ping_time=ping_time)
     ed = ep.echodata.from_ek80_arrays(d, synth.ek80_filters())
     cal = CALIBRATOR["EK80"](ed, env_params=None, cal_params=None, ecs_file=None, waveform_mode="BB",
-                             encode_mode="complex", dtype=args.dtype, device=None)
+                             encode_mode="complex", dtype=ctx.dtype, device=None)
     k, _ = cal._complex_inputs("Sv")
     ns = torch.from_numpy(ping_time.astype(np.int64)).cuda()
     bin_ns = 20_000_000_000
@@ -427,11 +468,9 @@ def run_ek80(ctx, name, cpu):
     range_bin = 0.1
     rmax = float((S - 1) * 8e-6 * 1500.5 / 2)
     n_r = len(np.arange(0, rmax + range_bin, range_bin)) - 1
-    rows = torch.zeros((C, P, _lib.NCOEF), dtype=torch.float64, device="cuda")
-    rows[..., _lib.CF_RA] = k["ccoef"][..., _lib.CC_RA]
-    rows[..., _lib.CF_RB] = k["ccoef"][..., _lib.CC_RB]
+    rows = ops.power_rows_of_complex(k["ccoef"])
 
-    def step(timer):
+    def one_pass(timer):
         bs = ops.time_bin_offsets(ns, e0, bin_ns, n_t)
         if timer is not None:
             timer.start()
@@ -441,130 +480,133 @@ def run_ek80(ctx, name, cpu):
             timer.stop()
         ops.mvbs(res["out"], bs, n_t, range_bin, n_r, coef=rows)
 
-    steps, warmup = ctx.steps(name)
-    elapsed, kernel_ms = ctx.timed(step, steps, warmup)
+    passes = ctx.passes(name)
+    elapsed, kernel_ms = ctx.timed(one_pass, passes)
     n = C * P * S
-    bps = B * 8 + (8 if args.dtype == "float64" else 4)  # SURVEY 8d line F: complex64 sectors in, Sv out
+    esz = 8 if variant == "planes64" else 4
+    bps = B * 2 * esz + (8 if ctx.dtype == "float64" else 4)  # SURVEY 8d line F: r/i sectors in, Sv out
     taps = int(k["max_taps"])
-    return line(ctx, value=n * steps / elapsed, steps=steps, warmup=warmup, elapsed=elapsed, scaling="weak", cpu=cpu,
-                workload=f"EK80 BB complex {C}ch x {P} pings x {S} samples x {B} sectors ({name}), float32 planes "
-                         f"resident, {taps}-tap replica: pulse compression + Sv, then MVBS (20 s x {range_bin} m); a "
-                         "sample = one (channel, ping, range_sample) output",
-                config={"pings_total": P, "sharding": "one GPU", "collective": "none",
-                        "fft_dtype": "complex128" if args.dtype == "float64" else "complex64"},
-                roofline=roofline("sv_complex_fft_kernel", kernel_ms, n * bps, bps, traffic_key=f"{name}:{args.dtype}",
-                                  direct_form_tflops=8.0 * taps * n / (kernel_ms * 1e-3) / 1e12,
-                                  note="in-place LDS FFT (DIF / DIT, 6 LDS round trips per 2048-sample tile); the "
-                                       "transform runs in the output's precision.  Instruction counters of this kernel "
-                                       "(profiles/r02_pmc_hot.txt, a replayed measurement): 241 (complex128) / 232 "
-                                       "(complex64) VALU wavefront instructions per output sample = 20 / 19 ms of pure "
-                                       "VALU issue at this volume -- the kernel meets its instruction-issue bound "
-                                       "before the HBM one"))
+    return line(ctx, samples_per_pass=n, passes=passes, elapsed=elapsed, scaling="weak", cpu=cpu,
+                workload=f"{name}: EK80 BB {C}x{P}x{S}x{B} sectors, {'float64' if esz == 8 else 'float32'} r/i planes, "
+                         f"{taps}-tap replica: pulse compression + Sv, then MVBS(20s x {range_bin}m)",
+                config={"sample": "one (channel, ping, range_sample) output", "sharding": "one GPU", "collective": "none",
+                        "fft_dtype": "complex128" if ctx.dtype == "float64" else "complex64"},
+                roofline=roofline("sv_complex_fft_kernel", kernel_ms, n * bps, bps,
+                                  traffic_key=f"{name}:{ctx.dtype}" + (":planes64" if esz == 8 else ""),
+                                  direct_form_tflops=8.0 * taps * n / (kernel_ms * 1e-3) / 1e12))
 
 
 # ---------------------------------------------------------------------------------------- cfg5: tiles, N >= 1
-def run_cfg5(ctx, cpu):
-    """BASELINE configs[4]: 4 x 2 M x 4096 split by ping_time over the ranks (STRONG scaling), each rank's share as
-    resident tiles of <= 250 000 pings.  N = 1: Sv of every tile goes to one reused buffer (131 GB in + 262 GB out does
-    not fit 288 GB otherwise) and tile edges sit on bin edges.  N > 1: two layouts are timed, see the module docstring."""
-    args, torch, ops, sharding, synth, world, rank = ctx.args, ctx.torch, ctx.ops, ctx.sharding, ctx.synth, ctx.world, ctx.rank
-    C, _, S = WORKLOADS["cfg5"][:3]
-    P_total = args.pings_total or WORKLOADS["cfg5"][1]
-    dt = ctx.dt
-    bin_ns = 20_000_000_000
-    p0, p1 = sharding.shard_bounds(P_total, world, rank, align=20)
-    tile_p = min(TILE_PINGS, max(20, p1 - p0))
-    spans = [(a, min(p1, a + tile_p)) for a in range(p0, p1, tile_p)]
-    tiles = []
-    for a, b in spans:
-        d = synth.ek60_device(C, b - a, S, seed=20260505 + a // 20, ping0=a, ss_every=args.ss_every)
-        d["tau0"] = torch.full((C,), 1.024e-3, dtype=torch.float64, device="cuda")  # ping 0 of the WHOLE file
-        tiles.append(d)
-    n_r = len(np.arange(0, float((S - 1) * 2.56e-4 * 1500.5 / 2) + 1.0, 1.0)) - 1
-    esz = 8 if args.dtype == "float64" else 4
-    free_b = torch.cuda.mem_get_info()[0]
-    keep_all = sum((b - a) for a, b in spans) * C * S * esz < free_b - (8 << 30)  # Sv of every tile resident?
-    if keep_all:
-        sv = [torch.empty((C, b - a, S), dtype=dt, device="cuda") for a, b in spans]
-    else:  # one buffer, every tile writes its Sv through a contiguous view of it
-        buf = torch.empty((C, tile_p, S), dtype=dt, device="cuda")
-        sv = [buf.view(-1)[:C * (b - a) * S].view(C, b - a, S) for a, b in spans]
-    steps, warmup = ctx.steps("cfg5")
+class Cfg5:
+    """BASELINE configs[4]: C x P_total x S split by ping_time over the ranks, each rank's share as resident tiles of
+    <= tile_pings pings.  ``layout(offset_ns)`` builds the time grid, the exchange plan and one pass of the hot path
+    for ping times shifted by ``offset_ns`` against the 20-s grid (0: tile edges on bin edges, no exchange;
+    10 s: every tile / shard edge cuts a bin)."""
 
-    def layout(offset_ns):
-        """Time grid + exchange plan for ping times shifted by ``offset_ns`` against the 20-s grid."""
-        info = []
-        ts = [d["ping_time_ns"] + offset_ns for d in tiles]
+    BIN_NS = 20_000_000_000
+
+    def __init__(self, ctx, C, P_total, S, tile_pings=None, ss_every=1, range_bin=1.0):
+        torch, sharding, synth = ctx.torch, ctx.sharding, ctx.synth
+        self.ctx, self.C, self.S, self.P_total, self.range_bin = ctx, C, S, P_total, range_bin
+        if tile_pings is None:  # the tiling belongs to the WORKLOAD (eight tiles of the whole volume), not to the split
+            tile_pings = min(TILE_PINGS, -(-P_total // 160) * 20)
+        p0, p1 = sharding.shard_bounds(P_total, ctx.world, ctx.rank, align=tile_pings)
+        self.tile_p = min(tile_pings, max(20, p1 - p0))
+        self.spans = [(a, min(p1, a + self.tile_p)) for a in range(p0, p1, self.tile_p)]
+        self.tiles = []
+        for a, b in self.spans:
+            d = synth.ek60_device(C, b - a, S, seed=20260505 + a // 20, ping0=a, ss_every=ss_every)
+            d["tau0"] = torch.full((C,), 1.024e-3, dtype=torch.float64, device="cuda")  # ping 0 of the WHOLE file
+            self.tiles.append(d)
+        self.n_r = len(np.arange(0, float((S - 1) * 2.56e-4 * 1500.5 / 2) + range_bin, range_bin)) - 1
+        dt = ctx.dt
+        esz = 8 if ctx.dtype == "float64" else 4
+        free_b = torch.cuda.mem_get_info()[0]
+        self.keep_all = sum((b - a) for a, b in self.spans) * C * S * esz < free_b - (8 << 30)  # Sv of every tile resident?
+        if self.keep_all:
+            self.sv = [torch.empty((C, b - a, S), dtype=dt, device="cuda") for a, b in self.spans]
+        else:  # one buffer, every tile writes its Sv through a contiguous view of it
+            buf = torch.empty((C, self.tile_p, S), dtype=dt, device="cuda")
+            self.sv = [buf.view(-1)[:C * (b - a) * S].view(C, b - a, S) for a, b in self.spans]
+        self.shard = sharding.ShardContext()
+
+    def layout(self, offset_ns):
+        ctx, torch, ops, sharding = self.ctx, self.ctx.torch, self.ctx.ops, self.ctx.sharding
+        C, n_r, dt = self.C, self.n_r, ctx.dt
+        ts = [d["ping_time_ns"] + offset_ns for d in self.tiles]
         ends = np.array([int(x) for t in ts for x in (t[0], t[-1])], dtype=np.int64)
-        e0, _ = sharding.global_time_grid(ends, bin_ns)  # ONE grid for every tile of every rank
+        e0, _ = sharding.global_time_grid(ends, self.BIN_NS)  # ONE grid for every tile of every rank
+        info = []
         for t in ts:
-            f, l = sharding.local_bin_span(t[[0, -1]].cpu().numpy(), e0, bin_ns)
-            info.append((t, e0 + f * bin_ns, f, l, l - f + 1))
-        plan = sharding.EdgeExchange([(f, l) for _, _, f, l, _ in info], C, n_r, "cuda")
+            f, l = sharding.local_bin_span(t[[0, -1]].cpu().numpy(), e0, self.BIN_NS)
+            info.append((t, e0 + f * self.BIN_NS, f, l, l - f + 1))
+        plan = self.shard.plan([(f, l) for _, _, f, l, _ in info], C, n_r, "cuda")
         mv = [torch.empty((C, n, n_r), dtype=dt, device="cuda") for *_, n in info]
-        return info, plan, mv
+        dst = {(i, w): mv[i][:, 0 if w == 0 else -1] for i in range(len(mv)) for w in (0, 1)}
+        tiles, sv, rb = self.tiles, self.sv, self.range_bin
 
-    def make_step(info, plan, mv):
-        def step(timer):
+        def one_pass(timer):
             rows = {}
             for i, d in enumerate(tiles):
                 t, e0l, f, l, n_t = info[i]
                 coef = _coef(ctx, d)
-                bs = ops.time_bin_offsets(t, e0l, bin_ns, n_t)
+                bs = ops.time_bin_offsets(t, e0l, self.BIN_NS, n_t)
                 if timer is not None and i == 0:
                     timer.start()
-                res = ops.sv_mvbs_fused(d["backscatter_r"], coef, bs, n_t, 1.0, n_r, dtype=dt, sv_out=sv[i],
+                res = ops.sv_mvbs_fused(d["backscatter_r"], coef, bs, n_t, rb, n_r, dtype=dt, sv_out=sv[i],
                                         mvbs_out=mv[i], want_partials=plan.shared)
                 if timer is not None and i == 0:
                     timer.stop()
                 if plan.shared:
                     for w, r in sharding.mvbs_edge_rows(res["sum"], res["cnt"]).items():
                         rows[(i, w)] = r
-            if plan.shared:  # ONE all-reduce for every cut bin of every tile of every rank, then finalise the owners' rows
-                tot = plan.merge(rows)
-                for k, w, _, owner in plan.edges:
-                    if owner:
-                        s, c = tot[(k, w)]
-                        mv[k][:, 0 if w == 0 else -1] = ops.mvbs_finalize(s.to(dt).contiguous(), c.to(torch.int32).contiguous())
-        return step
+            if plan.shared:  # ONE all-reduce for every cut bin of every tile of every rank; owners finalise their rows
+                plan.merge_mvbs(rows, dst)
 
-    # (a) bin-aligned layout: no bin is shared, no collective
-    info_a, plan_a, mv_a = layout(0)
+        return info, plan, mv, one_pass
+
+
+def run_cfg5(ctx, cpu):
+    """N = 1: all eight tiles on one GPU (Sv of every tile goes to one reused buffer: 131 GB in + 262 GB out does not fit
+    288 GB otherwise).  Two layouts are timed; the headline is the one WITH the exchange, at every N."""
+    args, world = ctx.args, ctx.world
+    C, _, S = WORKLOADS["cfg5"][:3]
+    P_total = args.pings_total or WORKLOADS["cfg5"][1]
+    job = Cfg5(ctx, C, P_total, S, ss_every=args.ss_every)
+    passes = ctx.passes("cfg5")
+    # (a) bin-aligned layout: no bin is shared, no data collective
+    _, plan_a, mv_a, pass_a = job.layout(0)
     assert not plan_a.shared
-    el_a, km_a = ctx.timed(make_step(info_a, plan_a, mv_a), steps, warmup)
-    out_cfg = {"pings_total": P_total, "sharding": f"ping_time x{world}, {len(spans)} resident tile(s) of <= {tile_p} pings per rank",
-               "sv_resident": "every tile" if keep_all else "one reused tile buffer"}
-    elapsed, kernel_ms, coll = el_a, km_a, "none (tile and shard edges on bin edges)"
-    if world > 1 or len(spans) > 1:
-        del mv_a
-        # (b) ping times 10 s off the grid: every tile / shard edge cuts a bin -> edge-bin all-reduce on the timed path
-        info_b, plan_b, mv_b = layout(10_000_000_000)
-        assert plan_b.shared
-        el_b, km_b = ctx.timed(make_step(info_b, plan_b, mv_b), steps, warmup)
-        out_cfg.update(aligned_ms_per_step=el_a / steps * 1e3, straddle_ms_per_step=el_b / steps * 1e3,
-                       collective_ms_per_step=(el_b - el_a) / steps * 1e3,
-                       edge_bins_per_step=len(plan_b.edges), allreduce_bytes=int(plan_b._buf.numel() * 8))
-        if world > 1:  # the headline of an N > 1 run is the layout WITH the exchange
-            elapsed, kernel_ms = el_b, km_b
-            coll = (f"edge-bin all-reduce ({args.backend}): one all_reduce(SUM) of {plan_b._buf.numel() * 8} B per step "
-                    "for the time bins cut by tile / shard edges")
-    out_cfg["collective"] = coll
-    n_first = C * (spans[0][1] - spans[0][0]) * S if spans else 0
-    bps = BYTES_PER_SAMPLE[args.dtype]
-    if rank != 0:
+    el_a, km_a = ctx.timed(pass_a, passes)
+    del mv_a, pass_a
+    # (b) ping times 10 s off the grid: every tile / shard edge cuts a bin -> edge exchange on the timed path
+    _, plan_b, mv_b, pass_b = job.layout(10_000_000_000)
+    n_tiles_global = -(-P_total // job.tile_p)
+    single = world == 1 and len(job.spans) == 1
+    assert plan_b.shared or single
+    elapsed, kernel_ms = (ctx.timed(pass_b, passes) if not single else (el_a, km_a))
+    steps = args.steps
+    cfg = {"pings_total": P_total, "tiles": f"{n_tiles_global} x {job.tile_p} pings over {world} rank(s)",
+           "sv_resident": "every tile" if job.keep_all else "one reused tile buffer",
+           "collective": (f"edge-bin exchange ({args.backend if world > 1 else 'one rank: no all-reduce'}): pack kernel -> "
+                          f"all_reduce(SUM) of {plan_b.nbytes} B -> finalize kernel, per pass"),
+           "edge_bins_per_rank": len(plan_b.edges), "allreduce_bytes": plan_b.nbytes,
+           "aligned_ms_per_step": el_a / steps * 1e3, "exchange_ms_per_pass": (elapsed - el_a) / steps / passes * 1e3}
+    n_first = C * (job.spans[0][1] - job.spans[0][0]) * S if job.spans else 0
+    bps = BYTES_PER_SAMPLE[ctx.dtype]
+    if ctx.rank != 0:
         return None
-    return line(ctx, value=C * P_total * S * steps / elapsed, steps=steps, warmup=warmup, elapsed=elapsed,
-                scaling="strong", cpu=cpu,
-                workload=f"EK60 CW {C}ch x {P_total} pings x {S} range TOTAL (cfg5 = BASELINE configs[4]), split by "
-                         f"ping_time over {world} rank(s), fused compute_Sv -> compute_MVBS (20 s x 1 m), Sv + MVBS written",
-                config=out_cfg,
-                roofline=roofline("epa_fused::fused_sv_mvbs_kernel", kernel_ms, n_first * bps, bps,
-                                  note="kernel_ms = launch over one tile (rank 0, first tile)"))
+    return line(ctx, samples_per_pass=C * P_total * S, passes=passes, elapsed=elapsed, scaling="strong", cpu=cpu,
+                workload=f"cfg5: EK60 CW {C}x{P_total}x{S} TOTAL (BASELINE configs[4]) split by ping_time, fused "
+                         "compute_Sv->compute_MVBS(20s x 1m), Sv+MVBS out, tile edges cut time bins",
+                config=cfg,
+                roofline=roofline("fused_sv_mvbs_kernel", kernel_ms, n_first * bps, bps,
+                                  traffic_key=f"cfg5:{ctx.dtype}", launch="one 250000-ping tile (rank 0, first tile)"))
 
 
 # ---------------------------------------------------------------------------------------- main
 def relaunch(args):
-    """`python bench.py --gpus N` without a launcher: start one rank per GPU and pass its single JSON line through."""
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU and pass its JSON line through."""
     import socket
 
     with socket.socket() as s:
@@ -575,6 +617,12 @@ def relaunch(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+def summary(out):
+    r = out["roofline"]
+    return (f"{out['value'] / 1e9:.1f} Gsamp/s {out['dtype']}, {out['config']['ms_per_pass']:.2f} ms/pass, kernel "
+            f"{r['kernel_ms']:.2f} ms, frac {r['frac']:.3f}")[:118]
 
 
 def main():
@@ -593,12 +641,16 @@ def main():
     elif args.workload:
         todo = [args.workload]
     else:
-        todo = (["cfg2"] if args.only_headline else ["cfg3", "cfg4", "cfg4:f32", "cfg5", "cfg2"])
-    # CPU baselines first: they fork worker processes, which must happen before HIP is initialised
+        todo = ["cfg5"] if args.only_headline else list(DEFAULT_LINES)
+
+    def kind_of(w):
+        return {"cfg3": "chain", "cfg4": "bb", "cfg4small": "bb"}.get(w.partition(":")[0], "ek60")
+
+    # CPU baselines first (rank 0): they fork worker processes, which must happen before HIP is initialised
     cpu = {}
-    if world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         for w in todo:
-            kind = {"cfg3": "chain", "cfg4": "bb", "cfg4small": "bb"}.get(w.partition(":")[0], "ek60")
+            kind = kind_of(w)
             if kind not in cpu:
                 cpu[kind] = (cpu_baseline_bb() if kind == "bb" else
                              cpu_baseline_ek60(chain=kind == "chain", multicore=kind == "ek60"))
@@ -613,24 +665,32 @@ def main():
         else:
             dist.init_process_group("gloo")
     ctx = Ctx(args, world, rank)
-    for w in todo:
-        w, _, other_dtype = w.partition(":")  # "cfg4:f32": the same workload with float32 output (complex64 transform)
-        kind = {"cfg3": "chain", "cfg4": "bb", "cfg4small": "bb"}.get(w, "ek60")
-        asked = args.dtype
-        if other_dtype:
-            args.dtype = {"f32": "float32", "f64": "float64"}[other_dtype]
-            ctx.dt = torch.float64 if args.dtype == "float64" else torch.float32
+    also = {}
+    for i, spec in enumerate(todo):
+        w, _, variant = spec.partition(":")
+        if w not in WORKLOADS:
+            sys.exit(f"unknown workload {w!r}")
+        ctx.dtype = DT.get(variant, args.dtype)
         if w == "cfg5":
-            out = run_cfg5(ctx, cpu.get(kind))
+            ctx.cache.clear()
+            ctx.free()
+            out = run_cfg5(ctx, cpu.get("ek60"))
+        elif w == "api":
+            out = run_api(ctx, cpu.get("ek60"))
         elif w.startswith("cfg4"):
-            out = run_ek80(ctx, w, cpu.get(kind))
+            out = run_ek80(ctx, w, variant, cpu.get("bb"))
         else:
-            out = run_ek60(ctx, w, cpu.get(kind))
+            out = run_ek60(ctx, w, variant, cpu.get(kind_of(w)))
         if rank == 0 and out is not None:
-            print(json.dumps(out), flush=True)
+            if i == len(todo) - 1 and also:  # the parsed line carries the others' key figures (flat, short strings)
+                out["config"].update(also)
+            also["also_" + spec.replace(":", "_")] = summary(out)
+            txt = json.dumps(out)
+            print(txt, flush=True)
+            if args.out:
+                with open(args.out, "a") as f:
+                    f.write(txt + "\n")
         ctx.free()
-        args.dtype = asked
-        ctx.dt = torch.float64 if asked == "float64" else torch.float32
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -88,6 +88,9 @@ SIGNATURES = {
     "epa_selftest_log10": [_vp, _vp, _sz, _vp],
     "epa_selftest_log10_inline": [_vp, _vp, _sz, _vp],
     "epa_mvbs_finalize": [_vp, _vp, _sz, _d, _vp, _i, _vp],
+    "epa_edge_pack": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "epa_edge_gather": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "epa_edge_finalize_mvbs": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, _i, _vp],
     "epa_affine_rows": [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
     "epa_depth_rows": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "epa_nanminmax": [_vp, _sz, _i, _vp, _vp, _vp],

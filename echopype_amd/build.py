@@ -21,7 +21,7 @@ LIBPATH = os.path.join(LIBDIR, f"libechopype_amd{('_' + VARIANT) if VARIANT else
 OBJDIR = os.path.join(HERE, "csrc", "_obj" + (("_" + VARIANT) if VARIANT else ""))
 
 SOURCES = ["runtime.hip", "power_coef.hip", "sv_power.hip", "block_reduce.hip", "fused_sv_mvbs.hip", "noise_apply.hip", "reduce_util.hip",
-           "ek80_complex.hip", "ek80_fft.hip", "noise_masks.hip", "nasc.hip", "chain_fast.hip"]
+           "ek80_complex.hip", "ek80_fft.hip", "noise_masks.hip", "nasc.hip", "chain_fast.hip", "edge_exchange.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))
 EXTRA = os.environ.get("EPA_EXTRA_FLAGS", "").split()
 FLAGS = [*EXTRA, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",

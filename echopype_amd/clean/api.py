@@ -63,10 +63,10 @@ def _estimate(ds_Sv, ping_num, range_sample_num, background_noise_max, shard=Non
     else:  # one rank's ping shard: blocks count from the dataset's first ping; blocks cut by a shard edge are merged
         from .. import sharding
 
-        ping_offset, group = shard
+        ping_offset, group, ctx = shard
         noise, es, ec = ops.noise_estimate(sv_t, a2, ping_num, range_sample_num, noise_max=nmax, **_rng_kw(rg_t),
                                            ping_phase=ping_offset % ping_num, want_edges=True)
-        sharding.merge_noise_edges(noise, es, ec, ping_offset, sv_t.shape[1], ping_num, nmax, group)
+        sharding.merge_noise_edges(noise, es, ec, ping_offset, sv_t.shape[1], ping_num, nmax, group, shard=ctx)
     return order, sv_t, rg_t, a2, noise, background_noise_max
 
 
@@ -84,7 +84,7 @@ def estimate_background_noise(ds_Sv, ping_num, range_sample_num, background_nois
 def remove_background_noise(ds_Sv, ping_num, range_sample_num, background_noise_max=None,
                             SNR_threshold="3.0dB", _shard=None):
     """Adds Sv_noise and Sv_corrected to ``ds_Sv`` and returns it (api.py:472-511).
-    (``_shard`` = (ping_offset, group): set by echopype_amd.sharding.remove_background_noise.)"""
+    (``_shard`` = (ping_offset, group, ShardContext | None): set by echopype_amd.sharding.remove_background_noise.)"""
     ds_Sv = from_xarray(ds_Sv)
     if SNR_threshold is not None:
         SNR_threshold = extract_dB(SNR_threshold)

@@ -86,11 +86,15 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
     if n_cap < 1:  # degenerate grid (one sample per ping, no valid range): the two calls deal with it
         ds_Sv = _compute_cal("Sv", echodata, **cal_kw)
         return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)
+    res = None
     try:
         res = ops.sv_mvbs_fused(raw, coef, bin_start, n_t, range_bin_m, n_cap, cal_flags=flags, skipna=True,
                                 closed="left", fill_value=fill_value, dtype=cal.dtype, want_range_max=True,
                                 want_partials=_shard is not None)
     except _lib.EpaError:  # e.g. a range grid too fine for the LDS accumulators: two calls instead
+        pass
+    # on a shard the fallback changes the collectives that follow: every rank takes it if any rank must
+    if (res is None) if _shard is None else _shard.agree(res is None):
         ds_Sv = _compute_cal("Sv", echodata, **cal_kw)
         return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)
     rmax = r_cap if range_var_max is not None else float(res["range_max"].item())

@@ -649,3 +649,61 @@ def sv_denoise_mvbs(raw, coef, alpha2, noise, ping_num, snr_threshold, bin_start
          float(fill_value), _p(sn), _p(sc), _p(rng), _p(out), _p(ssum), _p(cnt), _p(mm), _DT[dtype], _stream())
     return dict(MVBS=out, Sv_noise=sn, Sv_corrected=sc, echo_range=rng, sum=ssum, cnt=cnt,
                 minmax=mm.cpu().tolist() if want_minmax else None)
+
+
+# ---- cross-shard edge exchange (pack -> all-reduce -> gather) ------------------------------------------------
+
+def edge_pack(buf, rows, zero_first=True):
+    """rows: [(slot, sum (C, R) f32/f64 view with unit inner stride, cnt (C, R) int32 view)] -> slots of ``buf``
+    (n_slots, 2, C, R) f64, everything else zero."""
+    n_slots, _, C, R = buf.shape
+    n = len(rows)
+    sums, cnts = (ctypes.c_void_p * max(n, 1))(), (ctypes.c_void_p * max(n, 1))()
+    strides, slots = (ctypes.c_longlong * max(n, 1))(), (ctypes.c_int * max(n, 1))()
+    dt = None
+    for i, (slot, s, c) in enumerate(rows):
+        if not (s.is_cuda and c.is_cuda) or tuple(s.shape) != (C, R) or tuple(c.shape) != (C, R):
+            raise ValueError(f"edge_pack: row {i} must be a pair of ({C}, {R}) device tensors")
+        if s.stride(1) != 1 or c.stride(1) != 1 or s.stride(0) != c.stride(0) or c.dtype != torch.int32 or s.dtype not in _DT:
+            raise ValueError("edge_pack: rows need unit inner stride, equal channel strides, f32/f64 sums and int32 counts")
+        if dt is not None and s.dtype != dt:
+            raise ValueError("edge_pack: rows of mixed dtypes")
+        dt = s.dtype
+        sums[i], cnts[i], strides[i], slots[i] = s.data_ptr(), c.data_ptr(), s.stride(0), int(slot)
+    call("epa_edge_pack", sums, cnts, strides, slots, n, _DT[dt if dt is not None else torch.float64], C, R, n_slots,
+         1 if zero_first else 0, _p(buf), _stream())
+    return buf
+
+
+def edge_gather(buf, group_off, group_slots, n_edges, *, typed=None):
+    """Totals of the shared edges from the all-reduced buffer: (n_edges, 2, C, R) f64, or with ``typed`` (a torch
+    dtype) the pair (sum (n_edges, C, R) of that dtype, count (n_edges, C, R) int32) that mvbs_finalize takes."""
+    n_slots, _, C, R = buf.shape
+    dev = buf.device
+    if typed is None:
+        tot = torch.empty((n_edges, 2, C, R), dtype=torch.float64, device=dev)
+        call("epa_edge_gather", _p(buf), n_slots, _p(group_off), _p(group_slots), n_edges, C, R, _p(tot), None, None,
+             _lib.F64, _stream())
+        return tot
+    s = torch.empty((n_edges, C, R), dtype=typed, device=dev)
+    c = torch.empty((n_edges, C, R), dtype=torch.int32, device=dev)
+    call("epa_edge_gather", _p(buf), n_slots, _p(group_off), _p(group_slots), n_edges, C, R, None, _p(s), _p(c),
+         _DT[typed], _stream())
+    return s, c
+
+
+def edge_finalize_mvbs(buf, group_off, group_slots, rows, fill_value=float("nan")):
+    """rows: [(edge index, dst (C, R) f32/f64 view with unit inner stride)]: the merged, finalised MVBS of those shared
+    edges (10 log10(sum / count) of the all-reduced totals) written straight into the rows ``dst``."""
+    n_slots, _, C, R = buf.shape
+    n = len(rows)
+    if n == 0:
+        return
+    edges, dsts, strides = (ctypes.c_int * n)(), (ctypes.c_void_p * n)(), (ctypes.c_longlong * n)()
+    dt = rows[0][1].dtype
+    for i, (e, d) in enumerate(rows):
+        if not d.is_cuda or tuple(d.shape) != (C, R) or d.stride(1) != 1 or d.dtype != dt or dt not in _DT:
+            raise ValueError(f"edge_finalize_mvbs: row {i} must be a ({C}, {R}) f32/f64 device view with unit inner stride")
+        edges[i], dsts[i], strides[i] = int(e), d.data_ptr(), d.stride(0)
+    call("epa_edge_finalize_mvbs", _p(buf), n_slots, _p(group_off), _p(group_slots), edges, dsts, strides, n, C, R,
+         float(fill_value), _DT[dt], _stream())

@@ -12,10 +12,13 @@ quantities are
 Both exchanges have the same shape and share one mechanism, ``EdgeExchange``: a shard is a list of SEGMENTS
 (resident tiles; one per rank in the simplest case), every segment contributes the raw linear (sum, count) rows
 of its FIRST and LAST bin / block, one all-reduce(SUM) moves a (slots, 2, C, R) fp64 buffer (a few hundred KB:
-latency-bound on xGMI, never bandwidth-bound), and every holder of a shared bin reads the total back.  The slot
-topology is exchanged ONCE (host, at plan time); a step is: pack (device) -> all_reduce -> one small matrix
-product that adds the slots of each shared bin (device) -- no host synchronisation on the data path.
-When no bin is shared (shard edges on bin edges) the exchange is skipped: no collective at all.
+latency-bound on xGMI, never bandwidth-bound), and every holder of a shared bin reads the total back.
+Building a plan (the slot topology) is collective: two small all-reduces and host reads, once per layout -- the
+product entry points below build it per call (a dataset is calibrated once); a ``ShardContext`` passed as ``shard=``
+keeps plans between calls on the same layout (one scalar all-reduce per call checks that every rank still holds
+its plan).  A data step is: epa_edge_pack (device) -> all_reduce -> epa_edge_gather / epa_edge_finalize_mvbs
+(device) -- hand-written kernels on torch's stream, no host synchronisation, no library GEMM.
+When no bin is shared (shard edges on bin edges) the exchange is skipped: no data collective at all.
 
 Product entry points (same signatures as the single-process functions plus ``group`` / ``ping_offset``):
 ``compute_MVBS``, ``compute_Sv_MVBS``, ``remove_background_noise``.  Kernels are called through ops.
@@ -29,6 +32,12 @@ NO_BIN = -(2**62)  # id of an absent edge (matches nothing)
 
 def _world(group=None):
     return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
+def _collective(group=None):
+    """Collectives run whenever a process group exists -- also at world size 1, where they are identities: the code
+    path (communication buffer in HBM under RCCL, the all-reduce on it) is then the one N > 1 takes."""
+    return dist.is_initialized()
 
 
 def _rank(group=None):
@@ -58,7 +67,7 @@ def global_time_grid(local_ping_ns, dt_ns, group=None):
     t = t[t != np.iinfo(np.int64).min]
     lo = torch.tensor([t.min() if t.size else np.iinfo(np.int64).max], dtype=torch.int64)
     hi = torch.tensor([t.max() if t.size else np.iinfo(np.int64).min + 1], dtype=torch.int64)
-    if _world(group) > 1:
+    if _collective(group):
         dev = _comm_device(group)
         lo, hi = lo.to(dev), hi.to(dev)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
@@ -74,7 +83,7 @@ def global_max(value, group=None):
     """all-reduce MAX of one float (e.g. nanmax(echo_range) for the range grid, api.py:110); NaN = nothing here."""
     v = float(value)
     t = torch.tensor([v if v == v else -np.inf], dtype=torch.float64)
-    if _world(group) > 1:
+    if _collective(group):
         t = t.to(_comm_device(group))
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
@@ -104,15 +113,25 @@ class EdgeExchange:
       totals = plan.merge(rows) -- rows[(segment, which)] = (sum (C, R), count (C, R)) raw linear partials of every
                                local edge listed in plan.edges; returns {(segment, which): (sum, count)} fp64
                                totals over all segments of all ranks.  ONE all-reduce.
+      plan.merge_mvbs(rows, dst, fill) -- the same exchange, then the owners' cut bins finalised
+                               (10 log10(sum / count)) straight into their rows dst[(segment, which)] of the MVBS arrays.
     A segment with a single bin contributes it once (as its first edge).
+
+    Building a plan is collective (two small all-reduces + host reads of the topology); merge() on device rows is
+    epa_edge_pack -> all_reduce -> epa_edge_gather / epa_edge_finalize_mvbs on torch's current stream: hand-written
+    kernels, no host synchronisation, no library GEMM.  Under RCCL ("nccl") the communication buffer lives in HBM;
+    under gloo (dry runs) it is staged through a pinned host buffer.  CPU tensors (``device="cpu"``: the slot
+    bookkeeping tests of tests/test_sharding_gloo.py, which have no GPU) take an index-add on the host instead of the
+    two kernels -- device rows never do.
     """
 
     def __init__(self, spans, C, R, device, group=None):
         self.group, self.C, self.R = group, int(C), int(R)
         self.device = torch.device(device)
+        self.key = (tuple((int(f), int(l)) for f, l in spans), self.C, self.R, str(self.device))
         world, rank = _world(group), _rank(group)
         nseg = torch.tensor([len(spans)], dtype=torch.int64)
-        if world > 1:
+        if _collective(group):
             nseg = nseg.to(_comm_device(group))
             dist.all_reduce(nseg, op=dist.ReduceOp.MAX, group=group)
         self.max_seg = int(nseg.item())
@@ -122,7 +141,7 @@ class EdgeExchange:
                 ids[rank, k, 0] = f
                 if l != f:
                     ids[rank, k, 1] = l
-        if world > 1:  # every rank fills its own rows, the others are 0 after the shift
+        if _collective(group):  # every rank fills its own rows, the others are 0 after the shift
             t = torch.zeros((world, self.max_seg, 2), dtype=torch.int64)
             t[rank] = torch.from_numpy(ids[rank] - NO_BIN)
             t = t.to(_comm_device(group))
@@ -134,7 +153,7 @@ class EdgeExchange:
         for slot, b in enumerate(flat):
             if b != NO_BIN:
                 groups.setdefault(int(b), []).append(slot)
-        self.edges, rows = [], []
+        self.edges, goff, gslots = [], [0], []
         base = rank * self.max_seg * 2
         for k in range(len(spans)):
             for which in (0, 1):
@@ -142,32 +161,106 @@ class EdgeExchange:
                 if b == NO_BIN or len(groups[b]) < 2:
                     continue
                 self.edges.append((k, which, b, groups[b][0] == base + 2 * k + which))
-                m = np.zeros(self.n_slots)
-                m[groups[b]] = 1.0
-                rows.append(m)
+                gslots += groups[b]  # ascending slot order: the same order of additions on every holder
+                goff.append(len(gslots))
         self.shared = any(len(g) > 1 for g in groups.values())
         self._slot = {(k, w): base + 2 * k + w for k, w, _, _ in self.edges}
-        self._cdev = _comm_device(group) if world > 1 else self.device  # host buffer under gloo
-        self._buf = torch.zeros((self.n_slots, 2, self.C, self.R), dtype=torch.float64, device=self._cdev) \
-            if self.shared else None
-        self._pick = torch.from_numpy(np.stack(rows)).to(self._cdev) if rows else None
-
-    def merge(self, rows):
+        self._index = {(k, w): i for i, (k, w, _, _) in enumerate(self.edges)}
+        self._goff_host, self._gslots_host = np.asarray(goff, dtype=np.int32), np.asarray(gslots, dtype=np.int32)
+        self._buf = self._hbuf = self._goff = self._gslots = None
         if not self.shared:
-            return {}
+            return
+        self._buf = torch.zeros((self.n_slots, 2, self.C, self.R), dtype=torch.float64, device=self.device)
+        if self.device.type == "cuda":
+            self._goff = torch.from_numpy(self._goff_host).to(self.device)
+            self._gslots = torch.from_numpy(self._gslots_host if gslots else np.zeros(1, np.int32)).to(self.device)
+            if _collective(group) and _comm_device(group).type == "cpu":  # gloo dry run: staged through pinned host memory
+                self._hbuf = torch.empty(self._buf.shape, dtype=torch.float64, pin_memory=True)
+
+    @property
+    def nbytes(self):
+        """Bytes one all-reduce moves."""
+        return 0 if self._buf is None else self._buf.numel() * 8
+
+    def _exchange(self, rows):
+        """pack -> all-reduce; leaves the reduced slots in self._buf."""
         buf = self._buf
-        buf.zero_()
+        if self.device.type == "cuda":
+            from . import ops
+
+            ops.edge_pack(buf, [(self._slot[key], s, c) for key, (s, c) in rows.items() if key in self._slot])
+            if _collective(self.group):
+                if self._hbuf is None:  # RCCL: the buffer is reduced where it lies
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                else:
+                    self._hbuf.copy_(buf)
+                    dist.all_reduce(self._hbuf, op=dist.ReduceOp.SUM, group=self.group)
+                    buf.copy_(self._hbuf)
+            return
+        buf.zero_()  # CPU tensors: bookkeeping tests
         for key, (s, c) in rows.items():
             slot = self._slot.get(key)
             if slot is not None:
                 buf[slot, 0].copy_(s)
                 buf[slot, 1].copy_(c)
-        if _world(self.group) > 1:
+        if _collective(self.group):
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-        if self._pick is None:
+
+    def merge(self, rows):
+        if not self.shared:
             return {}
-        tot = (self._pick @ buf.view(self.n_slots, -1)).view(len(self.edges), 2, self.C, self.R).to(self.device)
+        self._exchange(rows)
+        if not self.edges:
+            return {}
+        if self.device.type == "cuda":
+            from . import ops
+
+            tot = ops.edge_gather(self._buf, self._goff, self._gslots, len(self.edges))
+        else:
+            tot = torch.stack([self._buf[self._gslots_host[a:b].tolist()].sum(0)
+                               for a, b in zip(self._goff_host[:-1], self._goff_host[1:])])
         return {(k, w): (tot[i, 0], tot[i, 1]) for i, (k, w, _, _) in enumerate(self.edges)}
+
+    def merge_mvbs(self, rows, dst, fill_value=float("nan")):
+        """The exchange, then every OWNED cut bin finalised into ``dst[(segment, which)]`` ((C, R) views of the MVBS
+        arrays, device): two kernel launches around the all-reduce for any number of bins up to 16."""
+        if not self.shared:
+            return
+        self._exchange(rows)
+        from . import ops
+
+        ops.edge_finalize_mvbs(self._buf, self._goff, self._gslots,
+                               [(self._index[(k, w)], dst[(k, w)]) for k, w, _, owner in self.edges if owner], fill_value)
+
+
+class ShardContext:
+    """Keeps exchange plans between calls on the same layout (a plan costs two small all-reduces and host reads; a
+    pipeline that calls the sharded functions once per file of a survey, or the bench once per step, builds it once).
+    ``plan()`` is collective: one scalar all-reduce(MIN) tells every rank whether ALL ranks hold the plan for their
+    key, so a rank whose layout changed can never run a different collective sequence from the others."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self._plans = {}
+
+    def plan(self, spans, C, R, device):
+        key = (tuple((int(f), int(l)) for f, l in spans), int(C), int(R), str(torch.device(device)))
+        hit = torch.tensor([1 if key in self._plans else 0], dtype=torch.int32)
+        if _collective(self.group):
+            hit = hit.to(_comm_device(self.group))
+            dist.all_reduce(hit, op=dist.ReduceOp.MIN, group=self.group)
+        if int(hit.item()) == 0:
+            self._plans[key] = EdgeExchange(spans, C, R, device, self.group)
+        return self._plans[key]
+
+    def agree(self, flag):
+        """True on every rank if ``flag`` is true on any (all-reduce MAX of one int): decisions that change the
+        sequence of collectives that follows (a fallback after a rank-local error) are taken together."""
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        if _collective(self.group):
+            t = t.to(_comm_device(self.group))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(int(t.item()))
 
 
 # ---- MVBS time bins ----------------------------------------------------------------------------------------------
@@ -180,14 +273,16 @@ def mvbs_edge_rows(ssum, cnt):
     return out
 
 
-def merge_straddling_bins(ssum, cnt, first_bin, last_bin, group=None):
+def merge_straddling_bins(ssum, cnt, first_bin, last_bin, group=None, shard=None):
     """One-segment convenience form: merge the partial sums of time bins shared between ranks.
     ssum, cnt : (C, n_local_bins, R) raw linear sums / counts, local bin j == global bin first_bin + j; modified
     in place so that every shared bin holds the global total.  Returns ``keep`` (bool per local bin): False for
     shared bins reported by a lower rank."""
     n_local = ssum.shape[1]
     keep = np.ones(n_local, dtype=bool)
-    plan = EdgeExchange([(first_bin, last_bin) if n_local else (0, -1)], ssum.shape[0], ssum.shape[2], ssum.device, group)
+    spans = [(first_bin, last_bin) if n_local else (0, -1)]
+    plan = (shard.plan if shard is not None else lambda *a: EdgeExchange(*a, group))(spans, ssum.shape[0], ssum.shape[2],
+                                                                                   ssum.device)
     rows = {(0, w): r for w, r in mvbs_edge_rows(ssum, cnt).items()} if n_local else {}
     for (k, w), (s, c) in plan.merge(rows).items():
         j = 0 if w == 0 else n_local - 1
@@ -207,13 +302,15 @@ def noise_block_span(ping_offset, P, ping_num):
 
 
 def merge_noise_edges(noise, edge_sum, edge_cnt, ping_offset, P, ping_num, noise_max=float("nan"), group=None,
-                      finalize=None):
+                      finalize=None, shard=None):
     """Replace the noise of the shard's first / last ping block by the value over the WHOLE block when a shard edge
     cuts it (clean/api.py:402-411: mean over the block, then dB, then min over range blocks).
     noise (C, n_blocks) f64, edge_sum / edge_cnt (2, C, Sb) from ops.noise_estimate(want_edges=True); in place.
     ``finalize(sum (rows, Sb), cnt (rows, Sb)) -> (rows,)``: epa_noise_finalize by default."""
     C, nb = noise.shape
-    plan = EdgeExchange([noise_block_span(ping_offset, P, ping_num)], C, edge_sum.shape[2], noise.device, group)
+    spans = [noise_block_span(ping_offset, P, ping_num)]
+    plan = shard.plan(spans, C, edge_sum.shape[2], noise.device) if shard is not None else \
+        EdgeExchange(spans, C, edge_sum.shape[2], noise.device, group)
     rows = {(0, 0): (edge_sum[0], edge_cnt[0])}
     if nb > 1:
         rows[(0, 1)] = (edge_sum[1], edge_cnt[1])
@@ -230,23 +327,21 @@ def merge_noise_edges(noise, edge_sum, edge_cnt, ping_offset, P, ping_num, noise
 
 
 def remove_background_noise(ds_Sv, ping_num, range_sample_num, background_noise_max=None, SNR_threshold="3.0dB", *,
-                            ping_offset, group=None):
+                            ping_offset, group=None, shard=None):
     """clean.remove_background_noise on THIS rank's ping shard of a longer dataset: ``ping_offset`` = global index
     of the shard's first ping.  Adds Sv_noise / Sv_corrected to ``ds_Sv`` exactly as the single-process call on
     the whole dataset would for these pings."""
     from .clean import api as clean_api
 
     return clean_api.remove_background_noise(ds_Sv, ping_num, range_sample_num, background_noise_max, SNR_threshold,
-                                             _shard=(int(ping_offset), group))
+                                             _shard=(int(ping_offset), group, shard))
 
 
 # ---- compute_MVBS / compute_Sv_MVBS on a shard -----------------------------------------------------------------------
 
-class MVBSShard:
-    """Hooks the single-process compute_MVBS calls when it runs on one rank's shard (commongrid/api.py)."""
-
-    def __init__(self, group=None):
-        self.group = group
+class MVBSShard(ShardContext):
+    """Hooks the single-process compute_MVBS calls when it runs on one rank's shard (commongrid/api.py); a
+    ShardContext, so an instance handed to several calls keeps its exchange plans."""
 
     def time_grid(self, ns, dt, closed):
         e0, n_glob = global_time_grid(ns, dt, self.group)
@@ -259,29 +354,32 @@ class MVBSShard:
     def finish(self, res, first_bin, last_bin, fill_value):
         """Merged, finalised MVBS of the bins this rank reports: (tensor (C, n_kept, R), index of the first kept
         local bin)."""
-        from . import ops
-
         ssum, cnt, mv = res["sum"], res["cnt"], res["MVBS"]
         n_local = mv.shape[1]
-        plan = EdgeExchange([(first_bin, last_bin) if n_local else (0, -1)], mv.shape[0], mv.shape[2], mv.device,
-                            self.group)
+        plan = self.plan([(first_bin, last_bin) if n_local else (0, -1)], mv.shape[0], mv.shape[2], mv.device)
         rows = {(0, w): r for w, r in mvbs_edge_rows(ssum, cnt).items()} if n_local else {}
-        tot = plan.merge(rows)
+        plan.merge_mvbs(rows, {(0, 0): mv[:, 0], (0, 1): mv[:, n_local - 1]} if n_local else {}, fill_value)
         lo, hi = 0, n_local
         for k, w, _, owner in plan.edges:
-            j = 0 if w == 0 else n_local - 1
             if owner:
-                s, c = tot[(k, w)]
-                mv[:, j] = ops.mvbs_finalize(s.to(mv.dtype).contiguous(), c.to(torch.int32).contiguous(), fill_value)
-            elif w == 0:
+                continue
+            if w == 0:
                 lo = 1
             else:
                 hi = n_local - 1
         return mv[:, lo:max(lo, hi)], lo
 
 
+def _context(group, shard):
+    if shard is None:
+        return MVBSShard(group)
+    if not isinstance(shard, MVBSShard):
+        raise TypeError("shard= takes a sharding.MVBSShard (a ShardContext with the compute_MVBS hooks)")
+    return shard
+
+
 def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="20s", skipna=True, fill_value=np.nan,
-                 closed="left", range_var_max=None, *, group=None):
+                 closed="left", range_var_max=None, *, group=None, shard=None):
     """commongrid.compute_MVBS on THIS rank's ping shard.  The time grid (day origin) and the range grid are those
     of the whole dataset; a time bin cut by a shard edge is summed over all its pings (one small all-reduce) and
     reported by the lowest rank holding it.  Returns the MVBS dataset of the bins this rank reports; concatenating
@@ -289,13 +387,13 @@ def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="
     from .commongrid import api as cg_api
 
     return cg_api.compute_MVBS(ds_Sv, range_var, range_bin, ping_time_bin, skipna=skipna, fill_value=fill_value,
-                               closed=closed, range_var_max=range_var_max, _shard=MVBSShard(group))
+                               closed=closed, range_var_max=range_var_max, _shard=_context(group, shard))
 
 
-def compute_Sv_MVBS(echodata, *, tau_effective_first_ping=None, group=None, **kw):
+def compute_Sv_MVBS(echodata, *, tau_effective_first_ping=None, group=None, shard=None, **kw):
     """fused.compute_Sv_MVBS on THIS rank's ping shard (see compute_MVBS above for the grid and the shared bins).
     EK60: tau_effective is ping 0 of the WHOLE file (calibrate_ek.py:154-162) -- pass the (channel,) values of the
     global first ping as ``tau_effective_first_ping`` on every rank but the first (None = this shard's own ping 0)."""
     from . import fused
 
-    return fused.compute_Sv_MVBS(echodata, _shard=MVBSShard(group), _tau_first=tau_effective_first_ping, **kw)
+    return fused.compute_Sv_MVBS(echodata, _shard=_context(group, shard), _tau_first=tau_effective_first_ping, **kw)

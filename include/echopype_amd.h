@@ -203,6 +203,34 @@ int epa_selftest_log10_inline(const double* x, double* out, size_t n, epa_stream
 int epa_mvbs_finalize(const void* sum, const uint32_t* cnt, size_t n, double fill_value, void* out,
                       int dtype, epa_stream_t stream);
 
+/* ---- cross-shard edge exchange (no reference counterpart: the reference is single-process) -------------
+ * A ping-sharded dataset sums an MVBS time bin over ALL its pings (commongrid/utils.py:614-627) and takes a background-
+ * noise block's mean before the minimum over range blocks (clean/api.py:402-411): the raw linear (sum, count) rows of
+ * the bins / blocks cut by a shard or tile edge are exchanged.  One step = epa_edge_pack -> ONE all-reduce(SUM) of
+ * `buf` (torch.distributed: RCCL over xGMI, the buffer stays in HBM) -> epa_edge_gather.
+ * buf: f64 [n_slots * 2 * C * R], slot layout (slot, {sum, count}, channel, range bin).
+ * epa_edge_pack: HOST tables of n_rows device rows: element (c, r) of row i at sum_rows[i][c * chan_stride[i] + r]
+ * (sum_dtype EPA_F32 / EPA_F64) and cnt_rows[i][...] (u32), written to slot slots[i]; zero_first clears the whole
+ * buffer before (slots of absent edges must be 0 for the SUM).
+ * epa_edge_gather: for local shared edge e, the sum of the slots group_slots[group_off[e] .. group_off[e+1]) (device
+ * int32 tables built once per plan), added in table order -- the same order on every rank, so every holder of a bin
+ * reads bit-identical totals.  Outputs (each optional): totals_out f64 [n_edges * 2 * C * R] (sum and count planes, what
+ * epa_noise_finalize takes); sum_out [n_edges * C * R] of sum_dtype + cnt_out u32 [n_edges * C * R] (what
+ * epa_mvbs_finalize takes).
+ * epa_edge_finalize_mvbs: gather + 10 log10(sum / count) (fill_value where the count is 0; the arithmetic of
+ * epa_mvbs_finalize on the totals rounded to dtype) of the listed edges (HOST tables: edges[i] = index into group_off,
+ * dst_rows[i] = device row with element (c, r) at [c * chan_stride[i] + r] of dtype) -- the owner of a cut time bin
+ * writes the bin's row of its MVBS array in one launch. */
+int epa_edge_pack(const void* const* sum_rows, const uint32_t* const* cnt_rows, const long long* chan_stride,
+                  const int* slots, int n_rows, int sum_dtype, int C, int R, int n_slots, int zero_first, double* buf,
+                  epa_stream_t stream);
+int epa_edge_gather(const double* buf, int n_slots, const int32_t* group_off, const int32_t* group_slots, int n_edges,
+                    int C, int R, double* totals_out, void* sum_out, uint32_t* cnt_out, int sum_dtype,
+                    epa_stream_t stream);
+int epa_edge_finalize_mvbs(const double* buf, int n_slots, const int32_t* group_off, const int32_t* group_slots,
+                           const int* edges, void* const* dst_rows, const long long* chan_stride, int n_rows, int C,
+                           int R, double fill_value, int dtype, epa_stream_t stream);
+
 /* ---- depth = offset[c,p] + scale[c,p] * echo_range -----------------------------------------------------------
  * The array pass of consolidate.add_depth (consolidate/api.py:226: transducer_depth +
  * orientation * echo_range * cos(tilt)); SURVEY 8f "next" row 1.  x, out: [C*P*S] of dtype;

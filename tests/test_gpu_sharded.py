@@ -112,3 +112,150 @@ def test_sharded_entry_points_equal_single_process(split):
     got2, t2 = cat(7, 8)
     np.testing.assert_array_equal(t2, np.asarray(mv2["ping_time"].values))
     np.testing.assert_allclose(got2, np.asarray(mv2["Sv"].values), rtol=1e-12, atol=1e-12, equal_nan=True)
+
+
+# ---- the exchange kernels themselves (one process, several segments: the shared bins are between tiles) --------------
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_edge_exchange_kernels_equal_numpy_bookkeeping(dtype):
+    """epa_edge_pack -> epa_edge_gather / epa_edge_finalize_mvbs on device rows == the slot arithmetic in NumPy: four
+    segments, bins shared by two and by three of them, a single-bin segment, an empty one."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need a GPU")
+    from echopype_amd import ops, sharding
+
+    tdt = getattr(torch, dtype)
+    C, R = 3, 37
+    spans = [(0, 4), (4, 4), (4, 9), (0, -1), (9, 12)]  # bin 4 held by three segments, bin 9 by two, one empty segment
+    rng = np.random.default_rng(3)
+    part = {}
+    for k, (f, l) in enumerate(spans):
+        n = max(0, l - f + 1)
+        s = torch.from_numpy(rng.random((C, max(n, 1), R))).to(tdt).cuda()
+        c = torch.from_numpy(rng.integers(0, 30, (C, max(n, 1), R)).astype(np.int32)).cuda()
+        part[k] = (s, c, n)
+    plan = sharding.EdgeExchange(spans, C, R, "cuda")
+    assert plan.shared and sorted(b for _, _, b, _ in plan.edges) == [4, 4, 4, 9, 9]
+    assert [o for _, _, b, o in plan.edges if b == 4] == [True, False, False]
+    rows = {(k, w): r for k, (s, c, n) in part.items() if n for w, r in sharding.mvbs_edge_rows(s[:, :n], c[:, :n]).items()}
+    tot = plan.merge(rows)
+    exp = {}
+    for b in (4, 9):
+        ssum = sum(part[k][0][:, b - f].double().cpu().numpy() for k, (f, l) in enumerate(spans) if f <= b <= l)
+        scnt = sum(part[k][1][:, b - f].double().cpu().numpy() for k, (f, l) in enumerate(spans) if f <= b <= l)
+        exp[b] = (ssum, scnt)
+    for k, w, b, _ in plan.edges:
+        s, c = tot[(k, w)]
+        np.testing.assert_allclose(s.cpu().numpy(), exp[b][0], rtol=1e-15)
+        np.testing.assert_array_equal(c.cpu().numpy(), exp[b][1])
+    # owners finalise straight into their MVBS rows; everybody else's rows stay untouched
+    mv = {k: torch.full((C, max(n, 1), R), -1.0, dtype=tdt, device="cuda") for k, (_, _, n) in part.items()}
+    dst = {(k, w): mv[k][:, 0 if w == 0 else part[k][2] - 1] for k in mv for w in (0, 1) if part[k][2]}
+    plan.merge_mvbs(rows, dst, fill_value=float("nan"))
+    for k, w, b, owner in plan.edges:
+        got = dst[(k, w)].cpu().numpy()
+        if not owner:
+            assert (got == -1.0).all()
+            continue
+        s = exp[b][0].astype(dtype)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            want = np.where(exp[b][1] > 0, 10 * np.log10(s / exp[b][1].astype(dtype)), np.nan)
+        np.testing.assert_allclose(got, want, rtol=2e-6 if dtype == "float32" else 1e-14, equal_nan=True)
+        direct = ops.mvbs_finalize(torch.from_numpy(s).cuda(), torch.from_numpy(exp[b][1].astype(np.int32)).cuda())
+        np.testing.assert_array_equal(got, direct.cpu().numpy())  # the arithmetic of epa_mvbs_finalize, bit for bit
+
+
+# ---- RCCL at world size 1: the device-buffer branch of the exchange, the bench's cfg5 layout, the sharded entry points --
+def _nccl_world1(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    import argparse
+
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    import bench
+    import echopype_amd as ep
+    from echopype_amd import sharding
+
+    assert sharding._comm_device().type == "cuda"
+    # (1) bench.Cfg5 at a small scale: 8 tiles, every tile edge cuts a 20-s bin, one all-reduce per pass on the HBM buffer
+    args = argparse.Namespace(dtype="float64", steps=1, warmup=0, passes=None, ss_every=1)
+    ctx = bench.Ctx(args, 1, 0)
+    job = bench.Cfg5(ctx, 3, 4000, 512, tile_pings=500, ss_every=3)
+    info, plan, mv, one_pass = job.layout(10_000_000_000)
+    assert plan.shared and plan._hbuf is None and plan._buf.is_cuda and len(plan.edges) == 14
+    one_pass(None)
+    torch.cuda.synchronize()
+    keep = []
+    for i, m in enumerate(mv):  # the owner of a cut bin is the first tile holding it
+        lo = 0 if i == 0 else 1
+        keep.append(m[:, lo:].cpu().numpy())
+    host = {k: np.concatenate([d[k].cpu().numpy() for d in job.tiles], axis=1)
+            for k in ("backscatter_r", "sample_interval", "transmit_duration_nominal", "transmit_power",
+                      "sound_speed_indicative", "absorption_indicative")}
+    for k in ("gain_correction", "sa_correction", "pulse_length", "equivalent_beam_angle", "frequency_nominal"):
+        host[k] = job.tiles[0][k].cpu().numpy()
+    host["ping_time"] = np.concatenate([d["ping_time"] for d in job.tiles]) + np.timedelta64(10, "s")
+    out = {"cfg5_mvbs": np.concatenate(keep, axis=1), "cfg5_host": host, "cfg5_n_r": job.n_r}
+    # (2) the sharded product entry points with a process group of one rank == the single-process functions
+    d = ep.synth.ek60_numpy(3, 230, 600, seed=77)
+    d["ping_time"] = d["ping_time"] + np.timedelta64(7, "s")
+    ed = ep.echodata.from_ek60_arrays(d)
+    shard = sharding.MVBSShard()
+    for _ in range(2):  # the second call reuses the cached plan
+        ds_a, mv_a = sharding.compute_Sv_MVBS(ed, range_bin="2m", ping_time_bin="20s", shard=shard)
+    ds_b, mv_b = ep.compute_Sv_MVBS(ed, range_bin="2m", ping_time_bin="20s")
+    ds = ep.calibrate.compute_Sv(ed)
+    sharding.remove_background_noise(ds, 20, 50, ping_offset=0)
+    mv_c = sharding.compute_MVBS(ds, range_bin="2m", ping_time_bin="20s")
+    ds2 = ep.calibrate.compute_Sv(ed)
+    ep.clean.remove_background_noise(ds2, 20, 50)
+    out.update(a=mv_a["Sv"].values, b=mv_b["Sv"].values, c=mv_c["Sv"].values, n1=ds["Sv_corrected"].values,
+               n2=ds2["Sv_corrected"].values, plans=len(shard._plans))
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_world1_cfg5_layout_and_entry_points():
+    """The NCCL (= RCCL) branch of the exchange with one rank: the communication buffer lives in HBM and the
+    all-reduce runs on it (an identity at world size 1); bench.py's straddling cfg5 layout at 3 x 4000 x 512 in eight
+    tiles against the oracle on the whole volume; sharding.* == the single-process functions."""
+    import torch
+    import torch.multiprocessing as mp
+
+    from oracle import calibrate as ocal
+    from oracle import commongrid as ogrid
+
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need a GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    h = out["cfg5_host"]
+    gain = ocal.vend_cal_params_power(h["transmit_duration_nominal"], h["pulse_length"], h["gain_correction"])
+    sa = ocal.vend_cal_params_power(h["transmit_duration_nominal"], h["pulse_length"], h["sa_correction"])
+    sv, er = ocal.cal_power_ek(
+        h["backscatter_r"], sonar="EK60", cal_type="Sv", sample_interval=h["sample_interval"],
+        sound_speed=h["sound_speed_indicative"], absorption=h["absorption_indicative"],
+        transmit_power=h["transmit_power"], tau_nominal=h["transmit_duration_nominal"], gain=gain, sa_correction=sa,
+        psi=h["equivalent_beam_angle"], f_nominal=h["frequency_nominal"], tau_eff=np.full(3, 1.024e-3))
+    exp, t_left, _ = ogrid.compute_MVBS(sv, er, h["ping_time"], "1m", "20s")
+    got = out["cfg5_mvbs"]
+    assert got.shape[1] == exp.shape[1] == 201            # 4000 pings, 10 s off the grid: 201 bins, each exactly once
+    n = min(got.shape[2], exp.shape[2])
+    assert np.isnan(got[..., n:]).all() and np.isnan(exp[..., n:]).all()
+    np.testing.assert_array_equal(np.isnan(got[..., :n]), np.isnan(exp[..., :n]))
+    f = np.isfinite(exp[..., :n])
+    assert np.max(np.abs(got[..., :n][f] - exp[..., :n][f]) / np.maximum(np.abs(exp[..., :n][f]), 1.0)) < 1e-9
+    np.testing.assert_allclose(out["a"], out["b"], rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(out["n1"], out["n2"], rtol=1e-12, atol=1e-10, equal_nan=True)
+    ds2_mv = out["c"]
+    assert ds2_mv.shape == out["b"].shape and out["plans"] == 1
