@@ -128,8 +128,7 @@ def cpu_baseline_ek60(chain=False, multicore=False):
     n = C * P * S
     what = "Sv+denoise(20x50,3dB)+MVBS" if chain else "Sv+MVBS"
     out = {"value": n / med, "unit": "range-samples/s", "cores": 1, "kind": "port",
-           "sample": f"configs[0] shape EK60 {C}x{P}x{S}, {what} 20s x 1m, NumPy f64 oracle, median of {n_runs}, "
-                     f"host has {os.cpu_count()} cores"}
+           "sample": f"configs[0] shape EK60 {C}x{P}x{S}, {what}, NumPy f64 oracle, median of {n_runs}, host: {os.cpu_count()} cores"}
     if multicore:  # what dask chunk-parallelism over ping_time could reach at best: the same slice in N processes
         try:
             import multiprocessing as mp
@@ -189,7 +188,7 @@ def measured_traffic(key):
     try:
         e = json.load(open(path)).get(key)
         if not e:
-            return None, "no PMC run of this line under profiles/"
+            return None, "no PMC run of this line"
         if e.get("csrc_sha16") != csrc_hash():
             return None, f"stale: PMC run at csrc {e.get('csrc_sha16')}"
         return e["bytes_per_launch"], f"PMC FETCH/WRITE_SIZE, {e.get('source', 'profiles/')}, csrc {e['csrc_sha16']}"
@@ -588,8 +587,8 @@ def run_cfg5(ctx, cpu):
     steps = args.steps
     cfg = {"pings_total": P_total, "tiles": f"{n_tiles_global} x {job.tile_p} pings over {world} rank(s)",
            "sv_resident": "every tile" if job.keep_all else "one reused tile buffer",
-           "collective": (f"edge-bin exchange ({args.backend if world > 1 else 'one rank: no all-reduce'}): pack kernel -> "
-                          f"all_reduce(SUM) of {plan_b.nbytes} B -> finalize kernel, per pass"),
+           "collective": (f"edge-bin exchange per pass: pack -> all_reduce(SUM, {args.backend if world > 1 else 'one rank: skipped'})"
+                          " -> finalize"),
            "edge_bins_per_rank": len(plan_b.edges), "allreduce_bytes": plan_b.nbytes,
            "aligned_ms_per_step": el_a / steps * 1e3, "exchange_ms_per_pass": (elapsed - el_a) / steps / passes * 1e3}
     n_first = C * (job.spans[0][1] - job.spans[0][0]) * S if job.spans else 0
@@ -597,11 +596,11 @@ def run_cfg5(ctx, cpu):
     if ctx.rank != 0:
         return None
     return line(ctx, samples_per_pass=C * P_total * S, passes=passes, elapsed=elapsed, scaling="strong", cpu=cpu,
-                workload=f"cfg5: EK60 CW {C}x{P_total}x{S} TOTAL (BASELINE configs[4]) split by ping_time, fused "
-                         "compute_Sv->compute_MVBS(20s x 1m), Sv+MVBS out, tile edges cut time bins",
+                workload=f"cfg5: EK60 CW {C}x{P_total}x{S} TOTAL split by ping_time, fused compute_Sv->compute_MVBS(20s x 1m), "
+                         "Sv+MVBS out, tile edges cut time bins",
                 config=cfg,
                 roofline=roofline("fused_sv_mvbs_kernel", kernel_ms, n_first * bps, bps,
-                                  traffic_key=f"cfg5:{ctx.dtype}", launch="one 250000-ping tile (rank 0, first tile)"))
+                                  traffic_key=f"cfg5:{ctx.dtype}", launch=f"one {job.tile_p}-ping tile (rank 0, first tile)"))
 
 
 # ---------------------------------------------------------------------------------------- main
@@ -621,8 +620,7 @@ def relaunch(args):
 
 def summary(out):
     r = out["roofline"]
-    return (f"{out['value'] / 1e9:.1f} Gsamp/s {out['dtype']}, {out['config']['ms_per_pass']:.2f} ms/pass, kernel "
-            f"{r['kernel_ms']:.2f} ms, frac {r['frac']:.3f}")[:118]
+    return f"{out['value'] / 1e9:.1f} Gs/s, {out['config']['ms_per_pass']:.2f} ms/pass, kernel {r['kernel_ms']:.2f} ms, frac {r['frac']:.3f}"
 
 
 def main():

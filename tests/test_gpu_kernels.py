@@ -457,15 +457,18 @@ def test_argument_errors_from_c_abi(env):
                                                           ("float32", "float64", "float32"), ("float64", "float32", None)])
 @pytest.mark.parametrize("taps,S,mixed,B", [(177, 5000, False, 4), (64, 2048, True, 4), (16, 1873, False, 4),
                                             (1024, 3000, True, 4), (333, 8192, False, 4), (90, 2500, True, 3),
-                                            (40, 1000, False, 1)])
+                                            (40, 1000, False, 1), (177, 2100, True, 4), (100, 1949, False, 4),
+                                            (31, 300, True, 2)])
 def test_sv_complex_fft_path_matches_direct(env, in_dtype, out_dtype, fft_dtype, taps, S, mixed, B):
     """The LDS-FFT circular correlation (epa_sv_complex_fft) against the sliding-window direct form
-    (epa_sv_complex) on echoes spanning 140 dB: several tiles, ragged last tile, per-sector second pass
+    (epa_sv_complex) on echoes spanning 140 dB: several tiles, per-sector second pass
     for mixed NaN patterns, NaN tails, two channels with different replica lengths; complex64 and complex128
-    transforms (default: the output's precision)."""
+    transforms (default: the output's precision).  The tiles are cut from the channel's pings laid end to end
+    (S + taps - 1 positions per ping): five pings put ping boundaries at ever different tile positions; (100, 1949) is
+    the shortest ping of the compare-only position arithmetic (2048 positions), shorter ones hold several pings per tile."""
     torch, ops, synth = env
     rng = np.random.default_rng(taps + S)
-    C, P = 2, 3
+    C, P = 2, 5
     amp = 10.0 ** rng.uniform(-7, 0, (C, P, S, 1))
     re = (amp * rng.standard_normal((C, P, S, B))).astype(in_dtype)
     im = (amp * rng.standard_normal((C, P, S, B))).astype(in_dtype)
@@ -482,8 +485,10 @@ def test_sv_complex_fft_path_matches_direct(env, in_dtype, out_dtype, fft_dtype,
     off = _dev(torch, np.array([0, lens[0], lens[0] + lens[1]], dtype=np.int32))
     cc = np.zeros((C, P, 8))
     cc[..., 0], cc[..., 1], cc[..., 2], cc[..., 3], cc[..., 4], cc[..., 5] = 2.6e-5, 750.0, 0.2, 0.02, -30.0, 1e3
-    # the last ping with its own sound speed / absorption: it leaves the per-channel time-varied-gain table
+    # a ping with its own sound speed / absorption: it leaves the per-channel time-varied-gain table (and its
+    # neighbours in a tile do not)
     cc[0, 2, 1], cc[1, 2, 3] = 751.5, 0.021
+    cc[:, 3, 4], cc[:, 4, 5] = -31.5, 1.1e3                 # per-ping gain / power terms
     kw = dict(replica=repf, replica_off=off, max_taps=taps, dtype=getattr(torch, out_dtype), want_prx=True)
     args = (_dev(torch, re), _dev(torch, im), _dev(torch, cc))
     d = ops.sv_complex(*args, method="direct", **kw)
