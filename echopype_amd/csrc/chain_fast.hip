@@ -793,6 +793,285 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_uniform_kernel
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pass 2, fp64, ping groups that the uniform kernel left because only the SOUND SPEED differs from ping to ping (an
+// EK60 / EK80 records the sound speed of the moment with every ping: rb = c / 2 drifts, sample interval, pulse length
+// and absorption stay).  With echo_range = k s, k = ra rb (EK rows: r0 = 0) and shift = d k:
+//   lin(Sv)       = 10^(g raw/10) . (s - d)^(n/10) . C_sv(ping) . E_p(s)        E_p(s) = 10^(a2 k_p s / 10)
+//   lin(Sv_noise) = C_n(ping) k_p^2 . s^2 . E_p(s)                              wherever k_p s >= 1
+//   Sv_noise      = [noise(ping) + 20 log10 k_p] + 20 log10 s + (a2 k_p) s
+// i.e. the per-COLUMN constants of the uniform kernel survive, joined by per-PING scalars (LDS, one ping per lane) and
+// E_p along the lane's four columns (one exponential per ping and lane + the ratios q1, q128, q129).  The range bin of
+// a column is fixed for the whole group when the slowest and the fastest ping of the group put it into the same bin
+// (the range is monotone in rb); the few columns near a bin edge, below 1 m or at the R' <= 0 guard take the
+// per-sample arithmetic of the general kernel (`plain` bit clear).  Anything else differing -> left to the general kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int kDriftPings = 128;
+struct PingDrift {  // what every sample of the ping needs ...
+  double g, csv, cnk2, snp, a2k, q1, q128, q129;
+};
+struct PingDriftRare {  // ... and what only the columns off the plain path read
+  double cn, nb, rb, shift;
+};
+
+template <bool WRITE_NOISE, bool WRITE_CORR, bool MINMAX>
+__global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
+    const float* __restrict__ raw, const epa::CoefRow* __restrict__ coef, const double* __restrict__ alpha2,
+    const double* __restrict__ noise, const int32_t* __restrict__ bin_start, double* __restrict__ noise_out,
+    double* __restrict__ corr_out, double* __restrict__ mvbs_out, double* __restrict__ sum_out,
+    uint32_t* __restrict__ cnt_out, Args a) {
+  typedef double T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* lsum = reinterpret_cast<T*>(smem);
+  uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + a.cnt_off);
+  const epa::MathTabs mt = epa::build_math_tabs(smem + a.tab_off);
+  __shared__ PingDrift pl[kDriftPings];
+  __shared__ PingDriftRare plr[kDriftPings];
+  __shared__ int differs;
+  __shared__ unsigned long long rb_lo_key, rb_hi_key;
+
+  const int c = blockIdx.y, tb0 = blockIdx.x * a.uni_bins;
+  const int nbn = min(a.uni_bins, a.n_tbins - tb0);
+  const int S = a.S, n_rbins = a.n_rbins;
+  const size_t cell0 = ((size_t)c * a.n_tbins + tb0) * n_rbins;
+  // (uniform) only the groups the uniform kernel marked; a group of two bins is marked in both or in neither
+  if (reinterpret_cast<const unsigned long long*>(mvbs_out + cell0)[0] != kLeftToGeneral) return;
+  const int pb = bin_start[tb0], pe = bin_start[tb0 + nbn], np = pe - pb;
+  for (int i = threadIdx.x; i < nbn * n_rbins; i += epa::kBlock) {
+    lsum[i] = (T)0;
+    lcnt[i] = 0u;
+  }
+  if (threadIdx.x == 0) {
+    differs = np > kDriftPings ? 1 : 0;
+    rb_lo_key = ~0ull;
+    rb_hi_key = 0ull;
+  }
+  __syncthreads();  // (also publishes the math tables)
+  const epa::CoefRow* __restrict__ rowp0 = coef + (size_t)c * a.P;
+  const double* __restrict__ a2p = alpha2 + (size_t)c * a.P;
+  const double* __restrict__ nzp = noise + (size_t)c * a.n_pblocks;
+  const epa::CoefRow r = rowp0[np > 0 ? pb : 0];
+  const double na2 = a2p[np > 0 ? pb : 0];
+  if ((int)threadIdx.x < min(np, kDriftPings)) {
+    const int p = pb + threadIdx.x;
+    const epa::CoefRow ri = rowp0[p];
+    const double a2i = a2p[p];
+    const double ki = ri.ra * ri.rb;
+    // shift = d k up to the roundings of either side (power_coef.hip builds both from the same numbers)
+    const bool same = (ri.ra == r.ra) & (ri.r0 == 0.0) & (ri.d == r.d) & (a2i == na2) & (ri.alpha2 == a2i) &
+                      (fabs(ri.shift - ri.d * ki) <= 8e-16 * fabs(ri.shift)) & (ri.rb > 0.0);
+    if (!same) differs = 1;
+    atomicMin(&rb_lo_key, ordered_key(ri.rb));
+    atomicMax(&rb_hi_key, ordered_key(ri.rb));
+    const double nbi = nzp[p / a.noise_ping_num];
+    const double a2k = a2i * ki;
+    const double cn = epa::lin_from_db(nbi, mt.exp2_tab);
+    const double q1 = epa::lin_from_db(a2k, mt.exp2_tab), q128 = epa::lin_from_db(128.0 * a2k, mt.exp2_tab);
+    pl[threadIdx.x] = PingDrift{ri.g, epa::lin_from_db(ri.A0 - ri.alpha2 * ri.shift, mt.exp2_tab), cn * (ki * ki),
+                                nbi + 20.0 * log10_pos(ki, mt.log_tab), a2k, q1, q128, q1 * q128};
+    plr[threadIdx.x] = PingDriftRare{cn, nbi, ri.rb, ri.shift};
+  }
+  __syncthreads();
+  if (differs) return;  // stays marked: the general kernel takes it
+  auto unkey = [](unsigned long long k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+  };
+  const double rb_lo = unkey(rb_lo_key), rb_hi = unkey(rb_hi_key);
+
+  const T nspread = (T)a.nspread, snr = (T)a.snr;
+  const double bin = a.range_bin, inv_bin = a.inv_range_bin;
+  const epa::LogCoef lk = epa::make_log_coef();
+  const float* __restrict__ raw_c = raw + (size_t)c * a.P * S;
+  T* __restrict__ sn_c = WRITE_NOISE ? noise_out + (size_t)c * a.P * S : nullptr;
+  T* __restrict__ sc_c = WRITE_CORR ? corr_out + (size_t)c * a.P * S : nullptr;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double mm[4] = {__builtin_inf(), -__builtin_inf(), __builtin_inf(), -__builtin_inf()};
+
+  for (int chunk0 = 0; chunk0 < S; chunk0 += kChunk) {
+    const int sA = chunk0 + wave * 256 + 2 * lane, sB = sA + 128;
+    if (sA >= S) continue;
+    const bool hasB = sB < S;
+    // ---- the group's per-column constants
+    T c2[VEC], sn20[VEC], acc_sum[VEC];
+    int rbin[VEC];
+    uint32_t acc_cnt[VEC];
+    unsigned plain = 0;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const double sj = (double)((j < 2 ? sA : sB) + (j & 1));
+      const double sra = sj * r.ra;
+      const double x_lo = sra * rb_lo, x_hi = sra * rb_hi;  // the group's extreme ranges of this column (monotone in rb)
+      const T v = (T)(sj - r.d), v2 = v * v;
+      c2[j] = v > (T)0 ? (nspread == (T)20 ? v2 : v2 * v2) : (T)0;
+      sn20[j] = (T)20 * log10_slow((T)sj, mt.log_tab);
+      const int b_lo = epa::range_bin_index(x_lo, bin, inv_bin, n_rbins, false);
+      const int b_hi = epa::range_bin_index(x_hi, bin, inv_bin, n_rbins, false);
+      rbin[j] = b_lo;
+      // plain: one range bin for every ping, echo_range >= 1 m (the transmission loss and the noise shape take their
+      // R >= 1 form) and s - d >= 1 (R' > 0 whatever the rounding of R - shift)
+      if (b_lo == b_hi && x_lo >= 1.0 && (sj - r.d) >= 1.0) plain |= 1u << j;
+      acc_sum[j] = (T)0;
+      acc_cnt[j] = 0u;
+    }
+    auto flush_col = [&](int g, int j) {
+      if (rbin[j] >= 0 && acc_cnt[j] > 0u) {
+        lds_add(lsum + g * n_rbins + rbin[j], acc_sum[j]);
+        atomicAdd(lcnt + g * n_rbins + rbin[j], acc_cnt[j]);
+      }
+      acc_sum[j] = (T)0;
+      acc_cnt[j] = 0u;
+    };
+    float2 nA = make_float2(0.f, 0.f), nB = nA;
+    if (np > 0) {
+      nA = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sA);
+      if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sB);
+    }
+    int g = 0, edge = bin_start[tb0 + 1];  // first ping of the next time bin
+    // ---- every column as a plain one (what the off-plain columns get here is overwritten below, never accumulated)
+    for (int p = pb; p < pe; ++p) {
+      while (p >= edge) {  // (uniform) ping p opens a later time bin; empty bins are stepped over
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) flush_col(g, j);
+        ++g;
+        edge = bin_start[tb0 + g + 1];
+      }
+      const size_t row_off = (size_t)p * S;
+      const float2 inA = nA, inB = nB;
+      if (p + 1 < pe) {
+        nA = *reinterpret_cast<const float2*>(raw_c + row_off + S + sA);
+        if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + row_off + S + sB);
+      }
+      const PingDrift q = pl[p - pb];
+      const float in[VEC] = {inA.x, inA.y, inB.x, inB.y};
+      T sn[VEC], sc[VEC];
+      const T e0 = epa::lin_from_db_lean(q.a2k * (double)sA, mt.exp2_tab);
+      const T ecol[VEC] = {e0, e0 * q.q1, e0 * q.q128, e0 * q.q129};
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (j >= 2 && !hasB) break;
+        const bool xok = in[j] == in[j];
+        const double sj = (double)((j < 2 ? sA : sB) + (j & 1));
+        // a NaN sample needs no masking: it makes the exponential, hence lin, NaN by itself
+        const T e = epa::lin_from_db_lean(q.g * (T)in[j], mt.exp2_tab);
+        const T lin = ecol[j] * fma(-q.cnk2, sj * sj, (e * c2[j]) * q.csv);
+        sn[j] = xok ? fma(q.a2k, sj, q.snp + sn20[j]) : epa::M<T>::nan();  // echo_range is NaN where the input is
+        const T corr = lin > (T)0 ? (T)10 * epa::fast_log10_lean(lin, mt.log_tab, lk) : epa::M<T>::nan();
+        const bool keep = corr - sn[j] > snr;
+        sc[j] = keep ? corr : epa::M<T>::nan();
+        const bool pj = ((plain >> j) & 1u) != 0u;
+        if (MINMAX) {
+          mm[0] = vmin_f64(mm[0], pj ? sn[j] : mm[0]);
+          mm[1] = vmax_f64(mm[1], pj ? sn[j] : mm[1]);
+          mm[2] = vmin_f64(mm[2], pj ? sc[j] : mm[2]);
+          mm[3] = vmax_f64(mm[3], pj ? sc[j] : mm[3]);
+        }
+        const bool take = pj & (rbin[j] >= 0) & keep;  // keep implies a finite positive lin (and a valid input)
+        acc_sum[j] += take ? lin : (T)0;
+        acc_cnt[j] += take ? 1u : 0u;
+      }
+      if (WRITE_NOISE) {
+        epa::store_nt2(sn_c + row_off + sA, sn[0], sn[1]);
+        if (hasB) epa::store_nt2(sn_c + row_off + sB, sn[2], sn[3]);
+      }
+      if (WRITE_CORR) {
+        epa::store_nt2(sc_c + row_off + sA, sc[0], sc[1]);
+        if (hasB) epa::store_nt2(sc_c + row_off + sB, sc[2], sc[3]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) flush_col(g, j);
+    // ---- the columns off the plain path (a few per wavefront): one column at a time with the wavefront's lanes
+    // spread over the PINGS of the group -- the general kernel's per-sample arithmetic, the range bin found per ping,
+    // the sums added straight to the group's rows
+    const unsigned have = hasB ? 0xfu : 0x3u;
+    const unsigned off_plain = (~plain) & have;
+    if (__ballot(off_plain != 0u) != 0ull) {
+#pragma unroll 1
+      for (int j = 0; j < VEC; ++j) {
+        unsigned long long todo = __ballot(((off_plain >> j) & 1u) != 0u);
+        while (todo != 0ull) {  // (wave-uniform)
+          const int src = __ffsll((long long)todo) - 1;
+          todo &= todo - 1ull;
+          const int sx = chunk0 + wave * 256 + 2 * src + (j < 2 ? 0 : 128) + (j & 1);
+          const double sj = (double)sx;
+          const T v = (T)(sj - r.d), v2 = v * v;
+          const T c2j = v > (T)0 ? (nspread == (T)20 ? v2 : v2 * v2) : (T)0;
+          const T sn20j = (T)20 * log10_slow((T)sj, mt.log_tab);
+          for (int p = pb + lane; p < pe; p += 64) {
+            int g2 = 0;
+            for (int t = 1; t < nbn; ++t) g2 += p >= bin_start[tb0 + t] ? 1 : 0;
+            const size_t o = (size_t)p * S + sx;
+            const float inv = raw_c[o];
+            const bool xok = inv == inv;
+            const PingDrift q = pl[p - pb];
+            const PingDriftRare qr = plr[p - pb];
+            const double x = (sj * r.ra) * qr.rb;
+            const double rtd = x - qr.shift;  // R' <= 0 -> NaN (calibrate_ek.py:107)
+            T cc = c2j;
+            if ((rtd > 0.0) & !(cc > (T)0)) {  // rounding residue of R - shift (rare): the range itself
+              const T w = (T)(rtd / (r.ra * qr.rb)), w2 = w * w;
+              cc = nspread == (T)20 ? w2 : w2 * w2;
+            }
+            cc = rtd > 0.0 ? cc : epa::M<T>::nan();
+            const T e = epa::lin_from_db_lean(q.g * (T)inv, mt.exp2_tab);
+            const T E = epa::lin_from_db_lean(q.a2k * sj, mt.exp2_tab);
+            const T mx = fmax((T)x, (T)1);
+            const T lin = E * fma(-qr.cn, mx * mx, (e * cc) * q.csv);
+            const T tl = x >= 1.0 ? (q.snp - qr.nb) + sn20j : (T)0;  // 20 log10(R >= 1 ? R : 1)
+            const T snv = xok ? (qr.nb + tl) + q.a2k * sj : epa::M<T>::nan();
+            const T corr = lin > (T)0 ? (T)10 * epa::fast_log10_lean(lin, mt.log_tab, lk) : epa::M<T>::nan();
+            const bool keep = corr - snv > snr;
+            const T scv = keep ? corr : epa::M<T>::nan();
+            if (WRITE_NOISE) sn_c[o] = snv;
+            if (WRITE_CORR) sc_c[o] = scv;
+            if (MINMAX) {
+              mm[0] = vmin_f64(mm[0], snv);
+              mm[1] = vmax_f64(mm[1], snv);
+              mm[2] = vmin_f64(mm[2], scv);
+              mm[3] = vmax_f64(mm[3], scv);
+            }
+            const int rb = xok ? epa::range_bin_index(x, bin, inv_bin, n_rbins, false) : -1;
+            if ((rb >= 0) & keep) {
+              lds_add(lsum + g2 * n_rbins + rb, lin);
+              atomicAdd(lcnt + g2 * n_rbins + rb, 1u);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (MINMAX) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mm[0] = fmin(mm[0], __shfl_down(mm[0], o, 64));
+      mm[1] = fmax(mm[1], __shfl_down(mm[1], o, 64));
+      mm[2] = fmin(mm[2], __shfl_down(mm[2], o, 64));
+      mm[3] = fmax(mm[3], __shfl_down(mm[3], o, 64));
+    }
+    if (lane == 0) {
+      if (mm[0] <= mm[1]) {
+        atomicMin(a.mm_keys + 0, ordered_key(mm[0]));
+        atomicMax(a.mm_keys + 1, ordered_key(mm[1]));
+      }
+      if (mm[2] <= mm[3]) {
+        atomicMin(a.mm_keys + 2, ordered_key(mm[2]));
+        atomicMax(a.mm_keys + 3, ordered_key(mm[3]));
+      }
+    }
+  }
+  __syncthreads();
+  T* out = mvbs_out + cell0;
+  T* gsum = sum_out ? sum_out + cell0 : nullptr;
+  uint32_t* gcnt = cnt_out ? cnt_out + cell0 : nullptr;
+  for (int i = threadIdx.x; i < nbn * n_rbins; i += epa::kBlock) {
+    const uint32_t n = lcnt[i];
+    const T s = lsum[i];
+    out[i] = n > 0u ? (T)10 * epa::M<T>::log10(s / (T)n) : (T)a.fill_value;  // (overwrites the mark of the group)
+    if (gsum) gsum[i] = s;
+    if (gcnt) gcnt[i] = n;
+  }
+}
+
 template <typename K>
 int set_lds(K kern, size_t lds) {
   if (lds > 64 * 1024)
@@ -861,6 +1140,29 @@ int launch_pass2(Args& a, const float* raw, const double* coef, const double* al
 #undef EPA_U2M
 #undef EPA_U2
     if (int rc = epa::check_launch("sv_denoise_mvbs_uniform_kernel")) return rc;
+    static const bool drift_off = [] {  // development knob: EPA_CHAIN_DRIFT=0 skips the sound-speed-drift kernel
+      const char* e = getenv("EPA_CHAIN_DRIFT");
+      return e && e[0] == '0';
+    }();
+    if (!drift_off) {
+#define EPA_D2(N, K, M)                                                                                  \
+  do {                                                                                                   \
+    auto kern = sv_denoise_mvbs_drift_kernel<N, K, M>;                                                   \
+    if (int rc = set_lds(kern, ulds)) return rc;                                                         \
+    hipLaunchKernelGGL(kern, ugrid, dim3(epa::kBlock), ulds, st, raw,                                    \
+                       reinterpret_cast<const epa::CoefRow*>(coef), alpha2, noise, bin_start,            \
+                       (double*)noise_out, (double*)corr_out, (double*)mvbs_out, (double*)sum_out, cnt_out, au); \
+  } while (0)
+#define EPA_D2M(N, K)                                                                                    \
+  do {                                                                                                   \
+    if (a.mm_keys) EPA_D2(N, K, true); else EPA_D2(N, K, false);                                         \
+  } while (0)
+      if (noise_out) { if (corr_out) EPA_D2M(true, true); else EPA_D2M(true, false); }
+      else { if (corr_out) EPA_D2M(false, true); else EPA_D2M(false, false); }
+#undef EPA_D2M
+#undef EPA_D2
+      if (int rc = epa::check_launch("sv_denoise_mvbs_drift_kernel")) return rc;
+    }
     a.flagged_only = 1;
   }
 #define EPA_P2(N, K)                                                                                     \

@@ -41,10 +41,6 @@
 //     non-zero staged samples (wave ballots) and its prefix popcounts.
 //   * a tile holding a sample whose sectors are only PARTLY NaN (never seen in files, allowed by the
 //     reference) is redone one sector at a time (block-uniform branch).
-//   * tiles are cut from the channel's pings laid end to end with `taps - 1` zeros between them (a virtual stream of
-//     pitch = S + taps - 1 positions per ping): the correlation of ping p never reaches ping p + 1, a tile may hold the
-//     tail of one ping and the head of the next, and a ping of S = 8192 samples costs 4.47 tiles of 1872 outputs
-//     instead of 5 (tiling every ping on its own wastes the last tile's 62 %).
 #include "fast_math.h"
 
 namespace {
@@ -308,8 +304,7 @@ __host__ __device__ inline size_t ws_mixed(int C) { return ws_stats(C) + 3 * kSt
 //   then                per channel {ra, rb, shift, 2 alpha of its first ping} + S values of the time-varied gain
 //                       n log10(R') + 2 alpha R' (tvg_table_kernel)
 __host__ __device__ inline size_t ws_tvg(int C, int P, int S) {
-  // (tiles per channel <= P (S + taps - 1) / (2049 - taps) + 1 <= P (S / 1025 + 2) + 1 for taps <= 1024)
-  return ws_mixed(C) + 2 + ((size_t)C * ((size_t)P * ((size_t)S / (kN / 2 + 1) + 2) + 1) + 63) / 64;
+  return ws_mixed(C) + 2 + ((size_t)C * (size_t)P * ((size_t)S / (kN / 2 + 1) + 1) + 63) / 64;
 }
 //   then                the 128 x {1/c, log10 c} table of fast_log10 (fast_math.h), copied to LDS by every workgroup
 __host__ __device__ inline size_t ws_logtab(int C, int P, int S) { return ws_tvg(C, P, S) + (size_t)C * ((size_t)S + 4); }
@@ -413,14 +408,13 @@ struct FftArgs {
   const double* ccoef;
   const double* ws;
   int C, P, S, B;
-  int tiles, out_per_tile;  // tiles per CHANNEL over the virtual stream of its pings; outputs kept per tile
-  int pitch;                // virtual positions per ping: S + max_taps - 1
+  int tiles, out_per_tile;
   double nspread;
   void* out;
   void* range_out;
   void* prx_out;
   double* stats_part;   // optional [3 * kStatSlots]: {min, max, NaN count} of echo_range, merged by atomics
-  unsigned* mixed_map;  // bit per tile (linear id c * tiles + tile): the tile holds a partly-NaN sample
+  unsigned* mixed_map;  // bit per tile (linear id (c * P + p) * tiles + tile): the tile holds a partly-NaN sample
   unsigned* mixed_cnt;  // number of bits set
   int map_words;
   const double* tvg;  // [C][4 + S], see ws_tvg
@@ -430,14 +424,14 @@ struct FftArgs {
 // sector sum (or one sector when only >= 0) + validity bits of sample s (bits 0..B-1 sector valid, bit 8: beam-0
 // real part valid = the echo_range mask of range.py:143-146)
 template <typename InT, typename F, int NB>
-__device__ __forceinline__ void load_sample(const InT* __restrict__ re, const InT* __restrict__ im, size_t sample,
-                                            bool valid, int Brt, int only, C2<F>& v, unsigned& m) {
+__device__ __forceinline__ void load_sample(const InT* __restrict__ re, const InT* __restrict__ im, size_t ping_base,
+                                            int S, int Brt, int s, int only, C2<F>& v, unsigned& m) {
   const int B = NB > 0 ? NB : Brt;
   F sr = (F)0, si = (F)0;
   m = 0;
-  if (valid) {  // `sample` = (c * P + p) * S + s; positions between pings and past the last ping are zeros
-    const InT* pr = re + sample * B;
-    const InT* pi = im + sample * B;
+  if (s < S) {
+    const InT* pr = re + ping_base + (size_t)s * B;
+    const InT* pi = im + ping_base + (size_t)s * B;
     if (NB > 0) {
       constexpr int kPer = 16 / sizeof(InT);
       typedef InT vec_t __attribute__((ext_vector_type(kPer)));
@@ -550,68 +544,18 @@ __global__ __launch_bounds__(epa::kBlock) void tvg_table_kernel(const double* __
   }
 }
 
-// Where tile position t of a tile starting at virtual position (p0, s0) lies: ping p, sample s.  pitch >= kN (every
-// file with S + taps > 2048): at most one ping boundary inside a tile, a compare; shorter pings: a division.
-struct TilePos {
-  int p0, s0, pitch;
-  bool wide;
-  __device__ __forceinline__ void at(int t, int& p, int& s) const {
-    s = s0 + t;
-    p = p0;
-    if (wide) {
-      if (s >= pitch) {
-        s -= pitch;
-        ++p;
-      }
-    } else {
-      const int q = s / pitch;
-      p += q;
-      s -= q * pitch;
-    }
-  }
-};
-
-// the per-(channel, ping) numbers of the epilogue
-template <typename T>
-struct RowC {
-  double ra, rb;
-  T shift, alpha2, Aadd, pscale;
-  bool tabulated;
-};
-template <typename T>
-__device__ __forceinline__ RowC<T> load_row(const double* __restrict__ ccoef, size_t row, const double* tkey) {
-  const double* cc = ccoef + row * EPA_NCCOEF;
-  RowC<T> r;
-  r.ra = cc[EPA_CC_RA];
-  r.rb = cc[EPA_CC_RB];
-  r.shift = (T)cc[EPA_CC_SHIFT];
-  r.alpha2 = (T)cc[EPA_CC_ALPHA2];
-  r.Aadd = (T)cc[EPA_CC_A];
-  r.pscale = (T)cc[EPA_CC_PSCALE];
-  // (float output: the hardware logarithm is cheaper than the table read -- measured; the table is not built then)
-  r.tabulated = sizeof(T) == 8 && ((tkey[0] == r.ra) & (tkey[1] == r.rb) & (tkey[2] == cc[EPA_CC_SHIFT]) &
-                                   (tkey[3] == cc[EPA_CC_ALPHA2]));
-  return r;
-}
-
 template <typename InT, typename T, typename F, int NB, bool MIXED>
-__device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, T>& L, const LaneMap& lm, int c, int tile) {
+__device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, T>& L, const LaneMap& lm, int c, int p,
+                                             int tile) {
   const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
   const int S = a.S, B = NB > 0 ? NB : a.B;
+  const int k_begin = tile * a.out_per_tile;
   const double* chan = a.ws + ws_chan() + 4 * (size_t)c;
   const InT* re = reinterpret_cast<const InT*>(a.re);
   const InT* im = reinterpret_cast<const InT*>(a.im);
+  const size_t ping_base = ((size_t)c * a.P + p) * (size_t)S * B;
   const C2<F>* spec = reinterpret_cast<const C2<F>*>(a.ws + (sizeof(F) == 4 ? ws_spec32(a.C, c) : ws_spec64(a.C, c)));
   const unsigned full = (1u << B) - 1u;
-  TilePos tp;
-  {
-    const long long u0 = (long long)tile * a.out_per_tile;
-    tp.pitch = a.pitch;
-    tp.p0 = (int)(u0 / a.pitch);
-    tp.s0 = (int)(u0 - (long long)tp.p0 * a.pitch);
-    tp.wide = a.pitch >= kN;
-  }
-  const size_t chan_row = (size_t)c * a.P;
 
   // ---- the lane's eight samples: sector sums + validity bits
   C2<F> v[8];
@@ -621,10 +565,7 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     unsigned mi;
-    int p, sx;
-    tp.at(j + 256 * i, p, sx);
-    const bool valid = sx < S && p < a.P;
-    load_sample<InT, F, NB>(re, im, (chan_row + p) * (size_t)S + sx, valid, B, -1, v[i], mi);
+    load_sample<InT, F, NB>(re, im, ping_base, S, B, k_begin + j + 256 * i, -1, v[i], mi);
     if (MIXED) m[i] = mi;
     vbits |= ((mi & full) != 0u ? 1u : 0u) << i;
     vbits |= ((mi >> 8) & 1u) << (8 + i);
@@ -639,9 +580,7 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
       unsigned dummy;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        int p, sx;
-        tp.at(j + 256 * i, p, sx);
-        load_sample<InT, F, NB>(re, im, (chan_row + p) * (size_t)S + sx, sx < S && p < a.P, B, only, v[i], dummy);
+        load_sample<InT, F, NB>(re, im, ping_base, S, B, k_begin + j + 256 * i, only, v[i], dummy);
         if (only == 0) y[i] = C2<F>{(F)0, (F)0};
       }
     }
@@ -664,7 +603,7 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
     const unsigned flags = L.wflags[0] | L.wflags[1] | L.wflags[2] | L.wflags[3];
     if (!MIXED && (flags & 1u)) {  // block-uniform: leave the tile to the per-sector pass
       if (j == 0) {
-        const size_t lin = (size_t)c * a.tiles + tile;
+        const size_t lin = ((size_t)c * a.P + p) * a.tiles + tile;
         atomicOr(a.mixed_map + (lin >> 5), 1u << (lin & 31));
         atomicAdd(a.mixed_cnt, 1u);
       }
@@ -706,102 +645,70 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
   }
 
   // ---- sector mean -> prx -> Sv/TS (calibrate_ek.py:483-490, 571-638)
+  const size_t row = (size_t)c * a.P + p;
+  const double* cc = a.ccoef + row * EPA_NCCOEF;
+  const double ra = cc[EPA_CC_RA], rb = cc[EPA_CC_RB];
+  const T shift = (T)cc[EPA_CC_SHIFT], alpha2 = (T)cc[EPA_CC_ALPHA2], Aadd = (T)cc[EPA_CC_A];
+  const T pscale = (T)(cc[EPA_CC_PSCALE]);
   const T nspread = (T)a.nspread;
   const double inv_norm = 1.0 / chan[0];
   const double inv_norm_b = inv_norm / (double)B;  // every sector valid (the only case of the fast form)
   const epa::LogCoef lk = epa::make_log_coef();
   const double* tkey = a.tvg + (size_t)c * (S + 4);
   const double* tvg_tab = tkey + 4;
+  // (float output: the hardware logarithm is cheaper than the read -- measured; the table is not built then)
+  const bool tabulated = sizeof(T) == 8 && ((tkey[0] == ra) & (tkey[1] == rb) & (tkey[2] == cc[EPA_CC_SHIFT]) &
+                                            (tkey[3] == cc[EPA_CC_ALPHA2]));
   T* out = reinterpret_cast<T*>(a.out);
   T* range_out = reinterpret_cast<T*>(a.range_out);
   T* prx_out = reinterpret_cast<T*>(a.prx_out);
   double rmin = __builtin_inf(), rmax = -__builtin_inf();
   unsigned rnan = 0;
-  // one output sample: `on` = this lane writes it, with the numbers `rc` of its ping.  yi: the compressed sector sum;
-  // mbits: the sample's sector-validity bits (MIXED) / its bit of vbits; range_ok: beam 0 valid
-  auto emit = [&](const C2<F> yi, unsigned mbits, bool range_ok, const RowC<T>& rc, bool on, size_t row, int sx) {
-    if (!on) return;
-    const unsigned nvalid = MIXED ? __popc(mbits & full) : (mbits ? (unsigned)B : 0u);
-    T mr, mi;
-    if (nvalid == 0u) {
-      mr = mi = epa::M<T>::nan();
-    } else {
-      const double invn = MIXED ? inv_norm / (double)nvalid : inv_norm_b;
-      mr = (T)((double)yi.re * invn);
-      mi = (T)((double)yi.im * invn);
-    }
-    T prx = rc.pscale * (mr * mr + mi * mi);
-    if (!(prx > (T)0)) prx = epa::M<T>::nan();
-    const double R = ((double)sx * rc.ra) * rc.rb;  // range.py:138 operation order
-    T tvg;
-    if (rc.tabulated) {  // (uniform)
-      tvg = (T)tvg_tab[sx];
-    } else {
-      T rt = sub_rn((T)R, rc.shift);  // never contracted with the range product into an fma
-      if (!(rt > (T)0)) rt = epa::M<T>::nan();
-      tvg = nspread * epa::fast_log10_lean(rt, L.log_tab, lk) + rc.alpha2 * rt;
-    }
-    // prx (and rt) are positive or NaN here: the lean log (zero / subnormal / inf / NaN through a rare branch)
-    // the range the reference calibrates with is the MASKED echo_range (NaN where beam 0 is, range.py:143-148): a
-    // sample whose beam 0 is missing is NaN even when its other sectors are valid (calibrate_ek.py:571-576)
-    const T val = range_ok ? ((T)10 * epa::fast_log10_lean(prx, L.log_tab, lk) + tvg) + rc.Aadd : epa::M<T>::nan();
-    const size_t o = row * S + sx;
-    out[o] = val;
-    if (range_out || a.stats_part) {  // (statistics without the array: epa_range_complex writes it when asked for)
-      if (range_out) range_out[o] = range_ok ? (T)R : epa::M<T>::nan();
-      if (range_ok) {
-        const double rr = (double)(T)R;
-        rmin = fmin(rmin, rr);
-        rmax = fmax(rmax, rr);
-      } else {
-        ++rnan;
-      }
-    }
-    if (prx_out) prx_out[o] = prx;
-  };
-  if (tp.wide) {
-    // At most two pings in the tile; position tw is the first that belongs to ping p0 + 1.  A run of 256 positions
-    // (sample slot i of the 256 lanes) lies on one side of tw, its row numbers are wave-uniform scalars -- except the
-    // one run tw falls into: its lanes below tw are written in the loop, the others afterwards from a parked copy of
-    // the slot (a uniform branch and a few moves per slot; register arrays want constant indices).
-    const int tw = tp.pitch - tp.s0;
-    const bool second = tp.p0 + 1 < a.P && tw < a.out_per_tile;  // (uniform) ping p0 + 1 has outputs in this tile
-    const RowC<T> r0 = load_row<T>(a.ccoef, chan_row + tp.p0, tkey);
-    const RowC<T> r1 = second ? load_row<T>(a.ccoef, chan_row + tp.p0 + 1, tkey) : r0;
-    C2<F> park_y{(F)0, (F)0};
-    unsigned park_m = 0;
-    bool park_ok = false;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int t = j + 256 * i;
-      const bool hi_side = 256 * i >= tw;  // (uniform)
-      const RowC<T> rs = hi_side ? r1 : r0;
-      const int sx = hi_side ? t - tw : tp.s0 + t;
-      const bool on = t < a.out_per_tile && sx < S && (hi_side ? second : t < tw);
+  for (int i = 0; i < 8; ++i) {
+    const int t = j + 256 * i;
+    const int s = k_begin + t;
+    if (t < a.out_per_tile && s < S) {
+      const unsigned nvalid = MIXED ? __popc(m[MIXED ? i : 0] & full) : (((vbits >> i) & 1u) ? (unsigned)B : 0u);
       const C2<F> yi = MIXED ? y[MIXED ? i : 0] : v[i];
-      const unsigned mbits = MIXED ? m[MIXED ? i : 0] : ((vbits >> i) & 1u);
-      const bool range_ok = ((vbits >> (8 + i)) & 1u) != 0u;
-      emit(yi, mbits, range_ok, rs, on, chan_row + tp.p0 + (hi_side ? 1 : 0), sx);
-      if (256 * i < tw && tw < 256 * i + 256) {  // (uniform) the run that holds tw
-        park_y = yi;
-        park_m = mbits;
-        park_ok = range_ok;
+      T mr, mi;
+      if (nvalid == 0u) {
+        mr = mi = epa::M<T>::nan();
+      } else {
+        const double invn = MIXED ? inv_norm / (double)nvalid : inv_norm_b;
+        mr = (T)((double)yi.re * invn);
+        mi = (T)((double)yi.im * invn);
       }
-    }
-    if (second && (tw & 255) != 0) {  // (uniform) the lanes at and above tw of that run
-      const int t = j + (tw & ~255);
-      emit(park_y, park_m, park_ok, r1, t >= tw && t < a.out_per_tile && t - tw < S, chan_row + tp.p0 + 1, t - tw);
-    }
-  } else {  // short pings (S + taps <= 2048): several per tile, the row numbers are read per sample
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int t = j + 256 * i;
-      int p, sx;
-      tp.at(t, p, sx);
-      const bool on = t < a.out_per_tile && sx < S && p < a.P;
-      const RowC<T> rc = load_row<T>(a.ccoef, chan_row + (on ? p : tp.p0), tkey);
-      emit(MIXED ? y[MIXED ? i : 0] : v[i], MIXED ? m[MIXED ? i : 0] : ((vbits >> i) & 1u), ((vbits >> (8 + i)) & 1u) != 0u,
-           rc, on, chan_row + p, sx);
+      T prx = pscale * (mr * mr + mi * mi);
+      if (!(prx > (T)0)) prx = epa::M<T>::nan();
+      const double R = ((double)s * ra) * rb;  // range.py:138 operation order
+      T tvg;
+      if (tabulated) {  // (block-uniform)
+        tvg = (T)tvg_tab[s];
+      } else {
+        T rt = sub_rn((T)R, shift);  // never contracted with the range product into an fma
+        if (!(rt > (T)0)) rt = epa::M<T>::nan();
+        tvg = nspread * epa::fast_log10_lean(rt, L.log_tab, lk) + alpha2 * rt;
+      }
+      // prx (and rt) are positive or NaN here: the lean log (zero / subnormal / inf / NaN through a rare branch)
+      // the range the reference calibrates with is the MASKED echo_range (NaN where beam 0 is, range.py:143-148): a
+      // sample whose beam 0 is missing is NaN even when its other sectors are valid (calibrate_ek.py:571-576)
+      const bool range_ok = ((vbits >> (8 + i)) & 1u) != 0u;
+      const T val = range_ok ? ((T)10 * epa::fast_log10_lean(prx, L.log_tab, lk) + tvg) + Aadd : epa::M<T>::nan();
+      const size_t o = row * S + s;
+      out[o] = val;
+      if (range_out || a.stats_part) {  // (statistics without the array: epa_range_complex writes it when asked for)
+        const bool ok = range_ok;
+        if (range_out) range_out[o] = ok ? (T)R : epa::M<T>::nan();
+        if (ok) {
+          const double rr = (double)(T)R;
+          rmin = fmin(rmin, rr);
+          rmax = fmax(rmax, rr);
+        } else {
+          ++rnan;
+        }
+      }
+      if (prx_out) prx_out[o] = prx;
     }
   }
   if (a.stats_part) {  // {nanmin, nanmax, NaN count} of the echo_range written by this workgroup
@@ -819,7 +726,7 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
     }
     __syncthreads();
     if (j == 0) {
-      const size_t lin = (size_t)c * a.tiles + tile;
+      const size_t lin = ((size_t)c * a.P + p) * a.tiles + tile;
       double* dst = a.stats_part + 3 * (lin & (kStatSlots - 1));
       const double mn = fmin(fmin(L.sred[0], L.sred[3]), fmin(L.sred[6], L.sred[9]));
       const double mx = fmax(fmax(L.sred[1], L.sred[4]), fmax(L.sred[7], L.sred[10]));
@@ -855,7 +762,9 @@ void sv_complex_fft_kernel(FftArgs a) {
   const LaneMap lm = lane_map();
   const TileLds<F, T> L{xs, tw, nzw, wp, wflags, log_tab, sred};
   if (!MIXED) {
-    process_tile<InT, T, F, NB, false>(a, L, lm, blockIdx.y, blockIdx.x);
+    const int c = blockIdx.y;
+    const int p = blockIdx.x / a.tiles;
+    process_tile<InT, T, F, NB, false>(a, L, lm, c, p, blockIdx.x - p * a.tiles);
   } else {
     for (int w = blockIdx.x; w < a.map_words; w += gridDim.x) {
       unsigned bits = a.mixed_map[w];
@@ -863,8 +772,10 @@ void sv_complex_fft_kernel(FftArgs a) {
         const int bit = __ffs(bits) - 1;
         bits &= bits - 1u;
         const size_t lin = (size_t)w * 32 + bit;
+        const int tile = (int)(lin % a.tiles);
+        const size_t row = lin / a.tiles;
         __syncthreads();  // the previous tile is done with the LDS arrays
-        process_tile<InT, T, F, NB, true>(a, L, lm, (int)(lin / a.tiles), (int)(lin % a.tiles));
+        process_tile<InT, T, F, NB, true>(a, L, lm, (int)(row / a.P), (int)(row % a.P), tile);
       }
     }
   }
@@ -872,7 +783,7 @@ void sv_complex_fft_kernel(FftArgs a) {
 
 template <typename InT, typename T, typename F>
 int launch_fft(FftArgs& a, hipStream_t st) {
-  const dim3 grid((unsigned)a.tiles, (unsigned)a.C);
+  const dim3 grid((unsigned)((long long)a.P * a.tiles), (unsigned)a.C);
   const bool b4 = a.B == 4 && (reinterpret_cast<uintptr_t>(a.re) & 15u) == 0 &&
                   (reinterpret_cast<uintptr_t>(a.im) & 15u) == 0;
   const int slow_grid = a.map_words < 2048 ? a.map_words : 2048;
@@ -954,16 +865,11 @@ extern "C" int epa_sv_complex_fft(const void* re, const void* im, int in_dtype, 
   a.re = re; a.im = im; a.ccoef = ccoef; a.ws = workspace;
   a.C = C; a.P = P; a.S = S; a.B = B;
   a.out_per_tile = kN - max_taps + 1;
-  a.pitch = S + max_taps - 1;  // the channel's pings end to end, max_taps - 1 zeros between them
-  {
-    const long long nt = ((long long)P * a.pitch + a.out_per_tile - 1) / a.out_per_tile;
-    EPA_CHECK_ARG(nt < (1ll << 31), "epa_sv_complex_fft: too many tiles per channel");
-    a.tiles = (int)nt;
-  }
+  a.tiles = (S + a.out_per_tile - 1) / a.out_per_tile;
   a.nspread = cal_type == EPA_CAL_SV ? 20.0 : 40.0;
   a.out = out; a.range_out = range_out; a.prx_out = prx_out;
   a.stats_part = range_stats_out ? workspace + ws_stats(C) : nullptr;
-  const size_t ntiles = (size_t)C * a.tiles;
+  const size_t ntiles = (size_t)C * P * a.tiles;
   EPA_CHECK_ARG(ntiles < ((size_t)1 << 36), "epa_sv_complex_fft: too many tiles");
   a.map_words = (int)((ntiles + 31) / 32);
   a.mixed_cnt = reinterpret_cast<unsigned*>(workspace + ws_mixed(C));

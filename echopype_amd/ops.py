@@ -404,7 +404,7 @@ def sv_complex(re, im, ccoef, *, replica=None, replica_off=None, max_taps=0, cal
     stats = None
     if use_fft:
         n_ws = (768 + 4 * C + 3 * C * _lib.EK80_NFFT + 3 * 1024 + 2
-                + (C * (P * (S // (_lib.EK80_NFFT // 2 + 1) + 2) + 1) + 63) // 64 + C * (S + 4) + 256)  # EPA_EK80_FFT_WS_DOUBLES
+                + (C * P * (S // (_lib.EK80_NFFT // 2 + 1) + 1) + 63) // 64 + C * (S + 4) + 256)  # EPA_EK80_FFT_WS_DOUBLES
         ws = torch.empty(n_ws, dtype=torch.float64, device=dev)
         fdt = torch_dtype(fft_dtype) if fft_dtype is not None else dtype
         if want_range_stats:

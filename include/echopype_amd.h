@@ -371,7 +371,7 @@ int epa_sv_complex(const void* re, const void* im, int in_dtype, const float* re
 #define EPA_EK80_NFFT 2048
 #define EPA_EK80_FFT_WS_DOUBLES(C, P, S)                                              \
   (768 + 4 * (size_t)(C) + 3 * (size_t)(C) * EPA_EK80_NFFT + 3 * 1024 + 2 +          \
-   ((size_t)(C) * ((size_t)(P) * ((size_t)(S) / (EPA_EK80_NFFT / 2 + 1) + 2) + 1) + 63) / 64 + \
+   ((size_t)(C) * (size_t)(P) * ((size_t)(S) / (EPA_EK80_NFFT / 2 + 1) + 1) + 63) / 64 + \
    (size_t)(C) * ((size_t)(S) + 4) + 256)
 int epa_sv_complex_fft(const void* re, const void* im, int in_dtype, const float* replica,
                        const int32_t* replica_off, int max_taps, const double* ccoef, int C, int P,

@@ -144,7 +144,7 @@ def test_compute_Sv_ek80_bb(ep, dtype, mixed):
     ed = ep.echodata.from_ek80_arrays(d, filt)
     ds = ep.calibrate.compute_Sv(ed, waveform_mode="BB", encode_mode="complex", dtype=dtype)
     (exp, exp_r, prx), teff = oc.ek80_complex(d, filt, "Sv")
-    assert_bb_close(ds["Sv"].values, exp, dtype)
+    assert_bb_close(ds["Sv"].values, exp, dtype, prx=prx)
     np.testing.assert_allclose(ds["tau_effective"].values, teff, rtol=1e-12)
     if dtype == "float64":
         np.testing.assert_array_equal(ds["echo_range"].values, exp_r)

@@ -142,17 +142,16 @@ def test_chain_fp32_vs_fp64_on_the_corrected_output(chain):
 
 
 # ---- configs[3]: EK80 broadband at 2 x 200 000 x 8192 x 4 ------------------------------------------------------------
-@pytest.fixture(scope="module")
-def bb():
-    torch = _need(150)
+def _bb_volume(torch, P, plane_dtype, out_dtypes):
+    """EK80 BB planes (C, P, 8192, 4) of ``plane_dtype`` generated in HBM + the Sv of the LDS-FFT path."""
     from echopype_amd import _lib, ops, synth
     from oracle import ek80 as oek
 
-    C, P, S, B = 2, 200_000, 8192, 4
+    C, S, B = 2, 8192, 4
     g = torch.Generator(device="cuda")
     g.manual_seed(20260504)
-    re = torch.empty((C, P, S, B), dtype=torch.float32, device="cuda")
-    im = torch.empty((C, P, S, B), dtype=torch.float32, device="cuda")
+    re = torch.empty((C, P, S, B), dtype=plane_dtype, device="cuda")
+    im = torch.empty((C, P, S, B), dtype=plane_dtype, device="cuda")
     for p0 in range(0, P, 4000):  # noise + a strong layer that moves with the ping: 60 dB of in-tile dynamic range
         n = min(4000, P - p0)
         for t in (re, im):
@@ -170,8 +169,8 @@ def bb():
         ri = torch.from_numpy(np.ascontiguousarray(reps[c].imag, dtype=np.float32)).cuda()
         amp = 1.0 / float(np.linalg.norm(reps[c]))  # compressed peak = amp, noise floor = 1e-3 / ||tx||: 60 dB
         for b in range(B):
-            re[c, ar, idx, b] += amp * rr[None, :]
-            im[c, ar, idx, b] += amp * ri[None, :]
+            re[c, ar, idx, b] += (amp * rr[None, :]).to(plane_dtype)
+            im[c, ar, idx, b] += (amp * ri[None, :]).to(plane_dtype)
     nan_pings = torch.rand(P, generator=g, device="cuda") < 0.10
     re[:, nan_pings, S - 410:] = float("nan")
     im[:, nan_pings, S - 410:] = float("nan")
@@ -184,25 +183,26 @@ def bb():
     cc[..., _lib.CC_PSCALE] = B / 8.0 * (abs(5400.0 + 75.0) / 5400.0) ** 2 / 75.0
     ccd = torch.from_numpy(cc).cuda()
     out = {}
-    for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+    for name, dt in out_dtypes:
         out[name] = ops.sv_complex(re, im, ccd, replica=repf, replica_off=off, max_taps=max(r.size for r in reps),
                                    dtype=dt, want_range=False)["out"]
     torch.cuda.synchronize()
-    yield dict(torch=torch, re=re, im=im, cc=cc, reps=reps, B=B, S=S, **out)
-    out.clear()
-    del re, im
+    return dict(torch=torch, ops=ops, re=re, im=im, cc=cc, reps=reps, repf=repf, off=off, B=B, S=S, **out)
+
+
+@pytest.fixture(scope="module")
+def bb():
+    torch = _need(150)
+    d = _bb_volume(torch, 200_000, torch.float32, (("f64", torch.float64), ("f32", torch.float32)))
+    yield d
+    d.clear()
     gc.collect()
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("p0", [0, 77_777, 199_990])
-def test_bb_windows_match_the_scipy_convolve_oracle(bb, p0):
-    """10 pings of the 2 x 200 000 x 8192 x 4 volume: pulse compression + sector mean + Sv == oracle.ek80 (the
-    reference's scipy.signal.convolve loop) + the Sv chain, complex128 transform to 2e-4 dB, complex64 per
-    tests/bb_tolerance.py."""
+def _bb_oracle_window(bb, p0, w):
     from oracle import ek80 as oek
 
-    w = 10
     x = (bb["re"][:, p0:p0 + w].cpu().numpy().astype(np.float64) + 1j * bb["im"][:, p0:p0 + w].cpu().numpy()).astype(np.complex64)
     prx = oek.power_from_complex(x, 5400.0, 75.0, bb["reps"])  # (C, w, S)
     cc = bb["cc"][:, p0:p0 + w]
@@ -212,8 +212,36 @@ def test_bb_windows_match_the_scipy_convolve_oracle(bb, p0):
         rt = np.where(rt > 0, rt, np.nan)
         prx = np.where(prx > 0, prx, np.nan)
         exp = 10 * np.log10(prx) + 20 * np.log10(rt) + cc[..., 3:4] * rt + cc[..., 4:5]
-    assert_bb_close(bb["f64"][:, p0:p0 + w].cpu().numpy(), exp, "float64")
-    assert_bb_close(bb["f32"][:, p0:p0 + w].cpu().numpy(), exp, "float32")
+    return exp, prx
+
+
+def test_bb_float64_planes_volume_windows_match_the_oracle():
+    """backscatter_r / _i as the converter stores them -- float64 (convert/parse_base.py:306-309) -- at 2 x 50 000 x
+    8192 x 4 (52 GB of planes, a quarter of configs[3]'s ping count: the full volume is 210 GB and would not fit next to
+    the float32 fixture of this module): windows at the start, in the middle and at the end against the scipy-convolve
+    oracle, complex128 transform -> float64 Sv and complex64 -> float32."""
+    torch = _need(70)
+    d = _bb_volume(torch, 50_000, torch.float64, (("f64", torch.float64), ("f32", torch.float32)))
+    try:
+        for p0 in (0, 31_313, 49_990):
+            exp, prx = _bb_oracle_window(d, p0, 10)
+            assert_bb_close(d["f64"][:, p0:p0 + 10].cpu().numpy(), exp, "float64", prx=prx)
+            assert_bb_close(d["f32"][:, p0:p0 + 10].cpu().numpy(), exp, "float32", prx=prx)
+    finally:
+        d.clear()
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("p0", [0, 77_777, 199_990])
+def test_bb_windows_match_the_scipy_convolve_oracle(bb, p0):
+    """10 pings of the 2 x 200 000 x 8192 x 4 volume: pulse compression + sector mean + Sv == oracle.ek80 (the
+    reference's scipy.signal.convolve loop) + the Sv chain, in linear power against the peak-relative bound of
+    tests/bb_tolerance.py (complex128 and complex64 transforms)."""
+    w = 10
+    exp, prx = _bb_oracle_window(bb, p0, w)
+    assert_bb_close(bb["f64"][:, p0:p0 + w].cpu().numpy(), exp, "float64", prx=prx)
+    assert_bb_close(bb["f32"][:, p0:p0 + w].cpu().numpy(), exp, "float32", prx=prx)
 
 
 # ---- configs[4]'s range depth: the fused kernel with 4096 samples and 787 range bins ---------------------------------

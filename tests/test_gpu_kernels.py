@@ -463,9 +463,7 @@ def test_sv_complex_fft_path_matches_direct(env, in_dtype, out_dtype, fft_dtype,
     """The LDS-FFT circular correlation (epa_sv_complex_fft) against the sliding-window direct form
     (epa_sv_complex) on echoes spanning 140 dB: several tiles, per-sector second pass
     for mixed NaN patterns, NaN tails, two channels with different replica lengths; complex64 and complex128
-    transforms (default: the output's precision).  The tiles are cut from the channel's pings laid end to end
-    (S + taps - 1 positions per ping): five pings put ping boundaries at ever different tile positions; (100, 1949) is
-    the shortest ping of the compare-only position arithmetic (2048 positions), shorter ones hold several pings per tile."""
+    transforms (default: the output's precision)."""
     torch, ops, synth = env
     rng = np.random.default_rng(taps + S)
     C, P = 2, 5
@@ -497,23 +495,27 @@ def test_sv_complex_fft_path_matches_direct(env, in_dtype, out_dtype, fft_dtype,
     st = f["range_stats"].cpu().numpy()
     assert st[2] == np.isnan(er).sum() and st[0] == np.nanmin(er) and st[1] == np.nanmax(er)
     pd, pf = d["prx"].cpu().numpy().astype(np.float64), f["prx"].cpu().numpy().astype(np.float64)
-    np.testing.assert_array_equal(np.isnan(pf), np.isnan(pd))
     np.testing.assert_array_equal(f["echo_range"].cpu().numpy(), d["echo_range"].cpu().numpy())
     with np.errstate(invalid="ignore"), warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)
-        peak = np.nanmax(pd, axis=2, keepdims=True)
+        peak = np.nanmax(pd, axis=2, keepdims=True)  # (every ping is tiled on its own)
+    fft32 = (fft_dtype or out_dtype) == "float32"
+    differ = np.isnan(pf) != np.isnan(pd)
+    if fft32:  # 130 dB under the strongest echo a complex64 transform returns rounding noise, which may be an exact 0 (-> NaN)
+        with np.errstate(invalid="ignore"):
+            differ &= ~(pd < 1e-13 * peak)
+    assert not differ.any(), np.argwhere(differ)[:5]
     # the direct path accumulates in the output precision; the transform in fft_dtype (default: the same).
     # Error model: the amplitude error of a transform is delta = eps_a * (strongest echo of the ping) whatever the
     # sample, so |d prx| <= delta * (2 sqrt(prx) + delta) (+ the relative rounding of the epilogue)
     f32 = out_dtype == "float32" or fft_dtype == "float32"
-    fft32 = (fft_dtype or out_dtype) == "float32"
     eps_a = 1e-12 if not f32 else 2e-6
     with np.errstate(invalid="ignore"):
         delta = eps_a * np.sqrt(peak)
         bound = delta * (2 * np.sqrt(pd) + delta) + eps_a * pd + 1e-300
         assert np.nanmax(np.abs(pf - pd) / bound) < 1.0
     sd, sf = d["out"].cpu().numpy().astype(np.float64), f["out"].cpu().numpy().astype(np.float64)
-    np.testing.assert_array_equal(np.isnan(sf), np.isnan(sd))
+    assert not ((np.isnan(sf) != np.isnan(sd)) & ~(np.isnan(pf) != np.isnan(pd))).any()  # (Sv is NaN where prx is)
     # dB values agree wherever the sample is within 100 dB (complex128 transform) / 40 dB (complex64 transform:
     # its error is relative to the tile's strongest echo) of the ping's strongest echo
     with np.errstate(invalid="ignore"):
