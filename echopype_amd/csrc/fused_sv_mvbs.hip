@@ -11,6 +11,8 @@
 // Reference lines replaced: see sv_power.hip and block_reduce.hip.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#include <cstdlib>
+
 #include "fast_math.h"
 #include "sample_math.h"
 
@@ -27,6 +29,7 @@ struct Args {
   unsigned cnt_off, tab_off;
   unsigned long long* rmax_key;  // optional: max valid echo_range as an order-preserving u64 key
   int xcd_map;  // time bins dealt to the XCDs in contiguous eighths (epa::xcd_contiguous)
+  int flagged_only;  // mvbs_of_sv_rows_kernel after the fixed-bin kernel: only the time bins that one left (kLeftToRows)
 };
 
 // order-preserving map double -> u64 (so that atomicMax on the key is a max on the double)
@@ -386,6 +389,179 @@ __device__ __forceinline__ void bin_sv_sample(SvColumn<T>& c, T sv, const epa::C
   c.acc_cnt += take ? 1u : 0u;
 }
 
+// ---- the time bins whose pings put (almost) every range column into ONE range bin ------------------------------------
+// The range of column s at ping p is fl(fl(s ra) rb_p) + r0: with ra and r0 shared by the pings of a time bin it is
+// monotone in rb_p, so a column whose range at the bin's smallest and largest rb falls into the same range bin stays
+// there for every ping.  Such columns need neither the range nor the two edge compares per sample -- the sweep is a
+// plain streaming sum of 10^(Sv/10) into a fixed bin (about 25 VALU instructions per sample, under 64 VGPRs: twice the
+// wavefronts of the per-sample form in flight).  The few columns near a range-bin edge are redone with the wavefront's
+// lanes spread over the pings.  A time bin whose pings differ in ra or r0, or longer than kFixedPings, is marked in its
+// first MVBS cell (a NaN payload no computation produces) and left to mvbs_of_sv_rows_kernel, launched right after.
+constexpr int kFixedPings = 512;
+template <typename T>
+struct LeftMark;
+template <>
+struct LeftMark<double> {
+  static constexpr unsigned long long kBits = 0x7ff8dead0c0ffee2ull;
+};
+template <>
+struct LeftMark<float> {
+  static constexpr unsigned kBits = 0x7fcdead2u;
+};
+__device__ __forceinline__ bool left_to_rows(const double* cell) {
+  return *reinterpret_cast<const unsigned long long*>(cell) == LeftMark<double>::kBits;
+}
+__device__ __forceinline__ bool left_to_rows(const float* cell) {
+  return *reinterpret_cast<const unsigned*>(cell) == LeftMark<float>::kBits;
+}
+__device__ __forceinline__ void mark_left(double* cell) {
+  *reinterpret_cast<unsigned long long*>(cell) = LeftMark<double>::kBits;
+}
+__device__ __forceinline__ void mark_left(float* cell) { *reinterpret_cast<unsigned*>(cell) = LeftMark<float>::kBits; }
+
+// (wavefronts per SIMD: measured at 4 x 500 000 x 2000 -- fp64 6.30 ms at 8 (64 VGPRs, six dwords of scratch), 5.80 at 6,
+//  the per-sample form 6.01; fp32 3.08 at 8, 3.17 at 6, the per-sample form 3.39)
+template <typename T, bool AS_STORED>
+__global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 6 : 8) void mvbs_of_sv_fixed_kernel(
+    const T* __restrict__ sv, const epa::CoefRow* __restrict__ coef, const int32_t* __restrict__ bin_start,
+    T* __restrict__ mvbs_out, T* __restrict__ sum_out, uint32_t* __restrict__ cnt_out, Args a) {
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* lsum = reinterpret_cast<T*>(smem);
+  uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + a.cnt_off);
+  const epa::MathTabs mt = epa::build_math_tabs(smem + a.tab_off);  // synchronised below
+  const double* tab = mt.exp2_tab;
+  __shared__ int differs;
+  __shared__ unsigned long long rb_lo_key, rb_hi_key;
+  const int c = blockIdx.y, tb = a.xcd_map ? epa::xcd_contiguous(blockIdx.x, a.n_tbins) : (int)blockIdx.x;
+  const int S = a.S, n_rbins = a.n_rbins;
+  const int pb = bin_start[tb], pe = bin_start[tb + 1], np = pe - pb;
+  const size_t cell0 = ((size_t)c * a.n_tbins + tb) * n_rbins;
+  for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
+    lsum[i] = (T)0;
+    lcnt[i] = 0u;
+  }
+  if (threadIdx.x == 0) {
+    differs = np > kFixedPings ? 1 : 0;
+    rb_lo_key = ~0ull;
+    rb_hi_key = 0ull;
+  }
+  __syncthreads();
+  const epa::CoefRow* __restrict__ rowp0 = coef + (size_t)c * a.P;
+  const epa::CoefRow r = rowp0[np > 0 ? pb : 0];
+  for (int i = threadIdx.x; i < min(np, kFixedPings); i += epa::kBlock) {
+    const epa::CoefRow ri = rowp0[pb + i];
+    if (!((ri.ra == r.ra) & (ri.r0 == r.r0) & (ri.rb == ri.rb) & (ri.ra > 0.0))) differs = 1;  // (a NaN row, too)
+    atomicMin(&rb_lo_key, ordered_key(ri.rb));
+    atomicMax(&rb_hi_key, ordered_key(ri.rb));
+  }
+  __syncthreads();
+  if (differs) {
+    if (threadIdx.x == 0) mark_left(mvbs_out + cell0);
+    return;
+  }
+  auto unkey = [](unsigned long long k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+  };
+  const double rb_lo = unkey(rb_lo_key), rb_hi = unkey(rb_hi_key);
+  const double bin = a.range_bin, inv_bin = a.inv_range_bin;
+  const T* __restrict__ sv_c = sv + (size_t)c * a.P * S;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  auto range_of = [&](int sx, double rb) {
+    const double x0 = ((double)sx * r.ra) * rb + r.r0;
+    return AS_STORED ? (double)(T)x0 : x0;
+  };
+  for (int chunk0 = 0; chunk0 < S; chunk0 += kChunk) {
+    const int sA = chunk0 + wave * 256 + 2 * lane;  // first sample of pair A
+    const int sB = sA + 128;                        // first sample of pair B
+    if (sA >= S) continue;
+    const bool hasB = sB < S;
+    int rbin[VEC];
+    T acc_sum[VEC];
+    uint32_t acc_cnt[VEC];
+    unsigned fixed = 0;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int sx = (j < 2 ? sA : sB) + (j & 1);
+      const int b_lo = epa::range_bin_index(range_of(sx, rb_lo), bin, inv_bin, n_rbins, false);
+      const int b_hi = epa::range_bin_index(range_of(sx, rb_hi), bin, inv_bin, n_rbins, false);
+      rbin[j] = b_lo;
+      if (b_lo == b_hi) fixed |= 1u << j;  // (out of the grid at both ends: fixed, nothing is taken)
+      acc_sum[j] = (T)0;
+      acc_cnt[j] = 0u;
+    }
+    // two pings in flight per lane
+    T2 nA0 = {(T)0, (T)0}, nB0 = nA0, nA1 = nA0, nB1 = nA0;
+    if (np > 0) {
+      nA0 = *reinterpret_cast<const T2*>(sv_c + (size_t)pb * S + sA);
+      if (hasB) nB0 = *reinterpret_cast<const T2*>(sv_c + (size_t)pb * S + sB);
+    }
+    if (np > 1) {
+      nA1 = *reinterpret_cast<const T2*>(sv_c + (size_t)(pb + 1) * S + sA);
+      if (hasB) nB1 = *reinterpret_cast<const T2*>(sv_c + (size_t)(pb + 1) * S + sB);
+    }
+    for (int p = pb; p < pe; ++p) {
+      const T2 inA = nA0, inB = nB0;
+      nA0 = nA1;
+      nB0 = nB1;
+      if (p + 2 < pe) {
+        const T* nx = sv_c + (size_t)(p + 2) * S;
+        nA1 = *reinterpret_cast<const T2*>(nx + sA);
+        if (hasB) nB1 = *reinterpret_cast<const T2*>(nx + sB);
+      }
+      const T in[VEC] = {inA.x, inA.y, inB.x, inB.y};
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (j >= 2 && !hasB) break;
+        const T v = epa::lin_from_db(in[j], tab);
+        const bool take = (((fixed >> j) & 1u) != 0u) & (rbin[j] >= 0) & (v == v);
+        acc_sum[j] += take ? v : (T)0;
+        acc_cnt[j] += take ? 1u : 0u;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      if (rbin[j] >= 0 && acc_cnt[j] > 0u) {
+        lds_add(lsum + rbin[j], acc_sum[j]);
+        atomicAdd(lcnt + rbin[j], acc_cnt[j]);
+      }
+    }
+    // the columns near a range-bin edge: one at a time, the lanes spread over the pings
+    const unsigned loose = (~fixed) & (hasB ? 0xfu : 0x3u);
+    if (__ballot(loose != 0u) != 0ull) {
+#pragma unroll 1
+      for (int j = 0; j < VEC; ++j) {
+        unsigned long long todo = __ballot(((loose >> j) & 1u) != 0u);
+        while (todo != 0ull) {  // (wave-uniform)
+          const int src = __ffsll((long long)todo) - 1;
+          todo &= todo - 1ull;
+          const int sx = chunk0 + wave * 256 + 2 * src + (j < 2 ? 0 : 128) + (j & 1);
+          for (int p = pb + lane; p < pe; p += 64) {
+            const T v = epa::lin_from_db(sv_c[(size_t)p * S + sx], tab);
+            const double x = range_of(sx, rowp0[p].rb);
+            const int rb = epa::range_bin_index(x, bin, inv_bin, n_rbins, false);
+            if ((rb >= 0) & (v == v)) {
+              lds_add(lsum + rb, v);
+              atomicAdd(lcnt + rb, 1u);
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  T* out = mvbs_out + cell0;
+  T* gsum = sum_out ? sum_out + cell0 : nullptr;
+  uint32_t* gcnt = cnt_out ? cnt_out + cell0 : nullptr;
+  for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
+    const uint32_t n = lcnt[i];
+    const T s = lsum[i];
+    out[i] = n > 0u ? (T)10 * epa::M<T>::log10(s / (T)n) : (T)a.fill_value;
+    if (gsum) gsum[i] = s;
+    if (gcnt) gcnt[i] = n;
+  }
+}
+
 template <typename T, bool AS_STORED>
 __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void mvbs_of_sv_rows_kernel(
     const T* __restrict__ sv, const epa::CoefRow* __restrict__ coef, const int32_t* __restrict__ bin_start,
@@ -398,6 +574,7 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void mvbs_of_sv_r
   const double* tab = mt.exp2_tab;
   const int c = blockIdx.y, tb = a.xcd_map ? epa::xcd_contiguous(blockIdx.x, a.n_tbins) : (int)blockIdx.x;
   const int S = a.S, n_rbins = a.n_rbins;
+  if (a.flagged_only && !left_to_rows(mvbs_out + ((size_t)c * a.n_tbins + tb) * n_rbins)) return;  // (uniform)
   for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
     lsum[i] = (T)0;
     lcnt[i] = 0u;
@@ -468,9 +645,13 @@ int launch_sv_rows(Args& a, const void* sv, const double* coef, const int32_t* b
   a.tab_off = (unsigned)((lds_bytes + 15) & ~(size_t)15);
   lds_bytes = a.tab_off + epa::kMathTabBytes;
   a.xcd_map = epa::xcd_map_enabled() ? 1 : 0;
-#define EPA_SR(AS)                                                                                       \
+  static const bool fixed_off = [] {  // development knob: EPA_MVBS_FIXED=0 sends every time bin to the per-sample form
+    const char* e = getenv("EPA_MVBS_FIXED");
+    return e && e[0] == '0';
+  }();
+#define EPA_SR(KERN, AS)                                                                                 \
   do {                                                                                                   \
-    auto kern = mvbs_of_sv_rows_kernel<T, AS>;                                                           \
+    auto kern = KERN<T, AS>;                                                                             \
     if (lds_bytes > 64 * 1024)                                                                           \
       EPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                             \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));    \
@@ -478,7 +659,13 @@ int launch_sv_rows(Args& a, const void* sv, const double* coef, const int32_t* b
                        reinterpret_cast<const epa::CoefRow*>(coef), bin_start, (T*)mvbs_out, (T*)sum_out, \
                        cnt_out, a);                                                                      \
   } while (0)
-  if (as_stored) EPA_SR(true); else EPA_SR(false);
+  a.flagged_only = 0;
+  if (!fixed_off) {
+    if (as_stored) EPA_SR(mvbs_of_sv_fixed_kernel, true); else EPA_SR(mvbs_of_sv_fixed_kernel, false);
+    if (int rc = epa::check_launch("mvbs_of_sv_fixed_kernel")) return rc;
+    a.flagged_only = 1;
+  }
+  if (as_stored) EPA_SR(mvbs_of_sv_rows_kernel, true); else EPA_SR(mvbs_of_sv_rows_kernel, false);
 #undef EPA_SR
   return epa::check_launch("mvbs_of_sv_rows_kernel");
 }
