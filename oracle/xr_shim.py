@@ -149,12 +149,22 @@ class DataArray:
                 a = a.isel(**{d: np.array([la.index(x) for x in common])})
                 b = b.isel(**{d: np.array([lb.index(x) for x in common])})
             elif d in b.dims and d in a.coords and d in b.coords:
-                # equal lengths: xarray would still join on the LABELS (reordering / dropping); the shim combines by
-                # position, so it insists that the labels agree -- anything else must fail loudly, not silently
+                # equal lengths, both labelled: xarray joins on the LABELS all the same (default join="inner":
+                # PandasIndex.join -> pandas Index.intersection, which keeps the order of the FIRST operand).  Equal
+                # labels combine by position; a permutation of the same unique labels is re-ordered through pandas
+                # itself; anything else (labels dropped by the join) must fail loudly, not silently
                 la, lb = np.asarray(a.coords[d]), np.asarray(b.coords[d])
                 same = la.shape == lb.shape and bool(np.all((la == lb) | ((la != la) & (lb != lb)))) \
                     if la.dtype.kind not in "OUS" else list(la) == list(lb)
-                assert same, f"operands carry different {d!r} labels: label alignment beyond the shim"
+                if not same:
+                    import pandas as pd
+
+                    ia, ib = pd.Index(la), pd.Index(lb)
+                    common = ia.intersection(ib)
+                    assert ia.is_unique and ib.is_unique and len(common) == len(ia), \
+                        f"operands carry different {d!r} labels: an inner join that drops labels is beyond the shim"
+                    a = a.isel(**{d: ia.get_indexer(common)})
+                    b = b.isel(**{d: ib.get_indexer(common)})
         return a, b
 
     def _binary(self, other, f, reflexive=False):
@@ -278,7 +288,7 @@ def _methods():
             return
         raise NotImplementedError(f"DataArray[{key!r}] = ...")
 
-    def sel(self, **ix):
+    def sel(self, drop=False, **ix):
         out = self
         for d, k in ix.items():
             if isinstance(k, slice):
@@ -292,8 +302,27 @@ def _methods():
                 out = out.isel(**{d: idx.slice_indexer(k.start, k.stop)})
                 continue
             k = _as_da(k)
-            if k is None or k.data.dtype != bool:
-                raise NotImplementedError("sel: label slices and boolean DataArray indexers only")
+            if k is not None and k.data.dtype != bool:
+                # vectorised (pointwise) selection by LABEL: the indexer's own dimensions are shared with the array,
+                # out[..., i, ...] = array[..., label -> position along d, ...] (xarray: the result drops d)
+                assert all(dd in out.dims for dd in k.dims) and d not in k.dims
+                labels = list(np.asarray(out.coords[d]))
+                pos = np.vectorize(lambda v: labels.index(v))(k.data)
+                for dd in k.dims:  # the shared dimensions must carry the same labels (xarray checks the indexer's)
+                    if dd in k.coords and dd in out.coords:
+                        assert list(np.asarray(k.coords[dd])) == list(np.asarray(out.coords[dd])), dd
+                rest = [x for x in out.dims if x != d]
+                src = np.transpose(out.data, [out.dims.index(d)] + [out.dims.index(x) for x in rest])
+                kk = DataArray(pos, dims=k.dims)._expand(rest)
+                kk = np.broadcast_to(kk, src.shape[1:])
+                res = np.take_along_axis(src, kk[None], axis=0)[0]
+                cs = {c: v for c, v in out.coords.items() if c != d and np.ndim(v) == 1}
+                if not ix.get("drop", False):
+                    pass
+                out = DataArray(res, cs, rest, out.name, out.attrs)
+                continue
+            if k is None:
+                raise NotImplementedError("sel: label slices, boolean and label DataArray indexers only")
             out = out.isel(**{d: np.flatnonzero(k.data)})
         return out
 
@@ -520,11 +549,94 @@ def _methods():
         for i in range(self.data.shape[0]):
             yield DataArray(self.data[i], dims=[], name=self.name)
 
-    for f in (isnull, where, transpose, isel, drop_vars, squeeze, to_dataset, sel, mean, fillna, _reduce, assign_coords,
-              reindex, reindex_like, coarsen, pipe, assign_attrs, rename, equals, resample, diff):
+    def idxmin(self, dim, skipna=True):
+        """Label of the minimum along ``dim`` (NaN skipped; an all-NaN slice gives NaN, as xarray's idxmin)."""
+        ax = self.dims.index(dim)
+        a = self.data.astype(np.float64)
+        allnan = np.all(np.isnan(a), axis=ax)
+        pos = np.argmin(np.where(np.isnan(a), np.inf, a), axis=ax)  # first minimum, as nanargmin
+        lab = np.asarray(self.coords[dim])[pos]
+        lab = np.where(allnan, np.nan, lab.astype(np.float64)) if allnan.any() else lab
+        return self._like(lab, [d for d in self.dims if d != dim])
+
+    def sortby(self, key, ascending=True):
+        k = key if isinstance(key, DataArray) else self[key]
+        assert k.ndim == 1 and k.dims[0] in self.dims
+        order = np.argsort(np.asarray(k.data), kind="stable")
+        return self.isel(**{k.dims[0]: order if ascending else order[::-1]})
+
+    def expand_dims(self, dim=None, **kw):
+        """expand_dims(name=labels): a new leading dimension carrying those labels (the data are repeated)."""
+        kw = {**(dim if isinstance(dim, dict) else {}), **kw}
+        out = self
+        for name, labels in reversed(list(kw.items())):
+            lab = np.asarray(labels.data if isinstance(labels, DataArray) else labels)
+            data = np.broadcast_to(out.data[None], (lab.shape[0],) + out.data.shape).copy()
+            out = DataArray(data, {**{k: v for k, v in out.coords.items()}, name: lab}, (name,) + out.dims, out.name, out.attrs)
+        return out
+
+    def dropna(self, dim, how="any"):
+        ax = self.dims.index(dim)
+        other = tuple(i for i in range(self.ndim) if i != ax)
+        bad = np.isnan(self.data.astype(np.float64))
+        drop = bad.any(axis=other) if how == "any" else bad.all(axis=other)
+        return self.isel(**{dim: np.flatnonzero(~drop)})
+
+    def squeeze2(self, dim=None):
+        if dim is None:
+            return squeeze(self)
+        dims = [dim] if isinstance(dim, str) else list(dim)
+        assert all(self.sizes[d] == 1 for d in dims)
+        keep = [d for d in self.dims if d not in dims]
+        # (the squeezed dimension's label stays behind as a scalar coordinate, as in xarray)
+        out = DataArray(self.data.reshape([self.sizes[d] for d in keep]),
+                        {k: (v if k in keep else np.asarray(v).reshape(())) for k, v in self.coords.items()}, keep,
+                        self.name, self.attrs)
+        return out
+
+    def interp(self, coords=None, method="linear", kwargs=None, **kw):
+        """1-D linear interpolation onto new labels of one dimension: xarray hands this to
+        scipy.interpolate.interp1d (bounds_error=False, the caller's fill_value) on the index turned into floats
+        (datetimes: nanoseconds from the smallest label) -- scipy itself is executed here."""
+        from scipy.interpolate import interp1d
+
+        coords = {**(coords or {}), **kw}
+        assert len(coords) == 1 and method == "linear"
+        (dim, new), = coords.items()
+        newv = np.asarray(new.data if isinstance(new, DataArray) else new)
+        x = np.asarray(self.coords[dim])
+        if x.dtype.kind == "M":
+            x0 = x.min()
+            xf = (x - x0).astype("timedelta64[ns]").astype(np.float64)
+            qf = (newv.astype(x.dtype) - x0).astype("timedelta64[ns]").astype(np.float64)
+        else:
+            xf, qf = x.astype(np.float64), newv.astype(np.float64)
+        ax = self.dims.index(dim)
+        f = interp1d(xf, self.data.astype(np.float64), kind="linear", axis=ax, bounds_error=False, copy=False,
+                     assume_sorted=False, **(kwargs or {}))
+        newdim = new.dims[0] if isinstance(new, DataArray) else dim
+        dims = tuple(newdim if d == dim else d for d in self.dims)
+        cs = {k: v for k, v in self.coords.items() if k != dim and np.ndim(v) == 1}
+        cs[newdim] = newv
+        if newdim != dim:
+            cs[dim] = newv  # xarray keeps the interpolated dimension's labels as a coordinate on the new dimension
+        out = DataArray(f(qf), cs, dims, self.name, self.attrs)
+        return out
+
+    def getattr_coord(self, name):
+        if name.startswith("_") or name not in self.__dict__.get("coords", {}):
+            raise AttributeError(name)
+        return self[name]
+
+    for f in (isnull, where, transpose, isel, drop_vars, to_dataset, sel, mean, fillna, _reduce, assign_coords,
+              reindex, reindex_like, coarsen, pipe, assign_attrs, rename, equals, resample, diff, idxmin, sortby,
+              expand_dims, dropna, interp):
         setattr(DataArray, f.__name__, f)
+    DataArray.squeeze = squeeze2
+    DataArray.__getattr__ = getattr_coord
     DataArray.min, DataArray.max = amin, amax
     DataArray.any = any_
+    DataArray.all = lambda self: DataArray(np.all(self.data), dims=[])
     DataArray.__iter__ = iterate
     DataArray.size = property(lambda self: int(self.data.size))
     DataArray.chunks = None

@@ -160,7 +160,72 @@ def test_scalar_conversions_and_strictness():
     a = _da(np.zeros((2, 3)), channel=np.arange(2), ping_time=np.arange(3))
     with pytest.raises(TypeError):  # an unlabelled ndarray of another shape does not broadcast silently
         a + np.zeros(3)
-    with pytest.raises(AssertionError):  # equal lengths but other / permuted labels: xarray would re-align, the shim refuses
-        _da(np.arange(3.0), channel=np.array(["a", "b", "c"])) + _da(np.arange(3.0), channel=np.array(["b", "a", "c"]))
+    # equal lengths, PERMUTED labels: joined on the labels in the first operand's order (xarray's default inner join =
+    # pandas Index.intersection, executed by the shim) ...
+    x = _da(np.array([1.0, 2.0, 3.0]), channel=np.array(["a", "b", "c"]))
+    y = _da(np.array([10.0, 20.0, 30.0]), channel=np.array(["b", "a", "c"]))
+    got = x + y
+    assert list(got.coords["channel"]) == list(pd.Index(["a", "b", "c"]).intersection(pd.Index(["b", "a", "c"])))
+    np.testing.assert_array_equal(got.values, (pd.Series([1.0, 2, 3], index=list("abc"))
+                                              + pd.Series([10.0, 20, 30], index=list("bac")))[list(got.coords["channel"])])
+    got = y - x
+    assert list(got.coords["channel"]) == ["b", "a", "c"]
+    np.testing.assert_array_equal(got.values, [8.0, 19.0, 27.0])
+    with pytest.raises(AssertionError):  # ... OTHER labels (the join would drop some): refused
+        x + _da(np.arange(3.0), channel=np.array(["a", "b", "d"]))
     with pytest.raises((AssertionError, KeyError)):  # same dimension, different lengths, no labels to join on
         a + xr.DataArray(np.zeros(4), dims=["ping_time"])
+
+
+def test_idxmin_sortby_expand_dims_and_pointwise_sel_against_pandas():
+    """The methods calibrate/cal_params.py::get_vend_cal_params_power chains (idxmin over pulse_length_bin, sortby,
+    expand_dims, sel with a labelled indexer), each against pandas / NumPy on the same numbers."""
+    rng = np.random.default_rng(3)
+    a = rng.normal(size=(4, 3, 5))
+    a[1, 2, :] = np.nan                      # an all-NaN slice
+    a[0, 0, 1] = np.nan
+    da = _da(a, ping_time=np.arange(4), channel=np.array(["x", "y", "z"]), plb=np.array([10, 11, 12, 13, 14]))
+    got = da.idxmin(dim="plb")
+    exp = pd.DataFrame(a.reshape(12, 5), columns=[10, 11, 12, 13, 14]).idxmin(axis=1, skipna=True).to_numpy(dtype=float)
+    assert got.dims == ("ping_time", "channel")
+    np.testing.assert_array_equal(got.values, exp.reshape(4, 3))
+    # sortby a coordinate, descending == pandas sort of the labels
+    s = da.sortby(da["channel"], ascending=False)
+    order = pd.Series(np.arange(3), index=["x", "y", "z"]).sort_index(ascending=False)
+    assert list(s.coords["channel"]) == list(order.index)
+    np.testing.assert_array_equal(s.values, a[:, order.to_numpy(), :])
+    # expand_dims(name=labels): a new leading dimension, data repeated
+    e = da.isel(ping_time=0).expand_dims(t=np.array([7, 8]))
+    assert e.dims == ("t", "channel", "plb") and list(e.coords["t"]) == [7, 8]
+    np.testing.assert_array_equal(e.values, np.broadcast_to(a[0][None], (2, 3, 5)))
+    # pointwise selection by label along plb with an indexer on (ping_time, channel)
+    idx = _da(rng.choice([10, 11, 12, 13, 14], size=(4, 3)), ping_time=np.arange(4), channel=np.array(["x", "y", "z"]))
+    got = da.transpose("plb", "ping_time", "channel").sel(plb=idx, drop=True)
+    assert got.dims == ("ping_time", "channel")
+    exp = np.take_along_axis(a, (idx.values - 10)[..., None], axis=2)[..., 0]
+    np.testing.assert_array_equal(got.values, exp)
+
+
+def test_dropna_squeeze_and_linear_interp_with_extrapolation():
+    """What calibrate/env_params.py::harmonize_env_param_time and utils/align.py::align_to_ping_time use: dropna along a
+    dimension, squeeze(dim), interp(method="linear", fill_value="extrapolate") on datetime labels -- against NumPy."""
+    t = np.datetime64("2017-06-20T01:00:00", "ns") + np.arange(5) * np.timedelta64(30, "s")
+    v = np.array([0.0, 1.0, np.nan, 3.0, 5.0])
+    da = xr.DataArray(v, coords={"time1": t}, dims=["time1"])
+    d = da.dropna(dim="time1")
+    np.testing.assert_array_equal(d.values, v[~np.isnan(v)])
+    np.testing.assert_array_equal(d.coords["time1"], t[~np.isnan(v)])
+    one = xr.DataArray(np.array([[7.0], [8.0]]), coords={"channel": np.arange(2), "time1": t[:1]}, dims=["channel", "time1"])
+    sq = one.squeeze(dim="time1")
+    assert sq.dims == ("channel",) and "time1" in sq.coords and sq.drop_vars("time1").dims == ("channel",)
+    q = np.array(["2017-06-20T01:00:15", "2017-06-20T00:59:30", "2017-06-20T01:03:00"], dtype="datetime64[ns]")
+    got = d.interp({"time1": xr.DataArray(q, coords={"ping_time": q}, dims=["ping_time"])}, method="linear",
+                   kwargs={"fill_value": "extrapolate"})
+    x = (d.coords["time1"] - t[0]).astype(np.int64).astype(float)
+    xq = (q - t[0]).astype(np.int64).astype(float)
+    y = d.values
+    exp = np.interp(xq, x, y)
+    exp[1] = y[0] + (y[1] - y[0]) * (xq[1] - x[0]) / (x[1] - x[0])       # linear extrapolation on either side
+    exp[2] = y[-1] + (y[-1] - y[-2]) * (xq[2] - x[-1]) / (x[-1] - x[-2])
+    assert got.dims == ("ping_time",)
+    np.testing.assert_allclose(got.values, exp, rtol=1e-14)
