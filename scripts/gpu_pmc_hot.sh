@@ -5,7 +5,7 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BU
   n=$(echo $grp | tr ' ' '_' | cut -c1-30)
   timeout 300 rocprofv3 --pmc $grp --kernel-trace -d $O/$n -o p --output-format csv -- python scripts/pmc_hot.py ${1:-all} > $O/$n.log 2>&1
 done
-python scripts/pmc_summary.py $O fast_kernel uniform_kernel fused_sv_mvbs_kernel sv_complex_fft > $O/summary.csv
+python scripts/pmc_summary.py $O fast_kernel uniform_kernel drift_kernel fused_sv_mvbs_kernel mvbs_of_sv sv_complex_fft > $O/summary.csv
 python - <<'PY'
 import csv, collections
 rows = collections.defaultdict(dict)

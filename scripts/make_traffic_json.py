@@ -16,11 +16,15 @@ sys.path.insert(0, ROOT)
 from bench import csrc_hash  # noqa: E402
 
 src = sys.argv[1]
+# traffic key of bench.py -> (rocprof output tag, kernel-name substrings, must also contain, algorithmic bytes per launch)
 KERNELS = {
     # (the <.., true, true> instantiation with the range-maximum by-product belongs to the Dataset-API timing of the run)
-    "cfg2": (["fused_sv_mvbs_kernel<double, float, true, false>"], 4 * 500_000 * 2000 * 12),
-    "cfg3": (["sv_noise_fast_kernel", "sv_denoise_mvbs_fast_kernel", "sv_denoise_mvbs_uniform_kernel"], 4 * 500_000 * 2000 * 32),
-    "cfg4": (["sv_complex_fft_kernel"], 2 * 200_000 * 8192 * 40),
+    "cfg2:float64": ("cfg2", ["fused_sv_mvbs_kernel<double, float, true, false>"], None, 4 * 500_000 * 2000 * 12),
+    "cfg3:float64": ("cfg3", ["sv_noise_fast_kernel", "sv_denoise_mvbs_fast_kernel", "sv_denoise_mvbs_uniform_kernel",
+                              "sv_denoise_mvbs_drift_kernel"], None, 4 * 500_000 * 2000 * 32),
+    "cfg4:float64": ("cfg4", ["sv_complex_fft_kernel<float, double, double"], None, 2 * 200_000 * 8192 * 40),
+    "cfg4:float64:planes64": ("cfg4_planes64", ["sv_complex_fft_kernel<double, double, double"], None, 2 * 200_000 * 8192 * 72),
+    "cfg5:float64": ("cfg5", ["fused_sv_mvbs_kernel<double, float, true, false>"], None, 4 * 250_000 * 4096 * 12),
 }
 
 
@@ -32,6 +36,8 @@ def mean_per_kernel(d, counter):
                 acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     if not acc:  # the raw dumps were dropped: the per-kernel means kept in <src>/pmc_traffic.csv (scripts/final_round.sh)
         wl = os.path.basename(d).split("_", 1)[1]
+        if not os.path.exists(os.path.join(src, "pmc_traffic.csv")):
+            return {}
         for row in csv.reader(open(os.path.join(src, "pmc_traffic.csv"), newline="")):
             if row and row[0] == wl and row[2] == counter:
                 acc[row[1]].append(float(row[3]))
@@ -39,26 +45,29 @@ def mean_per_kernel(d, counter):
 
 
 out = {}
-for wl, (names, algo) in KERNELS.items():
+for key, (wl, names, _, algo) in KERNELS.items():
     fd, wd = os.path.join(src, f"fetch_{wl}"), os.path.join(src, f"write_{wl}")
     if not (os.path.isdir(fd) and os.path.isdir(wd)):
         continue
     fe, wr = mean_per_kernel(fd, "FETCH_SIZE"), mean_per_kernel(wd, "WRITE_SIZE")
-    fkb = sum(v for k, v in fe.items() if any(n in k for n in names) and "true>" not in k.split("fft_kernel")[-1][:40])
-    wkb = sum(v for k, v in wr.items() if any(n in k for n in names) and "true>" not in k.split("fft_kernel")[-1][:40])
+    pick = lambda k: any(n in k for n in names) and "true>" not in k.split("fft_kernel")[-1][:40]  # noqa: E731
+    fkb = sum(v for k, v in fe.items() if pick(k))
+    wkb = sum(v for k, v in wr.items() if pick(k))
+    if fkb == 0 and wkb == 0:
+        continue
     e = {"bytes_per_launch": 2 * fkb * 1024 + wkb * 1024, "fetch_size_kb_raw": fkb, "write_size_kb_raw": wkb,
          "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE x1"
-                       + ("; the two kernels of a step summed" if len(names) > 1 else ""),
+                       + ("; the kernels of a pass summed" if len(names) > 1 else ""),
          "algorithmic_bytes": algo, "csrc_sha16": csrc_hash(),
-         "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of bench.py --workload {wl} (profiles/r02_pmc_traffic.csv)"}
+         "source": f"profiles/r03_pmc_traffic.csv (bench.py --workload {wl.replace('_', ':')})"}
     k0f = [v for k, v in fe.items() if "power_coef_ek_kernel" in k]
     k0w = [v for k, v in wr.items() if "power_coef_ek_kernel" in k]
     if wl in ("cfg2", "cfg3") and k0f and k0w:  # K0 reads 5 x (C, P) f64 + small tables, writes 64 B per (c, p)
         cp = 4 * 500_000
         e["calibration"] = {"kernel": "power_coef_ek_kernel (known 80 MB read, 128 MB write)",
                             "FETCH_SIZE_ratio_raw": k0f[0] * 1024 / (cp * 40.0), "WRITE_SIZE_ratio_raw": k0w[0] * 1024 / (cp * 64.0)}
-    out[f"{wl}:float64"] = e
-    print(wl, "traffic / algorithmic = %.4f" % (e["bytes_per_launch"] / algo), e.get("calibration"))
+    out[key] = e
+    print(key, "traffic / algorithmic = %.4f" % (e["bytes_per_launch"] / algo), e.get("calibration"))
 path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 json.dump(out, open(path, "w"), indent=1)
 print("wrote", path)

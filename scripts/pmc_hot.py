@@ -9,7 +9,7 @@ from echopype_amd import _lib, ops, synth
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 if which in ("all", "chain"):
     C, P, S = 4, 100_000, 2000
-    d = synth.ek60_device(C, P, S)
+    d = synth.ek60_device(C, P, S, ss_every=1)  # a new sound speed at every ping: pass 2 = the drift kernel
     coef = ops.power_coef_ek(d["sample_interval"], d["transmit_duration_nominal"], d["transmit_power"],
                              d["sound_speed_indicative"], d["absorption_indicative"], d["gain_correction"], d["sa_correction"],
                              d["equivalent_beam_angle"], d["frequency_nominal"], d["transmit_duration_nominal"][:, 0].contiguous(),
@@ -22,6 +22,7 @@ if which in ("all", "chain"):
         sv, _, nz = ops.sv_noise_fused(d["backscatter_r"], coef, a2, 20, 50)
         res = ops.sv_denoise_mvbs(d["backscatter_r"], coef, a2, nz, 20, 3.0, bs, n_t, 1.0, n_r, want_noise=True)
         res = ops.sv_mvbs_fused(d["backscatter_r"], coef, bs, n_t, 1.0, n_r)
+        ops.mvbs(res["Sv"], bs, n_t, 1.0, n_r, coef=coef, coef_as_stored=True)
     torch.cuda.synchronize()
     print("chain samples per launch", C * P * S)
     del d, sv, res

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Round-3 GPU call: whole -m gpu suite, PMC HBM-traffic passes (separate --pmc passes, --kernel-trace only), the default
+# bench (its lines carry the traffic just measured), 2-rank gloo dry run, rocprofv3 kernel stats of the default bench,
+# instruction counters of the hot kernels.  Results under gpurun_out/final3/.
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/final3; rm -rf $O; mkdir -p $O
+python -m pytest tests -q -m gpu 2>&1 | tail -15 > $O/tests.txt; tail -3 $O/tests.txt
+for wl in cfg2 cfg3 cfg4 cfg4:planes64 cfg5; do
+  tag=$(echo $wl | tr ':' '_')
+  extra=""; [ $wl = cfg5 ] && extra="--pings-total 500000"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    n=fetch; [ $c = "FETCH_SIZE" ] || n=write
+    timeout 500 rocprofv3 --pmc $c --kernel-trace -d $O/${n}_$tag -o p --output-format csv -- python bench.py --workload $wl --no-cpu-baseline --steps 1 --warmup 1 --passes 2 $extra > $O/${n}_$tag.log 2>&1
+  done
+done
+for wl in cfg2 cfg3 cfg4 cfg4_planes64 cfg5; do for n in fetch write; do python scripts/pmc_summary.py $O/${n}_$wl kernel | grep -v "^kernel," | sed "s/^/$wl,/" ; done; done > $O/pmc_traffic.csv
+python scripts/make_traffic_json.py $O | tee $O/traffic.txt
+cp profiles/hbm_traffic.json $O/hbm_traffic.json
+find $O -name "*counter_collection.csv" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
+# (the bench lines come after the traffic measurement: they carry it, stamped with the hash of the sources)
+python bench.py --steps 20 --warmup 5 --out $O/bench_default.jsonl > $O/bench_default.log 2> $O/bench_default.err
+python bench.py --gpus 2 --backend gloo --single-device --pings-total 400000 > $O/bench_gloo2.json 2> $O/bench_gloo2.err
+rocprofv3 --kernel-trace --stats -d $O/kt -o k --output-format csv -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_under_rocprof.jsonl 2> $O/bench_under_rocprof.err
+find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+find $O/kt -name "*kernel_trace.csv" -delete
+bash scripts/gpu_pmc_hot.sh all > $O/pmc_hot.txt 2>&1; cp gpurun_out/pmc_hot/summary.csv $O/pmc_hot.csv
+python - <<'PY'
+import json
+for l in open("gpurun_out/final3/bench_default.jsonl"):
+    d = json.loads(l)
+    print(d["config"]["workload"][:50], d["dtype"], "| %.1f G/s  %.2f ms/pass  kernel %.2f ms  frac %.3f  traffic %s" % (
+        d["value"] / 1e9, d["config"]["ms_per_pass"], d["roofline"]["kernel_ms"], d["roofline"]["frac"],
+        None if d["roofline"]["traffic"] is None else round(d["roofline"]["traffic"] / 1e9, 2)), len(l))
+PY
+tail -8 $O/pmc_hot.txt; cat $O/traffic.txt | cut -c1-160

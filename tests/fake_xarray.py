@@ -49,3 +49,57 @@ class Dataset:
         out = Dataset(attrs={**self.attrs, **(attrs or {}), **kw})
         out.coords, out.data_vars = self.coords, self.data_vars
         return out
+
+
+# ---- a DataTree-like container, as echopype's EchoData wraps one (echodata/echodata.py:43-346) -----------------------
+class DataTreeNode:
+    """One group of the tree: ``.ds`` / ``.dataset`` / ``.to_dataset()`` give its Dataset, ``.children`` its sub-groups."""
+
+    def __init__(self, ds=None, children=None):
+        self._ds = ds if ds is not None else Dataset()
+        self.children = dict(children or {})
+
+    @property
+    def ds(self):
+        return self._ds
+
+    dataset = ds
+
+    def to_dataset(self):
+        return self._ds
+
+    def __getitem__(self, path):
+        node = self
+        for part in path.split("/"):
+            node = node.children[part]
+        return node
+
+
+class TreeEchoData:
+    """The read API of echopype's EchoData over a DataTree: ``ed[path]`` walks the tree and returns the group's Dataset,
+    or None for a group the file does not have (echodata.py:327-335); ``group_paths`` lists what exists;
+    ``sonar_model`` / ``source_file`` / ``converted_raw_path`` as attributes."""
+
+    def __init__(self, sonar_model, root, source_file=None):
+        self.sonar_model, self.source_file, self.converted_raw_path = sonar_model, source_file, None
+        self._tree = root
+
+    @property
+    def group_paths(self):
+        out = ["Top-level"]
+
+        def walk(node, prefix):
+            for name, child in node.children.items():
+                out.append(prefix + name)
+                walk(child, prefix + name + "/")
+
+        walk(self._tree, "")
+        return out
+
+    def __getitem__(self, key):
+        if key in (None, "Top-level"):
+            return self._tree.ds
+        try:
+            return self._tree[key].ds
+        except KeyError:
+            return None

@@ -103,3 +103,54 @@ def test_first_argument_by_keyword_and_add_depth_in_place(ep):
     assert "depth" in ds.data_vars and isinstance(out, fx.Dataset)           # the caller's dataset carries depth now
     np.testing.assert_allclose(ds["depth"].values, ds["echo_range"].values + 3.5, rtol=1e-15, equal_nan=True)
     assert "history" in ds["depth"].attrs
+
+
+# ---- EchoData as the converter writes it: a DataTree-like container, every group, the converter's dtypes ---------------
+def test_converter_shaped_echodata_through_the_chain(ep):
+    """tests/converter_layout.py: EK60 (float32 power + angle planes, byte flags, Environment on (channel, time1)), EK80 BB
+    and CW (float64 r / i planes with a string-labelled beam dimension, filter tables on (channel, filter_time, n), one
+    Environment timestamp), AZFP -- through compute_Sv / compute_TS, remove_background_noise and compute_MVBS: "xarray"
+    out, values identical to the lite-container path on the same numbers."""
+    import converter_layout as cl
+    from test_gpu_api import _ek80
+
+    # EK60
+    lite = ep.echodata.from_ek60_arrays(ep.synth.ek60_numpy(3, 50, 400, vary_tau=True))
+    ed = cl.ek60(lite)
+    assert ed["Sonar/Beam_group2"] is None and "Sonar/Beam_group1" in ed.group_paths and ed["Top-level"] is not None
+    ref = ep.calibrate.compute_Sv(lite)
+    ds = ep.calibrate.compute_Sv(ed)
+    assert isinstance(ds, fx.Dataset)
+    np.testing.assert_array_equal(ds["Sv"].values, ref["Sv"].values)
+    np.testing.assert_array_equal(ds["echo_range"].values, ref["echo_range"].values)
+    np.testing.assert_array_equal(ep.calibrate.compute_TS(ed)["TS"].values, ep.calibrate.compute_TS(lite)["TS"].values)
+    out = ep.clean.remove_background_noise(ds, 10, 40)
+    ref2 = ep.clean.remove_background_noise(ref, 10, 40)
+    np.testing.assert_allclose(out["Sv_corrected"].values, ref2["Sv_corrected"].values, rtol=1e-12, equal_nan=True)
+    mv = ep.commongrid.compute_MVBS(ds, range_bin="5m", ping_time_bin="10s")
+    np.testing.assert_allclose(mv["Sv"].values, ep.commongrid.compute_MVBS(ref, range_bin="5m", ping_time_bin="10s")["Sv"].values,
+                               rtol=1e-12, equal_nan=True)
+    # EK80 complex, BB and CW
+    for wf in ("BB", "CW"):
+        d, filt = _ek80(ep, wf, C=2, P=9, S=700, mixed_nan=True)
+        lite = ep.echodata.from_ek80_arrays(d, filt, filter_time_idx=[0])
+        ed = cl.ek80(lite)
+        kw = dict(waveform_mode=wf, encode_mode="complex")
+        ref = ep.calibrate.compute_Sv(lite, **kw)
+        ds = ep.calibrate.compute_Sv(ed, **kw)
+        assert isinstance(ds, fx.Dataset) and ds["Sv"].dims == DIMS
+        np.testing.assert_array_equal(ds["Sv"].values, ref["Sv"].values)
+        np.testing.assert_array_equal(ds["echo_range"].values, ref["echo_range"].values)
+        mv = ep.commongrid.compute_MVBS(ds, range_bin="1m", ping_time_bin="5s")
+        np.testing.assert_allclose(mv["Sv"].values,
+                                   ep.commongrid.compute_MVBS(ref, range_bin="1m", ping_time_bin="5s")["Sv"].values,
+                                   rtol=1e-12, equal_nan=True)
+    # AZFP (salinity / pressure from the user, as the reference requires)
+    lite = ep.echodata.from_azfp_arrays(ep.synth.azfp_numpy(3, 30, 200))
+    ed = cl.azfp(lite)
+    env = {"salinity": 29.6, "pressure": 60.0}
+    ref = ep.calibrate.compute_Sv(lite, env_params=env)
+    ds = ep.calibrate.compute_Sv(ed, env_params=env)
+    np.testing.assert_array_equal(ds["Sv"].values, ref["Sv"].values)
+    out = ep.clean.remove_background_noise(ds, 5, 30)
+    assert "Sv_corrected" in ds.data_vars and isinstance(out, fx.Dataset)
