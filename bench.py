@@ -191,7 +191,7 @@ def measured_traffic(key):
             return None, "no PMC run of this line"
         if e.get("csrc_sha16") != csrc_hash():
             return None, f"stale: PMC run at csrc {e.get('csrc_sha16')}"
-        return e["bytes_per_launch"], f"PMC FETCH/WRITE_SIZE, {e.get('source', 'profiles/')}, csrc {e['csrc_sha16']}"
+        return e["bytes_per_launch"], f"PMC FETCH/WRITE_SIZE, {e.get('source', 'profiles/').split(' ')[0]}, csrc {e['csrc_sha16']}"
     except Exception as ex:  # noqa: BLE001
         return None, f"unreadable profiles/hbm_traffic.json: {ex!r}"[:100]
 
@@ -620,7 +620,7 @@ def relaunch(args):
 
 def summary(out):
     r = out["roofline"]
-    return f"{out['value'] / 1e9:.1f} Gs/s, {out['config']['ms_per_pass']:.2f} ms/pass, kernel {r['kernel_ms']:.2f} ms, frac {r['frac']:.3f}"
+    return f"{out['value'] / 1e9:.1f} Gs/s {out['config']['ms_per_pass']:.2f} ms/pass frac {r['frac']:.3f}"
 
 
 def main():

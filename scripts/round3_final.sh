@@ -7,7 +7,7 @@ O=gpurun_out/final3; rm -rf $O; mkdir -p $O
 python -m pytest tests -q -m gpu 2>&1 | tail -15 > $O/tests.txt; tail -3 $O/tests.txt
 for wl in cfg2 cfg3 cfg4 cfg4:planes64 cfg5; do
   tag=$(echo $wl | tr ':' '_')
-  extra=""; [ $wl = cfg5 ] && extra="--pings-total 500000"
+  extra=""
   for c in FETCH_SIZE WRITE_SIZE; do
     n=fetch; [ $c = "FETCH_SIZE" ] || n=write
     timeout 500 rocprofv3 --pmc $c --kernel-trace -d $O/${n}_$tag -o p --output-format csv -- python bench.py --workload $wl --no-cpu-baseline --steps 1 --warmup 1 --passes 2 $extra > $O/${n}_$tag.log 2>&1
