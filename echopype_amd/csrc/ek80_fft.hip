@@ -41,8 +41,6 @@
 //     non-zero staged samples (wave ballots) and its prefix popcounts.
 //   * a tile holding a sample whose sectors are only PARTLY NaN (never seen in files, allowed by the
 //     reference) is redone one sector at a time (block-uniform branch).
-#include <cstdlib>
-
 #include "fast_math.h"
 
 namespace {
@@ -173,7 +171,8 @@ struct LaneMap {
   int a1, a2, a3;  // first element of the lane's butterfly in the stride-64, stride-8 and stride-1 passes
   int t1, t2;      // twiddle table index (w_2048^t) of those butterflies' offset
 };
-__device__ __forceinline__ LaneMap lane_map(int j = threadIdx.x) {
+__device__ __forceinline__ LaneMap lane_map() {
+  const int j = threadIdx.x;
   LaneMap m;
   // After the first pass the transform is four independent 512-point transforms, elements [512 w, 512 w + 512): a
   // wavefront holds exactly one of them (64 lanes x 8 elements), so its three inner passes -- and their inverses --
@@ -208,8 +207,8 @@ constexpr int kTwEntries = kSmallTw<F> ? 68 : 256;
 // first forward pass (sub-size 2048, radix 4, two butterflies per lane), on the lane's registers:
 // v[i] = sample j + 256 i.  tw = 256-entry table of w_2048^m.
 template <typename F, bool SMALL>
-__device__ __forceinline__ void fwd_pass0(C2<F> (&v)[8], const C2<F>* tw, int j = threadIdx.x) {
-  const C2<F> wa = tw_any<F, SMALL>(tw, j);
+__device__ __forceinline__ void fwd_pass0(C2<F> (&v)[8], const C2<F>* tw) {
+  const C2<F> wa = tw_any<F, SMALL>(tw, threadIdx.x);
   const F kH = (F)0.70710678118654752440;
   const C2<F> wb = C2<F>{(wa.re + wa.im) * kH, (wa.im - wa.re) * kH};  // w^(j+256) = w^j e^{-i pi/4}
   dft4(v[0], v[2], v[4], v[6]);
@@ -218,8 +217,8 @@ __device__ __forceinline__ void fwd_pass0(C2<F> (&v)[8], const C2<F>* tw, int j 
   twiddle4<F, false>(v[3], v[5], v[7], wb);
 }
 template <typename F, bool SMALL>
-__device__ __forceinline__ void inv_pass0(C2<F> (&v)[8], const C2<F>* tw, int j = threadIdx.x) {
-  const C2<F> wa = tw_any<F, SMALL>(tw, j);
+__device__ __forceinline__ void inv_pass0(C2<F> (&v)[8], const C2<F>* tw) {
+  const C2<F> wa = tw_any<F, SMALL>(tw, threadIdx.x);
   const F kH = (F)0.70710678118654752440;
   const C2<F> wb = C2<F>{(wa.re + wa.im) * kH, (wa.im - wa.re) * kH};
   twiddle4<F, true>(v[2], v[4], v[6], wa);
@@ -239,10 +238,6 @@ __device__ __forceinline__ void st8(unsigned char* xs, int a0, const C2<F> (&v)[
   for (int r = 0; r < 8; ++r) Xs<F>::st(xs, a0 + STRIDE * r, v[r]);
 }
 
-template <typename F>
-__device__ __forceinline__ void correlate_inner(C2<F> (&v)[8], unsigned char* xs, const C2<F>* tw,
-                                                const C2<F>* __restrict__ spec, const LaneMap& lm);
-
 // Circular correlation of the tile held as v[i] = x[j + 256 i] with the channel's replica (spectrum `spec` in
 // the digit-reversed order of the forward transform, conj and 1/N applied).  Result in v, same ownership.
 // Barriers: the caller guarantees nobody still reads xs on entry; on exit xs holds nothing of value.
@@ -255,19 +250,6 @@ __device__ __forceinline__ void correlate(C2<F> (&v)[8], unsigned char* xs, cons
 #pragma unroll
   for (int i = 0; i < 8; ++i) Xs<F>::st(xs, j + 256 * i, v[i]);
   __syncthreads();
-  correlate_inner<F>(v, xs, tw, spec, lm);
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = Xs<F>::ld(xs, j + 256 * i);
-  inv_pass0<F, SMALL>(v, tw);
-}
-
-// The five wave-local LDS round trips between the first forward and the last inverse pass (the tile is in xs in the
-// order the first pass left it, and goes back there for the last pass); no workgroup barrier inside.
-template <typename F>
-__device__ __forceinline__ void correlate_inner(C2<F> (&v)[8], unsigned char* xs, const C2<F>* tw,
-                                                const C2<F>* __restrict__ spec, const LaneMap& lm) {
-  constexpr bool SMALL = kSmallTw<F>;
   ld8<F, 64>(xs, lm.a1, v);
   dft8(v);
   twiddle8<F, false>(v, tw_mul4<F, SMALL>(tw, lm.t1));
@@ -298,6 +280,10 @@ __device__ __forceinline__ void correlate_inner(C2<F> (&v)[8], unsigned char* xs
   twiddle8<F, true>(v, tw_mul4<F, SMALL>(tw, lm.t1));
   idft8(v);
   st8<F, 64>(xs, lm.a1, v);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = Xs<F>::ld(xs, j + 256 * i);
+  inv_pass0<F, SMALL>(v, tw);
 }
 
 // ---- workspace layout (doubles):
@@ -795,354 +781,14 @@ void sv_complex_fft_kernel(FftArgs a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// The complex128 transform on float32 planes, software-pipelined (round 3).
-//
-// One tile per 256-lane workgroup keeps at most 4 tiles per CU in flight (122 VGPRs and 40 KB of LDS each), and a
-// workgroup spends a third of its life waiting for the 64 KB of raw sectors of its tile: measured 38.7 ms where the
-// streaming part alone takes 24.4 and the arithmetic alone 28.9 (profiles/r03_fft_experiments.txt).  Here a PERSISTENT
-// workgroup of 512 lanes splits the work of a tile between two groups of four wavefronts,
-//   IO  (lanes 0-255)   raw sectors -> sector sums, zero / validity masks, first radix-4 pass -> LDS buffer
-//                       ... two steps later: last radix-4 pass of the same tile <- LDS buffer, epilogue, stores
-//   FFT (lanes 256-511) the five wave-local LDS round trips of the tile the IO group staged one step earlier
-// and walks its tiles in steps separated by ONE LDS-only barrier.  The IO group requests the raw sectors of tile k + 1
-// at the end of step k and sums them in step k + 1: its 64 registers of loads are in flight all the time (2 x 64 KB per
-// CU instead of 1.3 x on average), while the FFT group never waits for memory.  Two LDS tile buffers (the IO group
-// refills the buffer whose result it has just drained, lane by lane the same eight elements), 77 KB per workgroup, two
-// workgroups per CU.  Tiles with partly-NaN samples are recorded for the per-sector kernel exactly as before.
-// ------------------------------------------------------------------------------------------------
-// the per-(channel, ping) numbers of the epilogue
-template <typename T>
-struct RowC {
-  double ra, rb;
-  T shift, alpha2, Aadd, pscale;
-  bool tabulated;
-};
-template <typename T>
-__device__ __forceinline__ RowC<T> load_row(const double* __restrict__ ccoef, size_t row, const double* tkey) {
-  const double* cc = ccoef + row * EPA_NCCOEF;
-  RowC<T> r;
-  r.ra = cc[EPA_CC_RA];
-  r.rb = cc[EPA_CC_RB];
-  r.shift = (T)cc[EPA_CC_SHIFT];
-  r.alpha2 = (T)cc[EPA_CC_ALPHA2];
-  r.Aadd = (T)cc[EPA_CC_A];
-  r.pscale = (T)cc[EPA_CC_PSCALE];
-  // (float output: the hardware logarithm is cheaper than the table read -- measured; the table is not built then)
-  r.tabulated = sizeof(T) == 8 && ((tkey[0] == r.ra) & (tkey[1] == r.rb) & (tkey[2] == cc[EPA_CC_SHIFT]) &
-                                   (tkey[3] == cc[EPA_CC_ALPHA2]));
-  return r;
-}
-
-struct RawTile {  // the eight samples of a lane as loaded: 4 sectors x (re, im)
-  float4 r[8], i[8];
-};
-
-__device__ __forceinline__ void lds_barrier() {  // orders LDS traffic only: outstanding global loads / stores fly on
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <typename T>
-__global__ __launch_bounds__(512, 4) void sv_complex_fft_pipe_kernel(FftArgs a, long long n_tiles) {
-  typedef double F;
-  typedef float InT;
-  constexpr int B = 4;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* xs0 = smem;
-  unsigned char* xs1 = smem + Xs<F>::kBytes;
-  C2<F>* tw = reinterpret_cast<C2<F>*>(smem + 2 * Xs<F>::kBytes);                      // [68]
-  double2* log_tab = reinterpret_cast<double2*>(tw + kTwEntries<F>);                    // [kLogTabN]
-  unsigned long long* nzw = reinterpret_cast<unsigned long long*>(log_tab + epa::kLogTabN);  // [3][36]
-  unsigned* wflags = reinterpret_cast<unsigned*>(nzw + 3 * 36);                         // [3][4]
-  const int tid = threadIdx.x;
-  const bool io = tid < 256;
-  const int j = tid & 255, lane = tid & 63, wave = (tid >> 6) & 3;
-  {
-    const C2<F>* wtab = reinterpret_cast<const C2<F>*>(a.ws + ws_tw64());
-    if (tid < 68) tw[tid] = tid < 64 ? wtab[4 * tid] : wtab[tid - 64];
-    if (tid >= 256 && tid - 256 < epa::kLogTabN) log_tab[tid - 256] = reinterpret_cast<const double2*>(a.log_tab)[tid - 256];
-  }
-  const LaneMap lm = lane_map(j);
-  const int S = a.S;
-  const long long first = blockIdx.x, stride = gridDim.x;
-  const long long T_ = first < n_tiles ? (n_tiles - first + stride - 1) / stride : 0;  // tiles of this workgroup
-  const int tiles_per_chan_ping = a.tiles;
-  const double nspread_d = a.nspread;
-  const epa::LogCoef lk = epa::make_log_coef();
-  T* out = reinterpret_cast<T*>(a.out);
-  T* range_out = reinterpret_cast<T*>(a.range_out);
-  T* prx_out = reinterpret_cast<T*>(a.prx_out);
-  const InT* re = reinterpret_cast<const InT*>(a.re);
-  const InT* im = reinterpret_cast<const InT*>(a.im);
-  double rmin = __builtin_inf(), rmax = -__builtin_inf();
-  unsigned rnan = 0;
-
-  auto locate = [&](long long k, int& c, int& p, int& tile) {  // tile k of this workgroup
-    const long long lin = first + k * stride;
-    tile = (int)(lin % tiles_per_chan_ping);
-    const long long row = lin / tiles_per_chan_ping;
-    p = (int)(row % a.P);
-    c = (int)(row / a.P);
-  };
-  auto request = [&](long long k, RawTile& raw) {  // the lane's eight samples of tile k (zeros past the ping's end)
-    int c, p, tile;
-    locate(k, c, p, tile);
-    const size_t ping_base = ((size_t)c * a.P + p) * (size_t)S;
-    const int k_begin = tile * a.out_per_tile;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {  // unconditional loads (positions past the ping's end read its last sample: never used)
-      const int sx = min(k_begin + j + 256 * i, S - 1);
-      raw.r[i] = *reinterpret_cast<const float4*>(re + (ping_base + sx) * B);
-      raw.i[i] = *reinterpret_cast<const float4*>(im + (ping_base + sx) * B);
-    }
-  };
-
-  lds_barrier();  // tw / log_tab are in place
-  // The two groups run their OWN loops over the same T_ + 2 steps (the barrier counts wavefronts, not program points):
-  // what the IO group carries from step to step -- 64 registers of sectors in flight -- is then no live range of the
-  // FFT group's code.
-  if (!io) {
-    for (long long k = 0; k < T_ + 2; ++k) {
-      if (k >= 1 && k <= T_) {  // the inner passes of tile k - 1, staged by the IO group one step ago
-        const long long f = k - 1;
-        const int slot = (int)(f % 3);
-        const unsigned flags = wflags[slot * 4] | wflags[slot * 4 + 1] | wflags[slot * 4 + 2] | wflags[slot * 4 + 3];
-        if (!(flags & 1u)) {
-          int c, p, tile;
-          locate(f, c, p, tile);
-          const C2<F>* spec = reinterpret_cast<const C2<F>*>(a.ws + ws_spec64(a.C, c));
-          C2<F> v[8];
-          correlate_inner<F>(v, (f & 1) ? xs1 : xs0, tw, spec, lm);
-        }
-      }
-      lds_barrier();
-    }
-    return;
-  }
-  RawTile raw;
-  unsigned vb0 = 0, vb1 = 0, vb2 = 0;  // validity bits of the tiles of steps k, k - 1, k - 2 (as vbits of process_tile)
-  if (T_ > 0) request(0, raw);
-  for (long long k = 0; k < T_ + 2; ++k) {
-    unsigned char* xs_k = (k & 1) ? xs1 : xs0;
-    {
-      // ---- (1) tile k - 2: last pass, epilogue, stores
-      if (k >= 2) {
-        const long long e = k - 2;
-        const int slot = (int)(e % 3);
-        const unsigned flags = wflags[slot * 4] | wflags[slot * 4 + 1] | wflags[slot * 4 + 2] | wflags[slot * 4 + 3];
-        int c, p, tile;
-        locate(e, c, p, tile);
-        if (flags & 1u) {  // (uniform) a partly-NaN sample: left to the per-sector kernel
-          if (j == 0) {
-            const size_t lin = ((size_t)c * a.P + p) * a.tiles + tile;
-            atomicOr(a.mixed_map + (lin >> 5), 1u << (lin & 31));
-            atomicAdd(a.mixed_cnt, 1u);
-          }
-        } else {
-          const double* chan = a.ws + ws_chan() + 4 * (size_t)c;
-          // prefix popcounts of the non-zero mask, per wavefront (restores the exact zeros of the direct form)
-          const unsigned long long* nz = nzw + slot * 36;
-          unsigned excl = 0;
-          const bool zeros = (flags & 2u) != 0u;  // (uniform)
-          if (zeros) {
-            const unsigned cnt = lane < 32 ? (unsigned)__popcll(nz[lane]) : 0u;
-            unsigned incl = cnt;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-              const unsigned up = __shfl_up(incl, o, 64);
-              if (lane >= o) incl += up;
-            }
-            excl = incl - cnt;  // lane w: non-zero samples before word w (lane 32: the total)
-          }
-          const int lo = (int)chan[1], hi = (int)chan[2];
-          // sector mean -> prx -> Sv/TS (calibrate_ek.py:483-490, 571-638), as process_tile
-          const size_t row = (size_t)c * a.P + p;
-          const double* tkey = a.tvg + (size_t)c * (S + 4);
-          const double* tvg_tab = tkey + 4;
-          const RowC<T> rc = load_row<T>(a.ccoef, row, tkey);
-          const double inv_norm_b = (1.0 / chan[0]) / (double)B;
-          const int k_begin = tile * a.out_per_tile;
-          const C2<F> wa = tw_any<F, true>(tw, j);
-          const F kH = 0.70710678118654752440;
-          const C2<F> wb = C2<F>{(wa.re + wa.im) * kH, (wa.im - wa.re) * kH};  // w^(j + 256)
-          // the last radix-4 pass couples the samples i = h, h + 2, h + 4, h + 6 of a lane: two independent halves,
-          // each read from LDS, finished and written out before the other (the sectors of tile k + 1 are in flight in 64
-          // registers meanwhile)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            C2<F> u[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) u[q] = Xs<F>::ld(xs_k, j + 256 * (h + 2 * q));
-            twiddle4<F, true>(u[1], u[2], u[3], h == 0 ? wa : wb);
-            idft4(u[0], u[1], u[2], u[3]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int i = h + 2 * q;
-              const int t = j + 256 * i, sx = k_begin + t;
-              C2<F> y = u[q];
-              if (zeros) {
-                const int ta = t + lo, tb = min(t + hi, kN);
-                const unsigned wa_ = __shfl(excl, ta >> 6, 64), wb_ = __shfl(excl, tb >> 6, 64);
-                const unsigned long long na = (ta >> 6) < 32 ? nz[ta >> 6] : 0ull, nb2 = (tb >> 6) < 32 ? nz[tb >> 6] : 0ull;
-                const unsigned ca = wa_ + (unsigned)__popcll(na & ((1ull << (ta & 63)) - 1ull));
-                const unsigned cb = wb_ + (unsigned)__popcll(nb2 & ((1ull << (tb & 63)) - 1ull));
-                if (t < a.out_per_tile && ca == cb) y = C2<F>{0.0, 0.0};
-              }
-              if (t < a.out_per_tile && sx < S) {
-                T mr, mi;
-                if (!((vb2 >> i) & 1u)) {
-                  mr = mi = epa::M<T>::nan();
-                } else {
-                  mr = (T)(y.re * inv_norm_b);
-                  mi = (T)(y.im * inv_norm_b);
-                }
-                T prx = rc.pscale * (mr * mr + mi * mi);
-                if (!(prx > (T)0)) prx = epa::M<T>::nan();
-                const double R = ((double)sx * rc.ra) * rc.rb;  // range.py:138 operation order
-                T tvg;
-                if (rc.tabulated) {
-                  tvg = (T)tvg_tab[sx];
-                } else {
-                  T rt = sub_rn((T)R, rc.shift);
-                  if (!(rt > (T)0)) rt = epa::M<T>::nan();
-                  tvg = (T)nspread_d * epa::fast_log10_lean(rt, log_tab, lk) + rc.alpha2 * rt;
-                }
-                const bool range_ok = ((vb2 >> (8 + i)) & 1u) != 0u;
-                const T val = range_ok ? ((T)10 * epa::fast_log10_lean(prx, log_tab, lk) + tvg) + rc.Aadd : epa::M<T>::nan();
-                const size_t o = row * S + sx;
-                out[o] = val;
-                if (range_out || a.stats_part) {
-                  if (range_out) range_out[o] = range_ok ? (T)R : epa::M<T>::nan();
-                  if (range_ok) {
-                    const double rr = (double)(T)R;
-                    rmin = fmin(rmin, rr);
-                    rmax = fmax(rmax, rr);
-                  } else {
-                    ++rnan;
-                  }
-                }
-                if (prx_out) prx_out[o] = prx;
-              }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-      // ---- (2) tile k: sector sums of the sectors requested a step ago, masks, first pass -> this step's buffer
-      vb2 = vb1;
-      vb1 = vb0;
-      if (k < T_) {
-        int c, p, tile;
-        locate(k, c, p, tile);
-        const int k_begin = tile * a.out_per_tile;
-        const int slot = (int)(k % 3);
-        C2<F> v[8];
-        unsigned vbits = 0, mixed_l = 0, zero_l = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float4 r4 = raw.r[i], i4 = raw.i[i];
-          const bool in = k_begin + j + 256 * i < S;
-          const double fr = ((double)r4.x + (double)r4.y) + ((double)r4.z + (double)r4.w);
-          const double fi = ((double)i4.x + (double)i4.y) + ((double)i4.z + (double)i4.w);
-          unsigned m;
-          double sr = 0.0, si = 0.0;
-          if (__builtin_expect(in && fr == fr && fi == fi, 1)) {
-            // (the sums of process_tile: ((x + y) + z) + w in load_sample) -- kept identical below
-            sr = (((double)r4.x + (double)r4.y) + (double)r4.z) + (double)r4.w;
-            si = (((double)i4.x + (double)i4.y) + (double)i4.z) + (double)i4.w;
-            m = 0xfu | 0x100u;
-          } else {
-            m = 0;
-            if (in) {
-              const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w};
-#pragma unroll
-              for (int b = 0; b < 4; ++b) {
-                if (rr[b] == rr[b] && ii[b] == ii[b]) {
-                  m |= 1u << b;
-                  sr += (double)rr[b];
-                  si += (double)ii[b];
-                }
-              }
-              if (rr[0] == rr[0]) m |= 0x100u;
-            }
-          }
-          v[i] = C2<F>{sr, si};
-          vbits |= ((m & 0xfu) != 0u ? 1u : 0u) << i;
-          vbits |= ((m >> 8) & 1u) << (8 + i);
-          mixed_l |= ((m & 0xfu) != 0u && (m & 0xfu) != 0xfu) ? 1u : 0u;
-          const bool nz = sr != 0.0 || si != 0.0;
-          const unsigned long long bal = __ballot(nz);
-          if (lane == 0) nzw[slot * 36 + 4 * i + wave] = bal;
-          zero_l |= nz ? 0u : 2u;
-        }
-        vb0 = vbits;
-        {
-          const unsigned any = (__ballot(mixed_l != 0u) != 0ull ? 1u : 0u) | (__ballot(zero_l != 0u) != 0ull ? 2u : 0u);
-          if (lane == 0) wflags[slot * 4 + wave] = any;
-          if (j == 0) nzw[slot * 36 + 32] = 0ull;
-        }
-        fwd_pass0<F, true>(v, tw, j);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) Xs<F>::st(xs_k, j + 256 * i, v[i]);
-        // ---- (3) the sectors of tile k + 1 start their way
-        if (k + 1 < T_) request(k + 1, raw);
-      }
-    }
-    lds_barrier();
-  }
-  if (a.stats_part) {  // {nanmin, nanmax, NaN count} of the echo_range written by this wavefront
-    double cnt = (double)rnan;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      rmin = fmin(rmin, __shfl_down(rmin, o, 64));
-      rmax = fmax(rmax, __shfl_down(rmax, o, 64));
-      cnt += __shfl_down(cnt, o, 64);
-    }
-    if (lane == 0) {
-      double* dst = a.stats_part + 3 * ((blockIdx.x * 4 + wave) & (kStatSlots - 1));
-      if (rmin <= rmax) {
-        atomicMin(dst, rmin);
-        atomicMax(dst + 1, rmax);
-      }
-      if (cnt > 0.0) atomicAdd(dst + 2, cnt);
-    }
-  }
-}
-
-constexpr size_t kPipeLdsBytes = 2 * Xs<double>::kBytes + kTwEntries<double> * sizeof(C2<double>) +
-                                 epa::kLogTabN * sizeof(double2) + 3 * 36 * 8 + 3 * 4 * 4 + 16;
-
 template <typename InT, typename T, typename F>
 int launch_fft(FftArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)((long long)a.P * a.tiles), (unsigned)a.C);
   const bool b4 = a.B == 4 && (reinterpret_cast<uintptr_t>(a.re) & 15u) == 0 &&
                   (reinterpret_cast<uintptr_t>(a.im) & 15u) == 0;
   const int slow_grid = a.map_words < 2048 ? a.map_words : 2048;
-  static const bool pipe_off = [] {  // development knob: EPA_FFT_PIPE=0 keeps the one-tile-per-workgroup kernel
-    const char* e = getenv("EPA_FFT_PIPE");
-    return e && e[0] == '0';
-  }();
   if (b4) {
-    if constexpr (sizeof(InT) == 4 && sizeof(F) == 8) {
-      if (!pipe_off) {
-        auto kern = sv_complex_fft_pipe_kernel<T>;
-        EPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)kPipeLdsBytes));
-        const long long n_tiles = (long long)a.C * a.P * a.tiles;
-        int cus = 256;
-        {
-          int dev = 0;
-          hipDeviceProp_t prop;
-          if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        }
-        const long long wgs = n_tiles < 2ll * cus ? n_tiles : 2ll * cus;  // two resident workgroups per CU
-        hipLaunchKernelGGL(kern, dim3((unsigned)(wgs > 0 ? wgs : 1)), dim3(512), kPipeLdsBytes, st, a, n_tiles);
-      } else {
-        hipLaunchKernelGGL((sv_complex_fft_kernel<InT, T, F, 4, false>), grid, dim3(epa::kBlock), 0, st, a);
-      }
-    } else {
-      hipLaunchKernelGGL((sv_complex_fft_kernel<InT, T, F, 4, false>), grid, dim3(epa::kBlock), 0, st, a);
-    }
+    hipLaunchKernelGGL((sv_complex_fft_kernel<InT, T, F, 4, false>), grid, dim3(epa::kBlock), 0, st, a);
     hipLaunchKernelGGL((sv_complex_fft_kernel<InT, T, F, 4, true>), dim3(slow_grid), dim3(epa::kBlock), 0, st, a);
   } else {
     hipLaunchKernelGGL((sv_complex_fft_kernel<InT, T, F, 0, false>), grid, dim3(epa::kBlock), 0, st, a);
