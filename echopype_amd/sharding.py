@@ -226,6 +226,13 @@ class EdgeExchange:
         arrays, device): two kernel launches around the all-reduce for any number of bins up to 16."""
         if not self.shared:
             return
+        if self.device.type != "cuda":  # CPU tensors (bookkeeping tests): totals, then the same formula with torch
+            for (k, w), (s, c) in self.merge(rows).items():
+                if self.edges[self._index[(k, w)]][3]:
+                    d = dst[(k, w)]
+                    d.copy_(torch.where(c > 0, 10.0 * torch.log10(s / c.clamp_min(1.0)),
+                                        torch.full_like(s, fill_value)).to(d.dtype))
+            return
         self._exchange(rows)
         from . import ops
 

@@ -273,3 +273,65 @@ def test_noise_blocks_cut_by_shard_edges_equal_single_process(P_total, split, pi
     for rank, p0, p1, noise in res:
         blk = (np.arange(p1 - p0) + p0 % ping_num) // ping_num
         np.testing.assert_allclose(noise[:, blk], per_ping[:, p0:p1], rtol=1e-12, atol=1e-10)
+
+
+# ---- MVBSShard.finish (merge + finalise into the MVBS rows), kept plans, collective decisions ------------------------
+def _worker_finish(rank, world, port, P_total, split, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from echopype_amd import sharding
+
+    rng = np.random.default_rng(42)
+    C, S = 2, 64
+    Sv = rng.normal(-70, 6, size=(C, P_total, S))
+    er = np.tile(np.arange(S) * 0.19, (C, P_total, 1))
+    ns = (np.datetime64("2026-05-01T00:00:03", "ns").astype(np.int64) + np.arange(P_total) * 10**9)
+    bounds = [0] + list(split) + [P_total]
+    p0, p1 = bounds[rank], bounds[rank + 1]
+    dt = 20 * 10**9
+    shard = sharding.MVBSShard()
+    outs = []
+    for rep in range(2):  # the second call finds the plan kept by the first (one scalar all-reduce checks that on every rank)
+        e0, n_glob, first, last = shard.time_grid(ns[p0:p1], dt, "left")
+        rmax = shard.range_max(float(np.nanmax(er[:, p0:p1])))
+        r_edges = np.arange(0, rmax + 1.0, 1.0)
+        n_t = last - first + 1
+        ssum, cnt = _partials(Sv[:, p0:p1], er[:, p0:p1], ns[p0:p1], e0, dt, n_t, first, r_edges)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mv = np.where(cnt > 0, 10 * np.log10(ssum / np.maximum(cnt, 1)), np.nan)
+        res = {"sum": torch.from_numpy(ssum), "cnt": torch.from_numpy(cnt.astype(np.float64)), "MVBS": torch.from_numpy(mv)}
+        kept, lo = shard.finish(res, first, last, float("nan"))
+        outs.append((first + lo, kept.numpy().copy()))
+    assert len(shard._plans) == 1
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    # a decision taken on one rank only becomes everybody's
+    agreed = shard.agree(rank == world - 1)
+    q.put((rank, e0, outs[0][0], outs[0][1], agreed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("P_total,split", [(100, (47,)), (70, (13, 36))])
+def test_mvbs_shard_finish_kept_plan_and_collective_decision(P_total, split):
+    world = len(split) + 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_finish, args=(r, world, port, P_total, split, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(42)
+    C, S = 2, 64
+    Sv = rng.normal(-70, 6, size=(C, P_total, S))
+    er = np.tile(np.arange(S) * 0.19, (C, P_total, 1))
+    pt = np.datetime64("2026-05-01T00:00:03", "ns") + (np.arange(P_total) * 10**9).astype("timedelta64[ns]")
+    exp, t_left, _ = ogrid.compute_MVBS(Sv, er, pt, "1m", "20s")
+    got = np.concatenate([r[3] for r in res], axis=1)  # the ranks' kept bins, in rank order = in time order
+    assert [r[2] for r in res] == list(np.cumsum([0] + [r[3].shape[1] for r in res[:-1]]))
+    np.testing.assert_allclose(got, exp, rtol=1e-12, equal_nan=True)
+    assert all(r[4] for r in res)
