@@ -1,6 +1,7 @@
 """Shared plumbing of the calibrators (mirrors calibrate/calibrate_base.py:10-128)."""
 import abc
 import logging
+import os
 
 import numpy as np
 
@@ -31,6 +32,21 @@ def cp_array(v, C, P, name="parameter"):
         if a.shape == (C, 1):
             return np.ascontiguousarray(np.broadcast_to(a, (C, P)))
     raise ValueError(f"{name} of shape {a.shape} cannot be broadcast to (channel={C}, ping_time={P})")
+
+
+class PowerSource:
+    """What a deferred Sv/TS of power samples is made from (``LazyDeviceArray.source``): the raw samples, the
+    coefficient rows, the kernel flags, and the lazy echo_range that travels with it."""
+
+    __slots__ = ("raw", "coef", "flags", "cal_type", "dtype", "echo_range", "raw_version")
+
+    def __init__(self, raw, coef, flags, cal_type, dtype, echo_range):
+        self.raw, self.coef, self.flags, self.cal_type, self.dtype = raw, coef, flags, cal_type, dtype
+        self.echo_range, self.raw_version = echo_range, raw._version
+
+    def intact(self):
+        """The raw samples have not been written to since compute_Sv looked at them."""
+        return self.raw._version == self.raw_version
 
 
 class CalibrateBase(abc.ABC):
@@ -137,6 +153,11 @@ class CalibrateBase(abc.ABC):
         return ops.to_device(np.asarray(getattr(a, "values", a)), dtype=dtype, device=self.device)
 
     @staticmethod
+    def defer_enabled():
+        """EPA_DEFER_SV=0 turns the deferred Sv off (compute_Sv then runs its kernel before it returns)."""
+        return os.environ.get("EPA_DEFER_SV", "1") != "0"
+
+    @staticmethod
     def _wrap(t, dims, attrs=None, name=None, stats=None):
         if isinstance(t, DeviceArray):  # (a LazyDeviceArray carries its statistics already)
             return DataArray(t, dims, attrs=attrs, name=name)
@@ -153,6 +174,30 @@ class CalibrateBase(abc.ABC):
         out_t, _, stats = ops.sv_power(raw, coef, cal_type=cal_type, flags=flags, dtype=self.dtype, want_range=False,
                                        want_range_stats=True)
         return out_t, self._lazy_power_range(raw, coef, flags, stats), stats
+
+    def _deferred_sv_power(self, raw, coef, cal_type, flags):
+        """Sv/TS of power samples left to its first reader (the reference's Sv of a dask-backed EchoData is as lazy):
+        ``(sv, echo_range)`` as two LazyDeviceArrays.  Whoever reads ``sv.tensor`` runs K1 (``epa_sv_power_stats``: the
+        array + the echo_range statistics); ``compute_MVBS`` -- the usual next call -- recognises ``sv.source`` and
+        produces the array as a by-product of its own pass over the raw samples (``epa_sv_mvbs_fused``: 12 B/sample
+        for the two calls instead of 12 + 8).  Same values either way (the kernels share the arithmetic)."""
+        rng = self._lazy_power_range(raw, coef, flags)
+        version, dtype = raw._version, self.dtype
+        src = PowerSource(raw, coef, flags, cal_type, dtype, rng)
+
+        def make():
+            if raw._version != version:
+                raise RuntimeError(f"{cal_type} was left lazy by compute_{cal_type} and backscatter_r has been "
+                                   "modified in place since")
+            out_t, _, stats = ops.sv_power(raw, coef, cal_type=cal_type, flags=flags, dtype=dtype, want_range=False,
+                                           want_range_stats=True)
+            if rng.coef_rows() is not None:  # (the echo_range array, if somebody has read it, is still untouched)
+                rng.set_stats(stats)
+            return out_t
+
+        sv = LazyDeviceArray(tuple(raw.shape), dtype, raw.device, make, source=src)
+        rng.set_stats(None, hook=lambda: sv.tensor)  # statistics asked for first: they come with the Sv pass
+        return sv, rng
 
     def _lazy_power_range(self, raw, coef, flags, stats=None):
         """echo_range of power samples as a LazyDeviceArray: coefficient rows + the raw samples' NaN pattern; written by

@@ -201,6 +201,12 @@ class CalibrateEK(CalibrateBase):
     def _cal_power_samples(self, cal_type):
         """One fused pass for calibrate_ek.py:79-206."""
         raw, coef, flags, tau_eff = self._power_inputs(cal_type)
+        # (float64 only: the fused kernel bins on the range in double, compute_MVBS on a float32 dataset on the range
+        # rounded to float32 as the array would hold it -- a sample on a bin edge could change sides)
+        if cal_type == "Sv" and self.dtype == torch.float64 and self.defer_enabled() and \
+                ops.sv_power_vectorized(raw, raw.shape[2], self.dtype):
+            out_t, range_t = self._deferred_sv_power(raw, coef, cal_type, flags)
+            return self._finish(cal_type, out_t, range_t, tau_eff)
         out_t, range_t, stats = self._sv_power_lazy_range(raw, coef, cal_type, flags)
         return self._finish(cal_type, out_t, range_t, tau_eff, range_stats=stats)
 

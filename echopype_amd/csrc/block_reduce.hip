@@ -29,6 +29,8 @@ enum { BIN_PHYS = 0, BIN_INDEX = 1 };
 
 struct ReduceArgs {
   double* range_max_out;      // fused fast path only
+  double* range_stats_out;    // fused fast path only: {nanmin, nanmax, NaN count} of the echo_range, with range_max_out
+  int range_stats_filled;     // set by run_mvbs when the kernel it chose leaves them
   const int16_t* raw_i16;     // fused fast path only: instrument int16 power samples ...
   const int32_t* n_valid;     // ... with the recorded length of every ping
   const float* raw;
@@ -505,7 +507,7 @@ int epa_fused_fast_path(const void* raw, int raw_is_i16, const int32_t* n_valid,
                         int n_rbins, unsigned bin_flags, double fill_value, void* sv_out,
                         void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
                         size_t lds_bytes, unsigned cnt_off, unsigned long long* rmax_key,
-                        hipStream_t st);
+                        unsigned long long* rstat, hipStream_t st);
 
 // chain_fast.hip
 int epa_mvbs_rows_fast_path(const void* sv, const double* coef, int C, int P, int S, const int32_t* bin_start,
@@ -601,13 +603,14 @@ int run_mvbs(ReduceArgs& a, hipStream_t st) {
   const bool two_stage = pl.nparts > 1 || !pl.use_lds;
   if (SRC == SRC_RAW && !two_stage && pl.vec == 4 && !a.ping_perm && !a.range_out &&
       a.cal_flags == (EPA_FLAG_GUARD_POS | EPA_FLAG_MASK_RANGE) && a.bin_flags == EPA_BIN_SKIPNA &&
-      (a.raw_i16 || !getenv("EPA_NO_FAST_PATH")))
+      (a.raw_i16 || !getenv("EPA_NO_FAST_PATH")) && (a.range_stats_filled = a.range_stats_out != nullptr, true))
     return epa_fused_fast_path(a.raw_i16 ? (const void*)a.raw_i16 : (const void*)a.raw, a.raw_i16 != nullptr,
                                a.n_valid, reinterpret_cast<const double*>(a.coef), a.C, a.P, a.S,
                                a.nspread, a.cal_flags, a.bin_start, a.n_tbins, a.range_bin,
                                a.n_rbins, a.bin_flags, a.fill_value, a.sv_out, a.out, a.sum_out,
                                a.cnt_out, sizeof(T) == 8 ? EPA_F64 : EPA_F32, pl.tab_off,
-                               pl.cnt_off, reinterpret_cast<unsigned long long*>(a.range_max_out), st);
+                               pl.cnt_off, reinterpret_cast<unsigned long long*>(a.range_max_out),
+                               reinterpret_cast<unsigned long long*>(a.range_stats_out), st);
   if (SRC == SRC_RAW_DENOISE && !two_stage && pl.vec == 4 && !a.ping_perm && !a.range_out &&
       a.cal_flags == (EPA_FLAG_GUARD_POS | EPA_FLAG_MASK_RANGE) && a.bin_flags == EPA_BIN_SKIPNA &&
       !getenv("EPA_NO_FAST_PATH"))
@@ -668,6 +671,26 @@ __global__ void decode_minmax_kernel(double* p) {
 }
 __global__ void init_minmax_kernel(unsigned long long* p) { p[threadIdx.x] = (threadIdx.x & 1) ? 0ull : ~0ull; }
 
+// {min key, NaN count (u64), -} + the decoded maximum -> {nanmin, nanmax, NaN count}; as_f32: the values the float32
+// echo_range array holds (rounding is monotone)
+__global__ void decode_range_stats_kernel(double* st, const double* rmax, int as_f32) {
+  const unsigned long long k = reinterpret_cast<unsigned long long*>(st)[0];
+  const unsigned long long n = reinterpret_cast<unsigned long long*>(st)[1];
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  double lo = k == ~0ull ? __builtin_nan("") : __longlong_as_double(b), hi = *rmax;
+  if (as_f32) {
+    lo = (double)(float)lo;
+    hi = (double)(float)hi;
+  }
+  st[0] = lo;
+  st[1] = hi;
+  st[2] = (double)n;
+}
+__global__ void no_range_stats_kernel(double* st) {  // the kernel that ran leaves none: NaN count -1
+  st[0] = st[1] = __builtin_nan("");
+  st[2] = -1.0;
+}
+
 __global__ void decode_range_max_kernel(double* p) {
   const unsigned long long k = *reinterpret_cast<unsigned long long*>(p);
   // inverse of the order-preserving key; key 0 = nothing seen -> NaN
@@ -681,18 +704,21 @@ static int fused_entry(const float* raw, const int16_t* raw_i16, const int32_t* 
                        const int32_t* bin_start, const int32_t* ping_perm, int n_tbins,
                        double range_bin, int n_rbins, unsigned bin_flags, double fill_value,
                        void* sv_out, void* range_out, void* mvbs_out, void* sum_out,
-                       uint32_t* cnt_out, double* range_max_out, int dtype, epa_stream_t stream);
+                       uint32_t* cnt_out, double* range_max_out, double* range_stats_out, int dtype,
+                       epa_stream_t stream);
 
 extern "C" int epa_sv_mvbs_fused(const float* raw, const double* coef, int C, int P, int S,
                                  int cal_type, unsigned cal_flags, const int32_t* bin_start,
                                  const int32_t* ping_perm, int n_tbins, double range_bin,
                                  int n_rbins, unsigned bin_flags, double fill_value, void* sv_out,
                                  void* range_out, void* mvbs_out, void* sum_out, uint32_t* cnt_out,
-                                 double* range_max_out, int dtype, epa_stream_t stream) {
+                                 double* range_max_out, double* range_stats_out, int dtype,
+                                 epa_stream_t stream) {
   EPA_CHECK_ARG(raw != nullptr, "epa_sv_mvbs_fused: NULL array argument");
+  EPA_CHECK_ARG(!range_stats_out || range_max_out, "epa_sv_mvbs_fused: range_stats_out needs range_max_out");
   return fused_entry(raw, nullptr, nullptr, coef, C, P, S, cal_type, cal_flags, bin_start, ping_perm,
                      n_tbins, range_bin, n_rbins, bin_flags, fill_value, sv_out, range_out, mvbs_out,
-                     sum_out, cnt_out, range_max_out, dtype, stream);
+                     sum_out, cnt_out, range_max_out, range_stats_out, dtype, stream);
 }
 
 extern "C" int epa_sv_mvbs_fused_i16(const int16_t* raw, const int32_t* n_valid, const double* coef,
@@ -704,7 +730,7 @@ extern "C" int epa_sv_mvbs_fused_i16(const int16_t* raw, const int32_t* n_valid,
   return fused_entry(nullptr, raw, n_valid, coef, C, P, S, cal_type,
                      EPA_FLAG_GUARD_POS | EPA_FLAG_MASK_RANGE, bin_start, nullptr, n_tbins, range_bin,
                      n_rbins, EPA_BIN_SKIPNA, fill_value, sv_out, nullptr, mvbs_out, sum_out, cnt_out,
-                     range_max_out, dtype, stream);
+                     range_max_out, nullptr, dtype, stream);
 }
 
 static int fused_entry(const float* raw, const int16_t* raw_i16, const int32_t* n_valid,
@@ -712,7 +738,8 @@ static int fused_entry(const float* raw, const int16_t* raw_i16, const int32_t* 
                        const int32_t* bin_start, const int32_t* ping_perm, int n_tbins,
                        double range_bin, int n_rbins, unsigned bin_flags, double fill_value,
                        void* sv_out, void* range_out, void* mvbs_out, void* sum_out,
-                       uint32_t* cnt_out, double* range_max_out, int dtype, epa_stream_t stream) {
+                       uint32_t* cnt_out, double* range_max_out, double* range_stats_out, int dtype,
+                       epa_stream_t stream) {
   EPA_CHECK_ARG(coef && mvbs_out, "epa_sv_mvbs_fused: NULL array argument");
   EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_sv_mvbs_fused: C=%d P=%d S=%d", C, P, S);
   EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_sv_mvbs_fused: bad cal_type");
@@ -729,12 +756,22 @@ static int fused_entry(const float* raw, const int16_t* raw_i16, const int32_t* 
   a.fill_value = fill_value; a.noise_max = __builtin_nan("");
   a.sv_out = sv_out; a.range_out = range_out; a.out = mvbs_out; a.sum_out = sum_out; a.cnt_out = cnt_out;
   a.range_max_out = range_max_out;
+  a.range_stats_out = range_stats_out;
   EPA_CHECK_ARG(dtype == EPA_F64 || dtype == EPA_F32, "epa_sv_mvbs_fused: bad dtype %d", dtype);
   if (range_max_out) EPA_CHECK_HIP(hipMemsetAsync(range_max_out, 0, sizeof(double), (hipStream_t)stream));
+  if (range_stats_out) {  // min key ~0 (nothing seen), NaN count 0
+    EPA_CHECK_HIP(hipMemsetAsync(range_stats_out, 0xff, sizeof(double), (hipStream_t)stream));
+    EPA_CHECK_HIP(hipMemsetAsync(range_stats_out + 1, 0, 2 * sizeof(double), (hipStream_t)stream));
+  }
   const int rc = dtype == EPA_F64 ? run_mvbs<double, SRC_RAW>(a, (hipStream_t)stream)
                                   : run_mvbs<float, SRC_RAW>(a, (hipStream_t)stream);
   if (rc == EPA_OK && range_max_out) {
     hipLaunchKernelGGL(decode_range_max_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, range_max_out);
+    if (range_stats_out && a.range_stats_filled)
+      hipLaunchKernelGGL(decode_range_stats_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, range_stats_out,
+                         range_max_out, dtype == EPA_F32 ? 1 : 0);
+    else if (range_stats_out)
+      hipLaunchKernelGGL(no_range_stats_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, range_stats_out);
     return epa::check_launch("decode_range_max_kernel");
   }
   return rc;

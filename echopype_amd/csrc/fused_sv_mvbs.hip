@@ -28,6 +28,7 @@ struct Args {
   unsigned guard, mask_range, skipna, closed_right;
   unsigned cnt_off, tab_off;
   unsigned long long* rmax_key;  // optional: max valid echo_range as an order-preserving u64 key
+  unsigned long long* rstat;     // optional, with rmax_key: {min valid echo_range as a key, number of NaN echo_range values}
   int xcd_map;  // time bins dealt to the XCDs in contiguous eighths (epa::xcd_contiguous)
   int flagged_only;  // mvbs_of_sv_rows_kernel after the fixed-bin kernel: only the time bins that one left (kLeftToRows)
 };
@@ -74,9 +75,10 @@ struct Column {
 template <typename T>
 __device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::CoefRow& r, T g, T a2,
                                             T A0, T nspread, double bin, double inv_bin, int n_rbins,
-                                            const double* tab, T* lsum, uint32_t* lcnt, double& xmax) {
+                                            const double* tab, T* lsum, uint32_t* lcnt, double& xo) {
   const T NaN = epa::M<T>::nan();
   const double x = c.sra * r.rb + r.r0;  // echo_range = (s*ra)*rb [+0]
+  xo = x;  // (for the caller's range statistics; dead otherwise)
   const double rtd = x - r.shift;
   const T rt = (T)rtd;
   const bool pos = rtd > 0.0;
@@ -92,7 +94,6 @@ __device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::
 #endif
   // still inside the bin of the previous ping?  NaN raw -> NaN echo_range: never inside
   const bool xok = raw == raw;
-  xmax = fmax(xmax, xok ? x : xmax);  // dead code (removed) unless the caller reads xmax
   const bool same = xok & (x >= c.blo) & (x < c.bhi);
   if (!same) {
     const int rb = xok ? epa::range_bin_index(x, bin, inv_bin, n_rbins, false) : -1;
@@ -198,7 +199,8 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
   const int32_t* __restrict__ nv_c = n_valid ? n_valid + (size_t)c * a.P : nullptr;
   T* __restrict__ sv_c = WRITE_SV ? sv_out + (size_t)c * a.P * S : nullptr;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double xmax = -__builtin_inf();
+  double xmax = -__builtin_inf(), xmin = __builtin_inf();
+  unsigned nnan = 0u;
 
   for (int seg = 0; seg < nseg; ++seg) {
   const int pb = extra ? (seg == 0 ? 0 : bin_start[a.n_tbins]) : bin_start[tb];
@@ -238,8 +240,9 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
         }
       }
       const T g = (T)r.g, a2 = (T)r.alpha2, A0 = (T)r.A0;
-      const T sv0 = process_sample<T>(col[0], inA.x, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax);
-      const T sv1 = process_sample<T>(col[1], inA.y, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax);
+      double x0, x1, x2 = 0.0, x3 = 0.0;
+      const T sv0 = process_sample<T>(col[0], inA.x, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, x0);
+      const T sv1 = process_sample<T>(col[1], inA.y, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, x1);
       if (WRITE_SV) {
 #ifndef EPA_PLAIN_STORES  // streaming (nt) stores: +2 % at 4 G samples, Sv is never re-read here
         epa::store_nt2(sv_c + row_off + sA, sv0, sv1);
@@ -249,8 +252,8 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
 #endif
       }
       if (hasB) {
-        const T sv2 = process_sample<T>(col[2], inB.x, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax);
-        const T sv3 = process_sample<T>(col[3], inB.y, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax);
+        const T sv2 = process_sample<T>(col[2], inB.x, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, x2);
+        const T sv3 = process_sample<T>(col[3], inB.y, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, x3);
         if (WRITE_SV) {
 #ifndef EPA_PLAIN_STORES  // streaming (nt) stores: +2 % at 4 G samples, Sv is never re-read here
           epa::store_nt2(sv_c + row_off + sB, sv2, sv3);
@@ -258,6 +261,20 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
           const T o[2] = {sv2, sv3};
           epa::store_vec<T, 2>(sv_c + row_off + sB, o);
 #endif
+        }
+      }
+      if (RMAX) {
+        // {min, max, NaN count} of the echo_range, NaN exactly where the raw sample is: x + 0 * raw is the range or NaN,
+        // and v_max_f64 / v_min_f64 return the operand that is a number
+        const float in[4] = {inA.x, inA.y, inB.x, inB.y};
+        const double xs[4] = {x0, x1, x2, x3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j >= 2 && !hasB) break;
+          const double xq = fma((double)in[j], 0.0, xs[j]);
+          xmax = fmax(xmax, xq);
+          xmin = fmin(xmin, xq);
+          nnan += in[j] == in[j] ? 0u : 1u;
         }
       }
     }
@@ -269,6 +286,15 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) xmax = fmax(xmax, __shfl_down(xmax, o, 64));
     if (lane == 0 && xmax > -__builtin_inf()) atomicMax(a.rmax_key, ordered_key(xmax));
+    if (a.rstat) {  // (uniform) the rest of {nanmin, nanmax, NaN count}: what compute_MVBS asks of an echo_range array
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        xmin = fmin(xmin, __shfl_down(xmin, o, 64));
+        nnan += __shfl_down(nnan, o, 64);
+      }
+      if (lane == 0 && xmin < __builtin_inf()) atomicMin(a.rstat, ordered_key(xmin));
+      if (lane == 0 && nnan > 0u) atomicAdd(a.rstat + 1, (unsigned long long)nnan);
+    }
   }
   if (extra) return;
   __syncthreads();
@@ -724,9 +750,10 @@ int epa_fused_fast_path(const void* raw, int raw_is_i16, const int32_t* n_valid,
                         int n_rbins, unsigned bin_flags, double fill_value, void* sv_out,
                         void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
                         size_t lds_bytes, unsigned cnt_off, unsigned long long* rmax_key,
-                        hipStream_t st) {
+                        unsigned long long* rstat, hipStream_t st) {
   epa_fused::Args a{};
   a.rmax_key = rmax_key;
+  a.rstat = rmax_key ? rstat : nullptr;
   a.P = P; a.S = S; a.n_tbins = n_tbins; a.n_rbins = n_rbins;
   a.range_bin = range_bin; a.inv_range_bin = 1.0 / range_bin;
   a.nspread = nspread; a.fill_value = fill_value;

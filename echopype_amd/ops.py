@@ -154,8 +154,10 @@ def sv_mvbs_fused(raw, coef, bin_start, n_tbins, range_bin, n_rbins, *, cal_type
                   cal_flags=_lib.FLAG_GUARD_POS | _lib.FLAG_MASK_RANGE, skipna=True, closed="left",
                   fill_value=float("nan"), dtype=torch.float64, want_sv=True, want_range=False,
                   want_partials=False, ping_perm=None, sv_out=None, range_out=None, mvbs_out=None,
-                  want_range_max=False):
-    """K1+K5 -> dict(Sv, echo_range, MVBS, sum, cnt, range_max)."""
+                  want_range_max=False, want_range_stats=False):
+    """K1+K5 -> dict(Sv, echo_range, MVBS, sum, cnt, range_max, range_stats).  ``want_range_stats``: f64 device tensor
+    {nanmin, nanmax, NaN count} of the echo_range array that is NOT written (NaN count -1: the kernel that served the
+    configuration leaves the maximum only)."""
     C, P, S = raw.shape
     dev = raw.device
     if want_sv and sv_out is None:
@@ -168,14 +170,15 @@ def sv_mvbs_fused(raw, coef, bin_start, n_tbins, range_bin, n_rbins, *, cal_type
     if want_partials or reduce_needs_workspace(C, n_tbins, n_rbins, dtype):
         ssum = torch.empty((C, n_tbins, n_rbins), dtype=dtype, device=dev)
         cnt = torch.empty((C, n_tbins, n_rbins), dtype=torch.int32, device=dev)
-    rmax = torch.empty(1, dtype=torch.float64, device=dev) if want_range_max else None
+    rmax = torch.empty(1, dtype=torch.float64, device=dev) if want_range_max or want_range_stats else None
+    rstats = torch.empty(3, dtype=torch.float64, device=dev) if want_range_stats else None
     call("epa_sv_mvbs_fused", _p(raw), _p(coef), C, P, S,
          _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, cal_flags, _p(bin_start), _p(ping_perm),
          int(n_tbins), float(range_bin), int(n_rbins), _bin_flags(skipna, closed), float(fill_value),
          _p(sv_out) if want_sv else None, _p(range_out) if want_range else None, _p(mvbs_out),
-         _p(ssum), _p(cnt), _p(rmax), _DT[dtype], _stream())
+         _p(ssum), _p(cnt), _p(rmax), _p(rstats), _DT[dtype], _stream())
     return dict(Sv=sv_out if want_sv else None, echo_range=range_out if want_range else None,
-                MVBS=mvbs_out, sum=ssum, cnt=cnt, range_max=rmax)
+                MVBS=mvbs_out, sum=ssum, cnt=cnt, range_max=rmax, range_stats=rstats)
 
 
 def sv_mvbs_fused_i16(raw_i16, n_valid, coef, bin_start, n_tbins, range_bin, n_rbins, *, cal_type="Sv",

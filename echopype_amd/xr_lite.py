@@ -81,15 +81,20 @@ class LazyDeviceArray(DeviceArray):
     as long as this object lives (the echodata normally does anyway): replace the variable by
     ``DeviceArray(lazy.tensor)`` to cut that tie."""
 
-    __slots__ = ("_make", "_shape", "_tdtype", "_device", "_tensor", "_rows", "_mask", "_made_version")
+    __slots__ = ("_make", "_shape", "_tdtype", "_device", "_tensor", "_rows", "_mask", "_made_version", "source",
+                 "_stats_hook")
 
-    def __init__(self, shape, dtype, device, make, stats=None, rows=None, nan_where=None):
+    def __init__(self, shape, dtype, device, make, stats=None, rows=None, nan_where=None, source=None):
         self._make, self._shape, self._tdtype, self._device = make, tuple(int(n) for n in shape), dtype, device
         self._tensor = None
         self._made_version = None  # tensor._version right after make(): any later in-place write voids rows and stats
         self._host = None
         self._stats = (stats, 0) if stats is not None else None
         self._rows = rows
+        # what a deferred Sv is made from (calibrate_base.PowerSource): a consumer that can produce the array as a
+        # by-product of its own pass over the same inputs (compute_MVBS: the fused kernel) does so and calls fulfil()
+        self.source = source
+        self._stats_hook = None  # called once when the statistics are asked for and nobody has left them yet
         # the array is NaN exactly where this device tensor of the same shape is (the raw power samples): kernels that
         # need the NaN pattern as well as the values read it next to the rows
         self._mask = (nan_where, nan_where._version) if nan_where is not None else None
@@ -104,14 +109,32 @@ class LazyDeviceArray(DeviceArray):
     def materialized(self):
         return self._tensor is not None
 
+    def fulfil(self, tensor):
+        """Install the array produced elsewhere (same shape and dtype as make() would return)."""
+        if self._tensor is not None:
+            raise RuntimeError("the array has been written already")
+        if tuple(tensor.shape) != self._shape or tensor.dtype != self._tdtype:
+            raise ValueError(f"expected {self._shape} {self._tdtype}, got {tuple(tensor.shape)} {tensor.dtype}")
+        self._tensor, self._make, self.source = tensor, None, None
+        self._made_version = tensor._version
+        if self._stats is not None:
+            self._stats = (self._stats[0], tensor._version)
+
+    def set_stats(self, stats, hook=None):
+        """Leave the {nanmin, nanmax, NaN count} device tensor with the array (valid while nothing writes to it), or
+        a ``hook`` that will (it must end up calling set_stats(stats))."""
+        if stats is not None:
+            self._stats = (stats, self._tensor._version if self._tensor is not None else 0)
+            self._stats_hook = None
+        else:
+            self._stats_hook = hook
+
     @property
     def tensor(self):
         if self._tensor is None:
-            self._tensor = self._make()
-            self._make = None
-            self._made_version = self._tensor._version
-            if self._stats is not None:
-                self._stats = (self._stats[0], self._tensor._version)
+            t = self._make()
+            if self._tensor is None:  # (make() may have gone through fulfil())
+                self.fulfil(t)
         return self._tensor
 
     def coef_rows(self):
@@ -121,6 +144,9 @@ class LazyDeviceArray(DeviceArray):
         return self._rows
 
     def cached_stats(self):
+        if self._stats is None and self._stats_hook is not None:
+            hook, self._stats_hook = self._stats_hook, None
+            hook()
         if self._stats is None or (self._tensor is not None and self._stats[1] != self._tensor._version):
             return None
         lo, hi, nn = self._stats[0].cpu().tolist()

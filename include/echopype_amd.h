@@ -161,13 +161,17 @@ int epa_time_bin_offsets(const int64_t* ping_time, int P, int64_t t0, int64_t dt
  *   range_max_out : optional f64 [1]: nanmax(echo_range) as a by-product (what api.py:108-110 needs
  *                 to size the range grid: call with a conservative n_rbins, then trim); NULL if not
  *                 wanted.
+ *   range_stats_out : optional f64 [3] (needs range_max_out): {nanmin, nanmax, NaN count} of the echo_range array
+ *                 epa_range_power would write (rounded to dtype) -- what the next compute_MVBS / add_depth on
+ *                 the same dataset asks of its range variable; {NaN, NaN, -1} when the configuration is served
+ *                 by the generic kernel, which leaves the maximum only.
  */
 int epa_sv_mvbs_fused(const float* raw, const double* coef, int C, int P, int S, int cal_type,
                       unsigned cal_flags, const int32_t* bin_start, const int32_t* ping_perm,
                       int n_tbins, double range_bin, int n_rbins, unsigned bin_flags,
                       double fill_value, void* sv_out, void* range_out, void* mvbs_out,
-                      void* sum_out, uint32_t* cnt_out, double* range_max_out, int dtype,
-                      epa_stream_t stream);
+                      void* sum_out, uint32_t* cnt_out, double* range_max_out, double* range_stats_out,
+                      int dtype, epa_stream_t stream);
 
 /* Same pass fed with the instrument's own int16 power samples (SURVEY 8f "next" row 4; replaces the
  * ingest arithmetic of convert/parse_base.py:24,302 -- float32(int16) * float32(10*log10(2)/256) --

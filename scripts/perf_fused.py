@@ -19,7 +19,8 @@ n_r = int(np.ceil(S * 2.56e-4 * 1500.5 / 2)) + 1
 for dt, b in ((torch.float64, 8), (torch.float32, 4)):
     out = torch.empty((C, P, S), dtype=dt, device="cuda")
     mv = torch.empty((C, n_t, n_r), dtype=dt, device="cuda")
-    for name, kw, bps in (("write Sv", dict(sv_out=out), 4 + b), ("MVBS only", dict(want_sv=False), 4)):
+    for name, kw, bps in (("write Sv", dict(sv_out=out), 4 + b), ("Sv + stats", dict(sv_out=out, want_range_stats=True), 4 + b),
+                          ("MVBS only", dict(want_sv=False), 4)):
         fn = lambda: ops.sv_mvbs_fused(d["backscatter_r"], cf, bs, n_t, 1.0, n_r, dtype=dt, mvbs_out=mv, **kw)
         fn(); torch.cuda.synchronize(); ms = []
         for _ in range(7):

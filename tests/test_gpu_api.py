@@ -832,3 +832,102 @@ def test_add_depth_from_a_lazy_echo_range_and_its_statistics(dtype):
     np.testing.assert_allclose(a["Sv"].values, b["Sv"].values, rtol=1e-12 if dtype == "float64" else 1e-5,
                                atol=1e-12 if dtype == "float64" else 1e-4)
     assert np.isfinite(a["Sv"].values).any()
+
+
+# ---- Sv left to its first reader by compute_Sv on power samples; compute_MVBS writes it next to the bins ---------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float64"])
+def test_deferred_sv_is_written_by_compute_MVBS_and_equals_the_eager_calls(dtype, monkeypatch):
+    """compute_Sv on EK power samples returns Sv as a LazyDeviceArray; compute_MVBS right after runs ONE pass over the raw
+    samples (epa_sv_mvbs_fused) that writes the Sv array and the bins.  Same dataset as with EPA_DEFER_SV=0 (K1, then the
+    binning kernel on the Sv array): Sv bit for bit, MVBS up to the order of a bin's additions, the echo_range statistics,
+    the NaN-coordinate warning."""
+    import logging
+
+    import echopype_amd as ep
+    from echopype_amd.xr_lite import LazyDeviceArray
+
+    ed, _ = _lazy_case(ep)
+    monkeypatch.setenv("EPA_DEFER_SV", "0")
+    ds_e = ep.calibrate.compute_Sv(ed, dtype=dtype)
+    assert not isinstance(ds_e["Sv"].data, LazyDeviceArray)
+    mv_e = ep.commongrid.compute_MVBS(ds_e, range_bin="2m", ping_time_bin="10s")
+    monkeypatch.delenv("EPA_DEFER_SV")
+
+    ds = ep.calibrate.compute_Sv(ed, dtype=dtype)
+    sv, rng = ds["Sv"].data, ds["echo_range"].data
+    assert isinstance(sv, LazyDeviceArray) and not sv.materialized and sv.source is not None
+    assert ds["Sv"].shape == ds_e["Sv"].shape and ds["Sv"].dtype == np.dtype(dtype)
+    assert ds["Sv"].attrs == ds_e["Sv"].attrs and list(ds.data_vars) == list(ds_e.data_vars)
+    records = []
+    handler = logging.Handler()
+    handler.emit = records.append
+    logging.getLogger().addHandler(handler)
+    try:
+        mv = ep.commongrid.compute_MVBS(ds, range_bin="2m", ping_time_bin="10s")
+    finally:
+        logging.getLogger().removeHandler(handler)
+    assert any("coordinate array contain NaNs" in r.getMessage() for r in records)   # NaN-padded pings in _lazy_case
+    assert sv.materialized and sv.source is None and not rng.materialized
+    np.testing.assert_array_equal(ds["Sv"].values, ds_e["Sv"].values)
+    assert rng.cached_stats() == ds_e["echo_range"].data.cached_stats()
+    np.testing.assert_array_equal(mv["echo_range"].values, mv_e["echo_range"].values)
+    np.testing.assert_array_equal(mv["ping_time"].values, mv_e["ping_time"].values)
+    np.testing.assert_array_equal(np.isnan(mv["Sv"].values), np.isnan(mv_e["Sv"].values))
+    tol = dict(rtol=1e-12, atol=1e-12) if dtype == "float64" else dict(rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(mv["Sv"].values, mv_e["Sv"].values, **tol)
+    assert mv["Sv"].attrs == mv_e["Sv"].attrs
+    # a second grid on the same dataset: the plain route on the Sv array now there, echo_range still only its rows
+    mv2 = ep.commongrid.compute_MVBS(ds, range_bin="5m", ping_time_bin="20s")
+    mv2_e = ep.commongrid.compute_MVBS(ds_e, range_bin="5m", ping_time_bin="20s")
+    assert not rng.materialized
+    np.testing.assert_allclose(mv2["Sv"].values, mv2_e["Sv"].values, **tol)
+
+
+@pytest.mark.gpu
+def test_deferred_sv_other_first_readers(monkeypatch):
+    """Whoever reads a deferred Sv first gets the array K1 writes: .values, remove_background_noise, a right-closed or
+    skipna=False compute_MVBS (the plain route), the echo_range statistics asked for before anything else.  Raw samples
+    modified in place in between: an error instead of values of the wrong samples."""
+    import echopype_amd as ep
+    from echopype_amd.xr_lite import LazyDeviceArray
+
+    ed, _ = _lazy_case(ep)
+    monkeypatch.setenv("EPA_DEFER_SV", "0")
+    ds_e = ep.calibrate.compute_Sv(ed)
+    st_e = ds_e["echo_range"].data.cached_stats()
+    mv_r = ep.commongrid.compute_MVBS(ds_e, range_bin="2m", ping_time_bin="10s", closed="right")
+    clean_e = ep.clean.remove_background_noise(ep.calibrate.compute_Sv(ed), ping_num=20, range_sample_num=50)
+    monkeypatch.delenv("EPA_DEFER_SV")
+
+    ds = ep.calibrate.compute_Sv(ed)
+    assert not ds["Sv"].data.materialized
+    assert ds["echo_range"].data.cached_stats() == st_e      # the statistics come with the Sv pass: it ran now
+    assert ds["Sv"].data.materialized and not ds["echo_range"].data.materialized
+    np.testing.assert_array_equal(ds["Sv"].values, ds_e["Sv"].values)
+
+    ds = ep.calibrate.compute_Sv(ed)
+    np.testing.assert_array_equal(ds["Sv"].values, ds_e["Sv"].values)         # .values first
+    ds = ep.calibrate.compute_Sv(ed)
+    mv = ep.commongrid.compute_MVBS(ds, range_bin="2m", ping_time_bin="10s", closed="right")
+    np.testing.assert_allclose(mv["Sv"].values, mv_r["Sv"].values, rtol=1e-12, atol=1e-12)
+    assert ds["Sv"].data.materialized
+    ds = ep.calibrate.compute_Sv(ed)
+    clean = ep.clean.remove_background_noise(ds, ping_num=20, range_sample_num=50)
+    np.testing.assert_array_equal(clean["Sv"].values, clean_e["Sv"].values)
+    np.testing.assert_allclose(clean["Sv_corrected"].values, clean_e["Sv_corrected"].values, rtol=1e-12, atol=1e-12)
+    # a copy of the dataset shares the deferred array: written once, seen by both
+    ds = ep.calibrate.compute_Sv(ed)
+    cp = ds.copy()
+    ep.commongrid.compute_MVBS(cp, range_bin="2m", ping_time_bin="10s")
+    assert ds["Sv"].data.materialized and ds["Sv"].data is cp["Sv"].data
+    # TS is not deferred (nothing downstream fuses with it), nor is a float32 Sv (its MVBS bins on the float32 range)
+    assert not isinstance(ep.calibrate.compute_TS(ed)["TS"].data, LazyDeviceArray)
+    assert not isinstance(ep.calibrate.compute_Sv(ed, dtype="float32")["Sv"].data, LazyDeviceArray)
+    # raw samples written to between compute_Sv and the first read
+    ed2, _ = _lazy_case(ep)
+    ed2 = ed2.to_device()
+    ds = ep.calibrate.compute_Sv(ed2)
+    ed2["Sonar/Beam_group1"]["backscatter_r"].data.tensor.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        ep.commongrid.compute_MVBS(ds, range_bin="2m", ping_time_bin="10s")
