@@ -412,9 +412,19 @@ def run_api(ctx, cpu):
         mv_ms = med(lambda ds: ep.commongrid.compute_MVBS(ds, range_bin="1m", ping_time_bin="20s"),
                     prep=lambda: ep.calibrate.compute_Sv(ed, dtype=dtype))
         one_call = med(lambda: ep.compute_Sv_MVBS(ed, range_bin="1m", ping_time_bin="20s", dtype=dtype))
+
+        def three_calls():  # the chain as the reference's user writes it; the MVBS is that of Sv_corrected
+            ds = ep.calibrate.compute_Sv(ed, dtype=dtype)
+            ep.clean.remove_background_noise(ds, ping_num=20, range_sample_num=50)
+            corrected = ds.copy()
+            corrected["Sv"] = ds["Sv_corrected"]
+            return ds, ep.commongrid.compute_MVBS(corrected, range_bin="1m", ping_time_bin="20s")
+
+        chain_ms = med(three_calls)
         os.environ["EPA_DEFER_SV"] = "0"
         try:
             eager_ms = med(two_calls)
+            chain_eager_ms = med(three_calls)
         finally:
             del os.environ["EPA_DEFER_SV"]
     finally:
@@ -425,7 +435,8 @@ def run_api(ctx, cpu):
                 workload=f"api: EK60 CW {C}x{P}x{S}, calibrate.compute_Sv(echodata) then commongrid.compute_MVBS(ds_Sv) "
                          "through the Dataset API, echodata resident in HBM, Sv deferred to compute_MVBS's pass",
                 config={"compute_Sv_ms": sv_ms, "compute_MVBS_ms": mv_ms, "one_call_compute_Sv_MVBS_ms": one_call,
-                        "two_calls_not_deferred_ms": eager_ms, "sharding": "one GPU", "collective": "none"},
+                        "two_calls_not_deferred_ms": eager_ms, "chain_three_calls_ms": chain_ms,
+                        "chain_three_calls_not_deferred_ms": chain_eager_ms, "sharding": "one GPU", "collective": "none"},
                 roofline=roofline("fused_sv_mvbs_kernel inside compute_MVBS (+ host parameter selection)", region_ms, n * bps,
                                   bps, note="region = both API calls incl. host work"))
 

@@ -35,6 +35,11 @@ def _inputs(ds_Sv):
     else:
         rg_t = _dev(_full(ds_Sv["echo_range"], ds_Sv, order), sv_t.dtype)
     C, P, S = sv_t.shape
+    return order, sv_t, rg_t, _alpha2(ds_Sv, order, C, P)
+
+
+def _alpha2(ds_Sv, order, C, P):
+    """2 * sound_absorption of the dataset as a (C, P) float64 device tensor (clean/api.py:397-398 uses the dataset's)."""
     a = ds_Sv["sound_absorption"]
     av = np.asarray(a.values, dtype=np.float64)
     if av.ndim == 0:
@@ -43,7 +48,50 @@ def _inputs(ds_Sv):
         a2 = np.broadcast_to((2 * av)[:, None] if a.dims == (order[0],) or av.shape[0] == C else (2 * av)[None, :], (C, P))
     else:
         a2 = 2 * (av if a.dims[0] == order[0] else av.T)
-    return order, sv_t, rg_t, ops.to_device(np.ascontiguousarray(a2, dtype=np.float64))
+    return ops.to_device(np.ascontiguousarray(a2, dtype=np.float64))
+
+
+def _denoise_deferred_sv(ds_Sv, ping_num, range_sample_num, nmax, snr):
+    """``remove_background_noise`` as the FIRST reader of the Sv that compute_Sv deferred (power samples): two passes over
+    the raw samples instead of K1 + two sweeps of the Sv array --
+        pass 1 (epa_sv_noise_fused)    raw -> the Sv array + the noise estimate from the values in registers + the
+                                       echo_range statistics                                   4 + 8 B/sample
+        pass 2 (epa_sv_denoise_mvbs)   raw -> Sv_noise, Sv_corrected, their actual_range      4 + 16 B/sample
+    against 12 (K1) + 8 (estimate) + 24 (apply).  Pass 2 is the chain kernel of compute_Sv_clean_MVBS run on plain
+    20-ping groups with ONE range bin (its bins are not wanted here).  Returns (Sv_noise, Sv_corrected, minmax) or None:
+    the plain route then runs on whatever this one has written."""
+    from .. import _lib
+    from ..xr_lite import LazyDeviceArray
+
+    sv_da, rng_da = ds_Sv["Sv"], ds_Sv["echo_range"] if "echo_range" in ds_Sv else None
+    d = sv_da.data
+    src = d.source if isinstance(d, LazyDeviceArray) and not d.materialized else None
+    dims = ("channel", "ping_time", "range_sample")
+    if src is None or rng_da is None or src.cal_type != "Sv" or rng_da.data is not src.echo_range \
+            or tuple(sv_da.dims) != dims or tuple(rng_da.dims) != dims \
+            or src.echo_range.coef_rows() is not src.coef or not src.intact():
+        return None
+    C, P, S = d.shape
+    a2 = _alpha2(ds_Sv, dims, C, P)
+    try:
+        sv_t, _, noise, rstats = ops.sv_noise_fused(src.raw, src.coef, a2, ping_num, range_sample_num, flags=src.flags,
+                                                    dtype=src.dtype, noise_max=float("nan") if nmax is None else float(nmax),
+                                                    want_range_stats=True)
+    except _lib.EpaError:  # e.g. more range blocks than the LDS holds
+        return None
+    if float(rstats[2].item()) < 0:  # served by the generic kernel: no range statistics (K1 leaves them, plain route)
+        return None
+    d.fulfil(sv_t)
+    src.echo_range.set_stats(rstats)
+    group = 20
+    bin_start = torch.arange(0, P + group, group, dtype=torch.int32, device=sv_t.device).clamp_(max=P)
+    try:
+        res = ops.sv_denoise_mvbs(src.raw, src.coef, a2, noise, ping_num, float(snr), bin_start, bin_start.numel() - 1,
+                                  1e30, 1, flags=src.flags, dtype=src.dtype, want_noise=True, want_corrected=True,
+                                  want_minmax=True)
+    except _lib.EpaError:
+        return None
+    return res["Sv_noise"], res["Sv_corrected"], res["minmax"]
 
 
 def _rng_kw(rg_t, apply=False):
@@ -88,10 +136,17 @@ def remove_background_noise(ds_Sv, ping_num, range_sample_num, background_noise_
     ds_Sv = from_xarray(ds_Sv)
     if SNR_threshold is not None:
         SNR_threshold = extract_dB(SNR_threshold)
-    order, sv_t, rg_t, a2, noise, nmax = _estimate(ds_Sv, ping_num, range_sample_num, background_noise_max, _shard)
-    # actual_range of both outputs is a by-product of the kernel (no extra sweeps)
-    sn, sc, mm = ops.noise_apply(sv_t, a2, noise, ping_num, float(SNR_threshold), want_minmax=True, **_rng_kw(rg_t, apply=True),
-                                 ping_phase=0 if _shard is None else _shard[0] % ping_num)
+    done = None
+    if _shard is None and SNR_threshold is not None:
+        nmax = extract_dB(background_noise_max) if background_noise_max is not None else None
+        done = _denoise_deferred_sv(ds_Sv, ping_num, range_sample_num, nmax, SNR_threshold)
+    if done is not None:
+        order, (sn, sc, mm) = tuple(ds_Sv["Sv"].dims), done
+    else:
+        order, sv_t, rg_t, a2, noise, nmax = _estimate(ds_Sv, ping_num, range_sample_num, background_noise_max, _shard)
+        # actual_range of both outputs is a by-product of the kernel (no extra sweeps)
+        sn, sc, mm = ops.noise_apply(sv_t, a2, noise, ping_num, float(SNR_threshold), want_minmax=True,
+                                     **_rng_kw(rg_t, apply=True), ping_phase=0 if _shard is None else _shard[0] % ping_num)
     for name, t, kind, rng_mm in (("Sv_noise", sn, "noise", mm[0:2]), ("Sv_corrected", sc, "corrected", mm[2:4])):
         da = DataArray(DeviceArray(t), order)
         ds_Sv[name] = add_remove_background_noise_attrs(da, kind, ping_num, range_sample_num, SNR_threshold,

@@ -516,7 +516,8 @@ int epa_mvbs_rows_fast_path(const void* sv, const double* coef, int C, int P, in
                             unsigned cnt_off, hipStream_t st);
 int epa_chain_fast_pass1(const float* raw, const double* coef, const double* alpha2, int C, int P, int S,
                          double nspread, int ping_num, int rsn, double noise_max, void* sv_out,
-                         double* noise_out, unsigned long long* rmax_key, int dtype, hipStream_t st);
+                         double* noise_out, unsigned long long* rmax_key, unsigned long long* rstat, int dtype,
+                         hipStream_t st);
 int epa_chain_fast_pass2(const float* raw, const double* coef, const double* alpha2, const double* noise, int C,
                          int P, int S, double nspread, int ping_num, double snr, const int32_t* bin_start,
                          int n_tbins, double range_bin, int n_rbins, double fill_value, void* noise_out,
@@ -953,7 +954,8 @@ namespace {
 template <typename T>
 int run_sv_noise(const float* raw, const double* coef, const double* alpha2, int C, int P, int S,
                  double nspread, unsigned cal_flags, int ping_num, int rsn, double noise_max, void* sv_out,
-                 void* range_out, double* noise_out, double* range_max_out, hipStream_t st) {
+                 void* range_out, double* noise_out, double* range_max_out, double* range_stats_out, int* stats_filled,
+                 hipStream_t st) {
   const int Pb = (P + ping_num - 1) / ping_num, Sb = (S + rsn - 1) / rsn;
   ReduceArgs a{};
   a.raw = raw; a.coef = reinterpret_cast<const epa::CoefRow*>(coef); a.alpha2 = alpha2;
@@ -968,10 +970,13 @@ int run_sv_noise(const float* raw, const double* coef, const double* alpha2, int
   a.nparts = 1;
   EPA_CHECK_ARG(pl.use_lds, "epa_sv_noise_fused: %d range blocks exceed the LDS budget", Sb);
   if (pl.vec == 4 && !range_out && cal_flags == (EPA_FLAG_GUARD_POS | EPA_FLAG_MASK_RANGE) &&
-      !getenv("EPA_NO_FAST_PATH"))
+      !getenv("EPA_NO_FAST_PATH")) {
+    *stats_filled = range_stats_out != nullptr;
     return epa_chain_fast_pass1(raw, coef, alpha2, C, P, S, nspread, ping_num, rsn, noise_max, sv_out, noise_out,
                                 reinterpret_cast<unsigned long long*>(range_max_out),
+                                reinterpret_cast<unsigned long long*>(range_stats_out),
                                 sizeof(T) == 8 ? EPA_F64 : EPA_F32, st);
+  }
   return launch_reduce<T, SRC_RAW, OP_NOISE>(a, pl, st);
 }
 }  // namespace
@@ -979,7 +984,7 @@ int run_sv_noise(const float* raw, const double* coef, const double* alpha2, int
 extern "C" int epa_sv_noise_fused(const float* raw, const double* coef, const double* alpha2, int C, int P,
                                   int S, int cal_type, unsigned cal_flags, int ping_num,
                                   int range_sample_num, double noise_max, void* sv_out, void* range_out,
-                                  double* noise_out, double* range_max_out, int dtype,
+                                  double* noise_out, double* range_max_out, double* range_stats_out, int dtype,
                                   epa_stream_t stream) {
   EPA_CHECK_ARG(raw && coef && alpha2 && noise_out, "epa_sv_noise_fused: NULL array argument");
   EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && ping_num > 0 && range_sample_num > 0,
@@ -987,14 +992,25 @@ extern "C" int epa_sv_noise_fused(const float* raw, const double* coef, const do
   EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_sv_noise_fused: bad cal_type");
   const double nspread = cal_type == EPA_CAL_SV ? 20.0 : 40.0;
   EPA_CHECK_ARG(dtype == EPA_F64 || dtype == EPA_F32, "epa_sv_noise_fused: bad dtype %d", dtype);
+  EPA_CHECK_ARG(!range_stats_out || range_max_out, "epa_sv_noise_fused: range_stats_out needs range_max_out");
   if (range_max_out) EPA_CHECK_HIP(hipMemsetAsync(range_max_out, 0, sizeof(double), (hipStream_t)stream));
+  if (range_stats_out) {  // min key ~0 (nothing seen), NaN count 0
+    EPA_CHECK_HIP(hipMemsetAsync(range_stats_out, 0xff, sizeof(double), (hipStream_t)stream));
+    EPA_CHECK_HIP(hipMemsetAsync(range_stats_out + 1, 0, 2 * sizeof(double), (hipStream_t)stream));
+  }
+  int filled = 0;
   const int rc = dtype == EPA_F64
-      ? run_sv_noise<double>(raw, coef, alpha2, C, P, S, nspread, cal_flags, ping_num, range_sample_num,
-                             noise_max, sv_out, range_out, noise_out, range_max_out, (hipStream_t)stream)
-      : run_sv_noise<float>(raw, coef, alpha2, C, P, S, nspread, cal_flags, ping_num, range_sample_num,
-                            noise_max, sv_out, range_out, noise_out, range_max_out, (hipStream_t)stream);
+      ? run_sv_noise<double>(raw, coef, alpha2, C, P, S, nspread, cal_flags, ping_num, range_sample_num, noise_max,
+                             sv_out, range_out, noise_out, range_max_out, range_stats_out, &filled, (hipStream_t)stream)
+      : run_sv_noise<float>(raw, coef, alpha2, C, P, S, nspread, cal_flags, ping_num, range_sample_num, noise_max,
+                            sv_out, range_out, noise_out, range_max_out, range_stats_out, &filled, (hipStream_t)stream);
   if (rc == EPA_OK && range_max_out) {
     hipLaunchKernelGGL(decode_range_max_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, range_max_out);
+    if (range_stats_out && filled)  // (the fast kernel tracks the values as stored: no rounding left to do)
+      hipLaunchKernelGGL(decode_range_stats_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, range_stats_out,
+                         range_max_out, 0);
+    else if (range_stats_out)
+      hipLaunchKernelGGL(no_range_stats_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, range_stats_out);
     return epa::check_launch("decode_range_max_kernel");
   }
   return rc;

@@ -36,6 +36,7 @@ struct Args {
   double range_bin, inv_range_bin, fill_value, snr;
   unsigned cnt_off, tab_off;
   unsigned long long* rmax_key;
+  unsigned long long* rstat;  // optional, with rmax_key: {min valid echo_range as a key, number of NaN echo_range values}
   unsigned long long* mm_keys;  // pass 2, optional [4]: min/max of Sv_noise, min/max of Sv_corrected
   int flagged_only;  // pass 2, general kernel after the uniform-group kernel: only the groups that one left (kLeftToGeneral)
   int uni_bins;      // pass 2, uniform-group kernel: time bins per workgroup
@@ -244,7 +245,8 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
   T* __restrict__ sv_c = WRITE_SV ? sv_out + (size_t)c * a.P * S : nullptr;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int pb = pbk0 * a.ping_num, pe = min(a.P, pb + nb * a.ping_num);
-  double xmax = -__builtin_inf();
+  double xmax = -__builtin_inf(), xmin = __builtin_inf();
+  unsigned nnan = 0u;
   __shared__ T plog[kPingLogs];
   fill_ping_logs<T>(plog, rowp0 + pb, pe - pb, mt.log_tab);
   __syncthreads();
@@ -298,7 +300,12 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
         double x;
         sv[j] = calibrate<T>(col[j], in[j], r, g_, a2, A0, nspread, x, mt.log_tab);
         const bool xok = in[j] == in[j];
-        if (RMAX) xmax = fmax(xmax, xok ? (double)(T)x : xmax);
+        if (RMAX) {  // as stored (T); x + 0 * raw is the range or NaN, and v_max_f64 / v_min_f64 skip the NaN
+          const double xq = fma((double)in[j], 0.0, (double)(T)x);
+          xmax = fmax(xmax, xq);
+          xmin = fmin(xmin, xq);
+          nnan += xok ? 0u : 1u;
+        }
         // the block mean uses the UNMASKED range (the generic kernel does too: a masked sample has a NaN Sv)
         const T xr = (T)x;
 #ifdef EPA_LEAN_EXP
@@ -326,6 +333,15 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) xmax = fmax(xmax, __shfl_down(xmax, o, 64));
     if (lane == 0 && xmax > -__builtin_inf()) atomicMax(a.rmax_key, ordered_key(xmax));
+    if (a.rstat) {  // (uniform) the rest of {nanmin, nanmax, NaN count} of the echo_range
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        xmin = fmin(xmin, __shfl_down(xmin, o, 64));
+        nnan += __shfl_down(nnan, o, 64);
+      }
+      if (lane == 0 && xmin < __builtin_inf()) atomicMin(a.rstat, ordered_key(xmin));
+      if (lane == 0 && nnan > 0u) atomicAdd(a.rstat + 1, (unsigned long long)nnan);
+    }
   }
   // min over the range blocks of 10 log10(block mean) (clean/api.py:402-411), optional clamp (:418-422)
   for (int g = 0; g < nb; ++g) {
@@ -885,7 +901,20 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
   T* __restrict__ sn_c = WRITE_NOISE ? noise_out + (size_t)c * a.P * S : nullptr;
   T* __restrict__ sc_c = WRITE_CORR ? corr_out + (size_t)c * a.P * S : nullptr;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double mm[4] = {__builtin_inf(), -__builtin_inf(), __builtin_inf(), -__builtin_inf()};
+  // min / max of the two outputs (actual_range): one LDS slot per lane and quantity, updated by ds_min_f64 / ds_max_f64
+  // (a NaN operand leaves the slot alone) -- four running doubles per lane are eight registers this kernel does not
+  // have at 4 wavefronts / SIMD (held in registers they spilled into the ping loop: 15.0 -> 22.0 ms per 4 G samples)
+  __shared__ double mm_slot[MINMAX ? 4 * epa::kBlock : 1];
+  auto mm_min = [&](int k, double v) {
+    __hip_atomic_fetch_min(&mm_slot[k * epa::kBlock + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto mm_max = [&](int k, double v) {
+    __hip_atomic_fetch_max(&mm_slot[k * epa::kBlock + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  if (MINMAX) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mm_slot[k * epa::kBlock + threadIdx.x] = (k & 1) ? -__builtin_inf() : __builtin_inf();
+  }
 
   for (int chunk0 = 0; chunk0 < S; chunk0 += kChunk) {
     const int sA = chunk0 + wave * 256 + 2 * lane, sB = sA + 128;
@@ -921,6 +950,7 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
       acc_sum[j] = (T)0;
       acc_cnt[j] = 0u;
     };
+    const bool allplain = __all((plain | (hasB ? 0u : 0xcu)) == 0xfu) != 0;  // no column of this wavefront is redone below
     float2 nA = make_float2(0.f, 0.f), nB = nA;
     if (np > 0) {
       nA = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sA);
@@ -960,10 +990,12 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
         sc[j] = keep ? corr : epa::M<T>::nan();
         const bool pj = ((plain >> j) & 1u) != 0u;
         if (MINMAX) {
-          mm[0] = vmin_f64(mm[0], pj ? sn[j] : mm[0]);
-          mm[1] = vmax_f64(mm[1], pj ? sn[j] : mm[1]);
-          mm[2] = vmin_f64(mm[2], pj ? sc[j] : mm[2]);
-          mm[3] = vmax_f64(mm[3], pj ? sc[j] : mm[3]);
+          // (allplain: wavefront-uniform, the usual case; an off-plain column is redone -- and counted -- below)
+          const T vn = allplain || pj ? sn[j] : epa::M<T>::nan(), vc = allplain || pj ? sc[j] : epa::M<T>::nan();
+          mm_min(0, vn);
+          mm_max(1, vn);
+          mm_min(2, vc);
+          mm_max(3, vc);
         }
         const bool take = pj & (rbin[j] >= 0) & keep;  // keep implies a finite positive lin (and a valid input)
         acc_sum[j] += take ? lin : (T)0;
@@ -1025,10 +1057,10 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
             if (WRITE_NOISE) sn_c[o] = snv;
             if (WRITE_CORR) sc_c[o] = scv;
             if (MINMAX) {
-              mm[0] = vmin_f64(mm[0], snv);
-              mm[1] = vmax_f64(mm[1], snv);
-              mm[2] = vmin_f64(mm[2], scv);
-              mm[3] = vmax_f64(mm[3], scv);
+              mm_min(0, snv);
+              mm_max(1, snv);
+              mm_min(2, scv);
+              mm_max(3, scv);
             }
             const int rb = xok ? epa::range_bin_index(x, bin, inv_bin, n_rbins, false) : -1;
             if ((rb >= 0) & keep) {
@@ -1041,6 +1073,9 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
     }
   }
   if (MINMAX) {
+    double mm[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mm[k] = mm_slot[k * epa::kBlock + threadIdx.x];  // (the lane's own slots: no barrier)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       mm[0] = fmin(mm[0], __shfl_down(mm[0], o, 64));
@@ -1189,12 +1224,13 @@ int launch_pass2(Args& a, const float* raw, const double* coef, const double* al
 // Called by epa_sv_noise_fused (block_reduce.hip) when the fast path applies.
 int epa_chain_fast_pass1(const float* raw, const double* coef, const double* alpha2, int C, int P, int S,
                          double nspread, int ping_num, int rsn, double noise_max, void* sv_out,
-                         double* noise_out, unsigned long long* rmax_key, int dtype, hipStream_t st) {
+                         double* noise_out, unsigned long long* rmax_key, unsigned long long* rstat, int dtype,
+                         hipStream_t st) {
   epa_chain::Args a{};
   a.P = P; a.S = S; a.nspread = nspread;
   a.ping_num = ping_num; a.rsn = rsn;
   a.n_pblocks = (P + ping_num - 1) / ping_num; a.n_rblocks = (S + rsn - 1) / rsn;
-  a.noise_max = noise_max; a.rmax_key = rmax_key;
+  a.noise_max = noise_max; a.rmax_key = rmax_key; a.rstat = rmax_key ? rstat : nullptr;
   if (dtype == EPA_F64) return epa_chain::launch_pass1<double>(a, raw, coef, alpha2, sv_out, noise_out, C, st);
   return epa_chain::launch_pass1<float>(a, raw, coef, alpha2, sv_out, noise_out, C, st);
 }

@@ -592,8 +592,11 @@ def nasc(sv, depth, bin_start, n_dbins, range_bin, n_rbins, skipna=True, closed=
 
 def sv_noise_fused(raw, coef, alpha2, ping_num, range_sample_num, *, cal_type="Sv",
                    flags=_lib.FLAG_GUARD_POS | _lib.FLAG_MASK_RANGE, dtype=torch.float64,
-                   noise_max=float("nan"), want_sv=True, want_range=False, want_range_max=False):
-    """K1+K6 -> (Sv|None, echo_range|None, noise (C, ceil(P/ping_num)) f64[, nanmax(echo_range)])."""
+                   noise_max=float("nan"), want_sv=True, want_range=False, want_range_max=False,
+                   want_range_stats=False):
+    """K1+K6 -> (Sv|None, echo_range|None, noise (C, ceil(P/ping_num)) f64[, nanmax(echo_range)]).
+    ``want_range_stats``: the last element is instead the f64 device tensor {nanmin, nanmax, NaN count} of the echo_range
+    (NaN count -1: the kernel that served the configuration leaves none)."""
     C, P, S = raw.shape
     if raw.dtype != torch.float32:
         raise ValueError("raw power samples must be float32 (convert/parse_base.py:302)")
@@ -601,10 +604,13 @@ def sv_noise_fused(raw, coef, alpha2, ping_num, range_sample_num, *, cal_type="S
     sv = torch.empty((C, P, S), dtype=dtype, device=dev) if want_sv else None
     rng = torch.empty((C, P, S), dtype=dtype, device=dev) if want_range else None
     noise = torch.empty((C, -(-P // ping_num)), dtype=torch.float64, device=dev)
-    rmax = torch.empty(1, dtype=torch.float64, device=dev) if want_range_max else None
+    rmax = torch.empty(1, dtype=torch.float64, device=dev) if want_range_max or want_range_stats else None
+    rstats = torch.empty(3, dtype=torch.float64, device=dev) if want_range_stats else None
     call("epa_sv_noise_fused", _p(raw), _p(coef), _p(alpha2), C, P, S,
          _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, flags, int(ping_num), int(range_sample_num),
-         float(noise_max), _p(sv), _p(rng), _p(noise), _p(rmax), _DT[dtype], _stream())
+         float(noise_max), _p(sv), _p(rng), _p(noise), _p(rmax), _p(rstats), _DT[dtype], _stream())
+    if want_range_stats:
+        return sv, rng, noise, rstats
     return (sv, rng, noise, float(rmax.item())) if want_range_max else (sv, rng, noise)
 
 

@@ -502,11 +502,13 @@ int epa_nasc(const void* sv, const void* depth, int C, int P, int S, const int32
  * Pass 1 = K1 + K6: Sv (and optionally echo_range) written once, the noise estimate of
  * clean/api.py:397-422 accumulated from the Sv values still in registers (transmission loss from the
  * coefficient rows).  Arguments as epa_sv_power and epa_noise_estimate.  sv_out may be NULL;
- * range_max_out (f64 [1], optional) = nanmax(echo_range), which sizes the range grid of pass 2. */
+ * range_max_out (f64 [1], optional) = nanmax(echo_range), which sizes the range grid of pass 2;
+ * range_stats_out (f64 [3], optional, needs range_max_out) = {nanmin, nanmax, NaN count} of the echo_range as
+ * epa_sv_mvbs_fused leaves them ({NaN, NaN, -1} when the generic kernel serves the configuration). */
 int epa_sv_noise_fused(const float* raw, const double* coef, const double* alpha2, int C, int P, int S,
                        int cal_type, unsigned cal_flags, int ping_num, int range_sample_num,
                        double noise_max, void* sv_out, void* range_out, double* noise_out,
-                       double* range_max_out, int dtype, epa_stream_t stream);
+                       double* range_max_out, double* range_stats_out, int dtype, epa_stream_t stream);
 
 /* Pass 2 = K7 + K5: reads Sv once, applies clean/api.py:425-430,485-487 with the per-ping-block noise
  * of pass 1 and bins the CORRECTED Sv (commongrid/utils.py:592-627) in the same sweep.  Arguments as

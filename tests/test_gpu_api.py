@@ -912,10 +912,25 @@ def test_deferred_sv_other_first_readers(monkeypatch):
     mv = ep.commongrid.compute_MVBS(ds, range_bin="2m", ping_time_bin="10s", closed="right")
     np.testing.assert_allclose(mv["Sv"].values, mv_r["Sv"].values, rtol=1e-12, atol=1e-12)
     assert ds["Sv"].data.materialized
+    # remove_background_noise first: two passes over the raw samples (Sv + estimate, then Sv_noise / Sv_corrected) instead
+    # of K1 and two sweeps of the Sv array -- the estimate sums through LDS atomics either way (last-bit noise), and the
+    # odd sample sits exactly on the SNR threshold
     ds = ep.calibrate.compute_Sv(ed)
     clean = ep.clean.remove_background_noise(ds, ping_num=20, range_sample_num=50)
+    assert ds["Sv"].data.materialized and not ds["echo_range"].data.materialized
+    assert ds["echo_range"].data.cached_stats() == st_e
     np.testing.assert_array_equal(clean["Sv"].values, clean_e["Sv"].values)
-    np.testing.assert_allclose(clean["Sv_corrected"].values, clean_e["Sv_corrected"].values, rtol=1e-12, atol=1e-12)
+    np.testing.assert_array_equal(np.isnan(clean["Sv_noise"].values), np.isnan(clean_e["Sv_noise"].values))
+    np.testing.assert_allclose(clean["Sv_noise"].values, clean_e["Sv_noise"].values, rtol=1e-13, atol=1e-12)
+    ca, cb = clean["Sv_corrected"].values, clean_e["Sv_corrected"].values
+    both = np.isfinite(ca) & np.isfinite(cb)
+    assert both.any() and (np.isnan(ca) != np.isnan(cb)).mean() < 2e-3
+    np.testing.assert_allclose(ca[both], cb[both], rtol=1e-9, atol=1e-9)
+    for name in ("Sv_noise", "Sv_corrected"):
+        assert set(clean[name].attrs) == set(clean_e[name].attrs)
+        np.testing.assert_allclose(clean[name].attrs["actual_range"], clean_e[name].attrs["actual_range"], atol=0.011)
+    mv = ep.commongrid.compute_MVBS(clean, range_bin="2m", ping_time_bin="10s")     # (the rows route: range still lazy)
+    assert not ds["echo_range"].data.materialized and np.isfinite(mv["Sv"].values).any()
     # a copy of the dataset shares the deferred array: written once, seen by both
     ds = ep.calibrate.compute_Sv(ed)
     cp = ds.copy()
