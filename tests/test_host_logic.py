@@ -618,3 +618,45 @@ def test_lazy_device_array_bookkeeping():
     raw[0, 0, 0] = float("nan")                                   # the NaN source was written to
     assert lz2.nan_source() is None and lz2.coef_rows() is rows
     assert "lazy" in repr(lz2) and "materialized" in repr(lz)
+
+
+def test_lazy_device_array_fulfil_and_statistics_hook():
+    """The deferred Sv of compute_Sv: a consumer that produced the array in its own pass installs it with fulfil() (once,
+    shape and dtype checked; the producer never runs); statistics asked for before anybody left them trigger the hook once."""
+    import torch
+
+    from echopype_amd.xr_lite import LazyDeviceArray
+
+    calls = []
+
+    def make():
+        calls.append("make")
+        return torch.ones((2, 3), dtype=torch.float64)
+
+    src = object()
+    sv = LazyDeviceArray((2, 3), torch.float64, torch.device("cpu"), make, source=src)
+    assert sv.source is src and not sv.materialized
+    with pytest.raises(ValueError):
+        sv.fulfil(torch.zeros((2, 4), dtype=torch.float64))
+    with pytest.raises(ValueError):
+        sv.fulfil(torch.zeros((2, 3), dtype=torch.float32))
+    t = torch.full((2, 3), 5.0, dtype=torch.float64)
+    sv.fulfil(t)
+    assert sv.materialized and sv.tensor is t and sv.source is None and calls == []
+    with pytest.raises(RuntimeError):
+        sv.fulfil(t)
+    # the range variable that travels with it: no statistics yet, a hook that produces them (here: reading the Sv)
+    sv2 = LazyDeviceArray((2, 3), torch.float64, torch.device("cpu"), make, source=src)
+    rng = LazyDeviceArray((2, 3), torch.float64, torch.device("cpu"), lambda: torch.zeros((2, 3), dtype=torch.float64))
+
+    def hook():
+        calls.append("hook")
+        sv2.tensor
+        rng.set_stats(torch.tensor([0.0, 2.0, 1.0], dtype=torch.float64))
+
+    rng.set_stats(None, hook=hook)
+    assert calls == []
+    assert rng.cached_stats() == (0.0, 2.0, 1) and calls == ["hook", "make"] and sv2.materialized and not rng.materialized
+    assert rng.cached_stats() == (0.0, 2.0, 1) and calls == ["hook", "make"]      # asked again: nothing runs
+    rng.tensor.add_(1.0)                                                           # written to: the statistics are void
+    assert rng.cached_stats() is None
