@@ -16,7 +16,7 @@ for k, v in rows.items():
     n = 800e6 if "fft" not in k else 81.92e6
     # VALU-issue floor: wavefront instructions x 4 cycles over 256 CUs x 4 SIMDs at 2.4 GHz (what the kernel would take
     # if nothing but VALU issue limited it)
-    print("%-70s VALU/sample %.1f SALU/sample %.1f LDS/sample %.2f  VALU-issue floor %.2f ms  arch vgpr %s" % (
+    print("%-70s VALU/sample %.1f SALU/sample %.1f LDS/sample %.2f  VALU-issue floor %.2f ms  VGPRs per lane %s (rocprofv3's Arch_VGPR x 2: it counts pairs on wave64)" % (
         k[-70:], v.get("SQ_INSTS_VALU", 0) * 64 / n, v.get("SQ_INSTS_SALU", 0) * 64 / n, v.get("SQ_INSTS_LDS", 0) * 64 / n,
-        v.get("SQ_INSTS_VALU", 0) * 4 / 1024 / 2.4e9 * 1e3, v["vgpr"]))
+        v.get("SQ_INSTS_VALU", 0) * 4 / 1024 / 2.4e9 * 1e3, 2 * int(float(v["vgpr"]))))
 PY
