@@ -122,6 +122,21 @@ _WGS84_A = 6378137.0
 _WGS84_F = 1 / 298.257223563
 
 
+def assign_actual_range(ds_MVBS):
+    """Post-computation ``actual_range`` attribute of an MVBS dataset: [min, max] of ``Sv`` rounded to 2 digits
+    (commongrid/utils.py:631-651; compute_MVBS itself does not set it).  One reduction on the device."""
+    from .. import ops
+    from ..xr_lite import DeviceArray
+
+    d = ds_MVBS["Sv"].data
+    if isinstance(d, DeviceArray):
+        lo, hi = ops.nanminmax(d.tensor)
+    else:
+        a = np.asarray(d, dtype=np.float64)
+        lo, hi = np.nanmin(a), np.nanmax(a)
+    return ds_MVBS.assign_attrs({"actual_range": [round(float(lo), 2), round(float(hi), 2)]})
+
+
 def geodesic_distance_m(lat1, lon1, lat2, lon2):
     """Geodesic length in metres on WGS-84 between arrays of points (degrees), the quantity the
     reference takes from ``geopy.distance.distance`` (utils.py:219-225).  Vincenty's inverse

@@ -1,3 +1,3 @@
-from .api import add_depth  # noqa: F401
+from .api import add_depth, swap_dims_channel_frequency  # noqa: F401
 
-__all__ = ["add_depth"]
+__all__ = ["add_depth", "swap_dims_channel_frequency"]

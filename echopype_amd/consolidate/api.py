@@ -44,6 +44,30 @@ def _per_channel_ping(values, dims, C, P, what):
     raise ValueError(f"{what} has unsupported dimensions {dims}")
 
 
+@xarray_io()
+def swap_dims_channel_frequency(ds):
+    """``frequency_nominal`` in place of ``channel`` as the dataset's dimension and coordinate (consolidate/api.py:31-65:
+    set_coords -> swap_dims -> reset_coords("channel")); the reference's own compute_MVBS test bins such a dataset
+    (tests/commongrid/test_commongrid_api.py:261-276).  No array is copied: the variables keep their buffers."""
+    from ..xr_lite import Dataset
+
+    ds = from_xarray(ds)
+    fn = np.asarray(ds["frequency_nominal"].values)
+    if np.unique(fn).size != fn.size:  # only possible if no duplicated frequencies
+        raise ValueError("Duplicated transducer nominal frequencies exist in the file. Operation is not valid.")
+    out = Dataset(attrs=dict(ds.attrs))
+    for k, c in ds.coords.items():
+        if k != "channel":
+            out.coords[k] = c
+    out._set_coord("frequency_nominal", DataArray(fn, ("frequency_nominal",), attrs=dict(ds["frequency_nominal"].attrs)))
+    for k, v in ds.data_vars.items():
+        if k != "frequency_nominal":
+            dims = tuple("frequency_nominal" if d == "channel" else d for d in v.dims)
+            out.data_vars[k] = DataArray(v.data, dims, attrs=dict(v.attrs), name=k)
+    out["channel"] = (("frequency_nominal",), np.asarray(ds["channel"].values), dict(ds.coords["channel"].attrs))
+    return out
+
+
 @xarray_io(in_place=("depth",))  # the reference assigns ds["depth"] on the CALLER's dataset (consolidate/api.py:221-241)
 def add_depth(ds, echodata=None, depth_offset=None, tilt=None, downward=True,
               use_platform_vertical_offsets=False, use_platform_angles=False, use_beam_angles=False):
