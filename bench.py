@@ -674,6 +674,7 @@ def main():
             if kind not in cpu:
                 cpu[kind] = (cpu_baseline_bb() if kind == "bb" else
                              cpu_baseline_ek60(chain=kind == "chain", multicore=kind == "ek60"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (RCCL across processes needs dmabuf IPC on this host driver)
     import torch
     import torch.distributed as dist
 
