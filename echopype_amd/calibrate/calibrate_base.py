@@ -2,6 +2,7 @@
 import abc
 import logging
 import os
+import weakref
 
 import numpy as np
 
@@ -196,7 +197,14 @@ class CalibrateBase(abc.ABC):
             return out_t
 
         sv = LazyDeviceArray(tuple(raw.shape), dtype, raw.device, make, source=src)
-        rng.set_stats(None, hook=lambda: sv.tensor)  # statistics asked for first: they come with the Sv pass
+        sv_ref = weakref.ref(sv)  # (no cycle sv -> source -> echo_range -> hook -> sv: a dropped dataset frees at once)
+
+        def stats_with_sv():  # statistics asked for first: they come with the Sv pass
+            target = sv_ref()
+            if target is not None:
+                target.tensor
+
+        rng.set_stats(None, hook=stats_with_sv)
         return sv, rng
 
     def _lazy_power_range(self, raw, coef, flags, stats=None):

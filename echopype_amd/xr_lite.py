@@ -82,7 +82,7 @@ class LazyDeviceArray(DeviceArray):
     ``DeviceArray(lazy.tensor)`` to cut that tie."""
 
     __slots__ = ("_make", "_shape", "_tdtype", "_device", "_tensor", "_rows", "_mask", "_made_version", "source",
-                 "_stats_hook")
+                 "_stats_hook", "__weakref__")
 
     def __init__(self, shape, dtype, device, make, stats=None, rows=None, nan_where=None, source=None):
         self._make, self._shape, self._tdtype, self._device = make, tuple(int(n) for n in shape), dtype, device
