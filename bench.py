@@ -191,7 +191,7 @@ def measured_traffic(key):
             return None, "no PMC run of this line"
         if e.get("csrc_sha16") != csrc_hash():
             return None, f"stale: PMC run at csrc {e.get('csrc_sha16')}"
-        return e["bytes_per_launch"], f"PMC FETCH/WRITE_SIZE, {e.get('source', 'profiles/').split(' ')[0]}, csrc {e['csrc_sha16']}"
+        return e["bytes_per_launch"], f"PMC 2xFETCH+WRITE, csrc {e['csrc_sha16'][:8]}"  # (profiles/hbm_traffic.json names the csv)
     except Exception as ex:  # noqa: BLE001
         return None, f"unreadable profiles/hbm_traffic.json: {ex!r}"[:100]
 
@@ -609,8 +609,7 @@ def run_cfg5(ctx, cpu):
     steps = args.steps
     cfg = {"pings_total": P_total, "tiles": f"{n_tiles_global} x {job.tile_p} pings over {world} rank(s)",
            "sv_resident": "every tile" if job.keep_all else "one reused tile buffer",
-           "collective": (f"edge-bin exchange per pass: pack -> all_reduce(SUM, {args.backend if world > 1 else 'one rank: skipped'})"
-                          " -> finalize"),
+           "collective": f"edge bins per pass: pack -> all_reduce(SUM, {args.backend if world > 1 else '1 rank: skipped'}) -> finalize",
            "edge_bins_per_rank": len(plan_b.edges), "allreduce_bytes": plan_b.nbytes,
            "aligned_ms_per_step": el_a / steps * 1e3, "exchange_ms_per_pass": (elapsed - el_a) / steps / passes * 1e3}
     n_first = C * (job.spans[0][1] - job.spans[0][0]) * S if job.spans else 0
@@ -638,6 +637,17 @@ def relaunch(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+def compact(x):
+    """Floats to seven significant digits (the lines have to fit the driver's 2000-character tail)."""
+    if isinstance(x, float):
+        return float(f"{x:.7g}")
+    if isinstance(x, dict):
+        return {k: compact(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [compact(v) for v in x]
+    return x
 
 
 def summary(out):
@@ -706,7 +716,7 @@ def main():
             if i == len(todo) - 1 and also:  # the parsed line carries the others' key figures (flat, short strings)
                 out["config"].update(also)
             also["also_" + spec.replace(":", "_")] = summary(out)
-            txt = json.dumps(out)
+            txt = json.dumps(compact(out))
             print(txt, flush=True)
             if args.out:
                 with open(args.out, "a") as f:
