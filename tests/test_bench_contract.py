@@ -24,7 +24,7 @@ def _check_line(d, want_cpu):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6 and 0 < r["frac"] < 1  # (seven significant digits are printed)
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.001            # the dominant kernel is part of the step
     assert r["traffic"] is None or r["traffic"] > 0
     if want_cpu:
