@@ -42,6 +42,18 @@ struct Args {
   int uni_bins;      // pass 2, uniform-group kernel: time bins per workgroup
 };
 
+// v_max that returns the operand that is a number (IEEE maxNum), without the canonicalising copy fmax() adds
+__device__ __forceinline__ double vmax_num(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax_num(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ unsigned long long ordered_key(double v) {
   const unsigned long long b = __double_as_longlong(v);
   return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
@@ -100,19 +112,21 @@ struct ColBase {
 };
 
 // echo_range, R', Sv of one sample -- as process_sample of fused_sv_mvbs.hip
+// (r0v / A0: the ping's r0 and A0, which the callers keep in vector registers -- a VALU instruction takes one scalar
+// operand, the compiler otherwise copies the second one per sample)
 template <typename T>
-__device__ __forceinline__ T calibrate(const ColBase<T>& c, float raw, const epa::CoefRow& r, T g, T a2, T A0,
+__device__ __forceinline__ T calibrate(const ColBase<T>& c, float raw, const epa::CoefRow& r, double r0v, T g, T a2, T A0,
                                        T nspread, double& x, const double2* log_tab) {
   const T NaN = epa::M<T>::nan();
-  x = c.sra * r.rb + r.r0;
+  x = fma(c.sra, r.rb, r0v);
   const double rtd = x - r.shift;
   const T rt = (T)rtd;
   const bool pos = rtd > 0.0;
-  T spread = c.nL;
-  if (pos & !(spread > -(T)__builtin_inf()))  // rounding residue of R - shift (rare)
-    spread = nspread * (log10_exact<T>(rt) - log10_exact<T>((T)(r.ra * r.rb)));
-  spread = pos ? spread : NaN;
-  return fma(g, (T)raw, spread) + fma(a2, rt, A0);
+  T s1 = fma(g, (T)raw, c.nL);
+  if (pos & !(c.nL > -(T)__builtin_inf()))  // rounding residue of R - shift (rare)
+    s1 = fma(g, (T)raw, nspread * (log10_exact<T>(rt) - log10_exact<T>((T)(r.ra * r.rb))));
+  s1 = pos ? s1 : NaN;
+  return s1 + fma(a2, rt, A0);
 }
 
 // clean/api.py:397-398: 20 log10(R if R >= 1 else 1) + 2 alpha R, R = echo_range (NaN where masked)
@@ -291,14 +305,17 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
         if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + row_off + S + sB);
       }
       rc.update(r, col, sA, sB, nspread, mt.log_tab, plog, p - pb);
-      const T g_ = (T)r.g, a2 = (T)r.alpha2, A0 = (T)r.A0, na2 = (T)a2p[p];
+      const T g_ = (T)r.g, a2 = (T)r.alpha2, na2 = (T)a2p[p];
+      T A0 = (T)r.A0;
+      double r0v = r.r0;
+      asm volatile("" : "+v"(A0), "+v"(r0v));  // one copy per ping into vector registers, not one per sample
       const float in[VEC] = {inA.x, inA.y, inB.x, inB.y};
       T sv[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         if (j >= 2 && !hasB) break;
         double x;
-        sv[j] = calibrate<T>(col[j], in[j], r, g_, a2, A0, nspread, x, mt.log_tab);
+        sv[j] = calibrate<T>(col[j], in[j], r, r0v, g_, a2, A0, nspread, x, mt.log_tab);
         const bool xok = in[j] == in[j];
         if (RMAX) {  // as stored (T); x + 0 * raw is the range or NaN, and v_max_f64 / v_min_f64 skip the NaN
           const double xq = fma((double)in[j], 0.0, (double)(T)x);
@@ -308,14 +325,9 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
         }
         // the block mean uses the UNMASKED range (the generic kernel does too: a masked sample has a NaN Sv)
         const T xr = (T)x;
-#ifdef EPA_LEAN_EXP
         const T v = epa::lin_from_db_lean(sv[j] - transmission_loss<T>(col[j], xr, rc.log10k, na2), mt.exp2_tab);
-#else
-        const T v = epa::lin_from_db(sv[j] - transmission_loss<T>(col[j], xr, rc.log10k, na2), mt.exp2_tab);
-#endif
-        const bool take = v == v;
-        col[j].acc_sum += take ? v : (T)0;
-        col[j].acc_cnt += take ? 1u : 0u;
+        col[j].acc_sum += vmax_num(v, (T)0);  // v >= 0 or NaN: max(v, 0) adds nothing for a NaN
+        col[j].acc_cnt += v == v ? 1u : 0u;
       }
       if (WRITE_SV) {
         epa::store_nt2(sv_c + row_off + sA, sv[0], sv[1]);
@@ -514,7 +526,7 @@ __global__ __launch_bounds__(epa::kBlock, 3) void sv_denoise_mvbs_fast_kernel(
             lsv *= (T)epa::lin_from_db_lean(pc.da2k * (double)((j < 2 ? sA : sB) + (j & 1)), mt.exp2_tab);
           lin = ecol[j] * (lsv - (T)pc.cn * xx);
         } else {
-          const T sv = calibrate<T>(cj, in[j], r, g, a2, A0, nspread, x, mt.log_tab);
+          const T sv = calibrate<T>(cj, in[j], r, r.r0, g, a2, A0, nspread, x, mt.log_tab);
           const T xr = xok ? (T)x : epa::M<T>::nan();  // echo_range is NaN where the input is
           sn[j] = nb + transmission_loss<T>(cj, xr, rc.log10k, na2);
           lin = epa::lin_from_db(sv, mt.exp2_tab) - epa::lin_from_db(sn[j], mt.exp2_tab);

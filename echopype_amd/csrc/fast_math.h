@@ -52,8 +52,7 @@ __device__ __forceinline__ double lin_from_db(double u, const double* __restrict
   double r = fma(u, K256_HI, -m);
   r = fma(u, K256_LO, r);
   const double z = r * Z;
-  double p = fma(z, 1.0 / 120.0, 1.0 / 24.0);
-  p = fma(p, z, 1.0 / 6.0);
+  double p = fma(z, 1.0 / 24.0, 1.0 / 6.0);  // |z| <= ln(2)/512: the first term left out, z^5/120, is < 4e-17 relative
   p = fma(p, z, 0.5);
   p = fma(p, z, 1.0);
   p = fma(p, z, 1.0);
@@ -74,12 +73,13 @@ __device__ __forceinline__ double lin_from_db_lean(double u, const double* __res
   double r = fma(u, K256_HI, -m);
   r = fma(u, K256_LO, r);
   const double z = r * Z;
-  double p = fma(z, 1.0 / 120.0, 1.0 / 24.0);
-  p = fma(p, z, 1.0 / 6.0);
+  double p = fma(z, 1.0 / 24.0, 1.0 / 6.0);  // |z| <= ln(2)/512: the first term left out, z^5/120, is < 4e-17 relative
   p = fma(p, z, 0.5);
   p = fma(p, z, 1.0);
   p = fma(p, z, 1.0);
-  const int mi = (int)fmin(fmax(m, -300000.0), 300000.0);  // NaN -> -300000; p is NaN then, and so is the result
+  // v_cvt_i32_f64 saturates and turns NaN into 0: no clamp -- the table index is masked, a saturated exponent makes
+  // ldexp return inf / 0 as it should, and with a NaN argument p is NaN, hence the result
+  const int mi = __double2int_rz(m);
   double v = ldexp(p * tab[mi & 255], mi >> 8);
   if (__builtin_expect(__builtin_isinf(t), 0)) v = t < 0.0 ? 0.0 : t;
   return v;

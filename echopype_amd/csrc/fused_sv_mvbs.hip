@@ -69,34 +69,45 @@ struct Column {
   }
 };
 
+// v_max that returns the operand that is a number (IEEE maxNum), without the canonicalising copy fmax() adds
+__device__ __forceinline__ double vmax_num(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax_num(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // One sample: echo_range, R', Sv, linear value, bin membership, private accumulation.
 // Compile-time flags of the hot instantiation = the EK default (R' <= 0 guard, range masked by NaN
 // input, skipna, left-closed bins); any other combination runs the generic kernel (block_reduce.hip).
+// The kernel is as much VALU- as HBM-bound (without the Sv store it takes 3/4 of its time): every instruction of
+// this function counts.  r0v / A0v: the ping's r0 and A0 in vector registers (a VALU instruction takes one scalar
+// operand; the compiler otherwise copies the second one per sample).
 template <typename T>
-__device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::CoefRow& r, T g, T a2,
-                                            T A0, T nspread, double bin, double inv_bin, int n_rbins,
+__device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::CoefRow& r, double r0v, T g, T a2,
+                                            T A0v, T nspread, double bin, double inv_bin, int n_rbins,
                                             const double* tab, T* lsum, uint32_t* lcnt, double& xo) {
   const T NaN = epa::M<T>::nan();
-  const double x = c.sra * r.rb + r.r0;  // echo_range = (s*ra)*rb [+0]
+  const double x = fma(c.sra, r.rb, r0v);  // echo_range = (s*ra)*rb [+0]
   xo = x;  // (for the caller's range statistics; dead otherwise)
   const double rtd = x - r.shift;
   const T rt = (T)rtd;
   const bool pos = rtd > 0.0;
-  T spread = c.nL;
-  if (pos & !(spread > -(T)__builtin_inf()))  // rounding residue of R - shift (rare)
-    spread = nspread * (log10_slow<T>(rt) - log10_slow<T>((T)(r.ra * r.rb)));
-  spread = pos ? spread : NaN;
-  const T sv = fma(g, (T)raw, spread) + fma(a2, rt, A0);
-#ifdef EPA_LEAN_EXP
-  const T v = epa::lin_from_db_lean(sv, tab);  // +-inf through a rare branch instead of two selects per sample
-#else
-  const T v = epa::lin_from_db(sv, tab);
-#endif
-  // still inside the bin of the previous ping?  NaN raw -> NaN echo_range: never inside
-  const bool xok = raw == raw;
-  const bool same = xok & (x >= c.blo) & (x < c.bhi);
+  T s1 = fma(g, (T)raw, c.nL);
+  if (pos & !(c.nL > -(T)__builtin_inf()))  // rounding residue of R - shift (rare)
+    s1 = fma(g, (T)raw, nspread * (log10_slow<T>(rt) - log10_slow<T>((T)(r.ra * r.rb))));
+  s1 = pos ? s1 : NaN;
+  const T sv = s1 + fma(a2, rt, A0v);
+  const T v = epa::lin_from_db_lean(sv, tab);  // (+-inf through a rare branch)
+  // still inside the bin of the previous ping?  (A NaN raw sample makes Sv and v NaN: it is never accumulated, whatever
+  // bin the column sits in; the slow path below still parks such a column outside the grid.)
+  const bool same = (x >= c.blo) & (x < c.bhi);
   if (!same) {
-    const int rb = xok ? epa::range_bin_index(x, bin, inv_bin, n_rbins, false) : -1;
+    const int rb = raw == raw ? epa::range_bin_index(x, bin, inv_bin, n_rbins, false) : -1;
     if (rb != c.acc_rb) {
       c.flush(lsum, lcnt);
       c.acc_rb = rb;
@@ -106,9 +117,10 @@ __device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::
     c.blo = rb >= 0 ? (double)rb * bin : 1.0;
     c.bhi = rb >= 0 ? (double)(rb + 1) * bin : 0.0;
   }
-  const bool take = (c.acc_rb >= 0) & (v == v);
-  c.acc_sum += take ? v : (T)0;
-  c.acc_cnt += take ? 1u : 0u;
+  // (a column outside the grid, acc_rb < 0, accumulates too: flush() drops it.)  v >= 0 or NaN: max(v, 0) adds nothing
+  // for a NaN
+  c.acc_sum += vmax_num(v, (T)0);
+  c.acc_cnt += v == v ? 1u : 0u;
   return sv;
 }
 
@@ -239,10 +251,13 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
           col[j].sra = sj * r.ra;
         }
       }
-      const T g = (T)r.g, a2 = (T)r.alpha2, A0 = (T)r.A0;
+      const T g = (T)r.g, a2 = (T)r.alpha2;
+      T A0 = (T)r.A0;
+      double r0v = r.r0;
+      asm volatile("" : "+v"(A0), "+v"(r0v));  // one copy per ping into vector registers, not one per sample
       double x0, x1, x2 = 0.0, x3 = 0.0;
-      const T sv0 = process_sample<T>(col[0], inA.x, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, x0);
-      const T sv1 = process_sample<T>(col[1], inA.y, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, x1);
+      const T sv0 = process_sample<T>(col[0], inA.x, r, r0v, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, x0);
+      const T sv1 = process_sample<T>(col[1], inA.y, r, r0v, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, x1);
       if (WRITE_SV) {
 #ifndef EPA_PLAIN_STORES  // streaming (nt) stores: +2 % at 4 G samples, Sv is never re-read here
         epa::store_nt2(sv_c + row_off + sA, sv0, sv1);
@@ -252,8 +267,8 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
 #endif
       }
       if (hasB) {
-        const T sv2 = process_sample<T>(col[2], inB.x, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, x2);
-        const T sv3 = process_sample<T>(col[3], inB.y, r, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, x3);
+        const T sv2 = process_sample<T>(col[2], inB.x, r, r0v, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, x2);
+        const T sv3 = process_sample<T>(col[3], inB.y, r, r0v, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, x3);
         if (WRITE_SV) {
 #ifndef EPA_PLAIN_STORES  // streaming (nt) stores: +2 % at 4 G samples, Sv is never re-read here
           epa::store_nt2(sv_c + row_off + sB, sv2, sv3);
@@ -539,7 +554,7 @@ __global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 6 : 8) void mvbs_of_s
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         if (j >= 2 && !hasB) break;
-        const T v = epa::lin_from_db(in[j], tab);
+        const T v = epa::lin_from_db_lean(in[j], tab);  // (+-inf through a rare branch: 40 -> 35 VALU per sample)
         const bool take = (((fixed >> j) & 1u) != 0u) & (rbin[j] >= 0) & (v == v);
         acc_sum[j] += take ? v : (T)0;
         acc_cnt[j] += take ? 1u : 0u;
@@ -563,7 +578,7 @@ __global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 6 : 8) void mvbs_of_s
           todo &= todo - 1ull;
           const int sx = chunk0 + wave * 256 + 2 * src + (j < 2 ? 0 : 128) + (j & 1);
           for (int p = pb + lane; p < pe; p += 64) {
-            const T v = epa::lin_from_db(sv_c[(size_t)p * S + sx], tab);
+            const T v = epa::lin_from_db_lean(sv_c[(size_t)p * S + sx], tab);
             const double x = range_of(sx, rowp0[p].rb);
             const int rb = epa::range_bin_index(x, bin, inv_bin, n_rbins, false);
             if ((rb >= 0) & (v == v)) {
