@@ -554,15 +554,16 @@ __global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 6 : 8) void mvbs_of_s
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         if (j >= 2 && !hasB) break;
-        const T v = epa::lin_from_db_lean(in[j], tab);  // (+-inf through a rare branch: 40 -> 35 VALU per sample)
-        const bool take = (((fixed >> j) & 1u) != 0u) & (rbin[j] >= 0) & (v == v);
-        acc_sum[j] += take ? v : (T)0;
-        acc_cnt[j] += take ? 1u : 0u;
+        // every column accumulates (v >= 0 or NaN: max(v, 0) adds nothing for a NaN); the loose ones and those outside
+        // the grid are dropped below -- nothing per sample depends on the column's kind
+        const T v = epa::lin_from_db_lean(in[j], tab);  // (+-inf through a rare branch)
+        acc_sum[j] += vmax_num(v, (T)0);
+        acc_cnt[j] += v == v ? 1u : 0u;
       }
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      if (rbin[j] >= 0 && acc_cnt[j] > 0u) {
+      if (((fixed >> j) & 1u) != 0u && rbin[j] >= 0 && acc_cnt[j] > 0u) {
         lds_add(lsum + rbin[j], acc_sum[j]);
         atomicAdd(lcnt + rbin[j], acc_cnt[j]);
       }
