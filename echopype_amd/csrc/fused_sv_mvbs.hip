@@ -80,6 +80,11 @@ __device__ __forceinline__ float vmax_num(float a, float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+__device__ __forceinline__ double vmin_num(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 // One sample: echo_range, R', Sv, linear value, bin membership, private accumulation.
 // Compile-time flags of the hot instantiation = the EK default (R' <= 0 guard, range masked by NaN
@@ -87,13 +92,21 @@ __device__ __forceinline__ float vmax_num(float a, float b) {
 // The kernel is as much VALU- as HBM-bound (without the Sv store it takes 3/4 of its time): every instruction of
 // this function counts.  r0v / A0v: the ping's r0 and A0 in vector registers (a VALU instruction takes one scalar
 // operand; the compiler otherwise copies the second one per sample).
-template <typename T>
+template <typename T, bool STATS>
 __device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::CoefRow& r, double r0v, T g, T a2,
                                             T A0v, T nspread, double bin, double inv_bin, int n_rbins,
-                                            const double* tab, T* lsum, uint32_t* lcnt, double& xo) {
+                                            const double* tab, T* lsum, uint32_t* lcnt, double& xmax, double& xmin,
+                                            unsigned& nnan) {
   const T NaN = epa::M<T>::nan();
   const double x = fma(c.sra, r.rb, r0v);  // echo_range = (s*ra)*rb [+0]
-  xo = x;  // (for the caller's range statistics; dead otherwise)
+  if (STATS) {
+    // {min, max, NaN count} of the echo_range, NaN exactly where the raw sample is: x + 0 * raw is the range or NaN,
+    // and v_max_f64 / v_min_f64 return the operand that is a number
+    const double xq = fma((double)raw, 0.0, x);
+    xmax = vmax_num(xmax, xq);
+    xmin = vmin_num(xmin, xq);
+    nnan += (unsigned)__builtin_popcountll(__ballot(raw != raw));  // (per wavefront, in a scalar register)
+  }
   const double rtd = x - r.shift;
   const T rt = (T)rtd;
   const bool pos = rtd > 0.0;
@@ -180,7 +193,7 @@ struct PingLoad<int16_t> {
 #define EPA_FUSED_MIN_WAVES 1
 #endif
 template <typename T, typename RawT, bool WRITE_SV, bool RMAX>
-__global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvbs_kernel(
+__global__ __launch_bounds__(epa::kBlock, RMAX ? 4 : EPA_FUSED_MIN_WAVES) void fused_sv_mvbs_kernel(
     const RawT* __restrict__ raw, const int32_t* __restrict__ n_valid,
     const epa::CoefRow* __restrict__ coef,
     const int32_t* __restrict__ bin_start, T* __restrict__ sv_out, T* __restrict__ mvbs_out,
@@ -255,9 +268,8 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
       T A0 = (T)r.A0;
       double r0v = r.r0;
       asm volatile("" : "+v"(A0), "+v"(r0v));  // one copy per ping into vector registers, not one per sample
-      double x0, x1, x2 = 0.0, x3 = 0.0;
-      const T sv0 = process_sample<T>(col[0], inA.x, r, r0v, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, x0);
-      const T sv1 = process_sample<T>(col[1], inA.y, r, r0v, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, x1);
+      const T sv0 = process_sample<T, RMAX>(col[0], inA.x, r, r0v, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax, xmin, nnan);
+      const T sv1 = process_sample<T, RMAX>(col[1], inA.y, r, r0v, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax, xmin, nnan);
       if (WRITE_SV) {
 #ifndef EPA_PLAIN_STORES  // streaming (nt) stores: +2 % at 4 G samples, Sv is never re-read here
         epa::store_nt2(sv_c + row_off + sA, sv0, sv1);
@@ -267,8 +279,8 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
 #endif
       }
       if (hasB) {
-        const T sv2 = process_sample<T>(col[2], inB.x, r, r0v, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, x2);
-        const T sv3 = process_sample<T>(col[3], inB.y, r, r0v, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, x3);
+        const T sv2 = process_sample<T, RMAX>(col[2], inB.x, r, r0v, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax, xmin, nnan);
+        const T sv3 = process_sample<T, RMAX>(col[3], inB.y, r, r0v, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax, xmin, nnan);
         if (WRITE_SV) {
 #ifndef EPA_PLAIN_STORES  // streaming (nt) stores: +2 % at 4 G samples, Sv is never re-read here
           epa::store_nt2(sv_c + row_off + sB, sv2, sv3);
@@ -276,20 +288,6 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
           const T o[2] = {sv2, sv3};
           epa::store_vec<T, 2>(sv_c + row_off + sB, o);
 #endif
-        }
-      }
-      if (RMAX) {
-        // {min, max, NaN count} of the echo_range, NaN exactly where the raw sample is: x + 0 * raw is the range or NaN,
-        // and v_max_f64 / v_min_f64 return the operand that is a number
-        const float in[4] = {inA.x, inA.y, inB.x, inB.y};
-        const double xs[4] = {x0, x1, x2, x3};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (j >= 2 && !hasB) break;
-          const double xq = fma((double)in[j], 0.0, xs[j]);
-          xmax = fmax(xmax, xq);
-          xmin = fmin(xmin, xq);
-          nnan += in[j] == in[j] ? 0u : 1u;
         }
       }
     }
@@ -303,10 +301,7 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES) void fused_sv_mvb
     if (lane == 0 && xmax > -__builtin_inf()) atomicMax(a.rmax_key, ordered_key(xmax));
     if (a.rstat) {  // (uniform) the rest of {nanmin, nanmax, NaN count}: what compute_MVBS asks of an echo_range array
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        xmin = fmin(xmin, __shfl_down(xmin, o, 64));
-        nnan += __shfl_down(nnan, o, 64);
-      }
+      for (int o = 32; o > 0; o >>= 1) xmin = fmin(xmin, __shfl_down(xmin, o, 64));  // (nnan is the wavefront's already)
       if (lane == 0 && xmin < __builtin_inf()) atomicMin(a.rstat, ordered_key(xmin));
       if (lane == 0 && nnan > 0u) atomicAdd(a.rstat + 1, (unsigned long long)nnan);
     }
