@@ -231,7 +231,7 @@ struct NoiseCol : ColBase<T> {
 };
 
 template <typename T, bool WRITE_SV, bool RMAX>
-__global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 4 : 1) void sv_noise_fast_kernel(
+__global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
     const float* __restrict__ raw, const epa::CoefRow* __restrict__ coef,
     const double* __restrict__ alpha2, T* __restrict__ sv_out, double* __restrict__ noise_out, Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
