@@ -24,9 +24,14 @@ def t(f):
         del r  # one result resident at a time: the caching allocator hands the same blocks back
         torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     return float(np.median(ts)), r
-a, ds = t(lambda: ep.calibrate.compute_Sv(ed))
+# (compute_Sv defers the Sv array to its first reader: the two calls are timed together, on a fresh dataset each time;
+#  then compute_MVBS alone on a dataset whose Sv has been written)
+def two_calls():
+    ds_ = ep.calibrate.compute_Sv(ed)
+    return ds_, ep.commongrid.compute_MVBS(ds_, range_bin="1m", ping_time_bin="20s")
+a, (ds, mv) = t(two_calls)
 b, mv = t(lambda: ep.commongrid.compute_MVBS(ds, range_bin="1m", ping_time_bin="20s"))
-print(f"compute_Sv   {a*1e3:7.1f} ms = {n/a/1e9:6.1f} Gsamp/s      compute_MVBS {b*1e3:7.1f} ms = {n/b/1e9:6.1f} Gsamp/s     both {n/(a+b)/1e9:6.1f}")
+print(f"compute_Sv + compute_MVBS (Sv deferred) {a*1e3:7.1f} ms = {n/a/1e9:6.1f} Gsamp/s      compute_MVBS on the written Sv {b*1e3:7.1f} ms = {n/b/1e9:6.1f} Gsamp/s")
 del ds, mv
 c, r = t(lambda: ep.compute_Sv_MVBS(ed, range_bin="1m", ping_time_bin="20s"))
 print(f"compute_Sv_MVBS (one pass) {c*1e3:7.1f} ms = {n/c/1e9:6.1f} Gsamp/s")
