@@ -53,6 +53,11 @@ __device__ __forceinline__ float vmax_num(float a, float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+__device__ __forceinline__ double vmin_num(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 __device__ __forceinline__ unsigned long long ordered_key(double v) {
   const unsigned long long b = __double_as_longlong(v);
@@ -316,12 +321,11 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
         if (j >= 2 && !hasB) break;
         double x;
         sv[j] = calibrate<T>(col[j], in[j], r, r0v, g_, a2, A0, nspread, x, mt.log_tab);
-        const bool xok = in[j] == in[j];
         if (RMAX) {  // as stored (T); x + 0 * raw is the range or NaN, and v_max_f64 / v_min_f64 skip the NaN
           const double xq = fma((double)in[j], 0.0, (double)(T)x);
-          xmax = fmax(xmax, xq);
-          xmin = fmin(xmin, xq);
-          nnan += xok ? 0u : 1u;
+          xmax = vmax_num(xmax, xq);
+          xmin = vmin_num(xmin, xq);
+          nnan += (unsigned)__builtin_popcountll(__ballot(in[j] != in[j]));  // (per wavefront, in a scalar register)
         }
         // the block mean uses the UNMASKED range (the generic kernel does too: a masked sample has a NaN Sv)
         const T xr = (T)x;
@@ -347,10 +351,7 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
     if (lane == 0 && xmax > -__builtin_inf()) atomicMax(a.rmax_key, ordered_key(xmax));
     if (a.rstat) {  // (uniform) the rest of {nanmin, nanmax, NaN count} of the echo_range
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        xmin = fmin(xmin, __shfl_down(xmin, o, 64));
-        nnan += __shfl_down(nnan, o, 64);
-      }
+      for (int o = 32; o > 0; o >>= 1) xmin = fmin(xmin, __shfl_down(xmin, o, 64));  // (nnan is the wavefront's already)
       if (lane == 0 && xmin < __builtin_inf()) atomicMin(a.rstat, ordered_key(xmin));
       if (lane == 0 && nnan > 0u) atomicAdd(a.rstat + 1, (unsigned long long)nnan);
     }
