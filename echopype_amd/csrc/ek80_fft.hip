@@ -423,13 +423,13 @@ struct FftArgs {
 
 // sector sum (or one sector when only >= 0) + validity bits of sample s (bits 0..B-1 sector valid, bit 8: beam-0
 // real part valid = the echo_range mask of range.py:143-146)
-template <typename InT, typename F, int NB>
+template <typename InT, typename F, int NB, bool INSIDE = false>
 __device__ __forceinline__ void load_sample(const InT* __restrict__ re, const InT* __restrict__ im, size_t ping_base,
                                             int S, int Brt, int s, int only, C2<F>& v, unsigned& m) {
   const int B = NB > 0 ? NB : Brt;
   F sr = (F)0, si = (F)0;
   m = 0;
-  if (s < S) {
+  if (INSIDE || s < S) {
     const InT* pr = re + ping_base + (size_t)s * B;
     const InT* pi = im + ping_base + (size_t)s * B;
     if (NB > 0) {
@@ -562,14 +562,26 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
   unsigned m[MIXED ? 8 : 1];
   unsigned vbits = 0;  // bit i: sample i has valid sectors; bit 8 + i: its beam-0 real part is valid
   unsigned mixed_l = 0;
+  // (a tile that lies inside the ping -- all but the last one or two -- needs no per-sample bound test: block-uniform)
+  if (!MIXED && k_begin + kN <= S) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    unsigned mi;
-    load_sample<InT, F, NB>(re, im, ping_base, S, B, k_begin + j + 256 * i, -1, v[i], mi);
-    if (MIXED) m[i] = mi;
-    vbits |= ((mi & full) != 0u ? 1u : 0u) << i;
-    vbits |= ((mi >> 8) & 1u) << (8 + i);
-    mixed_l |= ((mi & full) != 0u && (mi & full) != full) ? 1u : 0u;
+    for (int i = 0; i < 8; ++i) {
+      unsigned mi;
+      load_sample<InT, F, NB, true>(re, im, ping_base, S, B, k_begin + j + 256 * i, -1, v[i], mi);
+      vbits |= ((mi & full) != 0u ? 1u : 0u) << i;
+      vbits |= ((mi >> 8) & 1u) << (8 + i);
+      mixed_l |= ((mi & full) != 0u && (mi & full) != full) ? 1u : 0u;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      unsigned mi;
+      load_sample<InT, F, NB>(re, im, ping_base, S, B, k_begin + j + 256 * i, -1, v[i], mi);
+      if (MIXED) m[i] = mi;
+      vbits |= ((mi & full) != 0u ? 1u : 0u) << i;
+      vbits |= ((mi >> 8) & 1u) << (8 + i);
+      mixed_l |= ((mi & full) != 0u && (mi & full) != full) ? 1u : 0u;
+    }
   }
 
   C2<F> y[MIXED ? 8 : 1];
