@@ -438,7 +438,7 @@ def run_api(ctx, cpu):
                         "two_calls_not_deferred_ms": eager_ms, "chain_three_calls_ms": chain_ms,
                         "chain_three_calls_not_deferred_ms": chain_eager_ms, "sharding": "one GPU", "collective": "none"},
                 roofline=roofline("fused_sv_mvbs_kernel inside compute_MVBS (+ host parameter selection)", region_ms, n * bps,
-                                  bps, note="region = both API calls incl. host work"))
+                                  bps, traffic_key=f"api:{dtype}", note="region = both API calls incl. host work"))
 
 
 # ---------------------------------------------------------------------------------------- EK80 BB: cfg4

@@ -25,6 +25,8 @@ KERNELS = {
     "cfg4:float64": ("cfg4", ["sv_complex_fft_kernel<float, double, double"], None, 2 * 200_000 * 8192 * 40),
     "cfg4:float64:planes64": ("cfg4_planes64", ["sv_complex_fft_kernel<double, double, double"], None, 2 * 200_000 * 8192 * 72),
     "cfg5:float64": ("cfg5", ["fused_sv_mvbs_kernel<double, float, true, false>"], None, 4 * 250_000 * 4096 * 12),
+    # the two reference calls with the Sv deferred: the statistics variant of the fused kernel inside compute_MVBS
+    "api:float64": ("api", ["fused_sv_mvbs_kernel<double, float, true, true>"], None, 4 * 500_000 * 2000 * 12),
 }
 
 

@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/final3; rm -rf $O; mkdir -p $O
 python -m pytest tests -q -m gpu 2>&1 | tail -15 > $O/tests.txt; tail -3 $O/tests.txt
-for wl in cfg2 cfg3 cfg4 cfg4:planes64 cfg5; do
+for wl in cfg2 cfg3 cfg4 cfg4:planes64 cfg5 api; do
   tag=$(echo $wl | tr ':' '_')
   extra=""
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -13,7 +13,7 @@ for wl in cfg2 cfg3 cfg4 cfg4:planes64 cfg5; do
     timeout 500 rocprofv3 --pmc $c --kernel-trace -d $O/${n}_$tag -o p --output-format csv -- python bench.py --workload $wl --no-cpu-baseline --steps 1 --warmup 1 --passes 2 $extra > $O/${n}_$tag.log 2>&1
   done
 done
-for wl in cfg2 cfg3 cfg4 cfg4_planes64 cfg5; do for n in fetch write; do python scripts/pmc_summary.py $O/${n}_$wl kernel | grep -v "^kernel," | sed "s/^/$wl,/" ; done; done > $O/pmc_traffic.csv
+for wl in cfg2 cfg3 cfg4 cfg4_planes64 cfg5 api; do for n in fetch write; do python scripts/pmc_summary.py $O/${n}_$wl kernel | grep -v "^kernel," | sed "s/^/$wl,/" ; done; done > $O/pmc_traffic.csv
 python scripts/make_traffic_json.py $O | tee $O/traffic.txt
 cp profiles/hbm_traffic.json $O/hbm_traffic.json
 find $O -name "*counter_collection.csv" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
