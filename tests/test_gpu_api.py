@@ -566,6 +566,16 @@ def test_power_chains_match_reference_method_goldens(ep):
             close(ds[cal].values, g[f"{tag}_{cal}"], 1e-9, f"{tag} API {cal}")
             np.testing.assert_array_equal(ds["echo_range"].values, g[f"{tag}_echo_range"])
         np.testing.assert_array_equal(ds["equivalent_beam_angle"].values, g[f"{tag}_psi"])
+        # ... and with compute_MVBS as the first reader of the deferred Sv: the array the FUSED kernel writes is held to
+        # the same reference-executed values (and range_var_max caps the grid as on the plain route)
+        ds = ep.calibrate.compute_Sv(ed, env_params=env, cal_params=calp)
+        deferred = not ds["Sv"].data.materialized
+        mv = ep.commongrid.compute_MVBS(ds, range_bin="0.5m", ping_time_bin="3s", range_var_max="4m")
+        assert deferred and ds["Sv"].data.materialized and not ds["echo_range"].data.materialized
+        close(ds["Sv"].values, g[f"{tag}_Sv"], 1e-9, f"{tag} API Sv written by compute_MVBS")
+        assert mv["echo_range"].values.max() == 4.0 and np.isfinite(mv["Sv"].values).any()
+        exp, _, _ = ogrid.compute_MVBS(g[f"{tag}_Sv"], g[f"{tag}_echo_range"], t, "0.5m", "3s", range_var_max="4m")
+        close(mv["Sv"].values, exp, 1e-9, f"{tag} MVBS of the deferred route")
     # AZFP through the Dataset API with the golden's parameters as user env / cal params
     C, P, S = g["azfp_counts"].shape
     t = np.datetime64("2026-05-01T00:00:00", "ns") + np.arange(P) * np.timedelta64(2, "s")
