@@ -984,3 +984,54 @@ def test_swap_dims_channel_frequency_then_MVBS_and_assign_actual_range(ep):
     v = mv["Sv"].values
     assert out.attrs["actual_range"] == [round(float(np.nanmin(v)), 2), round(float(np.nanmax(v)), 2)]
     assert "actual_range" not in mv.attrs
+
+
+def test_ek80_power_samples_through_the_api_match_the_reference_golden(ep):
+    """EK80 CW POWER samples (encode_mode="power", one GPT channel: calibrate_ek.py:79-206 with the EK80 flag) through the
+    Dataset API -- an EchoData whose power beam group is found through Sonar.waveform_encode_descr -- against the
+    reference-executed `ek80p_*` golden; Sv both as K1 writes it and as compute_MVBS writes it on the deferred route."""
+    import os
+
+    from echopype_amd.echodata import EchoData
+    from echopype_amd.xr_lite import Dataset
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_chain_goldens.npz"))
+    tag = "ek80p"
+    raw = g[f"{tag}_raw"]
+    C, P, S = raw.shape
+    chans = [f"ch{i}" for i in range(C)]
+    t = np.datetime64("2026-05-01T00:00:00", "ns") + np.arange(P) * np.timedelta64(1, "s")
+    cpd = ("channel", "ping_time")
+    beam = Dataset(coords={"channel": chans, "ping_time": t, "range_sample": np.arange(S)})
+    beam["backscatter_r"] = (("channel", "ping_time", "range_sample"), raw)
+    beam["sample_interval"] = (cpd, g[f"{tag}_sample_interval"])
+    beam["transmit_duration_nominal"] = (cpd, g[f"{tag}_tau"])
+    beam["transmit_power"] = (cpd, g[f"{tag}_transmit_power"])
+    beam["frequency_nominal"] = (("channel",), g[f"{tag}_frequency"])
+    sonar = Dataset(coords={"beam_group": ["Beam_group1"]})
+    sonar["waveform_encode_descr"] = (("beam_group",), np.array(["power"]))
+    vend = Dataset(coords={"channel": chans})
+    vend["transceiver_type"] = (("channel",), np.where(g[f"{tag}_is_gpt"], "GPT", "WBT"))
+    env_g = Dataset(coords={"channel": chans, "time1": t[:1]})   # what the EK80 converter always writes (set_groups_ek80.py)
+    for name, v in (("temperature", 8.0), ("salinity", 33.0), ("depth", 5.0), ("acidity", 8.0), ("sound_speed_indicative", 1490.0)):
+        env_g[name] = (("time1",), np.array([v]))
+    ed = EchoData("EK80", {"Sonar": sonar, "Sonar/Beam_group1": beam, "Vendor_specific": vend, "Environment": env_g},
+                  source_file="synthetic_ek80_power.raw")
+    cp = lambda a: ep.DataArray(a, cpd, {"channel": chans, "ping_time": t})  # noqa: E731
+    env = {"sound_speed": cp(g[f"{tag}_sound_speed"]), "sound_absorption": cp(g[f"{tag}_absorption"])}
+    calp = {"gain_correction": cp(g[f"{tag}_gain"]), "sa_correction": cp(g[f"{tag}_sa"]),
+            "equivalent_beam_angle": ep.DataArray(g[f"{tag}_psi"], ("channel",), {"channel": chans})}
+    kw = dict(env_params=env, cal_params=calp, waveform_mode="CW", encode_mode="power")
+    for cal in ("Sv", "TS"):
+        fn = ep.calibrate.compute_Sv if cal == "Sv" else ep.calibrate.compute_TS
+        ds = fn(ed, **kw)
+        close(ds[cal].values, g[f"{tag}_{cal}"], 1e-9, f"{tag} API {cal}")
+        np.testing.assert_array_equal(ds["echo_range"].values, g[f"{tag}_echo_range"])
+    np.testing.assert_allclose(ep.calibrate.compute_Sv(ed, **kw)["tau_effective"].values, g[f"{tag}_tau_effective"], rtol=1e-15)
+    ds = ep.calibrate.compute_Sv(ed, **kw)
+    deferred = not ds["Sv"].data.materialized
+    mv = ep.commongrid.compute_MVBS(ds, range_bin="0.5m", ping_time_bin="2s")
+    assert deferred and ds["Sv"].data.materialized
+    close(ds["Sv"].values, g[f"{tag}_Sv"], 1e-9, f"{tag} API Sv written by compute_MVBS")
+    exp, _, _ = ogrid.compute_MVBS(g[f"{tag}_Sv"], g[f"{tag}_echo_range"], t, "0.5m", "2s")
+    close(mv["Sv"].values, exp, 1e-9, f"{tag} MVBS of the deferred route")
