@@ -161,9 +161,10 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
         return None
     ping_time = np.asarray(ds_Sv["ping_time"].values).astype("datetime64[ns]", copy=False)
     ns = ping_time.view(np.int64)
-    if np.any(ns[1:] < ns[:-1]) or (ns.size and ns.min() == np.iinfo(np.int64).min):  # unsorted, or NaT (INT64_MIN)
+    # unsorted, or NaT (INT64_MIN: the smallest value, so in a sorted array it could only be the first)
+    if ns.size == 0 or np.any(ns[1:] < ns[:-1]) or ns[0] == np.iinfo(np.int64).min:
         return None
-    e0, dt, n_t = resample_edges(ping_time, ping_time_bin)
+    e0, dt, n_t = resample_edges(ping_time, ping_time_bin, sorted_valid=True)
     bin_start = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t)
     C, P, S = d.shape
     # the grid is np.arange(0, nanmax(echo_range) + bin, bin) (api.py:108-115): run on a conservative one (the largest

@@ -50,7 +50,7 @@ def ping_time_bin_parsing_and_conversion(ping_time_bin):
     return ns, "nanosecond"
 
 
-def resample_edges(ping_time, ping_time_bin):
+def resample_edges(ping_time, ping_time_bin, sorted_valid=False):
     """Bin edges of ``ping_time.resample(ping_time=bin)`` plus one trailing edge (api.py:118-124).
 
     pandas anchors fixed-frequency bins at midnight of the first timestamp's day
@@ -59,6 +59,12 @@ def resample_edges(ping_time, ping_time_bin):
     """
     t = np.asarray(ping_time).astype("datetime64[ns]", copy=False).view(np.int64)
     dt = timedelta_ns(ping_time_bin)
+    if sorted_valid and t.size:  # the caller has checked: non-decreasing, no NaT -- the ends are the extremes
+        first, last = int(t[0]), int(t[-1])
+        day = 86400 * 10**9
+        origin = (first // day) * day
+        e0 = origin + ((first - origin) // dt) * dt
+        return e0, dt, int((last - e0) // dt + 1)
     first = int(t.min()) if t.size else 0
     if t.size == 0 or first == np.iinfo(np.int64).min:  # NaT present (INT64_MIN): drop them
         t = t[t != np.iinfo(np.int64).min]

@@ -660,3 +660,17 @@ def test_lazy_device_array_fulfil_and_statistics_hook():
     assert rng.cached_stats() == (0.0, 2.0, 1) and calls == ["hook", "make"]      # asked again: nothing runs
     rng.tensor.add_(1.0)                                                           # written to: the statistics are void
     assert rng.cached_stats() is None
+
+
+def test_resample_edges_sorted_shortcut_equals_the_scan():
+    """compute_MVBS on a deferred Sv has already checked its ping times (non-decreasing, no NaT) and takes the bin edges
+    from the two ends: the same edges as the scan over all of them."""
+    from echopype_amd.commongrid.utils import resample_edges
+
+    rng = np.random.default_rng(3)
+    for bin_ in ("1s", "20s", "7min", "1h"):
+        for _ in range(20):
+            n = int(rng.integers(1, 400))
+            t0 = np.datetime64("2026-03-09T00:00:00", "ns") + np.timedelta64(int(rng.integers(0, 86400 * 3)), "s")
+            t = t0 + np.sort(rng.integers(0, 10**12, n)).astype("timedelta64[ns]")
+            assert resample_edges(t, bin_, sorted_valid=True) == resample_edges(t, bin_)
