@@ -229,14 +229,18 @@ struct RowCache {
 // ------------------------------------------------------------------------------------------------
 constexpr int kP1Blocks = 2;  // ping blocks per workgroup of pass 1
 
+// Pass 1 keeps the two cached logarithms of a range column -- n log10(s - d) and log10(s - d_tl) -- in LDS, every lane
+// its own four entries (written and read by the same lane: no barrier), instead of sixteen registers: with the sample
+// temporaries of two samples at a time that is what fits four wavefronts per SIMD without scratch.
 template <typename T>
-struct NoiseCol : ColBase<T> {
+struct NoiseCol {
+  double sra;  // fl(s * ra)
   T acc_sum;
   uint32_t acc_cnt;
 };
 
 template <typename T, bool WRITE_SV, bool RMAX>
-__global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
+__global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 4 : 1) void sv_noise_fast_kernel(
     const float* __restrict__ raw, const epa::CoefRow* __restrict__ coef,
     const double* __restrict__ alpha2, T* __restrict__ sv_out, double* __restrict__ noise_out, Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -267,6 +271,7 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
   double xmax = -__builtin_inf(), xmin = __builtin_inf();
   unsigned nnan = 0u;
   __shared__ T plog[kPingLogs];
+  __shared__ T col_nL[kChunk], col_lgs[kChunk];
   fill_ping_logs<T>(plog, rowp0 + pb, pe - pb, mt.log_tab);
   __syncthreads();
 
@@ -274,11 +279,13 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
     const int sA = chunk0 + wave * 256 + 2 * lane, sB = sA + 128;
     if (sA >= S) continue;
     const bool hasB = sB < S;
+    const int eA = wave * 256 + 2 * lane;  // the lane's entries of col_nL / col_lgs: eA, eA + 1, eA + 128, eA + 129
     NoiseCol<T> col[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      col[j].sra = 0.0; col[j].nL = epa::M<T>::nan(); col[j].lgs = (T)0; col[j].c2 = (T)0;
-      col[j].acc_sum = (T)0; col[j].acc_cnt = 0u;
+      col[j].sra = 0.0; col[j].acc_sum = (T)0; col[j].acc_cnt = 0u;
+      col_nL[eA + (j < 2 ? 0 : 128) + (j & 1)] = epa::M<T>::nan();
+      col_lgs[eA + (j < 2 ? 0 : 128) + (j & 1)] = (T)0;
     }
     int rbk[VEC];  // range block of each column
 #pragma unroll
@@ -309,18 +316,45 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
         nA = *reinterpret_cast<const float2*>(raw_c + row_off + S + sA);
         if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + row_off + S + sB);
       }
-      rc.update(r, col, sA, sB, nspread, mt.log_tab, plog, p - pb);
+      // refresh of the cached column logs when the row constants they depend on change (as RowCache::update)
+      if (!((r.d == rc.d) & (r.ra == rc.ra))) {
+        rc.d = r.d;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const double sj = (double)((j < 2 ? sA : sB) + (j & 1));
+          col_nL[eA + (j < 2 ? 0 : 128) + (j & 1)] = nspread * log10_exact<T>((T)(sj - r.d));
+          col[j].sra = sj * r.ra;
+        }
+      }
+      {
+        const double k = r.ra * r.rb;
+        if (p - pb < kPingLogs) {
+          rc.log10k = plog[p - pb];
+        } else if (!((r.ra == rc.ra) & (r.rb == rc.rb))) {  // sound speed may drift from ping to ping: table-driven log
+          rc.log10k = log10_pos((T)k, mt.log_tab);
+        }
+        rc.rb = r.rb;
+        rc.ra = r.ra;
+        const double dnew = r.r0 == 0.0 ? 0.0 : -r.r0 / k;  // EK rows: echo_range starts at 0
+        if (!(dnew == rc.dtl)) {
+          rc.dtl = dnew;
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const double sj = (double)((j < 2 ? sA : sB) + (j & 1));
+            col_lgs[eA + (j < 2 ? 0 : 128) + (j & 1)] = log10_slow((T)(sj - dnew), mt.log_tab);
+          }
+        }
+      }
       const T g_ = (T)r.g, a2 = (T)r.alpha2, na2 = (T)a2p[p];
       T A0 = (T)r.A0;
       double r0v = r.r0;
       asm volatile("" : "+v"(A0), "+v"(r0v));  // one copy per ping into vector registers, not one per sample
       const float in[VEC] = {inA.x, inA.y, inB.x, inB.y};
-      T sv[VEC];
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        if (j >= 2 && !hasB) break;
+      auto one = [&](int j) -> T {
         double x;
-        sv[j] = calibrate<T>(col[j], in[j], r, r0v, g_, a2, A0, nspread, x, mt.log_tab);
+        const int e = eA + (j < 2 ? 0 : 128) + (j & 1);
+        const ColBase<T> cb{col[j].sra, col_nL[e], col_lgs[e], (T)0};
+        const T svj = calibrate<T>(cb, in[j], r, r0v, g_, a2, A0, nspread, x, mt.log_tab);
         if (RMAX) {  // as stored (T); x + 0 * raw is the range or NaN, and v_max_f64 / v_min_f64 skip the NaN
           const double xq = fma((double)in[j], 0.0, (double)(T)x);
           xmax = vmax_num(xmax, xq);
@@ -329,13 +363,19 @@ __global__ __launch_bounds__(epa::kBlock) void sv_noise_fast_kernel(
         }
         // the block mean uses the UNMASKED range (the generic kernel does too: a masked sample has a NaN Sv)
         const T xr = (T)x;
-        const T v = epa::lin_from_db_lean(sv[j] - transmission_loss<T>(col[j], xr, rc.log10k, na2), mt.exp2_tab);
+        const T v = epa::lin_from_db_lean(svj - transmission_loss<T>(cb, xr, rc.log10k, na2), mt.exp2_tab);
         col[j].acc_sum += vmax_num(v, (T)0);  // v >= 0 or NaN: max(v, 0) adds nothing for a NaN
         col[j].acc_cnt += v == v ? 1u : 0u;
+        return svj;
+      };
+      // pair A, its store, then pair B: two samples' temporaries alive at a time instead of four (147 -> <= 128 VGPRs)
+      {
+        const T s0 = one(0), s1 = one(1);
+        if (WRITE_SV) epa::store_nt2(sv_c + row_off + sA, s0, s1);
       }
-      if (WRITE_SV) {
-        epa::store_nt2(sv_c + row_off + sA, sv[0], sv[1]);
-        if (hasB) epa::store_nt2(sv_c + row_off + sB, sv[2], sv[3]);
+      if (hasB) {
+        const T s2 = one(2), s3 = one(3);
+        if (WRITE_SV) epa::store_nt2(sv_c + row_off + sB, s2, s3);
       }
       if (--left == 0) {  // (uniform) the ping block is complete
         flush(g);
