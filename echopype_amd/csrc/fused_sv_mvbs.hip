@@ -94,7 +94,7 @@ __device__ __forceinline__ double vmin_num(double a, double b) {
 // operand; the compiler otherwise copies the second one per sample).
 template <typename T, bool STATS>
 __device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::CoefRow& r, double r0v, T g, T a2,
-                                            T A0v, T nspread, double bin, double inv_bin, int n_rbins,
+                                            T A0v, T nL, T nspread, double bin, double inv_bin, int n_rbins,
                                             const double* tab, T* lsum, uint32_t* lcnt, double& xmax, double& xmin,
                                             unsigned& nnan) {
   const T NaN = epa::M<T>::nan();
@@ -110,8 +110,8 @@ __device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::
   const double rtd = x - r.shift;
   const T rt = (T)rtd;
   const bool pos = rtd > 0.0;
-  T s1 = fma(g, (T)raw, c.nL);
-  if (pos & !(c.nL > -(T)__builtin_inf()))  // rounding residue of R - shift (rare)
+  T s1 = fma(g, (T)raw, nL);
+  if (pos & !(nL > -(T)__builtin_inf()))  // rounding residue of R - shift (rare)
     s1 = fma(g, (T)raw, nspread * (log10_slow<T>(rt) - log10_slow<T>((T)(r.ra * r.rb))));
   s1 = pos ? s1 : NaN;
   const T sv = s1 + fma(a2, rt, A0v);
@@ -203,6 +203,10 @@ __global__ __launch_bounds__(epa::kBlock, RMAX ? 4 : EPA_FUSED_MIN_WAVES) void f
   uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + a.cnt_off);
   const epa::MathTabs mt = epa::build_math_tabs(smem + a.tab_off);  // synchronised below
   const double* tab = mt.exp2_tab;
+  // The statistics variant keeps a column's cached n log10(s - d) in LDS, every lane its own four entries (written
+  // and read by the same lane: no barrier), instead of eight registers: the five registers of the running {min, max,
+  // NaN count} then fit four wavefronts per SIMD without scratch.
+  __shared__ T col_nL[RMAX ? kChunk : 1];
 
   const int c = blockIdx.y, tb = a.xcd_map ? epa::xcd_contiguous(blockIdx.x, a.n_tbins) : (int)blockIdx.x;
   const int S = a.S, n_rbins = a.n_rbins;
@@ -238,6 +242,10 @@ __global__ __launch_bounds__(epa::kBlock, RMAX ? 4 : EPA_FUSED_MIN_WAVES) void f
     Column<T> col[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) col[j].init();
+    const int eA = wave * 256 + 2 * lane;  // the lane's entries of col_nL: eA, eA + 1, eA + 128, eA + 129
+    if (RMAX) {
+      col_nL[eA] = col_nL[eA + 1] = col_nL[eA + 128] = col_nL[eA + 129] = epa::M<T>::nan();
+    }
     double dcur = __builtin_nan(""), racur = __builtin_nan("");
     // software prefetch: the raw samples and the coefficient row of ping p+1 are requested before
     // ping p is processed, so their latency hides behind ~150 instructions of arithmetic (+8 %)
@@ -260,7 +268,9 @@ __global__ __launch_bounds__(epa::kBlock, RMAX ? 4 : EPA_FUSED_MIN_WAVES) void f
         racur = r.ra;
         for (int j = 0; j < VEC; ++j) {
           const double sj = (double)((j < 2 ? sA : sB) + (j & 1));
-          col[j].nL = nspread * log10_slow<T>((T)(sj - r.d));
+          const T nl = nspread * log10_slow<T>((T)(sj - r.d));
+          if (RMAX) col_nL[eA + (j < 2 ? 0 : 128) + (j & 1)] = nl;  // (the statistics variant: see col_nL)
+          else col[j].nL = nl;
           col[j].sra = sj * r.ra;
         }
       }
@@ -268,8 +278,8 @@ __global__ __launch_bounds__(epa::kBlock, RMAX ? 4 : EPA_FUSED_MIN_WAVES) void f
       T A0 = (T)r.A0;
       double r0v = r.r0;
       asm volatile("" : "+v"(A0), "+v"(r0v));  // one copy per ping into vector registers, not one per sample
-      const T sv0 = process_sample<T, RMAX>(col[0], inA.x, r, r0v, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax, xmin, nnan);
-      const T sv1 = process_sample<T, RMAX>(col[1], inA.y, r, r0v, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax, xmin, nnan);
+      const T sv0 = process_sample<T, RMAX>(col[0], inA.x, r, r0v, g, a2, A0, RMAX ? col_nL[eA] : col[0].nL, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax, xmin, nnan);
+      const T sv1 = process_sample<T, RMAX>(col[1], inA.y, r, r0v, g, a2, A0, RMAX ? col_nL[eA + 1] : col[1].nL, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax, xmin, nnan);
       if (WRITE_SV) {
 #ifndef EPA_PLAIN_STORES  // streaming (nt) stores: +2 % at 4 G samples, Sv is never re-read here
         epa::store_nt2(sv_c + row_off + sA, sv0, sv1);
@@ -279,8 +289,8 @@ __global__ __launch_bounds__(epa::kBlock, RMAX ? 4 : EPA_FUSED_MIN_WAVES) void f
 #endif
       }
       if (hasB) {
-        const T sv2 = process_sample<T, RMAX>(col[2], inB.x, r, r0v, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax, xmin, nnan);
-        const T sv3 = process_sample<T, RMAX>(col[3], inB.y, r, r0v, g, a2, A0, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax, xmin, nnan);
+        const T sv2 = process_sample<T, RMAX>(col[2], inB.x, r, r0v, g, a2, A0, RMAX ? col_nL[eA + 128] : col[2].nL, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax, xmin, nnan);
+        const T sv3 = process_sample<T, RMAX>(col[3], inB.y, r, r0v, g, a2, A0, RMAX ? col_nL[eA + 129] : col[3].nL, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax, xmin, nnan);
         if (WRITE_SV) {
 #ifndef EPA_PLAIN_STORES  // streaming (nt) stores: +2 % at 4 G samples, Sv is never re-read here
           epa::store_nt2(sv_c + row_off + sB, sv2, sv3);
