@@ -37,6 +37,7 @@ struct Args {
   unsigned cnt_off, tab_off;
   unsigned long long* rmax_key;
   unsigned long long* rstat;  // optional, with rmax_key: {min valid echo_range as a key, number of NaN echo_range values}
+  int xcd_map;  // ping blocks / time-bin groups dealt to the XCDs in contiguous eighths (epa::xcd_contiguous)
   unsigned long long* mm_keys;  // pass 2, optional [4]: min/max of Sv_noise, min/max of Sv_corrected
   int flagged_only;  // pass 2, general kernel after the uniform-group kernel: only the groups that one left (kLeftToGeneral)
   int uni_bins;      // pass 2, uniform-group kernel: time bins per workgroup
@@ -253,7 +254,8 @@ __global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 4 : 1) void sv_noise_
   // column and chunk) are then paid once per 40 pings instead of once per 20 (interleaved A/B on one box, 2 G samples:
   // 5.45 -> 5.27 ms with 2 blocks, 5.30 with 4: the larger footprint of a workgroup starts to cost what the fixed work
   // saves).  lsum / lcnt hold one row of range-block sums per ping block.
-  const int c = blockIdx.y, pbk0 = blockIdx.x * kP1Blocks;
+  // (the workgroups of one XCD walk one contiguous eighth of the ping blocks: epa::xcd_contiguous)
+  const int c = blockIdx.y, pbk0 = (a.xcd_map ? epa::xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x) * kP1Blocks;
   const int nb = min(kP1Blocks, a.n_pblocks - pbk0);
   const int S = a.S, Sb = a.n_rblocks;
   for (int i = threadIdx.x; i < kP1Blocks * Sb; i += epa::kBlock) {
@@ -691,7 +693,7 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_uniform_kernel
 
   // a workgroup takes a.uni_bins consecutive time bins (their pings are one run): the per-column constants are paid
   // once for all of them; lsum / lcnt hold one row of range bins per time bin
-  const int c = blockIdx.y, tb0 = blockIdx.x * a.uni_bins;
+  const int c = blockIdx.y, tb0 = (a.xcd_map ? epa::xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x) * a.uni_bins;
   const int nbn = min(a.uni_bins, a.n_tbins - tb0);
   const int S = a.S, n_rbins = a.n_rbins;
   const int pb = bin_start[tb0], pe = bin_start[tb0 + nbn], np = pe - pb;
@@ -899,7 +901,7 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
   __shared__ int differs;
   __shared__ unsigned long long rb_lo_key, rb_hi_key;
 
-  const int c = blockIdx.y, tb0 = blockIdx.x * a.uni_bins;
+  const int c = blockIdx.y, tb0 = (a.xcd_map ? epa::xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x) * a.uni_bins;
   const int nbn = min(a.uni_bins, a.n_tbins - tb0);
   const int S = a.S, n_rbins = a.n_rbins;
   const size_t cell0 = ((size_t)c * a.n_tbins + tb0) * n_rbins;
@@ -1284,6 +1286,7 @@ int epa_chain_fast_pass1(const float* raw, const double* coef, const double* alp
   a.ping_num = ping_num; a.rsn = rsn;
   a.n_pblocks = (P + ping_num - 1) / ping_num; a.n_rblocks = (S + rsn - 1) / rsn;
   a.noise_max = noise_max; a.rmax_key = rmax_key; a.rstat = rmax_key ? rstat : nullptr;
+  a.xcd_map = epa::xcd_map_enabled() ? 1 : 0;
   if (dtype == EPA_F64) return epa_chain::launch_pass1<double>(a, raw, coef, alpha2, sv_out, noise_out, C, st);
   return epa_chain::launch_pass1<float>(a, raw, coef, alpha2, sv_out, noise_out, C, st);
 }
@@ -1299,6 +1302,7 @@ int epa_chain_fast_pass2(const float* raw, const double* coef, const double* alp
   a.noise_ping_num = ping_num; a.n_pblocks = (P + ping_num - 1) / ping_num; a.snr = snr;
   a.n_tbins = n_tbins; a.n_rbins = n_rbins; a.range_bin = range_bin; a.inv_range_bin = 1.0 / range_bin;
   a.fill_value = fill_value; a.cnt_off = cnt_off; a.mm_keys = mm_keys;
+  a.xcd_map = epa::xcd_map_enabled() ? 1 : 0;
   if (dtype == EPA_F64)
     return epa_chain::launch_pass2<double>(a, raw, coef, alpha2, noise, bin_start, noise_out, corr_out, mvbs_out,
                                            sum_out, cnt_out, C, lds_acc_bytes, st);
