@@ -206,9 +206,10 @@ constexpr int kTwEntries = kSmallTw<F> ? 68 : 256;
 
 // first forward pass (sub-size 2048, radix 4, two butterflies per lane), on the lane's registers:
 // v[i] = sample j + 256 i.  tw = 256-entry table of w_2048^m.
-template <typename F, bool SMALL>
-__device__ __forceinline__ void fwd_pass0(C2<F> (&v)[8], const C2<F>* tw) {
-  const C2<F> wa = tw_any<F, SMALL>(tw, threadIdx.x);
+// wa = w_2048^j comes from the caller (read from the full table in global memory next to the lane's samples): the
+// LDS copy of the table is only published by correlate()'s first barrier, which lies behind this pass.
+template <typename F>
+__device__ __forceinline__ void fwd_pass0(C2<F> (&v)[8], C2<F> wa) {
   const F kH = (F)0.70710678118654752440;
   const C2<F> wb = C2<F>{(wa.re + wa.im) * kH, (wa.im - wa.re) * kH};  // w^(j+256) = w^j e^{-i pi/4}
   dft4(v[0], v[2], v[4], v[6]);
@@ -241,12 +242,15 @@ __device__ __forceinline__ void st8(unsigned char* xs, int a0, const C2<F> (&v)[
 // Circular correlation of the tile held as v[i] = x[j + 256 i] with the channel's replica (spectrum `spec` in
 // the digit-reversed order of the forward transform, conj and 1/N applied).  Result in v, same ownership.
 // Barriers: the caller guarantees nobody still reads xs on entry; on exit xs holds nothing of value.
-template <typename F>
+// `before_last_barrier` runs when the lane's registers are empty (the last wave-local pass is stored): the place to
+// request what the epilogue reads.
+template <typename F, typename Pre>
 __device__ __forceinline__ void correlate(C2<F> (&v)[8], unsigned char* xs, const C2<F>* tw,
-                                          const C2<F>* __restrict__ spec, const LaneMap& lm) {
+                                          const C2<F>* __restrict__ spec, const LaneMap& lm, C2<F> w_lane,
+                                          Pre&& before_last_barrier) {
   const int j = threadIdx.x;
   constexpr bool SMALL = kSmallTw<F>;
-  fwd_pass0<F, SMALL>(v, tw);
+  fwd_pass0<F>(v, w_lane);
 #pragma unroll
   for (int i = 0; i < 8; ++i) Xs<F>::st(xs, j + 256 * i, v[i]);
   __syncthreads();
@@ -280,6 +284,7 @@ __device__ __forceinline__ void correlate(C2<F> (&v)[8], unsigned char* xs, cons
   twiddle8<F, true>(v, tw_mul4<F, SMALL>(tw, lm.t1));
   idft8(v);
   st8<F, 64>(xs, lm.a1, v);
+  before_last_barrier();
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = Xs<F>::ld(xs, j + 256 * i);
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(epa::kBlock) void replica_prepare_kernel(const floa
   for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);  // ||tx||^2 (ek80_complex.py:372-391)
   if ((j & 63) == 0) red[j >> 6] = part;
   const LaneMap lm = lane_map();
-  fwd_pass0<double, false>(v, tw);
+  fwd_pass0<double>(v, tw[j]);
 #pragma unroll
   for (int i = 0; i < 8; ++i) Xs<double>::st(xs, j + 256 * i, v[i]);
   __syncthreads();
@@ -489,6 +494,70 @@ __device__ __forceinline__ void load_sample(const InT* __restrict__ re, const In
   v = C2<F>{sr, si};
 }
 
+// The same in two steps, for the fixed sector counts of the fast form: every request of a lane goes out before the
+// first value is looked at.  (load_sample's rare per-sector branch ends a basic block after every sample, and the
+// requests of the next sample were only issued behind it: two 16-byte loads in flight per wavefront, eight round trips
+// to memory per tile.)
+template <typename InT, int NB>
+struct RawSample {
+  static constexpr int kPer = 16 / sizeof(InT);
+  static constexpr int kVec = NB / kPer;
+  typedef InT vec_t __attribute__((ext_vector_type(kPer)));
+  vec_t r[kVec], i[kVec];
+};
+template <typename InT, int NB, bool INSIDE>
+__device__ __forceinline__ void fetch_sample(const InT* __restrict__ re, const InT* __restrict__ im, size_t ping_base,
+                                             int S, int s, RawSample<InT, NB>& raw) {
+  typedef typename RawSample<InT, NB>::vec_t vec_t;
+#pragma unroll
+  for (int q = 0; q < RawSample<InT, NB>::kVec; ++q) raw.r[q] = raw.i[q] = (vec_t)(InT)0;
+  if (INSIDE || s < S) {
+    const vec_t* pr = reinterpret_cast<const vec_t*>(re + ping_base + (size_t)s * NB);
+    const vec_t* pi = reinterpret_cast<const vec_t*>(im + ping_base + (size_t)s * NB);
+#pragma unroll
+    for (int q = 0; q < RawSample<InT, NB>::kVec; ++q) {
+      raw.r[q] = pr[q];
+      raw.i[q] = pi[q];
+    }
+  }
+}
+template <typename InT, typename F, int NB>
+__device__ __forceinline__ void sum_sample(const RawSample<InT, NB>& raw, bool inside, C2<F>& v, unsigned& m) {
+  constexpr int kPer = RawSample<InT, NB>::kPer;
+  InT vr[NB], vi[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    vr[b] = raw.r[b / kPer][b % kPer];
+    vi[b] = raw.i[b / kPer][b % kPer];
+  }
+  F fr = (F)vr[0], fi = (F)vi[0];
+#pragma unroll
+  for (int b = 1; b < NB; ++b) {
+    fr += (F)vr[b];
+    fi += (F)vi[b];
+  }
+  F sr = (F)0, si = (F)0;
+  m = 0;
+  if (__builtin_expect(fr == fr && fi == fi, 1)) {  // 2 NB numbers (a sample past the ping's end: 2 NB zeros)
+    sr = fr;
+    si = fi;
+    m = ((1u << NB) - 1u) | 0x100u;
+  } else {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const bool ok = (vr[b] == vr[b]) && (vi[b] == vi[b]);
+      if (ok) {
+        m |= 1u << b;
+        sr += (F)vr[b];
+        si += (F)vi[b];
+      }
+    }
+    if (vr[0] == vr[0]) m |= 0x100u;
+  }
+  if (!inside) m = 0;
+  v = C2<F>{sr, si};
+}
+
 __device__ __forceinline__ double sub_rn(double a, double b) {
   asm volatile("" : "+v"(a));
   return a - b;
@@ -498,6 +567,9 @@ __device__ __forceinline__ float sub_rn(float a, float b) {
   return a - b;
 }
 
+#ifndef EPA_FFT_TVG_EARLY
+#define EPA_FFT_TVG_EARLY 0
+#endif
 #ifndef EPA_FFT_WAVES_F32
 #define EPA_FFT_WAVES_F32 4
 #endif
@@ -544,6 +616,16 @@ __global__ __launch_bounds__(epa::kBlock) void tvg_table_kernel(const double* __
   }
 }
 
+// twiddle and logarithm tables, L2 -> LDS (published by correlate()'s first barrier)
+template <typename T, typename F>
+__device__ __forceinline__ void stage_tables(const FftArgs& a, C2<F>* tw, double2* log_tab) {
+  const int j = threadIdx.x;
+  const C2<F>* wtab = reinterpret_cast<const C2<F>*>(a.ws + (sizeof(F) == 4 ? ws_tw32() : ws_tw64()));
+  if (!kSmallTw<F>) tw[j] = wtab[j];
+  else if (j < 68) tw[j] = j < 64 ? wtab[4 * j] : wtab[j - 64];
+  if (sizeof(T) == 8 && j < epa::kLogTabN) log_tab[j] = reinterpret_cast<const double2*>(a.log_tab)[j];
+}
+
 template <typename InT, typename T, typename F, int NB, bool MIXED>
 __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, T>& L, const LaneMap& lm, int c, int p,
                                              int tile) {
@@ -557,20 +639,38 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
   const C2<F>* spec = reinterpret_cast<const C2<F>*>(a.ws + (sizeof(F) == 4 ? ws_spec32(a.C, c) : ws_spec64(a.C, c)));
   const unsigned full = (1u << B) - 1u;
 
+  // w_2048^j of the first pass, from the full table in the workspace (requested with the samples)
+  const C2<F> w_lane = reinterpret_cast<const C2<F>*>(a.ws + (sizeof(F) == 4 ? ws_tw32() : ws_tw64()))[j];
   // ---- the lane's eight samples: sector sums + validity bits
   C2<F> v[8];
   unsigned m[MIXED ? 8 : 1];
   unsigned vbits = 0;  // bit i: sample i has valid sectors; bit 8 + i: its beam-0 real part is valid
   unsigned mixed_l = 0;
   // (a tile that lies inside the ping -- all but the last one or two -- needs no per-sample bound test: block-uniform)
-  if (!MIXED && k_begin + kN <= S) {
+  if (!MIXED && NB > 0) {
+    constexpr int kBatch = sizeof(InT) == 4 ? 8 : 4;  // 64 registers of requested sectors per lane at a time
+    constexpr int kNB = NB > 0 ? NB : 4;
+    const bool inside = k_begin + kN <= S;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      unsigned mi;
-      load_sample<InT, F, NB, true>(re, im, ping_base, S, B, k_begin + j + 256 * i, -1, v[i], mi);
-      vbits |= ((mi & full) != 0u ? 1u : 0u) << i;
-      vbits |= ((mi >> 8) & 1u) << (8 + i);
-      mixed_l |= ((mi & full) != 0u && (mi & full) != full) ? 1u : 0u;
+    for (int b0 = 0; b0 < 8; b0 += kBatch) {
+      RawSample<InT, kNB> raw[kBatch];
+      if (inside) {
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i)
+          fetch_sample<InT, kNB, true>(re, im, ping_base, S, k_begin + j + 256 * (b0 + i), raw[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i)
+          fetch_sample<InT, kNB, false>(re, im, ping_base, S, k_begin + j + 256 * (b0 + i), raw[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < kBatch; ++i) {
+        unsigned mi;
+        sum_sample<InT, F, kNB>(raw[i], inside || k_begin + j + 256 * (b0 + i) < S, v[b0 + i], mi);
+        vbits |= ((mi & full) != 0u ? 1u : 0u) << (b0 + i);
+        vbits |= ((mi >> 8) & 1u) << (8 + b0 + i);
+        mixed_l |= ((mi & full) != 0u && (mi & full) != full) ? 1u : 0u;
+      }
     }
   } else {
 #pragma unroll
@@ -584,6 +684,10 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
     }
   }
 
+  // the tabulated time-varied gain of the lane's samples, requested inside correlate() (used when the ping has the
+  // table's numbers -- the usual case; 8 bytes per sample from L2)
+  const double* tvg_row = a.tvg + (size_t)c * (S + 4) + 4;
+  double tvg_early[(!MIXED && sizeof(T) == 8 && EPA_FFT_TVG_EARLY) ? 8 : 1];
   C2<F> y[MIXED ? 8 : 1];
   for (int only = -1;;) {
     if (MIXED) {
@@ -611,7 +715,17 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
       if (j == 0) L.nzw[32] = 0ull;
     }
     // correlate() publishes nzw / wflags (and, on the first tile, tw / log_tab) with its first barrier
-    correlate<F>(v, L.xs, L.tw, spec, lm);
+    correlate<F>(v, L.xs, L.tw, spec, lm, w_lane, [&]() {
+#if EPA_FFT_TVG_EARLY
+      if (!MIXED && sizeof(T) == 8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int s = k_begin + j + 256 * i;
+          tvg_early[i] = tvg_row[s < S ? s : S - 1];
+        }
+      }
+#endif
+    });
     const unsigned flags = L.wflags[0] | L.wflags[1] | L.wflags[2] | L.wflags[3];
     if (!MIXED && (flags & 1u)) {  // block-uniform: leave the tile to the per-sector pass
       if (j == 0) {
@@ -696,7 +810,8 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
       const double R = ((double)s * ra) * rb;  // range.py:138 operation order
       T tvg;
       if (tabulated) {  // (block-uniform)
-        tvg = (T)tvg_tab[s];
+        tvg = (!MIXED && sizeof(T) == 8 && EPA_FFT_TVG_EARLY) ? (T)tvg_early[(!MIXED && sizeof(T) == 8 && EPA_FFT_TVG_EARLY) ? i : 0]
+                                                              : (T)tvg_tab[s];
       } else {
         T rt = sub_rn((T)R, shift);  // never contracted with the range product into an fma
         if (!(rt > (T)0)) rt = epa::M<T>::nan();
@@ -765,12 +880,7 @@ void sv_complex_fft_kernel(FftArgs a) {
   const int j = threadIdx.x;
   if (MIXED && *a.mixed_cnt == 0u) return;  // the usual case: no tile was deferred
 
-  {
-    const C2<F>* wtab = reinterpret_cast<const C2<F>*>(a.ws + (sizeof(F) == 4 ? ws_tw32() : ws_tw64()));
-    if (!kSmallTw<F>) tw[j] = wtab[j];
-    else if (j < 68) tw[j] = j < 64 ? wtab[4 * j] : wtab[j - 64];
-  }
-  if (sizeof(T) == 8 && j < epa::kLogTabN) log_tab[j] = reinterpret_cast<const double2*>(a.log_tab)[j];
+  stage_tables<T, F>(a, tw, log_tab);
   const LaneMap lm = lane_map();
   const TileLds<F, T> L{xs, tw, nzw, wp, wflags, log_tab, sred};
   if (!MIXED) {
