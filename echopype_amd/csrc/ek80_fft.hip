@@ -383,7 +383,7 @@ __global__ __launch_bounds__(epa::kBlock) void replica_prepare_kernel(const floa
     ch[0] = (red[0] + red[1]) + (red[2] + red[3]);
     ch[1] = (double)(tap_lo < tap_hi ? tap_lo : 0);
     ch[2] = (double)tap_hi;
-    ch[3] = 0.0;
+    ch[3] = 1.0 / ch[0];  // (the epilogue of every tile used to divide)
   }
   ld8<double, 64>(xs, lm.a1, v);
   dft8(v);
@@ -568,7 +568,7 @@ __device__ __forceinline__ float sub_rn(float a, float b) {
 }
 
 #ifndef EPA_FFT_TVG_EARLY
-#define EPA_FFT_TVG_EARLY 0
+#define EPA_FFT_TVG_EARLY 2
 #endif
 #ifndef EPA_FFT_WAVES_F32
 #define EPA_FFT_WAVES_F32 4
@@ -639,6 +639,25 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
   const C2<F>* spec = reinterpret_cast<const C2<F>*>(a.ws + (sizeof(F) == 4 ? ws_spec32(a.C, c) : ws_spec64(a.C, c)));
   const unsigned full = (1u << B) - 1u;
 
+  // the ping's and the channel's numbers of the epilogue, read before anything is written: uniform addresses with no
+  // store in front of them become scalar loads into SGPRs (behind the barriers they were vector loads from L2 with the
+  // wavefront waiting on them at the start of its epilogue)
+  const size_t row = (size_t)c * a.P + p;
+  const double* cc = a.ccoef + row * EPA_NCCOEF;
+  const double ra = cc[EPA_CC_RA], rb = cc[EPA_CC_RB];
+  const double shift_d = cc[EPA_CC_SHIFT], alpha2_d = cc[EPA_CC_ALPHA2];
+  const T shift = (T)shift_d, alpha2 = (T)alpha2_d, Aadd = (T)cc[EPA_CC_A];
+  const T pscale = (T)(cc[EPA_CC_PSCALE]);
+  const T nspread = (T)a.nspread;
+  const double inv_norm = chan[3];  // 1 / ||replica||^2, divided once in replica_prepare_kernel
+  const double inv_norm_b = (NB == 4 || NB == 2 || NB == 1 || NB == 8) ? inv_norm * (1.0 / (double)(NB > 0 ? NB : 1))
+                                                                     : inv_norm / (double)B;  // (exact either way)
+  const int zr_lo = (int)chan[1], zr_hi = (int)chan[2];
+  const double* tkey = a.tvg + (size_t)c * (S + 4);
+  const double* tvg_tab = tkey + 4;
+  // (float output: the hardware logarithm is cheaper than the read -- measured; the table is not built then)
+  const bool tabulated = sizeof(T) == 8 && ((tkey[0] == ra) & (tkey[1] == rb) & (tkey[2] == shift_d) & (tkey[3] == alpha2_d));
+  const epa::LogCoef lk = epa::make_log_coef();
   // w_2048^j of the first pass, from the full table in the workspace (requested with the samples)
   const C2<F> w_lane = reinterpret_cast<const C2<F>*>(a.ws + (sizeof(F) == 4 ? ws_tw32() : ws_tw64()))[j];
   // ---- the lane's eight samples: sector sums + validity bits
@@ -716,7 +735,7 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
     }
     // correlate() publishes nzw / wflags (and, on the first tile, tw / log_tab) with its first barrier
     correlate<F>(v, L.xs, L.tw, spec, lm, w_lane, [&]() {
-#if EPA_FFT_TVG_EARLY
+#if EPA_FFT_TVG_EARLY == 1
       if (!MIXED && sizeof(T) == 8) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -748,7 +767,7 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
         if (j < 33) L.wp[j] = incl - cnt;  // exclusive prefix; wp[32] = total
       }
       __syncthreads();
-      const int lo = (int)chan[1], hi = (int)chan[2];
+      const int lo = zr_lo, hi = zr_hi;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int t = j + 256 * i;
@@ -770,21 +789,18 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
     }
   }
 
-  // ---- sector mean -> prx -> Sv/TS (calibrate_ek.py:483-490, 571-638)
-  const size_t row = (size_t)c * a.P + p;
-  const double* cc = a.ccoef + row * EPA_NCCOEF;
-  const double ra = cc[EPA_CC_RA], rb = cc[EPA_CC_RB];
-  const T shift = (T)cc[EPA_CC_SHIFT], alpha2 = (T)cc[EPA_CC_ALPHA2], Aadd = (T)cc[EPA_CC_A];
-  const T pscale = (T)(cc[EPA_CC_PSCALE]);
-  const T nspread = (T)a.nspread;
-  const double inv_norm = 1.0 / chan[0];
-  const double inv_norm_b = inv_norm / (double)B;  // every sector valid (the only case of the fast form)
-  const epa::LogCoef lk = epa::make_log_coef();
-  const double* tkey = a.tvg + (size_t)c * (S + 4);
-  const double* tvg_tab = tkey + 4;
-  // (float output: the hardware logarithm is cheaper than the read -- measured; the table is not built then)
-  const bool tabulated = sizeof(T) == 8 && ((tkey[0] == ra) & (tkey[1] == rb) & (tkey[2] == cc[EPA_CC_SHIFT]) &
-                                            (tkey[3] == cc[EPA_CC_ALPHA2]));
+  // ---- sector mean -> prx -> Sv/TS (calibrate_ek.py:483-490, 571-638); the ping's numbers were read up front
+#if EPA_FFT_TVG_EARLY == 2
+  // all eight table reads of the lane go out together (inside the per-sample branches below they were eight round
+  // trips to L2, one after the other)
+  if (!MIXED && sizeof(T) == 8 && tabulated) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int s = k_begin + j + 256 * i;
+      tvg_early[i] = tvg_row[s < S ? s : S - 1];
+    }
+  }
+#endif
   T* out = reinterpret_cast<T*>(a.out);
   T* range_out = reinterpret_cast<T*>(a.range_out);
   T* prx_out = reinterpret_cast<T*>(a.prx_out);
