@@ -9,6 +9,7 @@ grep -E "epa_|sv_complex|block_reduce|power_coef|noise|mvbs|edge_" $F/pmc_traffi
 cp $F/pmc_hot.csv profiles/r03_pmc_hot.csv
 (cat $F/pmc_hot.txt; echo "(pmc_hot.py volumes: chain / fused 4 x 100 000 x 2000 = 0.8 G samples per launch; FFT 2 x 5000 x 8192 = 81.92 M output samples per launch)") > profiles/r03_pmc_hot.txt
 cp $F/tests.txt profiles/r03_tests_gpu.txt
+[ -f $F/pmc_fft_stalls.csv ] && cp $F/pmc_fft_stalls.csv profiles/r03_pmc_fft_stalls.csv
 cp $F/hbm_traffic.json profiles/hbm_traffic.json   # carries the hash of the kernel sources it was measured on
 python - <<'PY'
 import json, sys

@@ -24,6 +24,7 @@ rocprofv3 --kernel-trace --stats -d $O/kt -o k --output-format csv -- python ben
 find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 find $O/kt -name "*kernel_trace.csv" -delete
 bash scripts/gpu_pmc_hot.sh all > $O/pmc_hot.txt 2>&1; cp gpurun_out/pmc_hot/summary.csv $O/pmc_hot.csv
+bash scripts/gpu_pmc_fft.sh > $O/pmc_fft.txt 2>&1; cp gpurun_out/pmc_fft/summary.csv $O/pmc_fft_stalls.csv
 python - <<'PY'
 import json
 for l in open("gpurun_out/final3/bench_default.jsonl"):
