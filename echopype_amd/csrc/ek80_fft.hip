@@ -41,6 +41,8 @@
 //     non-zero staged samples (wave ballots) and its prefix popcounts.
 //   * a tile holding a sample whose sectors are only PARTLY NaN (never seen in files, allowed by the
 //     reference) is redone one sector at a time (block-uniform branch).
+#include <type_traits>
+
 #include "fast_math.h"
 
 namespace {
@@ -505,15 +507,18 @@ struct RawSample {
   typedef InT vec_t __attribute__((ext_vector_type(kPer)));
   vec_t r[kVec], i[kVec];
 };
+// (re_ping / im_ping: the ping's first sample, a uniform address; the lane's part is a 32-bit byte offset, so the
+// requests take the scalar-base + 32-bit-offset form instead of a 64-bit address sum per request)
 template <typename InT, int NB, bool INSIDE>
-__device__ __forceinline__ void fetch_sample(const InT* __restrict__ re, const InT* __restrict__ im, size_t ping_base,
-                                             int S, int s, RawSample<InT, NB>& raw) {
+__device__ __forceinline__ void fetch_sample(const InT* __restrict__ re_ping, const InT* __restrict__ im_ping, int S,
+                                             int s, RawSample<InT, NB>& raw) {
   typedef typename RawSample<InT, NB>::vec_t vec_t;
 #pragma unroll
   for (int q = 0; q < RawSample<InT, NB>::kVec; ++q) raw.r[q] = raw.i[q] = (vec_t)(InT)0;
   if (INSIDE || s < S) {
-    const vec_t* pr = reinterpret_cast<const vec_t*>(re + ping_base + (size_t)s * NB);
-    const vec_t* pi = reinterpret_cast<const vec_t*>(im + ping_base + (size_t)s * NB);
+    const unsigned off = (unsigned)s * (unsigned)(NB * sizeof(InT));
+    const vec_t* pr = reinterpret_cast<const vec_t*>(reinterpret_cast<const char*>(re_ping) + off);
+    const vec_t* pi = reinterpret_cast<const vec_t*>(reinterpret_cast<const char*>(im_ping) + off);
 #pragma unroll
     for (int q = 0; q < RawSample<InT, NB>::kVec; ++q) {
       raw.r[q] = pr[q];
@@ -521,41 +526,28 @@ __device__ __forceinline__ void fetch_sample(const InT* __restrict__ re, const I
     }
   }
 }
+// the plain sector sum (a NaN in any sector makes it NaN: the caller then takes the per-sector rules)
 template <typename InT, typename F, int NB>
-__device__ __forceinline__ void sum_sample(const RawSample<InT, NB>& raw, bool inside, C2<F>& v, unsigned& m) {
+__device__ __forceinline__ C2<F> sum_plain(const RawSample<InT, NB>& raw) {
   constexpr int kPer = RawSample<InT, NB>::kPer;
-  InT vr[NB], vi[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    vr[b] = raw.r[b / kPer][b % kPer];
-    vi[b] = raw.i[b / kPer][b % kPer];
-  }
-  F fr = (F)vr[0], fi = (F)vi[0];
+  F fr = (F)raw.r[0][0], fi = (F)raw.i[0][0];
 #pragma unroll
   for (int b = 1; b < NB; ++b) {
-    fr += (F)vr[b];
-    fi += (F)vi[b];
+    fr += (F)raw.r[b / kPer][b % kPer];
+    fi += (F)raw.i[b / kPer][b % kPer];
   }
-  F sr = (F)0, si = (F)0;
-  m = 0;
-  if (__builtin_expect(fr == fr && fi == fi, 1)) {  // 2 NB numbers (a sample past the ping's end: 2 NB zeros)
-    sr = fr;
-    si = fi;
-    m = ((1u << NB) - 1u) | 0x100u;
-  } else {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const bool ok = (vr[b] == vr[b]) && (vi[b] == vi[b]);
-      if (ok) {
-        m |= 1u << b;
-        sr += (F)vr[b];
-        si += (F)vi[b];
-      }
-    }
-    if (vr[0] == vr[0]) m |= 0x100u;
-  }
-  if (!inside) m = 0;
-  v = C2<F>{sr, si};
+  return C2<F>{fr, fi};
+}
+// v_min_f64 / v_max_f64 as the hardware has them (clang's fmin / fmax first canonicalise both operands)
+__device__ __forceinline__ double vmax_num(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmin_num(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 
 __device__ __forceinline__ double sub_rn(double a, double b) {
@@ -658,13 +650,17 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
   // (float output: the hardware logarithm is cheaper than the read -- measured; the table is not built then)
   const bool tabulated = sizeof(T) == 8 && ((tkey[0] == ra) & (tkey[1] == rb) & (tkey[2] == shift_d) & (tkey[3] == alpha2_d));
   const epa::LogCoef lk = epa::make_log_coef();
-  // w_2048^j of the first pass, from the full table in the workspace (requested with the samples)
-  const C2<F> w_lane = reinterpret_cast<const C2<F>*>(a.ws + (sizeof(F) == 4 ? ws_tw32() : ws_tw64()))[j];
+  // w_2048^j of the first pass, from the full table in the workspace (requested behind the samples)
+  C2<F> w_lane;
+  const C2<F>* w_table = reinterpret_cast<const C2<F>*>(a.ws + (sizeof(F) == 4 ? ws_tw32() : ws_tw64()));
   // ---- the lane's eight samples: sector sums + validity bits
   C2<F> v[8];
   unsigned m[MIXED ? 8 : 1];
   unsigned vbits = 0;  // bit i: sample i has valid sectors; bit 8 + i: its beam-0 real part is valid
   unsigned mixed_l = 0;
+  // (wavefront-uniform) every sample of the wavefront inside the ping holds 2 B numbers: the epilogue without the NaN
+  // rules of partly or wholly missing samples
+  bool clean = !MIXED && NB > 0;
   // (a tile that lies inside the ping -- all but the last one or two -- needs no per-sample bound test: block-uniform)
   if (!MIXED && NB > 0) {
     constexpr int kBatch = sizeof(InT) == 4 ? 8 : 4;  // 64 registers of requested sectors per lane at a time
@@ -676,22 +672,44 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
       if (inside) {
 #pragma unroll
         for (int i = 0; i < kBatch; ++i)
-          fetch_sample<InT, kNB, true>(re, im, ping_base, S, k_begin + j + 256 * (b0 + i), raw[i]);
+          fetch_sample<InT, kNB, true>(re + ping_base, im + ping_base, S, k_begin + j + 256 * (b0 + i), raw[i]);
       } else {
 #pragma unroll
         for (int i = 0; i < kBatch; ++i)
-          fetch_sample<InT, kNB, false>(re, im, ping_base, S, k_begin + j + 256 * (b0 + i), raw[i]);
+          fetch_sample<InT, kNB, false>(re + ping_base, im + ping_base, S, k_begin + j + 256 * (b0 + i), raw[i]);
       }
+      if (b0 == 0) w_lane = w_table[j];
+      // One test per wavefront and batch instead of per-sample validity bits: the plain sums, and a ballot of "some
+      // sum is NaN" (a scalar OR per sample).  Only a wavefront that holds a NaN sector looks at its samples one by
+      // one (load_sample again: the lines are in L2).
+      unsigned long long nan_lanes = 0ull;
 #pragma unroll
       for (int i = 0; i < kBatch; ++i) {
-        unsigned mi;
-        sum_sample<InT, F, kNB>(raw[i], inside || k_begin + j + 256 * (b0 + i) < S, v[b0 + i], mi);
-        vbits |= ((mi & full) != 0u ? 1u : 0u) << (b0 + i);
-        vbits |= ((mi >> 8) & 1u) << (8 + b0 + i);
-        mixed_l |= ((mi & full) != 0u && (mi & full) != full) ? 1u : 0u;
+        v[b0 + i] = sum_plain<InT, F, kNB>(raw[i]);
+        nan_lanes |= __ballot(v[b0 + i].re != v[b0 + i].re || v[b0 + i].im != v[b0 + i].im);
+      }
+      if (__builtin_expect(nan_lanes == 0ull, 1)) {
+        if (inside) {
+          vbits |= (((1u << kBatch) - 1u) * 0x101u) << b0;
+        } else {
+#pragma unroll
+          for (int i = 0; i < kBatch; ++i)
+            vbits |= (k_begin + j + 256 * (b0 + i) < S ? 0x101u : 0u) << (b0 + i);
+        }
+      } else {
+        clean = false;
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+          unsigned mi;
+          load_sample<InT, F, NB>(re, im, ping_base, S, B, k_begin + j + 256 * (b0 + i), -1, v[b0 + i], mi);
+          vbits |= ((mi & full) != 0u ? 1u : 0u) << (b0 + i);
+          vbits |= ((mi >> 8) & 1u) << (8 + b0 + i);
+          mixed_l |= ((mi & full) != 0u && (mi & full) != full) ? 1u : 0u;
+        }
       }
     }
   } else {
+    w_lane = w_table[j];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       unsigned mi;
@@ -806,54 +824,66 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
   T* prx_out = reinterpret_cast<T*>(a.prx_out);
   double rmin = __builtin_inf(), rmax = -__builtin_inf();
   unsigned rnan = 0;
+  // the ping's rows of the outputs (uniform) + 32-bit offsets: scalar-base stores
+  T* out_ping = out + row * S;
+  T* range_ping = range_out ? range_out + row * S : nullptr;
+  T* prx_ping = prx_out ? prx_out + row * S : nullptr;
+  auto epilogue = [&](auto clean_tag) {
+    constexpr bool CLEAN = decltype(clean_tag)::value;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int t = j + 256 * i;
-    const int s = k_begin + t;
-    if (t < a.out_per_tile && s < S) {
-      const unsigned nvalid = MIXED ? __popc(m[MIXED ? i : 0] & full) : (((vbits >> i) & 1u) ? (unsigned)B : 0u);
-      const C2<F> yi = MIXED ? y[MIXED ? i : 0] : v[i];
-      T mr, mi;
-      if (nvalid == 0u) {
-        mr = mi = epa::M<T>::nan();
-      } else {
-        const double invn = MIXED ? inv_norm / (double)nvalid : inv_norm_b;
-        mr = (T)((double)yi.re * invn);
-        mi = (T)((double)yi.im * invn);
-      }
-      T prx = pscale * (mr * mr + mi * mi);
-      if (!(prx > (T)0)) prx = epa::M<T>::nan();
-      const double R = ((double)s * ra) * rb;  // range.py:138 operation order
-      T tvg;
-      if (tabulated) {  // (block-uniform)
-        tvg = (!MIXED && sizeof(T) == 8 && EPA_FFT_TVG_EARLY) ? (T)tvg_early[(!MIXED && sizeof(T) == 8 && EPA_FFT_TVG_EARLY) ? i : 0]
-                                                              : (T)tvg_tab[s];
-      } else {
-        T rt = sub_rn((T)R, shift);  // never contracted with the range product into an fma
-        if (!(rt > (T)0)) rt = epa::M<T>::nan();
-        tvg = nspread * epa::fast_log10_lean(rt, L.log_tab, lk) + alpha2 * rt;
-      }
-      // prx (and rt) are positive or NaN here: the lean log (zero / subnormal / inf / NaN through a rare branch)
-      // the range the reference calibrates with is the MASKED echo_range (NaN where beam 0 is, range.py:143-148): a
-      // sample whose beam 0 is missing is NaN even when its other sectors are valid (calibrate_ek.py:571-576)
-      const bool range_ok = ((vbits >> (8 + i)) & 1u) != 0u;
-      const T val = range_ok ? ((T)10 * epa::fast_log10_lean(prx, L.log_tab, lk) + tvg) + Aadd : epa::M<T>::nan();
-      const size_t o = row * S + s;
-      out[o] = val;
-      if (range_out || a.stats_part) {  // (statistics without the array: epa_range_complex writes it when asked for)
-        const bool ok = range_ok;
-        if (range_out) range_out[o] = ok ? (T)R : epa::M<T>::nan();
-        if (ok) {
-          const double rr = (double)(T)R;
-          rmin = fmin(rmin, rr);
-          rmax = fmax(rmax, rr);
+    for (int i = 0; i < 8; ++i) {
+      const int t = j + 256 * i;
+      const int s = k_begin + t;
+      if (t < a.out_per_tile && s < S) {
+        const unsigned nvalid = CLEAN ? (unsigned)B
+                                      : (MIXED ? __popc(m[MIXED ? i : 0] & full) : (((vbits >> i) & 1u) ? (unsigned)B : 0u));
+        const C2<F> yi = MIXED ? y[MIXED ? i : 0] : v[i];
+        T mr, mi;
+        if (!CLEAN && nvalid == 0u) {
+          mr = mi = epa::M<T>::nan();
         } else {
-          ++rnan;
+          const double invn = MIXED ? inv_norm / (double)nvalid : inv_norm_b;
+          mr = (T)((double)yi.re * invn);
+          mi = (T)((double)yi.im * invn);
         }
+        T prx = pscale * (mr * mr + mi * mi);
+        if (!(prx > (T)0)) prx = epa::M<T>::nan();
+        const double R = ((double)s * ra) * rb;  // range.py:138 operation order
+        T tvg;
+        if (tabulated) {  // (block-uniform)
+          tvg = (!MIXED && sizeof(T) == 8 && EPA_FFT_TVG_EARLY) ? (T)tvg_early[(!MIXED && sizeof(T) == 8 && EPA_FFT_TVG_EARLY) ? i : 0]
+                                                                : (T)tvg_tab[s];
+        } else {
+          T rt = sub_rn((T)R, shift);  // never contracted with the range product into an fma
+          if (!(rt > (T)0)) rt = epa::M<T>::nan();
+          tvg = nspread * epa::fast_log10_lean(rt, L.log_tab, lk) + alpha2 * rt;
+        }
+        // prx (and rt) are positive or NaN here: the lean log (zero / subnormal / inf / NaN through a rare branch)
+        // the range the reference calibrates with is the MASKED echo_range (NaN where beam 0 is, range.py:143-148): a
+        // sample whose beam 0 is missing is NaN even when its other sectors are valid (calibrate_ek.py:571-576)
+        const bool range_ok = CLEAN || ((vbits >> (8 + i)) & 1u) != 0u;
+        const T val = range_ok ? ((T)10 * epa::fast_log10_lean(prx, L.log_tab, lk) + tvg) + Aadd : epa::M<T>::nan();
+        const unsigned o = (unsigned)s;
+        out_ping[o] = val;
+        if (range_out || a.stats_part) {  // (statistics without the array: epa_range_complex writes it when asked for)
+          if (range_out) range_ping[o] = range_ok ? (T)R : epa::M<T>::nan();
+          const double rr = (double)(T)R;
+          if (CLEAN) {  // (rr is a number: the hardware minimum / maximum without the canonicalising copy)
+            rmin = vmin_num(rmin, rr);
+            rmax = vmax_num(rmax, rr);
+          } else if (range_ok) {
+            rmin = fmin(rmin, rr);
+            rmax = fmax(rmax, rr);
+          } else {
+            ++rnan;
+          }
+        }
+        if (prx_out) prx_ping[o] = prx;
       }
-      if (prx_out) prx_out[o] = prx;
     }
-  }
+  };
+  if (clean) epilogue(std::true_type{});
+  else epilogue(std::false_type{});
   if (a.stats_part) {  // {nanmin, nanmax, NaN count} of the echo_range written by this workgroup
     double cnt = (double)rnan;
 #pragma unroll
@@ -893,7 +923,6 @@ void sv_complex_fft_kernel(FftArgs a) {
   __shared__ unsigned wflags[4];
   __shared__ double2 log_tab[sizeof(T) == 8 ? epa::kLogTabN : 1];
   __shared__ double sred[12];
-  const int j = threadIdx.x;
   if (MIXED && *a.mixed_cnt == 0u) return;  // the usual case: no tile was deferred
 
   stage_tables<T, F>(a, tw, log_tab);
