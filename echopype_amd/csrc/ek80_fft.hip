@@ -786,14 +786,21 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
       }
       __syncthreads();
       const int lo = zr_lo, hi = zr_hi;
+      const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+      auto nz_before = [&](int n) {  // non-zero staged samples in [0, n)
+        return L.wp[n >> 6] + (unsigned)__popcll(L.nzw[n >> 6] & ((1ull << (n & 63)) - 1ull));
+      };
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int t = j + 256 * i;
-        if (t < a.out_per_tile) {
+        // (outputs past the ping's end are never stored; and when the samples COMMON to the 64 windows of the
+        // wavefront's outputs hold a non-zero one -- a scalar test -- no window is all zeros)
+        const int t0 = 256 * i + 64 * wave_u;
+        const int ua = t0 + 63 + lo, ub = min(t0 + hi, kN);
+        if (ua < ub && nz_before(ua) != nz_before(ub)) continue;
+        if (t < a.out_per_tile && k_begin + t < S) {
           const int ta = t + lo, tb = min(t + hi, kN);
-          const unsigned ca = L.wp[ta >> 6] + (unsigned)__popcll(L.nzw[ta >> 6] & ((1ull << (ta & 63)) - 1ull));
-          const unsigned cb = L.wp[tb >> 6] + (unsigned)__popcll(L.nzw[tb >> 6] & ((1ull << (tb & 63)) - 1ull));
-          if (ca == cb) v[i] = C2<F>{(F)0, (F)0};
+          if (nz_before(ta) == nz_before(tb)) v[i] = C2<F>{(F)0, (F)0};
         }
       }
     }
@@ -815,7 +822,7 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int s = k_begin + j + 256 * i;
-      tvg_early[i] = tvg_row[s < S ? s : S - 1];
+      tvg_early[i] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(tvg_row) + (unsigned)(s < S ? s : S - 1) * 8u);
     }
   }
 #endif
