@@ -244,12 +244,9 @@ __device__ __forceinline__ void st8(unsigned char* xs, int a0, const C2<F> (&v)[
 // Circular correlation of the tile held as v[i] = x[j + 256 i] with the channel's replica (spectrum `spec` in
 // the digit-reversed order of the forward transform, conj and 1/N applied).  Result in v, same ownership.
 // Barriers: the caller guarantees nobody still reads xs on entry; on exit xs holds nothing of value.
-// `before_last_barrier` runs when the lane's registers are empty (the last wave-local pass is stored): the place to
-// request what the epilogue reads.
-template <typename F, typename Pre>
+template <typename F>
 __device__ __forceinline__ void correlate(C2<F> (&v)[8], unsigned char* xs, const C2<F>* tw,
-                                          const C2<F>* __restrict__ spec, const LaneMap& lm, C2<F> w_lane,
-                                          Pre&& before_last_barrier) {
+                                          const C2<F>* __restrict__ spec, const LaneMap& lm, C2<F> w_lane) {
   const int j = threadIdx.x;
   constexpr bool SMALL = kSmallTw<F>;
   fwd_pass0<F>(v, w_lane);
@@ -286,7 +283,6 @@ __device__ __forceinline__ void correlate(C2<F> (&v)[8], unsigned char* xs, cons
   twiddle8<F, true>(v, tw_mul4<F, SMALL>(tw, lm.t1));
   idft8(v);
   st8<F, 64>(xs, lm.a1, v);
-  before_last_barrier();
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = Xs<F>::ld(xs, j + 256 * i);
@@ -430,13 +426,13 @@ struct FftArgs {
 
 // sector sum (or one sector when only >= 0) + validity bits of sample s (bits 0..B-1 sector valid, bit 8: beam-0
 // real part valid = the echo_range mask of range.py:143-146)
-template <typename InT, typename F, int NB, bool INSIDE = false>
+template <typename InT, typename F, int NB>
 __device__ __forceinline__ void load_sample(const InT* __restrict__ re, const InT* __restrict__ im, size_t ping_base,
                                             int S, int Brt, int s, int only, C2<F>& v, unsigned& m) {
   const int B = NB > 0 ? NB : Brt;
   F sr = (F)0, si = (F)0;
   m = 0;
-  if (INSIDE || s < S) {
+  if (s < S) {
     const InT* pr = re + ping_base + (size_t)s * B;
     const InT* pi = im + ping_base + (size_t)s * B;
     if (NB > 0) {
@@ -559,9 +555,6 @@ __device__ __forceinline__ float sub_rn(float a, float b) {
   return a - b;
 }
 
-#ifndef EPA_FFT_TVG_EARLY
-#define EPA_FFT_TVG_EARLY 2
-#endif
 #ifndef EPA_FFT_WAVES_F32
 #define EPA_FFT_WAVES_F32 4
 #endif
@@ -724,7 +717,8 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
   // the tabulated time-varied gain of the lane's samples, requested inside correlate() (used when the ping has the
   // table's numbers -- the usual case; 8 bytes per sample from L2)
   const double* tvg_row = a.tvg + (size_t)c * (S + 4) + 4;
-  double tvg_early[(!MIXED && sizeof(T) == 8 && EPA_FFT_TVG_EARLY) ? 8 : 1];
+  constexpr bool kTvgRegs = !MIXED && sizeof(T) == 8;
+  double tvg_early[kTvgRegs ? 8 : 1];
   C2<F> y[MIXED ? 8 : 1];
   for (int only = -1;;) {
     if (MIXED) {
@@ -752,17 +746,7 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
       if (j == 0) L.nzw[32] = 0ull;
     }
     // correlate() publishes nzw / wflags (and, on the first tile, tw / log_tab) with its first barrier
-    correlate<F>(v, L.xs, L.tw, spec, lm, w_lane, [&]() {
-#if EPA_FFT_TVG_EARLY == 1
-      if (!MIXED && sizeof(T) == 8) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int s = k_begin + j + 256 * i;
-          tvg_early[i] = tvg_row[s < S ? s : S - 1];
-        }
-      }
-#endif
-    });
+    correlate<F>(v, L.xs, L.tw, spec, lm, w_lane);
     const unsigned flags = L.wflags[0] | L.wflags[1] | L.wflags[2] | L.wflags[3];
     if (!MIXED && (flags & 1u)) {  // block-uniform: leave the tile to the per-sector pass
       if (j == 0) {
@@ -815,17 +799,15 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
   }
 
   // ---- sector mean -> prx -> Sv/TS (calibrate_ek.py:483-490, 571-638); the ping's numbers were read up front
-#if EPA_FFT_TVG_EARLY == 2
   // all eight table reads of the lane go out together (inside the per-sample branches below they were eight round
   // trips to L2, one after the other)
-  if (!MIXED && sizeof(T) == 8 && tabulated) {
+  if (kTvgRegs && tabulated) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int s = k_begin + j + 256 * i;
       tvg_early[i] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(tvg_row) + (unsigned)(s < S ? s : S - 1) * 8u);
     }
   }
-#endif
   T* out = reinterpret_cast<T*>(a.out);
   T* range_out = reinterpret_cast<T*>(a.range_out);
   T* prx_out = reinterpret_cast<T*>(a.prx_out);
@@ -858,8 +840,7 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
         const double R = ((double)s * ra) * rb;  // range.py:138 operation order
         T tvg;
         if (tabulated) {  // (block-uniform)
-          tvg = (!MIXED && sizeof(T) == 8 && EPA_FFT_TVG_EARLY) ? (T)tvg_early[(!MIXED && sizeof(T) == 8 && EPA_FFT_TVG_EARLY) ? i : 0]
-                                                                : (T)tvg_tab[s];
+          tvg = kTvgRegs ? (T)tvg_early[kTvgRegs ? i : 0] : (T)tvg_tab[s];
         } else {
           T rt = sub_rn((T)R, shift);  // never contracted with the range product into an fma
           if (!(rt > (T)0)) rt = epa::M<T>::nan();
