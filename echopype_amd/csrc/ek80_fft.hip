@@ -289,6 +289,178 @@ __device__ __forceinline__ void correlate(C2<F> (&v)[8], unsigned char* xs, cons
   inv_pass0<F, SMALL>(v, tw);
 }
 
+// ---- complex64: the same transform on (re, im) register pairs with the packed-f32 instructions of gfx950.
+// Left to the vectoriser, the scalar C2<float> code above becomes v_pk_* instructions glued together with moves and
+// sign flips (189 v_mov / v_pk_mov and 35 v_xor in a 703-instruction transform): the operand modifiers of VOP3P --
+// op_sel / op_sel_hi pick which half of a source feeds the low / high lane, neg_lo / neg_hi negate it -- do the
+// swaps and negations of complex arithmetic for free, but the compiler does not use them for f32 pairs.  Written out:
+// one instruction per complex add (also with a factor of -i or +i on the second operand), two per complex product,
+// 26 per radix-8 butterfly.  Same operations in the same order as the scalar templates (products then fused
+// multiply-adds, the 1/sqrt2 rotations fused into the following sum).
+namespace pk {
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define EPA_PK2(name, text)                                              \
+  __device__ __forceinline__ f2 name(f2 a, f2 b) {                       \
+    f2 r;                                                                \
+    asm(text : "=v"(r) : "v"(a), "v"(b));                                \
+    return r;                                                            \
+  }
+#define EPA_PK3(name, text)                                              \
+  __device__ __forceinline__ f2 name(f2 a, f2 b, f2 c) {                 \
+    f2 r;                                                                \
+    asm(text : "=v"(r) : "v"(a), "v"(b), "v"(c));                        \
+    return r;                                                            \
+  }
+EPA_PK2(add, "v_pk_add_f32 %0, %1, %2")
+EPA_PK2(sub, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]")
+// a + (-i) b = (a.re + b.im, a.im - b.re);  a + i b = (a.re - b.im, a.im + b.re)
+EPA_PK2(add_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")
+EPA_PK2(add_pi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")
+EPA_PK2(mul, "v_pk_mul_f32 %0, %1, %2")
+// (a.im b.im, a.im b.re) and (a.im b.im, a.re b.im): the first halves of a b and of a conj(b)
+EPA_PK2(mul_ii_ir, "v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]")
+EPA_PK2(mul_ii_ri, "v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]")
+// (a.re b.re - t.lo, a.re b.im + t.hi);  (a.re b.re + t.lo, a.im b.re - t.hi)
+EPA_PK3(fma_rr_ri, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]")
+EPA_PK3(fma_rr_ir, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_hi:[0,0,1]")
+EPA_PK3(fma, "v_pk_fma_f32 %0, %1, %2, %3")
+EPA_PK3(fnma, "v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]")  // c - a b
+#undef EPA_PK2
+#undef EPA_PK3
+__device__ __forceinline__ f2 cmul(f2 a, f2 b) { return fma_rr_ri(a, b, mul_ii_ir(a, b)); }
+__device__ __forceinline__ f2 conj(f2 a) { return f2{a.x, -a.y}; }
+
+__device__ __forceinline__ void dft4(f2& u0, f2& u1, f2& u2, f2& u3) {
+  const f2 s02 = add(u0, u2), d02 = sub(u0, u2), s13 = add(u1, u3), d13 = sub(u1, u3);
+  u0 = add(s02, s13);
+  u2 = sub(s02, s13);
+  u1 = add_mi(d02, d13);
+  u3 = add_pi(d02, d13);
+}
+__device__ __forceinline__ void idft4(f2& u0, f2& u1, f2& u2, f2& u3) {
+  const f2 s02 = add(u0, u2), d02 = sub(u0, u2), s13 = add(u1, u3), d13 = sub(u1, u3);
+  u0 = add(s02, s13);
+  u2 = sub(s02, s13);
+  u1 = add_pi(d02, d13);
+  u3 = add_mi(d02, d13);
+}
+template <bool INV>
+__device__ __forceinline__ void dft8(f2 (&v)[8], f2 kh) {
+  f2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+  if (INV) {
+    idft4(e0, e1, e2, e3);
+    idft4(o0, o1, o2, o3);
+  } else {
+    dft4(e0, e1, e2, e3);
+    dft4(o0, o1, o2, o3);
+  }
+  // forward: o1 e^{-i pi/4} = kh (o1 - i o1), o3 e^{-3i pi/4} = -kh (o3 + i o3); inverse: the conjugate factors
+  const f2 q1 = INV ? add_pi(o1, o1) : add_mi(o1, o1);
+  const f2 q3 = INV ? add_mi(o3, o3) : add_pi(o3, o3);
+  v[0] = add(e0, o0);
+  v[4] = sub(e0, o0);
+  v[1] = fma(q1, kh, e1);
+  v[5] = fnma(q1, kh, e1);
+  v[2] = INV ? add_pi(e2, o2) : add_mi(e2, o2);
+  v[6] = INV ? add_mi(e2, o2) : add_pi(e2, o2);
+  v[3] = fnma(q3, kh, e3);
+  v[7] = fma(q3, kh, e3);
+}
+__device__ __forceinline__ void twiddle8(f2 (&v)[8], f2 w1) {
+  const f2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+  v[1] = cmul(v[1], w1);
+  v[2] = cmul(v[2], w2);
+  v[3] = cmul(v[3], w3);
+  v[4] = cmul(v[4], w4);
+  v[5] = cmul(v[5], cmul(w4, w1));
+  v[6] = cmul(v[6], cmul(w3, w3));
+  v[7] = cmul(v[7], cmul(w4, w3));
+}
+__device__ __forceinline__ void twiddle4(f2& u1, f2& u2, f2& u3, f2 w1) {
+  const f2 w2 = cmul(w1, w1);
+  u1 = cmul(u1, w1);
+  u2 = cmul(u2, w2);
+  u3 = cmul(u3, cmul(w2, w1));
+}
+__device__ __forceinline__ f2 ld(const unsigned char* xs, int a) { return reinterpret_cast<const f2*>(xs)[pad(a)]; }
+__device__ __forceinline__ void st(unsigned char* xs, int a, f2 v) { reinterpret_cast<f2*>(xs)[pad(a)] = v; }
+template <int STRIDE>
+__device__ __forceinline__ void ld8(const unsigned char* xs, int a0, f2 (&v)[8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = ld(xs, a0 + STRIDE * r);
+}
+template <int STRIDE>
+__device__ __forceinline__ void st8(unsigned char* xs, int a0, const f2 (&v)[8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) st(xs, a0 + STRIDE * r, v[r]);
+}
+}  // namespace pk
+
+template <>
+__device__ __forceinline__ void correlate<float>(C2<float> (&vc)[8], unsigned char* xs, const C2<float>* tw,
+                                                 const C2<float>* __restrict__ spec, const LaneMap& lm,
+                                                 C2<float> w_lane) {
+  using pk::f2;
+  const int j = threadIdx.x;
+  const f2* twp = reinterpret_cast<const f2*>(tw);
+  const f2* specp = reinterpret_cast<const f2*>(spec);
+  const f2 kh = f2{0.70710678118654752440f, 0.70710678118654752440f};
+  f2 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = f2{vc[i].re, vc[i].im};
+  // first pass (sub-size 2048, radix 4, two butterflies per lane): w^(j + 256) = w^j e^{-i pi/4} = kh (w - i w)
+  const f2 wa = f2{w_lane.re, w_lane.im};
+  const f2 wb = pk::mul(pk::add_mi(wa, wa), kh);
+  pk::dft4(v[0], v[2], v[4], v[6]);
+  pk::twiddle4(v[2], v[4], v[6], wa);
+  pk::dft4(v[1], v[3], v[5], v[7]);
+  pk::twiddle4(v[3], v[5], v[7], wb);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) pk::st(xs, j + 256 * i, v[i]);
+  __syncthreads();
+  pk::ld8<64>(xs, lm.a1, v);
+  pk::dft8<false>(v, kh);
+  pk::twiddle8(v, twp[lm.t1]);
+  pk::st8<64>(xs, lm.a1, v);
+  __builtin_amdgcn_wave_barrier();  // (own wavefront's data: ordering for the compiler only)
+  pk::ld8<8>(xs, lm.a2, v);
+  f2 sp[8];  // the replica spectrum of the fused pass, requested early
+#pragma unroll
+  for (int r = 0; r < 8; ++r) sp[r] = specp[lm.a3 + r];
+  pk::dft8<false>(v, kh);
+  pk::twiddle8(v, twp[lm.t2]);
+  pk::st8<8>(xs, lm.a2, v);
+  __builtin_amdgcn_wave_barrier();
+  pk::ld8<1>(xs, lm.a3, v);
+  pk::dft8<false>(v, kh);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = pk::cmul(v[r], sp[r]);
+  pk::dft8<true>(v, kh);
+  pk::st8<1>(xs, lm.a3, v);
+  __builtin_amdgcn_wave_barrier();
+  pk::ld8<8>(xs, lm.a2, v);
+  pk::twiddle8(v, pk::conj(twp[lm.t2]));
+  pk::dft8<true>(v, kh);
+  pk::st8<8>(xs, lm.a2, v);
+  __builtin_amdgcn_wave_barrier();
+  pk::ld8<64>(xs, lm.a1, v);
+  pk::twiddle8(v, pk::conj(twp[lm.t1]));
+  pk::dft8<true>(v, kh);
+  pk::st8<64>(xs, lm.a1, v);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = pk::ld(xs, j + 256 * i);
+  // last pass: conjugate twiddles, then the inverse radix-4 butterflies
+  const f2 wl = twp[j];
+  const f2 wlb = pk::mul(pk::add_mi(wl, wl), kh);
+  pk::twiddle4(v[2], v[4], v[6], pk::conj(wl));
+  pk::idft4(v[0], v[2], v[4], v[6]);
+  pk::twiddle4(v[3], v[5], v[7], pk::conj(wlb));
+  pk::idft4(v[1], v[3], v[5], v[7]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) vc[i] = C2<float>{v[i].x, v[i].y};
+}
+
 // ---- workspace layout (doubles):
 //   [0, 512)            256 twiddles w_2048^m as double2
 //   [512, 768)          the same as float2
