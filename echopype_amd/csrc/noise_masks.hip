@@ -345,10 +345,14 @@ __global__ __launch_bounds__(kBlock) void box_range_scan_kernel(const T* __restr
     }
     const long long nrow = row + gridDim.x;
     if (nrow < rows) {
-      const T* svn = sv + (size_t)nrow * S + s0;
+      // every request of the lane in ONE basic block, by 32-bit offsets from the row's (uniform) address: behind a
+      // per-element bound test the compiler computed each address into the register pair of the value it replaces and
+      // waited for all earlier requests before doing so -- six round trips per row.  (A lane without an element reads
+      // the row's first one and ignores it.)
+      const char* svn = reinterpret_cast<const char*>(sv + (size_t)nrow * S + s0);
 #pragma unroll
       for (int j = 0; j < kPf; ++j)
-        if (src[j] >= 0) pf[j] = svn[src[j]];
+        pf[j] = *reinterpret_cast<const T*>(svn + (unsigned)max(src[j], 0) * (unsigned)sizeof(T));
     }
     __syncthreads();
     for (int v = threadIdx.x; v < nvirt; v += kBlock) {  // run totals
