@@ -1578,11 +1578,16 @@ __global__ __launch_bounds__(kBlock, 3) void pool_value_mean_staged_kernel(PoolV
     T d[kStageRows];
     unsigned feas = 0;
     double vmin = __builtin_inf(), vmax = -__builtin_inf();
+    // (the eight requests of the lane first, from clamped positions: tested one by one they went out one by one)
+    {
+      const T* col = a.range + ((size_t)(c * a.P + p0)) * a.S + min(s, a.S - 1);
+#pragma unroll
+      for (int r = 0; r < kStageRows; ++r) d[r] = col[(size_t)min(r, nrows - 1) * a.S];
+    }
 #pragma unroll
     for (int r = 0; r < kStageRows; ++r) {
-      d[r] = epa::M<T>::nan();
+      if (!(r < nrows && in_row)) d[r] = epa::M<T>::nan();
       if (r < nrows && in_row) {
-        d[r] = a.range[((size_t)(c * a.P + p0 + r)) * a.S + s];
         if (pool_feasible(a, d[r], p0 + r)) {
           feas |= 1u << r;
           vmin = fmin(vmin, (double)(d[r] - a.bin));
