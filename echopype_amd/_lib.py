@@ -57,6 +57,7 @@ _i64 = ctypes.c_int64
 SIGNATURES = {
     "epa_version": [],
     "epa_last_error": [],
+    "epa_launch_trace": [_i],
     "epa_device_count": [ctypes.POINTER(_i)],
     "epa_set_device": [_i],
     "epa_device_name": [_i, ctypes.c_char_p, _sz],
@@ -123,7 +124,21 @@ SIGNATURES = {
 for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here = the .so does not export a declared symbol
     _fn.argtypes = _args
-    _fn.restype = ctypes.c_char_p if _name == "epa_last_error" else _i
+    _fn.restype = ctypes.c_char_p if _name in ("epa_last_error", "epa_launch_trace") else _i
+
+
+class launch_trace:
+    """``with launch_trace() as t: ...; t.kernels`` -- the names of the kernels the calls inside launched (tests)."""
+
+    def __enter__(self):
+        lib.epa_launch_trace(1)
+        self.kernels = []
+        return self
+
+    def __exit__(self, *exc):
+        self.kernels = [k for k in lib.epa_launch_trace(2).decode().split(";") if k]
+        lib.epa_launch_trace(0)
+        return False
 
 
 def last_error() -> str:

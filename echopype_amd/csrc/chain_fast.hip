@@ -1073,6 +1073,9 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
     const unsigned have = hasB ? 0xfu : 0x3u;
     const unsigned off_plain = (~plain) & have;
     if (__ballot(off_plain != 0u) != 0ull) {
+      // the lanes still here are 0 .. nact - 1 (sA grows with the lane): in the row's last, partial wavefront only
+      // they exist to share the pings, so the stride is their number, not 64
+      const int nact = (int)__popcll(__ballot(true));
 #pragma unroll 1
       for (int j = 0; j < VEC; ++j) {
         unsigned long long todo = __ballot(((off_plain >> j) & 1u) != 0u);
@@ -1084,7 +1087,7 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
           const T v = (T)(sj - r.d), v2 = v * v;
           const T c2j = v > (T)0 ? (nspread == (T)20 ? v2 : v2 * v2) : (T)0;
           const T sn20j = (T)20 * log10_slow((T)sj, mt.log_tab);
-          for (int p = pb + lane; p < pe; p += 64) {
+          for (int p = pb + lane; p < pe; p += nact) {
             int g2 = 0;
             for (int t = 1; t < nbn; ++t) g2 += p >= bin_start[tb0 + t] ? 1 : 0;
             const size_t o = (size_t)p * S + sx;

@@ -32,7 +32,14 @@ void set_error(const char* fmt, ...);
     }                                                                                    \
   } while (0)
 
+// Launch trace (epa_launch_trace in echopype_amd.h): while it is on, every kernel launch notes its name -- the tests
+// assert WHICH kernel served a call (a specialised kernel silently declining a shape otherwise passes every
+// "fast == generic" comparison as generic == generic).
+extern bool g_trace_on;
+void note_launch(const char* what);
+
 inline int check_launch(const char* what) {
+  if (g_trace_on) note_launch(what);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("launch of %s failed: %s", what, hipGetErrorString(e));

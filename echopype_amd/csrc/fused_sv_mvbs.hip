@@ -576,6 +576,9 @@ __global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 6 : 8) void mvbs_of_s
     // the columns near a range-bin edge: one at a time, the lanes spread over the pings
     const unsigned loose = (~fixed) & (hasB ? 0xfu : 0x3u);
     if (__ballot(loose != 0u) != 0ull) {
+      // the lanes still here are 0 .. nact - 1 (sA grows with the lane): in the row's last, partial wavefront only
+      // they exist to share the pings, so the stride is their number, not 64
+      const int nact = (int)__popcll(__ballot(true));
 #pragma unroll 1
       for (int j = 0; j < VEC; ++j) {
         unsigned long long todo = __ballot(((loose >> j) & 1u) != 0u);
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 6 : 8) void mvbs_of_s
           const int src = __ffsll((long long)todo) - 1;
           todo &= todo - 1ull;
           const int sx = chunk0 + wave * 256 + 2 * src + (j < 2 ? 0 : 128) + (j & 1);
-          for (int p = pb + lane; p < pe; p += 64) {
+          for (int p = pb + lane; p < pe; p += nact) {
             const T v = epa::lin_from_db_lean(sv_c[(size_t)p * S + sx], tab);
             const double x = range_of(sx, rowp0[p].rb);
             const int rb = epa::range_bin_index(x, bin, inv_bin, n_rbins, false);

@@ -11,6 +11,17 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+bool g_trace_on = false;
+static thread_local char g_trace[2048] = "";
+static thread_local size_t g_trace_len = 0;
+void note_launch(const char* what) {
+  const size_t n = strlen(what);
+  if (g_trace_len + n + 2 > sizeof(g_trace)) return;  // full: the first launches are the ones kept
+  memcpy(g_trace + g_trace_len, what, n);
+  g_trace_len += n;
+  g_trace[g_trace_len++] = ';';
+  g_trace[g_trace_len] = 0;
+}
 }  // namespace epa
 
 struct EpaTimer {
@@ -21,6 +32,14 @@ extern "C" {
 
 int epa_version(void) { return EPA_VERSION; }
 const char* epa_last_error(void) { return epa::g_err; }
+const char* epa_launch_trace(int mode) {
+  if (mode == 1 || mode == 0) {  // start afresh / stop
+    epa::g_trace_on = mode == 1;
+    epa::g_trace_len = 0;
+    epa::g_trace[0] = 0;
+  }
+  return epa::g_trace;
+}
 
 int epa_device_count(int* n) {
   EPA_CHECK_ARG(n != nullptr, "epa_device_count: n is NULL");

@@ -83,17 +83,17 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
             r_cap = _shard.range_max(r_cap)
         r_cap = r_cap if r_cap > float("-inf") else float("nan")
     n_cap = len(np.arange(0, r_cap + range_bin_m, range_bin_m)) - 1 if np.isfinite(r_cap) else 0
-    if n_cap < 1:  # degenerate grid (one sample per ping, no valid range): the two calls deal with it
-        ds_Sv = _compute_cal("Sv", echodata, **cal_kw)
-        return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)
+    # degenerate grid (one sample per ping, no valid range) or a kernel that declines (e.g. a range grid too fine for the
+    # LDS accumulators): the two calls deal with it.  On a shard the fallback changes the collectives that follow, so
+    # the decision is taken ONCE, together, before any rank returns: every rank takes it if any rank must.
     res = None
-    try:
-        res = ops.sv_mvbs_fused(raw, coef, bin_start, n_t, range_bin_m, n_cap, cal_flags=flags, skipna=True,
-                                closed="left", fill_value=fill_value, dtype=cal.dtype, want_range_max=True,
-                                want_partials=_shard is not None)
-    except _lib.EpaError:  # e.g. a range grid too fine for the LDS accumulators: two calls instead
-        pass
-    # on a shard the fallback changes the collectives that follow: every rank takes it if any rank must
+    if n_cap >= 1:
+        try:
+            res = ops.sv_mvbs_fused(raw, coef, bin_start, n_t, range_bin_m, n_cap, cal_flags=flags, skipna=True,
+                                    closed="left", fill_value=fill_value, dtype=cal.dtype, want_range_max=True,
+                                    want_partials=_shard is not None)
+        except _lib.EpaError:
+            pass
     if (res is None) if _shard is None else _shard.agree(res is None):
         ds_Sv = _compute_cal("Sv", echodata, **cal_kw)
         return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)

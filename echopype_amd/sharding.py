@@ -243,20 +243,31 @@ class EdgeExchange:
 class ShardContext:
     """Keeps exchange plans between calls on the same layout (a plan costs two small all-reduces and host reads; a
     pipeline that calls the sharded functions once per file of a survey, or the bench once per step, builds it once).
-    ``plan()`` is collective: one scalar all-reduce(MIN) tells every rank whether ALL ranks hold the plan for their
-    key, so a rank whose layout changed can never run a different collective sequence from the others."""
+    A plan depends on EVERY rank's spans (slot groups, ``shared``, the owner flags), so the cache is keyed on the
+    global layout: ``plan()`` is collective -- one small all-reduce hands every rank the digests of all ranks' local
+    keys, and the tuple of them is the cache key.  Every rank therefore hits or misses together (a rank whose layout
+    changed makes all ranks rebuild; a rank that returns to an earlier layout finds a plan only if all the others are
+    on the layout they had then, too), and no rank can run a different collective sequence from the others."""
 
     def __init__(self, group=None):
         self.group = group
         self._plans = {}
 
+    def _global_key(self, key):
+        import hashlib
+
+        h = int.from_bytes(hashlib.blake2b(repr(key).encode(), digest_size=8).digest(), "little", signed=True)
+        if not _collective(self.group):
+            return (h,)
+        t = torch.zeros(_world(self.group), dtype=torch.int64)
+        t[_rank(self.group)] = h
+        t = t.to(_comm_device(self.group))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)  # (one non-zero term per element: a gather)
+        return tuple(int(v) for v in t.cpu().tolist())
+
     def plan(self, spans, C, R, device):
-        key = (tuple((int(f), int(l)) for f, l in spans), int(C), int(R), str(torch.device(device)))
-        hit = torch.tensor([1 if key in self._plans else 0], dtype=torch.int32)
-        if _collective(self.group):
-            hit = hit.to(_comm_device(self.group))
-            dist.all_reduce(hit, op=dist.ReduceOp.MIN, group=self.group)
-        if int(hit.item()) == 0:
+        key = self._global_key((tuple((int(f), int(l)) for f, l in spans), int(C), int(R), str(torch.device(device))))
+        if key not in self._plans:
             self._plans[key] = EdgeExchange(spans, C, R, device, self.group)
         return self._plans[key]
 

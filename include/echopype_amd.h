@@ -74,6 +74,11 @@ enum epa_coef_slot { EPA_CF_RA = 0, EPA_CF_RB = 1, EPA_CF_R0 = 2, EPA_CF_SHIFT =
 /* ---- runtime ------------------------------------------------------------------------------------ */
 int epa_version(void);
 const char* epa_last_error(void);
+/* Launch trace, test infrastructure: mode 1 clears the calling thread's trace and switches tracing on, mode 0 clears and
+ * switches it off, any other mode leaves it as it is.  Returns the "kernel;kernel;..." names of the launches this thread
+ * made since (2 KiB kept; the string is valid until the next call on the thread).  Lets a parity test assert WHICH
+ * kernel served a call -- the reference has no counterpart. */
+const char* epa_launch_trace(int mode);
 int epa_device_count(int* n);
 int epa_set_device(int dev);
 int epa_device_name(int dev, char* buf, size_t len);

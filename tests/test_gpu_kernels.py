@@ -604,16 +604,34 @@ def test_fused_chain_with_a_fine_range_grid(env):
     _chain_equivalence(env, "float64", "left", 83, 20, 20, 100000, S=1000, rbin=0.1)
 
 
+@pytest.mark.parametrize("S", [260, 2052, 1000])
+@pytest.mark.parametrize("rbin", [1.0, 0.07])
+def test_fused_chain_sound_speed_jitter_in_a_partial_last_wavefront(env, S, rbin):
+    """The sound-speed-drift pass 2 (chain_fast.hip: sv_denoise_mvbs_drift_kernel) redoes the columns whose range
+    crosses a range-bin edge inside the time bin with the wavefront's lanes spread over the PINGS.  S = 260 / 2052 leave
+    two lanes in the row's last wavefront: the pings must be shared among the lanes that exist (round-3 ADVICE: a
+    stride of 64 dropped the pings of the missing lanes).  8 m/s of jitter moves the far columns by metres."""
+    # time bins of 7 pings: the planner keeps bins of up to 8 pings whole (block_reduce.hip make_plan), which is what the
+    # specialised pass-2 kernels serve; the launch trace asserts they ran
+    _chain_equivalence(env, "float64", "left", 143, 20, 7, 1, S=S, rbin=rbin, ss_jitter=8.0,
+                       expect_kernels=("sv_denoise_mvbs_uniform_kernel", "sv_denoise_mvbs_drift_kernel"))
+
+
 def test_fused_chain_with_empty_time_bins(env):
     """A 130-s hole in the pings: time bins without a single ping between bins of uniform pings (the uniform-group
     pass 2 writes their fill value) -- and an all-NaN ping block in the noise estimate."""
     _chain_equivalence(env, "float64", "left", 140, 20, 20, 100000, S=512, gap_after=60)
 
 
-def _chain_equivalence(env, dtype, closed, P, pn, bin_s, ss_every, S=1000, gap_after=None, rbin=1.0):
+def _chain_equivalence(env, dtype, closed, P, pn, bin_s, ss_every, S=1000, gap_after=None, rbin=1.0, ss_jitter=0.0,
+                       expect_kernels=()):
+    from echopype_amd import _lib
     torch, ops, synth = env
     C = 2
     d = synth.ek60_numpy(C, P, S, ss_every=ss_every)
+    if ss_jitter:  # a recorded sound speed that moves by metres per second from ping to ping: a column's range then
+        # crosses range-bin edges inside a time bin (the columns the drift kernel redoes with its lanes over the pings)
+        d["sound_speed_indicative"] = d["sound_speed_indicative"] + ss_jitter * np.random.default_rng(5).random((1, P))
     if gap_after is not None:
         d["ping_time"] = d["ping_time"].copy()
         d["ping_time"][gap_after:] += np.timedelta64(130, "s")
@@ -659,7 +677,10 @@ def _chain_equivalence(env, dtype, closed, P, pn, bin_s, ss_every, S=1000, gap_a
                     raw, coef, a2, pn, 50, dtype=dt, noise_max=-120.0)[2], pn, 3.0, bs, n_t, rbin, n_r, closed=closed,
                     dtype=dt, want_noise=True))]
     for name, run in variants:
-        res = run()
+        with _lib.launch_trace() as tr:
+            res = run()
+        if name == "raw-fast":
+            assert all(k in tr.kernels for k in expect_kernels), tr.kernels
         got_n, exp_n0 = res["Sv_noise"].cpu().numpy(), sn0.cpu().numpy()
         if name == "coef":  # affine range: finite where the masked echo_range (and the reference's Sv_noise) is NaN
             got_n = np.where(np.isnan(exp_n0), np.nan, got_n)
@@ -737,31 +758,45 @@ def test_sv_complex_matches_reference_method_goldens(env, tag, wf, method):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("S", [1000, 2052, 260])
-def test_mvbs_of_sv_through_coefficient_rows_fast_kernel(env, dtype, S):
+@pytest.mark.parametrize("ss_jitter", [0.0, 8.0])
+def test_mvbs_of_sv_through_coefficient_rows_fast_kernel(env, dtype, S, ss_jitter):
     """epa_mvbs with coefficient rows in place of the range array (compute_MVBS after a lazy echo_range): the
-    specialised kernel == the generic reduction (EPA_NO_FAST_PATH) == the reduction on the echo_range array K1 writes
-    (EPA_BIN_RANGE_AS_STORED), partial sums and counts included; NaN Sv skipped, pings before the first edge and empty
-    time bins, range bins finer than a sample step."""
+    specialised kernels (mvbs_of_sv_fixed_kernel + mvbs_of_sv_rows_kernel, asserted through the launch trace) == the
+    generic reduction (EPA_NO_FAST_PATH) == the reduction on the echo_range array K1 writes (EPA_BIN_RANGE_AS_STORED),
+    partial sums and counts included; NaN Sv skipped, pings before the first edge and empty time bins, range bins finer
+    than a sample step.  ss_jitter: a sound speed that moves by metres per second from ping to ping, so that (nearly)
+    every column crosses range-bin edges inside a time bin -- the "loose" columns the fixed-bin kernel redoes with its
+    lanes over the pings, in S = 260 / 2052 by the TWO lanes of the row's last wavefront (round-3 ADVICE: a stride of 64
+    there dropped the pings of the lanes that do not exist).  Time bins of 7 pings: the planner keeps time bins of up to
+    8 pings whole (block_reduce.hip make_plan), which is what the specialised kernels serve."""
     import os
+    from echopype_amd import _lib
     torch, ops, synth = env
-    d = synth.ek60_numpy(3, 157, S, ss_every=5)
+    P = 157
+    d = synth.ek60_numpy(3, P, S, ss_every=5 if not ss_jitter else 1)
+    if ss_jitter:
+        d["sound_speed_indicative"] = d["sound_speed_indicative"] + ss_jitter * np.random.default_rng(11).random((1, P))
     d["backscatter_r"][1, 40:44] = np.nan
     cf = _coef_ek60(torch, ops, d, "Sv")
     dt = getattr(torch, dtype)
     sv, rng = ops.sv_power(_dev(torch, d["backscatter_r"]), cf, dtype=dt)
     ns = torch.from_numpy(d["ping_time"].astype("datetime64[ns]").astype(np.int64)).cuda()
     e0 = int(ns[7])                         # the first 7 pings lie before the first edge
-    n_t = 12
-    dtn = (int(ns[-1]) - e0) // 9 + 1       # the last three time bins are empty
+    n_t = 25
+    dtn = (int(ns[-1]) - e0) // 21 + 1      # 7 pings per time bin; the last three time bins are empty
     bs = ops.time_bin_offsets(ns, e0, dtn, n_t)
     for rbin in (1.0, 0.07):
         n_r = int(float(np.nanmax(rng.cpu().numpy())) / rbin) + 1
-        fast = ops.mvbs(sv, bs, n_t, rbin, n_r, coef=cf, coef_as_stored=True, want_partials=True)
+        with _lib.launch_trace() as tr:
+            fast = ops.mvbs(sv, bs, n_t, rbin, n_r, coef=cf, coef_as_stored=True, want_partials=True)
+        assert "mvbs_of_sv_fixed_kernel" in tr.kernels and "mvbs_of_sv_rows_kernel" in tr.kernels, tr.kernels
         os.environ["EPA_NO_FAST_PATH"] = "1"
         try:
-            slow = ops.mvbs(sv, bs, n_t, rbin, n_r, coef=cf, coef_as_stored=True, want_partials=True)
+            with _lib.launch_trace() as tr:
+                slow = ops.mvbs(sv, bs, n_t, rbin, n_r, coef=cf, coef_as_stored=True, want_partials=True)
         finally:
             del os.environ["EPA_NO_FAST_PATH"]
+        assert "mvbs_of_sv_fixed_kernel" not in tr.kernels, tr.kernels
         arr = ops.mvbs(sv, bs, n_t, rbin, n_r, range=rng, want_partials=True)
         for other in (slow, arr):
             np.testing.assert_array_equal(fast["cnt"].cpu().numpy(), other["cnt"].cpu().numpy())

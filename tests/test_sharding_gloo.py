@@ -335,3 +335,52 @@ def test_mvbs_shard_finish_kept_plan_and_collective_decision(P_total, split):
     assert [r[2] for r in res] == list(np.cumsum([0] + [r[3].shape[1] for r in res[:-1]]))
     np.testing.assert_allclose(got, exp, rtol=1e-12, equal_nan=True)
     assert all(r[4] for r in res)
+
+
+# ---- the plan cache is keyed on the GLOBAL layout (round-3 ADVICE) -----------------------------------------------------
+def _worker_plan_cache(rank, world, port, q):
+    """Rank 1 goes layout 1 -> 2 -> 1 while rank 0 stays on its own: a cache keyed on the local spans alone lets both
+    ranks 'hit' on the third call with plans built against different partners (mismatched ``shared`` -> one rank skips
+    the all-reduce and the job hangs, or wrong slot groups)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from echopype_amd import sharding
+
+    shard = sharding.ShardContext()
+    C, R = 2, 5
+    # rank 0 always holds bins 0..4; rank 1 holds 4..9 (bin 4 shared), then 5..9 (nothing shared), then 4..9 again
+    seq = [[(0, 4)], [(0, 4)], [(0, 4)], [(0, 4)]] if rank == 0 else [[(4, 9)], [(5, 9)], [(4, 9)], [(5, 9)]]
+    out = []
+    for step, spans in enumerate(seq):
+        plan = shard.plan(spans, C, R, "cpu")
+        rows = {}
+        for which in (0, 1):
+            rows[(0, which)] = (torch.full((C, R), float(10 * rank + which + 1), dtype=torch.float64),
+                                torch.full((C, R), 1.0, dtype=torch.float64))
+        tot = plan.merge(rows)
+        out.append((plan.shared, len(plan.edges), {k: float(v[0][0, 0]) for k, v in tot.items()}))
+    q.put((rank, out, len(shard._plans)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_plan_cache_is_keyed_on_every_ranks_layout():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_plan_cache, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0, r1 = res[0][1], res[1][1]
+    # steps 0 and 2: bin 4 is rank 0's LAST edge (value 2) and rank 1's FIRST edge (value 11): total 13 on both
+    for step in (0, 2):
+        assert r0[step] == (True, 1, {(0, 1): 13.0}) and r1[step] == (True, 1, {(0, 0): 13.0})
+    for step in (1, 3):  # nothing shared anywhere: no exchange on either rank
+        assert r0[step] == (False, 0, {}) and r1[step] == (False, 0, {})
+    assert res[0][2] == 2 and res[1][2] == 2  # two global layouts, two plans on every rank, both re-used
