@@ -58,6 +58,7 @@ SIGNATURES = {
     "epa_version": [],
     "epa_last_error": [],
     "epa_launch_trace": [_i],
+    "epa_last_range_stats_filled": [],
     "epa_device_count": [ctypes.POINTER(_i)],
     "epa_set_device": [_i],
     "epa_device_name": [_i, ctypes.c_char_p, _sz],
@@ -90,6 +91,7 @@ SIGNATURES = {
     "epa_selftest_log10_inline": [_vp, _vp, _sz, _vp],
     "epa_mvbs_finalize": [_vp, _vp, _sz, _d, _vp, _i, _vp],
     "epa_edge_pack": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "epa_edge_prepare_max": [_vp, _i, _vp],
     "epa_edge_gather": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "epa_edge_finalize_mvbs": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, _i, _vp],
     "epa_affine_rows": [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp],

@@ -39,11 +39,13 @@ class PowerSource:
     """What a deferred Sv/TS of power samples is made from (``LazyDeviceArray.source``): the raw samples, the
     coefficient rows, the kernel flags, and the lazy echo_range that travels with it."""
 
-    __slots__ = ("raw", "coef", "flags", "cal_type", "dtype", "echo_range", "raw_version")
+    __slots__ = ("raw", "coef", "flags", "cal_type", "dtype", "echo_range", "raw_version", "reach_bound")
 
-    def __init__(self, raw, coef, flags, cal_type, dtype, echo_range):
+    def __init__(self, raw, coef, flags, cal_type, dtype, echo_range, reach_bound=None):
         self.raw, self.coef, self.flags, self.cal_type, self.dtype = raw, coef, flags, cal_type, dtype
         self.echo_range, self.raw_version = echo_range, raw._version
+        # an upper bound of every echo_range the rows can produce, known on the HOST (None: reduce the rows on the device)
+        self.reach_bound = reach_bound
 
     def intact(self):
         """The raw samples have not been written to since compute_Sv looked at them."""
@@ -184,7 +186,7 @@ class CalibrateBase(abc.ABC):
         for the two calls instead of 12 + 8).  Same values either way (the kernels share the arithmetic)."""
         rng = self._lazy_power_range(raw, coef, flags)
         version, dtype = raw._version, self.dtype
-        src = PowerSource(raw, coef, flags, cal_type, dtype, rng)
+        src = PowerSource(raw, coef, flags, cal_type, dtype, rng, reach_bound=self._host_reach_bound(raw.shape[2]))
 
         def make():
             if raw._version != version:
@@ -206,6 +208,28 @@ class CalibrateBase(abc.ABC):
 
         rng.set_stats(None, hook=stats_with_sv)
         return sv, rng
+
+    def _host_reach_bound(self, S):
+        """An upper bound of every echo_range the EK coefficient rows can produce -- fl((S - 1) max sample_interval)
+        * (max sound_speed / 2), the row formula (range.py:138) at the two maxima -- from HOST copies of the two
+        parameters (host arrays, or the mirrors EchoData.to_device keeps; memoised there), so that sizing the range
+        grid costs neither a device reduction nor a wait for the GPU.  None when a parameter lives in HBM only."""
+        def hmax(v):
+            d = v.data if isinstance(v, DataArray) else None
+            if isinstance(d, DeviceArray):
+                return d.host_nanmax()
+            a = np.asarray(getattr(v, "values", v), dtype=np.float64)
+            with np.errstate(invalid="ignore"):
+                m = float(np.fmax.reduce(a, axis=None)) if a.size else float("nan")
+            return m if m == m else None
+
+        env, beam = getattr(self, "env_params", None), getattr(self, "beam", None)
+        if not env or beam is None or "sound_speed" not in env or "sample_interval" not in beam:
+            return None
+        si, cw = hmax(beam["sample_interval"]), hmax(env["sound_speed"])
+        if si is None or cw is None or not (np.isfinite(si) and np.isfinite(cw) and si > 0 and cw > 0):
+            return None
+        return float((S - 1) * si) * (cw / 2) * (1 + 1e-12)
 
     def _lazy_power_range(self, raw, coef, flags, stats=None):
         """echo_range of power samples as a LazyDeviceArray: coefficient rows + the raw samples' NaN pattern; written by

@@ -11,7 +11,8 @@ import torch
 
 from .. import _lib, ops
 from ..utils.prov import echopype_prov_attrs, insert_processing_level
-from ..xr_lite import DataArray, Dataset, DeviceArray, LazyDeviceArray, from_xarray, xarray_io
+from ..xr_lite import (DataArray, Dataset, DeferredDataset, DeviceArray, LazyDeviceArray, defer_mvbs_enabled, from_xarray,
+                       xarray_io)
 from .utils import (_parse_x_bin, _set_MVBS_attrs, _setup_and_validate, coarsen_time_mean, get_distance_from_latlon,
                     ping_time_bin_parsing_and_conversion, resample_edges)
 
@@ -81,12 +82,17 @@ def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="
     if not isinstance(ping_time_bin, str):
         raise TypeError("ping_time_bin must be a string")
 
-    sv_da = ds_Sv["Sv"]
     if _shard is None and skipna and closed == "left":
         # Sv still deferred by compute_Sv: written by THIS pass over the raw samples, next to the bins
         done = _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max)
         if done is not None:
             return done
+    return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, skipna, fill_value, closed, range_var_max, _shard)
+
+
+def _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, skipna, fill_value, closed, range_var_max, _shard):
+    """The binning of an existing Sv array (arguments validated by compute_MVBS)."""
+    sv_da = ds_Sv["Sv"]
     order = tuple(sv_da.dims)
     dim_0 = order[0]
     sv_t = _dev(sv_da)
@@ -151,7 +157,13 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
     the usual sequence -- one pass over the raw samples (``epa_sv_mvbs_fused``) writes that Sv array AND the bins: the two
     reference calls cost 12 B/sample instead of 12 + 8.  Returns the MVBS dataset, or None when the plain route has to
     run (Sv already written or replaced, another range variable, unsorted / NaT pings, a grid the fused kernel does not
-    serve); when the pass ran, its Sv array and range statistics stay with the dataset either way."""
+    serve); when the pass ran, its Sv array and range statistics stay with the dataset either way.
+
+    Nothing here waits for the GPU: the kernel runs on a conservative range grid (the farthest any coefficient row can
+    reach, bounded on the host from the host copies of sample_interval / sound_speed when there are any), leaves
+    {nanmin, nanmax, NaN count} of the echo_range in HBM, and the dataset that needs them -- the grid is
+    ``np.arange(0, nanmax + bin, bin)`` (api.py:108-115) -- is a ``DeferredDataset``: read back, trimmed and assembled
+    on first use."""
     sv_da, rng_da = ds_Sv["Sv"], ds_Sv[range_var]
     d = sv_da.data
     src = d.source if isinstance(d, LazyDeviceArray) and not d.materialized else None
@@ -165,12 +177,11 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
     if ns.size == 0 or np.any(ns[1:] < ns[:-1]) or ns[0] == np.iinfo(np.int64).min:
         return None
     e0, dt, n_t = resample_edges(ping_time, ping_time_bin, sorted_valid=True)
-    bin_start = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t)
     C, P, S = d.shape
-    # the grid is np.arange(0, nanmax(echo_range) + bin, bin) (api.py:108-115): run on a conservative one (the largest
-    # range any coefficient row can reach), take the statistics of the echo_range as a by-product, trim
     if range_var_max is not None:
         r_cap = _parse_x_bin(range_var_max) + 1e-8
+    elif getattr(src, "reach_bound", None) is not None:
+        r_cap = src.reach_bound  # host-side bound: no device reduction, no wait
     else:
         coef = src.coef
         reach = torch.nan_to_num((S - 1) * coef[..., _lib.CF_RA] * coef[..., _lib.CF_RB] + coef[..., _lib.CF_R0], nan=float("-inf"))
@@ -178,27 +189,34 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
     n_cap = len(np.arange(0, r_cap + range_bin_m, range_bin_m)) - 1 if np.isfinite(r_cap) else 0
     if n_cap < 1:
         return None
+    bin_start = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t)
     try:
         res = ops.sv_mvbs_fused(src.raw, src.coef, bin_start, n_t, range_bin_m, n_cap, cal_flags=src.flags, skipna=True,
                                 closed="left", fill_value=fill_value, dtype=src.dtype, want_range_stats=True)
     except _lib.EpaError:  # e.g. a range grid too fine for the LDS accumulators
         return None
+    # served by the generic kernel (a handful of pings, a grid beyond the LDS)?  It leaves no range statistics, which
+    # every later step asks for -- K1 does, on the plain route.  (Known on the host: epa_last_range_stats_filled.)
+    if not res["range_stats_filled"]:
+        return None
     rng = src.echo_range
-    lo, hi, n_nan_range = res["range_stats"].cpu().tolist()
-    if n_nan_range < 0:  # served by the generic kernel (a handful of pings, a grid beyond the LDS): it leaves no range
-        return None      # statistics, which every later step asks for -- K1 does, on the plain route
     d.fulfil(res["Sv"])
     rng.set_stats(res["range_stats"])
-    rmax = hi if range_var_max is None else r_cap
-    r_edges = np.arange(0, rmax + range_bin_m, range_bin_m) if np.isfinite(rmax) else np.zeros(1)
-    n_r = len(r_edges) - 1
-    if n_r < 1:  # no valid range / an empty grid: the plain route raises or returns what the reference would
-        return None
-    if n_nan_range > 0:
-        logging.warning(f"The ```{range_var}``` coordinate array contain NaNs. {_AGG_MSG}")
-    mvbs_t = res["MVBS"][..., :n_r].contiguous() if n_r != n_cap else res["MVBS"]
-    return _assemble_mvbs(ds_Sv, mvbs_t, "channel", ping_time, e0, dt, n_t, r_edges, range_var, range_bin_m,
-                          ping_time_bin, "left")
+
+    def build():
+        lo, hi, n_nan_range = res["range_stats"].cpu().tolist()
+        rmax = hi if range_var_max is None else r_cap
+        r_edges = np.arange(0, rmax + range_bin_m, range_bin_m) if np.isfinite(rmax) else np.zeros(1)
+        n_r = len(r_edges) - 1
+        if n_r < 1:  # no valid range / an empty grid: the plain route raises or returns what the reference would
+            return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, True, fill_value, "left", range_var_max, None)
+        if n_nan_range > 0:
+            logging.warning(f"The ```{range_var}``` coordinate array contain NaNs. {_AGG_MSG}")
+        mvbs_t = res["MVBS"][..., :n_r].contiguous() if n_r != n_cap else res["MVBS"]
+        return _assemble_mvbs(ds_Sv, mvbs_t, "channel", ping_time, e0, dt, n_t, r_edges, range_var, range_bin_m,
+                              ping_time_bin, "left")
+
+    return DeferredDataset(build) if defer_mvbs_enabled() else build()
 
 
 def _assemble_mvbs(ds_Sv, mvbs_t, dim_0, ping_time, e0, dt, n_t, r_edges, range_var, range_bin_m,

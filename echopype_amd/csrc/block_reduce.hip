@@ -766,6 +766,7 @@ static int fused_entry(const float* raw, const int16_t* raw_i16, const int32_t* 
   }
   const int rc = dtype == EPA_F64 ? run_mvbs<double, SRC_RAW>(a, (hipStream_t)stream)
                                   : run_mvbs<float, SRC_RAW>(a, (hipStream_t)stream);
+  epa::note_range_stats_filled(rc == EPA_OK && range_stats_out && a.range_stats_filled ? 1 : 0);
   if (rc == EPA_OK && range_max_out) {
     hipLaunchKernelGGL(decode_range_max_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, range_max_out);
     if (range_stats_out && a.range_stats_filled)
@@ -1004,6 +1005,7 @@ extern "C" int epa_sv_noise_fused(const float* raw, const double* coef, const do
                              sv_out, range_out, noise_out, range_max_out, range_stats_out, &filled, (hipStream_t)stream)
       : run_sv_noise<float>(raw, coef, alpha2, C, P, S, nspread, cal_flags, ping_num, range_sample_num, noise_max,
                             sv_out, range_out, noise_out, range_max_out, range_stats_out, &filled, (hipStream_t)stream);
+  epa::note_range_stats_filled(rc == EPA_OK && range_stats_out && filled ? 1 : 0);
   if (rc == EPA_OK && range_max_out) {
     hipLaunchKernelGGL(decode_range_max_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, range_max_out);
     if (range_stats_out && filled)  // (the fast kernel tracks the values as stored: no rounding left to do)

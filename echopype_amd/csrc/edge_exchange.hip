@@ -172,3 +172,19 @@ extern "C" int epa_edge_finalize_mvbs(const double* buf, int n_slots, const int3
   }
   return EPA_OK;
 }
+
+// The other cross-shard number that lives in HBM: nanmax(echo_range) of a shard, left by the fused kernel as NaN when
+// the shard holds no valid range.  all-reduce(MAX) is not defined on NaN: the operand is prepared here (NaN -> -inf),
+// the all-reduce runs in place on the RCCL group, ordered on the device behind the kernel -- no host wait.
+namespace {
+__global__ void nan_to_neg_inf_kernel(double* p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !(p[i] == p[i])) p[i] = -__builtin_inf();
+}
+}  // namespace
+
+extern "C" int epa_edge_prepare_max(double* values, int n, epa_stream_t stream) {
+  EPA_CHECK_ARG(values != nullptr && n > 0, "epa_edge_prepare_max: empty argument");
+  hipLaunchKernelGGL(nan_to_neg_inf_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, values, n);
+  return epa::check_launch("nan_to_neg_inf_kernel");
+}

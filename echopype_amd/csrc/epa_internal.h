@@ -37,6 +37,8 @@ void set_error(const char* fmt, ...);
 // "fast == generic" comparison as generic == generic).
 extern bool g_trace_on;
 void note_launch(const char* what);
+// epa_last_range_stats_filled (echopype_amd.h): did the last fused call on this thread leave the range statistics?
+void note_range_stats_filled(int filled);
 
 inline int check_launch(const char* what) {
   if (g_trace_on) note_launch(what);

@@ -22,6 +22,8 @@ void note_launch(const char* what) {
   g_trace[g_trace_len++] = ';';
   g_trace[g_trace_len] = 0;
 }
+static thread_local int g_stats_filled = 0;
+void note_range_stats_filled(int filled) { g_stats_filled = filled; }
 }  // namespace epa
 
 struct EpaTimer {
@@ -32,6 +34,7 @@ extern "C" {
 
 int epa_version(void) { return EPA_VERSION; }
 const char* epa_last_error(void) { return epa::g_err; }
+int epa_last_range_stats_filled(void) { return epa::g_stats_filled; }
 const char* epa_launch_trace(int mode) {
   if (mode == 1 || mode == 0) {  // start afresh / stop
     epa::g_trace_on = mode == 1;

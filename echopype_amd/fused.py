@@ -19,7 +19,7 @@ from .clean.utils import add_remove_background_noise_attrs, extract_dB
 from .commongrid.api import _assemble_mvbs, compute_MVBS
 from .commongrid.utils import _parse_x_bin, resample_edges
 from .utils.prov import echopype_prov_attrs, insert_processing_level
-from .xr_lite import DataArray, Dataset, DeviceArray, xarray_io
+from .xr_lite import DataArray, Dataset, DeferredDataset, DeviceArray, defer_mvbs_enabled, xarray_io
 
 
 @xarray_io()
@@ -75,13 +75,16 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
     # grid (largest range any row can reach), get nanmax(echo_range) back as a by-product, trim
     if range_var_max is not None:
         r_cap = _parse_x_bin(range_var_max) + 1e-8
-    else:  # reduced on the device: one scalar comes back instead of three columns of the coefficient rows
-        reach = (S - 1) * coef[..., _lib.CF_RA] * coef[..., _lib.CF_RB] + coef[..., _lib.CF_R0]
-        reach = torch.nan_to_num(reach, nan=float("-inf"))
-        r_cap = float(reach.max().item())
+    else:
+        r_cap = cal._host_reach_bound(S)  # from host copies of sample_interval / sound_speed: no wait for the GPU
+        if r_cap is None:  # parameters in HBM only: reduced on the device, one scalar comes back
+            reach = (S - 1) * coef[..., _lib.CF_RA] * coef[..., _lib.CF_RB] + coef[..., _lib.CF_R0]
+            reach = torch.nan_to_num(reach, nan=float("-inf"))
+            r_cap = float(reach.max().item())
+            r_cap = r_cap if r_cap > float("-inf") else float("nan")
         if _shard is not None:
             r_cap = _shard.range_max(r_cap)
-        r_cap = r_cap if r_cap > float("-inf") else float("nan")
+            r_cap = r_cap if r_cap > float("-inf") else float("nan")
     n_cap = len(np.arange(0, r_cap + range_bin_m, range_bin_m)) - 1 if np.isfinite(r_cap) else 0
     # degenerate grid (one sample per ping, no valid range) or a kernel that declines (e.g. a range grid too fine for the
     # LDS accumulators): the two calls deal with it.  On a shard the fallback changes the collectives that follow, so
@@ -97,18 +100,14 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
     if (res is None) if _shard is None else _shard.agree(res is None):
         ds_Sv = _compute_cal("Sv", echodata, **cal_kw)
         return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)
-    rmax = r_cap if range_var_max is not None else float(res["range_max"].item())
+    # nanmax(echo_range) stays in HBM: on a shard it is all-reduced (MAX) there, behind the kernel; the host reads it
+    # when the MVBS dataset is first used (DeferredDataset) -- nothing in this call waits for the GPU
+    rmax_t = res["range_max"]
     if _shard is not None and range_var_max is None:
-        rmax = _shard.range_max(rmax)
+        rmax_t = _shard.range_max_device(rmax_t)
     if _shard is not None:  # bins cut by a shard edge: totals over all ranks, reported by the lowest holder
         res["MVBS"], lo = _shard.finish(res, first_bin, last_bin, fill_value)
         e0, n_t = e0 + lo * dt, res["MVBS"].shape[1]
-    if not np.isfinite(rmax):  # no valid echo_range at all
-        ds_Sv = _compute_cal("Sv", echodata, **cal_kw)
-        return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)
-    r_edges = np.arange(0, rmax + range_bin_m, range_bin_m)
-    n_r = len(r_edges) - 1
-    mvbs_t = res["MVBS"][..., :n_r].contiguous() if n_r != n_cap else res["MVBS"]
 
     dims = ("channel", "ping_time", "range_sample")
     ds_Sv = Dataset(coords={k: cal.beam.coords[k] for k in dims})
@@ -123,9 +122,18 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
     ds_Sv = cal._add_params_to_output(ds_Sv)
     ds_Sv["echo_range"] = DataArray(cal._lazy_power_range(raw, coef, flags), dims)
     ds_Sv = _finalize_cal_ds(ds_Sv, "Sv", echodata, waveform_mode, encode_mode)
-    ds_MVBS = _assemble_mvbs(ds_Sv, mvbs_t, "channel", ping_time, e0, dt, n_t, r_edges, "echo_range", range_bin_m,
-                             ping_time_bin, "left")
-    return ds_Sv, ds_MVBS
+
+    def build():
+        rmax = r_cap if range_var_max is not None else float(rmax_t.item())
+        if not np.isfinite(rmax):  # no valid echo_range at all (on any rank): the reference's grid does not exist
+            raise ValueError("range bins are empty: the range variable holds no valid values")
+        r_edges = np.arange(0, rmax + range_bin_m, range_bin_m)
+        n_r = len(r_edges) - 1
+        mvbs_t = res["MVBS"][..., :n_r].contiguous() if n_r != n_cap else res["MVBS"]
+        return _assemble_mvbs(ds_Sv, mvbs_t, "channel", ping_time, e0, dt, n_t, r_edges, "echo_range", range_bin_m,
+                              ping_time_bin, "left")
+
+    return ds_Sv, (DeferredDataset(build) if defer_mvbs_enabled() else build())
 
 
 @xarray_io()

@@ -38,21 +38,96 @@ def torch_dtype(dtype):
     return td
 
 
+class _Uploader:
+    """Host -> HBM copies that never make the HOST wait for the GPU.
+
+    ``tensor.to(device)`` from pageable memory is a blocking copy on torch's current stream: it returns only after every
+    kernel queued before it has finished -- a dozen small parameter uploads per API call then serialise the host with
+    the previous call's 10-ms kernel.  Here the array is staged in a pinned buffer (a pool: hipHostMalloc is slow, the
+    buffers are re-used once the copy that read them has completed), copied on a dedicated upload stream
+    (``non_blocking``), and the CURRENT stream is made to wait for that copy ON THE DEVICE (an event): the host moves on
+    at once, kernels launched afterwards see the data.  One instance per device."""
+
+    _MAX_POOL = 64
+    _MAX_BYTES = 256 << 20  # larger arrays (bulk sample data) take the plain blocking copy: staging them twice costs more
+
+    def __init__(self, device):
+        self.device = device
+        self.stream = torch.cuda.Stream(device=device)
+        self.pool = []  # [pinned uint8 tensor, event of the last copy that read it]
+
+    def _staging(self, nbytes):
+        best = None
+        for slot in self.pool:
+            buf, ev = slot
+            if buf.numel() >= nbytes and (ev is None or ev.query()) and (best is None or buf.numel() < best[0].numel()):
+                best = slot
+        if best is None:
+            if len(self.pool) >= self._MAX_POOL:  # drop the smallest idle buffer
+                idle = [s_ for s_ in self.pool if s_[1] is None or s_[1].query()]
+                if idle:
+                    self.pool.remove(min(idle, key=lambda s_: s_[0].numel()))
+            best = [torch.empty(max(4096, 1 << (int(nbytes) - 1).bit_length()), dtype=torch.uint8, pin_memory=True), None]
+            self.pool.append(best)
+        return best
+
+    def upload(self, a):
+        """C-contiguous numpy array -> device tensor of the same shape / dtype, ordered before whatever the current
+        stream is given next."""
+        nbytes = a.nbytes
+        if nbytes == 0 or nbytes > self._MAX_BYTES:
+            w = a if a.flags.writeable else a.copy()
+            return torch.from_numpy(w).to(self.device)
+        slot = self._staging(nbytes)
+        staged = slot[0][:nbytes]
+        staged.numpy().view(np.uint8)[:] = a.reshape(-1).view(np.uint8)
+        tdt = torch.from_numpy(np.empty(0, dtype=a.dtype)).dtype
+        cur = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self.stream):
+            out = torch.empty(a.shape, dtype=tdt, device=self.device)
+            out.view(-1).view(torch.uint8).copy_(staged, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        slot[1] = ev
+        cur.wait_event(ev)
+        out.record_stream(cur)  # (allocated on the upload stream, used on the current one)
+        return out
+
+
+_uploaders = {}
+
+
+def _uploader(dev):
+    up = _uploaders.get(dev)
+    if up is None:
+        up = _uploaders[dev] = _Uploader(dev)
+    return up
+
+
 def to_device(a, dtype=None, device=None):
-    """numpy / torch -> contiguous CUDA tensor (PCIe copy if it lives on the host)."""
+    """numpy / torch -> contiguous CUDA tensor.  Host arrays go up through :class:`_Uploader` (pinned staging, upload
+    stream, a device-side wait): the call does not synchronise the host with the kernels already queued."""
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device(dev)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     if isinstance(a, torch.Tensor):
         t = a
-    else:
-        a = np.ascontiguousarray(a)
-        if not a.flags.writeable:  # e.g. a contiguous broadcast view: torch wants a writable buffer
-            a = a.copy()
-        t = torch.from_numpy(a)
-    if dtype is not None and t.dtype != dtype:
-        t = t.to(dtype)
-    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-    if not t.is_cuda:
-        t = t.to(dev, non_blocking=False)
-    return t.contiguous()
+        if dtype is not None and t.dtype != dtype:
+            t = t.to(dtype)
+        if not t.is_cuda:
+            t = _uploader(dev).upload(t.contiguous().numpy()) if dev.type == "cuda" else t.to(dev)
+        return t.contiguous()
+    a = np.ascontiguousarray(a)
+    if dtype is not None:
+        want = np.dtype(str(dtype).replace("torch.", ""))
+        if a.dtype != want:
+            a = a.astype(want)
+    if a.dtype.kind == "M":  # datetime64 -> its int64 representation
+        a = a.view(np.int64)
+    if dev.type != "cuda":
+        return torch.from_numpy(a if a.flags.writeable else a.copy()).to(dev)
+    return _uploader(dev).upload(a)
 
 
 def _mode_of(t, C, P):
@@ -178,7 +253,8 @@ def sv_mvbs_fused(raw, coef, bin_start, n_tbins, range_bin, n_rbins, *, cal_type
          _p(sv_out) if want_sv else None, _p(range_out) if want_range else None, _p(mvbs_out),
          _p(ssum), _p(cnt), _p(rmax), _p(rstats), _DT[dtype], _stream())
     return dict(Sv=sv_out if want_sv else None, echo_range=range_out if want_range else None,
-                MVBS=mvbs_out, sum=ssum, cnt=cnt, range_max=rmax, range_stats=rstats)
+                MVBS=mvbs_out, sum=ssum, cnt=cnt, range_max=rmax, range_stats=rstats,
+                range_stats_filled=bool(_lib.lib.epa_last_range_stats_filled()) if want_range_stats else False)
 
 
 def sv_mvbs_fused_i16(raw_i16, n_valid, coef, bin_start, n_tbins, range_bin, n_rbins, *, cal_type="Sv",
@@ -682,6 +758,14 @@ def edge_pack(buf, rows, zero_first=True):
     call("epa_edge_pack", sums, cnts, strides, slots, n, _DT[dt if dt is not None else torch.float64], C, R, n_slots,
          1 if zero_first else 0, _p(buf), _stream())
     return buf
+
+
+def edge_prepare_max(t):
+    """NaN -> -inf in place on an f64 device tensor about to be all-reduced with MAX."""
+    if t.dtype != torch.float64:
+        raise ValueError("edge_prepare_max: f64 device tensor expected")
+    call("epa_edge_prepare_max", _p(t), t.numel(), _stream())
+    return t
 
 
 def edge_gather(buf, group_off, group_slots, n_edges, *, typed=None):

@@ -50,6 +50,42 @@ def _comm_device(group=None):
     return torch.device("cpu")
 
 
+# ---- control plane: host-side agreements travel over gloo, never over the device streams ----------------------------
+# A collective on the RCCL group is ordered behind the kernels already queued on the device, and reading its result
+# makes the host wait for them: a handful of scalar agreements per call (time grid, layout digests, fallback decisions)
+# would serialise every rank's host with its own 10-ms kernels.  Those scalars are host values to begin with, so they go
+# over a gloo group of the same ranks (TCP / shared memory between the processes of one node, ~100 us each); RCCL over
+# xGMI carries what lives in HBM: the cut-bin (sum, count) rows and the range maximum.
+_control = {}
+
+
+def control_group(group=None):
+    """The gloo group that carries the host-side scalars of ``group`` (``group`` itself when it is a gloo group).
+    Created on first use -- ``dist.new_group`` is collective over the default group, so the first sharded call must be
+    made by every rank (it is: the entry points are collective anyway)."""
+    if not dist.is_initialized():
+        return None
+    world_pg = dist.distributed_c10d._get_default_group()
+    hit = _control.get(group)
+    if hit is not None and hit[0] is world_pg:
+        return hit[1]
+    if dist.get_backend(group) == "gloo":
+        ctl = group
+    else:
+        ranks = dist.get_process_group_ranks(group if group is not None else world_pg)
+        ctl = dist.new_group(ranks=ranks, backend="gloo")
+    _control[group] = (world_pg, ctl)
+    return ctl
+
+
+def _host_allreduce(values, op, group=None, dtype=torch.int64):
+    """All-reduce of a few host scalars over the control group -> list of Python numbers (no device stream involved)."""
+    t = torch.tensor(list(values), dtype=dtype)
+    if _collective(group):
+        dist.all_reduce(t, op=op, group=control_group(group))
+    return t.tolist()
+
+
 def shard_bounds(P_total, world, rank, align=1):
     """Contiguous ping block of ``rank``; block edges are multiples of ``align`` where possible."""
     per = -(-P_total // world)
@@ -65,14 +101,10 @@ def global_time_grid(local_ping_ns, dt_ns, group=None):
     times: all-reduce MIN of the first and MAX of the last valid timestamp (two int64)."""
     t = np.asarray(local_ping_ns, dtype=np.int64)
     t = t[t != np.iinfo(np.int64).min]
-    lo = torch.tensor([t.min() if t.size else np.iinfo(np.int64).max], dtype=torch.int64)
-    hi = torch.tensor([t.max() if t.size else np.iinfo(np.int64).min + 1], dtype=torch.int64)
-    if _collective(group):
-        dev = _comm_device(group)
-        lo, hi = lo.to(dev), hi.to(dev)
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
-    first, last = int(lo.item()), int(hi.item())
+    lo = int(t.min()) if t.size else np.iinfo(np.int64).max
+    hi = int(t.max()) if t.size else np.iinfo(np.int64).min + 1
+    first, neg_last = _host_allreduce([lo, -hi], dist.ReduceOp.MIN, group)  # (one message: max = -min of the negation)
+    last = -neg_last
     day = 86400 * 10**9
     origin = (first // day) * day
     e0 = origin + ((first - origin) // dt_ns) * dt_ns
@@ -82,11 +114,25 @@ def global_time_grid(local_ping_ns, dt_ns, group=None):
 def global_max(value, group=None):
     """all-reduce MAX of one float (e.g. nanmax(echo_range) for the range grid, api.py:110); NaN = nothing here."""
     v = float(value)
-    t = torch.tensor([v if v == v else -np.inf], dtype=torch.float64)
-    if _collective(group):
-        t = t.to(_comm_device(group))
+    return float(_host_allreduce([v if v == v else -np.inf], dist.ReduceOp.MAX, group, dtype=torch.float64)[0])
+
+
+def global_max_device(t, group=None):
+    """The same maximum for a number that still lives in HBM (a 1-element f64 device tensor a kernel is about to fill;
+    NaN = nothing here): all-reduce MAX in place on the DATA group, ordered on the device behind the kernel -- the host
+    does not wait; whoever reads the tensor later finds the global value.  (gloo dry runs stage it through the host.)"""
+    if not _collective(group):
+        return t
+    from . import ops
+
+    ops.edge_prepare_max(t)
+    if _comm_device(group).type == "cuda":
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-    return float(t.item())
+    else:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+        t.copy_(h)
+    return t
 
 
 def local_bin_span(local_ping_ns, e0, dt_ns, closed="left"):
@@ -130,23 +176,18 @@ class EdgeExchange:
         self.device = torch.device(device)
         self.key = (tuple((int(f), int(l)) for f, l in spans), self.C, self.R, str(self.device))
         world, rank = _world(group), _rank(group)
-        nseg = torch.tensor([len(spans)], dtype=torch.int64)
-        if _collective(group):
-            nseg = nseg.to(_comm_device(group))
-            dist.all_reduce(nseg, op=dist.ReduceOp.MAX, group=group)
-        self.max_seg = int(nseg.item())
+        self.max_seg = int(_host_allreduce([len(spans)], dist.ReduceOp.MAX, group)[0])
         ids = np.full((world, self.max_seg, 2), NO_BIN, dtype=np.int64)
         for k, (f, l) in enumerate(spans):
             if l >= f:
                 ids[rank, k, 0] = f
                 if l != f:
                     ids[rank, k, 1] = l
-        if _collective(group):  # every rank fills its own rows, the others are 0 after the shift
+        if _collective(group):  # every rank fills its own rows, the others are 0 after the shift (host scalars: control group)
             t = torch.zeros((world, self.max_seg, 2), dtype=torch.int64)
             t[rank] = torch.from_numpy(ids[rank] - NO_BIN)
-            t = t.to(_comm_device(group))
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-            ids = t.cpu().numpy() + NO_BIN
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=control_group(group))
+            ids = t.numpy() + NO_BIN
         flat = ids.reshape(-1)  # slot = (rank * max_seg + segment) * 2 + which
         self.n_slots = flat.size
         groups = {}
@@ -261,9 +302,8 @@ class ShardContext:
             return (h,)
         t = torch.zeros(_world(self.group), dtype=torch.int64)
         t[_rank(self.group)] = h
-        t = t.to(_comm_device(self.group))
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)  # (one non-zero term per element: a gather)
-        return tuple(int(v) for v in t.cpu().tolist())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=control_group(self.group))  # (one non-zero term per element: a gather)
+        return tuple(int(v) for v in t.tolist())
 
     def plan(self, spans, C, R, device):
         key = self._global_key((tuple((int(f), int(l)) for f, l in spans), int(C), int(R), str(torch.device(device))))
@@ -274,11 +314,7 @@ class ShardContext:
     def agree(self, flag):
         """True on every rank if ``flag`` is true on any (all-reduce MAX of one int): decisions that change the
         sequence of collectives that follows (a fallback after a rank-local error) are taken together."""
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
-        if _collective(self.group):
-            t = t.to(_comm_device(self.group))
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        return bool(int(t.item()))
+        return bool(_host_allreduce([1 if flag else 0], dist.ReduceOp.MAX, self.group)[0])
 
 
 # ---- MVBS time bins ----------------------------------------------------------------------------------------------
@@ -368,6 +404,9 @@ class MVBSShard(ShardContext):
 
     def range_max(self, hi):
         return global_max(hi, self.group)
+
+    def range_max_device(self, t):
+        return global_max_device(t, self.group)
 
     def finish(self, res, first_bin, last_bin, fill_value):
         """Merged, finalised MVBS of the bins this rank reports: (tensor (C, n_kept, R), index of the first kept

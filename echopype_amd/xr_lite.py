@@ -19,17 +19,18 @@ try:  # pragma: no cover - not installed in the build image
 except Exception:  # noqa: BLE001
     _xr = None
 
-__all__ = ["DeviceArray", "LazyDeviceArray", "DataArray", "Dataset", "from_xarray", "is_device", "is_xarray", "to_xarray", "xarray_io"]
+__all__ = ["DeviceArray", "LazyDeviceArray", "DataArray", "Dataset", "DeferredDataset", "from_xarray", "is_device", "is_xarray", "to_xarray", "xarray_io"]
 
 
 class DeviceArray:
     """An array resident in GPU memory (wraps a torch CUDA tensor).  C-contiguous except for lazily transposed
     views (the impulse-noise mask); whoever hands the buffer to a kernel asks for ``.contiguous()`` first."""
 
-    __slots__ = ("tensor", "_stats", "_host")
+    __slots__ = ("tensor", "_stats", "_host", "_hmax")
 
     def __init__(self, tensor, stats=None, host=None):
         self.tensor = tensor
+        self._hmax = None
         # optional host copy the tensor was uploaded from (small parameter arrays, EchoData.to_device): host-side
         # decisions read it instead of copying the array back; void once the tensor has been modified in place
         self._host = (host, tensor._version) if host is not None else None
@@ -43,6 +44,20 @@ class DeviceArray:
             return None
         lo, hi, nn = self._stats[0].cpu().tolist()
         return lo, hi, int(nn)
+
+    def host_nanmax(self):
+        """nanmax of the array taken from its host copy -- None without one (or when nothing is finite).  Memoised while
+        the tensor is untouched: a host-side bound (how far can any echo_range reach?) then costs neither a device
+        reduction nor a wait for the GPU."""
+        if self._host is None or self._host[1] != self.tensor._version:
+            return None
+        if self._hmax is None or self._hmax[1] != self.tensor._version:
+            a = self._host[0]
+            with np.errstate(invalid="ignore"):
+                m = float(np.fmax.reduce(a, axis=None)) if a.size else float("nan")
+            self._hmax = (m, self.tensor._version)
+        m = self._hmax[0]
+        return m if m == m else None
 
     @property
     def shape(self):
@@ -87,6 +102,7 @@ class LazyDeviceArray(DeviceArray):
     def __init__(self, shape, dtype, device, make, stats=None, rows=None, nan_where=None, source=None):
         self._make, self._shape, self._tdtype, self._device = make, tuple(int(n) for n in shape), dtype, device
         self._tensor = None
+        self._hmax = None
         self._made_version = None  # tensor._version right after make(): any later in-place write voids rows and stats
         self._host = None
         self._stats = (stats, 0) if stats is not None else None
@@ -426,6 +442,49 @@ class Dataset:
         lines += [f"  coord {k}: {c.shape} {c.dtype}" for k, c in self.coords.items()]
         lines += [f"  {v!r}" for v in self.data_vars.values()]
         return "\n".join(lines)
+
+
+class DeferredDataset(Dataset):
+    """A Dataset whose assembly waits for its first use (the analogue of a dask-backed result of the reference).
+
+    ``compute_MVBS`` right after ``compute_Sv`` launches ONE kernel that writes the Sv array and the bins; the shape of
+    the result -- ``np.arange(0, nanmax(echo_range) + bin, bin)`` (commongrid/api.py:108-115) -- depends on a number
+    that kernel produces.  Waiting for it inside the call would stall the host for the ~10 ms the kernel runs; instead
+    the call returns this object at once, and ``build()`` (read the three statistics back, trim the grid, attach
+    coordinates / attributes) runs when anybody touches it: ``.coords``, ``.data_vars``, ``.attrs``, ``ds["Sv"]``,
+    ``.sizes``, ``repr`` ...  A pipeline that calibrates file k + 1 before it looks at the MVBS of file k keeps the GPU
+    busy back to back.  Errors and warnings the assembly raises (an empty range grid, NaN coordinates) surface at that
+    first use.  ``EPA_DEFER_MVBS=0`` makes the calls assemble before they return."""
+
+    def __init__(self, build):  # (Dataset.__init__ is not run: the three containers are the built dataset's)
+        self.__dict__["_build"] = build
+        self.__dict__["_ds"] = None
+
+    def _resolve(self):
+        d = self.__dict__
+        if d["_ds"] is None:
+            build, d["_build"] = d["_build"], None
+            if build is None:
+                raise RuntimeError("the assembly of this dataset failed earlier")
+            d["_ds"] = build()
+        return d["_ds"]
+
+    @property
+    def resolved(self):
+        return self.__dict__["_ds"] is not None
+
+    coords = property(lambda self: self._resolve().coords, lambda self, v: setattr(self._resolve(), "coords", v))
+    data_vars = property(lambda self: self._resolve().data_vars, lambda self, v: setattr(self._resolve(), "data_vars", v))
+    attrs = property(lambda self: self._resolve().attrs, lambda self, v: setattr(self._resolve(), "attrs", v))
+
+    def __repr__(self):
+        return Dataset.__repr__(self._resolve())
+
+
+def defer_mvbs_enabled():
+    import os
+
+    return os.environ.get("EPA_DEFER_MVBS", "1") != "0"
 
 
 def from_xarray(obj):

@@ -79,6 +79,10 @@ const char* epa_last_error(void);
  * made since (2 KiB kept; the string is valid until the next call on the thread).  Lets a parity test assert WHICH
  * kernel served a call -- the reference has no counterpart. */
 const char* epa_launch_trace(int mode);
+/* 1 when the last epa_sv_mvbs_fused / epa_sv_noise_fused call on the calling thread was served by the kernel that leaves range_stats_out
+ * {nanmin, nanmax, NaN count}; 0 when the generic kernel served it (it leaves the maximum only and writes NaN count -1).
+ * The same fact as the -1 on the device, known on the host without waiting for the kernel. */
+int epa_last_range_stats_filled(void);
 int epa_device_count(int* n);
 int epa_set_device(int dev);
 int epa_device_name(int dev, char* buf, size_t len);
@@ -239,6 +243,9 @@ int epa_edge_gather(const double* buf, int n_slots, const int32_t* group_off, co
 int epa_edge_finalize_mvbs(const double* buf, int n_slots, const int32_t* group_off, const int32_t* group_slots,
                            const int* edges, void* const* dst_rows, const long long* chan_stride, int n_rows, int C,
                            int R, double fill_value, int dtype, epa_stream_t stream);
+/* nanmax(echo_range) of a shard before its all-reduce(MAX) over the ranks (commongrid/api.py:108-115 takes the maximum of
+ * the WHOLE dataset): NaN (a shard without a valid range) -> -inf, in place, n device doubles. */
+int epa_edge_prepare_max(double* values, int n, epa_stream_t stream);
 
 /* ---- depth = offset[c,p] + scale[c,p] * echo_range -----------------------------------------------------------
  * The array pass of consolidate.add_depth (consolidate/api.py:226: transducer_depth +

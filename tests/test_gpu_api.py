@@ -873,8 +873,14 @@ def test_deferred_sv_is_written_by_compute_MVBS_and_equals_the_eager_calls(dtype
     handler = logging.Handler()
     handler.emit = records.append
     logging.getLogger().addHandler(handler)
+    from echopype_amd.xr_lite import DeferredDataset
     try:
         mv = ep.commongrid.compute_MVBS(ds, range_bin="2m", ping_time_bin="10s")
+        # the call launched the kernel and returned: the grid np.arange(0, nanmax(echo_range) + bin, bin) needs a number
+        # that kernel produces, so the dataset is assembled (and the NaN-coordinate warning logged) on first use
+        assert isinstance(mv, DeferredDataset) and not mv.resolved and not records
+        assert sv.materialized and sv.source is None  # (the Sv array is the kernel's output buffer already)
+        assert set(mv.sizes) == {"ping_time", "channel", "echo_range"} and mv.resolved
     finally:
         logging.getLogger().removeHandler(handler)
     assert any("coordinate array contain NaNs" in r.getMessage() for r in records)   # NaN-padded pings in _lazy_case

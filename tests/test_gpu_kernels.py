@@ -501,9 +501,14 @@ def test_sv_complex_fft_path_matches_direct(env, in_dtype, out_dtype, fft_dtype,
         peak = np.nanmax(pd, axis=2, keepdims=True)  # (every ping is tiled on its own)
     fft32 = (fft_dtype or out_dtype) == "float32"
     differ = np.isnan(pf) != np.isnan(pd)
-    if fft32:  # 130 dB under the strongest echo a complex64 transform returns rounding noise, which may be an exact 0 (-> NaN)
+    if fft32:
+        # 130 dB under the ping's strongest echo a complex64 transform returns rounding noise, which may be an exact 0;
+        # the reference turns a received power that is not > 0 into NaN (calibrate_ek.py:581 prx.where(prx > 0, nan)),
+        # and so do both kernels.  The only NaN difference allowed is that one: NaN from the complex64 transform where
+        # the direct form (accumulating in the output precision) still holds a positive value that small -- never the
+        # reverse, never on a sample of any strength.
         with np.errstate(invalid="ignore"):
-            differ &= ~(pd < 1e-13 * peak)
+            differ &= ~(np.isnan(pf) & (pd < 1e-13 * peak))
     assert not differ.any(), np.argwhere(differ)[:5]
     # the direct path accumulates in the output precision; the transform in fft_dtype (default: the same).
     # Error model: the amplitude error of a transform is delta = eps_a * (strongest echo of the ping) whatever the
