@@ -4,11 +4,18 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME[:VARIANT]] ...
 
 ONE workload carries the 1 -> 8 GPU curve: BASELINE configs[4], the metric's own volume -- EK60 CW 4 ch x 2 M pings x
-4096 range (32.8 G samples) as eight resident tiles of 250 000 pings, split by ping_time over the N ranks (STRONG
-scaling: N = 1 holds all eight tiles, N = 8 one each).  The ping-time origin sits 10 s off the 20-s bin grid, so every
-tile / shard edge cuts a time bin and the edge-bin exchange (sharding.EdgeExchange: epa_edge_pack -> ONE all-reduce of
-a few hundred KB -> epa_edge_finalize_mvbs) is inside the timed region at every N.  That line is printed LAST at every
-N (the driver parses the last line); the same invocation times the bin-aligned layout too (config.aligned_ms_per_step).
+4096 range (32.8 G samples) as eight resident tiles ("files") of 250 000 pings, dealt to the N ranks round-robin (STRONG
+scaling: N = 1 holds all eight, N = 8 one each), so that tiles j N .. j N + N - 1 are one contiguous dataset sharded by
+ping_time over the N ranks.  The HEADLINE (printed LAST at every N: the driver parses the last line) goes through the
+PRODUCT ENTRY POINTS, per resident tile: N = 1 the reference's own two calls, calibrate.compute_Sv(echodata) then
+commongrid.compute_MVBS(ds_Sv, "1m", "20s"); N > 1 sharding.compute_Sv_MVBS(echodata_shard, shard=MVBSShard()) -- the
+same pass on one rank's shard with the cut time bins summed over the ranks (ONE RCCL all-reduce of a few hundred KB per
+dataset: epa_edge_pack -> all_reduce -> epa_edge_finalize_mvbs) and nanmax(echo_range) all-reduced in HBM.  The calls
+do not wait for the GPU (uploads on a side stream, the MVBS dataset assembled on first use); the bench reads each
+result once the NEXT tile has been launched, as a pipeline writing results out would.  The ping-time origin sits 10 s
+off the 20-s bin grid, so every tile edge cuts a time bin.  Beside it, from the same invocation: the ops-level harness
+(kernels called directly on preallocated buffers, all cut bins of a rank's tiles exchanged) as config.ops_level_ms_per_pass
+and its bin-aligned layout as config.aligned_ms_per_step.
 
 A STEP is `passes_per_step` back-to-back passes of the hot path over the resident volume (so that the driver's 20 steps
 are a ~2 s region); `value` = samples processed by all ranks in the K timed steps / max-over-ranks wall time.
@@ -224,17 +231,22 @@ class Ctx:
             return self.args.passes
         return WORKLOADS[workload][3 if self.dtype == "float64" else 4]
 
-    def timed(self, one_pass, passes):
+    def timed(self, one_pass, passes, finish=None):
         """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks.  A step = ``passes``
-        calls of one_pass(timer | None); returns (elapsed s, mean HIP-event ms of the regions the passes timed)."""
+        calls of one_pass(timer | None); ``finish()`` (results still in flight are read) runs INSIDE the timed region,
+        before the closing synchronize.  Returns (elapsed s, mean HIP-event ms of the regions the passes timed)."""
         steps, warmup = self.args.steps, self.args.warmup
         timers = [self.ops.Timer() for _ in range(steps * passes)]
         for _ in range(warmup * passes):
             one_pass(None)
+        if finish:
+            finish()
         self.sync()
         t0 = time.perf_counter()
         for i in range(steps * passes):
             one_pass(timers[i])
+        if finish:
+            finish()
         self.sync()
         elapsed = time.perf_counter() - t0
         kernel_ms = float(np.mean([tm.elapsed_ms() for tm in timers]))
@@ -519,21 +531,24 @@ def run_ek80(ctx, name, variant, cpu):
 
 # ---------------------------------------------------------------------------------------- cfg5: tiles, N >= 1
 class Cfg5:
-    """BASELINE configs[4]: C x P_total x S split by ping_time over the ranks, each rank's share as resident tiles of
-    <= tile_pings pings.  ``layout(offset_ns)`` builds the time grid, the exchange plan and one pass of the hot path
-    for ping times shifted by ``offset_ns`` against the 20-s grid (0: tile edges on bin edges, no exchange;
-    10 s: every tile / shard edge cuts a bin)."""
+    """BASELINE configs[4]: C x P_total x S as resident tiles of <= tile_pings pings, dealt to the ranks round-robin
+    (tile g lives on rank g % N): tiles j N .. j N + N - 1 are a contiguous dataset sharded by ping_time over the N
+    ranks.  ``layout(offset_ns)``: the ops-level harness -- time grid, exchange plan and one pass of the kernels for ping
+    times shifted by ``offset_ns`` against the 20-s grid (0: tile edges on bin edges, no exchange; 10 s: every tile edge
+    cuts a bin).  ``api_layout(offset_ns)``: the same tiles as EchoData objects through the product entry points."""
 
     BIN_NS = 20_000_000_000
 
     def __init__(self, ctx, C, P_total, S, tile_pings=None, ss_every=1, range_bin=1.0):
         torch, sharding, synth = ctx.torch, ctx.sharding, ctx.synth
-        self.ctx, self.C, self.S, self.P_total, self.range_bin = ctx, C, S, P_total, range_bin
+        self.ctx, self.C, self.S, self.P_total, self.range_bin, self.ss_every = ctx, C, S, P_total, range_bin, ss_every
         if tile_pings is None:  # the tiling belongs to the WORKLOAD (eight tiles of the whole volume), not to the split
-            tile_pings = min(TILE_PINGS, -(-P_total // 160) * 20)
-        p0, p1 = sharding.shard_bounds(P_total, ctx.world, ctx.rank, align=tile_pings)
-        self.tile_p = min(tile_pings, max(20, p1 - p0))
-        self.spans = [(a, min(p1, a + self.tile_p)) for a in range(p0, p1, self.tile_p)]
+            n_tiles = -(-8 // ctx.world) * ctx.world  # (a multiple of the rank count: every rank joins every dataset)
+            tile_pings = min(TILE_PINGS, -(-P_total // (20 * n_tiles)) * 20)
+        self.tile_p = tile_pings
+        self.n_tiles = -(-P_total // tile_pings)
+        self.gtiles = list(range(ctx.rank, self.n_tiles, ctx.world))
+        self.spans = [(g * tile_pings, min(P_total, (g + 1) * tile_pings)) for g in self.gtiles]
         self.tiles = []
         for a, b in self.spans:
             d = synth.ek60_device(C, b - a, S, seed=20260505 + a // 20, ping0=a, ss_every=ss_every)
@@ -544,12 +559,93 @@ class Cfg5:
         esz = 8 if ctx.dtype == "float64" else 4
         free_b = torch.cuda.mem_get_info()[0]
         self.keep_all = sum((b - a) for a, b in self.spans) * C * S * esz < free_b - (8 << 30)  # Sv of every tile resident?
-        if self.keep_all:
-            self.sv = [torch.empty((C, b - a, S), dtype=dt, device="cuda") for a, b in self.spans]
-        else:  # one buffer, every tile writes its Sv through a contiguous view of it
-            buf = torch.empty((C, self.tile_p, S), dtype=dt, device="cuda")
-            self.sv = [buf.view(-1)[:C * (b - a) * S].view(C, b - a, S) for a, b in self.spans]
+        self.sv = None
         self.shard = sharding.ShardContext()
+
+    def sv_buffers(self):
+        """Ops-level harness: preallocated Sv outputs (one per tile when they all fit, else one reused buffer)."""
+        torch, C, S, dt = self.ctx.torch, self.C, self.S, self.ctx.dt
+        if self.sv is None:
+            if self.keep_all:
+                self.sv = [torch.empty((C, b - a, S), dtype=dt, device="cuda") for a, b in self.spans]
+            else:  # one buffer, every tile writes its Sv through a contiguous view of it
+                buf = torch.empty((C, self.tile_p, S), dtype=dt, device="cuda")
+                self.sv = [buf.view(-1)[:C * (b - a) * S].view(C, b - a, S) for a, b in self.spans]
+        return self.sv
+
+    def echodata(self, i, offset_ns):
+        """Tile ``i`` as the EchoData the converter would hand over (convert/set_groups_ek60.py), samples AND per-ping
+        parameters resident in HBM (EchoData.to_device: the analogue of persisting the reference's dask arrays)."""
+        import echopype_amd as ep
+
+        synth, C = self.ctx.synth, self.C
+        a, b = self.spans[i]
+        d = synth.ek60_numpy(C, 4, 8)  # channel names, per-channel values, the pulse-length tables
+        h = synth.ek60_params(C, b - a, ping0=a, ss_every=self.ss_every)
+        for k in ("sample_interval", "transmit_duration_nominal", "transmit_power", "sound_speed_indicative",
+                  "absorption_indicative"):
+            d[k] = h[k]
+        d["ping_time"] = h["ping_time"] + np.timedelta64(int(offset_ns), "ns")
+        d["backscatter_r"] = ep.DeviceArray(self.tiles[i]["backscatter_r"])
+        return ep.echodata.from_ek60_arrays(d, source_file=f"synthetic_ek60_tile{self.gtiles[i]:02d}.raw").to_device()
+
+    def api_layout(self, offset_ns, lag=1):
+        """(one_pass, finish, state): one pass = every resident tile through the product entry points -- world 1: the
+        reference's two calls; world > 1: sharding.compute_Sv_MVBS on the tile as this rank's shard of dataset j.  The
+        result of a tile is READ (the deferred MVBS dataset assembled: three doubles come back from the GPU) after the
+        next ``lag`` tiles have been launched, then dropped (its Sv array goes back to the allocator)."""
+        import collections
+        import logging
+
+        import echopype_amd as ep
+
+        ctx, sharding = self.ctx, self.ctx.sharding
+        eds = [self.echodata(i, offset_ns) for i in range(len(self.tiles))]
+        dtype = ctx.dtype
+        rb = f"{self.range_bin:g}m"
+        if ctx.world == 1:
+            def call(ed):
+                ds = ep.calibrate.compute_Sv(ed, dtype=dtype)
+                return ds, ep.commongrid.compute_MVBS(ds, range_bin=rb, ping_time_bin="20s")
+        else:
+            shard = sharding.MVBSShard()
+            tau0 = np.full(self.C, 1.024e-3)  # EK60 tau_effective = ping 0 of the WHOLE file (calibrate_ek.py:154-162)
+
+            def call(ed):
+                return sharding.compute_Sv_MVBS(ed, range_bin=rb, ping_time_bin="20s", dtype=dtype, shard=shard,
+                                                tau_effective_first_ping=tau0)
+        pending = collections.deque()
+        state = {"last": None, "n_read": 0}
+
+        def consume(item):
+            ds, mv = item
+            state["last"] = (tuple(mv["Sv"].shape),)  # (touching the dataset assembles it: the grid's size comes back from the GPU)
+            state["n_read"] += 1
+
+        def one_pass(timer):
+            logging.disable(logging.WARNING)  # (the NaN-coordinate warning of every tile: 10 % of the pings are padded)
+            try:
+                for i, ed in enumerate(eds):
+                    if timer is not None and i == 0:
+                        timer.start()
+                    item = call(ed)
+                    if timer is not None and i == 0:
+                        timer.stop()
+                    pending.append(item)
+                    while len(pending) > lag:
+                        consume(pending.popleft())
+            finally:
+                logging.disable(logging.NOTSET)
+
+        def finish():
+            logging.disable(logging.WARNING)
+            try:
+                while pending:
+                    consume(pending.popleft())
+            finally:
+                logging.disable(logging.NOTSET)
+
+        return one_pass, finish, state, eds
 
     def layout(self, offset_ns):
         ctx, torch, ops, sharding = self.ctx, self.ctx.torch, self.ctx.ops, self.ctx.sharding
@@ -564,7 +660,7 @@ class Cfg5:
         plan = self.shard.plan([(f, l) for _, _, f, l, _ in info], C, n_r, "cuda")
         mv = [torch.empty((C, n, n_r), dtype=dt, device="cuda") for *_, n in info]
         dst = {(i, w): mv[i][:, 0 if w == 0 else -1] for i in range(len(mv)) for w in (0, 1)}
-        tiles, sv, rb = self.tiles, self.sv, self.range_bin
+        tiles, sv, rb = self.tiles, self.sv_buffers(), self.range_bin
 
         def one_pass(timer):
             rows = {}
@@ -587,41 +683,72 @@ class Cfg5:
         return info, plan, mv, one_pass
 
 
+def ranks_info(ctx):
+    """world size, backend and the device every rank runs on, gathered over the process group: a SCALE record then
+    proves RCCL saw N ranks on N devices."""
+    torch, dist = ctx.torch, ctx.dist
+    mine = f"{ctx.rank}:cuda{torch.cuda.current_device()}:{torch.cuda.get_device_name()}"
+    if ctx.world == 1:
+        return {"world_size": 1, "backend": "none", "devices": [mine]}
+    got = [None] * ctx.world
+    dist.all_gather_object(got, mine, group=ctx.sharding.control_group())
+    return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices": got}
+
+
 def run_cfg5(ctx, cpu):
-    """N = 1: all eight tiles on one GPU (Sv of every tile goes to one reused buffer: 131 GB in + 262 GB out does not fit
-    288 GB otherwise).  Two layouts are timed; the headline is the one WITH the exchange, at every N."""
+    """The headline: the eight tiles through the product entry points (api_layout); beside it the ops-level harness on
+    the same resident tiles, with and without cut bins.  N = 1: Sv of the tiles goes to one reused buffer (ops level) /
+    to the allocator's recycled block (API): 131 GB in + 262 GB out does not fit 288 GB otherwise."""
     args, world = ctx.args, ctx.world
     C, _, S = WORKLOADS["cfg5"][:3]
     P_total = args.pings_total or WORKLOADS["cfg5"][1]
     job = Cfg5(ctx, C, P_total, S, ss_every=args.ss_every)
     passes = ctx.passes("cfg5")
-    # (a) bin-aligned layout: no bin is shared, no data collective
+    steps = args.steps
+    # (a) ops level, bin-aligned layout: no bin is shared, no data collective
     _, plan_a, mv_a, pass_a = job.layout(0)
     assert not plan_a.shared
     el_a, km_a = ctx.timed(pass_a, passes)
     del mv_a, pass_a
-    # (b) ping times 10 s off the grid: every tile / shard edge cuts a bin -> edge exchange on the timed path
+    # (b) ops level, ping times 10 s off the grid: every tile edge cuts a bin -> edge exchange on the timed path
     _, plan_b, mv_b, pass_b = job.layout(10_000_000_000)
-    n_tiles_global = -(-P_total // job.tile_p)
     single = world == 1 and len(job.spans) == 1
     assert plan_b.shared or single
-    elapsed, kernel_ms = (ctx.timed(pass_b, passes) if not single else (el_a, km_a))
-    steps = args.steps
-    cfg = {"pings_total": P_total, "tiles": f"{n_tiles_global} x {job.tile_p} pings over {world} rank(s)",
-           "sv_resident": "every tile" if job.keep_all else "one reused tile buffer",
-           "collective": f"edge bins per pass: pack -> all_reduce(SUM, {args.backend if world > 1 else '1 rank: skipped'}) -> finalize",
-           "edge_bins_per_rank": len(plan_b.edges), "allreduce_bytes": plan_b.nbytes,
-           "aligned_ms_per_step": el_a / steps * 1e3, "exchange_ms_per_pass": (elapsed - el_a) / steps / passes * 1e3}
+    el_b, km_b = (ctx.timed(pass_b, passes) if not single else (el_a, km_a))
+    edges_b, bytes_b = len(plan_b.edges), plan_b.nbytes
+    del mv_b, pass_b, plan_b
+    job.sv = None
+    ctx.free()
+    # (c) the product entry points on the same tiles, same 10-s offset: the headline
+    pass_c, finish_c, state, eds = job.api_layout(10_000_000_000)
+    elapsed, region_ms = ctx.timed(pass_c, passes, finish=finish_c)
+    assert state["n_read"] == len(job.tiles) * passes * (steps + args.warmup)  # every result was read
+    if world == 1:
+        route = "calibrate.compute_Sv(echodata) -> commongrid.compute_MVBS(ds_Sv,'1m','20s') per tile"
+        coll = "none (1 rank: every tile is its own dataset, as the reference run per file)"
+    else:
+        route = "sharding.compute_Sv_MVBS(echodata_shard, shard=MVBSShard()) per tile"
+        coll = (f"per dataset of {world} tiles: cut bins pack -> all_reduce(SUM, {args.backend}) -> finalize; "
+                f"nanmax(echo_range) all_reduce(MAX, {args.backend}) in HBM; control scalars over gloo")
+    cfg = {"pings_total": P_total, "tiles": f"{job.n_tiles} x {job.tile_p} pings over {world} rank(s)",
+           "route": route, "collective": coll, "results_read": "each tile's MVBS after the next tile's launch",
+           "mvbs_shape_last_tile": list(state["last"][0]),
+           "ops_level_ms_per_pass": el_b / steps / passes * 1e3, "ops_level_kernel_ms": km_b,
+           "ops_level_collective": f"all cut bins of a rank's tiles: pack -> all_reduce(SUM, {args.backend if world > 1 else '1 rank: skipped'}) -> finalize",
+           "ops_level_edge_bins_per_rank": edges_b, "allreduce_bytes": bytes_b,
+           "aligned_ms_per_step": el_a / steps * 1e3, "ranks": ranks_info(ctx)}
     n_first = C * (job.spans[0][1] - job.spans[0][0]) * S if job.spans else 0
     bps = BYTES_PER_SAMPLE[ctx.dtype]
+    del eds, pass_c, finish_c
     if ctx.rank != 0:
         return None
     return line(ctx, samples_per_pass=C * P_total * S, passes=passes, elapsed=elapsed, scaling="strong", cpu=cpu,
-                workload=f"cfg5: EK60 CW {C}x{P_total}x{S} TOTAL split by ping_time, fused compute_Sv->compute_MVBS(20s x 1m), "
-                         "Sv+MVBS out, tile edges cut time bins",
+                workload=f"cfg5: EK60 CW {C}x{P_total}x{S} TOTAL in ping_time tiles through the product entry points "
+                         "(compute_Sv -> compute_MVBS 20s x 1m), Sv+MVBS out, tile edges cut time bins",
                 config=cfg,
-                roofline=roofline("fused_sv_mvbs_kernel", kernel_ms, n_first * bps, bps,
-                                  traffic_key=f"cfg5:{ctx.dtype}", launch=f"one {job.tile_p}-ping tile (rank 0, first tile)"))
+                roofline=roofline("fused_sv_mvbs_kernel (+ the coefficient / bin-offset kernels of the calls)", region_ms,
+                                  n_first * bps, bps, traffic_key=f"cfg5api:{ctx.dtype}",
+                                  launch=f"the API calls of one {job.tile_p}-ping tile (rank 0, first tile), HIP events on torch's stream"))
 
 
 # ---------------------------------------------------------------------------------------- main

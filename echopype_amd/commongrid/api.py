@@ -201,10 +201,13 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
         return None
     rng = src.echo_range
     d.fulfil(res["Sv"])
-    rng.set_stats(res["range_stats"])
+    # the three numbers start their way to the host now, on a side stream behind THIS kernel: whoever reads them later
+    # (the assembly below, the next reader of the echo_range statistics) does not wait for kernels launched after it
+    stats = ops.fetch_async(res["range_stats"])
+    rng.set_stats(stats)
 
     def build():
-        lo, hi, n_nan_range = res["range_stats"].cpu().tolist()
+        lo, hi, n_nan_range = stats.tolist()
         rmax = hi if range_var_max is None else r_cap
         r_edges = np.arange(0, rmax + range_bin_m, range_bin_m) if np.isfinite(rmax) else np.zeros(1)
         n_r = len(r_edges) - 1

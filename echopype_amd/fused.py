@@ -105,6 +105,7 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
     rmax_t = res["range_max"]
     if _shard is not None and range_var_max is None:
         rmax_t = _shard.range_max_device(rmax_t)
+    rmax_f = ops.fetch_async(rmax_t)  # (on its way to the host behind this kernel / all-reduce, on a side stream)
     if _shard is not None:  # bins cut by a shard edge: totals over all ranks, reported by the lowest holder
         res["MVBS"], lo = _shard.finish(res, first_bin, last_bin, fill_value)
         e0, n_t = e0 + lo * dt, res["MVBS"].shape[1]
@@ -124,7 +125,7 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
     ds_Sv = _finalize_cal_ds(ds_Sv, "Sv", echodata, waveform_mode, encode_mode)
 
     def build():
-        rmax = r_cap if range_var_max is not None else float(rmax_t.item())
+        rmax = r_cap if range_var_max is not None else float(rmax_f.item())
         if not np.isfinite(rmax):  # no valid echo_range at all (on any rank): the reference's grid does not exist
             raise ValueError("range bins are empty: the range variable holds no valid values")
         r_edges = np.arange(0, rmax + range_bin_m, range_bin_m)

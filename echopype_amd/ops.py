@@ -94,7 +94,77 @@ class _Uploader:
         return out
 
 
+class HostFuture:
+    """A few numbers on their way from HBM to the host (``fetch_async``).  ``.cpu()`` waits for THAT copy only -- not
+    for whatever was queued on the compute stream after it -- and returns the host tensor (so ``fut.cpu().tolist()``
+    reads like the blocking ``tensor.cpu().tolist()`` it replaces)."""
+
+    __slots__ = ("_slot", "_host", "_event", "_value")
+
+    def __init__(self, slot, host, event):
+        self._slot, self._host, self._event, self._value = slot, host, event, None
+
+    def cpu(self):
+        if self._value is None:
+            self._event.synchronize()
+            self._value = self._host.clone()
+            self._slot[1] = None  # the staging buffer may be re-used
+            self._slot = self._host = None
+        return self._value
+
+    def tolist(self):
+        return self.cpu().tolist()
+
+    def item(self):
+        return self.cpu().item()
+
+
+class _Downloader:
+    """HBM -> host copies of kernel by-products (range statistics, a maximum) that do not queue behind later work.
+
+    ``tensor.cpu()`` is a copy on the CURRENT stream: issued after the next file's 10-ms kernel has been launched it
+    completes only when that kernel has.  Here an event marks the point of the current stream where the numbers are
+    final, a dedicated download stream waits for that event and copies into a pinned buffer, and the reader waits for
+    the copy's own event.  One instance per device; buffers come from a small pinned pool."""
+
+    def __init__(self, device):
+        self.device = device
+        self.stream = torch.cuda.Stream(device=device)
+        self.pool = []  # [pinned uint8 tensor, busy marker]
+
+    def fetch(self, t):
+        t = t.contiguous()
+        nbytes = t.numel() * t.element_size()
+        slot = next((s_ for s_ in self.pool if s_[1] is None and s_[0].numel() >= nbytes), None)
+        if slot is None:
+            slot = [torch.empty(max(256, 1 << (int(nbytes) - 1).bit_length()), dtype=torch.uint8, pin_memory=True), None]
+            self.pool.append(slot)
+        slot[1] = True
+        host = slot[0][:nbytes].view(t.dtype).view(t.shape)
+        cur = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            host.copy_(t, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        t.record_stream(self.stream)
+        return HostFuture(slot, host, done)
+
+
 _uploaders = {}
+_downloaders = {}
+
+
+def fetch_async(t):
+    """Start copying a (small) device tensor to the host NOW, on a side stream, ordered after everything queued on the
+    current stream so far; returns a :class:`HostFuture`."""
+    dl = _downloaders.get(t.device)
+    if dl is None:
+        dl = _downloaders[t.device] = _Downloader(t.device)
+    return dl.fetch(t)
+
 
 
 def _uploader(dev):
