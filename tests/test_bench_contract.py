@@ -34,7 +34,7 @@ def _check_line(d, want_cpu):
         assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
 
 
-LINES = os.path.join(ROOT, "profiles", "r03_bench_default.jsonl")
+LINES = os.path.join(ROOT, "profiles", "r04_bench_default.jsonl")
 
 
 def test_committed_bench_lines_keep_the_contract():
@@ -51,7 +51,13 @@ def test_committed_bench_lines_keep_the_contract():
     head = lines[-1]                                              # the headline (BASELINE.json's metric) comes last
     assert head["config"]["workload"].startswith("cfg5") and head["metric"].startswith("range-samples/sec")
     assert head["scaling"] == "strong" and head["config"]["samples_per_step"] == 4 * 2_000_000 * 4096 * head["config"]["passes_per_step"]
-    assert head["config"]["allreduce_bytes"] > 0 and head["config"]["edge_bins_per_rank"] == 14
+    # the headline goes through the product entry points; the ops-level harness on the same tiles rides beside it
+    assert "compute_Sv(echodata)" in head["config"]["route"] and head["config"]["ops_level_ms_per_pass"] > 0
+    assert head["config"]["ms_per_pass"] < 1.05 * head["config"]["ops_level_ms_per_pass"]   # within 5 % of the kernels alone
+    assert head["config"]["allreduce_bytes"] > 0 and head["config"]["ops_level_edge_bins_per_rank"] == 14
+    assert head["config"]["ranks"]["world_size"] == 1 and len(head["config"]["ranks"]["devices"]) == 1
+    assert head["roofline"]["frac"] >= 0.60
+    assert all(d["roofline"]["traffic"] is not None for d in lines), [d["config"]["workload"][:12] for d in lines if d["roofline"]["traffic"] is None]
     also = {k for k in head["config"] if k.startswith("also_")}
     assert also == {"also_" + w.replace(":", "_") for w in ("cfg3", "cfg3:ss2000", "cfg3:f32", "cfg2", "cfg2:f32", "api",
                                                           "cfg4", "cfg4:f32", "cfg4:planes64")}
@@ -73,6 +79,8 @@ def test_live_headline_line():
     _check_line(d, want_cpu=False)
     assert d["steps"] == 3 and d["warmup"] == 1 and d["n_gpus"] == 1 and d["scaling"] == "strong"
     assert d["config"]["workload"].startswith("cfg5") and d["config"]["allreduce_bytes"] > 0
+    assert "compute_Sv(echodata)" in d["config"]["route"] and d["config"]["mvbs_shape_last_tile"][0] == 4
+    assert d["config"]["ranks"] == {"world_size": 1, "backend": "none", "devices": d["config"]["ranks"]["devices"]}
 
 
 @pytest.mark.gpu
@@ -94,3 +102,8 @@ def test_gloo_two_ranks_print_the_same_workload_with_a_cpu_baseline():
     assert (one["n_gpus"], two["n_gpus"]) == (1, 2)
     assert one["config"]["samples_per_step"] == two["config"]["samples_per_step"]
     assert one["config"]["tiles"].split(" over ")[0] == two["config"]["tiles"].split(" over ")[0]
+    # N = 1: the reference's two calls per tile; N > 1: the sharded entry point, every rank and its device on the line
+    assert "sharding.compute_Sv_MVBS" in two["config"]["route"] and "compute_MVBS(ds_Sv" in one["config"]["route"]
+    r = two["config"]["ranks"]
+    assert r["world_size"] == 2 and r["backend"] == "gloo" and [x.split(":")[0] for x in r["devices"]] == ["0", "1"]
+    assert one["config"]["mvbs_shape_last_tile"][2] == two["config"]["mvbs_shape_last_tile"][2]

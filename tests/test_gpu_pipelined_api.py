@@ -1,0 +1,163 @@
+"""The reference's two calls without a wait for the GPU (round-4 review, item 1): ``compute_Sv(echodata)`` then
+``compute_MVBS(ds_Sv)`` on device-resident echodata launch their kernels and return -- parameter uploads go through a
+side stream (ops._Uploader), the size of the range grid is bounded on the host, the {nanmin, nanmax, NaN count} the grid
+needs travel back on a download stream (ops.fetch_async) and the MVBS dataset is assembled on first use
+(xr_lite.DeferredDataset).  Results are the ones the eager route gives."""
+import logging
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need a GPU")
+    import echopype_amd as ep
+
+    return torch, ep
+
+
+def test_uploader_and_fetch_async_round_trip_behind_a_busy_stream(env):
+    """Arrays of several dtypes / sizes go up while a long kernel occupies the compute stream; a kernel launched after
+    the upload sees the data (device-side event wait); the staging buffers are re-used; fetch_async returns what a
+    blocking .cpu() would, and does not wait for work queued after it."""
+    torch, ep = env
+    from echopype_amd import ops
+
+    rng = np.random.default_rng(0)
+    busy = torch.empty(1 << 28, dtype=torch.float32, device="cuda")  # 1 GiB: a fill takes a fraction of a millisecond
+    for rep in range(3):
+        arrs = [rng.standard_normal(n) for n in (1, 5, 1000, 250_001)] + [rng.integers(0, 9, 77).astype(np.int32),
+                                                                         np.arange(12, dtype=np.int64).reshape(3, 4),
+                                                                         (rng.random(9) > .5), np.zeros(0),
+                                                                         np.array("2026-05-01T00:00:03", "datetime64[ns]").reshape(1)]
+        for _ in range(4):
+            busy.fill_(float(rep))
+        ups = [ops.to_device(a) for a in arrs]
+        doubled = [(u * 2) if u.dtype.is_floating_point else u.clone() for u in ups]  # launched AFTER the uploads
+        for a, u, d2 in zip(arrs, ups, doubled):
+            exp = a.view(np.int64) if a.dtype.kind == "M" else a
+            assert tuple(u.shape) == a.shape
+            np.testing.assert_array_equal(u.cpu().numpy(), exp)
+            np.testing.assert_array_equal(d2.cpu().numpy(), exp * 2 if exp.dtype.kind == "f" else exp)
+    up = ops._uploaders[torch.device("cuda", torch.cuda.current_device())]
+    assert 1 <= len(up.pool) <= up._MAX_POOL
+    n_pool = len(up.pool)
+    for _ in range(50):
+        ops.to_device(rng.standard_normal(1000))
+    torch.cuda.synchronize()
+    assert len(up.pool) <= n_pool + 50 and len(up.pool) <= up._MAX_POOL
+    # float32 target dtype, a read-only broadcast view, a torch CPU tensor
+    np.testing.assert_array_equal(ops.to_device(np.arange(5.0), dtype=torch.float32).cpu().numpy(), np.arange(5, dtype=np.float32))
+    np.testing.assert_array_equal(ops.to_device(np.broadcast_to(np.arange(3.0), (2, 3))).cpu().numpy(), np.tile(np.arange(3.0), (2, 1)))
+    np.testing.assert_array_equal(ops.to_device(torch.arange(4)).cpu().numpy(), np.arange(4))
+    # fetch_async: the value at the point of the call, whatever is queued afterwards
+    t = torch.arange(3, dtype=torch.float64, device="cuda") + 1
+    fut = ops.fetch_async(t)
+    t.mul_(100)                      # queued after the fetch: must not be seen
+    for _ in range(4):
+        busy.fill_(1.0)
+    assert fut.tolist() == [1.0, 2.0, 3.0] and fut.cpu().tolist() == [1.0, 2.0, 3.0]
+    assert ops.fetch_async(t[:1]).item() == 100.0
+
+
+def _resident_case(ep, C=3, P=400, S=1024, seed=3):
+    d = ep.synth.ek60_numpy(C, P, S, seed=seed, ss_every=7)
+    d["backscatter_r"][1, 5, S - 60:] = np.nan
+    return d, ep.echodata.from_ek60_arrays(d).to_device()
+
+
+def test_two_calls_on_resident_echodata_make_no_host_synchronisation(env, monkeypatch):
+    """torch's synchronisation debug mode raises on any blocking call (tensor.cpu(), .item(), a pageable upload):
+    compute_Sv + compute_MVBS on device-resident echodata make none; reading the result does."""
+    torch, ep = env
+    from echopype_amd.xr_lite import DeferredDataset
+
+    _, ed = _resident_case(ep)
+    logging.disable(logging.WARNING)
+    try:
+        for _ in range(2):  # warm-up: the staging pools, the allocator's blocks
+            ep.commongrid.compute_MVBS(ep.calibrate.compute_Sv(ed), range_bin="1m", ping_time_bin="20s")["Sv"].shape
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            ds = ep.calibrate.compute_Sv(ed)
+            mv = ep.commongrid.compute_MVBS(ds, range_bin="1m", ping_time_bin="20s")
+            ds2 = ep.calibrate.compute_Sv(ed)  # the next file is launched before anything is read
+            mv2 = ep.commongrid.compute_MVBS(ds2, range_bin="1m", ping_time_bin="20s")
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        assert isinstance(mv, DeferredDataset) and not mv.resolved and not mv2.resolved
+        shape = mv["Sv"].shape
+        assert mv.resolved and not mv2.resolved and mv2["Sv"].shape == shape
+        # ... and with EPA_DEFER_MVBS=0 the call assembles before it returns
+        monkeypatch.setenv("EPA_DEFER_MVBS", "0")
+        mv3 = ep.commongrid.compute_MVBS(ep.calibrate.compute_Sv(ed), range_bin="1m", ping_time_bin="20s")
+        assert not isinstance(mv3, DeferredDataset)
+        np.testing.assert_array_equal(mv3["Sv"].values, mv["Sv"].values)
+        assert mv3["Sv"].attrs == mv["Sv"].attrs and mv3.attrs.keys() == mv.attrs.keys()
+    finally:
+        logging.disable(logging.NOTSET)
+
+
+@pytest.mark.parametrize("range_var_max", [None, "150m"])
+def test_deferred_result_equals_the_eager_route_and_the_oracle(env, monkeypatch, range_var_max):
+    """Same MVBS (values, coordinates, attributes) as with EPA_DEFER_SV=0 (K1, then the binning kernel on the Sv array,
+    everything read back inside the call), and as the oracle; the host-side range bound only sizes the launch."""
+    torch, ep = env
+    from oracle import calibrate as ocal
+    from oracle import commongrid as ogrid
+
+    d, ed = _resident_case(ep, seed=11)
+    logging.disable(logging.WARNING)
+    try:
+        kw = dict(range_bin="2m", ping_time_bin="10s", range_var_max=range_var_max)
+        ds = ep.calibrate.compute_Sv(ed)
+        assert ds["Sv"].data.source.reach_bound is not None  # (host mirrors of sample_interval / sound_speed)
+        mv = ep.commongrid.compute_MVBS(ds, **kw)
+        monkeypatch.setenv("EPA_DEFER_SV", "0")
+        ds_e = ep.calibrate.compute_Sv(ed)
+        mv_e = ep.commongrid.compute_MVBS(ds_e, **kw)
+    finally:
+        logging.disable(logging.NOTSET)
+    for k in ("echo_range", "ping_time", "channel"):
+        np.testing.assert_array_equal(mv[k].values, mv_e[k].values)
+    got, exp = mv["Sv"].values, mv_e["Sv"].values
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+    np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-12, equal_nan=True)
+    assert mv["Sv"].attrs == mv_e["Sv"].attrs
+    np.testing.assert_array_equal(ds["Sv"].values, ds_e["Sv"].values)
+    gain = ocal.vend_cal_params_power(d["transmit_duration_nominal"], d["pulse_length"], d["gain_correction"])
+    sa = ocal.vend_cal_params_power(d["transmit_duration_nominal"], d["pulse_length"], d["sa_correction"])
+    sv, er = ocal.cal_power_ek(
+        d["backscatter_r"], sonar="EK60", cal_type="Sv", sample_interval=d["sample_interval"],
+        sound_speed=d["sound_speed_indicative"], absorption=d["absorption_indicative"],
+        transmit_power=d["transmit_power"], tau_nominal=d["transmit_duration_nominal"], gain=gain, sa_correction=sa,
+        psi=d["equivalent_beam_angle"], f_nominal=d["frequency_nominal"], tau_eff=d["transmit_duration_nominal"][:, 0])
+    exp_mv, _, r_left = ogrid.compute_MVBS(sv, er, d["ping_time"], "2m", "10s", range_var_max=range_var_max)
+    np.testing.assert_array_equal(mv["echo_range"].values, r_left)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp_mv))
+    f = np.isfinite(exp_mv)
+    assert np.max(np.abs(got[f] - exp_mv[f]) / np.maximum(np.abs(exp_mv[f]), 1.0)) < 1e-9
+
+
+def test_deferred_error_surfaces_at_first_use(env):
+    """An all-NaN file: the reference's compute_MVBS raises on the empty range grid; here the same error comes out when
+    the dataset is first touched (the kernel that finds out has only been launched when the call returns)."""
+    torch, ep = env
+    d = ep.synth.ek60_numpy(2, 60, 512)
+    d["backscatter_r"][:] = np.nan
+    ed = ep.echodata.from_ek60_arrays(d).to_device()
+    logging.disable(logging.WARNING)
+    try:
+        ds = ep.calibrate.compute_Sv(ed)
+        mv = ep.commongrid.compute_MVBS(ds, range_bin="1m", ping_time_bin="20s")
+        with pytest.raises(ValueError, match="range bins are empty"):
+            mv["Sv"]
+    finally:
+        logging.disable(logging.NOTSET)

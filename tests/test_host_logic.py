@@ -674,3 +674,40 @@ def test_resample_edges_sorted_shortcut_equals_the_scan():
             t0 = np.datetime64("2026-03-09T00:00:00", "ns") + np.timedelta64(int(rng.integers(0, 86400 * 3)), "s")
             t = t0 + np.sort(rng.integers(0, 10**12, n)).astype("timedelta64[ns]")
             assert resample_edges(t, bin_, sorted_valid=True) == resample_edges(t, bin_)
+
+
+def test_deferred_dataset_assembles_once_on_first_use():
+    """xr_lite.DeferredDataset: a Dataset whose build() runs when anything touches it -- once; it IS a Dataset for every
+    isinstance check of the package, forwards reads and writes to the built object, and lets a failing build surface at
+    that first use (and say so on later ones)."""
+    from echopype_amd.xr_lite import DataArray, Dataset, DeferredDataset
+
+    calls = []
+
+    def build():
+        calls.append(1)
+        ds = Dataset(coords={"x": np.arange(3)}, attrs={"a": 1})
+        ds["v"] = (("x",), np.array([1.0, 2.0, 3.0]))
+        return ds
+
+    dd = DeferredDataset(build)
+    assert isinstance(dd, Dataset) and not dd.resolved and not calls
+    assert "v" in dd and calls == [1] and dd.resolved
+    assert dd.sizes["x"] == 3 and list(dd.data_vars) == ["v"] and dd.attrs == {"a": 1} and calls == [1]
+    np.testing.assert_array_equal(dd["v"].values, [1.0, 2.0, 3.0])
+    np.testing.assert_array_equal(dd.v.values, [1.0, 2.0, 3.0])            # attribute access like xarray's
+    dd["w"] = DataArray(np.zeros(3), ("x",))                               # writes land in the built dataset
+    dd.attrs["b"] = 2
+    assert set(dd.data_vars) == {"v", "w"} and dd.attrs == {"a": 1, "b": 2}
+    cp = dd.assign_attrs(c=3)
+    assert type(cp) is Dataset and cp.attrs["c"] == 3 and "c" not in dd.attrs
+    assert repr(dd).startswith("<Dataset") and calls == [1]
+
+    def bad():
+        raise ValueError("range bins are empty")
+
+    bd = DeferredDataset(bad)
+    with pytest.raises(ValueError, match="range bins are empty"):
+        bd.sizes
+    with pytest.raises(RuntimeError, match="failed earlier"):
+        bd["v"]
