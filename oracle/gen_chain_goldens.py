@@ -16,6 +16,12 @@ transpose -- strict: anything unimplemented raises).  The calibrator objects are
 their constructors (which parse files and parameters through the EchoData / ECS machinery) and given
 exactly the attributes the methods read; the parameter-selection code has its own goldens / KATs.
 Output = data only: seeded inputs + the outputs of the reference's code.
+
+A second file, tests/golden/ref_seam_goldens.npz, holds two LONG cases whose range axis crosses the seams of the HIP
+kernels (round-3 review, item 3): EK60 power with S = 2052 (two 1024-sample chunk boundaries of the power kernels and a
+4-sample tail) and EK80 broadband with S = 4200 (the overlap-save tiles of csrc/ek80_fft.hip: echoes straddling samples
+1872, 2048, 3744 and 4096 +- taps, partly-NaN sectors inside the overlap regions, a NaN in beam 0 there); inputs are
+float32-representable and stored as float32 to keep the file under 2 MB.
 """
 import logging
 import os
@@ -29,6 +35,7 @@ import xr_shim  # noqa: E402
 from gen_goldens import REF, _load  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "ref_chain_goldens.npz")
+OUT_SEAM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "ref_seam_goldens.npz")
 DA, DS = xr_shim.DataArray, xr_shim.Dataset
 
 
@@ -170,7 +177,7 @@ def azfp_case(az, g, C, P, S, seed):
         g[f"azfp_echo_range_{cal_type}"] = out["echo_range"].transpose("channel", "ping_time", "range_sample").data
 
 
-def ek80_complex_case(ek, ekc, rng_mod, g, tag, waveform, C, P, S, B, seed):
+def ek80_complex_case(ek, ekc, rng_mod, g, tag, waveform, C, P, S, B, seed, seam=False):
     rng = np.random.default_rng(seed)
     chans = np.array([f"ch{i}" for i in range(C)])
     pings = np.datetime64("2026-05-01T00:00:00", "ns") + np.arange(P) * np.timedelta64(1, "s")
@@ -192,6 +199,19 @@ def ek80_complex_case(ek, ekc, rng_mod, g, tag, waveform, C, P, S, B, seed):
             k0 = int(rng.integers(10, S - 10))
             n = min(r.size, S - k0)
             x[c, p, k0:k0 + n, :] += 0.3 * r[:n, None]
+    if seam:  # echoes across the tile seams of the LDS-FFT kernel (2048-sample tiles, 1872 new samples each) ...
+        for c in range(C):
+            r = tx[str(chans[c])]
+            for p in range(P):
+                for k0 in (1872 - r.size // 2, 2048 - r.size // 3, 2048 + 3, 3744 - 5, 4096 - r.size // 2, S - r.size // 2):
+                    n = min(r.size, S - k0)
+                    x[c, p, k0:k0 + n, :] += (0.2 + 0.1 * p) * r[:n, None]
+        # ... partly-NaN sectors inside the overlap regions, a NaN in beam 0 there (masks echo_range, range.py:143-148)
+        x[1, 0, 1860:1866, B - 1] = np.nan
+        x[0, 1, 2040:2052, 2] = np.nan
+        x[1, 3, 3740:3750, 0] = np.nan
+        x[0, 0, 2047:2049, :] = np.nan  # every sector missing on both sides of sample 2048
+        x = x.real.astype(np.float32).astype(np.float64) + 1j * x.imag.astype(np.float32).astype(np.float64)
     x[:, 1, S - 9:, :] = np.nan
     x[0, 2] = np.nan
     # partly-NaN samples: some sectors missing (the reference zeroes them for the convolution, restores the NaN and
@@ -237,7 +257,7 @@ def ek80_complex_case(ek, ekc, rng_mod, g, tag, waveform, C, P, S, B, seed):
     ek.get_transmit_signal = lambda *a, **k: (tx, tx_time)
     for k, v in dict(re=x.real, im=x.imag, sample_interval=si, tau=tau, transmit_power=pt, sound_speed=c_w,
                      absorption=alpha, gain=gain, sa=sa, psi=psi, f_center=fc).items():
-        g[f"{tag}_{k}"] = v
+        g[f"{tag}_{k}"] = v.astype(np.float32) if seam and k in ("re", "im") else v  # (exact: the values are float32's)
     for name in ("angle_offset_alongship", "angle_offset_athwartship", "beamwidth_alongship", "beamwidth_athwartship"):
         g[f"{tag}_{name}"] = cal[name].data
     for i, ch in enumerate(chans):
@@ -265,6 +285,14 @@ def main():
     print("wrote", os.path.normpath(OUT), f"{os.path.getsize(OUT)/1024:.1f} KiB,", len(g), "arrays")
     for k in ("ek60_Sv", "ek60_TS", "ek80p_Sv", "azfp_Sv", "azfp_TS", "ek80bb_Sv", "ek80bb_TS", "ek80cw_Sv"):
         print(k, g[k].shape, "NaN:", int(np.isnan(g[k]).sum()), "mean:", float(np.nanmean(g[k])))
+    # the long cases across the kernels' seams
+    h = {}
+    ek_case(ek, rng_mod, h, "ek60seam", "EK60", 2, 4, 2052, 7)
+    ek80_complex_case(ek, ekc, rng_mod, h, "ek80bbseam", "BB", 2, 4, 4200, 4, 8, seam=True)
+    np.savez_compressed(OUT_SEAM, **h)
+    print("wrote", os.path.normpath(OUT_SEAM), f"{os.path.getsize(OUT_SEAM)/1024:.1f} KiB,", len(h), "arrays")
+    for k in ("ek60seam_Sv", "ek60seam_TS", "ek80bbseam_Sv", "ek80bbseam_TS"):
+        print(k, h[k].shape, "NaN:", int(np.isnan(h[k]).sum()), "mean:", float(np.nanmean(h[k])))
 
 
 if __name__ == "__main__":

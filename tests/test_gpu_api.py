@@ -532,10 +532,13 @@ def test_power_chains_match_reference_method_goldens(ep):
 
     import torch
 
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_chain_goldens.npz"))
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = dict(np.load(os.path.join(gdir, "ref_chain_goldens.npz")))
+    g.update(np.load(os.path.join(gdir, "ref_seam_goldens.npz")))  # ek60seam: S = 2052, two chunk boundaries + a tail
     ops = ep.ops
     dev = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).cuda().to(dt)  # noqa: E731
-    for tag, sonar in (("ek60", "EK60"), ("ek80p", "EK80"), ("ek60psi", "EK60")):  # ek60psi: psi per (channel, ping)
+    for tag, sonar in (("ek60", "EK60"), ("ek80p", "EK80"), ("ek60psi", "EK60"),  # ek60psi: psi per (channel, ping)
+                       ("ek60seam", "EK60")):
         gpt = dev(g[f"{tag}_is_gpt"].astype(np.uint8), torch.uint8) if sonar == "EK80" else None
         for cal in ("Sv", "TS"):
             coef = ops.power_coef_ek(

@@ -704,17 +704,22 @@ def _chain_equivalence(env, dtype, closed, P, pn, bin_s, ss_every, S=1000, gap_a
 
 
 # ---- EK80 complex kernels against the reference's own _cal_complex_samples outputs ---------------------
-@pytest.mark.parametrize("tag,wf", [("ek80bb", "BB"), ("ek80cw", "CW")])
+@pytest.mark.parametrize("tag,wf,planes", [("ek80bb", "BB", "float64"), ("ek80cw", "CW", "float64"),
+                                           ("ek80bbseam", "BB", "float32"), ("ek80bbseam", "BB", "float64")])
 @pytest.mark.parametrize("method", ["direct", "fft"])
-def test_sv_complex_matches_reference_method_goldens(env, tag, wf, method):
+def test_sv_complex_matches_reference_method_goldens(env, tag, wf, planes, method):
     """epa_sv_complex / epa_sv_complex_fft on the inputs of tests/golden/ref_chain_goldens.npz vs the Sv / TS the
-    reference's CalibrateEK80._cal_complex_samples produced for them (oracle/gen_chain_goldens.py)."""
+    reference's CalibrateEK80._cal_complex_samples produced for them (oracle/gen_chain_goldens.py).  ``ek80bbseam``
+    (tests/golden/ref_seam_goldens.npz): 4200 samples per ping -- echoes straddling the overlap-save tile seams of the
+    LDS-FFT kernel (samples 1872, 2048, 3744, 4096 +- taps), partly-NaN sectors and a NaN beam 0 inside the overlap
+    regions; its inputs are float32 numbers, fed as float32 planes and as the converter's float64 planes."""
     import os
 
     torch, ops, synth = env
     from echopype_amd import _lib
 
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_chain_goldens.npz"))
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gdir, "ref_seam_goldens.npz" if tag.endswith("seam") else "ref_chain_goldens.npz"))
     C, P, S, B = g[f"{tag}_re"].shape
     reps = [g[f"{tag}_replica{i}"] for i in range(C)]
     cw, si, pt = g[f"{tag}_sound_speed"], g[f"{tag}_sample_interval"], g[f"{tag}_transmit_power"]
@@ -746,7 +751,11 @@ def test_sv_complex_matches_reference_method_goldens(env, tag, wf, method):
                       max_taps=max(r.size for r in reps), method=method)
         elif method == "fft":
             continue  # CW has no replica
-        res = ops.sv_complex(_dev(torch, g[f"{tag}_re"]), _dev(torch, g[f"{tag}_im"]), _dev(torch, cc), cal_type=cal, **kw)
+        with _lib.launch_trace() as tr:
+            res = ops.sv_complex(_dev(torch, g[f"{tag}_re"].astype(planes)), _dev(torch, g[f"{tag}_im"].astype(planes)),
+                                 _dev(torch, cc), cal_type=cal, **kw)
+        if wf == "BB":  # the kernel asked for is the one that ran
+            assert any("fft" in k for k in tr.kernels) == (method == "fft"), tr.kernels
         got, exp = res["out"].cpu().numpy(), g[f"{tag}_{cal}"]
         np.testing.assert_array_equal(res["echo_range"].cpu().numpy(), g[f"{tag}_echo_range"])
         np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
