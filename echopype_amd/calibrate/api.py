@@ -164,17 +164,29 @@ def _calibrate_filter_intervals(compute, cal_type, beam, vend, tau, pt, chans):
 
 
 @xarray_io()
-def compute_Sv(echodata, **kwargs):
-    """Volume backscattering strength Sv.  Same arguments as the reference (api.py:249-345):
-    env_params, cal_params, ecs_file, waveform_mode, encode_mode, assume_single_filter_time,
-    drop_last_hanning_zero (+ dtype, device; EK80 broadband: fft_dtype = arithmetic of the pulse-compression
-    transform, "float64" | "float32", default = dtype -- a complex64 transform is as precise as a float32 output,
-    with errors relative to the strongest echo of each 2048-sample tile; a float64 output always gets complex128
-    unless asked otherwise)."""
-    return _compute_cal(cal_type="Sv", echodata=echodata, **kwargs)
+def compute_Sv(echodata, *, env_params=None, cal_params=None, ecs_file=None, waveform_mode=None, encode_mode=None,
+               assume_single_filter_time=None, drop_last_hanning_zero=False, dtype="float64", device=None,
+               fft_dtype=None):
+    """Volume backscattering strength Sv.  The reference's ``compute_Sv(echodata, **kwargs)`` forwards to
+    ``_compute_cal`` (calibrate/api.py:23-33, 249-345); the keywords it accepts there are spelled out here, keyword-only
+    as they effectively are -- ``inspect.signature`` and tab completion show them, a misspelt one is a ``TypeError`` at
+    the call (tests/test_signatures.py compares with the reference's source).  Three more for the accelerated path:
+    ``dtype`` ("float64" | "float32": arithmetic and output type), ``device`` (torch device, default the current GPU)
+    and, EK80 broadband, ``fft_dtype`` = arithmetic of the pulse-compression transform ("float64" | "float32", default
+    = dtype -- a complex64 transform is as precise as a float32 output, with errors relative to the strongest echo of
+    each 2048-sample tile; a float64 output always gets complex128 unless asked otherwise)."""
+    return _compute_cal("Sv", echodata, env_params=env_params, cal_params=cal_params, ecs_file=ecs_file,
+                        waveform_mode=waveform_mode, encode_mode=encode_mode,
+                        assume_single_filter_time=assume_single_filter_time,
+                        drop_last_hanning_zero=drop_last_hanning_zero, dtype=dtype, device=device, fft_dtype=fft_dtype)
 
 
 @xarray_io()
-def compute_TS(echodata, **kwargs):
-    """Target strength TS (api.py:348-449)."""
-    return _compute_cal(cal_type="TS", echodata=echodata, **kwargs)
+def compute_TS(echodata, *, env_params=None, cal_params=None, ecs_file=None, waveform_mode=None, encode_mode=None,
+               assume_single_filter_time=None, drop_last_hanning_zero=False, dtype="float64", device=None,
+               fft_dtype=None):
+    """Target strength TS (calibrate/api.py:348-449); keywords as for :func:`compute_Sv`."""
+    return _compute_cal("TS", echodata, env_params=env_params, cal_params=cal_params, ecs_file=ecs_file,
+                        waveform_mode=waveform_mode, encode_mode=encode_mode,
+                        assume_single_filter_time=assume_single_filter_time,
+                        drop_last_hanning_zero=drop_last_hanning_zero, dtype=dtype, device=device, fft_dtype=fft_dtype)

@@ -130,7 +130,7 @@ def estimate_background_noise(ds_Sv, ping_num, range_sample_num, background_nois
 
 @xarray_io(in_place=("Sv_noise", "Sv_corrected"))
 def remove_background_noise(ds_Sv, ping_num, range_sample_num, background_noise_max=None,
-                            SNR_threshold="3.0dB", _shard=None):
+                            SNR_threshold="3.0dB", *, _shard=None):
     """Adds Sv_noise and Sv_corrected to ``ds_Sv`` and returns it (api.py:472-511).
     (``_shard`` = (ping_offset, group, ShardContext | None): set by echopype_amd.sharding.remove_background_noise.)"""
     ds_Sv = from_xarray(ds_Sv)

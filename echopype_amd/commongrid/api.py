@@ -71,7 +71,7 @@ def _full(da, ds, order):
 
 @xarray_io()
 def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="20s", method="map-reduce",
-                 reindex=False, skipna=True, fill_value=np.nan, closed="left", range_var_max=None, _shard=None,
+                 reindex=False, skipna=True, fill_value=np.nan, closed="left", range_var_max=None, *, _shard=None,
                  **flox_kwargs):
     """Mean volume backscattering strength on a (ping_time, range) grid in physical units.
     (``_shard``: set by echopype_amd.sharding.compute_MVBS when ``ds_Sv`` is one rank's ping shard.)"""

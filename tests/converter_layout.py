@@ -10,10 +10,44 @@ dtypes -- not only the handful the calibrators read:
         string-labelled ``beam`` dimension, int64 range_sample, transmit_type strings, the filter coefficients NaN-padded
         on (channel, filter_time, n), Environment on a single time1, Sonar with beam_group_descr / waveform_encode_descr.
   AZFP (set_groups_azfp.py:417-466, 583-608, 736-770): float64 counts, temperature on time1, tilt variables.
-Built from echopype_amd's own synthetic EchoData (same numbers), so results can be compared bit for bit."""
+Built from echopype_amd's own synthetic EchoData (same numbers), so results can be compared bit for bit.
+
+``use(module)`` switches the container library: tests/fake_xarray.py (default; xarray cannot be installed in the build
+image) or the REAL ``xarray`` -- the groups are then ``xarray.Dataset`` objects in an ``xarray.DataTree``, read through
+the same thin EchoData wrapper echopype puts around its tree (echodata/echodata.py:43-346)."""
 import numpy as np
 
 import fake_xarray as fx
+
+_FAKE = fx
+
+
+def use(module):
+    """Select the container library for the builders below; returns the previous one."""
+    global fx
+    prev, fx = fx, module
+    return prev
+
+
+class RealTreeEchoData:
+    """The read API of echopype's EchoData over a real ``xarray.DataTree`` (echodata.py:327-335: ``ed[path]`` gives the
+    group's Dataset, None for a group the file does not have)."""
+
+    def __init__(self, sonar_model, tree, source_file=None):
+        self.sonar_model, self.source_file, self.converted_raw_path = sonar_model, source_file, None
+        self._tree = tree
+
+    @property
+    def group_paths(self):
+        return ["Top-level"] + [g.lstrip("/") for g in self._tree.groups if g != "/"]
+
+    def __getitem__(self, key):
+        if key in (None, "Top-level"):
+            return self._tree.to_dataset()
+        try:
+            return self._tree[key].to_dataset()
+        except KeyError:
+            return None
 
 
 def _fake(ds, extra=None, coord_map=None):
@@ -45,6 +79,9 @@ def _common_groups(sonar_model, ping_time, extra_sonar=None):
 
 
 def _tree(sonar_model, top, groups, source_file):
+    if fx is not _FAKE:  # real xarray: a DataTree of the groups
+        tree = fx.DataTree.from_dict({"/": top, **{"/" + path: ds for path, ds in groups.items()}})
+        return RealTreeEchoData(sonar_model, tree, source_file=source_file)
     root = fx.DataTreeNode(top)
     for path, ds in groups.items():
         node = root

@@ -1,28 +1,36 @@
-"""xarray in -> xarray out (the drop-in keeps the reference's Dataset-in / Dataset-out signatures).  xarray
-cannot be installed here, so the boundary is exercised with tests/fake_xarray.py, a duck-typed stand-in for the public
-API subset it touches, patched in as ``echopype_amd.xr_lite._xr``: an "xarray" EchoData / Dataset goes in, "xarray"
-Datasets come out, and remove_background_noise writes Sv_noise / Sv_corrected into the CALLER's dataset as the reference
-does (/root/reference/echopype/clean/api.py:490-502)."""
+"""xarray in -> xarray out (the drop-in keeps the reference's Dataset-in / Dataset-out signatures).  Every
+test runs twice: with tests/fake_xarray.py, a duck-typed stand-in for the public API subset the boundary touches (xarray
+cannot be installed in the build image: no network), and with the REAL ``xarray`` -- Datasets in an ``xarray.DataTree``
+behind an EchoData-like wrapper -- wherever it is importable (``pytest.importorskip``): any box that has xarray proves
+the claim.  The library under test is patched in as ``echopype_amd.xr_lite._xr``: an "xarray" EchoData / Dataset goes
+in, "xarray" Datasets come out, and remove_background_noise writes Sv_noise / Sv_corrected into the CALLER's dataset as
+the reference does (/root/reference/echopype/clean/api.py:490-502)."""
 import numpy as np
 import pytest
 
-import fake_xarray as fx
+import fake_xarray
 
 pytestmark = pytest.mark.gpu
 DIMS = ("channel", "ping_time", "range_sample")
+fx = fake_xarray  # rebound by the ``ep`` fixture to the library of the running parametrisation
 
 
-@pytest.fixture()
-def ep(monkeypatch):
+@pytest.fixture(params=["stand-in", "xarray"])
+def ep(request, monkeypatch):
     import torch
 
     if not torch.cuda.is_available():
         pytest.fail("these tests need a GPU")
+    import converter_layout
     import echopype_amd
     from echopype_amd import xr_lite
 
-    monkeypatch.setattr(xr_lite, "_xr", fx)
-    return echopype_amd
+    lib = fake_xarray if request.param == "stand-in" else pytest.importorskip("xarray")
+    monkeypatch.setattr(xr_lite, "_xr", lib)
+    monkeypatch.setitem(globals(), "fx", lib)
+    prev = converter_layout.use(lib)
+    yield echopype_amd
+    converter_layout.use(prev)
 
 
 def _as_fake(ds):
@@ -38,7 +46,7 @@ class ForeignEchoData:
     def __init__(self, lite_ed):
         self.sonar_model, self.source_file, self.converted_raw_path = lite_ed.sonar_model, lite_ed.source_file, None
         self._g = {g: _as_fake(lite_ed[g]) for g in lite_ed.group_paths}
-        self.group_paths = list(self._g)
+        self.group_paths = list(self._g)  # (Datasets of the library under test: the stand-in's or xarray's)
 
     def __getitem__(self, g):
         return self._g[g]
