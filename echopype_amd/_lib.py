@@ -74,7 +74,7 @@ SIGNATURES = {
     "epa_timer_stop": [_vp, _vp],
     "epa_timer_elapsed_ms": [_vp, ctypes.POINTER(ctypes.c_float)],
     "epa_power_coef_ek": [_i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp,
-                          _vp, _vp, _i, _i, _vp, _vp],
+                          _vp, _i, _vp, _i, _i, _vp, _vp],
     "epa_pulse_table_lookup": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "epa_sv_power": [_vp, _vp, _i, _i, _i, _i, _u, _vp, _vp, _i, _vp],
     "epa_sv_power_stats": [_vp, _vp, _i, _i, _i, _i, _u, _vp, _vp, _i, _vp, _vp, _vp],
@@ -102,9 +102,12 @@ SIGNATURES = {
     "epa_noise_finalize": [_vp, _vp, _i, _i, _d, _vp, _vp],
     "epa_noise_apply": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp],
     "epa_noise_apply_rows": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _vp],
-    "epa_complex_coef_ek80": [_i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "epa_complex_coef_ek80": [_i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp],
     "epa_sv_complex": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "epa_sv_complex_indexed": [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "epa_sv_complex_fft": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    "epa_sv_complex_fft_indexed": [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i,
+                                   _vp, _vp, _vp],
     "epa_range_bin_smooth": [_vp, _vp, _i, _i, _i, _i, _d, _d, _i, _vp, _i, _vp],
     "epa_impulse_mask": [_vp, _i, _i, _i, _i, _d, _vp, _i, _vp],
     "epa_pool_sv": [_vp, _i, _i, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _i, _vp],

@@ -78,7 +78,9 @@ def _compute_cal(cal_type, echodata, env_params=None, cal_params=None, ecs_file=
             first = {ch: pt[np.flatnonzero(~np.isnan(tau[i]))[0]] for i, ch in enumerate(chans)}
             cal_ds = _compute_cal_ds({"first_valid_filter_time_per_channel": first})
         else:
-            cal_ds = _calibrate_filter_intervals(_compute_cal_ds, cal_type, beam, vend, tau, pt, chans)
+            # every (channel, filter interval) pair in ONE pass over the whole grid (the reference calibrates them one by
+            # one and merges, api.py:125-197): per-pair replicas / effective pulse lengths, a replica index per ping
+            cal_ds = _compute_cal_ds({"filter_intervals": True})
 
     return _finalize_cal_ds(cal_ds, cal_type, echodata, waveform_mode, encode_mode)
 
@@ -111,56 +113,6 @@ def _finalize_cal_ds(cal_ds, cal_type, echodata, waveform_mode, encode_mode):
     if "water_level" in echodata["Platform"].data_vars:
         cal_ds["water_level"] = echodata["Platform"]["water_level"]
     return cal_ds
-
-
-def _calibrate_filter_intervals(compute, cal_type, beam, vend, tau, pt, chans):
-    """Each channel x filter interval calibrated separately, then merged on the full
-    (channel, ping_time) grid -- NaN where nothing was calibrated (xr.merge(join="outer"),
-    api.py:125-197)."""
-    import torch
-
-    from ..xr_lite import DataArray, Dataset, DeviceArray
-
-    filter_times = np.sort(np.asarray(vend["filter_time"].values).astype("datetime64[ns]"))
-    C, P, S = beam["backscatter_r"].shape[:3]
-    merged = None
-    per_ping = {}
-    for ci, ch in enumerate(chans):
-        valid_pt = pt[~np.isnan(tau[ci])]
-        starts = np.intersect1d(valid_pt, filter_times)
-        for k, start in enumerate(starts):
-            end = None if k + 1 == len(starts) else starts[k + 1] - np.timedelta64(1, "ns")
-            ds = compute({"filter_time": start, "channel": ch, "beam_group_start_time": start,
-                          "beam_group_end_time": end})
-            idx = np.flatnonzero((pt >= start) & ((pt <= end) if end is not None else True))
-            if merged is None:
-                t0 = ds[cal_type].data.tensor
-                full = lambda: torch.full((C, P, S), float("nan"), dtype=t0.dtype, device=t0.device)  # noqa: E731
-                merged = {cal_type: full(), "echo_range": full()}
-            dev_idx = torch.as_tensor(idx, device=merged[cal_type].device)
-            for name in (cal_type, "echo_range"):
-                merged[name][ci].index_copy_(0, dev_idx, ds[name].data.tensor[0])
-            for name, da in ds.data_vars.items():
-                if name in (cal_type, "echo_range") or name == "source_filenames":
-                    continue
-                a = np.asarray(da.values, dtype=np.float64) if da.dtype.kind in "fiu" else None
-                if a is None:
-                    continue
-                store = per_ping.setdefault(name, np.full((C, P), np.nan))
-                if da.dims == ("channel", "ping_time"):
-                    store[ci, idx] = a[0]
-                elif da.dims == ("channel",):
-                    store[ci, idx] = a[0]
-                elif da.dims == ():
-                    store[ci, idx] = a
-    out = Dataset(coords={"channel": np.asarray(chans), "ping_time": pt, "range_sample": np.arange(S)})
-    dims = ("channel", "ping_time", "range_sample")
-    for name in (cal_type, "echo_range"):
-        out[name] = DataArray(DeviceArray(merged[name]), dims)
-    for name, a in per_ping.items():
-        out[name] = (("channel", "ping_time"), a)
-    out["frequency_nominal"] = beam["frequency_nominal"]
-    return out
 
 
 @xarray_io()

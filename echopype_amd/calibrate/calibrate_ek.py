@@ -154,7 +154,17 @@ class CalibrateEK(CalibrateBase):
         ds["echo_range"] = self._wrap(range_t, ECHO_DIMS, stats=range_stats)
         self.range_meter = ds["echo_range"]
         if cal_type == "Sv":
-            ds["tau_effective"] = DataArray(tau_eff, ("channel",), attrs=dict(
+            tau_eff, te_dims = np.asarray(tau_eff, dtype=np.float64), ("channel",)
+            if tau_eff.ndim == 2:
+                # several filter intervals: one value per channel when all its intervals agree -- what the reference's
+                # merge of the slices needs (xr.merge(compat="no_conflicts"), calibrate/api.py:190-194) -- else the grid
+                ok = ~np.isnan(tau_eff)
+                first = np.array([row[m][0] if m.any() else np.nan for row, m in zip(tau_eff, ok)])
+                if np.all((tau_eff == first[:, None]) | ~ok):
+                    tau_eff = first
+                else:
+                    te_dims = ("channel", "ping_time")
+            ds["tau_effective"] = DataArray(tau_eff, te_dims, attrs=dict(
                 long_name="Effective pulse length", units="s",
                 description="Effective pulse length used for Sv. GPT uses transmit_duration_nominal."))
         ds["frequency_nominal"] = self.beam["frequency_nominal"]
@@ -185,8 +195,14 @@ class CalibrateEK(CalibrateBase):
         else:
             kw = {}
             g_t, sa_t = cpd(g, "gain_correction"), cpd(sa, "sa_correction")
+        si_t = cpd(self.beam["sample_interval"], "sample_interval")
+        plan = getattr(self, "_plan", None)
+        if plan is not None and (plan["replica_id"] < 0).any():  # pings no filter interval covers: NaN rows
+            si_h = cp_array(self.beam["sample_interval"], C, P).copy()
+            si_h[plan["replica_id"] < 0] = np.nan
+            si_t = self._dev(si_h, f64)
         coef = ops.power_coef_ek(
-            cpd(self.beam["sample_interval"], "sample_interval"),
+            si_t,
             cpd(self.beam["transmit_duration_nominal"], "transmit_duration_nominal"),
             cpd(self.beam["transmit_power"], "transmit_power"),
             cpd(self.env_params["sound_speed"], "sound_speed"),
@@ -248,8 +264,14 @@ class CalibrateEK80(CalibrateEK):
         self.vend = self.echodata["Vendor_specific"]
         # multi-filter_time files (calibrate_ek.py:323-333): one (channel, filter interval) slice,
         # or the filter set of each channel's first valid ping when a single set is assumed
+        self._plan = None
         if "channel" in self.slice_dict:
             self.beam, self.vend = _slice_beam_vend(self.beam, self.vend, self.slice_dict)
+        if self.slice_dict.get("filter_intervals"):
+            # every (channel, filter interval) pair of the file in ONE pass over the whole (channel, ping_time) grid:
+            # the reference calibrates slice by slice and merges (calibrate/api.py:125-197); here each pair gets its own
+            # replica / effective pulse length and every ping the index of its pair (_interval_plan, _tau_effective)
+            self.vend_full = self.vend
         if "first_valid_filter_time_per_channel" in self.slice_dict:
             self.vend = _collapse_vend(self.vend, self.slice_dict)
         elif "filter_time" in self.vend.sizes:
@@ -258,6 +280,10 @@ class CalibrateEK80(CalibrateEK):
         vch = list(map(str, self.vend["channel"].values))
         if bch != vch:  # vend.sel(channel=beam.channel) (:333)
             self.vend = self.vend.isel(channel=[vch.index(c) for c in bch])
+            if self.slice_dict.get("filter_intervals"):
+                self.vend_full = self.vend_full.isel(channel=[vch.index(c) for c in bch])
+        if self.slice_dict.get("filter_intervals"):
+            self._plan = self._interval_plan()
         C, P = self.beam["backscatter_r"].shape[:2]
         self._fc_collapsed = False
         if waveform_mode == "BB":
@@ -288,6 +314,76 @@ class CalibrateEK80(CalibrateEK):
         sz = self.beam["backscatter_r"].shape
         return sz[0], sz[1], sz[2]
 
+    # -- a file with several filter_time entries ----------------------------------------------------------------------
+    def _interval_plan(self):
+        """The (channel, filter interval) pairs the reference loops over (calibrate/api.py:133-160): per channel the
+        filter_time stamps that are ping times with a valid transmit_duration_nominal start an interval that runs to
+        1 ns before the next one (the last to the end of the file).  Returns dict(pairs=[(channel index, filter_time
+        index, ping indices)], replica_id (C, P) int32 -- the pair of every ping, -1 for a ping no interval covers)."""
+        C, P = self.beam["backscatter_r"].shape[:2]
+        tau = cp_array(self.beam["transmit_duration_nominal"], C, P)
+        pt = np.asarray(self.beam["ping_time"].values).astype("datetime64[ns]")
+        ft_all = np.asarray(self.vend_full["filter_time"].values).astype("datetime64[ns]")
+        ft_sorted = np.sort(ft_all)
+        pairs, rid = [], np.full((C, P), -1, dtype=np.int32)
+        for ci in range(C):
+            starts = np.intersect1d(pt[~np.isnan(tau[ci])], ft_sorted)
+            for k, start in enumerate(starts):
+                keep = pt >= start
+                if k + 1 < len(starts):
+                    keep &= pt <= starts[k + 1] - np.timedelta64(1, "ns")
+                idx = np.flatnonzero(keep)
+                rid[ci, idx] = len(pairs)
+                pairs.append((ci, int(np.flatnonzero(ft_all == start)[0]), idx))
+        return dict(pairs=pairs, replica_id=rid)
+
+    def _pair_views(self, ci, fi, idx):
+        """(beam parameters, vend) of one (channel, filter interval) pair: the few host arrays get_transmit_signal and
+        get_filter_coeff read -- never the samples."""
+        C, P = self.beam["backscatter_r"].shape[:2]
+        ch = np.asarray(self.beam["channel"].values)[ci:ci + 1]
+        pt = np.asarray(self.beam["ping_time"].values)[idx]
+        small = Dataset(coords={"channel": ch, "ping_time": pt})
+        for name in ("transmit_duration_nominal", "slope", "transmit_frequency_start", "transmit_frequency_stop",
+                     "transmit_type"):
+            if name in self.beam:
+                a = np.asarray(self.beam[name].values)
+                small[name] = (("channel", "ping_time"), a[ci:ci + 1][:, idx])
+        small["frequency_nominal"] = (("channel",), np.asarray(self.beam["frequency_nominal"].values)[ci:ci + 1])
+        return small, self.vend_full.isel(filter_time=fi, channel=[ci])
+
+    def _tau_effective(self, flag_complex):
+        if self._plan is None:
+            return super()._tau_effective(flag_complex)
+        # per (channel, interval): the replica of THAT filter set and its effective pulse length, with the reference's
+        # fallback to the nominal pulse length of the slice's first ping (calibrate_ek.py:113-151); GPT channels nominal
+        C, P = self.beam["backscatter_r"].shape[:2]
+        tau = cp_array(self.beam["transmit_duration_nominal"], C, P)
+        gpt = self._gpt_mask()
+        fs_all = self.cal_params.get("receiver_sampling_frequency")
+        te = np.full((C, P), np.nan)
+        txs = []
+        for ci, fi, idx in self._plan["pairs"]:
+            tau0 = tau[ci, idx[0]]
+            tx = None
+            try:
+                beam_k, vend_k = self._pair_views(ci, fi, idx)
+                fs = np.asarray(getattr(fs_all, "values", fs_all), dtype=np.float64)
+                fs = fs if fs.ndim == 0 else fs[ci:ci + 1]
+                tx_d, tx_time = get_transmit_signal(beam_k, get_filter_coeff(vend_k), self.waveform_mode, fs,
+                                                    self.drop_last_hanning_zero)
+                val = get_tau_effective(tx_d, {k: 1 / np.diff(v[:2]) for k, v in tx_time.items()}, self.waveform_mode,
+                                        beam_k["channel"]).values[0]
+                tx = np.asarray(next(iter(tx_d.values())))
+            except Exception as e:  # noqa: BLE001 - same catch-all as the reference
+                mode = "complex" if flag_complex else "power"
+                logger.warning("Could not compute tau_effective from transmit signal in %s encoding mode; "
+                               "falling back to transmit_duration_nominal. Error: %s", mode, repr(e))
+                val = tau0
+            te[ci, idx] = tau0 if gpt[ci] else val
+            txs.append(tx)
+        return te, txs
+
     _FC_KEYS = ("sound_absorption", "gain_correction", "equivalent_beam_angle", "impedance_transducer",
                 "angle_offset_alongship", "angle_offset_athwartship", "angle_sensitivity_alongship",
                 "angle_sensitivity_athwartship", "beamwidth_alongship", "beamwidth_athwartship")
@@ -295,6 +391,18 @@ class CalibrateEK80(CalibrateEK):
     def _add_params_to_output(self, ds_out):
         """Parameters evaluated per channel because the centre frequency does not change along ping_time go out with
         the (channel, ping_time) dimensions the reference gives them (zero-copy broadcast views)."""
+        ds_out = self._add_params(ds_out)
+        if self._plan is not None and (self._plan["replica_id"] < 0).any():
+            # pings no filter interval covers are in none of the reference's slices: NaN after its outer join
+            hole = self._plan["replica_id"] < 0
+            for name, da in list(ds_out.data_vars.items()):
+                if tuple(da.dims) == ("channel", "ping_time") and da.dtype.kind == "f":
+                    a = np.array(da.values, dtype=np.float64)
+                    a[hole] = np.nan
+                    ds_out[name] = DataArray(a, da.dims, attrs=da.attrs)
+        return ds_out
+
+    def _add_params(self, ds_out):
         if not self._fc_collapsed:
             return super()._add_params_to_output(ds_out)
         C, P, _ = self._shape()
@@ -330,7 +438,11 @@ class CalibrateEK80(CalibrateEK):
         B = self.beam["backscatter_r"].shape[3]
         bb = self.waveform_mode == "BB"
         tau_eff, tx = self._tau_effective(True)
-        if tx is None:
+        plan = self._plan
+        if plan is not None and bb and any(t is None for t in tx):
+            raise ValueError("a filter interval without a usable transmit replica: broadband samples cannot be "
+                             "pulse-compressed (assume_single_filter_time=True calibrates with the first filter set)")
+        if plan is None and tx is None:
             coeff = get_filter_coeff(self.vend)
             tx, _ = get_transmit_signal(self.beam, coeff, self.waveform_mode,
                                         self.cal_params["receiver_sampling_frequency"],
@@ -348,7 +460,12 @@ class CalibrateEK80(CalibrateEK):
             return self._dev(cp_array(v, C, P, name), torch.float64)
 
         cpar, env = self.cal_params, self.env_params
-        params = dict(sample_interval=dv(self.beam["sample_interval"], "sample_interval"),
+        si_param = dv(self.beam["sample_interval"], "sample_interval")
+        if plan is not None and (plan["replica_id"] < 0).any():  # uncovered pings: a NaN row -> NaN Sv and echo_range
+            si_h = cp_array(self.beam["sample_interval"], C, P).copy()
+            si_h[plan["replica_id"] < 0] = np.nan
+            si_param = self._dev(si_h, torch.float64)
+        params = dict(sample_interval=si_param,
                       tau_nominal=dv(self.beam["transmit_duration_nominal"], "transmit_duration_nominal"),
                       transmit_power=dv(self.beam["transmit_power"], "transmit_power"),
                       sound_speed=dv(env["sound_speed"], "sound_speed"), absorption=dv(env["sound_absorption"], "sound_absorption"),
@@ -362,11 +479,13 @@ class CalibrateEK80(CalibrateEK):
                 params[k] = dv(cpar[k], k)
         cc_t = ops.complex_coef_ek80(params, self._dev(np.asarray(tau_eff, dtype=np.float64), torch.float64), C, P, B=B, bb=bb,
                                      cal_type=cal_type, gpt=self._dev(self._gpt_mask().astype(np.uint8)))
-        rep = off = None
+        rep = off = rid = None
         max_taps = 0
         if bb:
             chans = list(self.beam["channel"].values)
-            taps = [np.asarray(tx[ch]) for ch in chans]
+            taps = [np.asarray(tx[ch]) for ch in chans] if plan is None else [np.asarray(t) for t in tx]
+            if plan is not None:
+                rid = self._dev(np.ascontiguousarray(plan["replica_id"]))
             off_h = np.concatenate([[0], np.cumsum([t.size for t in taps])]).astype(np.int32)
             flat = np.concatenate(taps).astype(np.complex64)
             rep = self._dev(np.ascontiguousarray(flat.view(np.float32)))
@@ -376,7 +495,7 @@ class CalibrateEK80(CalibrateEK):
         im = self._dev(self.beam["backscatter_i"].data)
         if re.dtype not in (torch.float32, torch.float64):
             re, im = re.double(), im.double()
-        return dict(re=re, im=im, ccoef=cc_t, replica=rep, replica_off=off, max_taps=max_taps), tau_eff
+        return dict(re=re, im=im, ccoef=cc_t, replica=rep, replica_off=off, max_taps=max_taps, replica_id=rid), tau_eff
 
     def _cal_complex_samples(self, cal_type):
         """One fused pass for calibrate_ek.py:532-659 (+ ek80_complex.py:285-391 for BB)."""
@@ -386,7 +505,7 @@ class CalibrateEK80(CalibrateEK):
         lazy = k["replica"] is None or ops.sv_complex_uses_fft(k["replica"], k["max_taps"])
         res = ops.sv_complex(k["re"], k["im"], k["ccoef"], replica=k["replica"], replica_off=k["replica_off"],
                              max_taps=k["max_taps"], cal_type=cal_type, dtype=self.dtype, fft_dtype=self.fft_dtype,
-                             want_range=not lazy, want_range_stats=True)
+                             want_range=not lazy, want_range_stats=True, replica_id=k["replica_id"])
         range_t = res["echo_range"]
         if lazy:
             re, ccoef, dtype, version = k["re"], k["ccoef"], self.dtype, k["re"]._version

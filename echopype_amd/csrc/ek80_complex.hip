@@ -60,7 +60,9 @@ struct CxArgs {
   const void* re;
   const void* im;
   const float* replica;        // interleaved (re, im) f32
-  const int32_t* replica_off;  // [C+1] in complex elements, or NULL (CW)
+  const int32_t* replica_off;  // [n_replicas + 1] in complex elements, or NULL (CW)
+  const int32_t* replica_id;   // optional [C*P]: the replica of ping (c, p) (a file with several filter_time intervals:
+                               // one replica per (channel, interval)); NULL: replica c for every ping of channel c
   const double* ccoef;
   int C, P, S, B;
   int tiles;
@@ -185,7 +187,9 @@ __global__ __launch_bounds__(epa::kBlock, EPA_EK80_MIN_WAVES) void sv_complex_ke
   int taps = 0;
   A norm2 = (A)1;
   if (a.replica) {
-    const int r0 = a.replica_off[c], r1 = a.replica_off[c + 1];
+    // (a ping no interval covers has id -1 and a NaN coefficient row: whatever it is convolved with, its output is NaN)
+    const int rid = a.replica_id ? max(a.replica_id[(size_t)c * a.P + p], 0) : c;
+    const int r0 = a.replica_off[rid], r1 = a.replica_off[rid + 1];
     taps = r1 - r0;
     const int taps8 = (taps + kR - 1) / kR * kR;
     A part = (A)0;
@@ -487,7 +491,7 @@ int launch(CxArgs& a, int max_taps, hipStream_t st) {
 }  // namespace
 
 static int sv_complex_entry(const void* re, const void* im, int in_dtype, const float* replica,
-                            const int32_t* replica_off, int max_taps, const double* ccoef, int C,
+                            const int32_t* replica_off, const int32_t* replica_id, int max_taps, const double* ccoef, int C,
                             int P, int S, int B, int cal_type, void* out, void* range_out,
                             void* prx_out, int out_dtype, double* stats_part, epa_stream_t stream) {
   EPA_CHECK_ARG(re && im && ccoef && out, "epa_sv_complex: NULL array argument");
@@ -498,7 +502,7 @@ static int sv_complex_entry(const void* re, const void* im, int in_dtype, const 
                 "epa_sv_complex: replica and replica_off must both be given (BB) or both NULL (CW)");
   EPA_CHECK_ARG(!replica || max_taps > 0, "epa_sv_complex: max_taps must be positive for BB");
   CxArgs a{};
-  a.re = re; a.im = im; a.replica = replica; a.replica_off = replica_off; a.ccoef = ccoef;
+  a.re = re; a.im = im; a.replica = replica; a.replica_off = replica_off; a.replica_id = replica_id; a.ccoef = ccoef;
   a.C = C; a.P = P; a.S = S; a.B = B;
   a.nspread = cal_type == EPA_CAL_SV ? 20.0 : 40.0;
   a.out = out; a.range_out = range_out; a.prx_out = prx_out;
@@ -525,8 +529,18 @@ extern "C" int epa_sv_complex(const void* re, const void* im, int in_dtype, cons
                               const int32_t* replica_off, int max_taps, const double* ccoef, int C,
                               int P, int S, int B, int cal_type, void* out, void* range_out,
                               void* prx_out, int out_dtype, epa_stream_t stream) {
-  return sv_complex_entry(re, im, in_dtype, replica, replica_off, max_taps, ccoef, C, P, S, B, cal_type, out, range_out,
-                          prx_out, out_dtype, nullptr, stream);
+  return sv_complex_entry(re, im, in_dtype, replica, replica_off, nullptr, max_taps, ccoef, C, P, S, B, cal_type, out,
+                          range_out, prx_out, out_dtype, nullptr, stream);
+}
+
+extern "C" int epa_sv_complex_indexed(const void* re, const void* im, int in_dtype, const float* replica,
+                                      const int32_t* replica_off, const int32_t* replica_id, int n_replicas,
+                                      int max_taps, const double* ccoef, int C, int P, int S, int B, int cal_type,
+                                      void* out, void* range_out, void* prx_out, int out_dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(replica && replica_off && replica_id && n_replicas > 0,
+                "epa_sv_complex_indexed: replica, replica_off, replica_id and a positive n_replicas are needed");
+  return sv_complex_entry(re, im, in_dtype, replica, replica_off, replica_id, max_taps, ccoef, C, P, S, B, cal_type, out,
+                          range_out, prx_out, out_dtype, nullptr, stream);
 }
 
 extern "C" int epa_sv_complex_cw_stats(const void* re, const void* im, int in_dtype, const double* ccoef, int C, int P,
@@ -537,7 +551,7 @@ extern "C" int epa_sv_complex_cw_stats(const void* re, const void* im, int in_dt
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(cw_stats_init_kernel, dim3(1), dim3(epa::kBlock), 0, st, workspace);
   if (int rc = epa::check_launch("cw_stats_init_kernel")) return rc;
-  if (int rc = sv_complex_entry(re, im, in_dtype, nullptr, nullptr, 0, ccoef, C, P, S, B, cal_type, out, range_out,
+  if (int rc = sv_complex_entry(re, im, in_dtype, nullptr, nullptr, nullptr, 0, ccoef, C, P, S, B, cal_type, out, range_out,
                                 prx_out, out_dtype, workspace, stream))
     return rc;
   return epa_minmax_final(workspace, kCwStatSlots, range_stats_out, st);

@@ -583,6 +583,8 @@ struct FftArgs {
   const double* ccoef;
   const double* ws;
   int C, P, S, B;
+  int W;  // what the workspace layout was sized for: max(C, number of replicas)
+  const int32_t* replica_id;  // optional [C*P]: the replica (spectrum, norm) of ping (c, p); NULL: replica c
   int tiles, out_per_tile;
   double nspread;
   void* out;
@@ -789,11 +791,15 @@ __device__ __forceinline__ void process_tile(const FftArgs& a, const TileLds<F, 
   const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
   const int S = a.S, B = NB > 0 ? NB : a.B;
   const int k_begin = tile * a.out_per_tile;
-  const double* chan = a.ws + ws_chan() + 4 * (size_t)c;
+  // the ping's replica: its channel's, or -- a file with several filter_time intervals -- the one of its (channel,
+  // interval) pair (a ping no interval covers has id -1 and a NaN coefficient row: its output is NaN whatever it is
+  // correlated with)
+  const int rid = a.replica_id ? max(a.replica_id[(size_t)c * a.P + p], 0) : c;
+  const double* chan = a.ws + ws_chan() + 4 * (size_t)rid;
   const InT* re = reinterpret_cast<const InT*>(a.re);
   const InT* im = reinterpret_cast<const InT*>(a.im);
   const size_t ping_base = ((size_t)c * a.P + p) * (size_t)S * B;
-  const C2<F>* spec = reinterpret_cast<const C2<F>*>(a.ws + (sizeof(F) == 4 ? ws_spec32(a.C, c) : ws_spec64(a.C, c)));
+  const C2<F>* spec = reinterpret_cast<const C2<F>*>(a.ws + (sizeof(F) == 4 ? ws_spec32(a.W, rid) : ws_spec64(a.W, rid)));
   const unsigned full = (1u << B) - 1u;
 
   // the ping's and the channel's numbers of the epilogue, read before anything is written: uniform addresses with no
@@ -1167,11 +1173,36 @@ extern "C" int epa_range_complex(const void* re, int in_dtype, const double* cco
   return epa::check_launch("range_complex_kernel");
 }
 
+static int sv_complex_fft_entry(const void* re, const void* im, int in_dtype, const float* replica,
+                                const int32_t* replica_off, const int32_t* replica_id, int n_replicas, int max_taps,
+                                const double* ccoef, int C, int P, int S, int B, int cal_type, void* out,
+                                void* range_out, void* prx_out, int out_dtype, int fft_dtype, double* workspace,
+                                double* range_stats_out, epa_stream_t stream);
+
 extern "C" int epa_sv_complex_fft(const void* re, const void* im, int in_dtype, const float* replica,
                                   const int32_t* replica_off, int max_taps, const double* ccoef, int C,
                                   int P, int S, int B, int cal_type, void* out, void* range_out,
                                   void* prx_out, int out_dtype, int fft_dtype, double* workspace,
                                   double* range_stats_out, epa_stream_t stream) {
+  return sv_complex_fft_entry(re, im, in_dtype, replica, replica_off, nullptr, C, max_taps, ccoef, C, P, S, B, cal_type,
+                              out, range_out, prx_out, out_dtype, fft_dtype, workspace, range_stats_out, stream);
+}
+
+extern "C" int epa_sv_complex_fft_indexed(const void* re, const void* im, int in_dtype, const float* replica,
+                                          const int32_t* replica_off, const int32_t* replica_id, int n_replicas,
+                                          int max_taps, const double* ccoef, int C, int P, int S, int B, int cal_type,
+                                          void* out, void* range_out, void* prx_out, int out_dtype, int fft_dtype,
+                                          double* workspace, double* range_stats_out, epa_stream_t stream) {
+  EPA_CHECK_ARG(replica_id && n_replicas > 0, "epa_sv_complex_fft_indexed: replica_id and a positive n_replicas are needed");
+  return sv_complex_fft_entry(re, im, in_dtype, replica, replica_off, replica_id, n_replicas, max_taps, ccoef, C, P, S, B,
+                              cal_type, out, range_out, prx_out, out_dtype, fft_dtype, workspace, range_stats_out, stream);
+}
+
+static int sv_complex_fft_entry(const void* re, const void* im, int in_dtype, const float* replica,
+                                const int32_t* replica_off, const int32_t* replica_id, int n_replicas, int max_taps,
+                                const double* ccoef, int C, int P, int S, int B, int cal_type, void* out,
+                                void* range_out, void* prx_out, int out_dtype, int fft_dtype, double* workspace,
+                                double* range_stats_out, epa_stream_t stream) {
   EPA_CHECK_ARG(re && im && ccoef && out && replica && replica_off && workspace,
                 "epa_sv_complex_fft: NULL array argument");
   EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && B > 0, "epa_sv_complex_fft: C=%d P=%d S=%d B=%d", C, P, S, B);
@@ -1185,26 +1216,28 @@ extern "C" int epa_sv_complex_fft(const void* re, const void* im, int in_dtype, 
     return EPA_EUNSUPPORTED;
   }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(replica_prepare_kernel, dim3(C), dim3(epa::kBlock), 0, st, replica, replica_off, C, workspace,
-                     range_stats_out ? 1 : 0, workspace + ws_logtab(C, P, S));
+  const int W = n_replicas > C ? n_replicas : C;  // the workspace layout is that of W "channels" (header: WS_DOUBLES)
+  hipLaunchKernelGGL(replica_prepare_kernel, dim3(n_replicas), dim3(epa::kBlock), 0, st, replica, replica_off, W, workspace,
+                     range_stats_out ? 1 : 0, workspace + ws_logtab(W, P, S));
   if (int rc = epa::check_launch("replica_prepare_kernel")) return rc;
   FftArgs a{};
   a.re = re; a.im = im; a.ccoef = ccoef; a.ws = workspace;
   a.C = C; a.P = P; a.S = S; a.B = B;
+  a.W = W; a.replica_id = replica_id;
   a.out_per_tile = kN - max_taps + 1;
   a.tiles = (S + a.out_per_tile - 1) / a.out_per_tile;
   a.nspread = cal_type == EPA_CAL_SV ? 20.0 : 40.0;
   a.out = out; a.range_out = range_out; a.prx_out = prx_out;
-  a.stats_part = range_stats_out ? workspace + ws_stats(C) : nullptr;
+  a.stats_part = range_stats_out ? workspace + ws_stats(W) : nullptr;
   const size_t ntiles = (size_t)C * P * a.tiles;
   EPA_CHECK_ARG(ntiles < ((size_t)1 << 36), "epa_sv_complex_fft: too many tiles");
   a.map_words = (int)((ntiles + 31) / 32);
-  a.mixed_cnt = reinterpret_cast<unsigned*>(workspace + ws_mixed(C));
+  a.mixed_cnt = reinterpret_cast<unsigned*>(workspace + ws_mixed(W));
   a.mixed_map = a.mixed_cnt + 2;
   EPA_CHECK_HIP(hipMemsetAsync(a.mixed_cnt, 0, 8 + 4 * (size_t)a.map_words, st));
-  double* tvg = workspace + ws_tvg(C, P, S);
+  double* tvg = workspace + ws_tvg(W, P, S);
   a.tvg = tvg;
-  a.log_tab = workspace + ws_logtab(C, P, S);
+  a.log_tab = workspace + ws_logtab(W, P, S);
   {
     const dim3 tg((unsigned)((S + epa::kBlock - 1) / epa::kBlock), (unsigned)C);
     if (out_dtype == EPA_F64) {

@@ -16,7 +16,7 @@ struct CoefArgs {
   int C, P, K;
   const double *si, *tau, *pt;
   const double *ss, *ab, *gain, *sa, *pl;
-  int ss_mode, ab_mode, gain_mode, sa_mode, psi_mode;
+  int ss_mode, ab_mode, gain_mode, sa_mode, psi_mode, taueff_mode;
   const double *psi, *fnom, *taueff;
   const uint8_t* gpt;
   int sonar, cal_type;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(epa::kBlock) void power_coef_ek_kernel(CoefArgs a) 
   double A;
   if (a.cal_type == EPA_CAL_SV) {
     const double CSv = 10 * log10(pt) + 2 * G + fetch(a.psi, a.psi_mode, c, idx) +
-                       10 * log10(lambda * lambda * a.taueff[c] * cw / (32 * pi * pi));
+                       10 * log10(lambda * lambda * fetch(a.taueff, a.taueff_mode, c, idx) * cw / (32 * pi * pi));
     A = -CSv - 2 * sa;
   } else {
     const double CSp = 10 * log10(pt) + 2 * G + 10 * log10(lambda * lambda / (16 * pi * pi));
@@ -94,6 +94,7 @@ struct CCoefArgs {
   const double* p[EPA_CCP_COUNT];
   int mode[EPA_CCP_COUNT];
   const double* taueff;
+  int taueff_mode;
   const uint8_t* gpt;
   double* ccoef;
 };
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(epa::kBlock) void complex_coef_ek80_kernel(CCoefArg
   const double pi = 3.141592653589793;
   double A;
   if (a.cal_type == EPA_CAL_SV) {                    // calibrate_ek.py:610-638
-    A = -10 * log10(lambda * lambda * pt * cw / (32 * pi * pi)) - 2 * gain - 10 * log10(a.taueff[c]) - get(EPA_CCP_PSI);
+    A = -10 * log10(lambda * lambda * pt * cw / (32 * pi * pi)) - 2 * gain - 10 * log10(fetch(a.taueff, a.taueff_mode, c, idx)) - get(EPA_CCP_PSI);
     if (!a.bb) A -= 2 * get(EPA_CCP_SA_CORRECTION);
   } else {
     A = -10 * log10(lambda * lambda * pt / (16 * pi * pi)) - 2 * gain;
@@ -175,8 +176,8 @@ extern "C" int epa_power_coef_ek(int C, int P, const double* sample_interval,
                                  int abs_mode, const double* gain, int gain_mode,
                                  const double* sa_correction, int sa_mode,
                                  const double* pulse_length, int K, const double* psi, int psi_mode,
-                                 const double* f_nominal, const double* tau_eff, const uint8_t* gpt,
-                                 int sonar, int cal_type, double* coef, epa_stream_t stream) {
+                                 const double* f_nominal, const double* tau_eff, int tau_eff_mode,
+                                 const uint8_t* gpt, int sonar, int cal_type, double* coef, epa_stream_t stream) {
   EPA_CHECK_ARG(C > 0 && P > 0, "epa_power_coef_ek: C=%d P=%d must be positive", C, P);
   EPA_CHECK_ARG(sample_interval && tau_nominal && transmit_power && sound_speed && absorption &&
                     gain && sa_correction && psi && f_nominal && tau_eff && coef,
@@ -186,13 +187,15 @@ extern "C" int epa_power_coef_ek(int C, int P, const double* sample_interval,
   EPA_CHECK_ARG(gain_mode >= 0 && gain_mode <= 3 && sa_mode >= 0 && sa_mode <= 3,
                 "epa_power_coef_ek: bad gain/sa mode");
   EPA_CHECK_ARG(psi_mode >= 0 && psi_mode <= 2, "epa_power_coef_ek: bad equivalent_beam_angle mode");
+  EPA_CHECK_ARG(tau_eff_mode == EPA_PM_CHANNEL || tau_eff_mode == EPA_PM_CHANNEL_PING,
+                "epa_power_coef_ek: tau_eff is per channel or per (channel, ping)");
   if (gain_mode == EPA_PM_PULSE_TABLE || sa_mode == EPA_PM_PULSE_TABLE)
     EPA_CHECK_ARG(pulse_length != nullptr && K > 0,
                   "epa_power_coef_ek: pulse-table mode needs pulse_length and K > 0");
   EPA_CHECK_ARG(sonar == EPA_SONAR_EK60 || sonar == EPA_SONAR_EK80, "epa_power_coef_ek: bad sonar");
   EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_power_coef_ek: bad cal_type");
   CoefArgs a{C, P, K, sample_interval, tau_nominal, transmit_power, sound_speed, absorption, gain,
-             sa_correction, pulse_length, ss_mode, abs_mode, gain_mode, sa_mode, psi_mode, psi, f_nominal,
+             sa_correction, pulse_length, ss_mode, abs_mode, gain_mode, sa_mode, psi_mode, tau_eff_mode, psi, f_nominal,
              tau_eff, gpt, sonar, cal_type, coef};
   const long long n = (long long)C * P;
   const int grid = (int)((n + epa::kBlock - 1) / epa::kBlock);
@@ -201,11 +204,13 @@ extern "C" int epa_power_coef_ek(int C, int P, const double* sample_interval,
 }
 
 extern "C" int epa_complex_coef_ek80(int C, int P, const double* const* params, const int* modes,
-                                     const double* tau_eff, const uint8_t* gpt, int B, int bb, int cal_type,
-                                     double* ccoef, epa_stream_t stream) {
+                                     const double* tau_eff, int tau_eff_mode, const uint8_t* gpt, int B, int bb,
+                                     int cal_type, double* ccoef, epa_stream_t stream) {
   EPA_CHECK_ARG(C > 0 && P > 0 && B > 0, "epa_complex_coef_ek80: C=%d P=%d B=%d must be positive", C, P, B);
   EPA_CHECK_ARG(params && modes && tau_eff && ccoef, "epa_complex_coef_ek80: NULL array argument");
   EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_complex_coef_ek80: bad cal_type");
+  EPA_CHECK_ARG(tau_eff_mode == EPA_PM_CHANNEL || tau_eff_mode == EPA_PM_CHANNEL_PING,
+                "epa_complex_coef_ek80: tau_eff is per channel or per (channel, ping)");
   CCoefArgs a{};
   a.C = C; a.P = P; a.B = B; a.bb = bb ? 1 : 0; a.cal_type = cal_type;
   for (int k = 0; k < EPA_CCP_COUNT; ++k) {
@@ -216,7 +221,7 @@ extern "C" int epa_complex_coef_ek80(int C, int P, const double* const* params, 
     a.p[k] = params[k];
     a.mode[k] = modes[k];
   }
-  a.taueff = tau_eff; a.gpt = gpt; a.ccoef = ccoef;
+  a.taueff = tau_eff; a.taueff_mode = tau_eff_mode; a.gpt = gpt; a.ccoef = ccoef;
   const long long n = (long long)C * P;
   hipLaunchKernelGGL(complex_coef_ek80_kernel, dim3((unsigned)((n + epa::kBlock - 1) / epa::kBlock)), dim3(epa::kBlock), 0,
                      (hipStream_t)stream, a);

@@ -211,6 +211,15 @@ def _mode_of(t, C, P):
     raise ValueError(f"parameter of shape {tuple(t.shape)} is not scalar, (C,) or (C,P) with C={C}, P={P}")
 
 
+def _tau_mode(tau_eff, C, P):
+    """tau_effective: (C,) per channel, or (C, P) -- an EK80 file with several filter_time intervals."""
+    if tuple(tau_eff.shape) == (C,):
+        return _lib.PM_CHANNEL
+    if tuple(tau_eff.shape) == (C, P):
+        return _lib.PM_CHANNEL_PING
+    raise ValueError(f"tau_eff of shape {tuple(tau_eff.shape)}: expected ({C},) or ({C}, {P})")
+
+
 def power_coef_ek(sample_interval, tau_nominal, transmit_power, sound_speed, absorption, gain, sa,
                   psi, f_nominal, tau_eff, *, sonar="EK60", cal_type="Sv", pulse_length=None,
                   gain_is_table=False, sa_is_table=False, gpt=None):
@@ -223,7 +232,7 @@ def power_coef_ek(sample_interval, tau_nominal, transmit_power, sound_speed, abs
     call("epa_power_coef_ek", C, P, _p(sample_interval), _p(tau_nominal), _p(transmit_power),
          _p(sound_speed), _mode_of(sound_speed, C, P), _p(absorption), _mode_of(absorption, C, P),
          _p(gain), gmode, _p(sa), smode, _p(pulse_length), K, _p(psi), _mode_of(psi, C, P), _p(f_nominal), _p(tau_eff),
-         _p(gpt), _lib.SONAR_EK60 if sonar in ("EK60", "ES70") else _lib.SONAR_EK80,
+         _tau_mode(tau_eff, C, P), _p(gpt), _lib.SONAR_EK60 if sonar in ("EK60", "ES70") else _lib.SONAR_EK80,
          _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, _p(coef), _stream())
     return coef
 
@@ -503,7 +512,7 @@ def complex_coef_ek80(params, tau_eff, C, P, *, B, bb, cal_type="Sv", gpt=None):
         keep.append(t)
         ptrs[k], modes[k] = t.data_ptr(), _mode_of(t, C, P)
     out = torch.empty((C, P, _lib.NCCOEF), dtype=torch.float64, device=dev)
-    call("epa_complex_coef_ek80", C, P, ptrs, modes, _p(tau_eff), _p(gpt), int(B), 1 if bb else 0,
+    call("epa_complex_coef_ek80", C, P, ptrs, modes, _p(tau_eff), _tau_mode(tau_eff, C, P), _p(gpt), int(B), 1 if bb else 0,
          _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, _p(out), _stream())
     return out
 
@@ -532,14 +541,19 @@ def power_rows_of_complex(ccoef):
 
 def sv_complex(re, im, ccoef, *, replica=None, replica_off=None, max_taps=0, cal_type="Sv",
                dtype=torch.float64, want_range=True, want_prx=False, method="auto", fft_dtype=None,
-               want_range_stats=False):
+               want_range_stats=False, replica_id=None):
     """K3+K4 -> dict(out, echo_range, prx[, range_stats]).  ``method``: "direct" (sliding register window),
     "fft" (LDS-resident 2048-point FFT per tile) or "auto" (fft for replicas of 16 .. 1024 taps, where it is
     faster; direct otherwise and for CW).  ``fft_dtype``: arithmetic of the transform, default = ``dtype`` (float32
     output takes complex64 butterflies, as precise as that output; float64 output a complex128 transform).
     ``want_range_stats`` (fft form and CW): f64 device tensor {nanmin, nanmax, NaN count} of the echo_range as a by-product
-    of the same pass -- with ``want_range=False`` of the array range_complex would write."""
+    of the same pass -- with ``want_range=False`` of the array range_complex would write.
+    ``replica_id`` (C, P) int32: one replica per (channel, filter interval) instead of one per channel
+    (``replica_off`` then has one entry per replica + 1); -1 = a ping no interval covers (NaN coefficient row)."""
     C, P, S, B = re.shape
+    n_rep = C if replica_id is None else int(replica_off.numel()) - 1
+    if replica_id is not None and (replica is None or tuple(replica_id.shape) != (C, P) or replica_id.dtype != torch.int32):
+        raise ValueError("replica_id: int32 (C, P) next to replica / replica_off")
     if re.dtype != im.dtype or re.dtype not in _DT:
         raise ValueError("backscatter_r / backscatter_i must both be float32 or float64")
     if method not in ("auto", "direct", "fft"):
@@ -552,20 +566,29 @@ def sv_complex(re, im, ccoef, *, replica=None, replica_off=None, max_taps=0, cal
     use_fft = sv_complex_uses_fft(replica, max_taps, method)
     stats = None
     if use_fft:
-        n_ws = (768 + 4 * C + 3 * C * _lib.EK80_NFFT + 3 * 1024 + 2
-                + (C * P * (S // (_lib.EK80_NFFT // 2 + 1) + 1) + 63) // 64 + C * (S + 4) + 256)  # EPA_EK80_FFT_WS_DOUBLES
+        W = max(C, n_rep)
+        n_ws = (768 + 4 * W + 3 * W * _lib.EK80_NFFT + 3 * 1024 + 2
+                + (W * P * (S // (_lib.EK80_NFFT // 2 + 1) + 1) + 63) // 64 + W * (S + 4) + 256)  # EPA_EK80_FFT_WS_DOUBLES(W, P, S)
         ws = torch.empty(n_ws, dtype=torch.float64, device=dev)
         fdt = torch_dtype(fft_dtype) if fft_dtype is not None else dtype
         if want_range_stats:
             stats = torch.empty(3, dtype=torch.float64, device=dev)
-        call("epa_sv_complex_fft", _p(re), _p(im), _DT[re.dtype], _p(replica), _p(replica_off), int(max_taps),
-             _p(ccoef), C, P, S, B, cal, _p(out), _p(rng), _p(prx), _DT[dtype], _DT[fdt], _p(ws), _p(stats),
-             _stream())
+        if replica_id is None:
+            call("epa_sv_complex_fft", _p(re), _p(im), _DT[re.dtype], _p(replica), _p(replica_off), int(max_taps),
+                 _p(ccoef), C, P, S, B, cal, _p(out), _p(rng), _p(prx), _DT[dtype], _DT[fdt], _p(ws), _p(stats),
+                 _stream())
+        else:
+            call("epa_sv_complex_fft_indexed", _p(re), _p(im), _DT[re.dtype], _p(replica), _p(replica_off),
+                 _p(replica_id), n_rep, int(max_taps), _p(ccoef), C, P, S, B, cal, _p(out), _p(rng), _p(prx),
+                 _DT[dtype], _DT[fdt], _p(ws), _p(stats), _stream())
     elif replica is None and want_range_stats:  # CW: the streaming kernel leaves the statistics as well
         ws = torch.empty(3072, dtype=torch.float64, device=dev)  # EPA_SV_COMPLEX_CW_STATS_WS_DOUBLES
         stats = torch.empty(3, dtype=torch.float64, device=dev)
         call("epa_sv_complex_cw_stats", _p(re), _p(im), _DT[re.dtype], _p(ccoef), C, P, S, B, cal, _p(out), _p(rng),
              _p(prx), _DT[dtype], _p(ws), _p(stats), _stream())
+    elif replica_id is not None:
+        call("epa_sv_complex_indexed", _p(re), _p(im), _DT[re.dtype], _p(replica), _p(replica_off), _p(replica_id), n_rep,
+             int(max_taps), _p(ccoef), C, P, S, B, cal, _p(out), _p(rng), _p(prx), _DT[dtype], _stream())
     else:
         call("epa_sv_complex", _p(re), _p(im), _DT[re.dtype], _p(replica), _p(replica_off), int(max_taps),
              _p(ccoef), C, P, S, B, cal, _p(out), _p(rng), _p(prx), _DT[dtype], _stream())

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define EPA_VERSION 100 /* 0.1.0 */
+#define EPA_VERSION 101 /* 0.1.1: tau_eff per (channel, ping); replica indirection for files with several filter_time intervals */
 
 typedef void* epa_stream_t;
 
@@ -109,7 +109,9 @@ int epa_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the stop ev
  * pointer + epa_param_mode.  With EPA_PM_PULSE_TABLE, `gain`/`sa` are [C*K] tables matched against
  * pulse_length [C*K] by argmin_k |tau_nominal - pulse_length| (first minimum; NaN tau -> NaN).
  * psi (equivalent_beam_angle): pointer + epa_param_mode (scalar, [C] or [C*P]: calibrate_ek.py:154-162 broadcasts any
- * (channel, ping_time) cal parameter into CSv; Sv only).  f_nominal, tau_eff: [C].  gpt: [C] bytes or NULL (EK80: channels with GPT transceivers).
+ * (channel, ping_time) cal parameter into CSv; Sv only).  f_nominal: [C].  tau_eff: [C] (EPA_PM_CHANNEL) or [C*P]
+ * (EPA_PM_CHANNEL_PING: an EK80 file with several filter_time intervals has one effective pulse length per (channel,
+ * interval), calibrate/api.py:125-197).  gpt: [C] bytes or NULL (EK80: channels with GPT transceivers).
  * coef out: [C*P*EPA_NCOEF].
  */
 int epa_power_coef_ek(int C, int P, const double* sample_interval, const double* tau_nominal,
@@ -117,7 +119,7 @@ int epa_power_coef_ek(int C, int P, const double* sample_interval, const double*
                       const double* absorption, int abs_mode, const double* gain, int gain_mode,
                       const double* sa_correction, int sa_mode, const double* pulse_length, int K,
                       const double* psi, int psi_mode, const double* f_nominal, const double* tau_eff,
-                      const uint8_t* gpt, int sonar, int cal_type, double* coef, epa_stream_t stream);
+                      int tau_eff_mode, const uint8_t* gpt, int sonar, int cal_type, double* coef, epa_stream_t stream);
 
 /* The pulse-length table lookup on its own (calibrate/cal_params.py:261-324 get_vend_cal_params_power): out[c,p] =
  * table[c, argmin_k |tau_nominal[c,p] - pulse_length[c,k]|] (first minimum; NaN tau -> NaN).  What compute_Sv attaches to
@@ -355,19 +357,30 @@ enum epa_ccoef_slot { EPA_CC_RA = 0, EPA_CC_RB = 1, EPA_CC_SHIFT = 2, EPA_CC_ALP
  * epa_power_coef_ek; replaces the (channel, ping_time) arithmetic of calibrate_ek.py:483-490, 507-530, 583-638 and
  * range.py:180-199).  params / modes: HOST arrays of EPA_CCP_COUNT DEVICE pointers (f64) and their epa_param_mode
  * (SCALAR, CHANNEL [C] or CHANNEL_PING [C*P]), indexed by epa_ccoef_param; entries a mode does not use may be NULL
- * (the angle offsets / beamwidths without bb; sa_correction with bb or TS; psi with TS).  tau_eff: f64 [C] (device);
+ * (the angle offsets / beamwidths without bb; sa_correction with bb or TS; psi with TS).  tau_eff: f64 [C] or [C*P] (device;
+ * tau_eff_mode EPA_PM_CHANNEL / EPA_PM_CHANNEL_PING as for epa_power_coef_ek);
  * gpt: u8 [C] or NULL.  bb != 0: broadband (gain is compensated by B(theta, phi), no sa_correction). */
 enum epa_ccoef_param { EPA_CCP_SAMPLE_INTERVAL = 0, EPA_CCP_TAU_NOMINAL, EPA_CCP_TRANSMIT_POWER, EPA_CCP_SOUND_SPEED,
                        EPA_CCP_ABSORPTION, EPA_CCP_GAIN, EPA_CCP_FREQ_CENTER, EPA_CCP_PSI, EPA_CCP_SA_CORRECTION,
                        EPA_CCP_Z_ER, EPA_CCP_Z_ET, EPA_CCP_ANGLE_OFFSET_ALONGSHIP, EPA_CCP_ANGLE_OFFSET_ATHWARTSHIP,
                        EPA_CCP_BEAMWIDTH_ALONGSHIP, EPA_CCP_BEAMWIDTH_ATHWARTSHIP, EPA_CCP_COUNT };
 int epa_complex_coef_ek80(int C, int P, const double* const* params, const int* modes, const double* tau_eff,
-                          const uint8_t* gpt, int B, int bb, int cal_type, double* ccoef, epa_stream_t stream);
+                          int tau_eff_mode, const uint8_t* gpt, int B, int bb, int cal_type, double* ccoef,
+                          epa_stream_t stream);
 
 int epa_sv_complex(const void* re, const void* im, int in_dtype, const float* replica,
                    const int32_t* replica_off, int max_taps, const double* ccoef, int C, int P,
                    int S, int B, int cal_type, void* out, void* range_out, void* prx_out,
                    int out_dtype, epa_stream_t stream);
+/* The same with one replica per (channel, filter interval) instead of one per channel -- an EK80 file with several
+ * filter_time entries, which the reference calibrates slice by slice and merges (calibrate/api.py:125-197): ONE launch
+ * over the whole (channel, ping_time) grid.  replica_off: int32 [n_replicas + 1]; replica_id: int32 [C*P], the replica
+ * of every ping, -1 for a ping no interval covers (give it a NaN coefficient row: its output and range are NaN, the
+ * outer join's fill). */
+int epa_sv_complex_indexed(const void* re, const void* im, int in_dtype, const float* replica,
+                           const int32_t* replica_off, const int32_t* replica_id, int n_replicas, int max_taps,
+                           const double* ccoef, int C, int P, int S, int B, int cal_type, void* out, void* range_out,
+                           void* prx_out, int out_dtype, epa_stream_t stream);
 
 /* Same result for long replicas through an LDS-resident 2048-point FFT per tile (the matched filter as a
  * circular correlation; scipy.signal.convolve's method="auto" makes the same switch in the reference,
@@ -394,6 +407,13 @@ int epa_sv_complex_fft(const void* re, const void* im, int in_dtype, const float
                        int S, int B, int cal_type, void* out, void* range_out, void* prx_out,
                        int out_dtype, int fft_dtype, double* workspace, double* range_stats_out,
                        epa_stream_t stream);
+/* ... with one replica per (channel, filter interval), as epa_sv_complex_indexed.  workspace: f64
+ * [EPA_EK80_FFT_WS_DOUBLES(max(C, n_replicas), P, S)]. */
+int epa_sv_complex_fft_indexed(const void* re, const void* im, int in_dtype, const float* replica,
+                               const int32_t* replica_off, const int32_t* replica_id, int n_replicas, int max_taps,
+                               const double* ccoef, int C, int P, int S, int B, int cal_type, void* out,
+                               void* range_out, void* prx_out, int out_dtype, int fft_dtype, double* workspace,
+                               double* range_stats_out, epa_stream_t stream);
 
 /* epa_sv_complex on CW samples (no replica) with {nanmin, nanmax, NaN count} of the echo_range as a by-product
  * (range_stats_out f64 [3]; merged through 1024 slots of f64 atomics in workspace, f64

@@ -37,7 +37,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     from echopype_amd import _lib
 
     assert sorted(_lib.SIGNATURES) == declared_symbols()
-    assert _lib.lib.epa_version() == 100
+    assert _lib.lib.epa_version() == 101
 
 
 def test_library_contains_gfx950_code_object_only():

@@ -169,6 +169,87 @@ def test_compute_Sv_ek80_multi_filter_time_equals_single(ep):
     np.testing.assert_allclose(merged["sound_absorption"].values, single["sound_absorption"].values)
 
 
+@pytest.mark.parametrize("wf", ["BB", "CW"])
+@pytest.mark.parametrize("method", ["auto", "direct"])
+def test_compute_Sv_ek80_filter_intervals_with_different_replicas_in_one_launch(ep, wf, method, monkeypatch):
+    """A file whose filter_time intervals carry DIFFERENT filters (so replicas of different lengths and effective pulse
+    lengths) and whose first pings precede the first filter_time: the reference calibrates every (channel, interval)
+    slice on its own and merges with an outer join (calibrate/api.py:125-197).  Here ONE launch covers the grid (a
+    replica index per ping, epa_sv_complex[_fft]_indexed) -- held to the slices calibrated one by one as single-filter
+    files and merged in NumPy: NaN for the pings no interval covers, Sv / echo_range bit for bit elsewhere."""
+    from echopype_amd import _lib, ops
+
+    C, P, S = 2, 14, 2300
+    d, filt = _ek80(ep, wf, C=C, P=P, S=S, mixed_nan=True)
+    # (an EK80 file records ONE sound speed, from_ek80_arrays takes the first ping's: the same for the file and its slices)
+    d["sound_speed"] = np.full_like(d["sound_speed"], d["sound_speed"].flat[0])
+    starts = [2, 6, 10]                                   # pings 0, 1 lie before the first filter_time
+    k61 = np.arange(61)
+    filt2 = dict(filt, pc_fil=(np.hanning(61) * np.exp(2j * np.pi * 0.11 * k61) / 15).astype(np.complex64))
+    filts = [filt, filt2, filt]
+    ed = ep.echodata.from_ek80_arrays(d, filt, filter_time_idx=starts)
+    vend = ed["Vendor_specific"]
+    n_pc = vend["PC_coeffs_real"].shape[2]
+    for name, part in (("PC_coeffs_real", np.real), ("PC_coeffs_imag", np.imag)):   # the second interval's PC filter
+        a = np.array(vend[name].values)
+        a[:, 1, :] = np.nan
+        a[:, 1, :61] = part(filt2["pc_fil"])
+        vend[name] = (vend[name].dims, a)
+    assert n_pc >= 61
+    if method == "direct":
+        monkeypatch.setattr(ops, "sv_complex_uses_fft", lambda *a, **k: False)
+    kw = dict(waveform_mode=wf, encode_mode="complex")
+    with _lib.launch_trace() as tr:
+        got = ep.calibrate.compute_Sv(ed, **kw)
+    sample_kernels = [k for k in tr.kernels if k in ("sv_complex_kernel", "sv_complex_fft_kernel", "sv_complex_cw_kernel")]
+    assert len(sample_kernels) == 1, tr.kernels          # one launch for all six (channel, interval) pairs
+    if wf == "BB":
+        assert sample_kernels == ["sv_complex_fft_kernel" if method == "auto" else "sv_complex_kernel"]
+    exp_sv = np.full((C, P, S), np.nan)
+    exp_r = np.full((C, P, S), np.nan)
+    exp_te = np.full((C, P), np.nan)
+    bounds = starts + [P]
+    per_ping = ("backscatter_r", "backscatter_i", "sample_interval", "sound_speed")
+    for ci in range(C):
+        for k in range(3):
+            a, b = bounds[k], bounds[k + 1]
+            dk = {}
+            for key, v in d.items():
+                if key in per_ping:
+                    dk[key] = np.ascontiguousarray(v[ci:ci + 1, a:b])
+                elif key == "ping_time":
+                    dk[key] = v[a:b]
+                elif key == "channel":
+                    dk[key] = v[ci:ci + 1]
+                elif isinstance(v, np.ndarray) and v.shape[:1] == (C,):
+                    dk[key] = v[ci:ci + 1]
+                else:
+                    dk[key] = v
+            one = ep.calibrate.compute_Sv(ep.echodata.from_ek80_arrays(dk, filts[k]), **kw)
+            exp_sv[ci, a:b], exp_r[ci, a:b] = one["Sv"].values[0], one["echo_range"].values[0]
+            exp_te[ci, a:b] = one["tau_effective"].values[0]
+    if wf == "BB" and method == "auto":
+        # the overlap-save tiles are laid out for the LONGEST replica of the launch (2048 - max_taps + 1 outputs each):
+        # a slice calibrated on its own is tiled for its own replica, so the transforms round differently (~1e-7 dB;
+        # the reference's own tolerance for broadband Sv is 2e-3 dB)
+        np.testing.assert_array_equal(np.isnan(got["Sv"].values), np.isnan(exp_sv))
+        np.testing.assert_allclose(got["Sv"].values, exp_sv, rtol=0, atol=1e-5, equal_nan=True)
+    else:
+        np.testing.assert_array_equal(got["Sv"].values, exp_sv)
+    np.testing.assert_array_equal(got["echo_range"].values, exp_r)
+    assert np.isnan(got["Sv"].values[:, :2]).all() and np.isfinite(got["Sv"].values[:, 2:]).any()
+    # the second interval's filter gives another effective pulse length: tau_effective goes out per (channel, ping)
+    assert got["tau_effective"].dims == ("channel", "ping_time")
+    np.testing.assert_array_equal(got["tau_effective"].values, exp_te)
+    assert exp_te[0, 3] != exp_te[0, 7] and exp_te[0, 3] == exp_te[0, 11]
+    # (channel, ping_time) parameters are NaN where no slice exists (the outer join's fill)
+    grid_vars = [n for n, v in got.data_vars.items() if tuple(v.dims) == ("channel", "ping_time") and v.dtype.kind == "f"]
+    assert "tau_effective" in grid_vars and (wf == "CW" or "sound_absorption" in grid_vars)
+    for n in grid_vars:
+        a = got[n].values
+        assert np.isnan(a[:, :2]).all() and np.isfinite(a[:, 2:]).all(), n
+
+
 @pytest.mark.parametrize("cal", ["Sv", "TS"])
 def test_compute_Sv_TS_ek80_cw_complex(ep, cal):
     d, filt = _ek80(ep, "CW", C=2, P=10, S=700, mixed_nan=True)
