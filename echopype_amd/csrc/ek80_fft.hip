@@ -241,6 +241,76 @@ __device__ __forceinline__ void st8(unsigned char* xs, int a0, const C2<F> (&v)[
   for (int r = 0; r < 8; ++r) Xs<F>::st(xs, a0 + STRIDE * r, v[r]);
 }
 
+// ---- experiment (25), compile-time EPA_FFT_XPOSE (bit 0: stride-64 <-> stride-8, bit 1: stride-8 <-> stride-1): the
+// wave-local exchanges between two passes as register transposes across lanes instead of an LDS round trip.  With lane
+// l = 8 a + b the stride-64 pass holds element l + 64 r in register r, the stride-8 pass element 64 a + b + 8 r, the
+// stride-1 pass element 8 l + r: going from one to the next transposes the register index with the lane's bits 3..5
+// (a) resp. 0..2 (b) -- three exchange stages each, a 32-bit word at a time: v_permlane32_swap / v_permlane16_swap
+// (gfx950) for lane distances 32 and 16, DPP moves for 8, 4 (row_half_mirror then quad_perm), 2 and 1.
+#ifndef EPA_FFT_XPOSE
+#define EPA_FFT_XPOSE 0
+#endif
+namespace xp {
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp(unsigned x) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false);
+}
+// exchange word a of the lanes with `hi` set against word b of their partner (lane ^ distance) without it
+template <int DIST>
+__device__ __forceinline__ void exch(unsigned& a, unsigned& b, bool hi) {
+  if (DIST == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);  // a of lanes 32..63 <-> b of lanes 0..31
+    a = r[0];
+    b = r[1];
+  } else if (DIST == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);  // a of the odd rows <-> b of the even rows
+    a = r[0];
+    b = r[1];
+  } else {
+    const unsigned y = hi ? a : b;
+    unsigned t;
+    if (DIST == 8) t = dpp<0x128>(y);                 // row_ror:8
+    else if (DIST == 4) t = dpp<0x1B>(dpp<0x141>(y));  // row_half_mirror (l ^ 7), then quad_perm [3,2,1,0] (l ^ 3)
+    else if (DIST == 2) t = dpp<0x4E>(y);             // quad_perm [2,3,0,1]
+    else t = dpp<0xB1>(y);                            // quad_perm [1,0,3,2]
+    a = hi ? t : a;
+    b = hi ? b : t;
+  }
+}
+// transpose the register index of an 8-element lane set with three lane bits (LB = the lowest of them: 3 or 0)
+template <int LB, int WORDS>
+__device__ __forceinline__ void transpose(unsigned (&w)[8][WORDS]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int bit = 2; bit >= 0; --bit) {
+    const bool hi = ((lane >> (LB + bit)) & 1) != 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      if (r & (1 << bit)) continue;
+#pragma unroll
+      for (int k = 0; k < WORDS; ++k) {
+        if (LB + bit == 5) exch<32>(w[r][k], w[r | (1 << bit)][k], hi);
+        else if (LB + bit == 4) exch<16>(w[r][k], w[r | (1 << bit)][k], hi);
+        else if (LB + bit == 3) exch<8>(w[r][k], w[r | (1 << bit)][k], hi);
+        else if (LB + bit == 2) exch<4>(w[r][k], w[r | (1 << bit)][k], hi);
+        else if (LB + bit == 1) exch<2>(w[r][k], w[r | (1 << bit)][k], hi);
+        else exch<1>(w[r][k], w[r | (1 << bit)][k], hi);
+      }
+    }
+  }
+}
+template <int LB, typename V>
+__device__ __forceinline__ void transpose_vals(V (&v)[8]) {
+  constexpr int WORDS = sizeof(V) / 4;
+  unsigned w[8][WORDS];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) __builtin_memcpy(w[r], &v[r], sizeof(V));
+  transpose<LB, WORDS>(w);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) __builtin_memcpy(&v[r], w[r], sizeof(V));
+}
+}  // namespace xp
+
 // Circular correlation of the tile held as v[i] = x[j + 256 i] with the channel's replica (spectrum `spec` in
 // the digit-reversed order of the forward transform, conj and 1/N applied).  Result in v, same ownership.
 // Barriers: the caller guarantees nobody still reads xs on entry; on exit xs holds nothing of value.
@@ -256,30 +326,46 @@ __device__ __forceinline__ void correlate(C2<F> (&v)[8], unsigned char* xs, cons
   ld8<F, 64>(xs, lm.a1, v);
   dft8(v);
   twiddle8<F, false>(v, tw_mul4<F, SMALL>(tw, lm.t1));
-  st8<F, 64>(xs, lm.a1, v);
-  __builtin_amdgcn_wave_barrier();  // (own wavefront's data: ordering for the compiler only)
-  ld8<F, 8>(xs, lm.a2, v);
+  if (EPA_FFT_XPOSE & 1) {
+    xp::transpose_vals<3>(v);
+  } else {
+    st8<F, 64>(xs, lm.a1, v);
+    __builtin_amdgcn_wave_barrier();  // (own wavefront's data: ordering for the compiler only)
+    ld8<F, 8>(xs, lm.a2, v);
+  }
   // the replica spectrum of the fused pass: 8 consecutive elements per lane, requested before the barrier
   C2<F> sp[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) sp[r] = spec[lm.a3 + r];
   dft8(v);
   twiddle8<F, false>(v, tw_mul4<F, SMALL>(tw, lm.t2));
-  st8<F, 8>(xs, lm.a2, v);
-  __builtin_amdgcn_wave_barrier();  // (own wavefront's data: ordering for the compiler only)
-  ld8<F, 1>(xs, lm.a3, v);
+  if (EPA_FFT_XPOSE & 2) {
+    xp::transpose_vals<0>(v);
+  } else {
+    st8<F, 8>(xs, lm.a2, v);
+    __builtin_amdgcn_wave_barrier();  // (own wavefront's data: ordering for the compiler only)
+    ld8<F, 1>(xs, lm.a3, v);
+  }
   dft8(v);
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], sp[r]);
   idft8(v);
-  st8<F, 1>(xs, lm.a3, v);
-  __builtin_amdgcn_wave_barrier();  // (own wavefront's data: ordering for the compiler only)
-  ld8<F, 8>(xs, lm.a2, v);
+  if (EPA_FFT_XPOSE & 2) {
+    xp::transpose_vals<0>(v);
+  } else {
+    st8<F, 1>(xs, lm.a3, v);
+    __builtin_amdgcn_wave_barrier();  // (own wavefront's data: ordering for the compiler only)
+    ld8<F, 8>(xs, lm.a2, v);
+  }
   twiddle8<F, true>(v, tw_mul4<F, SMALL>(tw, lm.t2));
   idft8(v);
-  st8<F, 8>(xs, lm.a2, v);
-  __builtin_amdgcn_wave_barrier();  // (own wavefront's data: ordering for the compiler only)
-  ld8<F, 64>(xs, lm.a1, v);
+  if (EPA_FFT_XPOSE & 1) {
+    xp::transpose_vals<3>(v);
+  } else {
+    st8<F, 8>(xs, lm.a2, v);
+    __builtin_amdgcn_wave_barrier();  // (own wavefront's data: ordering for the compiler only)
+    ld8<F, 64>(xs, lm.a1, v);
+  }
   twiddle8<F, true>(v, tw_mul4<F, SMALL>(tw, lm.t1));
   idft8(v);
   st8<F, 64>(xs, lm.a1, v);
@@ -421,29 +507,45 @@ __device__ __forceinline__ void correlate<float>(C2<float> (&vc)[8], unsigned ch
   pk::ld8<64>(xs, lm.a1, v);
   pk::dft8<false>(v, kh);
   pk::twiddle8(v, twp[lm.t1]);
-  pk::st8<64>(xs, lm.a1, v);
-  __builtin_amdgcn_wave_barrier();  // (own wavefront's data: ordering for the compiler only)
-  pk::ld8<8>(xs, lm.a2, v);
+  if (EPA_FFT_XPOSE & 1) {
+    xp::transpose_vals<3>(v);
+  } else {
+    pk::st8<64>(xs, lm.a1, v);
+    __builtin_amdgcn_wave_barrier();  // (own wavefront's data: ordering for the compiler only)
+    pk::ld8<8>(xs, lm.a2, v);
+  }
   f2 sp[8];  // the replica spectrum of the fused pass, requested early
 #pragma unroll
   for (int r = 0; r < 8; ++r) sp[r] = specp[lm.a3 + r];
   pk::dft8<false>(v, kh);
   pk::twiddle8(v, twp[lm.t2]);
-  pk::st8<8>(xs, lm.a2, v);
-  __builtin_amdgcn_wave_barrier();
-  pk::ld8<1>(xs, lm.a3, v);
+  if (EPA_FFT_XPOSE & 2) {
+    xp::transpose_vals<0>(v);
+  } else {
+    pk::st8<8>(xs, lm.a2, v);
+    __builtin_amdgcn_wave_barrier();
+    pk::ld8<1>(xs, lm.a3, v);
+  }
   pk::dft8<false>(v, kh);
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] = pk::cmul(v[r], sp[r]);
   pk::dft8<true>(v, kh);
-  pk::st8<1>(xs, lm.a3, v);
-  __builtin_amdgcn_wave_barrier();
-  pk::ld8<8>(xs, lm.a2, v);
+  if (EPA_FFT_XPOSE & 2) {
+    xp::transpose_vals<0>(v);
+  } else {
+    pk::st8<1>(xs, lm.a3, v);
+    __builtin_amdgcn_wave_barrier();
+    pk::ld8<8>(xs, lm.a2, v);
+  }
   pk::twiddle8(v, pk::conj(twp[lm.t2]));
   pk::dft8<true>(v, kh);
-  pk::st8<8>(xs, lm.a2, v);
-  __builtin_amdgcn_wave_barrier();
-  pk::ld8<64>(xs, lm.a1, v);
+  if (EPA_FFT_XPOSE & 1) {
+    xp::transpose_vals<3>(v);
+  } else {
+    pk::st8<8>(xs, lm.a2, v);
+    __builtin_amdgcn_wave_barrier();
+    pk::ld8<64>(xs, lm.a1, v);
+  }
   pk::twiddle8(v, pk::conj(twp[lm.t1]));
   pk::dft8<true>(v, kh);
   pk::st8<64>(xs, lm.a1, v);
