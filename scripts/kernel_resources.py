@@ -1,5 +1,5 @@
 """Registers, scratch, LDS and occupancy of every kernel of the library as the compiler reports them
-(-Rpass-analysis=kernel-resource-usage; no GPU needed) -> profiles/r03_kernel_resources.txt.  rocprofv3's Arch_VGPR column
+(-Rpass-analysis=kernel-resource-usage; no GPU needed) -> profiles/r04_kernel_resources.txt.  rocprofv3's Arch_VGPR column
 counts register PAIRS on wave64 (half of "VGPRs" here)."""
 import os
 import re
@@ -24,13 +24,27 @@ for src in build.SOURCES:
             if key in line and cur:
                 v[key] = line.split(key)[1].split("[")[0].strip()
         if "LDS Size" in line and cur:
-            name = subprocess.run(["c++filt", cur], capture_output=True, text=True).stdout.strip().split("(")[0]
-            rows.append((src, name.replace("(anonymous namespace)::", "").replace("void ", ""), v))
+            # (strip the namespace BEFORE cutting the argument list off: "(anonymous namespace)::k<..>(Args)" starts
+            #  with a parenthesis -- round 3's table lost 201 of its 268 names to that)
+            full = subprocess.run(["c++filt", cur], capture_output=True, text=True).stdout.strip()
+            full = full.replace("(anonymous namespace)::", "").replace("void ", "")
+            depth, cut = 0, len(full)
+            for i, ch in enumerate(full):  # the argument list opens at the first "(" outside template brackets
+                if ch == "<":
+                    depth += 1
+                elif ch == ">":
+                    depth -= 1
+                elif ch == "(" and depth == 0:
+                    cut = i
+                    break
+            name = full[:cut].strip() or cur
+            rows.append((src, name, v))
             cur = None
 out = [__doc__.strip(), "", f"{'kernel':92s} {'VGPR':>5s} {'SGPR':>5s} {'scratch':>8s} {'waves/SIMD':>10s} {'static LDS':>10s}"]
 for src, name, v in sorted(rows, key=lambda r: (r[0], r[1])):
     out.append(f"{name[:92]:92s} {v.get('VGPRs:', '?'):>5s} {v.get('SGPRs:', '?'):>5s} {v.get('ScratchSize [bytes/lane]:', '?'):>8s} "
                f"{v.get('Occupancy [waves/SIMD]:', '?'):>10s} {v.get('LDS Size [bytes/block]:', '?'):>10s}")
-open(os.path.join(ROOT, "profiles", "r03_kernel_resources.txt"), "w").write("\n".join(out) + "\n")
+assert all(r[1] for r in rows), "a kernel without a name"
+open(os.path.join(ROOT, "profiles", "r04_kernel_resources.txt"), "w").write("\n".join(out) + "\n")
 print("\n".join(l for l in out if any(k in l for k in ("fused_sv_mvbs_kernel<double, float, true", "drift_kernel<true, true", "sv_noise_fast_kernel<double, true",
                                                        "sv_complex_fft_kernel<float, double, double, 4, false", "mvbs_of_sv_fixed_kernel<double, true", "kernel  "))))

@@ -25,6 +25,15 @@ KERNELS = {
     "cfg4:float64": ("cfg4", ["sv_complex_fft_kernel<float, double, double"], None, 2 * 200_000 * 8192 * 40),
     "cfg4:float64:planes64": ("cfg4_planes64", ["sv_complex_fft_kernel<double, double, double"], None, 2 * 200_000 * 8192 * 72),
     "cfg5:float64": ("cfg5", ["fused_sv_mvbs_kernel<double, float, true, false>"], None, 4 * 250_000 * 4096 * 12),
+    # the round-4 headline: the same tiles through calibrate.compute_Sv -> commongrid.compute_MVBS (statistics variant)
+    "cfg5api:float64": ("cfg5", ["fused_sv_mvbs_kernel<double, float, true, true>"], None, 4 * 250_000 * 4096 * 12),
+    "cfg2:float32": ("cfg2_f32", ["fused_sv_mvbs_kernel<float, float, true, false>"], None, 4 * 500_000 * 2000 * 8),
+    "cfg3:float32": ("cfg3_f32", ["sv_noise_fast_kernel", "sv_denoise_mvbs_fast_kernel", "sv_denoise_mvbs_uniform_kernel",
+                                  "sv_denoise_mvbs_drift_kernel"], None, 4 * 500_000 * 2000 * 20),
+    "cfg3:float64:ss2000": ("cfg3_ss2000", ["sv_noise_fast_kernel", "sv_denoise_mvbs_fast_kernel",
+                                            "sv_denoise_mvbs_uniform_kernel", "sv_denoise_mvbs_drift_kernel"], None,
+                            4 * 500_000 * 2000 * 32),
+    "cfg4:float32": ("cfg4_f32", ["sv_complex_fft_kernel<float, float, float"], None, 2 * 200_000 * 8192 * 36),
     # the two reference calls with the Sv deferred: the statistics variant of the fused kernel inside compute_MVBS
     "api:float64": ("api", ["fused_sv_mvbs_kernel<double, float, true, true>"], None, 4 * 500_000 * 2000 * 12),
 }
@@ -61,10 +70,10 @@ for key, (wl, names, _, algo) in KERNELS.items():
          "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE x1"
                        + ("; the kernels of a pass summed" if len(names) > 1 else ""),
          "algorithmic_bytes": algo, "csrc_sha16": csrc_hash(),
-         "source": f"profiles/r03_pmc_traffic.csv (bench.py --workload {wl.replace('_', ':')})"}
+         "source": f"profiles/r04_pmc_traffic.csv (bench.py --workload {wl.replace('_', ':')})"}
     k0f = [v for k, v in fe.items() if "power_coef_ek_kernel" in k]
     k0w = [v for k, v in wr.items() if "power_coef_ek_kernel" in k]
-    if wl in ("cfg2", "cfg3") and k0f and k0w:  # K0 reads 5 x (C, P) f64 + small tables, writes 64 B per (c, p)
+    if wl in ("cfg2", "cfg3", "cfg2_f32", "cfg3_f32", "cfg3_ss2000") and k0f and k0w:  # K0 reads 5 x (C, P) f64 + small tables, writes 64 B per (c, p)
         cp = 4 * 500_000
         e["calibration"] = {"kernel": "power_coef_ek_kernel (known 80 MB read, 128 MB write)",
                             "FETCH_SIZE_ratio_raw": k0f[0] * 1024 / (cp * 40.0), "WRITE_SIZE_ratio_raw": k0w[0] * 1024 / (cp * 64.0)}

@@ -1,7 +1,9 @@
 """BASELINE configs[4] at its FULL size on one GPU -- EK60 4 ch x 2 M pings x 4096 range as eight resident tiles of
-250 000 pings, exactly what ``bench.py`` times (bench.Cfg5, every tile edge cutting a 20-s time bin, the edge-bin
-exchange on the path): windows of the first tile, the last tile and a tile edge against the oracle.  The oracle cannot
-run 32.8 G samples; a 1000-ping window (50 whole time bins, or 51 cut ones) takes it a second.  Needs ~170 GB of HBM."""
+250 000 pings, exactly what ``bench.py`` times: the ops-level harness (bench.Cfg5.layout: every tile edge cutting a 20-s
+time bin, the edge-bin exchange on the path) AND the headline route through the product entry points
+(bench.Cfg5.echodata + calibrate.compute_Sv -> commongrid.compute_MVBS per tile, results read one tile late) -- windows
+of the first tile, a middle one, the last tile and the tile edges against the oracle.  The oracle cannot run 32.8 G
+samples; a 1000-ping window (50 whole time bins, or 51 cut ones) takes it a second.  Needs ~170 GB of HBM."""
 import argparse
 
 import numpy as np
@@ -97,3 +99,64 @@ def test_cfg5_time_bins_cut_by_a_tile_edge_hold_all_their_pings(job, edge):
     # ... and it differs from what either side alone would report (the exchange did something)
     half = ogrid.groupby_mean(sv_a, er_a, t_a, ogrid.ping_edges(t, "20s"), np.arange(0, n_r + 1.0, 1.0))
     assert np.nanmax(np.abs(half - exp)) > 1e-6
+
+
+def test_cfg5_tiles_through_the_reference_calls_match_the_oracle(job):
+    """The headline route of bench.py at N = 1: every resident tile as an EchoData through calibrate.compute_Sv and
+    commongrid.compute_MVBS(ds, "1m", "20s"), the next tile launched before the previous result is read (the calls do
+    not wait for the GPU; reading a deferred MVBS dataset does).  Each tile is its own dataset, as with the reference
+    run per file: its first and last bin hold the 10 pings on its side of the tile edge.  Windows of three tiles: 50
+    whole bins of the MVBS, the cut first bin, 600 pings of the Sv array."""
+    import collections
+    import logging
+
+    import echopype_amd as ep
+    from echopype_amd.xr_lite import DeferredDataset
+
+    torch, j = job["torch"], job["job"]
+    j.sv = None            # (the ops-level harness' reused Sv buffer: the API allocates its own outputs)
+    job["mv"].clear()
+    torch.cuda.empty_cache()
+    logging.disable(logging.WARNING)
+    checked = []
+
+    def check(tile, ds, mv):
+        assert mv["Sv"].shape == (C, 12501, j.n_r) and tuple(mv["Sv"].dims) == ("channel", "ping_time", "echo_range")
+        t0 = np.asarray(mv["ping_time"].values)[0]
+        d = j.tiles[tile]
+        first_ping = d["ping_time"][0] + np.timedelta64(OFFSET_NS, "ns")
+        assert first_ping - t0 == np.timedelta64(10, "s")          # the tile starts 10 s into its first bin
+        got = mv["Sv"].data.tensor
+        for a in (10, 123_450, 249_000 - 10):
+            sv, er, t = _oracle_window(job, tile, a, 1000)
+            exp = ogrid.groupby_mean(sv, er, t, ogrid.ping_edges(t, "20s"), np.arange(0, j.n_r + 1.0, 1.0))
+            b0 = (a + 10) // 20
+            _close(got[:, b0:b0 + 50].cpu().numpy(), exp)
+        sv, er, t = _oracle_window(job, tile, 0, 10)               # the cut first bin: this tile's 10 pings only
+        exp = ogrid.groupby_mean(sv, er, t, ogrid.ping_edges(t, "20s"), np.arange(0, j.n_r + 1.0, 1.0))
+        _close(got[:, :1].cpu().numpy(), exp)
+        sv, er, _ = _oracle_window(job, tile, 200_000, 600)
+        _close(ds["Sv"].data.tensor[:, 200_000:200_600].cpu().numpy(), sv)
+        np.testing.assert_array_equal(mv["echo_range"].values, np.arange(j.n_r, dtype=np.float64))
+        checked.append(tile)
+
+    try:
+        pending = collections.deque()
+        for tile in range(len(j.tiles)):
+            ed = j.echodata(tile, OFFSET_NS)
+            ds = ep.calibrate.compute_Sv(ed)
+            mv = ep.commongrid.compute_MVBS(ds, range_bin="1m", ping_time_bin="20s")
+            assert isinstance(mv, DeferredDataset) and not mv.resolved
+            pending.append((tile, ds, mv))
+            while len(pending) > 1:
+                t_, ds_, mv_ = pending.popleft()
+                if t_ in (0, 3):
+                    check(t_, ds_, mv_)
+                else:
+                    mv_["Sv"].shape
+                del ds_, mv_
+        t_, ds_, mv_ = pending.popleft()
+        check(t_, ds_, mv_)
+    finally:
+        logging.disable(logging.NOTSET)
+    assert checked == [0, 3, 7]
