@@ -99,7 +99,9 @@ def test_two_calls_on_resident_echodata_make_no_host_synchronisation(env, monkey
         monkeypatch.setenv("EPA_DEFER_MVBS", "0")
         mv3 = ep.commongrid.compute_MVBS(ep.calibrate.compute_Sv(ed), range_bin="1m", ping_time_bin="20s")
         assert not isinstance(mv3, DeferredDataset)
-        np.testing.assert_array_equal(mv3["Sv"].values, mv["Sv"].values)
+        # (a bin's samples are added by floating-point LDS atomics in whatever order the lanes arrive: two runs of the
+        #  same kernel agree to rounding, not bit for bit)
+        np.testing.assert_allclose(mv3["Sv"].values, mv["Sv"].values, rtol=1e-12, atol=1e-12, equal_nan=True)
         assert mv3["Sv"].attrs == mv["Sv"].attrs and mv3.attrs.keys() == mv.attrs.keys()
     finally:
         logging.disable(logging.NOTSET)
