@@ -135,7 +135,7 @@ def cpu_baseline_ek60(chain=False, multicore=False):
     n = C * P * S
     what = "Sv+denoise(20x50,3dB)+MVBS" if chain else "Sv+MVBS"
     out = {"value": n / med, "unit": "range-samples/s", "cores": 1, "kind": "port",
-           "sample": f"configs[0] shape EK60 {C}x{P}x{S}, {what}, NumPy f64 oracle, median of {n_runs}, host: {os.cpu_count()} cores"}
+           "sample": f"EK60 {C}x{P}x{S} {what}, NumPy f64 oracle, median of {n_runs}, {os.cpu_count()}-core host"}
     if multicore:  # what dask chunk-parallelism over ping_time could reach at best: the same slice in N processes
         try:
             import multiprocessing as mp
@@ -696,12 +696,15 @@ def ranks_info(ctx):
     """world size, backend and the device every rank runs on, gathered over the process group: a SCALE record then
     proves RCCL saw N ranks on N devices."""
     torch, dist = ctx.torch, ctx.dist
-    mine = f"{ctx.rank}:cuda{torch.cuda.current_device()}:{torch.cuda.get_device_name()}"
+    mine = f"{ctx.rank}:cuda{torch.cuda.current_device()}"
+    name = torch.cuda.get_device_name()
     if ctx.world == 1:
-        return {"world_size": 1, "backend": "none", "devices": [mine]}
+        return {"world_size": 1, "backend": "none", "devices": [mine], "device_name": name}
     got = [None] * ctx.world
-    dist.all_gather_object(got, mine, group=ctx.sharding.control_group())
-    return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices": got}
+    dist.all_gather_object(got, (mine, name), group=ctx.sharding.control_group())
+    names = sorted({n for _, n in got})
+    return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices": [m for m, _ in got],
+            "device_name": names[0] if len(names) == 1 else names}
 
 
 def run_cfg5(ctx, cpu):
@@ -733,18 +736,18 @@ def run_cfg5(ctx, cpu):
     elapsed, region_ms = ctx.timed(pass_c, passes, finish=finish_c)
     assert state["n_read"] == len(job.tiles) * passes * (steps + args.warmup)  # every result was read
     if world == 1:
-        route = "calibrate.compute_Sv(echodata) -> commongrid.compute_MVBS(ds_Sv,'1m','20s') per tile"
-        coll = "none (1 rank: every tile is its own dataset, as the reference run per file)"
+        route = "compute_Sv(echodata) -> compute_MVBS(ds_Sv,'1m','20s') per tile"
+        coll = "none at 1 rank (each tile its own dataset)"
     else:
         route = "sharding.compute_Sv_MVBS(echodata_shard, shard=MVBSShard()) per tile"
-        coll = (f"per dataset of {world} tiles: cut bins pack -> all_reduce(SUM, {args.backend}) -> finalize; "
-                f"nanmax(echo_range) all_reduce(MAX, {args.backend}) in HBM; control scalars over gloo")
-    cfg = {"pings_total": P_total, "tiles": f"{job.n_tiles} x {job.tile_p} pings over {world} rank(s)",
-           "route": route, "collective": coll, "results_read": "each tile's MVBS after the next tile's launch",
+        coll = (f"per dataset of {world} tiles: cut bins all_reduce(SUM) + range max all_reduce(MAX) in HBM over "
+                f"{args.backend}; control scalars over gloo")
+    # (ops_level_*: the kernels called directly on preallocated buffers, all cut bins of a rank's tiles exchanged)
+    cfg = {"tiles": f"{job.n_tiles} x {job.tile_p} pings over {world} rank(s)",
+           "route": route, "collective": coll, "results_read": "1 tile late",
            "mvbs_shape_last_tile": list(state["last"][0]),
            "ops_level_ms_per_pass": el_b / steps / passes * 1e3, "ops_level_kernel_ms": km_b,
-           "ops_level_collective": f"all cut bins of a rank's tiles: pack -> all_reduce(SUM, {args.backend if world > 1 else '1 rank: skipped'}) -> finalize",
-           "ops_level_edge_bins_per_rank": edges_b, "allreduce_bytes": bytes_b,
+           "ops_level_edge_bins": edges_b, "allreduce_bytes": bytes_b,
            "aligned_ms_per_step": el_a / steps * 1e3, "ranks": ranks_info(ctx)}
     n_first = C * (job.spans[0][1] - job.spans[0][0]) * S if job.spans else 0
     bps = BYTES_PER_SAMPLE[ctx.dtype]
@@ -752,12 +755,12 @@ def run_cfg5(ctx, cpu):
     if ctx.rank != 0:
         return None
     return line(ctx, samples_per_pass=C * P_total * S, passes=passes, elapsed=elapsed, scaling="strong", cpu=cpu,
-                workload=f"cfg5: EK60 CW {C}x{P_total}x{S} TOTAL in ping_time tiles through the product entry points "
-                         "(compute_Sv -> compute_MVBS 20s x 1m), Sv+MVBS out, tile edges cut time bins",
+                workload=f"cfg5: EK60 CW {C}x{P_total}x{S} TOTAL in ping_time tiles via the product entry points "
+                         "compute_Sv -> compute_MVBS(20s x 1m), Sv+MVBS out",
                 config=cfg,
-                roofline=roofline("fused_sv_mvbs_kernel (+ the coefficient / bin-offset kernels of the calls)", region_ms,
+                roofline=roofline("fused_sv_mvbs_kernel (+ K0 kernels of the calls)", region_ms,
                                   n_first * bps, bps, traffic_key=f"cfg5api:{ctx.dtype}",
-                                  launch=f"the API calls of one {job.tile_p}-ping tile (rank 0, first tile), HIP events on torch's stream"))
+                                  launch=f"API calls of one {job.tile_p}-ping tile, HIP events"))
 
 
 # ---------------------------------------------------------------------------------------- main
@@ -787,8 +790,8 @@ def compact(x):
 
 
 def summary(out):
-    r = out["roofline"]
-    return f"{out['value'] / 1e9:.1f} Gs/s {out['config']['ms_per_pass']:.2f} ms/pass frac {r['frac']:.3f}"
+    """'<Gsamp/s> f<fraction of 8 TB/s>' of a line, for the headline's also_* strings."""
+    return f"{out['value'] / 1e9:.1f} f{out['roofline']['frac']:.3f}"
 
 
 def main():
@@ -851,7 +854,10 @@ def main():
         if rank == 0 and out is not None:
             if i == len(todo) - 1 and also:  # the parsed line carries the others' key figures (flat, short strings)
                 out["config"].update(also)
-            also["also_" + spec.replace(":", "_")] = summary(out)
+                out["config"]["also_unit"] = "Gsamp/s f<frac>"
+            fam, _, var = spec.partition(":")  # one string per workload family: "441.4 f0.668; f32 628.0 f0.636"
+            key = "also_" + fam
+            also[key] = (also[key] + "; " if key in also else "") + (var + " " if var else "") + summary(out)
             txt = json.dumps(compact(out))
             print(txt, flush=True)
             if args.out:

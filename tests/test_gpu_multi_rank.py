@@ -174,7 +174,7 @@ def _run(world, backend):
     assert all(o["comm"] == ("cuda" if backend == "nccl" else "cpu") for o in res)
     info = res[0]["ranks"]
     assert info["world_size"] == world and info["backend"] == backend and len(info["devices"]) == world
-    assert [x.split(":")[0] for x in info["devices"]] == [str(r) for r in range(world)]
+    assert info["devices"] == [f"{r}:cuda{r if backend == 'nccl' else 0}" for r in range(world)]
 
     # ---- the whole volume, in time order, for the oracle
     tables = res[0]["tables"]
