@@ -118,6 +118,13 @@ class HostFuture:
     def item(self):
         return self.cpu().item()
 
+    def __del__(self):
+        # never read: hand the staging buffer back (a later copy into it is queued on the same download stream behind
+        # this one, so the two cannot overlap)
+        slot = getattr(self, "_slot", None)
+        if slot is not None:
+            slot[1] = None
+
 
 class _Downloader:
     """HBM -> host copies of kernel by-products (range statistics, a maximum) that do not queue behind later work.

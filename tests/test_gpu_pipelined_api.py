@@ -64,6 +64,12 @@ def test_uploader_and_fetch_async_round_trip_behind_a_busy_stream(env):
         busy.fill_(1.0)
     assert fut.tolist() == [1.0, 2.0, 3.0] and fut.cpu().tolist() == [1.0, 2.0, 3.0]
     assert ops.fetch_async(t[:1]).item() == 100.0
+    # futures nobody reads give their staging buffers back: the pinned pool does not grow with the number of calls
+    dl = ops._downloaders[t.device]
+    for _ in range(200):
+        ops.fetch_async(t)
+    assert len(dl.pool) <= 4, len(dl.pool)
+    assert ops.fetch_async(t).tolist() == [100.0, 200.0, 300.0]
 
 
 def _resident_case(ep, C=3, P=400, S=1024, seed=3):
