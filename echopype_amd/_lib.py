@@ -59,6 +59,7 @@ SIGNATURES = {
     "epa_last_error": [],
     "epa_launch_trace": [_i],
     "epa_last_range_stats_filled": [],
+    "epa_launch_seen": [],
     "epa_device_count": [ctypes.POINTER(_i)],
     "epa_set_device": [_i],
     "epa_device_name": [_i, ctypes.c_char_p, _sz],
@@ -129,7 +130,7 @@ SIGNATURES = {
 for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here = the .so does not export a declared symbol
     _fn.argtypes = _args
-    _fn.restype = ctypes.c_char_p if _name in ("epa_last_error", "epa_launch_trace") else _i
+    _fn.restype = ctypes.c_char_p if _name in ("epa_last_error", "epa_launch_trace", "epa_launch_seen") else _i
 
 
 class launch_trace:
@@ -144,6 +145,11 @@ class launch_trace:
         self.kernels = [k for k in lib.epa_launch_trace(2).decode().split(";") if k]
         lib.epa_launch_trace(0)
         return False
+
+
+def launched_kernels():
+    """Names of every kernel this process has launched through the library so far."""
+    return [k for k in lib.epa_launch_seen().decode().split(";") if k]
 
 
 def last_error() -> str:

@@ -40,8 +40,12 @@ void note_launch(const char* what);
 // epa_last_range_stats_filled (echopype_amd.h): did the last fused call on this thread leave the range statistics?
 void note_range_stats_filled(int filled);
 
+// every distinct kernel name launched by this process (epa_launch_seen): the test suite's kernel coverage
+void note_seen(const char* what);
+
 inline int check_launch(const char* what) {
   if (g_trace_on) note_launch(what);
+  note_seen(what);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("launch of %s failed: %s", what, hipGetErrorString(e));

@@ -2,6 +2,9 @@
 #include "epa_internal.h"
 
 #include <cstring>
+#include <mutex>
+#include <set>
+#include <string>
 
 namespace epa {
 static thread_local char g_err[512] = "";
@@ -22,6 +25,22 @@ void note_launch(const char* what) {
   g_trace[g_trace_len++] = ';';
   g_trace[g_trace_len] = 0;
 }
+// distinct names seen, process-wide.  The caller passes string literals: the common case (seen before, same pointer) is a
+// lock-free compare against a small per-thread cache of pointers.
+static std::mutex g_seen_mu;
+static std::set<std::string> g_seen;
+static std::string g_seen_joined;
+void note_seen(const char* what) {
+  static thread_local const char* cache[64];
+  static thread_local int ncache = 0;
+  for (int i = 0; i < ncache; ++i)
+    if (cache[i] == what) return;
+  {
+    std::lock_guard<std::mutex> lk(g_seen_mu);
+    g_seen.insert(what);
+  }
+  if (ncache < 64) cache[ncache++] = what;
+}
 static thread_local int g_stats_filled = 0;
 void note_range_stats_filled(int filled) { g_stats_filled = filled; }
 }  // namespace epa
@@ -35,6 +54,12 @@ extern "C" {
 int epa_version(void) { return EPA_VERSION; }
 const char* epa_last_error(void) { return epa::g_err; }
 int epa_last_range_stats_filled(void) { return epa::g_stats_filled; }
+const char* epa_launch_seen(void) {
+  std::lock_guard<std::mutex> lk(epa::g_seen_mu);
+  epa::g_seen_joined.clear();
+  for (const auto& k : epa::g_seen) epa::g_seen_joined += k + ";";
+  return epa::g_seen_joined.c_str();
+}
 const char* epa_launch_trace(int mode) {
   if (mode == 1 || mode == 0) {  // start afresh / stop
     epa::g_trace_on = mode == 1;

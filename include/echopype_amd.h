@@ -83,6 +83,9 @@ const char* epa_launch_trace(int mode);
  * {nanmin, nanmax, NaN count}; 0 when the generic kernel served it (it leaves the maximum only and writes NaN count -1).
  * The same fact as the -1 on the device, known on the host without waiting for the kernel. */
 int epa_last_range_stats_filled(void);
+/* Every distinct kernel name this PROCESS has launched so far, "name;name;..." (sorted; valid until the next call): the
+ * test suite's kernel coverage (tests/conftest.py writes it out at the end of a GPU session). */
+const char* epa_launch_seen(void);
 int epa_device_count(int* n);
 int epa_set_device(int dev);
 int epa_device_name(int dev, char* buf, size_t len);

@@ -818,3 +818,50 @@ def test_mvbs_of_sv_through_coefficient_rows_fast_kernel(env, dtype, S, ss_jitte
             np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
             np.testing.assert_allclose(a, b, rtol=1e-12 if dtype == "float64" else 1e-5, atol=1e-12 if dtype == "float64" else 1e-4)
         assert np.isfinite(fast["MVBS"].cpu().numpy()).any() and (fast["cnt"].cpu().numpy()[:, -3:] == 0).all()
+
+
+# ---- launch sites the API paths reach only from other processes / through other routes (kernel coverage, round 4) ---------
+def test_noise_finalize_edge_prepare_affine_rows_first_not_le(env):
+    """epa_noise_finalize (merged (sum, count) rows of a noise block cut by a shard edge -> clean/api.py:402-422: mean ->
+    dB -> min over the range blocks -> clamp), epa_edge_prepare_max (NaN -> -inf before an all-reduce(MAX)),
+    epa_affine_rows (consolidate/api.py:226 on an echo_range ARRAY) and epa_first_not_le on an empty array: in the product
+    they run inside the rank processes of the sharded tests or behind other routes; here each against NumPy."""
+    torch, ops, synth = env
+    rng = np.random.default_rng(8)
+    # noise finalize
+    rows, Sb = 7, 41
+    ssum = rng.random((rows, Sb)) * 1e-7
+    cnt = rng.integers(0, 5, (rows, Sb)).astype(np.float64)
+    cnt[3] = 0.0                                          # a row with nothing in it: NaN
+    ssum[5, 4] = 0.0                                      # an all-zero block mean: -inf dB is the minimum
+    for nmax in (float("nan"), -75.0):
+        got = ops.noise_finalize(_dev(torch, ssum), _dev(torch, cnt), nmax).cpu().numpy()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            db = np.where(cnt > 0, 10 * np.log10(ssum / np.where(cnt > 0, cnt, 1.0)), np.nan)
+        exp = np.array([np.nanmin(r) if np.isfinite(r).any() or np.isinf(r).any() else np.nan for r in db])
+        if nmax == nmax:  # noise.where(noise < max, max) (clean/api.py:418-422): a NaN block becomes the maximum, too
+            with np.errstate(invalid="ignore"):
+                exp = np.where(exp < nmax, exp, nmax)
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+        np.testing.assert_allclose(got[~np.isnan(exp)], exp[~np.isnan(exp)], rtol=1e-13)
+    # NaN -> -inf in place, numbers untouched
+    t = _dev(torch, np.array([np.nan, 3.5, -np.inf, np.nan, 0.0]))
+    assert ops.edge_prepare_max(t) is t
+    np.testing.assert_array_equal(t.cpu().numpy(), [-np.inf, 3.5, -np.inf, -np.inf, 0.0])
+    # depth = offset + scale * echo_range per (channel, ping)
+    C, P, S = 2, 5, 33
+    x = rng.random((C, P, S)) * 100
+    x[1, 2, 7:] = np.nan
+    sc, off = rng.random((C, P)) + 0.5, rng.random((C, P)) * 10
+    for dt in ("float64", "float32"):
+        got = ops.affine_rows(_dev(torch, x.astype(dt)), _dev(torch, sc), _dev(torch, off)).cpu().numpy()
+        exp = (off[..., None] + sc[..., None] * x.astype(dt).astype(np.float64)).astype(dt)
+        np.testing.assert_allclose(got, exp, rtol=1e-15 if dt == "float64" else 1e-6, equal_nan=True)
+    # first index whose value is not <= the limit: an empty array answers 0 (= its length)
+    import ctypes
+    from echopype_amd import _lib
+    live, out = _dev(torch, np.arange(4.0)), torch.full((1,), 7, dtype=torch.int64, device="cuda")
+    _lib.call("epa_first_not_le", ctypes.c_void_p(live.data_ptr()), 0, 1.0, _lib.F64, ctypes.c_void_p(out.data_ptr()), None)
+    torch.cuda.synchronize()
+    assert int(out.item()) == 0                                   # n = 0 on a live buffer
+    assert int(ops.first_not_le(_dev(torch, np.array([0.5, 1.0, 1.5, 0.2])), 1.0)) == 2
