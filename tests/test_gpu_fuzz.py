@@ -237,3 +237,68 @@ def test_lazy_echo_range_paths_against_the_array_paths(ep, seed):
     np.testing.assert_array_equal(da["depth"].values, db["depth"].values)
     assert da["depth"].data.cached_stats() == db["depth"].data.cached_stats()
     np.testing.assert_array_equal(lazy["echo_range"].values, arr["echo_range"].values)
+
+
+# ---- medium volumes that actually reach the specialised kernels (round 4) ---------------------------------------------------
+# The planner (block_reduce.hip make_plan) sends time bins of more than 8 pings to a two-stage generic reduction unless
+# C * n_tbins >= 1024: the tiny shapes above therefore never reach fused_sv_mvbs_kernel, mvbs_of_sv_fixed / rows_kernel or
+# the chain's pass-2 kernels.  These cases do (asserted through the launch trace), with the sound-speed regimes that pick
+# between them and the range lengths that leave a partial last wavefront.
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("EPA_FUZZ_MEDIUM", "12"))))  # (a longer hunt: EPA_FUZZ_MEDIUM=100)
+def test_random_medium_volumes_on_the_specialised_kernels(ep, seed):
+    import logging
+
+    from echopype_amd import _lib
+
+    rng = np.random.default_rng(7000 + seed)
+    C = int(rng.integers(1, 4))
+    S = int(rng.choice([260, 1000, 1028, 2052, 4096]))
+    P = int(rng.choice([1500, 2400, 3100]))
+    regime = str(rng.choice(["constant", "steps", "every-ping", "jitter"]))
+    d = ep.synth.ek60_numpy(C, P, S, seed=seed, ss_every={"constant": 10**9, "steps": 37, "every-ping": 1, "jitter": 1}[regime])
+    if regime == "jitter":  # metres per second from ping to ping: columns cross range-bin edges inside a time bin
+        d["sound_speed_indicative"] = d["sound_speed_indicative"] + 6.0 * rng.random((1, P))
+    raw = d["backscatter_r"]
+    raw[rng.random(raw.shape) < 0.01] = np.nan
+    raw[:, int(rng.integers(0, P))] = np.nan
+    tbin = str(rng.choice(["5s", "7s", "8s"]))            # <= 8 pings per bin: single-stage reduction
+    rbin = str(rng.choice(["0.25m", "1m", "5m"]))
+    sv, er = oc.ek60(d, "Sv")
+    exp_mv, t_left, r_left = ogrid.compute_MVBS(sv, er, d["ping_time"], rbin, tbin)
+    logging.disable(logging.WARNING)
+    try:
+        for resident in (False, True):
+            ed = ep.echodata.from_ek60_arrays(d)
+            if resident:
+                ed.to_device()
+            # (1) the two reference calls: Sv deferred, written by compute_MVBS's pass (statistics variant of the fused kernel)
+            with _lib.launch_trace() as tr:
+                ds = ep.calibrate.compute_Sv(ed)
+                mv = ep.commongrid.compute_MVBS(ds, range_bin=rbin, ping_time_bin=tbin)
+                shape = mv["Sv"].shape
+            assert "fused_sv_mvbs_kernel" in tr.kernels, (tr.kernels, C, P, S, tbin)
+            close(mv["Sv"].values, exp_mv, 1e-9, f"deferred MVBS {regime} C={C} P={P} S={S} {rbin} {tbin}")
+            close(ds["Sv"].values, sv, 1e-9, "Sv written by compute_MVBS")
+            np.testing.assert_array_equal(mv["echo_range"].values, r_left)
+            np.testing.assert_array_equal(mv["ping_time"].values, t_left)
+            assert shape == exp_mv.shape
+        # (2) a second grid on the Sv array now there: the fixed-bin / per-row kernels through the coefficient rows
+        rbin2 = "2m" if rbin != "5m" else "0.5m"
+        exp2, _, _ = ogrid.compute_MVBS(sv, er, d["ping_time"], rbin2, tbin)
+        with _lib.launch_trace() as tr:
+            mv2 = ep.commongrid.compute_MVBS(ds, range_bin=rbin2, ping_time_bin=tbin)
+        assert "mvbs_of_sv_fixed_kernel" in tr.kernels and "mvbs_of_sv_rows_kernel" in tr.kernels, tr.kernels
+        close(mv2["Sv"].values, exp2, 1e-9, f"MVBS of the Sv array {regime} {rbin2}")
+        # (3) the chain in two sweeps: uniform / drift / general pass 2 by regime
+        pn, rsn = int(rng.choice([5, 20])), int(rng.choice([50, 130]))
+        exp_n, exp_c = oclean.remove_background_noise(sv, er, d["absorption_indicative"], pn, rsn, None, "3.0dB")
+        exp_mvc, _, _ = ogrid.compute_MVBS(exp_c, er, d["ping_time"], rbin, tbin)
+        with _lib.launch_trace() as tr:
+            ds3, mv3 = ep.compute_Sv_clean_MVBS(ed, pn, rsn, range_bin=rbin, ping_time_bin=tbin)
+            mv3["Sv"].shape
+        assert "sv_noise_fast_kernel" in tr.kernels and "sv_denoise_mvbs_uniform_kernel" in tr.kernels, tr.kernels
+        close(ds3["Sv_noise"].values, exp_n, 1e-9, f"chain Sv_noise {regime}")
+        close(ds3["Sv_corrected"].values, exp_c, 1e-7, f"chain Sv_corrected {regime}")
+        close(mv3["Sv"].values, exp_mvc, 1e-7, f"chain MVBS {regime}")
+    finally:
+        logging.disable(logging.NOTSET)
