@@ -147,3 +147,38 @@ def test_index_binning_matches_coarsen_formula():
     np.testing.assert_allclose(mv[1, 2, 3], 10 * np.log10(lin[1, 6:9, 21:28].mean()), rtol=1e-14)
     np.testing.assert_allclose(mv[3, 33, 571], 10 * np.log10(lin[3, 99:, 3997:].mean()), rtol=1e-14)
     assert er[0, 0, 1] == d["echo_range"][0, 0, 7]
+
+
+# ---- bin-edge membership pinned to pandas itself (round 4) ------------------------------------------------------------
+@pytest.mark.parametrize("closed", ["left", "right"])
+def test_bin_membership_equals_pandas_intervalindex(closed):
+    """The reference bins through ``pd.IntervalIndex.from_breaks(edges, closed=closed)`` handed to flox as
+    expected_groups (commongrid/utils.py:283-302, 592-627); flox factorizes against exactly those intervals.  flox cannot
+    be installed here, pandas is: the oracle's ``bin_index`` (and through it every MVBS / NASC expectation and the HIP
+    kernels held to them) must put every value -- values ON edges, just beside them, NaN, outside the grid -- where
+    ``IntervalIndex.get_indexer`` and ``pd.cut`` put it.  Range edges as the reference builds them (np.arange(0, max +
+    bin, bin), api.py:108-115) and time edges on a 20-s grid."""
+    import pandas as pd
+
+    from oracle import commongrid as ogrid
+
+    rng = np.random.default_rng(5)
+    for rbin in (1.0, 0.1, 0.07, 2.5):
+        edges = np.arange(0, 37.3 + rbin, rbin)
+        on = edges[rng.integers(0, len(edges), 200)]
+        x = np.concatenate([on, np.nextafter(on, np.inf), np.nextafter(on, -np.inf), rng.uniform(-3, 45, 500),
+                            [np.nan, -0.0, 0.0, edges[-1], edges[-1] + 1e-9, np.inf, -np.inf]])
+        ii = pd.IntervalIndex.from_breaks(edges, closed=closed)
+        want = ii.get_indexer(x)  # -1 outside / NaN
+        np.testing.assert_array_equal(ogrid.bin_index(x, edges, closed), want)
+        cut = pd.cut(x, bins=ii).codes
+        np.testing.assert_array_equal(cut, want)
+    t0 = np.datetime64("2026-05-01T00:00:00", "ns")
+    t_edges = t0 + np.arange(0, 13) * np.timedelta64(20, "s")
+    t = np.concatenate([t_edges, t_edges + np.timedelta64(1, "ns"), t_edges - np.timedelta64(1, "ns"),
+                        t0 + rng.integers(-50, 300, 200) * np.timedelta64(1, "s"), [np.datetime64("NaT")]])
+    ii = pd.IntervalIndex.from_breaks(pd.DatetimeIndex(t_edges), closed=closed)
+    ok = ~np.isnat(t)
+    want = np.full(t.shape, -1)
+    want[ok] = ii.get_indexer(pd.DatetimeIndex(t[ok]))
+    np.testing.assert_array_equal(ogrid.bin_index(t, t_edges, closed), want)
