@@ -4,6 +4,7 @@ allocation, streams, RCCL), every computation is a call into libechopype_amd.so.
 All functions run on the tensors' device and torch's current stream and return torch tensors.
 """
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -55,6 +56,7 @@ class _Uploader:
         self.device = device
         self.stream = torch.cuda.Stream(device=device)
         self.pool = []  # [pinned uint8 tensor, event of the last copy that read it]
+        self.lock = threading.Lock()  # picking a staging buffer and marking it busy is one step, also across threads
 
     def _staging(self, nbytes):
         best = None
@@ -78,17 +80,18 @@ class _Uploader:
         if nbytes == 0 or nbytes > self._MAX_BYTES:
             w = a if a.flags.writeable else a.copy()
             return torch.from_numpy(w).to(self.device)
-        slot = self._staging(nbytes)
-        staged = slot[0][:nbytes]
-        staged.numpy().view(np.uint8)[:] = a.reshape(-1).view(np.uint8)
         tdt = torch.from_numpy(np.empty(0, dtype=a.dtype)).dtype
         cur = torch.cuda.current_stream(self.device)
-        with torch.cuda.stream(self.stream):
-            out = torch.empty(a.shape, dtype=tdt, device=self.device)
-            out.view(-1).view(torch.uint8).copy_(staged, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-        slot[1] = ev
+        with self.lock:
+            slot = self._staging(nbytes)
+            staged = slot[0][:nbytes]
+            staged.numpy().view(np.uint8)[:] = a.reshape(-1).view(np.uint8)
+            with torch.cuda.stream(self.stream):
+                out = torch.empty(a.shape, dtype=tdt, device=self.device)
+                out.view(-1).view(torch.uint8).copy_(staged, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+            slot[1] = ev
         cur.wait_event(ev)
         out.record_stream(cur)  # (allocated on the upload stream, used on the current one)
         return out
@@ -138,15 +141,17 @@ class _Downloader:
         self.device = device
         self.stream = torch.cuda.Stream(device=device)
         self.pool = []  # [pinned uint8 tensor, busy marker]
+        self.lock = threading.Lock()
 
     def fetch(self, t):
         t = t.contiguous()
         nbytes = t.numel() * t.element_size()
-        slot = next((s_ for s_ in self.pool if s_[1] is None and s_[0].numel() >= nbytes), None)
-        if slot is None:
-            slot = [torch.empty(max(256, 1 << (int(nbytes) - 1).bit_length()), dtype=torch.uint8, pin_memory=True), None]
-            self.pool.append(slot)
-        slot[1] = True
+        with self.lock:
+            slot = next((s_ for s_ in self.pool if s_[1] is None and s_[0].numel() >= nbytes), None)
+            if slot is None:
+                slot = [torch.empty(max(256, 1 << (int(nbytes) - 1).bit_length()), dtype=torch.uint8, pin_memory=True), None]
+                self.pool.append(slot)
+            slot[1] = True
         host = slot[0][:nbytes].view(t.dtype).view(t.shape)
         cur = torch.cuda.current_stream(self.device)
         ready = torch.cuda.Event()

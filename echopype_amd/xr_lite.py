@@ -480,6 +480,14 @@ class DeferredDataset(Dataset):
     def __repr__(self):
         return Dataset.__repr__(self._resolve())
 
+    def __copy__(self):  # (a shallow copy of the proxy would assemble twice)
+        return self._resolve().copy()
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        return copy.deepcopy(self._resolve(), memo)
+
 
 def defer_mvbs_enabled():
     import os
