@@ -79,7 +79,9 @@ def _denoise_deferred_sv(ds_Sv, ping_num, range_sample_num, nmax, snr):
                                                     want_range_stats=True)
     except _lib.EpaError:  # e.g. more range blocks than the LDS holds
         return None
-    if float(rstats[2].item()) < 0:  # served by the generic kernel: no range statistics (K1 leaves them, plain route)
+    # served by the generic kernel?  It leaves no range statistics (K1 does, on the plain route).  Known on the host
+    # (epa_last_range_stats_filled): pass 2 is launched without waiting for pass 1
+    if not _lib.lib.epa_last_range_stats_filled():
         return None
     d.fulfil(sv_t)
     src.echo_range.set_stats(rstats)
