@@ -66,10 +66,6 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
         return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)
     e0, dt, n_t = resample_edges(ping_time, ping_time_bin)
     first_bin = 0
-    if _shard is not None:  # the time grid of the whole dataset; this shard covers global bins first_bin .. last_bin
-        e0, _, first_bin, last_bin = _shard.time_grid(ns, dt, "left")
-        e0, n_t = e0 + first_bin * dt, last_bin - first_bin + 1
-    bin_start = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t)
 
     # range grid np.arange(0, nanmax(echo_range) + bin, bin) (api.py:108-115): run on a conservative
     # grid (largest range any row can reach), get nanmax(echo_range) back as a by-product, trim
@@ -82,9 +78,14 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
             reach = torch.nan_to_num(reach, nan=float("-inf"))
             r_cap = float(reach.max().item())
             r_cap = r_cap if r_cap > float("-inf") else float("nan")
-        if _shard is not None:
-            r_cap = _shard.range_max(r_cap)
-            r_cap = r_cap if r_cap > float("-inf") else float("nan")
+    if _shard is not None:
+        # the time grid of the whole dataset (this shard covers global bins first_bin .. last_bin) and its range cap:
+        # ONE control message
+        e0, _, first_bin, last_bin, g_cap = _shard.grid(ns, dt, "left", r_cap if range_var_max is None else float("nan"))
+        e0, n_t = e0 + first_bin * dt, last_bin - first_bin + 1
+        if range_var_max is None:
+            r_cap = g_cap
+    bin_start = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t)
     n_cap = len(np.arange(0, r_cap + range_bin_m, range_bin_m)) - 1 if np.isfinite(r_cap) else 0
     # degenerate grid (one sample per ping, no valid range) or a kernel that declines (e.g. a range grid too fine for the
     # LDS accumulators): the two calls deal with it.  On a shard the fallback changes the collectives that follow, so

@@ -111,6 +111,25 @@ def global_time_grid(local_ping_ns, dt_ns, group=None):
     return e0, int((last - e0) // dt_ns + 1)
 
 
+def global_grid(local_ping_ns, dt_ns, reach, group=None):
+    """``global_time_grid`` and ``global_max`` of a non-negative number in ONE message: all-reduce MIN of
+    [first timestamp, -last timestamp, -bits(reach)] (the IEEE bit pattern of a non-negative double orders like the
+    number).  Returns (first_edge, n_bins_global, global reach; NaN when no rank has one)."""
+    t = np.asarray(local_ping_ns, dtype=np.int64)
+    t = t[t != np.iinfo(np.int64).min]
+    lo = int(t.min()) if t.size else np.iinfo(np.int64).max
+    hi = int(t.max()) if t.size else np.iinfo(np.int64).min + 1
+    r = float(reach)
+    rbits = int(np.float64(r).view(np.int64)) if (r == r and r >= 0.0 and r != float("inf")) else -1
+    first, neg_last, neg_rbits = _host_allreduce([lo, -hi, -rbits], dist.ReduceOp.MIN, group)
+    last = -neg_last
+    day = 86400 * 10**9
+    origin = (first // day) * day
+    e0 = origin + ((first - origin) // dt_ns) * dt_ns
+    gr = float(np.int64(-neg_rbits).view(np.float64)) if -neg_rbits >= 0 else float("nan")
+    return e0, int((last - e0) // dt_ns + 1), gr
+
+
 def global_max(value, group=None):
     """all-reduce MAX of one float (e.g. nanmax(echo_range) for the range grid, api.py:110); NaN = nothing here."""
     v = float(value)
@@ -401,6 +420,12 @@ class MVBSShard(ShardContext):
         e0, n_glob = global_time_grid(ns, dt, self.group)
         first, last = local_bin_span(ns, e0, dt, closed)
         return e0, n_glob, first, last
+
+    def grid(self, ns, dt, closed, reach):
+        """time_grid + range_max(reach) in one control message (reach >= 0 or NaN)."""
+        e0, n_glob, gr = global_grid(ns, dt, reach, self.group)
+        first, last = local_bin_span(ns, e0, dt, closed)
+        return e0, n_glob, first, last, gr
 
     def range_max(self, hi):
         return global_max(hi, self.group)

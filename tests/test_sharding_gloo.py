@@ -384,3 +384,38 @@ def test_plan_cache_is_keyed_on_every_ranks_layout():
     for step in (1, 3):  # nothing shared anywhere: no exchange on either rank
         assert r0[step] == (False, 0, {}) and r1[step] == (False, 0, {})
     assert res[0][2] == 2 and res[1][2] == 2  # two global layouts, two plans on every rank, both re-used
+
+
+# ---- the time grid and the range cap in one control message ------------------------------------------------------------
+def _worker_grid(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from echopype_amd import sharding
+
+    ns = np.datetime64("2026-05-01T00:00:03", "ns").astype(np.int64) + (np.arange(40) + 40 * rank) * 10**9
+    shard = sharding.MVBSShard()
+    reach = [12.5, float("nan"), 786.4921875][rank]           # rank 1 has no valid range at all
+    a = shard.grid(ns, 20 * 10**9, "left", reach)
+    b = shard.time_grid(ns, 20 * 10**9, "left") + (shard.range_max(reach),)
+    none = shard.grid(ns, 20 * 10**9, "left", float("nan"))  # nobody has one: NaN
+    q.put((rank, a, b, none[4]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grid_in_one_message_equals_the_two_separate_agreements():
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_grid, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, a, b, none in res:
+        assert a == b and a[4] == 786.4921875 and np.isnan(none)
+    assert [r[1][2] for r in res] == [0, 2, 4] and res[0][1][0] == res[2][1][0]
