@@ -584,19 +584,22 @@ struct RaggedWindow {
 
 constexpr int kCandCap = 2048;  // candidates kept in LDS once the selected radix bucket is this small
 
-struct SelectScratch {
+template <int CAP>
+struct SelectScratchT {
+  static constexpr int kCap = CAP;
   unsigned hist[256];
   unsigned u4[4];
   unsigned long long q4[4];
   unsigned digit, krem, bucket, ncand;
-  unsigned long long cand[kCandCap];
+  unsigned long long cand[CAP];
 };
+using SelectScratch = SelectScratchT<kCandCap>;
 
 // One 8-bit radix step of the selection: histogram of digit (key >> shift) & 255 over the keys that
 // `each` enumerates and that match `prefix` on the bits above the digit; picks the bucket holding
 // rank k.  Returns the total number of keys counted; updates prefix / k; *bucket = size of the bucket.
-template <typename Each>
-__device__ __forceinline__ unsigned radix_step(Each each, SelectScratch* sc, int shift,
+template <typename Each, typename SC>
+__device__ __forceinline__ unsigned radix_step(Each each, SC* sc, int shift,
                                                unsigned long long& prefix, unsigned& k, unsigned& bucket,
                                                bool k_known, unsigned* total_out) {
   __syncthreads();
@@ -650,9 +653,10 @@ __device__ __forceinline__ unsigned radix_step(Each each, SelectScratch* sc, int
 // The window is swept from memory only until the bucket that holds the median has at most kCandCap
 // members (typically 2 sweeps for a 16 k-element block of dB values, 0 for a small window); those
 // candidates are then gathered into LDS in one more sweep and the remaining digits are resolved there.
-template <typename W>
-__device__ double window_median_lin(const W& w, SelectScratch* sc, const double* exp2_tab,
+template <typename W, typename SC>
+__device__ double window_median_lin(const W& w, SC* sc, const double* exp2_tab,
                                     unsigned& n_valid, int size_hint = 0x7fffffff) {
+  constexpr int kCandCap = SC::kCap;  // (shadows the default capacity)
   auto each_global = [&](auto f) {
     w.for_each([&](double v) {
       if (v == v) f(sort_key(v));
@@ -769,6 +773,302 @@ __global__ __launch_bounds__(kBlock) void pool_median_kernel(const T* __restrict
     if (threadIdx.x == 0) {
       if (pooled) pooled[job] = out;
       if (mask) mask[job] = (sv[job] - out > thr) ? 1 : 0;
+    }
+  }
+}
+
+// The same pooled median with the window CARRIED from ping to ping (round 4).  A workgroup owns one range column s of
+// one channel and walks a segment of pings (lane i owns window column i: the entering row p+n+1 is one coalesced
+// read).  A two-level histogram of the (2n+1) x (2m+1) window -- 4096 bins + 64 coarse sums -- is kept up to date with
+// 2 (2m+1) LDS atomics per step; the bin that holds the median rank comes from two 64-lane prefix scans (DPP; every
+// searching wavefront does them redundantly: no broadcast, no barrier), the handful of values of that bin (and of the
+// bin of the upper middle value when the count is even) are then ranked by counting.  The bins are 1/128 dB wide over
+// +-16 dB around the median of the segment's first window (found with 1/16-dB bins over [-256, 0) dB first), values
+// outside are clamped into the end bins: any monotone map selects exactly, a good one keeps the candidates few.  When
+// the median has drifted more than 8 dB from the centre and the candidates are many, the map is re-centred and the
+// histogram rebuilt.  Exact (the same two middle values, averaged in the linear domain); more than 64 values in the
+// median's bin (a flat field) fall back to the radix selection over the window in memory.
+// O(2m+1 + window/1000) per sample instead of O(window) per sample and sweep.
+constexpr int kMedBins = 4096, kMedCoarse = 64, kMedSeg = 512, kMedCap = 512;
+
+struct MedMap {
+  float scale, off;  // bin = clamp(x * scale + off)
+  __device__ __forceinline__ unsigned bin(double x) const {
+    return (unsigned)fminf(fmaxf(fmaf((float)x, scale, off), 0.0f), (float)(kMedBins - 1));
+  }
+};
+
+// inclusive prefix sum over the 64 lanes in 6 DPP additions (no LDS crossbar round trips): Hillis-Steele inside the
+// rows of 16 lanes (a lane whose source falls outside its row adds 0), then the last lane of row 0 / 2 into rows 1 / 3,
+// then lane 31 into rows 2 and 3.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_add(unsigned v) {
+  return v + (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ unsigned wave_scan_incl(unsigned v) {
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+// lane (= bin of a 64-bin histogram held one count per lane) that holds 0-based rank k < total; rem = rank inside it
+__device__ __forceinline__ unsigned wave_rank_lane(unsigned incl, unsigned v, unsigned k, unsigned& rem) {
+  const unsigned long long bal = __ballot(incl > k);
+  const int at = __ffsll((long long)bal) - 1;
+  rem = k - (unsigned)__builtin_amdgcn_readlane((int)(incl - v), at);
+  return (unsigned)at;
+}
+
+__device__ __forceinline__ unsigned long long wave_bcast64(unsigned long long v, int src) {  // src wavefront-uniform
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, src);
+  const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+constexpr unsigned kMedNoBin = 0xffffu;  // bin of a NaN (and of the padding of the bin ring)
+constexpr int kMedSel = 64;              // candidates the finishing wavefront ranks: one per lane
+
+// Two 16-bit bins per word: non-zero iff one of them lies in [b1, b1 + span] -- packed subtract (wraps below b1),
+// then saturating subtract from span + 1.  2 VALU instructions per 2 bins.
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned halves_in_span(unsigned x, unsigned b1b1, unsigned span1) {
+  const ushort2_t d = __builtin_bit_cast(ushort2_t, x) - __builtin_bit_cast(ushort2_t, b1b1);
+  const ushort2_t r = __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2_t, span1), d);
+  return __builtin_bit_cast(unsigned, r);
+}
+
+// What the workgroup keeps in LDS is the BIN of every window value (2 bytes), not the value: a leaving row is
+// un-counted from its bins, the members of the median's bin are found by comparing bins (4 per lane and read), and
+// only those few values are read again from memory (L2) -- by wavefront 3, one step later, while wavefronts 0-2
+// already search the next window: it ranks the candidates (one per lane, the others' keys by readlane), converts
+// and writes the result of the previous ping.  38 KB of LDS per workgroup instead of 80: 4 workgroups per CU hide
+// each other's barrier and LDS latencies.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pool_median_slide_kernel(const T* __restrict__ sv, int P, int S,
+                                                                   int s0, int n, int m, int nseg,
+                                                                   long long jobs, T thr,
+                                                                   T* __restrict__ pooled,
+                                                                   uint8_t* __restrict__ mask) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ SelectScratchT<kMedCap> sc;  // the radix selection's scratch (flat fields only)
+  const epa::MathTabs mt = epa::build_math_tabs(smem);
+  const int w = 2 * m + 1, R = 2 * n + 1, W = R * w, npack = (W + 3) >> 2;
+  unsigned* fine = reinterpret_cast<unsigned*>(smem + epa::kMathTabBytes);
+  unsigned* coarse = fine + kMedBins;
+  unsigned* ncand = coarse + kMedCoarse;                      // [2] (+ 2 words of padding), by parity of the ping
+  unsigned* meta = ncand + 4;                                 // [2][4]: state, r1, dk, b1
+  unsigned short* cidx = reinterpret_cast<unsigned short*>(meta + 8);  // [2][kMedSel] window elements of the candidates
+  unsigned short* bins = cidx + 2 * kMedSel;                  // [4 * npack]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool finisher = tid >= kBlock - 64;
+  const float inv_w = 1.0f / (float)w;
+  for (long long job = blockIdx.x; job < jobs; job += gridDim.x) {
+    const int s = (int)(job % S);
+    const long long t = job / S;
+    const int seg = (int)(t % nseg);
+    const size_t cbase = (size_t)(t / nseg) * P * S;
+    const int p0 = seg * kMedSeg, p1 = min(P, p0 + kMedSeg);
+    if (s < s0) {  // above the first pooled sample: NaN, never masked
+      for (int p = p0 + tid; p < p1; p += kBlock) {
+        const size_t at = cbase + (size_t)p * S + s;
+        if (pooled) pooled[at] = epa::M<T>::nan();
+        if (mask) mask[at] = 0;
+      }
+      continue;
+    }
+    const T* __restrict__ chan = sv + cbase;
+    MedMap map{16.0f, 4096.0f};
+    auto enter = [&](int e, T v) {  // value v becomes element e of the window
+      unsigned b = kMedNoBin;
+      if (v == v) {
+        b = map.bin((double)v);
+        atomicAdd(&fine[b], 1u);
+        atomicAdd(&coarse[b >> 6], 1u);
+      }
+      bins[e] = (unsigned short)b;
+    };
+    // element e of the window of ping p (ring slot rs holds its oldest row p - n): where it lives in memory
+    auto element = [&](int e, int p, int rs) -> const T* {
+      int slot = (int)(((float)e + 0.5f) * inv_w);
+      if (slot * w > e) --slot;
+      else if ((slot + 1) * w <= e) ++slot;
+      int k = slot - rs;
+      if (k < 0) k += R;
+      return chan + (size_t)reflect_index(p - n + k, P) * S + s0 + reflect_index(s - m + (e - slot * w) - s0, S - s0);
+    };
+    // bins (of rank k1 = lower middle, k1 + dk = upper middle) from the two-level histogram; false: no valid value
+    auto middle_bins = [&](unsigned& b1, unsigned& b2, unsigned& r1, unsigned& dk) -> bool {
+      const unsigned cv = coarse[lane];
+      const unsigned ci = wave_scan_incl(cv);
+      const unsigned N = (unsigned)__builtin_amdgcn_readlane((int)ci, 63);
+      if (!N) return false;
+      const unsigned k1 = (N - 1u) >> 1;
+      dk = (N & 1u) ? 0u : 1u;
+      unsigned rem1, rem2, r2;
+      const unsigned cb1 = wave_rank_lane(ci, cv, k1, rem1);
+      const unsigned cb2 = wave_rank_lane(ci, cv, k1 + dk, rem2);
+      const unsigned fv = fine[cb1 * 64 + lane];
+      const unsigned fi = wave_scan_incl(fv);
+      b1 = cb1 * 64 + wave_rank_lane(fi, fv, rem1, r1);
+      if (cb2 == cb1) {
+        b2 = cb1 * 64 + wave_rank_lane(fi, fv, rem2, r2);
+      } else {
+        const unsigned gv = fine[cb2 * 64 + lane];
+        const unsigned gi = wave_scan_incl(gv);
+        b2 = cb2 * 64 + wave_rank_lane(gi, gv, rem2, r2);
+      }
+      return true;
+    };
+    // histogram and bins of the window of ping p from memory (called by all threads; nobody reads either meanwhile)
+    auto rebuild = [&](int p, int rs) {
+      for (int i = tid; i < kMedBins + kMedCoarse; i += kBlock) fine[i] = 0u;
+      __syncthreads();
+      for (int e = tid; e < W; e += kBlock) enter(e, *element(e, p, rs));
+      __syncthreads();
+    };
+    // 1/128-dB bins centred on the value of bin b of the current map
+    auto recentre = [&](unsigned b) {
+      const float centre = ((float)b + 0.5f - map.off) / map.scale;
+      map.scale = 128.0f;
+      map.off = (float)(kMedBins / 2) - centre * 128.0f;
+    };
+    // wavefront 3: the median of ping pp from its listed candidates (parity z, ring slot rs of its oldest row)
+    auto finish = [&](int pp, int z, int rs, T xc) {
+      const unsigned state = meta[4 * z], r1 = meta[4 * z + 1], dk = meta[4 * z + 2];
+      if (state == 2u) return;  // (a flat field: written by the radix selection already)
+      T out = epa::M<T>::nan();
+      if (state == 1u) {
+        const int M = __builtin_amdgcn_readfirstlane((int)ncand[z]);  // <= kMedSel
+        unsigned long long ki = ~0ull;
+        if (lane < M) ki = sort_key((double)*element((int)cidx[z * kMedSel + lane], pp, rs));
+        unsigned rank = 0u;
+        for (int j = 0; j < M; ++j) {
+          const unsigned long long kj = wave_bcast64(ki, j);
+          rank += (kj < ki || (kj == ki && j < lane)) ? 1u : 0u;
+        }
+        const int a1 = __ffsll((long long)__ballot(lane < M && rank == r1)) - 1;
+        const int a2 = __ffsll((long long)__ballot(lane < M && rank == r1 + dk)) - 1;
+        const unsigned long long ka = wave_bcast64(ki, a1), kb = wave_bcast64(ki, a2);
+        const double la = epa::lin_from_db(key_value(ka), mt.exp2_tab);
+        const double med = ka == kb ? la : (la + epa::lin_from_db(key_value(kb), mt.exp2_tab)) * 0.5;
+        out = (T)(10.0 * epa::fast_log10(med, mt.log_tab));
+      }
+      if (lane == 0) {
+        const size_t at = cbase + (size_t)pp * S + s;
+        if (pooled) pooled[at] = out;
+        if (mask) mask[at] = (xc - out > thr) ? 1 : 0;
+      }
+    };
+    __syncthreads();  // the previous job's last readers
+    if (tid < 4) {
+      ncand[tid] = 0u;
+      bins[4 * (npack - 1) + tid] = (unsigned short)kMedNoBin;  // (the padding of the last pack)
+    }
+    rebuild(p0, 0);
+    {
+      unsigned b1, b2, r1, dk;
+      const bool any = middle_bins(b1, b2, r1, dk);
+      __syncthreads();
+      if (any) {
+        recentre(b1);
+        rebuild(p0, 0);
+      }
+    }
+    const bool own = tid < w;
+    const T* __restrict__ colp = chan + (own ? s0 + reflect_index(s - m + tid - s0, S - s0) : 0);
+    int rs = 0;  // ring slot of the row that leaves next
+    T xc = (T)0, xc_prev = (T)0;
+    for (int p = p0; p < p1; ++p) {
+      const bool more = p + 1 < p1;
+      const int z = p & 1;
+      T vin = epa::M<T>::nan();
+      if (own && more) vin = colp[(size_t)reflect_index(p + n + 1, P) * S];  // requested now, used after the search
+      xc_prev = xc;
+      if (tid == kBlock - 64 && mask) xc = chan[(size_t)p * S + s];
+      unsigned* nc = &ncand[z];
+      unsigned state, M;
+      for (bool first = true;; first = false) {
+        __syncthreads();  // B1: bins and histogram hold the window of ping p; *nc == 0
+        if (!finisher) {
+          unsigned b1 = 0u, b2 = 0u, r1 = 0u, dk = 0u;
+          const bool any = middle_bins(b1, b2, r1, dk);
+          if (tid == 0) {
+            meta[4 * z] = any ? 1u : 0u;
+            meta[4 * z + 1] = r1;
+            meta[4 * z + 2] = dk;
+            meta[4 * z + 3] = b1;
+          }
+          if (any) {  // the members of those bins (the bins between b1 and b2 are empty: "in [b1, b2]" selects them)
+            const unsigned h1 = b1 * 0x00010001u, sp = (b2 - b1 + 1u) * 0x00010001u;
+            const uint2* packs = reinterpret_cast<const uint2*>(bins);
+            constexpr int kSearch = kBlock - 64;
+            for (int j0 = tid; j0 < npack; j0 += 2 * kSearch) {
+              const int j1 = j0 + kSearch;
+              const uint2 pa = packs[j0];
+              uint2 pb = packs[min(j1, npack - 1)];
+              if (j1 >= npack) pb.x = pb.y = 0xffffffffu;
+              const unsigned hit = halves_in_span(pa.x, h1, sp) | halves_in_span(pa.y, h1, sp) |
+                                   halves_in_span(pb.x, h1, sp) | halves_in_span(pb.y, h1, sp);
+              if (hit) {
+                const unsigned q4[8] = {pa.x & 0xffffu, pa.x >> 16, pa.y & 0xffffu, pa.y >> 16,
+                                        pb.x & 0xffffu, pb.x >> 16, pb.y & 0xffffu, pb.y >> 16};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                  if (q4[u] - b1 <= b2 - b1) {
+                    const unsigned slot = atomicAdd(nc, 1u);
+                    if (slot < (unsigned)kMedSel)
+                      cidx[z * kMedSel + slot] = (unsigned short)(4 * (u < 4 ? j0 : j1) + (u & 3));
+                  }
+                }
+              }
+            }
+          }
+        } else if (first && p > p0) {
+          finish(p - 1, z ^ 1, rs == 0 ? R - 1 : rs - 1, xc_prev);
+          if (lane == 0) ncand[z ^ 1] = 0u;
+        }
+        __syncthreads();  // B2: candidates listed; nobody reads the histogram or the bins of ping p below
+        state = meta[4 * z];
+        M = state ? *nc : 0u;
+        if (M <= (unsigned)kMedSel) break;
+        const int drift = (int)meta[4 * z + 3] - kMedBins / 2;
+        if (drift < kMedBins / 4 && drift > -kMedBins / 4) break;
+        // many candidates and the median more than 8 dB from the centre of the map: re-centre, search again
+        recentre(meta[4 * z + 3]);
+        __syncthreads();  // (everybody has read *nc and meta)
+        if (tid == 0) *nc = 0u;
+        rebuild(p, rs);
+      }
+      if (M > (unsigned)kMedSel) {  // more than 64 values within 1/128 dB of the median: radix selection from memory
+        Window<T> gw{chan, S, p - n, R, s - m, w, P, s0, true};
+        unsigned nv;
+        const double med = window_median_lin(gw, &sc, mt.exp2_tab, nv, W);
+        const T out = (T)(10.0 * epa::fast_log10(med, mt.log_tab));
+        if (tid == kBlock - 64) {
+          const size_t at = cbase + (size_t)p * S + s;
+          if (pooled) pooled[at] = out;
+          if (mask) mask[at] = (xc - out > thr) ? 1 : 0;
+        }
+        if (tid == 0) meta[4 * z] = 2u;
+      }
+      if (more && own) {  // row p-n leaves, row p+n+1 enters (same ring slot)
+        const int e = rs * w + tid;
+        const unsigned ob = bins[e];
+        if (ob != kMedNoBin) {
+          atomicSub(&fine[ob], 1u);
+          atomicSub(&coarse[ob >> 6], 1u);
+        }
+        enter(e, vin);
+      }
+      rs = rs + 1 == R ? 0 : rs + 1;
+    }
+    __syncthreads();
+    if (finisher) {  // the last ping of the segment
+      finish(p1 - 1, (p1 - 1) & 1, rs == 0 ? R - 1 : rs - 1, xc);
     }
   }
 }
@@ -2100,6 +2400,25 @@ extern "C" int epa_pool_sv(const void* sv, int C, int P, int S, int first_sample
   const int s0 = first_sample < S ? first_sample : S;
   const int n = num_side_pings, m = num_side_samples;
   if (func == EPA_POOL_NANMEDIAN) {
+    const size_t W = (size_t)(2 * n + 1) * (2 * m + 1);
+    const size_t slide_lds = epa::kMathTabBytes + (size_t)(kMedBins + kMedCoarse + 4 + 8) * 4 + 2 * kMedSel * 2 +
+                             ((W + 3) / 4) * 8;
+    if (2 * m + 1 <= kBlock && W <= 65535 && slide_lds + sizeof(SelectScratchT<kMedCap>) + 512 <= kMaxLds) {
+      // the window carried from ping to ping: one workgroup per (channel, ping segment, column)
+      const int nseg = (P + kMedSeg - 1) / kMedSeg;
+      const long long jobs = (long long)C * nseg * S;
+      const int grid = (int)(jobs < (1 << 22) ? jobs : (1 << 22));
+#define EPA_MS(T)                                                                                    \
+  do {                                                                                               \
+    auto kern = pool_median_slide_kernel<T>;                                                         \
+    if (int rc = set_lds(kern, slide_lds)) return rc;                                                \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), slide_lds, st, (const T*)sv, P, S, s0, n, m,  \
+                       nseg, jobs, (T)threshold, (T*)pooled_out, mask_out);                          \
+  } while (0)
+      if (dtype == EPA_F64) EPA_MS(double); else EPA_MS(float);
+#undef EPA_MS
+      return epa::check_launch("pool_median_slide_kernel");
+    }
     const long long jobs = (long long)C * P * S;
     const int grid = (int)(jobs < (1 << 20) ? jobs : (1 << 20));
     if (dtype == EPA_F64)

@@ -60,5 +60,9 @@ for dt, b in ((torch.float64, 8), (torch.float32, 4)):
     svm, rgm = sv[:1, :Pm].contiguous(), rng[:1, :Pm].contiguous()
     nvm, _ = ops.range_rows_check(rgm)
     timeit(f"pool_sv nanmedian 51 x {2*n10+1} (1 x {Pm} x {S})", lambda: ops.pool_sv(svm, 100, 25, n10, func="nanmedian", threshold=12.0, want_pooled=False), svm.numel(), 0, reps=1)
+    Pb = min(P, 4096)
+    svb = sv[:1, :Pb].contiguous()
+    timeit(f"pool_sv nanmedian 51 x {2*n10+1} (1 x {Pb} x {S})", lambda: ops.pool_sv(svb, 100, 25, n10, func="nanmedian", threshold=12.0, want_pooled=False), svb.numel(), 0, reps=1)
+    del svb
     timeit(f"pool_sv_value nanmedian n=25 +-10 m (1 x {Pm} x {S})", lambda: ops.pool_sv_value(svm, rgm, nvm, 10.0, 25, 20.0, lo, hi, func="nanmedian", threshold=12.0, want_pooled=False), svm.numel(), 0, reps=1)
     del sv, rng

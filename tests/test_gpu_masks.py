@@ -291,6 +291,83 @@ def test_pool_sv_sliding_sum_keeps_small_values_after_a_huge_one(env):
     np.testing.assert_array_equal(got2[~hit], got[~hit])
 
 
+def _median_filter_db(sv2d, n, m):
+    import scipy.ndimage
+
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+        lin = 10 ** (sv2d.astype(np.float64) / 10)
+        return 10 * np.log10(scipy.ndimage.generic_filter(lin, np.nanmedian, size=[2 * n + 1, 2 * m + 1],
+                                                          mode="reflect"))
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_pool_sv_median_window_carried_from_ping_to_ping(env, dtype):
+    """nanmedian pooling walks the pings with the window in an LDS ring and a histogram kept up to date (entering /
+    leaving row): three 512-ping segments, values below and above the histogram's [-256, 0) dB span (clamped bins),
+    +-inf, 8 % NaN, a block with no valid value, even and odd counts -- against scipy's generic_filter + np.nanmedian,
+    the engine the reference's own test uses (tests/clean/test_noise.py:342-441)."""
+    from echopype_amd import _lib
+
+    torch, ops = env
+    rng = np.random.default_rng(21)
+    P, S, n, m = 1100, 24, 6, 4
+    sv = -80 + 3 * rng.standard_normal((1, P, S))
+    sv[0, rng.random((P, S)) < 0.04] = -300 - 20 * rng.random()
+    sv[0, rng.random((P, S)) < 0.04] = 5 + 20 * rng.random()
+    sv[0, 200:260, 3:9] = -330 + 30 * rng.random((60, 6))        # windows whose median lies in the lowest bin
+    sv[0, 600:650, 12:20] = 10 + 30 * rng.random((50, 8))        # ... in the highest bin
+    sv[0, 505:520, 5] = np.inf
+    sv[0, 900, 10:14] = -np.inf
+    sv[0, rng.random((P, S)) < 0.08] = np.nan
+    sv[0, 300:320, :] = np.nan
+    sv = sv.astype(dtype)
+    thr = 6.0
+    with _lib.launch_trace() as tr:
+        pooled, mask = ops.pool_sv(_dev(torch, sv), 2, n, m, func="nanmedian", threshold=thr)
+    assert "pool_median_slide_kernel" in tr.kernels
+    got = pooled.cpu().numpy()[0]
+    assert np.isnan(got[:, :2]).all() and not mask.cpu().numpy()[0, :, :2].any()
+    exp2 = _median_filter_db(sv[0, :, 2:], n, m)  # pooled from the first sample on: the reflect domain starts there
+    _close(got[:, 2:], exp2, RTOL[dtype], "carried median")
+    assert np.isnan(exp2).any() and (exp2[np.isfinite(exp2)] < -256).any() and (exp2[np.isfinite(exp2)] > 0).any()
+    with np.errstate(invalid="ignore"):
+        margin = sv[0, :, 2:].astype(np.float64) - exp2 - thr
+    sure = ~(np.abs(margin) < MARGIN[dtype])
+    np.testing.assert_array_equal(mask.cpu().numpy()[0, :, 2:].astype(bool)[sure], (margin > 0)[sure])
+
+
+def test_pool_sv_median_of_a_flat_field_uses_the_radix_selection(env):
+    """625 values within 0.01 dB: the median's histogram bin holds the whole window (more than the 512 candidates the
+    counting rank takes), every step falls back to the radix selection over the ring -- same answer."""
+    torch, ops = env
+    rng = np.random.default_rng(22)
+    P, S, n, m = 30, 30, 12, 12
+    sv = -70.003 + 0.01 * rng.random((1, P, S))
+    sv[0, rng.random((P, S)) < 0.05] = np.nan
+    exp = _median_filter_db(sv[0], n, m)
+    pooled, _ = ops.pool_sv(_dev(torch, sv), 0, n, m, func="nanmedian")
+    _close(pooled.cpu().numpy()[0], exp, 1e-12, "flat field")
+    # two bins, 300 + 325 values: the counting rank, with ties
+    sv2 = np.where(rng.random((1, P, S)) < 0.5, -70.0, -69.9)
+    exp = _median_filter_db(sv2[0], n, m)
+    pooled, _ = ops.pool_sv(_dev(torch, sv2), 0, n, m, func="nanmedian")
+    _close(pooled.cpu().numpy()[0], exp, 1e-12, "two values")
+
+
+def test_pool_sv_median_window_wider_than_a_workgroup_sweeps_every_window(env):
+    """2m+1 > 256 columns (or a window that does not fit the LDS ring): one workgroup per output sample, every window
+    swept from memory (the round-1 kernel)."""
+    from echopype_amd import _lib
+
+    torch, ops = env
+    sv, _ = _scene(1, 4, 40, 12, spikes=False, nan_frac=0.1)
+    exp = _median_filter_db(sv[0], 1, 130)
+    with _lib.launch_trace() as tr:
+        pooled, _ = ops.pool_sv(_dev(torch, sv), 0, 1, 130, func="nanmedian")
+    assert "pool_median_kernel" in tr.kernels
+    _close(pooled.cpu().numpy()[0], exp, 1e-9, "wide window")
+
+
 @pytest.mark.parametrize("same_rows", [False, True, "mixed"])
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_pool_sv_value_running_sums_equal_window_sums(env, dtype, same_rows):
