@@ -829,250 +829,6 @@ __device__ __forceinline__ unsigned long long wave_bcast64(unsigned long long v,
   return ((unsigned long long)hi << 32) | lo;
 }
 
-constexpr unsigned kMedNoBin = 0xffffu;  // bin of a NaN (and of the padding of the bin ring)
-constexpr int kMedSel = 64;              // candidates the finishing wavefront ranks: one per lane
-
-// Two 16-bit bins per word: non-zero iff one of them lies in [b1, b1 + span] -- packed subtract (wraps below b1),
-// then saturating subtract from span + 1.  2 VALU instructions per 2 bins.
-typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned halves_in_span(unsigned x, unsigned b1b1, unsigned span1) {
-  const ushort2_t d = __builtin_bit_cast(ushort2_t, x) - __builtin_bit_cast(ushort2_t, b1b1);
-  const ushort2_t r = __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2_t, span1), d);
-  return __builtin_bit_cast(unsigned, r);
-}
-
-// What the workgroup keeps in LDS is the BIN of every window value (2 bytes), not the value: a leaving row is
-// un-counted from its bins, the members of the median's bin are found by comparing bins (4 per lane and read), and
-// only those few values are read again from memory (L2) -- by wavefront 3, one step later, while wavefronts 0-2
-// already search the next window: it ranks the candidates (one per lane, the others' keys by readlane), converts
-// and writes the result of the previous ping.  38 KB of LDS per workgroup instead of 80: 4 workgroups per CU hide
-// each other's barrier and LDS latencies.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void pool_median_slide_kernel(const T* __restrict__ sv, int P, int S,
-                                                                   int s0, int n, int m, int nseg,
-                                                                   long long jobs, T thr,
-                                                                   T* __restrict__ pooled,
-                                                                   uint8_t* __restrict__ mask) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ SelectScratchT<kMedCap> sc;  // the radix selection's scratch (flat fields only)
-  const epa::MathTabs mt = epa::build_math_tabs(smem);
-  const int w = 2 * m + 1, R = 2 * n + 1, W = R * w, npack = (W + 3) >> 2;
-  unsigned* fine = reinterpret_cast<unsigned*>(smem + epa::kMathTabBytes);
-  unsigned* coarse = fine + kMedBins;
-  unsigned* ncand = coarse + kMedCoarse;                      // [2] (+ 2 words of padding), by parity of the ping
-  unsigned* meta = ncand + 4;                                 // [2][4]: state, r1, dk, b1
-  unsigned short* cidx = reinterpret_cast<unsigned short*>(meta + 8);  // [2][kMedSel] window elements of the candidates
-  unsigned short* bins = cidx + 2 * kMedSel;                  // [4 * npack]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const bool finisher = tid >= kBlock - 64;
-  const float inv_w = 1.0f / (float)w;
-  for (long long job = blockIdx.x; job < jobs; job += gridDim.x) {
-    const int s = (int)(job % S);
-    const long long t = job / S;
-    const int seg = (int)(t % nseg);
-    const size_t cbase = (size_t)(t / nseg) * P * S;
-    const int p0 = seg * kMedSeg, p1 = min(P, p0 + kMedSeg);
-    if (s < s0) {  // above the first pooled sample: NaN, never masked
-      for (int p = p0 + tid; p < p1; p += kBlock) {
-        const size_t at = cbase + (size_t)p * S + s;
-        if (pooled) pooled[at] = epa::M<T>::nan();
-        if (mask) mask[at] = 0;
-      }
-      continue;
-    }
-    const T* __restrict__ chan = sv + cbase;
-    MedMap map{16.0f, 4096.0f};
-    auto enter = [&](int e, T v) {  // value v becomes element e of the window
-      unsigned b = kMedNoBin;
-      if (v == v) {
-        b = map.bin((double)v);
-        atomicAdd(&fine[b], 1u);
-        atomicAdd(&coarse[b >> 6], 1u);
-      }
-      bins[e] = (unsigned short)b;
-    };
-    // element e of the window of ping p (ring slot rs holds its oldest row p - n): where it lives in memory
-    auto element = [&](int e, int p, int rs) -> const T* {
-      int slot = (int)(((float)e + 0.5f) * inv_w);
-      if (slot * w > e) --slot;
-      else if ((slot + 1) * w <= e) ++slot;
-      int k = slot - rs;
-      if (k < 0) k += R;
-      return chan + (size_t)reflect_index(p - n + k, P) * S + s0 + reflect_index(s - m + (e - slot * w) - s0, S - s0);
-    };
-    // bins (of rank k1 = lower middle, k1 + dk = upper middle) from the two-level histogram; false: no valid value
-    auto middle_bins = [&](unsigned& b1, unsigned& b2, unsigned& r1, unsigned& dk) -> bool {
-      const unsigned cv = coarse[lane];
-      const unsigned ci = wave_scan_incl(cv);
-      const unsigned N = (unsigned)__builtin_amdgcn_readlane((int)ci, 63);
-      if (!N) return false;
-      const unsigned k1 = (N - 1u) >> 1;
-      dk = (N & 1u) ? 0u : 1u;
-      unsigned rem1, rem2, r2;
-      const unsigned cb1 = wave_rank_lane(ci, cv, k1, rem1);
-      const unsigned cb2 = wave_rank_lane(ci, cv, k1 + dk, rem2);
-      const unsigned fv = fine[cb1 * 64 + lane];
-      const unsigned fi = wave_scan_incl(fv);
-      b1 = cb1 * 64 + wave_rank_lane(fi, fv, rem1, r1);
-      if (cb2 == cb1) {
-        b2 = cb1 * 64 + wave_rank_lane(fi, fv, rem2, r2);
-      } else {
-        const unsigned gv = fine[cb2 * 64 + lane];
-        const unsigned gi = wave_scan_incl(gv);
-        b2 = cb2 * 64 + wave_rank_lane(gi, gv, rem2, r2);
-      }
-      return true;
-    };
-    // histogram and bins of the window of ping p from memory (called by all threads; nobody reads either meanwhile)
-    auto rebuild = [&](int p, int rs) {
-      for (int i = tid; i < kMedBins + kMedCoarse; i += kBlock) fine[i] = 0u;
-      __syncthreads();
-      for (int e = tid; e < W; e += kBlock) enter(e, *element(e, p, rs));
-      __syncthreads();
-    };
-    // 1/128-dB bins centred on the value of bin b of the current map
-    auto recentre = [&](unsigned b) {
-      const float centre = ((float)b + 0.5f - map.off) / map.scale;
-      map.scale = 128.0f;
-      map.off = (float)(kMedBins / 2) - centre * 128.0f;
-    };
-    // wavefront 3: the median of ping pp from its listed candidates (parity z, ring slot rs of its oldest row)
-    auto finish = [&](int pp, int z, int rs, T xc) {
-      const unsigned state = meta[4 * z], r1 = meta[4 * z + 1], dk = meta[4 * z + 2];
-      if (state == 2u) return;  // (a flat field: written by the radix selection already)
-      T out = epa::M<T>::nan();
-      if (state == 1u) {
-        const int M = __builtin_amdgcn_readfirstlane((int)ncand[z]);  // <= kMedSel
-        unsigned long long ki = ~0ull;
-        if (lane < M) ki = sort_key((double)*element((int)cidx[z * kMedSel + lane], pp, rs));
-        unsigned rank = 0u;
-        for (int j = 0; j < M; ++j) {
-          const unsigned long long kj = wave_bcast64(ki, j);
-          rank += (kj < ki || (kj == ki && j < lane)) ? 1u : 0u;
-        }
-        const int a1 = __ffsll((long long)__ballot(lane < M && rank == r1)) - 1;
-        const int a2 = __ffsll((long long)__ballot(lane < M && rank == r1 + dk)) - 1;
-        const unsigned long long ka = wave_bcast64(ki, a1), kb = wave_bcast64(ki, a2);
-        const double la = epa::lin_from_db(key_value(ka), mt.exp2_tab);
-        const double med = ka == kb ? la : (la + epa::lin_from_db(key_value(kb), mt.exp2_tab)) * 0.5;
-        out = (T)(10.0 * epa::fast_log10(med, mt.log_tab));
-      }
-      if (lane == 0) {
-        const size_t at = cbase + (size_t)pp * S + s;
-        if (pooled) pooled[at] = out;
-        if (mask) mask[at] = (xc - out > thr) ? 1 : 0;
-      }
-    };
-    __syncthreads();  // the previous job's last readers
-    if (tid < 4) {
-      ncand[tid] = 0u;
-      bins[4 * (npack - 1) + tid] = (unsigned short)kMedNoBin;  // (the padding of the last pack)
-    }
-    rebuild(p0, 0);
-    {
-      unsigned b1, b2, r1, dk;
-      const bool any = middle_bins(b1, b2, r1, dk);
-      __syncthreads();
-      if (any) {
-        recentre(b1);
-        rebuild(p0, 0);
-      }
-    }
-    const bool own = tid < w;
-    const T* __restrict__ colp = chan + (own ? s0 + reflect_index(s - m + tid - s0, S - s0) : 0);
-    int rs = 0;  // ring slot of the row that leaves next
-    T xc = (T)0, xc_prev = (T)0;
-    for (int p = p0; p < p1; ++p) {
-      const bool more = p + 1 < p1;
-      const int z = p & 1;
-      T vin = epa::M<T>::nan();
-      if (own && more) vin = colp[(size_t)reflect_index(p + n + 1, P) * S];  // requested now, used after the search
-      xc_prev = xc;
-      if (tid == kBlock - 64 && mask) xc = chan[(size_t)p * S + s];
-      unsigned* nc = &ncand[z];
-      unsigned state, M;
-      for (bool first = true;; first = false) {
-        __syncthreads();  // B1: bins and histogram hold the window of ping p; *nc == 0
-        if (!finisher) {
-          unsigned b1 = 0u, b2 = 0u, r1 = 0u, dk = 0u;
-          const bool any = middle_bins(b1, b2, r1, dk);
-          if (tid == 0) {
-            meta[4 * z] = any ? 1u : 0u;
-            meta[4 * z + 1] = r1;
-            meta[4 * z + 2] = dk;
-            meta[4 * z + 3] = b1;
-          }
-          if (any) {  // the members of those bins (the bins between b1 and b2 are empty: "in [b1, b2]" selects them)
-            const unsigned h1 = b1 * 0x00010001u, sp = (b2 - b1 + 1u) * 0x00010001u;
-            const uint2* packs = reinterpret_cast<const uint2*>(bins);
-            constexpr int kSearch = kBlock - 64;
-            for (int j0 = tid; j0 < npack; j0 += 2 * kSearch) {
-              const int j1 = j0 + kSearch;
-              const uint2 pa = packs[j0];
-              uint2 pb = packs[min(j1, npack - 1)];
-              if (j1 >= npack) pb.x = pb.y = 0xffffffffu;
-              const unsigned hit = halves_in_span(pa.x, h1, sp) | halves_in_span(pa.y, h1, sp) |
-                                   halves_in_span(pb.x, h1, sp) | halves_in_span(pb.y, h1, sp);
-              if (hit) {
-                const unsigned q4[8] = {pa.x & 0xffffu, pa.x >> 16, pa.y & 0xffffu, pa.y >> 16,
-                                        pb.x & 0xffffu, pb.x >> 16, pb.y & 0xffffu, pb.y >> 16};
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                  if (q4[u] - b1 <= b2 - b1) {
-                    const unsigned slot = atomicAdd(nc, 1u);
-                    if (slot < (unsigned)kMedSel)
-                      cidx[z * kMedSel + slot] = (unsigned short)(4 * (u < 4 ? j0 : j1) + (u & 3));
-                  }
-                }
-              }
-            }
-          }
-        } else if (first && p > p0) {
-          finish(p - 1, z ^ 1, rs == 0 ? R - 1 : rs - 1, xc_prev);
-          if (lane == 0) ncand[z ^ 1] = 0u;
-        }
-        __syncthreads();  // B2: candidates listed; nobody reads the histogram or the bins of ping p below
-        state = meta[4 * z];
-        M = state ? *nc : 0u;
-        if (M <= (unsigned)kMedSel) break;
-        const int drift = (int)meta[4 * z + 3] - kMedBins / 2;
-        if (drift < kMedBins / 4 && drift > -kMedBins / 4) break;
-        // many candidates and the median more than 8 dB from the centre of the map: re-centre, search again
-        recentre(meta[4 * z + 3]);
-        __syncthreads();  // (everybody has read *nc and meta)
-        if (tid == 0) *nc = 0u;
-        rebuild(p, rs);
-      }
-      if (M > (unsigned)kMedSel) {  // more than 64 values within 1/128 dB of the median: radix selection from memory
-        Window<T> gw{chan, S, p - n, R, s - m, w, P, s0, true};
-        unsigned nv;
-        const double med = window_median_lin(gw, &sc, mt.exp2_tab, nv, W);
-        const T out = (T)(10.0 * epa::fast_log10(med, mt.log_tab));
-        if (tid == kBlock - 64) {
-          const size_t at = cbase + (size_t)p * S + s;
-          if (pooled) pooled[at] = out;
-          if (mask) mask[at] = (xc - out > thr) ? 1 : 0;
-        }
-        if (tid == 0) meta[4 * z] = 2u;
-      }
-      if (more && own) {  // row p-n leaves, row p+n+1 enters (same ring slot)
-        const int e = rs * w + tid;
-        const unsigned ob = bins[e];
-        if (ob != kMedNoBin) {
-          atomicSub(&fine[ob], 1u);
-          atomicSub(&coarse[ob >> 6], 1u);
-        }
-        enter(e, vin);
-      }
-      rs = rs + 1 == R ? 0 : rs + 1;
-    }
-    __syncthreads();
-    if (finisher) {  // the last ping of the segment
-      finish(p1 - 1, (p1 - 1) & 1, rs == 0 ? R - 1 : rs - 1, xc);
-    }
-  }
-}
-
 // One workgroup per (channel, ping): layer limits from THIS ping's range row (np.argmin: first
 // NaN, else first minimum), median of the ping's layer vs median of the 2n-ping block [p-n, p+n).
 template <typename T>
@@ -2304,6 +2060,358 @@ __global__ __launch_bounds__(kBlock) void pool_value_median_kernel(PoolValueArgs
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// nanmedian pooling with the window carried from ping to ping (see the comment above MedMap)
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned kMedNoBin = 0xffffu;  // bin of a NaN (and of the padding of the bin ring)
+constexpr int kMedSel = 64;              // candidates the finishing wavefront ranks: one per lane
+constexpr int kMedValueCap = 12288;      // window elements a value-window job may carry (its bins: 24 KB of LDS)
+
+// Two 16-bit bins per word: non-zero iff one of them lies in [b1, b1 + span] -- packed subtract (wraps below b1),
+// then saturating subtract from span + 1.  2 VALU instructions per 2 bins.
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned halves_in_span(unsigned x, unsigned b1b1, unsigned span1) {
+  const ushort2_t d = __builtin_bit_cast(ushort2_t, x) - __builtin_bit_cast(ushort2_t, b1b1);
+  const ushort2_t r = __builtin_elementwise_sub_sat(__builtin_bit_cast(ushort2_t, span1), d);
+  return __builtin_bit_cast(unsigned, r);
+}
+
+template <typename T>
+struct MedSlideArgs {
+  const T* sv;
+  int P, S, n, nseg;
+  long long jobs;
+  T thr;
+  T* pooled;
+  uint8_t* mask;
+  int cap;  // window elements the bin ring holds
+  // index windows (epa_pool_sv): first pooled sample, side samples
+  int s0, m;
+  // value windows (epa_pool_sv_value): per (channel, sample) intervals of the channels whose pings share one range
+  // vector (differ[c] == 0); the others -- and windows wider than a workgroup or the ring -- take every window from memory
+  PoolValueArgs<T> pv;
+  const int* ilo;
+  const int* ihi;
+  const int* differ;
+};
+
+// the window of a value-window job whose channel has one range vector: samples [lo, hi) of every ping it has
+template <typename T>
+struct SameRowsWindow {
+  const T* chan;
+  const int* nvalid;  // of the channel
+  int S, P, q_lo, nq, lo, hi;
+  template <typename F>
+  __device__ __forceinline__ void for_each(F f) const {
+    for (int j = 0; j < nq; ++j) {
+      const int q = q_lo + j;
+      if (q < 0 || q >= P) continue;
+      const int h = min(hi, nvalid[q]);
+      const T* row = chan + (size_t)q * S;
+      for (int k = lo + (int)threadIdx.x; k < h; k += kBlock) f((double)row[k]);
+    }
+  }
+};
+
+// What the workgroup keeps in LDS is the BIN of every window value (2 bytes), not the value: a leaving row is
+// un-counted from its bins, the members of the median's bin are found by comparing bins (4 per lane and read), and
+// only those few values are read again from memory (L2) -- by wavefront 3, one step later, while wavefronts 0-2
+// already search the next window: it ranks the candidates (one per lane, the others' keys by readlane), converts
+// and writes the result of the previous ping.  38 KB of LDS per workgroup: 4 workgroups per CU hide each other's
+// barrier and LDS latencies.
+// BY_VALUE == false: the (2n+1) x (2m+1) index window with reflected borders (pool_sv).
+// BY_VALUE == true : pings p-n .. p+n that exist, samples [ilo, ihi) of the channel's range vector (pool_Sv);
+//                    NaN where the reference declines to pool.
+template <typename T, bool BY_VALUE>
+__global__ __launch_bounds__(kBlock) void pool_median_slide_kernel(MedSlideArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ SelectScratchT<kMedCap> sc;  // the radix selection's scratch (flat fields, windows taken from memory)
+  const epa::MathTabs mt = epa::build_math_tabs(smem);
+  unsigned* fine = reinterpret_cast<unsigned*>(smem + epa::kMathTabBytes);
+  unsigned* coarse = fine + kMedBins;
+  unsigned* ncand = coarse + kMedCoarse;                      // [2] (+ 2 words of padding), by parity of the ping
+  unsigned* meta = ncand + 4;                                 // [2][4]: state, r1, dk, b1
+  unsigned short* cidx = reinterpret_cast<unsigned short*>(meta + 8);  // [2][kMedSel] window elements of the candidates
+  unsigned short* bins = cidx + 2 * kMedSel;                  // [4 * npack]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool finisher = tid >= kBlock - 64;
+  const int P = a.P, S = a.S, n = a.n, R = 2 * n + 1;
+  for (long long job = blockIdx.x; job < a.jobs; job += gridDim.x) {
+    const int s = (int)(job % S);
+    const long long t = job / S;
+    const int seg = (int)(t % a.nseg);
+    const long long c = t / a.nseg;
+    const size_t cbase = (size_t)c * P * S;
+    const int p0 = seg * kMedSeg, p1 = min(P, p0 + kMedSeg);
+    const T* __restrict__ chan = a.sv + cbase;
+    const int* __restrict__ nvalid = BY_VALUE ? a.pv.nvalid + (size_t)c * P : nullptr;
+    int w, c_lo = 0, c_hi = 0;  // window columns; value windows: the samples [c_lo, c_hi)
+    bool trivial, carried = true;
+    if (BY_VALUE) {
+      carried = a.differ[c] == 0;
+      c_lo = carried ? a.ilo[(size_t)c * S + s] : 0;
+      c_hi = carried ? a.ihi[(size_t)c * S + s] : 0;
+      w = c_hi - c_lo;
+      trivial = carried && (c_lo < 0 || w <= 0);  // the depth is never pooled (or past the vector's end)
+      carried = carried && !trivial && w <= kBlock && (long long)R * w <= a.cap;
+    } else {
+      w = 2 * a.m + 1;
+      trivial = s < a.s0;  // above the first pooled sample
+    }
+    if (trivial) {  // NaN, never masked
+      for (int p = p0 + tid; p < p1; p += kBlock) {
+        const size_t at = cbase + (size_t)p * S + s;
+        if (a.pooled) a.pooled[at] = epa::M<T>::nan();
+        if (a.mask) a.mask[at] = 0;
+      }
+      continue;
+    }
+    if (BY_VALUE && !carried) {  // every window of the segment from memory (the round-2 kernel's step)
+      int* wlo = reinterpret_cast<int*>(bins);
+      int* whi = wlo + R;
+      for (int p = p0; p < p1; ++p) {
+        const size_t at = cbase + (size_t)p * S + s;
+        const T d = a.pv.range[at];
+        T out = epa::M<T>::nan();
+        if (pool_feasible(a.pv, d, p)) {
+          const T lo_v = d - a.pv.bin, hi_v = d + a.pv.bin;
+          const int q0 = p - n, nq = min(p + n, P - 1) - q0 + 1;
+          __syncthreads();
+          for (int j = tid; j < nq; j += kBlock) {
+            const T* rr = a.pv.range + cbase + (size_t)(q0 + j) * S;
+            const int nv = nvalid[q0 + j];
+            wlo[j] = bound<T, false>(rr, nv, lo_v);
+            whi[j] = bound<T, true>(rr, nv, hi_v);
+          }
+          __syncthreads();
+          RaggedWindow<T> rw{chan, S, q0, nq, wlo, whi};
+          unsigned nv;
+          const double med = window_median_lin(rw, &sc, mt.exp2_tab, nv);
+          if (nv) out = (T)(10.0 * epa::fast_log10(med, mt.log_tab));
+        }
+        if (tid == 0) {
+          if (a.pooled) a.pooled[at] = out;
+          if (a.mask) a.mask[at] = (chan[(size_t)p * S + s] - out > a.thr) ? 1 : 0;
+        }
+      }
+      continue;
+    }
+    const int W = R * w, npack = (W + 3) >> 2;
+    const float inv_w = 1.0f / (float)w;
+    // column i of the window / row of virtual ping q: where they live in memory (nullptr: not part of the window)
+    auto column = [&](int i) -> int {
+      return BY_VALUE ? c_lo + i : a.s0 + reflect_index(s - a.m + i - a.s0, S - a.s0);
+    };
+    auto value_at = [&](int q, int col) -> T {
+      if (BY_VALUE) {
+        if (q < 0 || q >= P || col >= nvalid[q]) return epa::M<T>::nan();
+        return chan[(size_t)q * S + col];
+      }
+      return chan[(size_t)reflect_index(q, P) * S + col];
+    };
+    // does the reference pool at ping p?  (value windows: clean/utils.py:77-83; the sample must exist in ping p)
+    auto pooled_at = [&](int p) -> bool {
+      return !BY_VALUE || (p - n >= 0 && (long long)p + n <= (long long)P && s < nvalid[p]);
+    };
+    MedMap map{16.0f, 4096.0f};
+    auto enter = [&](int e, T v) {  // value v becomes element e of the window
+      unsigned b = kMedNoBin;
+      if (v == v) {
+        b = map.bin((double)v);
+        atomicAdd(&fine[b], 1u);
+        atomicAdd(&coarse[b >> 6], 1u);
+      }
+      bins[e] = (unsigned short)b;
+    };
+    // element e of the window of ping p (ring slot rs holds its oldest row p - n)
+    auto element = [&](int e, int p, int rs) -> T {
+      int slot = (int)(((float)e + 0.5f) * inv_w);
+      if (slot * w > e) --slot;
+      else if ((slot + 1) * w <= e) ++slot;
+      int k = slot - rs;
+      if (k < 0) k += R;
+      return value_at(p - n + k, column(e - slot * w));
+    };
+    // bins (of rank k1 = lower middle, k1 + dk = upper middle) from the two-level histogram; false: no valid value
+    auto middle_bins = [&](unsigned& b1, unsigned& b2, unsigned& r1, unsigned& dk) -> bool {
+      const unsigned cv = coarse[lane];
+      const unsigned ci = wave_scan_incl(cv);
+      const unsigned N = (unsigned)__builtin_amdgcn_readlane((int)ci, 63);
+      if (!N) return false;
+      const unsigned k1 = (N - 1u) >> 1;
+      dk = (N & 1u) ? 0u : 1u;
+      unsigned rem1, rem2, r2;
+      const unsigned cb1 = wave_rank_lane(ci, cv, k1, rem1);
+      const unsigned cb2 = wave_rank_lane(ci, cv, k1 + dk, rem2);
+      const unsigned fv = fine[cb1 * 64 + lane];
+      const unsigned fi = wave_scan_incl(fv);
+      b1 = cb1 * 64 + wave_rank_lane(fi, fv, rem1, r1);
+      if (cb2 == cb1) {
+        b2 = cb1 * 64 + wave_rank_lane(fi, fv, rem2, r2);
+      } else {
+        const unsigned gv = fine[cb2 * 64 + lane];
+        const unsigned gi = wave_scan_incl(gv);
+        b2 = cb2 * 64 + wave_rank_lane(gi, gv, rem2, r2);
+      }
+      return true;
+    };
+    // histogram and bins of the window of ping p from memory (called by all threads; nobody reads either meanwhile)
+    auto rebuild = [&](int p, int rs) {
+      for (int i = tid; i < kMedBins + kMedCoarse; i += kBlock) fine[i] = 0u;
+      __syncthreads();
+      for (int e = tid; e < W; e += kBlock) enter(e, element(e, p, rs));
+      __syncthreads();
+    };
+    // 1/128-dB bins centred on the value of bin b of the current map
+    auto recentre = [&](unsigned b) {
+      const float centre = ((float)b + 0.5f - map.off) / map.scale;
+      map.scale = 128.0f;
+      map.off = (float)(kMedBins / 2) - centre * 128.0f;
+    };
+    // wavefront 3: the median of ping pp from its listed candidates (parity z, ring slot rs of its oldest row)
+    auto finish = [&](int pp, int z, int rs, T xc) {
+      const unsigned state = meta[4 * z], r1 = meta[4 * z + 1], dk = meta[4 * z + 2];
+      if (state == 2u) return;  // (written by the radix selection already)
+      T out = epa::M<T>::nan();
+      if (state == 1u && pooled_at(pp)) {
+        const int M = __builtin_amdgcn_readfirstlane((int)ncand[z]);  // <= kMedSel
+        unsigned long long ki = ~0ull;
+        if (lane < M) ki = sort_key((double)element((int)cidx[z * kMedSel + lane], pp, rs));
+        unsigned rank = 0u;
+        for (int j = 0; j < M; ++j) {
+          const unsigned long long kj = wave_bcast64(ki, j);
+          rank += (kj < ki || (kj == ki && j < lane)) ? 1u : 0u;
+        }
+        const int a1 = __ffsll((long long)__ballot(lane < M && rank == r1)) - 1;
+        const int a2 = __ffsll((long long)__ballot(lane < M && rank == r1 + dk)) - 1;
+        const unsigned long long ka = wave_bcast64(ki, a1), kb = wave_bcast64(ki, a2);
+        const double la = epa::lin_from_db(key_value(ka), mt.exp2_tab);
+        const double med = ka == kb ? la : (la + epa::lin_from_db(key_value(kb), mt.exp2_tab)) * 0.5;
+        out = (T)(10.0 * epa::fast_log10(med, mt.log_tab));
+      }
+      if (lane == 0) {
+        const size_t at = cbase + (size_t)pp * S + s;
+        if (a.pooled) a.pooled[at] = out;
+        if (a.mask) a.mask[at] = (xc - out > a.thr) ? 1 : 0;
+      }
+    };
+    __syncthreads();  // the previous job's last readers
+    if (tid < 4) {
+      ncand[tid] = 0u;
+      bins[4 * (npack - 1) + tid] = (unsigned short)kMedNoBin;  // (the padding of the last pack)
+    }
+    rebuild(p0, 0);
+    {
+      unsigned b1, b2, r1, dk;
+      const bool any = middle_bins(b1, b2, r1, dk);
+      __syncthreads();
+      if (any) {
+        recentre(b1);
+        rebuild(p0, 0);
+      }
+    }
+    const bool own = tid < w;
+    const int col = own ? column(tid) : 0;
+    int rs = 0;  // ring slot of the row that leaves next
+    T xc = (T)0, xc_prev = (T)0;
+    for (int p = p0; p < p1; ++p) {
+      const bool more = p + 1 < p1;
+      const int z = p & 1;
+      T vin = epa::M<T>::nan();
+      if (own && more) vin = value_at(p + n + 1, col);  // requested now, used after the search
+      xc_prev = xc;
+      if (tid == kBlock - 64 && a.mask) xc = chan[(size_t)p * S + s];
+      unsigned* nc = &ncand[z];
+      unsigned state, M;
+      for (bool first = true;; first = false) {
+        __syncthreads();  // B1: bins and histogram hold the window of ping p; *nc == 0
+        if (!finisher) {
+          unsigned b1 = 0u, b2 = 0u, r1 = 0u, dk = 0u;
+          const bool any = middle_bins(b1, b2, r1, dk);
+          if (tid == 0) {
+            meta[4 * z] = any ? 1u : 0u;
+            meta[4 * z + 1] = r1;
+            meta[4 * z + 2] = dk;
+            meta[4 * z + 3] = b1;
+          }
+          if (any) {  // the members of those bins (the bins between b1 and b2 are empty: "in [b1, b2]" selects them)
+            const unsigned h1 = b1 * 0x00010001u, sp = (b2 - b1 + 1u) * 0x00010001u;
+            const uint2* packs = reinterpret_cast<const uint2*>(bins);
+            constexpr int kSearch = kBlock - 64;
+            for (int j0 = tid; j0 < npack; j0 += 2 * kSearch) {
+              const int j1 = j0 + kSearch;
+              const uint2 pa = packs[j0];
+              uint2 pb = packs[min(j1, npack - 1)];
+              if (j1 >= npack) pb.x = pb.y = 0xffffffffu;
+              const unsigned hit = halves_in_span(pa.x, h1, sp) | halves_in_span(pa.y, h1, sp) |
+                                   halves_in_span(pb.x, h1, sp) | halves_in_span(pb.y, h1, sp);
+              if (hit) {
+                const unsigned q4[8] = {pa.x & 0xffffu, pa.x >> 16, pa.y & 0xffffu, pa.y >> 16,
+                                        pb.x & 0xffffu, pb.x >> 16, pb.y & 0xffffu, pb.y >> 16};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                  if (q4[u] - b1 <= b2 - b1) {
+                    const unsigned slot = atomicAdd(nc, 1u);
+                    if (slot < (unsigned)kMedSel)
+                      cidx[z * kMedSel + slot] = (unsigned short)(4 * (u < 4 ? j0 : j1) + (u & 3));
+                  }
+                }
+              }
+            }
+          }
+        } else if (first && p > p0) {
+          finish(p - 1, z ^ 1, rs == 0 ? R - 1 : rs - 1, xc_prev);
+          if (lane == 0) ncand[z ^ 1] = 0u;
+        }
+        __syncthreads();  // B2: candidates listed; nobody reads the histogram or the bins of ping p below
+        state = meta[4 * z];
+        M = state ? *nc : 0u;
+        if (M <= (unsigned)kMedSel) break;
+        const int drift = (int)meta[4 * z + 3] - kMedBins / 2;
+        if (drift < kMedBins / 4 && drift > -kMedBins / 4) break;
+        // many candidates and the median more than 8 dB from the centre of the map: re-centre, search again
+        recentre(meta[4 * z + 3]);
+        __syncthreads();  // (everybody has read *nc and meta)
+        if (tid == 0) *nc = 0u;
+        rebuild(p, rs);
+      }
+      if (M > (unsigned)kMedSel) {  // more than 64 values within 1/128 dB of the median: radix selection from memory
+        unsigned nv;
+        double med;
+        if (BY_VALUE) {
+          SameRowsWindow<T> gw{chan, nvalid, S, P, p - n, R, c_lo, c_hi};
+          med = window_median_lin(gw, &sc, mt.exp2_tab, nv, W);
+        } else {
+          Window<T> gw{chan, S, p - n, R, s - a.m, w, P, a.s0, true};
+          med = window_median_lin(gw, &sc, mt.exp2_tab, nv, W);
+        }
+        T out = epa::M<T>::nan();
+        if (nv && pooled_at(p)) out = (T)(10.0 * epa::fast_log10(med, mt.log_tab));
+        if (tid == kBlock - 64) {
+          const size_t at = cbase + (size_t)p * S + s;
+          if (a.pooled) a.pooled[at] = out;
+          if (a.mask) a.mask[at] = (xc - out > a.thr) ? 1 : 0;
+        }
+        if (tid == 0) meta[4 * z] = 2u;
+      }
+      if (more && own) {  // row p-n leaves, row p+n+1 enters (same ring slot)
+        const int e = rs * w + tid;
+        const unsigned ob = bins[e];
+        if (ob != kMedNoBin) {
+          atomicSub(&fine[ob], 1u);
+          atomicSub(&coarse[ob >> 6], 1u);
+        }
+        enter(e, vin);
+      }
+      rs = rs + 1 == R ? 0 : rs + 1;
+    }
+    __syncthreads();
+    if (finisher) {  // the last ping of the segment
+      finish(p1 - 1, (p1 - 1) & 1, rs == 0 ? R - 1 : rs - 1, xc);
+    }
+  }
+}
+
 // out = mask ? src : fill   (fill: scalar, or an array like src when fill_arr != NULL)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void apply_mask_kernel(const T* __restrict__ src,
@@ -2333,6 +2441,11 @@ int set_lds(K kern, size_t lds) {
 }
 
 constexpr size_t kMaxLds = 156 * 1024;
+
+// dynamic LDS of pool_median_slide_kernel for a ring of W window elements
+inline size_t med_slide_lds(size_t W) {
+  return epa::kMathTabBytes + (size_t)(kMedBins + kMedCoarse + 4 + 8) * 4 + 2 * kMedSel * 2 + ((W + 3) / 4) * 8;
+}
 
 }  // namespace
 
@@ -2401,19 +2514,20 @@ extern "C" int epa_pool_sv(const void* sv, int C, int P, int S, int first_sample
   const int n = num_side_pings, m = num_side_samples;
   if (func == EPA_POOL_NANMEDIAN) {
     const size_t W = (size_t)(2 * n + 1) * (2 * m + 1);
-    const size_t slide_lds = epa::kMathTabBytes + (size_t)(kMedBins + kMedCoarse + 4 + 8) * 4 + 2 * kMedSel * 2 +
-                             ((W + 3) / 4) * 8;
+    const size_t slide_lds = med_slide_lds(W);
     if (2 * m + 1 <= kBlock && W <= 65535 && slide_lds + sizeof(SelectScratchT<kMedCap>) + 512 <= kMaxLds) {
       // the window carried from ping to ping: one workgroup per (channel, ping segment, column)
       const int nseg = (P + kMedSeg - 1) / kMedSeg;
       const long long jobs = (long long)C * nseg * S;
       const int grid = (int)(jobs < (1 << 22) ? jobs : (1 << 22));
-#define EPA_MS(T)                                                                                    \
-  do {                                                                                               \
-    auto kern = pool_median_slide_kernel<T>;                                                         \
-    if (int rc = set_lds(kern, slide_lds)) return rc;                                                \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), slide_lds, st, (const T*)sv, P, S, s0, n, m,  \
-                       nseg, jobs, (T)threshold, (T*)pooled_out, mask_out);                          \
+#define EPA_MS(T)                                                                                          \
+  do {                                                                                                     \
+    MedSlideArgs<T> a{};                                                                                   \
+    a.sv = (const T*)sv; a.P = P; a.S = S; a.n = n; a.nseg = nseg; a.jobs = jobs; a.thr = (T)threshold;    \
+    a.pooled = (T*)pooled_out; a.mask = mask_out; a.cap = (int)W; a.s0 = s0; a.m = m;                      \
+    auto kern = pool_median_slide_kernel<T, false>;                                                        \
+    if (int rc = set_lds(kern, slide_lds)) return rc;                                                      \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), slide_lds, st, a);                                  \
   } while (0)
       if (dtype == EPA_F64) EPA_MS(double); else EPA_MS(float);
 #undef EPA_MS
@@ -2556,6 +2670,29 @@ int launch_pool_value(const void* sv, const void* range, const int32_t* nvalid, 
     }
     hipLaunchKernelGGL(pool_value_mean_kernel<T>, grid, dim3(kBlock), 0, st, a, rows);
     return epa::check_launch("pool_value_mean_kernel");
+  }
+  if (ws && (long long)(2 * n + 1) * 2 * 4 <= (long long)kMedValueCap * 2) {
+    // window carried from ping to ping in the channels whose pings share one range vector
+    int* ilo = static_cast<int*>(ws);
+    int* ihi = ilo + (size_t)C * S;
+    int* ref = ihi + (size_t)C * S;
+    int* differ = ref + C;
+    const long long rows = (long long)C * P;
+    const dim3 rowg(row_grid(rows) < 16384 ? row_grid(rows) : 16384);
+    hipLaunchKernelGGL(ref_row_kernel, dim3(C), dim3(kBlock), 0, st, nvalid, P, ref, differ);
+    hipLaunchKernelGGL(rows_same_kernel<T>, rowg, dim3(kBlock), 0, st, (const T*)range, nvalid, rows, P, S, ref, differ);
+    hipLaunchKernelGGL(value_intervals_kernel<T>, dim3((S + kBlock - 1) / kBlock, C), dim3(kBlock), 0, st, a, ref, ilo, ihi);
+    if (int rc = epa::check_launch("value_intervals_kernel<median>")) return rc;
+    MedSlideArgs<T> ma{};
+    ma.sv = (const T*)sv; ma.P = P; ma.S = S; ma.n = n; ma.nseg = (P + kMedSeg - 1) / kMedSeg;
+    ma.jobs = (long long)C * ma.nseg * S; ma.thr = (T)thr; ma.pooled = (T*)pooled; ma.mask = mask;
+    ma.cap = kMedValueCap; ma.pv = a; ma.ilo = ilo; ma.ihi = ihi; ma.differ = differ;
+    const size_t lds = med_slide_lds(kMedValueCap);
+    auto kern = pool_median_slide_kernel<T, true>;
+    if (int rc = set_lds(kern, lds)) return rc;
+    const int grid = (int)(ma.jobs < (1 << 22) ? ma.jobs : (1 << 22));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, ma);
+    return epa::check_launch("pool_value_median_slide_kernel");
   }
   const long long jobs = (long long)C * P * S;
   const int grid = (int)(jobs < (1 << 20) ? jobs : (1 << 20));

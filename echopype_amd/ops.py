@@ -734,7 +734,8 @@ def pool_sv_value(sv, range, nvalid, depth_bin, num_side_pings, exclude_above, r
     """Value-window pooled Sv (pool_Sv) and/or the mask Sv - pooled > threshold.  ``running_sums`` (nanmean):
     per-row double-double running sums and interval sums in a 40 B/sample workspace instead of summing every window
     (EPA_POOL_VALUE_WS_BYTES in the header); when that does not fit next to the arrays the workspace-free kernel runs
-    (same results, every window summed value by value)."""
+    (same results, every window summed value by value).  nanmedian: with ``running_sums`` the window is carried from
+    ping to ping (a small workspace), without it every window is taken from memory."""
     C, P, S = sv.shape
     if range.dtype != sv.dtype:
         range = range.to(sv.dtype)
@@ -747,6 +748,8 @@ def pool_sv_value(sv, range, nvalid, depth_bin, num_side_pings, exclude_above, r
             ws = torch.empty((C * P * S * 40 + C * S * 8 + C * 8 + C * P + 7) // 8, dtype=torch.float64, device=sv.device)
         except torch.cuda.OutOfMemoryError:
             ws = None
+    elif running_sums:  # nanmedian: the per-channel sample intervals (EPA_POOL_VALUE_MEDIAN_WS_BYTES)
+        ws = torch.empty(2 * C * S + 2 * C, dtype=torch.int32, device=sv.device)
     call("epa_pool_sv_value", _p(sv), _p(range), _p(nvalid), C, P, S, float(depth_bin), int(num_side_pings),
          float(exclude_above), float(range_min), float(range_max), f, float(threshold), _p(pooled),
          _p(mask), _p(ws), _DT[sv.dtype], _stream())

@@ -510,6 +510,10 @@ int epa_range_rows_check(const void* range, int C, int P, int S, int dtype, int3
  * per-row running sums kept in double-double: a channel whose pings all share one range vector (checked on the
  * device) gets per-row interval sums + a sliding sum down every column, O(1) per sample; any other channel
  * O(pings) per sample.  Without it every window is summed value by value.  Same results to rounding. */
+/* ws for func = nanmedian (optional): EPA_POOL_VALUE_MEDIAN_WS_BYTES bytes, 4-byte aligned.  With it the channels whose
+ * pings share one range vector carry their window from ping to ping (a histogram of the window kept up to date, the
+ * median's bin ranked exactly): O(window columns) per sample instead of O(window).  Same results. */
+#define EPA_POOL_VALUE_MEDIAN_WS_BYTES(C, S) (((size_t)(C) * (S) * 2 + (size_t)(C) * 2) * 4)
 int epa_pool_sv_value(const void* sv, const void* range, const int32_t* nvalid, int C, int P, int S,
                       double depth_bin, int num_side_pings, double exclude_above, double range_min,
                       double range_max, int func, double threshold, void* pooled_out, uint8_t* mask_out,

@@ -65,4 +65,11 @@ for dt, b in ((torch.float64, 8), (torch.float32, 4)):
     timeit(f"pool_sv nanmedian 51 x {2*n10+1} (1 x {Pb} x {S})", lambda: ops.pool_sv(svb, 100, 25, n10, func="nanmedian", threshold=12.0, want_pooled=False), svb.numel(), 0, reps=1)
     del svb
     timeit(f"pool_sv_value nanmedian n=25 +-10 m (1 x {Pm} x {S})", lambda: ops.pool_sv_value(svm, rgm, nvm, 10.0, 25, 20.0, lo, hi, func="nanmedian", threshold=12.0, want_pooled=False), svm.numel(), 0, reps=1)
-    del sv, rng
+    Pb = min(P, 4096)
+    svb = sv[:1, :Pb].contiguous()
+    rgb = rng[:1, :1].expand(1, Pb, S).contiguous()
+    nvb, _ = ops.range_rows_check(rgb)
+    timeit(f"pool_sv_value nanmedian n=25 +-10 m, one range vector (1 x {Pb} x {S})", lambda: ops.pool_sv_value(svb, rgb, nvb, 10.0, 25, 20.0, lo, hi, func="nanmedian", threshold=12.0, want_pooled=False), svb.numel(), 0, reps=1)
+    Pc = min(P, 256)
+    timeit(f"pool_sv_value nanmedian, every window from memory (1 x {Pc} x {S})", lambda: ops.pool_sv_value(svb[:, :Pc].contiguous(), rgb[:, :Pc].contiguous(), nvb[:, :Pc].contiguous(), 10.0, 25, 20.0, lo, hi, func="nanmedian", threshold=12.0, want_pooled=False, running_sums=False), Pc * S, 0, reps=1)
+    del sv, rng, svb, rgb

@@ -408,6 +408,74 @@ def test_pool_sv_value_running_sums_equal_window_sums(env, dtype, same_rows):
     assert agree[sure].all()
 
 
+@pytest.mark.parametrize("same_rows", [False, True, "mixed"])
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_pool_sv_value_median_carried_window_equals_windows_from_memory(env, dtype, same_rows):
+    """Value-window nanmedian: the window carried from ping to ping (channels with one range vector; workspace given)
+    == every window taken from memory (workspace NULL) == the oracle's triple loop.  Rows of different valid lengths,
+    a spike, +inf, pings near both ends (p - n < 0, p + n == P is pooled, p + n > P is not)."""
+    from echopype_amd import _lib
+
+    torch, ops = env
+    rng = np.random.default_rng(9)
+    C, P, S, n, dbin = 2, 40, 300, 4, 1.45
+    sv, depth = _scene(C, P, S, 13, step=0.3)
+    if same_rows is False:
+        depth = depth * (1 + 0.01 * rng.random((C, P, 1)))
+    elif same_rows == "mixed":
+        depth[1] = depth[1] * (1 + 0.01 * rng.random((P, 1)))
+    depth[:, 7, S - 20:] = np.nan
+    depth[0, 30, S - 55:] = np.nan
+    sv[0, 30, S - 55:] = np.nan
+    sv[:, 7, S - 20:] = np.nan
+    sv[0, 10, 100] = 60.0
+    sv[1, 20, 50] = np.inf
+    sv, depth = sv.astype(dtype), depth.astype(dtype)
+    svt, rgt = _dev(torch, sv), _dev(torch, depth)
+    nvalid, bad = ops.range_rows_check(rgt)
+    assert bad == 0
+    lo, hi = ops.nanminmax(rgt)
+    with _lib.launch_trace() as tr:
+        a, ma = ops.pool_sv_value(svt, rgt, nvalid, dbin, n, 2.0, lo, hi, func="nanmedian", threshold=6.0)
+    assert "pool_value_median_slide_kernel" in tr.kernels
+    with _lib.launch_trace() as tr:
+        b, mb = ops.pool_sv_value(svt, rgt, nvalid, dbin, n, 2.0, lo, hi, func="nanmedian", threshold=6.0,
+                                  running_sums=False)
+    assert "pool_value_median_kernel" in tr.kernels
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    np.testing.assert_array_equal(a, b)   # the same two middle values, the same conversion
+    np.testing.assert_array_equal(ma.cpu().numpy(), mb.cpu().numpy())
+    exp = omask.pool_Sv(sv.astype(np.float64), depth.astype(np.float64), np.nanmedian, dbin, n, 2.0)
+    if dtype == "float64":
+        _close(a, exp, RTOL[dtype], "vs oracle")
+    else:  # d +- bin in fp32 moves a sample on a window edge in or out: a median may jump to its neighbour value
+        np.testing.assert_array_equal(np.isnan(a), np.isnan(exp))
+        fin = np.isfinite(exp)
+        off = np.abs(a[fin] - exp[fin]) > 1e-3 * np.maximum(np.abs(exp[fin]), 1.0)
+        assert off.mean() < 2e-3 and np.abs(a[fin] - exp[fin])[off].max(initial=0.0) < 1.0
+    assert np.isfinite(exp[:, P - n]).any() and np.isnan(exp[:, P - n + 1:]).all() and np.isnan(exp[:, :n]).all()
+
+
+def test_pool_sv_value_median_segments_and_flat_field(env):
+    """600 pings (two 512-ping segments) of one range vector; a stretch of identical values (more than 64 candidates in
+    the median's bin: the radix selection over the window in memory) and an all-NaN stretch."""
+    torch, ops = env
+    rng = np.random.default_rng(10)
+    C, P, S, n, dbin = 1, 600, 36, 3, 1.0
+    sv = -75 + 3 * rng.standard_normal((C, P, S))
+    sv[0, 100:140, :] = -70.0
+    sv[0, 300:320, :] = np.nan
+    sv[0, rng.random((P, S)) < 0.05] = np.nan
+    depth = np.broadcast_to(2.0 + 0.25 * np.arange(S), (C, P, S)).copy()
+    svt, rgt = _dev(torch, sv), _dev(torch, depth)
+    nvalid, bad = ops.range_rows_check(rgt)
+    lo, hi = ops.nanminmax(rgt)
+    a, _ = ops.pool_sv_value(svt, rgt, nvalid, dbin, n, 3.0, lo, hi, func="nanmedian")
+    exp = omask.pool_Sv(sv, depth, np.nanmedian, dbin, n, 3.0)
+    _close(a.cpu().numpy(), exp, 1e-9, "600 pings")
+    assert np.isnan(exp[0, 305:315, 10]).all() and np.isfinite(exp[0, 500:520, 10]).all()
+
+
 def test_pool_sv_value_rows_longer_than_the_lds_copy(env):
     """8200 samples per ping: the running sums of a row no longer fit the fused kernel's LDS copy, the unfused
     kernels (running sums and interval sums through the workspace) take over -- same answers."""
