@@ -879,386 +879,184 @@ __global__ __launch_bounds__(kBlock) void attenuated_mask_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same mask with the block median carried from ping to ping (round 2).  attenuated_mask_kernel sweeps the
-// 2n-ping x layer block of every ping three times (radix selection from memory): ~48 000 element visits per ping at
-// n = 15, a 520-sample layer.  Consecutive pings share all but one ping of their blocks, so a workgroup that walks a
-// CHUNK of consecutive pings keeps
-//   * a 4096-bin histogram of the block's values (dB quantised linearly over [-200, 50) dB: ~0.06 dB per bin -- any
-//     monotone map would do, the ends are clamped) in LDS, updated with the ping that enters and the ping that leaves;
-//   * the 12-bit codes of the 2n pings of the block in an LDS ring (2 bytes per value).
-// The bin holding the median rank comes from a prefix scan of the histogram; the few dozen values of that bin are
-// found by comparing the ring's codes, re-read from memory (L2) by position, and ranked exactly among themselves.
-// The ping's own median uses its ring slot the same way with a 256-bin histogram.  Exact medians, ~1 500 element
-// visits per ping.  The layer limits come from every ping's own range row as before; whenever they differ from the
-// previous ping's (or the block exceeds the ring) the block is rebuilt / the ping takes the sweeping path.
-// ------------------------------------------------------------------------------------------------
-constexpr int kAttBins = 4096;  // bins of the block's running histogram: the top 12 bits of a value's 16-bit code
-constexpr int kAttCand = 512;
-constexpr int kAttChunkMax = 256;  // pings per workgroup (+ 2n of warm-up): chosen by the launcher, at most this
-constexpr int kAttPre = 4;      // values of the entering ping a lane prefetches (layers up to 1024 samples)
+// Layer limits of every ping from its own range row (np.argmin: first NaN, else first minimum) and the median of the
+// ping's own layer, stashed in the first sixteen bytes of the ping's row of the (not yet written) mask: one fully
+// parallel pass over all pings instead of a dependent load + two selections in front of every step of the sequential
+// walk of attenuated_walk_kernel.  One WAVEFRONT per ping, no workgroup barrier anywhere: the two argmins by a
+// butterfly over the lanes; the median from 16-bit codes of the dB values (monotone, 0.004 dB) counted by their top
+// byte, then by the low byte inside the one or two selected top bytes (LDS atomics of the wavefront's own 3 KB, the
+// 256 counts scanned four per lane), then the one or two values of the selected code ranked exactly.  A layer of
+// more than 2048 samples or more than 64 values inside one code leave kOwnUnknown: the walk takes that ping's
+// medians from memory.
+constexpr int kPrepCols = 32;  // layer samples per lane: layers up to 2048 samples
+constexpr unsigned long long kOwnUnknown = 0x7ff8dead00000000ull;  // (a NaN no arithmetic produces)
 
-struct AttScratch {
-  unsigned hist[kAttBins];
-  unsigned small[256];    // the ping's own layer by the top 8 bits
-  unsigned sub_own[512];  // low 8 bits inside the one or two selected top-8 bins
-  unsigned sub_blk[256];  // low 4 bits inside the one or two selected 12-bit bins (32 used)
-  unsigned wsum[2][4];
-  unsigned ncand, overflow;
-  int bin[8];  // of two order statistics each: [0..1] own top-8, [2..3] block 12-bit, [4..5] own low bits, [6..7] block's
-  unsigned rank[8];
-  unsigned long long key[4];
-  unsigned long long cand[kAttCand];
-  unsigned ctag[kAttCand];  // bit 16: of the ping's own layer; low 16 bits: the code
-};
-
-__device__ __forceinline__ unsigned att_code(double v) {
-  // monotone 16-bit code of a dB value over [-200, 50] (clamped), NaN excluded by the caller; 0xffff is kept for NaN
-  const double t = (v + 200.0) * (65535.0 / 250.0);
-  const int c = (int)fmin(fmax(t, 0.0), 65534.0);
-  return (unsigned)c;
+__device__ __forceinline__ unsigned att_code_f(double v) {  // monotone 16-bit code over [-200, 50) dB, clamped; 0xffff: NaN
+  const float t = fmaf((float)v, 65534.0f / 250.0f, 200.0f * 65534.0f / 250.0f);
+  return (unsigned)fminf(fmaxf(t, 0.0f), 65534.0f);
+}
+// 256 counts held four per lane (h = bins 4l .. 4l+3, incl = inclusive scan of their sum tot): the bin of 0-based
+// rank k < total and the rank inside it
+__device__ __forceinline__ unsigned wave_locate4(const uint4& h, unsigned incl, unsigned tot, unsigned k, unsigned& r) {
+  const int at = __ffsll((long long)__ballot(incl > k)) - 1;
+  unsigned rem = k - (unsigned)__builtin_amdgcn_readlane((int)(incl - tot), at);
+  const unsigned h0 = (unsigned)__builtin_amdgcn_readlane((int)h.x, at), h1 = (unsigned)__builtin_amdgcn_readlane((int)h.y, at),
+                 h2 = (unsigned)__builtin_amdgcn_readlane((int)h.z, at);
+  unsigned d = 0u;
+  if (rem >= h0) { rem -= h0; d = 1u;
+    if (rem >= h1) { rem -= h1; d = 2u;
+      if (rem >= h2) { rem -= h2; d = 3u; } } }
+  r = rem;
+  return 4u * (unsigned)at + d;
+}
+// LDS traffic of ONE wavefront is processed in program order: this only keeps the compiler from reordering it
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+// lexicographic (value, index) minimum over the 64 lanes -- np.argmin's "first occurrence of the minimum"
+__device__ __forceinline__ int wave_argmin(double v, int idx) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double w = __shfl_xor(v, o, 64);
+    const int j = __shfl_xor(idx, o, 64);
+    if (w < v || (w == v && j < idx)) { v = w; idx = j; }
+  }
+  return idx;
 }
 
-template <int PER>
-struct AttScan {
-  unsigned h[PER], tot, incl;
-  __device__ __forceinline__ void load(const unsigned* hist) {  // this lane's PER consecutive bins + the wave's prefix
-    const int t = threadIdx.x;
-    tot = 0;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      h[i] = hist[t * PER + i];
-      tot += h[i];
-    }
-    incl = tot;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const unsigned u = __shfl_up(incl, o, 64);
-      if ((t & 63) >= o) incl += u;
-    }
-  }
-  // the lane whose bins hold rank k records the bin and the rank inside it
-  __device__ __forceinline__ void pick(unsigned base, unsigned k, int* bin, unsigned* rank) const {
-    const unsigned excl = base + incl - tot;
-    if (excl <= k && k < excl + tot) {
-      unsigned r = k - excl;
-      int b = 0;
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {  // (static indices: h stays in registers)
-        const bool here = b == i && r >= h[i];
-        r -= here ? h[i] : 0u;
-        b += here ? 1 : 0;
-      }
-      *bin = threadIdx.x * PER + b;
-      *rank = r;
-    }
-  }
-};
-
-// Two order statistics in each of two histograms (256 * PA and 256 * PB bins) behind ONE barrier -> sc->bin / rank
-// [ea..ea+1], [eb..eb+1].  MEDIAN: the two middle ones, else the given ranks.  na / nb = the counted values.  All threads
-// call it after a barrier that completed the histograms; the caller's next barrier publishes bin / rank.
-template <int PA, int PB, bool MEDIAN>
-__device__ __forceinline__ void att_locate2(const unsigned* ha, const unsigned* hb, AttScratch* sc, int ea, int eb,
-                                            unsigned& na, unsigned& nb, unsigned ka0 = 0, unsigned ka1 = 0,
-                                            unsigned kb0 = 0, unsigned kb1 = 0) {
-  const int t = threadIdx.x;
-  AttScan<PA> a;
-  AttScan<PB> b;
-  a.load(ha);
-  b.load(hb);
-  if ((t & 63) == 63) {
-    sc->wsum[0][t >> 6] = a.incl;
-    sc->wsum[1][t >> 6] = b.incl;
-  }
-  __syncthreads();
-  unsigned base_a = 0, base_b = 0;
-  na = nb = 0;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const unsigned wa = sc->wsum[0][w], wb = sc->wsum[1][w];
-    base_a += w < (t >> 6) ? wa : 0u;
-    base_b += w < (t >> 6) ? wb : 0u;
-    na += wa;
-    nb += wb;
-  }
-  if (na) {
-    a.pick(base_a, MEDIAN ? (na - 1u) / 2u : ka0, &sc->bin[ea], &sc->rank[ea]);
-    a.pick(base_a, MEDIAN ? na / 2u : ka1, &sc->bin[ea + 1], &sc->rank[ea + 1]);
-  }
-  if (nb) {
-    b.pick(base_b, MEDIAN ? (nb - 1u) / 2u : kb0, &sc->bin[eb], &sc->rank[eb]);
-    b.pick(base_b, MEDIAN ? nb / 2u : kb1, &sc->bin[eb + 1], &sc->rank[eb + 1]);
-  }
-}
-
-// exact order statistics crank[e] among the candidates tagged tag[e] -> sc->key[e]
-__device__ __forceinline__ void att_rank(AttScratch* sc, const unsigned (&tag)[4], const unsigned (&crank)[4]) {
-  const unsigned M = min(sc->ncand, (unsigned)kAttCand);
-  for (unsigned i = threadIdx.x; i < M; i += kBlock) {
-    const unsigned long long ki = sc->cand[i];
-    const unsigned ti = sc->ctag[i];
-    unsigned less = 0;
-    for (unsigned j = 0; j < M; ++j) {
-      const unsigned long long kj = sc->cand[j];
-      less += (sc->ctag[j] == ti && (kj < ki || (kj == ki && j < i))) ? 1u : 0u;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (ti == tag[e] && less == crank[e]) sc->key[e] = ki;
-  }
-  __syncthreads();
-}
-
-// layer limits of every ping from its own range row (np.argmin: first NaN, else first minimum), stashed in the first
-// eight bytes of the ping's row of the (not yet written) mask: one fully parallel sweep of the range array instead of a
-// dependent load + reduction in front of every step of the sequential walk below
 template <typename T>
-__global__ __launch_bounds__(kBlock) void attenuated_limits_kernel(const T* __restrict__ range, int S, long long rows,
-                                                                   T upper, T lower, uint8_t* __restrict__ mask) {
-  __shared__ double shv[4];
-  __shared__ int shi[4];
-  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+__global__ __launch_bounds__(kBlock) void attenuated_prepare_kernel(const T* __restrict__ sv, const T* __restrict__ range,
+                                                                    int P, int S, long long rows, T upper, T lower,
+                                                                    int n, uint8_t* __restrict__ mask) {
+  __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
+  __shared__ __attribute__((aligned(16))) unsigned hist[kBlock / 64][768];  // per wavefront: top[256], low[2][256]
+  __shared__ unsigned long long cand[kBlock / 64][64];
+  __shared__ unsigned ctag[kBlock / 64][64], ncand[kBlock / 64];
+  const epa::MathTabs mt = epa::build_math_tabs(tabs);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned* top = hist[wv];
+  unsigned* low = top + 256;
+  for (long long row = (long long)blockIdx.x * (kBlock / 64) + wv; row < rows; row += (long long)gridDim.x * (kBlock / 64)) {
+    const int p = (int)(row % P);
     const T* rr = range + (size_t)row * S;
     double bu = __builtin_inf(), bl = __builtin_inf();
     int iu = 0x7fffffff, il = 0x7fffffff;
-    for (int s = threadIdx.x; s < S; s += kBlock) {
-      const T r = rr[s];
-      T du = fabs(r - upper), dl = fabs(r - lower);
-      const double vu = (du == du) ? (double)du : -1.0;  // NaN beats every |.| >= 0
-      const double vl = (dl == dl) ? (double)dl : -1.0;
-      if (vu < bu) { bu = vu; iu = s; }
-      if (vl < bl) { bl = vl; il = s; }
-    }
-    const int up = block_argmin(bu, iu, shv, shi);
-    const int lw = block_argmin(bl, il, shv, shi);
-    if (threadIdx.x == 0) {
-      int* dst = reinterpret_cast<int*>(mask + (size_t)row * S);  // rows are S >= 8 bytes apart, S % 4 == 0 checked
-      dst[0] = up;
-      dst[1] = lw;
-    }
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(kBlock, 2) void attenuated_slide_kernel(
-    const T* __restrict__ sv, int P, int S, int nchunks, int chunk_len, int n, T thr, int ring_cap,
-    uint8_t* __restrict__ mask) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const epa::MathTabs mt = epa::build_math_tabs(smem);
-  unsigned short* ring = reinterpret_cast<unsigned short*>(smem + epa::kMathTabBytes);
-  // the sweeping path (blocks beyond the ring, many equal values) borrows the ring's memory: the ring is rebuilt after it
-  SelectScratch* sel = reinterpret_cast<SelectScratch*>(smem + epa::kMathTabBytes);
-  __shared__ AttScratch sc;
-  __shared__ int lim[kAttChunkMax][2];
-  const int c = blockIdx.x / nchunks, chunk = blockIdx.x - c * nchunks;
-  const int p0 = chunk * chunk_len, p1 = min(P, p0 + chunk_len);
-  const T* cb = sv + (size_t)c * P * S;
-  uint8_t* mb = mask + (size_t)c * P * S;
-  const int W = 2 * n;  // pings of a block: [p - n, p + n)
-  int w_up = -1, w_lw = -1, w_lo = 0;  // window state: layer limits and first ping of the block held in LDS
-  bool valid = false;
-  // the chunk's layer limits, read before any of its mask rows is overwritten
-  for (int i = threadIdx.x; i < p1 - p0; i += kBlock) {
-    const int* src = reinterpret_cast<const int*>(mb + (size_t)(p0 + i) * S);
-    lim[i][0] = src[0];
-    lim[i][1] = src[1];
-  }
-  __syncthreads();
-
-  auto enter = [&](int q, int L, const T (&pre)[kAttPre]) {  // values of ping q (already in registers) enter
-    unsigned short* slot = ring + (size_t)(q % W) * L;
+    for (int s0 = 0; s0 < S; s0 += 64 * 8) {  // eight requests in flight per lane
+      T r[8];
 #pragma unroll
-    for (int k = 0; k < kAttPre; ++k) {
-      const int i = threadIdx.x + k * kBlock;
-      if (i < L) {
-        const double v = (double)pre[k];
-        const unsigned code = (v == v) ? att_code(v) : 0xffffu;
-        slot[i] = (unsigned short)code;
-        if (code != 0xffffu) atomicAdd(&sc.hist[code >> 4], 1u);
+      for (int j = 0; j < 8; ++j) {
+        const int s = s0 + lane + 64 * j;
+        r[j] = s < S ? rr[s] : (T)0;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int s = s0 + lane + 64 * j;
+        if (s < S) {
+          T du = fabs(r[j] - upper), dl = fabs(r[j] - lower);
+          const double vu = (du == du) ? (double)du : -1.0;  // NaN beats every |.| >= 0
+          const double vl = (dl == dl) ? (double)dl : -1.0;
+          if (vu < bu) { bu = vu; iu = s; }
+          if (vl < bl) { bl = vl; il = s; }
+        }
       }
     }
-  };
-  auto fetch = [&](int q, int up, int L, T (&pre)[kAttPre]) {
-    const T* row = cb + (size_t)q * S + up;
+    const int up = wave_argmin(bu, iu), lw = wave_argmin(bl, il);
+    const int L = lw - up;
+    unsigned long long own = 0x7ff8000000000000ull;  // NaN: no valid sample, or no block around the ping
+    if (p - n >= 0 && (long long)p + n <= (long long)P - 1 && L > 0) {
+      own = kOwnUnknown;
+      if (L <= kPrepCols * 64) {
+        const T* layer = sv + (size_t)row * S + up;
+        const int nj = (L + 63) >> 6;
 #pragma unroll
-    for (int k = 0; k < kAttPre; ++k) {
-      const int i = threadIdx.x + k * kBlock;
-      pre[k] = (q < P && i < L) ? row[i] : (T)0;
-    }
-  };
-  auto leave = [&](int q, int L) {
-    const unsigned short* slot = ring + (size_t)(q % W) * L;
-    for (int i = threadIdx.x; i < L; i += kBlock) {
-      const unsigned code = slot[i];
-      if (code != 0xffffu) atomicSub(&sc.hist[code >> 4], 1u);
-    }
-  };
-  auto median_lin = [&](int e) {  // from sc.key[e], sc.key[e + 1]
-    const double a = epa::lin_from_db(key_value(sc.key[e]), mt.exp2_tab);
-    return sc.key[e] == sc.key[e + 1] ? a : (a + epa::lin_from_db(key_value(sc.key[e + 1]), mt.exp2_tab)) * 0.5;
-  };
-  auto sweep = [&](int p, int up, int L, bool& flag) {  // both medians from memory (window_median_lin)
-    unsigned nv;
-    Window<T> w1{cb, S, p, 1, up, L, P, 0, false};
-    const double m1 = window_median_lin(w1, sel, mt.exp2_tab, nv, L);
-    if (nv) {
-      Window<T> w2{cb, S, p - n, W, up, L, P, 0, false};
-      unsigned nv2;
-      const double m2 = window_median_lin(w2, sel, mt.exp2_tab, nv2, W * L);
-      const T ping_db = (T)(10.0 * epa::fast_log10(m1, mt.log_tab));
-      const T block_db = nv2 ? (T)(10.0 * epa::fast_log10(m2, mt.log_tab)) : epa::M<T>::nan();
-      flag = (ping_db - block_db) < thr;
-    }
-  };
-
-  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-  T pre[kAttPre];
-  int pre_q = -1, pre_up = -1, pre_L = -1;  // what `pre` holds: ping, layer
-  for (int p = p0; p < p1; ++p) {
-    const int up = lim[p - p0][0], lw = lim[p - p0][1];
-    bool flag = false;
-    if (p - n >= 0 && (long long)p + n <= (long long)P - 1 && lw > up) {
-      const int L = lw - up;
-      if ((long long)W * L > ring_cap || L > kAttPre * kBlock) {  // block beyond the ring
-        __syncthreads();
-        valid = false;
-        sweep(p, up, L, flag);
-      } else {
-        const unsigned short* slot = ring + (size_t)(p % W) * L;  // the ping's own codes
-        auto count_own = [&]() {
-          for (int i = threadIdx.x; i < L; i += kBlock) {
-            const unsigned code = slot[i];
-            if (code != 0xffffu) atomicAdd(&sc.small[code >> 8], 1u);
+        for (int i = 0; i < 12; ++i) top[lane + 64 * i] = 0u;  // top and both halves of low
+        if (lane == 0) ncand[wv] = 0u;
+        // only the codes stay in registers (the one or two values that decide are read again below): eight requests
+        // in flight per lane
+        unsigned short code[kPrepCols];
+#pragma unroll
+        for (int j0 = 0; j0 < kPrepCols; j0 += 8) {
+          T val[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int col = lane + 64 * (j0 + j);
+            val[j] = (j0 + j < nj && col < L) ? layer[col] : epa::M<T>::nan();
           }
-        };
-        sc.small[threadIdx.x] = 0u;  // (the step before ended on a barrier behind its last reads of these)
-        sc.sub_own[threadIdx.x] = 0u;
-        sc.sub_own[threadIdx.x + 256] = 0u;
-        sc.sub_blk[threadIdx.x] = 0u;
-        if (threadIdx.x == 0) {
-          sc.ncand = 0u;
-          sc.overflow = 0u;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            code[j0 + j] = (unsigned short)((val[j] == val[j]) ? att_code_f((double)val[j]) : 0xffffu);
         }
-        if (valid && up == w_up && lw == w_lw && w_lo == p - n - 1) {  // slide by one ping
-          if (!(pre_q == p + n - 1 && pre_up == up && pre_L == L)) fetch(p + n - 1, up, L, pre);
-          leave(p - n - 1, L);
-          __syncthreads();  // the leaving ping's slot is the entering ping's
-          enter(p + n - 1, L, pre);
-          if (n == 1) __syncthreads();  // (the entering ping is ping p itself)
-          count_own();
-        } else {  // (re)build the block
-          __syncthreads();
-          for (int i = threadIdx.x; i < kAttBins; i += kBlock) sc.hist[i] = 0u;
-          __syncthreads();
-          for (int q = p - n; q < p + n; ++q) {
-            fetch(q, up, L, pre);
-            enter(q, L, pre);
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < kPrepCols; ++j)
+          if (j < nj && code[j] != 0xffffu) atomicAdd(&top[code[j] >> 8], 1u);
+        wave_lds_fence();
+        const uint4 ht = reinterpret_cast<const uint4*>(top)[lane];
+        const unsigned tt = ht.x + ht.y + ht.z + ht.w, ti = wave_scan_incl(tt);
+        const unsigned N = (unsigned)__builtin_amdgcn_readlane((int)ti, 63);
+        if (!N) {
+          own = 0x7ff8000000000000ull;
+        } else {
+          const unsigned k1 = (N - 1u) >> 1, k2 = N >> 1;
+          unsigned r1t, r2t;
+          const unsigned t1 = wave_locate4(ht, ti, tt, k1, r1t), t2 = wave_locate4(ht, ti, tt, k2, r2t);
+#pragma unroll
+          for (int j = 0; j < kPrepCols; ++j) {
+            if (j < nj && code[j] != 0xffffu) {
+              const unsigned tb = code[j] >> 8;
+              if (tb == t1) atomicAdd(&low[code[j] & 255u], 1u);
+              else if (tb == t2) atomicAdd(&low[256u + (code[j] & 255u)], 1u);
+            }
           }
-          __syncthreads();
-          count_own();
-        }
-        valid = true;
-        w_up = up; w_lw = lw; w_lo = p - n;
-        // the ping that enters at the next step, requested now (its latency hides behind the medians of this step)
-        pre_q = p + n; pre_up = up; pre_L = L;
-        fetch(pre_q, up, L, pre);
-        __syncthreads();
-        // ---- first level: the ping's own layer by the top 8 bits of its codes, the block by its running 12-bit histogram
-        unsigned nv, nv2;
-        att_locate2<1, kAttBins / 256, true>(sc.small, sc.hist, &sc, 0, 2, nv, nv2);
-        __syncthreads();
-        if (nv && nv2) {
-          const int o0 = sc.bin[0], o1 = sc.bin[1], b0 = sc.bin[2], b1 = sc.bin[3];
-          // ---- second level: the remaining low bits inside the selected bins.  The ring is swept eight codes per
-          // 128-bit LDS read with packed 16-bit tests (no code lies strictly between two adjacent order statistics, so
-          // one range test per code is exact); a position is decoded only for the few codes that match
-          auto sweep_ring = [&](unsigned lo, unsigned hi, auto hit) {
-            const int total = W * L, first = (p - n) % W;
-            const unsigned short l16 = (unsigned short)lo, span1 = (unsigned short)(hi - lo + 1u);
-            const us2 lo2 = {l16, l16}, sp2 = {span1, span1};
-            const uint4* r4 = reinterpret_cast<const uint4*>(ring);
-            for (int i8 = threadIdx.x; i8 * 8 < total; i8 += kBlock) {
-              const uint4 v = r4[i8];
-              const unsigned w[4] = {v.x, v.y, v.z, v.w};
+          wave_lds_fence();
+          const uint4 ha = reinterpret_cast<const uint4*>(low)[lane], hb = reinterpret_cast<const uint4*>(low + 256)[lane];
+          const unsigned ta = ha.x + ha.y + ha.z + ha.w, ia = wave_scan_incl(ta);
+          const unsigned tb = hb.x + hb.y + hb.z + hb.w, ib = wave_scan_incl(tb);
+          unsigned rr1, rr2;
+          const unsigned c1 = (t1 << 8) | wave_locate4(ha, ia, ta, r1t, rr1);
+          const unsigned c2 = t2 == t1 ? ((t1 << 8) | wave_locate4(ha, ia, ta, r2t, rr2))
+                                       : ((t2 << 8) | wave_locate4(hb, ib, tb, r2t, rr2));
+          // the members of those codes: one per lane, ranked by counting (the others' keys by readlane)
 #pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                const us2 d = __builtin_bit_cast(us2, w[k]) - lo2;
-                const us2 m = __builtin_elementwise_min(d, sp2);
-                if (__builtin_bit_cast(unsigned, m) != __builtin_bit_cast(unsigned, sp2)) {
-#pragma unroll
-                  for (int hbit = 0; hbit < 2; ++hbit) {
-                    const unsigned code = hbit ? (w[k] >> 16) : (w[k] & 0xffffu);
-                    const int i = i8 * 8 + 2 * k + hbit;
-                    if (code - lo <= hi - lo && i < total) {
-                      const int sl = i / L, idx = i - sl * L;
-                      hit(code, p - n + (sl - first + W) % W, idx);
-                    }
-                  }
-                }
+          for (int j = 0; j < kPrepCols; ++j) {
+            if (j < nj && (code[j] == c1 || code[j] == c2)) {
+              const unsigned at = atomicAdd(&ncand[wv], 1u);
+              if (at < 64u) {
+                cand[wv][at] = sort_key((double)layer[lane + 64 * j]);
+                ctag[wv][at] = code[j];
               }
             }
-          };
-          // (the NaN code 0xffff shares the last 12-bit bin with values at the clamp: the range stops before it)
-          sweep_ring((unsigned)b0 << 4, min(((unsigned)b1 << 4) | 15u, 0xfffeu), [&](unsigned code, int, int) {
-            atomicAdd(&sc.sub_blk[((int)(code >> 4) == b0 ? 0u : 16u) + (code & 15u)], 1u);
-          });
-          for (int i = threadIdx.x; i < L; i += kBlock) {
-            const unsigned code = slot[i];
-            if (code != 0xffffu) {
-              const int ho = (int)(code >> 8);
-              if (ho == o0) atomicAdd(&sc.sub_own[code & 255u], 1u);
-              else if (ho == o1) atomicAdd(&sc.sub_own[256u + (code & 255u)], 1u);
+          }
+          wave_lds_fence();
+          const int M = __builtin_amdgcn_readfirstlane((int)ncand[wv]);
+          if (M <= 64) {
+            const unsigned long long ki = lane < M ? cand[wv][lane] : ~0ull;
+            const unsigned tg = lane < M ? ctag[wv][lane] : 0xffffffffu;
+            unsigned rank = 0u;
+            for (int j = 0; j < M; ++j) {
+              const unsigned long long kj = wave_bcast64(ki, j);
+              const unsigned tj = (unsigned)__builtin_amdgcn_readlane((int)tg, j);
+              rank += (tj == tg && (kj < ki || (kj == ki && j < lane))) ? 1u : 0u;
             }
-          }
-          // (two selected bins: the second one's ranks continue after the first one's members)
-          const unsigned ko0 = sc.rank[0], ko1 = o1 == o0 ? sc.rank[1] : sc.small[o0] + sc.rank[1];
-          const unsigned kb0 = sc.rank[2], kb1 = b1 == b0 ? sc.rank[3] : sc.hist[b0] + sc.rank[3];
-          __syncthreads();
-          unsigned d0, d1;
-          att_locate2<2, 1, false>(sc.sub_own, sc.sub_blk, &sc, 4, 6, d0, d1, ko0, ko1, kb0, kb1);
-          __syncthreads();
-          unsigned tag[4], crank[4];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const int io = sc.bin[4 + e], ib = sc.bin[6 + e];
-            tag[e] = 0x10000u | ((unsigned)(io < 256 ? o0 : o1) << 8) | (unsigned)(io & 255);
-            tag[2 + e] = ((unsigned)(ib < 16 ? b0 : b1) << 4) | (unsigned)(ib & 15);
-            crank[e] = sc.rank[4 + e];
-            crank[2 + e] = sc.rank[6 + e];
-          }
-          // ---- the values of exactly those codes, re-read by position; ranks settled among them
-          auto take = [&](unsigned code, int q, int idx, unsigned set) {
-            const unsigned long long key = sort_key((double)cb[(size_t)q * S + up + idx]);
-            const unsigned at = atomicAdd(&sc.ncand, 1u);
-            if (at < (unsigned)kAttCand) { sc.cand[at] = key; sc.ctag[at] = set | code; }
-            else sc.overflow = 1u;
-          };
-          sweep_ring(tag[2], tag[3], [&](unsigned code, int q, int idx) { take(code, q, idx, 0u); });
-          const unsigned oc0 = tag[0] & 0xffffu, oc1 = tag[1] & 0xffffu;
-          for (int i = threadIdx.x; i < L; i += kBlock) {
-            const unsigned code = slot[i];
-            if (code == oc0 || code == oc1) take(code, p, i, 0x10000u);
-          }
-          __syncthreads();
-          if (sc.overflow) {  // hundreds of values within 0.004 dB of the median: the sweeping path settles it
-            valid = false;
-            __syncthreads();
-            sweep(p, up, L, flag);
-            __syncthreads();
-          } else {
-            att_rank(&sc, tag, crank);
-            const T ping_db = (T)(10.0 * epa::fast_log10(median_lin(0), mt.log_tab));
-            const T block_db = (T)(10.0 * epa::fast_log10(median_lin(2), mt.log_tab));
-            flag = (ping_db - block_db) < thr;
+            const int a1 = __ffsll((long long)__ballot(tg == c1 && rank == rr1)) - 1;
+            const int a2 = __ffsll((long long)__ballot(tg == c2 && rank == rr2)) - 1;
+            const unsigned long long o1 = wave_bcast64(ki, a1), o2 = wave_bcast64(ki, a2);
+            const double la = epa::lin_from_db(key_value(o1), mt.exp2_tab);
+            const double m1 = o1 == o2 ? la : (la + epa::lin_from_db(key_value(o2), mt.exp2_tab)) * 0.5;
+            own = (unsigned long long)__double_as_longlong((double)(T)(10.0 * epa::fast_log10(m1, mt.log_tab)));
           }
         }
       }
-    } else {
-      valid = false;
     }
-    uint8_t* m = mb + (size_t)p * S;
-    const unsigned f4 = flag ? 0x01010101u : 0u;
-    for (int s = 4 * threadIdx.x; s < S; s += 4 * kBlock) *reinterpret_cast<unsigned*>(m + s) = f4;  // S % 4 == 0
+    if (lane == 0) {
+      int* dst = reinterpret_cast<int*>(mask + (size_t)row * S);  // rows are S >= 16 bytes apart, S % 4 == 0 checked
+      dst[0] = up;
+      dst[1] = lw;
+      dst[2] = (int)(unsigned)own;
+      dst[3] = (int)(unsigned)(own >> 32);
+    }
   }
 }
 
@@ -2412,6 +2210,381 @@ __global__ __launch_bounds__(kBlock) void pool_median_slide_kernel(MedSlideArgs<
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// attenuated-signal mask with the 2n-ping block carried from ping to ping on the same engine (round 4)
+// ------------------------------------------------------------------------------------------------
+// A workgroup walks a chunk of consecutive pings of one channel.  The block [p-n, p+n) x layer lives in LDS as BINS
+// (2 bytes per value, 1/128 dB wide around the block's median, clamped ends) + the two-level histogram of
+// pool_median_slide_kernel; ping p+n enters and ping p-n leaves at every step.  Wavefronts 0-2 locate the bins of the
+// block's two middle values and list the positions of their members; wavefront 3 works one ping behind: it reads
+// those few values again from memory (L2), ranks them exactly and compares the block median with the ping's own
+// median (attenuated_prepare_kernel); everybody writes that ping's mask row after the next barrier.  Whenever the
+// layer limits change, the block exceeds the ring or more than 64 values share the median's bin, the block is
+// rebuilt / the ping's medians are taken from memory by all threads.
+#ifndef EPA_ATT_MARGIN
+#define EPA_ATT_MARGIN 4
+#endif
+constexpr int kAttCols = 4;          // layer samples per lane: layers up to 1024 samples are carried
+constexpr int kAttWalkChunkMax = 256;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock, 2) void attenuated_walk_kernel(const T* __restrict__ sv, int P, int S, int nchunks,
+                                                                    int chunk_len, int n, T thr, int ring_cap,
+                                                                    uint8_t* __restrict__ mask) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ SelectScratchT<kMedCap> sc;  // (medians taken from memory)
+  __shared__ int lim[kAttWalkChunkMax][2];
+  __shared__ double own_db[kAttWalkChunkMax];  // the pings' own medians in dB (NaN: no valid sample in the layer)
+  const epa::MathTabs mt = epa::build_math_tabs(smem);
+  unsigned* fine = reinterpret_cast<unsigned*>(smem + epa::kMathTabBytes);
+  unsigned* coarse = fine + kMedBins;
+  unsigned* ncand = coarse + kMedCoarse;  // [2] (+ padding)
+  unsigned* meta = ncand + 4;             // [2][4]: state, r1, dk, b1
+  unsigned short* cidx = reinterpret_cast<unsigned short*>(meta + 8);  // [2][kMedSel]
+  unsigned short* bins = cidx + 2 * kMedSel;                           // [ring_cap], 16-byte aligned
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool finisher = tid >= kBlock - 64;
+  const int c = blockIdx.x / nchunks, chunk = blockIdx.x - c * nchunks;
+  const int p0 = chunk * chunk_len, p1 = min(P, p0 + chunk_len);
+  const T* __restrict__ cb = sv + (size_t)c * P * S;
+  uint8_t* mb = mask + (size_t)c * P * S;
+  const int R = 2 * n;  // pings of a block: [p - n, p + n)
+  // the chunk's layer limits, read before any of its mask rows is overwritten
+  for (int i = tid; i < p1 - p0; i += kBlock) {
+    const int* src = reinterpret_cast<const int*>(mb + (size_t)(p0 + i) * S);
+    lim[i][0] = src[0];
+    lim[i][1] = src[1];
+    own_db[i] = __hiloint2double(src[3], src[2]);
+  }
+  if (tid < 4) ncand[tid] = 0u;
+  __syncthreads();
+
+  MedMap map{16.0f, 4096.0f};
+  bool valid = false, centred = false;
+  // the block in LDS: ring column j of every slot is sample base + j (pitch Lp >= the layer + a margin on either
+  // side: limits that move by a few samples from ping to ping -- a depth with heave in it -- shift the layer inside
+  // the ring instead of rebuilding the block); layer [w_up, w_lw), first ping w_lo in ring slot rs.  Columns outside
+  // the layer hold kMedNoBin in every slot.
+  int base = 0, Lp = 8, w_up = -1, w_lw = -1, w_lo = 0, rs = 0, margin = EPA_ATT_MARGIN;
+  // the ping wavefront 3 still has to finish
+  bool pending = false;
+  int f_p = 0, f_rs = 0, f_lo = 0;
+
+  auto write_row = [&](int p, bool flag, int first, int step) {
+    unsigned* m = reinterpret_cast<unsigned*>(mb + (size_t)p * S);  // S % 4 == 0, 4-byte aligned (checked by the launcher)
+    const unsigned f4 = flag ? 0x01010101u : 0u;
+    for (int i = first; i < S / 4; i += step) m[i] = f4;
+  };
+  auto enter = [&](int e, T v) {
+    unsigned b = kMedNoBin;
+    if (v == v) {
+      b = map.bin((double)v);
+      atomicAdd(&fine[b], 1u);
+      atomicAdd(&coarse[b >> 6], 1u);
+    }
+    bins[e] = (unsigned short)b;
+  };
+  // element e of the block whose first ping lo sits in ring slot rs0
+  auto element = [&](int e, int lo, int rs0) -> T {
+    const float inv = 1.0f / (float)Lp;
+    int slot = (int)(((float)e + 0.5f) * inv);
+    if (slot * Lp > e) --slot;
+    else if ((slot + 1) * Lp <= e) ++slot;
+    int k = slot - rs0;
+    if (k < 0) k += R;
+    return cb[(size_t)(lo + k) * S + base + (e - slot * Lp)];
+  };
+  auto middle_bins = [&](unsigned& b1, unsigned& b2, unsigned& r1, unsigned& dk) -> bool {
+    const unsigned cv = coarse[lane];
+    const unsigned ci = wave_scan_incl(cv);
+    const unsigned N = (unsigned)__builtin_amdgcn_readlane((int)ci, 63);
+    if (!N) return false;
+    const unsigned k1 = (N - 1u) >> 1;
+    dk = (N & 1u) ? 0u : 1u;
+    unsigned rem1, rem2, r2;
+    const unsigned cb1 = wave_rank_lane(ci, cv, k1, rem1);
+    const unsigned cb2 = wave_rank_lane(ci, cv, k1 + dk, rem2);
+    const unsigned fv = fine[cb1 * 64 + lane];
+    const unsigned fi = wave_scan_incl(fv);
+    b1 = cb1 * 64 + wave_rank_lane(fi, fv, rem1, r1);
+    if (cb2 == cb1) {
+      b2 = cb1 * 64 + wave_rank_lane(fi, fv, rem2, r2);
+    } else {
+      const unsigned gv = fine[cb2 * 64 + lane];
+      const unsigned gi = wave_scan_incl(gv);
+      b2 = cb2 * 64 + wave_rank_lane(gi, gv, rem2, r2);
+    }
+    return true;
+  };
+  // histogram and bins of the block [lo, lo + R) x [up, lw) from memory, its first ping in slot 0 (all threads;
+  // base / Lp set by the caller)
+  auto rebuild = [&](int lo, int up, int lw) {
+    for (int i = tid; i < kMedBins + kMedCoarse; i += kBlock) fine[i] = 0u;
+    __syncthreads();
+    // sixteen elements per lane and trip, all their requests in flight together (a dependent load per element would
+    // cost the chunk as much as its whole walk)
+    constexpr int kTrip = 16;
+    const int total = R * Lp;
+    const float inv = 1.0f / (float)Lp;
+    for (int i0 = tid; i0 < total; i0 += kTrip * kBlock) {
+      T v[kTrip];
+      bool in[kTrip];
+#pragma unroll
+      for (int u = 0; u < kTrip; ++u) {
+        const int i = i0 + u * kBlock;
+        int slot = (int)(((float)i + 0.5f) * inv);
+        if (slot * Lp > i) --slot;
+        else if ((slot + 1) * Lp <= i) ++slot;
+        const int smp = base + (i - slot * Lp);
+        in[u] = i < total && smp >= up && smp < lw;
+        v[u] = in[u] ? cb[(size_t)(lo + slot) * S + smp] : epa::M<T>::nan();
+      }
+#pragma unroll
+      for (int u = 0; u < kTrip; ++u) {
+        const int i = i0 + u * kBlock;
+        if (in[u]) enter(i, v[u]);
+        else if (i < total) bins[i] = (unsigned short)kMedNoBin;
+      }
+    }
+    __syncthreads();
+  };
+  // the layer moves from [w_up, w_lw) to [up, lw) inside the ring: the samples that leave it are un-counted in every
+  // slot, those that join it are read from memory (all threads, between two barriers)
+  auto shift_layer = [&](int up, int lw) {
+    auto each = [&](int a, int b, bool join) {  // samples [a, b) of every slot
+      const int wd = b - a;
+      if (wd <= 0) return;
+      for (int i = tid; i < wd * R; i += kBlock) {
+        const int slot = i / wd, smp = a + (i - slot * wd);
+        const int e = slot * Lp + (smp - base);
+        if (join) {
+          int k = slot - rs;
+          if (k < 0) k += R;
+          enter(e, cb[(size_t)(w_lo + k) * S + smp]);
+        } else {
+          const unsigned ob = bins[e];
+          if (ob != kMedNoBin) {
+            atomicSub(&fine[ob], 1u);
+            atomicSub(&coarse[ob >> 6], 1u);
+          }
+          bins[e] = (unsigned short)kMedNoBin;
+        }
+      }
+    };
+    each(w_up, min(up, w_lw), false);
+    each(max(lw, w_up), w_lw, false);
+    each(up, min(w_up, lw), true);
+    each(max(w_lw, up), lw, true);
+  };
+  auto recentre = [&](unsigned b) {
+    const float centre = ((float)b + 0.5f - map.off) / map.scale;
+    map.scale = 128.0f;
+    map.off = (float)(kMedBins / 2) - centre * 128.0f;
+    centred = true;
+  };
+  // both medians of ping p from memory, by all threads
+  auto sweep = [&](int p, int up, int L) -> bool {
+    unsigned nv;
+    Window<T> w1{cb, S, p, 1, up, L, P, 0, false};
+    const double m1 = window_median_lin(w1, &sc, mt.exp2_tab, nv, L);
+    if (!nv) return false;
+    Window<T> w2{cb, S, p - n, R, up, L, P, 0, false};
+    unsigned nv2;
+    const double m2 = window_median_lin(w2, &sc, mt.exp2_tab, nv2, R * L);
+    const T ping_db = (T)(10.0 * epa::fast_log10(m1, mt.log_tab));
+    const T block_db = nv2 ? (T)(10.0 * epa::fast_log10(m2, mt.log_tab)) : epa::M<T>::nan();
+    return (ping_db - block_db) < thr;
+  };
+  // wavefront 3: the two medians of the pending ping, the comparison, its mask row
+  // wavefront 3: the block median of the pending ping from its listed candidates (read again from memory, ranked by
+  // counting: one per lane, the others' keys by readlane), compared with the ping's own median (attenuated_prepare_kernel)
+  auto finish = [&]() {
+    const int z = f_p & 1;
+    const unsigned state = meta[4 * z], r1 = meta[4 * z + 1], dk = meta[4 * z + 2];
+    const int M = state == 1u ? __builtin_amdgcn_readfirstlane((int)ncand[z]) : 0;  // <= kMedSel
+    const T ping_db = (T)own_db[f_p - p0];
+    bool flag = false;
+    if (M && ping_db == ping_db) {
+      unsigned long long ki = ~0ull;
+      if (lane < M) ki = sort_key((double)element((int)cidx[z * kMedSel + lane], f_lo, f_rs));
+      unsigned rank = 0u;
+      for (int j = 0; j < M; ++j) {
+        const unsigned long long kj = wave_bcast64(ki, j);
+        rank += (kj < ki || (kj == ki && j < lane)) ? 1u : 0u;
+      }
+      const int a1 = __ffsll((long long)__ballot(lane < M && rank == r1)) - 1;
+      const int a2 = __ffsll((long long)__ballot(lane < M && rank == r1 + dk)) - 1;
+      const unsigned long long ka = wave_bcast64(ki, a1), kb = wave_bcast64(ki, a2);
+      const double la = epa::lin_from_db(key_value(ka), mt.exp2_tab);
+      const double med = ka == kb ? la : (la + epa::lin_from_db(key_value(kb), mt.exp2_tab)) * 0.5;
+      const T block_db = (T)(10.0 * epa::fast_log10(med, mt.log_tab));
+      flag = (ping_db - block_db) < thr;
+    }
+    if (lane == 0) {
+      ncand[z] = 0u;
+      meta[4 * z + 3] = flag ? 1u : 0u;  // (b1 is no longer needed: the verdict takes its place)
+    }
+  };
+  auto drain = [&]() {  // the pending ping finished before the block changes under it (uniform)
+    if (pending) {
+      __syncthreads();
+      if (finisher) finish();
+      __syncthreads();
+      write_row(f_p, meta[4 * (f_p & 1) + 3] != 0u, tid, kBlock);
+      pending = false;
+    }
+  };
+
+  for (int p = p0; p < p1; ++p) {
+    const int up = lim[p - p0][0], lw = lim[p - p0][1], L = lw - up;
+    if (!(p - n >= 0 && (long long)p + n <= (long long)P - 1 && lw > up)) {
+      drain();
+      valid = false;
+      write_row(p, false, tid, kBlock);
+      continue;
+    }
+    if ((long long)R * ((L + 7) & ~7) > ring_cap || L > kAttCols * kBlock) {  // block beyond the ring
+      drain();
+      valid = false;
+      __syncthreads();
+      const bool flag = sweep(p, up, L);
+      write_row(p, flag, tid, kBlock);
+      continue;
+    }
+    if (valid && w_lo == p - n && up >= base && lw <= base + Lp) {
+      if (up != w_up || lw != w_lw) {  // the layer moved inside the ring
+        __syncthreads();
+        shift_layer(up, lw);
+        w_up = up; w_lw = lw;
+      }
+    } else {  // (re)build the block
+      // a layer that walked out of the ring: a wider margin from now on (every margin sample is searched at every step)
+      if (valid && w_lo == p - n) margin = min(64, 2 * margin);
+      drain();
+      // pitch: the layer + the margin on either side, as far as the ring and a lane's columns allow
+      Lp = min(min((L + 2 * margin + 7) & ~7, (ring_cap / R) & ~7), (kAttCols + 1) * kBlock);
+      base = max(0, up - (Lp - L) / 2);
+      if (!centred) {  // the first block: 1/16-dB bins over [-256, 0) dB find its median, then the fine map
+        rebuild(p - n, up, lw);
+        unsigned b1, b2, r1, dk;
+        const bool any = middle_bins(b1, b2, r1, dk);
+        __syncthreads();
+        if (any) recentre(b1);
+      }
+      rebuild(p - n, up, lw);
+      valid = true;
+      w_up = up; w_lw = lw; w_lo = p - n; rs = 0;
+    }
+    // will the block of the next ping be carried?  then its entering ping is requested now (over THIS ping's layer:
+    // a layer that differs is shifted at the next step)
+    bool slide = p + 1 < p1 && (long long)p + 1 + n <= (long long)P - 1;
+    if (slide) {
+      const int nu = lim[p + 1 - p0][0], nl = lim[p + 1 - p0][1];
+      slide = nl > nu && nu >= base && nl <= base + Lp && nl - nu <= kAttCols * kBlock;
+    }
+    T pre[kAttCols];
+#pragma unroll
+    for (int k = 0; k < kAttCols; ++k) {
+      const int col = tid + k * kBlock;
+      pre[k] = (slide && col < L) ? cb[(size_t)(p + n) * S + up + col] : epa::M<T>::nan();
+    }
+    const int z = p & 1;
+    unsigned* nc = &ncand[z];
+    const int total8 = (R * Lp) >> 3;  // (Lp is a multiple of 8)
+    unsigned state, M;
+    for (bool first = true;; first = false) {
+      __syncthreads();  // B1: bins and histogram hold the block of ping p; *nc == 0
+      if (!finisher) {
+        unsigned b1 = 0u, b2 = 0u, r1 = 0u, dk = 0u;
+        const bool any = middle_bins(b1, b2, r1, dk);
+        if (tid == 0) {
+          meta[4 * z] = any ? 1u : 0u;
+          meta[4 * z + 1] = r1;
+          meta[4 * z + 2] = dk;
+          meta[4 * z + 3] = b1;
+        }
+        if (any) {  // the members of those bins, eight bins per 128-bit read
+          const unsigned h1 = b1 * 0x00010001u, sp = (b2 - b1 + 1u) * 0x00010001u;
+          const uint4* packs = reinterpret_cast<const uint4*>(bins);
+          constexpr int kSearch = kBlock - 64;
+          for (int j0 = tid; j0 < total8; j0 += 2 * kSearch) {
+            const int j1 = j0 + kSearch;
+            const uint4 pa = packs[j0];
+            uint4 pb = packs[min(j1, total8 - 1)];
+            if (j1 >= total8) pb.x = pb.y = pb.z = pb.w = 0xffffffffu;
+            const unsigned hit = halves_in_span(pa.x, h1, sp) | halves_in_span(pa.y, h1, sp) |
+                                 halves_in_span(pa.z, h1, sp) | halves_in_span(pa.w, h1, sp) |
+                                 halves_in_span(pb.x, h1, sp) | halves_in_span(pb.y, h1, sp) |
+                                 halves_in_span(pb.z, h1, sp) | halves_in_span(pb.w, h1, sp);
+            if (hit) {
+              const unsigned wds[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+              for (int u = 0; u < 16; ++u) {
+                const unsigned q = (u & 1) ? (wds[u >> 1] >> 16) : (wds[u >> 1] & 0xffffu);
+                if (q - b1 <= b2 - b1) {
+                  const unsigned slot = atomicAdd(nc, 1u);
+                  if (slot < (unsigned)kMedSel)
+                    cidx[z * kMedSel + slot] = (unsigned short)(8 * (u < 8 ? j0 : j1) + (u & 7));
+                }
+              }
+            }
+          }
+        }
+      } else if (first && pending) {
+        finish();
+      }
+      __syncthreads();  // B2: candidates listed; the pending ping is finished
+      if (first && pending) write_row(f_p, meta[4 * (f_p & 1) + 3] != 0u, tid, kBlock);
+      state = meta[4 * z];
+      M = state ? *nc : 0u;
+      if (M <= (unsigned)kMedSel) break;
+      const int drift = (int)meta[4 * z + 3] - kMedBins / 2;
+      if (drift < kMedBins / 4 && drift > -kMedBins / 4) break;
+      // many candidates and the median more than 8 dB from the centre of the map: re-centre, search again
+      recentre(meta[4 * z + 3]);
+      __syncthreads();  // (everybody has read *nc and meta)
+      if (tid == 0) *nc = 0u;
+      pending = false;
+      rebuild(p - n, up, lw);
+      rs = 0;
+    }
+    pending = false;
+    const bool own_unknown = (unsigned long long)__double_as_longlong(own_db[p - p0]) == kOwnUnknown;
+    if (M > (unsigned)kMedSel || own_unknown) {  // more than 64 values in a median's bin: both medians from memory
+      const bool flag = sweep(p, up, L);
+      write_row(p, flag, tid, kBlock);
+      __syncthreads();
+      if (tid == 0) {
+        meta[4 * z] = 2u;
+        *nc = 0u;
+      }
+    } else {
+      pending = true;
+      f_p = p; f_rs = rs; f_lo = p - n;
+    }
+    if (slide) {  // ping p-n leaves, ping p+n enters (same ring slot)
+#pragma unroll
+      for (int k = 0; k < kAttCols; ++k) {
+        const int col = tid + k * kBlock;
+        if (col < L) {
+          const int e = rs * Lp + (up - base) + col;
+          const unsigned ob = bins[e];
+          if (ob != kMedNoBin) {
+            atomicSub(&fine[ob], 1u);
+            atomicSub(&coarse[ob >> 6], 1u);
+          }
+          enter(e, pre[k]);
+        }
+      }
+      rs = rs + 1 == R ? 0 : rs + 1;
+      w_lo = p - n + 1;
+    } else {
+      valid = false;
+    }
+  }
+  drain();
+}
+
 // out = mask ? src : fill   (fill: scalar, or an array like src when fill_arr != NULL)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void apply_mask_kernel(const T* __restrict__ src,
@@ -2730,18 +2903,19 @@ extern "C" int epa_attenuated_mask(const void* sv, const void* range, int C, int
   EPA_CHECK_ARG(num_side_pings >= 0, "epa_attenuated_mask: num_side_pings must be >= 0");
   EPA_CHECK_ARG(dtype == EPA_F32 || dtype == EPA_F64, "epa_attenuated_mask: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
-  if (num_side_pings >= 1 && S >= 8 && S % 4 == 0 && (reinterpret_cast<uintptr_t>(mask_out) & 3u) == 0) {
-    // block medians carried from ping to ping: layer limits of every ping first (stashed in the mask rows), then the walk
+  if (num_side_pings >= 1 && S >= 16 && S % 4 == 0 && (reinterpret_cast<uintptr_t>(mask_out) & 3u) == 0) {
+    // block medians carried from ping to ping: layer limits and own median of every ping first (stashed in the mask
+    // rows), then the walk
     const long long rows = (long long)C * P;
-    // pings per workgroup: every chunk pays 2n pings of warm-up, and the workgroups run in rounds of two per CU -- the
-    // length in [64, kAttChunkMax] with the fewest sequential steps (rounds x (length + 2n)) is taken
+    // pings per workgroup: every chunk pays a rebuild of its 2n-ping block, and the workgroups run in rounds of two
+    // per CU -- the length in [64, kAttWalkChunkMax] with the fewest sequential steps (rounds x (length + 2n)) is taken
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
       cus = 256;
     const long long slots = 2ll * std::max(cus, 1);
-    int chunk_len = std::min(P, kAttChunkMax);
+    int chunk_len = std::min(P, kAttWalkChunkMax);
     long long best = -1;
-    for (int len = std::min(P, kAttChunkMax); len >= std::min(P, 64); --len) {
+    for (int len = std::min(P, kAttWalkChunkMax); len >= std::min(P, 64); --len) {
       const long long wgs = (long long)C * ((P + len - 1) / len);
       const long long steps = ((wgs + slots - 1) / slots) * (len + 2ll * num_side_pings);
       if (best < 0 || steps < best) {
@@ -2750,22 +2924,20 @@ extern "C" int epa_attenuated_mask(const void* sv, const void* range, int C, int
       }
     }
     const int nchunks = (P + chunk_len - 1) / chunk_len;
-    const int ring_cap = 20480;  // u16 codes: 2 n x layer length up to this, longer blocks take the sweeping path
-    static_assert(sizeof(SelectScratch) <= 20480 * 2, "the sweeping path's scratch borrows the ring");
-    const size_t lds = epa::kMathTabBytes + (size_t)ring_cap * 2;
+    const int ring_cap = 20480;  // u16 bins: 2 n x layer length up to this, longer blocks take both medians from memory
+    const size_t wl = epa::kMathTabBytes + (size_t)(kMedBins + kMedCoarse + 4 + 8) * 4 + 2 * kMedSel * 2 + (size_t)ring_cap * 2;
     const dim3 grid((unsigned)((long long)C * nchunks));
-    if (dtype == EPA_F64) {
-      hipLaunchKernelGGL(attenuated_limits_kernel<double>, dim3(row_grid(rows)), dim3(kBlock), 0, st, (const double*)range, S,
-                         rows, upper_limit, lower_limit, mask_out);
-      hipLaunchKernelGGL(attenuated_slide_kernel<double>, grid, dim3(kBlock), lds, st, (const double*)sv, P, S, nchunks,
-                         chunk_len, num_side_pings, threshold, ring_cap, mask_out);
-    } else {
-      hipLaunchKernelGGL(attenuated_limits_kernel<float>, dim3(row_grid(rows)), dim3(kBlock), 0, st, (const float*)range, S,
-                         rows, (float)upper_limit, (float)lower_limit, mask_out);
-      hipLaunchKernelGGL(attenuated_slide_kernel<float>, grid, dim3(kBlock), lds, st, (const float*)sv, P, S, nchunks,
-                         chunk_len, num_side_pings, (float)threshold, ring_cap, mask_out);
-    }
-    return epa::check_launch("attenuated_slide_kernel");
+#define EPA_AW(T)                                                                                                     \
+  do {                                                                                                                \
+    hipLaunchKernelGGL(attenuated_prepare_kernel<T>, dim3(row_grid(rows)), dim3(kBlock), 0, st, (const T*)sv,         \
+                       (const T*)range, P, S, rows, (T)upper_limit, (T)lower_limit, num_side_pings, mask_out);        \
+    if (int rc = epa::check_launch("attenuated_prepare_kernel")) return rc;                                           \
+    hipLaunchKernelGGL(attenuated_walk_kernel<T>, grid, dim3(kBlock), wl, st, (const T*)sv, P, S, nchunks, chunk_len, \
+                       num_side_pings, (T)threshold, ring_cap, mask_out);                                             \
+  } while (0)
+    if (dtype == EPA_F64) EPA_AW(double); else EPA_AW(float);
+#undef EPA_AW
+    return epa::check_launch("attenuated_walk_kernel");
   }
   const long long rows = (long long)C * P;
   if (dtype == EPA_F64)

@@ -291,6 +291,45 @@ def test_pool_sv_sliding_sum_keeps_small_values_after_a_huge_one(env):
     np.testing.assert_array_equal(got2[~hit], got[~hit])
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("depth_kind", ["one vector", "limits change", "heave"])
+def test_attenuated_mask_carried_block_equals_medians_from_memory(env, dtype, depth_kind):
+    """The block carried from ping to ping (attenuated_prepare_kernel + attenuated_walk_kernel) against the kernel that
+    takes both medians of every ping from memory (reached with S % 4 != 0: one padding sample far below the layer):
+    attenuated pings, NaN, an all-NaN stretch, a flat stretch (more than 64 values in the median's bin and inside one
+    16-bit code of a ping's own layer), layer limits that change once / from ping to ping / move by a sample or two at
+    every ping (a depth with heave: the layer is shifted inside the ring), several chunks of pings."""
+    from echopype_amd import _lib
+
+    torch, ops = env
+    rng = np.random.default_rng(31)
+    C, P, S, n = 2, 1300, 400, 7
+    sv = -70 + 4 * rng.standard_normal((C, P, S)) - 10 * np.linspace(0, 1, S)
+    att = rng.random((C, P)) < 0.05
+    sv[att] -= rng.uniform(3, 30, size=att.sum())[:, None]
+    sv[rng.random((C, P, S)) < 0.03] = np.nan
+    sv[0, 500:520] = np.nan
+    sv[1, 900:960, 60:300] = -71.25
+    depth = np.broadcast_to(1.0 + 0.5 * np.arange(S), (C, P, S)).copy()
+    if depth_kind == "limits change":
+        depth[1, 700:] *= 1.1
+        depth[0, 1000:1010] *= 1 + 0.05 * rng.random((10, 1))
+    elif depth_kind == "heave":
+        depth = depth + 3.0 * np.sin(np.arange(P) / 7.0)[None, :, None]
+    svt, rgt = _dev(torch, sv.astype(dtype)), _dev(torch, depth.astype(dtype))
+    with _lib.launch_trace() as tr:
+        new = ops.attenuated_mask(svt, rgt, 40.0, 140.0, n, -6.0)
+    assert "attenuated_walk_kernel" in tr.kernels and "attenuated_prepare_kernel" in tr.kernels
+    pad = torch.nn.functional.pad
+    with _lib.launch_trace() as tr:
+        ref = ops.attenuated_mask(pad(svt, (0, 1), value=float("nan")).contiguous(),
+                                  pad(rgt, (0, 1), value=1.0e6).contiguous(), 40.0, 140.0, n, -6.0)[:, :, :S]
+    assert tr.kernels == ["attenuated_mask_kernel"]
+    a, b = new.cpu().numpy(), ref.cpu().numpy()
+    np.testing.assert_array_equal(a, b)
+    assert 20 < a[:, :, 0].sum() < 0.2 * C * P and (a == a[:, :, :1]).all()
+
+
 def _median_filter_db(sv2d, n, m):
     import scipy.ndimage
 
