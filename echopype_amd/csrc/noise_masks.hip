@@ -1930,7 +1930,7 @@ __global__ __launch_bounds__(kBlock) void pool_median_slide_kernel(MedSlideArgs<
   unsigned* ncand = coarse + kMedCoarse;                      // [2] (+ 2 words of padding), by parity of the ping
   unsigned* meta = ncand + 4;                                 // [2][4]: state, r1, dk, b1
   unsigned short* cidx = reinterpret_cast<unsigned short*>(meta + 8);  // [2][kMedSel] window elements of the candidates
-  unsigned short* bins = cidx + 2 * kMedSel;                  // [4 * npack]
+  unsigned short* bins = cidx + 2 * kMedSel;                  // [8 * npack], 16-byte aligned
   const int tid = threadIdx.x, lane = tid & 63;
   const bool finisher = tid >= kBlock - 64;
   const int P = a.P, S = a.S, n = a.n, R = 2 * n + 1;
@@ -1994,7 +1994,7 @@ __global__ __launch_bounds__(kBlock) void pool_median_slide_kernel(MedSlideArgs<
       }
       continue;
     }
-    const int W = R * w, npack = (W + 3) >> 2;
+    const int W = R * w, npack = (W + 7) >> 3;  // bins are searched eight per 128-bit read
     const float inv_w = 1.0f / (float)w;
     // column i of the window / row of virtual ping q: where they live in memory (nullptr: not part of the window)
     auto column = [&](int i) -> int {
@@ -2094,10 +2094,8 @@ __global__ __launch_bounds__(kBlock) void pool_median_slide_kernel(MedSlideArgs<
       }
     };
     __syncthreads();  // the previous job's last readers
-    if (tid < 4) {
-      ncand[tid] = 0u;
-      bins[4 * (npack - 1) + tid] = (unsigned short)kMedNoBin;  // (the padding of the last pack)
-    }
+    if (tid < 4) ncand[tid] = 0u;
+    if (tid < 8) bins[8 * (npack - 1) + tid] = (unsigned short)kMedNoBin;  // (the padding of the last pack)
     rebuild(p0, 0);
     {
       unsigned b1, b2, r1, dk;
@@ -2134,24 +2132,35 @@ __global__ __launch_bounds__(kBlock) void pool_median_slide_kernel(MedSlideArgs<
           }
           if (any) {  // the members of those bins (the bins between b1 and b2 are empty: "in [b1, b2]" selects them)
             const unsigned h1 = b1 * 0x00010001u, sp = (b2 - b1 + 1u) * 0x00010001u;
-            const uint2* packs = reinterpret_cast<const uint2*>(bins);
-            constexpr int kSearch = kBlock - 64;
-            for (int j0 = tid; j0 < npack; j0 += 2 * kSearch) {
-              const int j1 = j0 + kSearch;
-              const uint2 pa = packs[j0];
-              uint2 pb = packs[min(j1, npack - 1)];
-              if (j1 >= npack) pb.x = pb.y = 0xffffffffu;
-              const unsigned hit = halves_in_span(pa.x, h1, sp) | halves_in_span(pa.y, h1, sp) |
-                                   halves_in_span(pb.x, h1, sp) | halves_in_span(pb.y, h1, sp);
-              if (hit) {
-                const unsigned q4[8] = {pa.x & 0xffffu, pa.x >> 16, pa.y & 0xffffu, pa.y >> 16,
-                                        pb.x & 0xffffu, pb.x >> 16, pb.y & 0xffffu, pb.y >> 16};
+            const uint4* packs = reinterpret_cast<const uint4*>(bins);
+            constexpr int kSearch = kBlock - 64, kFly = 4;  // 128-bit reads in flight per lane
+            for (int j0 = tid; j0 < npack; j0 += kFly * kSearch) {
+              uint4 pk[kFly];
+              unsigned hit[kFly];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                  if (q4[u] - b1 <= b2 - b1) {
-                    const unsigned slot = atomicAdd(nc, 1u);
-                    if (slot < (unsigned)kMedSel)
-                      cidx[z * kMedSel + slot] = (unsigned short)(4 * (u < 4 ? j0 : j1) + (u & 3));
+              for (int f = 0; f < kFly; ++f) {
+                const int j = j0 + f * kSearch;
+                pk[f] = packs[min(j, npack - 1)];
+                if (j >= npack) pk[f].x = pk[f].y = pk[f].z = pk[f].w = 0xffffffffu;
+              }
+#pragma unroll
+              for (int f = 0; f < kFly; ++f)
+                hit[f] = halves_in_span(pk[f].x, h1, sp) | halves_in_span(pk[f].y, h1, sp) |
+                         halves_in_span(pk[f].z, h1, sp) | halves_in_span(pk[f].w, h1, sp);
+              if (hit[0] | hit[1] | hit[2] | hit[3]) {
+#pragma unroll
+                for (int f = 0; f < kFly; ++f) {
+                  if (hit[f]) {
+                    const unsigned wds[4] = {pk[f].x, pk[f].y, pk[f].z, pk[f].w};
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                      const unsigned q = (u & 1) ? (wds[u >> 1] >> 16) : (wds[u >> 1] & 0xffffu);
+                      if (q - b1 <= b2 - b1) {
+                        const unsigned slot = atomicAdd(nc, 1u);
+                        if (slot < (unsigned)kMedSel)
+                          cidx[z * kMedSel + slot] = (unsigned short)(8 * (j0 + f * kSearch) + u);
+                      }
+                    }
                   }
                 }
               }
@@ -2435,12 +2444,44 @@ __global__ __launch_bounds__(kBlock, 2) void attenuated_walk_kernel(const T* __r
     }
   };
 
+  // the block moves on by one ping: the oldest ping leaves, ping w_lo + R (its layer samples in `pre`) takes its slot
+  auto advance = [&](const T (&pre)[kAttCols]) {
+    const int Lw = w_lw - w_up;
+#pragma unroll
+    for (int k = 0; k < kAttCols; ++k) {
+      const int col = tid + k * kBlock;
+      if (col < Lw) {
+        const int e = rs * Lp + (w_up - base) + col;
+        const unsigned ob = bins[e];
+        if (ob != kMedNoBin) {
+          atomicSub(&fine[ob], 1u);
+          atomicSub(&coarse[ob >> 6], 1u);
+        }
+        enter(e, pre[k]);
+      }
+    }
+    rs = rs + 1 == R ? 0 : rs + 1;
+    ++w_lo;
+  };
+
   for (int p = p0; p < p1; ++p) {
     const int up = lim[p - p0][0], lw = lim[p - p0][1], L = lw - up;
     if (!(p - n >= 0 && (long long)p + n <= (long long)P - 1 && lw > up)) {
+      // no verdict for this ping (its range row gives no layer, or it has no 2n-ping block) -- the block in LDS stays
+      // good for the pings behind it: it moves on over its own layer
       drain();
-      valid = false;
       write_row(p, false, tid, kBlock);
+      if (valid && w_lo == p - n && p + 1 < p1 && (long long)p + n <= (long long)P - 1) {
+        T pre[kAttCols];
+#pragma unroll
+        for (int k = 0; k < kAttCols; ++k) {
+          const int col = tid + k * kBlock;
+          pre[k] = col < w_lw - w_up ? cb[(size_t)(p + n) * S + w_up + col] : epa::M<T>::nan();
+        }
+        advance(pre);
+      } else {
+        valid = false;
+      }
       continue;
     }
     if ((long long)R * ((L + 7) & ~7) > ring_cap || L > kAttCols * kBlock) {  // block beyond the ring
@@ -2477,10 +2518,10 @@ __global__ __launch_bounds__(kBlock, 2) void attenuated_walk_kernel(const T* __r
     }
     // will the block of the next ping be carried?  then its entering ping is requested now (over THIS ping's layer:
     // a layer that differs is shifted at the next step)
-    bool slide = p + 1 < p1 && (long long)p + 1 + n <= (long long)P - 1;
+    bool slide = p + 1 < p1;  // (ping p + n exists: this ping has a block)
     if (slide) {
       const int nu = lim[p + 1 - p0][0], nl = lim[p + 1 - p0][1];
-      slide = nl > nu && nu >= base && nl <= base + Lp && nl - nu <= kAttCols * kBlock;
+      slide = nl <= nu || (nu >= base && nl <= base + Lp && nl - nu <= kAttCols * kBlock);
     }
     T pre[kAttCols];
 #pragma unroll
@@ -2506,25 +2547,34 @@ __global__ __launch_bounds__(kBlock, 2) void attenuated_walk_kernel(const T* __r
         if (any) {  // the members of those bins, eight bins per 128-bit read
           const unsigned h1 = b1 * 0x00010001u, sp = (b2 - b1 + 1u) * 0x00010001u;
           const uint4* packs = reinterpret_cast<const uint4*>(bins);
-          constexpr int kSearch = kBlock - 64;
-          for (int j0 = tid; j0 < total8; j0 += 2 * kSearch) {
-            const int j1 = j0 + kSearch;
-            const uint4 pa = packs[j0];
-            uint4 pb = packs[min(j1, total8 - 1)];
-            if (j1 >= total8) pb.x = pb.y = pb.z = pb.w = 0xffffffffu;
-            const unsigned hit = halves_in_span(pa.x, h1, sp) | halves_in_span(pa.y, h1, sp) |
-                                 halves_in_span(pa.z, h1, sp) | halves_in_span(pa.w, h1, sp) |
-                                 halves_in_span(pb.x, h1, sp) | halves_in_span(pb.y, h1, sp) |
-                                 halves_in_span(pb.z, h1, sp) | halves_in_span(pb.w, h1, sp);
-            if (hit) {
-              const unsigned wds[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+          constexpr int kSearch = kBlock - 64, kFly = 4;  // 128-bit reads in flight per lane
+          for (int j0 = tid; j0 < total8; j0 += kFly * kSearch) {
+            uint4 pk[kFly];
+            unsigned hit[kFly];
 #pragma unroll
-              for (int u = 0; u < 16; ++u) {
-                const unsigned q = (u & 1) ? (wds[u >> 1] >> 16) : (wds[u >> 1] & 0xffffu);
-                if (q - b1 <= b2 - b1) {
-                  const unsigned slot = atomicAdd(nc, 1u);
-                  if (slot < (unsigned)kMedSel)
-                    cidx[z * kMedSel + slot] = (unsigned short)(8 * (u < 8 ? j0 : j1) + (u & 7));
+            for (int f = 0; f < kFly; ++f) {
+              const int j = j0 + f * kSearch;
+              pk[f] = packs[min(j, total8 - 1)];
+              if (j >= total8) pk[f].x = pk[f].y = pk[f].z = pk[f].w = 0xffffffffu;
+            }
+#pragma unroll
+            for (int f = 0; f < kFly; ++f)
+              hit[f] = halves_in_span(pk[f].x, h1, sp) | halves_in_span(pk[f].y, h1, sp) |
+                       halves_in_span(pk[f].z, h1, sp) | halves_in_span(pk[f].w, h1, sp);
+            if (hit[0] | hit[1] | hit[2] | hit[3]) {
+#pragma unroll
+              for (int f = 0; f < kFly; ++f) {
+                if (hit[f]) {
+                  const unsigned wds[4] = {pk[f].x, pk[f].y, pk[f].z, pk[f].w};
+#pragma unroll
+                  for (int u = 0; u < 8; ++u) {
+                    const unsigned q = (u & 1) ? (wds[u >> 1] >> 16) : (wds[u >> 1] & 0xffffu);
+                    if (q - b1 <= b2 - b1) {
+                      const unsigned slot = atomicAdd(nc, 1u);
+                      if (slot < (unsigned)kMedSel)
+                        cidx[z * kMedSel + slot] = (unsigned short)(8 * (j0 + f * kSearch) + u);
+                    }
+                  }
                 }
               }
             }
@@ -2562,25 +2612,8 @@ __global__ __launch_bounds__(kBlock, 2) void attenuated_walk_kernel(const T* __r
       pending = true;
       f_p = p; f_rs = rs; f_lo = p - n;
     }
-    if (slide) {  // ping p-n leaves, ping p+n enters (same ring slot)
-#pragma unroll
-      for (int k = 0; k < kAttCols; ++k) {
-        const int col = tid + k * kBlock;
-        if (col < L) {
-          const int e = rs * Lp + (up - base) + col;
-          const unsigned ob = bins[e];
-          if (ob != kMedNoBin) {
-            atomicSub(&fine[ob], 1u);
-            atomicSub(&coarse[ob >> 6], 1u);
-          }
-          enter(e, pre[k]);
-        }
-      }
-      rs = rs + 1 == R ? 0 : rs + 1;
-      w_lo = p - n + 1;
-    } else {
-      valid = false;
-    }
+    if (slide) advance(pre);  // ping p-n leaves, ping p+n enters (same ring slot)
+    else valid = false;
   }
   drain();
 }
@@ -2617,7 +2650,7 @@ constexpr size_t kMaxLds = 156 * 1024;
 
 // dynamic LDS of pool_median_slide_kernel for a ring of W window elements
 inline size_t med_slide_lds(size_t W) {
-  return epa::kMathTabBytes + (size_t)(kMedBins + kMedCoarse + 4 + 8) * 4 + 2 * kMedSel * 2 + ((W + 3) / 4) * 8;
+  return epa::kMathTabBytes + (size_t)(kMedBins + kMedCoarse + 4 + 8) * 4 + 2 * kMedSel * 2 + ((W + 7) / 8) * 16;
 }
 
 }  // namespace
