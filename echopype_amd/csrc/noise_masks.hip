@@ -1354,8 +1354,9 @@ __global__ __launch_bounds__(kBlock) void row_running_sum_kernel(const T* __rest
             }
           }
         }
-        fa.rh[base + s] = has_inf ? __builtin_inf() : sum.hi;
-        fa.rl[base + s] = has_inf ? 0.0 : sum.lo;
+        // ONE double per interval sum: what the double-double running sums buy is an interval sum without
+        // cancellation; rounded once (1.1e-16 relative) it enters and leaves the column's window as the same number
+        fa.rh[base + s] = has_inf ? __builtin_inf() : sum.hi + sum.lo;
         fa.rn[base + s] = cnt;
       }
     }
@@ -1747,8 +1748,7 @@ __global__ __launch_bounds__(kBlock) void row_interval_sum_kernel(
         }
       }
     }
-    rh[base + s] = has_inf ? __builtin_inf() : sum.hi;
-    rl[base + s] = has_inf ? 0.0 : sum.lo;
+    rh[base + s] = has_inf ? __builtin_inf() : sum.hi + sum.lo;
     rn[base + s] = cnt;
   }
 }
@@ -1757,7 +1757,6 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void value_slide_kernel(PoolValueArgs<T> a, const int* __restrict__ differ,
                                                              const int* __restrict__ ilo,
                                                              const double* __restrict__ rh,
-                                                             const double* __restrict__ rl,
                                                              const int* __restrict__ rn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const epa::MathTabs mt = epa::build_math_tabs(smem);
@@ -1769,20 +1768,18 @@ __global__ __launch_bounds__(kBlock) void value_slide_kernel(PoolValueArgs<T> a,
   const size_t cbase = (size_t)c * P * S;
   const bool depth_ok = ilo[(size_t)c * S + s] >= 0;
   const double* __restrict__ h = rh + cbase + s;
-  const double* __restrict__ l = rl + cbase + s;
   const int* __restrict__ k = rn + cbase + s;
   DdSum w;
   if (depth_ok)
     for (int q = max(0, p0 - n); q <= min(P - 1, p0 + n); ++q) {
       const size_t r = (size_t)q * S;
       w.add(h[r], k[r], 1.0);
-      w.add(l[r], 0, 1.0);
     }
   // four pings per trip: the rows entering and leaving at each of them (and the Sv compared with the result)
   // are requested together, then consumed in order
   constexpr int U = 4;
   for (int pb = p0; pb < p1; pb += U) {
-    double hin[U], lin_[U], hout[U], lout[U];
+    double hin[U], hout[U];
     int kin[U], kout[U], nvp[U];
     T x[U];
 #pragma unroll
@@ -1792,10 +1789,8 @@ __global__ __launch_bounds__(kBlock) void value_slide_kernel(PoolValueArgs<T> a,
       const bool gi = depth_ok && p > p0 && in <= P - 1, go = depth_ok && p > p0 && out >= 0;
       const size_t ri = (size_t)(gi ? in : 0) * S, ro = (size_t)(go ? out : 0) * S;
       hin[j] = gi ? h[ri] : 0.0;
-      lin_[j] = gi ? l[ri] : 0.0;
       kin[j] = gi ? k[ri] : 0;
       hout[j] = go ? h[ro] : 0.0;
-      lout[j] = go ? l[ro] : 0.0;
       kout[j] = go ? k[ro] : 0;
       nvp[j] = a.nvalid[(size_t)c * P + p];
       x[j] = a.mask ? a.sv[cbase + (size_t)p * S + s] : (T)0;
@@ -1805,9 +1800,7 @@ __global__ __launch_bounds__(kBlock) void value_slide_kernel(PoolValueArgs<T> a,
       const int p = pb + j;
       if (p >= p1) break;
       w.add(hin[j], kin[j], 1.0);
-      w.add(lin_[j], 0, 1.0);
       w.add(hout[j], kout[j], -1.0);
-      w.add(lout[j], 0, -1.0);
       T res = epa::M<T>::nan();
       const bool ok = depth_ok && (p - n >= 0) && ((long long)p + n <= (long long)P) && s < nvp[j];
       if (ok && w.cnt > 0) res = (T)(10.0 * epa::fast_log10(w.value() / (double)w.cnt, mt.log_tab));
@@ -2230,6 +2223,9 @@ __global__ __launch_bounds__(kBlock) void pool_median_slide_kernel(MedSlideArgs<
 // median (attenuated_prepare_kernel); everybody writes that ping's mask row after the next barrier.  Whenever the
 // layer limits change, the block exceeds the ring or more than 64 values share the median's bin, the block is
 // rebuilt / the ping's medians are taken from memory by all threads.
+#ifndef EPA_ATT_SCALE
+#define EPA_ATT_SCALE 128
+#endif
 #ifndef EPA_ATT_MARGIN
 #define EPA_ATT_MARGIN 4
 #endif
@@ -2387,8 +2383,8 @@ __global__ __launch_bounds__(kBlock, 2) void attenuated_walk_kernel(const T* __r
   };
   auto recentre = [&](unsigned b) {
     const float centre = ((float)b + 0.5f - map.off) / map.scale;
-    map.scale = 128.0f;
-    map.off = (float)(kMedBins / 2) - centre * 128.0f;
+    map.scale = (float)EPA_ATT_SCALE;
+    map.off = (float)(kMedBins / 2) - centre * (float)EPA_ATT_SCALE;
     centred = true;
   };
   // both medians of ping p from memory, by all threads
@@ -2865,7 +2861,7 @@ int launch_pool_value(const void* sv, const void* range, const int32_t* nvalid, 
         return EPA_EINVAL;
       }
       hipLaunchKernelGGL(value_slide_kernel<T>, g2, dim3(kBlock), epa::kMathTabBytes + kSlidePad, st, a, differ, ilo, rh,
-                         rl, rn);
+                         rn);
       if (int rc = epa::check_launch("value_slide_kernel")) return rc;
       {  // channels whose pings differ in their range vectors: neighbour rows staged in LDS
         const long long ngroups = (long long)C * ((P + kStageRows - 1) / kStageRows);
