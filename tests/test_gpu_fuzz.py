@@ -302,3 +302,84 @@ def test_random_medium_volumes_on_the_specialised_kernels(ep, seed):
         close(mv3["Sv"].values, exp_mvc, 1e-7, f"chain MVBS {regime}")
     finally:
         logging.disable(logging.NOTSET)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("EPA_FUZZ_CARRIED", "16"))))
+def test_random_carried_windows_against_the_windows_taken_from_memory(ep, seed):
+    """The round-4 carried-window kernels (nanmedian pooling by value windows, attenuated-signal mask) on random
+    medium shapes -- ping counts around the 512-ping segments / the walk's chunks, layers and windows around the lane
+    counts, NaN tails, flat stretches, quantised values (ties) -- against the kernels that take every window from
+    memory (the workspace-free pooling; the per-ping attenuated kernel, reached with S % 4 != 0)."""
+    import torch
+
+    from echopype_amd import ops
+
+    rng = np.random.default_rng(9000 + seed)
+    C = int(rng.integers(1, 3))
+    P = int(rng.choice([3, 40, 511, 513, 700, 1100]))
+    S = 4 * int(rng.integers(6, 120))
+    sv = -70 + float(rng.choice([0.5, 4.0])) * rng.standard_normal((C, P, S)) - 10 * np.linspace(0, 1, S)
+    if rng.random() < 0.5:
+        sv = np.round(sv * 4) / 4                       # quantised: many equal values
+    att = rng.random((C, P)) < 0.08
+    sv[att] -= rng.uniform(3, 40, size=int(att.sum()))[:, None]
+    sv[rng.random((C, P, S)) < float(rng.choice([0.0, 0.05, 0.4]))] = np.nan
+    if P > 60:
+        sv[0, 20:45] = -71.0
+        sv[C - 1, 50:55] = np.nan
+    step = float(rng.choice([0.2, 0.5]))
+    depth = np.broadcast_to(1.0 + step * np.arange(S), (C, P, S)).copy()
+    kind = int(rng.integers(0, 3))
+    if kind == 1:
+        depth = depth + 2 * step * np.sin(np.arange(P) / 5.0)[None, :, None]     # heave
+    elif kind == 2 and P > 4:
+        depth[:, P // 2:] *= 1.07                                                  # limits change once
+    tail = rng.random((C, P)) < 0.1
+    depth[tail, S - S // 10:] = np.nan
+    sv[np.isnan(depth)] = np.nan
+    svt, rgt = torch.from_numpy(sv).cuda(), torch.from_numpy(depth).cuda()
+    # attenuated-signal mask
+    n = int(rng.choice([1, 2, 7, 15]))
+    up, lw = sorted(rng.uniform(1.0, 1.0 + step * S, 2))
+    pad = torch.nn.functional.pad
+    got = ops.attenuated_mask(svt, rgt, float(up), float(lw), n, -4.0)
+    ref = ops.attenuated_mask(pad(svt, (0, 1), value=float("nan")).contiguous(), pad(rgt, (0, 1), value=1.0e7).contiguous(),
+                              float(up), float(lw), n, -4.0)[:, :, :S]
+    got, ref = got.cpu().numpy(), ref.cpu().numpy()
+    for c, p in np.argwhere(got[:, :, 0] != ref[:, :, 0]):
+        # only a ping whose difference of medians sits ON the threshold may differ (quantised values: 10 log10(10^(x/10))
+        # rounds differently where the compiler contracts the two kernels' multiplications differently)
+        iu, il = int(np.argmin(np.abs(depth[c, p] - up))), int(np.argmin(np.abs(depth[c, p] - lw)))
+        with np.errstate(invalid="ignore"):
+            pm = 10 * np.log10(np.nanmedian(10 ** (sv[c, p, iu:il] / 10)))
+            bm = 10 * np.log10(np.nanmedian(10 ** (sv[c, p - n:p + n, iu:il] / 10)))
+        assert abs(pm - bm + 4.0) < 1e-9, f"attenuated seed {seed} ping {c},{p}: {pm} - {bm}"
+    assert (got == got[:, :, :1]).all() and (got[:, :, 0] != ref[:, :, 0]).sum() <= max(4, 0.02 * C * P)
+    # nanmedian pooling by value windows (one range vector per channel unless heave made them differ)
+    nvalid, bad = ops.range_rows_check(rgt)
+    assert bad == 0
+    lo, hi = ops.nanminmax(rgt)
+    ns = int(rng.choice([0, 1, 3, 9]))
+    dbin = float(rng.choice([0.6, 2.3, 11.0]))
+    excl = float(rng.choice([0.0, 5.0]))
+    a, ma = ops.pool_sv_value(svt, rgt, nvalid, dbin, ns, excl, lo, hi, func="nanmedian", threshold=5.0)
+    b, mb = ops.pool_sv_value(svt, rgt, nvalid, dbin, ns, excl, lo, hi, func="nanmedian", threshold=5.0,
+                              running_sums=False)
+    np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy(), err_msg=f"value median seed {seed}")
+    np.testing.assert_array_equal(ma.cpu().numpy(), mb.cpu().numpy())
+    # nanmedian pooling by index windows: a small cut against scipy's generic_filter
+    import scipy.ndimage
+
+    Pc, Sc = min(P, 60), min(S, 48)
+    cut = sv[0, :Pc, :Sc]
+    nn, mm = int(rng.integers(0, 5)), int(rng.integers(0, 9))
+    if 2 * nn + 1 <= 2 * Pc and 2 * mm + 1 <= 2 * Sc:
+        with np.errstate(invalid="ignore", divide="ignore"), __import__("warnings").catch_warnings():
+            __import__("warnings").simplefilter("ignore", RuntimeWarning)
+            exp = 10 * np.log10(scipy.ndimage.generic_filter(10 ** (cut / 10), np.nanmedian, size=[2 * nn + 1, 2 * mm + 1],
+                                                             mode="reflect"))
+        got, _ = ops.pool_sv(torch.from_numpy(np.ascontiguousarray(cut[None])).cuda(), 0, nn, mm, func="nanmedian")
+        got = got.cpu().numpy()[0]
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+        fin = np.isfinite(exp)
+        assert np.max(np.abs(got[fin] - exp[fin]) / np.maximum(np.abs(exp[fin]), 1.0), initial=0.0) < 1e-9
