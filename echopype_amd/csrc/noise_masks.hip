@@ -1194,10 +1194,8 @@ __device__ __forceinline__ Dd dd_shfl_up(const Dd& v, int o) {
   return Dd{__shfl_up(v.hi, o, 64), __shfl_up(v.lo, o, 64)};
 }
 
-// FUSED: for the channels whose pings share one range vector the running sums of a row never leave LDS -- the row's
-// interval sums R[s] = W[hi(s)-1] - W[lo(s)-1] are formed right there and only they are written (28 instead of
-// 88 B/sample of traffic for the two steps); rows of the other channels are left to the unfused launch, which in
-// turn skips these (skip_same).
+// The channels whose pings share one range vector do not take this route: their rows' interval sums come from
+// row_interval_blocks_kernel below (no running sums, no subtraction) and this launch skips them (skip_same).
 struct FuseArgs {
   const int* differ;
   const int* nvalid;
@@ -1209,12 +1207,11 @@ struct FuseArgs {
   int P, skip_same;
 };
 
-template <typename T, bool FUSED>
+template <typename T>
 __global__ __launch_bounds__(kBlock) void row_running_sum_kernel(const T* __restrict__ sv, long long rows, int S,
                                                                  double* __restrict__ wh, double* __restrict__ wl,
                                                                  int* __restrict__ wn, uint8_t* __restrict__ dirty,
                                                                  FuseArgs fa) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char fuse_smem[];  // FUSED: W of one row, 20 B / sample
   __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
   __shared__ double th[4], tl[4];
   __shared__ int tc[4], any_inf;
@@ -1228,7 +1225,7 @@ __global__ __launch_bounds__(kBlock) void row_running_sum_kernel(const T* __rest
   typedef int ipair_t __attribute__((ext_vector_type(2), aligned(4)));
   for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
     const long long chan = row / fa.P;
-    if (FUSED ? fa.differ[chan] != 0 : (fa.skip_same && fa.differ[chan] == 0)) continue;  // uniform per workgroup
+    if (fa.skip_same && fa.differ[chan] == 0) continue;  // uniform per workgroup (row_interval_blocks_kernel has it)
     __syncthreads();
     if (threadIdx.x == 0) any_inf = 0;
     const T* svr = sv + (size_t)row * S;
@@ -1275,9 +1272,9 @@ __global__ __launch_bounds__(kBlock) void row_running_sum_kernel(const T* __rest
       carry.add(Dd{th[w], tl[w]}, 1.0);
       carry_n += tc[w];
     }
-    double* whr = FUSED ? reinterpret_cast<double*>(fuse_smem) : wh + (size_t)row * S;
-    double* wlr = FUSED ? whr + ((S + 1) & ~1) : wl + (size_t)row * S;
-    int* wnr = FUSED ? reinterpret_cast<int*>(wlr + ((S + 1) & ~1)) : wn + (size_t)row * S;
+    double* whr = wh + (size_t)row * S;
+    double* wlr = wl + (size_t)row * S;
+    int* wnr = wn + (size_t)row * S;
     for (int kb = k0; kb < k1; kb += 128) {
       const int k = kb + 2 * lane;
       T v0 = epa::M<T>::nan(), v1 = epa::M<T>::nan();
@@ -1326,40 +1323,143 @@ __global__ __launch_bounds__(kBlock) void row_running_sum_kernel(const T* __rest
       carry_n += __shfl(c, 63, 64);
     }
     if (threadIdx.x == 0) dirty[row] = (uint8_t)any_inf;
-    if (FUSED) {  // the row's interval sums, straight from the LDS copy of W (row_interval_sum_kernel otherwise)
-      __syncthreads();
-      const int nv = fa.nvalid[row];
-      const bool row_dirty = any_inf != 0;
-      const size_t base = (size_t)row * S;
-      for (int s = threadIdx.x; s < S; s += kBlock) {
-        const int lo = min(fa.ilo[(size_t)chan * S + s], nv), hi = min(fa.ihi[(size_t)chan * S + s], nv);
-        Dd sum{0.0, 0.0};
-        int cnt = 0;
-        bool has_inf = false;
-        if (lo >= 0 && hi > lo) {
-          if (row_dirty) {
-            for (int k = lo; k < hi; ++k) {
-              double x;
-              int c1;
-              lin_of(svr[k], x, c1, has_inf);
-              sum.add(x);
-              cnt += c1;
-            }
-          } else {
-            sum.add(Dd{whr[hi - 1], wlr[hi - 1]}, 1.0);
-            cnt = wnr[hi - 1];
-            if (lo > 0) {
-              sum.add(Dd{whr[lo - 1], wlr[lo - 1]}, -1.0);
-              cnt -= wnr[lo - 1];
-            }
-          }
-        }
-        // ONE double per interval sum: what the double-double running sums buy is an interval sum without
-        // cancellation; rounded once (1.1e-16 relative) it enters and leaves the column's window as the same number
-        fa.rh[base + s] = has_inf ? __builtin_inf() : sum.hi + sum.lo;
-        fa.rn[base + s] = cnt;
+  }
+}
+
+// The interval sums of a row WITHOUT a subtraction (round 4; channels whose pings share one range vector).  van Herk /
+// Gil-Werman with blocks of 16 samples -- one DPP row: every sample gets the sum from its block's start up to it
+// (pre) and from it to its block's end (suf), four DPP additions each, in plain doubles; an interval [lo, hi) that
+// leaves lo's block is  suf[lo] + the whole blocks in between + pre[hi-1]  -- additions of non-negative numbers only,
+// so a sample 10^14 times its neighbours disturbs nobody outside its own intervals and the double-double running sums
+// of row_running_sum_kernel (two sweeps of the row, 6-step shuffle scans of pairs of doubles) are not needed.  An
+// interval inside one block is summed value by value (<= 16, read again from memory).  Counts of valid / +inf
+// samples the same way, packed.  One conversion per sample, the row read once.  LDS: 20 B per sample; the channel's
+// intervals stay in registers from row to row.
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_add(double v) {  // v + (v of the lane CTRL says, 0 where the row ends)
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)b >> 32), CTRL, 0xf, 0xf, false);
+  return v + __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_row_addu(unsigned v) {
+  return v + (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void row_interval_blocks_kernel(const T* __restrict__ sv, long long rows, int S,
+                                                                     FuseArgs fa) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
+  const epa::MathTabs mt = epa::build_math_tabs(tabs);
+  const int Sp = (S + 63) & ~63;
+  double* pre = reinterpret_cast<double*>(smem);  // [Sp]
+  double* suf = pre + Sp;
+  double* tot = suf + Sp;                         // [Sp / 16]
+  unsigned short* cpre = reinterpret_cast<unsigned short*>(tot + Sp / 16);  // valid | inf << 8, inside the block
+  unsigned short* csuf = cpre + Sp;
+  unsigned short* ctot = csuf + Sp;               // [Sp / 16]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int trips = Sp >> 6;
+  constexpr int kFly = 8;  // requests in flight per lane
+  constexpr int kCols = 8; // columns per lane whose interval is kept in registers (rows up to 2048 samples)
+  long long have = -1;
+  int clo[kCols], chi[kCols];
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const long long chan = row / fa.P;
+    if (fa.differ[chan] != 0) continue;  // uniform per workgroup
+    if (chan != have) {
+      have = chan;
+#pragma unroll
+      for (int j = 0; j < kCols; ++j) {
+        const int s = threadIdx.x + j * kBlock;
+        clo[j] = s < S ? fa.ilo[(size_t)chan * S + s] : -1;
+        chi[j] = s < S ? fa.ihi[(size_t)chan * S + s] : -1;
       }
     }
+    const T* svr = sv + (size_t)row * S;
+    __syncthreads();  // the previous row's readers
+    for (int t0 = wave; t0 < trips; t0 += 4 * kFly) {
+      T v[kFly];
+#pragma unroll
+      for (int f = 0; f < kFly; ++f) {
+        const int i = (t0 + 4 * f) * 64 + lane;
+        v[f] = (t0 + 4 * f < trips && i < S) ? svr[i] : epa::M<T>::nan();
+      }
+#pragma unroll
+      for (int f = 0; f < kFly; ++f) {
+        if (t0 + 4 * f < trips) {
+          const int i = (t0 + 4 * f) * 64 + lane;
+          double x = 0.0;
+          unsigned c = 0u;
+          if (v[f] == v[f]) {
+            const double y = (double)epa::lin_from_db(v[f], mt.exp2_tab);
+            c = 1u;
+            if (y == __builtin_inf()) c = 0x101u; else x = y;
+          }
+          double fs = x, bs = x;
+          unsigned fc = c, bc = c;
+          fs = dpp_row_add<0x111>(fs); fs = dpp_row_add<0x112>(fs); fs = dpp_row_add<0x114>(fs); fs = dpp_row_add<0x118>(fs);
+          bs = dpp_row_add<0x101>(bs); bs = dpp_row_add<0x102>(bs); bs = dpp_row_add<0x104>(bs); bs = dpp_row_add<0x108>(bs);
+          fc = dpp_row_addu<0x111>(fc); fc = dpp_row_addu<0x112>(fc); fc = dpp_row_addu<0x114>(fc); fc = dpp_row_addu<0x118>(fc);
+          bc = dpp_row_addu<0x101>(bc); bc = dpp_row_addu<0x102>(bc); bc = dpp_row_addu<0x104>(bc); bc = dpp_row_addu<0x108>(bc);
+          pre[i] = fs;
+          suf[i] = bs;
+          cpre[i] = (unsigned short)fc;
+          csuf[i] = (unsigned short)bc;
+          if ((lane & 15) == 15) {
+            tot[i >> 4] = fs;
+            ctot[i >> 4] = (unsigned short)fc;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int nv = fa.nvalid[row];
+    const size_t base = (size_t)row * S;
+    auto column = [&](int s, int lo, int hi) {
+      lo = min(lo, nv);
+      hi = min(hi, nv);
+      double sum = 0.0;
+      unsigned valid = 0u, infs = 0u;
+      if (lo >= 0 && hi > lo) {
+        const int bl = lo >> 4, bh = (hi - 1) >> 4;
+        if (bl == bh) {
+          for (int k = lo; k < hi; ++k) {
+            const T v = svr[k];
+            if (v == v) {
+              const double y = (double)epa::lin_from_db(v, mt.exp2_tab);
+              if (y != __builtin_inf()) sum += y;
+            }
+          }
+          const unsigned a = cpre[hi - 1], b = (lo & 15) ? cpre[lo - 1] : 0u;  // (integers: a difference is exact)
+          valid = (a & 255u) - (b & 255u);
+          infs = (a >> 8) - (b >> 8);
+        } else {
+          sum = suf[lo];
+          unsigned c = csuf[lo];
+          valid = c & 255u; infs = c >> 8;
+          for (int b = bl + 1; b < bh; ++b) {
+            sum += tot[b];
+            c = ctot[b];
+            valid += c & 255u; infs += c >> 8;
+          }
+          sum += pre[hi - 1];
+          c = cpre[hi - 1];
+          valid += c & 255u; infs += c >> 8;
+        }
+      }
+      fa.rh[base + s] = infs ? __builtin_inf() : sum;
+      fa.rn[base + s] = (int)valid;
+    };
+#pragma unroll
+    for (int j = 0; j < kCols; ++j) {
+      const int s = threadIdx.x + j * kBlock;
+      if (s < S) column(s, clo[j], chi[j]);
+    }
+    for (int s = threadIdx.x + kCols * kBlock; s < S; s += kBlock)
+      column(s, fa.ilo[(size_t)chan * S + s], fa.ihi[(size_t)chan * S + s]);
   }
 }
 
@@ -2840,16 +2940,17 @@ int launch_pool_value(const void* sv, const void* range, const int32_t* nvalid, 
       if (int rc = epa::check_launch("rows_same_kernel")) return rc;
       // those channels: running sums in LDS -> interval sums per row (one kernel), then a sliding sum down every
       // column; the others: running sums to the workspace, then row by row
-      const size_t fuse_lds = (size_t)((S + 1) & ~1) * 16 + (size_t)S * 4;
+      const size_t Sp = ((size_t)S + 63) & ~(size_t)63;
+      const size_t fuse_lds = Sp * 20 + (Sp / 16) * 10 + 16;
       const bool fuse = fuse_lds + epa::kMathTabBytes + 1024 <= kMaxLds;
       FuseArgs fa{differ, nvalid, ilo, ihi, rh, rl, rn, P, fuse ? 1 : 0};
       if (fuse) {
-        auto kern = row_running_sum_kernel<T, true>;
+        auto kern = row_interval_blocks_kernel<T>;
         if (int rc = set_lds(kern, fuse_lds)) return rc;
-        hipLaunchKernelGGL(kern, rowg, dim3(kBlock), fuse_lds, st, (const T*)sv, rows, S, wh, wl, wn, dirty, fa);
-        if (int rc = epa::check_launch("row_running_sum_kernel<fused>")) return rc;
+        hipLaunchKernelGGL(kern, rowg, dim3(kBlock), fuse_lds, st, (const T*)sv, rows, S, fa);
+        if (int rc = epa::check_launch("row_interval_blocks_kernel")) return rc;
       }
-      hipLaunchKernelGGL((row_running_sum_kernel<T, false>), rowg, dim3(kBlock), 0, st, (const T*)sv, rows, S, wh, wl, wn,
+      hipLaunchKernelGGL(row_running_sum_kernel<T>, rowg, dim3(kBlock), 0, st, (const T*)sv, rows, S, wh, wl, wn,
                          dirty, fa);
       if (int rc = epa::check_launch("row_running_sum_kernel")) return rc;
       if (!fuse)
