@@ -1202,7 +1202,6 @@ struct FuseArgs {
   const int* ilo;
   const int* ihi;
   double* rh;
-  double* rl;
   int* rn;
   int P, skip_same;
 };
@@ -1812,7 +1811,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void row_interval_sum_kernel(
     PoolValueArgs<T> a, long long rows, const double* __restrict__ wh, const double* __restrict__ wl,
     const int* __restrict__ wn, const uint8_t* __restrict__ dirty, const int* __restrict__ differ,
-    const int* __restrict__ ilo, const int* __restrict__ ihi, double* __restrict__ rh, double* __restrict__ rl,
+    const int* __restrict__ ilo, const int* __restrict__ ihi, double* __restrict__ rh,
     int* __restrict__ rn) {
   __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
   const epa::MathTabs mt = epa::build_math_tabs(tabs);
@@ -2943,7 +2942,7 @@ int launch_pool_value(const void* sv, const void* range, const int32_t* nvalid, 
       const size_t Sp = ((size_t)S + 63) & ~(size_t)63;
       const size_t fuse_lds = Sp * 20 + (Sp / 16) * 10 + 16;
       const bool fuse = fuse_lds + epa::kMathTabBytes + 1024 <= kMaxLds;
-      FuseArgs fa{differ, nvalid, ilo, ihi, rh, rl, rn, P, fuse ? 1 : 0};
+      FuseArgs fa{differ, nvalid, ilo, ihi, rh, rn, P, fuse ? 1 : 0};
       if (fuse) {
         auto kern = row_interval_blocks_kernel<T>;
         if (int rc = set_lds(kern, fuse_lds)) return rc;
@@ -2955,7 +2954,7 @@ int launch_pool_value(const void* sv, const void* range, const int32_t* nvalid, 
       if (int rc = epa::check_launch("row_running_sum_kernel")) return rc;
       if (!fuse)
         hipLaunchKernelGGL(row_interval_sum_kernel<T>, grid, dim3(kBlock), 0, st, a, rows, wh, wl, wn, dirty, differ, ilo,
-                           ihi, rh, rl, rn);
+                           ihi, rh, rn);
       const dim3 g2((P + kSlideSeg - 1) / kSlideSeg, (S + kBlock - 1) / kBlock, C);
       if (g2.y > 65535u || g2.z > 65535u) {
         epa::set_error("epa_pool_sv_value: more than 65535 channels or 16.7 M samples per ping");

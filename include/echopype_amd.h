@@ -506,9 +506,9 @@ int epa_range_rows_check(const void* range, int C, int P, int S, int dtype, int3
  * range rows must pass epa_range_rows_check (nvalid from it).  func / threshold / outputs as epa_pool_sv. */
 #define EPA_POOL_VALUE_WS_BYTES(C, P, S) \
   ((size_t)(C) * (P) * (S) * 40 + (size_t)(C) * (S) * 8 + (size_t)(C) * 8 + (size_t)(C) * (P))
-/* ws (optional, nanmean only): EPA_POOL_VALUE_WS_BYTES bytes, 8-byte aligned.  With it the window sums come from
- * per-row running sums kept in double-double: a channel whose pings all share one range vector (checked on the
- * device) gets per-row interval sums + a sliding sum down every column, O(1) per sample; any other channel
+/* ws (optional, nanmean only): EPA_POOL_VALUE_WS_BYTES bytes, 8-byte aligned.  With it a channel whose pings all share
+ * one range vector (checked on the device) gets per-row interval sums (blocks of 16 samples, no subtraction) + a
+ * sliding sum down every column, O(1) per sample; any other channel per-row running sums kept in double-double,
  * O(pings) per sample.  Without it every window is summed value by value.  Same results to rounding. */
 /* ws for func = nanmedian (optional): EPA_POOL_VALUE_MEDIAN_WS_BYTES bytes, 4-byte aligned.  With it the channels whose
  * pings share one range vector carry their window from ping to ping (a histogram of the window kept up to date, the
