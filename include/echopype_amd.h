@@ -456,8 +456,9 @@ int epa_impulse_mask(const void* up, int C, int P, int S, int num_side_pings, do
  * generic_filter over a (2*num_side_pings+1) x (2*num_side_samples+1) window of the linear Sv,
  * mode="reflect", restricted to range_sample >= first_sample; NaN above) and the mask
  * Sv - pooled > threshold (clean/api.py:166).  func: EPA_POOL_NANMEAN (separable box sums; needs
- * ws_sum f64 [C*P*S] and ws_cnt int32 [C*P*S]) or EPA_POOL_NANMEDIAN (radix selection per output
- * sample, O(window) each -- meant for subsets, as in the reference; workspaces unused).
+ * ws_sum f64 [C*P*S] and ws_cnt int32 [C*P*S]) or EPA_POOL_NANMEDIAN (exact; the window carried from ping to
+ * ping with its histogram when it is at most 256 samples wide and fits LDS, a radix selection per output
+ * sample otherwise; workspaces unused).
  * pooled_out ([C*P*S] of dtype) and mask_out may each be NULL. */
 enum epa_pool_func { EPA_POOL_NANMEAN = 0, EPA_POOL_NANMEDIAN = 1 };
 int epa_pool_sv(const void* sv, int C, int P, int S, int first_sample, int num_side_pings,
@@ -467,7 +468,9 @@ int epa_pool_sv(const void* sv, int C, int P, int S, int first_sample, int num_s
 /* Attenuated-signal mask (clean/utils.py:326-372 echopy_attenuated_signal_mask, per channel):
  * per ping, up / lw = argmin |range - limit| of that ping (first NaN if any, as np.argmin); when
  * p-n >= 0, p+n <= P-1 and Sv[p, up:lw] is not all NaN, the whole ping is masked if
- * 10log10(nanmedian lin Sv[p, up:lw]) - 10log10(nanmedian lin Sv[p-n:p+n, up:lw]) < threshold. */
+ * 10log10(nanmedian lin Sv[p, up:lw]) - 10log10(nanmedian lin Sv[p-n:p+n, up:lw]) < threshold.
+ * S % 4 == 0, S >= 16 and a 4-byte aligned mask_out take the carried-block route (mask_out's rows hold the
+ * per-ping limits and medians between its two kernels), anything else two selections per ping. */
 int epa_attenuated_mask(const void* sv, const void* range, int C, int P, int S, double upper_limit,
                         double lower_limit, int num_side_pings, double threshold, uint8_t* mask_out,
                         int dtype, epa_stream_t stream);
