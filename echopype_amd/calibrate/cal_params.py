@@ -63,6 +63,14 @@ class PulseTableParam(DataArray):
         return self._data is not None
 
     @property
+    def on_device(self):
+        """The device the per-ping pulse lengths live on as a (channel, ping_time) array, else None."""
+        tau = self._tau.data
+        if isinstance(tau, DeviceArray) and self._tau.dims[0] == "channel":
+            return tau.tensor.device
+        return None
+
+    @property
     def shape(self):
         return self._shape
 

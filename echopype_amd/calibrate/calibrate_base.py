@@ -5,9 +5,11 @@ import os
 import weakref
 
 import numpy as np
+import torch
 
 from .. import _lib, ops
 from ..xr_lite import DataArray, DeviceArray, LazyDeviceArray
+from .cal_params import PulseTableParam
 
 logger = logging.getLogger("echopype_amd.calibrate")
 
@@ -104,7 +106,13 @@ class CalibrateBase(abc.ABC):
             for key, val in group.items():
                 if val is None:
                     continue
-                if isinstance(val, DataArray):
+                if isinstance(val, PulseTableParam) and not val.materialized and val.on_device:
+                    # still only the (C, K) table: the (C, P) array is looked up when somebody reads the variable
+                    # (one small kernel less in front of every file's calibration kernel)
+                    lazy = LazyDeviceArray(val.shape, torch.float64, val.on_device,
+                                           (lambda v=val: v.data.tensor))
+                    ds_out[key] = DataArray(lazy, val.dims, attrs=val.attrs, name=key)
+                elif isinstance(val, DataArray):
                     ds_out[key] = DataArray(val.data, val.dims, attrs=val.attrs, name=key)
                 elif isinstance(val, str):
                     ds_out[key] = np.asarray(val)
