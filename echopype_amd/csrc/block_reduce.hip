@@ -672,31 +672,52 @@ __global__ void decode_minmax_kernel(double* p) {
 }
 __global__ void init_minmax_kernel(unsigned long long* p) { p[threadIdx.x] = (threadIdx.x & 1) ? 0ull : ~0ull; }
 
-// {min key, NaN count (u64), -} + the decoded maximum -> {nanmin, nanmax, NaN count}; as_f32: the values the float32
-// echo_range array holds (rounding is monotone)
-__global__ void decode_range_stats_kernel(double* st, const double* rmax, int as_f32) {
-  const unsigned long long k = reinterpret_cast<unsigned long long*>(st)[0];
-  const unsigned long long n = reinterpret_cast<unsigned long long*>(st)[1];
-  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-  double lo = k == ~0ull ? __builtin_nan("") : __longlong_as_double(b), hi = *rmax;
-  if (as_f32) {
-    lo = (double)(float)lo;
-    hi = (double)(float)hi;
+// The by-products of a calibration pass -- the maximum of echo_range (an order-preserving key the kernels raise with
+// atomics) and {min key, NaN count} -- are set up by ONE single-lane launch before the pass and decoded by ONE after
+// it (round 4: three memsets and two kernels before; every launch in front of a 9-ms kernel costs the API route its
+// dispatch gap).  mode 0: the maximum only; 1: statistics -> {nanmin, nanmax, NaN count} (as_f32: the values the
+// float32 echo_range array holds -- rounding is monotone); 2: the kernel that ran leaves none: NaN count -1.
+__global__ void init_range_out_kernel(double* rmax, double* st) {
+  if (rmax) *reinterpret_cast<unsigned long long*>(rmax) = 0ull;  // key 0 = nothing seen
+  if (st) {
+    unsigned long long* u = reinterpret_cast<unsigned long long*>(st);
+    u[0] = ~0ull;  // min key: nothing seen
+    u[1] = 0ull;   // NaN count
+    u[2] = 0ull;
   }
-  st[0] = lo;
-  st[1] = hi;
-  st[2] = (double)n;
 }
-__global__ void no_range_stats_kernel(double* st) {  // the kernel that ran leaves none: NaN count -1
-  st[0] = st[1] = __builtin_nan("");
-  st[2] = -1.0;
+__global__ void decode_range_out_kernel(double* rmax, double* st, int mode, int as_f32) {
+  const unsigned long long km = *reinterpret_cast<unsigned long long*>(rmax);
+  // inverse of the order-preserving key; key 0 = nothing seen -> NaN
+  const unsigned long long bm = (km >> 63) ? (km & 0x7fffffffffffffffull) : ~km;
+  const double mx = km == 0ull ? __builtin_nan("") : __longlong_as_double(bm);
+  *rmax = mx;
+  if (mode == 1) {
+    const unsigned long long k = reinterpret_cast<unsigned long long*>(st)[0];
+    const unsigned long long n = reinterpret_cast<unsigned long long*>(st)[1];
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    double lo = k == ~0ull ? __builtin_nan("") : __longlong_as_double(b), hi = mx;
+    if (as_f32) {
+      lo = (double)(float)lo;
+      hi = (double)(float)hi;
+    }
+    st[0] = lo;
+    st[1] = hi;
+    st[2] = (double)n;
+  } else if (mode == 2) {
+    st[0] = st[1] = __builtin_nan("");
+    st[2] = -1.0;
+  }
 }
 
-__global__ void decode_range_max_kernel(double* p) {
-  const unsigned long long k = *reinterpret_cast<unsigned long long*>(p);
-  // inverse of the order-preserving key; key 0 = nothing seen -> NaN
-  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-  *p = k == 0ull ? __builtin_nan("") : __longlong_as_double(b);
+int init_range_outputs(double* rmax, double* st, hipStream_t stream) {
+  if (!rmax && !st) return EPA_OK;
+  hipLaunchKernelGGL(init_range_out_kernel, dim3(1), dim3(1), 0, stream, rmax, st);
+  return epa::check_launch("init_range_out_kernel");
+}
+int decode_range_outputs(double* rmax, double* st, bool filled, int as_f32, hipStream_t stream) {
+  hipLaunchKernelGGL(decode_range_out_kernel, dim3(1), dim3(1), 0, stream, rmax, st, st ? (filled ? 1 : 2) : 0, as_f32);
+  return epa::check_launch("decode_range_out_kernel");
 }
 }  // namespace
 
@@ -759,22 +780,13 @@ static int fused_entry(const float* raw, const int16_t* raw_i16, const int32_t* 
   a.range_max_out = range_max_out;
   a.range_stats_out = range_stats_out;
   EPA_CHECK_ARG(dtype == EPA_F64 || dtype == EPA_F32, "epa_sv_mvbs_fused: bad dtype %d", dtype);
-  if (range_max_out) EPA_CHECK_HIP(hipMemsetAsync(range_max_out, 0, sizeof(double), (hipStream_t)stream));
-  if (range_stats_out) {  // min key ~0 (nothing seen), NaN count 0
-    EPA_CHECK_HIP(hipMemsetAsync(range_stats_out, 0xff, sizeof(double), (hipStream_t)stream));
-    EPA_CHECK_HIP(hipMemsetAsync(range_stats_out + 1, 0, 2 * sizeof(double), (hipStream_t)stream));
-  }
+  if (int rc0 = init_range_outputs(range_max_out, range_stats_out, (hipStream_t)stream)) return rc0;
   const int rc = dtype == EPA_F64 ? run_mvbs<double, SRC_RAW>(a, (hipStream_t)stream)
                                   : run_mvbs<float, SRC_RAW>(a, (hipStream_t)stream);
   epa::note_range_stats_filled(rc == EPA_OK && range_stats_out && a.range_stats_filled ? 1 : 0);
   if (rc == EPA_OK && range_max_out) {
-    hipLaunchKernelGGL(decode_range_max_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, range_max_out);
-    if (range_stats_out && a.range_stats_filled)
-      hipLaunchKernelGGL(decode_range_stats_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, range_stats_out,
-                         range_max_out, dtype == EPA_F32 ? 1 : 0);
-    else if (range_stats_out)
-      hipLaunchKernelGGL(no_range_stats_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, range_stats_out);
-    return epa::check_launch("decode_range_max_kernel");
+    return decode_range_outputs(range_max_out, range_stats_out, a.range_stats_filled != 0, dtype == EPA_F32 ? 1 : 0,
+                                (hipStream_t)stream);
   }
   return rc;
 }
@@ -994,11 +1006,7 @@ extern "C" int epa_sv_noise_fused(const float* raw, const double* coef, const do
   const double nspread = cal_type == EPA_CAL_SV ? 20.0 : 40.0;
   EPA_CHECK_ARG(dtype == EPA_F64 || dtype == EPA_F32, "epa_sv_noise_fused: bad dtype %d", dtype);
   EPA_CHECK_ARG(!range_stats_out || range_max_out, "epa_sv_noise_fused: range_stats_out needs range_max_out");
-  if (range_max_out) EPA_CHECK_HIP(hipMemsetAsync(range_max_out, 0, sizeof(double), (hipStream_t)stream));
-  if (range_stats_out) {  // min key ~0 (nothing seen), NaN count 0
-    EPA_CHECK_HIP(hipMemsetAsync(range_stats_out, 0xff, sizeof(double), (hipStream_t)stream));
-    EPA_CHECK_HIP(hipMemsetAsync(range_stats_out + 1, 0, 2 * sizeof(double), (hipStream_t)stream));
-  }
+  if (int rc0 = init_range_outputs(range_max_out, range_stats_out, (hipStream_t)stream)) return rc0;
   int filled = 0;
   const int rc = dtype == EPA_F64
       ? run_sv_noise<double>(raw, coef, alpha2, C, P, S, nspread, cal_flags, ping_num, range_sample_num, noise_max,
@@ -1007,13 +1015,8 @@ extern "C" int epa_sv_noise_fused(const float* raw, const double* coef, const do
                             sv_out, range_out, noise_out, range_max_out, range_stats_out, &filled, (hipStream_t)stream);
   epa::note_range_stats_filled(rc == EPA_OK && range_stats_out && filled ? 1 : 0);
   if (rc == EPA_OK && range_max_out) {
-    hipLaunchKernelGGL(decode_range_max_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, range_max_out);
-    if (range_stats_out && filled)  // (the fast kernel tracks the values as stored: no rounding left to do)
-      hipLaunchKernelGGL(decode_range_stats_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, range_stats_out,
-                         range_max_out, 0);
-    else if (range_stats_out)
-      hipLaunchKernelGGL(no_range_stats_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, range_stats_out);
-    return epa::check_launch("decode_range_max_kernel");
+    // (the fast kernel tracks the values as stored: no rounding left to do)
+    return decode_range_outputs(range_max_out, range_stats_out, filled != 0, 0, (hipStream_t)stream);
   }
   return rc;
 }
