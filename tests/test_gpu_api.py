@@ -726,6 +726,36 @@ def test_to_device_keeps_a_host_view_of_the_parameters(ep):
     assert not host_readable(big)
 
 
+def test_pulse_table_parameters_of_the_output_are_looked_up_when_read(ep):
+    """gain_correction / sa_correction of a device-resident file: the calibration kernel takes the Vendor_specific
+    (C, K) tables themselves; the (channel, ping_time) variables of the output dataset run their look-up kernel when
+    somebody reads them -- and then hold what the reference's get_vend_cal_params_power returns (cal_params.py:261-324,
+    here: the oracle's restatement), pulse lengths that change from ping to ping included."""
+    from oracle import calibrate as ocal
+
+    from echopype_amd import _lib
+
+    d = ep.synth.ek60_numpy(3, 50, 64, vary_tau=True)
+    ed = ep.echodata.from_ek60_arrays(d).to_device()
+    with _lib.launch_trace() as tr:
+        ds = ep.calibrate.compute_Sv(ed)
+        ds["Sv"].values
+    assert "pulse_table_lookup_kernel" not in tr.kernels and "power_coef_ek_kernel" in tr.kernels
+    with _lib.launch_trace() as tr:
+        g, sa = ds["gain_correction"], ds["sa_correction"]
+        assert g.dims == ("channel", "ping_time") and g.shape == (3, 50)
+        gv, sav = g.values, sa.values
+    assert tr.kernels.count("pulse_table_lookup_kernel") == 2
+    np.testing.assert_array_equal(gv, ocal.vend_cal_params_power(d["transmit_duration_nominal"], d["pulse_length"],
+                                                                 d["gain_correction"]))
+    np.testing.assert_array_equal(sav, ocal.vend_cal_params_power(d["transmit_duration_nominal"], d["pulse_length"],
+                                                                  d["sa_correction"]))
+    # ... and the host route (no device-resident parameters) holds the same numbers
+    ds_h = ep.calibrate.compute_Sv(ep.echodata.from_ek60_arrays(d))
+    np.testing.assert_array_equal(ds_h["gain_correction"].values, gv)
+    np.testing.assert_array_equal(ds_h["Sv"].values, ds["Sv"].values)
+
+
 # ---- echo_range left lazy by compute_Sv on power samples -------------------------------------------------------------
 def _lazy_case(ep, S=1000, dtype="float64", P=240):
     d = ep.synth.ek60_numpy(3, P, S, ss_every=7)
