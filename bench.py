@@ -441,6 +441,22 @@ def run_api(ctx, cpu):
             return ds, ep.commongrid.compute_MVBS(corrected, range_bin="1m", ping_time_bin="20s")
 
         chain_ms = med(three_calls)
+
+        def chain_pipelined(n_files=6):  # file after file, each MVBS read after the next file's launch
+            ctx.torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            prev = None
+            for _ in range(n_files):
+                cur = three_calls()
+                if prev is not None:
+                    prev[1]["Sv"].shape
+                prev = cur
+            prev[1]["Sv"].shape
+            ctx.torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n_files * 1e3
+
+        chain_pipelined()
+        chain_pipe_ms = chain_pipelined()
         os.environ["EPA_DEFER_SV"] = "0"
         try:
             eager_ms = med(two_calls)
@@ -457,6 +473,7 @@ def run_api(ctx, cpu):
                          "result read after the next pass's launch",
                 config={"compute_Sv_ms": sv_ms, "compute_MVBS_ms": mv_ms, "one_call_compute_Sv_MVBS_ms": one_call,
                         "two_calls_not_deferred_ms": eager_ms, "chain_three_calls_ms": chain_ms,
+                        "chain_three_calls_file_after_file_ms": chain_pipe_ms,
                         "chain_three_calls_not_deferred_ms": chain_eager_ms, "sharding": "one GPU", "collective": "none"},
                 roofline=roofline("fused_sv_mvbs_kernel inside compute_MVBS (+ host parameter selection)", region_ms, n * bps,
                                   bps, traffic_key=f"api:{dtype}", note="region = both API calls incl. host work"))

@@ -8,6 +8,7 @@ Also the Ryan et al. (2015) noise masks (api.py:30-359: mask_transient_noise, ma
 mask_attenuated_signal), each a handful of launches from csrc/noise_masks.hip.
 """
 import logging
+import os
 
 import numpy as np
 import torch
@@ -16,7 +17,7 @@ from .. import ops
 from ..commongrid.api import _coef_rows, _dev, _full, _range_stats
 from ..commongrid.utils import _parse_x_bin
 from ..utils.prov import echopype_prov_attrs, insert_processing_level
-from ..xr_lite import DataArray, DeviceArray, from_xarray, xarray_io
+from ..xr_lite import DataArray, DeviceArray, LazyDeviceArray, from_xarray, xarray_io
 from .utils import add_remove_background_noise_attrs, extract_dB
 
 
@@ -51,23 +52,88 @@ def _alpha2(ds_Sv, order, C, P):
     return ops.to_device(np.ascontiguousarray(a2, dtype=np.float64))
 
 
+class DenoiseSource:
+    """What the ``Sv_noise`` / ``Sv_corrected`` that ``remove_background_noise`` left deferred are made from
+    (``LazyDeviceArray.source``).  Pass 1 has run (the Sv array, the noise estimate); pass 2 -- raw -> Sv_noise,
+    Sv_corrected and their minima / maxima (the ``actual_range`` attributes) -- runs when somebody reads one of the
+    two arrays or attributes, or, the usual sequence, INSIDE ``compute_MVBS``'s pass when the corrected Sv is what is
+    binned (``commongrid.api._mvbs_of_deferred_clean``: one sweep writes both arrays and the bins)."""
+
+    def __init__(self, power, a2, noise, ping_num, snr, sv_t):
+        self.power, self.a2, self.noise, self.ping_num, self.snr, self.sv_t = power, a2, noise, ping_num, snr, sv_t
+        self.raw_version = power.raw._version
+        self.minmax = None  # HostFuture / list of [min, max of Sv_noise, min, max of Sv_corrected] once pass 2 has run
+        shape, dev = tuple(power.raw.shape), power.raw.device
+        self.lazy = {k: LazyDeviceArray(shape, power.dtype, dev, (lambda k=k: self._make(k)), source=self)
+                     for k in ("noise", "corrected")}
+
+    def intact(self):
+        """The raw samples have not been written to since pass 1 looked at them."""
+        return self.power.raw._version == self.raw_version
+
+    def install(self, res):
+        """The by-products of a pass 2 somebody ran (``ops.sv_denoise_mvbs`` with minmax_async)."""
+        for k, name in (("noise", "Sv_noise"), ("corrected", "Sv_corrected")):
+            if not self.lazy[k].materialized:
+                self.lazy[k].fulfil(res[name])
+        self.minmax = res["minmax"]
+        self.sv_t = None
+
+    def run_plain(self):
+        """Pass 2 alone: the chain kernel on plain 20-ping groups with ONE range bin (its bins are not wanted)."""
+        from .. import _lib
+
+        if not self.intact():
+            raise RuntimeError("the raw samples were modified between remove_background_noise and the first read of "
+                               "its deferred outputs (EPA_DEFER_CLEAN=0 writes them inside the call)")
+        p = self.power
+        P = p.raw.shape[1]
+        group = 20
+        bin_start = torch.arange(0, P + group, group, dtype=torch.int32, device=p.raw.device).clamp_(max=P)
+        try:
+            res = ops.sv_denoise_mvbs(p.raw, p.coef, self.a2, self.noise, self.ping_num, float(self.snr), bin_start,
+                                      bin_start.numel() - 1, 1e30, 1, flags=p.flags, dtype=p.dtype, want_noise=True,
+                                      want_corrected=True, want_minmax=True, minmax_async=True)
+        except _lib.EpaError:  # a geometry the chain kernel does not serve: the array kernel on the Sv of pass 1
+            sn, sc, mm = ops.noise_apply(self.sv_t, self.a2, self.noise, self.ping_num, float(self.snr), want_minmax=True,
+                                         coef=p.coef, mask_raw=p.raw, ping_phase=0)
+            res = dict(Sv_noise=sn, Sv_corrected=sc, minmax=mm)
+        self.install(res)
+
+    def _make(self, which):
+        if self.minmax is None:
+            self.run_plain()
+        return self.lazy[which]._tensor
+
+    def actual_range(self, which):
+        if self.minmax is None:
+            self.run_plain()
+        mm = self.minmax.tolist() if hasattr(self.minmax, "tolist") else list(self.minmax)
+        return mm[0:2] if which == "noise" else mm[2:4]
+
+
+def defer_clean_enabled():
+    """EPA_DEFER_CLEAN=0: remove_background_noise writes Sv_noise / Sv_corrected before it returns."""
+    return os.environ.get("EPA_DEFER_CLEAN", "1") != "0"
+
+
 def _denoise_deferred_sv(ds_Sv, ping_num, range_sample_num, nmax, snr):
     """``remove_background_noise`` as the FIRST reader of the Sv that compute_Sv deferred (power samples): two passes over
     the raw samples instead of K1 + two sweeps of the Sv array --
         pass 1 (epa_sv_noise_fused)    raw -> the Sv array + the noise estimate from the values in registers + the
                                        echo_range statistics                                   4 + 8 B/sample
         pass 2 (epa_sv_denoise_mvbs)   raw -> Sv_noise, Sv_corrected, their actual_range      4 + 16 B/sample
-    against 12 (K1) + 8 (estimate) + 24 (apply).  Pass 2 is the chain kernel of compute_Sv_clean_MVBS run on plain
-    20-ping groups with ONE range bin (its bins are not wanted here).  Returns (Sv_noise, Sv_corrected, minmax) or None:
-    the plain route then runs on whatever this one has written."""
+    against 12 (K1) + 8 (estimate) + 24 (apply).  Pass 1 runs here; pass 2 is left to a ``DenoiseSource`` (see there).
+    Nothing waits for the GPU.  Returns the DenoiseSource, or None: the plain route then runs on whatever this one
+    has written."""
     from .. import _lib
-    from ..xr_lite import LazyDeviceArray
 
     sv_da, rng_da = ds_Sv["Sv"], ds_Sv["echo_range"] if "echo_range" in ds_Sv else None
     d = sv_da.data
     src = d.source if isinstance(d, LazyDeviceArray) and not d.materialized else None
     dims = ("channel", "ping_time", "range_sample")
-    if src is None or rng_da is None or src.cal_type != "Sv" or rng_da.data is not src.echo_range \
+    if src is None or isinstance(src, DenoiseSource) or rng_da is None or src.cal_type != "Sv" \
+            or rng_da.data is not src.echo_range \
             or tuple(sv_da.dims) != dims or tuple(rng_da.dims) != dims \
             or src.echo_range.coef_rows() is not src.coef or not src.intact():
         return None
@@ -80,20 +146,16 @@ def _denoise_deferred_sv(ds_Sv, ping_num, range_sample_num, nmax, snr):
     except _lib.EpaError:  # e.g. more range blocks than the LDS holds
         return None
     # served by the generic kernel?  It leaves no range statistics (K1 does, on the plain route).  Known on the host
-    # (epa_last_range_stats_filled): pass 2 is launched without waiting for pass 1
+    # (epa_last_range_stats_filled): nothing waits for pass 1
     if not _lib.lib.epa_last_range_stats_filled():
         return None
     d.fulfil(sv_t)
-    src.echo_range.set_stats(rstats)
-    group = 20
-    bin_start = torch.arange(0, P + group, group, dtype=torch.int32, device=sv_t.device).clamp_(max=P)
-    try:
-        res = ops.sv_denoise_mvbs(src.raw, src.coef, a2, noise, ping_num, float(snr), bin_start, bin_start.numel() - 1,
-                                  1e30, 1, flags=src.flags, dtype=src.dtype, want_noise=True, want_corrected=True,
-                                  want_minmax=True)
-    except _lib.EpaError:
-        return None
-    return res["Sv_noise"], res["Sv_corrected"], res["minmax"]
+    # (the three numbers start their way to the host now, behind pass 1 only: compute_MVBS sizes its grid from them)
+    src.echo_range.set_stats(ops.fetch_async(rstats))
+    dsrc = DenoiseSource(src, a2, noise, ping_num, snr, sv_t)
+    if not defer_clean_enabled():
+        dsrc.run_plain()
+    return dsrc
 
 
 def _rng_kw(rg_t, apply=False):
@@ -143,14 +205,20 @@ def remove_background_noise(ds_Sv, ping_num, range_sample_num, background_noise_
         nmax = extract_dB(background_noise_max) if background_noise_max is not None else None
         done = _denoise_deferred_sv(ds_Sv, ping_num, range_sample_num, nmax, SNR_threshold)
     if done is not None:
-        order, (sn, sc, mm) = tuple(ds_Sv["Sv"].dims), done
+        order = tuple(ds_Sv["Sv"].dims)
+        sn, sc = (done.lazy[k] if not done.lazy[k].materialized else done.lazy[k].tensor for k in ("noise", "corrected"))
+        mm = None
     else:
         order, sv_t, rg_t, a2, noise, nmax = _estimate(ds_Sv, ping_num, range_sample_num, background_noise_max, _shard)
         # actual_range of both outputs is a by-product of the kernel (no extra sweeps)
         sn, sc, mm = ops.noise_apply(sv_t, a2, noise, ping_num, float(SNR_threshold), want_minmax=True,
                                      **_rng_kw(rg_t, apply=True), ping_phase=0 if _shard is None else _shard[0] % ping_num)
-    for name, t, kind, rng_mm in (("Sv_noise", sn, "noise", mm[0:2]), ("Sv_corrected", sc, "corrected", mm[2:4])):
-        da = DataArray(DeviceArray(t), order)
+    for name, t, kind in (("Sv_noise", sn, "noise"), ("Sv_corrected", sc, "corrected")):
+        da = DataArray(t if isinstance(t, DeviceArray) else DeviceArray(t), order)
+        if done is not None:  # minimum / maximum: by-products of pass 2, read when somebody reads the attribute
+            rng_mm = (lambda k=kind: done.actual_range(k))
+        else:
+            rng_mm = mm[0:2] if kind == "noise" else mm[2:4]
         ds_Sv[name] = add_remove_background_noise_attrs(da, kind, ping_num, range_sample_num, SNR_threshold,
                                                         nmax, rng_mm)
     prov = echopype_prov_attrs(process_type="processing")

@@ -85,6 +85,8 @@ def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="
     if _shard is None and skipna and closed == "left":
         # Sv still deferred by compute_Sv: written by THIS pass over the raw samples, next to the bins
         done = _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max)
+        if done is None:  # ... or the Sv_corrected remove_background_noise deferred: its pass 2 bins as well
+            done = _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max)
         if done is not None:
             return done
     return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, skipna, fill_value, closed, range_var_max, _shard)
@@ -168,9 +170,10 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
     d = sv_da.data
     src = d.source if isinstance(d, LazyDeviceArray) and not d.materialized else None
     dims = ("channel", "ping_time", "range_sample")
-    if src is None or src.cal_type != "Sv" or rng_da.data is not src.echo_range or tuple(sv_da.dims) != dims \
+    if src is None or getattr(src, "cal_type", None) != "Sv" or rng_da.data is not src.echo_range \
+            or tuple(sv_da.dims) != dims \
             or tuple(rng_da.dims) != dims or src.echo_range.coef_rows() is not src.coef or not src.intact():
-        return None
+        return None  # (also: an Sv deferred by something else than compute_Sv, e.g. remove_background_noise)
     ping_time = np.asarray(ds_Sv["ping_time"].values).astype("datetime64[ns]", copy=False)
     ns = ping_time.view(np.int64)
     # unsorted, or NaT (INT64_MIN: the smallest value, so in a sorted array it could only be the first)
@@ -212,6 +215,73 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
         r_edges = np.arange(0, rmax + range_bin_m, range_bin_m) if np.isfinite(rmax) else np.zeros(1)
         n_r = len(r_edges) - 1
         if n_r < 1:  # no valid range / an empty grid: the plain route raises or returns what the reference would
+            return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, True, fill_value, "left", range_var_max, None)
+        if n_nan_range > 0:
+            logging.warning(f"The ```{range_var}``` coordinate array contain NaNs. {_AGG_MSG}")
+        mvbs_t = res["MVBS"][..., :n_r].contiguous() if n_r != n_cap else res["MVBS"]
+        return _assemble_mvbs(ds_Sv, mvbs_t, "channel", ping_time, e0, dt, n_t, r_edges, range_var, range_bin_m,
+                              ping_time_bin, "left")
+
+    return DeferredDataset(build) if defer_mvbs_enabled() else build()
+
+
+def _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max):
+    """The chain as the reference's user writes it -- ``compute_Sv``, ``remove_background_noise``, then
+    ``compute_MVBS`` of the dataset with ``Sv := Sv_corrected`` -- arrives here with an Sv that
+    ``remove_background_noise`` left deferred (``clean.api.DenoiseSource``: pass 1 has run).  Pass 2 runs NOW, on the
+    real grid: one sweep of the raw samples writes Sv_noise, Sv_corrected, their minima / maxima AND the bins
+    (``epa_sv_denoise_mvbs``) -- 20 B/sample instead of 20 + 8 for the pass and a separate binning of the array it
+    wrote.  Nothing waits for the GPU (conservative grid, ``DeferredDataset``: see ``_mvbs_of_deferred_sv``).  None:
+    the plain route runs (it reads the array, which runs pass 2 by itself)."""
+    from ..clean.api import DenoiseSource
+
+    sv_da, rng_da = ds_Sv["Sv"], ds_Sv[range_var]
+    d = sv_da.data
+    src = d.source if isinstance(d, LazyDeviceArray) and not d.materialized else None
+    dims = ("channel", "ping_time", "range_sample")
+    if not isinstance(src, DenoiseSource) or d is not src.lazy["corrected"] or src.minmax is not None or not src.intact():
+        return None
+    p = src.power
+    if rng_da.data is not p.echo_range or tuple(sv_da.dims) != dims or tuple(rng_da.dims) != dims \
+            or p.echo_range.coef_rows() is not p.coef:
+        return None
+    ping_time = np.asarray(ds_Sv["ping_time"].values).astype("datetime64[ns]", copy=False)
+    ns = ping_time.view(np.int64)
+    if ns.size == 0 or np.any(ns[1:] < ns[:-1]) or ns[0] == np.iinfo(np.int64).min:  # unsorted pings, NaT
+        return None
+    e0, dt, n_t = resample_edges(ping_time, ping_time_bin, sorted_valid=True)
+    C, P, S = d.shape
+    if range_var_max is not None:
+        r_cap = _parse_x_bin(range_var_max) + 1e-8
+    elif getattr(p, "reach_bound", None) is not None:
+        r_cap = p.reach_bound
+    else:
+        coef = p.coef
+        reach = torch.nan_to_num((S - 1) * coef[..., _lib.CF_RA] * coef[..., _lib.CF_RB] + coef[..., _lib.CF_R0], nan=float("-inf"))
+        r_cap = float(reach.max().item())
+    n_cap = len(np.arange(0, r_cap + range_bin_m, range_bin_m)) - 1 if np.isfinite(r_cap) else 0
+    if n_cap < 1:
+        return None
+    bin_start = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t)
+    try:
+        res = ops.sv_denoise_mvbs(p.raw, p.coef, src.a2, src.noise, src.ping_num, float(src.snr), bin_start, n_t,
+                                  range_bin_m, n_cap, flags=p.flags, dtype=p.dtype, skipna=True, closed="left",
+                                  fill_value=fill_value, want_noise=True, want_corrected=True, want_minmax=True,
+                                  minmax_async=True)
+    except _lib.EpaError:  # e.g. a range grid too fine for the LDS accumulators
+        return None
+    src.install(res)
+    rng = p.echo_range
+
+    def build():
+        stats = rng.cached_stats()  # left by pass 1, on their way to the host since then
+        if stats is None:
+            return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, True, fill_value, "left", range_var_max, None)
+        lo, hi, n_nan_range = stats
+        rmax = hi if range_var_max is None else r_cap
+        r_edges = np.arange(0, rmax + range_bin_m, range_bin_m) if np.isfinite(rmax) else np.zeros(1)
+        n_r = len(r_edges) - 1
+        if n_r < 1:
             return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, True, fill_value, "left", range_var_max, None)
         if n_nan_range > 0:
             logging.warning(f"The ```{range_var}``` coordinate array contain NaNs. {_AGG_MSG}")

@@ -823,9 +823,11 @@ def denoise_mvbs(sv, alpha2, noise, ping_num, snr_threshold, bin_start, n_tbins,
 def sv_denoise_mvbs(raw, coef, alpha2, noise, ping_num, snr_threshold, bin_start, n_tbins, range_bin, n_rbins,
                     *, cal_type="Sv", flags=_lib.FLAG_GUARD_POS | _lib.FLAG_MASK_RANGE, dtype=torch.float64,
                     skipna=True, closed="left", fill_value=float("nan"), ping_perm=None, want_noise=False,
-                    want_corrected=True, want_range=False, want_partials=False, want_minmax=False):
+                    want_corrected=True, want_range=False, want_partials=False, want_minmax=False,
+                    minmax_async=False):
     """K1+K7+K5 from the raw power -> dict(MVBS of the corrected Sv, Sv_noise, Sv_corrected, echo_range, sum,
-    cnt, minmax = [min, max of Sv_noise, min, max of Sv_corrected] (host floats) if asked)."""
+    cnt, minmax = [min, max of Sv_noise, min, max of Sv_corrected] (host floats) if asked; ``minmax_async``: a
+    ``HostFuture`` of the four numbers instead -- the call then does not wait for its kernel)."""
     C, P, S = raw.shape
     dev = raw.device
     mk = lambda want: torch.empty((C, P, S), dtype=dtype, device=dev) if want else None  # noqa: E731
@@ -841,7 +843,7 @@ def sv_denoise_mvbs(raw, coef, alpha2, noise, ping_num, snr_threshold, bin_start
          _p(bin_start), _p(ping_perm), int(n_tbins), float(range_bin), int(n_rbins), _bin_flags(skipna, closed),
          float(fill_value), _p(sn), _p(sc), _p(rng), _p(out), _p(ssum), _p(cnt), _p(mm), _DT[dtype], _stream())
     return dict(MVBS=out, Sv_noise=sn, Sv_corrected=sc, echo_range=rng, sum=ssum, cnt=cnt,
-                minmax=mm.cpu().tolist() if want_minmax else None)
+                minmax=(fetch_async(mm) if minmax_async else mm.cpu().tolist()) if want_minmax else None)
 
 
 # ---- cross-shard edge exchange (pack -> all-reduce -> gather) ------------------------------------------------

@@ -201,6 +201,142 @@ def host_readable(a):
     return a._host is not None and a._host[1] == a.tensor._version
 
 
+class _Once:
+    """A thunk evaluated once (shared by the copies of the attrs that carry it)."""
+
+    __slots__ = ("fn", "value", "done")
+
+    def __init__(self, fn):
+        self.fn, self.value, self.done = fn, None, False
+
+    def __call__(self):
+        if not self.done:
+            self.value, self.done, self.fn = self.fn(), True, None
+        return self.value
+
+
+_PENDING = type("Pending", (), {"__repr__": lambda self: "<value on its way from the GPU>"})()
+
+
+class LazyAttrs(dict):
+    """Attributes some of whose VALUES are numbers a kernel is still producing (``actual_range`` of
+    ``remove_background_noise``'s outputs: their minimum / maximum): ``set_lazy(key, thunk)`` reserves the key in
+    place, the thunk runs the first time anybody READS the value -- ``attrs[key]``, ``.get``, ``.items()``,
+    ``.values()``, ``dict(attrs)``, ``{**attrs}``, ``==``, ``repr``, ``json.dumps`` -- and the result then sits in
+    the dict like any other value.  Keys, ``len`` and ``in`` never wait.  ``copy()`` (what DataArray construction
+    uses) keeps the thunks, shared: the value is computed once.  Everything else is a plain dict."""
+
+    __slots__ = ("_pending",)
+
+    def __init__(self, *a, **kw):
+        self._pending = {}
+        super().__init__()
+        self.update(*a, **kw)
+
+    def set_lazy(self, key, thunk):
+        dict.__setitem__(self, key, _PENDING)
+        self._pending[key] = thunk if isinstance(thunk, _Once) else _Once(thunk)
+
+    def has_pending(self, key=None):
+        return bool(self._pending) if key is None else key in self._pending
+
+    def _settle(self, key=None):
+        for k in ([key] if key is not None else list(self._pending)):
+            th = self._pending.pop(k, None)
+            if th is not None:
+                dict.__setitem__(self, k, th())
+
+    # -- reads of values settle them
+    def __getitem__(self, key):
+        self._settle(key)
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        self._settle(key)
+        return dict.get(self, key, default)
+
+    def pop(self, key, *default):
+        self._settle(key)
+        return dict.pop(self, key, *default)
+
+    def popitem(self):
+        self._settle()
+        return dict.popitem(self)
+
+    def setdefault(self, key, default=None):
+        self._settle(key)
+        return dict.setdefault(self, key, default)
+
+    def items(self):
+        self._settle()
+        return dict.items(self)
+
+    def values(self):
+        self._settle()
+        return dict.values(self)
+
+    def __iter__(self):  # (overridden on purpose: dict(attrs) / {**attrs} then go through keys() + __getitem__)
+        return dict.__iter__(self)
+
+    def __eq__(self, other):
+        self._settle()
+        if isinstance(other, LazyAttrs):
+            other._settle()
+        return dict.__eq__(self, other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        self._settle()
+        return dict.__repr__(self)
+
+    def __reduce__(self):
+        self._settle()
+        return (dict, (dict(dict.items(self)),))
+
+    # -- writes drop what they replace
+    def __setitem__(self, key, value):
+        self._pending.pop(key, None)
+        dict.__setitem__(self, key, value)
+
+    def __delitem__(self, key):
+        self._pending.pop(key, None)
+        dict.__delitem__(self, key)
+
+    def update(self, *a, **kw):
+        for k, v in dict(*a, **kw).items():
+            self[k] = v
+
+    def clear(self):
+        self._pending.clear()
+        dict.clear(self)
+
+    def copy(self):
+        out = LazyAttrs()
+        for k in dict.__iter__(self):
+            if k in self._pending:
+                out.set_lazy(k, self._pending[k])
+            else:
+                dict.__setitem__(out, k, dict.__getitem__(self, k))
+        return out
+
+    __copy__ = copy
+
+    def __deepcopy__(self, memo):
+        import copy as _copy
+
+        self._settle()
+        return _copy.deepcopy(dict(dict.items(self)), memo)
+
+
+def _copy_attrs(attrs):
+    """A new attrs dict; numbers still on their way from the GPU stay on their way."""
+    return attrs.copy() if isinstance(attrs, LazyAttrs) else dict(attrs or {})
+
+
 class DataArray:
     def __init__(self, data, dims=None, coords=None, attrs=None, name=None):
         if isinstance(data, DataArray):
@@ -222,7 +358,7 @@ class DataArray:
         self.coords = OrderedDict()
         for k, v in (coords or {}).items():
             self.coords[k] = v if isinstance(v, np.ndarray) else np.asarray(getattr(v, "values", v))
-        self.attrs = dict(attrs or {})
+        self.attrs = _copy_attrs(attrs)
         self.name = name
 
     # -- array protocol ---------------------------------------------------------------------
@@ -268,10 +404,10 @@ class DataArray:
 
     def copy(self):
         d = self.data if isinstance(self.data, DeviceArray) else self.data.copy()
-        return DataArray(d, self.dims, dict(self.coords), dict(self.attrs), self.name)
+        return DataArray(d, self.dims, dict(self.coords), self.attrs, self.name)
 
     def assign_attrs(self, attrs=None, **kw):
-        out = DataArray(self.data, self.dims, dict(self.coords), dict(self.attrs), self.name)
+        out = DataArray(self.data, self.dims, dict(self.coords), self.attrs, self.name)
         out.attrs.update(attrs or {})
         out.attrs.update(kw)
         return out
@@ -288,7 +424,7 @@ class DataArray:
             if np.isscalar(idx) or isinstance(idx, (int, np.integer)):
                 dims.pop(ax)
         coords = {k: v for k, v in coords.items() if k in dims}
-        return DataArray(a, dims, coords, dict(self.attrs), self.name)
+        return DataArray(a, dims, coords, self.attrs, self.name)
 
     def isnull(self):
         return DataArray(np.isnan(self.values), self.dims, dict(self.coords))

@@ -169,3 +169,94 @@ def test_deferred_error_surfaces_at_first_use(env):
             mv["Sv"]
     finally:
         logging.disable(logging.NOTSET)
+
+
+# ---- the chain compute_Sv -> remove_background_noise -> compute_MVBS as three reference calls -------------------------
+def _three_calls(ep, ed, **mv_kw):
+    ds = ep.calibrate.compute_Sv(ed)
+    ep.clean.remove_background_noise(ds, ping_num=20, range_sample_num=50)
+    corrected = ds.copy()
+    corrected["Sv"] = ds["Sv_corrected"]
+    return ds, ep.commongrid.compute_MVBS(corrected, **mv_kw)
+
+
+def test_three_calls_of_the_chain_wait_for_nothing_and_run_two_passes(env):
+    """compute_Sv leaves Sv deferred; remove_background_noise runs pass 1 (Sv + the noise estimate) and leaves
+    Sv_noise / Sv_corrected deferred (their actual_range attributes too: by-products of the kernel that will write
+    them); compute_MVBS of the dataset with Sv := Sv_corrected runs pass 2 on its grid: one sweep writes both arrays
+    AND the bins.  No host synchronisation anywhere; two kernels over the samples, no separate binning of an array."""
+    torch, ep = env
+    from echopype_amd import _lib
+    from echopype_amd.xr_lite import DeferredDataset, LazyAttrs, LazyDeviceArray
+
+    _, ed = _resident_case(ep)
+    kw = dict(range_bin="1m", ping_time_bin="20s")
+    logging.disable(logging.WARNING)
+    try:
+        for _ in range(2):
+            _three_calls(ep, ed, **kw)[1]["Sv"].shape
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            with _lib.launch_trace() as tr:
+                ds, mv = _three_calls(ep, ed, **kw)
+                ds2, mv2 = _three_calls(ep, ed, **kw)  # the next file, before anything of the first is read
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        big = [k for k in tr.kernels if k.startswith(("sv_noise", "sv_denoise", "mvbs_of", "block_reduce", "sv_power",
+                                                       "fused_sv", "noise_"))]
+        # (pass 2 + bins: one of the chain kernels at full size, the generic reduction at this one -- ONE launch either way)
+        assert len(big) == 4 and big[0].startswith("sv_noise") and big[2].startswith("sv_noise"), tr.kernels
+        assert all(k.startswith(("sv_denoise_mvbs", "block_reduce")) for k in (big[1], big[3])), tr.kernels
+        assert isinstance(mv, DeferredDataset) and not mv.resolved
+        for name in ("Sv_noise", "Sv_corrected"):
+            v = ds.data_vars[name]
+            assert isinstance(v.data, LazyDeviceArray) and v.data.materialized          # written by compute_MVBS's pass
+            assert isinstance(v.attrs, LazyAttrs) and v.attrs.has_pending("actual_range")
+        lo, hi = ds["Sv_corrected"].attrs["actual_range"]
+        sc = ds["Sv_corrected"].values
+        assert lo == round(float(np.nanmin(sc)), 2) and hi == round(float(np.nanmax(sc)), 2)
+        assert list(ds["Sv_noise"].attrs)[:4] == ["long_name", "units", "actual_range", "noise_ping_num"]
+        assert mv["Sv"].shape == mv2["Sv"].shape
+    finally:
+        logging.disable(logging.NOTSET)
+
+
+@pytest.mark.parametrize("read_first", [False, True])
+def test_three_calls_deferred_equal_eager(env, monkeypatch, read_first):
+    """Same datasets as with EPA_DEFER_SV=0 / EPA_DEFER_CLEAN=0 (every call writes its arrays before it returns and
+    the binning reads the corrected array) -- also when somebody reads Sv_corrected between the calls (pass 2 then runs
+    alone and compute_MVBS bins the array)."""
+    torch, ep = env
+    _, ed = _resident_case(ep, seed=17)
+    kw = dict(range_bin="2m", ping_time_bin="10s")
+    logging.disable(logging.WARNING)
+    try:
+        ds = ep.calibrate.compute_Sv(ed)
+        ep.clean.remove_background_noise(ds, ping_num=20, range_sample_num=50, background_noise_max="-125.0dB")
+        if read_first:
+            first = ds["Sv_corrected"].values.copy()
+        corrected = ds.copy()
+        corrected["Sv"] = ds["Sv_corrected"]
+        mv = ep.commongrid.compute_MVBS(corrected, **kw)
+        monkeypatch.setenv("EPA_DEFER_SV", "0")
+        monkeypatch.setenv("EPA_DEFER_CLEAN", "0")
+        ds_e = ep.calibrate.compute_Sv(ed)
+        ep.clean.remove_background_noise(ds_e, ping_num=20, range_sample_num=50, background_noise_max="-125.0dB")
+        corrected_e = ds_e.copy()
+        corrected_e["Sv"] = ds_e["Sv_corrected"]
+        mv_e = ep.commongrid.compute_MVBS(corrected_e, **kw)
+    finally:
+        logging.disable(logging.NOTSET)
+    for name in ("Sv", "Sv_noise", "Sv_corrected"):
+        # (the passes over the raw samples and the array kernels contract their multiplications differently: 1e-16)
+        np.testing.assert_array_equal(np.isnan(ds[name].values), np.isnan(ds_e[name].values))
+        np.testing.assert_allclose(ds[name].values, ds_e[name].values, rtol=1e-13, atol=0, equal_nan=True)
+        assert dict(ds[name].attrs) == dict(ds_e[name].attrs), name
+    if read_first:
+        np.testing.assert_array_equal(first, ds["Sv_corrected"].values)
+    for k in ("echo_range", "ping_time", "channel"):
+        np.testing.assert_array_equal(mv[k].values, mv_e[k].values)
+    np.testing.assert_array_equal(np.isnan(mv["Sv"].values), np.isnan(mv_e["Sv"].values))
+    np.testing.assert_allclose(mv["Sv"].values, mv_e["Sv"].values, rtol=1e-12, atol=1e-12, equal_nan=True)
+    assert dict(mv["Sv"].attrs) == dict(mv_e["Sv"].attrs) and set(ds.attrs) == set(ds_e.attrs)

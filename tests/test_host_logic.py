@@ -711,3 +711,47 @@ def test_deferred_dataset_assembles_once_on_first_use():
         bd.sizes
     with pytest.raises(RuntimeError, match="failed earlier"):
         bd["v"]
+
+
+def test_lazy_attrs_settle_on_first_read_of_a_value_only():
+    """xr_lite.LazyAttrs (the ``actual_range`` of remove_background_noise's deferred outputs): keys, len and ``in``
+    never run the thunk; any read of the value does, once, whatever the route (``[]``, get, items, dict(), ``**``,
+    ``==``, json, pickle, copies); DataArray / Dataset construction keeps the thunk; a write replaces it."""
+    import copy
+    import json
+    import pickle
+
+    from echopype_amd.xr_lite import DataArray, Dataset, LazyAttrs
+
+    calls = []
+
+    def make():
+        a = LazyAttrs({"long_name": "x", "units": "dB"})
+        a.set_lazy("actual_range", lambda: (calls.append(1), [1.0, 2.0])[1])
+        a["n"] = 3
+        return a
+
+    a = make()
+    assert list(a) == ["long_name", "units", "actual_range", "n"] and len(a) == 4 and "actual_range" in a
+    assert list(a.keys()) == list(a) and a.has_pending("actual_range") and not calls
+    ds = Dataset(coords={"x": np.arange(3)})
+    ds["v"] = DataArray(np.zeros(3), ("x",), attrs=a)
+    v, cp = ds["v"], ds.copy()["v"].copy()
+    assert isinstance(v.attrs, LazyAttrs) and v.attrs.has_pending() and cp.attrs.has_pending() and not calls
+    assert cp.attrs["actual_range"] == [1.0, 2.0] and calls == [1]
+    assert a["actual_range"] == [1.0, 2.0] and v.attrs.get("actual_range") == [1.0, 2.0] and calls == [1]  # shared, once
+    assert dict(make()) == {"long_name": "x", "units": "dB", "actual_range": [1.0, 2.0], "n": 3}
+    assert {**make()}["actual_range"] == [1.0, 2.0] and make() == dict(a) and dict(a) == make()
+    assert json.loads(json.dumps(make()))["actual_range"] == [1.0, 2.0]
+    assert pickle.loads(pickle.dumps(make())) == dict(a) and type(copy.deepcopy(make())) is dict
+    assert list(make().items())[2] == ("actual_range", [1.0, 2.0]) and [1.0, 2.0] in make().values()
+    assert "1.0, 2.0" in repr(make()) and make().pop("actual_range") == [1.0, 2.0]
+    n = len(calls)
+    w = make()
+    w["actual_range"] = [0, 0]
+    u = make()
+    u.update(actual_range=5)
+    d = make()
+    del d["actual_range"]
+    assert w["actual_range"] == [0, 0] and u["actual_range"] == 5 and "actual_range" not in d and len(calls) == n
+    assert not w.has_pending() and not u.has_pending() and not d.has_pending()
