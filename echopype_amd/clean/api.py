@@ -211,12 +211,16 @@ def remove_background_noise(ds_Sv, ping_num, range_sample_num, background_noise_
     else:
         order, sv_t, rg_t, a2, noise, nmax = _estimate(ds_Sv, ping_num, range_sample_num, background_noise_max, _shard)
         # actual_range of both outputs is a by-product of the kernel (no extra sweeps)
+        # (... read when somebody reads the attribute: the call does not wait for the kernel)
         sn, sc, mm = ops.noise_apply(sv_t, a2, noise, ping_num, float(SNR_threshold), want_minmax=True,
+                                     minmax_async=defer_clean_enabled(),
                                      **_rng_kw(rg_t, apply=True), ping_phase=0 if _shard is None else _shard[0] % ping_num)
     for name, t, kind in (("Sv_noise", sn, "noise"), ("Sv_corrected", sc, "corrected")):
         da = DataArray(t if isinstance(t, DeviceArray) else DeviceArray(t), order)
         if done is not None:  # minimum / maximum: by-products of pass 2, read when somebody reads the attribute
             rng_mm = (lambda k=kind: done.actual_range(k))
+        elif hasattr(mm, "tolist"):  # a HostFuture
+            rng_mm = (lambda k=kind, f=mm: f.tolist()[0:2] if k == "noise" else f.tolist()[2:4])
         else:
             rng_mm = mm[0:2] if kind == "noise" else mm[2:4]
         ds_Sv[name] = add_remove_background_noise_attrs(da, kind, ping_num, range_sample_num, SNR_threshold,

@@ -489,10 +489,10 @@ def noise_finalize(ssum, cnt, noise_max=float("nan")):
 
 
 def noise_apply(sv, alpha2, noise, ping_num, snr_threshold, *, range=None, coef=None, mask_raw=None,
-                want_noise=True, want_corrected=True, want_minmax=False, ping_phase=0):
+                want_noise=True, want_corrected=True, want_minmax=False, ping_phase=0, minmax_async=False):
     """K7 -> (Sv_noise, Sv_corrected[, [min, max of Sv_noise, min, max of Sv_corrected]]).  ``coef`` + ``mask_raw``
     (the f32 power samples) in place of ``range``: the echo_range array evaluated in the kernel, NaN where the raw
-    sample is."""
+    sample is.  ``minmax_async``: the four numbers as a ``HostFuture`` (the call does not wait for its kernel)."""
     C, P, S = sv.shape
     if range is not None and range.dtype != sv.dtype:
         range = range.to(sv.dtype)
@@ -505,7 +505,7 @@ def noise_apply(sv, alpha2, noise, ping_num, snr_threshold, *, range=None, coef=
     else:
         call("epa_noise_apply", _p(sv), _p(range), _p(coef), _p(alpha2), _p(noise), C, P, S, int(ping_num),
              int(ping_phase), float(snr_threshold), _p(sn), _p(sc), _p(mm), _DT[sv.dtype], _stream())
-    return (sn, sc, mm.cpu().tolist()) if want_minmax else (sn, sc)
+    return (sn, sc, fetch_async(mm) if minmax_async else mm.cpu().tolist()) if want_minmax else (sn, sc)
 
 
 def complex_coef_ek80(params, tau_eff, C, P, *, B, bb, cal_type="Sv", gpt=None):
