@@ -9,6 +9,7 @@ mask_attenuated_signal), each a handful of launches from csrc/n
 """
 import logging
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -63,9 +64,20 @@ class DenoiseSource:
         self.power, self.a2, self.noise, self.ping_num, self.snr, self.sv_t = power, a2, noise, ping_num, snr, sv_t
         self.raw_version = power.raw._version
         self.minmax = None  # HostFuture / list of [min, max of Sv_noise, min, max of Sv_corrected] once pass 2 has run
-        shape, dev = tuple(power.raw.shape), power.raw.device
-        self.lazy = {k: LazyDeviceArray(shape, power.dtype, dev, (lambda k=k: self._make(k)), source=self)
-                     for k in ("noise", "corrected")}
+        self._lazy = {}     # weak: the arrays own this object (source, make), not the other way round -- a dataset
+        #                     dropped unread frees the Sv of pass 1 with it, no reference cycle to wait for
+
+    def arrays(self):
+        """The two deferred arrays (created once; the caller keeps them alive by putting them into its dataset)."""
+        shape, dev = tuple(self.power.raw.shape), self.power.raw.device
+        out = {k: LazyDeviceArray(shape, self.power.dtype, dev, (lambda k=k: self._make(k)), source=self)
+               for k in ("noise", "corrected")}
+        self._lazy = {k: weakref.ref(v) for k, v in out.items()}
+        return out
+
+    def lazy(self, which):
+        ref = self._lazy.get(which)
+        return ref() if ref is not None else None
 
     def intact(self):
         """The raw samples have not been written to since pass 1 looked at them."""
@@ -74,8 +86,9 @@ class DenoiseSource:
     def install(self, res):
         """The by-products of a pass 2 somebody ran (``ops.sv_denoise_mvbs`` with minmax_async)."""
         for k, name in (("noise", "Sv_noise"), ("corrected", "Sv_corrected")):
-            if not self.lazy[k].materialized:
-                self.lazy[k].fulfil(res[name])
+            la = self.lazy(k)
+            if la is not None and not la.materialized:
+                la.fulfil(res[name])
         self.minmax = res["minmax"]
         self.sv_t = None
 
@@ -103,7 +116,7 @@ class DenoiseSource:
     def _make(self, which):
         if self.minmax is None:
             self.run_plain()
-        return self.lazy[which]._tensor
+        return self.lazy(which)._tensor
 
     def actual_range(self, which):
         if self.minmax is None:
@@ -153,9 +166,10 @@ def _denoise_deferred_sv(ds_Sv, ping_num, range_sample_num, nmax, snr):
     # (the three numbers start their way to the host now, behind pass 1 only: compute_MVBS sizes its grid from them)
     src.echo_range.set_stats(ops.fetch_async(rstats))
     dsrc = DenoiseSource(src, a2, noise, ping_num, snr, sv_t)
+    arrays = dsrc.arrays()
     if not defer_clean_enabled():
         dsrc.run_plain()
-    return dsrc
+    return dsrc, arrays
 
 
 def _rng_kw(rg_t, apply=False):
@@ -206,7 +220,8 @@ def remove_background_noise(ds_Sv, ping_num, range_sample_num, background_noise_
         done = _denoise_deferred_sv(ds_Sv, ping_num, range_sample_num, nmax, SNR_threshold)
     if done is not None:
         order = tuple(ds_Sv["Sv"].dims)
-        sn, sc = (done.lazy[k] if not done.lazy[k].materialized else done.lazy[k].tensor for k in ("noise", "corrected"))
+        done, arrays = done
+        sn, sc = arrays["noise"], arrays["corrected"]
         mm = None
     else:
         order, sv_t, rg_t, a2, noise, nmax = _estimate(ds_Sv, ping_num, range_sample_num, background_noise_max, _shard)

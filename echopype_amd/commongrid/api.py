@@ -239,7 +239,7 @@ def _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_v
     d = sv_da.data
     src = d.source if isinstance(d, LazyDeviceArray) and not d.materialized else None
     dims = ("channel", "ping_time", "range_sample")
-    if not isinstance(src, DenoiseSource) or d is not src.lazy["corrected"] or src.minmax is not None or not src.intact():
+    if not isinstance(src, DenoiseSource) or d is not src.lazy("corrected") or src.minmax is not None or not src.intact():
         return None
     p = src.power
     if rng_da.data is not p.echo_range or tuple(sv_da.dims) != dims or tuple(rng_da.dims) != dims \

@@ -260,3 +260,30 @@ def test_three_calls_deferred_equal_eager(env, monkeypatch, read_first):
     np.testing.assert_array_equal(np.isnan(mv["Sv"].values), np.isnan(mv_e["Sv"].values))
     np.testing.assert_allclose(mv["Sv"].values, mv_e["Sv"].values, rtol=1e-12, atol=1e-12, equal_nan=True)
     assert dict(mv["Sv"].attrs) == dict(mv_e["Sv"].attrs) and set(ds.attrs) == set(ds_e.attrs)
+
+
+def test_deferred_outputs_dropped_unread_free_their_inputs_at_once(env):
+    """The deferred Sv_noise / Sv_corrected own their DenoiseSource (which holds the raw samples, the noise estimate and
+    the Sv of pass 1), not the other way round: a dataset dropped before anybody read them is freed by reference
+    counting -- no cycle for the collector to find while 30-GB arrays wait."""
+    import gc
+    import weakref
+
+    torch, ep = env
+    _, ed = _resident_case(ep, seed=5)
+    logging.disable(logging.WARNING)
+    try:
+        gc.collect()
+        gc.disable()
+        try:
+            ds = ep.calibrate.compute_Sv(ed)
+            ep.clean.remove_background_noise(ds, ping_num=20, range_sample_num=50)
+            lazy = ds.data_vars["Sv_corrected"].data
+            refs = [weakref.ref(lazy), weakref.ref(lazy.source), weakref.ref(ds.data_vars["Sv"].data)]
+            assert not lazy.materialized
+            del lazy, ds
+            assert [r() for r in refs] == [None, None, None]
+        finally:
+            gc.enable()
+    finally:
+        logging.disable(logging.NOTSET)
