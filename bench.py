@@ -55,7 +55,8 @@ WORKLOADS = {
     "cfg5": (4, 2_000_000, 4096, 2, 3),
     "small": (4, 20_000, 2000, 50, 50),
 }
-DEFAULT_LINES = ["cfg3", "cfg3:ss2000", "cfg3:f32", "cfg2", "cfg2:f32", "api", "cfg4", "cfg4:f32", "cfg4:planes64", "cfg5"]
+DEFAULT_LINES = ["cfg3", "cfg3:ss2000", "cfg3:f32", "cfg2", "cfg2:f32", "api", "api:chain", "cfg4", "cfg4:f32", "cfg4:planes64",
+                 "cfg5"]
 TILE_PINGS = 250_000
 DT = {"f32": "float32", "f64": "float64"}
 
@@ -366,8 +367,11 @@ def run_ek60(ctx, name, variant, cpu):
                                   else "fused_sv_mvbs_kernel", kernel_ms, n * bps, bps, traffic_key=key))
 
 
-def run_api(ctx, cpu):
-    """The reference's own two calls on the cfg2 volume through the drop-in Dataset API, echodata resident in HBM
+def run_api(ctx, cpu, variant=""):
+    """``api:chain``: the reference's THREE calls of the chain on the cfg3 volume -- compute_Sv, remove_background_noise,
+    compute_MVBS of the dataset with Sv := Sv_corrected -- file after file: two passes over the raw samples (32 B per
+    sample in fp64), the second one inside compute_MVBS (clean.api.DenoiseSource).  Otherwise:
+    The reference's own two calls on the cfg2 volume through the drop-in Dataset API, echodata resident in HBM
     (EchoData.to_device): one pass = calibrate.compute_Sv(echodata) then commongrid.compute_MVBS(ds_Sv, '1m', '20s').
     compute_Sv leaves Sv (and echo_range) to the first reader; compute_MVBS, reading first, writes the Sv array and the
     bins in ONE pass over the raw samples: 4 B in + 8 B out per sample for both calls (fp64).  Also timed: the same two
@@ -395,12 +399,20 @@ def run_api(ctx, cpu):
         assert ds["Sv"].data.tensor is not None  # (the Sv array exists when the two calls return)
         return ds, mv
 
+    def three_calls_of_the_chain():
+        ds = ep.calibrate.compute_Sv(ed, dtype=dtype)
+        ep.clean.remove_background_noise(ds, ping_num=20, range_sample_num=50)
+        corrected = ds.copy()
+        corrected["Sv"] = ds["Sv_corrected"]
+        return ds, ep.commongrid.compute_MVBS(corrected, range_bin="1m", ping_time_bin="20s")
+
+    chain = variant == "chain"
     held = []  # the previous pass's result: read (the deferred MVBS dataset assembled) after this pass's launch
 
     def one_pass(timer):
         if timer is not None:
             timer.start()
-        r = two_calls()
+        r = three_calls_of_the_chain() if chain else two_calls()
         if timer is not None:
             timer.stop()
         held.append(r)
@@ -415,6 +427,18 @@ def run_api(ctx, cpu):
     try:
         passes = ctx.passes("api")
         elapsed, region_ms = ctx.timed(one_pass, passes, finish=finish)
+        if chain:
+            n = C * P * S
+            bps = 32 if dtype == "float64" else 20  # raw in twice, Sv, Sv_noise, Sv_corrected out
+            return line(ctx, samples_per_pass=n, passes=passes, elapsed=elapsed, scaling="weak", cpu=cpu,
+                        workload=f"api:chain: EK60 CW {C}x{P}x{S}, calibrate.compute_Sv(echodata), "
+                                 "clean.remove_background_noise(ds, 20, 50), commongrid.compute_MVBS(ds with Sv := "
+                                 "Sv_corrected) through the Dataset API, echodata resident in HBM, pass 2 deferred to "
+                                 "compute_MVBS, each result read after the next file's launch",
+                        config={"sharding": "one GPU", "collective": "none"},
+                        roofline=roofline("sv_noise_fast_kernel + sv_denoise_mvbs_* inside the three calls", region_ms,
+                                          n * bps, bps, traffic_key=f"api:chain:{dtype}",
+                                          note="region = the three API calls of one file incl. host work"))
 
         def med(f, prep=None):
             ts = []
@@ -641,7 +665,7 @@ class Cfg5:
                 return sharding.compute_Sv_MVBS(ed, range_bin=rb, ping_time_bin="20s", dtype=dtype, shard=shard,
                                                 tau_effective_first_ping=tau0)
         pending = collections.deque()
-        state = {"last": None, "n_read": 0}
+        state = {"last": None, "n_read": 0, "pass": 0}
 
         def consume(item):
             ds, mv = item
@@ -650,12 +674,16 @@ class Cfg5:
 
         def one_pass(timer):
             logging.disable(logging.WARNING)  # (the NaN-coordinate warning of every tile: 10 % of the pings are padded)
+            # the HIP-event bracket goes round the tiles from pass to pass: roofline.kernel_ms is the mean over ALL tiles
+            # of the volume (the calls of a tile behind a busy stream), not the first tile's
+            timed_tile = state["pass"] % len(eds)
+            state["pass"] += 1
             try:
                 for i, ed in enumerate(eds):
-                    if timer is not None and i == 0:
+                    if timer is not None and i == timed_tile:
                         timer.start()
                     item = call(ed)
-                    if timer is not None and i == 0:
+                    if timer is not None and i == timed_tile:
                         timer.stop()
                     pending.append(item)
                     while len(pending) > lag:
@@ -688,17 +716,21 @@ class Cfg5:
         dst = {(i, w): mv[i][:, 0 if w == 0 else -1] for i in range(len(mv)) for w in (0, 1)}
         tiles, sv, rb = self.tiles, self.sv_buffers(), self.range_bin
 
+        turn = [0]
+
         def one_pass(timer):
             rows = {}
+            timed_tile = turn[0] % len(tiles)  # (the bracket goes round the tiles: kernel_ms = mean over all of them)
+            turn[0] += 1
             for i, d in enumerate(tiles):
                 t, e0l, f, l, n_t = info[i]
                 coef = _coef(ctx, d)
                 bs = ops.time_bin_offsets(t, e0l, self.BIN_NS, n_t)
-                if timer is not None and i == 0:
+                if timer is not None and i == timed_tile:
                     timer.start()
                 res = ops.sv_mvbs_fused(d["backscatter_r"], coef, bs, n_t, rb, n_r, dtype=dt, sv_out=sv[i],
                                         mvbs_out=mv[i], want_partials=plan.shared)
-                if timer is not None and i == 0:
+                if timer is not None and i == timed_tile:
                     timer.stop()
                 if plan.shared:
                     for w, r in sharding.mvbs_edge_rows(res["sum"], res["cnt"]).items():
@@ -777,7 +809,7 @@ def run_cfg5(ctx, cpu):
                 config=cfg,
                 roofline=roofline("fused_sv_mvbs_kernel (+ K0 kernels of the calls)", region_ms,
                                   n_first * bps, bps, traffic_key=f"cfg5api:{ctx.dtype}",
-                                  launch=f"API calls of one {job.tile_p}-ping tile, HIP events"))
+                                  launch=f"API calls of one {job.tile_p}-ping tile (mean over the tiles), HIP events"))
 
 
 # ---------------------------------------------------------------------------------------- main
@@ -830,6 +862,8 @@ def main():
         todo = ["cfg5"] if args.only_headline else list(DEFAULT_LINES)
 
     def kind_of(w):
+        if w == "api:chain":
+            return "chain"
         return {"cfg3": "chain", "cfg4": "bb", "cfg4small": "bb"}.get(w.partition(":")[0], "ek60")
 
     # CPU baselines first (rank 0): they fork worker processes, which must happen before HIP is initialised
@@ -863,7 +897,7 @@ def main():
             ctx.free()
             out = run_cfg5(ctx, cpu.get("ek60"))
         elif w == "api":
-            out = run_api(ctx, cpu.get("ek60"))
+            out = run_api(ctx, cpu.get("chain" if variant == "chain" else "ek60"), variant)
         elif w.startswith("cfg4"):
             out = run_ek80(ctx, w, variant, cpu.get("bb"))
         else:

@@ -36,6 +36,9 @@ KERNELS = {
     "cfg4:float32": ("cfg4_f32", ["sv_complex_fft_kernel<float, float, float"], None, 2 * 200_000 * 8192 * 36),
     # the two reference calls with the Sv deferred: the statistics variant of the fused kernel inside compute_MVBS
     "api:float64": ("api", ["fused_sv_mvbs_kernel<double, float, true, true>"], None, 4 * 500_000 * 2000 * 12),
+    # the three reference calls of the chain: pass 1 inside remove_background_noise, pass 2 inside compute_MVBS
+    "api:chain:float64": ("api_chain", ["sv_noise_fast_kernel", "sv_denoise_mvbs_fast_kernel", "sv_denoise_mvbs_uniform_kernel",
+                                        "sv_denoise_mvbs_drift_kernel"], None, 4 * 500_000 * 2000 * 32),
 }
 
 

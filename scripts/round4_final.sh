@@ -4,14 +4,14 @@
 # default bench, instruction counters of the hot kernels, the API probe.  Results under gpurun_out/final4/.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/final4; rm -rf $O; mkdir -p $O
-for wl in cfg2 cfg2:f32 cfg3 cfg3:f32 cfg3:ss2000 cfg4 cfg4:f32 cfg4:planes64 cfg5 api; do
+for wl in cfg2 cfg2:f32 cfg3 cfg3:f32 cfg3:ss2000 cfg4 cfg4:f32 cfg4:planes64 cfg5 api api:chain; do
   tag=$(echo $wl | tr ':' '_')
   for c in FETCH_SIZE WRITE_SIZE; do
     n=fetch; [ $c = "FETCH_SIZE" ] || n=write
     timeout 600 rocprofv3 --pmc $c --kernel-trace -d $O/${n}_$tag -o p --output-format csv -- python bench.py --workload $wl --no-cpu-baseline --steps 1 --warmup 1 --passes 2 > $O/${n}_$tag.log 2>&1
   done
 done
-for wl in cfg2 cfg2_f32 cfg3 cfg3_f32 cfg3_ss2000 cfg4 cfg4_f32 cfg4_planes64 cfg5 api; do for n in fetch write; do python scripts/pmc_summary.py $O/${n}_$wl kernel | grep -v "^kernel," | sed "s/^/$wl,/" ; done; done > $O/pmc_traffic.csv
+for wl in cfg2 cfg2_f32 cfg3 cfg3_f32 cfg3_ss2000 cfg4 cfg4_f32 cfg4_planes64 cfg5 api api_chain; do for n in fetch write; do python scripts/pmc_summary.py $O/${n}_$wl kernel | grep -v "^kernel," | sed "s/^/$wl,/" ; done; done > $O/pmc_traffic.csv
 python scripts/make_traffic_json.py $O | tee $O/traffic.txt
 cp profiles/hbm_traffic.json $O/hbm_traffic.json
 find $O -name "*counter_collection.csv" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete

@@ -41,7 +41,7 @@ def test_committed_bench_lines_keep_the_contract():
     if not os.path.exists(LINES):
         pytest.skip("no committed default run of this round yet")
     lines = [json.loads(x) for x in open(LINES) if x.strip()]
-    assert len(lines) == 10
+    assert len(lines) == 11
     for d in lines:
         _check_line(d, want_cpu=True)
         assert d["n_gpus"] == 1 and d["config"]["passes_per_step"] >= 1
@@ -64,6 +64,12 @@ def test_committed_bench_lines_keep_the_contract():
     assert head["config"]["also_cfg3"].count(";") == 2 and "ss2000" in head["config"]["also_cfg3"]
     by = {d["config"]["workload"].split(":")[0] + ":" + d["dtype"] for d in lines}
     assert {"cfg2:f64", "cfg2:f32", "cfg3:f64", "cfg3:f32", "cfg4:f64", "cfg4:f32", "cfg5:f64", "api:f64"} <= by
+    # the chain through the reference's THREE calls runs at the chain kernels' own speed (ops-level: the cfg3 line)
+    chain = [d for d in lines if d["config"]["workload"].startswith("api:chain")]
+    cfg3 = [d for d in lines if d["config"]["workload"].startswith("cfg3") and d["dtype"] == "f64"]
+    assert len(chain) == 1 and "remove_background_noise" in chain[0]["config"]["workload"]
+    assert chain[0]["config"]["ms_per_pass"] < 1.08 * min(d["config"]["ms_per_pass"] for d in cfg3)
+    assert "chain" in head["config"]["also_api"]
 
 
 @pytest.mark.gpu
