@@ -23,7 +23,7 @@ are a ~2 s region); `value` = samples processed by all ranks in the K timed step
 N = 1 prints, before the headline, one JSON line per single-GPU configuration of BASELINE.json (skipped with
 --only-headline or an explicit --workload): cfg3 = configs[2] (compute_Sv -> remove_background_noise -> compute_MVBS;
 SURVEY 8d recipe: a new sound speed at every ping; then the every-2000-pings variant and fp32), cfg2 = configs[1] (fp64,
-fp32), the reference's own two API calls on the cfg2 volume, cfg4 = configs[3] (EK80 BB pulse compression + Sv, float32
+fp32), the reference's own two API calls on the cfg2 volume and its THREE calls of the cfg3 chain (api:chain), cfg4 = configs[3] (EK80 BB pulse compression + Sv, float32
 planes -> fp64 / fp32, and float64 planes as the converter stores them).  Every line carries `roofline` (HIP-event
 time of the dominant kernel on torch's stream vs the algorithmic bytes of SURVEY 8d) and `cpu_baseline` (the NumPy /
 SciPy oracle with the reference's pass structure on a bounded slice, host cores, timed before HIP is initialised).
