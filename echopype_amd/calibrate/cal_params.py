@@ -7,7 +7,7 @@ Mirrors /root/reference/echopype/calibrate/cal_params.py: CAL_PARAMS / EK80_DEFA
 """
 import numpy as np
 
-from ..xr_lite import DataArray, DeviceArray
+from ..xr_lite import DataArray, DeviceArray, host_readable
 
 CAL_PARAMS = {
     "EK60": ("sa_correction", "gain_correction", "equivalent_beam_angle", "angle_offset_alongship",
@@ -102,6 +102,21 @@ class PulseTableParam(DataArray):
     @data.setter
     def data(self, v):
         self._data = v
+
+    @property
+    def values(self):
+        """Host values.  Per-ping pulse lengths that live in HBM WITH a host mirror (EchoData.to_device) are looked up
+        on the host: a host-side consumer (the BB gain interpolation, get_cal_params_EK) then costs neither a kernel nor
+        a wait for the GPU."""
+        if self._data is None:
+            tau = self._tau.data
+            if isinstance(tau, DeviceArray) and host_readable(tau):
+                if getattr(self, "_host_values", None) is None:
+                    t = np.asarray(tau, dtype=np.float64)
+                    self._host_values = _lookup_host(t if self._tau.dims[0] == "channel" else t.T, self.pulse_length,
+                                                     self.table)
+                return self._host_values
+        return np.asarray(self.data)
 
 
 def _lookup_host(tau, pl, tab):

@@ -251,5 +251,7 @@ class CalibrateBase(abc.ABC):
                                    "modified in place since: its NaN mask can no longer be reproduced")
             return ops.range_power(raw, coef, flags=mask_flag, dtype=dtype)
 
-        return LazyDeviceArray(tuple(raw.shape), dtype, raw.device, make, stats=stats, rows=coef,
-                               nan_where=raw if mask_flag else None)
+        rng = LazyDeviceArray(tuple(raw.shape), dtype, raw.device, make, stats=stats, rows=coef,
+                              nan_where=raw if mask_flag else None)
+        rng.reach_bound = self._host_reach_bound(raw.shape[2])
+        return rng

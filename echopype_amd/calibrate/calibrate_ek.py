@@ -518,6 +518,8 @@ class CalibrateEK80(CalibrateEK):
 
             range_t = LazyDeviceArray(res["out"].shape, dtype, re.device, make, stats=res["range_stats"],
                                       rows=ops.power_rows_of_complex(ccoef))
+            # (range.py:138-160: s * sample_interval * sound_speed / 2 minus a non-negative offset, clipped at 0)
+            range_t.reach_bound = self._host_reach_bound(res["out"].shape[2])
         return self._finish(cal_type, res["out"], range_t, tau_eff, range_stats=res["range_stats"])
 
     def _compute_cal(self, cal_type):

@@ -92,8 +92,10 @@ def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="
     return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, skipna, fill_value, closed, range_var_max, _shard)
 
 
-def _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, skipna, fill_value, closed, range_var_max, _shard):
-    """The binning of an existing Sv array (arguments validated by compute_MVBS)."""
+def _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, skipna, fill_value, closed, range_var_max, _shard,
+                allow_defer=True):
+    """The binning of an existing Sv array (arguments validated by compute_MVBS).  ``allow_defer=False``: the dataset is
+    assembled before the call returns (the fallback of the deferred routes' own assembly)."""
     sv_da = ds_Sv["Sv"]
     order = tuple(sv_da.dims)
     dim_0 = order[0]
@@ -104,6 +106,14 @@ def _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, skipna, fill_value
     rows = _coef_rows(ds_Sv[range_var], order, sv_t) if skipna else None
     rg_t = _dev(_full(ds_Sv[range_var], ds_Sv, order), sv_t.dtype) if rows is None else None
     C, P, S = sv_t.shape
+
+    if _shard is None and rows is not None and allow_defer and defer_mvbs_enabled():
+        # a lazy range (coefficient rows) that knows on the host how far it can reach and whose exact statistics are a
+        # kernel's by-product still in HBM: the bins are launched on the conservative grid, the dataset trimmed when read
+        done = _mvbs_of_array_without_waiting(ds_Sv, sv_t, rows, range_var, range_bin_m, ping_time_bin, skipna,
+                                              fill_value, closed, range_var_max)
+        if done is not None:
+            return done
 
     # range edges: np.arange(0, max + bin, bin)  (api.py:108-115)
     lo, hi, n_nan_range = _range_stats(ds_Sv[range_var], rg_t)
@@ -152,6 +162,53 @@ def _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, skipna, fill_value
 
     return _assemble_mvbs(ds_Sv, mvbs_t, dim_0, ping_time, e0, dt, n_t, r_edges, range_var, range_bin_m,
                           ping_time_bin, closed)
+
+
+def _mvbs_of_array_without_waiting(ds_Sv, sv_t, rows, range_var, range_bin_m, ping_time_bin, skipna, fill_value, closed,
+                                   range_var_max):
+    """The binning of an Sv ARRAY whose range variable is still lazy (``compute_Sv`` on EK80 complex samples; an EK60 Sv
+    somebody has read already) -- without the wait ``_mvbs_plain`` pays for nanmax(range) before it can size its grid:
+    the kernel runs on ``np.arange(0, bound + bin, bin)`` with the host-side bound the lazy range carries
+    (``reach_bound``) and the dataset, a ``DeferredDataset``, is trimmed to ``nanmax`` when somebody reads it.  None: the
+    plain route (no bound, no statistics, unsorted pings, a grid the kernels refuse)."""
+    rng_d = ds_Sv[range_var].data
+    if not isinstance(rng_d, LazyDeviceArray):
+        return None
+    bound = (_parse_x_bin(range_var_max) + 1e-8) if range_var_max is not None else rng_d.reach_bound
+    if bound is None or not np.isfinite(bound):
+        return None
+    ping_time = np.asarray(ds_Sv["ping_time"].values).astype("datetime64[ns]", copy=False)
+    ns = ping_time.view(np.int64)
+    if ns.size == 0 or np.any(ns[1:] < ns[:-1]) or ns[0] == np.iinfo(np.int64).min:  # unsorted pings, NaT
+        return None
+    n_cap = len(np.arange(0, bound + range_bin_m, range_bin_m)) - 1
+    stats = rng_d.stats_async() if n_cap >= 1 else None
+    if stats is None:
+        return None
+    C, P, S = sv_t.shape
+    e0, dt, n_t = resample_edges(ping_time, ping_time_bin, sorted_valid=True)
+    bin_start = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t, closed=closed)
+    try:
+        res = ops.mvbs(sv_t, bin_start, n_t, range_bin_m, n_cap, coef=rows, coef_as_stored=True, skipna=skipna,
+                       closed=closed, fill_value=fill_value)
+    except _lib.EpaError:
+        return None
+    dim_0 = tuple(ds_Sv["Sv"].dims)[0]
+
+    def build():
+        lo, hi, n_nan_range = stats.tolist()
+        rmax = hi if range_var_max is None else bound
+        r_edges = np.arange(0, rmax + range_bin_m, range_bin_m) if np.isfinite(rmax) else np.zeros(1)
+        n_r = len(r_edges) - 1
+        if n_r < 1 or n_r > n_cap:  # (no valid range / an empty grid: the plain route raises or returns the reference's)
+            return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, skipna, fill_value, closed, range_var_max, None, allow_defer=False)
+        if n_nan_range > 0:
+            logging.warning(f"The ```{range_var}``` coordinate array contain NaNs. {_AGG_MSG}")
+        mvbs_t = res["MVBS"][..., :n_r].contiguous() if n_r != n_cap else res["MVBS"]
+        return _assemble_mvbs(ds_Sv, mvbs_t, dim_0, ping_time, e0, dt, n_t, r_edges, range_var, range_bin_m,
+                              ping_time_bin, closed)
+
+    return DeferredDataset(build)
 
 
 def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max):
@@ -215,7 +272,7 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
         r_edges = np.arange(0, rmax + range_bin_m, range_bin_m) if np.isfinite(rmax) else np.zeros(1)
         n_r = len(r_edges) - 1
         if n_r < 1:  # no valid range / an empty grid: the plain route raises or returns what the reference would
-            return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, True, fill_value, "left", range_var_max, None)
+            return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, True, fill_value, "left", range_var_max, None, allow_defer=False)
         if n_nan_range > 0:
             logging.warning(f"The ```{range_var}``` coordinate array contain NaNs. {_AGG_MSG}")
         mvbs_t = res["MVBS"][..., :n_r].contiguous() if n_r != n_cap else res["MVBS"]
@@ -276,13 +333,13 @@ def _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_v
     def build():
         stats = rng.cached_stats()  # left by pass 1, on their way to the host since then
         if stats is None:
-            return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, True, fill_value, "left", range_var_max, None)
+            return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, True, fill_value, "left", range_var_max, None, allow_defer=False)
         lo, hi, n_nan_range = stats
         rmax = hi if range_var_max is None else r_cap
         r_edges = np.arange(0, rmax + range_bin_m, range_bin_m) if np.isfinite(rmax) else np.zeros(1)
         n_r = len(r_edges) - 1
         if n_r < 1:
-            return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, True, fill_value, "left", range_var_max, None)
+            return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, True, fill_value, "left", range_var_max, None, allow_defer=False)
         if n_nan_range > 0:
             logging.warning(f"The ```{range_var}``` coordinate array contain NaNs. {_AGG_MSG}")
         mvbs_t = res["MVBS"][..., :n_r].contiguous() if n_r != n_cap else res["MVBS"]

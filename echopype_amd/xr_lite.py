@@ -97,7 +97,7 @@ class LazyDeviceArray(DeviceArray):
     ``DeviceArray(lazy.tensor)`` to cut that tie."""
 
     __slots__ = ("_make", "_shape", "_tdtype", "_device", "_tensor", "_rows", "_mask", "_made_version", "source",
-                 "_stats_hook", "__weakref__")
+                 "_stats_hook", "reach_bound", "__weakref__")
 
     def __init__(self, shape, dtype, device, make, stats=None, rows=None, nan_where=None, source=None):
         self._make, self._shape, self._tdtype, self._device = make, tuple(int(n) for n in shape), dtype, device
@@ -111,6 +111,9 @@ class LazyDeviceArray(DeviceArray):
         # by-product of its own pass over the same inputs (compute_MVBS: the fused kernel) does so and calls fulfil()
         self.source = source
         self._stats_hook = None  # called once when the statistics are asked for and nobody has left them yet
+        # an upper bound of every value of the array known on the HOST (an echo_range: how far can any row reach?), or
+        # None: a consumer sizes its launch from it and reads the exact statistics later (stats_async)
+        self.reach_bound = None
         # the array is NaN exactly where this device tensor of the same shape is (the raw power samples): kernels that
         # need the NaN pattern as well as the values read it next to the rows
         self._mask = (nan_where, nan_where._version) if nan_where is not None else None
@@ -158,6 +161,20 @@ class LazyDeviceArray(DeviceArray):
         if self._tensor is not None and self._made_version != self._tensor._version:
             return None
         return self._rows
+
+    def stats_async(self):
+        """The {nanmin, nanmax, NaN count} as an object whose ``.tolist()`` does not wait for kernels launched after
+        this call (``ops.HostFuture``: the three numbers start for the host now, on a side stream), or None when
+        nobody has left them (or something wrote to the array since)."""
+        if self._stats is None or (self._tensor is not None and self._stats[1] != self._tensor._version):
+            return None
+        st = self._stats[0]
+        if not hasattr(st, "tolist") or hasattr(st, "is_cuda"):  # a device tensor: send it on its way
+            from . import ops
+
+            st = ops.fetch_async(st)
+            self._stats = (st, self._stats[1])
+        return st
 
     def cached_stats(self):
         if self._stats is None and self._stats_hook is not None:
