@@ -159,15 +159,15 @@ struct PingLoad<float> {
 };
 template <>
 struct PingLoad<int16_t> {
-  // One 8-byte load per lane covers the wave's 256-sample tile (lane l holds samples 4l..4l+3 as two
-  // packed 32-bit words, word j = samples {2j, 2j+1} sits in lane j/2 slot j&1); two ds_bpermute
-  // per pair then hand lane l its words l and 64+l, i.e. the same {2l, 2l+1}, {128+2l, 128+2l+1}
-  // ownership as the float path.  (4-byte loads per lane measured 25 % SLOWER than the f32 input
-  // despite half the bytes.)
-  uint2 q;
-  __device__ __forceinline__ PingLoad() : q(make_uint2(0u, 0u)) {}
-  __device__ __forceinline__ void issue(const int16_t* __restrict__ row, int, int, bool, int s4, int S) {
-    if (s4 < S) q = *reinterpret_cast<const uint2*>(row + s4);
+  // The float path's ownership with the float path's two requests per lane, 4 bytes each: word A = samples
+  // {sA, sA+1}, word B = {sB, sB+1}; one SDWA conversion + one multiplication per sample.  Measured on
+  // 4 x 500 000 x 2000 (round 4): 9.10 ms -- the float source's 8.98 -- against 10.6 ms for one 8-byte load per lane
+  // redistributed by four ds_bpermute, and 11.3 ms with the padding test on every sample (round 3).
+  unsigned a, b;
+  __device__ __forceinline__ PingLoad() : a(0u), b(0u) {}
+  __device__ __forceinline__ void issue(const int16_t* __restrict__ row, int sA, int sB, bool hasB, int, int) {
+    a = *reinterpret_cast<const unsigned*>(row + sA);
+    if (hasB) b = *reinterpret_cast<const unsigned*>(row + sB);
   }
   static __device__ __forceinline__ float2 unpack(unsigned w, int s, int n_valid) {
     constexpr float kIndex2Power = 0.011758984205624266f;  // float32(10*log10(2)/256)
@@ -175,12 +175,19 @@ struct PingLoad<int16_t> {
     const float x = (float)(short)(w & 0xffffu), y = (float)(short)(w >> 16);
     return make_float2(s < n_valid ? x * kIndex2Power : nanv, s + 1 < n_valid ? y * kIndex2Power : nanv);
   }
-  __device__ __forceinline__ void resolve(float2& A, float2& B, int sA, int sB, int nv, int lane) const {
-    const int src = lane >> 1;
-    const unsigned a0 = __shfl(q.x, src, 64), a1 = __shfl(q.y, src, 64);
-    const unsigned b0 = __shfl(q.x, 32 + src, 64), b1 = __shfl(q.y, 32 + src, 64);
-    A = unpack((lane & 1) ? a1 : a0, sA, nv);
-    B = unpack((lane & 1) ? b1 : b0, sB, nv);
+  static __device__ __forceinline__ float2 unpack_all(unsigned w) {  // every sample of the pair is a recorded one
+    constexpr float kIndex2Power = 0.011758984205624266f;
+    return make_float2((float)(short)(w & 0xffffu) * kIndex2Power, (float)(short)(w >> 16) * kIndex2Power);
+  }
+  __device__ __forceinline__ void resolve(float2& A, float2& B, int sA, int sB, int nv, int) const {
+    // (uniform per wavefront in the usual case: a ping recorded at full length has no padding to test for)
+    if (nv >= sB + 2) {
+      A = unpack_all(a);
+      B = unpack_all(b);
+    } else {
+      A = unpack(a, sA, nv);
+      B = unpack(b, sB, nv);
+    }
   }
 };
 
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(epa::kBlock, RMAX ? 4 : EPA_FUSED_MIN_WAVES) void f
     double dcur = __builtin_nan(""), racur = __builtin_nan("");
     // software prefetch: the raw samples and the coefficient row of ping p+1 are requested before
     // ping p is processed, so their latency hides behind ~150 instructions of arithmetic (+8 %)
-    const int s4 = chunk0 + wave * 256 + 4 * lane;  // int16 source: this lane's 8-byte quad
+    const int s4 = chunk0 + wave * 256 + 4 * lane;  // (a source that loads quads: unused by the present ones)
     PingLoad<RawT> nxt;
     epa::CoefRow nxtR = rowp0[pb < pe ? pb : 0];
     if (pb < pe) nxt.issue(raw_c + (size_t)pb * S, sA, sB, hasB, s4, S);
