@@ -56,6 +56,7 @@ _i64 = ctypes.c_int64
 # name -> argtypes; every function returns int status except epa_version / epa_last_error
 SIGNATURES = {
     "epa_version": [],
+    "epa_source_digest": [],
     "epa_last_error": [],
     "epa_launch_trace": [_i],
     "epa_last_range_stats_filled": [],
@@ -130,7 +131,29 @@ SIGNATURES = {
 for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here = the .so does not export a declared symbol
     _fn.argtypes = _args
-    _fn.restype = ctypes.c_char_p if _name in ("epa_last_error", "epa_launch_trace", "epa_launch_seen") else _i
+    _fn.restype = ctypes.c_char_p if _name in ("epa_last_error", "epa_launch_trace", "epa_launch_seen", "epa_source_digest") else _i
+
+
+def _check_source_digest():
+    """The library must have been built from the sources lying beside it (csrc/, include/): a stale binary raises here
+    instead of answering for code it was not made from.  Skipped for an alternative build handed in through
+    ECHOPYPE_AMD_LIB (A/B tuning: other flags on purpose) and when the sources are not there (an installed copy)."""
+    if os.environ.get("ECHOPYPE_AMD_LIB"):
+        return
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_epa_build", os.path.join(_HERE, "build.py"))
+    if spec is None or not os.path.isdir(os.path.join(_HERE, "csrc")):
+        return
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    want, got = b.source_digest(), lib.epa_source_digest().decode()
+    if want != got:
+        raise ImportError(f"{LIB_PATH} was built from other sources (digest {got}, the tree has {want}): "
+                          "rebuild it with `python echopype_amd/build.py`")
+
+
+_check_source_digest()
 
 
 class launch_trace:

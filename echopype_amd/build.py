@@ -6,6 +6,7 @@
 The shared library is the product: there is no CPU fallback.  hipcc cross-compiles for gfx950
 without a GPU, so this runs in the authoring container and the built .so travels with the tree.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -26,6 +27,21 @@ HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))
 EXTRA = os.environ.get("EPA_EXTRA_FLAGS", "").split()
 FLAGS = [*EXTRA, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}"]
+
+
+def source_digest():
+    """sha256 over every source the library is made of (csrc/*.hip, csrc/*.h, the public header) and the base compiler
+    flags.  build_library() compiles it into the library (``epa_source_digest()``); ``_lib`` recomputes it from the
+    files at import time and refuses a library built from other sources -- a stale shipped binary cannot pass."""
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, x) for x in HEADERS] + \
+            [os.path.join(INCLUDE, "echopype_amd.h")]:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    h.update(" ".join(f for f in FLAGS if not f.startswith("-I") and f not in EXTRA).encode())
+    return h.hexdigest()[:32]
 
 
 def _hipcc():
@@ -50,14 +66,19 @@ def build_library(force=False, verbose=True):
                                                        os.path.abspath(__file__)]
     jobs = []
     objs = []
+    digest = source_digest()
+    stamp = os.path.join(OBJDIR, "source_digest.txt")
+    old = open(stamp).read().strip() if os.path.exists(stamp) else ""
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
             raise FileNotFoundError(sp)
         op = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(op)
-        if force or _stale(op, [sp] + hdrs):
-            jobs.append([hipcc, *FLAGS, "-c", sp, "-o", op])
+        # runtime.hip carries the digest of ALL sources: recompiled whenever any of them changed
+        extra = [f'-DEPA_SOURCE_DIGEST="{digest}"'] if src == "runtime.hip" else []
+        if force or _stale(op, [sp] + hdrs) or (extra and old != digest):
+            jobs.append([hipcc, *FLAGS, *extra, "-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:
@@ -72,6 +93,8 @@ def build_library(force=False, verbose=True):
         list(ex.map(run, jobs))
     if jobs or force or _stale(LIBPATH, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIBPATH])
+    with open(stamp, "w") as f:
+        f.write(digest + "\n")
     return LIBPATH
 
 

@@ -68,7 +68,23 @@ class CalibrateAZFP(CalibrateBase):
             rows[..., _lib.CF_A0] = A + n * np.log10(k)
             rows[..., _lib.CF_G] = 1.0 / (26214 * DS)
             rows[..., _lib.CF_D] = -r0 / k
+        self._reach_terms = (k, r0)
         return rows
+
+    def _host_reach_bound(self, S):
+        """Upper bound of every echo_range of the rows ``_rows`` made last: max((S - 1) k + r0) over (channel, ping) --
+        the AZFP range starts at r0 = c L / (2 f) + (c / 4) ((N - 1) / f + tau) > 0 (range.py:81-89), which the EK
+        bound of the base class does not know.  The rows are host arrays: no device reduction, no wait."""
+        terms = getattr(self, "_reach_terms", None)
+        if terms is None:
+            return None
+        k, r0 = terms
+        with np.errstate(invalid="ignore"):
+            reach = (S - 1) * k + r0
+            m = float(np.fmax.reduce(reach, axis=None)) if reach.size else float("nan")
+        if not (np.isfinite(m) and m > 0):
+            return None
+        return m * (1 + (1e-12 if str(self.dtype).endswith("64") else 1e-6))
 
     def _power_inputs(self, cal_type):
         if cal_type not in ("Sv", "TS"):

@@ -218,7 +218,8 @@ class CalibrateBase(abc.ABC):
         return sv, rng
 
     def _host_reach_bound(self, S):
-        """An upper bound of every echo_range the EK coefficient rows can produce -- fl((S - 1) max sample_interval)
+        """EK only (CalibrateAZFP overrides it: its rows carry an offset r0 > 0).
+        An upper bound of every echo_range the EK coefficient rows can produce -- fl((S - 1) max sample_interval)
         * (max sound_speed / 2), the row formula (range.py:138) at the two maxima -- from HOST copies of the two
         parameters (host arrays, or the mirrors EchoData.to_device keeps; memoised there), so that sizing the range
         grid costs neither a device reduction nor a wait for the GPU.  None when a parameter lives in HBM only."""
@@ -237,7 +238,10 @@ class CalibrateBase(abc.ABC):
         si, cw = hmax(beam["sample_interval"]), hmax(env["sound_speed"])
         if si is None or cw is None or not (np.isfinite(si) and np.isfinite(cw) and si > 0 and cw > 0):
             return None
-        return float((S - 1) * si) * (cw / 2) * (1 + 1e-12)
+        # (float32 outputs: the range statistics the kernels leave are rounded to float32, up to 6e-8 above the float64
+        #  value the bound is made from -- the margin keeps nanmax(echo_range) inside the conservative grid)
+        margin = 1e-12 if str(getattr(self, "dtype", "float64")).endswith("64") else 1e-6
+        return float((S - 1) * si) * (cw / 2) * (1 + margin)
 
     def _lazy_power_range(self, raw, coef, flags, stats=None):
         """echo_range of power samples as a LazyDeviceArray: coefficient rows + the raw samples' NaN pattern; written by

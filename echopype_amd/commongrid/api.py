@@ -194,6 +194,11 @@ def _mvbs_of_array_without_waiting(ds_Sv, sv_t, rows, range_var, range_bin_m, pi
     except _lib.EpaError:
         return None
     dim_0 = tuple(ds_Sv["Sv"].dims)[0]
+    # what the assembly needs is taken NOW: the caller may replace variables or edit attributes of its dataset between
+    # this call and the first use of the result, and the result must not change with them; the kernel's partial sums /
+    # counts are not kept alive by the closure
+    ds_Sv, mv_full = ds_Sv.copy(), res["MVBS"]
+    del res
 
     def build():
         lo, hi, n_nan_range = stats.tolist()
@@ -204,7 +209,7 @@ def _mvbs_of_array_without_waiting(ds_Sv, sv_t, rows, range_var, range_bin_m, pi
             return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, skipna, fill_value, closed, range_var_max, None, allow_defer=False)
         if n_nan_range > 0:
             logging.warning(f"The ```{range_var}``` coordinate array contain NaNs. {_AGG_MSG}")
-        mvbs_t = res["MVBS"][..., :n_r].contiguous() if n_r != n_cap else res["MVBS"]
+        mvbs_t = mv_full[..., :n_r].contiguous() if n_r != n_cap else mv_full
         return _assemble_mvbs(ds_Sv, mvbs_t, dim_0, ping_time, e0, dt, n_t, r_edges, range_var, range_bin_m,
                               ping_time_bin, closed)
 
@@ -265,17 +270,21 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
     # (the assembly below, the next reader of the echo_range statistics) does not wait for kernels launched after it
     stats = ops.fetch_async(res["range_stats"])
     rng.set_stats(stats)
+    ds_Sv, mv_full = ds_Sv.copy(), res["MVBS"]  # (snapshot: see _mvbs_of_array_without_waiting)
+    del res
 
     def build():
         lo, hi, n_nan_range = stats.tolist()
         rmax = hi if range_var_max is None else r_cap
         r_edges = np.arange(0, rmax + range_bin_m, range_bin_m) if np.isfinite(rmax) else np.zeros(1)
         n_r = len(r_edges) - 1
-        if n_r < 1:  # no valid range / an empty grid: the plain route raises or returns what the reference would
+        # no valid range / an empty grid: the plain route raises or returns what the reference would; a maximum beyond the
+        # conservative grid the kernel ran on (it must not happen: the bound is an upper one): binned again, exactly
+        if n_r < 1 or n_r > n_cap:
             return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, True, fill_value, "left", range_var_max, None, allow_defer=False)
         if n_nan_range > 0:
             logging.warning(f"The ```{range_var}``` coordinate array contain NaNs. {_AGG_MSG}")
-        mvbs_t = res["MVBS"][..., :n_r].contiguous() if n_r != n_cap else res["MVBS"]
+        mvbs_t = mv_full[..., :n_r].contiguous() if n_r != n_cap else mv_full
         return _assemble_mvbs(ds_Sv, mvbs_t, "channel", ping_time, e0, dt, n_t, r_edges, range_var, range_bin_m,
                               ping_time_bin, "left")
 
@@ -329,6 +338,8 @@ def _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_v
         return None
     src.install(res)
     rng = p.echo_range
+    ds_Sv, mv_full = ds_Sv.copy(), res["MVBS"]  # (snapshot: see _mvbs_of_array_without_waiting)
+    del res
 
     def build():
         stats = rng.cached_stats()  # left by pass 1, on their way to the host since then
@@ -338,11 +349,11 @@ def _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_v
         rmax = hi if range_var_max is None else r_cap
         r_edges = np.arange(0, rmax + range_bin_m, range_bin_m) if np.isfinite(rmax) else np.zeros(1)
         n_r = len(r_edges) - 1
-        if n_r < 1:
+        if n_r < 1 or n_r > n_cap:
             return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, True, fill_value, "left", range_var_max, None, allow_defer=False)
         if n_nan_range > 0:
             logging.warning(f"The ```{range_var}``` coordinate array contain NaNs. {_AGG_MSG}")
-        mvbs_t = res["MVBS"][..., :n_r].contiguous() if n_r != n_cap else res["MVBS"]
+        mvbs_t = mv_full[..., :n_r].contiguous() if n_r != n_cap else mv_full
         return _assemble_mvbs(ds_Sv, mvbs_t, "channel", ping_time, e0, dt, n_t, r_edges, range_var, range_bin_m,
                               ping_time_bin, "left")
 

@@ -3,6 +3,8 @@
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -35,7 +37,7 @@ void set_error(const char* fmt, ...);
 // Launch trace (epa_launch_trace in echopype_amd.h): while it is on, every kernel launch notes its name -- the tests
 // assert WHICH kernel served a call (a specialised kernel silently declining a shape otherwise passes every
 // "fast == generic" comparison as generic == generic).
-extern bool g_trace_on;
+extern std::atomic<bool> g_trace_on;
 void note_launch(const char* what);
 // epa_last_range_stats_filled (echopype_amd.h): did the last fused call on this thread leave the range statistics?
 void note_range_stats_filled(int filled);
@@ -44,7 +46,7 @@ void note_range_stats_filled(int filled);
 void note_seen(const char* what);
 
 inline int check_launch(const char* what) {
-  if (g_trace_on) note_launch(what);
+  if (g_trace_on.load(std::memory_order_relaxed)) note_launch(what);
   note_seen(what);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

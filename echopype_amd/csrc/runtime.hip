@@ -1,6 +1,7 @@
 // Runtime plumbing of the C ABI: error reporting, device memory helpers, HIP-event timers.
 #include "epa_internal.h"
 
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <set>
@@ -14,7 +15,7 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
-bool g_trace_on = false;
+std::atomic<bool> g_trace_on{false};
 static thread_local char g_trace[2048] = "";
 static thread_local size_t g_trace_len = 0;
 void note_launch(const char* what) {
@@ -31,7 +32,10 @@ static std::mutex g_seen_mu;
 static std::set<std::string> g_seen;
 static std::string g_seen_joined;
 void note_seen(const char* what) {
-  static thread_local const char* cache[64];
+  // (larger than the number of distinct launch names in the library -- about 70 -- so that every name ends up cached and
+  //  the mutex below is taken once per name and thread, never on the steady-state launch path)
+  constexpr int kCache = 256;
+  static thread_local const char* cache[kCache];
   static thread_local int ncache = 0;
   for (int i = 0; i < ncache; ++i)
     if (cache[i] == what) return;
@@ -39,7 +43,7 @@ void note_seen(const char* what) {
     std::lock_guard<std::mutex> lk(g_seen_mu);
     g_seen.insert(what);
   }
-  if (ncache < 64) cache[ncache++] = what;
+  if (ncache < kCache) cache[ncache++] = what;
 }
 static thread_local int g_stats_filled = 0;
 void note_range_stats_filled(int filled) { g_stats_filled = filled; }
@@ -52,6 +56,10 @@ struct EpaTimer {
 extern "C" {
 
 int epa_version(void) { return EPA_VERSION; }
+#ifndef EPA_SOURCE_DIGEST
+#define EPA_SOURCE_DIGEST "unknown"
+#endif
+const char* epa_source_digest(void) { return EPA_SOURCE_DIGEST; }
 const char* epa_last_error(void) { return epa::g_err; }
 int epa_last_range_stats_filled(void) { return epa::g_stats_filled; }
 const char* epa_launch_seen(void) {
@@ -62,7 +70,7 @@ const char* epa_launch_seen(void) {
 }
 const char* epa_launch_trace(int mode) {
   if (mode == 1 || mode == 0) {  // start afresh / stop
-    epa::g_trace_on = mode == 1;
+    epa::g_trace_on.store(mode == 1, std::memory_order_relaxed);
     epa::g_trace_len = 0;
     epa::g_trace[0] = 0;
   }

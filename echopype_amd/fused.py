@@ -125,14 +125,22 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
     ds_Sv["echo_range"] = DataArray(cal._lazy_power_range(raw, coef, flags), dims)
     ds_Sv = _finalize_cal_ds(ds_Sv, "Sv", echodata, waveform_mode, encode_mode)
 
+    ds_snap, mv_full = ds_Sv.copy(), res["MVBS"]  # (what the assembly needs, as it is NOW; sums / counts are let go)
+    del res
+
     def build():
         rmax = r_cap if range_var_max is not None else float(rmax_f.item())
         if not np.isfinite(rmax):  # no valid echo_range at all (on any rank): the reference's grid does not exist
             raise ValueError("range bins are empty: the range variable holds no valid values")
         r_edges = np.arange(0, rmax + range_bin_m, range_bin_m)
         n_r = len(r_edges) - 1
-        mvbs_t = res["MVBS"][..., :n_r].contiguous() if n_r != n_cap else res["MVBS"]
-        return _assemble_mvbs(ds_Sv, mvbs_t, "channel", ping_time, e0, dt, n_t, r_edges, "echo_range", range_bin_m,
+        if n_r > n_cap:  # (it must not happen: r_cap bounds every row's reach from above)
+            if _shard is not None:
+                raise RuntimeError(f"nanmax(echo_range) = {rmax} lies beyond the range grid the shards agreed on "
+                                   f"({n_cap} bins of {range_bin_m} m)")
+            return compute_MVBS(ds_snap, **{**mv_kw, "_shard": None})  # binned again from the Sv array, exactly
+        mvbs_t = mv_full[..., :n_r].contiguous() if n_r != n_cap else mv_full
+        return _assemble_mvbs(ds_snap, mvbs_t, "channel", ping_time, e0, dt, n_t, r_edges, "echo_range", range_bin_m,
                               ping_time_bin, "left")
 
     return ds_Sv, (DeferredDataset(build) if defer_mvbs_enabled() else build())

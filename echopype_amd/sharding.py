@@ -61,8 +61,9 @@ _control = {}
 
 def control_group(group=None):
     """The gloo group that carries the host-side scalars of ``group`` (``group`` itself when it is a gloo group).
-    Created on first use -- ``dist.new_group`` is collective over the default group, so the first sharded call must be
-    made by every rank (it is: the entry points are collective anyway)."""
+    Created on first use by the MEMBERS of ``group`` only (``use_local_synchronization``: ``dist.new_group`` otherwise
+    has to be entered by every rank of the default group, and a sub-group's first sharded call is made by its members
+    alone -- the others would never arrive).  ``register_control_group`` hands in one created elsewhere."""
     if not dist.is_initialized():
         return None
     world_pg = dist.distributed_c10d._get_default_group()
@@ -73,9 +74,19 @@ def control_group(group=None):
         ctl = group
     else:
         ranks = dist.get_process_group_ranks(group if group is not None else world_pg)
-        ctl = dist.new_group(ranks=ranks, backend="gloo")
+        ctl = dist.new_group(ranks=ranks, backend="gloo", use_local_synchronization=True)
     _control[group] = (world_pg, ctl)
     return ctl
+
+
+def register_control_group(group, control):
+    """Use ``control`` (a gloo group of exactly the ranks of ``group``, created by the caller) for the host-side scalars
+    of ``group`` instead of creating one on first use."""
+    world_pg = dist.distributed_c10d._get_default_group()
+    want = dist.get_process_group_ranks(group if group is not None else world_pg)
+    if dist.get_backend(control) != "gloo" or dist.get_process_group_ranks(control) != want:
+        raise ValueError("the control group must be a gloo group of the same ranks as the data group")
+    _control[group] = (world_pg, control)
 
 
 def _host_allreduce(values, op, group=None, dtype=torch.int64):

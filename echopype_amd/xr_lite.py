@@ -612,14 +612,19 @@ class DeferredDataset(Dataset):
     def __init__(self, build):  # (Dataset.__init__ is not run: the three containers are the built dataset's)
         self.__dict__["_build"] = build
         self.__dict__["_ds"] = None
+        self.__dict__["_error"] = None
 
     def _resolve(self):
         d = self.__dict__
         if d["_ds"] is None:
             build, d["_build"] = d["_build"], None
-            if build is None:
-                raise RuntimeError("the assembly of this dataset failed earlier")
-            d["_ds"] = build()
+            if build is None:  # the assembly failed at an earlier access: the same error again, not a generic one
+                raise d["_error"]
+            try:
+                d["_ds"] = build()
+            except BaseException as e:
+                d["_error"] = e
+                raise
         return d["_ds"]
 
     @property

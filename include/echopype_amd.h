@@ -73,6 +73,10 @@ enum epa_coef_slot { EPA_CF_RA = 0, EPA_CF_RB = 1, EPA_CF_R0 = 2, EPA_CF_SHIFT =
 
 /* ---- runtime ------------------------------------------------------------------------------------ */
 int epa_version(void);
+/* Hex digest (sha256, 32 characters) of the sources and compiler flags this library was built from
+ * (echopype_amd/build.py:source_digest).  The binding recomputes it from the files beside it at import time and refuses
+ * a library built from other sources: the shipped binary is the shipped code.  No reference counterpart. */
+const char* epa_source_digest(void);
 const char* epa_last_error(void);
 /* Launch trace, test infrastructure: mode 1 clears the calling thread's trace and switches tracing on, mode 0 clears and
  * switches it off, any other mode leaves it as it is.  Returns the "kernel;kernel;..." names of the launches this thread

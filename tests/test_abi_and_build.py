@@ -40,6 +40,31 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert _lib.lib.epa_version() == 101
 
 
+def test_library_carries_the_digest_of_the_sources_it_was_built_from(tmp_path):
+    """epa_source_digest() == build.source_digest() of the tree, and the binding refuses a library whose digest differs
+    (a stale shipped binary cannot answer for newer sources)."""
+    from echopype_amd import _lib
+    from echopype_amd.build import source_digest
+
+    assert _lib.lib.epa_source_digest().decode() == source_digest()
+    assert len(source_digest()) == 32
+    # a source edit changes the digest the binding expects: the check raises
+    import echopype_amd.build as b
+
+    real = b.CSRC
+    fake = tmp_path / "csrc"
+    import shutil
+
+    shutil.copytree(real, fake, ignore=shutil.ignore_patterns("_obj*"))
+    with open(fake / "runtime.hip", "a") as f:
+        f.write("// edited\n")
+    b.CSRC = str(fake)
+    try:
+        assert b.source_digest() != _lib.lib.epa_source_digest().decode()
+    finally:
+        b.CSRC = real
+
+
 def test_library_contains_gfx950_code_object_only():
     from echopype_amd.build import LIBPATH
 

@@ -167,6 +167,34 @@ def test_deferred_error_surfaces_at_first_use(env):
         mv = ep.commongrid.compute_MVBS(ds, range_bin="1m", ping_time_bin="20s")
         with pytest.raises(ValueError, match="range bins are empty"):
             mv["Sv"]
+        # ... and again at every later access: the SAME error, not a generic "failed earlier"
+        with pytest.raises(ValueError, match="range bins are empty"):
+            mv.attrs
+    finally:
+        logging.disable(logging.NOTSET)
+
+
+def test_deferred_result_does_not_follow_later_edits_of_the_input_dataset(env):
+    """What the deferred assembly needs from ds_Sv is taken when compute_MVBS is CALLED: replacing variables or editing
+    attributes of the input afterwards does not change the result (the reference's result never depends on what happens
+    to its input after the call)."""
+    torch, ep = env
+    d, ed = _resident_case(ep)
+    logging.disable(logging.WARNING)
+    try:
+        ds = ep.calibrate.compute_Sv(ed)
+        mv_ref = ep.commongrid.compute_MVBS(ds, range_bin="1m", ping_time_bin="20s")
+        ref_vals, ref_chan = mv_ref["Sv"].values, list(mv_ref["channel"].values)
+        ref_freq = mv_ref["frequency_nominal"].values.copy()
+        ds2 = ep.calibrate.compute_Sv(ed)
+        mv = ep.commongrid.compute_MVBS(ds2, range_bin="1m", ping_time_bin="20s")
+        assert not mv.resolved
+        ds2["frequency_nominal"] = (("channel",), np.zeros(len(ref_chan)))   # edits AFTER the call
+        ds2["Sv"] = (("channel", "ping_time", "range_sample"), np.zeros(ds2["Sv"].shape))
+        ds2.attrs["processing_level"] = "edited"
+        np.testing.assert_array_equal(mv["Sv"].values, ref_vals)
+        np.testing.assert_array_equal(mv["frequency_nominal"].values, ref_freq)
+        assert mv.attrs.get("processing_level") == mv_ref.attrs.get("processing_level")
     finally:
         logging.disable(logging.NOTSET)
 
