@@ -119,10 +119,10 @@ SIGNATURES = {
     "epa_range_step_mean": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "epa_first_not_le": [_vp, _sz, _d, _i, _vp, _vp],
     "epa_range_rows_check": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
-    "epa_sv_noise_fused": [_vp, _vp, _vp, _i, _i, _i, _i, _u, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "epa_sv_noise_fused": [_vp, _vp, _vp, _i, _i, _i, _i, _u, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "epa_denoise_mvbs": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _vp, _vp, _i, _d, _i, _u, _d, _vp, _vp, _vp,
                          _vp, _vp, _i, _vp],
-    "epa_sv_denoise_mvbs": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _i, _d, _vp, _vp, _i, _d, _i, _u, _d, _vp, _vp, _vp,
+    "epa_sv_denoise_mvbs": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _i, _i, _d, _vp, _vp, _i, _d, _i, _u, _d, _vp, _vp, _vp,
                             _vp, _vp, _vp, _vp, _i, _vp],
     "epa_nasc": [_vp, _vp, _i, _i, _i, _vp, _i, _d, _i, _u, _vp, _vp, _vp, _vp, _i, _vp],
     "epa_pool_sv_value": [_vp, _vp, _vp, _i, _i, _i, _d, _i, _d, _d, _d, _i, _d, _vp, _vp, _vp, _i, _vp],

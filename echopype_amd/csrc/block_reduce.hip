@@ -515,13 +515,13 @@ int epa_mvbs_rows_fast_path(const void* sv, const double* coef, int C, int P, in
                             void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype, size_t lds_bytes,
                             unsigned cnt_off, hipStream_t st);
 int epa_chain_fast_pass1(const float* raw, const double* coef, const double* alpha2, int C, int P, int S,
-                         double nspread, int ping_num, int rsn, double noise_max, void* sv_out,
-                         double* noise_out, unsigned long long* rmax_key, unsigned long long* rstat, int dtype,
-                         hipStream_t st);
+                         double nspread, int ping_num, int rsn, int ping_phase, double noise_max, void* sv_out,
+                         double* noise_out, double* edge_sum_out, uint32_t* edge_cnt_out,
+                         unsigned long long* rmax_key, unsigned long long* rstat, int dtype, hipStream_t st);
 int epa_chain_fast_pass2(const float* raw, const double* coef, const double* alpha2, const double* noise, int C,
-                         int P, int S, double nspread, int ping_num, double snr, const int32_t* bin_start,
-                         int n_tbins, double range_bin, int n_rbins, double fill_value, void* noise_out,
-                         void* corr_out, void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
+                         int P, int S, double nspread, int ping_num, int ping_phase, double snr,
+                         const int32_t* bin_start, int n_tbins, double range_bin, int n_rbins, double fill_value,
+                         void* noise_out, void* corr_out, void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
                          size_t lds_acc_bytes, unsigned cnt_off, unsigned long long* mm_keys, hipStream_t st);
 
 namespace {
@@ -616,7 +616,7 @@ int run_mvbs(ReduceArgs& a, hipStream_t st) {
       a.cal_flags == (EPA_FLAG_GUARD_POS | EPA_FLAG_MASK_RANGE) && a.bin_flags == EPA_BIN_SKIPNA &&
       !getenv("EPA_NO_FAST_PATH"))
     return epa_chain_fast_pass2(a.raw, reinterpret_cast<const double*>(a.coef), a.alpha2, a.noise, a.C, a.P, a.S,
-                                a.nspread, a.noise_ping_num, a.snr, a.bin_start, a.n_tbins, a.range_bin,
+                                a.nspread, a.noise_ping_num, a.noise_phase, a.snr, a.bin_start, a.n_tbins, a.range_bin,
                                 a.n_rbins, a.fill_value, a.sv_noise_out, a.sv_out, a.out, a.sum_out, a.cnt_out,
                                 sizeof(T) == 8 ? EPA_F64 : EPA_F32, pl.tab_off, pl.cnt_off, a.mm_keys, st);
   if (SRC == SRC_SV && !a.range && a.coef && !two_stage && pl.vec == 4 && !a.ping_perm &&
@@ -966,18 +966,19 @@ extern "C" int epa_noise_finalize(const double* sum, const double* cnt, int rows
 namespace {
 template <typename T>
 int run_sv_noise(const float* raw, const double* coef, const double* alpha2, int C, int P, int S,
-                 double nspread, unsigned cal_flags, int ping_num, int rsn, double noise_max, void* sv_out,
-                 void* range_out, double* noise_out, double* range_max_out, double* range_stats_out, int* stats_filled,
-                 hipStream_t st) {
-  const int Pb = (P + ping_num - 1) / ping_num, Sb = (S + rsn - 1) / rsn;
+                 double nspread, unsigned cal_flags, int ping_num, int rsn, int ping_phase, double noise_max,
+                 void* sv_out, void* range_out, double* noise_out, double* edge_sum_out, uint32_t* edge_cnt_out,
+                 double* range_max_out, double* range_stats_out, int* stats_filled, hipStream_t st) {
+  const int Pb = (P + ping_phase + ping_num - 1) / ping_num, Sb = (S + rsn - 1) / rsn;
   ReduceArgs a{};
   a.raw = raw; a.coef = reinterpret_cast<const epa::CoefRow*>(coef); a.alpha2 = alpha2;
   a.C = C; a.P = P; a.S = S; a.nspread = nspread; a.cal_flags = cal_flags;
-  a.bin_start = nullptr; a.n_tbins = Pb; a.ping_num = ping_num;
+  a.bin_start = nullptr; a.n_tbins = Pb; a.ping_num = ping_num; a.ping_phase = ping_phase;
   a.bin_mode = BIN_INDEX; a.range_bin = 1.0; a.inv_range_bin = 1.0; a.n_rbins = Sb;
   a.range_sample_num = rsn; a.bin_flags = EPA_BIN_SKIPNA;
   a.fill_value = __builtin_nan(""); a.noise_max = noise_max;
   a.sv_out = sv_out; a.range_out = range_out; a.out = noise_out; a.range_max_out = range_max_out;
+  a.edge_sum_out = edge_sum_out; a.edge_cnt_out = edge_cnt_out;
   Plan pl = make_plan<T>(C, P, S, Pb, Sb, al16(raw) && al16(sv_out) && al16(range_out));
   pl.nparts = 1;
   a.nparts = 1;
@@ -985,7 +986,8 @@ int run_sv_noise(const float* raw, const double* coef, const double* alpha2, int
   if (pl.vec == 4 && !range_out && cal_flags == (EPA_FLAG_GUARD_POS | EPA_FLAG_MASK_RANGE) &&
       !getenv("EPA_NO_FAST_PATH")) {
     *stats_filled = range_stats_out != nullptr;
-    return epa_chain_fast_pass1(raw, coef, alpha2, C, P, S, nspread, ping_num, rsn, noise_max, sv_out, noise_out,
+    return epa_chain_fast_pass1(raw, coef, alpha2, C, P, S, nspread, ping_num, rsn, ping_phase, noise_max, sv_out,
+                                noise_out, edge_sum_out, edge_cnt_out,
                                 reinterpret_cast<unsigned long long*>(range_max_out),
                                 reinterpret_cast<unsigned long long*>(range_stats_out),
                                 sizeof(T) == 8 ? EPA_F64 : EPA_F32, st);
@@ -996,12 +998,16 @@ int run_sv_noise(const float* raw, const double* coef, const double* alpha2, int
 
 extern "C" int epa_sv_noise_fused(const float* raw, const double* coef, const double* alpha2, int C, int P,
                                   int S, int cal_type, unsigned cal_flags, int ping_num,
-                                  int range_sample_num, double noise_max, void* sv_out, void* range_out,
-                                  double* noise_out, double* range_max_out, double* range_stats_out, int dtype,
-                                  epa_stream_t stream) {
+                                  int range_sample_num, int ping_phase, double noise_max, void* sv_out,
+                                  void* range_out, double* noise_out, double* edge_sum_out, uint32_t* edge_cnt_out,
+                                  double* range_max_out, double* range_stats_out, int dtype, epa_stream_t stream) {
   EPA_CHECK_ARG(raw && coef && alpha2 && noise_out, "epa_sv_noise_fused: NULL array argument");
   EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && ping_num > 0 && range_sample_num > 0,
                 "epa_sv_noise_fused: sizes must be positive");
+  EPA_CHECK_ARG(ping_phase >= 0 && ping_phase < ping_num, "epa_sv_noise_fused: ping_phase %d not in [0, %d)",
+                ping_phase, ping_num);
+  EPA_CHECK_ARG((edge_sum_out == nullptr) == (edge_cnt_out == nullptr),
+                "epa_sv_noise_fused: edge_sum_out and edge_cnt_out come together");
   EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_sv_noise_fused: bad cal_type");
   const double nspread = cal_type == EPA_CAL_SV ? 20.0 : 40.0;
   EPA_CHECK_ARG(dtype == EPA_F64 || dtype == EPA_F32, "epa_sv_noise_fused: bad dtype %d", dtype);
@@ -1009,10 +1015,12 @@ extern "C" int epa_sv_noise_fused(const float* raw, const double* coef, const do
   if (int rc0 = init_range_outputs(range_max_out, range_stats_out, (hipStream_t)stream)) return rc0;
   int filled = 0;
   const int rc = dtype == EPA_F64
-      ? run_sv_noise<double>(raw, coef, alpha2, C, P, S, nspread, cal_flags, ping_num, range_sample_num, noise_max,
-                             sv_out, range_out, noise_out, range_max_out, range_stats_out, &filled, (hipStream_t)stream)
-      : run_sv_noise<float>(raw, coef, alpha2, C, P, S, nspread, cal_flags, ping_num, range_sample_num, noise_max,
-                            sv_out, range_out, noise_out, range_max_out, range_stats_out, &filled, (hipStream_t)stream);
+      ? run_sv_noise<double>(raw, coef, alpha2, C, P, S, nspread, cal_flags, ping_num, range_sample_num, ping_phase,
+                             noise_max, sv_out, range_out, noise_out, edge_sum_out, edge_cnt_out, range_max_out,
+                             range_stats_out, &filled, (hipStream_t)stream)
+      : run_sv_noise<float>(raw, coef, alpha2, C, P, S, nspread, cal_flags, ping_num, range_sample_num, ping_phase,
+                            noise_max, sv_out, range_out, noise_out, edge_sum_out, edge_cnt_out, range_max_out,
+                            range_stats_out, &filled, (hipStream_t)stream);
   epa::note_range_stats_filled(rc == EPA_OK && range_stats_out && filled ? 1 : 0);
   if (rc == EPA_OK && range_max_out) {
     // (the fast kernel tracks the values as stored: no rounding left to do)
@@ -1051,18 +1059,21 @@ extern "C" int epa_denoise_mvbs(const void* sv, const void* range, const double*
 
 extern "C" int epa_sv_denoise_mvbs(const float* raw, const double* coef, const double* alpha2,
                                    const double* noise, int C, int P, int S, int cal_type, unsigned cal_flags,
-                                   int ping_num, double snr_threshold, const int32_t* bin_start,
+                                   int ping_num, int ping_phase, double snr_threshold, const int32_t* bin_start,
                                    const int32_t* ping_perm, int n_tbins, double range_bin, int n_rbins,
                                    unsigned bin_flags, double fill_value, void* sv_noise_out,
                                    void* sv_corrected_out, void* range_out, void* mvbs_out, void* sum_out,
                                    uint32_t* cnt_out, double* minmax_out, int dtype, epa_stream_t stream) {
   EPA_CHECK_ARG(raw && coef && alpha2 && noise && mvbs_out, "epa_sv_denoise_mvbs: NULL array argument");
   EPA_CHECK_ARG(C > 0 && P > 0 && S > 0 && ping_num > 0, "epa_sv_denoise_mvbs: sizes must be positive");
+  EPA_CHECK_ARG(ping_phase >= 0 && ping_phase < ping_num, "epa_sv_denoise_mvbs: ping_phase %d not in [0, %d)",
+                ping_phase, ping_num);
   EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_sv_denoise_mvbs: bad cal_type");
   if (int rc = check_bins("epa_sv_denoise_mvbs", bin_start, n_tbins, range_bin, n_rbins)) return rc;
   ReduceArgs a{};
   a.raw = raw; a.coef = reinterpret_cast<const epa::CoefRow*>(coef);
-  a.alpha2 = alpha2; a.noise = noise; a.noise_ping_num = ping_num; a.n_pblocks = (P + ping_num - 1) / ping_num;
+  a.alpha2 = alpha2; a.noise = noise; a.noise_ping_num = ping_num; a.noise_phase = ping_phase;
+  a.n_pblocks = (P + ping_phase + ping_num - 1) / ping_num;
   a.snr = snr_threshold;
   a.C = C; a.P = P; a.S = S;
   a.nspread = cal_type == EPA_CAL_SV ? 20.0 : 40.0;

@@ -31,6 +31,11 @@ struct Args {
   // pass 1
   int ping_num, rsn, n_pblocks, n_rblocks;
   double noise_max;
+  // a ping shard of a longer file: local ping p belongs to noise block (p + ping_phase) / ping_num (both passes); pass 1
+  // also leaves the raw (sum, count) rows of its first / last block for the cross-shard merge (epa_noise_estimate's layout)
+  int ping_phase;
+  double* edge_sum;
+  uint32_t* edge_cnt;
   // pass 2
   int n_tbins, n_rbins, noise_ping_num;
   double range_bin, inv_range_bin, fill_value, snr;
@@ -269,7 +274,8 @@ __global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 4 : 1) void sv_noise_
   const float* __restrict__ raw_c = raw + (size_t)c * a.P * S;
   T* __restrict__ sv_c = WRITE_SV ? sv_out + (size_t)c * a.P * S : nullptr;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int pb = pbk0 * a.ping_num, pe = min(a.P, pb + nb * a.ping_num);
+  // (a shard whose first ping is ping_phase pings into its first block: that block is shorter by as much)
+  const int pb = max(0, pbk0 * a.ping_num - a.ping_phase), pe = min(a.P, (pbk0 + nb) * a.ping_num - a.ping_phase);
   double xmax = -__builtin_inf(), xmin = __builtin_inf();
   unsigned nnan = 0u;
   __shared__ T plog[kPingLogs];
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 4 : 1) void sv_noise_
     epa::CoefRow nxtR = rowp0[pb];
     nA = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sA);
     if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sB);
-    int left = a.ping_num, g = 0;  // pings left in the current ping block
+    int left = pbk0 == 0 ? a.ping_num - a.ping_phase : a.ping_num, g = 0;  // pings left in the current ping block
     for (int p = pb; p < pe; ++p) {
       const epa::CoefRow r = nxtR;
       const size_t row_off = (size_t)p * S;
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 4 : 1) void sv_noise_
         left = a.ping_num;
       }
     }
-    if (left != a.ping_num) flush(g);  // the last, shorter ping block of the array
+    if (g < nb) flush(g);  // the last, shorter ping block of the array (nothing left in the columns otherwise)
   }
   if (RMAX) {
 #pragma unroll
@@ -401,6 +407,13 @@ __global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 4 : 1) void sv_noise_
   // min over the range blocks of 10 log10(block mean) (clean/api.py:402-411), optional clamp (:418-422)
   for (int g = 0; g < nb; ++g) {
     __syncthreads();  // the sums are complete / the previous block's `red` is consumed
+    if (a.edge_sum && (pbk0 + g == 0 || pbk0 + g == a.n_pblocks - 1)) {  // (uniform) rows for the cross-shard merge
+      const size_t e0 = ((size_t)(pbk0 + g == 0 ? 0 : 1) * gridDim.y + c) * Sb;  // (a single block: its first edge only)
+      for (int i = threadIdx.x; i < Sb; i += epa::kBlock) {
+        a.edge_sum[e0 + i] = (double)lsum[g * Sb + i];
+        a.edge_cnt[e0 + i] = lcnt[g * Sb + i];
+      }
+    }
     T best = (T)__builtin_inf();
     int any = 0;
     for (int i = threadIdx.x; i < Sb; i += epa::kBlock) {
@@ -501,7 +514,7 @@ __global__ __launch_bounds__(epa::kBlock, 3) void sv_denoise_mvbs_fast_kernel(
   const int pe = extra ? (seg == 0 ? bin_start[0] : a.P) : bin_start[tb + 1];
   __syncthreads();  // all wavefronts are done with the previous segment's logs
   fill_ping_logs<T>(plog, rowp0 + pb, pe - pb, mt.log_tab);
-  if (kProd) fill_ping_consts(pcs, rowp0 + pb, a2p + pb, nzp, pb, pe - pb, a.noise_ping_num, mt.exp2_tab);
+  if (kProd) fill_ping_consts(pcs, rowp0 + pb, a2p + pb, nzp, pb + a.ping_phase, pe - pb, a.noise_ping_num, mt.exp2_tab);
   __syncthreads();
   for (int chunk0 = 0; chunk0 < S; chunk0 += kChunk) {
     const int sA = chunk0 + wave * 256 + 2 * lane, sB = sA + 128;
@@ -533,7 +546,7 @@ __global__ __launch_bounds__(epa::kBlock, 3) void sv_denoise_mvbs_fast_kernel(
       }
       rc.update(r, col, sA, sB, nspread, mt.log_tab, plog, p - pb);
       const T g = (T)r.g, a2 = (T)r.alpha2, A0 = (T)r.A0, na2 = (T)a2p[p];
-      const T nb = (T)nzp[p / a.noise_ping_num];
+      const T nb = (T)nzp[(p + a.ping_phase) / a.noise_ping_num];
       const float in[VEC] = {inA.x, inA.y, inB.x, inB.y};
       T sn[VEC], sc[VEC];
       // product form (fp64): per-ping constants, E at the lane's first column, ratios to the other three
@@ -716,7 +729,7 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_uniform_kernel
     const bool same = (ri.ra == r.ra) & (ri.rb == r.rb) & (ri.r0 == r.r0) & (ri.shift == r.shift) & (ri.d == r.d) &
                       (a2i == na2) & (ri.alpha2 == a2i);
     if (!same) differs = 1;
-    const double nbi = nzp[p / a.noise_ping_num];
+    const double nbi = nzp[(p + a.ping_phase) / a.noise_ping_num];
     pl[threadIdx.x] = PingLin{ri.g, epa::lin_from_db(ri.A0 - ri.alpha2 * ri.shift + ri.alpha2 * ri.r0, mt.exp2_tab),
                               epa::lin_from_db(nbi + a2i * ri.r0, mt.exp2_tab), nbi};
   }
@@ -934,7 +947,7 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
     if (!same) differs = 1;
     atomicMin(&rb_lo_key, ordered_key(ri.rb));
     atomicMax(&rb_hi_key, ordered_key(ri.rb));
-    const double nbi = nzp[p / a.noise_ping_num];
+    const double nbi = nzp[(p + a.ping_phase) / a.noise_ping_num];
     const double a2k = a2i * ki;
     const double cn = epa::lin_from_db(nbi, mt.exp2_tab);
     const double q1 = epa::lin_from_db(a2k, mt.exp2_tab), q128 = epa::lin_from_db(128.0 * a2k, mt.exp2_tab);
@@ -1281,13 +1294,14 @@ int launch_pass2(Args& a, const float* raw, const double* coef, const double* al
 
 // Called by epa_sv_noise_fused (block_reduce.hip) when the fast path applies.
 int epa_chain_fast_pass1(const float* raw, const double* coef, const double* alpha2, int C, int P, int S,
-                         double nspread, int ping_num, int rsn, double noise_max, void* sv_out,
-                         double* noise_out, unsigned long long* rmax_key, unsigned long long* rstat, int dtype,
-                         hipStream_t st) {
+                         double nspread, int ping_num, int rsn, int ping_phase, double noise_max, void* sv_out,
+                         double* noise_out, double* edge_sum_out, uint32_t* edge_cnt_out,
+                         unsigned long long* rmax_key, unsigned long long* rstat, int dtype, hipStream_t st) {
   epa_chain::Args a{};
   a.P = P; a.S = S; a.nspread = nspread;
-  a.ping_num = ping_num; a.rsn = rsn;
-  a.n_pblocks = (P + ping_num - 1) / ping_num; a.n_rblocks = (S + rsn - 1) / rsn;
+  a.ping_num = ping_num; a.rsn = rsn; a.ping_phase = ping_phase;
+  a.edge_sum = edge_sum_out; a.edge_cnt = edge_cnt_out;
+  a.n_pblocks = (P + ping_phase + ping_num - 1) / ping_num; a.n_rblocks = (S + rsn - 1) / rsn;
   a.noise_max = noise_max; a.rmax_key = rmax_key; a.rstat = rmax_key ? rstat : nullptr;
   a.xcd_map = epa::xcd_map_enabled() ? 1 : 0;
   if (dtype == EPA_F64) return epa_chain::launch_pass1<double>(a, raw, coef, alpha2, sv_out, noise_out, C, st);
@@ -1296,13 +1310,14 @@ int epa_chain_fast_pass1(const float* raw, const double* coef, const double* alp
 
 // Called by epa_sv_denoise_mvbs (block_reduce.hip) when the fast path applies.
 int epa_chain_fast_pass2(const float* raw, const double* coef, const double* alpha2, const double* noise, int C,
-                         int P, int S, double nspread, int ping_num, double snr, const int32_t* bin_start,
+                         int P, int S, double nspread, int ping_num, int ping_phase, double snr, const int32_t* bin_start,
                          int n_tbins, double range_bin, int n_rbins, double fill_value, void* noise_out,
                          void* corr_out, void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
                          size_t lds_acc_bytes, unsigned cnt_off, unsigned long long* mm_keys, hipStream_t st) {
   epa_chain::Args a{};
   a.P = P; a.S = S; a.nspread = nspread;
-  a.noise_ping_num = ping_num; a.n_pblocks = (P + ping_num - 1) / ping_num; a.snr = snr;
+  a.noise_ping_num = ping_num; a.ping_phase = ping_phase; a.n_pblocks = (P + ping_phase + ping_num - 1) / ping_num;
+  a.snr = snr;
   a.n_tbins = n_tbins; a.n_rbins = n_rbins; a.range_bin = range_bin; a.inv_range_bin = 1.0 / range_bin;
   a.fill_value = fill_value; a.cnt_off = cnt_off; a.mm_keys = mm_keys;
   a.xcd_map = epa::xcd_map_enabled() ? 1 : 0;

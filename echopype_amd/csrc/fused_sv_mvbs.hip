@@ -61,13 +61,48 @@ struct Column {
   __device__ __forceinline__ void init() {
     sra = 0.0; blo = 1.0; bhi = 0.0; nL = epa::M<T>::nan(); acc_sum = (T)0; acc_rb = -1; acc_cnt = 0u;
   }
-  __device__ __forceinline__ void flush(T* lsum, uint32_t* lcnt) {
-    if (acc_rb >= 0 && acc_cnt > 0u) {
+  // ``n_clean``: the pings of this chunk the whole wavefront took on the lean path so far (a scalar: every column of
+  // every lane got one valid value from each of them).  A column counts only what the general path added, relative to
+  // the scalar's value when the column last changed its bin: values in the bin = acc_cnt + n_clean (mod 2^32).
+  __device__ __forceinline__ void flush(T* lsum, uint32_t* lcnt, uint32_t n_clean) {
+    const uint32_t n = acc_cnt + n_clean;
+    if (acc_rb >= 0 && n > 0u) {
       lds_add(lsum + acc_rb, acc_sum);
-      atomicAdd(lcnt + acc_rb, acc_cnt);
+      atomicAdd(lcnt + acc_rb, n);
     }
   }
+  // the column has left the range bin it sat in: find the new one (``valid`` false: a NaN raw sample, parked outside)
+  __device__ __forceinline__ void rebin(double x, bool valid, double bin, double inv_bin, int n_rbins, T* lsum,
+                                        uint32_t* lcnt, uint32_t n_clean) {
+    const int rb = valid ? epa::range_bin_index(x, bin, inv_bin, n_rbins, false) : -1;
+    if (rb != acc_rb) {
+      flush(lsum, lcnt, n_clean);
+      acc_rb = rb;
+      acc_sum = (T)0;
+      acc_cnt = 0u - n_clean;
+    }
+    blo = rb >= 0 ? (double)rb * bin : 1.0;
+    bhi = rb >= 0 ? (double)(rb + 1) * bin : 0.0;
+  }
 };
+
+// 10^(u/10) for the BIN sums of the lean path: the argument reduction in one word and a third-degree polynomial on the
+// 256-entry table -- 2e-13 relative (z^4/24 with |z| <= ln(2)/512, plus |u| * 1.2e-17 for the dropped low word of
+// 256 log2(10)/10), five instructions fewer than lin_from_db_lean's 4e-16.  A mean of such values in dB is off by less
+// than 1e-12 dB; the Sv array never goes through it.  Finite arguments only (the lean path's precondition).
+__device__ __forceinline__ double lin_bins(double u, const double* __restrict__ tab) {
+  constexpr double K256 = 85.04135922911648, Z = 0.0027076061740622863;
+  constexpr double C1 = Z, C2 = Z * Z / 2.0, C3 = Z * Z * Z / 6.0;
+  const double t = u * K256;
+  const double m = __builtin_rint(t);
+  const double r = fma(u, K256, -m);
+  double p = fma(r, C3, C2);
+  p = fma(p, r, C1);
+  p = fma(p, r, 1.0);
+  const int mi = __double2int_rz(m);
+  return ldexp(p * tab[mi & 255], mi >> 8);
+}
+__device__ __forceinline__ float lin_bins(float u, const double*) { return ::exp10f(u * 0.1f); }
 
 // v_max that returns the operand that is a number (IEEE maxNum), without the canonicalising copy fmax() adds
 __device__ __forceinline__ double vmax_num(double a, double b) {
@@ -96,7 +131,7 @@ template <typename T, bool STATS>
 __device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::CoefRow& r, double r0v, T g, T a2,
                                             T A0v, T nL, T nspread, double bin, double inv_bin, int n_rbins,
                                             const double* tab, T* lsum, uint32_t* lcnt, double& xmax, double& xmin,
-                                            unsigned& nnan) {
+                                            unsigned& nnan, uint32_t n_clean) {
   const T NaN = epa::M<T>::nan();
   const double x = fma(c.sra, r.rb, r0v);  // echo_range = (s*ra)*rb [+0]
   if (STATS) {
@@ -119,23 +154,81 @@ __device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::
   // still inside the bin of the previous ping?  (A NaN raw sample makes Sv and v NaN: it is never accumulated, whatever
   // bin the column sits in; the slow path below still parks such a column outside the grid.)
   const bool same = (x >= c.blo) & (x < c.bhi);
-  if (!same) {
-    const int rb = raw == raw ? epa::range_bin_index(x, bin, inv_bin, n_rbins, false) : -1;
-    if (rb != c.acc_rb) {
-      c.flush(lsum, lcnt);
-      c.acc_rb = rb;
-      c.acc_sum = (T)0;
-      c.acc_cnt = 0u;
-    }
-    c.blo = rb >= 0 ? (double)rb * bin : 1.0;
-    c.bhi = rb >= 0 ? (double)(rb + 1) * bin : 0.0;
-  }
+  if (!same) c.rebin(x, raw == raw, bin, inv_bin, n_rbins, lsum, lcnt, n_clean);
   // (a column outside the grid, acc_rb < 0, accumulates too: flush() drops it.)  v >= 0 or NaN: max(v, 0) adds nothing
   // for a NaN
   c.acc_sum += vmax_num(v, (T)0);
   c.acc_cnt += v == v ? 1u : 0u;
   return sv;
 }
+
+// ---- one PAIR of samples of a ping, lean unless the wavefront found the ping not clean ------------------------------------
+// ``clean`` (a scalar, established per ping by the kernel): every raw sample of the wavefront is a finite number, every
+// cached n log10(s - d) is finite and R' > 0 for every lane.  Then none of process_sample's per-sample NaN handling is
+// needed -- no guard select, no rounding-residue test, no max(v, 0), no count (the ping is counted once, in a scalar
+// register), no inf test around the exponential, {min, max} of the echo_range taken once per ping by the caller.  A ping
+// that is not clean (NaN padding, the first samples of a row, a NaN row) runs the SAME body with the general forms
+// patched in by wave-uniform branches: one instruction stream, the registers of one.  The Sv arithmetic is
+// process_sample's, operation for operation, on either side of the branches: the same bits.
+template <typename T, bool STATS, bool WRITE_SV>
+__device__ __forceinline__ void process_pair(Column<T>& c0, Column<T>& c1, float2 in, bool clean, const epa::CoefRow& r,
+                                             double r0v, T g, T a2, T A0v, T nL0, T nL1, T nspread, double bin,
+                                             double inv_bin, int n_rbins, const double* tab, T* lsum, uint32_t* lcnt,
+                                             T* __restrict__ sv_dst, double& xmax, double& xmin, unsigned& nnan,
+                                             uint32_t n_clean, double& xfirst, double& xlast) {
+  const double x0 = fma(c0.sra, r.rb, r0v), x1 = fma(c1.sra, r.rb, r0v);  // echo_range = (s*ra)*rb [+0]
+  const double rtd0 = x0 - r.shift, rtd1 = x1 - r.shift;
+  const T rt0 = (T)rtd0, rt1 = (T)rtd1;
+  T s10 = fma(g, (T)in.x, nL0), s11 = fma(g, (T)in.y, nL1);
+  if (!clean) {  // (scalar) R' <= 0 guard, rounding residue of R - shift, {min, max, NaN count} per sample
+    const T NaN = epa::M<T>::nan();
+    const bool pos0 = rtd0 > 0.0, pos1 = rtd1 > 0.0;
+    if (pos0 & !(nL0 > -(T)__builtin_inf()))
+      s10 = fma(g, (T)in.x, nspread * (log10_slow<T>(rt0) - log10_slow<T>((T)(r.ra * r.rb))));
+    if (pos1 & !(nL1 > -(T)__builtin_inf()))
+      s11 = fma(g, (T)in.y, nspread * (log10_slow<T>(rt1) - log10_slow<T>((T)(r.ra * r.rb))));
+    s10 = pos0 ? s10 : NaN;
+    s11 = pos1 ? s11 : NaN;
+    if (STATS) {  // x + 0 * raw is the range or NaN; v_max_f64 / v_min_f64 return the operand that is a number
+      const double xq0 = fma((double)in.x, 0.0, x0), xq1 = fma((double)in.y, 0.0, x1);
+      xmax = vmax_num(vmax_num(xmax, xq0), xq1);
+      xmin = vmin_num(vmin_num(xmin, xq0), xq1);
+      nnan += (unsigned)__builtin_popcountll(__ballot(in.x != in.x)) + (unsigned)__builtin_popcountll(__ballot(in.y != in.y));
+    }
+  }
+  const T sv0 = s10 + fma(a2, rt0, A0v), sv1 = s11 + fma(a2, rt1, A0v);
+  if (WRITE_SV) {
+#ifndef EPA_PLAIN_STORES  // streaming (nt) stores: +2 % at 4 G samples, Sv is never re-read here
+    epa::store_nt2(sv_dst, sv0, sv1);
+#else
+    const T o[2] = {sv0, sv1};
+    epa::store_vec<T, 2>(sv_dst, o);
+#endif
+  }
+  T v0 = lin_bins(sv0, tab), v1 = lin_bins(sv1, tab);
+  if (!clean) {  // (scalar) +-inf goes through lin_bins as NaN: 10^(+inf) = +inf, 10^(-inf) = 0
+    if (__builtin_expect(__builtin_isinf(sv0), 0)) v0 = sv0 < (T)0 ? (T)0 : sv0;
+    if (__builtin_expect(__builtin_isinf(sv1), 0)) v1 = sv1 < (T)0 ? (T)0 : sv1;
+  }
+  // still inside the bin of the previous ping?  (A NaN raw sample makes Sv and v NaN: it is never accumulated, whatever
+  // bin the column sits in; rebin still parks such a column outside the grid.)
+  if (!((x0 >= c0.blo) & (x0 < c0.bhi))) c0.rebin(x0, in.x == in.x, bin, inv_bin, n_rbins, lsum, lcnt, n_clean);
+  if (!((x1 >= c1.blo) & (x1 < c1.bhi))) c1.rebin(x1, in.y == in.y, bin, inv_bin, n_rbins, lsum, lcnt, n_clean);
+  if (clean) {
+    c0.acc_sum += v0;
+    c1.acc_sum += v1;
+  } else {  // v >= 0 or NaN: max(v, 0) adds nothing for a NaN (a column outside the grid accumulates too: flush drops it)
+    c0.acc_sum += vmax_num(v0, (T)0);
+    c1.acc_sum += vmax_num(v1, (T)0);
+    c0.acc_cnt += v0 == v0 ? 1u : 0u;
+    c1.acc_cnt += v1 == v1 ? 1u : 0u;
+  }
+  xfirst = x0;
+  xlast = x1;
+}
+
+// raw sample that is NaN or +-inf (v_cmp_class_f32: signalling / quiet NaN, -inf, +inf)
+__device__ __forceinline__ bool not_finite(float x) { return __builtin_amdgcn_classf(x, 0x207); }
 
 // Raw-sample sources.  float: backscatter_r as the converter stores it (f32, NaN-padded,
 // convert/parse_base.py:302).  int16_t: the instrument's own power samples:
@@ -199,8 +292,11 @@ struct PingLoad<int16_t> {
 #ifndef EPA_FUSED_MIN_WAVES
 #define EPA_FUSED_MIN_WAVES 1
 #endif
+#ifndef EPA_FUSED_LEAN  // development knob: 0 = every ping takes the general per-sample path (the round-4 kernel)
+#define EPA_FUSED_LEAN 1
+#endif
 template <typename T, typename RawT, bool WRITE_SV, bool RMAX>
-__global__ __launch_bounds__(epa::kBlock, RMAX ? 4 : EPA_FUSED_MIN_WAVES) void fused_sv_mvbs_kernel(
+__global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES > 4 ? EPA_FUSED_MIN_WAVES : 4) void fused_sv_mvbs_kernel(
     const RawT* __restrict__ raw, const int32_t* __restrict__ n_valid,
     const epa::CoefRow* __restrict__ coef,
     const int32_t* __restrict__ bin_start, T* __restrict__ sv_out, T* __restrict__ mvbs_out,
@@ -210,10 +306,11 @@ __global__ __launch_bounds__(epa::kBlock, RMAX ? 4 : EPA_FUSED_MIN_WAVES) void f
   uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + a.cnt_off);
   const epa::MathTabs mt = epa::build_math_tabs(smem + a.tab_off);  // synchronised below
   const double* tab = mt.exp2_tab;
-  // The statistics variant keeps a column's cached n log10(s - d) in LDS, every lane its own four entries (written
-  // and read by the same lane: no barrier), instead of eight registers: the five registers of the running {min, max,
-  // NaN count} then fit four wavefronts per SIMD without scratch.
-  __shared__ T col_nL[RMAX ? kChunk : 1];
+  // A column's cached n log10(s - d) lives in LDS, every lane its own four entries (written and read by the same lane:
+  // no barrier), instead of eight registers: four wavefronts per SIMD without scratch.  The float instances without
+  // the statistics have the registers to spare (measured round 5: 6.4-6.5 ms with the LDS reads, 6.0-6.3 without).
+  constexpr bool NL_LDS = RMAX || sizeof(T) == 8;
+  __shared__ T col_nL[NL_LDS ? kChunk : 1];
 
   const int c = blockIdx.y, tb = a.xcd_map ? epa::xcd_contiguous(blockIdx.x, a.n_tbins) : (int)blockIdx.x;
   const int S = a.S, n_rbins = a.n_rbins;
@@ -250,10 +347,14 @@ __global__ __launch_bounds__(epa::kBlock, RMAX ? 4 : EPA_FUSED_MIN_WAVES) void f
 #pragma unroll
     for (int j = 0; j < VEC; ++j) col[j].init();
     const int eA = wave * 256 + 2 * lane;  // the lane's entries of col_nL: eA, eA + 1, eA + 128, eA + 129
-    if (RMAX) {
+    if (NL_LDS) {
       col_nL[eA] = col_nL[eA + 1] = col_nL[eA + 128] = col_nL[eA + 129] = epa::M<T>::nan();
     }
-    double dcur = __builtin_nan(""), racur = __builtin_nan("");
+    // (compared as BITS, in scalar registers: a float compare of two scalars is two vector instructions per ping; the
+    //  initial pattern is a NaN payload no row holds)
+    long long dcur = 0x7ff8dead00000001ll, racur = 0x7ff8dead00000002ll;
+    uint32_t n_clean = 0u;  // (scalar) pings of this chunk the wavefront took on the lean path
+    bool plain = false;     // (scalar) every cached n log10(s - d) of the wavefront is a finite number
     // software prefetch: the raw samples and the coefficient row of ping p+1 are requested before
     // ping p is processed, so their latency hides behind ~150 instructions of arithmetic (+8 %)
     const int s4 = chunk0 + wave * 256 + 4 * lane;  // (a source that loads quads: unused by the present ones)
@@ -270,46 +371,55 @@ __global__ __launch_bounds__(epa::kBlock, RMAX ? 4 : EPA_FUSED_MIN_WAVES) void f
         nxtR = rowp0[p + 1];
         nxt.issue(raw_c + row_off + S, sA, sB, hasB, s4, S);
       }
-      if (!((r.d == dcur) & (r.ra == racur))) {  // uniform; once per column for a file with
-        dcur = r.d;                               // constant tau / sample_interval
-        racur = r.ra;
+      if (!((__double_as_longlong(r.d) == dcur) & (__double_as_longlong(r.ra) == racur))) {  // uniform; once per column
+        dcur = __double_as_longlong(r.d);                     // for a file with constant tau / sample_interval
+        racur = __double_as_longlong(r.ra);
+        bool fin = true;
         for (int j = 0; j < VEC; ++j) {
           const double sj = (double)((j < 2 ? sA : sB) + (j & 1));
           const T nl = nspread * log10_slow<T>((T)(sj - r.d));
-          if (RMAX) col_nL[eA + (j < 2 ? 0 : 128) + (j & 1)] = nl;  // (the statistics variant: see col_nL)
+          if (NL_LDS) col_nL[eA + (j < 2 ? 0 : 128) + (j & 1)] = nl;  // (see col_nL)
           else col[j].nL = nl;
           col[j].sra = sj * r.ra;
+          fin = fin & ((j >= 2 && !hasB) | (fabs(nl) < (T)__builtin_inf()));
         }
+        plain = __ballot(!fin) == 0ull;
       }
       const T g = (T)r.g, a2 = (T)r.alpha2;
       T A0 = (T)r.A0;
       double r0v = r.r0;
       asm volatile("" : "+v"(A0), "+v"(r0v));  // one copy per ping into vector registers, not one per sample
-      const T sv0 = process_sample<T, RMAX>(col[0], inA.x, r, r0v, g, a2, A0, RMAX ? col_nL[eA] : col[0].nL, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax, xmin, nnan);
-      const T sv1 = process_sample<T, RMAX>(col[1], inA.y, r, r0v, g, a2, A0, RMAX ? col_nL[eA + 1] : col[1].nL, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax, xmin, nnan);
-      if (WRITE_SV) {
-#ifndef EPA_PLAIN_STORES  // streaming (nt) stores: +2 % at 4 G samples, Sv is never re-read here
-        epa::store_nt2(sv_c + row_off + sA, sv0, sv1);
-#else
-        const T o[2] = {sv0, sv1};
-        epa::store_vec<T, 2>(sv_c + row_off + sA, o);
-#endif
+      // Is the ping CLEAN for this wavefront -- every raw sample finite, R' > 0 at the lane's first column (then at all
+      // of them: the range grows with the sample number when ra, rb > 0; a NaN row fails the test), the cached logs
+      // finite?  Then process_pair takes its lean form (about half the instructions).
+      bool clean = false;
+#if EPA_FUSED_LEAN
+      {
+        const double xa = fma(col[0].sra, r.rb, r0v);
+        const bool bad = not_finite(inA.x) | not_finite(inA.y) | not_finite(inB.x) | not_finite(inB.y) |
+                         !(xa - r.shift > 0.0);
+        const bool kpos = (__double2hiint(r.ra) > 0) & (__double2hiint(r.rb) > 0);  // (scalar) ra, rb > 0
+        clean = plain & kpos & (__ballot(bad) == 0ull);
       }
-      if (hasB) {
-        const T sv2 = process_sample<T, RMAX>(col[2], inB.x, r, r0v, g, a2, A0, RMAX ? col_nL[eA + 128] : col[2].nL, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax, xmin, nnan);
-        const T sv3 = process_sample<T, RMAX>(col[3], inB.y, r, r0v, g, a2, A0, RMAX ? col_nL[eA + 129] : col[3].nL, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt, xmax, xmin, nnan);
-        if (WRITE_SV) {
-#ifndef EPA_PLAIN_STORES  // streaming (nt) stores: +2 % at 4 G samples, Sv is never re-read here
-          epa::store_nt2(sv_c + row_off + sB, sv2, sv3);
-#else
-          const T o[2] = {sv2, sv3};
-          epa::store_vec<T, 2>(sv_c + row_off + sB, o);
 #endif
+      double xf, xl, xdummy;
+      process_pair<T, RMAX, WRITE_SV>(col[0], col[1], inA, clean, r, r0v, g, a2, A0, NL_LDS ? col_nL[eA] : col[0].nL,
+                                      NL_LDS ? col_nL[eA + 1] : col[1].nL, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt,
+                                      WRITE_SV ? sv_c + row_off + sA : nullptr, xmax, xmin, nnan, n_clean, xf, xl);
+      if (hasB)
+        process_pair<T, RMAX, WRITE_SV>(col[2], col[3], inB, clean, r, r0v, g, a2, A0, NL_LDS ? col_nL[eA + 128] : col[2].nL,
+                                        NL_LDS ? col_nL[eA + 129] : col[3].nL, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt,
+                                        WRITE_SV ? sv_c + row_off + sB : nullptr, xmax, xmin, nnan, n_clean, xdummy, xl);
+      if (clean) {  // (scalar)
+        if (RMAX) {  // no NaN among the wavefront's samples: the lane's smallest / largest range of the ping
+          xmin = vmin_num(xmin, xf);
+          xmax = vmax_num(xmax, xl);
         }
+        ++n_clean;
       }
     }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) col[j].flush(lsum, lcnt);
+    for (int j = 0; j < VEC; ++j) col[j].flush(lsum, lcnt, n_clean);
   }
   }
   if (RMAX) {  // max valid echo_range seen by this workgroup -> one atomic per wave

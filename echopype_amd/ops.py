@@ -777,25 +777,33 @@ def nasc(sv, depth, bin_start, n_dbins, range_bin, n_rbins, skipna=True, closed=
 def sv_noise_fused(raw, coef, alpha2, ping_num, range_sample_num, *, cal_type="Sv",
                    flags=_lib.FLAG_GUARD_POS | _lib.FLAG_MASK_RANGE, dtype=torch.float64,
                    noise_max=float("nan"), want_sv=True, want_range=False, want_range_max=False,
-                   want_range_stats=False):
-    """K1+K6 -> (Sv|None, echo_range|None, noise (C, ceil(P/ping_num)) f64[, nanmax(echo_range)]).
+                   want_range_stats=False, ping_phase=0, want_edges=False):
+    """K1+K6 -> (Sv|None, echo_range|None, noise (C, ceil((P + ping_phase)/ping_num)) f64[, nanmax(echo_range)]).
     ``want_range_stats``: the last element is instead the f64 device tensor {nanmin, nanmax, NaN count} of the echo_range
-    (NaN count -1: the kernel that served the configuration leaves none)."""
+    (NaN count -1: the kernel that served the configuration leaves none).  ``ping_phase`` / ``want_edges``: a ping shard
+    of a longer file, as ``noise_estimate`` -- with ``want_edges`` two more elements follow: edge_sum f64 (2, C, Sb),
+    edge_cnt int32 (2, C, Sb), the raw (sum, count) rows of the shard's first / last ping block."""
     C, P, S = raw.shape
     if raw.dtype != torch.float32:
         raise ValueError("raw power samples must be float32 (convert/parse_base.py:302)")
     dev = raw.device
     sv = torch.empty((C, P, S), dtype=dtype, device=dev) if want_sv else None
     rng = torch.empty((C, P, S), dtype=dtype, device=dev) if want_range else None
-    noise = torch.empty((C, -(-P // ping_num)), dtype=torch.float64, device=dev)
+    noise = torch.empty((C, -(-(P + ping_phase) // ping_num)), dtype=torch.float64, device=dev)
     rmax = torch.empty(1, dtype=torch.float64, device=dev) if want_range_max or want_range_stats else None
     rstats = torch.empty(3, dtype=torch.float64, device=dev) if want_range_stats else None
+    es = ec = None
+    if want_edges:
+        Sb = -(-S // range_sample_num)
+        es = torch.zeros((2, C, Sb), dtype=torch.float64, device=dev)
+        ec = torch.zeros((2, C, Sb), dtype=torch.int32, device=dev)
     call("epa_sv_noise_fused", _p(raw), _p(coef), _p(alpha2), C, P, S,
-         _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, flags, int(ping_num), int(range_sample_num),
-         float(noise_max), _p(sv), _p(rng), _p(noise), _p(rmax), _p(rstats), _DT[dtype], _stream())
+         _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, flags, int(ping_num), int(range_sample_num), int(ping_phase),
+         float(noise_max), _p(sv), _p(rng), _p(noise), _p(es), _p(ec), _p(rmax), _p(rstats), _DT[dtype], _stream())
+    edges = (es, ec) if want_edges else ()
     if want_range_stats:
-        return sv, rng, noise, rstats
-    return (sv, rng, noise, float(rmax.item())) if want_range_max else (sv, rng, noise)
+        return (sv, rng, noise, rstats) + edges
+    return ((sv, rng, noise, float(rmax.item())) if want_range_max else (sv, rng, noise)) + edges
 
 
 def denoise_mvbs(sv, alpha2, noise, ping_num, snr_threshold, bin_start, n_tbins, range_bin, n_rbins, *,
@@ -824,7 +832,7 @@ def sv_denoise_mvbs(raw, coef, alpha2, noise, ping_num, snr_threshold, bin_start
                     *, cal_type="Sv", flags=_lib.FLAG_GUARD_POS | _lib.FLAG_MASK_RANGE, dtype=torch.float64,
                     skipna=True, closed="left", fill_value=float("nan"), ping_perm=None, want_noise=False,
                     want_corrected=True, want_range=False, want_partials=False, want_minmax=False,
-                    minmax_async=False):
+                    minmax_async=False, ping_phase=0):
     """K1+K7+K5 from the raw power -> dict(MVBS of the corrected Sv, Sv_noise, Sv_corrected, echo_range, sum,
     cnt, minmax = [min, max of Sv_noise, min, max of Sv_corrected] (host floats) if asked; ``minmax_async``: a
     ``HostFuture`` of the four numbers instead -- the call then does not wait for its kernel)."""
@@ -839,7 +847,7 @@ def sv_denoise_mvbs(raw, coef, alpha2, noise, ping_num, snr_threshold, bin_start
         cnt = torch.empty((C, n_tbins, n_rbins), dtype=torch.int32, device=dev)
     mm = torch.empty(4, dtype=torch.float64, device=dev) if want_minmax else None
     call("epa_sv_denoise_mvbs", _p(raw), _p(coef), _p(alpha2), _p(noise), C, P, S,
-         _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, flags, int(ping_num), float(snr_threshold),
+         _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, flags, int(ping_num), int(ping_phase), float(snr_threshold),
          _p(bin_start), _p(ping_perm), int(n_tbins), float(range_bin), int(n_rbins), _bin_flags(skipna, closed),
          float(fill_value), _p(sn), _p(sc), _p(rng), _p(out), _p(ssum), _p(cnt), _p(mm), _DT[dtype], _stream())
     return dict(MVBS=out, Sv_noise=sn, Sv_corrected=sc, echo_range=rng, sum=ssum, cnt=cnt,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define EPA_VERSION 101 /* 0.1.1: tau_eff per (channel, ping); replica indirection for files with several filter_time intervals */
+#define EPA_VERSION 102 /* 0.1.2: ping_phase / edge rows on the two-pass chain (ping shards); epa_source_digest */
 
 typedef void* epa_stream_t;
 
@@ -551,10 +551,17 @@ int epa_nasc(const void* sv, const void* depth, int C, int P, int S, const int32
  * range_max_out (f64 [1], optional) = nanmax(echo_range), which sizes the range grid of pass 2;
  * range_stats_out (f64 [3], optional, needs range_max_out) = {nanmin, nanmax, NaN count} of the echo_range as
  * epa_sv_mvbs_fused leaves them ({NaN, NaN, -1} when the generic kernel serves the configuration). */
+/* A ping shard of a longer file: ping_phase = (global index of the shard's first ping) % ping_num, i.e. local
+ * ping p belongs to noise block (p + ping_phase) / ping_num and noise_out has ceil((P + ping_phase) / ping_num) columns;
+ * edge_sum_out f64 [2][C][Sb] / edge_cnt_out u32 [2][C][Sb] (optional, together; zero them first) receive the raw linear
+ * (sum, count) per range block of the shard's FIRST and LAST ping block -- what a block cut by a shard edge contributes to
+ * the mean over all its pings (clean/api.py:402-411); a shard with a single block fills slot 0 only.  As
+ * epa_noise_estimate. */
 int epa_sv_noise_fused(const float* raw, const double* coef, const double* alpha2, int C, int P, int S,
-                       int cal_type, unsigned cal_flags, int ping_num, int range_sample_num,
-                       double noise_max, void* sv_out, void* range_out, double* noise_out,
-                       double* range_max_out, double* range_stats_out, int dtype, epa_stream_t stream);
+                       int cal_type, unsigned cal_flags, int ping_num, int range_sample_num, int ping_phase,
+                       double noise_max, void* sv_out, void* range_out, double* noise_out, double* edge_sum_out,
+                       uint32_t* edge_cnt_out, double* range_max_out, double* range_stats_out, int dtype,
+                       epa_stream_t stream);
 
 /* Pass 2 = K7 + K5: reads Sv once, applies clean/api.py:425-430,485-487 with the per-ping-block noise
  * of pass 1 and bins the CORRECTED Sv (commongrid/utils.py:592-627) in the same sweep.  Arguments as
@@ -575,8 +582,9 @@ int epa_denoise_mvbs(const void* sv, const void* range, const double* coef, cons
  * = 24..32 B/sample.  range_out optional as in epa_sv_power.  minmax_out (f64 [4], optional): NaN-skipping
  * {min, max} of Sv_noise and {min, max} of Sv_corrected as a by-product (the actual_range attributes of
  * clean/utils.py:392-395, otherwise one more sweep of each array). */
+/* ping_phase as in epa_sv_noise_fused: the noise of local ping p is noise[c][(p + ping_phase) / ping_num]. */
 int epa_sv_denoise_mvbs(const float* raw, const double* coef, const double* alpha2, const double* noise,
-                        int C, int P, int S, int cal_type, unsigned cal_flags, int ping_num,
+                        int C, int P, int S, int cal_type, unsigned cal_flags, int ping_num, int ping_phase,
                         double snr_threshold, const int32_t* bin_start, const int32_t* ping_perm,
                         int n_tbins, double range_bin, int n_rbins, unsigned bin_flags, double fill_value,
                         void* sv_noise_out, void* sv_corrected_out, void* range_out, void* mvbs_out,

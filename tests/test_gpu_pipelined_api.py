@@ -192,7 +192,8 @@ def test_deferred_result_does_not_follow_later_edits_of_the_input_dataset(env):
         ds2["frequency_nominal"] = (("channel",), np.zeros(len(ref_chan)))   # edits AFTER the call
         ds2["Sv"] = (("channel", "ping_time", "range_sample"), np.zeros(ds2["Sv"].shape))
         ds2.attrs["processing_level"] = "edited"
-        np.testing.assert_array_equal(mv["Sv"].values, ref_vals)
+        # (two runs of the kernel add a bin's partial sums in LDS in whatever order the wavefronts arrive: an ulp)
+        np.testing.assert_allclose(mv["Sv"].values, ref_vals, rtol=1e-13, atol=0, equal_nan=True)
         np.testing.assert_array_equal(mv["frequency_nominal"].values, ref_freq)
         assert mv.attrs.get("processing_level") == mv_ref.attrs.get("processing_level")
     finally:
