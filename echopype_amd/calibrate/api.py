@@ -36,7 +36,8 @@ def check_input_args_combination(waveform_mode, encode_mode, pulse_compression=N
 
 def _compute_cal(cal_type, echodata, env_params=None, cal_params=None, ecs_file=None, waveform_mode=None,
                  encode_mode=None, assume_single_filter_time=None, drop_last_hanning_zero=False,
-                 dtype="float64", device=None, fft_dtype=None):
+                 dtype="float64", device=None, fft_dtype=None, _file=None):
+    """(``_file``: the whole-file facts of a ping shard, echopype_amd.sharding.file_scalars -- set by sharding.compute_Sv.)"""
     waveform_mode = "BB" if waveform_mode == "FM" else waveform_mode
     if echodata.sonar_model == "EK80":
         if waveform_mode is None or encode_mode is None:
@@ -58,7 +59,8 @@ def _compute_cal(cal_type, echodata, env_params=None, cal_params=None, ecs_file=
         cal_obj = CALIBRATOR[echodata.sonar_model](
             echodata, env_params=env_params, cal_params=cal_params, ecs_file=ecs_file,
             waveform_mode=waveform_mode, encode_mode=encode_mode, slice_dict=slice_dict,
-            drop_last_hanning_zero=drop_last_hanning_zero, dtype=dtype, device=device, fft_dtype=fft_dtype)
+            drop_last_hanning_zero=drop_last_hanning_zero, dtype=dtype, device=device, fft_dtype=fft_dtype,
+            file_scalars=_file)
         cal_obj._check_echodata_backscatter_size()
         return cal_obj.compute_Sv() if cal_type == "Sv" else cal_obj.compute_TS()
 
@@ -74,8 +76,11 @@ def _compute_cal(cal_type, echodata, env_params=None, cal_params=None, ecs_file=
         pt = np.asarray(beam["ping_time"].values).astype("datetime64[ns]")
         chans = list(beam["channel"].values)
         if assume_single_filter_time:
-            # filter set of each channel's first valid ping (api.py:101-123)
-            first = {ch: pt[np.flatnonzero(~np.isnan(tau[i]))[0]] for i, ch in enumerate(chans)}
+            # filter set of each channel's first valid ping (api.py:101-123) -- of the WHOLE file on a ping shard
+            if _file is not None and _file.get("first_valid_ping_time") is not None:
+                first = {ch: np.datetime64(int(_file["first_valid_ping_time"][i]), "ns") for i, ch in enumerate(chans)}
+            else:
+                first = {ch: pt[np.flatnonzero(~np.isnan(tau[i]))[0]] for i, ch in enumerate(chans)}
             cal_ds = _compute_cal_ds({"first_valid_filter_time_per_channel": first})
         else:
             # every (channel, filter interval) pair in ONE pass over the whole grid (the reference calibrates them one by

@@ -83,6 +83,10 @@ class CalibrateBase(abc.ABC):
         self.dtype = ops.torch_dtype(kwargs.get("dtype", "float64"))
         self.device = kwargs.get("device")
         self.fft_dtype = kwargs.get("fft_dtype")  # EK80 BB: arithmetic of the pulse-compression transform (None = dtype)
+        # a ping shard of a longer file (echopype_amd.sharding.file_scalars): the whole-file facts the reference reads
+        # off the whole file -- nominal pulse length of the FILE's first ping, each channel's first valid ping, the
+        # transmit parameters that must not change, the filter intervals' starts.  None: the echodata is the whole file.
+        self.file_scalars = kwargs.get("file_scalars")
 
     @abc.abstractmethod
     def compute_echo_range(self, **kwargs):

@@ -128,13 +128,15 @@ class CalibrateEK(CalibrateBase):
             tau_nom0 = tdn.data.tensor[:, 0].double().cpu().numpy()  # C values
         else:
             tau_nom0 = np.asarray(self._cp(tdn, "transmit_duration_nominal"))[:, 0]
-        if getattr(self, "tau_nominal_first_ping", None) is not None:  # a ping shard: ping 0 of the WHOLE file
-            tau_nom0 = np.asarray(self.tau_nominal_first_ping, dtype=np.float64).reshape(tau_nom0.shape)
+        fsc = self.file_scalars or {}
+        if fsc.get("tau_nominal_first_ping") is not None:  # a ping shard: ping 0 of the WHOLE file
+            tau_nom0 = np.asarray(fsc["tau_nominal_first_ping"], dtype=np.float64).reshape(tau_nom0.shape)
         try:
             coeff = get_filter_coeff(self.vend)
             fs = self.cal_params["receiver_sampling_frequency"]  # KeyError for EK60 -> fallback
             tx, tx_time = get_transmit_signal(self.beam, coeff, self.waveform_mode, fs,
-                                              getattr(self, "drop_last_hanning_zero", False))
+                                              getattr(self, "drop_last_hanning_zero", False),
+                                              whole_file=fsc.get("transmit_params"))
             te = get_tau_effective(tx, {k: 1 / np.diff(v[:2]) for k, v in tx_time.items()},
                                    self.waveform_mode, self.beam["channel"]).values.copy()
         except Exception as e:  # noqa: BLE001 - same catch-all as the reference
@@ -326,13 +328,19 @@ class CalibrateEK80(CalibrateEK):
         ft_all = np.asarray(self.vend_full["filter_time"].values).astype("datetime64[ns]")
         ft_sorted = np.sort(ft_all)
         pairs, rid = [], np.full((C, P), -1, dtype=np.int32)
+        fsc = self.file_scalars or {}
         for ci in range(C):
-            starts = np.intersect1d(pt[~np.isnan(tau[ci])], ft_sorted)
+            if fsc.get("interval_starts") is not None:  # a ping shard: the stamps that start an interval ANYWHERE in the file
+                starts = np.sort(ft_all[np.asarray(fsc["interval_starts"][ci], dtype=bool)])
+            else:
+                starts = np.intersect1d(pt[~np.isnan(tau[ci])], ft_sorted)
             for k, start in enumerate(starts):
                 keep = pt >= start
                 if k + 1 < len(starts):
                     keep &= pt <= starts[k + 1] - np.timedelta64(1, "ns")
                 idx = np.flatnonzero(keep)
+                if idx.size == 0:  # (a ping shard: the interval lies on other ranks)
+                    continue
                 rid[ci, idx] = len(pairs)
                 pairs.append((ci, int(np.flatnonzero(ft_all == start)[0]), idx))
         return dict(pairs=pairs, replica_id=rid)
@@ -363,15 +371,20 @@ class CalibrateEK80(CalibrateEK):
         fs_all = self.cal_params.get("receiver_sampling_frequency")
         te = np.full((C, P), np.nan)
         txs = []
+        fsc = self.file_scalars or {}
         for ci, fi, idx in self._plan["pairs"]:
             tau0 = tau[ci, idx[0]]
+            whole = None
+            if fsc.get("interval_tau0") is not None:  # a ping shard: the INTERVAL's first ping, its transmit parameters
+                tau0 = float(fsc["interval_tau0"][ci, fi])
+                whole = {k: (v[0][ci:ci + 1, fi], v[1][ci:ci + 1, fi]) for k, v in fsc["interval_transmit_params"].items()}
             tx = None
             try:
                 beam_k, vend_k = self._pair_views(ci, fi, idx)
                 fs = np.asarray(getattr(fs_all, "values", fs_all), dtype=np.float64)
                 fs = fs if fs.ndim == 0 else fs[ci:ci + 1]
                 tx_d, tx_time = get_transmit_signal(beam_k, get_filter_coeff(vend_k), self.waveform_mode, fs,
-                                                    self.drop_last_hanning_zero)
+                                                    self.drop_last_hanning_zero, whole_file=whole)
                 val = get_tau_effective(tx_d, {k: 1 / np.diff(v[:2]) for k, v in tx_time.items()}, self.waveform_mode,
                                         beam_k["channel"]).values[0]
                 tx = np.asarray(next(iter(tx_d.values())))
@@ -446,7 +459,8 @@ class CalibrateEK80(CalibrateEK):
             coeff = get_filter_coeff(self.vend)
             tx, _ = get_transmit_signal(self.beam, coeff, self.waveform_mode,
                                         self.cal_params["receiver_sampling_frequency"],
-                                        self.drop_last_hanning_zero)
+                                        self.drop_last_hanning_zero,
+                                        whole_file=(self.file_scalars or {}).get("transmit_params"))
         # the (C, P, 8) coefficient rows are built on the device (epa_complex_coef_ek80): parameters go up in the shape
         # they have -- scalar, (C,), or (C, P) (straight from HBM when the echodata is resident) -- no (C, P) NumPy math
         def dv(v, name):

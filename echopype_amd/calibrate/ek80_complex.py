@@ -89,8 +89,11 @@ def get_tau_effective(ytx_dict, fs_deci_dict, waveform_mode, channel=None, ping_
     return DataArray(np.asarray(vals, dtype=np.float64), ("channel",), {"channel": ch_vals})
 
 
-def get_transmit_signal(beam, coeff, waveform_mode, fs, drop_last_hanning_zero=False):
-    """Per-channel replica and its time axis; transmit parameters must be constant across pings."""
+def get_transmit_signal(beam, coeff, waveform_mode, fs, drop_last_hanning_zero=False, *, whole_file=None):
+    """Per-channel replica and its time axis; transmit parameters must be constant across pings.
+    ``whole_file`` (a ping shard; sharding.file_scalars): {parameter: (min (C,), max (C,))} over the pings of the WHOLE
+    file (or filter interval) -- the uniqueness test and the value are the file's, not the shard's, so that a shard
+    holding none (or only some) of a channel's valid pings builds the same replica and raises the same error."""
     tt = np.asarray(beam["transmit_type"].values) if "transmit_type" in beam else None
     if waveform_mode == "BB" and tt is not None and np.all(tt == "CW"):
         raise TypeError("File does not contain BB mode complex samples!")
@@ -102,6 +105,9 @@ def get_transmit_signal(beam, coeff, waveform_mode, fs, drop_last_hanning_zero=F
         for p in ("transmit_duration_nominal", "slope", "transmit_frequency_start", "transmit_frequency_stop"):
             if waveform_mode == "CW" and p.startswith("transmit_frequency"):
                 v = np.unique(np.asarray(beam["frequency_nominal"].values)[i])
+            elif whole_file is not None and p in whole_file:
+                lo, hi = float(whole_file[p][0][i]), float(whole_file[p][1][i])
+                v = np.array([lo]) if (lo == hi and np.isfinite(lo)) else (np.array([]) if lo > hi else np.array([lo, hi]))
             else:
                 v = np.unique(np.asarray(beam[p].values)[i])
                 v = v[~np.isnan(v)]

@@ -60,8 +60,11 @@ class DenoiseSource:
     two arrays or attributes, or, the usual sequence, INSIDE ``compute_MVBS``'s pass when the corrected Sv is what is
     binned (``commongrid.api._mvbs_of_deferred_clean``: one sweep writes both arrays and the bins)."""
 
-    def __init__(self, power, a2, noise, ping_num, snr, sv_t):
+    def __init__(self, power, a2, noise, ping_num, snr, sv_t, ping_phase=0, global_rmax=None):
         self.power, self.a2, self.noise, self.ping_num, self.snr, self.sv_t = power, a2, noise, ping_num, snr, sv_t
+        # a ping shard of a longer file: local ping p belongs to noise block (p + ping_phase) // ping_num, and
+        # nanmax(echo_range) over ALL shards (a HostFuture; all-reduced in HBM behind pass 1) sizes the range grid
+        self.ping_phase, self.global_rmax = int(ping_phase), global_rmax
         self.raw_version = power.raw._version
         self.minmax = None  # HostFuture / list of [min, max of Sv_noise, min, max of Sv_corrected] once pass 2 has run
         self._lazy = {}     # weak: the arrays own this object (source, make), not the other way round -- a dataset
@@ -106,10 +109,11 @@ class DenoiseSource:
         try:
             res = ops.sv_denoise_mvbs(p.raw, p.coef, self.a2, self.noise, self.ping_num, float(self.snr), bin_start,
                                       bin_start.numel() - 1, 1e30, 1, flags=p.flags, dtype=p.dtype, want_noise=True,
-                                      want_corrected=True, want_minmax=True, minmax_async=True)
+                                      want_corrected=True, want_minmax=True, minmax_async=True,
+                                      ping_phase=self.ping_phase)
         except _lib.EpaError:  # a geometry the chain kernel does not serve: the array kernel on the Sv of pass 1
             sn, sc, mm = ops.noise_apply(self.sv_t, self.a2, self.noise, self.ping_num, float(self.snr), want_minmax=True,
-                                         coef=p.coef, mask_raw=p.raw, ping_phase=0)
+                                         coef=p.coef, mask_raw=p.raw, ping_phase=self.ping_phase)
             res = dict(Sv_noise=sn, Sv_corrected=sc, minmax=mm)
         self.install(res)
 
@@ -130,7 +134,7 @@ def defer_clean_enabled():
     return os.environ.get("EPA_DEFER_CLEAN", "1") != "0"
 
 
-def _denoise_deferred_sv(ds_Sv, ping_num, range_sample_num, nmax, snr):
+def _denoise_deferred_sv(ds_Sv, ping_num, range_sample_num, nmax, snr, shard=None):
     """``remove_background_noise`` as the FIRST reader of the Sv that compute_Sv deferred (power samples): two passes over
     the raw samples instead of K1 + two sweeps of the Sv array --
         pass 1 (epa_sv_noise_fused)    raw -> the Sv array + the noise estimate from the values in registers + the
@@ -138,7 +142,14 @@ def _denoise_deferred_sv(ds_Sv, ping_num, range_sample_num, nmax, snr):
         pass 2 (epa_sv_denoise_mvbs)   raw -> Sv_noise, Sv_corrected, their actual_range      4 + 16 B/sample
     against 12 (K1) + 8 (estimate) + 24 (apply).  Pass 1 runs here; pass 2 is left to a ``DenoiseSource`` (see there).
     Nothing waits for the GPU.  Returns the DenoiseSource, or None: the plain route then runs on whatever this one
-    has written."""
+    has written.
+
+    ``shard`` = (ping_offset, group, ShardContext): ``ds_Sv`` is one rank's ping shard.  Noise blocks count from the
+    file's first ping (``ping_phase``); pass 1 also leaves the raw (sum, count) rows of the shard's first / last block,
+    and a block cut by a shard edge gets the mean over ALL its pings (clean/api.py:402-411) through one all-reduce in
+    HBM (sharding.merge_noise_edges) before pass 2 reads the noise.  Whether the route is taken must not depend on the
+    rank (the collectives that follow differ): the shards of one file agree in everything the test below looks at but
+    the kernel's verdict, which is put to a vote."""
     from .. import _lib
 
     sv_da, rng_da = ds_Sv["Sv"], ds_Sv["echo_range"] if "echo_range" in ds_Sv else None
@@ -152,20 +163,35 @@ def _denoise_deferred_sv(ds_Sv, ping_num, range_sample_num, nmax, snr):
         return None
     C, P, S = d.shape
     a2 = _alpha2(ds_Sv, dims, C, P)
+    phase = 0 if shard is None else int(shard[0]) % int(ping_num)
+    out = None
     try:
-        sv_t, _, noise, rstats = ops.sv_noise_fused(src.raw, src.coef, a2, ping_num, range_sample_num, flags=src.flags,
-                                                    dtype=src.dtype, noise_max=float("nan") if nmax is None else float(nmax),
-                                                    want_range_stats=True)
+        out = ops.sv_noise_fused(src.raw, src.coef, a2, ping_num, range_sample_num, flags=src.flags, dtype=src.dtype,
+                                 noise_max=float("nan") if nmax is None else float(nmax), want_range_stats=True,
+                                 ping_phase=phase, want_edges=shard is not None)
     except _lib.EpaError:  # e.g. more range blocks than the LDS holds
-        return None
+        pass
     # served by the generic kernel?  It leaves no range statistics (K1 does, on the plain route).  Known on the host
     # (epa_last_range_stats_filled): nothing waits for pass 1
-    if not _lib.lib.epa_last_range_stats_filled():
+    declined = out is None or not _lib.lib.epa_last_range_stats_filled()
+    if shard is not None:
+        from .. import sharding
+
+        ctx = shard[2] if shard[2] is not None else sharding.ShardContext(shard[1])
+        declined = ctx.agree(declined)  # (every rank takes the plain route if any has to)
+    if declined:
         return None
+    sv_t, _, noise, rstats = out[:4]
+    global_rmax = None
+    if shard is not None:
+        sharding.merge_noise_edges(noise, out[4], out[5], int(shard[0]), P, ping_num,
+                                   float("nan") if nmax is None else float(nmax), shard[1], shard=ctx)
+        # nanmax(echo_range) over all shards, for the range grid compute_MVBS will need: all-reduced where it lies
+        global_rmax = ops.fetch_async(sharding.global_max_device(rstats[1:2].clone(), shard[1]))
     d.fulfil(sv_t)
     # (the three numbers start their way to the host now, behind pass 1 only: compute_MVBS sizes its grid from them)
     src.echo_range.set_stats(ops.fetch_async(rstats))
-    dsrc = DenoiseSource(src, a2, noise, ping_num, snr, sv_t)
+    dsrc = DenoiseSource(src, a2, noise, ping_num, snr, sv_t, ping_phase=phase, global_rmax=global_rmax)
     arrays = dsrc.arrays()
     if not defer_clean_enabled():
         dsrc.run_plain()
@@ -215,9 +241,9 @@ def remove_background_noise(ds_Sv, ping_num, range_sample_num, background_noise_
     if SNR_threshold is not None:
         SNR_threshold = extract_dB(SNR_threshold)
     done = None
-    if _shard is None and SNR_threshold is not None:
+    if SNR_threshold is not None:
         nmax = extract_dB(background_noise_max) if background_noise_max is not None else None
-        done = _denoise_deferred_sv(ds_Sv, ping_num, range_sample_num, nmax, SNR_threshold)
+        done = _denoise_deferred_sv(ds_Sv, ping_num, range_sample_num, nmax, SNR_threshold, shard=_shard)
     if done is not None:
         order = tuple(ds_Sv["Sv"].dims)
         done, arrays = done

@@ -82,11 +82,12 @@ def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="
     if not isinstance(ping_time_bin, str):
         raise TypeError("ping_time_bin must be a string")
 
-    if _shard is None and skipna and closed == "left":
+    if skipna and closed == "left":
         # Sv still deferred by compute_Sv: written by THIS pass over the raw samples, next to the bins
-        done = _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max)
+        # (on a ping shard, too: the grid is the whole dataset's, cut bins are exchanged in HBM -- see _shard_grid)
+        done = _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max, _shard)
         if done is None:  # ... or the Sv_corrected remove_background_noise deferred: its pass 2 bins as well
-            done = _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max)
+            done = _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max, _shard)
         if done is not None:
             return done
     return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, skipna, fill_value, closed, range_var_max, _shard)
@@ -216,7 +217,34 @@ def _mvbs_of_array_without_waiting(ds_Sv, sv_t, rows, range_var, range_bin_m, pi
     return DeferredDataset(build)
 
 
-def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max):
+def _shard_grid(_shard, ns, dt, r_cap, range_var_max):
+    """One rank's ping shard: the time grid and the range cap of the WHOLE dataset in ONE control message
+    (sharding.MVBSShard.grid).  Returns (left edge of this shard's first bin, number of its bins, global index of its
+    first / last bin, the range cap to launch on)."""
+    e0, _, first_bin, last_bin, g_cap = _shard.grid(ns, dt, "left", r_cap if range_var_max is None else float("nan"))
+    return e0 + first_bin * dt, last_bin - first_bin + 1, first_bin, last_bin, (g_cap if range_var_max is None else r_cap)
+
+
+def _shard_assemble(ds_Sv, mv_full, n_cap, rmax, r_cap, range_var_max, n_nan_range, ping_time, e0, dt, n_t, range_var,
+                    range_bin_m, ping_time_bin):
+    """The deferred assembly on a ping shard: ``rmax`` = nanmax(range) over ALL shards (all-reduced in HBM).  No
+    fallback here -- a fallback would be a collective at a time only this rank chooses."""
+    rmax = rmax if range_var_max is None else r_cap
+    if not np.isfinite(rmax):  # no valid range on any rank: the reference's grid does not exist
+        raise ValueError("range bins are empty: the range variable holds no valid values")
+    r_edges = np.arange(0, rmax + range_bin_m, range_bin_m)
+    n_r = len(r_edges) - 1
+    if n_r > n_cap:
+        raise RuntimeError(f"nanmax({range_var}) = {rmax} lies beyond the range grid the shards agreed on "
+                           f"({n_cap} bins of {range_bin_m} m)")
+    if n_nan_range > 0:
+        logging.warning(f"The ```{range_var}``` coordinate array contain NaNs. {_AGG_MSG}")
+    mvbs_t = mv_full[..., :n_r].contiguous() if n_r != n_cap else mv_full
+    return _assemble_mvbs(ds_Sv, mvbs_t, "channel", ping_time, e0, dt, n_t, r_edges, range_var, range_bin_m,
+                          ping_time_bin, "left")
+
+
+def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max, _shard=None):
     """``compute_Sv`` on power samples leaves Sv deferred (``LazyDeviceArray`` with a ``source``); binned right after --
     the usual sequence -- one pass over the raw samples (``epa_sv_mvbs_fused``) writes that Sv array AND the bins: the two
     reference calls cost 12 B/sample instead of 12 + 8.  Returns the MVBS dataset, or None when the plain route has to
@@ -251,18 +279,26 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
         coef = src.coef
         reach = torch.nan_to_num((S - 1) * coef[..., _lib.CF_RA] * coef[..., _lib.CF_RB] + coef[..., _lib.CF_R0], nan=float("-inf"))
         r_cap = float(reach.max().item())
+    first_bin = last_bin = 0
+    if _shard is not None:  # (every rank of the dataset gets here or none does: the tests above look at nothing rank-local)
+        e0, n_t, first_bin, last_bin, r_cap = _shard_grid(_shard, ns, dt, r_cap, range_var_max)
     n_cap = len(np.arange(0, r_cap + range_bin_m, range_bin_m)) - 1 if np.isfinite(r_cap) else 0
     if n_cap < 1:
         return None
     bin_start = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t)
+    res = None
     try:
         res = ops.sv_mvbs_fused(src.raw, src.coef, bin_start, n_t, range_bin_m, n_cap, cal_flags=src.flags, skipna=True,
-                                closed="left", fill_value=fill_value, dtype=src.dtype, want_range_stats=True)
+                                closed="left", fill_value=fill_value, dtype=src.dtype, want_range_stats=True,
+                                want_partials=_shard is not None)
     except _lib.EpaError:  # e.g. a range grid too fine for the LDS accumulators
-        return None
+        pass
     # served by the generic kernel (a handful of pings, a grid beyond the LDS)?  It leaves no range statistics, which
     # every later step asks for -- K1 does, on the plain route.  (Known on the host: epa_last_range_stats_filled.)
-    if not res["range_stats_filled"]:
+    declined = res is None or not res["range_stats_filled"]
+    if _shard is not None:  # the plain route runs other collectives: every rank takes it if any has to
+        declined = _shard.agree(declined)
+    if declined:
         return None
     rng = src.echo_range
     d.fulfil(res["Sv"])
@@ -270,6 +306,21 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
     # (the assembly below, the next reader of the echo_range statistics) does not wait for kernels launched after it
     stats = ops.fetch_async(res["range_stats"])
     rng.set_stats(stats)
+    if _shard is not None:
+        # nanmax(echo_range) of the whole dataset: all-reduced (MAX) where it lies, behind the kernel; cut bins: totals
+        # over all ranks, reported by the lowest holder (one all-reduce in HBM) -- the host waits for neither
+        gmax = ops.fetch_async(_shard.range_max_device(res["range_stats"][1:2].clone())) if range_var_max is None else None
+        mv_full, lo = _shard.finish(res, first_bin, last_bin, fill_value)
+        e0, n_t = e0 + lo * dt, mv_full.shape[1]
+        ds_Sv = ds_Sv.copy()
+        del res
+
+        def build_shard():
+            return _shard_assemble(ds_Sv, mv_full, n_cap, gmax.item() if gmax is not None else r_cap, r_cap,
+                                   range_var_max, stats.tolist()[2], ping_time, e0, dt, n_t, range_var, range_bin_m,
+                                   ping_time_bin)
+
+        return DeferredDataset(build_shard) if defer_mvbs_enabled() else build_shard()
     ds_Sv, mv_full = ds_Sv.copy(), res["MVBS"]  # (snapshot: see _mvbs_of_array_without_waiting)
     del res
 
@@ -291,7 +342,7 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
     return DeferredDataset(build) if defer_mvbs_enabled() else build()
 
 
-def _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max):
+def _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max, _shard=None):
     """The chain as the reference's user writes it -- ``compute_Sv``, ``remove_background_noise``, then
     ``compute_MVBS`` of the dataset with ``Sv := Sv_corrected`` -- arrives here with an Sv that
     ``remove_background_noise`` left deferred (``clean.api.DenoiseSource``: pass 1 has run).  Pass 2 runs NOW, on the
@@ -325,19 +376,41 @@ def _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_v
         coef = p.coef
         reach = torch.nan_to_num((S - 1) * coef[..., _lib.CF_RA] * coef[..., _lib.CF_RB] + coef[..., _lib.CF_R0], nan=float("-inf"))
         r_cap = float(reach.max().item())
+    first_bin = last_bin = 0
+    if _shard is not None:
+        if src.global_rmax is None:  # (pass 1 did not run as a shard's: the plain route, on every rank alike)
+            return None
+        e0, n_t, first_bin, last_bin, r_cap = _shard_grid(_shard, ns, dt, r_cap, range_var_max)
     n_cap = len(np.arange(0, r_cap + range_bin_m, range_bin_m)) - 1 if np.isfinite(r_cap) else 0
     if n_cap < 1:
         return None
     bin_start = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t)
+    res = None
     try:
         res = ops.sv_denoise_mvbs(p.raw, p.coef, src.a2, src.noise, src.ping_num, float(src.snr), bin_start, n_t,
                                   range_bin_m, n_cap, flags=p.flags, dtype=p.dtype, skipna=True, closed="left",
                                   fill_value=fill_value, want_noise=True, want_corrected=True, want_minmax=True,
-                                  minmax_async=True)
+                                  minmax_async=True, ping_phase=src.ping_phase, want_partials=_shard is not None)
     except _lib.EpaError:  # e.g. a range grid too fine for the LDS accumulators
+        pass
+    if (_shard.agree(res is None) if _shard is not None else res is None):
         return None
     src.install(res)
     rng = p.echo_range
+    if _shard is not None:  # cut bins: totals over all ranks, reported by the lowest holder (one all-reduce in HBM)
+        mv_full, lo = _shard.finish(res, first_bin, last_bin, fill_value)
+        e0, n_t = e0 + lo * dt, mv_full.shape[1]
+        ds_Sv, gmax = ds_Sv.copy(), src.global_rmax
+        del res
+
+        def build_shard():
+            st = rng.cached_stats()  # (local: the NaN-coordinate warning)
+            rmax = float(gmax.item())
+            return _shard_assemble(ds_Sv, mv_full, n_cap, rmax if rmax > float("-inf") else float("nan"), r_cap,
+                                   range_var_max, st[2] if st is not None else 0, ping_time, e0, dt, n_t, range_var,
+                                   range_bin_m, ping_time_bin)
+
+        return DeferredDataset(build_shard) if defer_mvbs_enabled() else build_shard()
     ds_Sv, mv_full = ds_Sv.copy(), res["MVBS"]  # (snapshot: see _mvbs_of_array_without_waiting)
     del res
 

@@ -26,7 +26,7 @@ from .xr_lite import DataArray, Dataset, DeferredDataset, DeviceArray, defer_mvb
 def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=True, fill_value=np.nan,
                     closed="left", range_var_max=None, materialize_echo_range=False, env_params=None,
                     cal_params=None, ecs_file=None, waveform_mode=None, encode_mode=None, dtype="float64",
-                    device=None, _shard=None, _tau_first=None):
+                    device=None, _shard=None, _file=None):
     cal_kw = dict(env_params=env_params, cal_params=cal_params, ecs_file=ecs_file, waveform_mode=waveform_mode,
                   encode_mode=encode_mode, dtype=dtype, device=device)
     mv_kw = dict(range_bin=range_bin, ping_time_bin=ping_time_bin, skipna=skipna, fill_value=fill_value,
@@ -35,10 +35,8 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
         echodata.sonar_model in ("EK80", "ES80", "EA640") and encode_mode == "power")
     fast = is_power and not materialize_echo_range and skipna and closed == "left" and \
         echodata.sonar_model != "AZFP"  # AZFP rows carry no guard/mask flags -> generic kernel, two calls
-    if _tau_first is not None and not fast:
-        raise NotImplementedError("a ping shard with tau_effective_first_ping is served by the fused EK power path only")
-    if not fast:
-        ds_Sv = _compute_cal("Sv", echodata, **cal_kw)
+    if not fast:  # (EK80 complex samples, AZFP, other binning flags: the two calls -- on a ping shard with the file's scalars)
+        ds_Sv = _compute_cal("Sv", echodata, _file=_file, **cal_kw)
         return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)
 
     # argument checks in the reference's order (_compute_cal, then _setup_and_validate)
@@ -52,15 +50,14 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
 
     cal = CALIBRATOR[echodata.sonar_model](echodata, env_params=env_params, cal_params=cal_params,
                                            ecs_file=ecs_file, waveform_mode=waveform_mode,
-                                           encode_mode=encode_mode, dtype=dtype, device=device)
+                                           encode_mode=encode_mode, dtype=dtype, device=device, file_scalars=_file)
     cal._check_echodata_backscatter_size()
-    cal.tau_nominal_first_ping = _tau_first
     raw, coef, flags, tau_eff = cal._power_inputs("Sv")
     C, P, S = raw.shape
     ping_time = np.asarray(cal.beam["ping_time"].values).astype("datetime64[ns]", copy=False)
     ns = ping_time.view(np.int64)
     if np.any(ns[1:] < ns[:-1]) or (ns.size and ns.min() == np.iinfo(np.int64).min):  # unsorted, or NaT (INT64_MIN)
-        if _tau_first is not None:
+        if _shard is not None:
             raise NotImplementedError("a ping shard needs sorted, valid ping times")
         ds_Sv = _compute_cal("Sv", echodata, **cal_kw)  # unsorted / NaT pings: generic path
         return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)
@@ -99,7 +96,7 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
         except _lib.EpaError:
             pass
     if (res is None) if _shard is None else _shard.agree(res is None):
-        ds_Sv = _compute_cal("Sv", echodata, **cal_kw)
+        ds_Sv = _compute_cal("Sv", echodata, _file=_file, **cal_kw)
         return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)
     # nanmax(echo_range) stays in HBM: on a shard it is all-reduced (MAX) there, behind the kernel; the host reads it
     # when the MVBS dataset is first used (DeferredDataset) -- nothing in this call waits for the GPU

@@ -91,7 +91,7 @@ def register_control_group(group, control):
 
 def _host_allreduce(values, op, group=None, dtype=torch.int64):
     """All-reduce of a few host scalars over the control group -> list of Python numbers (no device stream involved)."""
-    t = torch.tensor(list(values), dtype=dtype)
+    t = torch.tensor(np.asarray(values).tolist() if isinstance(values, np.ndarray) else list(values), dtype=dtype)
     if _collective(group):
         dist.all_reduce(t, op=op, group=control_group(group))
     return t.tolist()
@@ -483,10 +483,147 @@ def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="
                                closed=closed, range_var_max=range_var_max, _shard=_context(group, shard))
 
 
-def compute_Sv_MVBS(echodata, *, tau_effective_first_ping=None, group=None, shard=None, **kw):
+def compute_Sv_MVBS(echodata, *, tau_effective_first_ping=None, file_scalars=None, group=None, shard=None, **kw):
     """fused.compute_Sv_MVBS on THIS rank's ping shard (see compute_MVBS above for the grid and the shared bins).
     EK60: tau_effective is ping 0 of the WHOLE file (calibrate_ek.py:154-162) -- pass the (channel,) values of the
-    global first ping as ``tau_effective_first_ping`` on every rank but the first (None = this shard's own ping 0)."""
+    global first ping as ``tau_effective_first_ping`` on every rank but the first (None = this shard's own ping 0), or
+    everything a shard cannot know by itself as ``file_scalars`` (``sharding.file_scalars``: EK80 complex samples,
+    files with several filter intervals)."""
     from . import fused
 
-    return fused.compute_Sv_MVBS(echodata, _shard=_context(group, shard), _tau_first=tau_effective_first_ping, **kw)
+    fs = dict(file_scalars) if file_scalars is not None else None
+    if tau_effective_first_ping is not None:
+        fs = dict(fs or {}, tau_nominal_first_ping=np.asarray(tau_effective_first_ping, dtype=np.float64))
+    return fused.compute_Sv_MVBS(echodata, _shard=_context(group, shard), _file=fs, **kw)
+
+
+# ---- whole-file scalars of a ping-sharded file ------------------------------------------------------------------------
+
+_TX_PARAMS = ("transmit_duration_nominal", "slope", "transmit_frequency_start", "transmit_frequency_stop")
+_I64_MAX = np.iinfo(np.int64).max
+
+
+def _minmax_rows(a):
+    """NaN-skipping (min, max) along the last axis of a 2-D array; (+inf, -inf) for a row without a number."""
+    a = np.asarray(a, dtype=np.float64)
+    return np.where(np.isnan(a), np.inf, a).min(axis=-1, initial=np.inf), \
+        np.where(np.isnan(a), -np.inf, a).max(axis=-1, initial=-np.inf)
+
+
+def file_scalars(echodata, *, waveform_mode=None, encode_mode=None, group=None):
+    """The whole-file facts the reference reads off the WHOLE file and a ping shard cannot know by itself (SURVEY 8e:
+    "compute these once ... and broadcast") -- collective over the control group, two or three small host messages,
+    once per file; every rank gets the same dict:
+
+      tau_nominal_first_ping   (C,)   transmit_duration_nominal at the file's FIRST ping: EK60 / GPT tau_effective
+                                      (calibrate_ek.py:113-162)
+      first_valid_ping_time    (C,)   int64 ns, each channel's first ping with a valid pulse length: the filter set
+                                      ``assume_single_filter_time`` selects (calibrate/api.py:98-123)          [EK80]
+      transmit_params          {name: (min (C,), max (C,))} of the four parameters the replica is built from -- they
+                                      must not change along the file (ek80_complex.py:255-282)                 [EK80]
+      interval_starts          (C, F) bool, the filter_time stamps that start a filter interval for the channel (a ping
+                                      time with a valid pulse length ANYWHERE in the file; calibrate/api.py:133-160);
+      interval_tau0            (C, F) the nominal pulse length at that ping;
+      interval_transmit_params {name: (min (C, F), max (C, F))} over the pings of the interval   [EK80, F > 1 stamps]
+
+    Hand the result to ``sharding.compute_Sv / compute_TS / compute_Sv_MVBS`` (``file_scalars=``).  The small groups
+    (Environment, Vendor_specific, Sonar) are expected whole on every rank; only the beam group is sharded."""
+    from .calibrate.calibrate_base import cp_array
+    from .calibrate.calibrate_ek import retrieve_correct_beam_group
+    from .echodata import BEAM1
+
+    ek80 = echodata.sonar_model in ("EK80", "ES80", "EA640")
+    beam = echodata[retrieve_correct_beam_group(echodata, "BB" if waveform_mode == "FM" else waveform_mode, encode_mode)
+                    if ek80 else BEAM1]
+    C, P = beam["backscatter_r"].shape[:2]
+    ns = np.asarray(beam["ping_time"].values).astype("datetime64[ns]").view(np.int64)
+    tau = cp_array(beam["transmit_duration_nominal"], C, P) if "transmit_duration_nominal" in beam else np.full((C, P), np.nan)
+    ok = ns != np.iinfo(np.int64).min
+    # message 1 (MIN, int64): the file's first ping; each channel's first ping with a valid pulse length
+    first_local = int(ns[ok].min()) if ok.any() else _I64_MAX
+    fv_local = [int(ns[ok & ~np.isnan(tau[c])].min()) if (ok & ~np.isnan(tau[c])).any() else _I64_MAX for c in range(C)]
+    got = _host_allreduce([first_local] + fv_local, dist.ReduceOp.MIN, group)
+    first, fv = int(got[0]), np.asarray(got[1:], dtype=np.int64)
+    # message 2 (MIN, float64; maxima as negated minima, "nothing here" = +inf)
+    held = np.flatnonzero(ns == first)
+    tau_first = tau[:, held[0]] if held.size else np.full(C, np.inf)
+    parts = [np.where(np.isnan(tau_first), np.inf, tau_first)]
+    F, ft = 0, None
+    if ek80:
+        for name in _TX_PARAMS:
+            lo, hi = _minmax_rows(cp_array(beam[name], C, P)) if name in beam else (np.full(C, np.inf), np.full(C, -np.inf))
+            parts += [lo, -hi]
+        vend = echodata["Vendor_specific"]
+        if vend.sizes.get("filter_time", 1) > 1:
+            ft = np.asarray(vend["filter_time"].values).astype("datetime64[ns]").view(np.int64)
+            F = ft.size
+            starts = np.zeros((C, F))
+            tau0 = np.full((C, F), np.inf)
+            for c in range(C):
+                valid = ok & ~np.isnan(tau[c])
+                for f in range(F):
+                    hit = np.flatnonzero(valid & (ns == ft[f]))
+                    if hit.size:
+                        starts[c, f], tau0[c, f] = -1.0, tau[c, hit[0]]
+            parts += [starts.reshape(-1), tau0.reshape(-1)]
+    got = np.asarray(_host_allreduce(np.concatenate(parts), dist.ReduceOp.MIN, group, dtype=torch.float64))
+    out = {"tau_nominal_first_ping": np.where(np.isinf(got[:C]), np.nan, got[:C])}
+    if not ek80:
+        return out
+    out["first_valid_ping_time"] = fv
+    o = C
+    out["transmit_params"] = {}
+    for name in _TX_PARAMS:
+        out["transmit_params"][name] = (got[o:o + C].copy(), -got[o + C:o + 2 * C])
+        o += 2 * C
+    if F:
+        out["interval_starts"] = got[o:o + C * F].reshape(C, F) < 0
+        t0 = got[o + C * F:o + 2 * C * F].reshape(C, F)
+        out["interval_tau0"] = np.where(np.isinf(t0), np.nan, t0)
+        # message 3: the transmit parameters over the pings of every (channel, interval) -- an interval runs from its
+        # start to 1 ns before the channel's next start (calibrate/api.py:133-160), over all the shards it crosses
+        parts = []
+        for name in _TX_PARAMS:
+            a = cp_array(beam[name], C, P) if name in beam else np.full((C, P), np.nan)
+            lo, hi = np.full((C, F), np.inf), np.full((C, F), -np.inf)
+            for c in range(C):
+                order = [f for f in np.argsort(ft) if out["interval_starts"][c, f]]
+                for k, f in enumerate(order):
+                    keep = ok & (ns >= ft[f])
+                    if k + 1 < len(order):
+                        keep &= ns <= ft[order[k + 1]] - 1
+                    if keep.any():
+                        l, h = _minmax_rows(a[c:c + 1, keep])
+                        lo[c, f], hi[c, f] = l[0], h[0]
+            parts += [lo.reshape(-1), -hi.reshape(-1)]
+        got = np.asarray(_host_allreduce(np.concatenate(parts), dist.ReduceOp.MIN, group, dtype=torch.float64))
+        out["interval_transmit_params"] = {}
+        for k, name in enumerate(_TX_PARAMS):
+            out["interval_transmit_params"][name] = (got[2 * k * C * F:(2 * k + 1) * C * F].reshape(C, F).copy(),
+                                                     -got[(2 * k + 1) * C * F:(2 * k + 2) * C * F].reshape(C, F))
+    return out
+
+
+def _compute_cal_shard(cal_type, echodata, file_scalars_, group, kw):
+    from .calibrate.api import _compute_cal
+
+    if file_scalars_ is None:
+        file_scalars_ = file_scalars(echodata, waveform_mode=kw.get("waveform_mode"), encode_mode=kw.get("encode_mode"),
+                                     group=group)
+    return _compute_cal(cal_type, echodata, _file=file_scalars_, **kw)
+
+
+def compute_Sv(echodata, *, file_scalars=None, group=None, **kw):
+    """calibrate.compute_Sv on THIS rank's ping shard: same keywords, same dataset for these pings as the single-process
+    call on the whole file gives.  ``file_scalars``: the result of ``sharding.file_scalars`` (None: computed here --
+    collective, two or three small host messages)."""
+    from .xr_lite import xarray_io
+
+    return xarray_io()(lambda ed: _compute_cal_shard("Sv", ed, file_scalars, group, kw))(echodata)
+
+
+def compute_TS(echodata, *, file_scalars=None, group=None, **kw):
+    """calibrate.compute_TS on THIS rank's ping shard (see compute_Sv)."""
+    from .xr_lite import xarray_io
+
+    return xarray_io()(lambda ed: _compute_cal_shard("TS", ed, file_scalars, group, kw))(echodata)

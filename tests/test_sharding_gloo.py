@@ -419,3 +419,71 @@ def test_grid_in_one_message_equals_the_two_separate_agreements():
     for rank, a, b, none in res:
         assert a == b and a[4] == 786.4921875 and np.isnan(none)
     assert [r[1][2] for r in res] == [0, 2, 4] and res[0][1][0] == res[2][1][0]
+
+
+# ---- whole-file scalars of a ping-sharded file (sharding.file_scalars) ------------------------------------------------
+def _worker_file_scalars(rank, world, port, cuts, filter_pings, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from shard_cases import ek80_bb_file, shard_of
+
+    from echopype_amd import sharding
+
+    ed = ek80_bb_file(P=40, S=16, late=12, filter_pings=filter_pings)
+    bounds = [0] + list(cuts) + [40]
+    fs = sharding.file_scalars(shard_of(ed, bounds[rank], bounds[rank + 1]), waveform_mode="BB", encode_mode="complex")
+    q.put((rank, fs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cuts,filter_pings", [((8, 20), None), ((8, 20), [0, 12, 25]), ((13,), [0, 12, 25]), ((30,), [0, 5])])
+def test_file_scalars_equal_the_whole_files(cuts, filter_pings):
+    """Every rank gets the facts of the WHOLE file -- first ping's pulse length, each channel's first valid ping, the
+    transmit parameters' (min, max), the filter intervals' starts / first pulse lengths / parameter ranges -- whichever
+    shard holds the pings they come from (calibrate/api.py:98-160, calibrate_ek.py:113-162, ek80_complex.py:255-282)."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from shard_cases import ek80_bb_file
+
+    from echopype_amd.echodata import BEAM1
+
+    world = len(cuts) + 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_file_scalars, args=(r, world, port, cuts, filter_pings, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [fs for _, fs in sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    beam = ek80_bb_file(P=40, S=16, late=12, filter_pings=filter_pings)[BEAM1]
+    tau = np.asarray(beam["transmit_duration_nominal"].values)
+    ns = np.asarray(beam["ping_time"].values).astype("datetime64[ns]").view(np.int64)
+    for fs in res:
+        np.testing.assert_array_equal(fs["tau_nominal_first_ping"], tau[:, 0])  # (NaN for the channel that starts late)
+        np.testing.assert_array_equal(fs["first_valid_ping_time"], [ns[0], ns[12]])
+        for name, (lo, hi) in fs["transmit_params"].items():
+            a = np.asarray(beam[name].values)
+            np.testing.assert_array_equal(lo, np.nanmin(a, axis=1))
+            np.testing.assert_array_equal(hi, np.nanmax(a, axis=1))
+        if filter_pings is None:
+            assert "interval_starts" not in fs
+            continue
+        F = len(filter_pings)
+        exp_start = np.array([[not np.isnan(tau[c, p]) for p in filter_pings] for c in range(2)])
+        np.testing.assert_array_equal(fs["interval_starts"], exp_start)
+        exp_tau0 = np.array([[tau[c, p] for p in filter_pings] for c in range(2)])
+        np.testing.assert_array_equal(fs["interval_tau0"], exp_tau0)
+        lo, hi = fs["interval_transmit_params"]["transmit_duration_nominal"]
+        assert lo.shape == (2, F)
+        for c in range(2):
+            for f in range(F):
+                if exp_start[c, f]:
+                    assert lo[c, f] == hi[c, f] == np.nanmin(tau[c])
+                else:
+                    assert lo[c, f] == np.inf and hi[c, f] == -np.inf
