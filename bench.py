@@ -54,9 +54,10 @@ WORKLOADS = {
     "cfg4small": (2, 20_000, 8192, 20, 30),
     "cfg5": (4, 2_000_000, 4096, 2, 3),
     "small": (4, 20_000, 2000, 50, 50),
+    "next": (4, 100_000, 2000, 2, 2),  # SURVEY 8f rows through their API entry points (scripts/perf_masks.py's volume)
 }
-DEFAULT_LINES = ["cfg3", "cfg3:ss2000", "cfg3:f32", "cfg2", "cfg2:f32", "api", "api:chain", "cfg4", "cfg4:f32", "cfg4:planes64",
-                 "cfg5"]
+DEFAULT_LINES = ["cfg3", "cfg3:ss2000", "cfg3:f32", "cfg2", "cfg2:f32", "cfg2:int16", "api", "api:chain", "cfg4", "cfg4:f32",
+                 "cfg4:planes64", "next:depth", "next:masks", "next:nasc", "cfg5"]
 TILE_PINGS = 250_000
 DT = {"f32": "float32", "f64": "float64"}
 
@@ -83,6 +84,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend (nccl = RCCL; gloo only for dry runs of the N>1 logic)")
     ap.add_argument("--single-device", action="store_true", help="dry run: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--sharded-at-1", action="store_true",
+                    help="N = 1: a one-rank process group (--backend) and the SHARDED entry points per tile -- the host "
+                         "cost of the N > 1 route (control messages, exchange plan, collectives as identities) on one GPU")
     ap.add_argument("--out", default=None, help="also append every JSON line to this file")
     return ap.parse_args()
 
@@ -503,6 +507,101 @@ def run_api(ctx, cpu, variant=""):
                                   bps, traffic_key=f"api:{dtype}", note="region = both API calls incl. host work"))
 
 
+# ---------------------------------------------------------------------------------------- next:*
+def run_next(ctx, variant, cpu):
+    """The "next" rows of SURVEY 8f on the driver's record, each through its API entry point on a resident EK60 dataset
+    (4 x 100 000 x 2000, a new sound speed at every ping -- so every ping has its own range / depth vector):
+      depth  compute_Sv -> consolidate.add_depth(ds, depth_offset) -> commongrid.compute_MVBS(ds, range_var="depth")
+             (consolidate/api.py:68-243, commongrid/api.py:30-191): K1 12 + depth 12 + binning 16 = 40 B/sample
+      masks  clean.mask_impulse_noise / mask_attenuated_signal / mask_transient_noise on ``depth`` + mask.apply_mask of the
+             three (clean/api.py:30-359, mask/api.py:307-464): 3 x (8 + 8 + 1) + (8 + 3 + 8) = 70 B/sample
+      nasc   commongrid.compute_NASC(ds) (commongrid/api.py:269-416): Sv + depth read, 16 B/sample
+    (int16 ingest, the fourth row, is the ``cfg2:int16`` line.)  ``roofline`` = the HIP-event bracket round the calls of
+    one pass against those algorithmic bytes."""
+    import logging
+
+    import echopype_amd as ep
+
+    C, P, S = WORKLOADS["next"][:3]
+    key = ("next", C, P, S)
+    if key not in ctx.cache:
+        for k in [k for k in ctx.cache if k != key]:
+            del ctx.cache[k]
+        ctx.free()
+        d = ctx.synth.ek60_numpy(C, 4, 8)
+        h = ctx.synth.ek60_params(C, P, ss_every=1)
+        for k in ("sample_interval", "transmit_duration_nominal", "transmit_power", "sound_speed_indicative",
+                  "absorption_indicative"):
+            d[k] = h[k]
+        d["ping_time"] = h["ping_time"]
+        d["backscatter_r"] = ep.DeviceArray(ctx.synth.ek60_device(C, P, S, seed=20260509, ss_every=1)["backscatter_r"])
+        ctx.cache[key] = ep.echodata.from_ek60_arrays(d).to_device()
+    ed = ctx.cache[key]
+    dtype = ctx.dtype
+    logging.disable(logging.WARNING)
+    try:
+        if variant == "depth":
+            def one_pass(timer):
+                if timer is not None:
+                    timer.start()
+                ds = ep.calibrate.compute_Sv(ed, dtype=dtype)
+                ds = ep.consolidate.add_depth(ds, depth_offset=5.0)
+                mv = ep.commongrid.compute_MVBS(ds, range_var="depth", range_bin="1m", ping_time_bin="20s")
+                shape = mv["Sv"].shape
+                if timer is not None:
+                    timer.stop()
+                return shape
+            bps, kern = 40 if dtype == "float64" else 24, "sv_power + depth_rows + block_reduce / mvbs kernels of the three calls"
+            what = "compute_Sv -> add_depth(depth_offset=5) -> compute_MVBS(range_var='depth', 1m x 20s)"
+        else:
+            ds = ep.calibrate.compute_Sv(ed, dtype=dtype)
+            ds = ep.consolidate.add_depth(ds, depth_offset=5.0)
+            ds["Sv"].data.tensor, ds["depth"].data.tensor  # (resident arrays: the rows below start from an Sv dataset)
+            if variant == "masks":
+                def one_pass(timer):
+                    if timer is not None:
+                        timer.start()
+                    m1 = ep.clean.mask_impulse_noise(ds, depth_bin="5m", num_side_pings=2, impulse_noise_threshold="10.0dB")
+                    m2 = ep.clean.mask_attenuated_signal(ds, upper_limit_sl="150.0m", lower_limit_sl="250.0m",
+                                                         num_side_pings=15, attenuation_signal_threshold="8.0dB")
+                    m3 = ep.clean.mask_transient_noise(ds, func="nanmean", depth_bin="10m", num_side_pings=25,
+                                                       exclude_above="20.0m", transient_noise_threshold="12.0dB")
+                    out = ep.mask.apply_mask(ds, [m1, m2, m3])
+                    if timer is not None:
+                        timer.stop()
+                    return out
+                bps = 70 if dtype == "float64" else 38
+                kern = "range_bin_smooth + impulse_compare + attenuated_* + pool_value_* + mask_and + apply_mask kernels"
+                what = "mask_impulse_noise + mask_attenuated_signal + mask_transient_noise (on depth) + apply_mask"
+            elif variant == "nasc":
+                p = np.arange(P)
+                ds["latitude"] = (("ping_time",), 45.0 + 1e-5 * p)
+                ds["longitude"] = (("ping_time",), -125.0 + 2e-5 * p)
+
+                def one_pass(timer):
+                    if timer is not None:
+                        timer.start()
+                    out = ep.commongrid.compute_NASC(ds, range_bin="10m", dist_bin="0.5nmi")
+                    if timer is not None:
+                        timer.stop()
+                    return out
+                bps, kern = 16 if dtype == "float64" else 8, "nasc_accumulate + nasc_finalize kernels"
+                what = "compute_NASC(range_bin='10m', dist_bin='0.5nmi')"
+            else:
+                sys.exit(f"unknown next:{variant}")
+        passes = ctx.passes("next")
+        elapsed, region_ms = ctx.timed(one_pass, passes)
+    finally:
+        logging.disable(logging.NOTSET)
+    n = C * P * S
+    return line(ctx, samples_per_pass=n, passes=passes, elapsed=elapsed, scaling="weak", cpu=cpu,
+                metric="range-samples/sec through the SURVEY 8f row",
+                workload=f"next:{variant}: EK60 CW {C}x{P}x{S} Sv dataset resident in HBM, {what} through the Dataset API",
+                config={"sharding": "one GPU", "collective": "none", "sound_speed_changes_every_n_pings": 1},
+                roofline=roofline(kern, region_ms, n * bps, bps, traffic_key=f"next:{variant}:{dtype}",
+                                  note="region = the API calls of one pass incl. host work"))
+
+
 # ---------------------------------------------------------------------------------------- EK80 BB: cfg4
 def run_ek80(ctx, name, variant, cpu):
     """EK80 BB complex -> pulse compression + Sv (epa_sv_complex_fft) -> MVBS.  The per-(channel, ping) parameter rows
@@ -653,7 +752,7 @@ class Cfg5:
         eds = [self.echodata(i, offset_ns) for i in range(len(self.tiles))]
         dtype = ctx.dtype
         rb = f"{self.range_bin:g}m"
-        if ctx.world == 1:
+        if ctx.world == 1 and not getattr(ctx.args, "sharded_at_1", False):
             def call(ed):
                 ds = ep.calibrate.compute_Sv(ed, dtype=dtype)
                 return ds, ep.commongrid.compute_MVBS(ds, range_bin=rb, ping_time_bin="20s")
@@ -665,7 +764,10 @@ class Cfg5:
                 return sharding.compute_Sv_MVBS(ed, range_bin=rb, ping_time_bin="20s", dtype=dtype, shard=shard,
                                                 tau_effective_first_ping=tau0)
         pending = collections.deque()
-        state = {"last": None, "n_read": 0, "pass": 0}
+        # host_s / calls: wall time the HOST spends inside the entry-point calls of a tile (launches, control-plane
+        # messages; no wait for the GPU on the deferred routes) -- what has to stay under the kernel's ~9 ms per tile for
+        # the GPU to run back to back, and the per-call cost that decides the scaling at N = 8 (one tile per rank and pass)
+        state = {"last": None, "n_read": 0, "pass": 0, "host_s": 0.0, "calls": 0}
 
         def consume(item):
             ds, mv = item
@@ -682,7 +784,11 @@ class Cfg5:
                 for i, ed in enumerate(eds):
                     if timer is not None and i == timed_tile:
                         timer.start()
+                    t_host = time.perf_counter()
                     item = call(ed)
+                    if timer is not None:  # (timed passes only)
+                        state["host_s"] += time.perf_counter() - t_host
+                        state["calls"] += 1
                     if timer is not None and i == timed_tile:
                         timer.stop()
                     pending.append(item)
@@ -784,7 +890,7 @@ def run_cfg5(ctx, cpu):
     pass_c, finish_c, state, eds = job.api_layout(10_000_000_000)
     elapsed, region_ms = ctx.timed(pass_c, passes, finish=finish_c)
     assert state["n_read"] == len(job.tiles) * passes * (steps + args.warmup)  # every result was read
-    if world == 1:
+    if world == 1 and not getattr(args, "sharded_at_1", False):
         route = "compute_Sv(echodata) -> compute_MVBS(ds_Sv,'1m','20s') per tile"
         coll = "none at 1 rank (each tile its own dataset)"
     else:
@@ -792,8 +898,13 @@ def run_cfg5(ctx, cpu):
         coll = (f"per dataset of {world} tiles: cut bins all_reduce(SUM) + range max all_reduce(MAX) in HBM over "
                 f"{args.backend}; control scalars over gloo")
     # (ops_level_*: the kernels called directly on preallocated buffers, all cut bins of a rank's tiles exchanged)
+    host_ms = state["host_s"] / max(1, state["calls"]) * 1e3
+    if world > 1:  # the slowest rank's figure
+        t = ctx.torch.tensor([host_ms], dtype=ctx.torch.float64)
+        ctx.dist.all_reduce(t, op=ctx.dist.ReduceOp.MAX, group=ctx.sharding.control_group())
+        host_ms = float(t.item())
     cfg = {"tiles": f"{job.n_tiles} x {job.tile_p} pings over {world} rank(s)",
-           "route": route, "collective": coll, "results_read": "1 tile late",
+           "route": route, "collective": coll, "results_read": "1 tile late", "host_ms_per_call": host_ms,
            "mvbs_shape_last_tile": list(state["last"][0]),
            "ops_level_ms_per_pass": el_b / steps / passes * 1e3, "ops_level_kernel_ms": km_b,
            "ops_level_edge_bins": edges_b, "allreduce_bytes": bytes_b,
@@ -885,6 +996,13 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
+    if world == 1 and args.sharded_at_1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=0, world_size=1)
     ctx = Ctx(args, world, rank)
     also = {}
     for i, spec in enumerate(todo):
@@ -892,6 +1010,8 @@ def main():
         if w not in WORKLOADS:
             sys.exit(f"unknown workload {w!r}")
         ctx.dtype = DT.get(variant, args.dtype)
+        if w == "next" and not variant:
+            sys.exit("next:depth | next:masks | next:nasc")
         if w == "cfg5":
             ctx.cache.clear()
             ctx.free()
@@ -900,6 +1020,8 @@ def main():
             out = run_api(ctx, cpu.get("chain" if variant == "chain" else "ek60"), variant)
         elif w.startswith("cfg4"):
             out = run_ek80(ctx, w, variant, cpu.get("bb"))
+        elif w == "next":
+            out = run_next(ctx, variant, cpu.get("ek60"))
         else:
             out = run_ek60(ctx, w, variant, cpu.get(kind_of(w)))
         if rank == 0 and out is not None:
@@ -915,7 +1037,7 @@ def main():
                 with open(args.out, "a") as f:
                     f.write(txt + "\n")
         ctx.free()
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

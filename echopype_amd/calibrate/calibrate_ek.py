@@ -162,7 +162,15 @@ class CalibrateEK(CalibrateBase):
                 # merge of the slices needs (xr.merge(compat="no_conflicts"), calibrate/api.py:190-194) -- else the grid
                 ok = ~np.isnan(tau_eff)
                 first = np.array([row[m][0] if m.any() else np.nan for row, m in zip(tau_eff, ok)])
-                if np.all((tau_eff == first[:, None]) | ~ok):
+                same = np.all((tau_eff == first[:, None]) | ~ok)
+                pairs = getattr(self, "_pair_te", None)
+                if pairs:  # (every pair of the file, also those whose pings another shard holds: the file's answer)
+                    for ci in range(len(first)):
+                        vals = [v for c_, v in pairs if c_ == ci and not np.isnan(v)]
+                        if vals:
+                            first[ci] = vals[0]
+                            same = same and all(v == vals[0] for v in vals)
+                if same:
                     tau_eff = first
                 else:
                     te_dims = ("channel", "ping_time")
@@ -339,7 +347,9 @@ class CalibrateEK80(CalibrateEK):
                 if k + 1 < len(starts):
                     keep &= pt <= starts[k + 1] - np.timedelta64(1, "ns")
                 idx = np.flatnonzero(keep)
-                if idx.size == 0:  # (a ping shard: the interval lies on other ranks)
+                # (a ping shard may hold no ping of the interval: the pair stays in the plan -- its effective pulse length
+                #  is part of the file's answer for the channel, see _finish)
+                if idx.size == 0 and fsc.get("interval_starts") is None:
                     continue
                 rid[ci, idx] = len(pairs)
                 pairs.append((ci, int(np.flatnonzero(ft_all == start)[0]), idx))
@@ -372,8 +382,9 @@ class CalibrateEK80(CalibrateEK):
         te = np.full((C, P), np.nan)
         txs = []
         fsc = self.file_scalars or {}
+        self._pair_te = []  # (channel index, effective pulse length) of every pair of the FILE
         for ci, fi, idx in self._plan["pairs"]:
-            tau0 = tau[ci, idx[0]]
+            tau0 = tau[ci, idx[0]] if idx.size else np.nan
             whole = None
             if fsc.get("interval_tau0") is not None:  # a ping shard: the INTERVAL's first ping, its transmit parameters
                 tau0 = float(fsc["interval_tau0"][ci, fi])
@@ -394,6 +405,7 @@ class CalibrateEK80(CalibrateEK):
                                "falling back to transmit_duration_nominal. Error: %s", mode, repr(e))
                 val = tau0
             te[ci, idx] = tau0 if gpt[ci] else val
+            self._pair_te.append((ci, tau0 if gpt[ci] else val))
             txs.append(tx)
         return te, txs
 

@@ -95,7 +95,7 @@ def get_transmit_signal(beam, coeff, waveform_mode, fs, drop_last_hanning_zero=F
     file (or filter interval) -- the uniqueness test and the value are the file's, not the shard's, so that a shard
     holding none (or only some) of a channel's valid pings builds the same replica and raises the same error."""
     tt = np.asarray(beam["transmit_type"].values) if "transmit_type" in beam else None
-    if waveform_mode == "BB" and tt is not None and np.all(tt == "CW"):
+    if waveform_mode == "BB" and tt is not None and tt.size and np.all(tt == "CW"):  # (tt empty: a shard without pings)
         raise TypeError("File does not contain BB mode complex samples!")
     chans = list(beam["channel"].values)
     fs_all = np.asarray(getattr(fs, "values", fs), dtype=np.float64)

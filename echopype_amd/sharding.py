@@ -57,6 +57,7 @@ def _comm_device(group=None):
 # over a gloo group of the same ranks (TCP / shared memory between the processes of one node, ~100 us each); RCCL over
 # xGMI carries what lives in HBM: the cut-bin (sum, count) rows and the range maximum.
 _control = {}
+SEPARATE_CONTROL_GROUP = False  # test hook: a gloo control group of its own even when the data group is a gloo group
 
 
 def control_group(group=None):
@@ -70,7 +71,7 @@ def control_group(group=None):
     hit = _control.get(group)
     if hit is not None and hit[0] is world_pg:
         return hit[1]
-    if dist.get_backend(group) == "gloo":
+    if dist.get_backend(group) == "gloo" and not SEPARATE_CONTROL_GROUP:
         ctl = group
     else:
         ranks = dist.get_process_group_ranks(group if group is not None else world_pg)

@@ -34,17 +34,19 @@ def _check_line(d, want_cpu):
         assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
 
 
-LINES = os.path.join(ROOT, "profiles", "r04_bench_default.jsonl")
+LINES = os.path.join(ROOT, "profiles", "r05_bench_default.jsonl")
 
 
 def test_committed_bench_lines_keep_the_contract():
     if not os.path.exists(LINES):
         pytest.skip("no committed default run of this round yet")
     lines = [json.loads(x) for x in open(LINES) if x.strip()]
-    assert len(lines) == 11
+    assert len(lines) == 15
     for d in lines:
         _check_line(d, want_cpu=True)
         assert d["n_gpus"] == 1 and d["config"]["passes_per_step"] >= 1
+        if d["config"]["workload"].startswith("next:"):  # (a SURVEY 8f row: its own metric string)
+            assert "SURVEY 8f" in d["metric"]
         n = d["config"]["samples_per_step"]
         assert abs(d["value"] - n / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6    # value = samples per step / step time
         assert len(json.dumps(d)) < 2000                                              # a line fits the driver's tail
@@ -59,11 +61,13 @@ def test_committed_bench_lines_keep_the_contract():
     assert head["roofline"]["frac"] >= 0.60
     assert all(d["roofline"]["traffic"] is not None for d in lines), [d["config"]["workload"][:12] for d in lines if d["roofline"]["traffic"] is None]
     also = {k for k in head["config"] if k.startswith("also_")}   # the other lines' figures, one flat string per family
-    assert also == {"also_cfg3", "also_cfg2", "also_api", "also_cfg4", "also_unit"}
+    assert also == {"also_cfg3", "also_cfg2", "also_api", "also_cfg4", "also_next", "also_unit"}
+    assert head["config"]["also_next"].count(";") == 2 and "int16" in head["config"]["also_cfg2"]  # the SURVEY 8f rows
+    assert head["config"]["host_ms_per_call"] > 0
     assert all(len(head["config"][k]) <= 120 for k in also)
     assert head["config"]["also_cfg3"].count(";") == 2 and "ss2000" in head["config"]["also_cfg3"]
     by = {d["config"]["workload"].split(":")[0] + ":" + d["dtype"] for d in lines}
-    assert {"cfg2:f64", "cfg2:f32", "cfg3:f64", "cfg3:f32", "cfg4:f64", "cfg4:f32", "cfg5:f64", "api:f64"} <= by
+    assert {"cfg2:f64", "cfg2:f32", "cfg3:f64", "cfg3:f32", "cfg4:f64", "cfg4:f32", "cfg5:f64", "api:f64", "next:f64"} <= by
     # the chain through the reference's THREE calls runs at the chain kernels' own speed (ops-level: the cfg3 line)
     chain = [d for d in lines if d["config"]["workload"].startswith("api:chain")]
     cfg3 = [d for d in lines if d["config"]["workload"].startswith("cfg3") and d["dtype"] == "f64"]

@@ -679,7 +679,7 @@ def test_resample_edges_sorted_shortcut_equals_the_scan():
 def test_deferred_dataset_assembles_once_on_first_use():
     """xr_lite.DeferredDataset: a Dataset whose build() runs when anything touches it -- once; it IS a Dataset for every
     isinstance check of the package, forwards reads and writes to the built object, and lets a failing build surface at
-    that first use (and say so on later ones)."""
+    that first use (and again, the same error, on later ones)."""
     from echopype_amd.xr_lite import DataArray, Dataset, DeferredDataset
 
     calls = []
@@ -709,7 +709,7 @@ def test_deferred_dataset_assembles_once_on_first_use():
     bd = DeferredDataset(bad)
     with pytest.raises(ValueError, match="range bins are empty"):
         bd.sizes
-    with pytest.raises(RuntimeError, match="failed earlier"):
+    with pytest.raises(ValueError, match="range bins are empty"):  # the SAME error again, not a generic "failed earlier"
         bd["v"]
 
 

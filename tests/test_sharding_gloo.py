@@ -487,3 +487,49 @@ def test_file_scalars_equal_the_whole_files(cuts, filter_pings):
                     assert lo[c, f] == hi[c, f] == np.nanmin(tau[c])
                 else:
                     assert lo[c, f] == np.inf and hi[c, f] == -np.inf
+
+
+# ---- the control group of a strict SUB-group is created by its members alone (round-4 advice) ---------------------------
+def _worker_subgroup(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from echopype_amd import sharding
+
+    sub = dist.new_group(ranks=[0, 1])  # (collective over the world: every rank, also rank 2)
+    out = None
+    if rank < 2:
+        sharding.SEPARATE_CONTROL_GROUP = True  # the path an RCCL data group takes: a gloo group of the same ranks
+        ns = np.datetime64("2026-05-01T00:00:03", "ns").astype(np.int64) + (np.arange(30) + 30 * rank) * 10**9
+        e0, n = sharding.global_time_grid(ns, 20 * 10**9, group=sub)   # first sharded call: creates the control group
+        ctl = sharding.control_group(sub)
+        assert ctl is not sub and dist.get_process_group_ranks(ctl) == [0, 1]
+        ctx = sharding.ShardContext(sub)
+        out = (e0, n, sharding.global_max(float(rank), group=sub), ctx.agree(rank == 1))
+        # a control group handed in instead
+        mine = dist.new_group(ranks=[0, 1], backend="gloo", use_local_synchronization=True)
+        sharding.register_control_group(sub, mine)
+        assert sharding.control_group(sub) is mine
+        out += (sharding.global_max(10.0 + rank, group=sub),)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_control_group_of_a_sub_group_is_created_by_its_members_only():
+    """Ranks 0 and 1 of a three-rank world shard a dataset between them; rank 2 never calls into sharding.  The gloo
+    control group behind the sub-group's host-side agreements must come up without rank 2 (dist.new_group with
+    use_local_synchronization) -- it used to wait for every rank of the default group."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_subgroup, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[2] is None
+    assert res[0] == res[1] and res[0][1] == 4 and res[0][2] == 1.0 and res[0][3] is True and res[0][4] == 11.0
