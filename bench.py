@@ -707,7 +707,9 @@ class Cfg5:
         dt = ctx.dt
         esz = 8 if ctx.dtype == "float64" else 4
         free_b = torch.cuda.mem_get_info()[0]
-        self.keep_all = sum((b - a) for a, b in self.spans) * C * S * esz < free_b - (8 << 30)  # Sv of every tile resident?
+        # Sv of every tile resident?  (not when the ranks share one device: each sees the same free memory)
+        self.keep_all = sum((b - a) for a, b in self.spans) * C * S * esz < free_b - (8 << 30) and \
+            not getattr(ctx.args, "single_device", False)
         self.sv = None
         self.shard = sharding.ShardContext()
 

@@ -221,7 +221,8 @@ def _shard_grid(_shard, ns, dt, r_cap, range_var_max):
     """One rank's ping shard: the time grid and the range cap of the WHOLE dataset in ONE control message
     (sharding.MVBSShard.grid).  Returns (left edge of this shard's first bin, number of its bins, global index of its
     first / last bin, the range cap to launch on)."""
-    e0, _, first_bin, last_bin, g_cap = _shard.grid(ns, dt, "left", r_cap if range_var_max is None else float("nan"))
+    e0, _, first_bin, last_bin, g_cap = _shard.grid(ns, dt, "left", r_cap if range_var_max is None else float("nan"),
+                                                    sorted_valid=True)  # (the deferred routes serve sorted, valid pings only)
     return e0 + first_bin * dt, last_bin - first_bin + 1, first_bin, last_bin, (g_cap if range_var_max is None else r_cap)
 
 
@@ -296,8 +297,11 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
     # served by the generic kernel (a handful of pings, a grid beyond the LDS)?  It leaves no range statistics, which
     # every later step asks for -- K1 does, on the plain route.  (Known on the host: epa_last_range_stats_filled.)
     declined = res is None or not res["range_stats_filled"]
-    if _shard is not None:  # the plain route runs other collectives: every rank takes it if any has to
-        declined = _shard.agree(declined)
+    done = None
+    if _shard is not None:  # the plain route runs other collectives: every rank takes it if any has to -- the vote rides
+        done = _shard.finish(None if declined else res, first_bin, last_bin, fill_value,  # with the exchange plan's message
+                             shape=(C, n_t, n_cap), device=src.raw.device)
+        declined = done is None
     if declined:
         return None
     rng = src.echo_range
@@ -310,10 +314,10 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
         # nanmax(echo_range) of the whole dataset: all-reduced (MAX) where it lies, behind the kernel; cut bins: totals
         # over all ranks, reported by the lowest holder (one all-reduce in HBM) -- the host waits for neither
         gmax = ops.fetch_async(_shard.range_max_device(res["range_stats"][1:2].clone())) if range_var_max is None else None
-        mv_full, lo = _shard.finish(res, first_bin, last_bin, fill_value)
+        mv_full, lo = done
         e0, n_t = e0 + lo * dt, mv_full.shape[1]
         ds_Sv = ds_Sv.copy()
-        del res
+        del res, done
 
         def build_shard():
             return _shard_assemble(ds_Sv, mv_full, n_cap, gmax.item() if gmax is not None else r_cap, r_cap,
@@ -393,15 +397,18 @@ def _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_v
                                   minmax_async=True, ping_phase=src.ping_phase, want_partials=_shard is not None)
     except _lib.EpaError:  # e.g. a range grid too fine for the LDS accumulators
         pass
-    if (_shard.agree(res is None) if _shard is not None else res is None):
+    done = None
+    if _shard is not None:  # (the vote on the fallback rides with the exchange plan's message)
+        done = _shard.finish(res, first_bin, last_bin, fill_value, shape=(C, n_t, n_cap), device=p.raw.device)
+    if (done is None) if _shard is not None else res is None:
         return None
     src.install(res)
     rng = p.echo_range
     if _shard is not None:  # cut bins: totals over all ranks, reported by the lowest holder (one all-reduce in HBM)
-        mv_full, lo = _shard.finish(res, first_bin, last_bin, fill_value)
+        mv_full, lo = done
         e0, n_t = e0 + lo * dt, mv_full.shape[1]
         ds_Sv, gmax = ds_Sv.copy(), src.global_rmax
-        del res
+        del res, done
 
         def build_shard():
             st = rng.cached_stats()  # (local: the NaN-coordinate warning)

@@ -61,7 +61,7 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
             raise NotImplementedError("a ping shard needs sorted, valid ping times")
         ds_Sv = _compute_cal("Sv", echodata, **cal_kw)  # unsorted / NaT pings: generic path
         return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)
-    e0, dt, n_t = resample_edges(ping_time, ping_time_bin)
+    e0, dt, n_t = resample_edges(ping_time, ping_time_bin, sorted_valid=True)
     first_bin = 0
 
     # range grid np.arange(0, nanmax(echo_range) + bin, bin) (api.py:108-115): run on a conservative
@@ -78,7 +78,8 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
     if _shard is not None:
         # the time grid of the whole dataset (this shard covers global bins first_bin .. last_bin) and its range cap:
         # ONE control message
-        e0, _, first_bin, last_bin, g_cap = _shard.grid(ns, dt, "left", r_cap if range_var_max is None else float("nan"))
+        e0, _, first_bin, last_bin, g_cap = _shard.grid(ns, dt, "left", r_cap if range_var_max is None else float("nan"),
+                                                        sorted_valid=True)  # (checked above)
         e0, n_t = e0 + first_bin * dt, last_bin - first_bin + 1
         if range_var_max is None:
             r_cap = g_cap
@@ -95,7 +96,10 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
                                     want_partials=_shard is not None)
         except _lib.EpaError:
             pass
-    if (res is None) if _shard is None else _shard.agree(res is None):
+    # (on a shard the plan of the cut-bin exchange and the vote on the fallback travel in ONE control message)
+    done = None if _shard is None else _shard.finish(res, first_bin, last_bin, fill_value, shape=(C, n_t, n_cap),
+                                                     device=raw.device)
+    if (res is None) if _shard is None else done is None:
         ds_Sv = _compute_cal("Sv", echodata, _file=_file, **cal_kw)
         return ds_Sv, compute_MVBS(ds_Sv, **mv_kw)
     # nanmax(echo_range) stays in HBM: on a shard it is all-reduced (MAX) there, behind the kernel; the host reads it
@@ -105,7 +109,7 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
         rmax_t = _shard.range_max_device(rmax_t)
     rmax_f = ops.fetch_async(rmax_t)  # (on its way to the host behind this kernel / all-reduce, on a side stream)
     if _shard is not None:  # bins cut by a shard edge: totals over all ranks, reported by the lowest holder
-        res["MVBS"], lo = _shard.finish(res, first_bin, last_bin, fill_value)
+        res["MVBS"], lo = done
         e0, n_t = e0 + lo * dt, res["MVBS"].shape[1]
 
     dims = ("channel", "ping_time", "range_sample")

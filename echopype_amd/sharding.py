@@ -123,14 +123,18 @@ def global_time_grid(local_ping_ns, dt_ns, group=None):
     return e0, int((last - e0) // dt_ns + 1)
 
 
-def global_grid(local_ping_ns, dt_ns, reach, group=None):
+def global_grid(local_ping_ns, dt_ns, reach, group=None, sorted_valid=False):
     """``global_time_grid`` and ``global_max`` of a non-negative number in ONE message: all-reduce MIN of
     [first timestamp, -last timestamp, -bits(reach)] (the IEEE bit pattern of a non-negative double orders like the
-    number).  Returns (first_edge, n_bins_global, global reach; NaN when no rank has one)."""
+    number).  Returns (first_edge, n_bins_global, global reach; NaN when no rank has one).  ``sorted_valid``: the
+    caller has checked that the timestamps are sorted and hold no NaT -- the ends are the extremes (no O(P) pass)."""
     t = np.asarray(local_ping_ns, dtype=np.int64)
-    t = t[t != np.iinfo(np.int64).min]
-    lo = int(t.min()) if t.size else np.iinfo(np.int64).max
-    hi = int(t.max()) if t.size else np.iinfo(np.int64).min + 1
+    if sorted_valid and t.size:
+        lo, hi = int(t[0]), int(t[-1])
+    else:
+        t = t[t != np.iinfo(np.int64).min]
+        lo = int(t.min()) if t.size else np.iinfo(np.int64).max
+        hi = int(t.max()) if t.size else np.iinfo(np.int64).min + 1
     r = float(reach)
     rbits = int(np.float64(r).view(np.int64)) if (r == r and r >= 0.0 and r != float("inf")) else -1
     first, neg_last, neg_rbits = _host_allreduce([lo, -hi, -rbits], dist.ReduceOp.MIN, group)
@@ -166,10 +170,13 @@ def global_max_device(t, group=None):
     return t
 
 
-def local_bin_span(local_ping_ns, e0, dt_ns, closed="left"):
-    """Global indices (first, last) of the time bins this shard's pings fall in."""
+def local_bin_span(local_ping_ns, e0, dt_ns, closed="left", sorted_valid=False):
+    """Global indices (first, last) of the time bins this shard's pings fall in (``sorted_valid``: see global_grid)."""
     t = np.asarray(local_ping_ns, dtype=np.int64)
-    t = t[t != np.iinfo(np.int64).min]
+    if sorted_valid and t.size:
+        t = t[[0, -1]]  # (the bin index is monotone in the timestamp)
+    else:
+        t = t[t != np.iinfo(np.int64).min]
     if t.size == 0:
         return 0, -1
     if closed == "left":
@@ -325,19 +332,29 @@ class ShardContext:
         self.group = group
         self._plans = {}
 
-    def _global_key(self, key):
+    def _global_key(self, key, flag=False):
+        """(digests of every rank's layout, True if ``flag`` is set on any rank) -- ONE control message: the vote rides
+        in an extra slot of the gather."""
         import hashlib
 
         h = int.from_bytes(hashlib.blake2b(repr(key).encode(), digest_size=8).digest(), "little", signed=True)
         if not _collective(self.group):
-            return (h,)
-        t = torch.zeros(_world(self.group), dtype=torch.int64)
+            return (h,), bool(flag)
+        w = _world(self.group)
+        t = torch.zeros(w + 1, dtype=torch.int64)
         t[_rank(self.group)] = h
+        t[w] = 1 if flag else 0
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=control_group(self.group))  # (one non-zero term per element: a gather)
-        return tuple(int(v) for v in t.tolist())
+        vals = t.tolist()
+        return tuple(int(v) for v in vals[:w]), vals[w] > 0
 
-    def plan(self, spans, C, R, device):
-        key = self._global_key((tuple((int(f), int(l)) for f, l in spans), int(C), int(R), str(torch.device(device))))
+    def plan(self, spans, C, R, device, declined=None):
+        """The exchange plan of this layout (kept between calls).  ``declined`` (bool): the call doubles as the vote on a
+        fallback -- returns None when any rank declined (every rank then takes the fallback, nobody builds a plan)."""
+        key, any_declined = self._global_key((tuple((int(f), int(l)) for f, l in spans), int(C), int(R),
+                                              str(torch.device(device))), bool(declined))
+        if declined is not None and any_declined:
+            return None
         if key not in self._plans:
             self._plans[key] = EdgeExchange(spans, C, R, device, self.group)
         return self._plans[key]
@@ -433,10 +450,10 @@ class MVBSShard(ShardContext):
         first, last = local_bin_span(ns, e0, dt, closed)
         return e0, n_glob, first, last
 
-    def grid(self, ns, dt, closed, reach):
+    def grid(self, ns, dt, closed, reach, sorted_valid=False):
         """time_grid + range_max(reach) in one control message (reach >= 0 or NaN)."""
-        e0, n_glob, gr = global_grid(ns, dt, reach, self.group)
-        first, last = local_bin_span(ns, e0, dt, closed)
+        e0, n_glob, gr = global_grid(ns, dt, reach, self.group, sorted_valid=sorted_valid)
+        first, last = local_bin_span(ns, e0, dt, closed, sorted_valid=sorted_valid)
         return e0, n_glob, first, last, gr
 
     def range_max(self, hi):
@@ -445,12 +462,20 @@ class MVBSShard(ShardContext):
     def range_max_device(self, t):
         return global_max_device(t, self.group)
 
-    def finish(self, res, first_bin, last_bin, fill_value):
+    def finish(self, res, first_bin, last_bin, fill_value, shape=None, device=None):
         """Merged, finalised MVBS of the bins this rank reports: (tensor (C, n_kept, R), index of the first kept
-        local bin)."""
-        ssum, cnt, mv = res["sum"], res["cnt"], res["MVBS"]
-        n_local = mv.shape[1]
-        plan = self.plan([(first_bin, last_bin) if n_local else (0, -1)], mv.shape[0], mv.shape[2], mv.device)
+        local bin).  With ``shape`` = (C, local bins, R) the call is also the vote on a fallback: ``res`` None = this
+        rank's kernel declined; returns None on EVERY rank if any declined (one control message for plan and vote)."""
+        if shape is not None:
+            C, n_local, R = shape
+            plan = self.plan([(first_bin, last_bin) if n_local else (0, -1)], C, R, device, declined=res is None)
+            if plan is None:
+                return None
+            ssum, cnt, mv = res["sum"], res["cnt"], res["MVBS"]
+        else:
+            ssum, cnt, mv = res["sum"], res["cnt"], res["MVBS"]
+            n_local = mv.shape[1]
+            plan = self.plan([(first_bin, last_bin) if n_local else (0, -1)], mv.shape[0], mv.shape[2], mv.device)
         rows = {(0, w): r for w, r in mvbs_edge_rows(ssum, cnt).items()} if n_local else {}
         plan.merge_mvbs(rows, {(0, 0): mv[:, 0], (0, 1): mv[:, n_local - 1]} if n_local else {}, fill_value)
         lo, hi = 0, n_local

@@ -360,6 +360,11 @@ def _worker_plan_cache(rank, world, port, q):
                                 torch.full((C, R), 1.0, dtype=torch.float64))
         tot = plan.merge(rows)
         out.append((plan.shared, len(plan.edges), {k: float(v[0][0, 0]) for k, v in tot.items()}))
+    # the plan's message doubles as the vote on a fallback: a rank that declines takes every rank with it, in ONE message
+    n_plans = len(shard._plans)
+    votes = [shard.plan(seq[0], C, R, "cpu", declined=(rank == 1 and k == 1)) for k in range(3)]
+    assert [v is None for v in votes] == [False, True, False] and len(shard._plans) == n_plans
+    assert votes[0] is shard.plan(seq[0], C, R, "cpu")
     q.put((rank, out, len(shard._plans)))
     dist.barrier()
     dist.destroy_process_group()
