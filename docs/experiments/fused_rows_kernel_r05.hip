@@ -1,19 +1,22 @@
 // EXPERIMENT, NOT COMPILED INTO THE LIBRARY (round 5) -- the row-major form of fused_sv_mvbs_kernel.
 //
-// Why it was written: scripts/probes/hbm_walk2_probe.hip / hbm_walk3_probe.hip (profiles/r05_walk_probes.txt) show that the
-// headline traffic mix (4 B read + 8 B written per sample) streams at 5.1-5.4 TB/s for EVERY walk in which a workgroup
-// strides through its 20 rows a 1024-sample piece at a time (the shipped kernel: 5.3), and at 6.0-6.3 TB/s when a workgroup
-// takes its 20 rows WHOLE, one after the other (one contiguous run of 20 x S samples; XCD-contiguous order of the bins).
-// Why it is not shipped: a lane then meets 16 columns per ping and cannot carry lane-private sums for them, so every
-// pair of samples goes to the LDS accumulators with atomics and the bin index is computed per sample.  Measured
-// (profiles/r05_fused_rows_experiment.txt, 4 x 250 000 x 4096, fp64, same box, interleaved):
+// Why it was written: on two boxes of the pool the headline traffic mix (4 B read + 8 B written per sample) streamed at
+// 6.0-6.3 TB/s when a workgroup takes its 20 rows WHOLE, one after the other (one contiguous run of 20 x S samples,
+// XCD-contiguous order of the bins), against 5.1-5.4 TB/s for every walk that strides through the rows a 1024-sample
+// piece at a time (scripts/probes/hbm_walk{2,3,3b}_probe.hip).  The side-by-side probe (hbm_walk5_probe.hip, three
+// walks on ONE box, run on two more boxes) then showed that figure to be a property of those boxes: elsewhere the
+// row-major walk is 3 % ahead of the shipped one (5.12-5.22 against 4.95-5.07 TB/s), and only the loop-free walk
+// (one 1024-sample piece per workgroup, 6.2 TB/s everywhere) is really faster -- and that one cannot own a time bin
+// (its bins through global atomics: 4.3-5.5 TB/s).  All of it in profiles/r05_walk_probes.txt.
+// Why it is not shipped: a lane of the row-major form meets 16 columns per ping and cannot carry lane-private sums
+// for them, so every pair of samples goes to the LDS accumulators with atomics and the bin index is computed per sample.
+// Measured (profiles/r05_fused_rows_experiment.txt, 4 x 250 000 x 4096, fp64, same box, interleaved):
 //     this kernel   12.0-12.4 ms with the Sv store, 10.2 ms without      (fp32: 14.2 ms -- the LDS float add)
 //     shipped        9.2- 9.4 ms                      5.2 ms
-// i.e. the walk is better (on 4 x 500 000 x 2000 the two kernels are within 3 % although this one does 7.0 ms of
-// arithmetic + LDS traffic against 5.35) but the per-sample LDS atomics and the arithmetic that replaces the column state
-// do not hide behind the memory time at four wavefronts per SIMD.  It passed the GPU suite (257 tests up to the first one
-// that asserts the kernel's NAME).  Kept here so that the next attempt starts from working code: what it needs is a way to
-// reduce the 5 samples of a range bin before they reach LDS (one atomic per bin and ping instead of one per pair).
+// On 4 x 500 000 x 2000 (two chunks, cached logs) the two are within 3 % although this one does 7.0 ms of arithmetic +
+// LDS traffic against 5.35.  It passed the GPU suite (257 tests up to the first one that asserts the kernel's NAME).
+// (This file is the FIRST form, four chunks unrolled flat -- ~200 registers; the measured one took a ping in two groups
+//  of two chunks with the logarithm evaluated per sample: git show 5427237:echopype_amd/csrc/fused_sv_mvbs.hip.)
 // Drop-in: paste above `launch()` in csrc/fused_sv_mvbs.hip and dispatch from epa_fused_fast_path for S <= 4096.
 
 // ---- the ROW-MAJOR form of the same kernel (round 5) -----------------------------------------------------------------

@@ -9,6 +9,8 @@
 // samples so that every wavefront access is a contiguous run of 16 B per lane (LaneMap in
 // sample_math.h).  The row constants are wave-uniform -> scalar loads.  HBM-bound: 4 B in + 8 B (f64) out per sample (+8 B with
 // echo_range); MFMA is irrelevant here (no contraction).
+#include "fast_math.h"
+#include "log_tab_data.h"
 #include "sample_math.h"
 
 namespace {
@@ -86,6 +88,197 @@ __global__ __launch_bounds__(epa::kBlock) void sv_power_kernel(const float* __re
   }
 }
 
+// ---- the same pass as ONE-PIECE workgroups (round 5) ------------------------------------------------------------------
+// sv_power_kernel above keeps a workgroup on one range chunk while it strides over the rows (the cached column logs
+// then never change).  Measured on the traffic mix alone (scripts/probes/hbm_walk5_probe.hip, profiles/r05_walk_probes.txt,
+// every box of the pool): a workgroup that LOOPS over strided pieces streams 4 B read + 8 B written per sample at
+// 5.0-5.4 TB/s, a workgroup that takes ONE 1024-sample piece and ends at 6.2 TB/s.  Nothing in compute_Sv ties a
+// workgroup to more than one piece -- only the cached n log10(s - d) did; here it is evaluated per sample instead
+// (table-driven, ~22 instructions, from the 2-KB table in device memory: a workgroup that lives for four samples per lane
+// cannot build it in LDS), and a workgroup is (row, chunk), chunk fastest, the XCDs walking contiguous eighths.
+// Same arithmetic otherwise (cal_power_sample); the logarithm is fast_log10_lean's (4e-16) instead of ocml's: Sv moves by
+// less than 1e-14 dB against the kernel above.  {min, max, NaN count} of the echo_range go to three ordered keys with
+// atomics a wavefront issues only when its value would change the key (almost never after the first workgroups).
+__device__ __forceinline__ unsigned long long ordered_key(double v) {
+  const unsigned long long b = __double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+constexpr int kStatSlots = 4096;  // {max key, min key, NaN count} per slot; a wavefront uses slot (row mod kStatSlots)
+constexpr unsigned long long kDKeyNone = ~0ull;
+
+// n log10(s - d) of a sample: from the channel's table when every row of the channel has the same d (EK files: d is the
+// TVG correction in samples, a constant of the channel), else evaluated here.
+template <typename T>
+__device__ __forceinline__ T piece_nlog(double sd, T nspread) {
+  if (sizeof(T) == 4) return nspread * epa::M<T>::log10((T)sd);
+  if (__builtin_expect(sd >= 1.0, 1)) return nspread * (T)epa::fast_log10_lean(sd, epa::kLogTabGlobal);
+  return nspread * epa::log10_noinline<T>((T)sd);
+}
+
+// {min, max} of the rows' d per channel as ordered keys (a NaN d, or rows that differ in ra -- the table would not depend
+// on it, but a channel whose sample interval changes is not the plain case -- poison the channel: keys {0, ~0})
+__global__ __launch_bounds__(epa::kBlock) void d_span_kernel(const epa::CoefRow* __restrict__ coef, int P,
+                                                             unsigned long long* __restrict__ dkeys) {
+  const int c = blockIdx.y;
+  double lo = __builtin_inf(), hi = -__builtin_inf();
+  bool bad = false;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+    const double d = coef[(size_t)c * P + p].d;
+    bad |= !(d == d);
+    lo = fmin(lo, d);
+    hi = fmax(hi, d);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fmin(lo, __shfl_down(lo, o, 64));
+    hi = fmax(hi, __shfl_down(hi, o, 64));
+  }
+  const bool any_bad = __ballot(bad) != 0ull;
+  if ((threadIdx.x & 63) == 0) {
+    if (any_bad) {
+      atomicMin(dkeys + 2 * c, 0ull);
+      atomicMax(dkeys + 2 * c + 1, kDKeyNone);
+    } else if (lo <= hi) {
+      atomicMin(dkeys + 2 * c, ordered_key(lo));
+      atomicMax(dkeys + 2 * c + 1, ordered_key(hi));
+    }
+  }
+}
+__global__ void d_keys_init_kernel(unsigned long long* dkeys, int C) {
+  for (int i = threadIdx.x; i < C; i += blockDim.x) {
+    dkeys[2 * i] = kDKeyNone;
+    dkeys[2 * i + 1] = 0ull;
+  }
+}
+// table[c][s] = nspread * log10(s - d_c), the value ColumnLog::update caches (same out-of-line ocml log10: the same bits)
+template <typename T>
+__global__ __launch_bounds__(epa::kBlock) void nl_table_kernel(const unsigned long long* __restrict__ dkeys, int S,
+                                                               T nspread, T* __restrict__ table) {
+  const int c = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long klo = dkeys[2 * c], khi = dkeys[2 * c + 1];
+  if (klo != khi || s >= S) return;  // (not one d for the channel: the table is not used)
+  const double d = __longlong_as_double((long long)((klo >> 63) ? (klo & 0x7fffffffffffffffull) : ~klo));
+  table[(size_t)c * S + s] = nspread * epa::log10_noinline<T>((T)((double)s - d));
+}
+
+template <typename T, bool RANGE, bool STATS>
+__global__ __launch_bounds__(epa::kBlock) void sv_power_piece_kernel(const float* __restrict__ raw,
+                                                                     const epa::CoefRow* __restrict__ coef, int S, int P,
+                                                                     int chunks_per_row, T nspread, unsigned flags,
+                                                                     T* __restrict__ out, T* __restrict__ range_out,
+                                                                     unsigned long long* __restrict__ keys,
+                                                                     const unsigned long long* __restrict__ dkeys,
+                                                                     const T* __restrict__ table, int xcd_map) {
+  using LM = epa::LaneMap<T>;
+  constexpr int NSEG = LM::NSEG, LEN = LM::LEN;
+  const bool guard = flags & EPA_FLAG_GUARD_POS;
+  const bool mask_range = flags & EPA_FLAG_MASK_RANGE;
+  const int b = xcd_map ? epa::xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int row = b / chunks_per_row, chunk = b - row * chunks_per_row;
+  const epa::RowK<T> rk(coef[row]);
+  bool tabled = false;  // (scalar)
+  const T* __restrict__ trow = nullptr;
+  if (sizeof(T) == 8 && table) {
+    const int c = row / P;
+    tabled = dkeys[2 * c] == dkeys[2 * c + 1];
+    trow = table + (size_t)c * S;
+  }
+  double lo = __builtin_inf(), hi = -__builtin_inf();
+  unsigned nn = 0u;
+  // (the slot's keys are requested FIRST, with plain loads: their latency hides behind the samples', and a stale value --
+  //  from a cache or from another wavefront's update in flight -- only makes the test below conservative)
+  unsigned long long* kslot = STATS ? keys + 3 * (row & (kStatSlots - 1)) : nullptr;
+  unsigned long long kmax = 0ull, kmin = 0ull;
+  if (STATS) {
+    kmax = *reinterpret_cast<volatile unsigned long long*>(kslot + 0);
+    kmin = *reinterpret_cast<volatile unsigned long long*>(kslot + 1);
+  }
+#pragma unroll
+  for (int g = 0; g < NSEG; ++g) {
+    const int s0 = LM::first(chunk * 1024, g);
+    if (s0 >= S) continue;
+    const size_t off = (size_t)row * S + s0;
+    epa::RawVec<LEN> in;
+    in.load(raw + off);
+    T nl[LEN];
+    if (tabled) epa::load_vec<T, LEN>(trow + s0, nl);
+    T o[LEN], rg[LEN];
+#pragma unroll
+    for (int j = 0; j < LEN; ++j) {
+      const double r = rk.range(s0 + j);
+      if (!tabled) nl[j] = piece_nlog<T>((double)(s0 + j) - rk.d, nspread);
+      o[j] = epa::cal_power_sample<T>(in.v[j], s0 + j, rk, nspread, nl[j], guard, r);
+      if (RANGE || STATS) rg[j] = (mask_range && !(in.v[j] == in.v[j])) ? epa::M<T>::nan() : (T)r;
+      if (STATS) {
+        const double x = (double)rg[j];
+        lo = fmin(lo, x);  // fmin / fmax ignore a NaN operand
+        hi = fmax(hi, x);
+        nn += (unsigned)__builtin_popcountll(__ballot(!(x == x)));  // (the wavefront's count, in a scalar register)
+      }
+    }
+    epa::store_vec<T, LEN>(out + off, o);
+    if (RANGE) epa::store_vec<T, LEN>(range_out + off, rg);
+  }
+  if (STATS) {
+    // One of kStatSlots slots per row (a single key sees an atomic from nearly every row of a file whose sound speed
+    // drifts: 30 ms of serialised atomics, measured).  A workgroup lives for four samples per lane, so even the
+    // wavefront reduction is too dear to run every time (+35 %, measured): every lane first tests its own values against
+    // the slot's keys as they are now (a stale read only makes the test conservative: the keys move one way), and the
+    // wavefront reduces and touches the slot only if some lane would move a key -- almost never after the first rows.
+    unsigned long long* k = kslot;
+    const bool need = (hi > -__builtin_inf() && ordered_key(hi) > kmax) || (lo < __builtin_inf() && ordered_key(lo) < kmin);
+    if (__ballot(need) != 0ull) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        lo = fmin(lo, __shfl_down(lo, o, 64));
+        hi = fmax(hi, __shfl_down(hi, o, 64));
+      }
+      if ((threadIdx.x & 63) == 0) {
+        if (hi > -__builtin_inf()) atomicMax(k + 0, ordered_key(hi));
+        if (lo < __builtin_inf()) atomicMin(k + 1, ordered_key(lo));
+      }
+    }
+    if (nn > 0u && (threadIdx.x & 63) == 0) atomicAdd(k + 2, (unsigned long long)nn);
+  }
+}
+
+__global__ __launch_bounds__(epa::kBlock) void piece_keys_init_kernel(unsigned long long* keys) {
+  for (int i = threadIdx.x; i < kStatSlots; i += blockDim.x) {
+    keys[3 * i + 0] = 0ull;   // max key: nothing seen
+    keys[3 * i + 1] = ~0ull;  // min key: nothing seen
+    keys[3 * i + 2] = 0ull;   // NaN count
+  }
+}
+__global__ __launch_bounds__(epa::kBlock) void piece_keys_decode_kernel(const unsigned long long* keys, double* stats) {
+  __shared__ unsigned long long smax[4], smin[4], scnt[4];
+  unsigned long long mx = 0ull, mn = ~0ull, cnt = 0ull;
+  for (int i = threadIdx.x; i < kStatSlots; i += blockDim.x) {
+    mx = keys[3 * i] > mx ? keys[3 * i] : mx;
+    mn = keys[3 * i + 1] < mn ? keys[3 * i + 1] : mn;
+    cnt += keys[3 * i + 2];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long a = __shfl_down(mx, o, 64), b2 = __shfl_down(mn, o, 64), c2 = __shfl_down(cnt, o, 64);
+    mx = a > mx ? a : mx;
+    mn = b2 < mn ? b2 : mn;
+    cnt += c2;
+  }
+  if ((threadIdx.x & 63) == 0) { smax[threadIdx.x >> 6] = mx; smin[threadIdx.x >> 6] = mn; scnt[threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) { mx = smax[w] > mx ? smax[w] : mx; mn = smin[w] < mn ? smin[w] : mn; }
+    cnt = scnt[0] + scnt[1] + scnt[2] + scnt[3];
+    auto unkey = [](unsigned long long k) {
+      return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+    };
+    stats[0] = mn == ~0ull ? __builtin_nan("") : unkey(mn);
+    stats[1] = mx == 0ull ? __builtin_nan("") : unkey(mx);
+    stats[2] = (double)cnt;
+  }
+}
+
 // Scalar path for odd sizes / unaligned buffers: one sample per lane.
 template <typename T, bool RANGE>
 __global__ __launch_bounds__(epa::kBlock) void sv_power_scalar_kernel(
@@ -129,6 +322,58 @@ int launch(const float* raw, const double* coef, int C, int P, int S, int cal_ty
     epa::set_error("epa_sv_power_stats: range statistics without the echo_range array need S %% %d == 0 and 16-byte "
                    "aligned buffers (S=%d)", need, S);
     return EPA_EUNSUPPORTED;
+  }
+  // one-piece workgroups (EPA_K1_PIECES=0: the strided-rows kernel; development knob)
+  const char* pe = getenv("EPA_K1_PIECES");  // (read per call: a test compares the two kernels in one process)
+  const bool pieces_off = pe && pe[0] == '0';
+  // (fp64 with the echo_range array written as well -- 20 B per sample -- is the one variant the strided-rows kernel
+  //  serves faster: 13.6-13.9 against 14.2-15.4 ms per 4 G samples, profiles/r05_k1_pieces_ab.txt)
+  if (vec && !pieces_off && rows * chunks_per_row < (1ll << 31) && !(sizeof(T) == 8 && range_out)) {
+    const dim3 pgrid((unsigned)(rows * chunks_per_row));
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(part);
+    const int xm = epa::xcd_map_enabled() ? 1 : 0;
+    // fp64: the per-channel table of n log10(s - d) and the {min, max} keys of d, in stream-ordered scratch memory
+    // (freed behind the kernel).  No memory pool on the device: the strided-rows kernel serves the call.
+    void* scratch = nullptr;
+    T* table = nullptr;
+    unsigned long long* dkeys = nullptr;
+    if (sizeof(T) == 8) {
+      const size_t kbytes = ((size_t)2 * C * sizeof(unsigned long long) + 255) & ~(size_t)255;
+      if (hipMallocAsync(&scratch, kbytes + (size_t)C * S * sizeof(T), st) != hipSuccess) {
+        (void)hipGetLastError();
+        scratch = nullptr;
+      }
+      if (scratch) {
+        dkeys = reinterpret_cast<unsigned long long*>(scratch);
+        table = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(scratch) + kbytes);
+        hipLaunchKernelGGL(d_keys_init_kernel, dim3(1), dim3(64), 0, st, dkeys, C);
+        hipLaunchKernelGGL(d_span_kernel, dim3((unsigned)((P + 4 * epa::kBlock - 1) / (4 * epa::kBlock) < 256 ? (P + 4 * epa::kBlock - 1) / (4 * epa::kBlock) : 256), (unsigned)C),
+                           dim3(epa::kBlock), 0, st, cf, P, dkeys);
+        hipLaunchKernelGGL((nl_table_kernel<T>), dim3((unsigned)((S + epa::kBlock - 1) / epa::kBlock), (unsigned)C),
+                           dim3(epa::kBlock), 0, st, dkeys, S, nspread, table);
+        if (int rc = epa::check_launch("nl_table_kernel")) { (void)hipFreeAsync(scratch, st); return rc; }
+      }
+    }
+    if (sizeof(T) == 4 || scratch) {
+      if (stats_out) {
+        hipLaunchKernelGGL(piece_keys_init_kernel, dim3(1), dim3(epa::kBlock), 0, st, keys);
+        if (int rc = epa::check_launch("piece_keys_init_kernel")) return rc;
+      }
+#define EPA_PIECE(R, ST)                                                                                                 \
+  hipLaunchKernelGGL((sv_power_piece_kernel<T, R, ST>), pgrid, dim3(epa::kBlock), 0, st, raw, cf, S, P, chunks_per_row, \
+                     nspread, flags, (T*)out, (T*)range_out, keys, dkeys, table, xm)
+      if (stats_out) { if (range_out) EPA_PIECE(true, true); else EPA_PIECE(false, true); }
+      else { if (range_out) EPA_PIECE(true, false); else EPA_PIECE(false, false); }
+#undef EPA_PIECE
+      const int rc = epa::check_launch("sv_power_piece_kernel");
+      if (scratch) (void)hipFreeAsync(scratch, st);
+      if (rc) return rc;
+      if (stats_out) {
+        hipLaunchKernelGGL(piece_keys_decode_kernel, dim3(1), dim3(epa::kBlock), 0, st, keys, stats_out);
+        return epa::check_launch("piece_keys_decode_kernel");
+      }
+      return EPA_OK;
+    }
   }
   if (vec && stats_out) {  // echo_range statistics as a by-product: one partial per workgroup, then one small kernel
     if (range_out)

@@ -40,6 +40,34 @@ KERNELS = {
     "api:chain:float64": ("api_chain", ["sv_noise_fast_kernel", "sv_denoise_mvbs_fast_kernel", "sv_denoise_mvbs_uniform_kernel",
                                         "sv_denoise_mvbs_drift_kernel"], None, 4 * 500_000 * 2000 * 32),
 }
+# the SURVEY 8f rows (round 5): a pass launches several kernels, some of them more than once -- the traffic of a pass is
+# the SUM over every dispatch of the listed kernels in the PMC run divided by the passes it made (--steps 1 --warmup 1
+# --passes 2 = 4); kernels of the line's one-off setup (compute_Sv / add_depth of the resident dataset) are not listed
+PASSES_IN_PMC_RUN = 4
+PER_PASS = {
+    "cfg2:float64:int16": ("cfg2_int16", ["fused_sv_mvbs_kernel<double, short"], 4 * 500_000 * 2000 * 10),
+    "next:depth:float64": ("next_depth", ["sv_power", "depth_rows", "block_reduce", "mvbs_of_sv", "mvbs_finalize",
+                                          "minmax", "range_power"], 4 * 100_000 * 2000 * 40),
+    "next:masks:float64": ("next_masks", ["range_bin_smooth", "impulse_compare", "attenuated", "pool_value", "value_",
+                                          "row_interval", "row_running", "rows_check", "rows_same", "mask_and", "apply_mask",
+                                          "minmax", "step_", "box_"], 4 * 100_000 * 2000 * 70),
+    "next:nasc:float64": ("next_nasc", ["nasc_"], 4 * 100_000 * 2000 * 16),
+}
+
+
+def sum_per_kernel(d, counter):
+    acc = defaultdict(float)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f, newline="")):
+            if r["Counter_Name"] == counter and not r["Kernel_Name"].startswith("void at::"):
+                acc[r["Kernel_Name"]] += float(r["Counter_Value"])
+    if not acc:  # the raw dumps were dropped: per-kernel mean x dispatches kept in <src>/pmc_traffic.csv
+        wl = os.path.basename(d).split("_", 1)[1]
+        if os.path.exists(os.path.join(src, "pmc_traffic.csv")):
+            for row in csv.reader(open(os.path.join(src, "pmc_traffic.csv"), newline="")):
+                if row and row[0] == wl and row[2] == counter:
+                    acc[row[1]] += float(row[3]) * float(row[4])
+    return acc
 
 
 def mean_per_kernel(d, counter):
@@ -73,7 +101,7 @@ for key, (wl, names, _, algo) in KERNELS.items():
          "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE x1"
                        + ("; the kernels of a pass summed" if len(names) > 1 else ""),
          "algorithmic_bytes": algo, "csrc_sha16": csrc_hash(),
-         "source": f"profiles/r04_pmc_traffic.csv (bench.py --workload {wl.replace('_', ':')})"}
+         "source": f"profiles/r05_pmc_traffic.csv (bench.py --workload {wl.replace('_', ':')})"}
     k0f = [v for k, v in fe.items() if "power_coef_ek_kernel" in k]
     k0w = [v for k, v in wr.items() if "power_coef_ek_kernel" in k]
     if wl in ("cfg2", "cfg3", "cfg2_f32", "cfg3_f32", "cfg3_ss2000") and k0f and k0w:  # K0 reads 5 x (C, P) f64 + small tables, writes 64 B per (c, p)
@@ -82,6 +110,20 @@ for key, (wl, names, _, algo) in KERNELS.items():
                             "FETCH_SIZE_ratio_raw": k0f[0] * 1024 / (cp * 40.0), "WRITE_SIZE_ratio_raw": k0w[0] * 1024 / (cp * 64.0)}
     out[key] = e
     print(key, "traffic / algorithmic = %.4f" % (e["bytes_per_launch"] / algo), e.get("calibration"))
+for key, (wl, names, algo) in PER_PASS.items():
+    fd, wd = os.path.join(src, f"fetch_{wl}"), os.path.join(src, f"write_{wl}")
+    if not (os.path.isdir(fd) and os.path.isdir(wd)):
+        continue
+    fe, wr = sum_per_kernel(fd, "FETCH_SIZE"), sum_per_kernel(wd, "WRITE_SIZE")
+    fkb = sum(v for k, v in fe.items() if any(n in k for n in names)) / PASSES_IN_PMC_RUN
+    wkb = sum(v for k, v in wr.items() if any(n in k for n in names)) / PASSES_IN_PMC_RUN
+    if fkb == 0 and wkb == 0:
+        continue
+    out[key] = {"bytes_per_launch": 2 * fkb * 1024 + wkb * 1024, "fetch_size_kb_raw": fkb, "write_size_kb_raw": wkb,
+                "correction": "FETCH_SIZE x2, WRITE_SIZE x1; every dispatch of the pass's kernels summed, per pass",
+                "algorithmic_bytes": algo, "csrc_sha16": csrc_hash(),
+                "source": f"profiles/r05_pmc_traffic.csv (bench.py --workload {wl.replace('_', ':')})"}
+    print(key, "traffic / algorithmic = %.4f" % (out[key]["bytes_per_launch"] / algo))
 path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 json.dump(out, open(path, "w"), indent=1)
 print("wrote", path)

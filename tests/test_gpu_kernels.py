@@ -92,6 +92,50 @@ def test_sv_power_ek60(env, dtype, cal_type, shape):
     assert np.isnan(exp[:, :, :3]).all()  # samples 0..2: R' <= 0
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("case", ["uniform_d", "nan_ping", "d_differs"])
+@pytest.mark.parametrize("shape", [(2, 50, 1000), (3, 17, 2052), (1, 9, 4096)])
+def test_sv_power_one_piece_workgroups_equal_the_strided_rows_kernel(env, monkeypatch, dtype, case, shape):
+    """K1's two kernels (round 5): one 1024-sample piece per workgroup (the default) and a workgroup striding over the
+    rows of one chunk (EPA_K1_PIECES=0).  Same arithmetic; the cached n log10(s - d) comes from a per-channel table when
+    the channel's rows share one d (bit for bit the strided kernel's), else from the table-driven logarithm (1e-13).
+    The by-products -- echo_range, its {nanmin, nanmax, NaN count} with and without the array -- are identical."""
+    torch, ops, synth = env
+    from echopype_amd import _lib
+
+    d = synth.ek60_numpy(*shape, vary_tau=(case == "d_differs"))  # (EK60: d = 2 whatever tau is ...)
+    if case == "nan_ping":
+        d["transmit_duration_nominal"][0, 3] = np.nan           # a NaN row: its d is NaN, the channel has no table
+    coef = _coef_ek60(torch, ops, d, "Sv")
+    if case == "d_differs":                                      # (... so the rows' d is edited: two values per channel)
+        coef[:, 1::2, _lib.CF_D] += 0.25
+    raw = _dev(torch, d["backscatter_r"])
+    dt = getattr(torch, dtype)
+    outs = {}
+    for pieces in ("1", "0"):
+        monkeypatch.setenv("EPA_K1_PIECES", pieces)
+        with _lib.launch_trace() as tr:
+            a = ops.sv_power(raw, coef, dtype=dt)
+            b = ops.sv_power(raw, coef, dtype=dt, want_range=False, want_range_stats=True)
+            c = ops.sv_power(raw, coef, dtype=dt, want_range=True, want_range_stats=True)
+        # (fp64 with the echo_range array written too stays with the strided-rows kernel: it is the faster one there)
+        assert ("sv_power_piece_kernel" in tr.kernels) == (pieces == "1"), tr.kernels
+        assert ("sv_power_kernel" in tr.kernels) == (pieces == "0" or dtype == "float64"), tr.kernels
+        outs[pieces] = [t.cpu().numpy() for t in (a[0], a[1], b[0], b[2], c[0], c[1], c[2])]
+    new, old = outs["1"], outs["0"]
+    exact = dtype == "float32" or case == "uniform_d"
+    for i in (0, 2, 4):  # Sv
+        np.testing.assert_array_equal(np.isnan(new[i]), np.isnan(old[i]))
+        if exact:
+            np.testing.assert_array_equal(new[i], old[i])
+        else:
+            f = np.isfinite(old[i])
+            assert np.max(np.abs(new[i][f] - old[i][f])) < 1e-11
+    for i in (1, 3, 5, 6):  # echo_range, statistics
+        np.testing.assert_array_equal(new[i], old[i])
+    assert new[3][2] == np.isnan(new[1]).sum()
+
+
 def test_sv_power_ek80_cw_power_with_gpt(env):
     torch, ops, synth = env
     d = synth.ek60_numpy(2, 30, 512)
