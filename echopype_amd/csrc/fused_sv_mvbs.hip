@@ -175,7 +175,7 @@ __device__ __forceinline__ void process_pair(Column<T>& c0, Column<T>& c1, float
                                              double r0v, T g, T a2, T A0v, T nL0, T nL1, T nspread, double bin,
                                              double inv_bin, int n_rbins, const double* tab, T* lsum, uint32_t* lcnt,
                                              T* __restrict__ sv_dst, double& xmax, double& xmin, unsigned& nnan,
-                                             uint32_t n_clean, double& xfirst, double& xlast, T& svo0, T& svo1) {
+                                             uint32_t n_clean, double& xfirst, double& xlast) {
   const double x0 = fma(c0.sra, r.rb, r0v), x1 = fma(c1.sra, r.rb, r0v);  // echo_range = (s*ra)*rb [+0]
   const double rtd0 = x0 - r.shift, rtd1 = x1 - r.shift;
   const T rt0 = (T)rtd0, rt1 = (T)rtd1;
@@ -198,16 +198,12 @@ __device__ __forceinline__ void process_pair(Column<T>& c0, Column<T>& c1, float
   }
   const T sv0 = s10 + fma(a2, rt0, A0v), sv1 = s11 + fma(a2, rt1, A0v);
   if (WRITE_SV) {
-    if (sv_dst) {
 #ifndef EPA_PLAIN_STORES  // streaming (nt) stores: +2 % at 4 G samples, Sv is never re-read here
-      epa::store_nt2(sv_dst, sv0, sv1);
+    epa::store_nt2(sv_dst, sv0, sv1);
 #else
-      const T o[2] = {sv0, sv1};
-      epa::store_vec<T, 2>(sv_dst, o);
+    const T o[2] = {sv0, sv1};
+    epa::store_vec<T, 2>(sv_dst, o);
 #endif
-    }
-    svo0 = sv0;  // (sv_dst NULL: the caller stores the lane's four values with one request)
-    svo1 = sv1;
   }
   T v0 = lin_bins(sv0, tab), v1 = lin_bins(sv1, tab);
   if (!clean) {  // (scalar) +-inf goes through lin_bins as NaN: 10^(+inf) = +inf, 10^(-inf) = 0
@@ -246,12 +242,6 @@ struct PingLoad<float> {
   float2 a, b;
   __device__ __forceinline__ PingLoad() : a(make_float2(0.f, 0.f)), b(make_float2(0.f, 0.f)) {}
   __device__ __forceinline__ void issue(const float* __restrict__ row, int sA, int sB, bool hasB, int, int) {
-    if (sB == sA + 2) {  // (the float-output lane map: four consecutive samples, one 16-byte request)
-      const float4 q = *reinterpret_cast<const float4*>(row + sA);
-      a = make_float2(q.x, q.y);
-      b = make_float2(q.z, q.w);
-      return;
-    }
     a = *reinterpret_cast<const float2*>(row + sA);
     if (hasB) b = *reinterpret_cast<const float2*>(row + sB);
   }
@@ -349,21 +339,16 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES > 4 ? EPA_FUSED_MI
   const int pb = extra ? (seg == 0 ? 0 : bin_start[a.n_tbins]) : bin_start[tb];
   const int pe = extra ? (seg == 0 ? bin_start[0] : a.P) : bin_start[tb + 1];
   for (int chunk0 = 0; chunk0 < S; chunk0 += kChunk) {
-    // float outputs from float samples: the lane owns FOUR CONSECUTIVE samples -- one 16-byte request in, one 16-byte
-    // streaming store out, where the pair map's 8-byte stores make a wavefront instruction cover 512 B only
-    // (K1's float instance went from 0.54 to 0.78 of peak on 16-byte accesses alone, profiles/r05_k1_pieces_ab.txt)
-    constexpr bool QUAD = sizeof(T) == 4 && sizeof(RawT) == 4;
-    constexpr int oB = QUAD ? 2 : 128;              // distance of pair B from pair A
-    const int sA = chunk0 + wave * 256 + (QUAD ? 4 : 2) * lane;  // first sample of pair A
-    const int sB = sA + oB;                         // first sample of pair B
+    const int sA = chunk0 + wave * 256 + 2 * lane;  // first sample of pair A
+    const int sB = sA + 128;                        // first sample of pair B
     if (sA >= S) continue;
     const bool hasB = sB < S;
     Column<T> col[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) col[j].init();
-    const int eA = wave * 256 + (QUAD ? 4 : 2) * lane;  // the lane's entries of col_nL: eA, eA + 1, eA + oB, eA + oB + 1
+    const int eA = wave * 256 + 2 * lane;  // the lane's entries of col_nL: eA, eA + 1, eA + 128, eA + 129
     if (NL_LDS) {
-      col_nL[eA] = col_nL[eA + 1] = col_nL[eA + oB] = col_nL[eA + oB + 1] = epa::M<T>::nan();
+      col_nL[eA] = col_nL[eA + 1] = col_nL[eA + 128] = col_nL[eA + 129] = epa::M<T>::nan();
     }
     // (compared as BITS, in scalar registers: a float compare of two scalars is two vector instructions per ping; the
     //  initial pattern is a NaN payload no row holds)
@@ -393,7 +378,7 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES > 4 ? EPA_FUSED_MI
         for (int j = 0; j < VEC; ++j) {
           const double sj = (double)((j < 2 ? sA : sB) + (j & 1));
           const T nl = nspread * log10_slow<T>((T)(sj - r.d));
-          if (NL_LDS) col_nL[eA + (j < 2 ? 0 : oB) + (j & 1)] = nl;  // (see col_nL)
+          if (NL_LDS) col_nL[eA + (j < 2 ? 0 : 128) + (j & 1)] = nl;  // (see col_nL)
           else col[j].nL = nl;
           col[j].sra = sj * r.ra;
           fin = fin & ((j >= 2 && !hasB) | (fabs(nl) < (T)__builtin_inf()));
@@ -418,17 +403,13 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES > 4 ? EPA_FUSED_MI
       }
 #endif
       double xf, xl, xdummy;
-      T q0, q1, q2 = (T)0, q3 = (T)0;
       process_pair<T, RMAX, WRITE_SV>(col[0], col[1], inA, clean, r, r0v, g, a2, A0, NL_LDS ? col_nL[eA] : col[0].nL,
                                       NL_LDS ? col_nL[eA + 1] : col[1].nL, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt,
-                                      WRITE_SV && !QUAD ? sv_c + row_off + sA : nullptr, xmax, xmin, nnan, n_clean, xf, xl,
-                                      q0, q1);
+                                      WRITE_SV ? sv_c + row_off + sA : nullptr, xmax, xmin, nnan, n_clean, xf, xl);
       if (hasB)
-        process_pair<T, RMAX, WRITE_SV>(col[2], col[3], inB, clean, r, r0v, g, a2, A0, NL_LDS ? col_nL[eA + oB] : col[2].nL,
-                                        NL_LDS ? col_nL[eA + oB + 1] : col[3].nL, nspread, bin, inv_bin, n_rbins, tab, lsum,
-                                        lcnt, WRITE_SV && !QUAD ? sv_c + row_off + sB : nullptr, xmax, xmin, nnan, n_clean,
-                                        xdummy, xl, q2, q3);
-      if (WRITE_SV && QUAD) epa::store_nt4(sv_c + row_off + sA, q0, q1, q2, q3);  // (S % 4 == 0 on this path: hasB)
+        process_pair<T, RMAX, WRITE_SV>(col[2], col[3], inB, clean, r, r0v, g, a2, A0, NL_LDS ? col_nL[eA + 128] : col[2].nL,
+                                        NL_LDS ? col_nL[eA + 129] : col[3].nL, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt,
+                                        WRITE_SV ? sv_c + row_off + sB : nullptr, xmax, xmin, nnan, n_clean, xdummy, xl);
       if (clean) {  // (scalar)
         if (RMAX) {  // no NaN among the wavefront's samples: the lane's smallest / largest range of the ping
           xmin = vmin_num(xmin, xf);

@@ -108,14 +108,6 @@ __device__ __forceinline__ void store_nt2(float* p, float a, float b) {
   epa_f2 v = {a, b};
   __builtin_nontemporal_store(v, reinterpret_cast<epa_f2*>(p));
 }
-__device__ __forceinline__ void store_nt4(float* p, float a, float b, float c, float d) {
-  epa_f4 v = {a, b, c, d};
-  __builtin_nontemporal_store(v, reinterpret_cast<epa_f4*>(p));
-}
-__device__ __forceinline__ void store_nt4(double* p, double a, double b, double c, double d) {  // (two 16-byte halves)
-  store_nt2(p, a, b);
-  store_nt2(p + 2, c, d);
-}
 
 template <typename T, int VEC>
 __device__ __forceinline__ void store_vec(T* p, const T (&v)[VEC]);

@@ -326,9 +326,11 @@ int launch(const float* raw, const double* coef, int C, int P, int S, int cal_ty
   // one-piece workgroups (EPA_K1_PIECES=0: the strided-rows kernel; development knob)
   const char* pe = getenv("EPA_K1_PIECES");  // (read per call: a test compares the two kernels in one process)
   const bool pieces_off = pe && pe[0] == '0';
-  // (fp64 with the echo_range array written as well -- 20 B per sample -- is the one variant the strided-rows kernel
-  //  serves faster: 13.6-13.9 against 14.2-15.4 ms per 4 G samples, profiles/r05_k1_pieces_ab.txt)
-  if (vec && !pieces_off && rows * chunks_per_row < (1ll << 31) && !(sizeof(T) == 8 && range_out)) {
+  // (fp64 with the echo_range array written as well -- 20 B per sample -- or with its statistics as a by-product are the
+  //  variants the strided-rows kernel serves faster: 13.6-13.9 against 14.2-15.4 ms and 8.7-9.2 against 10.3-10.7 ms per
+  //  4 G samples; a workgroup that lives for four samples per lane pays for the statistics every time.  fp32 and plain
+  //  fp64 Sv / TS take the pieces: profiles/r05_k1_pieces_ab.txt)
+  if (vec && !pieces_off && rows * chunks_per_row < (1ll << 31) && !(sizeof(T) == 8 && (range_out || stats_out))) {
     const dim3 pgrid((unsigned)(rows * chunks_per_row));
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(part);
     const int xm = epa::xcd_map_enabled() ? 1 : 0;

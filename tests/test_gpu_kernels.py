@@ -118,11 +118,19 @@ def test_sv_power_one_piece_workgroups_equal_the_strided_rows_kernel(env, monkey
             a = ops.sv_power(raw, coef, dtype=dt)
             b = ops.sv_power(raw, coef, dtype=dt, want_range=False, want_range_stats=True)
             c = ops.sv_power(raw, coef, dtype=dt, want_range=True, want_range_stats=True)
-        # (fp64 with the echo_range array written too stays with the strided-rows kernel: it is the faster one there)
-        assert ("sv_power_piece_kernel" in tr.kernels) == (pieces == "1"), tr.kernels
+        # (fp64 with the echo_range array or its statistics stays with the strided-rows kernel: the faster one there;
+        #  the plain fp64 Sv of the extra call below takes the pieces)
+        d0 = ops.sv_power(raw, coef, dtype=dt, want_range=False)[0] if pieces == "1" else None
+        assert ("sv_power_piece_kernel" in tr.kernels) == (pieces == "1" and dtype == "float32"), tr.kernels
         assert ("sv_power_kernel" in tr.kernels) == (pieces == "0" or dtype == "float64"), tr.kernels
+        if d0 is not None:
+            with _lib.launch_trace() as tr2:
+                d0 = ops.sv_power(raw, coef, dtype=dt, want_range=False)[0]
+            assert tr2.kernels.count("sv_power_piece_kernel") == 1, tr2.kernels
+            plain_pieces = d0.cpu().numpy()
         outs[pieces] = [t.cpu().numpy() for t in (a[0], a[1], b[0], b[2], c[0], c[1], c[2])]
     new, old = outs["1"], outs["0"]
+    new = [plain_pieces] + new[1:]  # (the Sv of the one-piece kernel, whatever the dtype)
     exact = dtype == "float32" or case == "uniform_d"
     for i in (0, 2, 4):  # Sv
         np.testing.assert_array_equal(np.isnan(new[i]), np.isnan(old[i]))
