@@ -124,6 +124,7 @@ SIGNATURES = {
                          _vp, _vp, _i, _vp],
     "epa_sv_denoise_mvbs": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _i, _i, _d, _vp, _vp, _i, _d, _i, _u, _d, _vp, _vp, _vp,
                             _vp, _vp, _vp, _vp, _i, _vp],
+    "epa_geodesic_steps": [_vp, _vp, _i, _vp, _vp],
     "epa_nasc": [_vp, _vp, _i, _i, _i, _vp, _i, _d, _i, _u, _vp, _vp, _vp, _vp, _i, _vp],
     "epa_pool_sv_value": [_vp, _vp, _vp, _i, _i, _i, _d, _i, _d, _d, _d, _i, _d, _vp, _vp, _vp, _i, _vp],
 }

@@ -143,6 +143,9 @@ def assign_actual_range(ds_MVBS):
     return ds_MVBS.assign_attrs({"actual_range": [round(float(lo), 2), round(float(hi), 2)]})
 
 
+_GEODESIC_ON_DEVICE = 8192  # pings from which get_distance_from_latlon takes the steps from the device kernel
+
+
 def geodesic_distance_m(lat1, lon1, lat2, lon2):
     """Geodesic length in metres on WGS-84 between arrays of points (degrees), the quantity the
     reference takes from ``geopy.distance.distance`` (utils.py:219-225).  Vincenty's inverse
@@ -190,7 +193,13 @@ def get_distance_from_latlon(ds_Sv):
     if not ok.any():
         raise ValueError("All lat/lon entries are NaN!")
     step = np.zeros(P)
-    step[ok] = geodesic_distance_m(lat[ok], lon[ok], lat2[ok], lon2[ok]) / 1852.0
+    if P >= _GEODESIC_ON_DEVICE:  # a long track: one launch (30 ms of NumPy per 100 000 pings otherwise)
+        from .. import ops
+
+        dev = ops.geodesic_steps(ops.to_device(lat), ops.to_device(lon)).cpu().numpy()
+        step[ok] = dev[ok] / 1852.0
+    else:
+        step[ok] = geodesic_distance_m(lat[ok], lon[ok], lat2[ok], lon2[ok]) / 1852.0
     dist = np.where(ok, np.cumsum(step), np.nan)  # pandas cumsum skips NaN rows but keeps them NaN
     idx = np.where(ok, np.arange(P), -1)
     last = np.maximum.accumulate(idx)  # forward fill

@@ -758,6 +758,15 @@ def pool_sv_value(sv, range, nvalid, depth_bin, num_side_pings, exclude_above, r
 
 # ---- NASC ---------------------------------------------------------------------------
 
+def geodesic_steps(lat, lon):
+    """WGS-84 geodesic length in metres from every ping to the next (f64 device tensors (P,) in degrees; NaN for the
+    last ping and NaN positions) -- commongrid/utils.py:208-231's geopy loop as one launch."""
+    P = lat.numel()
+    out = torch.empty(P, dtype=torch.float64, device=lat.device)
+    call("epa_geodesic_steps", _p(lat), _p(lon), P, _p(out), _stream())
+    return out
+
+
 def nasc(sv, depth, bin_start, n_dbins, range_bin, n_rbins, skipna=True, closed="left", want_parts=False):
     """compute_raw_NASC -> NASC (C, n_dbins, n_rbins) [, sv_mean, h_mean]."""
     C, P, S = sv.shape

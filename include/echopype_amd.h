@@ -537,6 +537,10 @@ int epa_pool_sv_value(const void* sv, const void* range, const int32_t* nvalid, 
  *   workspace : 24 * C*n_dbins*n_rbins bytes (zeroed by the call); a depth grid too fine for the LDS accumulators
  *               (> ~6500 bins) is accumulated straight into it with atomics
  *   nasc_out  : [C*n_dbins*n_rbins] of dtype; sv_mean_out / h_mean_out likewise, optional */
+/* Along-track step of every ping for compute_NASC's distance bins: step_m_out[i] = WGS-84 geodesic length in metres
+ * from ping i to ping i + 1 (Vincenty's inverse formula; NaN for the last ping and wherever a position is NaN), the
+ * quantity commongrid/utils.py:208-231 takes from geopy.distance.distance ping by ping.  lat / lon: f64 [P], degrees. */
+int epa_geodesic_steps(const double* lat, const double* lon, int P, double* step_m_out, epa_stream_t stream);
 int epa_nasc(const void* sv, const void* depth, int C, int P, int S, const int32_t* bin_start, int n_dbins,
              double range_bin, int n_rbins, unsigned bin_flags, void* workspace, void* nasc_out,
              void* sv_mean_out, void* h_mean_out, int dtype, epa_stream_t stream);

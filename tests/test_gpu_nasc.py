@@ -146,3 +146,41 @@ def test_nasc_depth_grid_beyond_the_lds_accumulators(ep):
     got = ep.ops.nasc(torch.from_numpy(Sv).cuda(), torch.from_numpy(depth).cuda(), torch.from_numpy(starts).cuda(),
                       len(d_edges) - 1, 0.1, len(r_edges) - 1)
     _close(got.cpu().numpy(), exp, 1e-10)
+
+
+def test_geodesic_steps_kernel_equals_the_host_vincenty(ep):
+    """epa_geodesic_steps (one launch) against commongrid.utils.geodesic_distance_m (vectorised NumPy, itself held to
+    geopy's numbers in tests/test_host_logic.py): a track with long and short steps, a pole-ward leg, coincident points,
+    NaN positions; and get_distance_from_latlon gives the same cumulative distance on either side of the size switch."""
+    import torch
+
+    from echopype_amd import ops
+    from echopype_amd.commongrid import utils as cgu
+
+    rng = np.random.default_rng(5)
+    P = 20_000
+    lat = 45.0 + np.cumsum(rng.normal(0, 2e-5, P))
+    lon = -125.0 + np.cumsum(rng.normal(1e-5, 3e-5, P))
+    lat[1000:1010] = lat[1000]                # coincident points
+    lon[1000:1010] = lon[1000]
+    lat[5000:5300] += np.linspace(0, 35, 300)  # a long pole-ward leg (large steps)
+    lat[7000], lon[7013] = np.nan, np.nan
+    got = ops.geodesic_steps(torch.from_numpy(lat).cuda(), torch.from_numpy(lon).cuda()).cpu().numpy()
+    exp = cgu.geodesic_distance_m(lat[:-1], lon[:-1], lat[1:], lon[1:])
+    assert np.isnan(got[-1])
+    np.testing.assert_array_equal(np.isnan(got[:-1]), np.isnan(exp))
+    f = ~np.isnan(exp)
+    assert np.all(got[:-1][f][exp[f] == 0] == 0)
+    # (both iterate lambda to 1e-14 rad = 6e-8 m on the ellipsoid; the NumPy form keeps iterating EVERY pair until the
+    #  last one has converged, the kernel stops pair by pair: they agree to the iteration's own tolerance)
+    np.testing.assert_allclose(got[:-1][f], exp[f], rtol=1e-11, atol=2e-7)
+    ds = ep.Dataset(coords={"ping_time": np.arange(P)})
+    ds["latitude"] = (("ping_time",), lat)
+    ds["longitude"] = (("ping_time",), lon)
+    on_device = cgu.get_distance_from_latlon(ds)
+    old, cgu._GEODESIC_ON_DEVICE = cgu._GEODESIC_ON_DEVICE, 10**9
+    try:
+        on_host = cgu.get_distance_from_latlon(ds)
+    finally:
+        cgu._GEODESIC_ON_DEVICE = old
+    np.testing.assert_allclose(on_device, on_host, rtol=1e-12, atol=2e-7 * P / 1852.0)
