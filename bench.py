@@ -894,7 +894,7 @@ def run_cfg5(ctx, cpu):
     assert state["n_read"] == len(job.tiles) * passes * (steps + args.warmup)  # every result was read
     if world == 1 and not getattr(args, "sharded_at_1", False):
         route = "compute_Sv(echodata) -> compute_MVBS(ds_Sv,'1m','20s') per tile"
-        coll = "none at 1 rank (each tile its own dataset)"
+        coll = "none at 1 rank (a tile = a dataset)"
     else:
         route = "sharding.compute_Sv_MVBS(echodata_shard, shard=MVBSShard()) per tile"
         coll = (f"per dataset of {world} tiles: cut bins all_reduce(SUM) + range max all_reduce(MAX) in HBM over "
@@ -917,12 +917,12 @@ def run_cfg5(ctx, cpu):
     if ctx.rank != 0:
         return None
     return line(ctx, samples_per_pass=C * P_total * S, passes=passes, elapsed=elapsed, scaling="strong", cpu=cpu,
-                workload=f"cfg5: EK60 CW {C}x{P_total}x{S} TOTAL in ping_time tiles via the product entry points "
+                workload=f"cfg5: EK60 CW {C}x{P_total}x{S} TOTAL in ping_time tiles, product entry points "
                          "compute_Sv -> compute_MVBS(20s x 1m), Sv+MVBS out",
                 config=cfg,
-                roofline=roofline("fused_sv_mvbs_kernel (+ K0 kernels of the calls)", region_ms,
+                roofline=roofline("fused_sv_mvbs_kernel (+ K0 of the calls)", region_ms,
                                   n_first * bps, bps, traffic_key=f"cfg5api:{ctx.dtype}",
-                                  launch=f"API calls of one {job.tile_p}-ping tile (mean over the tiles), HIP events"))
+                                  launch=f"API calls of one {job.tile_p}-ping tile (mean), HIP events"))
 
 
 # ---------------------------------------------------------------------------------------- main
@@ -1033,7 +1033,7 @@ def main():
             fam, _, var = spec.partition(":")  # one string per workload family: "441.4 f0.668; f32 628.0 f0.636"
             key = "also_" + fam
             also[key] = (also[key] + "; " if key in also else "") + (var + " " if var else "") + summary(out)
-            txt = json.dumps(compact(out))
+            txt = json.dumps(compact(out), separators=(",", ":"))  # (no padding: the headline carries the other lines' figures)
             print(txt, flush=True)
             if args.out:
                 with open(args.out, "a") as f:

@@ -20,8 +20,14 @@ its plan).  A data step is: epa_edge_pack (device) -> all_reduce -> epa_edge_gat
 (device) -- hand-written kernels on torch's stream, no host synchronisation, no library GEMM.
 When no bin is shared (shard edges on bin edges) the exchange is skipped: no data collective at all.
 
-Product entry points (same signatures as the single-process functions plus ``group`` / ``ping_offset``):
-``compute_MVBS``, ``compute_Sv_MVBS``, ``remove_background_noise``.  Kernels are called through ops.
+Product entry points (same signatures as the single-process functions plus ``group`` / ``ping_offset`` /
+``file_scalars``): ``compute_Sv``, ``compute_TS``, ``compute_MVBS``, ``compute_Sv_MVBS``, ``remove_background_noise``; and
+``file_scalars`` -- the whole-file facts (first ping's pulse length, first valid ping per channel, the EK80 replica's
+transmit parameters, the filter intervals' starts) a shard cannot know by itself, gathered in two or three small control
+messages.  On device-resident shards the calls take the same no-wait routes as the single-process ones: one kernel for
+``compute_Sv`` -> ``compute_MVBS``, two sweeps of the samples for the chain with ``remove_background_noise`` in between;
+a rank whose kernel declines takes every rank to the fallback (the vote rides with the exchange plan's message).
+Kernels are called through ops.
 """
 import numpy as np
 import torch

@@ -40,7 +40,9 @@ LINES = os.path.join(ROOT, "profiles", "r05_bench_default.jsonl")
 def test_committed_bench_lines_keep_the_contract():
     if not os.path.exists(LINES):
         pytest.skip("no committed default run of this round yet")
-    lines = [json.loads(x) for x in open(LINES) if x.strip()]
+    raw = [x.strip() for x in open(LINES) if x.strip()]
+    assert all(len(x) < 2000 for x in raw), [len(x) for x in raw]                     # a line fits the driver's tail
+    lines = [json.loads(x) for x in raw]
     assert len(lines) == 15
     for d in lines:
         _check_line(d, want_cpu=True)
@@ -49,7 +51,6 @@ def test_committed_bench_lines_keep_the_contract():
             assert "SURVEY 8f" in d["metric"]
         n = d["config"]["samples_per_step"]
         assert abs(d["value"] - n / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6    # value = samples per step / step time
-        assert len(json.dumps(d)) < 2000                                              # a line fits the driver's tail
     head = lines[-1]                                              # the headline (BASELINE.json's metric) comes last
     assert head["config"]["workload"].startswith("cfg5") and head["metric"].startswith("range-samples/sec")
     assert head["scaling"] == "strong" and head["config"]["samples_per_step"] == 4 * 2_000_000 * 4096 * head["config"]["passes_per_step"]
@@ -119,3 +120,18 @@ def test_gloo_two_ranks_print_the_same_workload_with_a_cpu_baseline():
     r = two["config"]["ranks"]
     assert r["world_size"] == 2 and r["backend"] == "gloo" and r["devices"] == ["0:cuda0", "1:cuda0"]
     assert one["config"]["mvbs_shape_last_tile"][2] == two["config"]["mvbs_shape_last_tile"][2]
+
+
+@pytest.mark.gpu
+def test_sharded_route_on_a_one_rank_rccl_group_prints_its_host_cost():
+    """`--sharded-at-1`: the SHARDED entry points per tile on a one-rank RCCL group (every collective of the N > 1 route
+    executes, as an identity) -- the line carries the host time per call next to the N = 1 figures."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--only-headline", "--no-cpu-baseline", "--steps", "2",
+                        "--warmup", "1", "--pings-total", "200000", "--sharded-at-1"], capture_output=True, text=True,
+                       cwd=ROOT, check=True)
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    _check_line(d, want_cpu=False)
+    assert d["n_gpus"] == 1 and "sharding.compute_Sv_MVBS" in d["config"]["route"]
+    assert 0 < d["config"]["host_ms_per_call"] < 50 and d["config"]["allreduce_bytes"] > 0
