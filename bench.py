@@ -56,10 +56,10 @@ WORKLOADS = {
     "small": (4, 20_000, 2000, 50, 50),
     "next": (4, 100_000, 2000, 2, 2),  # SURVEY 8f rows through their API entry points (scripts/perf_masks.py's volume)
 }
-DEFAULT_LINES = ["cfg3", "cfg3:ss2000", "cfg3:f32", "cfg2", "cfg2:f32", "cfg2:int16", "api", "api:chain", "cfg4", "cfg4:f32",
-                 "cfg4:planes64", "next:depth", "next:masks", "next:nasc", "cfg5"]
+DEFAULT_LINES = ["cfg3", "cfg3:ss2000", "cfg3:f32", "cfg2", "cfg2:f32", "cfg2:int16", "cfg2:sv", "cfg2:sv32", "api", "api:chain",
+                 "cfg4", "cfg4:f32", "cfg4:planes64", "next:depth", "next:masks", "next:nasc", "cfg5"]
 TILE_PINGS = 250_000
-DT = {"f32": "float32", "f64": "float64"}
+DT = {"f32": "float32", "f64": "float64", "sv32": "float32"}
 
 
 def parse():
@@ -73,7 +73,7 @@ def parse():
                          "no two pings share a range vector)")
     ap.add_argument("--workload", default=None,
                     help="one line only: cfg2 | cfg3 | cfg4 | cfg5 | api | small | cfg4small, optionally with a variant "
-                         "(:f32, :ss2000, :planes64, :int16)")
+                         "(:f32, :ss2000, :planes64, :int16, :sv, :sv32)")
     ap.add_argument("--only-headline", action="store_true", help="N=1: skip the other single-GPU lines")
     ap.add_argument("--dtype", default="float64", choices=["float64", "float32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -323,6 +323,7 @@ def run_ek60(ctx, name, variant, cpu):
     C, P, S = WORKLOADS[name][:3]
     chain = name == "cfg3"
     i16 = variant == "int16" and not chain
+    k1 = variant in ("sv", "sv32") and not chain  # BASELINE configs[1] to the letter: the compute_Sv kernel alone (K1)
     ss_every = 2000 if variant == "ss2000" else args.ss_every
     dt = ctx.dt
     d = ek60_volume(ctx, name, ss_every, i16)
@@ -345,6 +346,8 @@ def run_ek60(ctx, name, variant, cpu):
             _, _, nz = ops.sv_noise_fused(d["backscatter_r"], coef, a2, 20, 50, dtype=dt)
             ops.sv_denoise_mvbs(d["backscatter_r"], coef, a2, nz, 20, 3.0, bs, n_t, 1.0, n_r, dtype=dt,
                                 want_noise=args.chain_outputs == "all")
+        elif k1:
+            ops.sv_power(d["backscatter_r"], coef, dtype=dt, want_range=False, out=sv)
         elif i16:
             ops.sv_mvbs_fused_i16(d["raw_i16"], d["n_valid"], coef, bs, n_t, 1.0, n_r, dtype=dt, sv_out=sv, mvbs_out=mvbs)
         else:
@@ -358,17 +361,19 @@ def run_ek60(ctx, name, variant, cpu):
     bps = BYTES_PER_SAMPLE[ctx.dtype] - (2 if i16 else 0)
     if chain:  # two sweeps over the 4-B input + Sv, Sv_corrected (+ Sv_noise) out: SURVEY 8d line E = 32 / 20 B
         bps = 2 * BYTES_PER_SAMPLE[ctx.dtype] + ((BYTES_PER_SAMPLE[ctx.dtype] - 4) if args.chain_outputs == "all" else 0)
-    key = f"{name}:{ctx.dtype}" + (":int16" if i16 else "") + (":corrected" if chain and args.chain_outputs != "all" else "") \
-        + (f":ss{ss_every}" if chain and ss_every != 1 else "")
-    what = ("fused compute_Sv->compute_MVBS(20s x 1m), Sv+MVBS out" if not chain else
+    key = f"{name}:{ctx.dtype}" + (":int16" if i16 else "") + (":sv" if k1 else "") + \
+        (":corrected" if chain and args.chain_outputs != "all" else "") + (f":ss{ss_every}" if chain and ss_every != 1 else "")
+    what = ("compute_Sv alone (K1, echo_range left lazy), Sv out" if k1 else
+            "fused compute_Sv->compute_MVBS(20s x 1m), Sv+MVBS out" if not chain else
             "compute_Sv->remove_background_noise(20x50,3dB)->compute_MVBS(20s x 1m) in two sweeps, Sv+"
             + ("Sv_noise+" if args.chain_outputs == "all" else "") + "Sv_corrected+MVBS out")
     return line(ctx, samples_per_pass=n, passes=passes, elapsed=elapsed, scaling="weak",
-                metric=METRIC + (" with remove_background_noise" if chain else ""),
+                metric=("range-samples/sec through compute_Sv" if k1 else METRIC + (" with remove_background_noise" if chain else "")),
                 workload=f"{name}: EK60 CW {C}x{P}x{S}, {what}" + (", int16 samples in" if i16 else ""),
                 config={"sound_speed_changes_every_n_pings": ss_every, "sharding": "one GPU", "collective": "none"}, cpu=cpu,
                 roofline=roofline("sv_noise_fast_kernel + sv_denoise_mvbs_{uniform,fast}_kernel" if chain
-                                  else "fused_sv_mvbs_kernel", kernel_ms, n * bps, bps, traffic_key=key))
+                                  else "sv_power_piece_kernel" if k1 else "fused_sv_mvbs_kernel", kernel_ms, n * bps, bps,
+                                  traffic_key=key))
 
 
 def run_api(ctx, cpu, variant=""):

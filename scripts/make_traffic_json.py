@@ -46,6 +46,8 @@ KERNELS = {
 PASSES_IN_PMC_RUN = 4
 PER_PASS = {
     "cfg2:float64:int16": ("cfg2_int16", ["fused_sv_mvbs_kernel<double, short"], 4 * 500_000 * 2000 * 10),
+    "cfg2:float64:sv": ("cfg2_sv", ["sv_power_piece_kernel<double", "nl_table_kernel", "d_span_kernel"], 4 * 500_000 * 2000 * 12),
+    "cfg2:float32:sv": ("cfg2_sv32", ["sv_power_piece_kernel<float"], 4 * 500_000 * 2000 * 8),
     "next:depth:float64": ("next_depth", ["sv_power", "depth_rows", "block_reduce", "mvbs_of_sv", "mvbs_finalize",
                                           "minmax", "range_power"], 4 * 100_000 * 2000 * 40),
     "next:masks:float64": ("next_masks", ["range_bin_smooth", "impulse_compare", "attenuated", "pool_value", "value_",

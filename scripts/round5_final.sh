@@ -5,7 +5,7 @@
 # kernels.  Results under gpurun_out/final5/ (scripts/copy_round5_artifacts.sh takes them to profiles/).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/final5; rm -rf $O; mkdir -p $O
-LINES="cfg2 cfg2:f32 cfg2:int16 cfg3 cfg3:f32 cfg3:ss2000 cfg4 cfg4:f32 cfg4:planes64 cfg5 api api:chain next:depth next:masks next:nasc"
+LINES="cfg2 cfg2:f32 cfg2:int16 cfg2:sv cfg2:sv32 cfg3 cfg3:f32 cfg3:ss2000 cfg4 cfg4:f32 cfg4:planes64 cfg5 api api:chain next:depth next:masks next:nasc"
 for wl in $LINES; do
   tag=$(echo $wl | tr ':' '_')
   for c in FETCH_SIZE WRITE_SIZE; do

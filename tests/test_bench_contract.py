@@ -43,7 +43,7 @@ def test_committed_bench_lines_keep_the_contract():
     raw = [x.strip() for x in open(LINES) if x.strip()]
     assert all(len(x) < 2000 for x in raw), [len(x) for x in raw]                     # a line fits the driver's tail
     lines = [json.loads(x) for x in raw]
-    assert len(lines) == 15
+    assert len(lines) == 17
     for d in lines:
         _check_line(d, want_cpu=True)
         assert d["n_gpus"] == 1 and d["config"]["passes_per_step"] >= 1
@@ -64,8 +64,9 @@ def test_committed_bench_lines_keep_the_contract():
     also = {k for k in head["config"] if k.startswith("also_")}   # the other lines' figures, one flat string per family
     assert also == {"also_cfg3", "also_cfg2", "also_api", "also_cfg4", "also_next", "also_unit"}
     assert head["config"]["also_next"].count(";") == 2 and "int16" in head["config"]["also_cfg2"]  # the SURVEY 8f rows
+    assert "sv " in head["config"]["also_cfg2"] and "sv32 " in head["config"]["also_cfg2"]             # K1 alone (configs[1])
     assert head["config"]["host_ms_per_call"] > 0
-    assert all(len(head["config"][k]) <= 120 for k in also)
+    assert all(len(head["config"][k]) <= 130 for k in also)
     assert head["config"]["also_cfg3"].count(";") == 2 and "ss2000" in head["config"]["also_cfg3"]
     by = {d["config"]["workload"].split(":")[0] + ":" + d["dtype"] for d in lines}
     assert {"cfg2:f64", "cfg2:f32", "cfg3:f64", "cfg3:f32", "cfg4:f64", "cfg4:f32", "cfg5:f64", "api:f64", "next:f64"} <= by
