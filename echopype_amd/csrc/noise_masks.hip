@@ -1122,6 +1122,12 @@ __device__ __forceinline__ bool pool_feasible(const PoolValueArgs<T>& a, T d, in
          (p - a.n >= 0) && ((long long)p + a.n <= (long long)a.P);
 }
 
+// (the part of pool_feasible that depends on the range value only)
+template <typename T>
+__device__ __forceinline__ bool pool_depth_feasible(const PoolValueArgs<T>& a, T d) {
+  return (d - a.bin >= a.rmin) && (d + a.bin <= a.rmax) && (d - a.bin >= a.exclude_above);
+}
+
 // nanmean: one thread per output sample
 template <typename T>
 __global__ __launch_bounds__(kBlock) void pool_value_mean_kernel(PoolValueArgs<T> a, long long rows) {
@@ -1506,7 +1512,8 @@ __global__ __launch_bounds__(kBlock, 3) void pool_value_mean_staged_kernel(PoolV
                                                                         const double* __restrict__ wl,
                                                                         const int* __restrict__ wn,
                                                                         const uint8_t* __restrict__ dirty,
-                                                                        const int* __restrict__ differ) {
+                                                                        const int* __restrict__ differ,
+                                                                        const uint8_t* __restrict__ todo) {
   __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
   // seg_r[2 + i] = range[kmin + i], two -inf before and two +inf behind: the three candidate positions around a guess
   // are tested without a bounds check
@@ -1515,6 +1522,13 @@ __global__ __launch_bounds__(kBlock, 3) void pool_value_mean_staged_kernel(PoolV
   __shared__ int seg_n[kStageCap + 1];
   __shared__ double red_lo[4], red_hi[4];
   __shared__ int kspan[2 * kSpanMax];
+  {  // (uniform) a workgroup with nothing to do -- the usual case behind the lean kernel -- leaves before the tables
+    bool any = false;
+    const int gpc = (a.P + kStageRows - 1) / kStageRows;
+    for (long long grp = blockIdx.x; grp < (long long)C * gpc && !any; grp += gridDim.x)
+      any = differ[grp / gpc] != 0 && (!todo || todo[(long long)blockIdx.y * ((long long)C * gpc) + grp] != 0);
+    if (!any) return;
+  }
   const epa::MathTabs mt = epa::build_math_tabs(tabs);
   __syncthreads();
   const int s = blockIdx.y * kBlock + threadIdx.x;
@@ -1526,11 +1540,13 @@ __global__ __launch_bounds__(kBlock, 3) void pool_value_mean_staged_kernel(PoolV
   for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const long long c = grp / groups_per_channel;
     if (!differ[c]) continue;  // every ping of the channel has the same range vector: value_slide_kernel
+    // (after pool_value_mean_lean_kernel: only the groups it has left -- todo is indexed band-major as its work items)
+    if (todo && !todo[(long long)blockIdx.y * ngroups + grp]) continue;
     const int p0 = (int)(grp - c * groups_per_channel) * kStageRows;
     const int nrows = min(kStageRows, a.P - p0);
     // ---- this lane's samples of the group's pings
     T d[kStageRows];
-    unsigned feas = 0;
+    unsigned feas = 0, dfeas = 0;  // dfeas: feasible but for the ping window (its interval may be SHARED with a later ping)
     double vmin = __builtin_inf(), vmax = -__builtin_inf();
     // (the eight requests of the lane first, from clamped positions: tested one by one they went out one by one)
     {
@@ -1542,6 +1558,7 @@ __global__ __launch_bounds__(kBlock, 3) void pool_value_mean_staged_kernel(PoolV
     for (int r = 0; r < kStageRows; ++r) {
       if (!(r < nrows && in_row)) d[r] = epa::M<T>::nan();
       if (r < nrows && in_row) {
+        if (pool_depth_feasible(a, d[r])) dfeas |= 1u << r;
         if (pool_feasible(a, d[r], p0 + r)) {
           feas |= 1u << r;
           vmin = fmin(vmin, (double)(d[r] - a.bin));
@@ -1651,7 +1668,9 @@ __global__ __launch_bounds__(kBlock, 3) void pool_value_mean_staged_kernel(PoolV
 #pragma unroll
           for (int r = 0; r < kStageRows; ++r) {
             if (r < r_lo || r > r_hi) continue;  // (uniform)
-            const bool live = (feas >> r) & 1u;
+            // (depth-feasible, not only feasible: a ping too close to the file's start shares its interval with the next
+            //  ping of the same range value, which may be feasible -- the search below must not leave its lanes out)
+            const bool live = (dfeas >> r) & 1u;
             if (!__all(d[r] == same_d || !live)) {  // (uniform)
               same_d = d[r];
               const T lo_v = d[r] - a.bin, hi_v = d[r] + a.bin;
@@ -1733,6 +1752,244 @@ __global__ __launch_bounds__(kBlock, 3) void pool_value_mean_staged_kernel(PoolV
         const double tot = ((has_inf >> r) & 1u) ? __builtin_inf() : sum[r];
         out = (T)(10.0 * epa::fast_log10(tot / (double)cnt[r], mt.log_tab));
       }
+      const size_t at = ((size_t)(c * a.P + p0 + r)) * a.S + s;
+      if (a.pooled) a.pooled[at] = out;
+      if (a.mask) a.mask[at] = (a.sv[at] - out > a.thr) ? 1 : 0;
+      __builtin_amdgcn_sched_barrier(0);  // (one row's logarithm at a time: eight side by side cost 40 registers)
+    }
+  }
+}
+
+// ---- the same, for the groups every neighbour of which can be staged (all of them, in a file without +inf Sv) -------
+// The kernel above spends its time ISSUING instructions, not waiting for memory (rocprofv3 counters, 4 x 20 000 x 2000:
+// VALU busy 62 % + scalar 32 % + LDS 7 % of the SIMDs' issue slots at three wavefronts each; ~415 vector and ~220 scalar
+// instructions per wavefront and neighbour, 148 scalar registers spilled to vector lanes): the three ways a neighbour
+// can be read, the hints of the global-memory route and the +inf bookkeeping all live in one loop.  This kernel keeps
+// only the staged route -- a group with a neighbour it cannot stage (a span beyond the LDS copy, a row holding a +inf
+// Sv, a ping window beyond kSpanMax) is flagged in ``todo`` and left to the kernel above -- and guesses window positions
+// in float32 (they are confirmed on the staged values of type T either way).
+__device__ __forceinline__ bool same_bits(double x, double y) { return __double_as_longlong(x) == __double_as_longlong(y); }
+__device__ __forceinline__ bool same_bits(float x, float y) { return __float_as_int(x) == __float_as_int(y); }
+
+#ifndef EPA_LEAN_WGS  // (development knob) workgroups per CU the register budget is set for
+#define EPA_LEAN_WGS 4
+#endif
+template <typename T>
+__global__ __launch_bounds__(kBlock, EPA_LEAN_WGS) void pool_value_mean_lean_kernel(PoolValueArgs<T> a, int C,
+                                                                      const double* __restrict__ wh,
+                                                                      const double* __restrict__ wl,
+                                                                      const int* __restrict__ wn,
+                                                                      const uint8_t* __restrict__ dirty,
+                                                                      const int* __restrict__ differ, int nbands,
+                                                                      int xcd_map, uint8_t* __restrict__ todo) {
+  __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
+  typedef double dd_t __attribute__((ext_vector_type(2)));
+  // seg_r[1 + i] = range[kmin + i], -inf before and +inf behind; seg_w[i] = {Wh, Wl}[kmin - 1 + i], seg_n[i] the count
+  // (0 before the row)
+  __shared__ T seg_r[kStageCap + 3];
+  __shared__ __attribute__((aligned(16))) dd_t seg_w[kStageCap + 1];
+  __shared__ int seg_n[kStageCap + 1];
+  __shared__ double red_lo[4], red_hi[4];
+  __shared__ int kspan[2 * kSpanMax];
+  epa::MathTabs mt{};
+  bool have_tabs = false;  // (built by the first group that is this kernel's: a channel whose pings share one range vector
+                           //  sends its workgroups through here with nothing to do)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int groups_per_channel = (a.P + kStageRows - 1) / kStageRows;
+  const long long ngroups = (long long)C * groups_per_channel;
+  const long long nwork = ngroups * nbands;
+  const T inf = (T)__builtin_inf();
+  for (long long w0 = blockIdx.x; w0 < nwork; w0 += gridDim.x) {
+    // (the workgroups an XCD runs side by side take consecutive groups of one band of columns: neighbouring groups
+    //  share all but kStageRows of their neighbour rows, and every XCD has its own L2)
+    const long long w = (xcd_map && nwork == (long long)gridDim.x) ? (long long)epa::xcd_contiguous((int)w0, (int)nwork) : w0;
+    const int band = (int)(w / ngroups);
+    const long long grp = w - (long long)band * ngroups;
+    const long long c = grp / groups_per_channel;
+    if (!differ[c]) continue;  // every ping of the channel has the same range vector: value_slide_kernel
+    if (!have_tabs) {
+      mt = epa::build_math_tabs(tabs);
+      have_tabs = true;  // (the barriers below come before the tables' first use)
+    }
+    const int s = band * kBlock + threadIdx.x;
+    const bool in_row = s < a.S;
+    const int p0 = (int)(grp - c * groups_per_channel) * kStageRows;
+    const int nrows = min(kStageRows, a.P - p0);
+    T d[kStageRows];
+    unsigned feas = 0, dfeas = 0;  // dfeas: feasible but for the ping window (its interval may be SHARED with a later ping)
+    double vmin = __builtin_inf(), vmax = -__builtin_inf();
+    {
+      const T* col = a.range + ((size_t)(c * a.P + p0)) * a.S + min(s, a.S - 1);
+#pragma unroll
+      for (int r = 0; r < kStageRows; ++r) d[r] = col[(size_t)min(r, nrows - 1) * a.S];
+    }
+#pragma unroll
+    for (int r = 0; r < kStageRows; ++r) {
+      if (!(r < nrows && in_row)) d[r] = epa::M<T>::nan();
+      if (r < nrows && in_row) {
+        if (pool_depth_feasible(a, d[r])) dfeas |= 1u << r;
+        if (pool_feasible(a, d[r], p0 + r)) {
+          feas |= 1u << r;
+          vmin = fmin(vmin, (double)(d[r] - a.bin));
+          vmax = fmax(vmax, (double)(d[r] + a.bin));
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      vmin = fmin(vmin, __shfl_down(vmin, o, 64));
+      vmax = fmax(vmax, __shfl_down(vmax, o, 64));
+    }
+    __syncthreads();  // (the previous group is done with red / kspan / the staged span)
+    if (lane == 0) {
+      red_lo[wave] = vmin;
+      red_hi[wave] = vmax;
+    }
+    __syncthreads();
+    const T gmin = (T)fmin(fmin(red_lo[0], red_lo[1]), fmin(red_lo[2], red_lo[3]));
+    const T gmax = (T)fmax(fmax(red_hi[0], red_hi[1]), fmax(red_hi[2], red_hi[3]));
+    double sum[kStageRows];
+    int cnt[kStageRows];
+#pragma unroll
+    for (int r = 0; r < kStageRows; ++r) {
+      sum[r] = 0.0;
+      cnt[r] = 0;
+    }
+    bool bail = false;  // (uniform)
+    if (gmin <= gmax) {  // (uniform) some window of the group is feasible
+      const int q_first = max(p0 - a.n, 0), q_last = min(p0 + nrows - 1 + a.n, a.P - 1);
+      const int nq = q_last - q_first + 1;
+      int bad = nq > kSpanMax ? 1 : 0;
+      if (!bad) {  // the spans of all neighbours: one binary search per lane, side by side
+        for (int i = threadIdx.x; i < 2 * nq; i += kBlock) {
+          const size_t row = (size_t)(c * a.P + q_first) + (i >> 1);
+          const T* r2 = a.range + row * a.S;
+          if ((i & 1) && dirty[row] != 0) bad = 1;
+          kspan[i] = (i & 1) ? bound<T, true>(r2, a.nvalid[row], gmax) : bound<T, false>(r2, a.nvalid[row], gmin);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nq; i += kBlock) bad |= kspan[2 * i + 1] - kspan[2 * i] > kStageCap ? 1 : 0;
+      }
+      bail = __syncthreads_or(bad) != 0;
+      if (!bail) {
+        // float32 copies of the samples' offsets from the group's lowest window edge: the guesses are made in float32
+        float df[kStageRows];
+#pragma unroll
+        for (int r = 0; r < kStageRows; ++r) df[r] = (float)(d[r] - gmin);
+        T pre_r[kStageLoads];
+        double pre_h[kStageLoads], pre_l[kStageLoads];
+        int pre_n[kStageLoads];
+        // Requests without predicates (no branch round each): positions are clamped into the span, a slot of 256
+        // entries that lies wholly beyond it is skipped by a uniform branch, and what a clamped request brought is
+        // replaced when the registers go to LDS.  Uniform row pointers + a 32-bit lane offset per request.
+        auto fetch = [&](int qi) {
+          const int kmin = __builtin_amdgcn_readfirstlane(kspan[2 * qi]);
+          const int len = __builtin_amdgcn_readfirstlane(kspan[2 * qi + 1]) - kmin;
+          const size_t base = (size_t)(c * a.P + q_first + qi) * a.S;
+          const T* rb = a.range + base;
+          const double *hb = wh + base, *lb = wl + base;
+          const int* nb = wn + base;
+#pragma unroll
+          for (int u = 0; u < kStageLoads; ++u) {
+            if (u * kBlock > len) continue;  // (uniform)
+            const int i = threadIdx.x + u * kBlock;
+            const unsigned kr = (unsigned)(kmin + min(i, max(len - 1, 0)));  // range[kmin + i], i < len
+            const unsigned kw = (unsigned)max(kmin - 1 + min(i, len), 0);    // W[kmin - 1 + i], i <= len
+            pre_r[u] = rb[kr];
+            pre_h[u] = hb[kw];
+            pre_l[u] = lb[kw];
+            pre_n[u] = nb[kw];
+          }
+        };
+        auto store = [&](int kmin, int len) {
+          if (threadIdx.x == 0) seg_r[0] = -inf;
+#pragma unroll
+          for (int u = 0; u < kStageLoads; ++u) {
+            if (u * kBlock > len) continue;  // (uniform)
+            const int i = threadIdx.x + u * kBlock;
+            if (i <= len) {
+              const bool before = u == 0 && kmin == 0 && i == 0;  // entry 0 = W[-1] = 0 when the span starts the row
+              seg_r[1 + i] = i == len ? inf : pre_r[u];          // (+inf: the sentinel behind the span)
+              seg_w[i] = before ? dd_t{0.0, 0.0} : dd_t{pre_h[u], pre_l[u]};
+              seg_n[i] = before ? 0 : pre_n[u];
+            }
+          }
+        };
+        fetch(0);
+        const float binf = (float)a.bin;
+        // Pings of the group with the same range value at a column -- all of them, while the recorded sound speed
+        // holds -- share the interval in a neighbour's row and its sum.  Which pings differ from the one before them
+        // in ANY lane of the wavefront is settled here, once: the loop over neighbours tests a scalar bit.
+        unsigned chg = 0;
+#pragma unroll
+        for (int r = 1; r < kStageRows; ++r)
+          chg |= __any(!same_bits(d[r], d[r - 1])) ? 1u << r : 0u;
+#pragma unroll 1
+        for (int qi = 0; qi < nq; ++qi) {
+          const int kmin = __builtin_amdgcn_readfirstlane(kspan[2 * qi]);
+          const int len = __builtin_amdgcn_readfirstlane(kspan[2 * qi + 1]) - kmin;
+          __syncthreads();  // the previous neighbour's span has been consumed
+          store(kmin, len);
+          __syncthreads();
+          if (qi + 1 < nq) fetch(qi + 1);  // (in flight while this neighbour is summed)
+          // the group's pings that have q inside their ping window [p - n, min(p + n, P - 1)]
+          const int q = q_first + qi;
+          const int r_lo = max(q - a.n - p0, 0), r_hi = min(q + a.n - p0, nrows - 1);
+          // range rows are (nearly always) affine in the sample index: the position of a value is guessed from the
+          // span's ends and confirmed on the two values it must lie between; anything else is searched
+          const T first = seg_r[1], last = seg_r[len];
+          const float firstf = (float)(first - gmin);
+          const float invf = (len > 1 && last > first) ? (float)(len - 1) / (float)(last - first) : 0.0f;
+          const float reachf = binf * invf;
+          // the interval [l, h) of q's row inside [dv - bin, dv + bin] and its sum / count
+          auto resolve = [&](T dv, float dvf, bool live, double& w_out, int& c_out) {
+            const T lo_v = dv - a.bin, hi_v = dv + a.bin;
+            const float x = (dvf - firstf) * invf;
+            // first index with range >= lo_v / > hi_v, as positions 0 .. len inside the span
+            int gl = (int)__builtin_ceilf(x - reachf), gh = (int)__builtin_floorf(x + reachf) + 1;
+            gl = min(max(gl, 0), len);
+            gh = min(max(gh, 0), len);
+            const T a1 = seg_r[gl], a2 = seg_r[gl + 1];
+            const T b1 = seg_r[gh], b2 = seg_r[gh + 1];
+            // (& not &&: all four values are requested before the first comparison)
+            int l = ((a1 < lo_v) & (lo_v <= a2)) ? gl : -1;
+            int h = ((b1 <= hi_v) & (hi_v < b2)) ? gh : -1;
+            if (__any(live & ((l | h) < 0))) {  // (uniform, rare) a guess off by one, a row that is not affine here
+              if (live && l < 0) l = bound<T, false>(seg_r + 1, len, lo_v);
+              if (live && h < 0) h = bound<T, true>(seg_r + 1, len, hi_v);
+            }
+            l = max(l, 0);
+            h = max(h, 0);
+            // W[hi-1] - W[lo-1]: the high parts subtract exactly when they are close (a window far down a row whose
+            // total is 1e14 times its own), the low parts carry what the running sum had rounded away
+            const dd_t w_h = seg_w[h], w_l = seg_w[l];
+            const double wsum = (w_h.x - w_l.x) + (w_h.y - w_l.y);
+            const int n_in = seg_n[h] - seg_n[l];
+            w_out = h > l ? wsum : 0.0;
+            c_out = h > l ? n_in : 0;
+          };
+          double same_w = 0.0;
+          int same_c = 0;
+#pragma unroll
+          for (int r = 0; r < kStageRows; ++r) {
+            if (r < r_lo || r > r_hi) continue;  // (uniform)
+            if (r == r_lo || ((chg >> r) & 1u))  // (uniform) the first ping q is a neighbour of, or a new range value
+              resolve(d[r], df[r], (dfeas >> r) & 1u, same_w, same_c);  // (dfeas: a later ping may share the interval)
+            sum[r] += same_w;  // (a plain sum of the -- non-negative -- window sums)
+            cnt[r] += same_c;
+          }
+        }
+      }
+    }
+    if (bail) {  // (uniform) the general kernel takes this group
+      if (threadIdx.x == 0) todo[w] = 1;
+      continue;
+    }
+#pragma unroll
+    for (int r = 0; r < kStageRows; ++r) {
+      if (r >= nrows || !in_row) continue;
+      T out = epa::M<T>::nan();
+      if (((feas >> r) & 1u) && cnt[r] > 0) out = (T)(10.0 * epa::fast_log10(sum[r] / (double)cnt[r], mt.log_tab));
       const size_t at = ((size_t)(c * a.P + p0 + r)) * a.S + s;
       if (a.pooled) a.pooled[at] = out;
       if (a.mask) a.mask[at] = (a.sv[at] - out > a.thr) ? 1 : 0;
@@ -2966,7 +3223,21 @@ int launch_pool_value(const void* sv, const void* range, const int32_t* nvalid, 
       {  // channels whose pings differ in their range vectors: neighbour rows staged in LDS
         const long long ngroups = (long long)C * ((P + kStageRows - 1) / kStageRows);
         const dim3 sgrid((unsigned)std::min<long long>(ngroups, 65535 * 4), grid.y);
-        hipLaunchKernelGGL(pool_value_mean_staged_kernel<T>, sgrid, dim3(kBlock), 0, st, a, C, wh, wl, wn, dirty, differ);
+        // the lean kernel first; the groups it flags in ``todo`` (kept in the workspace's spare quarter: rl is not used
+        // on this route) go to the general one.  EPA_POOL_LEAN=0: the general kernel for everything (development knob)
+        static const bool lean = [] { const char* e = getenv("EPA_POOL_LEAN"); return !(e && e[0] == '0'); }();
+        uint8_t* todo = nullptr;
+        const long long nwork = ngroups * (long long)grid.y;
+        if (lean && nwork <= (long long)(N * sizeof(double))) {
+          todo = reinterpret_cast<uint8_t*>(rl);
+          EPA_CHECK_HIP(hipMemsetAsync(todo, 0, (size_t)nwork, st));
+          hipLaunchKernelGGL(pool_value_mean_lean_kernel<T>, dim3((unsigned)std::min<long long>(nwork, 1ll << 30)),
+                             dim3(kBlock), 0, st, a, C, wh, wl, wn, dirty, differ, (int)grid.y,
+                             epa::xcd_map_enabled() ? 1 : 0, todo);
+          if (int rc = epa::check_launch("pool_value_mean_lean_kernel")) return rc;
+        }
+        hipLaunchKernelGGL(pool_value_mean_staged_kernel<T>, sgrid, dim3(kBlock), 0, st, a, C, wh, wl, wn, dirty, differ,
+                           todo);
       }
       return epa::check_launch("pool_value_mean_staged_kernel");
     }
