@@ -1767,13 +1767,23 @@ __global__ __launch_bounds__(kBlock, 3) void pool_value_mean_staged_kernel(PoolV
 // can be read, the hints of the global-memory route and the +inf bookkeeping all live in one loop.  This kernel keeps
 // only the staged route -- a group with a neighbour it cannot stage (a span beyond the LDS copy, a row holding a +inf
 // Sv, a ping window beyond kSpanMax) is flagged in ``todo`` and left to the kernel above -- and guesses window positions
-// in float32 (they are confirmed on the staged values of type T either way).
+// in float32 (they are confirmed on the staged values of type T either way).  Per neighbour and wavefront it issues
+// ~150 vector + ~115 scalar instructions when the pings of a group share their range values (one interval per
+// neighbour) and is still issue-bound: four wavefronts per SIMD, 29 % of each wavefront's cycles issuing.
+// 4 x 100 000 x 2000, the range vector changing every 2000 pings / at every ping: 57 / 76 ms float64 and 45 / 63 ms
+// float32 (91 / 137 and 80 / 118 ms with the kernel above alone); L2 misses 101 M instead of 392 M per 0.16 G samples
+// with the rotated neighbour order (profiles/r05_pool_value_lean_ab.txt).
 __device__ __forceinline__ bool same_bits(double x, double y) { return __double_as_longlong(x) == __double_as_longlong(y); }
 __device__ __forceinline__ bool same_bits(float x, float y) { return __float_as_int(x) == __float_as_int(y); }
 
 #ifndef EPA_LEAN_WGS  // (development knob) workgroups per CU the register budget is set for
 #define EPA_LEAN_WGS 4
 #endif
+#ifndef EPA_LEAN_ROWS  // (development knob) pings per group: a multiple of kStageRows
+#define EPA_LEAN_ROWS 8
+#endif
+constexpr int kLeanRows = EPA_LEAN_ROWS;
+static_assert(kLeanRows % kStageRows == 0, "the general kernel takes over whole groups of its own");
 template <typename T>
 __global__ __launch_bounds__(kBlock, EPA_LEAN_WGS) void pool_value_mean_lean_kernel(PoolValueArgs<T> a, int C,
                                                                       const double* __restrict__ wh,
@@ -1791,17 +1801,18 @@ __global__ __launch_bounds__(kBlock, EPA_LEAN_WGS) void pool_value_mean_lean_ker
   __shared__ int seg_n[kStageCap + 1];
   __shared__ double red_lo[4], red_hi[4];
   __shared__ int kspan[2 * kSpanMax];
+  __shared__ float kinv[kSpanMax], kfirst[kSpanMax];  // per neighbour: samples per metre of its span, its first value - gmin
   epa::MathTabs mt{};
   bool have_tabs = false;  // (built by the first group that is this kernel's: a channel whose pings share one range vector
                            //  sends its workgroups through here with nothing to do)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int groups_per_channel = (a.P + kStageRows - 1) / kStageRows;
+  const int groups_per_channel = (a.P + kLeanRows - 1) / kLeanRows;
   const long long ngroups = (long long)C * groups_per_channel;
   const long long nwork = ngroups * nbands;
   const T inf = (T)__builtin_inf();
   for (long long w0 = blockIdx.x; w0 < nwork; w0 += gridDim.x) {
     // (the workgroups an XCD runs side by side take consecutive groups of one band of columns: neighbouring groups
-    //  share all but kStageRows of their neighbour rows, and every XCD has its own L2)
+    //  share all but kLeanRows of their neighbour rows, and every XCD has its own L2)
     const long long w = (xcd_map && nwork == (long long)gridDim.x) ? (long long)epa::xcd_contiguous((int)w0, (int)nwork) : w0;
     const int band = (int)(w / ngroups);
     const long long grp = w - (long long)band * ngroups;
@@ -1813,18 +1824,18 @@ __global__ __launch_bounds__(kBlock, EPA_LEAN_WGS) void pool_value_mean_lean_ker
     }
     const int s = band * kBlock + threadIdx.x;
     const bool in_row = s < a.S;
-    const int p0 = (int)(grp - c * groups_per_channel) * kStageRows;
-    const int nrows = min(kStageRows, a.P - p0);
-    T d[kStageRows];
+    const int p0 = (int)(grp - c * groups_per_channel) * kLeanRows;
+    const int nrows = min(kLeanRows, a.P - p0);
+    T d[kLeanRows];
     unsigned feas = 0, dfeas = 0;  // dfeas: feasible but for the ping window (its interval may be SHARED with a later ping)
     double vmin = __builtin_inf(), vmax = -__builtin_inf();
     {
       const T* col = a.range + ((size_t)(c * a.P + p0)) * a.S + min(s, a.S - 1);
 #pragma unroll
-      for (int r = 0; r < kStageRows; ++r) d[r] = col[(size_t)min(r, nrows - 1) * a.S];
+      for (int r = 0; r < kLeanRows; ++r) d[r] = col[(size_t)min(r, nrows - 1) * a.S];
     }
 #pragma unroll
-    for (int r = 0; r < kStageRows; ++r) {
+    for (int r = 0; r < kLeanRows; ++r) {
       if (!(r < nrows && in_row)) d[r] = epa::M<T>::nan();
       if (r < nrows && in_row) {
         if (pool_depth_feasible(a, d[r])) dfeas |= 1u << r;
@@ -1848,10 +1859,10 @@ __global__ __launch_bounds__(kBlock, EPA_LEAN_WGS) void pool_value_mean_lean_ker
     __syncthreads();
     const T gmin = (T)fmin(fmin(red_lo[0], red_lo[1]), fmin(red_lo[2], red_lo[3]));
     const T gmax = (T)fmax(fmax(red_hi[0], red_hi[1]), fmax(red_hi[2], red_hi[3]));
-    double sum[kStageRows];
-    int cnt[kStageRows];
+    double sum[kLeanRows];
+    int cnt[kLeanRows];
 #pragma unroll
-    for (int r = 0; r < kStageRows; ++r) {
+    for (int r = 0; r < kLeanRows; ++r) {
       sum[r] = 0.0;
       cnt[r] = 0;
     }
@@ -1868,80 +1879,120 @@ __global__ __launch_bounds__(kBlock, EPA_LEAN_WGS) void pool_value_mean_lean_ker
           kspan[i] = (i & 1) ? bound<T, true>(r2, a.nvalid[row], gmax) : bound<T, false>(r2, a.nvalid[row], gmin);
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < nq; i += kBlock) bad |= kspan[2 * i + 1] - kspan[2 * i] > kStageCap ? 1 : 0;
+        // range rows are (nearly always) affine in the sample index: the position of a value inside a neighbour's span
+        // is guessed from the span's two ends -- its slope and first value, worked out here for all neighbours at once
+        for (int i = threadIdx.x; i < nq; i += kBlock) {
+          const int kmin = kspan[2 * i], len = kspan[2 * i + 1] - kmin;
+          bad |= len > kStageCap ? 1 : 0;
+          const T* r2 = a.range + ((size_t)(c * a.P + q_first) + i) * a.S;
+          const T first = len > 0 ? r2[kmin] : (T)0, last = len > 0 ? r2[kmin + len - 1] : (T)0;
+          kinv[i] = (len > 1 && last > first) ? (float)(len - 1) / (float)(last - first) : 0.0f;
+          kfirst[i] = (float)(first - gmin);
+        }
       }
       bail = __syncthreads_or(bad) != 0;
       if (!bail) {
-        // float32 copies of the samples' offsets from the group's lowest window edge: the guesses are made in float32
-        float df[kStageRows];
-#pragma unroll
-        for (int r = 0; r < kStageRows; ++r) df[r] = (float)(d[r] - gmin);
-        T pre_r[kStageLoads];
-        double pre_h[kStageLoads], pre_l[kStageLoads];
-        int pre_n[kStageLoads];
+        // (two slots of 256 entries travel through registers ahead of time; the third -- spans beyond 511 samples, a
+        //  window of more than +-125 samples -- is read when the span is stored: its registers cost the usual case
+        //  a spill in every trip of the loop)
+        constexpr int kAhead = 2;
+        T pre_r[kAhead];
+        double pre_h[kAhead], pre_l[kAhead];
+        int pre_n[kAhead];
         // Requests without predicates (no branch round each): positions are clamped into the span, a slot of 256
         // entries that lies wholly beyond it is skipped by a uniform branch, and what a clamped request brought is
-        // replaced when the registers go to LDS.  Uniform row pointers + a 32-bit lane offset per request.
+        // replaced when the registers go to LDS.  Uniform row pointers (stepped from neighbour to neighbour) + a
+        // 32-bit lane offset per request.
+        const size_t base0 = (size_t)(c * a.P + q_first) * a.S;
+        const T* rb = a.range + base0;
+        const double *hb = wh + base0, *lb = wl + base0;
+        const int* nb = wn + base0;
+        int kmin_n = 0, len_n = 0;  // (uniform) the span in the registers
         auto fetch = [&](int qi) {
-          const int kmin = __builtin_amdgcn_readfirstlane(kspan[2 * qi]);
-          const int len = __builtin_amdgcn_readfirstlane(kspan[2 * qi + 1]) - kmin;
-          const size_t base = (size_t)(c * a.P + q_first + qi) * a.S;
-          const T* rb = a.range + base;
-          const double *hb = wh + base, *lb = wl + base;
-          const int* nb = wn + base;
+          kmin_n = __builtin_amdgcn_readfirstlane(kspan[2 * qi]);
+          len_n = __builtin_amdgcn_readfirstlane(kspan[2 * qi + 1]) - kmin_n;
 #pragma unroll
-          for (int u = 0; u < kStageLoads; ++u) {
-            if (u * kBlock > len) continue;  // (uniform)
+          for (int u = 0; u < kAhead; ++u) {
+            if (u * kBlock > len_n) continue;  // (uniform)
             const int i = threadIdx.x + u * kBlock;
-            const unsigned kr = (unsigned)(kmin + min(i, max(len - 1, 0)));  // range[kmin + i], i < len
-            const unsigned kw = (unsigned)max(kmin - 1 + min(i, len), 0);    // W[kmin - 1 + i], i <= len
+            const unsigned kr = (unsigned)(kmin_n + min(i, max(len_n - 1, 0)));  // range[kmin + i], i < len
+            const unsigned kw = (unsigned)max(kmin_n - 1 + min(i, len_n), 0);    // W[kmin - 1 + i], i <= len
             pre_r[u] = rb[kr];
             pre_h[u] = hb[kw];
             pre_l[u] = lb[kw];
             pre_n[u] = nb[kw];
           }
         };
-        auto store = [&](int kmin, int len) {
+        auto step_rows = [&](long long rows) {  // (uniform) the row pointers, `rows` rows on
+          const long long o = rows * a.S;
+          rb += o; hb += o; lb += o; nb += o;
+        };
+        auto store = [&](int kmin, int len, int qi_cur) {
           if (threadIdx.x == 0) seg_r[0] = -inf;
 #pragma unroll
-          for (int u = 0; u < kStageLoads; ++u) {
+          for (int u = 0; u < kAhead; ++u) {
             if (u * kBlock > len) continue;  // (uniform)
             const int i = threadIdx.x + u * kBlock;
             if (i <= len) {
-              const bool before = u == 0 && kmin == 0 && i == 0;  // entry 0 = W[-1] = 0 when the span starts the row
-              seg_r[1 + i] = i == len ? inf : pre_r[u];          // (+inf: the sentinel behind the span)
-              seg_w[i] = before ? dd_t{0.0, 0.0} : dd_t{pre_h[u], pre_l[u]};
-              seg_n[i] = before ? 0 : pre_n[u];
+              seg_r[1 + i] = i == len ? inf : pre_r[u];  // (+inf: the sentinel behind the span)
+              seg_w[i] = dd_t{pre_h[u], pre_l[u]};
+              seg_n[i] = pre_n[u];
             }
           }
+          if (len >= kAhead * kBlock) {  // (uniform, rare) the third slot, straight from this neighbour's row
+            const int i = threadIdx.x + kAhead * kBlock;
+            if (i <= len) {
+              const size_t cur = base0 + (size_t)qi_cur * a.S;
+              const unsigned kr = (unsigned)(kmin + min(i, len - 1)), kw = (unsigned)(kmin - 1 + i);
+              seg_r[1 + i] = i == len ? inf : a.range[cur + kr];
+              seg_w[i] = dd_t{wh[cur + kw], wl[cur + kw]};
+              seg_n[i] = wn[cur + kw];
+            }
+          }
+          if (kmin == 0 && threadIdx.x == 0) {  // (uniform, rare) the span starts the row: entry 0 = W[-1] = 0
+            seg_w[0] = dd_t{0.0, 0.0};          // (the thread that wrote entry 0 above)
+            seg_n[0] = 0;
+          }
         };
-        fetch(0);
+        // Neighbours are taken in ROTATED order: at trip t the row of the window whose ping index is congruent to t
+        // modulo the window length.  The groups an XCD runs side by side are consecutive and start together; taken
+        // from the first row on, a row two groups share would be asked for 8 trips apart -- with 128 workgroups'
+        // requests in between, 10 MB against the XCD's 4 MB of L2 (measured: 75 % of the requests missed, 226 GB over
+        // the fabric per 0.8 G samples).  Rotated, the groups that share a row ask for it in the same trip.
+        const int qi0 = (nq - q_first % nq) % nq;
+        step_rows(qi0);
+        fetch(qi0);
         const float binf = (float)a.bin;
         // Pings of the group with the same range value at a column -- all of them, while the recorded sound speed
         // holds -- share the interval in a neighbour's row and its sum.  Which pings differ from the one before them
-        // in ANY lane of the wavefront is settled here, once: the loop over neighbours tests a scalar bit.
+        // in ANY lane of the wavefront is settled here, once: the loop over neighbours tests scalar bits.
         unsigned chg = 0;
 #pragma unroll
-        for (int r = 1; r < kStageRows; ++r)
-          chg |= __any(!same_bits(d[r], d[r - 1])) ? 1u << r : 0u;
+        for (int r = 1; r < kLeanRows; ++r)
+          chg |= __builtin_amdgcn_ballot_w64(!same_bits(d[r], d[r - 1])) != 0 ? 1u << r : 0u;
+        int qi = qi0;
 #pragma unroll 1
-        for (int qi = 0; qi < nq; ++qi) {
-          const int kmin = __builtin_amdgcn_readfirstlane(kspan[2 * qi]);
-          const int len = __builtin_amdgcn_readfirstlane(kspan[2 * qi + 1]) - kmin;
+        for (int trip = 0; trip < nq; ++trip) {
+          const int kmin = kmin_n, len = len_n;
           __syncthreads();  // the previous neighbour's span has been consumed
-          store(kmin, len);
+          store(kmin, len, qi);
           __syncthreads();
-          if (qi + 1 < nq) fetch(qi + 1);  // (in flight while this neighbour is summed)
-          // the group's pings that have q inside their ping window [p - n, min(p + n, P - 1)]
+          const int qi_next = qi + 1 < nq ? qi + 1 : 0;
+          if (trip + 1 < nq) {
+            step_rows(qi_next ? 1 : 1 - nq);
+            fetch(qi_next);  // (in flight while this neighbour is summed)
+          }
+          // the group's pings that have q inside their ping window [p - n, min(p + n, P - 1)], as a mask; the pings
+          // whose interval has to be resolved: the first of them and those with a new range value
           const int q = q_first + qi;
           const int r_lo = max(q - a.n - p0, 0), r_hi = min(q + a.n - p0, nrows - 1);
-          // range rows are (nearly always) affine in the sample index: the position of a value is guessed from the
-          // span's ends and confirmed on the two values it must lie between; anything else is searched
-          const T first = seg_r[1], last = seg_r[len];
-          const float firstf = (float)(first - gmin);
-          const float invf = (len > 1 && last > first) ? (float)(len - 1) / (float)(last - first) : 0.0f;
+          const unsigned rmask = r_hi >= r_lo ? (~0u >> (31 - r_hi)) & (~0u << r_lo) : 0u;
+          const unsigned lmask = rmask & (chg | (1u << r_lo));
+          const float firstf = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, kfirst[qi])));
+          const float invf = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, kinv[qi])));
           const float reachf = binf * invf;
-          // the interval [l, h) of q's row inside [dv - bin, dv + bin] and its sum / count
+          // the interval [l, h) of q's row inside [dv - bin, dv + bin] and its sum / count.  The position of a value is
+          // guessed (in float32, from dvf = the value's offset from the group's lowest window edge) and confirmed on the two staged values it must lie between; anything else is searched.
           auto resolve = [&](T dv, float dvf, bool live, double& w_out, int& c_out) {
             const T lo_v = dv - a.bin, hi_v = dv + a.bin;
             const float x = (dvf - firstf) * invf;
@@ -1952,41 +2003,42 @@ __global__ __launch_bounds__(kBlock, EPA_LEAN_WGS) void pool_value_mean_lean_ker
             const T a1 = seg_r[gl], a2 = seg_r[gl + 1];
             const T b1 = seg_r[gh], b2 = seg_r[gh + 1];
             // (& not &&: all four values are requested before the first comparison)
-            int l = ((a1 < lo_v) & (lo_v <= a2)) ? gl : -1;
-            int h = ((b1 <= hi_v) & (hi_v < b2)) ? gh : -1;
-            if (__any(live & ((l | h) < 0))) {  // (uniform, rare) a guess off by one, a row that is not affine here
-              if (live && l < 0) l = bound<T, false>(seg_r + 1, len, lo_v);
-              if (live && h < 0) h = bound<T, true>(seg_r + 1, len, hi_v);
+            const bool ok_l = (a1 < lo_v) & (lo_v <= a2), ok_h = (b1 <= hi_v) & (hi_v < b2);
+            int l = gl, h = gh;
+            if (__builtin_amdgcn_ballot_w64(live & !(ok_l & ok_h)) != 0) {  // (uniform, rare) off by one, a row not affine here
+              if (live && !ok_l) l = bound<T, false>(seg_r + 1, len, lo_v);
+              if (live && !ok_h) h = bound<T, true>(seg_r + 1, len, hi_v);
             }
-            l = max(l, 0);
-            h = max(h, 0);
             // W[hi-1] - W[lo-1]: the high parts subtract exactly when they are close (a window far down a row whose
-            // total is 1e14 times its own), the low parts carry what the running sum had rounded away
+            // total is 1e14 times its own), the low parts carry what the running sum had rounded away.  (h >= l in
+            // every lane that counts: an empty interval subtracts an entry from itself.)
             const dd_t w_h = seg_w[h], w_l = seg_w[l];
-            const double wsum = (w_h.x - w_l.x) + (w_h.y - w_l.y);
-            const int n_in = seg_n[h] - seg_n[l];
-            w_out = h > l ? wsum : 0.0;
-            c_out = h > l ? n_in : 0;
+            w_out = (w_h.x - w_l.x) + (w_h.y - w_l.y);
+            c_out = seg_n[h] - seg_n[l];
           };
           double same_w = 0.0;
           int same_c = 0;
 #pragma unroll
-          for (int r = 0; r < kStageRows; ++r) {
-            if (r < r_lo || r > r_hi) continue;  // (uniform)
-            if (r == r_lo || ((chg >> r) & 1u))  // (uniform) the first ping q is a neighbour of, or a new range value
-              resolve(d[r], df[r], (dfeas >> r) & 1u, same_w, same_c);  // (dfeas: a later ping may share the interval)
-            sum[r] += same_w;  // (a plain sum of the -- non-negative -- window sums)
-            cnt[r] += same_c;
+          for (int r = 0; r < kLeanRows; ++r) {
+            if ((lmask >> r) & 1u)  // (uniform)
+              resolve(d[r], (float)(d[r] - gmin), (dfeas >> r) & 1u, same_w, same_c);  // (dfeas: a later ping may share the interval)
+            if ((rmask >> r) & 1u) {  // (uniform)
+              sum[r] += same_w;  // (a plain sum of the -- non-negative -- window sums)
+              cnt[r] += same_c;
+            }
           }
+          qi = qi_next;
         }
       }
     }
-    if (bail) {  // (uniform) the general kernel takes this group
-      if (threadIdx.x == 0) todo[w] = 1;
+    if (bail) {  // (uniform) the general kernel takes this group: flags per group of ITS size, band-major
+      const int gpc8 = (a.P + kStageRows - 1) / kStageRows;
+      if (threadIdx.x < kLeanRows / kStageRows && p0 + (int)threadIdx.x * kStageRows < a.P)
+        todo[((long long)band * C + c) * gpc8 + p0 / kStageRows + threadIdx.x] = 1;
       continue;
     }
 #pragma unroll
-    for (int r = 0; r < kStageRows; ++r) {
+    for (int r = 0; r < kLeanRows; ++r) {
       if (r >= nrows || !in_row) continue;
       T out = epa::M<T>::nan();
       if (((feas >> r) & 1u) && cnt[r] > 0) out = (T)(10.0 * epa::fast_log10(sum[r] / (double)cnt[r], mt.log_tab));
@@ -3228,10 +3280,11 @@ int launch_pool_value(const void* sv, const void* range, const int32_t* nvalid, 
         static const bool lean = [] { const char* e = getenv("EPA_POOL_LEAN"); return !(e && e[0] == '0'); }();
         uint8_t* todo = nullptr;
         const long long nwork = ngroups * (long long)grid.y;
+        const long long nlean = (long long)C * ((P + kLeanRows - 1) / kLeanRows) * (long long)grid.y;
         if (lean && nwork <= (long long)(N * sizeof(double))) {
           todo = reinterpret_cast<uint8_t*>(rl);
           EPA_CHECK_HIP(hipMemsetAsync(todo, 0, (size_t)nwork, st));
-          hipLaunchKernelGGL(pool_value_mean_lean_kernel<T>, dim3((unsigned)std::min<long long>(nwork, 1ll << 30)),
+          hipLaunchKernelGGL(pool_value_mean_lean_kernel<T>, dim3((unsigned)std::min<long long>(nlean, 1ll << 30)),
                              dim3(kBlock), 0, st, a, C, wh, wl, wn, dirty, differ, (int)grid.y,
                              epa::xcd_map_enabled() ? 1 : 0, todo);
           if (int rc = epa::check_launch("pool_value_mean_lean_kernel")) return rc;

@@ -6,12 +6,10 @@ i=0
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" \
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SMEM" \
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA" \
-           "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum" \
-           "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum" \
-           "SQ_INSTS_VALU_MFMA_F64 SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_WAVES_EQ_64 SQ_INSTS_FLAT SQ_INSTS_WAVE32_LDS"; do
+           "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum"; do
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $grp --kernel-trace -d $O/g$i -o p --output-format csv -- python scripts/perf_pool_value.py 4 20000 2000 > $O/g$i.log 2>&1
   echo "group $i rc $?"; tail -2 $O/g$i.log | cut -c1-200
 done
-python scripts/pmc_summary.py $O pool_value_mean_staged > $O/summary.csv
+python scripts/pmc_summary.py $O pool_value_mean > $O/summary.csv
 cat $O/summary.csv | cut -c1-200

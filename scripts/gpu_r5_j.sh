@@ -1,9 +1,8 @@
 #!/bin/bash
-# mask tests on the default library, then the value-window pooling timings of the named variants
+# mask tests on the default library (or the library named by TEST_LIB), then the value-window pooling timings of the named variants
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r5j; mkdir -p $O
+if [ -n "$TEST_LIB" ]; then export ECHOPYPE_AMD_LIB=$PWD/echopype_amd/lib/libechopype_amd_$TEST_LIB.so; fi
 timeout 1500 python -m pytest tests/test_gpu_masks.py tests/test_gpu_masks_api.py tests/test_gpu_fuzz.py -x -q -m gpu > $O/tests.txt 2>&1; echo "tests rc $?"; tail -5 $O/tests.txt
+unset ECHOPYPE_AMD_LIB
 bash scripts/gpu_r5_i.sh "$@"
-echo "== base, EPA_POOL_LEAN=0" >> gpurun_out/r5i/pool_value_ab.txt
-EPA_POOL_LEAN=0 timeout 600 python scripts/perf_pool_value.py >> gpurun_out/r5i/pool_value_ab.txt 2>&1
-tail -8 gpurun_out/r5i/pool_value_ab.txt

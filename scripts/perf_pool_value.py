@@ -9,7 +9,8 @@ from echopype_amd import ops, synth
 
 C, P, S = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (4, 100000, 2000)))
 t = ops.Timer()
-for ss in (2000, 1, P):
+import os
+for ss in ([int(x) for x in os.environ['PV_SS'].split(',')] if os.environ.get('PV_SS') else (2000, 1, P)):
     d = synth.ek60_device(C, P, S, ss_every=ss)
     cf = ops.power_coef_ek(d["sample_interval"], d["transmit_duration_nominal"], d["transmit_power"],
         d["sound_speed_indicative"], d["absorption_indicative"], d["gain_correction"], d["sa_correction"],

@@ -536,8 +536,8 @@ def test_pool_sv_value_rows_longer_than_the_lds_copy(env):
     assert np.isfinite(a).any()
 
 
-@pytest.mark.parametrize("case", ["blocks_of_pings", "span_beyond_the_lds_copy", "more_neighbours_than_span_slots",
-                                  "rows_not_affine"])
+@pytest.mark.parametrize("case", ["blocks_of_pings", "span_beyond_the_lds_copy", "span_in_the_third_slot",
+                                  "more_neighbours_than_span_slots", "rows_not_affine"])
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_pool_sv_value_staged_neighbour_rows(env, dtype, case):
     """The LDS-staged value-window kernel (pings whose range rows differ) against summing every window: the range
@@ -552,6 +552,8 @@ def test_pool_sv_value_staged_neighbour_rows(env, dtype, case):
         C, P, S, n, dbin, step = 2, 43, 700, 6, 3.1, 0.3
     elif case == "span_beyond_the_lds_copy":
         C, P, S, n, dbin, step = 1, 21, 1500, 3, 85.0, 0.3
+    elif case == "span_in_the_third_slot":  # 512 .. 767 samples: the lean kernel reads that slot when it stores the span
+        C, P, S, n, dbin, step = 1, 21, 1500, 3, 50.0, 0.3
     else:
         C, P, S, n, dbin, step = 1, 1100, 70, 530, 1.3, 0.3
     sv, _ = _scene(C, P, S, 12, step=step)
