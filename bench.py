@@ -15,7 +15,7 @@ do not wait for the GPU (uploads on a side stream, the MVBS dataset assembled on
 result once the NEXT tile has been launched, as a pipeline writing results out would.  The ping-time origin sits 10 s
 off the 20-s bin grid, so every tile edge cuts a time bin.  Beside it, from the same invocation: the ops-level harness
 (kernels called directly on preallocated buffers, all cut bins of a rank's tiles exchanged) as config.ops_level_ms_per_pass
-and its bin-aligned layout as config.aligned_ms_per_step.
+(its bin-aligned layout is timed as a check and not printed).
 
 A STEP is `passes_per_step` back-to-back passes of the hot path over the resident volume (so that the driver's 20 steps
 are a ~2 s region); `value` = samples processed by all ranks in the K timed steps / max-over-ranks wall time.
@@ -57,7 +57,7 @@ WORKLOADS = {
     "next": (4, 100_000, 2000, 2, 2),  # SURVEY 8f rows through their API entry points (scripts/perf_masks.py's volume)
 }
 DEFAULT_LINES = ["cfg3", "cfg3:ss2000", "cfg3:f32", "cfg2", "cfg2:f32", "cfg2:int16", "cfg2:sv", "cfg2:sv32", "api", "api:chain",
-                 "cfg4", "cfg4:f32", "cfg4:planes64", "next:depth", "next:masks", "next:nasc", "cfg5"]
+                 "cfg4", "cfg4:f32", "cfg4:planes64", "next:depth", "next:masks", "next:nasc", "cfg5:one", "cfg5"]
 TILE_PINGS = 250_000
 DT = {"f32": "float32", "f64": "float64", "sv32": "float32"}
 
@@ -87,6 +87,9 @@ def parse():
     ap.add_argument("--sharded-at-1", action="store_true",
                     help="N = 1: a one-rank process group (--backend) and the SHARDED entry points per tile -- the host "
                          "cost of the N > 1 route (control messages, exchange plan, collectives as identities) on one GPU")
+    ap.add_argument("--tile-streams", type=int, default=2,
+                    help="cfg5: the resident tiles (independent datasets) are dealt round-robin to this many HIP streams -- "
+                         "the tail of a tile's kernel runs beside the head of the next tile's")
     ap.add_argument("--out", default=None, help="also append every JSON line to this file")
     return ap.parse_args()
 
@@ -140,7 +143,7 @@ def cpu_baseline_ek60(chain=False, multicore=False):
     n = C * P * S
     what = "Sv+denoise(20x50,3dB)+MVBS" if chain else "Sv+MVBS"
     out = {"value": n / med, "unit": "range-samples/s", "cores": 1, "kind": "port",
-           "sample": f"EK60 {C}x{P}x{S} {what}, NumPy f64 oracle, median of {n_runs}, {os.cpu_count()}-core host"}
+           "sample": f"EK60 {C}x{P}x{S} {what}, NumPy f64 oracle, median of {n_runs}"}
     if multicore:  # what dask chunk-parallelism over ping_time could reach at best: the same slice in N processes
         try:
             import multiprocessing as mp
@@ -771,14 +774,19 @@ class Cfg5:
                 return sharding.compute_Sv_MVBS(ed, range_bin=rb, ping_time_bin="20s", dtype=dtype, shard=shard,
                                                 tau_effective_first_ping=tau0)
         pending = collections.deque()
+        torch = ctx.torch
+        n_streams = max(1, int(getattr(ctx, "tile_streams", 1) or 1))
+        # tile i -> stream i % n_streams (the calls of a tile, and the read of its result, under that stream)
+        streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_streams - 1)]
         # host_s / calls: wall time the HOST spends inside the entry-point calls of a tile (launches, control-plane
         # messages; no wait for the GPU on the deferred routes) -- what has to stay under the kernel's ~9 ms per tile for
         # the GPU to run back to back, and the per-call cost that decides the scaling at N = 8 (one tile per rank and pass)
         state = {"last": None, "n_read": 0, "pass": 0, "host_s": 0.0, "calls": 0}
 
         def consume(item):
-            ds, mv = item
-            state["last"] = (tuple(mv["Sv"].shape),)  # (touching the dataset assembles it: the grid's size comes back from the GPU)
+            (ds, mv), st = item
+            with torch.cuda.stream(st):
+                state["last"] = (tuple(mv["Sv"].shape),)  # (touching the dataset assembles it: the grid's size comes back from the GPU)
             state["n_read"] += 1
 
         def one_pass(timer):
@@ -789,16 +797,18 @@ class Cfg5:
             state["pass"] += 1
             try:
                 for i, ed in enumerate(eds):
-                    if timer is not None and i == timed_tile:
-                        timer.start()
-                    t_host = time.perf_counter()
-                    item = call(ed)
-                    if timer is not None:  # (timed passes only)
-                        state["host_s"] += time.perf_counter() - t_host
-                        state["calls"] += 1
-                    if timer is not None and i == timed_tile:
-                        timer.stop()
-                    pending.append(item)
+                    st = streams[i % n_streams]
+                    with torch.cuda.stream(st):
+                        if timer is not None and i == timed_tile:
+                            timer.start()
+                        t_host = time.perf_counter()
+                        item = call(ed)
+                        if timer is not None:  # (timed passes only)
+                            state["host_s"] += time.perf_counter() - t_host
+                            state["calls"] += 1
+                        if timer is not None and i == timed_tile:
+                            timer.stop()
+                    pending.append((item, st))
                     while len(pending) > lag:
                         consume(pending.popleft())
             finally:
@@ -869,11 +879,14 @@ def ranks_info(ctx):
             "device_name": names[0] if len(names) == 1 else names}
 
 
-def run_cfg5(ctx, cpu):
+def run_cfg5(ctx, cpu, variant=""):
     """The headline: the eight tiles through the product entry points (api_layout); beside it the ops-level harness on
-    the same resident tiles, with and without cut bins.  N = 1: Sv of the tiles goes to one reused buffer (ops level) /
+    the same resident tiles, with and without cut bins.  N = 1: the tiles -- independent datasets -- are dealt to
+    ``--tile-streams`` HIP streams (default 2: the kernel of a tile runs beside the next tile's; ``cfg5:one`` = one stream,
+    a launch at a time); N > 1 and --sharded-at-1: one stream.  N = 1: Sv of the tiles goes to one reused buffer (ops level) /
     to the allocator's recycled block (API): 131 GB in + 262 GB out does not fit 288 GB otherwise."""
     args, world = ctx.args, ctx.world
+    ctx.tile_streams = 1 if (variant == "one" or world > 1 or getattr(args, "sharded_at_1", False)) else max(1, args.tile_streams)
     C, _, S = WORKLOADS["cfg5"][:3]
     P_total = args.pings_total or WORKLOADS["cfg5"][1]
     job = Cfg5(ctx, C, P_total, S, ss_every=args.ss_every)
@@ -915,19 +928,29 @@ def run_cfg5(ctx, cpu):
            "mvbs_shape_last_tile": list(state["last"][0]),
            "ops_level_ms_per_pass": el_b / steps / passes * 1e3, "ops_level_kernel_ms": km_b,
            "ops_level_edge_bins": edges_b, "allreduce_bytes": bytes_b,
-           "aligned_ms_per_step": el_a / steps * 1e3, "ranks": ranks_info(ctx)}
+           "ranks": ranks_info(ctx)}
     n_first = C * (job.spans[0][1] - job.spans[0][0]) * S if job.spans else 0
     bps = BYTES_PER_SAMPLE[ctx.dtype]
     del eds, pass_c, finish_c
     if ctx.rank != 0:
         return None
+    k = ctx.tile_streams
+    if k > 1:
+        # Launches run side by side: the HIP-event bracket of ONE tile's calls spans the time it shares the GPU with its
+        # neighbour.  The GPU is busy with this rank's launches and nothing else, so the duration a launch costs is the
+        # timed region's wall time per launch (host gaps included: an upper bound); the bracket goes beside it.
+        cfg["tile_streams"] = k
+        extra = {"launch": f"wall per {job.tile_p}-ping tile, {k} side by side",
+                 "kernel_ms_each": region_ms}
+        region_ms = elapsed / steps / passes / max(1, len(job.tiles)) * 1e3
+    else:
+        extra = {"launch": f"API calls of one {job.tile_p}-ping tile (mean), HIP events"}
     return line(ctx, samples_per_pass=C * P_total * S, passes=passes, elapsed=elapsed, scaling="strong", cpu=cpu,
-                workload=f"cfg5: EK60 CW {C}x{P_total}x{S} TOTAL in ping_time tiles, product entry points "
+                workload=f"cfg5: EK60 CW {C}x{P_total}x{S} in ping_time tiles, entry points "
                          "compute_Sv -> compute_MVBS(20s x 1m), Sv+MVBS out",
                 config=cfg,
                 roofline=roofline("fused_sv_mvbs_kernel (+ K0 of the calls)", region_ms,
-                                  n_first * bps, bps, traffic_key=f"cfg5api:{ctx.dtype}",
-                                  launch=f"API calls of one {job.tile_p}-ping tile (mean), HIP events"))
+                                  n_first * bps, bps, traffic_key=f"cfg5api:{ctx.dtype}", **extra))
 
 
 # ---------------------------------------------------------------------------------------- main
@@ -1022,7 +1045,7 @@ def main():
         if w == "cfg5":
             ctx.cache.clear()
             ctx.free()
-            out = run_cfg5(ctx, cpu.get("ek60"))
+            out = run_cfg5(ctx, cpu.get("ek60"), variant)
         elif w == "api":
             out = run_api(ctx, cpu.get("chain" if variant == "chain" else "ek60"), variant)
         elif w.startswith("cfg4"):

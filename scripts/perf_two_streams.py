@@ -8,12 +8,15 @@ import torch
 sys.path.insert(0, ".")
 from echopype_amd import ops, synth, sharding
 
-C, PT, S = 4, 500000, 2000
+C, PT, S = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (4, 500000, 2000)))
+CARVE = len(sys.argv) > 4 and sys.argv[4] == "carve"   # the N datasets as consecutive blocks of ONE allocation
 t = ops.Timer()
-for dt in (torch.float64, torch.float32):
-    for N in (1, 2, 4, 8):
+for dt in (torch.float64,):
+    for N in (1, 2, 4):
         P = PT // N
         sets = []
+        big_raw = torch.empty((N, C, P, S), dtype=torch.float32, device="cuda") if CARVE else None
+        big_sv = torch.empty((N, C, P, S), dtype=dt, device="cuda") if CARVE else None
         for i in range(N):
             d = synth.ek60_device(C, P, S, seed=20260509 + i, ss_every=1)
             coef = ops.power_coef_ek(d["sample_interval"], d["transmit_duration_nominal"], d["transmit_power"],
@@ -27,9 +30,14 @@ for dt in (torch.float64, torch.float32):
             bs = ops.time_bin_offsets(ns, e0, bin_ns, n_t)
             r_max = float((S - 1) * 2.56e-4 * float(d["sound_speed_indicative"].max()) / 2)
             n_r = len(np.arange(0, r_max + 1.0, 1.0)) - 1
-            sv = torch.empty((C, P, S), dtype=dt, device="cuda")
+            sv = big_sv[i] if CARVE else torch.empty((C, P, S), dtype=dt, device="cuda")
             mv = torch.empty((C, n_t, n_r), dtype=dt, device="cuda")
-            sets.append((d["backscatter_r"], coef, bs, n_t, n_r, sv, mv))
+            raw = d["backscatter_r"]
+            if CARVE:
+                big_raw[i].copy_(raw)
+                raw = big_raw[i]
+            sets.append((raw, coef, bs, n_t, n_r, sv, mv))
+            del d
         streams = [torch.cuda.Stream() for _ in range(N)]
         def seq():
             for raw, coef, bs, n_t, n_r, sv, mv in sets:
@@ -52,5 +60,5 @@ for dt in (torch.float64, torch.float32):
             m = float(np.median(ms))
             b = 12 if dt == torch.float64 else 8
             print(f"{str(dt):14s} {N} x 4x{P}x{S}  {name:11s} {m:8.3f} ms  {C*PT*S/m/1e6:7.1f} Gsamp/s  {C*PT*S*b/m/1e9:5.2f} TB/s = {C*PT*S*b/m/1e9/8:.3f}", flush=True)
-        del sets
+        del sets, big_raw, big_sv
         torch.cuda.empty_cache()

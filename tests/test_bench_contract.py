@@ -43,7 +43,7 @@ def test_committed_bench_lines_keep_the_contract():
     raw = [x.strip() for x in open(LINES) if x.strip()]
     assert all(len(x) < 2000 for x in raw), [len(x) for x in raw]                     # a line fits the driver's tail
     lines = [json.loads(x) for x in raw]
-    assert len(lines) == 17
+    assert len(lines) == 18
     for d in lines:
         _check_line(d, want_cpu=True)
         assert d["n_gpus"] == 1 and d["config"]["passes_per_step"] >= 1
@@ -62,7 +62,14 @@ def test_committed_bench_lines_keep_the_contract():
     assert head["roofline"]["frac"] >= 0.60
     assert all(d["roofline"]["traffic"] is not None for d in lines), [d["config"]["workload"][:12] for d in lines if d["roofline"]["traffic"] is None]
     also = {k for k in head["config"] if k.startswith("also_")}   # the other lines' figures, one flat string per family
-    assert also == {"also_cfg3", "also_cfg2", "also_api", "also_cfg4", "also_next", "also_unit"}
+    assert also == {"also_cfg3", "also_cfg2", "also_api", "also_cfg4", "also_next", "also_cfg5", "also_unit"}
+    # the tiles go to two streams: the roofline's duration is the wall time a launch costs, the HIP-event bracket of one
+    # launch (sharing the GPU with its neighbour) rides beside it; the one-stream line comes just before the headline
+    assert head["config"]["tile_streams"] == 2 and head["roofline"]["kernel_ms_each"] > head["roofline"]["kernel_ms"]
+    assert abs(head["roofline"]["kernel_ms"] * 8 - head["config"]["ms_per_pass"]) < 1e-3 * head["config"]["ms_per_pass"]
+    one = lines[-2]
+    assert one["config"]["workload"] == head["config"]["workload"] and "tile_streams" not in one["config"]
+    assert "kernel_ms_each" not in one["roofline"] and head["config"]["also_cfg5"].startswith("one ")
     assert head["config"]["also_next"].count(";") == 2 and "int16" in head["config"]["also_cfg2"]  # the SURVEY 8f rows
     assert "sv " in head["config"]["also_cfg2"] and "sv32 " in head["config"]["also_cfg2"]             # K1 alone (configs[1])
     assert head["config"]["host_ms_per_call"] > 0
