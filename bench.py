@@ -90,6 +90,8 @@ def parse():
     ap.add_argument("--tile-streams", type=int, default=2,
                     help="cfg5: the resident tiles (independent datasets) are dealt round-robin to this many HIP streams -- "
                          "the tail of a tile's kernel runs beside the head of the next tile's")
+    ap.add_argument("--read-lag", type=int, default=1,
+                    help="cfg5: the result of a tile is read after this many further tiles have been launched")
     ap.add_argument("--out", default=None, help="also append every JSON line to this file")
     return ap.parse_args()
 
@@ -907,7 +909,8 @@ def run_cfg5(ctx, cpu, variant=""):
     job.sv = None
     ctx.free()
     # (c) the product entry points on the same tiles, same 10-s offset: the headline
-    pass_c, finish_c, state, eds = job.api_layout(10_000_000_000)
+    lag = max(1, args.read_lag)
+    pass_c, finish_c, state, eds = job.api_layout(10_000_000_000, lag=lag)
     elapsed, region_ms = ctx.timed(pass_c, passes, finish=finish_c)
     assert state["n_read"] == len(job.tiles) * passes * (steps + args.warmup)  # every result was read
     if world == 1 and not getattr(args, "sharded_at_1", False):
@@ -924,7 +927,7 @@ def run_cfg5(ctx, cpu, variant=""):
         ctx.dist.all_reduce(t, op=ctx.dist.ReduceOp.MAX, group=ctx.sharding.control_group())
         host_ms = float(t.item())
     cfg = {"tiles": f"{job.n_tiles} x {job.tile_p} pings over {world} rank(s)",
-           "route": route, "collective": coll, "results_read": "1 tile late", "host_ms_per_call": host_ms,
+           "route": route, "collective": coll, "results_read": f"{lag} tile(s) late", "host_ms_per_call": host_ms,
            "mvbs_shape_last_tile": list(state["last"][0]),
            "ops_level_ms_per_pass": el_b / steps / passes * 1e3, "ops_level_kernel_ms": km_b,
            "ops_level_edge_bins": edges_b, "allreduce_bytes": bytes_b,
