@@ -1915,7 +1915,8 @@ __global__ __launch_bounds__(kBlock, EPA_LEAN_WGS) void pool_value_mean_lean_ker
           for (int u = 0; u < kAhead; ++u) {
             if (u * kBlock > len_n) continue;  // (uniform)
             const int i = threadIdx.x + u * kBlock;
-            const unsigned kr = (unsigned)(kmin_n + min(i, max(len_n - 1, 0)));  // range[kmin + i], i < len
+            // (an empty span at the very end of a row: kmin = S -- the request stays inside the row)
+            const unsigned kr = (unsigned)min(kmin_n + min(i, max(len_n - 1, 0)), a.S - 1);  // range[kmin + i], i < len
             const unsigned kw = (unsigned)max(kmin_n - 1 + min(i, len_n), 0);    // W[kmin - 1 + i], i <= len
             pre_r[u] = rb[kr];
             pre_h[u] = hb[kw];

@@ -537,7 +537,7 @@ def test_pool_sv_value_rows_longer_than_the_lds_copy(env):
 
 
 @pytest.mark.parametrize("case", ["blocks_of_pings", "span_beyond_the_lds_copy", "span_in_the_third_slot",
-                                  "more_neighbours_than_span_slots", "rows_not_affine"])
+                                  "more_neighbours_than_span_slots", "rows_not_affine", "a_shallow_neighbour_row"])
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_pool_sv_value_staged_neighbour_rows(env, dtype, case):
     """The LDS-staged value-window kernel (pings whose range rows differ) against summing every window: the range
@@ -548,7 +548,7 @@ def test_pool_sv_value_staged_neighbour_rows(env, dtype, case):
     P, S not multiples of 8 / 256."""
     torch, ops = env
     rng = np.random.default_rng(23)
-    if case in ("blocks_of_pings", "rows_not_affine"):
+    if case in ("blocks_of_pings", "rows_not_affine", "a_shallow_neighbour_row"):
         C, P, S, n, dbin, step = 2, 43, 700, 6, 3.1, 0.3
     elif case == "span_beyond_the_lds_copy":
         C, P, S, n, dbin, step = 1, 21, 1500, 3, 85.0, 0.3
@@ -566,6 +566,9 @@ def test_pool_sv_value_staged_neighbour_rows(env, dtype, case):
         depth = (1.5 + uneven + 2e-4 * k * k + 3.0 * (k > 300))[None, None, :] * np.repeat(scale, block, axis=1)[:, :P] \
             + 0.7 * rng.random((C, P, 1))
         assert (np.diff(depth, axis=-1) > 0).all()
+    if case == "a_shallow_neighbour_row":  # pings whose deepest sample lies above the deeper bands of their neighbours:
+        depth[:, 20] *= 0.3                # the span of such a row is empty and starts at the row's end (kmin = S)
+        depth[0, 31] *= 0.05
     depth[:, 7, S - 20:] = np.nan
     sv[:, 7, S - 20:] = np.nan
     sv[0, 10, 100 % S] = 60.0
@@ -582,7 +585,7 @@ def test_pool_sv_value_staged_neighbour_rows(env, dtype, case):
     np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
     _close(a, b, 1e-12 if dtype == "float64" else 1e-5, "staged running sums vs window sums")
     assert np.isposinf(a).any() and np.isfinite(a).any()
-    if case in ("blocks_of_pings", "rows_not_affine") and dtype == "float64":  # (fp32 window edges d -+ bin round differently: a vs b only)
+    if case in ("blocks_of_pings", "rows_not_affine", "a_shallow_neighbour_row") and dtype == "float64":  # (fp32 window edges d -+ bin round differently: a vs b only)
         exp = omask.pool_Sv(sv.astype(np.float64), depth.astype(np.float64), np.nanmean, dbin, n, 2.0)
         _close(a, exp, RTOL[dtype], "vs oracle")
 
