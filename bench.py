@@ -90,6 +90,8 @@ def parse():
     ap.add_argument("--tile-streams", type=int, default=2,
                     help="cfg5: the resident tiles (independent datasets) are dealt round-robin to this many HIP streams -- "
                          "the tail of a tile's kernel runs beside the head of the next tile's")
+    ap.add_argument("--tile-pings", type=int, default=None,
+                    help="cfg5 (experiments): pings per tile instead of the workload's eight tiles")
     ap.add_argument("--read-lag", type=int, default=1,
                     help="cfg5: the result of a tile is read after this many further tiles have been launched")
     ap.add_argument("--out", default=None, help="also append every JSON line to this file")
@@ -891,7 +893,7 @@ def run_cfg5(ctx, cpu, variant=""):
     ctx.tile_streams = 1 if (variant == "one" or world > 1 or getattr(args, "sharded_at_1", False)) else max(1, args.tile_streams)
     C, _, S = WORKLOADS["cfg5"][:3]
     P_total = args.pings_total or WORKLOADS["cfg5"][1]
-    job = Cfg5(ctx, C, P_total, S, ss_every=args.ss_every)
+    job = Cfg5(ctx, C, P_total, S, tile_pings=args.tile_pings, ss_every=args.ss_every)
     passes = ctx.passes("cfg5")
     steps = args.steps
     # (a) ops level, bin-aligned layout: no bin is shared, no data collective
