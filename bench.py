@@ -57,7 +57,7 @@ WORKLOADS = {
     "next": (4, 100_000, 2000, 2, 2),  # SURVEY 8f rows through their API entry points (scripts/perf_masks.py's volume)
 }
 DEFAULT_LINES = ["cfg3", "cfg3:ss2000", "cfg3:f32", "cfg2", "cfg2:f32", "cfg2:int16", "cfg2:sv", "cfg2:sv32", "api", "api:chain",
-                 "cfg4", "cfg4:f32", "cfg4:planes64", "next:depth", "next:masks", "next:nasc", "cfg5:one", "cfg5"]
+                 "cfg4", "cfg4:f32", "cfg4:planes64", "next:depth", "next:depthw", "next:masks", "next:nasc", "cfg5:one", "cfg5"]
 TILE_PINGS = 250_000
 DT = {"f32": "float32", "f64": "float64", "sv32": "float32"}
 
@@ -524,7 +524,8 @@ def run_next(ctx, variant, cpu):
     """The "next" rows of SURVEY 8f on the driver's record, each through its API entry point on a resident EK60 dataset
     (4 x 100 000 x 2000, a new sound speed at every ping -- so every ping has its own range / depth vector):
       depth  compute_Sv -> consolidate.add_depth(ds, depth_offset) -> commongrid.compute_MVBS(ds, range_var="depth")
-             (consolidate/api.py:68-243, commongrid/api.py:30-191): K1 12 + depth 12 + binning 16 = 40 B/sample
+             (consolidate/api.py:68-243, commongrid/api.py:30-191): one sweep, raw in + Sv out = 12 B/sample (depth stays
+             lazy); ``depthw``: depth written by the same sweep, 20 B/sample
       masks  clean.mask_impulse_noise / mask_attenuated_signal / mask_transient_noise on ``depth`` + mask.apply_mask of the
              three (clean/api.py:30-359, mask/api.py:307-464): 3 x (8 + 8 + 1) + (8 + 3 + 8) = 70 B/sample
       nasc   commongrid.compute_NASC(ds) (commongrid/api.py:269-416): Sv + depth read, 16 B/sample
@@ -552,19 +553,38 @@ def run_next(ctx, variant, cpu):
     dtype = ctx.dtype
     logging.disable(logging.WARNING)
     try:
-        if variant == "depth":
+        finish = None
+        if variant in ("depth", "depthw"):
+            # depth: lazy (an affine function of the coefficient rows, binned inside the pass that writes Sv);
+            # depthw: the depth array written by the same pass as well (EPA_DEPTH_WITH_MVBS=1)
+            held = []  # the previous pass's result: read (the deferred MVBS dataset assembled) after this pass's launch
+            written = variant == "depthw"
+
             def one_pass(timer):
                 if timer is not None:
                     timer.start()
                 ds = ep.calibrate.compute_Sv(ed, dtype=dtype)
                 ds = ep.consolidate.add_depth(ds, depth_offset=5.0)
                 mv = ep.commongrid.compute_MVBS(ds, range_var="depth", range_bin="1m", ping_time_bin="20s")
-                shape = mv["Sv"].shape
+                assert ds["Sv"].data.materialized and ds["depth"].data.materialized == written
                 if timer is not None:
                     timer.stop()
-                return shape
-            bps, kern = 40 if dtype == "float64" else 24, "sv_power + depth_rows + block_reduce / mvbs kernels of the three calls"
-            what = "compute_Sv -> add_depth(depth_offset=5) -> compute_MVBS(range_var='depth', 1m x 20s)"
+                held.append(mv)
+                while len(held) > 1:
+                    held.pop(0)["Sv"].shape
+
+            def finish():
+                while held:
+                    held.pop(0)["Sv"].shape
+
+            if written:
+                os.environ["EPA_DEPTH_WITH_MVBS"] = "1"
+            f64 = dtype == "float64"
+            bps = (20 if f64 else 12) if written else (12 if f64 else 8)
+            kern = "fused_sv_mvbs_kernel<.., DEPTH> inside compute_MVBS: the three calls are one sweep of the raw samples"
+            what = ("compute_Sv -> add_depth(depth_offset=5) -> compute_MVBS(range_var='depth', 1m x 20s)"
+                    + (", depth written by the same pass" if written else ", depth left lazy")
+                    + ", each result read after the next pass's launch")
         else:
             ds = ep.calibrate.compute_Sv(ed, dtype=dtype)
             ds = ep.consolidate.add_depth(ds, depth_offset=5.0)
@@ -602,8 +622,9 @@ def run_next(ctx, variant, cpu):
             else:
                 sys.exit(f"unknown next:{variant}")
         passes = ctx.passes("next")
-        elapsed, region_ms = ctx.timed(one_pass, passes)
+        elapsed, region_ms = ctx.timed(one_pass, passes, finish=finish)
     finally:
+        os.environ.pop("EPA_DEPTH_WITH_MVBS", None)
         logging.disable(logging.NOTSET)
     n = C * P * S
     return line(ctx, samples_per_pass=n, passes=passes, elapsed=elapsed, scaling="weak", cpu=cpu,
@@ -1046,7 +1067,7 @@ def main():
             sys.exit(f"unknown workload {w!r}")
         ctx.dtype = DT.get(variant, args.dtype)
         if w == "next" and not variant:
-            sys.exit("next:depth | next:masks | next:nasc")
+            sys.exit("next:depth | next:depthw | next:masks | next:nasc")
         if w == "cfg5":
             ctx.cache.clear()
             ctx.free()

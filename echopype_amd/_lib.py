@@ -87,6 +87,8 @@ SIGNATURES = {
     "epa_sv_mvbs_fused": [_vp, _vp, _i, _i, _i, _i, _u, _vp, _vp, _i, _d, _i, _u, _d, _vp, _vp, _vp,
                           _vp, _vp, _vp, _vp, _i, _vp],
     "epa_sv_mvbs_fused_i16": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _d, _i, _d, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "epa_sv_mvbs_fused_depth": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _d, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _i,
+                                _vp],
     "epa_mvbs": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _d, _i, _u, _d, _vp, _vp, _vp, _i, _vp],
     "epa_selftest_lin_from_db": [_vp, _vp, _sz, _vp],
     "epa_selftest_log10": [_vp, _vp, _sz, _vp],

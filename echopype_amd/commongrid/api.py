@@ -5,6 +5,7 @@ kernel launch through the C ABI (epa_mvbs / epa_mvbs_index).  ``method``, ``rein
 ``**flox_kwargs`` are accepted for signature compatibility (flox is not involved).
 """
 import logging
+import os
 
 import numpy as np
 import torch
@@ -261,7 +262,15 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
     d = sv_da.data
     src = d.source if isinstance(d, LazyDeviceArray) and not d.materialized else None
     dims = ("channel", "ping_time", "range_sample")
-    if src is None or getattr(src, "cal_type", None) != "Sv" or rng_da.data is not src.echo_range \
+    # ``depth`` left lazy by add_depth on this dataset's lazy echo_range (offset + scale * echo_range, row by row): binned
+    # inside the same pass (epa_sv_mvbs_fused_depth) -- the three reference calls at the 12 B/sample of the two
+    rng_d, depth = rng_da.data, None
+    if src is not None and rng_d is not getattr(src, "echo_range", None) and isinstance(rng_d, LazyDeviceArray):
+        aff = rng_d.affine_of()
+        if aff is not None and aff[0] is getattr(src, "echo_range", None) \
+                and src.flags == (_lib.FLAG_GUARD_POS | _lib.FLAG_MASK_RANGE) and rng_d.dtype == d.dtype:
+            depth = aff[1:]
+    if src is None or getattr(src, "cal_type", None) != "Sv" or (depth is None and rng_d is not src.echo_range) \
             or tuple(sv_da.dims) != dims \
             or tuple(rng_da.dims) != dims or src.echo_range.coef_rows() is not src.coef or not src.intact():
         return None  # (also: an Sv deferred by something else than compute_Sv, e.g. remove_background_noise)
@@ -274,12 +283,16 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
     C, P, S = d.shape
     if range_var_max is not None:
         r_cap = _parse_x_bin(range_var_max) + 1e-8
-    elif getattr(src, "reach_bound", None) is not None:
+    elif depth is not None and rng_d.reach_bound is not None:
+        r_cap = rng_d.reach_bound
+    elif depth is None and getattr(src, "reach_bound", None) is not None:
         r_cap = src.reach_bound  # host-side bound: no device reduction, no wait
     else:
         coef = src.coef
-        reach = torch.nan_to_num((S - 1) * coef[..., _lib.CF_RA] * coef[..., _lib.CF_RB] + coef[..., _lib.CF_R0], nan=float("-inf"))
-        r_cap = float(reach.max().item())
+        reach = (S - 1) * coef[..., _lib.CF_RA] * coef[..., _lib.CF_RB] + coef[..., _lib.CF_R0]
+        if depth is not None:  # offset + scale * [r0, reach], whichever end is the deeper one
+            reach = torch.fmax(depth[1] + depth[0] * reach, depth[1] + depth[0] * coef[..., _lib.CF_R0]) * (1 + 1e-6)
+        r_cap = float(torch.nan_to_num(reach, nan=float("-inf")).max().item())
     first_bin = last_bin = 0
     if _shard is not None:  # (every rank of the dataset gets here or none does: the tests above look at nothing rank-local)
         e0, n_t, first_bin, last_bin, r_cap = _shard_grid(_shard, ns, dt, r_cap, range_var_max)
@@ -289,9 +302,16 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
     bin_start = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t)
     res = None
     try:
-        res = ops.sv_mvbs_fused(src.raw, src.coef, bin_start, n_t, range_bin_m, n_cap, cal_flags=src.flags, skipna=True,
-                                closed="left", fill_value=fill_value, dtype=src.dtype, want_range_stats=True,
-                                want_partials=_shard is not None)
+        if depth is not None:
+            # EPA_DEPTH_WITH_MVBS=1: the depth array is written by this pass as well (+8 B/sample here instead of the
+            # 4 + 8 of epa_depth_rows when somebody reads it later); default: it stays lazy
+            res = ops.sv_mvbs_fused_depth(src.raw, src.coef, depth[0], depth[1], bin_start, n_t, range_bin_m, n_cap,
+                                          fill_value=fill_value, dtype=src.dtype, want_partials=_shard is not None,
+                                          want_depth=not rng_d.materialized and os.environ.get("EPA_DEPTH_WITH_MVBS") == "1")
+        else:
+            res = ops.sv_mvbs_fused(src.raw, src.coef, bin_start, n_t, range_bin_m, n_cap, cal_flags=src.flags, skipna=True,
+                                    closed="left", fill_value=fill_value, dtype=src.dtype, want_range_stats=True,
+                                    want_partials=_shard is not None)
     except _lib.EpaError:  # e.g. a range grid too fine for the LDS accumulators
         pass
     # served by the generic kernel (a handful of pings, a grid beyond the LDS)?  It leaves no range statistics, which
@@ -304,8 +324,10 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
         declined = done is None
     if declined:
         return None
-    rng = src.echo_range
+    rng = rng_d if depth is not None else src.echo_range  # (the statistics are the binned variable's)
     d.fulfil(res["Sv"])
+    if res.get("depth") is not None:
+        rng_d.fulfil(res["depth"])
     # the three numbers start their way to the host now, on a side stream behind THIS kernel: whoever reads them later
     # (the assembly below, the next reader of the echo_range statistics) does not wait for kernels launched after it
     stats = ops.fetch_async(res["range_stats"])

@@ -9,6 +9,7 @@ vertical offsets, platform angles, beam angles; consolidate/ek_depth_utils.py).
 """
 import datetime
 import logging
+import weakref
 from numbers import Number
 
 import numpy as np
@@ -137,20 +138,30 @@ def add_depth(ds, echodata=None, depth_offset=None, tilt=None, downward=True,
             scaling, sc_dims = ek_use_beam_angles(echodata[f"Sonar/{beam_group_name}"])
 
     mult = 1.0 if downward else -1.0
-    scale = ops.to_device(np.ascontiguousarray(mult * _per_channel_ping(scaling, sc_dims, C, P, "echo range scaling")))
-    offset = ops.to_device(np.ascontiguousarray(_per_channel_ping(transducer_depth, td_dims, C, P, "transducer depth")))
-    # {nanmin, nanmax, NaN count} of depth come out of the same pass (what compute_MVBS(range_var="depth") asks next)
-    if er_t is None:
-        depth, stats = ops.depth_rows(scale, offset, coef=rows, mask_raw=raw, shape=lazy.shape,
-                                      dtype=torch.float64 if lazy.dtype == np.dtype("float64") else torch.float32)
+    if sc_dims == () and td_dims == ():  # two numbers: filled on the device, nothing to upload
+        scale_h, offset_h = np.float64(mult * scaling), np.float64(transducer_depth)
+        dev = raw.device if er_t is None else er_t.device
+        scale = torch.full((C, P), float(scale_h), dtype=torch.float64, device=dev)
+        offset = torch.full((C, P), float(offset_h), dtype=torch.float64, device=dev)
     else:
+        scale_h = mult * _per_channel_ping(scaling, sc_dims, C, P, "echo range scaling")
+        offset_h = _per_channel_ping(transducer_depth, td_dims, C, P, "transducer depth")
+        scale, offset = ops.to_device(np.ascontiguousarray(scale_h)), ops.to_device(np.ascontiguousarray(offset_h))
+    if er_t is None:
+        # echo_range is still a function of the coefficient rows: so is depth.  The array is written when somebody reads
+        # it; compute_MVBS(range_var="depth") right after -- the usual sequence -- bins on it inside the pass that writes
+        # Sv (epa_sv_mvbs_fused_depth) and leaves its {nanmin, nanmax, NaN count}.
+        depth_data = _lazy_depth(lazy, rows, raw, scale, offset, scale_h, offset_h)
+    else:
+        # {nanmin, nanmax, NaN count} of depth come out of the same pass (what compute_MVBS(range_var="depth") asks next)
         depth, stats = ops.depth_rows(scale, offset, range=er_t)
+        depth_data = DeviceArray(depth, stats=stats)
 
     used_offsets = use_platform_vertical_offsets and not _truthy(depth_offset)
     used_platform_angles = use_platform_angles and not _truthy(tilt)
     used_beam_angles = use_beam_angles and not _truthy(tilt)
     now = datetime.datetime.now(datetime.timezone.utc)
-    ds["depth"] = DataArray(DeviceArray(depth, stats=stats), order, attrs={
+    ds["depth"] = DataArray(depth_data, order, attrs={
         "long_name": "Depth", "standard_name": "depth", "units": "m",
         "history": f"{now}. `depth` calculated using: Sv `echo_range`"
                    + (", Echodata `Platform` Vertical Offsets" if used_offsets else "")
@@ -158,6 +169,44 @@ def add_depth(ds, echodata=None, depth_offset=None, tilt=None, downward=True,
                    + (f", Echodata `{beam_group_name}` Angles" if used_beam_angles and beam_group_name else "")
                    + "."})
     return ds
+
+
+def _lazy_depth(er_lazy, rows, raw, scale, offset, scale_h, offset_h):
+    """depth = offset + scale * echo_range of a lazy echo_range as a LazyDeviceArray: written by ``epa_depth_rows`` from
+    the coefficient rows (+ the raw samples' NaN pattern) on first read, and known to be that affine function of the
+    echo_range until then (``affine_of``)."""
+    shape = er_lazy.shape
+    tdt = torch.float64 if er_lazy.dtype == np.dtype("float64") else torch.float32
+
+    def make():
+        t, st = ops.depth_rows(scale, offset, coef=rows, mask_raw=raw, shape=shape, dtype=tdt)
+        me = ref()
+        if me is not None and me.stats_async() is None:
+            me.set_stats(st)  # (fulfil() stamps them with the tensor's version)
+        return t
+
+    def stats_with_depth():  # statistics asked for before any pass left them: they come with the array
+        me = ref()
+        if me is not None:
+            me.tensor
+
+    depth_lazy = LazyDeviceArray(shape, tdt, raw.device, make)
+    ref = weakref.ref(depth_lazy)  # (no cycle through the closures: a dropped dataset frees at once)
+    depth_lazy.set_affine(er_lazy, scale, offset)
+    depth_lazy.set_stats(None, hook=stats_with_depth)
+    depth_lazy.reach_bound = _depth_reach_bound(er_lazy.reach_bound, scale_h, offset_h)
+    return depth_lazy
+
+
+def _depth_reach_bound(range_bound, scale, offset):
+    """An upper bound of every depth value known on the host: offset + scale * echo_range with echo_range within
+    [0, range_bound] (None without a bound on the range, or when nothing is finite)."""
+    if range_bound is None or not np.isfinite(range_bound):
+        return None
+    with np.errstate(invalid="ignore"):
+        hi = np.fmax.reduce(np.atleast_1d(np.fmax(offset, offset + scale * float(range_bound))), axis=None)
+        hi = hi * (1 + 1e-6) if hi > 0 else hi  # (float32 depth values round up to 6e-8 above the float64 ones)
+    return float(hi) if np.isfinite(hi) else None
 
 
 def _truthy(v):

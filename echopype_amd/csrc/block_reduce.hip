@@ -33,6 +33,9 @@ struct ReduceArgs {
   int range_stats_filled;     // set by run_mvbs when the kernel it chose leaves them
   const int16_t* raw_i16;     // fused fast path only: instrument int16 power samples ...
   const int32_t* n_valid;     // ... with the recorded length of every ping
+  const double* dscale;       // fused fast path only: bin on depth = doffset[c,p] + dscale[c,p] * echo_range ...
+  const double* doffset;
+  void* depth_out;            // ... and optionally write that array
   const float* raw;
   const void* sv;
   const void* range;
@@ -507,7 +510,8 @@ int epa_fused_fast_path(const void* raw, int raw_is_i16, const int32_t* n_valid,
                         int n_rbins, unsigned bin_flags, double fill_value, void* sv_out,
                         void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
                         size_t lds_bytes, unsigned cnt_off, unsigned long long* rmax_key,
-                        unsigned long long* rstat, hipStream_t st);
+                        unsigned long long* rstat, const double* dscale, const double* doffset, void* depth_out,
+                        hipStream_t st);
 
 // chain_fast.hip
 int epa_mvbs_rows_fast_path(const void* sv, const double* coef, int C, int P, int S, const int32_t* bin_start,
@@ -611,7 +615,13 @@ int run_mvbs(ReduceArgs& a, hipStream_t st) {
                                a.n_rbins, a.bin_flags, a.fill_value, a.sv_out, a.out, a.sum_out,
                                a.cnt_out, sizeof(T) == 8 ? EPA_F64 : EPA_F32, pl.tab_off,
                                pl.cnt_off, reinterpret_cast<unsigned long long*>(a.range_max_out),
-                               reinterpret_cast<unsigned long long*>(a.range_stats_out), st);
+                               reinterpret_cast<unsigned long long*>(a.range_stats_out), a.dscale, a.doffset,
+                               a.depth_out, st);
+  if (a.dscale) {
+    epa::set_error("epa_sv_mvbs_fused_depth: binning on depth is served by the default configuration only (sorted "
+                   "pings, S %% 4 == 0, aligned arrays, range grid within LDS)");
+    return EPA_EUNSUPPORTED;
+  }
   if (SRC == SRC_RAW_DENOISE && !two_stage && pl.vec == 4 && !a.ping_perm && !a.range_out &&
       a.cal_flags == (EPA_FLAG_GUARD_POS | EPA_FLAG_MASK_RANGE) && a.bin_flags == EPA_BIN_SKIPNA &&
       !getenv("EPA_NO_FAST_PATH"))
@@ -727,7 +737,8 @@ static int fused_entry(const float* raw, const int16_t* raw_i16, const int32_t* 
                        double range_bin, int n_rbins, unsigned bin_flags, double fill_value,
                        void* sv_out, void* range_out, void* mvbs_out, void* sum_out,
                        uint32_t* cnt_out, double* range_max_out, double* range_stats_out, int dtype,
-                       epa_stream_t stream);
+                       epa_stream_t stream, const double* dscale = nullptr, const double* doffset = nullptr,
+                       void* depth_out = nullptr);
 
 extern "C" int epa_sv_mvbs_fused(const float* raw, const double* coef, int C, int P, int S,
                                  int cal_type, unsigned cal_flags, const int32_t* bin_start,
@@ -755,19 +766,35 @@ extern "C" int epa_sv_mvbs_fused_i16(const int16_t* raw, const int32_t* n_valid,
                      range_max_out, nullptr, dtype, stream);
 }
 
+extern "C" int epa_sv_mvbs_fused_depth(const float* raw, const double* coef, const double* depth_scale,
+                                       const double* depth_offset, int C, int P, int S, int cal_type,
+                                       const int32_t* bin_start, int n_tbins, double range_bin, int n_rbins,
+                                       double fill_value, void* sv_out, void* depth_out, void* mvbs_out, void* sum_out,
+                                       uint32_t* cnt_out, double* depth_stats_out, int dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(raw && depth_scale && depth_offset && depth_stats_out, "epa_sv_mvbs_fused_depth: NULL array argument");
+  EPA_CHECK_ARG(!depth_out || sv_out, "epa_sv_mvbs_fused_depth: depth_out needs sv_out");
+  // depth_stats_out[32] is the slot of the maximum's key while the kernel runs (decoded into [1]): 256 bytes from the
+  // other keys -- every workgroup sends atomics to these words, and two busy words in one cache line cost the launch
+  // 15 % (round 6: identical code, 2.37 against 2.05 ms per 0.8 G samples)
+  return fused_entry(raw, nullptr, nullptr, coef, C, P, S, cal_type, EPA_FLAG_GUARD_POS | EPA_FLAG_MASK_RANGE, bin_start,
+                     nullptr, n_tbins, range_bin, n_rbins, EPA_BIN_SKIPNA, fill_value, sv_out, nullptr, mvbs_out, sum_out,
+                     cnt_out, depth_stats_out + 32, depth_stats_out, dtype, stream, depth_scale, depth_offset, depth_out);
+}
+
 static int fused_entry(const float* raw, const int16_t* raw_i16, const int32_t* n_valid,
                        const double* coef, int C, int P, int S, int cal_type, unsigned cal_flags,
                        const int32_t* bin_start, const int32_t* ping_perm, int n_tbins,
                        double range_bin, int n_rbins, unsigned bin_flags, double fill_value,
                        void* sv_out, void* range_out, void* mvbs_out, void* sum_out,
                        uint32_t* cnt_out, double* range_max_out, double* range_stats_out, int dtype,
-                       epa_stream_t stream) {
+                       epa_stream_t stream, const double* dscale, const double* doffset, void* depth_out) {
   EPA_CHECK_ARG(coef && mvbs_out, "epa_sv_mvbs_fused: NULL array argument");
   EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_sv_mvbs_fused: C=%d P=%d S=%d", C, P, S);
   EPA_CHECK_ARG(cal_type == EPA_CAL_SV || cal_type == EPA_CAL_TS, "epa_sv_mvbs_fused: bad cal_type");
   if (int rc = check_bins("epa_sv_mvbs_fused", bin_start, n_tbins, range_bin, n_rbins)) return rc;
   ReduceArgs a{};
   a.raw = raw; a.raw_i16 = raw_i16; a.n_valid = n_valid;
+  a.dscale = dscale; a.doffset = doffset; a.depth_out = depth_out;
   a.coef = reinterpret_cast<const epa::CoefRow*>(coef);
   a.C = C; a.P = P; a.S = S;
   a.nspread = cal_type == EPA_CAL_SV ? 20.0 : 40.0;

@@ -245,6 +245,53 @@ struct NoiseCol {
   uint32_t acc_cnt;
 };
 
+// The workgroup's {min, max} pairs (already reduced over each wavefront; an empty pair has min > max) -> global keys.
+// The four wavefronts meet in LDS and ONE lane sends at most four atomics without a return value: the L2 serialises
+// the atomics of a 128-byte line, and one per wavefront and key (6.4 M per 0.8 G samples on the four keys' line) is
+// what a launch then waits for (round 6, measured on the fused kernel: fused_sv_mvbs.hip).  Every lane of the
+// workgroup must call it (two barriers).
+#ifndef EPA_WG_KEYS
+#define EPA_WG_KEYS 1
+#endif
+__device__ __forceinline__ void wg_minmax_keys(const double (&mm)[4], unsigned long long* keys, int lane) {
+#if !EPA_WG_KEYS  // (development knob: the round-5 form, one atomic per wavefront and key)
+  if (lane == 0) {
+    if (mm[0] <= mm[1]) {
+      atomicMin(keys + 0, ordered_key(mm[0]));
+      atomicMax(keys + 1, ordered_key(mm[1]));
+    }
+    if (mm[2] <= mm[3]) {
+      atomicMin(keys + 2, ordered_key(mm[2]));
+      atomicMax(keys + 3, ordered_key(mm[3]));
+    }
+  }
+  return;
+#endif
+  __shared__ unsigned long long wk[4];
+  if (threadIdx.x == 0) {
+    wk[0] = wk[2] = ~0ull;
+    wk[1] = wk[3] = 0ull;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    if (mm[0] <= mm[1]) {
+      atomicMin(&wk[0], ordered_key(mm[0]));
+      atomicMax(&wk[1], ordered_key(mm[1]));
+    }
+    if (mm[2] <= mm[3]) {
+      atomicMin(&wk[2], ordered_key(mm[2]));
+      atomicMax(&wk[3], ordered_key(mm[3]));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (wk[0] != ~0ull) atomicMin(keys + 0, wk[0]);
+    if (wk[1] != 0ull) atomicMax(keys + 1, wk[1]);
+    if (wk[2] != ~0ull) atomicMin(keys + 2, wk[2]);
+    if (wk[3] != 0ull) atomicMax(keys + 3, wk[3]);
+  }
+}
+
 template <typename T, bool WRITE_SV, bool RMAX>
 __global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 4 : 1) void sv_noise_fast_kernel(
     const float* __restrict__ raw, const epa::CoefRow* __restrict__ coef,
@@ -280,6 +327,10 @@ __global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 4 : 1) void sv_noise_
   unsigned nnan = 0u;
   __shared__ T plog[kPingLogs];
   __shared__ T col_nL[kChunk], col_lgs[kChunk];
+  // (the instance that also carries the echo_range statistics: fl(s * ra) of a column likewise -- eight registers, the
+  // difference between 32 B of scratch per lane and none; a scratch reload in the ping loop waits for the stores in flight)
+  constexpr bool SRA_LDS = RMAX && sizeof(T) == 8;
+  __shared__ double col_sra[SRA_LDS ? kChunk : 1];
   fill_ping_logs<T>(plog, rowp0 + pb, pe - pb, mt.log_tab);
   __syncthreads();
 
@@ -331,7 +382,8 @@ __global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 4 : 1) void sv_noise_
         for (int j = 0; j < VEC; ++j) {
           const double sj = (double)((j < 2 ? sA : sB) + (j & 1));
           col_nL[eA + (j < 2 ? 0 : 128) + (j & 1)] = nspread * log10_exact<T>((T)(sj - r.d));
-          col[j].sra = sj * r.ra;
+          if (SRA_LDS) col_sra[eA + (j < 2 ? 0 : 128) + (j & 1)] = sj * r.ra;
+          else col[j].sra = sj * r.ra;
         }
       }
       {
@@ -361,7 +413,7 @@ __global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 4 : 1) void sv_noise_
       auto one = [&](int j) -> T {
         double x;
         const int e = eA + (j < 2 ? 0 : 128) + (j & 1);
-        const ColBase<T> cb{col[j].sra, col_nL[e], col_lgs[e], (T)0};
+        const ColBase<T> cb{SRA_LDS ? col_sra[e] : col[j].sra, col_nL[e], col_lgs[e], (T)0};
         const T svj = calibrate<T>(cb, in[j], r, r0v, g_, a2, A0, nspread, x, mt.log_tab);
         if (RMAX) {  // as stored (T); x + 0 * raw is the range or NaN, and v_max_f64 / v_min_f64 skip the NaN
           const double xq = fma((double)in[j], 0.0, (double)(T)x);
@@ -393,15 +445,31 @@ __global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 4 : 1) void sv_noise_
     }
     if (g < nb) flush(g);  // the last, shorter ping block of the array (nothing left in the columns otherwise)
   }
-  if (RMAX) {
+  if (RMAX) {  // {max, min, NaN count} of the echo_range: per workgroup, one lane, no return value (see wg_minmax_keys)
+    __shared__ unsigned long long wr[2];
+    __shared__ unsigned wn;
+    if (threadIdx.x == 0) {
+      wr[0] = 0ull;
+      wr[1] = ~0ull;
+      wn = 0u;
+    }
+    __syncthreads();
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) xmax = fmax(xmax, __shfl_down(xmax, o, 64));
-    if (lane == 0 && xmax > -__builtin_inf()) atomicMax(a.rmax_key, ordered_key(xmax));
-    if (a.rstat) {  // (uniform) the rest of {nanmin, nanmax, NaN count} of the echo_range
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) xmin = fmin(xmin, __shfl_down(xmin, o, 64));  // (nnan is the wavefront's already)
-      if (lane == 0 && xmin < __builtin_inf()) atomicMin(a.rstat, ordered_key(xmin));
-      if (lane == 0 && nnan > 0u) atomicAdd(a.rstat + 1, (unsigned long long)nnan);
+    for (int o = 32; o > 0; o >>= 1) xmin = fmin(xmin, __shfl_down(xmin, o, 64));  // (nnan is the wavefront's already)
+    if (lane == 0) {
+      if (xmax > -__builtin_inf()) atomicMax(&wr[0], ordered_key(xmax));
+      if (xmin < __builtin_inf()) atomicMin(&wr[1], ordered_key(xmin));
+      if (nnan > 0u) atomicAdd(&wn, nnan);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (wr[0] != 0ull) atomicMax(a.rmax_key, wr[0]);
+      if (a.rstat) {  // the rest of {nanmin, nanmax, NaN count} of the echo_range
+        if (wr[1] != ~0ull) atomicMin(a.rstat, wr[1]);
+        if (wn > 0u) atomicAdd(a.rstat + 1, (unsigned long long)wn);
+      }
     }
   }
   // min over the range blocks of 10 log10(block mean) (clean/api.py:402-411), optional clamp (:418-422)
@@ -637,16 +705,7 @@ __global__ __launch_bounds__(epa::kBlock, 3) void sv_denoise_mvbs_fast_kernel(
       mm[2] = fmin(mm[2], __shfl_down(mm[2], o, 64));
       mm[3] = fmax(mm[3], __shfl_down(mm[3], o, 64));
     }
-    if (lane == 0) {
-      if (mm[0] <= mm[1]) {
-        atomicMin(a.mm_keys + 0, ordered_key(mm[0]));
-        atomicMax(a.mm_keys + 1, ordered_key(mm[1]));
-      }
-      if (mm[2] <= mm[3]) {
-        atomicMin(a.mm_keys + 2, ordered_key(mm[2]));
-        atomicMax(a.mm_keys + 3, ordered_key(mm[3]));
-      }
-    }
+    wg_minmax_keys(mm, a.mm_keys, lane);
   }
   if (extra) return;
   __syncthreads();
@@ -853,16 +912,7 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_uniform_kernel
       mm[2] = fmin(mm[2], __shfl_down(mm[2], o, 64));
       mm[3] = fmax(mm[3], __shfl_down(mm[3], o, 64));
     }
-    if (lane == 0) {
-      if (mm[0] <= mm[1]) {
-        atomicMin(a.mm_keys + 0, ordered_key(mm[0]));
-        atomicMax(a.mm_keys + 1, ordered_key(mm[1]));
-      }
-      if (mm[2] <= mm[3]) {
-        atomicMin(a.mm_keys + 2, ordered_key(mm[2]));
-        atomicMax(a.mm_keys + 3, ordered_key(mm[3]));
-      }
-    }
+    wg_minmax_keys(mm, a.mm_keys, lane);
   }
   __syncthreads();
   T* out = mvbs_out + cell0;
@@ -1154,16 +1204,7 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
       mm[2] = fmin(mm[2], __shfl_down(mm[2], o, 64));
       mm[3] = fmax(mm[3], __shfl_down(mm[3], o, 64));
     }
-    if (lane == 0) {
-      if (mm[0] <= mm[1]) {
-        atomicMin(a.mm_keys + 0, ordered_key(mm[0]));
-        atomicMax(a.mm_keys + 1, ordered_key(mm[1]));
-      }
-      if (mm[2] <= mm[3]) {
-        atomicMin(a.mm_keys + 2, ordered_key(mm[2]));
-        atomicMax(a.mm_keys + 3, ordered_key(mm[3]));
-      }
-    }
+    wg_minmax_keys(mm, a.mm_keys, lane);
   }
   __syncthreads();
   T* out = mvbs_out + cell0;

@@ -127,6 +127,22 @@ __device__ __forceinline__ double row_range(const CoefRow& r, int s) {
   return ((double)s * r.ra) * r.rb + r.r0;
 }
 
+// depth of a sample (consolidate/api.py:221: transducer_depth + orientation * echo_range * echo_range_scaling): the
+// product is rounded, then the sum -- NumPy's two operations, never one contracted fma -- in the array's own type, so
+// that the depth array, and whatever is binned on it without writing it, hold the reference's bits.
+// (contraction switched off for the two statements: hipcc's default -ffp-contract=fast turns even __dadd_rn(o, __dmul_rn(a, r))
+// into one v_fma_f64)
+__device__ __forceinline__ double depth_of(double scale, double offset, double range) {
+#pragma clang fp contract(off)
+  const double prod = scale * range;
+  return offset + prod;
+}
+__device__ __forceinline__ float depth_of(float scale, float offset, float range) {
+#pragma clang fp contract(off)
+  const float prod = scale * range;
+  return offset + prod;
+}
+
 }  // namespace epa
 
 // reduce_util.hip: {min, max, NaN count} partials (3 doubles per workgroup) -> out[3]

@@ -12,6 +12,7 @@
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "fast_math.h"
 #include "sample_math.h"
@@ -31,6 +32,11 @@ struct Args {
   unsigned long long* rstat;     // optional, with rmax_key: {min valid echo_range as a key, number of NaN echo_range values}
   int xcd_map;  // time bins dealt to the XCDs in contiguous eighths (epa::xcd_contiguous)
   int flagged_only;  // mvbs_of_sv_rows_kernel after the fixed-bin kernel: only the time bins that one left (kLeftToRows)
+  // binned on ``depth`` instead of the echo_range (consolidate/api.py:221 between compute_Sv and compute_MVBS):
+  // depth[c,p,s] = doffset[c,p] + dscale[c,p] * echo_range[c,p,s], [C*P] doubles each; NULL: binned on the echo_range
+  const double* dscale;
+  const double* doffset;
+  void* depth_out;  // optional [C*P*S] of T: the depth array written by the same pass (NaN where the raw sample is)
 };
 
 // order-preserving map double -> u64 (so that atomicMax on the key is a max on the double)
@@ -170,14 +176,24 @@ __device__ __forceinline__ T process_sample(Column<T>& c, float raw, const epa::
 // that is not clean (NaN padding, the first samples of a row, a NaN row) runs the SAME body with the general forms
 // patched in by wave-uniform branches: one instruction stream, the registers of one.  The Sv arithmetic is
 // process_sample's, operation for operation, on either side of the branches: the same bits.
-template <typename T, bool STATS, bool WRITE_SV>
+// DEPTH (1: bin on depth, 2: and write it): the coordinate that is binned and whose {min, max, NaN count} are taken is
+// depth = dof + dsc * echo_range, evaluated in T on the echo_range rounded to T -- the value the depth array holds
+// (epa::depth_of; the array is written only for DEPTH == 2) -- instead of the echo_range itself.
+template <typename T, bool STATS, bool WRITE_SV, int DEPTH>
 __device__ __forceinline__ void process_pair(Column<T>& c0, Column<T>& c1, float2 in, bool clean, const epa::CoefRow& r,
                                              double r0v, T g, T a2, T A0v, T nL0, T nL1, T nspread, double bin,
                                              double inv_bin, int n_rbins, const double* tab, T* lsum, uint32_t* lcnt,
                                              T* __restrict__ sv_dst, double& xmax, double& xmin, unsigned& nnan,
-                                             uint32_t n_clean, double& xfirst, double& xlast) {
-  const double x0 = fma(c0.sra, r.rb, r0v), x1 = fma(c1.sra, r.rb, r0v);  // echo_range = (s*ra)*rb [+0]
-  const double rtd0 = x0 - r.shift, rtd1 = x1 - r.shift;
+                                             uint32_t n_clean, double& xfirst, double& xlast, T dsc, T dof,
+                                             T* __restrict__ depth_dst, double sra0, double sra1) {
+  const double e0 = fma(sra0, r.rb, r0v), e1 = fma(sra1, r.rb, r0v);  // echo_range = (s*ra)*rb [+0]
+  const double rtd0 = e0 - r.shift, rtd1 = e1 - r.shift;
+  T d0 = (T)0, d1 = (T)0;
+  if (DEPTH) {
+    d0 = epa::depth_of(dsc, dof, (T)e0);
+    d1 = epa::depth_of(dsc, dof, (T)e1);
+  }
+  const double x0 = DEPTH ? (double)d0 : e0, x1 = DEPTH ? (double)d1 : e1;  // the binning coordinate
   const T rt0 = (T)rtd0, rt1 = (T)rtd1;
   T s10 = fma(g, (T)in.x, nL0), s11 = fma(g, (T)in.y, nL1);
   if (!clean) {  // (scalar) R' <= 0 guard, rounding residue of R - shift, {min, max, NaN count} per sample
@@ -193,9 +209,15 @@ __device__ __forceinline__ void process_pair(Column<T>& c0, Column<T>& c1, float
       const double xq0 = fma((double)in.x, 0.0, x0), xq1 = fma((double)in.y, 0.0, x1);
       xmax = vmax_num(vmax_num(xmax, xq0), xq1);
       xmin = vmin_num(vmin_num(xmin, xq0), xq1);
-      nnan += (unsigned)__builtin_popcountll(__ballot(in.x != in.x)) + (unsigned)__builtin_popcountll(__ballot(in.y != in.y));
+      // (a NaN coordinate: the raw sample's NaN, or a NaN coefficient / depth row)
+      nnan += (unsigned)__builtin_popcountll(__ballot(xq0 != xq0)) + (unsigned)__builtin_popcountll(__ballot(xq1 != xq1));
+    }
+    if (DEPTH == 2) {  // the depth array is NaN where the echo_range is: where the raw sample is
+      d0 = fma((T)in.x, (T)0, d0);
+      d1 = fma((T)in.y, (T)0, d1);
     }
   }
+  if (DEPTH == 2) epa::store_nt2(depth_dst, d0, d1);
   const T sv0 = s10 + fma(a2, rt0, A0v), sv1 = s11 + fma(a2, rt1, A0v);
   if (WRITE_SV) {
 #ifndef EPA_PLAIN_STORES  // streaming (nt) stores: +2 % at 4 G samples, Sv is never re-read here
@@ -295,12 +317,21 @@ struct PingLoad<int16_t> {
 #ifndef EPA_FUSED_LEAN  // development knob: 0 = every ping takes the general per-sample path (the round-4 kernel)
 #define EPA_FUSED_LEAN 1
 #endif
-template <typename T, typename RawT, bool WRITE_SV, bool RMAX>
+// a wave-uniform double, pinned to scalar registers
+__device__ __forceinline__ double uniform(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// (the exponent field of a double held in scalar registers: integer instructions only)
+__device__ __forceinline__ bool finite_bits(double v) { return (__double2hiint(v) & 0x7ff00000) != 0x7ff00000; }
+
+template <typename T, typename RawT, bool WRITE_SV, bool RMAX, int DEPTH>
 __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES > 4 ? EPA_FUSED_MIN_WAVES : 4) void fused_sv_mvbs_kernel(
     const RawT* __restrict__ raw, const int32_t* __restrict__ n_valid,
     const epa::CoefRow* __restrict__ coef,
     const int32_t* __restrict__ bin_start, T* __restrict__ sv_out, T* __restrict__ mvbs_out,
-    T* __restrict__ sum_out, uint32_t* __restrict__ cnt_out, Args a) {
+    T* __restrict__ sum_out, uint32_t* __restrict__ cnt_out, const double* __restrict__ dscale,
+    const double* __restrict__ doffset, Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* lsum = reinterpret_cast<T*>(smem);
   uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + a.cnt_off);
@@ -311,6 +342,18 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES > 4 ? EPA_FUSED_MI
   // the statistics have the registers to spare (measured round 5: 6.4-6.5 ms with the LDS reads, 6.0-6.3 without).
   constexpr bool NL_LDS = RMAX || sizeof(T) == 8;
   __shared__ T col_nL[NL_LDS ? kChunk : 1];
+  // ... and, for the variants that also carry the coordinate's {min, max, NaN count}, a column's fl(s * ra) likewise
+  // (eight more registers: round 6 found those variants at 128 VGPRs + 32 B of scratch per lane, and a scratch reload
+  // inside the ping loop waits for every store in flight: 2.12 instead of 1.94 ms per 0.8 G samples)
+  constexpr bool SRA_LDS = RMAX && sizeof(T) == 8;
+  __shared__ double col_sra[SRA_LDS ? kChunk : 1];
+  __shared__ unsigned long long wg_keys[2];  // RMAX: the workgroup's {max key, min key} and NaN count (see the end)
+  __shared__ unsigned wg_nnan;
+  if (RMAX && threadIdx.x == 0) {
+    wg_keys[0] = 0ull;
+    wg_keys[1] = ~0ull;
+    wg_nnan = 0u;
+  }
 
   const int c = blockIdx.y, tb = a.xcd_map ? epa::xcd_contiguous(blockIdx.x, a.n_tbins) : (int)blockIdx.x;
   const int S = a.S, n_rbins = a.n_rbins;
@@ -331,6 +374,10 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES > 4 ? EPA_FUSED_MI
   const RawT* __restrict__ raw_c = raw + (size_t)c * a.P * S;
   const int32_t* __restrict__ nv_c = n_valid ? n_valid + (size_t)c * a.P : nullptr;
   T* __restrict__ sv_c = WRITE_SV ? sv_out + (size_t)c * a.P * S : nullptr;
+  T* __restrict__ dp_c = DEPTH == 2 ? reinterpret_cast<T*>(a.depth_out) + (size_t)c * a.P * S : nullptr;
+  // (kernel parameters, not members of ``a``: read-only + restrict is what makes the per-ping reads scalar loads)
+  const double* __restrict__ dsc_c = DEPTH ? dscale + (size_t)c * a.P : nullptr;
+  const double* __restrict__ dof_c = DEPTH ? doffset + (size_t)c * a.P : nullptr;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double xmax = -__builtin_inf(), xmin = __builtin_inf();
   unsigned nnan = 0u;
@@ -360,15 +407,25 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES > 4 ? EPA_FUSED_MI
     const int s4 = chunk0 + wave * 256 + 4 * lane;  // (a source that loads quads: unused by the present ones)
     PingLoad<RawT> nxt;
     epa::CoefRow nxtR = rowp0[pb < pe ? pb : 0];
+    double nxtDs = 1.0, nxtDo = 0.0;  // (scalar) the ping's depth scale and offset
+    if (DEPTH) {
+      nxtDs = uniform(dsc_c[pb < pe ? pb : 0]);
+      nxtDo = uniform(dof_c[pb < pe ? pb : 0]);
+    }
     if (pb < pe) nxt.issue(raw_c + (size_t)pb * S, sA, sB, hasB, s4, S);
     for (int p = pb; p < pe; ++p) {
       const epa::CoefRow r = nxtR;
+      const double curDs = nxtDs, curDo = nxtDo;
       const size_t row_off = (size_t)p * S;
       const int nv = nv_c ? nv_c[p] : S;
       float2 inA, inB;
       nxt.resolve(inA, inB, sA, sB, nv, lane);
       if (p + 1 < pe) {
         nxtR = rowp0[p + 1];
+        if (DEPTH) {
+          nxtDs = uniform(dsc_c[p + 1]);
+          nxtDo = uniform(dof_c[p + 1]);
+        }
         nxt.issue(raw_c + row_off + S, sA, sB, hasB, s4, S);
       }
       if (!((__double_as_longlong(r.d) == dcur) & (__double_as_longlong(r.ra) == racur))) {  // uniform; once per column
@@ -380,7 +437,8 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES > 4 ? EPA_FUSED_MI
           const T nl = nspread * log10_slow<T>((T)(sj - r.d));
           if (NL_LDS) col_nL[eA + (j < 2 ? 0 : 128) + (j & 1)] = nl;  // (see col_nL)
           else col[j].nL = nl;
-          col[j].sra = sj * r.ra;
+          if (SRA_LDS) col_sra[eA + (j < 2 ? 0 : 128) + (j & 1)] = sj * r.ra;
+          else col[j].sra = sj * r.ra;
           fin = fin & ((j >= 2 && !hasB) | (fabs(nl) < (T)__builtin_inf()));
         }
         plain = __ballot(!fin) == 0ull;
@@ -395,25 +453,41 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES > 4 ? EPA_FUSED_MI
       bool clean = false;
 #if EPA_FUSED_LEAN
       {
-        const double xa = fma(col[0].sra, r.rb, r0v);
+        const double xa = fma(SRA_LDS ? col_sra[eA] : col[0].sra, r.rb, r0v);
         const bool bad = not_finite(inA.x) | not_finite(inA.y) | not_finite(inB.x) | not_finite(inB.y) |
                          !(xa - r.shift > 0.0);
-        const bool kpos = (__double2hiint(r.ra) > 0) & (__double2hiint(r.rb) > 0);  // (scalar) ra, rb > 0
+        // (scalar) ra, rb > 0, and the row's other coefficients are numbers: a NaN / inf gain, absorption or constant
+        // makes Sv NaN / inf with finite raw samples -- the general forms skip such values, the lean ones would add them
+        bool kpos = (__double2hiint(r.ra) > 0) & (__double2hiint(r.rb) > 0) & finite_bits(r.g) & finite_bits(r.A0) &
+                    finite_bits(r.alpha2);
+        if (DEPTH) kpos = kpos & finite_bits(curDs) & finite_bits(curDo);  // (a NaN depth row: counted per sample)
         clean = plain & kpos & (__ballot(bad) == 0ull);
       }
 #endif
+      const T dsc = (T)curDs, dof = (T)curDo;
       double xf, xl, xdummy;
-      process_pair<T, RMAX, WRITE_SV>(col[0], col[1], inA, clean, r, r0v, g, a2, A0, NL_LDS ? col_nL[eA] : col[0].nL,
-                                      NL_LDS ? col_nL[eA + 1] : col[1].nL, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt,
-                                      WRITE_SV ? sv_c + row_off + sA : nullptr, xmax, xmin, nnan, n_clean, xf, xl);
+      process_pair<T, RMAX, WRITE_SV, DEPTH>(col[0], col[1], inA, clean, r, r0v, g, a2, A0, NL_LDS ? col_nL[eA] : col[0].nL,
+                                             NL_LDS ? col_nL[eA + 1] : col[1].nL, nspread, bin, inv_bin, n_rbins, tab, lsum,
+                                             lcnt, WRITE_SV ? sv_c + row_off + sA : nullptr, xmax, xmin, nnan, n_clean, xf,
+                                             xl, dsc, dof, DEPTH == 2 ? dp_c + row_off + sA : nullptr,
+                                             SRA_LDS ? col_sra[eA] : col[0].sra, SRA_LDS ? col_sra[eA + 1] : col[1].sra);
       if (hasB)
-        process_pair<T, RMAX, WRITE_SV>(col[2], col[3], inB, clean, r, r0v, g, a2, A0, NL_LDS ? col_nL[eA + 128] : col[2].nL,
-                                        NL_LDS ? col_nL[eA + 129] : col[3].nL, nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt,
-                                        WRITE_SV ? sv_c + row_off + sB : nullptr, xmax, xmin, nnan, n_clean, xdummy, xl);
+        process_pair<T, RMAX, WRITE_SV, DEPTH>(col[2], col[3], inB, clean, r, r0v, g, a2, A0,
+                                               NL_LDS ? col_nL[eA + 128] : col[2].nL, NL_LDS ? col_nL[eA + 129] : col[3].nL,
+                                               nspread, bin, inv_bin, n_rbins, tab, lsum, lcnt,
+                                               WRITE_SV ? sv_c + row_off + sB : nullptr, xmax, xmin, nnan, n_clean, xdummy,
+                                               xl, dsc, dof, DEPTH == 2 ? dp_c + row_off + sB : nullptr,
+                                               SRA_LDS ? col_sra[eA + 128] : col[2].sra,
+                                               SRA_LDS ? col_sra[eA + 129] : col[3].sra);
       if (clean) {  // (scalar)
         if (RMAX) {  // no NaN among the wavefront's samples: the lane's smallest / largest range of the ping
-          xmin = vmin_num(xmin, xf);
-          xmax = vmax_num(xmax, xl);
+          if (DEPTH) {  // (depth falls with the sample number for an upward-looking transducer: either end is either)
+            xmin = vmin_num(vmin_num(xmin, xf), xl);
+            xmax = vmax_num(vmax_num(xmax, xf), xl);
+          } else {
+            xmin = vmin_num(xmin, xf);
+            xmax = vmax_num(xmax, xl);
+          }
         }
         ++n_clean;
       }
@@ -422,15 +496,30 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES > 4 ? EPA_FUSED_MI
     for (int j = 0; j < VEC; ++j) col[j].flush(lsum, lcnt, n_clean);
   }
   }
-  if (RMAX) {  // max valid echo_range seen by this workgroup -> one atomic per wave
+  if (RMAX) {
+    // {max, min, NaN count} of the binned coordinate seen by this workgroup: wavefront reduction, then the workgroup's
+    // four wavefronts meet in LDS, then ONE lane sends at most three atomics WITHOUT a return value -- nobody waits for
+    // them.  Measured round 6 (4 x 100 000 x 2000 fp64, ms per launch): one atomic per wavefront and key 1.96-2.12
+    // (2.5 with the three words in one 128-byte line: the L2 serialises a line's atomics); per workgroup, filtered by a
+    // read of the current keys 2.05 (the read is what a workgroup then waits for); per workgroup, unconditional 1.82 =
+    // the kernel without the statistics.  The words live in different 128-byte lines where the caller's layout allows.
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) xmax = fmax(xmax, __shfl_down(xmax, o, 64));
-    if (lane == 0 && xmax > -__builtin_inf()) atomicMax(a.rmax_key, ordered_key(xmax));
-    if (a.rstat) {  // (uniform) the rest of {nanmin, nanmax, NaN count}: what compute_MVBS asks of an echo_range array
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) xmin = fmin(xmin, __shfl_down(xmin, o, 64));  // (nnan is the wavefront's already)
-      if (lane == 0 && xmin < __builtin_inf()) atomicMin(a.rstat, ordered_key(xmin));
-      if (lane == 0 && nnan > 0u) atomicAdd(a.rstat + 1, (unsigned long long)nnan);
+    for (int o = 32; o > 0; o >>= 1) xmin = fmin(xmin, __shfl_down(xmin, o, 64));  // (nnan is the wavefront's already)
+    if (lane == 0) {
+      if (xmax > -__builtin_inf()) atomicMax(&wg_keys[0], ordered_key(xmax));
+      if (xmin < __builtin_inf()) atomicMin(&wg_keys[1], ordered_key(xmin));
+      if (nnan > 0u) atomicAdd(&wg_nnan, nnan);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned long long kmax = wg_keys[0], kmin = wg_keys[1];
+      if (kmax != 0ull) atomicMax(a.rmax_key, kmax);  // (key 0 = nothing seen)
+      if (a.rstat) {  // the rest of {nanmin, nanmax, NaN count}: what compute_MVBS asks of its range variable
+        if (kmin != ~0ull) atomicMin(a.rstat, kmin);  // (key ~0 = nothing seen)
+        if (wg_nnan > 0u) atomicAdd(a.rstat + 1, (unsigned long long)wg_nnan);
+      }
     }
   }
   if (extra) return;
@@ -456,22 +545,33 @@ int launch(Args& a, const RawT* raw, const int32_t* n_valid, const double* coef,
   a.tab_off = (unsigned)((lds_bytes + 15) & ~(size_t)15);
   lds_bytes = a.tab_off + epa::kMathTabBytes;
   a.xcd_map = epa::xcd_map_enabled() ? 1 : 0;
-#define EPA_FL(W, R)                                                                           \
+#define EPA_FL(W, R) EPA_FLD(W, R, 0)
+#define EPA_FLD(W, R, D)                                                                       \
   do {                                                                                         \
-    auto kern = fused_sv_mvbs_kernel<T, RawT, W, R>;                                           \
+    auto kern = fused_sv_mvbs_kernel<T, RawT, W, R, D>;                                        \
     if (lds_bytes > 64 * 1024)                                                                 \
       EPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
                                         hipFuncAttributeMaxDynamicSharedMemorySize,            \
                                         (int)lds_bytes));                                      \
     hipLaunchKernelGGL(kern, grid, dim3(epa::kBlock), lds_bytes, st, raw, n_valid,             \
                        reinterpret_cast<const epa::CoefRow*>(coef), bin_start, (T*)sv_out,     \
-                       (T*)mvbs_out, (T*)sum_out, cnt_out, a);                                 \
+                       (T*)mvbs_out, (T*)sum_out, cnt_out, a.dscale, a.doffset, a);            \
   } while (0)
-  if (a.rmax_key) {
+  if (a.dscale) {  // binned on depth (float samples, always with the statistics of the depth)
+    if constexpr (std::is_same<RawT, float>::value) {
+      if (a.depth_out) EPA_FLD(true, true, 2);
+      else if (sv_out) EPA_FLD(true, true, 1);
+      else EPA_FLD(false, true, 1);
+    } else {
+      epa::set_error("epa_sv_mvbs_fused_depth: float power samples only");
+      return EPA_EUNSUPPORTED;
+    }
+  } else if (a.rmax_key) {
     if (sv_out) EPA_FL(true, true); else EPA_FL(false, true);
   } else {
     if (sv_out) EPA_FL(true, false); else EPA_FL(false, false);
   }
+#undef EPA_FLD
 #undef EPA_FL
   return epa::check_launch("fused_sv_mvbs_kernel");
 }
@@ -891,8 +991,10 @@ int epa_fused_fast_path(const void* raw, int raw_is_i16, const int32_t* n_valid,
                         int n_rbins, unsigned bin_flags, double fill_value, void* sv_out,
                         void* mvbs_out, void* sum_out, uint32_t* cnt_out, int dtype,
                         size_t lds_bytes, unsigned cnt_off, unsigned long long* rmax_key,
-                        unsigned long long* rstat, hipStream_t st) {
+                        unsigned long long* rstat, const double* dscale, const double* doffset, void* depth_out,
+                        hipStream_t st) {
   epa_fused::Args a{};
+  a.dscale = dscale; a.doffset = doffset; a.depth_out = dscale ? depth_out : nullptr;
   a.rmax_key = rmax_key;
   a.rstat = rmax_key ? rstat : nullptr;
   a.P = P; a.S = S; a.n_tbins = n_tbins; a.n_rbins = n_rbins;

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(epa::kBlock) void affine_rows_kernel(const T* __res
     const T a = (T)scale[row], b = (T)offset[row];
     const T* xr = x + (size_t)row * S;
     T* orow = out + (size_t)row * S;
-    for (int s = threadIdx.x; s < S; s += blockDim.x) orow[s] = b + a * xr[s];
+    for (int s = threadIdx.x; s < S; s += blockDim.x) orow[s] = epa::depth_of(a, b, xr[s]);
   }
 }
 
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(epa::kBlock) void depth_rows_kernel(const T* __rest
         r = (T)epa::row_range(cr, s);
         if (mask_raw && !(mask_raw[base + s] == mask_raw[base + s])) r = epa::M<T>::nan();
       }
-      const T d = b + a * r;
+      const T d = epa::depth_of(a, b, r);
       orow[s] = d;
       if (part) {
         const double dd = (double)d;

@@ -348,6 +348,32 @@ def sv_mvbs_fused(raw, coef, bin_start, n_tbins, range_bin, n_rbins, *, cal_type
                 range_stats_filled=bool(_lib.lib.epa_last_range_stats_filled()) if want_range_stats else False)
 
 
+def sv_mvbs_fused_depth(raw, coef, depth_scale, depth_offset, bin_start, n_tbins, range_bin, n_rbins, *, cal_type="Sv",
+                        fill_value=float("nan"), dtype=torch.float64, want_sv=True, want_depth=False,
+                        want_partials=False, sv_out=None, mvbs_out=None):
+    """K1+K5 binned on depth = depth_offset[c,p] + depth_scale[c,p] * echo_range (add_depth fused into the pass) ->
+    dict(Sv, depth, MVBS, sum, cnt, range_stats = f64 device tensor {nanmin, nanmax, NaN count} of the depth array).
+    Raises EpaError (EPA_EUNSUPPORTED) for a configuration only the generic kernels serve."""
+    C, P, S = raw.shape
+    dev = raw.device
+    if want_sv and sv_out is None:
+        sv_out = torch.empty((C, P, S), dtype=dtype, device=dev)
+    depth_out = torch.empty((C, P, S), dtype=dtype, device=dev) if want_depth else None
+    if mvbs_out is None:
+        mvbs_out = torch.empty((C, n_tbins, n_rbins), dtype=dtype, device=dev)
+    ssum = cnt = None
+    if want_partials:
+        ssum = torch.empty((C, n_tbins, n_rbins), dtype=dtype, device=dev)
+        cnt = torch.empty((C, n_tbins, n_rbins), dtype=torch.int32, device=dev)
+    rstats = torch.empty(64, dtype=torch.float64, device=dev)
+    call("epa_sv_mvbs_fused_depth", _p(raw), _p(coef), _p(depth_scale), _p(depth_offset), C, P, S,
+         _lib.CAL_SV if cal_type == "Sv" else _lib.CAL_TS, _p(bin_start), int(n_tbins), float(range_bin), int(n_rbins),
+         float(fill_value), _p(sv_out) if want_sv else None, _p(depth_out), _p(mvbs_out), _p(ssum), _p(cnt), _p(rstats),
+         _DT[dtype], _stream())
+    return dict(Sv=sv_out if want_sv else None, depth=depth_out, MVBS=mvbs_out, sum=ssum, cnt=cnt,
+                range_stats=rstats[:3], range_stats_filled=True)
+
+
 def sv_mvbs_fused_i16(raw_i16, n_valid, coef, bin_start, n_tbins, range_bin, n_rbins, *, cal_type="Sv",
                       fill_value=float("nan"), dtype=torch.float64, want_sv=True, want_partials=False,
                       sv_out=None, mvbs_out=None, want_range_max=False):

@@ -97,7 +97,7 @@ class LazyDeviceArray(DeviceArray):
     ``DeviceArray(lazy.tensor)`` to cut that tie."""
 
     __slots__ = ("_make", "_shape", "_tdtype", "_device", "_tensor", "_rows", "_mask", "_made_version", "source",
-                 "_stats_hook", "reach_bound", "__weakref__")
+                 "_stats_hook", "reach_bound", "_affine", "__weakref__")
 
     def __init__(self, shape, dtype, device, make, stats=None, rows=None, nan_where=None, source=None):
         self._make, self._shape, self._tdtype, self._device = make, tuple(int(n) for n in shape), dtype, device
@@ -114,6 +114,10 @@ class LazyDeviceArray(DeviceArray):
         # an upper bound of every value of the array known on the HOST (an echo_range: how far can any row reach?), or
         # None: a consumer sizes its launch from it and reads the exact statistics later (stats_async)
         self.reach_bound = None
+        # (base lazy array, scale (C, P) f64 device tensor, offset likewise): this array is offset + scale * base, row by
+        # row (consolidate.add_depth on a lazy echo_range) -- a kernel that evaluates the base from its coefficient rows
+        # evaluates this one next to it (compute_MVBS(range_var="depth")); see affine_of()
+        self._affine = None
         # the array is NaN exactly where this device tensor of the same shape is (the raw power samples): kernels that
         # need the NaN pattern as well as the values read it next to the rows
         self._mask = (nan_where, nan_where._version) if nan_where is not None else None
@@ -161,6 +165,19 @@ class LazyDeviceArray(DeviceArray):
         if self._tensor is not None and self._made_version != self._tensor._version:
             return None
         return self._rows
+
+    def set_affine(self, base, scale, offset):
+        self._affine = (base, scale, offset, scale._version, offset._version)
+
+    def affine_of(self):
+        """(base, scale, offset) while this array still is ``offset + scale * base`` row by row and the base still is the
+        function of its coefficient rows it was created as; None otherwise."""
+        if self._affine is None or (self._tensor is not None and self._made_version != self._tensor._version):
+            return None
+        base, scale, offset, vs, vo = self._affine
+        if scale._version != vs or offset._version != vo or base.coef_rows() is None:
+            return None
+        return base, scale, offset
 
     def stats_async(self):
         """The {nanmin, nanmax, NaN count} as an object whose ``.tolist()`` does not wait for kernels launched after

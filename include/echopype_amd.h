@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define EPA_VERSION 102 /* 0.1.2: ping_phase / edge rows on the two-pass chain (ping shards); epa_source_digest */
+#define EPA_VERSION 103 /* 0.1.3: epa_sv_mvbs_fused_depth */
 
 typedef void* epa_stream_t;
 
@@ -202,6 +202,25 @@ int epa_sv_mvbs_fused_i16(const int16_t* raw, const int32_t* n_valid, const doub
                           int S, int cal_type, const int32_t* bin_start, int n_tbins, double range_bin,
                           int n_rbins, double fill_value, void* sv_out, void* mvbs_out, void* sum_out,
                           uint32_t* cnt_out, double* range_max_out, int dtype, epa_stream_t stream);
+
+/* The same pass binned on ``depth`` -- consolidate.add_depth between compute_Sv and compute_MVBS(range_var="depth")
+ * (SURVEY 8f "next" row 1).  Replaces consolidate/api.py:221 (depth = transducer_depth + orientation * echo_range *
+ * echo_range_scaling: one multiplication and one addition per sample, each rounded, in dtype) fused into K1+K5, so the
+ * three reference calls cost the 12 B/sample of the two: the depth array is an affine function of the coefficient
+ * rows and is written only when asked for (depth_out, +8 B/sample).
+ *   depth_scale, depth_offset : f64 [C*P] -- orientation * echo_range_scaling and transducer_depth per (channel, ping)
+ *   depth_out       : [C*P*S] of dtype or NULL (needs sv_out); NaN where the raw sample is, like the echo_range
+ *   depth_stats_out : f64 [64], 128-byte aligned: {nanmin, nanmax, NaN count} of the depth array in slots 0..2 (the rest
+ *                     is scratch) -- what sizes the range grid (commongrid/api.py:108-115): call with a conservative
+ *                     n_rbins, then trim
+ * Default configuration only (R' <= 0 guard, echo_range masked by NaN input, skipna, left-closed bins, sorted pings,
+ * S % 4 == 0, grid within LDS): EPA_EUNSUPPORTED otherwise.  Other arguments as epa_sv_mvbs_fused.
+ */
+int epa_sv_mvbs_fused_depth(const float* raw, const double* coef, const double* depth_scale,
+                            const double* depth_offset, int C, int P, int S, int cal_type, const int32_t* bin_start,
+                            int n_tbins, double range_bin, int n_rbins, double fill_value, void* sv_out,
+                            void* depth_out, void* mvbs_out, void* sum_out, uint32_t* cnt_out, double* depth_stats_out,
+                            int dtype, epa_stream_t stream);
 
 /* ---- K5: compute_MVBS on an existing Sv dataset -----------------------------------------------------------
  * Replaces commongrid/utils.py:504-628 (+ :92).  sv: [C*P*S] of dtype.  Range coordinate either
