@@ -153,7 +153,7 @@ def _check_source_digest():
     want, got = b.source_digest(), lib.epa_source_digest().decode()
     if want != got:
         raise ImportError(f"{LIB_PATH} was built from other sources (digest {got}, the tree has {want}): "
-                          "rebuild it with `python echopype_amd/build.py`")
+                          "rebuild it with `python echopype_amd/build.py` (`--force` recompiles every translation unit)")
 
 
 _check_source_digest()

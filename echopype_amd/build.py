@@ -67,7 +67,9 @@ def build_library(force=False, verbose=True):
     jobs = []
     objs = []
     digest = source_digest()
-    stamp = os.path.join(OBJDIR, "source_digest.txt")
+    # the digest runtime.o was compiled with, written next to it when it is compiled (the directory is not tracked: a
+    # checkout that changes a source cannot bring a matching stamp along and leave a stale runtime.o behind)
+    stamp = os.path.join(OBJDIR, "runtime.o.digest")
     old = open(stamp).read().strip() if os.path.exists(stamp) else ""
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
@@ -91,10 +93,11 @@ def build_library(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
+    if any("runtime.hip" in " ".join(j) for j in jobs):
+        with open(stamp, "w") as f:
+            f.write(digest + "\n")
     if jobs or force or _stale(LIBPATH, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIBPATH])
-    with open(stamp, "w") as f:
-        f.write(digest + "\n")
     return LIBPATH
 
 

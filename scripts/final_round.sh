@@ -21,7 +21,7 @@ find $O/kt -name "*kernel_trace.csv" -delete
 python scripts/perf_api_resident.py > $O/api_resident.txt 2>&1
 python scripts/perf_api_two_calls.py 2>&1 | grep -v "^$" | cut -c1-160 > $O/api_two_calls.txt
 python scripts/perf_masks.py > $O/masks_probe.txt 2>&1
-(python scripts/perf_cw.py 2>&1 | grep -v amdgpu.ids; echo "== scripts/probes/hbm_ek80_probe.hip"; [ -x echopype_amd/lib/hbm_ek80_probe ] && echopype_amd/lib/hbm_ek80_probe) > $O/cw_probe.txt 2>&1
+(python scripts/perf_cw.py 2>&1 | grep -v amdgpu.ids; echo "== scripts/probes/hbm_ek80_probe.hip"; [ -x scripts/probes/bin/hbm_ek80_probe ] && scripts/probes/bin/hbm_ek80_probe) > $O/cw_probe.txt 2>&1
 python scripts/pmc_summary.py $O/fetch_cfg2 > $O/pmc_traffic_a.csv 2>/dev/null
 for wl in cfg2 cfg3 cfg4; do for n in fetch write; do python scripts/pmc_summary.py $O/${n}_$wl kernel | grep -v "^kernel," | sed "s/^/$wl,/" ; done; done > $O/pmc_traffic.csv
 find $O -name "*counter_collection.csv" -delete; find $O -name "*kernel_trace.csv" -delete
