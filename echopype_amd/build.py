@@ -26,7 +26,7 @@ SOURCES = ["runtime.hip", "power_coef.hip", "sv_power.hip", "block_reduce.hip", 
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))
 EXTRA = os.environ.get("EPA_EXTRA_FLAGS", "").split()
 FLAGS = [*EXTRA, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-         "-Wall", "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}"]
+         "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 
 def source_digest():
