@@ -148,18 +148,27 @@ def _denoise_deferred_sv(ds_Sv, ping_num, range_sample_num, nmax, snr, shard=Non
     file's first ping (``ping_phase``); pass 1 also leaves the raw (sum, count) rows of the shard's first / last block,
     and a block cut by a shard edge gets the mean over ALL its pings (clean/api.py:402-411) through one all-reduce in
     HBM (sharding.merge_noise_edges) before pass 2 reads the noise.  Whether the route is taken must not depend on the
-    rank (the collectives that follow differ): the shards of one file agree in everything the test below looks at but
-    the kernel's verdict, which is put to a vote."""
+    rank (the collectives that follow differ): it is put to ONE vote -- a rank that cannot take it for a rank-local reason
+    (its Sv already read, a kernel that declines) votes against, and then every rank takes the plain route."""
     from .. import _lib
 
     sv_da, rng_da = ds_Sv["Sv"], ds_Sv["echo_range"] if "echo_range" in ds_Sv else None
     d = sv_da.data
     src = d.source if isinstance(d, LazyDeviceArray) and not d.materialized else None
     dims = ("channel", "ping_time", "range_sample")
+    ctx = None
+    if shard is not None:
+        from .. import sharding
+
+        ctx = shard[2] if shard[2] is not None else sharding.ShardContext(shard[1])
     if src is None or isinstance(src, DenoiseSource) or rng_da is None or src.cal_type != "Sv" \
             or rng_da.data is not src.echo_range \
             or tuple(sv_da.dims) != dims or tuple(rng_da.dims) != dims \
             or src.echo_range.coef_rows() is not src.coef or not src.intact():
+        # (rank-local state -- this rank's Sv already read, its raw samples written to: the other ranks of the file may be
+        #  on their way into the vote below, and this one must cast its own before it takes the plain route)
+        if ctx is not None:
+            ctx.agree(True)
         return None
     C, P, S = d.shape
     a2 = _alpha2(ds_Sv, dims, C, P)
@@ -175,9 +184,6 @@ def _denoise_deferred_sv(ds_Sv, ping_num, range_sample_num, nmax, snr, shard=Non
     # (epa_last_range_stats_filled): nothing waits for pass 1
     declined = out is None or not _lib.lib.epa_last_range_stats_filled()
     if shard is not None:
-        from .. import sharding
-
-        ctx = shard[2] if shard[2] is not None else sharding.ShardContext(shard[1])
         declined = ctx.agree(declined)  # (every rank takes the plain route if any has to)
     if declined:
         return None

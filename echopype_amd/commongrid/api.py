@@ -83,21 +83,58 @@ def compute_MVBS(ds_Sv, range_var="echo_range", range_bin="20m", ping_time_bin="
     if not isinstance(ping_time_bin, str):
         raise TypeError("ping_time_bin must be a string")
 
+    hint = None
     if skipna and closed == "left":
-        # Sv still deferred by compute_Sv: written by THIS pass over the raw samples, next to the bins
-        # (on a ping shard, too: the grid is the whole dataset's, cut bins are exchanged in HBM -- see _shard_grid)
-        done = _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max, _shard)
-        if done is None:  # ... or the Sv_corrected remove_background_noise deferred: its pass 2 bins as well
-            done = _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max, _shard)
+        # Sv still deferred by compute_Sv: written by THIS pass over the raw samples, next to the bins ...
+        # ... or the Sv_corrected remove_background_noise deferred: its pass 2 bins as well
+        if _shard is None:
+            done = _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max)
+            if done is None:
+                done = _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max)
+        else:  # a ping shard: the grid is the whole dataset's, cut bins are exchanged in HBM; the route is voted on
+            done, hint = _sharded_deferred(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max, _shard)
         if done is not None:
             return done
-    return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, skipna, fill_value, closed, range_var_max, _shard)
+    return _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, skipna, fill_value, closed, range_var_max, _shard,
+                       grid_hint=hint)
+
+
+def _sharded_deferred(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max, _shard):
+    """One rank's ping shard: which route the call takes is decided TOGETHER.  Whether a rank could take a deferred route
+    depends on rank-local state (its Sv already read or replaced, its pings unsorted, its raw samples written to ...), and
+    the routes run different collectives -- so every rank names the route it could take (1: Sv deferred by compute_Sv,
+    2: Sv_corrected deferred by remove_background_noise, 0: neither) in the call's FIRST control message, the one that
+    also carries the time grid and the range cap of the whole dataset (sharding.MVBSShard.grid), and a deferred route
+    runs only if all ranks named it.  Returns (the MVBS dataset or None, the time grid for the plain route: it does not
+    ask for it again)."""
+    from .utils import timedelta_ns
+
+    args = (ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max, _shard)
+    route, fn, prep = 0, None, None
+    for rid, f in ((1, _mvbs_of_deferred_sv), (2, _mvbs_of_deferred_clean)):
+        prep = f(*args, _grid="probe")
+        if prep is not None:
+            route, fn = rid, f
+            break
+    if route:
+        ns, dt, r_cap = prep
+    else:  # (unsorted pings, NaT, an empty shard: the message takes them as they are)
+        ns = np.asarray(ds_Sv["ping_time"].values).astype("datetime64[ns]", copy=False).view(np.int64)
+        dt, r_cap = timedelta_ns(ping_time_bin), float("nan")
+    reach = r_cap if (route and range_var_max is None) else float("nan")
+    e0g, n_glob, first_bin, last_bin, g_cap, agreed = _shard.grid(ns, dt, "left", reach, sorted_valid=bool(route), route=route)
+    hint = (e0g, n_glob, first_bin, last_bin)
+    if not route or agreed != route:
+        return None, hint
+    grid = (e0g + first_bin * dt, last_bin - first_bin + 1, first_bin, last_bin, g_cap if range_var_max is None else r_cap)
+    return fn(*args, _grid=grid), hint
 
 
 def _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, skipna, fill_value, closed, range_var_max, _shard,
-                allow_defer=True):
+                allow_defer=True, grid_hint=None):
     """The binning of an existing Sv array (arguments validated by compute_MVBS).  ``allow_defer=False``: the dataset is
-    assembled before the call returns (the fallback of the deferred routes' own assembly)."""
+    assembled before the call returns (the fallback of the deferred routes' own assembly).  ``grid_hint``: the time grid
+    of the whole dataset, when the call's route vote has fetched it already (_sharded_deferred)."""
     sv_da = ds_Sv["Sv"]
     order = tuple(sv_da.dims)
     dim_0 = order[0]
@@ -140,7 +177,7 @@ def _mvbs_plain(ds_Sv, range_var, range_bin_m, ping_time_bin, skipna, fill_value
     ns = ping_time.astype(np.int64)
     first_bin = 0
     if _shard is not None:  # day origin of the whole dataset; this shard covers global bins first_bin .. last_bin
-        e0, _, first_bin, last_bin = _shard.time_grid(ns, dt, closed)
+        e0, _, first_bin, last_bin = grid_hint if grid_hint is not None else _shard.time_grid(ns, dt, closed)
         e0, n_t = e0 + first_bin * dt, last_bin - first_bin + 1
     perm = None
     # unsorted pings: sort once on the host, kernels follow the permutation.  NaT is INT64_MIN: the stable sort puts
@@ -218,15 +255,6 @@ def _mvbs_of_array_without_waiting(ds_Sv, sv_t, rows, range_var, range_bin_m, pi
     return DeferredDataset(build)
 
 
-def _shard_grid(_shard, ns, dt, r_cap, range_var_max):
-    """One rank's ping shard: the time grid and the range cap of the WHOLE dataset in ONE control message
-    (sharding.MVBSShard.grid).  Returns (left edge of this shard's first bin, number of its bins, global index of its
-    first / last bin, the range cap to launch on)."""
-    e0, _, first_bin, last_bin, g_cap = _shard.grid(ns, dt, "left", r_cap if range_var_max is None else float("nan"),
-                                                    sorted_valid=True)  # (the deferred routes serve sorted, valid pings only)
-    return e0 + first_bin * dt, last_bin - first_bin + 1, first_bin, last_bin, (g_cap if range_var_max is None else r_cap)
-
-
 def _shard_assemble(ds_Sv, mv_full, n_cap, rmax, r_cap, range_var_max, n_nan_range, ping_time, e0, dt, n_t, range_var,
                     range_bin_m, ping_time_bin):
     """The deferred assembly on a ping shard: ``rmax`` = nanmax(range) over ALL shards (all-reduced in HBM).  No
@@ -246,7 +274,7 @@ def _shard_assemble(ds_Sv, mv_full, n_cap, rmax, r_cap, range_var_max, n_nan_ran
                           ping_time_bin, "left")
 
 
-def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max, _shard=None):
+def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max, _shard=None, _grid=None):
     """``compute_Sv`` on power samples leaves Sv deferred (``LazyDeviceArray`` with a ``source``); binned right after --
     the usual sequence -- one pass over the raw samples (``epa_sv_mvbs_fused``) writes that Sv array AND the bins: the two
     reference calls cost 12 B/sample instead of 12 + 8.  Returns the MVBS dataset, or None when the plain route has to
@@ -294,8 +322,10 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
             reach = torch.fmax(depth[1] + depth[0] * reach, depth[1] + depth[0] * coef[..., _lib.CF_R0]) * (1 + 1e-6)
         r_cap = float(torch.nan_to_num(reach, nan=float("-inf")).max().item())
     first_bin = last_bin = 0
-    if _shard is not None:  # (every rank of the dataset gets here or none does: the tests above look at nothing rank-local)
-        e0, n_t, first_bin, last_bin, r_cap = _shard_grid(_shard, ns, dt, r_cap, range_var_max)
+    if _shard is not None:
+        if isinstance(_grid, str):  # "probe": this rank could take the route (_sharded_deferred puts it to the vote)
+            return ns, dt, r_cap
+        e0, n_t, first_bin, last_bin, r_cap = _grid  # (the whole dataset's: the same on every rank)
     n_cap = len(np.arange(0, r_cap + range_bin_m, range_bin_m)) - 1 if np.isfinite(r_cap) else 0
     if n_cap < 1:
         return None
@@ -368,7 +398,7 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
     return DeferredDataset(build) if defer_mvbs_enabled() else build()
 
 
-def _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max, _shard=None):
+def _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_value, range_var_max, _shard=None, _grid=None):
     """The chain as the reference's user writes it -- ``compute_Sv``, ``remove_background_noise``, then
     ``compute_MVBS`` of the dataset with ``Sv := Sv_corrected`` -- arrives here with an Sv that
     ``remove_background_noise`` left deferred (``clean.api.DenoiseSource``: pass 1 has run).  Pass 2 runs NOW, on the
@@ -404,9 +434,11 @@ def _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_v
         r_cap = float(reach.max().item())
     first_bin = last_bin = 0
     if _shard is not None:
-        if src.global_rmax is None:  # (pass 1 did not run as a shard's: the plain route, on every rank alike)
+        if src.global_rmax is None:  # (pass 1 did not run as a shard's: the plain route -- by the vote, if on this rank only)
             return None
-        e0, n_t, first_bin, last_bin, r_cap = _shard_grid(_shard, ns, dt, r_cap, range_var_max)
+        if isinstance(_grid, str):  # "probe": see _mvbs_of_deferred_sv
+            return ns, dt, r_cap
+        e0, n_t, first_bin, last_bin, r_cap = _grid
     n_cap = len(np.arange(0, r_cap + range_bin_m, range_bin_m)) - 1 if np.isfinite(r_cap) else 0
     if n_cap < 1:
         return None

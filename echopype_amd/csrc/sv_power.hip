@@ -349,8 +349,10 @@ int launch(const float* raw, const double* coef, int C, int P, int S, int cal_ty
         dkeys = reinterpret_cast<unsigned long long*>(scratch);
         table = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(scratch) + kbytes);
         hipLaunchKernelGGL(d_keys_init_kernel, dim3(1), dim3(64), 0, st, dkeys, C);
+        if (int rc = epa::check_launch("d_keys_init_kernel")) { (void)hipFreeAsync(scratch, st); return rc; }
         hipLaunchKernelGGL(d_span_kernel, dim3((unsigned)((P + 4 * epa::kBlock - 1) / (4 * epa::kBlock) < 256 ? (P + 4 * epa::kBlock - 1) / (4 * epa::kBlock) : 256), (unsigned)C),
                            dim3(epa::kBlock), 0, st, cf, P, dkeys);
+        if (int rc = epa::check_launch("d_span_kernel")) { (void)hipFreeAsync(scratch, st); return rc; }
         hipLaunchKernelGGL((nl_table_kernel<T>), dim3((unsigned)((S + epa::kBlock - 1) / epa::kBlock), (unsigned)C),
                            dim3(epa::kBlock), 0, st, dkeys, S, nspread, table);
         if (int rc = epa::check_launch("nl_table_kernel")) { (void)hipFreeAsync(scratch, st); return rc; }
@@ -359,7 +361,10 @@ int launch(const float* raw, const double* coef, int C, int P, int S, int cal_ty
     if (sizeof(T) == 4 || scratch) {
       if (stats_out) {
         hipLaunchKernelGGL(piece_keys_init_kernel, dim3(1), dim3(epa::kBlock), 0, st, keys);
-        if (int rc = epa::check_launch("piece_keys_init_kernel")) return rc;
+        if (int rc = epa::check_launch("piece_keys_init_kernel")) {
+          if (scratch) (void)hipFreeAsync(scratch, st);
+          return rc;
+        }
       }
 #define EPA_PIECE(R, ST)                                                                                                 \
   hipLaunchKernelGGL((sv_power_piece_kernel<T, R, ST>), pgrid, dim3(epa::kBlock), 0, st, raw, cf, S, P, chunks_per_row, \

@@ -129,11 +129,14 @@ def global_time_grid(local_ping_ns, dt_ns, group=None):
     return e0, int((last - e0) // dt_ns + 1)
 
 
-def global_grid(local_ping_ns, dt_ns, reach, group=None, sorted_valid=False):
+def global_grid(local_ping_ns, dt_ns, reach, group=None, sorted_valid=False, route=None):
     """``global_time_grid`` and ``global_max`` of a non-negative number in ONE message: all-reduce MIN of
     [first timestamp, -last timestamp, -bits(reach)] (the IEEE bit pattern of a non-negative double orders like the
     number).  Returns (first_edge, n_bins_global, global reach; NaN when no rank has one).  ``sorted_valid``: the
-    caller has checked that the timestamps are sorted and hold no NaT -- the ends are the extremes (no O(P) pass)."""
+    caller has checked that the timestamps are sorted and hold no NaT -- the ends are the extremes (no O(P) pass).
+    ``route`` (a small non-negative int, or None): the message doubles as a vote on which route the call takes -- what
+    each rank could take is decided by rank-local state (is its Sv still deferred? are its pings sorted?), and the
+    routes run different collectives; a fourth value comes back, the route every rank named, or 0 when they differ."""
     t = np.asarray(local_ping_ns, dtype=np.int64)
     if sorted_valid and t.size:
         lo, hi = int(t[0]), int(t[-1])
@@ -143,13 +146,17 @@ def global_grid(local_ping_ns, dt_ns, reach, group=None, sorted_valid=False):
         hi = int(t.max()) if t.size else np.iinfo(np.int64).min + 1
     r = float(reach)
     rbits = int(np.float64(r).view(np.int64)) if (r == r and r >= 0.0 and r != float("inf")) else -1
-    first, neg_last, neg_rbits = _host_allreduce([lo, -hi, -rbits], dist.ReduceOp.MIN, group)
+    msg = [lo, -hi, -rbits] + ([int(route), -int(route)] if route is not None else [])
+    got = _host_allreduce(msg, dist.ReduceOp.MIN, group)
+    first, neg_last, neg_rbits = got[:3]
     last = -neg_last
     day = 86400 * 10**9
     origin = (first // day) * day
     e0 = origin + ((first - origin) // dt_ns) * dt_ns
     gr = float(np.int64(-neg_rbits).view(np.float64)) if -neg_rbits >= 0 else float("nan")
-    return e0, int((last - e0) // dt_ns + 1), gr
+    if route is None:
+        return e0, int((last - e0) // dt_ns + 1), gr
+    return e0, int((last - e0) // dt_ns + 1), gr, (int(got[3]) if got[3] == -got[4] else 0)
 
 
 def global_max(value, group=None):
@@ -456,11 +463,13 @@ class MVBSShard(ShardContext):
         first, last = local_bin_span(ns, e0, dt, closed)
         return e0, n_glob, first, last
 
-    def grid(self, ns, dt, closed, reach, sorted_valid=False):
-        """time_grid + range_max(reach) in one control message (reach >= 0 or NaN)."""
-        e0, n_glob, gr = global_grid(ns, dt, reach, self.group, sorted_valid=sorted_valid)
+    def grid(self, ns, dt, closed, reach, sorted_valid=False, route=None):
+        """time_grid + range_max(reach) in one control message (reach >= 0 or NaN); with ``route`` also the vote on
+        the route of the call (global_grid): a sixth value, the agreed route (0: the ranks differ)."""
+        got = global_grid(ns, dt, reach, self.group, sorted_valid=sorted_valid, route=route)
+        e0, n_glob, gr = got[:3]
         first, last = local_bin_span(ns, e0, dt, closed, sorted_valid=sorted_valid)
-        return e0, n_glob, first, last, gr
+        return (e0, n_glob, first, last, gr) + ((got[3],) if route is not None else ())
 
     def range_max(self, hi):
         return global_max(hi, self.group)

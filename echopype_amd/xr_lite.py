@@ -639,8 +639,11 @@ class DeferredDataset(Dataset):
                 raise d["_error"]
             try:
                 d["_ds"] = build()
-            except BaseException as e:
+            except Exception as e:  # kept: every later access raises the same error
                 d["_error"] = e
+                raise
+            except BaseException:  # an interrupt is not the assembly's verdict: the next access tries again
+                d["_build"] = build
                 raise
         return d["_ds"]
 

@@ -252,3 +252,45 @@ def test_depth_written_by_the_binning_pass_on_request(ep, monkeypatch):
     np.testing.assert_array_equal(ds["Sv"].values, ref["Sv"].values)
     np.testing.assert_allclose(mv["Sv"].values, mv0["Sv"].values, rtol=1e-12, atol=1e-12)
     assert ds["depth"].data.cached_stats() == ref["depth"].data.cached_stats()
+
+
+@pytest.mark.parametrize("depth", [False, True])
+def test_a_ping_with_a_nan_coefficient_is_skipped_not_added(ep, depth):
+    """Finite raw samples under a NaN gain: Sv of that ping is NaN, the nanmean skips it (commongrid/utils.py:614-627) --
+    a time bin that also holds valid pings keeps the mean of those, a bin of such pings only is empty.  (The fused
+    kernel's lean path must not take such a ping: ADVICE round 5.)"""
+    import torch
+    from echopype_amd import _lib, ops
+
+    d = _case(ep, C=2, P=120, S=1000, ss_every=1000)
+    d["backscatter_r"][:] = np.where(np.isnan(d["backscatter_r"]), np.float32(-70.0), d["backscatter_r"])  # every sample finite
+    ed = ep.echodata.from_ek60_arrays(d)
+    cal = ep.calibrate.api.CALIBRATOR["EK60"](ed, None, None, None, dtype="float64")
+    raw, coef, flags, _ = cal._power_inputs("Sv")
+    coef = coef.clone()
+    coef[0, 7, _lib.CF_G] = float("nan")          # one ping inside a bin of valid pings
+    coef[1, 40:60, _lib.CF_A0] = float("inf")     # a whole time bin (20 pings of 1 s)
+    C, P, S = raw.shape
+    ns = d["ping_time"].astype("datetime64[ns]").astype(np.int64)
+    e0, dt = int(ns[0]), 20 * 10**9
+    n_t = int((ns[-1] - e0) // dt) + 1
+    bs = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t)
+    one = torch.ones((C, P), dtype=torch.float64, device="cuda")
+    zero = torch.zeros((C, P), dtype=torch.float64, device="cuda")
+    with _lib.launch_trace() as tr:
+        if depth:
+            res = ops.sv_mvbs_fused_depth(raw, coef, one, zero, bs, n_t, 5.0, 60)
+        else:
+            res = ops.sv_mvbs_fused(raw, coef, bs, n_t, 5.0, 60, want_range_stats=True)
+    assert "fused_sv_mvbs_kernel" in tr.kernels
+    sv = res["Sv"].cpu().numpy()
+    assert np.isnan(sv[0, 7, 3:]).all() and np.isinf(sv[1, 40:60, 3:]).all() and np.isfinite(sv[0, 8, 3:]).all()
+    # the generic kernel on the same Sv array and the echo_range: the reference's skipna mean
+    rng = ops.range_power(raw, coef)
+    exp = ops.mvbs(res["Sv"], bs, n_t, 5.0, 60, range=rng)["MVBS"].cpu().numpy()
+    got = res["MVBS"].cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+    fin = np.isfinite(exp)
+    np.testing.assert_allclose(got[fin], exp[fin], rtol=1e-12)
+    np.testing.assert_array_equal(np.isinf(got), np.isinf(exp))
+    assert np.isfinite(got[0, 0]).any()

@@ -269,3 +269,101 @@ def test_sharded_chain_runs_two_sweeps_and_equals_the_oracle(world):
         f = np.isfinite(o["sc"])
         assert o["ar"] == [round(float(o["sc"][f].min()), 2), round(float(o["sc"][f].max()), 2)]
     _close(np.concatenate([o["mv"] for o in res], axis=1), exp_mv, 1e-9 * 200, "MVBS of the corrected Sv")
+
+
+def _worker_vote(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import logging
+
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, HERE)
+    from test_gpu_multi_rank import _slice_ek60
+
+    import echopype_amd as ep
+    from echopype_amd import _lib, sharding
+
+    logging.disable(logging.WARNING)
+    C, P, S = 2, 150, 1024
+    d = ep.synth.ek60_numpy(C, P, S, seed=31, ss_every=1)
+    p0, p1 = sharding.shard_bounds(P, world, rank)
+    ed = ep.echodata.from_ek60_arrays(_slice_ek60(d, p0, p1)).to_device()
+    shard = sharding.MVBSShard()
+    fs = sharding.file_scalars(ed)
+    out = dict(p0=p0, p1=p1)
+    # (a) the two calls; rank 0 has read its Sv before it bins (its Sv is an array, the other rank's still deferred)
+    with _lib.launch_trace() as tr:
+        ds = sharding.compute_Sv(ed, file_scalars=fs)
+        if rank == 0:
+            ds["Sv"].values
+        mv = sharding.compute_MVBS(ds, range_bin="2m", ping_time_bin="20s", shard=shard)
+        out["a_mv"], out["a_t"] = np.asarray(mv["Sv"].values), np.asarray(mv["ping_time"].values)
+    out["a_kernels"] = tr.kernels
+    # (b) the chain; rank 1 has read its Sv before remove_background_noise, rank 0 its Sv_corrected before compute_MVBS
+    ds = sharding.compute_Sv(ed, file_scalars=fs)
+    if rank == 1:
+        ds["Sv"].values
+    sharding.remove_background_noise(ds, 20, 50, ping_offset=p0, shard=shard)
+    out["b_sc"] = np.asarray(ds["Sv_corrected"].values)
+    # (c) the chain on the deferred routes up to the binning; rank 0 reads Sv_corrected first
+    ds = sharding.compute_Sv(ed, file_scalars=fs)
+    sharding.remove_background_noise(ds, 20, 50, ping_offset=p0, shard=shard)
+    corrected = ds.copy()
+    corrected["Sv"] = ds["Sv_corrected"]
+    if rank == 0:
+        corrected["Sv"].values
+    mv = sharding.compute_MVBS(corrected, range_bin="2m", ping_time_bin="20s", shard=shard)
+    out["c_mv"], out["c_t"] = np.asarray(mv["Sv"].values), np.asarray(mv["ping_time"].values)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_route_is_voted_on_when_a_rank_cannot_take_it():
+    """Whether a rank's Sv is still deferred is rank-local state; the deferred and the plain routes run different
+    collectives.  A rank that has read its array must not leave the others waiting in a collective it never joins
+    (ADVICE round 5): the route is voted on in the call's first control message, every rank takes the plain route, and
+    the results are the whole file's."""
+    import torch
+    import torch.multiprocessing as mp
+
+    from oracle import clean as oclean
+    from oracle import commongrid as ogrid
+
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need a GPU")
+    sys.path.insert(0, HERE)
+    from test_gpu_multi_rank import TABLES, _oracle_sv
+
+    import echopype_amd as ep
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_vote, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [o for _, o in sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
+    C, P, S = 2, 150, 1024
+    d = ep.synth.ek60_numpy(C, P, S, seed=31, ss_every=1)
+    sv, er = _oracle_sv(d, {k: d[k] for k in TABLES}, d["transmit_duration_nominal"][:, 0])
+    exp_mv, t_left, _ = ogrid.compute_MVBS(sv, er, d["ping_time"], "2m", "20s")
+    _close(np.concatenate([o["a_mv"] for o in res], axis=1), exp_mv, 1e-9 * 200, "MVBS, one rank's Sv read early")
+    np.testing.assert_array_equal(np.concatenate([o["a_t"] for o in res]), t_left)
+    assert all("fused_sv_mvbs_kernel" not in o["a_kernels"] for o in res)  # (both ranks took the plain route)
+    exp_n, exp_c = oclean.remove_background_noise(sv, er, d["absorption_indicative"], 20, 50, None, "3.0dB")
+    _close(np.concatenate([o["b_sc"] for o in res], axis=1), exp_c, 1e-9 * 200, "Sv_corrected, one rank's Sv read early")
+    exp_mvc, t_left, _ = ogrid.compute_MVBS(exp_c, er, d["ping_time"], "2m", "20s")
+    _close(np.concatenate([o["c_mv"] for o in res], axis=1), exp_mvc, 1e-9 * 200, "MVBS, one rank's Sv_corrected read early")
+    np.testing.assert_array_equal(np.concatenate([o["c_t"] for o in res]), t_left)

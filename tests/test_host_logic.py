@@ -755,3 +755,30 @@ def test_lazy_attrs_settle_on_first_read_of_a_value_only():
     del d["actual_range"]
     assert w["actual_range"] == [0, 0] and u["actual_range"] == 5 and "actual_range" not in d and len(calls) == n
     assert not w.has_pending() and not u.has_pending() and not d.has_pending()
+
+
+def test_deferred_dataset_keeps_errors_but_retries_after_an_interrupt():
+    """xr_lite.DeferredDataset: an error of the assembly is THE result (raised again at every access); an interrupt is
+    not -- the next access assembles again."""
+    from echopype_amd.xr_lite import Dataset, DeferredDataset
+
+    calls = []
+
+    def build():
+        calls.append(1)
+        if len(calls) == 1:
+            raise KeyboardInterrupt
+        return Dataset(coords={"x": np.arange(3)})
+
+    ds = DeferredDataset(build)
+    with pytest.raises(KeyboardInterrupt):
+        ds.coords
+    assert list(ds.coords["x"].values) == [0, 1, 2] and len(calls) == 2
+
+    def fails():
+        raise ValueError("range bins are empty")
+
+    bad = DeferredDataset(fails)
+    for _ in range(2):
+        with pytest.raises(ValueError, match="range bins are empty"):
+            bad.attrs

@@ -404,7 +404,12 @@ def _worker_grid(rank, world, port, q):
     a = shard.grid(ns, 20 * 10**9, "left", reach)
     b = shard.time_grid(ns, 20 * 10**9, "left") + (shard.range_max(reach),)
     none = shard.grid(ns, 20 * 10**9, "left", float("nan"))  # nobody has one: NaN
-    q.put((rank, a, b, none[4]))
+    # the same message as the vote on the call's route: the route every rank names, 0 when they differ (a rank whose
+    # pings are unsorted names 0 and hands its times over as they are)
+    same = shard.grid(ns, 20 * 10**9, "left", reach, sorted_valid=True, route=2)
+    mixed = shard.grid(ns[::-1] if rank == 1 else ns, 20 * 10**9, "left", reach if rank != 1 else float("nan"),
+                       sorted_valid=rank != 1, route=0 if rank == 1 else 1)
+    q.put((rank, a, b, none[4], same, mixed))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -421,8 +426,9 @@ def test_grid_in_one_message_equals_the_two_separate_agreements():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, a, b, none in res:
+    for rank, a, b, none, same, mixed in res:
         assert a == b and a[4] == 786.4921875 and np.isnan(none)
+        assert same == a + (2,) and mixed == a + (0,)
     assert [r[1][2] for r in res] == [0, 2, 4] and res[0][1][0] == res[2][1][0]
 
 
