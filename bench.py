@@ -56,7 +56,7 @@ WORKLOADS = {
     "small": (4, 20_000, 2000, 50, 50),
     "next": (4, 100_000, 2000, 2, 2),  # SURVEY 8f rows through their API entry points (scripts/perf_masks.py's volume)
 }
-DEFAULT_LINES = ["cfg3", "cfg3:ss2000", "cfg3:f32", "cfg2", "cfg2:f32", "cfg2:int16", "cfg2:sv", "cfg2:sv32", "api", "api:chain",
+DEFAULT_LINES = ["cfg3", "cfg3:ss2000", "cfg3:f32", "cfg2", "cfg2:f32", "cfg2:int16", "cfg2:sv", "cfg2:sv32", "api", "api:chain", "api:pcie",
                  "cfg4", "cfg4:f32", "cfg4:planes64", "next:depth", "next:depthw", "next:masks", "next:nasc", "cfg5:one", "cfg5"]
 TILE_PINGS = 250_000
 DT = {"f32": "float32", "f64": "float64", "sv32": "float32"}
@@ -129,11 +129,14 @@ def _time_runs(run, budget_s=12.0, max_runs=5):
 
 
 def _cpu_worker(a):
-    C, P, S, seed = a
+    C, P, S, seed, reps = a
     from echopype_amd import synth
 
-    _oracle_ek60(synth.ek60_numpy(C, P, S, seed=20260501 + seed), False)
-    return 0
+    d = synth.ek60_numpy(C, P, S, seed=20260501 + seed)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        _oracle_ek60(d, False)
+    return time.perf_counter() - t0
 
 
 def cpu_baseline_ek60(chain=False, multicore=False):
@@ -148,17 +151,31 @@ def cpu_baseline_ek60(chain=False, multicore=False):
     what = "Sv+denoise(20x50,3dB)+MVBS" if chain else "Sv+MVBS"
     out = {"value": n / med, "unit": "range-samples/s", "cores": 1, "kind": "port",
            "sample": f"EK60 {C}x{P}x{S} {what}, NumPy f64 oracle, median of {n_runs}"}
-    if multicore:  # what dask chunk-parallelism over ping_time could reach at best: the same slice in N processes
+    if multicore:
+        # what dask chunk-parallelism over ping_time could reach at best: a ping slice of the same volume in EVERY core
+        # the process may use (north_star: "the same box's host cores (core count stated)"), a quarter of the pings per
+        # worker (the workers' footprint -- ~0.4 GB each -- stays well inside the host's memory), repeated to ~2 s of
+        # work per core so that the fork does not weigh
         try:
             import multiprocessing as mp
 
-            ncore = max(1, min(32, (os.cpu_count() or 1) // 2))
+            ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            try:
+                import psutil
+
+                ncore = max(1, min(ncore, int(psutil.virtual_memory().available // (1 << 30))))  # >= 1 GiB per worker
+            except Exception:  # noqa: BLE001
+                pass
             if ncore > 1:
+                Pw = P // 4
+                reps = max(1, int(round(2.0 / (med / 4))))
                 with mp.get_context("fork").Pool(ncore) as pool:
                     t0 = time.perf_counter()
-                    pool.map(_cpu_worker, [(C, P, S, i) for i in range(ncore)])
+                    busy = pool.map(_cpu_worker, [(C, Pw, S, i, reps) for i in range(ncore)], chunksize=1)
                     dtm = time.perf_counter() - t0
-                out["multicore_value"], out["multicore_cores"] = n * ncore / dtm, ncore
+                out["multicore_value"], out["multicore_cores"] = C * Pw * S * reps * ncore / dtm, ncore
+                out["multicore_sample"] = (f"{ncore} processes x {reps} x EK60 {C}x{Pw}x{S}, wall {dtm:.1f} s "
+                                           f"(slowest worker busy {max(busy):.1f} s), host has {os.cpu_count()} hardware threads")
         except Exception as e:  # noqa: BLE001 - the single-core figure stands on its own
             out["multicore_error"] = repr(e)[:100]
     return out
@@ -243,10 +260,12 @@ class Ctx:
             return self.args.passes
         return WORKLOADS[workload][3 if self.dtype == "float64" else 4]
 
-    def timed(self, one_pass, passes, finish=None):
+    def timed(self, one_pass, passes, finish=None, timers_of=None):
         """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks.  A step = ``passes``
         calls of one_pass(timer | None); ``finish()`` (results still in flight are read) runs INSIDE the timed region,
-        before the closing synchronize.  Returns (elapsed s, mean HIP-event ms of the regions the passes timed)."""
+        before the closing synchronize.  Returns (elapsed s, mean HIP-event ms of the regions the passes timed);
+        ``timers_of()``: the harness brackets its launches with its own timers (a pipeline that launches ahead of the
+        pass it is asked for) and hands them over here."""
         steps, warmup = self.args.steps, self.args.warmup
         timers = [self.ops.Timer() for _ in range(steps * passes)]
         for _ in range(warmup * passes):
@@ -261,7 +280,7 @@ class Ctx:
             finish()
         self.sync()
         elapsed = time.perf_counter() - t0
-        kernel_ms = float(np.mean([tm.elapsed_ms() for tm in timers]))
+        kernel_ms = float(np.mean([tm.elapsed_ms() for tm in (timers_of() if timers_of else timers)]))
         t = self.torch.tensor([elapsed], dtype=self.torch.float64)
         if self.world > 1:
             t = t.to(self.sharding._comm_device())
@@ -383,6 +402,56 @@ def run_ek60(ctx, name, variant, cpu):
                                   traffic_key=key))
 
 
+def run_api_pcie(ctx, cpu):
+    """``api:pcie``: the two reference calls on a plain HOST echodata (NumPy arrays, nothing resident, no
+    ``EchoData.to_device``) -- what a caller who hands over host buffers gets: every pass uploads the raw samples
+    (4 B/sample over PCIe, pageable memory) before the kernel can run, and reads the MVBS back; Sv stays in HBM.  Never
+    the headline's ``value`` (inputs resident is the contract); reported beside it as ``also_pcie``."""
+    import logging
+
+    import echopype_amd as ep
+
+    C, P, S = 4, 100_000, 2000
+    ctx.cache.clear()
+    ctx.free()
+    d = ctx.synth.ek60_numpy(C, 4, 8)
+    h = ctx.synth.ek60_params(C, P, ss_every=ctx.args.ss_every)
+    for k in ("sample_interval", "transmit_duration_nominal", "transmit_power", "sound_speed_indicative",
+              "absorption_indicative"):
+        d[k] = h[k]
+    d["ping_time"] = h["ping_time"]
+    d["backscatter_r"] = ctx.synth.ek60_device(C, P, S, seed=20260511, ss_every=ctx.args.ss_every)["backscatter_r"].cpu().numpy()
+    ed = ep.echodata.from_ek60_arrays(d)  # host arrays
+    dtype = ctx.dtype
+
+    def one_pass(timer):
+        if timer is not None:
+            timer.start()
+        ds = ep.calibrate.compute_Sv(ed, dtype=dtype)
+        mv = ep.commongrid.compute_MVBS(ds, range_bin="1m", ping_time_bin="20s")
+        host = mv["Sv"].values  # the MVBS grid back on the host
+        if timer is not None:
+            timer.stop()
+        return host.shape
+
+    logging.disable(logging.WARNING)
+    try:
+        elapsed, region_ms = ctx.timed(one_pass, 1)
+    finally:
+        logging.disable(logging.NOTSET)
+    n = C * P * S
+    bps = BYTES_PER_SAMPLE[dtype]
+    out = line(ctx, samples_per_pass=n, passes=1, elapsed=elapsed, scaling="weak", cpu=cpu,
+               workload=f"api:pcie: EK60 CW {C}x{P}x{S} on HOST arrays (no to_device): compute_Sv(echodata) then "
+                        "compute_MVBS(ds_Sv), MVBS read back; PCIe-inclusive, never the headline",
+               config={"sharding": "one GPU", "collective": "none", "h2d_bytes_per_sample": 4,
+                       "h2d_GBps": n * 4 / (elapsed / ctx.args.steps) / 1e9},
+               roofline=roofline("fused_sv_mvbs_kernel behind the upload of its input", region_ms, n * bps, bps,
+                                 traffic_key=None, note="region = upload + both calls + MVBS read-back; bound by PCIe, "
+                                                        "not HBM: the fraction says how far from the resident rate"))
+    return out
+
+
 def run_api(ctx, cpu, variant=""):
     """``api:chain``: the reference's THREE calls of the chain on the cfg3 volume -- compute_Sv, remove_background_noise,
     compute_MVBS of the dataset with Sv := Sv_corrected -- file after file: two passes over the raw samples (32 B per
@@ -396,6 +465,8 @@ def run_api(ctx, cpu, variant=""):
 
     import echopype_amd as ep
 
+    if variant == "pcie":
+        return run_api_pcie(ctx, cpu)
     C, P, S = WORKLOADS["api"][:3]
     raw = ek60_volume(ctx, "cfg2", ctx.args.ss_every)["backscatter_r"]
     d = ctx.synth.ek60_numpy(C, 4, 8)
@@ -778,7 +849,6 @@ class Cfg5:
         reference's two calls; world > 1: sharding.compute_Sv_MVBS on the tile as this rank's shard of dataset j.  The
         result of a tile is READ (the deferred MVBS dataset assembled: three doubles come back from the GPU) after the
         next ``lag`` tiles have been launched, then dropped (its Sv array goes back to the allocator)."""
-        import collections
         import logging
 
         import echopype_amd as ep
@@ -798,52 +868,62 @@ class Cfg5:
             def call(ed):
                 return sharding.compute_Sv_MVBS(ed, range_bin=rb, ping_time_bin="20s", dtype=dtype, shard=shard,
                                                 tau_effective_first_ping=tau0)
-        pending = collections.deque()
         torch = ctx.torch
         n_streams = max(1, int(getattr(ctx, "tile_streams", 1) or 1))
-        # tile i -> stream i % n_streams (the calls of a tile, and the read of its result, under that stream)
-        streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_streams - 1)]
+        # The loop itself is the product's: ``echopype_amd.pipeline`` deals consecutive tiles to ``n_streams`` side
+        # streams and hands a tile's result out -- the deferred MVBS dataset assembled: three doubles come back from the
+        # GPU -- after the next ``lag`` tiles have been launched.  ONE pipeline runs through all the passes of a timed
+        # region (no drain at a pass boundary); ``finish`` reads what is still in flight.
         # host_s / calls: wall time the HOST spends inside the entry-point calls of a tile (launches, control-plane
         # messages; no wait for the GPU on the deferred routes) -- what has to stay under the kernel's ~9 ms per tile for
         # the GPU to run back to back, and the per-call cost that decides the scaling at N = 8 (one tile per rank and pass)
-        state = {"last": None, "n_read": 0, "pass": 0, "host_s": 0.0, "calls": 0}
+        state = {"last": None, "n_read": 0, "host_s": 0.0, "calls": 0, "timing": False, "timers": [], "pipe": None,
+                 "launched": 0}
+        T = len(eds)
 
-        def consume(item):
-            (ds, mv), st = item
-            with torch.cuda.stream(st):
-                state["last"] = (tuple(mv["Sv"].shape),)  # (touching the dataset assembles it: the grid's size comes back from the GPU)
+        def launch(i):
+            # the HIP-event bracket goes round the tiles from pass to pass: roofline.kernel_ms is the mean over ALL tiles
+            # of the volume (the calls of a tile behind a busy stream), not the first tile's
+            timed = state["timing"] and (i % T) == (i // T) % T
+            tm = None
+            if timed:
+                tm = ctx.ops.Timer()
+                tm.start()
+            t_host = time.perf_counter()
+            item = call(eds[i % T])
+            if state["timing"]:
+                state["host_s"] += time.perf_counter() - t_host
+                state["calls"] += 1
+            if tm is not None:
+                tm.stop()
+                state["timers"].append(tm)
+            return item
+
+        def read(item):
+            ds, mv = item
+            state["last"] = (tuple(mv["Sv"].shape),)
             state["n_read"] += 1
 
         def one_pass(timer):
             logging.disable(logging.WARNING)  # (the NaN-coordinate warning of every tile: 10 % of the pings are padded)
-            # the HIP-event bracket goes round the tiles from pass to pass: roofline.kernel_ms is the mean over ALL tiles
-            # of the volume (the calls of a tile behind a busy stream), not the first tile's
-            timed_tile = state["pass"] % len(eds)
-            state["pass"] += 1
             try:
-                for i, ed in enumerate(eds):
-                    st = streams[i % n_streams]
-                    with torch.cuda.stream(st):
-                        if timer is not None and i == timed_tile:
-                            timer.start()
-                        t_host = time.perf_counter()
-                        item = call(ed)
-                        if timer is not None:  # (timed passes only)
-                            state["host_s"] += time.perf_counter() - t_host
-                            state["calls"] += 1
-                        if timer is not None and i == timed_tile:
-                            timer.stop()
-                    pending.append((item, st))
-                    while len(pending) > lag:
-                        consume(pending.popleft())
+                if state["pipe"] is None:
+                    state["timing"] = timer is not None
+                    state["pipe"] = ep.pipeline.Pipeline(launch, streams=n_streams if n_streams > 1 else 0, lag=lag)
+                for _ in range(T):
+                    for item in state["pipe"].submit(state["launched"]):
+                        read(item)
+                    state["launched"] += 1
             finally:
                 logging.disable(logging.NOTSET)
 
         def finish():
             logging.disable(logging.WARNING)
             try:
-                while pending:
-                    consume(pending.popleft())
+                if state["pipe"] is not None:
+                    for item in state["pipe"].drain():
+                        read(item)
+                state["pipe"] = None
             finally:
                 logging.disable(logging.NOTSET)
 
@@ -895,8 +975,9 @@ def ranks_info(ctx):
     torch, dist = ctx.torch, ctx.dist
     mine = f"{ctx.rank}:cuda{torch.cuda.current_device()}"
     name = torch.cuda.get_device_name()
-    if ctx.world == 1:
-        return {"world_size": 1, "backend": "none", "devices": [mine], "device_name": name}
+    if ctx.world == 1:  # (--sharded-at-1: a one-rank group of the real backend)
+        return {"world_size": 1, "backend": dist.get_backend() if dist.is_initialized() else "none", "devices": [mine],
+                "device_name": name}
     got = [None] * ctx.world
     dist.all_gather_object(got, (mine, name), group=ctx.sharding.control_group())
     names = sorted({n for _, n in got})
@@ -907,11 +988,12 @@ def ranks_info(ctx):
 def run_cfg5(ctx, cpu, variant=""):
     """The headline: the eight tiles through the product entry points (api_layout); beside it the ops-level harness on
     the same resident tiles, with and without cut bins.  N = 1: the tiles -- independent datasets -- are dealt to
-    ``--tile-streams`` HIP streams (default 2: the kernel of a tile runs beside the next tile's; ``cfg5:one`` = one stream,
-    a launch at a time); N > 1 and --sharded-at-1: one stream.  N = 1: Sv of the tiles goes to one reused buffer (ops level) /
+    ``--tile-streams`` HIP streams by the package's own loop, ``echopype_amd.pipeline.run`` (default 2: the kernel of a tile
+    runs beside the next tile's; ``cfg5:one`` = the caller's stream, a launch at a time); N > 1 and --sharded-at-1 alike:
+    a rank's consecutive shards alternate between the streams, the collectives are issued in item order.  N = 1: Sv of the tiles goes to one reused buffer (ops level) /
     to the allocator's recycled block (API): 131 GB in + 262 GB out does not fit 288 GB otherwise."""
     args, world = ctx.args, ctx.world
-    ctx.tile_streams = 1 if (variant == "one" or world > 1 or getattr(args, "sharded_at_1", False)) else max(1, args.tile_streams)
+    ctx.tile_streams = 1 if variant == "one" else max(1, args.tile_streams)
     C, _, S = WORKLOADS["cfg5"][:3]
     P_total = args.pings_total or WORKLOADS["cfg5"][1]
     job = Cfg5(ctx, C, P_total, S, tile_pings=args.tile_pings, ss_every=args.ss_every)
@@ -934,7 +1016,7 @@ def run_cfg5(ctx, cpu, variant=""):
     # (c) the product entry points on the same tiles, same 10-s offset: the headline
     lag = max(1, args.read_lag)
     pass_c, finish_c, state, eds = job.api_layout(10_000_000_000, lag=lag)
-    elapsed, region_ms = ctx.timed(pass_c, passes, finish=finish_c)
+    elapsed, region_ms = ctx.timed(pass_c, passes, finish=finish_c, timers_of=lambda: state["timers"])
     assert state["n_read"] == len(job.tiles) * passes * (steps + args.warmup)  # every result was read
     if world == 1 and not getattr(args, "sharded_at_1", False):
         route = "compute_Sv(echodata) -> compute_MVBS(ds_Sv,'1m','20s') per tile"
@@ -1086,6 +1168,8 @@ def main():
                 out["config"]["also_unit"] = "Gsamp/s f<frac>"
             fam, _, var = spec.partition(":")  # one string per workload family: "441.4 f0.668; f32 628.0 f0.636"
             key = "also_" + fam
+            if spec == "api:pcie":  # (its own key: the PCIe-inclusive rate must not be mistaken for a resident line)
+                key, var = "also_pcie", ""
             also[key] = (also[key] + "; " if key in also else "") + (var + " " if var else "") + summary(out)
             txt = json.dumps(compact(out), separators=(",", ":"))  # (no padding: the headline carries the other lines' figures)
             print(txt, flush=True)

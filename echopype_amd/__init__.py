@@ -8,11 +8,11 @@ HIP kernels.  There is no CPU fallback: importing the package loads libechopype_
 loudly if it has not been built (``python echopype_amd/build.py``).
 """
 from . import _lib  # noqa: F401  (loads the HIP library; raises if missing)
-from . import calibrate, clean, commongrid, consolidate, mask, ops, synth, utils  # noqa: F401
+from . import calibrate, clean, commongrid, consolidate, mask, ops, pipeline, synth, utils  # noqa: F401
 from .echodata import EchoData  # noqa: F401
 from .fused import compute_Sv_clean_MVBS, compute_Sv_MVBS  # noqa: F401
 from .xr_lite import DataArray, Dataset, DeviceArray  # noqa: F401
 
 __version__ = "0.1.0"
-__all__ = ["calibrate", "clean", "commongrid", "consolidate", "mask", "utils", "ops", "synth", "compute_Sv_MVBS", "compute_Sv_clean_MVBS", "EchoData", "Dataset", "DataArray",
+__all__ = ["calibrate", "clean", "commongrid", "consolidate", "mask", "utils", "ops", "synth", "pipeline", "compute_Sv_MVBS", "compute_Sv_clean_MVBS", "EchoData", "Dataset", "DataArray",
            "DeviceArray"]

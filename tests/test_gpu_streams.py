@@ -101,3 +101,62 @@ def test_chain_on_alternating_streams(env):
             np.testing.assert_allclose(m, m0, rtol=1e-11, atol=1e-11, equal_nan=True)
     finally:
         logging.disable(logging.NOTSET)
+
+
+# ---- the package's own loop: echopype_amd.pipeline -------------------------------------------------------------------------
+@pytest.mark.parametrize("streams,lag", [(2, 1), (3, 2), (0, 1), (2, 0)])
+def test_pipeline_sv_mvbs_equals_the_plain_loop(env, streams, lag):
+    """ep.pipeline.sv_mvbs: consecutive files on alternating side streams, results handed out ``lag`` files late, in
+    order, assembled, and readable on the CALLER's stream (its stream waits for the file's on the device) -- the plain
+    loop's datasets."""
+    torch, ep, synth = env
+    from echopype_amd.xr_lite import DeferredDataset
+
+    C, P, S = 4, 30000, 2000
+    files = [_file(ep, synth, C, P, S, seed=500 + i, ping0=i * P) for i in range(5)]
+    logging.disable(logging.WARNING)
+    try:
+        ref = []
+        for ed in files:
+            ds, mv = _two_calls(ep, ed, "float64")
+            ref.append((ds["Sv"].values.copy(), mv["Sv"].values.copy(), mv["ping_time"].values.copy()))
+        torch.cuda.synchronize()
+        launched = []
+
+        def feed():
+            for i, ed in enumerate(files):
+                launched.append(i)
+                yield ed
+
+        got = 0
+        for k, (ds, mv) in enumerate(ep.pipeline.sv_mvbs(feed(), streams=streams, lag=lag, range_bin="1m", ping_time_bin="20s")):
+            assert len(launched) == min(len(files), k + lag + 1)        # handed out ``lag`` files late
+            assert not isinstance(mv, DeferredDataset) or mv.resolved   # ... assembled
+            sv0, mv0, t0 = ref[k]
+            # read on the caller's stream, no stream context: its stream was made to wait for the file's
+            np.testing.assert_array_equal(ds["Sv"].data.tensor.cpu().numpy(), sv0)
+            np.testing.assert_array_equal(mv["ping_time"].values, t0)
+            np.testing.assert_allclose(mv["Sv"].values, mv0, rtol=1e-11, atol=1e-11, equal_nan=True)
+            got += 1
+        assert got == len(files)
+    finally:
+        logging.disable(logging.NOTSET)
+
+
+def test_pipeline_run_orders_items_behind_the_callers_stream(env):
+    """What the caller queued on its stream before an item is launched is finished before the item's kernels read it."""
+    torch, ep, synth = env
+
+    base = torch.zeros(1 << 22, dtype=torch.float64, device="cuda")
+
+    def items():
+        for i in range(6):
+            base.add_(1.0)              # on the caller's stream, right before the item is launched
+            yield i
+
+    def fn(i):
+        return base.sum()               # on the item's side stream
+
+    # (lag 0: an item is handed out -- the caller's stream waits for it -- before the caller touches ``base`` again)
+    out = [float(t.item()) for t in ep.pipeline.run(items(), fn, streams=2, lag=0, settle=False)]
+    assert out == [float((i + 1) * (1 << 22)) for i in range(6)]
