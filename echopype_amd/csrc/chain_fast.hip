@@ -65,6 +65,12 @@ __device__ __forceinline__ double vmin_num(double a, double b) {
   return r;
 }
 
+__device__ __forceinline__ float vmin_num(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ unsigned long long ordered_key(double v) {
   const unsigned long long b = __double_as_longlong(v);
   return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
@@ -253,7 +259,9 @@ struct NoiseCol {
 #ifndef EPA_WG_KEYS
 #define EPA_WG_KEYS 1
 #endif
-__device__ __forceinline__ void wg_minmax_keys(const double (&mm)[4], unsigned long long* keys, int lane) {
+template <typename U>
+__device__ __forceinline__ void wg_minmax_keys(const U (&mm_)[4], unsigned long long* keys, int lane) {
+  const double mm[4] = {(double)mm_[0], (double)mm_[1], (double)mm_[2], (double)mm_[3]};
 #if !EPA_WG_KEYS  // (development knob: the round-5 form, one atomic per wavefront and key)
   if (lane == 0) {
     if (mm[0] <= mm[1]) {
@@ -520,6 +528,17 @@ __global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 4 : 1) void sv_noise_
 // written by the uniform-group kernel into the first MVBS cell of a group it leaves to the general kernel (a NaN
 // payload no computation produces; the general kernel overwrites it)
 constexpr unsigned long long kLeftToGeneral = 0x7ff8dead0c0ffee1ull;
+constexpr unsigned kLeftToGeneral32 = 0x7fcdead1u;  // (float grids: a cell is four bytes)
+__device__ __forceinline__ bool left_to_general(const double* cell) {
+  return *reinterpret_cast<const unsigned long long*>(cell) == kLeftToGeneral;
+}
+__device__ __forceinline__ bool left_to_general(const float* cell) {
+  return *reinterpret_cast<const unsigned*>(cell) == kLeftToGeneral32;
+}
+__device__ __forceinline__ void mark_left_to_general(double* cell) {
+  *reinterpret_cast<unsigned long long*>(cell) = kLeftToGeneral;
+}
+__device__ __forceinline__ void mark_left_to_general(float* cell) { *reinterpret_cast<unsigned*>(cell) = kLeftToGeneral32; }
 
 template <typename T>
 struct BinCol : ColBase<T> {
@@ -553,8 +572,7 @@ __global__ __launch_bounds__(epa::kBlock, 3) void sv_denoise_mvbs_fast_kernel(
   // blockIdx.x == n_tbins: pings that belong to no time bin still get their Sv_noise / Sv_corrected
   const bool extra = tb == a.n_tbins;
   if (extra && !(WRITE_NOISE || WRITE_CORR)) return;
-  if (a.flagged_only && !extra &&
-      reinterpret_cast<const unsigned long long*>(mvbs_out + ((size_t)c * a.n_tbins + tb) * n_rbins)[0] != kLeftToGeneral)
+  if (a.flagged_only && !extra && !left_to_general(mvbs_out + ((size_t)c * a.n_tbins + tb) * n_rbins))
     return;  // (uniform) the group was done by sv_denoise_mvbs_uniform_kernel
   const int nseg = extra ? 2 : 1;
   for (int i = threadIdx.x; i < n_rbins; i += epa::kBlock) {
@@ -723,7 +741,7 @@ __global__ __launch_bounds__(epa::kBlock, 3) void sv_denoise_mvbs_fast_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass 2, fp64, ping groups whose pings share ONE range vector and ONE absorption (the sample interval, sound speed,
+// pass 2, ping groups whose pings share ONE range vector and ONE absorption (the sample interval, sound speed,
 // pulse length and absorption of a file rarely change from ping to ping).  Then everything that depends on the range is
 // a per-column constant of the group -- the spreading and absorption factors of the linear Sv, the linear noise shape,
 // the transmission loss in dB, the range bin -- and a sample costs one exp10 (of g raw), one log10 and a few multiplies:
@@ -734,33 +752,23 @@ __global__ __launch_bounds__(epa::kBlock, 3) void sv_denoise_mvbs_fast_kernel(
 // kUniPings) marks the group's first MVBS cell and leaves it to sv_denoise_mvbs_fast_kernel, launched right after.
 // ------------------------------------------------------------------------------------------------
 constexpr int kUniPings = 256;
-struct PingLin {
-  double g, csv, cn, nb;
+template <typename T>
+struct PingLin {  // (the per-ping constants in the output's type: the float instance must not meet a double per sample)
+  T g, csv, cn, nb;
 };
 
-__device__ __forceinline__ double vmin_f64(double a, double b) {  // IEEE minNum / maxNum without the canonicalising copy
-  double r;
-  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ double vmax_f64(double a, double b) {
-  double r;
-  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
-template <bool WRITE_NOISE, bool WRITE_CORR, bool MINMAX>
+// (round 6: templated on the output type -- the float chain's pass 2 ran the general kernel, 10.0 ms per 4 G samples)
+template <typename T, bool WRITE_NOISE, bool WRITE_CORR, bool MINMAX>
 __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_uniform_kernel(
     const float* __restrict__ raw, const epa::CoefRow* __restrict__ coef, const double* __restrict__ alpha2,
-    const double* __restrict__ noise, const int32_t* __restrict__ bin_start, double* __restrict__ noise_out,
-    double* __restrict__ corr_out, double* __restrict__ mvbs_out, double* __restrict__ sum_out,
+    const double* __restrict__ noise, const int32_t* __restrict__ bin_start, T* __restrict__ noise_out,
+    T* __restrict__ corr_out, T* __restrict__ mvbs_out, T* __restrict__ sum_out,
     uint32_t* __restrict__ cnt_out, Args a) {
-  typedef double T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* lsum = reinterpret_cast<T*>(smem);
   uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + a.cnt_off);
   const epa::MathTabs mt = epa::build_math_tabs(smem + a.tab_off);
-  __shared__ PingLin pl[kUniPings];
+  __shared__ PingLin<T> pl[kUniPings];
   __shared__ int differs;
 
   // a workgroup takes a.uni_bins consecutive time bins (their pings are one run): the per-column constants are paid
@@ -789,13 +797,12 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_uniform_kernel
                       (a2i == na2) & (ri.alpha2 == a2i);
     if (!same) differs = 1;
     const double nbi = nzp[(p + a.ping_phase) / a.noise_ping_num];
-    pl[threadIdx.x] = PingLin{ri.g, epa::lin_from_db(ri.A0 - ri.alpha2 * ri.shift + ri.alpha2 * ri.r0, mt.exp2_tab),
-                              epa::lin_from_db(nbi + a2i * ri.r0, mt.exp2_tab), nbi};
+    pl[threadIdx.x] = PingLin<T>{(T)ri.g, (T)epa::lin_from_db(ri.A0 - ri.alpha2 * ri.shift + ri.alpha2 * ri.r0, mt.exp2_tab),
+                                 (T)epa::lin_from_db(nbi + a2i * ri.r0, mt.exp2_tab), (T)nbi};
   }
   __syncthreads();
   if (differs) {
-    if ((int)threadIdx.x < nbn)
-      reinterpret_cast<unsigned long long*>(mvbs_out + cell0 + (size_t)threadIdx.x * n_rbins)[0] = kLeftToGeneral;
+    if ((int)threadIdx.x < nbn) mark_left_to_general(mvbs_out + cell0 + (size_t)threadIdx.x * n_rbins);
     return;
   }
 
@@ -808,7 +815,7 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_uniform_kernel
   T* __restrict__ sn_c = WRITE_NOISE ? noise_out + (size_t)c * a.P * S : nullptr;
   T* __restrict__ sc_c = WRITE_CORR ? corr_out + (size_t)c * a.P * S : nullptr;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double mm[4] = {__builtin_inf(), -__builtin_inf(), __builtin_inf(), -__builtin_inf()};
+  T mm[4] = {(T)__builtin_inf(), -(T)__builtin_inf(), (T)__builtin_inf(), -(T)__builtin_inf()};
 
   for (int chunk0 = 0; chunk0 < S; chunk0 += kChunk) {
     const int sA = chunk0 + wave * 256 + 2 * lane, sB = sA + 128;
@@ -830,7 +837,7 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_uniform_kernel
         c2 = nspread == (T)20 ? w2 : w2 * w2;
       }
       c2 = rtd > 0.0 ? c2 : epa::M<T>::nan();
-      const T E = epa::lin_from_db_lean(a2k * sj, mt.exp2_tab);
+      const T E = (T)epa::lin_from_db_lean(a2k * sj, mt.exp2_tab);
       const T mx = fmax((T)x, (T)1);
       c2E[j] = c2 * E;
       xxE[j] = (mx * mx) * E;
@@ -869,7 +876,7 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_uniform_kernel
         nA = *reinterpret_cast<const float2*>(raw_c + row_off + S + sA);
         if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + row_off + S + sB);
       }
-      const PingLin q = pl[p - pb];
+      const PingLin<T> q = pl[p - pb];
       const float in[VEC] = {inA.x, inA.y, inB.x, inB.y};
       T sn[VEC], sc[VEC];
 #pragma unroll
@@ -883,11 +890,11 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_uniform_kernel
         sn[j] = xok ? q.nb + sncol[j] : epa::M<T>::nan();  // echo_range is NaN where the input is
         const bool keep = corr - sn[j] > snr;
         sc[j] = keep ? corr : epa::M<T>::nan();
-        if (MINMAX) {
-          mm[0] = vmin_f64(mm[0], sn[j]);
-          mm[1] = vmax_f64(mm[1], sn[j]);
-          mm[2] = vmin_f64(mm[2], sc[j]);
-          mm[3] = vmax_f64(mm[3], sc[j]);
+        if (MINMAX) {  // (IEEE minNum / maxNum: a NaN operand leaves the running value alone)
+          mm[0] = vmin_num(mm[0], sn[j]);
+          mm[1] = vmax_num(mm[1], sn[j]);
+          mm[2] = vmin_num(mm[2], sc[j]);
+          mm[3] = vmax_num(mm[3], sc[j]);
         }
         const bool take = (rbin[j] >= 0) & keep;  // keep implies a finite positive lin (and a valid input)
         acc_sum[j] += take ? lin : (T)0;
@@ -928,7 +935,7 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_uniform_kernel
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass 2, fp64, ping groups that the uniform kernel left because only the SOUND SPEED differs from ping to ping (an
+// pass 2, ping groups that the uniform kernel left because only the SOUND SPEED differs from ping to ping (an
 // EK60 / EK80 records the sound speed of the moment with every ping: rb = c / 2 drifts, sample interval, pulse length
 // and absorption stay).  With echo_range = k s, k = ra rb (EK rows: r0 = 0) and shift = d k:
 //   lin(Sv)       = 10^(g raw/10) . (s - d)^(n/10) . C_sv(ping) . E_p(s)        E_p(s) = 10^(a2 k_p s / 10)
@@ -941,26 +948,28 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_uniform_kernel
 // per-sample arithmetic of the general kernel (`plain` bit clear).  Anything else differing -> left to the general kernel.
 // ------------------------------------------------------------------------------------------------
 constexpr int kDriftPings = 128;
+template <typename T>
 struct PingDrift {  // what every sample of the ping needs ...
-  double g, csv, cnk2, snp, a2k, q1, q128, q129;
+  T g, csv, cnk2, snp, a2k, q1, q128, q129;
 };
+template <typename T>
 struct PingDriftRare {  // ... and what only the columns off the plain path read
-  double cn, nb, rb, shift;
+  T cn, nb;
+  double rb, shift;
 };
 
-template <bool WRITE_NOISE, bool WRITE_CORR, bool MINMAX>
+template <typename T, bool WRITE_NOISE, bool WRITE_CORR, bool MINMAX>
 __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
     const float* __restrict__ raw, const epa::CoefRow* __restrict__ coef, const double* __restrict__ alpha2,
-    const double* __restrict__ noise, const int32_t* __restrict__ bin_start, double* __restrict__ noise_out,
-    double* __restrict__ corr_out, double* __restrict__ mvbs_out, double* __restrict__ sum_out,
+    const double* __restrict__ noise, const int32_t* __restrict__ bin_start, T* __restrict__ noise_out,
+    T* __restrict__ corr_out, T* __restrict__ mvbs_out, T* __restrict__ sum_out,
     uint32_t* __restrict__ cnt_out, Args a) {
-  typedef double T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* lsum = reinterpret_cast<T*>(smem);
   uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + a.cnt_off);
   const epa::MathTabs mt = epa::build_math_tabs(smem + a.tab_off);
-  __shared__ PingDrift pl[kDriftPings];
-  __shared__ PingDriftRare plr[kDriftPings];
+  __shared__ PingDrift<T> pl[kDriftPings];
+  __shared__ PingDriftRare<T> plr[kDriftPings];
   __shared__ int differs;
   __shared__ unsigned long long rb_lo_key, rb_hi_key;
 
@@ -969,7 +978,7 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
   const int S = a.S, n_rbins = a.n_rbins;
   const size_t cell0 = ((size_t)c * a.n_tbins + tb0) * n_rbins;
   // (uniform) only the groups the uniform kernel marked; a group of two bins is marked in both or in neither
-  if (reinterpret_cast<const unsigned long long*>(mvbs_out + cell0)[0] != kLeftToGeneral) return;
+  if (!left_to_general(mvbs_out + cell0)) return;
   const int pb = bin_start[tb0], pe = bin_start[tb0 + nbn], np = pe - pb;
   for (int i = threadIdx.x; i < nbn * n_rbins; i += epa::kBlock) {
     lsum[i] = (T)0;
@@ -1001,9 +1010,9 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
     const double a2k = a2i * ki;
     const double cn = epa::lin_from_db(nbi, mt.exp2_tab);
     const double q1 = epa::lin_from_db(a2k, mt.exp2_tab), q128 = epa::lin_from_db(128.0 * a2k, mt.exp2_tab);
-    pl[threadIdx.x] = PingDrift{ri.g, epa::lin_from_db(ri.A0 - ri.alpha2 * ri.shift, mt.exp2_tab), cn * (ki * ki),
-                                nbi + 20.0 * log10_pos(ki, mt.log_tab), a2k, q1, q128, q1 * q128};
-    plr[threadIdx.x] = PingDriftRare{cn, nbi, ri.rb, ri.shift};
+    pl[threadIdx.x] = PingDrift<T>{(T)ri.g, (T)epa::lin_from_db(ri.A0 - ri.alpha2 * ri.shift, mt.exp2_tab), (T)(cn * (ki * ki)),
+                                   (T)(nbi + 20.0 * log10_pos(ki, mt.log_tab)), (T)a2k, (T)q1, (T)q128, (T)(q1 * q128)};
+    plr[threadIdx.x] = PingDriftRare<T>{(T)cn, (T)nbi, ri.rb, ri.shift};
   }
   __syncthreads();
   if (differs) return;  // stays marked: the general kernel takes it
@@ -1022,16 +1031,16 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
   // min / max of the two outputs (actual_range): one LDS slot per lane and quantity, updated by ds_min_f64 / ds_max_f64
   // (a NaN operand leaves the slot alone) -- four running doubles per lane are eight registers this kernel does not
   // have at 4 wavefronts / SIMD (held in registers they spilled into the ping loop: 15.0 -> 22.0 ms per 4 G samples)
-  __shared__ double mm_slot[MINMAX ? 4 * epa::kBlock : 1];
-  auto mm_min = [&](int k, double v) {
+  __shared__ T mm_slot[MINMAX ? 4 * epa::kBlock : 1];
+  auto mm_min = [&](int k, T v) {
     __hip_atomic_fetch_min(&mm_slot[k * epa::kBlock + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
-  auto mm_max = [&](int k, double v) {
+  auto mm_max = [&](int k, T v) {
     __hip_atomic_fetch_max(&mm_slot[k * epa::kBlock + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
   if (MINMAX) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) mm_slot[k * epa::kBlock + threadIdx.x] = (k & 1) ? -__builtin_inf() : __builtin_inf();
+    for (int k = 0; k < 4; ++k) mm_slot[k * epa::kBlock + threadIdx.x] = (k & 1) ? -(T)__builtin_inf() : (T)__builtin_inf();
   }
 
   for (int chunk0 = 0; chunk0 < S; chunk0 += kChunk) {
@@ -1089,16 +1098,16 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
         nA = *reinterpret_cast<const float2*>(raw_c + row_off + S + sA);
         if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + row_off + S + sB);
       }
-      const PingDrift q = pl[p - pb];
+      const PingDrift<T> q = pl[p - pb];
       const float in[VEC] = {inA.x, inA.y, inB.x, inB.y};
       T sn[VEC], sc[VEC];
-      const T e0 = epa::lin_from_db_lean(q.a2k * (double)sA, mt.exp2_tab);
+      const T e0 = epa::lin_from_db_lean(q.a2k * (T)sA, mt.exp2_tab);
       const T ecol[VEC] = {e0, e0 * q.q1, e0 * q.q128, e0 * q.q129};
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         if (j >= 2 && !hasB) break;
         const bool xok = in[j] == in[j];
-        const double sj = (double)((j < 2 ? sA : sB) + (j & 1));
+        const T sj = (T)((j < 2 ? sA : sB) + (j & 1));
         // a NaN sample needs no masking: it makes the exponential, hence lin, NaN by itself
         const T e = epa::lin_from_db_lean(q.g * (T)in[j], mt.exp2_tab);
         const T lin = ecol[j] * fma(-q.cnk2, sj * sj, (e * c2[j]) * q.csv);
@@ -1156,8 +1165,8 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
             const size_t o = (size_t)p * S + sx;
             const float inv = raw_c[o];
             const bool xok = inv == inv;
-            const PingDrift q = pl[p - pb];
-            const PingDriftRare qr = plr[p - pb];
+            const PingDrift<T> q = pl[p - pb];
+            const PingDriftRare<T> qr = plr[p - pb];
             const double x = (sj * r.ra) * qr.rb;
             const double rtd = x - qr.shift;  // R' <= 0 -> NaN (calibrate_ek.py:107)
             T cc = c2j;
@@ -1167,11 +1176,11 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
             }
             cc = rtd > 0.0 ? cc : epa::M<T>::nan();
             const T e = epa::lin_from_db_lean(q.g * (T)inv, mt.exp2_tab);
-            const T E = epa::lin_from_db_lean(q.a2k * sj, mt.exp2_tab);
+            const T E = epa::lin_from_db_lean(q.a2k * (T)sj, mt.exp2_tab);
             const T mx = fmax((T)x, (T)1);
             const T lin = E * fma(-qr.cn, mx * mx, (e * cc) * q.csv);
             const T tl = x >= 1.0 ? (q.snp - qr.nb) + sn20j : (T)0;  // 20 log10(R >= 1 ? R : 1)
-            const T snv = xok ? (qr.nb + tl) + q.a2k * sj : epa::M<T>::nan();
+            const T snv = xok ? (qr.nb + tl) + q.a2k * (T)sj : epa::M<T>::nan();
             const T corr = lin > (T)0 ? (T)10 * epa::fast_log10_lean(lin, mt.log_tab, lk) : epa::M<T>::nan();
             const bool keep = corr - snv > snr;
             const T scv = keep ? corr : epa::M<T>::nan();
@@ -1196,7 +1205,7 @@ __global__ __launch_bounds__(epa::kBlock, 4) void sv_denoise_mvbs_drift_kernel(
   if (MINMAX) {
     double mm[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) mm[k] = mm_slot[k * epa::kBlock + threadIdx.x];  // (the lane's own slots: no barrier)
+    for (int k = 0; k < 4; ++k) mm[k] = (double)mm_slot[k * epa::kBlock + threadIdx.x];  // (the lane's own slots: no barrier)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       mm[0] = fmin(mm[0], __shfl_down(mm[0], o, 64));
@@ -1260,23 +1269,23 @@ int launch_pass2(Args& a, const float* raw, const double* coef, const double* al
     const char* e = getenv("EPA_CHAIN_UNIFORM");
     return e && e[0] == '0';
   }();
-  if (sizeof(T) == 8 && a.n_tbins > 0 && a.n_rbins > 0 && !uniform_off) {
+  if (a.n_tbins > 0 && a.n_rbins > 0 && !uniform_off) {
     // uniform ping groups first; the general kernel then takes the groups that one left, and the pings outside every bin
     // two time bins per workgroup (the per-column constants paid once for both) when both rows of accumulators fit
     Args au = a;
-    au.uni_bins = (size_t)2 * a.n_rbins * 12 + epa::kMathTabBytes <= 48 * 1024 ? 2 : 1;
-    const size_t usum = ((size_t)au.uni_bins * a.n_rbins * sizeof(double) + 15) & ~(size_t)15;
+    au.uni_bins = (size_t)2 * a.n_rbins * (sizeof(T) + 4) + epa::kMathTabBytes <= 48 * 1024 ? 2 : 1;
+    const size_t usum = ((size_t)au.uni_bins * a.n_rbins * sizeof(T) + 15) & ~(size_t)15;
     au.cnt_off = (unsigned)usum;
     au.tab_off = (unsigned)((usum + (size_t)au.uni_bins * a.n_rbins * 4 + 15) & ~(size_t)15);
     const size_t ulds = au.tab_off + epa::kMathTabBytes;
     const dim3 ugrid((unsigned)((a.n_tbins + au.uni_bins - 1) / au.uni_bins), (unsigned)C);
 #define EPA_U2(N, K, M)                                                                                  \
   do {                                                                                                   \
-    auto kern = sv_denoise_mvbs_uniform_kernel<N, K, M>;                                                 \
+    auto kern = sv_denoise_mvbs_uniform_kernel<T, N, K, M>;                                                 \
     if (int rc = set_lds(kern, ulds)) return rc;                                                         \
     hipLaunchKernelGGL(kern, ugrid, dim3(epa::kBlock), ulds, st, raw,                                    \
                        reinterpret_cast<const epa::CoefRow*>(coef), alpha2, noise, bin_start,            \
-                       (double*)noise_out, (double*)corr_out, (double*)mvbs_out, (double*)sum_out, cnt_out, au); \
+                       (T*)noise_out, (T*)corr_out, (T*)mvbs_out, (T*)sum_out, cnt_out, au);                \
   } while (0)
 #define EPA_U2M(N, K)                                                                                    \
   do {                                                                                                   \
@@ -1294,11 +1303,11 @@ int launch_pass2(Args& a, const float* raw, const double* coef, const double* al
     if (!drift_off) {
 #define EPA_D2(N, K, M)                                                                                  \
   do {                                                                                                   \
-    auto kern = sv_denoise_mvbs_drift_kernel<N, K, M>;                                                   \
+    auto kern = sv_denoise_mvbs_drift_kernel<T, N, K, M>;                                                 \
     if (int rc = set_lds(kern, ulds)) return rc;                                                         \
     hipLaunchKernelGGL(kern, ugrid, dim3(epa::kBlock), ulds, st, raw,                                    \
                        reinterpret_cast<const epa::CoefRow*>(coef), alpha2, noise, bin_start,            \
-                       (double*)noise_out, (double*)corr_out, (double*)mvbs_out, (double*)sum_out, cnt_out, au); \
+                       (T*)noise_out, (T*)corr_out, (T*)mvbs_out, (T*)sum_out, cnt_out, au);                \
   } while (0)
 #define EPA_D2M(N, K)                                                                                    \
   do {                                                                                                   \

@@ -45,6 +45,6 @@ for src, name, v in sorted(rows, key=lambda r: (r[0], r[1])):
     out.append(f"{name[:92]:92s} {v.get('VGPRs:', '?'):>5s} {v.get('SGPRs:', '?'):>5s} {v.get('ScratchSize [bytes/lane]:', '?'):>8s} "
                f"{v.get('Occupancy [waves/SIMD]:', '?'):>10s} {v.get('LDS Size [bytes/block]:', '?'):>10s}")
 assert all(r[1] for r in rows), "a kernel without a name"
-open(os.path.join(ROOT, "profiles", "r05_kernel_resources.txt"), "w").write("\n".join(out) + "\n")
+open(os.path.join(ROOT, "profiles", "r06_kernel_resources.txt"), "w").write("\n".join(out) + "\n")
 print("\n".join(l for l in out if any(k in l for k in ("fused_sv_mvbs_kernel<double, float, true", "drift_kernel<true, true", "sv_noise_fast_kernel<double, true",
                                                        "sv_complex_fft_kernel<float, double, double, 4, false", "mvbs_of_sv_fixed_kernel<double, true", "kernel  "))))

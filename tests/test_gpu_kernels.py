@@ -647,37 +647,41 @@ def test_fused_chain_equals_the_four_separate_kernels(env, dtype, closed, few_bi
     _chain_equivalence(env, dtype, closed, 45 if few_bins else 203, pn, bin_s, ss_every)
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("bin_s", [100, 300])
-def test_fused_chain_long_uniform_groups(env, bin_s):
+def test_fused_chain_long_uniform_groups(env, bin_s, dtype):
     """Time bins of 100 pings (beyond the 64 per-ping logs of the general kernel, inside the 256 per-ping constants of
     the uniform-group kernel) and of 300 pings (beyond both: the uniform-group kernel hands the bin over) on a file
     whose pings share one range vector."""
-    _chain_equivalence(env, "float64", "left", 620, 20, bin_s, 100000, S=512)
+    _chain_equivalence(env, dtype, "left", 620, 20, bin_s, 100000, S=512)
 
 
-def test_fused_chain_with_a_fine_range_grid(env):
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_fused_chain_with_a_fine_range_grid(env, dtype):
     """0.1-m range bins over 190 m: 1900 bins -- one row of LDS accumulators per workgroup instead of the two the
     uniform-bin kernel otherwise keeps."""
-    _chain_equivalence(env, "float64", "left", 83, 20, 20, 100000, S=1000, rbin=0.1)
+    _chain_equivalence(env, dtype, "left", 83, 20, 20, 100000, S=1000, rbin=0.1)
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("S", [260, 2052, 1000])
 @pytest.mark.parametrize("rbin", [1.0, 0.07])
-def test_fused_chain_sound_speed_jitter_in_a_partial_last_wavefront(env, S, rbin):
+def test_fused_chain_sound_speed_jitter_in_a_partial_last_wavefront(env, S, rbin, dtype):
     """The sound-speed-drift pass 2 (chain_fast.hip: sv_denoise_mvbs_drift_kernel) redoes the columns whose range
     crosses a range-bin edge inside the time bin with the wavefront's lanes spread over the PINGS.  S = 260 / 2052 leave
     two lanes in the row's last wavefront: the pings must be shared among the lanes that exist (round-3 ADVICE: a
     stride of 64 dropped the pings of the missing lanes).  8 m/s of jitter moves the far columns by metres."""
     # time bins of 7 pings: the planner keeps bins of up to 8 pings whole (block_reduce.hip make_plan), which is what the
     # specialised pass-2 kernels serve; the launch trace asserts they ran
-    _chain_equivalence(env, "float64", "left", 143, 20, 7, 1, S=S, rbin=rbin, ss_jitter=8.0,
+    _chain_equivalence(env, dtype, "left", 143, 20, 7, 1, S=S, rbin=rbin, ss_jitter=8.0,
                        expect_kernels=("sv_denoise_mvbs_uniform_kernel", "sv_denoise_mvbs_drift_kernel"))
 
 
-def test_fused_chain_with_empty_time_bins(env):
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_fused_chain_with_empty_time_bins(env, dtype):
     """A 130-s hole in the pings: time bins without a single ping between bins of uniform pings (the uniform-group
     pass 2 writes their fill value) -- and an all-NaN ping block in the noise estimate."""
-    _chain_equivalence(env, "float64", "left", 140, 20, 20, 100000, S=512, gap_after=60)
+    _chain_equivalence(env, dtype, "left", 140, 20, 20, 100000, S=512, gap_after=60)
 
 
 def _chain_equivalence(env, dtype, closed, P, pn, bin_s, ss_every, S=1000, gap_after=None, rbin=1.0, ss_jitter=0.0,
