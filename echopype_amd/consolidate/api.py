@@ -179,9 +179,10 @@ def _lazy_depth(er_lazy, rows, raw, scale, offset, scale_h, offset_h):
     tdt = torch.float64 if er_lazy.dtype == np.dtype("float64") else torch.float32
 
     def make():
-        t, st = ops.depth_rows(scale, offset, coef=rows, mask_raw=raw, shape=shape, dtype=tdt)
         me = ref()
-        if me is not None and me.stats_async() is None:
+        known = me is not None and me.stats_async() is not None  # (left by the pass that binned on this depth)
+        t, st = ops.depth_rows(scale, offset, coef=rows, mask_raw=raw, shape=shape, dtype=tdt, want_stats=not known)
+        if me is not None and not known:
             me.set_stats(st)  # (fulfil() stamps them with the tensor's version)
         return t
 

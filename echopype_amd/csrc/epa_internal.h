@@ -145,5 +145,9 @@ __device__ __forceinline__ float depth_of(float scale, float offset, float range
 
 }  // namespace epa
 
+// reduce_util.hip: echo_range / depth from the coefficient rows as one-piece workgroups (-1: the shape is not served)
+int epa_rows_piece_launch(const float* mask_raw, const void* x, const double* coef, const double* scale,
+                          const double* offset, long long rows, int S, void* out, int dtype, double* workspace,
+                          double* stats_out, hipStream_t st);
 // reduce_util.hip: {min, max, NaN count} partials (3 doubles per workgroup) -> out[3]
 int epa_minmax_final(const double* part, int nparts, double* out, hipStream_t st);

@@ -2,7 +2,9 @@
 //   ds_Sv[range_var].max(skipna=True)            commongrid/api.py:108-110 (range bin edges)
 //   round(float(da.min())), round(float(da.max()))  clean/utils.py:392-395, commongrid/api.py:252-255
 // Two launches: per-workgroup partials (wave __shfl reduction, then LDS), then one workgroup.
-#include "epa_internal.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "sample_math.h"
 
 namespace {
 
@@ -60,13 +62,13 @@ __global__ __launch_bounds__(epa::kBlock) void minmax_partial_kernel(const T* __
 
 __global__ __launch_bounds__(epa::kBlock) void minmax_final_kernel(const double* __restrict__ part,
                                                                    int nparts,
-                                                                   double* __restrict__ out) {
+                                                                   double* __restrict__ out, int stride = 3) {
   __shared__ double slo[4], shi[4], snan[4];
   double lo = __builtin_inf(), hi = -__builtin_inf(), nn = 0.0;
   for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
-    lo = fmin(lo, part[3 * i]);
-    hi = fmax(hi, part[3 * i + 1]);
-    nn += part[3 * i + 2];
+    lo = fmin(lo, part[(size_t)stride * i]);
+    hi = fmax(hi, part[(size_t)stride * i + 1]);
+    nn += part[(size_t)stride * i + 2];
   }
   wave_minmax<double>(lo, hi);
 #pragma unroll
@@ -240,6 +242,138 @@ __global__ __launch_bounds__(epa::kBlock) void depth_rows_kernel(const T* __rest
 }
 }  // namespace
 
+// ---- one-piece workgroups for the affine row passes (round 6) ---------------------------------------------------------
+// echo_range (epa_range_power) and depth = offset + scale * echo_range (epa_depth_rows without the statistics) written
+// from the coefficient rows: a workgroup = ONE 1024-sample piece of one row, 16-byte accesses, then it ends -- the
+// loop-free form that streams at 6.2 TB/s where workgroups striding over the rows reach 5.0-5.4 (DESIGN 4.2, and K1 in
+// sv_power.hip).  NaN where the raw sample is, when the mask is given.  DEPTH: 0 the range itself, 1 the depth.
+namespace {
+constexpr int kPieceSlots = 256, kPieceSlotStride = 16;  // {min, max, NaN count} slots of the statistics, 128 bytes apart
+__global__ void piece_slots_init_kernel(double* slots) {
+  double* p = slots + (size_t)threadIdx.x * kPieceSlotStride;
+  p[0] = __builtin_inf();
+  p[1] = -__builtin_inf();
+  p[2] = 0.0;
+}
+
+// SRC: 0 the range evaluated from the coefficient rows (NaN where the raw sample is, with MASK), 1 read from the array x.
+// STATS: {min, max, NaN count} of what is written -- the workgroup's lanes meet in LDS (ds_min / ds_max on 32 slots, a
+// NaN operand leaves a slot alone), one lane sends three atomics WITHOUT a return value to one of kPieceSlots lines
+// (nobody waits for them: fused_sv_mvbs.hip, round 6), epa_minmax_final folds the slots.
+template <typename T, int DEPTH, bool MASK, int SRC, bool STATS>
+__global__ __launch_bounds__(epa::kBlock) void rows_piece_kernel(const float* __restrict__ raw, const T* __restrict__ x,
+                                                                 const epa::CoefRow* __restrict__ coef,
+                                                                 const double* __restrict__ scale,
+                                                                 const double* __restrict__ offset, int S,
+                                                                 int chunks_per_row, long long pieces, T* __restrict__ out,
+                                                                 int xcd_map, double* __restrict__ slots) {
+  using LM = epa::LaneMap<T>;
+  __shared__ T wlo[STATS ? 32 : 1], whi[STATS ? 32 : 1];
+  __shared__ unsigned wnn;
+  if (STATS) {
+    if (threadIdx.x < 32) {
+      wlo[threadIdx.x] = (T)__builtin_inf();
+      whi[threadIdx.x] = -(T)__builtin_inf();
+    }
+    if (threadIdx.x == 0) wnn = 0u;
+    __syncthreads();
+  }
+  const long long piece = xcd_map ? epa::xcd_contiguous((int)blockIdx.x, (int)pieces) : (long long)blockIdx.x;
+  const long long row = piece / chunks_per_row;
+  const int chunk0 = (int)(piece - row * chunks_per_row) * 1024;
+  epa::CoefRow cr{};
+  if (SRC == 0) cr = coef[row];
+  T a = (T)1, b = (T)0;
+  if (DEPTH) {
+    a = (T)scale[row];
+    b = (T)offset[row];
+  }
+  T lo = (T)__builtin_inf(), hi = -(T)__builtin_inf();
+  unsigned nn = 0u;  // (the wavefront's: a scalar)
+#pragma unroll
+  for (int g = 0; g < LM::NSEG; ++g) {
+    const int s0 = LM::first(chunk0, g);
+    if (s0 >= S) continue;
+    const size_t off = (size_t)row * S + s0;
+    T o[LM::LEN], xin[LM::LEN];
+    epa::RawVec<LM::LEN> in;
+    if (SRC == 0 && MASK) in.load(raw + off);
+    if (SRC == 1) epa::load_vec<T, LM::LEN>(x + off, xin);
+#pragma unroll
+    for (int j = 0; j < LM::LEN; ++j) {
+      T r = SRC == 1 ? xin[j] : (T)epa::row_range(cr, s0 + j);
+      if (SRC == 0 && MASK && !(in.v[j] == in.v[j])) r = epa::M<T>::nan();
+      o[j] = DEPTH ? epa::depth_of(a, b, r) : r;
+      if (STATS) {
+        lo = fmin(lo, o[j]);  // fmin / fmax ignore a NaN operand
+        hi = fmax(hi, o[j]);
+        nn += (unsigned)__builtin_popcountll(__ballot(!(o[j] == o[j])));
+      }
+    }
+    epa::store_vec<T, LM::LEN>(out + off, o);
+  }
+  if (STATS) {
+    __hip_atomic_fetch_min(&wlo[threadIdx.x & 31], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_max(&whi[threadIdx.x & 31], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if ((threadIdx.x & 63) == 0 && nn > 0u) atomicAdd(&wnn, nn);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      double l2 = (double)wlo[threadIdx.x & 31], h2 = (double)whi[threadIdx.x & 31];
+      wave_minmax<double>(l2, h2);
+      if (threadIdx.x == 0) {
+        double* sl = slots + (size_t)(blockIdx.x & (kPieceSlots - 1)) * kPieceSlotStride;
+        if (l2 <= h2) {
+          unsafeAtomicMin(sl + 0, l2);
+          unsafeAtomicMax(sl + 1, h2);
+        }
+        if (wnn > 0u) unsafeAtomicAdd(sl + 2, (double)wnn);
+      }
+    }
+  }
+}
+}  // namespace
+
+// (sv_power.hip's epa_range_power and epa_depth_rows below) -> EPA_OK when the pieces served the call, -1 when the
+// shape does not take the vector form (S not a multiple of the 16-byte access, unaligned buffers, too many pieces).
+// x: the range as an array instead of the coefficient rows; workspace + stats_out: {min, max, NaN count} of the output.
+int epa_rows_piece_launch(const float* mask_raw, const void* x, const double* coef, const double* scale,
+                          const double* offset, long long rows, int S, void* out, int dtype, double* workspace,
+                          double* stats_out, hipStream_t st) {
+  const int need = dtype == EPA_F64 ? 2 : 4;
+  auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+  static const bool off = [] { const char* e = getenv("EPA_ROW_PIECES"); return e && e[0] == '0'; }();  // development knob
+  const int chunks = (S + 1023) / 1024;
+  const long long pieces = rows * chunks;
+  if (off || S % need != 0 || !al16(mask_raw) || !al16(x) || !al16(out) || pieces >= (1ll << 31)) return -1;
+  const epa::CoefRow* cf = reinterpret_cast<const epa::CoefRow*>(coef);
+  const int xm = epa::xcd_map_enabled() ? 1 : 0;
+  const bool stats = stats_out != nullptr;
+  if (stats) {
+    hipLaunchKernelGGL(piece_slots_init_kernel, dim3(1), dim3(kPieceSlots), 0, st, workspace);
+    if (int rc = epa::check_launch("piece_slots_init_kernel")) return rc;
+  }
+#define EPA_RP(T, D, M, SRC, ST)                                                                                   \
+  hipLaunchKernelGGL((rows_piece_kernel<T, D, M, SRC, ST>), dim3((unsigned)pieces), dim3(epa::kBlock), 0, st,      \
+                     mask_raw, (const T*)x, cf, scale, offset, S, chunks, pieces, (T*)out, xm, workspace)
+#define EPA_RP4(T, D)                                                                                              \
+  do {                                                                                                             \
+    if (x) { if (stats) EPA_RP(T, D, false, 1, true); else EPA_RP(T, D, false, 1, false); }                        \
+    else if (mask_raw) { if (stats) EPA_RP(T, D, true, 0, true); else EPA_RP(T, D, true, 0, false); }              \
+    else { if (stats) EPA_RP(T, D, false, 0, true); else EPA_RP(T, D, false, 0, false); }                          \
+  } while (0)
+  if (dtype == EPA_F64) { if (scale) EPA_RP4(double, 1); else EPA_RP4(double, 0); }
+  else { if (scale) EPA_RP4(float, 1); else EPA_RP4(float, 0); }
+#undef EPA_RP4
+#undef EPA_RP
+  if (int rc = epa::check_launch("rows_piece_kernel")) return rc;
+  if (stats) {
+    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(epa::kBlock), 0, st, workspace, kPieceSlots, stats_out,
+                       kPieceSlotStride);
+    return epa::check_launch("minmax_final_kernel");
+  }
+  return EPA_OK;
+}
+
 extern "C" int epa_depth_rows(const void* range, const double* coef, const float* mask_raw, const double* scale,
                               const double* offset, int C, int P, int S, void* out, int dtype, double* workspace,
                               double* stats_out, epa_stream_t stream) {
@@ -252,6 +386,11 @@ extern "C" int epa_depth_rows(const void* range, const double* coef, const float
   hipStream_t st = (hipStream_t)stream;
   const epa::CoefRow* cf = reinterpret_cast<const epa::CoefRow*>(coef);
   double* part = stats_out ? workspace : nullptr;
+  {  // one-piece workgroups where the shape takes 16-byte accesses
+    const int rc = epa_rows_piece_launch(range ? nullptr : mask_raw, range, coef, scale, offset, rows, S, out, dtype, workspace,
+                                         stats_out, st);
+    if (rc >= 0) return rc;
+  }
   if (dtype == EPA_F64)
     hipLaunchKernelGGL(depth_rows_kernel<double>, dim3(grid), dim3(epa::kBlock), 0, st, (const double*)range, cf,
                        mask_raw, scale, offset, rows, S, (double*)out, part);

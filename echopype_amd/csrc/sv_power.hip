@@ -184,20 +184,27 @@ __global__ __launch_bounds__(epa::kBlock) void sv_power_piece_kernel(const float
     tabled = dkeys[2 * c] == dkeys[2 * c + 1];
     trow = table + (size_t)c * S;
   }
-  double lo = __builtin_inf(), hi = -__builtin_inf();
-  unsigned nn = 0u;
-  // (the slot's keys are requested FIRST, with plain loads: their latency hides behind the samples', and a stale value --
-  //  from a cache or from another wavefront's update in flight -- only makes the test below conservative)
   unsigned long long* kslot = STATS ? keys + 3 * (row & (kStatSlots - 1)) : nullptr;
-  unsigned long long kmax = 0ull, kmin = 0ull;
-  if (STATS) {
-    kmax = *reinterpret_cast<volatile unsigned long long*>(kslot + 0);
-    kmin = *reinterpret_cast<volatile unsigned long long*>(kslot + 1);
+  T rall[STATS ? NSEG * LEN : 1];  // STATS: every range value of the lane (for the wavefronts that need them one by one)
+  bool lane_nan = false;           // STATS: one of the lane's range values is NaN
+  // STATS: the raw samples next to the wavefront's 256, requested first (scalar loads of lines the neighbours stream
+  // anyway): is there a valid sample before / after this wavefront in the row?  (see the end)
+  const int w_s0 = chunk * 1024 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 256;
+  float before = __builtin_nanf(""), after = __builtin_nanf("");
+  if (STATS && mask_range) {
+    if (w_s0 > 0) before = raw[(size_t)row * S + w_s0 - 1];
+    if (w_s0 + 256 < S) after = raw[(size_t)row * S + w_s0 + 256];
   }
 #pragma unroll
   for (int g = 0; g < NSEG; ++g) {
     const int s0 = LM::first(chunk * 1024, g);
-    if (s0 >= S) continue;
+    if (s0 >= S) {
+      if (STATS) {
+#pragma unroll
+        for (int j = 0; j < LEN; ++j) rall[g * LEN + j] = epa::M<T>::nan();
+      }
+      continue;
+    }
     const size_t off = (size_t)row * S + s0;
     epa::RawVec<LEN> in;
     in.load(raw + off);
@@ -211,35 +218,62 @@ __global__ __launch_bounds__(epa::kBlock) void sv_power_piece_kernel(const float
       o[j] = epa::cal_power_sample<T>(in.v[j], s0 + j, rk, nspread, nl[j], guard, r);
       if (RANGE || STATS) rg[j] = (mask_range && !(in.v[j] == in.v[j])) ? epa::M<T>::nan() : (T)r;
       if (STATS) {
-        const double x = (double)rg[j];
-        lo = fmin(lo, x);  // fmin / fmax ignore a NaN operand
-        hi = fmax(hi, x);
-        nn += (unsigned)__builtin_popcountll(__ballot(!(x == x)));  // (the wavefront's count, in a scalar register)
+        rall[g * LEN + j] = rg[j];
+        lane_nan |= !(rg[j] == rg[j]);
       }
     }
     epa::store_vec<T, LEN>(out + off, o);
     if (RANGE) epa::store_vec<T, LEN>(range_out + off, rg);
   }
   if (STATS) {
-    // One of kStatSlots slots per row (a single key sees an atomic from nearly every row of a file whose sound speed
-    // drifts: 30 ms of serialised atomics, measured).  A workgroup lives for four samples per lane, so even the
-    // wavefront reduction is too dear to run every time (+35 %, measured): every lane first tests its own values against
-    // the slot's keys as they are now (a stale read only makes the test conservative: the keys move one way), and the
-    // wavefront reduces and touches the slot only if some lane would move a key -- almost never after the first rows.
+    // {min, max, NaN count} of the echo_range.  One of kStatSlots slots per row (a single key sees an atomic from
+    // nearly every row of a file whose sound speed drifts: 30 ms of serialised atomics, measured).  A workgroup lives
+    // for four samples per lane: a per-sample min / max / NaN ballot and a wavefront reduction cost it a third of its
+    // time (round 5: +35 %; with the reduction skipped behind a read of the slot's keys still 1.5-2 ms per 4 G samples --
+    // the read waits for a cache line the others' atomics keep busy; two atomics per wavefront without a return value:
+    // 0.8 ms, round 6).  What is left to skip is the atomics themselves.  The range grows with the sample number
+    // (ra, rb > 0), so a COMPLETE wavefront without a NaN has its smallest value in lane 0's first sample and its
+    // largest in lane 63's last (one ballot, two v_readlane) -- and it can hold the ROW's smallest value only if no valid
+    // sample precedes it in the row, the largest only if none follows: the two neighbouring raw samples, requested
+    // at the start, say so (with the range masked by NaN inputs; else the row's ends are its first and last sample).
+    // By induction over the wavefronts of a row some wavefront that sends holds a value <= (>=) any valid one.  A row
+    // of full-length pings then costs two atomics, not two per wavefront.  Every other wavefront (a NaN inside: the
+    // padded tail of one ping in ten; the end of a row; a row that does not grow) goes through its values one by one
+    // and always sends.
     unsigned long long* k = kslot;
-    const bool need = (hi > -__builtin_inf() && ordered_key(hi) > kmax) || (lo < __builtin_inf() && ordered_key(lo) < kmin);
-    if (__ballot(need) != 0ull) {
+    const unsigned long long nanlanes = __ballot(lane_nan);
+    const bool whole = w_s0 + 256 <= S;  // (scalar) no idle lane
+    double lo, hi;
+    unsigned nn = 0u;
+    bool send_lo = true, send_hi = true;  // (scalar)
+    if (nanlanes == 0ull && whole && rk.ra > 0.0 && rk.rb > 0.0) {
+      const double first = (double)rall[0], last = (double)rall[NSEG * LEN - 1];
+      lo = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(first), 0), __builtin_amdgcn_readlane(__double2loint(first), 0));
+      hi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(last), 63), __builtin_amdgcn_readlane(__double2loint(last), 63));
+      send_lo = mask_range ? !(before == before) : w_s0 == 0;        // (NaN, or the row starts here)
+      send_hi = mask_range ? !(after == after) : w_s0 + 256 >= S;    // (NaN, or the row ends here)
+    } else {
+      lo = __builtin_inf();
+      hi = -__builtin_inf();
+#pragma unroll
+      for (int i = 0; i < NSEG * LEN; ++i) {
+        const double x = (double)rall[i];
+        lo = fmin(lo, x);  // fmin / fmax ignore a NaN operand
+        hi = fmax(hi, x);
+        const int s_i = LM::first(chunk * 1024, i / LEN) + i % LEN;  // (an idle lane's placeholder is not a value)
+        nn += (unsigned)__builtin_popcountll(__ballot(s_i < S && !(x == x)));
+      }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
         lo = fmin(lo, __shfl_down(lo, o, 64));
         hi = fmax(hi, __shfl_down(hi, o, 64));
       }
-      if ((threadIdx.x & 63) == 0) {
-        if (hi > -__builtin_inf()) atomicMax(k + 0, ordered_key(hi));
-        if (lo < __builtin_inf()) atomicMin(k + 1, ordered_key(lo));
-      }
     }
-    if (nn > 0u && (threadIdx.x & 63) == 0) atomicAdd(k + 2, (unsigned long long)nn);
+    if ((threadIdx.x & 63) == 0) {
+      if (send_hi && hi > -__builtin_inf()) atomicMax(k + 0, ordered_key(hi));
+      if (send_lo && lo < __builtin_inf()) atomicMin(k + 1, ordered_key(lo));
+      if (nn > 0u) atomicAdd(k + 2, (unsigned long long)nn);
+    }
   }
 }
 
@@ -330,7 +364,13 @@ int launch(const float* raw, const double* coef, int C, int P, int S, int cal_ty
   //  variants the strided-rows kernel serves faster: 13.6-13.9 against 14.2-15.4 ms and 8.7-9.2 against 10.3-10.7 ms per
   //  4 G samples; a workgroup that lives for four samples per lane pays for the statistics every time.  fp32 and plain
   //  fp64 Sv / TS take the pieces: profiles/r05_k1_pieces_ab.txt)
-  if (vec && !pieces_off && rows * chunks_per_row < (1ll << 31) && !(sizeof(T) == 8 && (range_out || stats_out))) {
+  // (EPA_K1_F64_STATS_PIECES=1: the pieces for fp64 with the statistics, too -- round 6 measured them again with the
+  //  statistics' cost cut (no key reads, atomics from the row-end wavefronts only): 9.5-10.7 against 8.9-9.3 ms per 4 G
+  //  samples for the strided rows, which keep the case; fp32 gained, 6.7 -> 6.1-6.3.  profiles/r06_k1_pieces_ab.txt)
+  const char* pf = getenv("EPA_K1_F64_STATS_PIECES");
+  const bool f64_stats_pieces = pf && pf[0] == '1';
+  if (vec && !pieces_off && rows * chunks_per_row < (1ll << 31) &&
+      !(sizeof(T) == 8 && (range_out || (stats_out && !f64_stats_pieces)))) {
     const dim3 pgrid((unsigned)(rows * chunks_per_row));
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(part);
     const int xm = epa::xcd_map_enabled() ? 1 : 0;
@@ -436,6 +476,11 @@ extern "C" int epa_range_power(const float* raw, const double* coef, int C, int 
   EPA_CHECK_ARG(C > 0 && P > 0 && S > 0, "epa_range_power: C=%d P=%d S=%d must be positive", C, P, S);
   EPA_CHECK_ARG(out_dtype == EPA_F64 || out_dtype == EPA_F32, "epa_range_power: bad out_dtype %d", out_dtype);
   const long long rows = (long long)C * P;
+  {  // one-piece workgroups (reduce_util.hip) where the shape takes 16-byte accesses
+    const int rc = epa_rows_piece_launch((flags & EPA_FLAG_MASK_RANGE) ? raw : nullptr, nullptr, coef, nullptr, nullptr, rows,
+                                         S, range_out, out_dtype, nullptr, nullptr, (hipStream_t)stream);
+    if (rc >= 0) return rc;
+  }
   const int chunks = (S + epa::kBlock - 1) / epa::kBlock;
   long long gx = 16384 / chunks;
   if (gx < 1) gx = 1;

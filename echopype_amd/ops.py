@@ -446,10 +446,11 @@ def affine_rows(x, scale, offset):
     return out
 
 
-def depth_rows(scale, offset, *, range=None, coef=None, mask_raw=None, shape=None, dtype=None):
+def depth_rows(scale, offset, *, range=None, coef=None, mask_raw=None, shape=None, dtype=None, want_stats=True):
     """depth = offset[c,p] + scale[c,p] * echo_range -> (depth (C,P,S), f64 device tensor {nanmin, nanmax, NaN count} of
-    it).  echo_range as the array ``range`` or evaluated from the coefficient rows ``coef`` (+ ``mask_raw``: NaN where
-    the raw power sample is), then ``shape`` = (C, P, S) and ``dtype`` say what to produce."""
+    it, or None without ``want_stats``: from the coefficient rows that is the loop-free one-piece kernel).  echo_range as
+    the array ``range`` or evaluated from the coefficient rows ``coef`` (+ ``mask_raw``: NaN where the raw power sample
+    is), then ``shape`` = (C, P, S) and ``dtype`` say what to produce."""
     if range is not None:
         C, P, S = range.shape
         dtype, dev = range.dtype, range.device
@@ -457,8 +458,10 @@ def depth_rows(scale, offset, *, range=None, coef=None, mask_raw=None, shape=Non
         C, P, S = shape
         dev = coef.device
     out = torch.empty((C, P, S), dtype=dtype, device=dev)
-    ws = torch.empty(3 * 16384, dtype=torch.float64, device=dev)  # EPA_DEPTH_ROWS_WS_DOUBLES
-    stats = torch.empty(3, dtype=torch.float64, device=dev)
+    ws = stats = None
+    if want_stats:
+        ws = torch.empty(3 * 16384, dtype=torch.float64, device=dev)  # EPA_DEPTH_ROWS_WS_DOUBLES
+        stats = torch.empty(3, dtype=torch.float64, device=dev)
     call("epa_depth_rows", _p(range), _p(coef), _p(mask_raw), _p(scale), _p(offset), C, P, S, _p(out), _DT[dtype],
          _p(ws), _p(stats), _stream())
     return out, stats
