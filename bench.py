@@ -56,10 +56,10 @@ WORKLOADS = {
     "small": (4, 20_000, 2000, 50, 50),
     "next": (4, 100_000, 2000, 2, 2),  # SURVEY 8f rows through their API entry points (scripts/perf_masks.py's volume)
 }
-DEFAULT_LINES = ["cfg3", "cfg3:ss2000", "cfg3:f32", "cfg2", "cfg2:f32", "cfg2:int16", "cfg2:sv", "cfg2:sv32", "api", "api:chain", "api:pcie",
+DEFAULT_LINES = ["cfg3", "cfg3:ss2000", "cfg3:f32", "cfg2", "cfg2:f32", "cfg2:int16", "cfg2:int16f32", "cfg2:bins", "cfg2:int16bins", "cfg2:sv", "cfg2:sv32", "api", "api:chain", "api:pcie",
                  "cfg4", "cfg4:f32", "cfg4:planes64", "next:depth", "next:depthw", "next:masks", "next:nasc", "cfg5:one", "cfg5"]
 TILE_PINGS = 250_000
-DT = {"f32": "float32", "f64": "float64", "sv32": "float32"}
+DT = {"f32": "float32", "f64": "float64", "sv32": "float32", "int16f32": "float32"}
 
 
 def parse():
@@ -348,7 +348,8 @@ def run_ek60(ctx, name, variant, cpu):
     args, torch, ops, sharding = ctx.args, ctx.torch, ctx.ops, ctx.sharding
     C, P, S = WORKLOADS[name][:3]
     chain = name == "cfg3"
-    i16 = variant == "int16" and not chain
+    i16 = variant.startswith("int16") and not chain
+    bins_only = variant.endswith("bins") and not chain  # no Sv array out: what the input's width is worth (2 / 4 B/sample)
     k1 = variant in ("sv", "sv32") and not chain  # BASELINE configs[1] to the letter: the compute_Sv kernel alone (K1)
     ss_every = 2000 if variant == "ss2000" else args.ss_every
     dt = ctx.dt
@@ -359,7 +360,7 @@ def run_ek60(ctx, name, variant, cpu):
     n_t = P // 20
     r_max = float((S - 1) * 2.56e-4 * float(d["sound_speed_indicative"].max()) / 2)  # analytic for this recipe
     n_r = len(np.arange(0, r_max + 1.0, 1.0)) - 1
-    sv = torch.empty((C, P, S), dtype=dt, device="cuda") if not chain else None
+    sv = torch.empty((C, P, S), dtype=dt, device="cuda") if not (chain or bins_only) else None
     mvbs = torch.empty((C, n_t, n_r), dtype=dt, device="cuda")
 
     def one_pass(timer):
@@ -375,21 +376,24 @@ def run_ek60(ctx, name, variant, cpu):
         elif k1:
             ops.sv_power(d["backscatter_r"], coef, dtype=dt, want_range=False, out=sv)
         elif i16:
-            ops.sv_mvbs_fused_i16(d["raw_i16"], d["n_valid"], coef, bs, n_t, 1.0, n_r, dtype=dt, sv_out=sv, mvbs_out=mvbs)
+            ops.sv_mvbs_fused_i16(d["raw_i16"], d["n_valid"], coef, bs, n_t, 1.0, n_r, dtype=dt, sv_out=sv, mvbs_out=mvbs,
+                                  want_sv=not bins_only)
         else:
-            ops.sv_mvbs_fused(d["backscatter_r"], coef, bs, n_t, 1.0, n_r, dtype=dt, sv_out=sv, mvbs_out=mvbs)
+            ops.sv_mvbs_fused(d["backscatter_r"], coef, bs, n_t, 1.0, n_r, dtype=dt, sv_out=sv, mvbs_out=mvbs,
+                              want_sv=not bins_only)
         if timer is not None:
             timer.stop()
 
     passes = ctx.passes(name)
     elapsed, kernel_ms = ctx.timed(one_pass, passes)
     n = C * P * S
-    bps = BYTES_PER_SAMPLE[ctx.dtype] - (2 if i16 else 0)
+    bps = BYTES_PER_SAMPLE[ctx.dtype] - (2 if i16 else 0) - ((8 if ctx.dtype == "float64" else 4) if bins_only else 0)
     if chain:  # two sweeps over the 4-B input + Sv, Sv_corrected (+ Sv_noise) out: SURVEY 8d line E = 32 / 20 B
         bps = 2 * BYTES_PER_SAMPLE[ctx.dtype] + ((BYTES_PER_SAMPLE[ctx.dtype] - 4) if args.chain_outputs == "all" else 0)
-    key = f"{name}:{ctx.dtype}" + (":int16" if i16 else "") + (":sv" if k1 else "") + \
+    key = f"{name}:{ctx.dtype}" + (":int16" if i16 else "") + (":bins" if bins_only else "") + (":sv" if k1 else "") + \
         (":corrected" if chain and args.chain_outputs != "all" else "") + (f":ss{ss_every}" if chain and ss_every != 1 else "")
     what = ("compute_Sv alone (K1, echo_range left lazy), Sv out" if k1 else
+            "fused compute_Sv->compute_MVBS(20s x 1m), MVBS out only" if bins_only else
             "fused compute_Sv->compute_MVBS(20s x 1m), Sv+MVBS out" if not chain else
             "compute_Sv->remove_background_noise(20x50,3dB)->compute_MVBS(20s x 1m) in two sweeps, Sv+"
             + ("Sv_noise+" if args.chain_outputs == "all" else "") + "Sv_corrected+MVBS out")

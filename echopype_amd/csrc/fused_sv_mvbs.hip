@@ -267,7 +267,7 @@ struct PingLoad<float> {
     a = *reinterpret_cast<const float2*>(row + sA);
     if (hasB) b = *reinterpret_cast<const float2*>(row + sB);
   }
-  __device__ __forceinline__ void resolve(float2& A, float2& B, int, int, int, int) const {
+  __device__ __forceinline__ void resolve(float2& A, float2& B, int, int, int, bool) const {
     A = a;
     B = b;
   }
@@ -294,9 +294,12 @@ struct PingLoad<int16_t> {
     constexpr float kIndex2Power = 0.011758984205624266f;
     return make_float2((float)(short)(w & 0xffffu) * kIndex2Power, (float)(short)(w >> 16) * kIndex2Power);
   }
-  __device__ __forceinline__ void resolve(float2& A, float2& B, int sA, int sB, int nv, int) const {
-    // (uniform per wavefront in the usual case: a ping recorded at full length has no padding to test for)
-    if (nv >= sB + 2) {
+  // ``full`` (a scalar): every sample of the wavefront's 256 is a recorded one -- the usual case, a ping recorded at
+  // full length -- and no lane tests for padding (round 6: the per-lane test, and the finite-value test the kernel
+  // then repeated on values that cannot be anything else, made the int16 source 15-18 % SLOWER than the float one
+  // wherever the Sv store did not hide it: fp32 out 7.3 against 6.2 ms, bins only 6.4 against 5.5 per 4 G samples)
+  __device__ __forceinline__ void resolve(float2& A, float2& B, int sA, int sB, int nv, bool full) const {
+    if (full) {
       A = unpack_all(a);
       B = unpack_all(b);
     } else {
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES > 4 ? EPA_FUSED_MI
   // ... and, for the variants that also carry the coordinate's {min, max, NaN count}, a column's fl(s * ra) likewise
   // (eight more registers: round 6 found those variants at 128 VGPRs + 32 B of scratch per lane, and a scratch reload
   // inside the ping loop waits for every store in flight: 2.12 instead of 1.94 ms per 0.8 G samples)
-  constexpr bool SRA_LDS = RMAX && sizeof(T) == 8;
+  constexpr bool SRA_LDS = (RMAX || std::is_same<RawT, int16_t>::value) && sizeof(T) == 8;  // (the int16 source: likewise)
   __shared__ double col_sra[SRA_LDS ? kChunk : 1];
   __shared__ unsigned long long wg_keys[2];  // RMAX: the workgroup's {max key, min key} and NaN count (see the end)
   __shared__ unsigned wg_nnan;
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES > 4 ? EPA_FUSED_MI
   // (kernel parameters, not members of ``a``: read-only + restrict is what makes the per-ping reads scalar loads)
   const double* __restrict__ dsc_c = DEPTH ? dscale + (size_t)c * a.P : nullptr;
   const double* __restrict__ dof_c = DEPTH ? doffset + (size_t)c * a.P : nullptr;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (wave: a scalar)
   double xmax = -__builtin_inf(), xmin = __builtin_inf();
   unsigned nnan = 0u;
 
@@ -412,16 +415,20 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES > 4 ? EPA_FUSED_MI
       nxtDs = uniform(dsc_c[pb < pe ? pb : 0]);
       nxtDo = uniform(dof_c[pb < pe ? pb : 0]);
     }
-    if (pb < pe) nxt.issue(raw_c + (size_t)pb * S, sA, sB, hasB, s4, S);
+    int nxtNv = nv_c && pb < pe ? nv_c[pb] : S;  // (the recorded length of the next ping, requested a ping ahead like its row:
+    if (pb < pe) nxt.issue(raw_c + (size_t)pb * S, sA, sB, hasB, s4, S);  //  read where it is used it stalled every ping)
     for (int p = pb; p < pe; ++p) {
       const epa::CoefRow r = nxtR;
       const double curDs = nxtDs, curDo = nxtDo;
       const size_t row_off = (size_t)p * S;
-      const int nv = nv_c ? nv_c[p] : S;
+      const int nv = nxtNv;
       float2 inA, inB;
-      nxt.resolve(inA, inB, sA, sB, nv, lane);
+      // (scalar) int16 source: no padding inside this wavefront's samples of the ping, hence every value finite
+      const bool full = nv_c != nullptr && nv >= chunk0 + wave * 256 + 256;
+      nxt.resolve(inA, inB, sA, sB, nv, full);
       if (p + 1 < pe) {
         nxtR = rowp0[p + 1];
+        if (nv_c) nxtNv = nv_c[p + 1];
         if (DEPTH) {
           nxtDs = uniform(dsc_c[p + 1]);
           nxtDo = uniform(dof_c[p + 1]);
@@ -454,8 +461,8 @@ __global__ __launch_bounds__(epa::kBlock, EPA_FUSED_MIN_WAVES > 4 ? EPA_FUSED_MI
 #if EPA_FUSED_LEAN
       {
         const double xa = fma(SRA_LDS ? col_sra[eA] : col[0].sra, r.rb, r0v);
-        const bool bad = not_finite(inA.x) | not_finite(inA.y) | not_finite(inB.x) | not_finite(inB.y) |
-                         !(xa - r.shift > 0.0);
+        bool bad = !(xa - r.shift > 0.0);
+        if (!full) bad = bad | not_finite(inA.x) | not_finite(inA.y) | not_finite(inB.x) | not_finite(inB.y);
         // (scalar) ra, rb > 0, and the row's other coefficients are numbers: a NaN / inf gain, absorption or constant
         // makes Sv NaN / inf with finite raw samples -- the general forms skip such values, the lean ones would add them
         bool kpos = (__double2hiint(r.ra) > 0) & (__double2hiint(r.rb) > 0) & finite_bits(r.g) & finite_bits(r.A0) &
