@@ -371,15 +371,18 @@ __global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 4 : 1) void sv_noise_
     RowCache<T> rc;
     float2 nA = make_float2(0.f, 0.f), nB = nA;
     epa::CoefRow nxtR = rowp0[pb];
+    double nxtA2 = a2p[pb];  // (requested a ping ahead like the row: a scalar load consumed where it is issued stalls the ping)
     nA = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sA);
     if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + (size_t)pb * S + sB);
     int left = pbk0 == 0 ? a.ping_num - a.ping_phase : a.ping_num, g = 0;  // pings left in the current ping block
     for (int p = pb; p < pe; ++p) {
       const epa::CoefRow r = nxtR;
+      const double curA2 = nxtA2;
       const size_t row_off = (size_t)p * S;
       const float2 inA = nA, inB = nB;
       if (p + 1 < pe) {  // software prefetch of the next ping
         nxtR = rowp0[p + 1];
+        nxtA2 = a2p[p + 1];
         nA = *reinterpret_cast<const float2*>(raw_c + row_off + S + sA);
         if (hasB) nB = *reinterpret_cast<const float2*>(raw_c + row_off + S + sB);
       }
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(epa::kBlock, sizeof(T) == 8 ? 4 : 1) void sv_noise_
           }
         }
       }
-      const T g_ = (T)r.g, a2 = (T)r.alpha2, na2 = (T)a2p[p];
+      const T g_ = (T)r.g, a2 = (T)r.alpha2, na2 = (T)curA2;
       T A0 = (T)r.A0;
       double r0v = r.r0;
       asm volatile("" : "+v"(A0), "+v"(r0v));  // one copy per ping into vector registers, not one per sample
