@@ -165,7 +165,10 @@ class CalibrateBase(abc.ABC):
         if isinstance(a, DeviceArray):
             t = a.tensor
             return t if dtype is None or t.dtype == dtype else t.to(dtype)
-        return ops.to_device(np.asarray(getattr(a, "values", a)), dtype=dtype, device=self.device)
+        a = np.asarray(getattr(a, "values", a))
+        if a.nbytes <= 2048:  # (per-channel vectors and pulse-length tables: kept in HBM by content, ops.to_device_small)
+            return ops.to_device_small(a, dtype=dtype, device=self.device)
+        return ops.to_device(a, dtype=dtype, device=self.device)
 
     @staticmethod
     def defer_enabled():

@@ -217,8 +217,8 @@ def _mvbs_of_array_without_waiting(ds_Sv, sv_t, rows, range_var, range_bin_m, pi
     if bound is None or not np.isfinite(bound):
         return None
     ping_time = np.asarray(ds_Sv["ping_time"].values).astype("datetime64[ns]", copy=False)
-    ns = ping_time.view(np.int64)
-    if ns.size == 0 or np.any(ns[1:] < ns[:-1]) or ns[0] == np.iinfo(np.int64).min:  # unsorted pings, NaT
+    ns, sorted_valid, _ = ops.ping_time_facts(ping_time, want_device=False)
+    if not sorted_valid:  # unsorted pings, NaT
         return None
     n_cap = len(np.arange(0, bound + range_bin_m, range_bin_m)) - 1
     stats = rng_d.stats_async() if n_cap >= 1 else None
@@ -226,7 +226,7 @@ def _mvbs_of_array_without_waiting(ds_Sv, sv_t, rows, range_var, range_bin_m, pi
         return None
     C, P, S = sv_t.shape
     e0, dt, n_t = resample_edges(ping_time, ping_time_bin, sorted_valid=True)
-    bin_start = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t, closed=closed)
+    bin_start = ops.time_bin_offsets(ops.ping_time_facts(ping_time)[2], e0, dt, n_t, closed=closed)
     try:
         res = ops.mvbs(sv_t, bin_start, n_t, range_bin_m, n_cap, coef=rows, coef_as_stored=True, skipna=skipna,
                        closed=closed, fill_value=fill_value)
@@ -303,9 +303,9 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
             or tuple(rng_da.dims) != dims or src.echo_range.coef_rows() is not src.coef or not src.intact():
         return None  # (also: an Sv deferred by something else than compute_Sv, e.g. remove_background_noise)
     ping_time = np.asarray(ds_Sv["ping_time"].values).astype("datetime64[ns]", copy=False)
-    ns = ping_time.view(np.int64)
-    # unsorted, or NaT (INT64_MIN: the smallest value, so in a sorted array it could only be the first)
-    if ns.size == 0 or np.any(ns[1:] < ns[:-1]) or ns[0] == np.iinfo(np.int64).min:
+    # (kept with the array when it is resident data, EchoData.to_device: no O(P) pass, no upload per call)
+    ns, sorted_valid, _ = ops.ping_time_facts(ping_time, want_device=False)
+    if not sorted_valid:  # unsorted, NaT, or no ping at all
         return None
     e0, dt, n_t = resample_edges(ping_time, ping_time_bin, sorted_valid=True)
     C, P, S = d.shape
@@ -329,7 +329,7 @@ def _mvbs_of_deferred_sv(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_valu
     n_cap = len(np.arange(0, r_cap + range_bin_m, range_bin_m)) - 1 if np.isfinite(r_cap) else 0
     if n_cap < 1:
         return None
-    bin_start = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t)
+    bin_start = ops.time_bin_offsets(ops.ping_time_facts(ping_time)[2], e0, dt, n_t)
     res = None
     try:
         if depth is not None:
@@ -419,8 +419,8 @@ def _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_v
             or p.echo_range.coef_rows() is not p.coef:
         return None
     ping_time = np.asarray(ds_Sv["ping_time"].values).astype("datetime64[ns]", copy=False)
-    ns = ping_time.view(np.int64)
-    if ns.size == 0 or np.any(ns[1:] < ns[:-1]) or ns[0] == np.iinfo(np.int64).min:  # unsorted pings, NaT
+    ns, sorted_valid, _ = ops.ping_time_facts(ping_time, want_device=False)
+    if not sorted_valid:  # unsorted pings, NaT
         return None
     e0, dt, n_t = resample_edges(ping_time, ping_time_bin, sorted_valid=True)
     C, P, S = d.shape
@@ -442,7 +442,7 @@ def _mvbs_of_deferred_clean(ds_Sv, range_var, range_bin_m, ping_time_bin, fill_v
     n_cap = len(np.arange(0, r_cap + range_bin_m, range_bin_m)) - 1 if np.isfinite(r_cap) else 0
     if n_cap < 1:
         return None
-    bin_start = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t)
+    bin_start = ops.time_bin_offsets(ops.ping_time_facts(ping_time)[2], e0, dt, n_t)
     res = None
     try:
         res = ops.sv_denoise_mvbs(p.raw, p.coef, src.a2, src.noise, src.ping_num, float(src.snr), bin_start, n_t,

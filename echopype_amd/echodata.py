@@ -66,6 +66,13 @@ class EchoData:
                     mirror.flags.writeable = False
                 ds.data_vars[name] = DataArray(DeviceArray(ops.to_device(host, device=device), host=mirror), da.dims,
                                                da.coords, da.attrs, name)
+            # the ping_time coordinate: resident like the samples -- its int64 twin goes up now and stays with the (from
+            # here on read-only) host array, so that compute_MVBS neither scans nor uploads it per call
+            if gname != "Environment" and "ping_time" in ds.coords:
+                pt = ds.coords["ping_time"].values
+                if isinstance(pt, np.ndarray) and pt.dtype == np.dtype("datetime64[ns]"):
+                    pt.flags.writeable = False
+                    ops.ping_time_facts(pt)
         return self
 
     def __repr__(self):

@@ -55,8 +55,8 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
     raw, coef, flags, tau_eff = cal._power_inputs("Sv")
     C, P, S = raw.shape
     ping_time = np.asarray(cal.beam["ping_time"].values).astype("datetime64[ns]", copy=False)
-    ns = ping_time.view(np.int64)
-    if np.any(ns[1:] < ns[:-1]) or (ns.size and ns.min() == np.iinfo(np.int64).min):  # unsorted, or NaT (INT64_MIN)
+    ns, sorted_valid, _ = ops.ping_time_facts(ping_time, want_device=False)
+    if ns.size and not sorted_valid:  # unsorted, or NaT (INT64_MIN)
         if _shard is not None:
             raise NotImplementedError("a ping shard needs sorted, valid ping times")
         ds_Sv = _compute_cal("Sv", echodata, **cal_kw)  # unsorted / NaT pings: generic path
@@ -83,7 +83,7 @@ def compute_Sv_MVBS(echodata, *, range_bin="20m", ping_time_bin="20s", skipna=Tr
         e0, n_t = e0 + first_bin * dt, last_bin - first_bin + 1
         if range_var_max is None:
             r_cap = g_cap
-    bin_start = ops.time_bin_offsets(ops.to_device(ns), e0, dt, n_t)
+    bin_start = ops.time_bin_offsets(ops.ping_time_facts(ping_time)[2], e0, dt, n_t)
     n_cap = len(np.arange(0, r_cap + range_bin_m, range_bin_m)) - 1 if np.isfinite(r_cap) else 0
     # degenerate grid (one sample per ping, no valid range) or a kernel that declines (e.g. a range grid too fine for the
     # LDS accumulators): the two calls deal with it.  On a shard the fallback changes the collectives that follow, so

@@ -94,6 +94,7 @@ class _Uploader:
             slot[1] = ev
         cur.wait_event(ev)
         out.record_stream(cur)  # (allocated on the upload stream, used on the current one)
+        out._epa_ready = ev  # (a holder that hands the tensor to ANOTHER stream later makes that stream wait for it)
         return out
 
 
@@ -210,6 +211,77 @@ def to_device(a, dtype=None, device=None):
     if dev.type != "cuda":
         return torch.from_numpy(a if a.flags.writeable else a.copy()).to(dev)
     return _uploader(dev).upload(a)
+
+
+# ---- what does not change from call to call stays in HBM ----------------------------------------------------------------
+_SMALL = {}        # (device, dtype, shape, bytes) -> tensor: per-channel tables and vectors (<= 2 KiB), the same for every
+_SMALL_MAX = 256   # file of a survey; read-only by contract (kernel inputs)
+
+
+def to_device_small(a, dtype=None, device=None):
+    """``to_device`` for a tiny parameter array (a (C,) vector, a (C, K) table): the device copy is kept, keyed on the
+    CONTENT, and handed out again -- a call then uploads nothing for parameters it shares with the previous call (six
+    staging copies and events per compute_Sv, a quarter of its host time).  Larger arrays take ``to_device``.  The
+    tensors are shared: nobody writes to them."""
+    a = np.ascontiguousarray(a)
+    if dtype is not None:
+        want = np.dtype(str(dtype).replace("torch.", ""))
+        if a.dtype != want:
+            a = a.astype(want)
+    if a.nbytes > 2048 or a.nbytes == 0:
+        return to_device(a, device=device)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (dev, a.dtype.str, a.shape, a.tobytes())
+    ent = _SMALL.get(key)
+    if ent is None:
+        if len(_SMALL) >= _SMALL_MAX:
+            _SMALL.clear()
+        t = to_device(a, device=dev)
+        ev = getattr(t, "_epa_ready", None)
+        if ev is not None:
+            ev.synchronize()  # (once per distinct content: afterwards the copy is there for every stream)
+        _SMALL[key] = ent = t
+    return ent
+
+
+_PING_NS = {}  # id(ndarray) -> (weakref to it, int64 view, sorted and valid?, {device: tensor})
+
+
+def ping_time_facts(ping_time, want_device=True):
+    """(int64 ns view, sorted without NaT?, int64 device tensor | None) of a datetime64[ns] ping_time coordinate.  For an array
+    that cannot be written to (``EchoData.to_device`` marks the beam groups' ping_time so -- resident data, like the
+    samples) the three are kept with the ARRAY OBJECT: the O(P) look at the time stamps and their 8 P-byte upload are
+    then paid once per file, not once per call.  A writeable array is looked at and uploaded every time."""
+    import weakref
+
+    pt = np.asarray(ping_time)
+    if pt.dtype != np.dtype("datetime64[ns]"):
+        pt = pt.astype("datetime64[ns]")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ent = _PING_NS.get(id(pt)) if not pt.flags.writeable else None
+    if ent is not None and ent[0]() is pt:
+        _, ns, ok, tens = ent
+    else:
+        ns = pt.view(np.int64)
+        # unsorted, or NaT (INT64_MIN: the smallest value, so in a sorted array it could only be the first)
+        ok = bool(ns.size) and not bool(np.any(ns[1:] < ns[:-1])) and ns[0] != np.iinfo(np.int64).min
+        tens = {}
+        if not pt.flags.writeable:
+            key = id(pt)
+            _PING_NS[key] = (weakref.ref(pt, lambda _r, k=key: _PING_NS.pop(k, None)), ns, ok, tens)
+    if not want_device:
+        return ns, ok, None
+    t = tens.get(dev)
+    if t is None:
+        t = to_device(ns, device=dev)
+        tens[dev] = t
+    else:  # (uploaded under another call's stream: this one waits for that copy on the device)
+        ev = getattr(t, "_epa_ready", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+    return ns, ok, t
 
 
 def _mode_of(t, C, P):
