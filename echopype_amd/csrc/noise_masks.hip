@@ -1210,6 +1210,10 @@ struct FuseArgs {
   double* rh;
   int* rn;
   int P, skip_same;
+  // the run form (round 6): row_interval_blocks_kernel takes the rows of the long runs of the channels that differ (tables
+  // ilo / ihi indexed by the row's slot); row_running_sum_kernel only the rows some staged ping still needs (need_w)
+  const int* row_slot;
+  const uint8_t* need_w;
 };
 
 template <typename T>
@@ -1231,6 +1235,7 @@ __global__ __launch_bounds__(kBlock) void row_running_sum_kernel(const T* __rest
   for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
     const long long chan = row / fa.P;
     if (fa.skip_same && fa.differ[chan] == 0) continue;  // uniform per workgroup (row_interval_blocks_kernel has it)
+    if (fa.need_w && !fa.need_w[row]) continue;           // (uniform) no ping left to the staged kernels reads this row
     __syncthreads();
     if (threadIdx.x == 0) any_inf = 0;
     const T* svr = sv + (size_t)row * S;
@@ -1371,9 +1376,19 @@ __global__ __launch_bounds__(kBlock) void row_interval_blocks_kernel(const T* __
   constexpr int kCols = 8; // columns per lane whose interval is kept in registers (rows up to 2048 samples)
   long long have = -1;
   int clo[kCols], chi[kCols];
-  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
-    const long long chan = row / fa.P;
-    if (fa.differ[chan] != 0) continue;  // uniform per workgroup
+  // (the run form walks CONSECUTIVE rows per workgroup: the interval table in registers changes with the run, not with
+  //  every row)
+  const long long per = (rows + gridDim.x - 1) / gridDim.x;
+  for (long long it = 0; it < per; ++it) {
+    const long long row = fa.row_slot ? (long long)blockIdx.x * per + it : (long long)blockIdx.x + it * gridDim.x;
+    if (row >= rows) break;
+    long long chan = row / fa.P;
+    if (fa.row_slot) {  // uniform per workgroup
+      if (fa.differ[chan] == 0 || fa.row_slot[row] < 0) continue;
+      chan = fa.row_slot[row];
+    } else if (fa.differ[chan] != 0) {
+      continue;
+    }
     if (chan != have) {
       have = chan;
 #pragma unroll
@@ -1506,6 +1521,17 @@ __device__ __forceinline__ int bound_hint(const T* __restrict__ row, int n, T v,
 // registers; the fp64 instantiation spills 12 dwords outside the loop over neighbours).
 constexpr int kStageRows = 8, kStageLoads = 3, kStageCap = kStageLoads * kBlock - 1, kSpanMax = 512;
 
+// Runs (round 6): inside a channel whose pings do not all share one range vector, the pings of a RUN that does -- a
+// recorded sound speed that holds for two thousand pings -- take the sliding route when their whole ping window lies
+// inside the run (``elig``, per ping; see the run kernels below); a group of pings that are all eligible is none of the
+// lean / staged kernels' business.
+__device__ __forceinline__ bool group_all_eligible(const uint8_t* __restrict__ elig, long long row0, int nrows) {
+  if (!elig) return false;
+  bool all = true;
+  for (int i = 0; i < nrows; ++i) all = all && elig[row0 + i] != 0;
+  return all;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock, 3) void pool_value_mean_staged_kernel(PoolValueArgs<T> a, int C,
                                                                         const double* __restrict__ wh,
@@ -1513,7 +1539,8 @@ __global__ __launch_bounds__(kBlock, 3) void pool_value_mean_staged_kernel(PoolV
                                                                         const int* __restrict__ wn,
                                                                         const uint8_t* __restrict__ dirty,
                                                                         const int* __restrict__ differ,
-                                                                        const uint8_t* __restrict__ todo) {
+                                                                        const uint8_t* __restrict__ todo,
+                                                                        const uint8_t* __restrict__ elig) {
   __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
   // seg_r[2 + i] = range[kmin + i], two -inf before and two +inf behind: the three candidate positions around a guess
   // are tested without a bounds check
@@ -1525,8 +1552,12 @@ __global__ __launch_bounds__(kBlock, 3) void pool_value_mean_staged_kernel(PoolV
   {  // (uniform) a workgroup with nothing to do -- the usual case behind the lean kernel -- leaves before the tables
     bool any = false;
     const int gpc = (a.P + kStageRows - 1) / kStageRows;
-    for (long long grp = blockIdx.x; grp < (long long)C * gpc && !any; grp += gridDim.x)
-      any = differ[grp / gpc] != 0 && (!todo || todo[(long long)blockIdx.y * ((long long)C * gpc) + grp] != 0);
+    for (long long grp = blockIdx.x; grp < (long long)C * gpc && !any; grp += gridDim.x) {
+      const long long cc = grp / gpc;
+      const int q0 = (int)(grp - cc * gpc) * kStageRows;
+      any = differ[cc] != 0 && (!todo || todo[(long long)blockIdx.y * ((long long)C * gpc) + grp] != 0) &&
+            !group_all_eligible(elig, cc * a.P + q0, min(kStageRows, a.P - q0));
+    }
     if (!any) return;
   }
   const epa::MathTabs mt = epa::build_math_tabs(tabs);
@@ -1544,6 +1575,7 @@ __global__ __launch_bounds__(kBlock, 3) void pool_value_mean_staged_kernel(PoolV
     if (todo && !todo[(long long)blockIdx.y * ngroups + grp]) continue;
     const int p0 = (int)(grp - c * groups_per_channel) * kStageRows;
     const int nrows = min(kStageRows, a.P - p0);
+    if (group_all_eligible(elig, c * a.P + p0, nrows)) continue;  // (uniform) the sliding route has these pings
     // ---- this lane's samples of the group's pings
     T d[kStageRows];
     unsigned feas = 0, dfeas = 0;  // dfeas: feasible but for the ping window (its interval may be SHARED with a later ping)
@@ -1791,7 +1823,8 @@ __global__ __launch_bounds__(kBlock, EPA_LEAN_WGS) void pool_value_mean_lean_ker
                                                                       const int* __restrict__ wn,
                                                                       const uint8_t* __restrict__ dirty,
                                                                       const int* __restrict__ differ, int nbands,
-                                                                      int xcd_map, uint8_t* __restrict__ todo) {
+                                                                      int xcd_map, uint8_t* __restrict__ todo,
+                                                                      const uint8_t* __restrict__ elig) {
   __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
   typedef double dd_t __attribute__((ext_vector_type(2)));
   // seg_r[1 + i] = range[kmin + i], -inf before and +inf behind; seg_w[i] = {Wh, Wl}[kmin - 1 + i], seg_n[i] the count
@@ -1818,14 +1851,15 @@ __global__ __launch_bounds__(kBlock, EPA_LEAN_WGS) void pool_value_mean_lean_ker
     const long long grp = w - (long long)band * ngroups;
     const long long c = grp / groups_per_channel;
     if (!differ[c]) continue;  // every ping of the channel has the same range vector: value_slide_kernel
+    const int p0 = (int)(grp - c * groups_per_channel) * kLeanRows;
+    const int nrows = min(kLeanRows, a.P - p0);
+    if (group_all_eligible(elig, c * a.P + p0, nrows)) continue;  // (uniform) the sliding route has these pings
     if (!have_tabs) {
       mt = epa::build_math_tabs(tabs);
       have_tabs = true;  // (the barriers below come before the tables' first use)
     }
     const int s = band * kBlock + threadIdx.x;
     const bool in_row = s < a.S;
-    const int p0 = (int)(grp - c * groups_per_channel) * kLeanRows;
-    const int nrows = min(kLeanRows, a.P - p0);
     T d[kLeanRows];
     unsigned feas = 0, dfeas = 0;  // dfeas: feasible but for the ping window (its interval may be SHARED with a later ping)
     double vmin = __builtin_inf(), vmax = -__builtin_inf();
@@ -2122,15 +2156,21 @@ __global__ __launch_bounds__(kBlock) void row_interval_sum_kernel(
     PoolValueArgs<T> a, long long rows, const double* __restrict__ wh, const double* __restrict__ wl,
     const int* __restrict__ wn, const uint8_t* __restrict__ dirty, const int* __restrict__ differ,
     const int* __restrict__ ilo, const int* __restrict__ ihi, double* __restrict__ rh,
-    int* __restrict__ rn) {
+    int* __restrict__ rn, const int* __restrict__ row_slot = nullptr) {
   __shared__ __attribute__((aligned(16))) unsigned char tabs[epa::kMathTabBytes];
   const epa::MathTabs mt = epa::build_math_tabs(tabs);
   __syncthreads();
   const int s = blockIdx.y * kBlock + threadIdx.x;
   if (s >= a.S) return;
   for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
-    const long long c = row / a.P;
-    if (differ[c]) continue;
+    // row_slot (the run form): the interval table of the row's RUN inside a channel that differs; else the channel's
+    long long c = row / a.P;
+    if (row_slot) {
+      if (!differ[c] || row_slot[row] < 0) continue;
+      c = row_slot[row];
+    } else if (differ[c]) {
+      continue;
+    }
     const int nv = a.nvalid[row];
     const int lo = min(ilo[(size_t)c * a.S + s], nv), hi = min(ihi[(size_t)c * a.S + s], nv);
     const size_t base = (size_t)row * a.S;
@@ -2212,6 +2252,273 @@ __global__ __launch_bounds__(kBlock) void value_slide_kernel(PoolValueArgs<T> a,
       w.add(hout[j], kout[j], -1.0);
       T res = epa::M<T>::nan();
       const bool ok = depth_ok && (p - n >= 0) && ((long long)p + n <= (long long)P) && s < nvp[j];
+      if (ok && w.cnt > 0) res = (T)(10.0 * epa::fast_log10(w.value() / (double)w.cnt, mt.log_tab));
+      const size_t at = cbase + (size_t)p * S + s;
+      if (a.pooled) a.pooled[at] = res;
+      if (a.mask) a.mask[at] = (x[j] - res > a.thr) ? 1 : 0;
+    }
+  }
+}
+
+// ---- runs of pings with one range vector inside a channel that has several (round 6) -----------------------------------
+// An EK60 records the sound speed of the moment with every ping; an operator's setting holds for thousands of pings.
+// The sliding route above then applies run by run: a ping whose whole window p - n .. p + n lies inside a run of pings
+// that share a range vector pools exactly as in a channel with one vector.  Nothing here returns to the host:
+//   run_flag      does ping p start a run?  (three samples of it against ping p - 1: the range is affine in the sample
+//                 number -- a proposal; run_verify holds every row of a long run to the run's reference, value by value)
+//   run_scan_*    start of the run of every ping (a max-scan of the flags: tiles of 1024 pings, then the tiles' carries)
+//   run_stats     length of every run and its reference row (the longest; the first of those), by atomics at its start
+//   run_verify    a row of a long run that differs from the reference on its own valid samples spoils the run
+//   run_finish    per ping: eligible?  which interval table (slot) does its run use?  per slot: its reference row.
+//                 Slots: run starts of long runs lie at least Lmin = 2n + 1 pings apart, so c * ceil(P / Lmin) +
+//                 start / Lmin is a table index without collisions and without a compaction
+// then value_intervals_kernel per slot, row_interval_sum_kernel with the row's slot, value_slide_runs_kernel; the lean
+// and the staged kernel skip the groups whose pings are all eligible.
+constexpr int kRunTile = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void run_flag_kernel(const T* __restrict__ range, const int* __restrict__ nvalid,
+                                                          const int* __restrict__ differ, long long rows, int P, int S,
+                                                          uint8_t* __restrict__ flag) {
+  for (long long row = (long long)blockIdx.x * kBlock + threadIdx.x; row < rows; row += (long long)gridDim.x * kBlock) {
+    const long long c = row / P;
+    const int p = (int)(row - c * P);
+    uint8_t f = 1;
+    if (differ[c] && p > 0) {
+      const int m = min(nvalid[row], nvalid[row - 1]);
+      const T* x = range + (size_t)row * S;
+      const T* y = x - S;
+      // (a row without a valid sample joins the run it lies in: nothing of it is ever pooled)
+      f = (m > 0 && (x[0] != y[0] || x[m >> 1] != y[m >> 1] || x[m - 1] != y[m - 1])) ? 1 : 0;
+    }
+    flag[row] = f;
+  }
+}
+
+// start[row] = the last ping <= p of the row's tile with a flag, or -1; tile_last[c * ntiles + t] likewise for the tile
+__global__ __launch_bounds__(kBlock) void run_scan_tiles_kernel(const uint8_t* __restrict__ flag, int P, int ntiles,
+                                                                int* __restrict__ start, int* __restrict__ tile_last) {
+  __shared__ int wmax[kBlock / 64];
+  const int c = blockIdx.y, t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p0 = t * kRunTile + threadIdx.x * 4;  // four consecutive pings per lane
+  int v[4];
+  int run = -1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = p0 + j;
+    if (p < P && flag[(size_t)c * P + p]) run = p;
+    v[j] = run;
+  }
+  int incl = run;  // inclusive max-scan over the wavefront, then over the workgroup's four wavefronts
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl = max(incl, up);
+  }
+  if (lane == 63) wmax[wave] = incl;
+  __syncthreads();
+  int before = __shfl_up(incl, 1, 64);
+  if (lane == 0) before = -1;
+  for (int w = 0; w < wave; ++w) before = max(before, wmax[w]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (p0 + j < P) start[(size_t)c * P + p0 + j] = max(v[j], before);
+  if (threadIdx.x == kBlock - 1) tile_last[c * ntiles + t] = max(incl, before);
+}
+
+// tile_last -> the last flag BEFORE the tile (exclusive carry), in place; one lane per channel (a few thousand tiles)
+__global__ void run_scan_carry_kernel(int* __restrict__ tile_last, int ntiles) {
+  int* tl = tile_last + (size_t)blockIdx.x * ntiles;
+  int carry = -1;
+  for (int t = 0; t < ntiles; ++t) {
+    const int v = tl[t];
+    tl[t] = carry;
+    carry = max(carry, v);
+  }
+}
+
+// start[] completed with the carries; length of every run and the key of its reference row, at the run's first row
+__global__ __launch_bounds__(kBlock) void run_stats_kernel(const int* __restrict__ nvalid, const int* __restrict__ differ,
+                                                           const int* __restrict__ tile_carry, long long rows, int P,
+                                                           int ntiles, int* __restrict__ start, int* __restrict__ run_len,
+                                                           unsigned long long* __restrict__ run_key) {
+  for (long long row = (long long)blockIdx.x * kBlock + threadIdx.x; row < rows; row += (long long)gridDim.x * kBlock) {
+    const long long c = row / P;
+    if (!differ[c]) continue;
+    const int p = (int)(row - c * P);
+    const int rs = max(start[row], tile_carry[c * ntiles + p / kRunTile]);  // (>= 0: ping 0 carries a flag)
+    start[row] = rs;
+    atomicAdd(&run_len[c * P + rs], 1);
+    // the longest row; among those the first
+    atomicMax(&run_key[c * P + rs], ((unsigned long long)(unsigned)nvalid[row] << 32) | (unsigned)(0x7fffffff - p));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void run_verify_kernel(const T* __restrict__ range, const int* __restrict__ nvalid,
+                                                            const int* __restrict__ differ, const int* __restrict__ start,
+                                                            const int* __restrict__ run_len,
+                                                            const unsigned long long* __restrict__ run_key, long long rows,
+                                                            int P, int S, int lmin, uint8_t* __restrict__ run_bad) {
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const long long c = row / P;
+    if (!differ[c]) continue;
+    const long long r0 = c * P + start[row];
+    if (run_len[r0] < lmin || __atomic_load_n(&run_bad[r0], __ATOMIC_RELAXED)) continue;  // (uniform)
+    const int ref = 0x7fffffff - (int)(unsigned)(run_key[r0] & 0xffffffffull);
+    if (c * P + ref == row) continue;
+    const T* x = range + (size_t)row * S;
+    const T* y = range + (size_t)(c * P + ref) * S;
+    const int nv = nvalid[row];
+    int bad = 0;
+    for (int k = threadIdx.x; k < nv; k += kBlock) bad |= x[k] != y[k];
+    if (bad) __atomic_store_n(&run_bad[r0], (uint8_t)1, __ATOMIC_RELAXED);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void run_finish_kernel(const int* __restrict__ differ, const int* __restrict__ start,
+                                                            const int* __restrict__ run_len,
+                                                            const unsigned long long* __restrict__ run_key,
+                                                            const uint8_t* __restrict__ run_bad, long long rows, int P, int n,
+                                                            int lmin, int nslotc, uint8_t* __restrict__ elig,
+                                                            int* __restrict__ row_slot, int* __restrict__ slot_ref) {
+  for (long long row = (long long)blockIdx.x * kBlock + threadIdx.x; row < rows; row += (long long)gridDim.x * kBlock) {
+    const long long c = row / P;
+    uint8_t e = 0;
+    int slot = -1;
+    if (differ[c]) {
+      const int p = (int)(row - c * P), rs = start[row];
+      const long long r0 = c * P + rs;
+      const int len = run_len[r0];
+      if (len >= lmin && !run_bad[r0]) {
+        slot = (int)(c * nslotc + rs / lmin);
+        e = (p - n >= rs && p + n < rs + len) ? 1 : 0;
+        if (p == rs) slot_ref[slot] = (int)(0x7fffffff - (int)(unsigned)(run_key[r0] & 0xffffffffull));
+      }
+    }
+    elig[row] = e;
+    row_slot[row] = slot;
+  }
+}
+
+// need_w[row]: some ping within ``n`` (the caller's: side pings + a group of pings) of the row is not eligible -- the
+// staged kernels, which read the running sums of their pings' neighbour rows, may ask for this one
+__global__ __launch_bounds__(kBlock) void run_need_rows_kernel(const int* __restrict__ differ, const uint8_t* __restrict__ elig,
+                                                               long long rows, int P, int n, uint8_t* __restrict__ need_w) {
+  for (long long row = (long long)blockIdx.x * kBlock + threadIdx.x; row < rows; row += (long long)gridDim.x * kBlock) {
+    const long long c = row / P;
+    const int p = (int)(row - c * P);
+    uint8_t need = 0;
+    if (differ[c]) {
+      const uint8_t* e = elig + c * P;
+      for (int q = max(0, p - n); q <= min(P - 1, p + n) && !need; ++q) need = e[q] ? 0 : 1;
+    }
+    need_w[row] = need;
+  }
+}
+
+// value_intervals_kernel per slot: ref row of the slot's run (a ping index of channel slot / nslotc), -1 = no run here
+template <typename T>
+__global__ __launch_bounds__(kBlock) void value_intervals_runs_kernel(PoolValueArgs<T> a, const int* __restrict__ slot_ref,
+                                                                      int nslotc, int* __restrict__ ilo, int* __restrict__ ihi) {
+  const int s = blockIdx.y * kBlock + threadIdx.x, slot = blockIdx.x;
+  const int ref = slot_ref[slot];
+  if (s >= a.S || ref < 0) return;
+  const size_t rrow = (size_t)(slot / nslotc) * a.P + ref;
+  const T* rr = a.range + rrow * a.S;
+  const int nv = a.nvalid[rrow];
+  int lo = -1, hi = -1;
+  if (s < nv) {
+    const T d = rr[s];
+    if (pool_depth_feasible(a, d)) {
+      lo = bound<T, false>(rr, nv, d - a.bin);
+      hi = bound<T, true>(rr, nv, d + a.bin);
+    }
+  }
+  ilo[(size_t)slot * a.S + s] = lo;
+  ihi[(size_t)slot * a.S + s] = hi;
+}
+
+// value_slide_kernel for the eligible pings of the channels that differ: the window sum slides while consecutive pings
+// are eligible in one run, and is taken afresh (2n + 1 rows) where eligibility resumes
+template <typename T>
+__global__ __launch_bounds__(kBlock) void value_slide_runs_kernel(PoolValueArgs<T> a, const int* __restrict__ differ,
+                                                                  const uint8_t* __restrict__ elig,
+                                                                  const int* __restrict__ row_slot,
+                                                                  const int* __restrict__ ilo,
+                                                                  const double* __restrict__ rh,
+                                                                  const int* __restrict__ rn) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int s = blockIdx.y * kBlock + threadIdx.x, c = blockIdx.z;
+  if (!differ[c]) return;
+  const int P = a.P, S = a.S, n = a.n;
+  const int p0 = blockIdx.x * kSlideSeg, p1 = min(P, p0 + kSlideSeg);
+  const uint8_t* __restrict__ el = elig + (size_t)c * P;
+  {  // (uniform) a segment without an eligible ping leaves before the tables
+    bool any = false;
+    for (int p = p0; p < p1 && !any; ++p) any = el[p] != 0;
+    if (!any) return;
+  }
+  const epa::MathTabs mt = epa::build_math_tabs(smem);
+  __syncthreads();
+  if (s >= S) return;
+  const size_t cbase = (size_t)c * P * S;
+  const double* __restrict__ h = rh + cbase + s;
+  const int* __restrict__ k = rn + cbase + s;
+  const int* __restrict__ slots = row_slot + (size_t)c * P;
+  DdSum w;
+  int cur_slot = -1;   // (uniform) slot of the run the window sum belongs to; -1: no window sum
+  bool depth_ok = false;
+  constexpr int U = 4;
+  for (int pb = p0; pb < p1; pb += U) {
+    double hin[U], hout[U];
+    int kin[U], kout[U], nvp[U], sl[U];
+    bool cont[U];
+    T x[U];
+    int prev_slot = cur_slot;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int p = min(pb + j, p1 - 1);
+      sl[j] = (pb + j < p1 && el[p]) ? slots[p] : -1;
+      cont[j] = sl[j] >= 0 && sl[j] == prev_slot;  // slides on from the ping before (same run, both eligible)
+      prev_slot = sl[j];
+      const bool g = cont[j] && depth_ok;  // (depth_ok: of the current run; a fresh window re-reads it below)
+      const size_t ri = (size_t)(g ? p + n : 0) * S, ro = (size_t)(g ? p - n - 1 : 0) * S;
+      hin[j] = g ? h[ri] : 0.0;
+      kin[j] = g ? k[ri] : 0;
+      hout[j] = g ? h[ro] : 0.0;
+      kout[j] = g ? k[ro] : 0;
+      nvp[j] = a.nvalid[(size_t)c * P + p];
+      x[j] = a.mask ? a.sv[cbase + (size_t)p * S + s] : (T)0;
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int p = pb + j;
+      if (p >= p1) break;
+      if (sl[j] < 0) {  // (uniform) not this kernel's ping
+        cur_slot = -1;
+        continue;
+      }
+      if (!cont[j] || sl[j] != cur_slot) {  // (uniform) eligibility resumes, or another run: the window afresh
+        cur_slot = sl[j];
+        depth_ok = ilo[(size_t)cur_slot * S + s] >= 0;
+        w = DdSum();
+        if (depth_ok)
+          for (int q = p - n; q <= p + n; ++q) w.add(h[(size_t)q * S], k[(size_t)q * S], 1.0);
+      } else if (depth_ok) {
+        // (the requests above were made with the depth_ok of the run as it stood at the top of the batch: a run that
+        //  began inside this batch reads its rows here)
+        const bool pre = hin[j] != 0.0 || kin[j] != 0 || hout[j] != 0.0 || kout[j] != 0;
+        if (pre) {
+          w.add(hin[j], kin[j], 1.0);
+          w.add(hout[j], kout[j], -1.0);
+        } else {
+          w.add(h[(size_t)(p + n) * S], k[(size_t)(p + n) * S], 1.0);
+          w.add(h[(size_t)(p - n - 1) * S], k[(size_t)(p - n - 1) * S], -1.0);
+        }
+      }
+      T res = epa::M<T>::nan();
+      const bool ok = depth_ok && s < nvp[j];  // (an eligible ping has its whole ping window inside the file)
       if (ok && w.cnt > 0) res = (T)(10.0 * epa::fast_log10(w.value() / (double)w.cnt, mt.log_tab));
       const size_t at = cbase + (size_t)p * S + s;
       if (a.pooled) a.pooled[at] = res;
@@ -3247,24 +3554,95 @@ int launch_pool_value(const void* sv, const void* range, const int32_t* nvalid, 
       hipLaunchKernelGGL(rows_same_kernel<T>, rowg, dim3(kBlock), 0, st, (const T*)range, nvalid, rows, P, S, ref, differ);
       hipLaunchKernelGGL(value_intervals_kernel<T>, dim3((S + kBlock - 1) / kBlock, C), dim3(kBlock), 0, st, a, ref, ilo, ihi);
       if (int rc = epa::check_launch("rows_same_kernel")) return rc;
-      // those channels: running sums in LDS -> interval sums per row (one kernel), then a sliding sum down every
-      // column; the others: running sums to the workspace, then row by row
+      // channels whose pings differ in their range vectors: the RUNS of pings that do share one take the sliding route
+      // (see run_flag_kernel); their bookkeeping lives in the workspace's spare quarter (rl is not used on this route),
+      // behind the lean kernel's ``todo`` bytes.  EPA_POOL_RUNS=0: off (development knob)
+      const uint8_t* elig = nullptr;
+      const uint8_t* need_w = nullptr;
+      int* row_slot = nullptr;
+      int *ilo2 = nullptr, *ihi2 = nullptr;
+      {
+        static const bool runs_on = [] { const char* e = getenv("EPA_POOL_RUNS"); return !(e && e[0] == '0'); }();
+        const int lmin = 2 * n + 1, nslotc = (P + lmin - 1) / lmin, ntiles = (P + kRunTile - 1) / kRunTile;
+        const long long nslots = (long long)C * nslotc;
+        const long long nwork0 = (long long)C * ((P + kStageRows - 1) / kStageRows) * (long long)grid.y;
+        auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        size_t off = up16((size_t)nwork0);
+        unsigned char* base = reinterpret_cast<unsigned char*>(rl);
+        auto take = [&](size_t bytes) { unsigned char* q = base + off; off = up16(off + bytes); return q; };
+        uint8_t* flag = take((size_t)rows);
+        uint8_t* run_bad = take((size_t)rows);
+        uint8_t* el = take((size_t)rows);
+        uint8_t* nw = take((size_t)rows);
+        int* start = reinterpret_cast<int*>(take((size_t)rows * 4));
+        int* run_len = reinterpret_cast<int*>(take((size_t)rows * 4));
+        int* rslot = reinterpret_cast<int*>(take((size_t)rows * 4));
+        unsigned long long* run_key = reinterpret_cast<unsigned long long*>(take((size_t)rows * 8));
+        int* tile_last = reinterpret_cast<int*>(take((size_t)C * ntiles * 4));
+        int* slot_ref = reinterpret_cast<int*>(take((size_t)nslots * 4));
+        int* tlo = reinterpret_cast<int*>(take((size_t)nslots * S * 4));
+        int* thi = reinterpret_cast<int*>(take((size_t)nslots * S * 4));
+        if (runs_on && n >= 1 && off <= N * sizeof(double) && nslots < (1ll << 31) && ntiles < (1 << 30)) {
+          const dim3 flat((unsigned)std::min<long long>((rows + kBlock - 1) / kBlock, 65536));
+          EPA_CHECK_HIP(hipMemsetAsync(run_bad, 0, (size_t)rows, st));
+          EPA_CHECK_HIP(hipMemsetAsync(run_len, 0, (size_t)rows * 4, st));
+          EPA_CHECK_HIP(hipMemsetAsync(run_key, 0, (size_t)rows * 8, st));
+          EPA_CHECK_HIP(hipMemsetAsync(slot_ref, 0xff, (size_t)nslots * 4, st));
+          hipLaunchKernelGGL(run_flag_kernel<T>, flat, dim3(kBlock), 0, st, (const T*)range, nvalid, differ, rows, P, S, flag);
+          if (int rc = epa::check_launch("run_flag_kernel")) return rc;
+          hipLaunchKernelGGL(run_scan_tiles_kernel, dim3((unsigned)ntiles, (unsigned)C), dim3(kBlock), 0, st, flag, P, ntiles,
+                             start, tile_last);
+          if (int rc = epa::check_launch("run_scan_tiles_kernel")) return rc;
+          hipLaunchKernelGGL(run_scan_carry_kernel, dim3((unsigned)C), dim3(1), 0, st, tile_last, ntiles);
+          if (int rc = epa::check_launch("run_scan_carry_kernel")) return rc;
+          hipLaunchKernelGGL(run_stats_kernel, flat, dim3(kBlock), 0, st, nvalid, differ, tile_last, rows, P, ntiles, start,
+                             run_len, run_key);
+          if (int rc = epa::check_launch("run_stats_kernel")) return rc;
+          hipLaunchKernelGGL(run_verify_kernel<T>, rowg, dim3(kBlock), 0, st, (const T*)range, nvalid, differ, start, run_len,
+                             run_key, rows, P, S, lmin, run_bad);
+          if (int rc = epa::check_launch("run_verify_kernel")) return rc;
+          hipLaunchKernelGGL(run_finish_kernel, flat, dim3(kBlock), 0, st, differ, start, run_len, run_key, run_bad, rows, P,
+                             n, lmin, nslotc, el, rslot, slot_ref);
+          if (int rc = epa::check_launch("run_finish_kernel")) return rc;
+          // (the staged kernels take whole groups of pings: an eligible ping of a mixed group is done there as well)
+          hipLaunchKernelGGL(run_need_rows_kernel, flat, dim3(kBlock), 0, st, differ, el, rows, P,
+                             n + std::max(kLeanRows, kStageRows) - 1, nw);
+          if (int rc = epa::check_launch("run_need_rows_kernel")) return rc;
+          hipLaunchKernelGGL(value_intervals_runs_kernel<T>, dim3((unsigned)nslots, (S + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                             st, a, slot_ref, nslotc, tlo, thi);
+          if (int rc = epa::check_launch("value_intervals_runs_kernel")) return rc;
+          elig = el; row_slot = rslot; ilo2 = tlo; ihi2 = thi; need_w = nw;
+        }
+      }
+      // the channels with one vector, and the long runs of the others: running sums in LDS -> interval sums per row
+      // (one kernel), then a sliding sum down every column; what is left: running sums to the workspace -- of the rows a
+      // staged ping can still ask for --, then row by row
       const size_t Sp = ((size_t)S + 63) & ~(size_t)63;
       const size_t fuse_lds = Sp * 20 + (Sp / 16) * 10 + 16;
       const bool fuse = fuse_lds + epa::kMathTabBytes + 1024 <= kMaxLds;
-      FuseArgs fa{differ, nvalid, ilo, ihi, rh, rn, P, fuse ? 1 : 0};
+      FuseArgs fa{differ, nvalid, ilo, ihi, rh, rn, P, fuse ? 1 : 0, nullptr, fuse ? need_w : nullptr};
       if (fuse) {
         auto kern = row_interval_blocks_kernel<T>;
         if (int rc = set_lds(kern, fuse_lds)) return rc;
         hipLaunchKernelGGL(kern, rowg, dim3(kBlock), fuse_lds, st, (const T*)sv, rows, S, fa);
         if (int rc = epa::check_launch("row_interval_blocks_kernel")) return rc;
+        if (elig) {
+          FuseArgs fr{differ, nvalid, ilo2, ihi2, rh, rn, P, 1, row_slot, nullptr};
+          hipLaunchKernelGGL(kern, rowg, dim3(kBlock), fuse_lds, st, (const T*)sv, rows, S, fr);
+          if (int rc = epa::check_launch("row_interval_blocks_kernel")) return rc;
+        }
       }
       hipLaunchKernelGGL(row_running_sum_kernel<T>, rowg, dim3(kBlock), 0, st, (const T*)sv, rows, S, wh, wl, wn,
                          dirty, fa);
       if (int rc = epa::check_launch("row_running_sum_kernel")) return rc;
-      if (!fuse)
+      if (!fuse) {
         hipLaunchKernelGGL(row_interval_sum_kernel<T>, grid, dim3(kBlock), 0, st, a, rows, wh, wl, wn, dirty, differ, ilo,
                            ihi, rh, rn);
+        if (elig)
+          hipLaunchKernelGGL(row_interval_sum_kernel<T>, grid, dim3(kBlock), 0, st, a, rows, wh, wl, wn, dirty, differ, ilo2,
+                             ihi2, rh, rn, row_slot);
+        if (int rc = epa::check_launch("row_interval_sum_kernel")) return rc;
+      }
       const dim3 g2((P + kSlideSeg - 1) / kSlideSeg, (S + kBlock - 1) / kBlock, C);
       if (g2.y > 65535u || g2.z > 65535u) {
         epa::set_error("epa_pool_sv_value: more than 65535 channels or 16.7 M samples per ping");
@@ -3273,7 +3651,12 @@ int launch_pool_value(const void* sv, const void* range, const int32_t* nvalid, 
       hipLaunchKernelGGL(value_slide_kernel<T>, g2, dim3(kBlock), epa::kMathTabBytes + kSlidePad, st, a, differ, ilo, rh,
                          rn);
       if (int rc = epa::check_launch("value_slide_kernel")) return rc;
-      {  // channels whose pings differ in their range vectors: neighbour rows staged in LDS
+      if (elig) {
+        hipLaunchKernelGGL(value_slide_runs_kernel<T>, g2, dim3(kBlock), epa::kMathTabBytes + kSlidePad, st, a, differ, elig,
+                           row_slot, ilo2, rh, rn);
+        if (int rc = epa::check_launch("value_slide_runs_kernel")) return rc;
+      }
+      {  // ... and the pings the runs leave: neighbour rows staged in LDS
         const long long ngroups = (long long)C * ((P + kStageRows - 1) / kStageRows);
         const dim3 sgrid((unsigned)std::min<long long>(ngroups, 65535 * 4), grid.y);
         // the lean kernel first; the groups it flags in ``todo`` (kept in the workspace's spare quarter: rl is not used
@@ -3287,11 +3670,11 @@ int launch_pool_value(const void* sv, const void* range, const int32_t* nvalid, 
           EPA_CHECK_HIP(hipMemsetAsync(todo, 0, (size_t)nwork, st));
           hipLaunchKernelGGL(pool_value_mean_lean_kernel<T>, dim3((unsigned)std::min<long long>(nlean, 1ll << 30)),
                              dim3(kBlock), 0, st, a, C, wh, wl, wn, dirty, differ, (int)grid.y,
-                             epa::xcd_map_enabled() ? 1 : 0, todo);
+                             epa::xcd_map_enabled() ? 1 : 0, todo, elig);
           if (int rc = epa::check_launch("pool_value_mean_lean_kernel")) return rc;
         }
         hipLaunchKernelGGL(pool_value_mean_staged_kernel<T>, sgrid, dim3(kBlock), 0, st, a, C, wh, wl, wn, dirty, differ,
-                           todo);
+                           todo, elig);
       }
       return epa::check_launch("pool_value_mean_staged_kernel");
     }

@@ -590,6 +590,56 @@ def test_pool_sv_value_staged_neighbour_rows(env, dtype, case):
         _close(a, exp, RTOL[dtype], "vs oracle")
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("case", ["runs", "bridged", "short_runs", "one_side_ping"])
+def test_pool_sv_value_runs_of_one_range_vector(env, dtype, case):
+    """Round 6: inside a channel whose pings do not all share a range vector, the pings of a RUN that does take the
+    sliding route when their ping window lies inside the run (value_slide_runs_kernel), the others the staged kernels --
+    the same pooled values as summing every window (and the oracle's triple loop, clean/utils.py:29-106).  Runs of 60,
+    23 and 90 pings with n = 9 (the 23-ping run has 5 eligible pings), NaN tails of different lengths inside a run, a
+    row without a valid sample, a +inf sample; ``bridged``: a short row between two different vectors that agrees with
+    both on its own samples -- the proposal joins the runs, the verification against the reference rejects the run;
+    ``short_runs``: no run reaches 2 n + 1 pings; ``one_side_ping``: n = 1."""
+    from echopype_amd import _lib
+    torch, ops = env
+    rng = np.random.default_rng(41)
+    C, S, dbin, step = 2, 520, 2.3, 0.3
+    n = 1 if case == "one_side_ping" else 9
+    lens = [60, 23, 90, 40] if case != "short_runs" else [11, 7, 15, 9, 13, 12, 10, 14, 8, 16, 18, 17, 5, 18]
+    P = sum(lens)
+    sv, _ = _scene(C, P, S, 12, step=step)
+    scale = np.repeat(1 + 0.004 * np.arange(len(lens)), lens)
+    depth = (1.5 + step * np.arange(S))[None, None, :] * scale[None, :, None] * np.ones((C, 1, 1))
+    depth[1] *= 1.0 + 0.0007 * rng.random((P, 1))  # channel 1: a vector of its own at every ping
+    depth[0, 7, S - 20:] = np.nan
+    depth[0, 30, S - 55:] = np.nan
+    depth[0, 100, :] = np.nan                      # a row without a valid sample inside a run
+    if case == "bridged":                          # ping 59 | 60: a row of 3 samples that equals BOTH neighbours there
+        depth[0, 60:83] = depth[0, 0] + 0.0        # the second run takes the first run's vector ...
+        depth[0, 61:83, 10:] += 0.004 * (np.arange(S - 10) + 1)  # ... except beyond sample 10, and row 60 is cut before
+        depth[0, 60, 3:] = np.nan
+    sv[np.isnan(depth)] = np.nan
+    sv[0, 10, 100] = 60.0
+    sv[0, 75, 50] = np.inf
+    sv[rng.random((C, P, S)) < 0.03] = np.nan
+    sv, depth = sv.astype(dtype), depth.astype(dtype)
+    svt, rgt = _dev(torch, sv), _dev(torch, depth)
+    nvalid, bad = ops.range_rows_check(rgt)
+    assert bad == 0
+    lo, hi = ops.nanminmax(rgt)
+    with _lib.launch_trace() as tr:
+        a, ma = ops.pool_sv_value(svt, rgt, nvalid, dbin, n, 2.0, lo, hi, threshold=6.0, running_sums=True)
+    assert "value_slide_runs_kernel" in tr.kernels and "run_verify_kernel" in tr.kernels
+    b, mb = ops.pool_sv_value(svt, rgt, nvalid, dbin, n, 2.0, lo, hi, threshold=6.0, running_sums=False)
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+    _close(a, b, 1e-12 if dtype == "float64" else 1e-5, "runs vs window sums")
+    assert np.isposinf(a).any() and np.isfinite(a).any()
+    if dtype == "float64" and case in ("runs", "bridged"):  # (the triple loop takes half a minute at this size)
+        exp = omask.pool_Sv(sv.astype(np.float64), depth.astype(np.float64), np.nanmean, dbin, n, 2.0)
+        _close(a, exp, RTOL[dtype], "vs oracle")
+
+
 def test_pool_sv_everything_above_exclusion(env):
     torch, ops = env
     sv, _ = _scene(1, 6, 10, 3)

@@ -369,3 +369,43 @@ def test_ek80_broadband_two_calls_wait_for_nothing_and_equal_the_eager_route(env
     np.testing.assert_allclose(mv["Sv"].values, mv_e["Sv"].values, rtol=1e-12, atol=1e-12, equal_nan=True)
     assert mv["Sv"].shape == mv_b["Sv"].shape and dict(mv["Sv"].attrs) == dict(mv_e["Sv"].attrs)
     assert mv["echo_range"].values[-1] <= float(np.nanmax(ds["echo_range"].values)) < ds["echo_range"].data.reach_bound
+
+
+@pytest.mark.gpu
+def test_ping_time_is_kept_only_for_resident_data_and_small_uploads_by_content():
+    """ops.ping_time_facts keeps the int64 twin / sortedness of a ping_time array with the ARRAY OBJECT only when nobody
+    can write to it (EchoData.to_device marks it so); a plain host dataset whose ping_time is edited in place between two
+    calls is looked at again.  ops.to_device_small hands out one device copy per distinct content."""
+    import torch
+
+    import echopype_amd as ep
+    from echopype_amd import ops
+
+    d = ep.synth.ek60_numpy(2, 120, 600, ss_every=1000)
+    ed = ep.echodata.from_ek60_arrays(d)
+    ds = ep.calibrate.compute_Sv(ed)
+    a = ep.commongrid.compute_MVBS(ds, range_bin="5m", ping_time_bin="20s")
+    n_a = a["Sv"].shape[1]
+    pt = ds["ping_time"].values
+    assert pt.flags.writeable
+    pt += np.timedelta64(1000, "s") * np.arange(pt.size)  # in place: the pings now spread over many more bins
+    ds2 = ep.calibrate.compute_Sv(ed)
+    b = ep.commongrid.compute_MVBS(ds2, range_bin="5m", ping_time_bin="20s")
+    assert b["Sv"].shape[1] > 10 * n_a
+    np.testing.assert_array_equal(b["ping_time"].values[0], a["ping_time"].values[0])
+    # resident: read-only, looked at once
+    ed_r = ep.echodata.from_ek60_arrays(ep.synth.ek60_numpy(2, 120, 600, ss_every=1000)).to_device()
+    ptr = ed_r["Sonar/Beam_group1"]["ping_time"].values
+    assert not ptr.flags.writeable
+    with pytest.raises(ValueError):
+        ptr[0] = ptr[1]
+    ns1, ok1, t1 = ops.ping_time_facts(ptr)
+    ns2, ok2, t2 = ops.ping_time_facts(ptr)
+    assert ok1 and ok2 and t1 is t2 and ns1 is ns2
+    np.testing.assert_array_equal(t1.cpu().numpy(), ptr.view(np.int64))
+    # small uploads: one tensor per content, another for other content; large arrays are not kept
+    x = np.arange(5, dtype=np.float64)
+    u, v, w = ops.to_device_small(x), ops.to_device_small(x.copy()), ops.to_device_small(x + 1)
+    assert u is v and w is not u and torch.equal(w, u + 1)
+    big = np.zeros(4096)
+    assert ops.to_device_small(big) is not ops.to_device_small(big)
