@@ -57,7 +57,7 @@ WORKLOADS = {
     "next": (4, 100_000, 2000, 2, 2),  # SURVEY 8f rows through their API entry points (scripts/perf_masks.py's volume)
 }
 DEFAULT_LINES = ["cfg3", "cfg3:ss2000", "cfg3:f32", "cfg2", "cfg2:f32", "cfg2:int16", "cfg2:int16f32", "cfg2:bins", "cfg2:int16bins", "cfg2:sv", "cfg2:sv32", "api", "api:chain", "api:pcie",
-                 "cfg4", "cfg4:f32", "cfg4:planes64", "next:depth", "next:depthw", "next:masks", "next:nasc", "cfg5:one", "cfg5"]
+                 "cfg4", "cfg4:f32", "cfg4:planes64", "next:depth", "next:depthw", "next:masks", "next:masks2000", "next:nasc", "cfg5:one", "cfg5"]
 TILE_PINGS = 250_000
 DT = {"f32": "float32", "f64": "float64", "sv32": "float32", "int16f32": "float32"}
 
@@ -174,8 +174,7 @@ def cpu_baseline_ek60(chain=False, multicore=False):
                     busy = pool.map(_cpu_worker, [(C, Pw, S, i, reps) for i in range(ncore)], chunksize=1)
                     dtm = time.perf_counter() - t0
                 out["multicore_value"], out["multicore_cores"] = C * Pw * S * reps * ncore / dtm, ncore
-                out["multicore_sample"] = (f"{ncore} processes x {reps} x EK60 {C}x{Pw}x{S}, wall {dtm:.1f} s "
-                                           f"(slowest worker busy {max(busy):.1f} s), host has {os.cpu_count()} hardware threads")
+                out["multicore_sample"] = f"{ncore} procs x {reps} x {C}x{Pw}x{S}, {dtm:.0f} s wall, {os.cpu_count()} hw threads"
         except Exception as e:  # noqa: BLE001 - the single-core figure stands on its own
             out["multicore_error"] = repr(e)[:100]
     return out
@@ -611,18 +610,23 @@ def run_next(ctx, variant, cpu):
     import echopype_amd as ep
 
     C, P, S = WORKLOADS["next"][:3]
-    key = ("next", C, P, S)
+    # masks2000: the recorded sound speed -- hence the range / depth vector -- changes every 2000 pings (an operator's
+    # setting holds for a while) instead of at every ping, the worst case the other rows use
+    ss_every = 2000 if variant == "masks2000" else 1
+    if variant == "masks2000":
+        variant = "masks"
+    key = ("next", C, P, S, ss_every)
     if key not in ctx.cache:
         for k in [k for k in ctx.cache if k != key]:
             del ctx.cache[k]
         ctx.free()
         d = ctx.synth.ek60_numpy(C, 4, 8)
-        h = ctx.synth.ek60_params(C, P, ss_every=1)
+        h = ctx.synth.ek60_params(C, P, ss_every=ss_every)
         for k in ("sample_interval", "transmit_duration_nominal", "transmit_power", "sound_speed_indicative",
                   "absorption_indicative"):
             d[k] = h[k]
         d["ping_time"] = h["ping_time"]
-        d["backscatter_r"] = ep.DeviceArray(ctx.synth.ek60_device(C, P, S, seed=20260509, ss_every=1)["backscatter_r"])
+        d["backscatter_r"] = ep.DeviceArray(ctx.synth.ek60_device(C, P, S, seed=20260509, ss_every=ss_every)["backscatter_r"])
         ctx.cache[key] = ep.echodata.from_ek60_arrays(d).to_device()
     ed = ctx.cache[key]
     dtype = ctx.dtype
@@ -704,9 +708,11 @@ def run_next(ctx, variant, cpu):
     n = C * P * S
     return line(ctx, samples_per_pass=n, passes=passes, elapsed=elapsed, scaling="weak", cpu=cpu,
                 metric="range-samples/sec through the SURVEY 8f row",
-                workload=f"next:{variant}: EK60 CW {C}x{P}x{S} Sv dataset resident in HBM, {what} through the Dataset API",
-                config={"sharding": "one GPU", "collective": "none", "sound_speed_changes_every_n_pings": 1},
-                roofline=roofline(kern, region_ms, n * bps, bps, traffic_key=f"next:{variant}:{dtype}",
+                workload=f"next:{variant}{'2000' if ss_every != 1 else ''}: EK60 CW {C}x{P}x{S} Sv dataset resident in HBM, "
+                         f"{what} through the Dataset API",
+                config={"sharding": "one GPU", "collective": "none", "sound_speed_changes_every_n_pings": ss_every},
+                roofline=roofline(kern, region_ms, n * bps, bps,
+                                  traffic_key=f"next:{variant}{'2000' if ss_every != 1 else ''}:{dtype}",
                                   note="region = the API calls of one pass incl. host work"))
 
 
@@ -1058,8 +1064,7 @@ def run_cfg5(ctx, cpu, variant=""):
     else:
         extra = {"launch": f"API calls of one {job.tile_p}-ping tile (mean), HIP events"}
     return line(ctx, samples_per_pass=C * P_total * S, passes=passes, elapsed=elapsed, scaling="strong", cpu=cpu,
-                workload=f"cfg5: EK60 CW {C}x{P_total}x{S} in ping_time tiles, entry points "
-                         "compute_Sv -> compute_MVBS(20s x 1m), Sv+MVBS out",
+                workload=f"cfg5: EK60 CW {C}x{P_total}x{S} in ping_time tiles, compute_Sv -> compute_MVBS(20s x 1m), Sv+MVBS out",
                 config=cfg,
                 roofline=roofline("fused_sv_mvbs_kernel (+ K0 of the calls)", region_ms,
                                   n_first * bps, bps, traffic_key=f"cfg5api:{ctx.dtype}", **extra))
@@ -1110,7 +1115,7 @@ def main():
         if todo != ["cfg5"]:
             sys.exit("N > 1 runs the ping-sharded cfg5 workload")
     elif args.workload:
-        todo = [args.workload]
+        todo = args.workload.split(",")  # (several lines in one process, in this order: "cfg5:one,cfg5")
     else:
         todo = ["cfg5"] if args.only_headline else list(DEFAULT_LINES)
 
@@ -1128,6 +1133,7 @@ def main():
                 cpu[kind] = (cpu_baseline_bb() if kind == "bb" else
                              cpu_baseline_ek60(chain=kind == "chain", multicore=kind == "ek60"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (RCCL across processes needs dmabuf IPC on this host driver)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (echopype_amd sets it too: the pipeline's two streams need queues of their own)
     import torch
     import torch.distributed as dist
 
@@ -1153,7 +1159,7 @@ def main():
             sys.exit(f"unknown workload {w!r}")
         ctx.dtype = DT.get(variant, args.dtype)
         if w == "next" and not variant:
-            sys.exit("next:depth | next:depthw | next:masks | next:nasc")
+            sys.exit("next:depth | next:depthw | next:masks | next:masks2000 | next:nasc")
         if w == "cfg5":
             ctx.cache.clear()
             ctx.free()
@@ -1174,7 +1180,8 @@ def main():
             key = "also_" + fam
             if spec == "api:pcie":  # (its own key: the PCIe-inclusive rate must not be mistaken for a resident line)
                 key, var = "also_pcie", ""
-            also[key] = (also[key] + "; " if key in also else "") + (var + " " if var else "") + summary(out)
+            if spec not in ("cfg2:int16f32", "cfg2:bins", "cfg2:int16bins"):  # (own lines only: the headline has 2000 characters)
+                also[key] = (also[key] + "; " if key in also else "") + (var + " " if var else "") + summary(out)
             txt = json.dumps(compact(out), separators=(",", ":"))  # (no padding: the headline carries the other lines' figures)
             print(txt, flush=True)
             if args.out:

@@ -931,3 +931,24 @@ def test_noise_finalize_edge_prepare_affine_rows_first_not_le(env):
     torch.cuda.synchronize()
     assert int(out.item()) == 0                                   # n = 0 on a live buffer
     assert int(ops.first_not_le(_dev(torch, np.array([0.5, 1.0, 1.5, 0.2])), 1.0)) == 2
+
+
+def test_range_power_rows_kernel_serves_what_the_pieces_do_not(env):
+    """epa_range_power: S = 1001 takes no 16-byte accesses -- the strided-rows kernel, the same values as the one-piece
+    kernel writes for the first 1000 samples of the same rows (bit for bit), NaN where the raw sample is."""
+    torch, ops, synth = env
+    from echopype_amd import _lib
+
+    d = synth.ek60_numpy(2, 9, 1001)
+    coef = _coef_ek60(torch, ops, d, "Sv")
+    raw = _dev(torch, d["backscatter_r"])
+    for dtype in (torch.float64, torch.float32):
+        with _lib.launch_trace() as tr:
+            a = ops.range_power(raw, coef, dtype=dtype)
+        assert "range_power_kernel" in tr.kernels and "rows_piece_kernel" not in tr.kernels
+        with _lib.launch_trace() as tr:
+            b = ops.range_power(raw[:, :, :1000].contiguous(), coef, dtype=dtype)
+        assert "rows_piece_kernel" in tr.kernels
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        np.testing.assert_array_equal(a[:, :, :1000], b)
+        np.testing.assert_array_equal(np.isnan(a), np.isnan(d["backscatter_r"]))
