@@ -19,15 +19,15 @@ src = sys.argv[1]
 # traffic key of bench.py -> (rocprof output tag, kernel-name substrings, must also contain, algorithmic bytes per launch)
 KERNELS = {
     # (the <.., true, true> instantiation with the range-maximum by-product belongs to the Dataset-API timing of the run)
-    "cfg2:float64": ("cfg2", ["fused_sv_mvbs_kernel<double, float, true, false>"], None, 4 * 500_000 * 2000 * 12),
+    "cfg2:float64": ("cfg2", ["fused_sv_mvbs_kernel<double, float, true, false, 0>"], None, 4 * 500_000 * 2000 * 12),
     "cfg3:float64": ("cfg3", ["sv_noise_fast_kernel", "sv_denoise_mvbs_fast_kernel", "sv_denoise_mvbs_uniform_kernel",
                               "sv_denoise_mvbs_drift_kernel"], None, 4 * 500_000 * 2000 * 32),
     "cfg4:float64": ("cfg4", ["sv_complex_fft_kernel<float, double, double"], None, 2 * 200_000 * 8192 * 40),
     "cfg4:float64:planes64": ("cfg4_planes64", ["sv_complex_fft_kernel<double, double, double"], None, 2 * 200_000 * 8192 * 72),
-    "cfg5:float64": ("cfg5", ["fused_sv_mvbs_kernel<double, float, true, false>"], None, 4 * 250_000 * 4096 * 12),
+    "cfg5:float64": ("cfg5", ["fused_sv_mvbs_kernel<double, float, true, false, 0>"], None, 4 * 250_000 * 4096 * 12),
     # the round-4 headline: the same tiles through calibrate.compute_Sv -> commongrid.compute_MVBS (statistics variant)
-    "cfg5api:float64": ("cfg5", ["fused_sv_mvbs_kernel<double, float, true, true>"], None, 4 * 250_000 * 4096 * 12),
-    "cfg2:float32": ("cfg2_f32", ["fused_sv_mvbs_kernel<float, float, true, false>"], None, 4 * 500_000 * 2000 * 8),
+    "cfg5api:float64": ("cfg5", ["fused_sv_mvbs_kernel<double, float, true, true, 0>"], None, 4 * 250_000 * 4096 * 12),
+    "cfg2:float32": ("cfg2_f32", ["fused_sv_mvbs_kernel<float, float, true, false, 0>"], None, 4 * 500_000 * 2000 * 8),
     "cfg3:float32": ("cfg3_f32", ["sv_noise_fast_kernel", "sv_denoise_mvbs_fast_kernel", "sv_denoise_mvbs_uniform_kernel",
                                   "sv_denoise_mvbs_drift_kernel"], None, 4 * 500_000 * 2000 * 20),
     "cfg3:float64:ss2000": ("cfg3_ss2000", ["sv_noise_fast_kernel", "sv_denoise_mvbs_fast_kernel",
@@ -35,7 +35,7 @@ KERNELS = {
                             4 * 500_000 * 2000 * 32),
     "cfg4:float32": ("cfg4_f32", ["sv_complex_fft_kernel<float, float, float"], None, 2 * 200_000 * 8192 * 36),
     # the two reference calls with the Sv deferred: the statistics variant of the fused kernel inside compute_MVBS
-    "api:float64": ("api", ["fused_sv_mvbs_kernel<double, float, true, true>"], None, 4 * 500_000 * 2000 * 12),
+    "api:float64": ("api", ["fused_sv_mvbs_kernel<double, float, true, true, 0>"], None, 4 * 500_000 * 2000 * 12),
     # the three reference calls of the chain: pass 1 inside remove_background_noise, pass 2 inside compute_MVBS
     "api:chain:float64": ("api_chain", ["sv_noise_fast_kernel", "sv_denoise_mvbs_fast_kernel", "sv_denoise_mvbs_uniform_kernel",
                                         "sv_denoise_mvbs_drift_kernel"], None, 4 * 500_000 * 2000 * 32),
@@ -45,14 +45,22 @@ KERNELS = {
 # --passes 2 = 4); kernels of the line's one-off setup (compute_Sv / add_depth of the resident dataset) are not listed
 PASSES_IN_PMC_RUN = 4
 PER_PASS = {
-    "cfg2:float64:int16": ("cfg2_int16", ["fused_sv_mvbs_kernel<double, short"], 4 * 500_000 * 2000 * 10),
+    "cfg2:float64:int16": ("cfg2_int16", ["fused_sv_mvbs_kernel<double, short, true"], 4 * 500_000 * 2000 * 10),
+    "cfg2:float32:int16": ("cfg2_int16f32", ["fused_sv_mvbs_kernel<float, short, true"], 4 * 500_000 * 2000 * 6),
+    "cfg2:float64:bins": ("cfg2_bins", ["fused_sv_mvbs_kernel<double, float, false"], 4 * 500_000 * 2000 * 4),
+    "cfg2:float64:int16:bins": ("cfg2_int16bins", ["fused_sv_mvbs_kernel<double, short, false"], 4 * 500_000 * 2000 * 2),
     "cfg2:float64:sv": ("cfg2_sv", ["sv_power_piece_kernel<double", "nl_table_kernel", "d_span_kernel"], 4 * 500_000 * 2000 * 12),
     "cfg2:float32:sv": ("cfg2_sv32", ["sv_power_piece_kernel<float"], 4 * 500_000 * 2000 * 8),
-    "next:depth:float64": ("next_depth", ["sv_power", "depth_rows", "block_reduce", "mvbs_of_sv", "mvbs_finalize",
-                                          "minmax", "range_power"], 4 * 100_000 * 2000 * 40),
+    # round 6: compute_Sv -> add_depth -> compute_MVBS(range_var="depth") is ONE sweep of the raw samples (DEPTH = 1: depth
+    # stays an affine description; DEPTH = 2 / next:depthw: the depth array is written beside Sv)
+    "next:depth:float64": ("next_depth", ["fused_sv_mvbs_kernel<double, float, true, true, 1>"], 4 * 100_000 * 2000 * 12),
+    "next:depthw:float64": ("next_depthw", ["fused_sv_mvbs_kernel<double, float, true, true, 2>"], 4 * 100_000 * 2000 * 20),
     "next:masks:float64": ("next_masks", ["range_bin_smooth", "impulse_compare", "attenuated", "pool_value", "value_",
                                           "row_interval", "row_running", "rows_check", "rows_same", "mask_and", "apply_mask",
                                           "minmax", "step_", "box_"], 4 * 100_000 * 2000 * 70),
+    "next:masks2000:float64": ("next_masks2000", ["range_bin_smooth", "impulse_compare", "attenuated", "pool_value", "value_",
+                                                  "row_interval", "row_running", "rows_check", "rows_same", "mask_and",
+                                                  "apply_mask", "minmax", "step_", "box_", "run_"], 4 * 100_000 * 2000 * 70),
     "next:nasc:float64": ("next_nasc", ["nasc_"], 4 * 100_000 * 2000 * 16),
 }
 
@@ -103,7 +111,7 @@ for key, (wl, names, _, algo) in KERNELS.items():
          "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE x1"
                        + ("; the kernels of a pass summed" if len(names) > 1 else ""),
          "algorithmic_bytes": algo, "csrc_sha16": csrc_hash(),
-         "source": f"profiles/r05_pmc_traffic.csv (bench.py --workload {wl.replace('_', ':')})"}
+         "source": f"profiles/r06_pmc_traffic.csv (bench.py --workload {wl.replace('_', ':')})"}
     k0f = [v for k, v in fe.items() if "power_coef_ek_kernel" in k]
     k0w = [v for k, v in wr.items() if "power_coef_ek_kernel" in k]
     if wl in ("cfg2", "cfg3", "cfg2_f32", "cfg3_f32", "cfg3_ss2000") and k0f and k0w:  # K0 reads 5 x (C, P) f64 + small tables, writes 64 B per (c, p)
@@ -124,7 +132,7 @@ for key, (wl, names, algo) in PER_PASS.items():
     out[key] = {"bytes_per_launch": 2 * fkb * 1024 + wkb * 1024, "fetch_size_kb_raw": fkb, "write_size_kb_raw": wkb,
                 "correction": "FETCH_SIZE x2, WRITE_SIZE x1; every dispatch of the pass's kernels summed, per pass",
                 "algorithmic_bytes": algo, "csrc_sha16": csrc_hash(),
-                "source": f"profiles/r05_pmc_traffic.csv (bench.py --workload {wl.replace('_', ':')})"}
+                "source": f"profiles/r06_pmc_traffic.csv (bench.py --workload {wl.replace('_', ':')})"}
     print(key, "traffic / algorithmic = %.4f" % (out[key]["bytes_per_launch"] / algo))
 path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 json.dump(out, open(path, "w"), indent=1)
