@@ -57,7 +57,7 @@ WORKLOADS = {
     "next": (4, 100_000, 2000, 2, 2),  # SURVEY 8f rows through their API entry points (scripts/perf_masks.py's volume)
 }
 DEFAULT_LINES = ["cfg3", "cfg3:ss2000", "cfg3:f32", "cfg2", "cfg2:f32", "cfg2:int16", "cfg2:int16f32", "cfg2:bins", "cfg2:int16bins", "cfg2:sv", "cfg2:sv32", "api", "api:chain", "api:pcie",
-                 "cfg4", "cfg4:f32", "cfg4:planes64", "next:depth", "next:depthw", "next:masks", "next:masks2000", "next:nasc", "cfg5:one", "cfg5"]
+                 "cfg4", "cfg4:f32", "cfg4:planes64", "next:depth", "next:depthw", "next:masks", "next:masks2000", "next:masksidx", "next:nasc", "cfg5:one", "cfg5"]
 TILE_PINGS = 250_000
 DT = {"f32": "float32", "f64": "float64", "sv32": "float32", "int16f32": "float32"}
 
@@ -129,14 +129,25 @@ def _time_runs(run, budget_s=12.0, max_runs=5):
 
 
 def _cpu_worker(a):
-    C, P, S, seed, reps = a
+    """Whole oracle passes over this worker's ping slice until the common deadline (at least one): (passes, busy s)."""
+    C, P, S, seed, deadline = a
     from echopype_amd import synth
 
     d = synth.ek60_numpy(C, P, S, seed=20260501 + seed)
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    t0, reps = time.perf_counter(), 0
+    while reps == 0 or time.time() < deadline:
         _oracle_ek60(d, False)
-    return time.perf_counter() - t0
+        reps += 1
+    return reps, time.perf_counter() - t0
+
+
+def _cpu_quota():
+    """The cgroup's CPU limit in cores (None = unlimited / unknown): a box can show 256 hardware threads and grant ten."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(per), 1)
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def cpu_baseline_ek60(chain=False, multicore=False):
@@ -154,8 +165,9 @@ def cpu_baseline_ek60(chain=False, multicore=False):
     if multicore:
         # what dask chunk-parallelism over ping_time could reach at best: a ping slice of the same volume in EVERY core
         # the process may use (north_star: "the same box's host cores (core count stated)"), a quarter of the pings per
-        # worker (the workers' footprint -- ~0.4 GB each -- stays well inside the host's memory), repeated to ~2 s of
-        # work per core so that the fork does not weigh
+        # worker (the workers' footprint -- ~0.4 GB each -- stays well inside the host's memory), whole passes until a
+        # common 12-s deadline (a fixed number of passes took 160 s of wall on a 256-thread box: the sample is bounded
+        # by time, whatever the box grants)
         try:
             import multiprocessing as mp
 
@@ -167,14 +179,15 @@ def cpu_baseline_ek60(chain=False, multicore=False):
             except Exception:  # noqa: BLE001
                 pass
             if ncore > 1:
-                Pw = P // 4
-                reps = max(1, int(round(2.0 / (med / 4))))
+                Pw, budget_s = P // 4, 12.0
                 with mp.get_context("fork").Pool(ncore) as pool:
                     t0 = time.perf_counter()
-                    busy = pool.map(_cpu_worker, [(C, Pw, S, i, reps) for i in range(ncore)], chunksize=1)
+                    got = pool.map(_cpu_worker, [(C, Pw, S, i, time.time() + budget_s) for i in range(ncore)], chunksize=1)
                     dtm = time.perf_counter() - t0
-                out["multicore_value"], out["multicore_cores"] = C * Pw * S * reps * ncore / dtm, ncore
-                out["multicore_sample"] = f"{ncore} procs x {reps} x {C}x{Pw}x{S}, {dtm:.0f} s wall, {os.cpu_count()} hw threads"
+                reps = sum(r for r, _ in got)
+                out["multicore_value"], out["multicore_cores"] = C * Pw * S * reps / dtm, ncore
+                out["multicore_sample"] = (f"{ncore} procs, {reps} x {C}x{Pw}x{S} in {dtm:.0f} s, {os.cpu_count()} hw threads, "
+                                           f"cgroup quota {_cpu_quota()}")
         except Exception as e:  # noqa: BLE001 - the single-core figure stands on its own
             out["multicore_error"] = repr(e)[:100]
     return out
@@ -612,8 +625,11 @@ def run_next(ctx, variant, cpu):
     C, P, S = WORKLOADS["next"][:3]
     # masks2000: the recorded sound speed -- hence the range / depth vector -- changes every 2000 pings (an operator's
     # setting holds for a while) instead of at every ping, the worst case the other rows use
+    # masksidx: the masks that have an index-binned form (SURVEY 8f rank 2 names those) with use_index_binning=True
     ss_every = 2000 if variant == "masks2000" else 1
-    if variant == "masks2000":
+    by_index = variant == "masksidx"
+    tag = variant
+    if variant in ("masks2000", "masksidx"):
         variant = "masks"
     key = ("next", C, P, S, ss_every)
     if key not in ctx.cache:
@@ -672,18 +688,21 @@ def run_next(ctx, variant, cpu):
                 def one_pass(timer):
                     if timer is not None:
                         timer.start()
-                    m1 = ep.clean.mask_impulse_noise(ds, depth_bin="5m", num_side_pings=2, impulse_noise_threshold="10.0dB")
+                    m1 = ep.clean.mask_impulse_noise(ds, depth_bin="5m", num_side_pings=2, impulse_noise_threshold="10.0dB",
+                                                     use_index_binning=by_index)
                     m2 = ep.clean.mask_attenuated_signal(ds, upper_limit_sl="150.0m", lower_limit_sl="250.0m",
                                                          num_side_pings=15, attenuation_signal_threshold="8.0dB")
                     m3 = ep.clean.mask_transient_noise(ds, func="nanmean", depth_bin="10m", num_side_pings=25,
-                                                       exclude_above="20.0m", transient_noise_threshold="12.0dB")
+                                                       exclude_above="20.0m", transient_noise_threshold="12.0dB",
+                                                       use_index_binning=by_index)
                     out = ep.mask.apply_mask(ds, [m1, m2, m3])
                     if timer is not None:
                         timer.stop()
                     return out
                 bps = 70 if dtype == "float64" else 38
                 kern = "range_bin_smooth + impulse_compare + attenuated_* + pool_value_* + mask_and + apply_mask kernels"
-                what = "mask_impulse_noise + mask_attenuated_signal + mask_transient_noise (on depth) + apply_mask"
+                what = ("mask_impulse_noise + mask_attenuated_signal + mask_transient_noise (on depth) + apply_mask"
+                        + (", use_index_binning=True" if by_index else ""))
             elif variant == "nasc":
                 p = np.arange(P)
                 ds["latitude"] = (("ping_time",), 45.0 + 1e-5 * p)
@@ -708,11 +727,11 @@ def run_next(ctx, variant, cpu):
     n = C * P * S
     return line(ctx, samples_per_pass=n, passes=passes, elapsed=elapsed, scaling="weak", cpu=cpu,
                 metric="range-samples/sec through the SURVEY 8f row",
-                workload=f"next:{variant}{'2000' if ss_every != 1 else ''}: EK60 CW {C}x{P}x{S} Sv dataset resident in HBM, "
+                workload=f"next:{tag}: EK60 CW {C}x{P}x{S} Sv dataset resident in HBM, "
                          f"{what} through the Dataset API",
                 config={"sharding": "one GPU", "collective": "none", "sound_speed_changes_every_n_pings": ss_every},
                 roofline=roofline(kern, region_ms, n * bps, bps,
-                                  traffic_key=f"next:{variant}{'2000' if ss_every != 1 else ''}:{dtype}",
+                                  traffic_key=f"next:{tag}:{dtype}",
                                   note="region = the API calls of one pass incl. host work"))
 
 
@@ -1003,7 +1022,8 @@ def run_cfg5(ctx, cpu, variant=""):
     a rank's consecutive shards alternate between the streams, the collectives are issued in item order.  N = 1: Sv of the tiles goes to one reused buffer (ops level) /
     to the allocator's recycled block (API): 131 GB in + 262 GB out does not fit 288 GB otherwise."""
     args, world = ctx.args, ctx.world
-    ctx.tile_streams = 1 if variant == "one" else max(1, args.tile_streams)
+    # (--single-device: the ranks of the dry run share ONE GPU's 288 GB -- a second Sv in flight per rank does not fit)
+    ctx.tile_streams = 1 if variant == "one" or args.single_device else max(1, args.tile_streams)
     C, _, S = WORKLOADS["cfg5"][:3]
     P_total = args.pings_total or WORKLOADS["cfg5"][1]
     job = Cfg5(ctx, C, P_total, S, tile_pings=args.tile_pings, ss_every=args.ss_every)
@@ -1029,8 +1049,8 @@ def run_cfg5(ctx, cpu, variant=""):
     elapsed, region_ms = ctx.timed(pass_c, passes, finish=finish_c, timers_of=lambda: state["timers"])
     assert state["n_read"] == len(job.tiles) * passes * (steps + args.warmup)  # every result was read
     if world == 1 and not getattr(args, "sharded_at_1", False):
-        route = "compute_Sv(echodata) -> compute_MVBS(ds_Sv,'1m','20s') per tile"
-        coll = "none at 1 rank (a tile = a dataset)"
+        route = "compute_Sv -> compute_MVBS('1m','20s') per tile"
+        coll = "none at 1 rank"
     else:
         route = "sharding.compute_Sv_MVBS(echodata_shard, shard=MVBSShard()) per tile"
         coll = (f"per dataset of {world} tiles: cut bins all_reduce(SUM) + range max all_reduce(MAX) in HBM over "
@@ -1096,9 +1116,33 @@ def compact(x):
     return x
 
 
+# what a line can lose, in this order, when it would not fit the driver's 2000-character tail (the last line carries the
+# other lines' figures and grows with them); everything the contract names stays
+DROP_ORDER = (("config", "ops_level_edge_bins"), ("config", "allreduce_bytes"), ("config", "ops_level_kernel_ms"),
+              ("config", "ops_level_ms_per_pass"), ("config", "mvbs_shape_last_tile"), ("config", "results_read"),
+              ("roofline", "traffic_source"), ("cpu_baseline", "multicore_sample"), ("config", "route"),
+              ("roofline", "launch"), ("config", "also_cfg4"), ("config", "also_cfg3"), ("config", "collective"))
+
+
+def fit(out, limit=1950):
+    """The line as compact JSON, optional keys dropped (the first ``config.dropped`` of DROP_ORDER) until it fits."""
+    out = compact(out)
+    dropped = []
+    for sec, key in DROP_ORDER:
+        txt = json.dumps(out, separators=(",", ":"))
+        if len(txt) <= limit:
+            return txt
+        if key in out.get(sec, {}):
+            del out[sec][key]
+            dropped.append(key)
+            out["config"]["dropped"] = len(dropped)
+    return json.dumps(out, separators=(",", ":"))
+
+
 def summary(out):
     """'<Gsamp/s> f<fraction of 8 TB/s>' of a line, for the headline's also_* strings."""
-    return f"{out['value'] / 1e9:.1f} f{out['roofline']['frac']:.3f}"
+    g = out["value"] / 1e9
+    return (f"{g:.0f}" if g >= 100 else f"{g:.1f}") + f" f{out['roofline']['frac']:.3f}"
 
 
 def main():
@@ -1159,7 +1203,7 @@ def main():
             sys.exit(f"unknown workload {w!r}")
         ctx.dtype = DT.get(variant, args.dtype)
         if w == "next" and not variant:
-            sys.exit("next:depth | next:depthw | next:masks | next:masks2000 | next:nasc")
+            sys.exit("next:depth | next:depthw | next:masks | next:masks2000 | next:masksidx | next:nasc")
         if w == "cfg5":
             ctx.cache.clear()
             ctx.free()
@@ -1182,7 +1226,7 @@ def main():
                 key, var = "also_pcie", ""
             if spec not in ("cfg2:int16f32", "cfg2:bins", "cfg2:int16bins"):  # (own lines only: the headline has 2000 characters)
                 also[key] = (also[key] + "; " if key in also else "") + (var + " " if var else "") + summary(out)
-            txt = json.dumps(compact(out), separators=(",", ":"))  # (no padding: the headline carries the other lines' figures)
+            txt = fit(out)  # (no padding: the headline carries the other lines' figures)
             print(txt, flush=True)
             if args.out:
                 with open(args.out, "a") as f:

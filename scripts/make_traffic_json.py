@@ -61,6 +61,8 @@ PER_PASS = {
     "next:masks2000:float64": ("next_masks2000", ["range_bin_smooth", "impulse_compare", "attenuated", "pool_value", "value_",
                                                   "row_interval", "row_running", "rows_check", "rows_same", "mask_and",
                                                   "apply_mask", "minmax", "step_", "box_", "run_"], 4 * 100_000 * 2000 * 70),
+    "next:masksidx:float64": ("next_masksidx", ["range_bin_smooth", "impulse_compare", "attenuated", "pool_", "mask_and",
+                                                "apply_mask", "minmax", "step_", "box_"], 4 * 100_000 * 2000 * 70),
     "next:nasc:float64": ("next_nasc", ["nasc_"], 4 * 100_000 * 2000 * 16),
 }
 
@@ -96,7 +98,10 @@ def mean_per_kernel(d, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
-out = {}
+path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+# "merge": keep the entries of the committed file that this directory does not measure again (a later line added to the
+# record without repeating every pass; the entries carry the hash of the sources they were measured on)
+out = json.load(open(path)) if len(sys.argv) > 2 and sys.argv[2] == "merge" else {}
 for key, (wl, names, _, algo) in KERNELS.items():
     fd, wd = os.path.join(src, f"fetch_{wl}"), os.path.join(src, f"write_{wl}")
     if not (os.path.isdir(fd) and os.path.isdir(wd)):
@@ -134,6 +139,5 @@ for key, (wl, names, algo) in PER_PASS.items():
                 "algorithmic_bytes": algo, "csrc_sha16": csrc_hash(),
                 "source": f"profiles/r06_pmc_traffic.csv (bench.py --workload {wl.replace('_', ':')})"}
     print(key, "traffic / algorithmic = %.4f" % (out[key]["bytes_per_launch"] / algo))
-path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 json.dump(out, open(path, "w"), indent=1)
 print("wrote", path)
