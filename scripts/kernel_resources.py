@@ -1,5 +1,5 @@
 """Registers, scratch, LDS and occupancy of every kernel of the library as the compiler reports them
-(-Rpass-analysis=kernel-resource-usage; no GPU needed) -> profiles/r05_kernel_resources.txt.  rocprofv3's Arch_VGPR column
+(-Rpass-analysis=kernel-resource-usage; no GPU needed) -> profiles/r06_kernel_resources.txt.  rocprofv3's Arch_VGPR column
 counts register PAIRS on wave64 (half of "VGPRs" here)."""
 import os
 import re
