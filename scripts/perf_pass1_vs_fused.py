@@ -5,7 +5,7 @@ import numpy as np
 import torch
 sys.path.insert(0, ".")
 from echopype_amd import _lib, ops, synth
-C, P, S = 4, 250000, 2000
+C, P, S = 4, int(sys.argv[1]) if len(sys.argv) > 1 else 250000, 2000
 d = synth.ek60_device(C, P, S)
 coef = ops.power_coef_ek(d["sample_interval"], d["transmit_duration_nominal"], d["transmit_power"],
     d["sound_speed_indicative"], d["absorption_indicative"], d["gain_correction"], d["sa_correction"],
@@ -28,6 +28,12 @@ def timeit(name, fn, reps=5):
 for rsn in (50, 2000):
     timeit(f"pass 1, noise blocks 20 x {rsn}", lambda: ops.sv_noise_fused(raw, coef, a2, 20, rsn))
 timeit("pass 1, noise blocks 100 x 50", lambda: ops.sv_noise_fused(raw, coef, a2, 100, 50))
+timeit("pass 1, 20 x 50, no Sv store", lambda: ops.sv_noise_fused(raw, coef, a2, 20, 50, want_sv=False))
+timeit("pass 1, 20 x 50, + range statistics", lambda: ops.sv_noise_fused(raw, coef, a2, 20, 50, want_range_stats=True))
+timeit("pass 1, 20 x 50, float32", lambda: ops.sv_noise_fused(raw, coef, a2, 20, 50, dtype=torch.float32))
+timeit("pass 1, 20 x 50, float32, no Sv store", lambda: ops.sv_noise_fused(raw, coef, a2, 20, 50, dtype=torch.float32, want_sv=False))
+timeit("fused Sv -> MVBS (20 s x 1 m), bins only", lambda: ops.sv_mvbs_fused(raw, coef, bs, n_t, 1.0, n_r, want_sv=False))
+timeit("K1 compute_Sv alone", lambda: ops.sv_power(raw, coef, want_range=False))
 timeit("fused Sv -> MVBS (20 s x 1 m)", lambda: ops.sv_mvbs_fused(raw, coef, bs, n_t, 1.0, n_r))
 for nb in (20, 40, 100, 500):
     dtb2 = nb * 1_000_000_000
