@@ -942,7 +942,8 @@ class Cfg5:
                 for _ in range(T):
                     for item in state["pipe"].submit(state["launched"]):
                         read(item)
-                    item = None  # (a result that has been read is not kept over the next launch: its Sv array is 32.8 GB)
+                    if not os.environ.get("EPA_BENCH_KEEP"):  # (development knob)
+                        item = None  # (a result that has been read is not kept over the next launch: its Sv array is 32.8 GB)
                     state["launched"] += 1
             finally:
                 logging.disable(logging.NOTSET)

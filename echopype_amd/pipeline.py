@@ -8,7 +8,8 @@ their results are looked at:
 
 * consecutive items go to alternating HIP side streams, so the kernel of file k + 1 starts beside the tail of file k's (one
   bin-owning walk leaves part of the memory system idle; two launches side by side stream the same mix 10-15 % faster,
-  profiles/r05_tile_streams.txt);
+  profiles/r05_tile_streams.txt) -- streams that were SEEN to run side by side: two streams the runtime has bound to one
+  hardware queue take turns (``_runs_beside``);
 * the result of item k is handed out only after the next ``lag`` items have been launched: touching a deferred dataset
   (its grid size comes back from the GPU) then never stalls the queue.
 
@@ -35,18 +36,59 @@ def _settle(result):
             r._resolve()
 
 
+def _runs_beside(a, b, cycles=100_000):
+    """True when kernels queued on streams ``a`` and ``b`` execute at the same time.  The HIP runtime binds a stream, at
+    its first use, to one of ``GPU_MAX_HW_QUEUES`` hardware queues; two streams of one queue run their kernels one after
+    the other, and which streams share a queue depends on everything the process has used before (measured, round 6: the
+    same two-stream loop at 0.73 of the roofline in a fresh process and at 0.665 -- one stream's figure -- at the end of
+    a long one; profiles/r06_stream_pairs.txt).  Two spin kernels of one workgroup each: side by side they take the
+    time of one.  Waits for the GPU (a few hundred microseconds, once per process and device)."""
+    home = torch.cuda.current_stream()
+
+    def timed(streams):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(home)
+        for st in streams:
+            st.wait_event(e0)
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(cycles)
+        for st in streams:
+            home.wait_stream(st)
+        e1.record(home)
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+
+    timed([a, b])  # (first use binds the streams)
+    one = min(timed([a]) for _ in range(2))
+    both = min(timed([a, b]) for _ in range(2))
+    return both < 1.5 * one
+
+
 class _Streams:
-    """``n`` side streams of the current device, kept per (device, n): a loop that calls ``run`` once per batch does not
-    create streams every time."""
+    """``n`` side streams of the current device that run side by side (``_runs_beside``: a candidate that shares a
+    hardware queue with a stream already chosen is set aside, up to ``_TRIES`` candidates per slot), kept per
+    (device, n): a loop that calls ``run`` once per batch does not create streams -- or wait for the check -- every time."""
 
     _cache = {}
+    _TRIES = 8
+    checked = {}  # (device, n) -> every pair of the set was seen running side by side
 
     @classmethod
     def get(cls, n):
         dev = torch.cuda.current_stream().device
         key = (dev, n)
         if key not in cls._cache:
-            cls._cache[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+            chosen, ok = [], True
+            for _ in range(n):
+                cand = None
+                for _ in range(cls._TRIES):
+                    cand = torch.cuda.Stream(device=dev)
+                    if all(_runs_beside(c, cand) for c in chosen):
+                        break
+                else:
+                    ok = False  # (GPU_MAX_HW_QUEUES=1, or every queue taken: the last candidate serves)
+                chosen.append(cand)
+            cls._cache[key], cls.checked[key] = chosen, ok
         return cls._cache[key]
 
 

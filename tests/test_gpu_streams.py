@@ -160,3 +160,21 @@ def test_pipeline_run_orders_items_behind_the_callers_stream(env):
     # (lag 0: an item is handed out -- the caller's stream waits for it -- before the caller touches ``base`` again)
     out = [float(t.item()) for t in ep.pipeline.run(items(), fn, streams=2, lag=0, settle=False)]
     assert out == [float((i + 1) * (1 << 22)) for i in range(6)]
+
+
+def test_pipeline_streams_were_seen_running_side_by_side(env):
+    """The side streams the pipeline deals items to are checked, not assumed: two streams the HIP runtime has bound to
+    one hardware queue run their kernels in turns (the headline's two-stream gain came and went with that between runs
+    of one bench process, profiles/r06_stream_pairs.txt).  A stream against itself is the serial case."""
+    torch, ep, _ = env
+    a, b = ep.pipeline._Streams.get(2)
+    assert a is not b and ep.pipeline._Streams.checked[(a.device, 2)]
+    assert ep.pipeline._runs_beside(a, b)
+    assert not ep.pipeline._runs_beside(a, a)
+    # more streams than the runtime has hardware queues for (GPU_MAX_HW_QUEUES, 8 unless the user set it): the check sets
+    # a sharing candidate aside, so a set of three still runs pairwise side by side
+    three = ep.pipeline._Streams.get(3)
+    assert len({id(s) for s in three}) == 3
+    if ep.pipeline._Streams.checked[(a.device, 3)]:
+        assert all(ep.pipeline._runs_beside(three[i], three[j]) for i in range(3) for j in range(i + 1, 3))
+    torch.cuda.synchronize()
