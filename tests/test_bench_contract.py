@@ -138,7 +138,7 @@ def test_live_headline_line():
     _check_line(d, want_cpu=False)
     assert d["steps"] == 3 and d["warmup"] == 1 and d["n_gpus"] == 1 and d["scaling"] == "strong"
     assert d["config"]["workload"].startswith("cfg5") and d["config"]["allreduce_bytes"] > 0
-    assert "compute_Sv(echodata)" in d["config"]["route"] and d["config"]["mvbs_shape_last_tile"][0] == 4
+    assert "compute_Sv -> compute_MVBS" in d["config"]["route"] and d["config"]["mvbs_shape_last_tile"][0] == 4
     assert d["config"]["ranks"]["world_size"] == 1 and d["config"]["ranks"]["devices"] == ["0:cuda0"]
     assert len(lines[0]) < 1800                                   # (room for eight ranks' devices under the driver's 2000)
 
@@ -163,7 +163,7 @@ def test_gloo_two_ranks_print_the_same_workload_with_a_cpu_baseline():
     assert one["config"]["samples_per_step"] == two["config"]["samples_per_step"]
     assert one["config"]["tiles"].split(" over ")[0] == two["config"]["tiles"].split(" over ")[0]
     # N = 1: the reference's two calls per tile; N > 1: the sharded entry point, every rank and its device on the line
-    assert "sharding.compute_Sv_MVBS" in two["config"]["route"] and "compute_MVBS(ds_Sv" in one["config"]["route"]
+    assert "sharding.compute_Sv_MVBS" in two["config"]["route"] and "compute_Sv -> compute_MVBS" in one["config"]["route"]
     r = two["config"]["ranks"]
     assert r["world_size"] == 2 and r["backend"] == "gloo" and r["devices"] == ["0:cuda0", "1:cuda0"]
     assert one["config"]["mvbs_shape_last_tile"][2] == two["config"]["mvbs_shape_last_tile"][2]
