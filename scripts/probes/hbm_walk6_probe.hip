@@ -83,7 +83,43 @@ void run(const float* in, double* out, int P, int S, int R, int xcd) {
   fflush(stdout);
 }
 
-int main() {
+template <int D>
+double rate(const float* in, double* out, int P, int S, int R) {
+  const int grid = (P / R) * (S / 1024);
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  float best = 1e9f;
+  for (int rep = 0; rep < 4; ++rep) {
+    (void)hipEventRecord(a);
+    hipLaunchKernelGGL((walk<D, 1>), dim3(grid), dim3(256), 0, 0, in, out, S, R, 1);
+    (void)hipEventRecord(b);
+    (void)hipEventSynchronize(b);
+    float ms;
+    (void)hipEventElapsedTime(&ms, a, b);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  return (double)(P / R * R) * S * 12.0 / best / 1e9;
+}
+
+int main(int argc, char**) {
+  if (argc > 1) {  // several allocation sets of one process: the placement of a set decides more than any variant
+    const int S = 4096, P = 200000;
+    printf("set   rows ahead: 0      1      2      4      6   | R = 1 (loop-free)   (TB/s, R = 20 rows per workgroup)\n");
+    for (int k = 0; k < 8; ++k) {
+      float* in;
+      double* out;
+      (void)hipMalloc(&in, (size_t)P * S * 4);
+      (void)hipMalloc(&out, (size_t)P * S * 8);
+      (void)hipMemset(in, 0, (size_t)P * S * 4);
+      (void)hipMemset(out, 0, (size_t)P * S * 8);
+      printf("%3d            %6.3f %6.3f %6.3f %6.3f %6.3f   | %6.3f\n", k, rate<0>(in, out, P, S, 20), rate<1>(in, out, P, S, 20),
+             rate<2>(in, out, P, S, 20), rate<4>(in, out, P, S, 20), rate<6>(in, out, P, S, 20), rate<0>(in, out, P, S, 1));
+      fflush(stdout);
+    }
+    return 0;
+  }
+
   for (int S : {4096, 2048}) {
     const int P = S == 4096 ? 200000 : 400000;
     float* in;
