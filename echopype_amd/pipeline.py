@@ -39,10 +39,13 @@ def _settle(result):
 def _runs_beside(a, b, cycles=100_000):
     """True when kernels queued on streams ``a`` and ``b`` execute at the same time.  The HIP runtime binds a stream, at
     its first use, to one of ``GPU_MAX_HW_QUEUES`` hardware queues; two streams of one queue run their kernels one after
-    the other, and which streams share a queue depends on everything the process has used before (measured, round 6: the
-    same two-stream loop at 0.73 of the roofline in a fresh process and at 0.665 -- one stream's figure -- at the end of
-    a long one; profiles/r06_stream_pairs.txt).  Two spin kernels of one workgroup each: side by side they take the
-    time of one.  Waits for the GPU (a few hundred microseconds, once per process and device)."""
+    the other, and which streams share a queue depends on everything the process has used before (measured, round 6,
+    with the runtime's default of four queues: the two-stream loop at 0.73 of the roofline on most pairs of ten streams
+    and at 0.666 -- one stream's figure -- on the pairs five apart; profiles/r06_stream_pairs.txt).  Two spin kernels of
+    one workgroup each: side by side they take the time of one.  Waits for the GPU (a few hundred microseconds, once
+    per process and device)."""
+    if not hasattr(torch.cuda, "_sleep"):  # (a private helper of torch: without it the streams are taken as they come)
+        return a is not b
     home = torch.cuda.current_stream()
 
     def timed(streams):
