@@ -33,6 +33,7 @@ CCP = ("sample_interval", "tau_nominal", "transmit_power", "sound_speed", "absor
        "sa_correction", "z_er", "z_et", "angle_offset_alongship", "angle_offset_athwartship", "beamwidth_alongship",
        "beamwidth_athwartship")  # enum epa_ccoef_param
 EK80_NFFT = 2048
+APPLY_MASKS_WS_DOUBLES = 131072  # EPA_APPLY_MASKS_WS_DOUBLES
 
 
 class EpaError(RuntimeError):
@@ -117,6 +118,7 @@ SIGNATURES = {
     "epa_pool_sv": [_vp, _i, _i, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _i, _vp],
     "epa_attenuated_mask": [_vp, _vp, _i, _i, _i, _d, _d, _i, _d, _vp, _i, _vp],
     "epa_apply_mask": [_vp, _vp, _sz, _sz, _d, _vp, _sz, _vp, _i, _vp],
+    "epa_apply_masks": [_vp, _vp, _vp, _i, _sz, _d, _vp, _sz, _vp, _vp, _vp, _i, _vp],
     "epa_mask_and": [_vp, _vp, _sz, _sz, _vp, _vp],
     "epa_range_step_mean": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "epa_first_not_le": [_vp, _sz, _d, _i, _vp, _vp],

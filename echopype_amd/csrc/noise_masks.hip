@@ -3341,6 +3341,78 @@ __global__ __launch_bounds__(kBlock) void apply_mask_kernel(const T* __restrict_
     out[i] = mask[i % mask_period] ? src[i] : (fill_arr ? fill_arr[i % fill_period] : fill);
 }
 
+// The same with up to four masks -- apply_mask(ds, [m1, m2, m3]) is where(m1 & m2 & m3, src, fill) (mask/api.py:402-432):
+// one sweep, 8 + 3 + 8 B per fp64 sample instead of two mask_and passes (3 B each) before it and a min / max sweep (8 B)
+// behind it for the variable's actual_range -- and the NaN-skipping {min, max} of what is written, one pair per workgroup
+// in ``part`` (folded by minmax_pairs_kernel).  A mask whose period is the whole array is indexed without the division.
+struct MaskSet {
+  const uint8_t* m[4];
+  size_t period[4];
+  int n;
+};
+template <typename T>
+__global__ __launch_bounds__(kBlock) void apply_masks_kernel(const T* __restrict__ src, MaskSet ms, size_t n, T fill,
+                                                             const T* __restrict__ fill_arr, size_t fill_period,
+                                                             T* __restrict__ out, double* __restrict__ part) {
+  double lo = __builtin_inf(), hi = -__builtin_inf();
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    bool keep = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < ms.n) keep = keep & (ms.m[k][ms.period[k] == n ? i : i % ms.period[k]] != 0);
+    const T v = keep ? src[i] : (fill_arr ? fill_arr[fill_period == n ? i : i % fill_period] : fill);
+    out[i] = v;
+    if (part) {  // fmin / fmax ignore a NaN operand
+      lo = fmin(lo, (double)v);
+      hi = fmax(hi, (double)v);
+    }
+  }
+  if (part) {
+    __shared__ double slo[kBlock / 64], shi[kBlock / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo = fmin(lo, __shfl_down(lo, o, 64));
+      hi = fmax(hi, __shfl_down(hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      slo[threadIdx.x >> 6] = lo;
+      shi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      part[2 * (size_t)blockIdx.x] = fmin(fmin(slo[0], slo[1]), fmin(slo[2], slo[3]));
+      part[2 * (size_t)blockIdx.x + 1] = fmax(fmax(shi[0], shi[1]), fmax(shi[2], shi[3]));
+    }
+  }
+}
+
+// {min, max} pairs of the workgroups -> out[0], out[1] (NaN when nothing was a number)
+__global__ __launch_bounds__(kBlock) void minmax_pairs_kernel(const double* __restrict__ part, int npairs,
+                                                              double* __restrict__ out) {
+  __shared__ double slo[kBlock / 64], shi[kBlock / 64];
+  double lo = __builtin_inf(), hi = -__builtin_inf();
+  for (int i = threadIdx.x; i < npairs; i += kBlock) {
+    lo = fmin(lo, part[2 * i]);
+    hi = fmax(hi, part[2 * i + 1]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fmin(lo, __shfl_down(lo, o, 64));
+    hi = fmax(hi, __shfl_down(hi, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    slo[threadIdx.x >> 6] = lo;
+    shi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    lo = fmin(fmin(slo[0], slo[1]), fmin(slo[2], slo[3]));
+    hi = fmax(fmax(shi[0], shi[1]), fmax(shi[2], shi[3]));
+    out[0] = lo <= hi ? lo : __builtin_nan("");
+    out[1] = lo <= hi ? hi : __builtin_nan("");
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void mask_and_kernel(const uint8_t* __restrict__ a,
                                                           const uint8_t* __restrict__ b, size_t n,
                                                           size_t b_period, uint8_t* __restrict__ out) {
@@ -3809,6 +3881,42 @@ extern "C" int epa_apply_mask(const void* src, const uint8_t* mask, size_t n, si
                        n, mask_period, (float)fill_value, (const float*)fill_array,
                        fill_array ? fill_period : 1, (float*)out);
   return epa::check_launch("apply_mask_kernel");
+}
+
+extern "C" int epa_apply_masks(const void* src, const uint8_t* const* masks, const size_t* mask_periods, int n_masks,
+                               size_t n, double fill_value, const void* fill_array, size_t fill_period, void* out,
+                               double* workspace, double* minmax_out, int dtype, epa_stream_t stream) {
+  EPA_CHECK_ARG(src && masks && mask_periods && out, "epa_apply_masks: NULL array argument");
+  EPA_CHECK_ARG(n_masks >= 1 && n_masks <= 4, "epa_apply_masks: 1 to 4 masks (got %d)", n_masks);
+  MaskSet ms{};
+  ms.n = n_masks;
+  for (int k = 0; k < n_masks; ++k) {
+    EPA_CHECK_ARG(masks[k] != nullptr, "epa_apply_masks: mask %d is NULL", k);
+    EPA_CHECK_ARG(mask_periods[k] > 0 && n % mask_periods[k] == 0, "epa_apply_masks: mask %d does not tile the source", k);
+    ms.m[k] = masks[k];
+    ms.period[k] = mask_periods[k];
+  }
+  EPA_CHECK_ARG(!fill_array || (fill_period > 0 && n % fill_period == 0),
+                "epa_apply_masks: fill array does not tile the source");
+  EPA_CHECK_ARG(dtype == EPA_F32 || dtype == EPA_F64, "epa_apply_masks: bad dtype %d", dtype);
+  EPA_CHECK_ARG(!minmax_out || workspace, "epa_apply_masks: minmax_out needs the workspace");
+  if (n == 0) return EPA_OK;
+  const size_t blocks = (n + kBlock - 1) / kBlock;
+  const int grid = (int)(blocks < EPA_APPLY_MASKS_WS_DOUBLES / 2 ? blocks : EPA_APPLY_MASKS_WS_DOUBLES / 2);
+  hipStream_t st = (hipStream_t)stream;
+  double* part = minmax_out ? workspace : nullptr;
+  if (dtype == EPA_F64)
+    hipLaunchKernelGGL(apply_masks_kernel<double>, dim3(grid), dim3(kBlock), 0, st, (const double*)src, ms, n,
+                       fill_value, (const double*)fill_array, fill_array ? fill_period : 1, (double*)out, part);
+  else
+    hipLaunchKernelGGL(apply_masks_kernel<float>, dim3(grid), dim3(kBlock), 0, st, (const float*)src, ms, n,
+                       (float)fill_value, (const float*)fill_array, fill_array ? fill_period : 1, (float*)out, part);
+  if (int rc = epa::check_launch("apply_masks_kernel")) return rc;
+  if (minmax_out) {
+    hipLaunchKernelGGL(minmax_pairs_kernel, dim3(1), dim3(kBlock), 0, st, part, grid, minmax_out);
+    return epa::check_launch("minmax_pairs_kernel");
+  }
+  return EPA_OK;
 }
 
 extern "C" int epa_mask_and(const uint8_t* a, const uint8_t* b, size_t n, size_t b_period, uint8_t* out,

@@ -137,11 +137,15 @@ def apply_mask(source_ds, mask, var_name="Sv", fill_value=np.nan, storage_option
     masks = mask if isinstance(mask, list) else [mask]
     # channel-carrying masks first so that the channel-less ones broadcast into them (xr.broadcast, :403)
     tensors = sorted((_mask_tensor(m, order) for m in masks), key=lambda t: -t.dim())
-    final = tensors[0]
+    final = tensors[0]  # (its shape is the shape of the AND of all: the others broadcast into it)
     for t in tensors[1:]:
         if final.numel() % t.numel() != 0 or tuple(final.shape[-t.dim():]) != tuple(t.shape):
             raise ValueError("All masks must have the same shape in the 'channel' dimension.")
-        final = ops.mask_and(final, t)
+    # up to four masks go to the kernel as they are (one sweep: the AND, the selection and the result's min / max); a
+    # fifth and further ones are folded into the first beforehand
+    while len(tensors) > 4:
+        tensors = [ops.mask_and(tensors[0], tensors.pop())] + tensors[1:]
+        final = tensors[0]
     has_chan = "channel" in order
     src_chan_shape = tuple(src_t.shape[1:]) if has_chan and order[0] == "channel" else tuple(
         n for d, n in zip(order, src_t.shape) if d != "channel")
@@ -158,13 +162,13 @@ def apply_mask(source_ds, mask, var_name="Sv", fill_value=np.nan, storage_option
 
     if isinstance(fill_value, DataArray):
         fill_t = _dev(fill_value, src_t.dtype).reshape(src_chan_shape).contiguous()
-        out_t = ops.apply_mask(src_t, final, fill_array=fill_t)
+        out_t, mm = ops.apply_masks(src_t, tensors, fill_array=fill_t, want_minmax=True)
     else:
-        out_t = ops.apply_mask(src_t, final, fill_value=float(fill_value))
+        out_t, mm = ops.apply_masks(src_t, tensors, fill_value=float(fill_value), want_minmax=True)
 
     output_ds = source_ds.copy()
     attrs = dict(source_da.attrs)
-    lo, hi = ops.nanminmax(out_t)
+    lo, hi = mm.cpu().tolist()  # (a by-product of the sweep that wrote the array)
     attrs.update({
         "long_name": "Volume backscattering strength, masked (Sv re 1 m-1)",
         "actual_range": [round(lo, 2), round(hi, 2)],

@@ -798,6 +798,28 @@ def apply_mask(src, mask, fill_value=float("nan"), fill_array=None):
     return out
 
 
+def apply_masks(src, masks, fill_value=float("nan"), fill_array=None, want_minmax=False):
+    """where(AND of ``masks``, src, fill) in one sweep (1 to 4 uint8 masks, each tiling ``src`` over its leading dims)
+    -> (out, f64 device tensor {nanmin, nanmax} of out | None)."""
+    import ctypes
+
+    if not 1 <= len(masks) <= 4:
+        raise ValueError("apply_masks takes 1 to 4 masks (AND further ones with mask_and first)")
+    out = torch.empty_like(src)
+    if fill_array is not None and fill_array.dtype != src.dtype:
+        fill_array = fill_array.to(src.dtype)
+    ptrs = (ctypes.c_void_p * len(masks))(*[m.data_ptr() for m in masks])
+    periods = (ctypes.c_size_t * len(masks))(*[m.numel() for m in masks])
+    ws = mm = None
+    if want_minmax:
+        ws = torch.empty(_lib.APPLY_MASKS_WS_DOUBLES, dtype=torch.float64, device=src.device)
+        mm = torch.empty(2, dtype=torch.float64, device=src.device)
+    call("epa_apply_masks", _p(src), ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(periods, ctypes.c_void_p), len(masks),
+         src.numel(), float(fill_value), _p(fill_array), fill_array.numel() if fill_array is not None else 1, _p(out),
+         _p(ws), _p(mm), _DT[src.dtype], _stream())
+    return out, mm
+
+
 def mask_and(a, b):
     """a & b, ``b`` broadcast over the leading dims of ``a``."""
     out = torch.empty_like(a)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define EPA_VERSION 103 /* 0.1.3: epa_sv_mvbs_fused_depth */
+#define EPA_VERSION 104 /* 0.1.4: epa_apply_masks */
 
 typedef void* epa_stream_t;
 
@@ -504,6 +504,16 @@ int epa_attenuated_mask(const void* sv, const void* range, int C, int P, int S, 
 int epa_apply_mask(const void* src, const uint8_t* mask, size_t n, size_t mask_period,
                    double fill_value, const void* fill_array, size_t fill_period, void* out,
                    int dtype, epa_stream_t stream);
+
+/* out[i] = (masks[0][i % p0] & ... & masks[n_masks-1][..]) ? src[i] : fill -- mask/api.py:402-432 in ONE sweep for a LIST
+ * of masks (np.logical_and.reduce over the broadcast masks, :405-408, then xr.where, :428-432): 1 <= n_masks <= 4 (AND
+ * further ones with epa_mask_and first); ``masks`` / ``mask_periods`` are HOST arrays of device pointers / periods.
+ * minmax_out != NULL: f64 [2] on the device = NaN-skipping {min, max} of what was written (the variable's actual_range,
+ * mask/api.py:434-444 via clean/utils.py:392-395), with workspace = f64 [EPA_APPLY_MASKS_WS_DOUBLES] on the device. */
+#define EPA_APPLY_MASKS_WS_DOUBLES 131072
+int epa_apply_masks(const void* src, const uint8_t* const* masks, const size_t* mask_periods, int n_masks, size_t n,
+                    double fill_value, const void* fill_array, size_t fill_period, void* out, double* workspace,
+                    double* minmax_out, int dtype, epa_stream_t stream);
 
 /* out = a & b[i % b_period]  (mask/api.py:405-408, np.logical_and.reduce over broadcast masks). */
 int epa_mask_and(const uint8_t* a, const uint8_t* b, size_t n, size_t b_period, uint8_t* out,

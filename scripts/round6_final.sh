@@ -6,7 +6,7 @@
 #   SKIP_TESTS=1 leaves the test suite out, SKIP_PMC=1 the counter passes.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/final6; rm -rf $O; mkdir -p $O
-LINES="cfg2 cfg2:f32 cfg2:int16 cfg2:int16f32 cfg2:bins cfg2:int16bins cfg2:sv cfg2:sv32 cfg3 cfg3:f32 cfg3:ss2000 cfg4 cfg4:f32 cfg4:planes64 cfg5 api api:chain next:depth next:depthw next:masks next:masks2000 next:nasc"
+LINES="cfg2 cfg2:f32 cfg2:int16 cfg2:int16f32 cfg2:bins cfg2:int16bins cfg2:sv cfg2:sv32 cfg3 cfg3:f32 cfg3:ss2000 cfg4 cfg4:f32 cfg4:planes64 cfg5 api api:chain next:depth next:depthw next:masks next:masks2000 next:masksidx next:nasc"
 if [ -z "$SKIP_PMC" ]; then
 for wl in $LINES; do
   tag=$(echo $wl | tr ':' '_')

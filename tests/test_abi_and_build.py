@@ -37,7 +37,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     from echopype_amd import _lib
 
     assert sorted(_lib.SIGNATURES) == declared_symbols()
-    assert _lib.lib.epa_version() == 103
+    assert _lib.lib.epa_version() == 104
 
 
 def test_library_carries_the_digest_of_the_sources_it_was_built_from(tmp_path):

@@ -665,6 +665,46 @@ def test_apply_mask_and_mask_and(env, dtype):
     np.testing.assert_array_equal(got.cpu().numpy(), np.where(m1, src, fill[None]))
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("shape", [(3, 7, 11), (4, 300, 2050)])
+def test_apply_masks_is_the_and_the_selection_and_the_range_in_one_sweep(env, dtype, shape):
+    """ops.apply_masks (epa_apply_masks): where(m1 & m2 & ..., src, fill) for up to four masks, channel-less ones broadcast,
+    scalar or array fill, + the NaN-skipping {min, max} of the result -- against the oracle's apply_mask (mask/api.py:402-432)
+    and against the separate kernels it replaces on the API's route (mask_and + apply_mask + nanminmax)."""
+    torch, ops = env
+    rng = np.random.default_rng(41)
+    C, P, S = shape
+    src = rng.standard_normal(shape).astype(dtype)
+    src[rng.random(shape) < 0.05] = np.nan
+    m1 = rng.random(shape) < 0.6
+    m2 = rng.random((P, S)) < 0.7      # channel-less, broadcast
+    m3 = rng.random(shape) < 0.9
+    m4 = rng.random((P, S)) < 0.95
+    dev = lambda m: _dev(torch, m.astype(np.uint8))
+    for ms in ([m1], [m1, m2], [m1, m2, m3], [m1, m3, m2, m4]):
+        out, mm = ops.apply_masks(_dev(torch, src), [dev(m) for m in ms], fill_value=-999.0, want_minmax=True)
+        exp = omask.apply_mask(src, ms, -999.0).astype(dtype)
+        np.testing.assert_array_equal(out.cpu().numpy(), exp)
+        lo, hi = mm.cpu().tolist()
+        assert lo == float(np.nanmin(exp)) and hi == float(np.nanmax(exp))
+    # the separate kernels give the same array
+    both = ops.mask_and(ops.mask_and(dev(m1), dev(m2)), dev(m3))
+    sep = ops.apply_mask(_dev(torch, src), both, fill_value=-999.0)
+    one, none = ops.apply_masks(_dev(torch, src), [dev(m1), dev(m2), dev(m3)], fill_value=-999.0)
+    assert none is None and torch.equal(sep.view(torch.int64 if dtype == "float64" else torch.int32),
+                                         one.view(torch.int64 if dtype == "float64" else torch.int32))
+    # an array fill (NaN where it is NaN), and nothing kept / nothing a number -> {NaN, NaN}
+    fill = rng.standard_normal((P, S)).astype(dtype)
+    out, mm = ops.apply_masks(_dev(torch, src), [dev(m1), dev(m2)], fill_array=_dev(torch, fill), want_minmax=True)
+    exp = np.where(m1 & m2[None], src, fill[None])
+    np.testing.assert_array_equal(out.cpu().numpy(), exp)
+    assert mm.cpu().tolist() == [float(np.nanmin(exp)), float(np.nanmax(exp))]
+    out, mm = ops.apply_masks(_dev(torch, src), [dev(np.zeros(shape, bool))], want_minmax=True)
+    assert np.isnan(out.cpu().numpy()).all() and all(np.isnan(v) for v in mm.cpu().tolist())
+    with pytest.raises(ValueError):
+        ops.apply_masks(_dev(torch, src), [dev(m1)] * 5)
+
+
 def _box_mean_db(sv, n, m, s0):
     """Index-window pooled Sv by separable running sums in extended precision (np.pad 'symmetric' == scipy
     'reflect', periodic for windows wider than the data)."""
